@@ -1,0 +1,198 @@
+/* ============================================================================
+ * rcppml_gpu.h -- C ABI of RcppML_gpu.so, the MI355X (gfx950) backend for RcppML's
+ * alternating-NNLS NMF hot path.
+ *
+ * Two layers, both plain C (pointers and sizes only; no torch / Rcpp / Eigen types):
+ *
+ *  (1) PLUGIN BOUNDARY -- host-pointer entry points the unmodified R package binds:
+ *      R `.C()` through `.gpu_call` (reference R/gpu_backend.R:24-27) and C++
+ *      `dlsym(RTLD_DEFAULT, name)` from RcppML.so (reference
+ *      inst/include/FactorNet/gpu/loader.hpp:44-48).  Signatures are byte-for-byte the
+ *      reference plugin's (src/gpu_bridge_cluster.cu:24-46, src/gpu_bridge_nmf.cu:34-80,
+ *      type inst/include/FactorNet/gpu/bridge_nmf.hpp:39-75).  Every scalar is a pointer
+ *      (R `.C` convention).  Nothing throws across the boundary: failures set
+ *      *out_status = -1 (reference src/gpu_bridge_nmf.cu:206-209), which makes the caller
+ *      fall back to its CPU path (inst/include/FactorNet/nmf/fit.hpp:125-133).
+ *
+ *  (2) DEVICE-LEVEL OPS -- the kernels of the path on caller-owned DEVICE memory and a
+ *      caller-supplied HIP stream.  This is what the host harness (the Python modules under rcppml_amd/, one
+ *      process per GPU under torch.distributed/RCCL) and bench.py drive; PyTorch only
+ *      provides the allocations, the stream and the collectives.
+ *
+ * All dense matrices are column-major with the factor rank k as leading dimension:
+ *   W_T : k x m   (reference "W" in/out array of the ABI, W[f + i*k])
+ *   H   : k x n
+ *   G   : k x k
+ * Sparse input is CSC with int32 indices (dgCMatrix / Eigen::SparseMatrix<_,ColMajor,int>).
+ * ==========================================================================*/
+#ifndef RCPPML_GPU_H
+#define RCPPML_GPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RCPPML_GPU_API __attribute__((visibility("default")))
+
+/* --------------------------------------------------------------------------
+ * (1) Plugin boundary
+ * ------------------------------------------------------------------------*/
+
+/* Replaces reference src/gpu_bridge_cluster.cu:24-46 (callers: R/gpu_backend.R:101-106,
+ * gpu/loader.hpp:73-92 -- arrays of length *max_gpus, normally 8).
+ * out_status = 0 and num_gpus > 0  <=>  backend available. */
+RCPPML_GPU_API void rcppml_gpu_detect(int* num_gpus, double* total_mem_mb, double* free_mem_mb,
+                                      int* max_gpus, int* out_status);
+
+/* Replaces reference src/gpu_bridge_nmf.cu:460-624 (`rcppml_gpu_nmf_unified_float`, the symbol
+ * gpu/bridge_nmf.hpp:187 resolves) and :34-210 (`_double`).  73 pointer arguments, order per
+ * SURVEY.md Appendix B.  `_float` computes in fp32 (like the reference; set env
+ * RCPPML_GPU_PRECISION=fp64 to force fp64), `_double` computes in fp64.  Arrays at the ABI are
+ * always double.  W (k x m), H (k x n), d (k) are in/out.  Unlike the reference plugin this one
+ * sorts factors by descending d before returning (what CPU nmf() returns) unless env
+ * RCPPML_GPU_SORT=0.  Features it does not implement (L21, angular, graph, guides, projective,
+ * symmetric, losses other than MSE/NB) are REJECTED with *out_status = -1 so the caller falls back
+ * to CPU rather than silently dropping them. */
+#define RCPPML_NMF_UNIFIED_ARGS                                                                    \
+    const int* col_ptr, const int* row_idx, const double* values, int* m, int* n, int* nnz, int* k, \
+        double* W, double* H, double* d, int* max_iter, double* tol, double* L1_H, double* L1_W,   \
+        double* L2_H, double* L2_W, double* L21_H, double* L21_W, double* ortho_H, double* ortho_W, \
+        double* ub_H, double* ub_W, int* cd_maxit, int* verbose, int* seed, int* loss_every,       \
+        int* patience, int* nonneg_W, int* nonneg_H, int* loss_type, double* huber_delta,          \
+        int* irls_max_iter, double* irls_tol, int* norm_type, int* projective, int* symmetric,     \
+        int* solver_mode, const int* graph_W_p, const int* graph_W_i, const double* graph_W_x,     \
+        int* graph_W_dim, int* graph_W_nnz, double* graph_W_lambda, const int* graph_H_p,          \
+        const int* graph_H_i, const double* graph_H_x, int* graph_H_dim, int* graph_H_nnz,         \
+        double* graph_H_lambda, int* gp_dispersion_mode, double* gp_theta_init,                    \
+        double* gp_theta_max, double* gp_theta_min, double* nb_size_init, double* nb_size_max,     \
+        double* nb_size_min, double* gamma_phi_init, double* gamma_phi_max, double* gamma_phi_min, \
+        double* robust_delta, double* tweedie_power, double* out_theta, int* out_theta_len,        \
+        const int* guide_H_labels_flat, const int* guide_H_ns, const double* guide_H_lambdas,      \
+        const int* guide_H_ncs, int* guide_H_count, int* out_iter, int* out_converged,             \
+        double* out_loss, int* out_status, double* out_tol
+
+RCPPML_GPU_API void rcppml_gpu_nmf_unified_float(RCPPML_NMF_UNIFIED_ARGS);
+RCPPML_GPU_API void rcppml_gpu_nmf_unified_double(RCPPML_NMF_UNIFIED_ARGS);
+
+/* Build-defined extras (not in the reference ABI).  Same 73 arguments plus what the
+ * reference bridge does not transmit (gpu/bridge_nmf.hpp:180-346 drops config.mask, cd_tol,
+ * sort_model): an explicit mask in CSC (nonzero = masked; nmf/masked_nnls.hpp), cd_tol, sort flag,
+ * compute precision (0 = fp32, 1 = fp64) and an optional per-iteration loss history buffer
+ * (length >= *max_iter, may be NULL). */
+RCPPML_GPU_API void rcppml_gpu_nmf_ex(RCPPML_NMF_UNIFIED_ARGS, const int* mask_p, const int* mask_i,
+                                      int* mask_nnz, double* cd_tol, int* sort_model,
+                                      int* precision, double* loss_history);
+
+/* fp64 projection h = NNLS(w^T w, w^T A): GPU entry for R nnls()/predict(), which have no GPU
+ * hook in the reference (src/RcppFunctions_utils.cpp:313-366 c_nnls, :23-52 Rcpp_predict).
+ * w_T: k x m, A: m x n CSC (host pointers), h: k x n in/out (warm start if *warm != 0). */
+RCPPML_GPU_API void rcppml_gpu_nnls_double(const int* col_ptr, const int* row_idx,
+                                           const double* values, int* m, int* n, int* nnz, int* k,
+                                           const double* w_T, double* h, int* cd_maxit,
+                                           double* cd_tol, double* L1, double* L2, double* ub,
+                                           int* nonneg, int* warm, int* out_status);
+
+/* fp64 evaluate(): mean squared error of W diag(d) H against A over all m*n entries or (mask_zeros)
+ * over nonzeros only, WITHOUT densifying W H (reference src/RcppFunctions_utils.cpp:95-163 builds
+ * the dense m x n product).  W_T: k x m. */
+RCPPML_GPU_API void rcppml_gpu_evaluate_mse_double(const int* col_ptr, const int* row_idx,
+                                                   const double* values, int* m, int* n, int* nnz,
+                                                   int* k, const double* W_T, const double* d,
+                                                   const double* H, int* mask_zeros,
+                                                   double* out_loss, int* out_status);
+
+/* Last error text of the calling thread ("" if none). */
+RCPPML_GPU_API const char* rcppml_gpu_last_error(void);
+
+/* --------------------------------------------------------------------------
+ * (2) Device-level ops.  dtype: 0 = fp32, 1 = fp64.  All pointers are DEVICE pointers unless
+ * named host_*.  Every op is enqueued on the context's stream and returns 0 on success
+ * (non-zero: see rcppml_gpu_last_error).  No op synchronises the stream.
+ * ------------------------------------------------------------------------*/
+typedef struct rcppml_hip_ctx rcppml_hip_ctx;
+
+enum { RCPPML_F32 = 0, RCPPML_F64 = 1 };
+/* CD kernel variants (rcppml_hip_solve_cd `variant`) */
+enum { RCPPML_CD_AUTO = 0, RCPPML_CD_LANE = 1 /* one lane per column, G broadcast from SGPRs */,
+       RCPPML_CD_WAVE = 2 /* one wavefront per column, active-coordinate ballot skipping */ };
+
+/* stream: a hipStream_t (NULL = the device's null stream).  The context owns scratch memory only. */
+RCPPML_GPU_API int rcppml_hip_ctx_create(rcppml_hip_ctx** out, int device, void* stream);
+RCPPML_GPU_API void rcppml_hip_ctx_destroy(rcppml_hip_ctx* ctx);
+RCPPML_GPU_API int rcppml_hip_ctx_sync(rcppml_hip_ctx* ctx);
+
+/* G = F F^T (+ eps on the diagonal, then + l2) -- reference primitives/cpu/gram.hpp:37-67 and
+ * nmf/fit_cpu.hpp:506,738.  F: k x r.  MFMA kernel (v_mfma_f32_32x32x2_f32 / v_mfma_f64_16x16x4_f64),
+ * split over r with a deterministic two-pass reduction. */
+RCPPML_GPU_API int rcppml_hip_gram(rcppml_hip_ctx* ctx, int dtype, const void* F, int k, int64_t r,
+                                   double eps, double l2, void* G);
+
+/* B(:,j) = sum_{i in nz(j)} A(i,j) F(:,i) -- reference primitives/cpu/rhs.hpp:52-70 and the RHS
+ * step of primitives/cpu/fused_nnls.hpp:109-114.  One wavefront per output column. */
+RCPPML_GPU_API int rcppml_hip_rhs(rcppml_hip_ctx* ctx, int dtype, const int* col_ptr,
+                                  const int* row_idx, const void* values, int64_t ncols,
+                                  const void* F, int k, void* B);
+
+/* Per-column CD NNLS -- reference primitives/cpu/nnls_batch.hpp:70-132 (cd_nnls_col_fixed) with the
+ * prologues of fused_nnls.hpp:116-123 / nnls_batch.hpp:167-174:
+ *   b = B(:,j); if (l1_pre>0) b -= l1_pre; x = zero_init ? 0 : X(:,j); if (warm) b -= G x;
+ *   CD(G, b, x, l1_cd, l2_cd, nonneg, maxit, ub_cd, tol); if (ub_post>0) x = min(x, ub_post).
+ * B is NOT modified (the residual lives in registers).  G: k x k. */
+RCPPML_GPU_API int rcppml_hip_solve_cd(rcppml_hip_ctx* ctx, int dtype, const void* G, const void* B,
+                                       void* X, int k, int64_t ncols, double l1_pre, int warm,
+                                       int zero_init, double l1_cd, double l2_cd, int nonneg,
+                                       int maxit, double tol, double ub_cd, double ub_post,
+                                       int variant);
+
+/* Cholesky solve + clip -- reference primitives/cpu/fused_nnls.hpp:185-219:
+ *   L = chol(G) once; x = L^-T L^-1 (B(:,j) - l1_pre); clip >= 0 (nonneg); clip <= ub_post. */
+RCPPML_GPU_API int rcppml_hip_solve_chol(rcppml_hip_ctx* ctx, int dtype, const void* G,
+                                         const void* B, void* X, int k, int64_t ncols,
+                                         double l1_pre, int nonneg, double ub_post);
+
+/* Row norms of X (k x c): out[i] = sum_j |X_ij| (norm_type 0) or sum_j X_ij^2 (norm_type 1);
+ * no epsilon, no sqrt -- the distributed harness all-reduces these partial sums. */
+RCPPML_GPU_API int rcppml_hip_row_norms(rcppml_hip_ctx* ctx, int dtype, const void* X, int k,
+                                        int64_t ncols, int norm_type, void* out);
+/* d = (norm_type==1 ? sqrt(s) : s) + 1e-15; X(i,:) /= d_i -- reference
+ * nmf/variant_helpers.hpp:286-305.  `sums` as produced by rcppml_hip_row_norms. */
+RCPPML_GPU_API int rcppml_hip_apply_scaling(rcppml_hip_ctx* ctx, int dtype, void* X, int k,
+                                            int64_t ncols, int norm_type, const void* sums, void* d);
+
+/* sum of squares of a length-len vector in fp64 -> out[0] (double, device) -- trace_AtA,
+ * reference primitives/primitives.hpp:100-115. */
+RCPPML_GPU_API int rcppml_hip_sumsq(rcppml_hip_ctx* ctx, int dtype, const void* x, int64_t len,
+                                    double* out);
+
+/* MSE loss by the Gram trick -- reference nmf/fit_cpu.hpp:1710-1753:
+ *   cross = sum_{l,i} d_i W_T(i,l) B_w(i,l); recon = sum_ij d_i d_j G_wt(i,j) G_saved(i,j);
+ *   out[0] = trAtA[0] - 2 cross + recon; out[1] = cross; out[2] = recon   (double, device). */
+RCPPML_GPU_API int rcppml_hip_loss_mse(rcppml_hip_ctx* ctx, int dtype, const double* trAtA,
+                                       const void* d, const void* W_T, const void* B_w, int k,
+                                       int64_t m, const void* G_wt, const void* G_saved,
+                                       double* out);
+
+/* Explicit-mask per-column NNLS -- reference nmf/masked_nnls.hpp:96-154 / 177-242.
+ * A and mask share shape (rows x ncols, CSC; mask nonzero = masked; mask values not needed). */
+RCPPML_GPU_API int rcppml_hip_solve_masked(rcppml_hip_ctx* ctx, int dtype, const int* col_ptr,
+                                           const int* row_idx, const void* values,
+                                           const int* mask_p, const int* mask_i, int64_t ncols,
+                                           const void* F, const void* G_full, void* X, int k,
+                                           double l1, double l2, int nonneg, int cd_maxit,
+                                           double cd_tol, int solver_mode, int warm);
+/* Over unmasked NONZEROS, with p = sum_f d_f W_T(f,i) H(f,j):  out[0] = sum (a - p)^2 (reference
+ * nmf/masked_nnls.hpp:250-282), out[1] = sum p^2.  mask_p may be NULL (no mask: all nonzeros).
+ * out: 2 doubles, device. */
+RCPPML_GPU_API int rcppml_hip_loss_nonzeros(rcppml_hip_ctx* ctx, int dtype, const int* col_ptr,
+                                            const int* row_idx, const void* values,
+                                            const int* mask_p, const int* mask_i, int64_t ncols,
+                                            const void* W_T, const void* d, const void* H, int k,
+                                            double* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RCPPML_GPU_H */

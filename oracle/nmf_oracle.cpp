@@ -1,0 +1,508 @@
+// ============================================================================
+// oracle/nmf_oracle.cpp -- CPU restatement of RcppML's ALS-NNLS NMF loop + C surface
+//
+// TEST INFRASTRUCTURE ONLY (see nmf_oracle.hpp header).  "parity unpinned" except for
+// the known answers listed there.  Built by oracle/Makefile into oracle/liboracle.so.
+//
+// Restates (paths relative to /root/reference/inst/include/FactorNet):
+//   nmf/fit_cpu.hpp:171-254        setup (W_T, H, d, trAtA, CSC(A^T))
+//   nmf/fit_cpu.hpp:444-894        ALS loop, H then W half-update
+//   nmf/fit_cpu.hpp:1674-1855      loss, convergence/patience, packaging, sort
+//   nmf/masked_nnls.hpp:45-282     explicit-mask per-column NNLS and loss
+//   primitives/cpu/nnls_batch_irls.hpp:202-329,465-520  per-column IRLS (NB weights)
+//   nmf/fit_cpu.hpp:1094-1265      NB size (r) method-of-moments update
+//   nmf/explicit_loss.hpp:53-77, math/loss.hpp:248-256,415-426   NB weight and NLL
+//   src/RcppFunctions_utils.cpp:23-52,95-163,313-366  predict / evaluate / c_nnls (fp64)
+// ============================================================================
+#include "nmf_oracle.hpp"
+
+namespace oracle {
+
+// math/loss.hpp:248-256  irls_weight_nb (computed in double, eps = tiny_num = 1e-15)
+template <class S> static inline S irls_weight_nb(S predicted, S nb_size) {
+    double mu = std::max(static_cast<double>(predicted), static_cast<double>(static_cast<S>(1e-15)));
+    double r = std::max(static_cast<double>(nb_size), 1e-10);
+    double w = r / (mu * (r + mu));
+    w = std::min(w, 1e6);
+    return static_cast<S>(w);
+}
+// math/loss.hpp:415-426  loss_contribution_nb
+template <class S> static inline S loss_contribution_nb(S observed, S predicted, S nb_size) {
+    double y = static_cast<double>(observed);
+    double mu = std::max(static_cast<double>(predicted), 1e-10);
+    double r = std::max(static_cast<double>(nb_size), 1e-10);
+    double nll = -std::lgamma(y + r) + std::lgamma(r) - r * std::log(r / (r + mu)) -
+                 y * std::log(mu / (r + mu));
+    return static_cast<S>(nll);
+}
+
+// nmf/masked_nnls.hpp:96-154 (H side) / :177-242 (W side): same routine, data = A or A^T
+template <class S>
+static void masked_nnls(const Csc<S>& A, const S* F, const S* G_full, S* X, const Csc<S>& mask,
+                        int k, S L1, S L2, bool nonneg, int cd_maxit, S cd_tol, int solver_mode,
+                        int threads, bool warm_start) {
+    const int nt = eff_threads(threads); (void)nt;
+    const int nrow = A.rows;
+#pragma omp parallel num_threads(nt)
+    {
+        std::vector<S> b(k), x(k), Gl((size_t)k * k), L((size_t)k * k);
+        std::vector<char> is_masked(nrow, 0);
+        std::vector<int> mrows;
+#pragma omp for schedule(dynamic, 64)
+        for (int j = 0; j < A.cols; ++j) {
+            mrows.clear();
+            for (int t = mask.p[j]; t < mask.p[j + 1]; ++t)
+                if (mask.x[t] != 0) mrows.push_back(mask.i[t]);
+            for (int f = 0; f < k; ++f) b[f] = 0;
+            for (int r : mrows) is_masked[r] = 1;
+            for (int t = A.p[j]; t < A.p[j + 1]; ++t) {
+                if (is_masked[A.i[t]]) continue;
+                const S a = A.x[t]; const S* fc = F + (size_t)A.i[t] * k;
+                for (int f = 0; f < k; ++f) b[f] += a * fc[f];
+            }
+            for (int r : mrows) is_masked[r] = 0;
+            std::memcpy(Gl.data(), G_full, sizeof(S) * k * k);
+            for (int r : mrows) {
+                const S* fr = F + (size_t)r * k;
+                for (int c = 0; c < k; ++c) {
+                    const S fc = fr[c];
+                    S* g = Gl.data() + (size_t)c * k;
+                    for (int a2 = 0; a2 < k; ++a2) g[a2] -= fr[a2] * fc;
+                }
+            }
+            for (int i = 0; i < k; ++i) { b[i] -= L1; Gl[(size_t)i * k + i] += L2; }
+            S* xj = X + (size_t)j * k;
+            for (int i = 0; i < k; ++i) x[i] = warm_start ? xj[i] : S(0);
+            if (solver_mode == 1) {
+                // cholesky_clip_col(G_local, b, x, k, 0, 0, nonneg, ...)  cholesky_clip.hpp:64-106
+                llt_factor(Gl.data(), k, L.data());
+                for (int i = 0; i < k; ++i) x[i] = b[i];
+                llt_solve(L.data(), k, x.data());
+                if (nonneg) for (int i = 0; i < k; ++i) x[i] = std::max(x[i], S(0));
+            } else {
+                cd_nnls_col_fixed(Gl.data(), b.data(), x.data(), k, S(0), S(0), nonneg, cd_maxit,
+                                  S(0), cd_tol);
+            }
+            for (int i = 0; i < k; ++i) xj[i] = x[i];
+        }
+    }
+}
+
+// nmf/masked_nnls.hpp:250-282   masked_loss (sparse A: unmasked NONZEROS only, MSE)
+template <class S>
+static S masked_loss(const Csc<S>& A, const S* W_Td, const S* H, const Csc<S>& mask, int k,
+                     int threads) {
+    const int nt = eff_threads(threads); (void)nt;
+    S total = 0;
+#pragma omp parallel num_threads(nt) reduction(+ : total)
+    {
+        std::vector<char> is_masked(A.rows, 0);
+#pragma omp for schedule(dynamic, 64)
+        for (int j = 0; j < A.cols; ++j) {
+            for (int t = mask.p[j]; t < mask.p[j + 1]; ++t)
+                if (mask.x[t] != 0) is_masked[mask.i[t]] = 1;
+            const S* h = H + (size_t)j * k;
+            for (int t = A.p[j]; t < A.p[j + 1]; ++t) {
+                const int i = A.i[t];
+                if (is_masked[i]) continue;
+                const S* w = W_Td + (size_t)i * k;
+                S pred = 0;
+                for (int f = 0; f < k; ++f) pred += w[f] * h[f];
+                const S diff = A.x[t] - pred;
+                total += diff * diff;
+            }
+            for (int t = mask.p[j]; t < mask.p[j + 1]; ++t) is_masked[mask.i[t]] = 0;
+        }
+    }
+    return total;
+}
+
+// primitives/cpu/nnls_batch_irls.hpp:465-520 + :202-329   NB-weighted per-column IRLS
+// theta_row: indexed by the ROW of `A` (nonzero's row); theta_col: indexed by the column.
+template <class S>
+static void nnls_batch_irls_sparse_nb(const Csc<S>& A, const S* F, const S* G_base, S* X, int k,
+                                      S L1, S L2, bool nonneg, int cd_maxit, int irls_max_iter,
+                                      S irls_tol, int threads, const S* theta_row,
+                                      const S* theta_col) {
+    const int nt = eff_threads(threads); (void)nt;
+    std::fill(X, X + (size_t)k * A.cols, S(0));   // H.setZero(): no warm start across ALS iters
+#pragma omp parallel num_threads(nt)
+    {
+        std::vector<S> Gw((size_t)k * k), bw(k), bc(k), xold(k);
+#pragma omp for schedule(dynamic)
+        for (int j = 0; j < A.cols; ++j) {
+            S* x = X + (size_t)j * k;
+            for (int it = 0; it < irls_max_iter; ++it) {
+                std::memcpy(Gw.data(), G_base, sizeof(S) * k * k);
+                for (int f = 0; f < k; ++f) bw[f] = 0;
+                for (int t = A.p[j]; t < A.p[j + 1]; ++t) {
+                    const int row = A.i[t];
+                    const S* fr = F + (size_t)row * k;
+                    S recon = 0;
+                    for (int f = 0; f < k; ++f) recon += fr[f] * x[f];
+                    const S th = theta_col ? theta_col[j] : (theta_row ? theta_row[row] : S(0));
+                    const S w = irls_weight_nb(recon, th);
+                    const S dw = w - S(1);
+                    const S wv = w * A.x[t];
+                    // G_w += dw * f f^T  (reference: W_nnz_scaled * W_block^T)
+                    for (int c = 0; c < k; ++c) {
+                        const S fc = fr[c];
+                        S* g = Gw.data() + (size_t)c * k;
+                        for (int a2 = 0; a2 < k; ++a2) g[a2] += (fr[a2] * dw) * fc;
+                    }
+                    for (int f = 0; f < k; ++f) bw[f] += fr[f] * wv;
+                }
+                if (L2 > 0) for (int i = 0; i < k; ++i) Gw[(size_t)i * k + i] += L2;
+                for (int i = 0; i < k; ++i) { xold[i] = x[i]; bc[i] = bw[i]; }
+                for (int c = 0; c < k; ++c) {
+                    const S xc = xold[c]; const S* gc = Gw.data() + (size_t)c * k;
+                    for (int r = 0; r < k; ++r) bc[r] -= gc[r] * xc;
+                }
+                cd_nnls_col_fixed(Gw.data(), bc.data(), x, k, L1, S(0), nonneg, cd_maxit, S(0), S(0));
+                S max_change = 0;
+                for (int i = 0; i < k; ++i) {
+                    const S rel = std::abs(x[i] - xold[i]) / (std::abs(xold[i]) + static_cast<S>(1e-12));
+                    if (rel > max_change) max_change = rel;
+                }
+                if (max_change < irls_tol) break;
+            }
+        }
+    }
+}
+
+// nmf/fit_cpu.hpp:1094-1265   NB size update (PER_ROW / GLOBAL), sparse branch
+template <class S>
+static void nb_size_update(const Csc<S>& A, const S* W_T, const S* H, const S* d, int k,
+                           const FitConfig<S>& cfg, std::vector<S>& nb_size) {
+    const int m = A.rows, n = A.cols;
+    std::vector<S> Wd((size_t)k * m);
+    for (int i = 0; i < m; ++i) for (int f = 0; f < k; ++f) Wd[(size_t)i * k + f] = W_T[(size_t)i * k + f] * d[f];
+    const double r_min = static_cast<double>(cfg.nb_size_min), r_max = static_cast<double>(cfg.nb_size_max);
+    std::vector<double> s_mu2(m, 0.0), s_res2(m, 0.0);
+    for (int j = 0; j < n; ++j) {
+        const S* h = H + (size_t)j * k;
+        for (int t = A.p[j]; t < A.p[j + 1]; ++t) {
+            const int i = A.i[t];
+            const S* w = Wd.data() + (size_t)i * k;
+            S dot = 0;
+            for (int f = 0; f < k; ++f) dot += w[f] * h[f];
+            const double y = static_cast<double>(A.x[t]);
+            const double mu = std::max(static_cast<double>(dot), 1e-10);
+            const double resid = y - mu;
+            s_mu2[i] += mu * mu;
+            s_res2[i] += resid * resid;
+        }
+    }
+    std::vector<S> h_rs(k, S(0));
+    for (int j = 0; j < n; ++j) { const S* h = H + (size_t)j * k; for (int f = 0; f < k; ++f) h_rs[f] += h[f]; }
+    std::vector<S> GH((size_t)k * k);
+    gram(H, k, n, GH.data());
+    for (int i = 0; i < m; ++i) {
+        const S* w = Wd.data() + (size_t)i * k;
+        S tm = 0;
+        for (int f = 0; f < k; ++f) tm += w[f] * h_rs[f];
+        const double total_mu = static_cast<double>(tm);
+        double total_mu_sq = 0.0;
+        for (int a = 0; a < k; ++a)
+            for (int b = 0; b < k; ++b)
+                total_mu_sq += static_cast<double>(w[a]) * static_cast<double>(GH[(size_t)b * k + a]) * static_cast<double>(w[b]);
+        const double total_resid_sq = s_res2[i] + (total_mu_sq - s_mu2[i]);
+        const double excess = total_resid_sq - total_mu;
+        if (excess > 1e-10 && total_mu_sq > 1e-10) {
+            double r_new = total_mu_sq / excess;
+            r_new = std::max(r_min, std::min(r_new, r_max));
+            if (std::isfinite(r_new)) nb_size[i] = static_cast<S>(r_new);
+        } else {
+            nb_size[i] = static_cast<S>(r_max);
+        }
+    }
+    if (cfg.dispersion_mode == 1) {  // GLOBAL: median via nth_element at m/2
+        std::vector<S> r_vals(nb_size.begin(), nb_size.begin() + m);
+        std::nth_element(r_vals.begin(), r_vals.begin() + m / 2, r_vals.end());
+        const S med = r_vals[m / 2];
+        std::fill(nb_size.begin(), nb_size.end(), med);
+    }
+}
+
+// nmf/explicit_loss.hpp:53-77   NB NLL over NONZEROS only (per-row theta)
+template <class S>
+static S explicit_loss_sparse_nb(const Csc<S>& A, const S* W_Td, const S* H, int k,
+                                 const S* theta_row, int threads) {
+    const int nt = eff_threads(threads); (void)nt;
+    S total = 0;
+#pragma omp parallel for reduction(+ : total) num_threads(nt) schedule(dynamic, 64)
+    for (int j = 0; j < A.cols; ++j) {
+        const S* h = H + (size_t)j * k;
+        for (int t = A.p[j]; t < A.p[j + 1]; ++t) {
+            const S* w = W_Td + (size_t)A.i[t] * k;
+            S pred = 0;
+            for (int f = 0; f < k; ++f) pred += w[f] * h[f];
+            total += loss_contribution_nb(A.x[t], pred, theta_row ? theta_row[A.i[t]] : S(0));
+        }
+    }
+    return total;
+}
+
+// ---------------------------------------------------------------------------
+// nmf/fit_cpu.hpp:171-1855   nmf_fit<CPU>, standard (non-projective, non-symmetric) variant
+// W_T (k x m) and H (k x n) hold the initial factors on entry (the harness builds them:
+// fit_cpu.hpp:195-207 / nmf_init.hpp:166-182) and the result on exit (W_T not transposed).
+// ---------------------------------------------------------------------------
+template <class S>
+FitResult<S> nmf_fit(const Csc<S>& A, const FitConfig<S>& cfg, S* W_T, S* H, S* d) {
+    const int m = A.rows, n = A.cols, k = cfg.k;
+    FitResult<S> res;
+    for (int i = 0; i < k; ++i) d[i] = 1;
+
+    const S trAtA = trace_AtA(A);                 // fit_cpu.hpp:224
+    CscOwned<S> At_own = transpose_csc(A);        // fit_cpu.hpp:251-253
+    const Csc<S> At = At_own.view();
+    const int threads = eff_threads(cfg.threads);
+
+    CscOwned<S> maskT_own;
+    if (cfg.has_mask) maskT_own = transpose_csc(cfg.mask);   // fit_cpu.hpp:276-280
+    const bool is_nb = cfg.loss_type == 5;
+    const bool irls = is_nb;
+    std::vector<S> nb_size;
+    if (is_nb)                                                // fit_cpu.hpp:316-328 (PER_ROW/GLOBAL/NONE)
+        nb_size.assign(m, cfg.dispersion_mode == 0 ? cfg.nb_size_max : cfg.nb_size_init);
+
+    std::vector<S> G((size_t)k * k), G_saved((size_t)k * k), G_wt((size_t)k * k);
+    S prev_loss = std::numeric_limits<S>::max();
+    int patience_counter = 0;
+
+    for (int iter = 0; iter < cfg.max_iter; ++iter) {
+        // ------------------------------------------------ H half-update
+        gram(W_T, k, m, G.data());                                       // :491
+        if (cfg.has_mask) {
+            // :560-564 G rebuilt unmodified (eps only); L1/L2 per column inside
+            masked_nnls(A, W_T, G.data(), H, cfg.mask, k, cfg.L1_H, cfg.L2_H, cfg.nonneg_H,
+                        cfg.cd_maxit, cfg.cd_tol, cfg.solver_mode, threads, iter > 0);
+        } else if (irls) {
+            // :565-606 gram recomputed (eps only); L1 inside CD, L2 on G_w
+            nnls_batch_irls_sparse_nb(A, W_T, G.data(), H, k, cfg.L1_H, cfg.L2_H, cfg.nonneg_H,
+                                      cfg.cd_maxit, cfg.irls_max_iter, cfg.irls_tol, cfg.threads,
+                                      nb_size.data(), (const S*)nullptr);
+        } else {
+            if (cfg.L2_H > 0) for (int i = 0; i < k; ++i) G[(size_t)i * k + i] += cfg.L2_H;   // :506
+            if (cfg.solver_mode == 0)
+                fused_rhs_nnls_sparse(A, W_T, G.data(), H, k, cfg.cd_maxit, cfg.cd_tol, cfg.L1_H,
+                                      cfg.nonneg_H, threads, iter > 0, S(0));                // :516-524
+            else
+                fused_rhs_cholesky_sparse(A, W_T, G.data(), H, k, cfg.L1_H, cfg.nonneg_H, threads, S(0));
+        }
+        if (cfg.ub_H > 0) apply_upper_bound(H, (size_t)k * n, cfg.ub_H);  // :636-637
+        extract_scaling(H, k, n, d, cfg.norm_type);                       // :645
+
+        // ------------------------------------------------ W half-update
+        gram(H, k, n, G.data());                                          // :715
+        const bool saved_for_loss = !cfg.has_mask && !irls;
+        if (saved_for_loss) G_saved = G;                                  // :719-722
+        if (cfg.has_mask) {
+            masked_nnls(At, H, G.data(), W_T, maskT_own.view(), k, cfg.L1_W, cfg.L2_W, cfg.nonneg_W,
+                        cfg.cd_maxit, cfg.cd_tol, cfg.solver_mode, threads, iter > 0);   // :799-810
+        } else if (irls) {
+            // :811-852: theta_per_col = nb_size (row of A == column of A^T)
+            nnls_batch_irls_sparse_nb(At, H, G.data(), W_T, k, cfg.L1_W, cfg.L2_W, cfg.nonneg_W,
+                                      cfg.cd_maxit, cfg.irls_max_iter, cfg.irls_tol, cfg.threads,
+                                      (const S*)nullptr, nb_size.data());
+        } else {
+            if (cfg.L2_W > 0) for (int i = 0; i < k; ++i) G[(size_t)i * k + i] += cfg.L2_W;   // :738
+            if (cfg.solver_mode == 0)
+                fused_rhs_nnls_sparse(At, H, G.data(), W_T, k, cfg.cd_maxit, cfg.cd_tol, cfg.L1_W,
+                                      cfg.nonneg_W, threads, iter > 0, S(0));                // :748-757
+            else
+                fused_rhs_cholesky_sparse(At, H, G.data(), W_T, k, cfg.L1_W, cfg.nonneg_W, threads, S(0));
+        }
+        if (cfg.ub_W > 0) apply_upper_bound(W_T, (size_t)k * m, cfg.ub_W);  // :884-885
+        extract_scaling(W_T, k, m, d, cfg.norm_type);                       // :893
+
+        // ------------------------------------------------ NB dispersion (:1094-1265)
+        if (is_nb && cfg.dispersion_mode != 0) nb_size_update(A, W_T, H, d, k, cfg, nb_size);
+
+        // ------------------------------------------------ loss (:1684-1767)
+        S loss_val;
+        if (cfg.has_mask || irls) {
+            std::vector<S> Wd((size_t)k * m);
+            for (int i = 0; i < m; ++i) for (int f = 0; f < k; ++f) Wd[(size_t)i * k + f] = W_T[(size_t)i * k + f] * d[f];
+            loss_val = cfg.has_mask ? masked_loss(A, Wd.data(), H, cfg.mask, k, threads)
+                                    : explicit_loss_sparse_nb(A, Wd.data(), H, k, nb_size.data(), cfg.threads > 0 ? cfg.threads : 1);
+        } else {
+            gram(W_T, k, m, G_wt.data());                                                   // :1734-1735
+            const S cross = loss_cross_term_sparse_via_At(At, W_T, H, d, k, threads);        // :1740-1741
+            S recon = 0;
+            for (int i = 0; i < k; ++i)
+                for (int j = 0; j < k; ++j)
+                    recon += d[i] * d[j] * G_wt[(size_t)j * k + i] * G_saved[(size_t)j * k + i];   // :1748-1751
+            loss_val = trAtA - static_cast<S>(2) * cross + recon;                            // :1753
+        }
+        res.loss_history.push_back(loss_val);
+        bool loss_converged = false;
+        if (iter > 0) {
+            const S rel = std::abs(prev_loss - loss_val) / (std::abs(prev_loss) + static_cast<S>(1e-15));
+            res.final_tol = rel;
+            if (rel < cfg.tol) loss_converged = true;
+        }
+        prev_loss = loss_val;
+        if (iter > 0) {                                                   // :1797-1809
+            if (loss_converged) {
+                if (++patience_counter >= cfg.patience) {
+                    res.converged = true; res.train_loss = prev_loss; res.iterations = iter + 1;
+                    break;
+                }
+            } else patience_counter = 0;
+        }
+        res.iterations = iter + 1;
+    }
+    if (res.train_loss == 0 && !res.loss_history.empty()) res.train_loss = res.loss_history.back();
+    if (is_nb) res.theta = nb_size;
+    if (cfg.sort_model) sort_by_d(W_T, H, d, k, m, n);                    // :1847
+    return res;
+}
+
+template FitResult<float> nmf_fit<float>(const Csc<float>&, const FitConfig<float>&, float*, float*, float*);
+template FitResult<double> nmf_fit<double>(const Csc<double>&, const FitConfig<double>&, double*, double*, double*);
+
+}  // namespace oracle
+
+// ============================================================================
+// C surface (ctypes).  *_f32 / *_f64 pairs.  All matrices column-major, k leading.
+// ============================================================================
+using namespace oracle;
+
+#define ORACLE_API extern "C" __attribute__((visibility("default")))
+
+ORACLE_API uint64_t oracle_splitmix_next(uint64_t* state) {
+    SplitMix64 r(1); r.state = *state; const uint64_t v = r.next(); *state = r.state; return v;
+}
+ORACLE_API uint64_t oracle_splitmix_init_state(uint64_t seed) { return SplitMix64(seed).state; }
+ORACLE_API void oracle_fill_uniform_f64(uint64_t seed, double* out, int rows, int cols) { SplitMix64 r(seed); r.fill_uniform(out, rows, cols); }
+ORACLE_API void oracle_fill_uniform_f32(uint64_t seed, float* out, int rows, int cols) { SplitMix64 r(seed); r.fill_uniform(out, rows, cols); }
+// nmf_init.hpp:166-182  one stream fills W_T (k x m) then continues into H (k x n)
+ORACLE_API void oracle_init_factors_f64(uint32_t seed, int k, int m, int n, double* W_T, double* H) { SplitMix64 r(seed); r.fill_uniform(W_T, k, m); r.fill_uniform(H, k, n); }
+ORACLE_API void oracle_init_factors_f32(uint32_t seed, int k, int m, int n, float* W_T, float* H) { SplitMix64 r(seed); r.fill_uniform(W_T, k, m); r.fill_uniform(H, k, n); }
+
+template <class S> static Csc<S> mk(int rows, int cols, const int* p, const int* i, const S* x) { return Csc<S>{rows, cols, p, i, x}; }
+
+#define DEFINE_PRIMS(SUF, S)                                                                              \
+    ORACLE_API void oracle_gram_##SUF(const S* F, int k, int r, S* G) { gram(F, k, r, G); }                \
+    ORACLE_API void oracle_rhs_##SUF(int rows, int cols, const int* p, const int* i, const S* x,          \
+                                     const S* F, int k, S* B, int threads) {                              \
+        rhs(mk(rows, cols, p, i, x), F, k, B, threads);                                                   \
+    }                                                                                                     \
+    ORACLE_API int oracle_cd_col_##SUF(const S* G, S* b, S* x, int k, S L1, S L2, int nonneg, int maxit,  \
+                                       S ub, S tol) {                                                     \
+        return cd_nnls_col_fixed(G, b, x, k, L1, L2, nonneg != 0, maxit, ub, tol);                        \
+    }                                                                                                     \
+    ORACLE_API void oracle_nnls_batch_##SUF(const S* G, S* B, S* X, int k, int n, int maxit, S tol,       \
+                                            S L1, S L2, int nonneg, int threads, S ub, int warm) {        \
+        nnls_batch(G, B, X, k, n, maxit, tol, L1, L2, nonneg != 0, threads, ub, warm != 0);               \
+    }                                                                                                     \
+    ORACLE_API void oracle_fused_cd_##SUF(int rows, int cols, const int* p, const int* i, const S* x,     \
+                                          const S* F, const S* G, S* X, int k, int maxit, S tol, S L1,    \
+                                          int nonneg, int threads, int warm, S ub) {                      \
+        fused_rhs_nnls_sparse(mk(rows, cols, p, i, x), F, G, X, k, maxit, tol, L1, nonneg != 0, threads,  \
+                              warm != 0, ub);                                                             \
+    }                                                                                                     \
+    ORACLE_API void oracle_fused_chol_##SUF(int rows, int cols, const int* p, const int* i, const S* x,   \
+                                            const S* F, const S* G, S* X, int k, S L1, int nonneg,        \
+                                            int threads, S ub) {                                          \
+        fused_rhs_cholesky_sparse(mk(rows, cols, p, i, x), F, G, X, k, L1, nonneg != 0, threads, ub);     \
+    }                                                                                                     \
+    ORACLE_API void oracle_chol_clip_batch_##SUF(const S* G, const S* B, S* X, int k, int n, int nonneg,  \
+                                                 int threads) {                                           \
+        cholesky_clip_batch(G, B, X, k, n, nonneg != 0, threads);                                         \
+    }                                                                                                     \
+    ORACLE_API int oracle_llt_##SUF(const S* G, int k, S* L) { return llt_factor(G, k, L) ? 1 : 0; }      \
+    ORACLE_API void oracle_extract_scaling_##SUF(S* X, int k, int c, S* d, int norm_type) {               \
+        extract_scaling(X, k, c, d, norm_type);                                                           \
+    }                                                                                                     \
+    ORACLE_API S oracle_trace_AtA_##SUF(int rows, int cols, const int* p, const int* i, const S* x) {     \
+        return trace_AtA(mk(rows, cols, p, i, x));                                                        \
+    }                                                                                                     \
+    ORACLE_API S oracle_loss_cross_##SUF(int rows, int cols, const int* p, const int* i, const S* x,      \
+                                         const S* W_T, const S* H, const S* d, int k, int threads) {      \
+        return loss_cross_term_sparse_via_At(mk(rows, cols, p, i, x), W_T, H, d, k, threads);             \
+    }                                                                                                     \
+    ORACLE_API void oracle_transpose_csc_##SUF(int rows, int cols, const int* p, const int* i,            \
+                                               const S* x, int* tp, int* ti, S* tx) {                     \
+        CscOwned<S> T = transpose_csc(mk(rows, cols, p, i, x));                                           \
+        std::memcpy(tp, T.p.data(), sizeof(int) * T.p.size());                                            \
+        std::memcpy(ti, T.i.data(), sizeof(int) * T.i.size());                                            \
+        std::memcpy(tx, T.x.data(), sizeof(S) * T.x.size());                                              \
+    }                                                                                                     \
+    /* Full fit.  mask_p == NULL => no mask.  loss_hist: >= max_iter entries or NULL.  theta: m or NULL */ \
+    ORACLE_API void oracle_nmf_fit_##SUF(                                                                  \
+        int m, int n, const int* p, const int* i, const S* x, int k, S* W_T, S* H, S* d, int max_iter,    \
+        S tol, S L1_H, S L1_W, S L2_H, S L2_W, S ub_H, S ub_W, int cd_maxit, S cd_tol, int patience,      \
+        int nonneg_W, int nonneg_H, int norm_type, int solver_mode, int loss_type, int irls_max_iter,     \
+        S irls_tol, int dispersion_mode, S nb_size_init, S nb_size_max, S nb_size_min, int sort_model,    \
+        int threads, const int* mask_p, const int* mask_i, const S* mask_x, int* out_iter,                \
+        int* out_converged, S* out_loss, S* out_tol, S* loss_hist, S* out_theta) {                        \
+        FitConfig<S> c;                                                                                   \
+        c.k = k; c.max_iter = max_iter; c.tol = tol; c.L1_H = L1_H; c.L1_W = L1_W; c.L2_H = L2_H;         \
+        c.L2_W = L2_W; c.ub_H = ub_H; c.ub_W = ub_W; c.cd_maxit = cd_maxit; c.cd_tol = cd_tol;            \
+        c.patience = patience; c.nonneg_W = nonneg_W != 0; c.nonneg_H = nonneg_H != 0;                    \
+        c.norm_type = norm_type; c.solver_mode = solver_mode; c.loss_type = loss_type;                    \
+        c.irls_max_iter = irls_max_iter; c.irls_tol = irls_tol; c.dispersion_mode = dispersion_mode;      \
+        c.nb_size_init = nb_size_init; c.nb_size_max = nb_size_max; c.nb_size_min = nb_size_min;          \
+        c.sort_model = sort_model != 0; c.threads = threads;                                              \
+        if (mask_p) { c.has_mask = true; c.mask = mk(m, n, mask_p, mask_i, mask_x); }                     \
+        FitResult<S> r = nmf_fit(mk(m, n, p, i, x), c, W_T, H, d);                                        \
+        *out_iter = r.iterations; *out_converged = r.converged ? 1 : 0; *out_loss = r.train_loss;         \
+        *out_tol = r.final_tol;                                                                           \
+        if (loss_hist) for (size_t t = 0; t < r.loss_history.size(); ++t) loss_hist[t] = r.loss_history[t]; \
+        if (out_theta) for (size_t t = 0; t < r.theta.size(); ++t) out_theta[t] = r.theta[t];             \
+    }
+
+DEFINE_PRIMS(f32, float)
+DEFINE_PRIMS(f64, double)
+
+// ---------------------------------------------------------------------------
+// src/RcppFunctions_utils.cpp:313-366  c_nnls (fp64): h = NNLS(w^T w, w^T A)
+//   w_T: k x m (already transposed), A: m x n CSC.  G gets eps TWICE (gram + :327).
+//   warm != 0: h holds the warm start; B -= G h; CD with cd_tol = 0 (default arg).
+// ---------------------------------------------------------------------------
+ORACLE_API void oracle_c_nnls(const double* w_T, int k, int m, int n, const int* p, const int* i,
+                              const double* x, double* h, int cd_maxit, double cd_tol, double L1,
+                              double L2, double ub, int nonneg, int threads, int warm) {
+    std::vector<double> G((size_t)k * k), B((size_t)k * n);
+    gram(w_T, k, m, G.data());
+    for (int a = 0; a < k; ++a) G[(size_t)a * k + a] += 1e-15;
+    if (L2 > 0) for (int a = 0; a < k; ++a) G[(size_t)a * k + a] += L2;
+    rhs(mk(m, n, p, i, x), w_T, k, B.data(), threads);
+    if (warm) nnls_batch(G.data(), B.data(), h, k, n, cd_maxit, 0.0, L1, 0.0, nonneg != 0, threads, ub, true);
+    else      nnls_batch(G.data(), B.data(), h, k, n, cd_maxit, cd_tol, L1, 0.0, nonneg != 0, threads, ub, false);
+}
+// src/RcppFunctions_utils.cpp:23-52  Rcpp_predict: same with cd_maxit=100, cd_tol=1e-8, nonneg=true
+ORACLE_API void oracle_predict(const double* w_T, int k, int m, int n, const int* p, const int* i,
+                               const double* x, double* h, double L1, double L2, int threads, double ub) {
+    oracle_c_nnls(w_T, k, m, n, p, i, x, h, 100, 1e-8, L1, L2, ub, 1, threads, 0);
+}
+// src/RcppFunctions_utils.cpp:95-163  Rcpp_evaluate_loss (MSE): MEAN squared error of
+// W diag(d) H over all m*n entries, or over nonzeros only if mask_zeros.  W: m x k col-major.
+ORACLE_API double oracle_evaluate_mse(const double* W, const double* d, const double* H, int k, int m,
+                                      int n, const int* p, const int* i, const double* x, int mask_zeros) {
+    double total = 0; long long count = 0;
+    std::vector<double> col(m);
+    for (int j = 0; j < n; ++j) {
+        const double* h = H + (size_t)j * k;
+        for (int r = 0; r < m; ++r) {
+            double s = 0;
+            for (int f = 0; f < k; ++f) s += W[(size_t)f * m + r] * d[f] * h[f];
+            col[r] = s;
+        }
+        if (mask_zeros) {
+            for (int t = p[j]; t < p[j + 1]; ++t) { const double df = x[t] - col[i[t]]; total += df * df; ++count; }
+        } else {
+            int t = p[j];
+            for (int r = 0; r < m; ++r) {
+                double obs = 0;
+                if (t < p[j + 1] && i[t] == r) obs = x[t++];
+                const double df = obs - col[r]; total += df * df; ++count;
+            }
+        }
+    }
+    return count > 0 ? total / (double)count : 0.0;
+}
+ORACLE_API int oracle_num_threads() { return eff_threads(0); }

@@ -1,0 +1,258 @@
+"""ctypes binding of rcppml_amd/lib/RcppML_gpu.so (C ABI declared in include/rcppml_gpu.h).
+
+This is the ONLY compute backend of the package: there is no CPU or PyTorch fallback.  If the
+shared library is missing or cannot be loaded, importing the symbols raises immediately.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "RcppML_gpu.so")
+_lib = None
+
+F32, F64 = 0, 1
+CD_AUTO, CD_LANE, CD_WAVE = 0, 1, 2
+
+# Every symbol include/rcppml_gpu.h declares (tests check the library exports all of them).
+EXPORTED_SYMBOLS = [
+    "rcppml_gpu_detect", "rcppml_gpu_nmf_unified_float", "rcppml_gpu_nmf_unified_double", "rcppml_gpu_nmf_ex",
+    "rcppml_gpu_nnls_double", "rcppml_gpu_evaluate_mse_double", "rcppml_gpu_last_error",
+    "rcppml_hip_ctx_create", "rcppml_hip_ctx_destroy", "rcppml_hip_ctx_sync", "rcppml_hip_gram", "rcppml_hip_rhs",
+    "rcppml_hip_solve_cd", "rcppml_hip_solve_chol", "rcppml_hip_row_norms", "rcppml_hip_apply_scaling",
+    "rcppml_hip_sumsq", "rcppml_hip_loss_mse", "rcppml_hip_solve_masked", "rcppml_hip_loss_nonzeros",
+]
+
+
+class BackendError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load RcppML_gpu.so (RTLD_GLOBAL, as R's dyn.load(local=FALSE) does: reference R/gpu_backend.R:87)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise BackendError(
+                "HIP backend missing: %s not built (run `python -c 'import __graft_entry__ as g; g.build()'` or "
+                "`make -C rcppml_amd/csrc`).  There is no CPU fallback." % LIB_PATH)
+        try:
+            _lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+        except OSError as e:  # e.g. libamdhip64 missing
+            raise BackendError("cannot load %s: %s" % (LIB_PATH, e))
+        _lib.rcppml_gpu_last_error.restype = C.c_char_p
+        for name in ("rcppml_hip_ctx_create", "rcppml_hip_ctx_sync", "rcppml_hip_gram", "rcppml_hip_rhs",
+                     "rcppml_hip_solve_cd", "rcppml_hip_solve_chol", "rcppml_hip_row_norms", "rcppml_hip_apply_scaling",
+                     "rcppml_hip_sumsq", "rcppml_hip_loss_mse", "rcppml_hip_solve_masked", "rcppml_hip_loss_nonzeros"):
+            getattr(_lib, name).restype = C.c_int
+        _lib.rcppml_hip_ctx_destroy.restype = None
+    return _lib
+
+
+def last_error():
+    return lib().rcppml_gpu_last_error().decode("utf-8", "replace")
+
+
+def _chk(rc, what):
+    if rc != 0:
+        raise BackendError("%s failed: %s" % (what, last_error()))
+
+
+# ----------------------------------------------------------------------------- plugin boundary
+def detect(max_gpus=8):
+    """rcppml_gpu_detect -> list of (total_mb, free_mb); [] if no device (reference R/gpu_backend.R:101-106)."""
+    n, st, mx = C.c_int(0), C.c_int(0), C.c_int(max_gpus)
+    tot = (C.c_double * max_gpus)()
+    fre = (C.c_double * max_gpus)()
+    lib().rcppml_gpu_detect(C.byref(n), tot, fre, C.byref(mx), C.byref(st))
+    if st.value != 0:
+        return []
+    return [(tot[i], fre[i]) for i in range(n.value)]
+
+
+def _ci(v):
+    return C.byref(C.c_int(int(v)))
+
+
+def _cd(v):
+    return C.byref(C.c_double(float(v)))
+
+
+def _np_ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def nmf_unified(p, i, x, m, n, k, W_T, H, *, entry="float", max_iter=100, tol=1e-4, L1_H=0.0, L1_W=0.0, L2_H=0.0,
+                L2_W=0.0, L21_H=0.0, L21_W=0.0, ortho_H=0.0, ortho_W=0.0, ub_H=0.0, ub_W=0.0, cd_maxit=100, verbose=0,
+                seed=0, loss_every=1, patience=5, nonneg_W=1, nonneg_H=1, loss_type=0, huber_delta=1.0, irls_max_iter=5,
+                irls_tol=1e-4, norm_type=0, projective=0, symmetric=0, solver_mode=0, gp_dispersion_mode=2,
+                nb_size=(10.0, 1e6, 0.01), mask=None, cd_tol=1e-8, sort_model=1, precision=F64, want_history=False,
+                graph_W_nnz=0, guide_H_count=0):
+    """Call the 73-pointer plugin entry exactly as reference gpu/bridge_nmf.hpp:310-342 does.
+
+    p, i: int32 CSC arrays; x: float64 values.  W_T (m, k) and H (n, k) float64 arrays (memory = column-major
+    k x m / k x n) are updated IN PLACE.  entry: "float" | "double" (the reference symbols) or "ex" (build-defined,
+    adds mask / cd_tol / sort / precision / loss history).  Returns dict(d, iter, converged, loss, tol, status, ...).
+    """
+    L = lib()
+    p = np.ascontiguousarray(p, np.int32)
+    i = np.ascontiguousarray(i, np.int32)
+    x = np.ascontiguousarray(x, np.float64)
+    assert W_T.dtype == np.float64 and H.dtype == np.float64 and W_T.flags.c_contiguous and H.flags.c_contiguous
+    assert W_T.shape == (m, k) and H.shape == (n, k)
+    d = np.ones(k, np.float64)
+    dummy_i = np.zeros(2, np.int32)
+    dummy_d = np.zeros(2, np.float64)
+    theta = np.zeros(max(m, 1), np.float64)
+    out_iter, out_conv, out_status, out_theta_len = C.c_int(0), C.c_int(0), C.c_int(-99), C.c_int(0)
+    out_loss, out_tol = C.c_double(0), C.c_double(0)
+    args = [
+        _np_ptr(p), _np_ptr(i), _np_ptr(x), _ci(m), _ci(n), _ci(x.shape[0]), _ci(k),
+        _np_ptr(W_T), _np_ptr(H), _np_ptr(d), _ci(max_iter), _cd(tol),
+        _cd(L1_H), _cd(L1_W), _cd(L2_H), _cd(L2_W), _cd(L21_H), _cd(L21_W), _cd(ortho_H), _cd(ortho_W),
+        _cd(ub_H), _cd(ub_W), _ci(cd_maxit), _ci(verbose), _ci(seed), _ci(loss_every), _ci(patience),
+        _ci(nonneg_W), _ci(nonneg_H), _ci(loss_type), _cd(huber_delta), _ci(irls_max_iter), _cd(irls_tol),
+        _ci(norm_type), _ci(projective), _ci(symmetric), _ci(solver_mode),
+        _np_ptr(dummy_i), _np_ptr(dummy_i), _np_ptr(dummy_d), _ci(0), _ci(graph_W_nnz), _cd(0.0),
+        _np_ptr(dummy_i), _np_ptr(dummy_i), _np_ptr(dummy_d), _ci(0), _ci(0), _cd(0.0),
+        _ci(gp_dispersion_mode), _cd(0.1), _cd(5.0), _cd(0.0), _cd(nb_size[0]), _cd(nb_size[1]), _cd(nb_size[2]),
+        _cd(1.0), _cd(1e4), _cd(1e-6), _cd(0.0), _cd(1.5),
+        _np_ptr(theta), C.byref(out_theta_len),
+        _np_ptr(dummy_i), _np_ptr(dummy_i), _np_ptr(dummy_d), _np_ptr(dummy_i), _ci(guide_H_count),
+        C.byref(out_iter), C.byref(out_conv), C.byref(out_loss), C.byref(out_status), C.byref(out_tol),
+    ]
+    assert len(args) == 73
+    hist = None
+    if entry == "float":
+        L.rcppml_gpu_nmf_unified_float(*args)
+    elif entry == "double":
+        L.rcppml_gpu_nmf_unified_double(*args)
+    elif entry == "ex":
+        if mask is not None:
+            mp = np.ascontiguousarray(mask[0], np.int32)
+            mi = np.ascontiguousarray(mask[1], np.int32)
+            mnnz = int(mi.shape[0])
+        else:
+            mp, mi, mnnz = dummy_i, dummy_i, 0
+        hist = np.full(max(max_iter, 1), np.nan) if want_history else None
+        L.rcppml_gpu_nmf_ex(*args, _np_ptr(mp), _np_ptr(mi), _ci(mnnz), _cd(cd_tol), _ci(sort_model), _ci(precision),
+                            _np_ptr(hist) if hist is not None else None)
+    else:
+        raise ValueError(entry)
+    res = dict(d=d, iter=out_iter.value, converged=bool(out_conv.value), loss=out_loss.value, tol=out_tol.value,
+               status=out_status.value, theta=theta[:out_theta_len.value].copy())
+    if hist is not None:
+        res["loss_history"] = hist[:out_iter.value].copy()
+    if out_status.value != 0:
+        res["error"] = last_error()
+    return res
+
+
+def nnls_double(p, i, x, m, n, k, w_T, h, *, cd_maxit=100, cd_tol=1e-8, L1=0.0, L2=0.0, ub=0.0, nonneg=1, warm=0):
+    st = C.c_int(-99)
+    p = np.ascontiguousarray(p, np.int32); i = np.ascontiguousarray(i, np.int32); x = np.ascontiguousarray(x, np.float64)
+    assert w_T.shape == (m, k) and h.shape == (n, k) and w_T.dtype == np.float64 and h.dtype == np.float64
+    lib().rcppml_gpu_nnls_double(_np_ptr(p), _np_ptr(i), _np_ptr(x), _ci(m), _ci(n), _ci(x.shape[0]), _ci(k),
+                                 _np_ptr(np.ascontiguousarray(w_T)), _np_ptr(h), _ci(cd_maxit), _cd(cd_tol), _cd(L1),
+                                 _cd(L2), _cd(ub), _ci(nonneg), _ci(warm), C.byref(st))
+    if st.value != 0:
+        raise BackendError("rcppml_gpu_nnls_double: " + last_error())
+    return h
+
+
+def evaluate_mse_double(p, i, x, m, n, k, W_T, d, H, mask_zeros=False):
+    st, out = C.c_int(-99), C.c_double(0)
+    p = np.ascontiguousarray(p, np.int32); i = np.ascontiguousarray(i, np.int32); x = np.ascontiguousarray(x, np.float64)
+    lib().rcppml_gpu_evaluate_mse_double(_np_ptr(p), _np_ptr(i), _np_ptr(x), _ci(m), _ci(n), _ci(x.shape[0]), _ci(k),
+                                         _np_ptr(np.ascontiguousarray(W_T, np.float64)),
+                                         _np_ptr(np.ascontiguousarray(d, np.float64)),
+                                         _np_ptr(np.ascontiguousarray(H, np.float64)), _ci(int(mask_zeros)),
+                                         C.byref(out), C.byref(st))
+    if st.value != 0:
+        raise BackendError("rcppml_gpu_evaluate_mse_double: " + last_error())
+    return out.value
+
+
+# ----------------------------------------------------------------------------- device-level ops
+def _dptr(t):
+    """Device pointer of a torch tensor (or raw int / None)."""
+    if t is None:
+        return None
+    if isinstance(t, int):
+        return C.c_void_p(t)
+    return C.c_void_p(t.data_ptr())
+
+
+class Context:
+    """rcppml_hip_ctx bound to a device and a HIP stream (default: torch's current stream on that device)."""
+
+    def __init__(self, device=0, stream=None):
+        self._h = C.c_void_p()
+        if stream is None:
+            import torch
+            stream = torch.cuda.current_stream(device).cuda_stream
+        _chk(lib().rcppml_hip_ctx_create(C.byref(self._h), C.c_int(device), C.c_void_p(stream)), "ctx_create")
+        self.device = device
+
+    def close(self):
+        if self._h:
+            lib().rcppml_hip_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self):
+        _chk(lib().rcppml_hip_ctx_sync(self._h), "ctx_sync")
+
+    # ---- ops (dt: F32/F64; tensors are torch CUDA tensors laid out (cols, k) == column-major k x cols)
+    def gram(self, dt, F, k, r, eps, l2, G):
+        _chk(lib().rcppml_hip_gram(self._h, C.c_int(dt), _dptr(F), C.c_int(k), C.c_int64(r), C.c_double(eps),
+                                   C.c_double(l2), _dptr(G)), "gram")
+
+    def rhs(self, dt, col_ptr, row_idx, values, ncols, F, k, B):
+        _chk(lib().rcppml_hip_rhs(self._h, C.c_int(dt), _dptr(col_ptr), _dptr(row_idx), _dptr(values), C.c_int64(ncols),
+                                  _dptr(F), C.c_int(k), _dptr(B)), "rhs")
+
+    def solve_cd(self, dt, G, B, X, k, ncols, l1_pre=0.0, warm=0, zero_init=0, l1_cd=0.0, l2_cd=0.0, nonneg=1, maxit=100,
+                 tol=1e-8, ub_cd=0.0, ub_post=0.0, variant=CD_AUTO):
+        _chk(lib().rcppml_hip_solve_cd(self._h, C.c_int(dt), _dptr(G), _dptr(B), _dptr(X), C.c_int(k), C.c_int64(ncols),
+                                       C.c_double(l1_pre), C.c_int(warm), C.c_int(zero_init), C.c_double(l1_cd),
+                                       C.c_double(l2_cd), C.c_int(nonneg), C.c_int(maxit), C.c_double(tol),
+                                       C.c_double(ub_cd), C.c_double(ub_post), C.c_int(variant)), "solve_cd")
+
+    def solve_chol(self, dt, G, B, X, k, ncols, l1_pre=0.0, nonneg=1, ub_post=0.0):
+        _chk(lib().rcppml_hip_solve_chol(self._h, C.c_int(dt), _dptr(G), _dptr(B), _dptr(X), C.c_int(k), C.c_int64(ncols),
+                                         C.c_double(l1_pre), C.c_int(nonneg), C.c_double(ub_post)), "solve_chol")
+
+    def row_norms(self, dt, X, k, ncols, norm_type, out):
+        _chk(lib().rcppml_hip_row_norms(self._h, C.c_int(dt), _dptr(X), C.c_int(k), C.c_int64(ncols), C.c_int(norm_type),
+                                        _dptr(out)), "row_norms")
+
+    def apply_scaling(self, dt, X, k, ncols, norm_type, sums, d):
+        _chk(lib().rcppml_hip_apply_scaling(self._h, C.c_int(dt), _dptr(X), C.c_int(k), C.c_int64(ncols),
+                                            C.c_int(norm_type), _dptr(sums), _dptr(d)), "apply_scaling")
+
+    def sumsq(self, dt, x, length, out):
+        _chk(lib().rcppml_hip_sumsq(self._h, C.c_int(dt), _dptr(x), C.c_int64(length), _dptr(out)), "sumsq")
+
+    def loss_mse(self, dt, trAtA, d, W_T, B_w, k, m, G_wt, G_saved, out):
+        _chk(lib().rcppml_hip_loss_mse(self._h, C.c_int(dt), _dptr(trAtA), _dptr(d), _dptr(W_T), _dptr(B_w), C.c_int(k),
+                                       C.c_int64(m), _dptr(G_wt), _dptr(G_saved), _dptr(out)), "loss_mse")
+
+    def solve_masked(self, dt, col_ptr, row_idx, values, mask_p, mask_i, ncols, F, G_full, X, k, l1=0.0, l2=0.0, nonneg=1,
+                     cd_maxit=100, cd_tol=1e-8, solver_mode=0, warm=0):
+        _chk(lib().rcppml_hip_solve_masked(self._h, C.c_int(dt), _dptr(col_ptr), _dptr(row_idx), _dptr(values),
+                                           _dptr(mask_p), _dptr(mask_i), C.c_int64(ncols), _dptr(F), _dptr(G_full),
+                                           _dptr(X), C.c_int(k), C.c_double(l1), C.c_double(l2), C.c_int(nonneg),
+                                           C.c_int(cd_maxit), C.c_double(cd_tol), C.c_int(solver_mode), C.c_int(warm)),
+             "solve_masked")
+
+    def loss_nonzeros(self, dt, col_ptr, row_idx, values, mask_p, mask_i, ncols, W_T, d, H, k, out):
+        _chk(lib().rcppml_hip_loss_nonzeros(self._h, C.c_int(dt), _dptr(col_ptr), _dptr(row_idx), _dptr(values),
+                                            _dptr(mask_p), _dptr(mask_i), C.c_int64(ncols), _dptr(W_T), _dptr(d),
+                                            _dptr(H), C.c_int(k), _dptr(out)), "loss_nonzeros")

@@ -1,0 +1,61 @@
+// common.hip.h -- context, error plumbing and scratch memory shared by ops.hip and plugin.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <type_traits>
+#include <vector>
+
+#include "../../include/rcppml_gpu.h"
+
+// thread-local last error (never throw across the C ABI: reference src/gpu_bridge_nmf.cu:206-209)
+inline std::string& rcppml_err() {
+    static thread_local std::string e;
+    return e;
+}
+
+#define HIPCHK(expr)                                                                             \
+    do {                                                                                         \
+        hipError_t _e = (expr);                                                                  \
+        if (_e != hipSuccess)                                                                    \
+            throw std::runtime_error(std::string(#expr) + " failed: " + hipGetErrorString(_e) +  \
+                                     " (" __FILE__ ":" + std::to_string(__LINE__) + ")");        \
+    } while (0)
+
+#define RCPPML_CATCH_RET                                      \
+    catch (const std::exception& e) {                         \
+        rcppml_err() = e.what();                              \
+        return 1;                                             \
+    }                                                         \
+    catch (...) {                                             \
+        rcppml_err() = "unknown error";                       \
+        return 1;                                             \
+    }
+
+enum { WS_GRAM = 0, WS_GPAD, WS_CHOL, WS_RED, WS_RED2, WS_COUNT };
+
+struct rcppml_hip_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int num_cu = 256;
+    struct Buf { void* ptr = nullptr; size_t bytes = 0; };
+    Buf bufs[WS_COUNT];
+    // Grow-only scratch.  Growth frees the old block with hipFree, which synchronises the device,
+    // so no in-flight kernel can still be using it.
+    void* scratch(int slot, size_t bytes) {
+        Buf& b = bufs[slot];
+        if (bytes > b.bytes) {
+            if (b.ptr) HIPCHK(hipFree(b.ptr));
+            b.ptr = nullptr; b.bytes = 0;
+            size_t want = bytes < 4096 ? 4096 : bytes;
+            HIPCHK(hipMalloc(&b.ptr, want));
+            b.bytes = want;
+        }
+        return b.ptr;
+    }
+};

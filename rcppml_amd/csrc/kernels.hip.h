@@ -1,0 +1,838 @@
+// ============================================================================
+// kernels.hip.h -- hand-written CDNA4 (gfx950) kernels for RcppML's ALS-NNLS NMF hot path.
+// Written for 64-wide wavefronts, MI355X only (no CUDA/portable paths).
+//
+// Layout conventions: dense matrices column-major with rank k as leading dimension
+// (W_T k x m, H k x n, G k x k, B k x c); CSC with int32 indices.
+// Each kernel cites the reference routine it implements
+// (paths relative to /root/reference/inst/include/FactorNet).
+// ============================================================================
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rk {
+
+// Order LDS traffic between lanes of ONE wavefront (no block barrier: waves diverge in trip counts).
+#define RK_WAVE_SYNC()                                              \
+    do {                                                            \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      \
+        __builtin_amdgcn_wave_barrier();                            \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");      \
+    } while (0)
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+
+template <class T> __device__ __forceinline__ T tabs(T v) { return v < T(0) ? -v : v; }
+__device__ __forceinline__ float tfma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double tfma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+
+__device__ __forceinline__ float shfl_xor_t(float v, int m) { return __shfl_xor(v, m, 64); }
+__device__ __forceinline__ double shfl_xor_t(double v, int m) { return __shfl_xor(v, m, 64); }
+
+// ---------------------------------------------------------------------------
+// Gram  G = F F^T  (reference primitives/cpu/gram.hpp:37-67)
+//
+// MFMA kernels.  F (k x r) is streamed straight from HBM into the MFMA A/B operand registers:
+// for v_mfma_f32_32x32x2_f32 lane l supplies A[i = l&31][kk = l>>5] = F[32*t + (l&31), c + (l>>5)],
+// which is two contiguous 128-B runs per wave -- no LDS staging needed.  B operand of tile (ti,tj)
+// is the A operand of row-tile tj, so a wave loads T operand registers per K-step and issues T MFMAs
+// for the tile row blockIdx.y = ti.  The r dimension is split over waves; partial tiles are reduced
+// in fixed order (in-block through LDS, then across blocks by gram_finalize) so the result is
+// deterministic and bitwise symmetric.
+// ---------------------------------------------------------------------------
+template <int T_TILES>  // KP = 32 * T_TILES
+__global__ __launch_bounds__(256) void gram_partial_f32(const float* __restrict__ F, int k, int64_t r,
+                                                         float* __restrict__ partial) {
+    constexpr int KP = 32 * T_TILES;
+    __shared__ float red[3][T_TILES * 1024];
+    const int ti = blockIdx.y;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t nw = (int64_t)gridDim.x * 4, wid = (int64_t)blockIdx.x * 4 + wave;
+    const int64_t npairs = (r + 1) / 2;
+    const int64_t per = (npairs + nw - 1) / nw;
+    const int64_t p0 = wid * per;
+    const int64_t p1 = p0 + per < npairs ? p0 + per : npairs;
+    const int kk = lane >> 5, row = lane & 31;
+    f32x16 acc[T_TILES];
+#pragma unroll
+    for (int t = 0; t < T_TILES; ++t)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[t][v] = 0.f;
+    const int rowi = 32 * ti + row;
+#pragma unroll 4
+    for (int64_t p = p0; p < p1; ++p) {
+        const int64_t c = 2 * p + kk;
+        const bool cok = c < r;
+        const float* fc = F + c * (int64_t)k;
+        const float ai = (cok && rowi < k) ? fc[rowi] : 0.f;
+        float a[T_TILES];
+#pragma unroll
+        for (int t = 0; t < T_TILES; ++t) {
+            const int rr = 32 * t + row;
+            a[t] = (cok && rr < k) ? fc[rr] : 0.f;
+        }
+#pragma unroll
+        for (int t = 0; t < T_TILES; ++t)
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ai, a[t], acc[t], 0, 0, 0);
+    }
+    // in-block reduction, fixed order wave0 + wave1 + wave2 + wave3
+    if (wave > 0) {
+#pragma unroll
+        for (int t = 0; t < T_TILES; ++t)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) red[wave - 1][t * 1024 + v * 64 + lane] = acc[t][v];
+    }
+    __syncthreads();
+    if (wave == 0) {
+        float* out = partial + ((int64_t)blockIdx.x * KP * KP);
+#pragma unroll
+        for (int t = 0; t < T_TILES; ++t)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                float s = acc[t][v];
+                s += red[0][t * 1024 + v * 64 + lane];
+                s += red[1][t * 1024 + v * 64 + lane];
+                s += red[2][t * 1024 + v * 64 + lane];
+                // C/D map of 32x32 MFMA: col = lane&31, row = (v&3) + 8*(v>>2) + 4*(lane>>5)
+                const int i = 32 * ti + (v & 3) + 8 * (v >> 2) + 4 * (lane >> 5);
+                const int j = 32 * t + (lane & 31);
+                out[(int64_t)j * KP + i] = s;
+            }
+    }
+}
+
+template <int T_TILES>  // KP = 16 * T_TILES  (v_mfma_f64_16x16x4_f64)
+__global__ __launch_bounds__(256) void gram_partial_f64(const double* __restrict__ F, int k, int64_t r,
+                                                         double* __restrict__ partial) {
+    constexpr int KP = 16 * T_TILES;
+    __shared__ double red[3][T_TILES * 256];
+    const int ti = blockIdx.y;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t nw = (int64_t)gridDim.x * 4, wid = (int64_t)blockIdx.x * 4 + wave;
+    const int64_t nquad = (r + 3) / 4;
+    const int64_t per = (nquad + nw - 1) / nw;
+    const int64_t p0 = wid * per;
+    const int64_t p1 = p0 + per < nquad ? p0 + per : nquad;
+    const int kk = lane >> 4, row = lane & 15;
+    f64x4 acc[T_TILES];
+#pragma unroll
+    for (int t = 0; t < T_TILES; ++t)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) acc[t][v] = 0.0;
+    const int rowi = 16 * ti + row;
+#pragma unroll 2
+    for (int64_t p = p0; p < p1; ++p) {
+        const int64_t c = 4 * p + kk;
+        const bool cok = c < r;
+        const double* fc = F + c * (int64_t)k;
+        const double ai = (cok && rowi < k) ? fc[rowi] : 0.0;
+        double a[T_TILES];
+#pragma unroll
+        for (int t = 0; t < T_TILES; ++t) {
+            const int rr = 16 * t + row;
+            a[t] = (cok && rr < k) ? fc[rr] : 0.0;
+        }
+#pragma unroll
+        for (int t = 0; t < T_TILES; ++t)
+            acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, a[t], acc[t], 0, 0, 0);
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int t = 0; t < T_TILES; ++t)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) red[wave - 1][t * 256 + v * 64 + lane] = acc[t][v];
+    }
+    __syncthreads();
+    if (wave == 0) {
+        double* out = partial + ((int64_t)blockIdx.x * KP * KP);
+#pragma unroll
+        for (int t = 0; t < T_TILES; ++t)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                double s = acc[t][v];
+                s += red[0][t * 256 + v * 64 + lane];
+                s += red[1][t * 256 + v * 64 + lane];
+                s += red[2][t * 256 + v * 64 + lane];
+                // C/D map of the f64 16x16x4 MFMA: col = lane&15, row = (lane>>4) + 4*v
+                const int i = 16 * ti + (lane >> 4) + 4 * v;
+                const int j = 16 * t + (lane & 15);
+                out[(int64_t)j * KP + i] = s;
+            }
+    }
+}
+
+// Sum the per-block partial tiles in block order, add eps then l2 on the diagonal
+// (gram.hpp:51 tiny_num, fit_cpu.hpp:506/738 L2), write the k x k result.
+template <class T>
+__global__ void gram_finalize(const T* __restrict__ partial, int nblk, int KP, int k, T eps, T l2,
+                              T* __restrict__ G) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= KP * KP) return;
+    const int i = e % KP, j = e / KP;
+    if (i >= k || j >= k) return;
+    T s = 0;
+    for (int b = 0; b < nblk; ++b) s += partial[(int64_t)b * KP * KP + e];
+    if (i == j) { s += eps; s += l2; }
+    G[(int64_t)j * k + i] = s;
+}
+
+// ---------------------------------------------------------------------------
+// RHS  B(:,j) = sum_{i in nz(j)} A(i,j) F(:,i)   (reference primitives/cpu/rhs.hpp:52-70,
+// fused_nnls.hpp:109-114).  The SpMM-like, HBM/L2-bound kernel of the path.
+//
+// One wavefront per output column.  The wave is split into NG = 64/LPN lane groups; a group of LPN
+// lanes covers one k-vector of F with VEC contiguous elements per lane (16-byte loads when k allows),
+// so one wave-wide load instruction gathers NG rows of F (k=64 fp32: 4 rows, 1 KiB).  Group g walks
+// nonzeros start+g, start+g+NG, ...; (row, value) pairs are read with group-uniform addresses
+// (consecutive int32 / T, cache-line coalesced).  U independent gathers are kept in flight per lane.
+// Group partial sums are combined with xor-shuffles at the end.
+// ---------------------------------------------------------------------------
+template <class T, int VEC> struct VecT;
+template <> struct VecT<float, 1> { typedef float type; };
+template <> struct VecT<float, 2> { typedef float type __attribute__((ext_vector_type(2))); };
+template <> struct VecT<float, 4> { typedef float type __attribute__((ext_vector_type(4))); };
+template <> struct VecT<double, 1> { typedef double type; };
+template <> struct VecT<double, 2> { typedef double type __attribute__((ext_vector_type(2))); };
+
+template <class T, int VEC, int LPN, int U>
+__global__ __launch_bounds__(256) void rhs_kernel(const int* __restrict__ colptr,
+                                                   const int* __restrict__ rowidx,
+                                                   const T* __restrict__ vals, int64_t ncols,
+                                                   const T* __restrict__ F, int k,
+                                                   T* __restrict__ B) {
+    constexpr int NG = 64 / LPN;
+    const int64_t j = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (j >= ncols) return;
+    const int lane = threadIdx.x & 63;
+    const int g = lane / LPN, li = lane % LPN;
+    const int f0 = li * VEC;
+    const bool fok = f0 < k;
+    const int start = colptr[j], end = colptr[j + 1];
+    T acc[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) acc[e] = T(0);
+    const T* Fl = F + f0;
+    for (int t = start + g; t < end; t += NG * U) {
+        int rr[U];
+        T vv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int tt = t + u * NG;
+            const bool ok = tt < end;
+            rr[u] = ok ? rowidx[tt] : 0;
+            vv[u] = ok ? vals[tt] : T(0);
+        }
+        T ff[U][VEC];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (fok) {
+                const T* src = Fl + (int64_t)rr[u] * k;
+                if constexpr (VEC == 1) {
+                    ff[u][0] = src[0];
+                } else {
+                    typedef typename VecT<T, VEC>::type V;
+                    const V v = *reinterpret_cast<const V*>(src);
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) ff[u][e] = v[e];
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) ff[u][e] = T(0);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) acc[e] = tfma(vv[u], ff[u][e], acc[e]);
+    }
+#pragma unroll
+    for (int off = LPN; off < 64; off <<= 1)
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) acc[e] += shfl_xor_t(acc[e], off);
+    if (g == 0 && fok) {
+        T* dst = B + j * (int64_t)k + f0;
+        if constexpr (VEC == 1) {
+            dst[0] = acc[0];
+        } else {
+            typedef typename VecT<T, VEC>::type V;
+            V v;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) v[e] = acc[e];
+            *reinterpret_cast<V*>(dst) = v;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Padding helper for the solve kernels: Gp (KP x KP) = G (k x k) with identity on the padded
+// diagonal; invd[i] = 1/G_ii (0 if G_ii <= 0: the reference skips such coordinates,
+// nnls_batch.hpp:88-89).
+// ---------------------------------------------------------------------------
+template <class T>
+__global__ void pad_gram(const T* __restrict__ G, int k, int KP, T* __restrict__ Gp,
+                         T* __restrict__ invd) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= KP * KP) return;
+    const int i = e % KP, j = e / KP;
+    T v = (i < k && j < k) ? G[(int64_t)j * k + i] : (i == j ? T(1) : T(0));
+    Gp[e] = v;
+    if (i == j) invd[i] = v > T(0) ? T(1) / v : T(0);
+}
+
+// ---------------------------------------------------------------------------
+// CD NNLS, one LANE per column ("lane" variant).
+// Reference: primitives/cpu/nnls_batch.hpp:70-132 cd_nnls_col_fixed, with the prologue of
+// fused_nnls.hpp:116-123.  A wave solves 64 columns at once: the residual b (KP registers per lane)
+// and x live with the lane, G(:,i) is wave-uniform and is read through the scalar cache into SGPRs,
+// so the rank-1 residual update of a coordinate is KP v_fma with an SGPR operand and every scalar
+// decision of the reference (clamp, skip, tolerance) is lane-parallel.  Per-column early exit
+// (cd_tol) freezes the lane through the exec mask; the wave leaves when all its columns are done.
+// A coordinate whose step is 0 is a no-op in the reference (`continue`); here it executes
+// b -= G(:,i)*0 and tol += 0, which is the same arithmetic result.
+//   EXACT = true : IEEE divisions as the reference writes them (fp64 parity mode)
+//   EXACT = false: multiply by precomputed 1/G_ii, v_rcp for the tolerance term (fp32 throughput mode)
+// ---------------------------------------------------------------------------
+template <class T> __device__ __forceinline__ T fast_div(T a, T b);
+template <> __device__ __forceinline__ float fast_div<float>(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+template <> __device__ __forceinline__ double fast_div<double>(double a, double b) { return a / b; }
+
+template <class T, int KP, bool EXACT>
+__global__ __launch_bounds__(64) void cd_lane_kernel(const T* __restrict__ Gp,
+                                                      const T* __restrict__ invd,
+                                                      const T* __restrict__ B, T* __restrict__ X,
+                                                      int k, int64_t ncols, T l1_pre, int warm,
+                                                      int zero_init, T l1_cd, T l2_cd, int nonneg,
+                                                      int maxit, T tol, T ub_cd, T ub_post) {
+    const int64_t j = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    const bool inb = j < ncols;
+    T b[KP], x[KP];
+    const T* bj = B + j * (int64_t)k;
+    T* xj = X + j * (int64_t)k;
+#pragma unroll
+    for (int i = 0; i < KP; ++i) {
+        b[i] = (inb && i < k) ? bj[i] : T(0);
+        x[i] = (inb && i < k && !zero_init) ? xj[i] : T(0);
+    }
+    if (l1_pre != T(0)) {
+#pragma unroll
+        for (int i = 0; i < KP; ++i)
+            if (i < k) b[i] -= l1_pre;
+    }
+    if (warm) {  // b -= G x   (fused_nnls.hpp:121-123)
+#pragma unroll
+        for (int c = 0; c < KP; ++c) {
+            const T xc = x[c];
+#pragma unroll
+            for (int r = 0; r < KP; ++r) b[r] = tfma(-Gp[c * KP + r], xc, b[r]);
+        }
+    }
+    const bool has_upper = ub_cd > T(0);
+    const bool check = tol > T(0);
+    const T inv_k = T(1) / static_cast<T>(k);
+    bool active = inb;
+    for (int it = 0; it < maxit; ++it) {
+        if (!__any(active)) break;
+        if (active) {
+            T tol_sum = T(0);
+#pragma unroll
+            for (int i = 0; i < KP; ++i) {
+                const T ginv = invd[i];
+                if (ginv > T(0)) {   // wave-uniform: reference `if (g_diag <= 0) continue;`
+                    T diff;
+                    if constexpr (EXACT) diff = b[i] / Gp[i * KP + i];
+                    else diff = b[i] * ginv;
+                    if (l1_cd != T(0)) diff -= l1_cd;
+                    if (l2_cd != T(0)) diff += l2_cd * x[i];
+                    const T nv = x[i] + diff;
+                    T ad = diff, nx = nv;
+                    if (nonneg && nv < T(0)) { ad = -x[i]; nx = T(0); }
+                    else if (has_upper && nv > ub_cd) { ad = ub_cd - x[i]; nx = ub_cd; }
+                    x[i] = nx;
+                    if (check) {
+                        if constexpr (EXACT) tol_sum += tabs(ad) / (tabs(nx) + T(1e-15));
+                        else tol_sum += fast_div<T>(tabs(ad), tabs(nx) + T(1e-15));
+                    }
+#pragma unroll
+                    for (int r = 0; r < KP; ++r) b[r] = tfma(-Gp[i * KP + r], ad, b[r]);
+                }
+            }
+            if (check && tol_sum * inv_k < tol) active = false;
+        }
+    }
+    if (inb) {
+#pragma unroll
+        for (int i = 0; i < KP; ++i)
+            if (i < k) {
+                T v = x[i];
+                if (ub_post > T(0)) v = v < ub_post ? v : ub_post;
+                xj[i] = v;
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// CD NNLS, one WAVEFRONT per column with active-coordinate ballot skipping ("wave" variant).
+// Same reference routine.  Lane r owns coordinates r, r+64, ... (VPL = KP/64 of them): its residual
+// b_r, iterate x_r and 1/G_rr stay in registers; G sits in LDS ([i][r], conflict-free column reads).
+// The reference visits coordinates in order and most visits are no-ops (x_i = 0 and the step would
+// make it negative, or a zero step).  Whether coordinate r is a no-op depends only on the current
+// residual, and the residual only changes at an effective step, so all lanes evaluate their own
+// coordinate in parallel, a ballot + s_ff1 finds the next coordinate >= cur that really moves, and
+// everything before it is skipped exactly.  Cost is per EFFECTIVE step, which is what makes this
+// variant win when the solution is sparse and for ranks the lane variant cannot hold in registers.
+// Persistent blocks: each wave strides over columns, G is staged into LDS once per block.
+// ---------------------------------------------------------------------------
+template <class T, int KP, bool EXACT>
+__global__ __launch_bounds__(256) void cd_wave_kernel(const T* __restrict__ Gp,
+                                                       const T* __restrict__ invd,
+                                                       const T* __restrict__ B, T* __restrict__ X,
+                                                       int k, int64_t ncols, T l1_pre, int warm,
+                                                       int zero_init, T l1_cd, T l2_cd, int nonneg,
+                                                       int maxit, T tol, T ub_cd, T ub_post) {
+    constexpr int VPL = KP / 64;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    T* Gs = reinterpret_cast<T*>(smem_raw);
+    for (int e = threadIdx.x; e < KP * KP; e += blockDim.x) Gs[e] = Gp[e];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    const bool has_upper = ub_cd > T(0);
+    const bool check = tol > T(0);
+    const T inv_k = T(1) / static_cast<T>(k);
+    T ginv[VPL], gdiag[VPL];
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) { ginv[v] = invd[lane + 64 * v]; gdiag[v] = Gs[(lane + 64 * v) * KP + lane + 64 * v]; }
+
+    for (int64_t j = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); j < ncols; j += nwaves) {
+        T b[VPL], x[VPL];
+        const T* bj = B + j * (int64_t)k;
+        T* xj = X + j * (int64_t)k;
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) {
+            const int f = lane + 64 * v;
+            b[v] = f < k ? bj[f] : T(0);
+            x[v] = (f < k && !zero_init) ? xj[f] : T(0);
+            if (l1_pre != T(0) && f < k) b[v] -= l1_pre;
+        }
+        if (warm) {  // b -= G x: broadcast x_c, column c of G from LDS
+            for (int c = 0; c < k; ++c) {
+                const T xc = __shfl(x[c >> 6], c & 63, 64);
+                if (xc != T(0)) {
+#pragma unroll
+                    for (int v = 0; v < VPL; ++v) b[v] = tfma(-Gs[c * KP + lane + 64 * v], xc, b[v]);
+                }
+            }
+        }
+        for (int it = 0; it < maxit; ++it) {
+            T tol_sum = T(0);
+#pragma unroll
+            for (int v = 0; v < VPL; ++v) {
+                int cur = 0;  // next coordinate (within this 64-slab) the sweep has not visited
+                while (true) {
+                    T diff;
+                    if constexpr (EXACT) diff = b[v] / gdiag[v];
+                    else diff = b[v] * ginv[v];
+                    if (l1_cd != T(0)) diff -= l1_cd;
+                    if (l2_cd != T(0)) diff += l2_cd * x[v];
+                    const T nv = x[v] + diff;
+                    T ad = diff, nx = nv;
+                    if (nonneg && nv < T(0)) { ad = -x[v]; nx = T(0); }
+                    else if (has_upper && nv > ub_cd) { ad = ub_cd - x[v]; nx = ub_cd; }
+                    const bool moves = (ginv[v] > T(0)) && (ad != T(0)) && (lane >= cur);
+                    const unsigned long long mask = __ballot(moves);
+                    if (mask == 0ull) break;
+                    const int i = __builtin_ctzll(mask);   // first coordinate >= cur that moves
+                    const T ad_i = __shfl(ad, i, 64);
+                    const T nx_i = __shfl(nx, i, 64);
+                    if (lane == i) x[v] = nx_i;
+                    if (check) {
+                        if constexpr (EXACT) tol_sum += tabs(ad_i) / (tabs(nx_i) + T(1e-15));
+                        else tol_sum += fast_div<T>(tabs(ad_i), tabs(nx_i) + T(1e-15));
+                    }
+                    const T* gc = Gs + (i + 64 * v) * KP;
+#pragma unroll
+                    for (int u = 0; u < VPL; ++u) b[u] = tfma(-gc[lane + 64 * u], ad_i, b[u]);
+                    cur = i + 1;
+                    if (cur >= 64) break;
+                }
+            }
+            if (check && tol_sum * inv_k < tol) break;
+        }
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) {
+            const int f = lane + 64 * v;
+            if (f < k) {
+                T val = x[v];
+                if (ub_post > T(0)) val = val < ub_post ? val : ub_post;
+                xj[f] = val;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Cholesky of the (padded) Gram, one wavefront: right-looking, column by column, in LDS.
+// Restates Eigen::LLT as used at reference primitives/cpu/fused_nnls.hpp:185.
+// Output L (KP x KP, lower, column-major) and invl[i] = 1/L_ii.
+// ---------------------------------------------------------------------------
+template <class T, int KP>
+__global__ __launch_bounds__(64) void chol_factor_kernel(const T* __restrict__ Gp, T* __restrict__ L,
+                                                          T* __restrict__ invl) {
+    __shared__ T A[KP * KP];
+    const int lane = threadIdx.x;
+    for (int e = lane; e < KP * KP; e += 64) A[e] = Gp[e];
+    __syncthreads();
+    for (int j = 0; j < KP; ++j) {
+        // left-looking: column j minus contributions of previous columns, rows i >= j
+        for (int i = j + lane; i < KP; i += 64) {
+            T s = A[j * KP + i];
+            for (int p = 0; p < j; ++p) s -= A[p * KP + i] * A[p * KP + j];
+            A[j * KP + i] = s;
+        }
+        __syncthreads();
+        T djj = A[j * KP + j];
+        if (!(djj > T(0))) djj = tabs(djj) + T(1e-30);
+        const T ljj = sqrt(djj);
+        __syncthreads();
+        for (int i = j + lane; i < KP; i += 64) A[j * KP + i] = (i == j) ? ljj : A[j * KP + i] / ljj;
+        __syncthreads();
+    }
+    for (int e = lane; e < KP * KP; e += 64) {
+        const int i = e % KP, j = e / KP;
+        L[e] = i >= j ? A[e] : T(0);
+    }
+    for (int i = lane; i < KP; i += 64) invl[i] = T(1) / A[i * KP + i];
+}
+
+// ---------------------------------------------------------------------------
+// Cholesky solve + clip, one lane per column (reference fused_nnls.hpp:200-218):
+// x = L^-T L^-1 (b - l1); x = max(x, 0) if nonneg; x = min(x, ub) if ub > 0.
+// L is wave-uniform (SGPR operands), b per lane.  Divisions as the reference's llt.solve.
+// ---------------------------------------------------------------------------
+template <class T, int KP>
+__global__ __launch_bounds__(64) void chol_solve_kernel(const T* __restrict__ L,
+                                                         const T* __restrict__ B, T* __restrict__ X,
+                                                         int k, int64_t ncols, T l1_pre, int nonneg,
+                                                         T ub_post) {
+    const int64_t j = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (j >= ncols) return;
+    T x[KP];
+    const T* bj = B + j * (int64_t)k;
+#pragma unroll
+    for (int i = 0; i < KP; ++i) x[i] = i < k ? bj[i] : T(0);
+    if (l1_pre != T(0)) {
+#pragma unroll
+        for (int i = 0; i < KP; ++i)
+            if (i < k) x[i] -= l1_pre;
+    }
+#pragma unroll
+    for (int i = 0; i < KP; ++i) {
+        T t = x[i];
+#pragma unroll
+        for (int p = 0; p < i; ++p) t = tfma(-L[p * KP + i], x[p], t);
+        x[i] = t / L[i * KP + i];
+    }
+#pragma unroll
+    for (int i = KP - 1; i >= 0; --i) {
+        T t = x[i];
+#pragma unroll
+        for (int p = i + 1; p < KP; ++p) t = tfma(-L[i * KP + p], x[p], t);
+        x[i] = t / L[i * KP + i];
+    }
+    T* xj = X + j * (int64_t)k;
+#pragma unroll
+    for (int i = 0; i < KP; ++i)
+        if (i < k) {
+            T v = x[i];
+            if (nonneg) v = v > T(0) ? v : T(0);
+            if (ub_post > T(0)) v = v < ub_post ? v : ub_post;
+            xj[i] = v;
+        }
+}
+
+// ---------------------------------------------------------------------------
+// Scaling (reference nmf/variant_helpers.hpp:286-305): row sums of |x| or x^2, two deterministic
+// passes; then d = (sqrt) + 1e-15 and X(i,:) /= d_i.
+// ---------------------------------------------------------------------------
+template <class T>
+__global__ __launch_bounds__(256) void row_norm_partial(const T* __restrict__ X, int k, int64_t ncols,
+                                                         int norm_type, T* __restrict__ partial) {
+    // thread t handles feature f = t % kp2 (kp2 = pow2 >= k, <= 256) and column slot t / kp2
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    T* sh = reinterpret_cast<T*>(smem_raw);
+    int kp2 = 1;
+    while (kp2 < k) kp2 <<= 1;
+    if (kp2 > 256) kp2 = 256;  // k > 256 handled by the feature loop below
+    const int slots = 256 / kp2;
+    const int f0 = threadIdx.x % kp2, slot = threadIdx.x / kp2;
+    const int64_t per = (ncols + gridDim.x - 1) / gridDim.x;
+    const int64_t c0 = (int64_t)blockIdx.x * per;
+    const int64_t c1 = c0 + per < ncols ? c0 + per : ncols;
+    for (int f = f0; f < k; f += kp2) {
+        T acc = 0;
+        for (int64_t c = c0 + slot; c < c1; c += slots) {
+            const T v = X[c * (int64_t)k + f];
+            acc += norm_type == 0 ? tabs(v) : v * v;
+        }
+        sh[threadIdx.x] = acc;
+        __syncthreads();
+        if (slot == 0) {
+            T s = acc;
+            for (int q = 1; q < slots; ++q) s += sh[q * kp2 + f0];
+            partial[(int64_t)blockIdx.x * k + f] = s;
+        }
+        __syncthreads();
+    }
+}
+template <class T>
+__global__ void row_norm_final(const T* __restrict__ partial, int nblk, int k, T* __restrict__ out) {
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= k) return;
+    T s = 0;
+    for (int b = 0; b < nblk; ++b) s += partial[(int64_t)b * k + f];
+    out[f] = s;
+}
+template <class T>
+__global__ void scaling_finalize(const T* __restrict__ sums, int k, int norm_type, T* __restrict__ d) {
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= k) return;
+    if (norm_type == 2) { d[f] = T(1); return; }
+    T s = sums[f];
+    if (norm_type == 1) s = sqrt(s);
+    d[f] = s + T(1e-15);
+}
+template <class T>
+__global__ __launch_bounds__(256) void scale_rows(T* __restrict__ X, int k, int64_t total,
+                                                   const T* __restrict__ d) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride)
+        X[e] = X[e] / d[e % k];
+}
+
+// ---------------------------------------------------------------------------
+// fp64 reductions for the loss (reference primitives/primitives.hpp:100-115 trace_AtA;
+// nmf/fit_cpu.hpp:1740-1753 cross term and recon norm).  Block partials then a fixed-order sum.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ double block_sum_256(double v, double* sh) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) sh[wave] = v;
+    __syncthreads();
+    double s = 0;
+    if (threadIdx.x == 0) s = sh[0] + sh[1] + sh[2] + sh[3];
+    __syncthreads();
+    return s;
+}
+template <class T>
+__global__ __launch_bounds__(256) void sumsq_partial(const T* __restrict__ x, int64_t len,
+                                                      double* __restrict__ partial) {
+    __shared__ double sh[4];
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    double acc = 0;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < len; e += stride) {
+        const double v = static_cast<double>(x[e]);
+        acc += v * v;
+    }
+    const double s = block_sum_256(acc, sh);
+    if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+// cross partials: sum_e d[e%k] * W[e] * Bw[e]
+template <class T>
+__global__ __launch_bounds__(256) void cross_partial(const T* __restrict__ W, const T* __restrict__ Bw,
+                                                      const T* __restrict__ d, int k, int64_t total,
+                                                      double* __restrict__ partial) {
+    __shared__ double sh[4];
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    double acc = 0;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride)
+        acc += static_cast<double>(d[e % k]) * static_cast<double>(W[e]) * static_cast<double>(Bw[e]);
+    const double s = block_sum_256(acc, sh);
+    if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+static __global__ __launch_bounds__(256) void sum_partials(const double* __restrict__ partial, int n,
+                                                     double* __restrict__ out) {
+    __shared__ double sh[4];
+    double acc = 0;
+    for (int i = threadIdx.x; i < n; i += 256) acc += partial[i];
+    const double s = block_sum_256(acc, sh);
+    if (threadIdx.x == 0) out[0] = s;
+}
+// out[0] = trAtA - 2 cross + recon; out[1] = cross; out[2] = recon    (single block of 256)
+template <class T>
+__global__ __launch_bounds__(256) void loss_mse_final(const double* __restrict__ trAtA,
+                                                       const double* __restrict__ cross_part, int npart,
+                                                       const T* __restrict__ d, const T* __restrict__ Gwt,
+                                                       const T* __restrict__ Gsaved, int k,
+                                                       double* __restrict__ out) {
+    __shared__ double sh[4];
+    double acc = 0;
+    for (int e = threadIdx.x; e < k * k; e += 256) {
+        const int i = e % k, j = e / k;
+        acc += static_cast<double>(d[i]) * static_cast<double>(d[j]) * static_cast<double>(Gwt[e]) *
+               static_cast<double>(Gsaved[e]);
+    }
+    const double recon = block_sum_256(acc, sh);
+    if (threadIdx.x == 0) {
+        double cross = 0;
+        for (int i = 0; i < npart; ++i) cross += cross_part[i];
+        out[0] = trAtA[0] - 2.0 * cross + recon;
+        out[1] = cross;
+        out[2] = recon;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Explicit-mask per-column NNLS (reference nmf/masked_nnls.hpp:96-154 / 177-242).
+// One wavefront per column; lane r owns feature r (k <= 64).  The per-column Gram
+//   G_loc = G_full - sum_{r in masked(j)} f_r f_r^T  (+ l2 on the diagonal)
+// lives in LDS (one k x k tile per wave); b skips masked rows of A (two-pointer merge: both row
+// lists are sorted).  Solve: CD exactly as the wave variant above (sequential visit, in-order), or
+// in-LDS Cholesky + clip for solver_mode 1.
+// ---------------------------------------------------------------------------
+template <class T, int KP>   // KP = 64 only (k <= 64)
+__global__ __launch_bounds__(256) void masked_solve_kernel(
+    const int* __restrict__ colptr, const int* __restrict__ rowidx, const T* __restrict__ vals,
+    const int* __restrict__ mask_p, const int* __restrict__ mask_i, int64_t ncols,
+    const T* __restrict__ F, const T* __restrict__ Gfull, T* __restrict__ X, int k, T l1, T l2,
+    int nonneg, int maxit, T tol, int solver_mode, int warm) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    T* Gl = reinterpret_cast<T*>(smem_raw) + (size_t)wave * KP * KP;   // [c][r]
+    const int64_t j = (int64_t)blockIdx.x * 4 + wave;
+    if (j >= ncols) return;
+    const bool fok = lane < k;
+    // G_loc = G_full (padded with identity)
+    for (int c = 0; c < KP; ++c) {
+        T v = (fok && c < k) ? Gfull[(int64_t)c * k + lane] : (c == lane ? T(1) : T(0));
+        Gl[c * KP + lane] = v;
+    }
+    // b over unmasked nonzeros; delta-G over ALL masked rows
+    T b = T(0);
+    const int as = colptr[j], ae = colptr[j + 1];
+    int ms = mask_p[j];
+    const int me = mask_p[j + 1];
+    for (int t = as; t < ae; ++t) {
+        const int row = rowidx[t];
+        while (ms < me && mask_i[ms] < row) ++ms;
+        const bool masked = ms < me && mask_i[ms] == row;
+        if (!masked && fok) b = tfma(vals[t], F[(int64_t)row * k + lane], b);
+    }
+    for (int t = mask_p[j]; t < me; ++t) {
+        const int row = mask_i[t];
+        const T fr = fok ? F[(int64_t)row * k + lane] : T(0);
+        for (int c = 0; c < k; ++c) {
+            const T fc = __shfl(fr, c, 64);
+            Gl[c * KP + lane] -= fr * fc;
+        }
+    }
+    if (fok) { b -= l1; Gl[lane * KP + lane] += l2; }
+    RK_WAVE_SYNC();
+    T x = (warm && fok) ? X[j * (int64_t)k + lane] : T(0);
+    if (solver_mode == 1) {
+        // in-LDS Cholesky (left-looking) then forward/back substitution; x = clip(G_loc^-1 b)
+        for (int c = 0; c < KP; ++c) {
+            T s = Gl[c * KP + lane];
+            for (int p = 0; p < c; ++p) s -= Gl[p * KP + lane] * Gl[p * KP + c];
+            T dcc = __shfl(s, c, 64);
+            if (!(dcc > T(0))) dcc = tabs(dcc) + T(1e-30);
+            const T lcc = sqrt(dcc);
+            Gl[c * KP + lane] = lane == c ? lcc : (lane > c ? s / lcc : T(0));
+            RK_WAVE_SYNC();
+        }
+        T y = b;
+        for (int i = 0; i < k; ++i) {   // forward: y_i = (b_i - sum_{p<i} L_ip y_p) / L_ii
+            const T yi = __shfl(y, i, 64) / Gl[i * KP + i];
+            if (lane == i) y = yi;
+            else if (lane > i) y -= Gl[i * KP + lane] * yi;
+        }
+        for (int i = k - 1; i >= 0; --i) {  // backward: x_i = (y_i - sum_{p>i} L_pi x_p) / L_ii
+            const T xi = __shfl(y, i, 64) / Gl[i * KP + i];
+            if (lane == i) y = xi;
+            else if (lane < i) y -= Gl[lane * KP + i] * xi;
+        }
+        x = y;
+        if (nonneg) x = x > T(0) ? x : T(0);
+    } else {
+        const bool check = tol > T(0);
+        const T inv_k = T(1) / static_cast<T>(k);
+        const T gd = Gl[lane * KP + lane];
+        for (int it = 0; it < maxit; ++it) {
+            T tol_sum = T(0);
+            int cur = 0;
+            while (true) {
+                const T diff = b / gd;
+                const T nv = x + diff;
+                T ad = diff, nx = nv;
+                if (nonneg && nv < T(0)) { ad = -x; nx = T(0); }
+                const bool moves = fok && (gd > T(0)) && (ad != T(0)) && (lane >= cur);
+                const unsigned long long mask = __ballot(moves);
+                if (mask == 0ull) break;
+                const int i = __builtin_ctzll(mask);
+                const T ad_i = __shfl(ad, i, 64), nx_i = __shfl(nx, i, 64);
+                if (lane == i) x = nx_i;
+                if (check) tol_sum += tabs(ad_i) / (tabs(nx_i) + T(1e-15));
+                b = tfma(-Gl[i * KP + lane], ad_i, b);
+                cur = i + 1;
+                if (cur >= 64) break;
+            }
+            if (check && tol_sum * inv_k < tol) break;
+        }
+    }
+    if (fok) X[j * (int64_t)k + lane] = x;
+}
+
+// Loss over (unmasked) nonzeros, fp64 accumulation, one wavefront per column
+// (reference nmf/masked_nnls.hpp:250-282; also the nonzero pass of evaluate()):
+//   partial[2b]   = sum (a - p)^2,  partial[2b+1] = sum p^2,   p = sum_f d_f W_T(f,i) H(f,j)
+template <class T>
+__global__ __launch_bounds__(256) void loss_nonzeros_kernel(
+    const int* __restrict__ colptr, const int* __restrict__ rowidx, const T* __restrict__ vals,
+    const int* __restrict__ mask_p, const int* __restrict__ mask_i, int64_t ncols,
+    const T* __restrict__ W_T, const T* __restrict__ d, const T* __restrict__ H, int k,
+    double* __restrict__ partial) {
+    __shared__ double sh[8];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t j = (int64_t)blockIdx.x * 4 + wave;
+    double acc = 0, acc2 = 0;
+    if (j < ncols) {
+        int ms = mask_p ? mask_p[j] : 0;
+        const int me = mask_p ? mask_p[j + 1] : 0;
+        for (int t = colptr[j]; t < colptr[j + 1]; ++t) {
+            const int row = rowidx[t];
+            while (ms < me && mask_i[ms] < row) ++ms;
+            if (ms < me && mask_i[ms] == row) continue;
+            T p = T(0);
+            for (int f = lane; f < k; f += 64)
+                p += (W_T[(int64_t)row * k + f] * d[f]) * H[j * (int64_t)k + f];
+            double pd = static_cast<double>(p);
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) pd += __shfl_xor(pd, off, 64);
+            const double df = static_cast<double>(vals[t]) - pd;
+            acc += df * df;   // identical in all lanes
+            acc2 += pd * pd;
+        }
+    }
+    if (lane == 0) { sh[wave] = acc; sh[4 + wave] = acc2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        partial[2 * (int64_t)blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+        partial[2 * (int64_t)blockIdx.x + 1] = sh[4] + sh[5] + sh[6] + sh[7];
+    }
+}
+// out[0] = sum of even partials, out[1] = sum of odd partials (fixed order)
+static __global__ __launch_bounds__(256) void sum_partials2(const double* __restrict__ partial, int n,
+                                                      double* __restrict__ out) {
+    __shared__ double sh[4];
+    double a0 = 0, a1 = 0;
+    for (int i = threadIdx.x; i < n; i += 256) { a0 += partial[2 * i]; a1 += partial[2 * i + 1]; }
+    const double s0 = block_sum_256(a0, sh);
+    const double s1 = block_sum_256(a1, sh);
+    if (threadIdx.x == 0) { out[0] = s0; out[1] = s1; }
+}
+
+}  // namespace rk

@@ -1,0 +1,95 @@
+// ops_gram.hip -- context + Gram (device-level C ABI, include/rcppml_gpu.h layer 2)
+#include "common.hip.h"
+#include "kernels.hip.h"
+
+using namespace rk;
+// ----------------------------------------------------------------------------
+// context
+// ----------------------------------------------------------------------------
+extern "C" int rcppml_hip_ctx_create(rcppml_hip_ctx** out, int device, void* stream) {
+    try {
+        int ndev = 0;
+        HIPCHK(hipGetDeviceCount(&ndev));
+        if (ndev <= 0) throw std::runtime_error("no HIP device visible");
+        if (device < 0 || device >= ndev) throw std::runtime_error("device index out of range");
+        HIPCHK(hipSetDevice(device));
+        rcppml_hip_ctx* c = new rcppml_hip_ctx();
+        c->device = device;
+        c->stream = static_cast<hipStream_t>(stream);
+        hipDeviceProp_t prop;
+        HIPCHK(hipGetDeviceProperties(&prop, device));
+        c->num_cu = prop.multiProcessorCount;
+        *out = c;
+        return 0;
+    }
+    RCPPML_CATCH_RET
+}
+extern "C" void rcppml_hip_ctx_destroy(rcppml_hip_ctx* c) {
+    if (!c) return;
+    for (auto& b : c->bufs)
+        if (b.ptr) (void)hipFree(b.ptr);
+    delete c;
+}
+extern "C" int rcppml_hip_ctx_sync(rcppml_hip_ctx* c) {
+    try { HIPCHK(hipStreamSynchronize(c->stream)); return 0; }
+    RCPPML_CATCH_RET
+}
+
+// ----------------------------------------------------------------------------
+// Gram
+// ----------------------------------------------------------------------------
+template <class T> static int gram_kp(int k);
+template <> int gram_kp<float>(int k) { return ((k + 31) / 32) * 32; }
+template <> int gram_kp<double>(int k) { return ((k + 15) / 16) * 16; }
+
+template <class T>
+static void gram_impl(rcppml_hip_ctx* c, const T* F, int k, int64_t r, T eps, T l2, T* G) {
+    const int KP = gram_kp<T>(k);
+    if (KP > 256) throw std::runtime_error("gram: k > 256 not supported");
+    // number of blocks: enough waves to fill the chip, each wave >= 64 K-steps
+    const int64_t step = std::is_same<T, float>::value ? 2 : 4;
+    int64_t nblk = (r / step + 4 * 64 - 1) / (4 * 64);
+    if (nblk < 1) nblk = 1;
+    if (nblk > 2 * (int64_t)c->num_cu) nblk = 2 * c->num_cu;
+    T* partial = static_cast<T*>(c->scratch(WS_GRAM, (size_t)nblk * KP * KP * sizeof(T)));
+    if constexpr (std::is_same<T, float>::value) {
+        const int tt = KP / 32;
+        dim3 grid((unsigned)nblk, tt), block(256);
+        switch (tt) {
+            case 1: hipLaunchKernelGGL(gram_partial_f32<1>, grid, block, 0, c->stream, F, k, r, partial); break;
+            case 2: hipLaunchKernelGGL(gram_partial_f32<2>, grid, block, 0, c->stream, F, k, r, partial); break;
+            case 3: hipLaunchKernelGGL(gram_partial_f32<3>, grid, block, 0, c->stream, F, k, r, partial); break;
+            case 4: hipLaunchKernelGGL(gram_partial_f32<4>, grid, block, 0, c->stream, F, k, r, partial); break;
+            case 5: hipLaunchKernelGGL(gram_partial_f32<5>, grid, block, 0, c->stream, F, k, r, partial); break;
+            case 6: hipLaunchKernelGGL(gram_partial_f32<6>, grid, block, 0, c->stream, F, k, r, partial); break;
+            case 7: hipLaunchKernelGGL(gram_partial_f32<7>, grid, block, 0, c->stream, F, k, r, partial); break;
+            default: hipLaunchKernelGGL(gram_partial_f32<8>, grid, block, 0, c->stream, F, k, r, partial); break;
+        }
+    } else {
+        const int tt = KP / 16;
+        dim3 grid((unsigned)nblk, tt), block(256);
+#define GRAM64_CASE(N) case N: hipLaunchKernelGGL(gram_partial_f64<N>, grid, block, 0, c->stream, F, k, r, partial); break;
+        switch (tt) {
+            GRAM64_CASE(1) GRAM64_CASE(2) GRAM64_CASE(3) GRAM64_CASE(4) GRAM64_CASE(5) GRAM64_CASE(6)
+            GRAM64_CASE(7) GRAM64_CASE(8) GRAM64_CASE(9) GRAM64_CASE(10) GRAM64_CASE(11) GRAM64_CASE(12)
+            GRAM64_CASE(13) GRAM64_CASE(14) GRAM64_CASE(15)
+            default: hipLaunchKernelGGL(gram_partial_f64<16>, grid, block, 0, c->stream, F, k, r, partial); break;
+        }
+#undef GRAM64_CASE
+    }
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(gram_finalize<T>, dim3((KP * KP + 255) / 256), dim3(256), 0, c->stream, partial,
+                       (int)nblk, KP, k, eps, l2, G);
+    HIPCHK(hipGetLastError());
+}
+extern "C" int rcppml_hip_gram(rcppml_hip_ctx* c, int dtype, const void* F, int k, int64_t r, double eps,
+                               double l2, void* G) {
+    try {
+        HIPCHK(hipSetDevice(c->device));
+        if (dtype == RCPPML_F32) gram_impl<float>(c, (const float*)F, k, r, (float)eps, (float)l2, (float*)G);
+        else gram_impl<double>(c, (const double*)F, k, r, eps, l2, (double*)G);
+        return 0;
+    }
+    RCPPML_CATCH_RET
+}
+

@@ -1,0 +1,169 @@
+// ops_misc.hip -- scaling, loss reductions, explicit-mask solve (device-level C ABI)
+#include "common.hip.h"
+#include "kernels.hip.h"
+
+using namespace rk;
+// ----------------------------------------------------------------------------
+// Scaling
+// ----------------------------------------------------------------------------
+template <class T>
+static void row_norms_impl(rcppml_hip_ctx* c, const T* X, int k, int64_t ncols, int norm_type, T* out) {
+    int64_t nblk = (ncols + 255) / 256;
+    if (nblk > 2 * (int64_t)c->num_cu) nblk = 2 * c->num_cu;
+    if (nblk < 1) nblk = 1;
+    T* partial = static_cast<T*>(c->scratch(WS_RED, (size_t)nblk * k * sizeof(T)));
+    hipLaunchKernelGGL(row_norm_partial<T>, dim3((unsigned)nblk), dim3(256), 256 * sizeof(T), c->stream, X, k, ncols,
+                       norm_type, partial);
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(row_norm_final<T>, dim3((k + 63) / 64), dim3(64), 0, c->stream, partial, (int)nblk, k, out);
+    HIPCHK(hipGetLastError());
+}
+extern "C" int rcppml_hip_row_norms(rcppml_hip_ctx* c, int dtype, const void* X, int k, int64_t ncols,
+                                    int norm_type, void* out) {
+    try {
+        HIPCHK(hipSetDevice(c->device));
+        if (dtype == RCPPML_F32) row_norms_impl<float>(c, (const float*)X, k, ncols, norm_type, (float*)out);
+        else row_norms_impl<double>(c, (const double*)X, k, ncols, norm_type, (double*)out);
+        return 0;
+    }
+    RCPPML_CATCH_RET
+}
+template <class T>
+static void apply_scaling_impl(rcppml_hip_ctx* c, T* X, int k, int64_t ncols, int norm_type, const T* sums, T* d) {
+    hipLaunchKernelGGL(scaling_finalize<T>, dim3((k + 63) / 64), dim3(64), 0, c->stream, sums, k, norm_type, d);
+    HIPCHK(hipGetLastError());
+    if (norm_type == 2) return;
+    const int64_t total = (int64_t)k * ncols;
+    int64_t nblk = (total + 255) / 256;
+    if (nblk > 8 * (int64_t)c->num_cu) nblk = 8 * c->num_cu;
+    if (nblk < 1) nblk = 1;
+    hipLaunchKernelGGL(scale_rows<T>, dim3((unsigned)nblk), dim3(256), 0, c->stream, X, k, total, d);
+    HIPCHK(hipGetLastError());
+}
+extern "C" int rcppml_hip_apply_scaling(rcppml_hip_ctx* c, int dtype, void* X, int k, int64_t ncols, int norm_type,
+                                        const void* sums, void* d) {
+    try {
+        HIPCHK(hipSetDevice(c->device));
+        if (dtype == RCPPML_F32) apply_scaling_impl<float>(c, (float*)X, k, ncols, norm_type, (const float*)sums, (float*)d);
+        else apply_scaling_impl<double>(c, (double*)X, k, ncols, norm_type, (const double*)sums, (double*)d);
+        return 0;
+    }
+    RCPPML_CATCH_RET
+}
+
+// ----------------------------------------------------------------------------
+// Loss pieces
+// ----------------------------------------------------------------------------
+template <class T>
+static void sumsq_impl(rcppml_hip_ctx* c, const T* x, int64_t len, double* out) {
+    int64_t nblk = (len + 256 * 8 - 1) / (256 * 8);
+    if (nblk > 4 * (int64_t)c->num_cu) nblk = 4 * c->num_cu;
+    if (nblk < 1) nblk = 1;
+    double* partial = static_cast<double*>(c->scratch(WS_RED, (size_t)nblk * sizeof(double)));
+    hipLaunchKernelGGL(sumsq_partial<T>, dim3((unsigned)nblk), dim3(256), 0, c->stream, x, len, partial);
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(sum_partials, dim3(1), dim3(256), 0, c->stream, partial, (int)nblk, out);
+    HIPCHK(hipGetLastError());
+}
+extern "C" int rcppml_hip_sumsq(rcppml_hip_ctx* c, int dtype, const void* x, int64_t len, double* out) {
+    try {
+        HIPCHK(hipSetDevice(c->device));
+        if (dtype == RCPPML_F32) sumsq_impl<float>(c, (const float*)x, len, out);
+        else sumsq_impl<double>(c, (const double*)x, len, out);
+        return 0;
+    }
+    RCPPML_CATCH_RET
+}
+template <class T>
+static void loss_mse_impl(rcppml_hip_ctx* c, const double* trAtA, const T* d, const T* W_T, const T* B_w, int k,
+                          int64_t m, const T* G_wt, const T* G_saved, double* out) {
+    const int64_t total = (int64_t)k * m;
+    int64_t nblk = (total + 256 * 8 - 1) / (256 * 8);
+    if (nblk > 4 * (int64_t)c->num_cu) nblk = 4 * c->num_cu;
+    if (nblk < 1) nblk = 1;
+    double* partial = static_cast<double*>(c->scratch(WS_RED, (size_t)nblk * sizeof(double)));
+    hipLaunchKernelGGL(cross_partial<T>, dim3((unsigned)nblk), dim3(256), 0, c->stream, W_T, B_w, d, k, total, partial);
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(loss_mse_final<T>, dim3(1), dim3(256), 0, c->stream, trAtA, partial, (int)nblk, d, G_wt,
+                       G_saved, k, out);
+    HIPCHK(hipGetLastError());
+}
+extern "C" int rcppml_hip_loss_mse(rcppml_hip_ctx* c, int dtype, const double* trAtA, const void* d, const void* W_T,
+                                   const void* B_w, int k, int64_t m, const void* G_wt, const void* G_saved,
+                                   double* out) {
+    try {
+        HIPCHK(hipSetDevice(c->device));
+        if (dtype == RCPPML_F32)
+            loss_mse_impl<float>(c, trAtA, (const float*)d, (const float*)W_T, (const float*)B_w, k, m, (const float*)G_wt, (const float*)G_saved, out);
+        else
+            loss_mse_impl<double>(c, trAtA, (const double*)d, (const double*)W_T, (const double*)B_w, k, m, (const double*)G_wt, (const double*)G_saved, out);
+        return 0;
+    }
+    RCPPML_CATCH_RET
+}
+
+// ----------------------------------------------------------------------------
+// Explicit mask
+// ----------------------------------------------------------------------------
+template <class T>
+static void solve_masked_impl(rcppml_hip_ctx* c, const int* cp, const int* ri, const T* vals, const int* mp,
+                              const int* mi, int64_t ncols, const T* F, const T* Gfull, T* X, int k, T l1, T l2,
+                              int nonneg, int maxit, T tol, int solver_mode, int warm) {
+    if (ncols <= 0) return;
+    if (k > 64) throw std::runtime_error("solve_masked: k > 64 not supported");
+    const size_t smem = (size_t)4 * 64 * 64 * sizeof(T);
+    auto kern = masked_solve_kernel<T, 64>;
+    static bool attr_set = false;
+    if (!attr_set && smem > 48 * 1024) {
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        attr_set = true;
+    }
+    const int64_t nblk = (ncols + 3) / 4;
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), smem, c->stream, cp, ri, vals, mp, mi, ncols, F, Gfull, X,
+                       k, l1, l2, nonneg, maxit, tol, solver_mode, warm);
+    HIPCHK(hipGetLastError());
+}
+extern "C" int rcppml_hip_solve_masked(rcppml_hip_ctx* c, int dtype, const int* col_ptr, const int* row_idx,
+                                       const void* values, const int* mask_p, const int* mask_i, int64_t ncols,
+                                       const void* F, const void* G_full, void* X, int k, double l1, double l2,
+                                       int nonneg, int cd_maxit, double cd_tol, int solver_mode, int warm) {
+    try {
+        HIPCHK(hipSetDevice(c->device));
+        if (dtype == RCPPML_F32)
+            solve_masked_impl<float>(c, col_ptr, row_idx, (const float*)values, mask_p, mask_i, ncols, (const float*)F,
+                                     (const float*)G_full, (float*)X, k, (float)l1, (float)l2, nonneg, cd_maxit,
+                                     (float)cd_tol, solver_mode, warm);
+        else
+            solve_masked_impl<double>(c, col_ptr, row_idx, (const double*)values, mask_p, mask_i, ncols, (const double*)F,
+                                      (const double*)G_full, (double*)X, k, l1, l2, nonneg, cd_maxit, cd_tol,
+                                      solver_mode, warm);
+        return 0;
+    }
+    RCPPML_CATCH_RET
+}
+template <class T>
+static void loss_nonzeros_impl(rcppml_hip_ctx* c, const int* cp, const int* ri, const T* vals, const int* mp,
+                               const int* mi, int64_t ncols, const T* W_T, const T* d, const T* H, int k, double* out) {
+    const int64_t nblk = ncols > 0 ? (ncols + 3) / 4 : 1;
+    double* partial = static_cast<double*>(c->scratch(WS_RED2, (size_t)nblk * 2 * sizeof(double)));
+    hipLaunchKernelGGL(loss_nonzeros_kernel<T>, dim3((unsigned)nblk), dim3(256), 0, c->stream, cp, ri, vals, mp, mi,
+                       ncols, W_T, d, H, k, partial);
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(sum_partials2, dim3(1), dim3(256), 0, c->stream, partial, (int)nblk, out);
+    HIPCHK(hipGetLastError());
+}
+extern "C" int rcppml_hip_loss_nonzeros(rcppml_hip_ctx* c, int dtype, const int* col_ptr, const int* row_idx,
+                                        const void* values, const int* mask_p, const int* mask_i, int64_t ncols,
+                                        const void* W_T, const void* d, const void* H, int k, double* out) {
+    try {
+        HIPCHK(hipSetDevice(c->device));
+        if (dtype == RCPPML_F32)
+            loss_nonzeros_impl<float>(c, col_ptr, row_idx, (const float*)values, mask_p, mask_i, ncols, (const float*)W_T,
+                                      (const float*)d, (const float*)H, k, out);
+        else
+            loss_nonzeros_impl<double>(c, col_ptr, row_idx, (const double*)values, mask_p, mask_i, ncols,
+                                       (const double*)W_T, (const double*)d, (const double*)H, k, out);
+        return 0;
+    }
+    RCPPML_CATCH_RET
+}

@@ -1,0 +1,479 @@
+// ============================================================================
+// plugin.hip -- the plugin boundary of RcppML_gpu.so (include/rcppml_gpu.h, layer 1):
+// host-pointer entry points bound by the unmodified R package, and the ALS loop that drives the
+// device-level ops.  Replaces reference src/gpu_bridge_nmf.cu:34-210,460-624 and
+// src/gpu_bridge_cluster.cu:24-46 (boundary) and inst/include/FactorNet/nmf/fit_gpu.cuh (loop);
+// the loop follows the CPU semantics of inst/include/FactorNet/nmf/fit_cpu.hpp:444-1855 because
+// CPU nmf() is the parity target.
+// ============================================================================
+#include "common.hip.h"
+
+#include <algorithm>
+#include <cmath>
+#include <numeric>
+
+extern "C" const char* rcppml_gpu_last_error(void) { return rcppml_err().c_str(); }
+
+namespace {
+
+#define OPCHK(expr)                                                                  \
+    do {                                                                             \
+        if ((expr) != 0) throw std::runtime_error(std::string(#expr) + ": " + rcppml_err()); \
+    } while (0)
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    DevBuf() {}
+    explicit DevBuf(size_t b) { alloc(b); }
+    void alloc(size_t b) {
+        release();
+        bytes = b < 16 ? 16 : b;
+        HIPCHK(hipMalloc(&p, bytes));
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+    ~DevBuf() { release(); }
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    template <class U> U* as() const { return static_cast<U*>(p); }
+};
+
+struct CtxGuard {
+    rcppml_hip_ctx* c = nullptr;
+    hipStream_t s = nullptr;
+    explicit CtxGuard(int device) {
+        HIPCHK(hipSetDevice(device));
+        HIPCHK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        if (rcppml_hip_ctx_create(&c, device, s) != 0) {
+            (void)hipStreamDestroy(s);
+            throw std::runtime_error("ctx_create: " + rcppml_err());
+        }
+    }
+    ~CtxGuard() {
+        if (c) rcppml_hip_ctx_destroy(c);
+        if (s) (void)hipStreamDestroy(s);
+    }
+};
+
+int env_device() {
+    const char* e = getenv("RCPPML_GPU_DEVICE");
+    return e ? atoi(e) : 0;
+}
+
+// CSC(A^T) on the host: counting sort, rows stay sorted within each column
+// (reference nmf/fit_cpu.hpp:251-253 At = A.transpose()).
+template <class T>
+void transpose_csc_host(int rows, int cols, const int* p, const int* i, const T* x, std::vector<int>& tp,
+                        std::vector<int>& ti, std::vector<T>* tx) {
+    const int64_t nnz = p[cols];
+    tp.assign((size_t)rows + 1, 0);
+    ti.resize((size_t)nnz);
+    if (tx) tx->resize((size_t)nnz);
+    for (int64_t t = 0; t < nnz; ++t) tp[(size_t)i[t] + 1]++;
+    for (int r = 0; r < rows; ++r) tp[r + 1] += tp[r];
+    std::vector<int> cur(tp.begin(), tp.end() - 1);
+    for (int j = 0; j < cols; ++j)
+        for (int t = p[j]; t < p[j + 1]; ++t) {
+            const int dst = cur[i[t]]++;
+            ti[dst] = j;
+            if (tx) (*tx)[dst] = x[t];
+        }
+}
+
+struct FitParams {
+    int m, n, k;
+    int64_t nnz;
+    const int* col_ptr; const int* row_idx; const double* values;
+    double *W, *H, *d;            // in/out (host, double)
+    int max_iter; double tol;
+    double L1_H, L1_W, L2_H, L2_W, ub_H, ub_W;
+    int cd_maxit; double cd_tol;
+    int verbose, patience, nonneg_W, nonneg_H, norm_type, solver_mode;
+    const int* mask_p; const int* mask_i;   // NULL = no mask
+    int sort_model;
+    double* loss_history;                    // may be NULL
+    // outputs
+    int out_iter = 0, out_converged = 0; double out_loss = 0, out_tol = 0;
+};
+
+template <class T> struct DT;
+template <> struct DT<float> { static constexpr int id = RCPPML_F32; };
+template <> struct DT<double> { static constexpr int id = RCPPML_F64; };
+
+template <class T>
+void upload_cast(const double* src, size_t n, DevBuf& dst, hipStream_t s) {
+    dst.alloc(n * sizeof(T));
+    if constexpr (std::is_same<T, double>::value) {
+        HIPCHK(hipMemcpyAsync(dst.p, src, n * sizeof(T), hipMemcpyHostToDevice, s));
+        HIPCHK(hipStreamSynchronize(s));
+    } else {
+        std::vector<T> tmp(n);
+        for (size_t t = 0; t < n; ++t) tmp[t] = static_cast<T>(src[t]);
+        HIPCHK(hipMemcpyAsync(dst.p, tmp.data(), n * sizeof(T), hipMemcpyHostToDevice, s));
+        HIPCHK(hipStreamSynchronize(s));
+    }
+}
+template <class T>
+void download_cast(const DevBuf& src, size_t n, double* dst, hipStream_t s) {
+    if constexpr (std::is_same<T, double>::value) {
+        HIPCHK(hipMemcpyAsync(dst, src.p, n * sizeof(T), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+    } else {
+        std::vector<T> tmp(n);
+        HIPCHK(hipMemcpyAsync(tmp.data(), src.p, n * sizeof(T), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        for (size_t t = 0; t < n; ++t) dst[t] = static_cast<double>(tmp[t]);
+    }
+}
+void upload_ints(const int* src, size_t n, DevBuf& dst, hipStream_t s) {
+    dst.alloc(n * sizeof(int));
+    HIPCHK(hipMemcpyAsync(dst.p, src, n * sizeof(int), hipMemcpyHostToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));
+}
+
+// ----------------------------------------------------------------------------
+// The ALS loop (MSE; fused-path semantics of fit_cpu.hpp, or the explicit-mask path).
+// ----------------------------------------------------------------------------
+template <class T>
+void fit(FitParams& P) {
+    constexpr int dt = DT<T>::id;
+    const int m = P.m, n = P.n, k = P.k;
+    CtxGuard g(env_device());
+    rcppml_hip_ctx* c = g.c;
+    hipStream_t s = g.s;
+
+    // ---- upload A, build and upload A^T (one-time setup, fit_cpu.hpp:237-254)
+    DevBuf dAp, dAi, dAx, dTp, dTi, dTx;
+    upload_ints(P.col_ptr, (size_t)n + 1, dAp, s);
+    upload_ints(P.row_idx, (size_t)P.nnz, dAi, s);
+    upload_cast<T>(P.values, (size_t)P.nnz, dAx, s);
+    {
+        std::vector<int> tp, ti;
+        std::vector<double> tx;
+        transpose_csc_host<double>(m, n, P.col_ptr, P.row_idx, P.values, tp, ti, &tx);
+        upload_ints(tp.data(), tp.size(), dTp, s);
+        upload_ints(ti.data(), ti.size(), dTi, s);
+        upload_cast<T>(tx.data(), tx.size(), dTx, s);
+    }
+    const bool has_mask = P.mask_p != nullptr;
+    DevBuf dMp, dMi, dMTp, dMTi;
+    if (has_mask) {
+        const int mnnz = P.mask_p[n];
+        upload_ints(P.mask_p, (size_t)n + 1, dMp, s);
+        upload_ints(P.mask_i, (size_t)std::max(mnnz, 1), dMi, s);
+        std::vector<int> tp, ti;
+        transpose_csc_host<double>(m, n, P.mask_p, P.mask_i, nullptr, tp, ti, nullptr);
+        upload_ints(tp.data(), tp.size(), dMTp, s);
+        if (ti.empty()) ti.push_back(0);
+        upload_ints(ti.data(), ti.size(), dMTi, s);
+    }
+
+    // ---- factors
+    DevBuf dW, dH, dd;
+    upload_cast<T>(P.W, (size_t)k * m, dW, s);
+    upload_cast<T>(P.H, (size_t)k * n, dH, s);
+    dd.alloc((size_t)k * sizeof(T));
+    {
+        std::vector<T> ones(k, T(1));                       // fit_cpu.hpp:198 d = 1
+        HIPCHK(hipMemcpyAsync(dd.p, ones.data(), k * sizeof(T), hipMemcpyHostToDevice, s));
+        HIPCHK(hipStreamSynchronize(s));
+    }
+    DevBuf dBh((size_t)k * n * sizeof(T)), dBw((size_t)k * m * sizeof(T));
+    DevBuf dG((size_t)k * k * sizeof(T)), dGs((size_t)k * k * sizeof(T)), dGwt((size_t)k * k * sizeof(T));
+    DevBuf dsums((size_t)k * sizeof(T));
+    DevBuf dtr(sizeof(double)), dloss(4 * sizeof(double));
+    double* hloss = nullptr;
+    HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&hloss), 4 * sizeof(double)));
+    struct HostFree { double* p; ~HostFree() { (void)hipHostFree(p); } } hf{hloss};
+
+    OPCHK(rcppml_hip_sumsq(c, dt, dAx.p, P.nnz, dtr.as<double>()));       // trAtA, primitives.hpp:100-115
+
+    const double eps = 1e-15;
+    double prev_loss = std::numeric_limits<double>::max();
+    if (std::is_same<T, float>::value) prev_loss = std::numeric_limits<float>::max();
+    int patience_counter = 0;
+    int iterations = 0;
+    bool converged = false;
+    double final_tol = 0, train_loss = 0, last_loss = 0;
+
+    for (int iter = 0; iter < P.max_iter; ++iter) {
+        const int warm = iter > 0 ? 1 : 0;
+        // ================= H half-update (fit_cpu.hpp:486-645)
+        if (has_mask) {
+            OPCHK(rcppml_hip_gram(c, dt, dW.p, k, m, eps, 0.0, dG.p));                 // :562 unmodified G
+            OPCHK(rcppml_hip_solve_masked(c, dt, dAp.as<int>(), dAi.as<int>(), dAx.p, dMp.as<int>(), dMi.as<int>(),
+                                          n, dW.p, dG.p, dH.p, k, P.L1_H, P.L2_H, P.nonneg_H, P.cd_maxit, P.cd_tol,
+                                          P.solver_mode, warm));
+            if (P.ub_H > 0) throw std::runtime_error("upper bound with explicit mask: not supported");
+        } else {
+            OPCHK(rcppml_hip_gram(c, dt, dW.p, k, m, eps, P.L2_H, dG.p));              // :491,506
+            OPCHK(rcppml_hip_rhs(c, dt, dAp.as<int>(), dAi.as<int>(), dAx.p, n, dW.p, k, dBh.p));
+            if (P.solver_mode == 0)                                                     // :516-524
+                OPCHK(rcppml_hip_solve_cd(c, dt, dG.p, dBh.p, dH.p, k, n, P.L1_H > 0 ? P.L1_H : 0.0, warm, 0, 0.0, 0.0,
+                                          P.nonneg_H, P.cd_maxit, P.cd_tol, 0.0, P.ub_H, RCPPML_CD_AUTO));
+            else                                                                        // :527-534
+                OPCHK(rcppml_hip_solve_chol(c, dt, dG.p, dBh.p, dH.p, k, n, P.L1_H > 0 ? P.L1_H : 0.0, P.nonneg_H, P.ub_H));
+        }
+        OPCHK(rcppml_hip_row_norms(c, dt, dH.p, k, n, P.norm_type, dsums.p));           // :645 extract_scaling
+        OPCHK(rcppml_hip_apply_scaling(c, dt, dH.p, k, n, P.norm_type, dsums.p, dd.p));
+
+        // ================= W half-update (fit_cpu.hpp:711-893)
+        if (has_mask) {
+            OPCHK(rcppml_hip_gram(c, dt, dH.p, k, n, eps, 0.0, dG.p));
+            OPCHK(rcppml_hip_solve_masked(c, dt, dTp.as<int>(), dTi.as<int>(), dTx.p, dMTp.as<int>(), dMTi.as<int>(),
+                                          m, dH.p, dG.p, dW.p, k, P.L1_W, P.L2_W, P.nonneg_W, P.cd_maxit, P.cd_tol,
+                                          P.solver_mode, warm));
+        } else {
+            OPCHK(rcppml_hip_gram(c, dt, dH.p, k, n, eps, 0.0, dGs.p));                 // :715-722 G_w_saved
+            if (P.L2_W > 0) OPCHK(rcppml_hip_gram(c, dt, dH.p, k, n, eps, P.L2_W, dG.p)); // :738
+            else HIPCHK(hipMemcpyAsync(dG.p, dGs.p, (size_t)k * k * sizeof(T), hipMemcpyDeviceToDevice, s));
+            OPCHK(rcppml_hip_rhs(c, dt, dTp.as<int>(), dTi.as<int>(), dTx.p, m, dH.p, k, dBw.p));
+            if (P.solver_mode == 0)
+                OPCHK(rcppml_hip_solve_cd(c, dt, dG.p, dBw.p, dW.p, k, m, P.L1_W > 0 ? P.L1_W : 0.0, warm, 0, 0.0, 0.0,
+                                          P.nonneg_W, P.cd_maxit, P.cd_tol, 0.0, P.ub_W, RCPPML_CD_AUTO));
+            else
+                OPCHK(rcppml_hip_solve_chol(c, dt, dG.p, dBw.p, dW.p, k, m, P.L1_W > 0 ? P.L1_W : 0.0, P.nonneg_W, P.ub_W));
+        }
+        OPCHK(rcppml_hip_row_norms(c, dt, dW.p, k, m, P.norm_type, dsums.p));           // :893
+        OPCHK(rcppml_hip_apply_scaling(c, dt, dW.p, k, m, P.norm_type, dsums.p, dd.p));
+
+        // ================= loss (fit_cpu.hpp:1684-1753)
+        if (has_mask) {
+            OPCHK(rcppml_hip_loss_nonzeros(c, dt, dAp.as<int>(), dAi.as<int>(), dAx.p, dMp.as<int>(), dMi.as<int>(), n,
+                                           dW.p, dd.p, dH.p, k, dloss.as<double>()));
+        } else {
+            OPCHK(rcppml_hip_gram(c, dt, dW.p, k, m, eps, 0.0, dGwt.p));                // :1734-1735
+            // B_w (raw RHS of the W update) is exactly the h_at of loss_cross_term_sparse_via_At
+            // (fused_nnls.hpp:305-362): the third O(nnz k) pass of the reference is not needed.
+            OPCHK(rcppml_hip_loss_mse(c, dt, dtr.as<double>(), dd.p, dW.p, dBw.p, k, m, dGwt.p, dGs.p, dloss.as<double>()));
+        }
+        HIPCHK(hipMemcpyAsync(hloss, dloss.p, 4 * sizeof(double), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        double loss_val = hloss[0];
+        if (std::is_same<T, float>::value) loss_val = static_cast<double>(static_cast<float>(loss_val));
+        last_loss = loss_val;
+        if (P.loss_history) P.loss_history[iter] = loss_val;
+
+        bool loss_converged = false;
+        double rel = 0;
+        if (iter > 0) {                                                                 // :1769-1775
+            rel = std::fabs(prev_loss - loss_val) / (std::fabs(prev_loss) + 1e-15);
+            final_tol = rel;
+            if (rel < P.tol) loss_converged = true;
+        }
+        prev_loss = loss_val;
+        if (P.verbose) fprintf(stderr, "[rcppml_gpu] iter %d loss %.9g rel %.3g\n", iter + 1, loss_val, rel);
+        if (iter > 0) {                                                                 // :1797-1809
+            if (loss_converged) {
+                if (++patience_counter >= P.patience) {
+                    converged = true; train_loss = prev_loss; iterations = iter + 1;
+                    break;
+                }
+            } else patience_counter = 0;
+        }
+        iterations = iter + 1;
+    }
+    if (!converged) train_loss = last_loss;
+
+    // ---- download, sort by descending d (core/result.hpp:169-188)
+    download_cast<T>(dW, (size_t)k * m, P.W, s);
+    download_cast<T>(dH, (size_t)k * n, P.H, s);
+    download_cast<T>(dd, (size_t)k, P.d, s);
+    if (P.sort_model) {
+        std::vector<int> idx(k);
+        std::iota(idx.begin(), idx.end(), 0);
+        std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return P.d[a] > P.d[b]; });
+        std::vector<double> tmp(k);
+        for (int j = 0; j < m; ++j) { double* w = P.W + (size_t)j * k; for (int i = 0; i < k; ++i) tmp[i] = w[idx[i]]; std::copy(tmp.begin(), tmp.end(), w); }
+        for (int j = 0; j < n; ++j) { double* h = P.H + (size_t)j * k; for (int i = 0; i < k; ++i) tmp[i] = h[idx[i]]; std::copy(tmp.begin(), tmp.end(), h); }
+        for (int i = 0; i < k; ++i) tmp[i] = P.d[idx[i]];
+        std::copy(tmp.begin(), tmp.end(), P.d);
+    }
+    P.out_iter = iterations; P.out_converged = converged ? 1 : 0; P.out_loss = train_loss; P.out_tol = final_tol;
+}
+
+// Shared body of the three NMF entry points
+void nmf_entry(RCPPML_NMF_UNIFIED_ARGS, const int* mask_p, const int* mask_i, double cd_tol, int sort_model,
+               int precision, double* loss_history) {
+    try {
+        rcppml_err().clear();
+        *out_status = -1;
+        *out_theta_len = 0;
+        (void)seed; (void)loss_every; (void)huber_delta; (void)irls_max_iter; (void)irls_tol;
+        (void)graph_W_p; (void)graph_W_i; (void)graph_W_x; (void)graph_W_dim; (void)graph_W_lambda;
+        (void)graph_H_p; (void)graph_H_i; (void)graph_H_x; (void)graph_H_dim; (void)graph_H_lambda;
+        (void)gp_dispersion_mode; (void)gp_theta_init; (void)gp_theta_max; (void)gp_theta_min;
+        (void)nb_size_init; (void)nb_size_max; (void)nb_size_min; (void)gamma_phi_init; (void)gamma_phi_max;
+        (void)gamma_phi_min; (void)tweedie_power; (void)out_theta; (void)guide_H_labels_flat; (void)guide_H_ns;
+        (void)guide_H_lambdas; (void)guide_H_ncs;
+        // Reject what is not implemented so the caller falls back to CPU (SURVEY.md 8b "Semantics")
+        if (*loss_type != 0) throw std::runtime_error("loss_type != MSE not supported by this plugin build");
+        if (*robust_delta > 0) throw std::runtime_error("robust loss not supported");
+        if (*L21_H != 0 || *L21_W != 0) throw std::runtime_error("L21 not supported");
+        if (*ortho_H != 0 || *ortho_W != 0) throw std::runtime_error("angular penalty not supported");
+        if (*graph_W_nnz > 0 || *graph_H_nnz > 0) throw std::runtime_error("graph regularisation not supported");
+        if (*guide_H_count > 0) throw std::runtime_error("classifier guides not supported");
+        if (*projective != 0 || *symmetric != 0) throw std::runtime_error("projective/symmetric NMF not supported");
+        if (*solver_mode != 0 && *solver_mode != 1) throw std::runtime_error("solver_mode must be 0 (CD) or 1 (Cholesky+clip)");
+        if (*k < 1 || *k > 128) throw std::runtime_error("k must be in [1,128]");
+        if (*m < 1 || *n < 1) throw std::runtime_error("empty matrix");
+        if (*norm_type < 0 || *norm_type > 2) throw std::runtime_error("bad norm_type");
+        if (col_ptr[*n] != *nnz) throw std::runtime_error("col_ptr[n] != nnz");
+        FitParams P;
+        P.m = *m; P.n = *n; P.k = *k; P.nnz = *nnz;
+        P.col_ptr = col_ptr; P.row_idx = row_idx; P.values = values;
+        P.W = W; P.H = H; P.d = d;
+        P.max_iter = *max_iter; P.tol = *tol;
+        P.L1_H = *L1_H; P.L1_W = *L1_W; P.L2_H = *L2_H; P.L2_W = *L2_W; P.ub_H = *ub_H; P.ub_W = *ub_W;
+        P.cd_maxit = *cd_maxit > 0 ? *cd_maxit : 10;          // src/RcppFunctions_nmf.cpp:22-95
+        P.cd_tol = cd_tol > 0 ? cd_tol : 1e-8;
+        P.verbose = *verbose; P.patience = *patience; P.nonneg_W = *nonneg_W; P.nonneg_H = *nonneg_H;
+        P.norm_type = *norm_type; P.solver_mode = *solver_mode;
+        P.mask_p = mask_p; P.mask_i = mask_i;
+        P.sort_model = sort_model; P.loss_history = loss_history;
+        if (precision == RCPPML_F64) fit<double>(P); else fit<float>(P);
+        *out_iter = P.out_iter; *out_converged = P.out_converged; *out_loss = P.out_loss; *out_tol = P.out_tol;
+        *out_status = 0;
+    } catch (const std::exception& e) {
+        rcppml_err() = e.what();
+        if (getenv("RCPPML_GPU_VERBOSE")) fprintf(stderr, "[rcppml_gpu] NMF error: %s\n", e.what());
+        *out_status = -1;
+    } catch (...) {
+        rcppml_err() = "unknown error";
+        *out_status = -1;
+    }
+}
+
+#define RCPPML_NMF_UNIFIED_PASS                                                                              \
+    col_ptr, row_idx, values, m, n, nnz, k, W, H, d, max_iter, tol, L1_H, L1_W, L2_H, L2_W, L21_H, L21_W,    \
+        ortho_H, ortho_W, ub_H, ub_W, cd_maxit, verbose, seed, loss_every, patience, nonneg_W, nonneg_H,     \
+        loss_type, huber_delta, irls_max_iter, irls_tol, norm_type, projective, symmetric, solver_mode,      \
+        graph_W_p, graph_W_i, graph_W_x, graph_W_dim, graph_W_nnz, graph_W_lambda, graph_H_p, graph_H_i,     \
+        graph_H_x, graph_H_dim, graph_H_nnz, graph_H_lambda, gp_dispersion_mode, gp_theta_init,              \
+        gp_theta_max, gp_theta_min, nb_size_init, nb_size_max, nb_size_min, gamma_phi_init, gamma_phi_max,   \
+        gamma_phi_min, robust_delta, tweedie_power, out_theta, out_theta_len, guide_H_labels_flat,           \
+        guide_H_ns, guide_H_lambdas, guide_H_ncs, guide_H_count, out_iter, out_converged, out_loss,          \
+        out_status, out_tol
+
+int env_sort() {
+    const char* e = getenv("RCPPML_GPU_SORT");
+    return (e && !strcmp(e, "0")) ? 0 : 1;
+}
+
+}  // namespace
+
+// ----------------------------------------------------------------------------
+// exported entry points
+// ----------------------------------------------------------------------------
+extern "C" void rcppml_gpu_detect(int* num_gpus, double* total_mem_mb, double* free_mem_mb, int* max_gpus,
+                                  int* out_status) {
+    *num_gpus = 0;
+    *out_status = 0;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { (void)hipGetLastError(); return; }
+    const int cap = (max_gpus && *max_gpus > 0) ? *max_gpus : 8;
+    int cnt = 0;
+    for (int dv = 0; dv < ndev && cnt < cap; ++dv) {
+        size_t fr = 0, tot = 0;
+        if (hipSetDevice(dv) != hipSuccess) continue;
+        if (hipMemGetInfo(&fr, &tot) != hipSuccess) continue;
+        total_mem_mb[cnt] = static_cast<double>(tot) / (1024.0 * 1024.0);
+        free_mem_mb[cnt] = static_cast<double>(fr) / (1024.0 * 1024.0);
+        ++cnt;
+    }
+    *num_gpus = cnt;
+}
+
+extern "C" void rcppml_gpu_nmf_unified_float(RCPPML_NMF_UNIFIED_ARGS) {
+    const char* e = getenv("RCPPML_GPU_PRECISION");
+    const int prec = (e && !strcmp(e, "fp64")) ? RCPPML_F64 : RCPPML_F32;
+    nmf_entry(RCPPML_NMF_UNIFIED_PASS, nullptr, nullptr, 1e-8, env_sort(), prec, nullptr);
+}
+extern "C" void rcppml_gpu_nmf_unified_double(RCPPML_NMF_UNIFIED_ARGS) {
+    const char* e = getenv("RCPPML_GPU_PRECISION");
+    const int prec = (e && !strcmp(e, "fp32")) ? RCPPML_F32 : RCPPML_F64;
+    nmf_entry(RCPPML_NMF_UNIFIED_PASS, nullptr, nullptr, 1e-8, env_sort(), prec, nullptr);
+}
+extern "C" void rcppml_gpu_nmf_ex(RCPPML_NMF_UNIFIED_ARGS, const int* mask_p, const int* mask_i, int* mask_nnz,
+                                  double* cd_tol, int* sort_model, int* precision, double* loss_history) {
+    const bool use_mask = mask_p && mask_nnz && *mask_nnz > 0;
+    nmf_entry(RCPPML_NMF_UNIFIED_PASS, use_mask ? mask_p : nullptr, use_mask ? mask_i : nullptr, *cd_tol, *sort_model,
+              *precision, loss_history);
+}
+
+// nnls()/predict() projection in fp64 (src/RcppFunctions_utils.cpp:313-366)
+extern "C" void rcppml_gpu_nnls_double(const int* col_ptr, const int* row_idx, const double* values, int* m, int* n,
+                                       int* nnz, int* k, const double* w_T, double* h, int* cd_maxit, double* cd_tol,
+                                       double* L1, double* L2, double* ub, int* nonneg, int* warm, int* out_status) {
+    try {
+        rcppml_err().clear();
+        *out_status = -1;
+        if (*k < 1 || *k > 128) throw std::runtime_error("k must be in [1,128]");
+        CtxGuard g(env_device());
+        hipStream_t s = g.s;
+        DevBuf dAp, dAi, dAx, dW, dH;
+        upload_ints(col_ptr, (size_t)*n + 1, dAp, s);
+        upload_ints(row_idx, (size_t)std::max(*nnz, 1), dAi, s);
+        upload_cast<double>(values, (size_t)std::max(*nnz, 1), dAx, s);
+        upload_cast<double>(w_T, (size_t)*k * *m, dW, s);
+        upload_cast<double>(h, (size_t)*k * *n, dH, s);
+        DevBuf dG((size_t)*k * *k * 8), dB((size_t)*k * *n * 8);
+        // gram adds eps; c_nnls adds eps a second time (:327), then L2
+        OPCHK(rcppml_hip_gram(g.c, RCPPML_F64, dW.p, *k, *m, 2e-15, *L2 > 0 ? *L2 : 0.0, dG.p));
+        OPCHK(rcppml_hip_rhs(g.c, RCPPML_F64, dAp.as<int>(), dAi.as<int>(), dAx.p, *n, dW.p, *k, dB.p));
+        // warm: B -= G h, CD with default cd_tol = 0 (:349-356); cold: X = 0, CD(cd_tol)
+        OPCHK(rcppml_hip_solve_cd(g.c, RCPPML_F64, dG.p, dB.p, dH.p, *k, *n, 0.0, *warm ? 1 : 0, *warm ? 0 : 1, *L1, 0.0,
+                                  *nonneg, *cd_maxit, *warm ? 0.0 : *cd_tol, *ub, 0.0, RCPPML_CD_AUTO));
+        download_cast<double>(dH, (size_t)*k * *n, h, s);
+        *out_status = 0;
+    } catch (const std::exception& e) {
+        rcppml_err() = e.what();
+        *out_status = -1;
+    } catch (...) { rcppml_err() = "unknown error"; *out_status = -1; }
+}
+
+// evaluate() in fp64 without densifying W H (src/RcppFunctions_utils.cpp:95-163 semantics: MEAN)
+extern "C" void rcppml_gpu_evaluate_mse_double(const int* col_ptr, const int* row_idx, const double* values, int* m,
+                                               int* n, int* nnz, int* k, const double* W_T, const double* d,
+                                               const double* H, int* mask_zeros, double* out_loss, int* out_status) {
+    try {
+        rcppml_err().clear();
+        *out_status = -1;
+        CtxGuard g(env_device());
+        hipStream_t s = g.s;
+        DevBuf dAp, dAi, dAx, dW, dH, dd;
+        upload_ints(col_ptr, (size_t)*n + 1, dAp, s);
+        upload_ints(row_idx, (size_t)std::max(*nnz, 1), dAi, s);
+        upload_cast<double>(values, (size_t)std::max(*nnz, 1), dAx, s);
+        upload_cast<double>(W_T, (size_t)*k * *m, dW, s);
+        upload_cast<double>(H, (size_t)*k * *n, dH, s);
+        upload_cast<double>(d, (size_t)*k, dd, s);
+        DevBuf dout(4 * sizeof(double));
+        OPCHK(rcppml_hip_loss_nonzeros(g.c, RCPPML_F64, dAp.as<int>(), dAi.as<int>(), dAx.p, nullptr, nullptr, *n, dW.p,
+                                       dd.p, dH.p, *k, dout.as<double>()));
+        double nz[2];
+        HIPCHK(hipMemcpyAsync(nz, dout.p, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        if (*mask_zeros) {
+            *out_loss = *nnz > 0 ? nz[0] / static_cast<double>(*nnz) : 0.0;
+        } else {
+            // sum_all (a-p)^2 = sum_nz[(a-p)^2 - p^2] + sum_all p^2,  sum_all p^2 = <G_Wd, G_H> (Gram trick)
+            DevBuf dGw((size_t)*k * *k * 8), dGh((size_t)*k * *k * 8);
+            OPCHK(rcppml_hip_gram(g.c, RCPPML_F64, dW.p, *k, *m, 0.0, 0.0, dGw.p));
+            OPCHK(rcppml_hip_gram(g.c, RCPPML_F64, dH.p, *k, *n, 0.0, 0.0, dGh.p));
+            std::vector<double> gw((size_t)*k * *k), gh((size_t)*k * *k);
+            HIPCHK(hipMemcpyAsync(gw.data(), dGw.p, gw.size() * 8, hipMemcpyDeviceToHost, s));
+            HIPCHK(hipMemcpyAsync(gh.data(), dGh.p, gh.size() * 8, hipMemcpyDeviceToHost, s));
+            HIPCHK(hipStreamSynchronize(s));
+            double allp2 = 0;
+            for (int a = 0; a < *k; ++a)
+                for (int b = 0; b < *k; ++b) allp2 += d[a] * d[b] * gw[(size_t)b * *k + a] * gh[(size_t)b * *k + a];
+            const double total = (nz[0] - nz[1]) + allp2;
+            *out_loss = total / (static_cast<double>(*m) * static_cast<double>(*n));
+        }
+        *out_status = 0;
+    } catch (const std::exception& e) {
+        rcppml_err() = e.what();
+        *out_status = -1;
+    } catch (...) { rcppml_err() = "unknown error"; *out_status = -1; }
+}

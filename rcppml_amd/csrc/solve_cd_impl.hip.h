@@ -1,0 +1,74 @@
+// solve_cd_impl.hip.h -- CD solve launch logic (instantiated per dtype in ops_cd_f32.hip / ops_cd_f64.hip)
+#pragma once
+#include "solve_common.hip.h"
+// ----------------------------------------------------------------------------
+// CD solve
+// ----------------------------------------------------------------------------
+template <class T, int KP>
+static void cd_lane_launch(rcppml_hip_ctx* c, const T* Gp, const T* invd, const T* B, T* X, int k,
+                           int64_t ncols, T l1_pre, int warm, int zero_init, T l1_cd, T l2_cd, int nonneg,
+                           int maxit, T tol, T ub_cd, T ub_post) {
+    constexpr bool EXACT = std::is_same<T, double>::value;
+    const int64_t nblk = (ncols + 63) / 64;
+    hipLaunchKernelGGL((cd_lane_kernel<T, KP, EXACT>), dim3((unsigned)nblk), dim3(64), 0, c->stream, Gp, invd,
+                       B, X, k, ncols, l1_pre, warm, zero_init, l1_cd, l2_cd, nonneg, maxit, tol, ub_cd, ub_post);
+    HIPCHK(hipGetLastError());
+}
+template <class T, int KP>
+static void cd_wave_launch(rcppml_hip_ctx* c, const T* Gp, const T* invd, const T* B, T* X, int k,
+                           int64_t ncols, T l1_pre, int warm, int zero_init, T l1_cd, T l2_cd, int nonneg,
+                           int maxit, T tol, T ub_cd, T ub_post) {
+    constexpr bool EXACT = std::is_same<T, double>::value;
+    const size_t smem = (size_t)KP * KP * sizeof(T);
+    auto kern = cd_wave_kernel<T, KP, EXACT>;
+    static bool attr_set = false;
+    if (!attr_set && smem > 48 * 1024) {
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        attr_set = true;
+    }
+    // persistent blocks: as many 256-thread blocks per CU as LDS allows (<= 8), capped by the work
+    int per_cu = (int)((160 * 1024) / (smem + 256));
+    if (per_cu > 8) per_cu = 8;
+    if (per_cu < 1) per_cu = 1;
+    int64_t nblk = (int64_t)c->num_cu * per_cu;
+    const int64_t need = (ncols + 3) / 4;
+    if (nblk > need) nblk = need;
+    if (nblk < 1) nblk = 1;
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), smem, c->stream, Gp, invd, B, X, k, ncols, l1_pre,
+                       warm, zero_init, l1_cd, l2_cd, nonneg, maxit, tol, ub_cd, ub_post);
+    HIPCHK(hipGetLastError());
+}
+
+template <class T>
+static void solve_cd_impl(rcppml_hip_ctx* c, const T* G, const T* B, T* X, int k, int64_t ncols, T l1_pre,
+                          int warm, int zero_init, T l1_cd, T l2_cd, int nonneg, int maxit, T tol, T ub_cd,
+                          T ub_post, int variant) {
+    if (ncols <= 0) return;
+    if (k < 1 || k > 128) throw std::runtime_error("solve_cd: k must be in [1,128]");
+    int KP = solve_kp(k);
+    // lane variant holds b and x (2*KP values) in registers: fp32 up to KP=64, fp64 up to KP=32
+    const int lane_max = std::is_same<T, float>::value ? 64 : 32;
+    if (variant == RCPPML_CD_AUTO) {
+        const char* e = getenv("RCPPML_GPU_CD_VARIANT");
+        if (e && !strcmp(e, "lane")) variant = RCPPML_CD_LANE;
+        else if (e && !strcmp(e, "wave")) variant = RCPPML_CD_WAVE;
+        else variant = (KP <= lane_max) ? RCPPML_CD_LANE : RCPPML_CD_WAVE;
+    }
+    if (variant == RCPPML_CD_LANE && KP > 64) variant = RCPPML_CD_WAVE;
+    if (variant == RCPPML_CD_WAVE && KP < 64) KP = 64;   // the wave variant pads to a full 64-lane slab
+    T *Gp, *invd;
+    pad_impl<T>(c, G, k, KP, &Gp, &invd);
+#define CD_ARGS c, Gp, invd, B, X, k, ncols, l1_pre, warm, zero_init, l1_cd, l2_cd, nonneg, maxit, tol, ub_cd, ub_post
+    if (variant == RCPPML_CD_LANE) {
+        switch (KP) {
+            case 16: cd_lane_launch<T, 16>(CD_ARGS); break;
+            case 32: cd_lane_launch<T, 32>(CD_ARGS); break;
+            case 64: cd_lane_launch<T, 64>(CD_ARGS); break;
+            default: cd_wave_launch<T, 128>(CD_ARGS); break;   // 2*128 residual/iterate registers spill: wave variant
+        }
+    } else {
+        if (KP == 64) cd_wave_launch<T, 64>(CD_ARGS);
+        else cd_wave_launch<T, 128>(CD_ARGS);
+    }
+#undef CD_ARGS
+}

@@ -1,0 +1,263 @@
+"""GPU parity tests, kernel level: each device-level op of include/rcppml_gpu.h (called through the
+C-ABI via rcppml_amd._abi) against the CPU oracle on the same seeded inputs.
+
+Tolerances (stated per test): fp64 differences come only from FMA contraction and summation order
+(the gather splits a column's nonzeros over lane groups; reductions are tree-shaped) -> <= 1e-11
+relative; fp32 the same effects at fp32 epsilon -> <= 5e-5 relative.  CD results are compared after
+the same number of sweeps with the same early-exit rule, so they inherit those bounds times a small
+amplification; integer outputs (none here) would be exact.
+"""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests.util import load_fixture, lowrank_csc, random_csc, rel_err
+
+pytestmark = pytest.mark.gpu
+
+TOL = {np.float32: 5e-5, np.float64: 1e-11}
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    from rcppml_amd import _abi
+    ctx = _abi.Context(0)
+    return torch, _abi, ctx
+
+
+def _dt(_abi, dtype):
+    return _abi.F32 if dtype == np.float32 else _abi.F64
+
+
+def _tt(torch, dtype):
+    return torch.float32 if dtype == np.float32 else torch.float64
+
+
+def _dev(torch, a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _csc_dev(torch, A, dtype):
+    return _dev(torch, A.p), _dev(torch, A.i), _dev(torch, A.values(dtype))
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("k,r", [(10, 183), (16, 64), (32, 1000), (64, 5000), (64, 7), (100, 333), (128, 2049)])
+def test_gram(env, dtype, k, r):
+    torch, _abi, ctx = env
+    rng = np.random.default_rng(k * 1000 + r)
+    # asymmetric, sign-varying input catches row/col mapping errors of the MFMA C/D layout
+    F = (rng.standard_normal((r, k)) * (1 + np.arange(k))[None, :]).astype(dtype)
+    G_ref = O.gram(F)
+    dF = _dev(torch, F)
+    dG = torch.empty((k, k), dtype=_tt(torch, dtype), device="cuda")
+    ctx.gram(_dt(_abi, dtype), dF, k, r, 1e-15, 0.0, dG)
+    G = dG.cpu().numpy()
+    assert np.array_equal(G, G.T), "Gram must be bitwise symmetric"
+    assert rel_err(G, G_ref) < TOL[dtype] * 4
+    # eps / L2 on the diagonal
+    ctx.gram(_dt(_abi, dtype), dF, k, r, 1e-15, 0.5, dG)
+    G2 = dG.cpu().numpy()
+    assert rel_err(np.diag(G2) - np.diag(G), 0.5 * np.ones(k)) < 1e-4
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("k", [1, 3, 10, 16, 32, 48, 64, 128])
+def test_rhs(env, dtype, k):
+    torch, _abi, ctx = env
+    A = random_csc(300, 257, 0.08, seed=k)
+    # empty and heavy columns
+    F = np.random.default_rng(k).standard_normal((A.rows, k)).astype(dtype)
+    B_ref = O.rhs(A, F, dtype)
+    dp, di, dx = _csc_dev(torch, A, dtype)
+    dB = torch.full((A.cols, k), 7.0, dtype=_tt(torch, dtype), device="cuda")
+    ctx.rhs(_dt(_abi, dtype), dp, di, dx, A.cols, _dev(torch, F), k, dB)
+    assert rel_err(dB.cpu().numpy(), B_ref) < TOL[dtype]
+
+
+def test_rhs_empty_columns_and_fixture(env):
+    torch, _abi, ctx = env
+    A = load_fixture("movielens")
+    At = A.transpose()          # many short/empty columns
+    k = 32
+    F = np.random.default_rng(0).uniform(size=(At.rows, k))
+    B_ref = O.rhs(At, F, np.float64)
+    dp, di, dx = _csc_dev(torch, At, np.float64)
+    dB = torch.empty((At.cols, k), dtype=torch.float64, device="cuda")
+    ctx.rhs(_abi.F64, dp, di, dx, At.cols, _dev(torch, F), k, dB)
+    assert rel_err(dB.cpu().numpy(), B_ref) < 1e-12
+    empties = np.nonzero(np.diff(At.p) == 0)[0]
+    if len(empties):
+        assert np.all(dB.cpu().numpy()[empties] == 0)
+
+
+def _cd_problem(k, n, dtype, seed):
+    rng = np.random.default_rng(seed)
+    Fm = rng.uniform(size=(4 * k + 5, k))
+    G = (Fm.T @ Fm).astype(dtype)
+    G[np.diag_indices(k)] += dtype(1e-15)
+    B = (rng.standard_normal((n, k)) * 3 + 1).astype(dtype)
+    X0 = rng.uniform(size=(n, k)).astype(dtype)
+    return G, B, X0
+
+
+@pytest.mark.parametrize("variant", ["lane", "wave"])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("k", [2, 10, 16, 32, 64, 100, 128])
+def test_cd_cold(env, dtype, k, variant):
+    """nnls_batch cold start (X = 0), reference nnls_batch.hpp:150-225, incl. early exit on cd_tol."""
+    torch, _abi, ctx = env
+    n = 131
+    G, B, _ = _cd_problem(k, n, dtype, k)
+    X_ref = O.nnls_batch(G, B, maxit=100, tol=1e-8)
+    dX = torch.full((n, k), 5.0, dtype=_tt(torch, dtype), device="cuda")
+    ctx.solve_cd(_dt(_abi, dtype), _dev(torch, G), _dev(torch, B), dX, k, n, zero_init=1, maxit=100, tol=1e-8,
+                 variant=_abi.CD_LANE if variant == "lane" else _abi.CD_WAVE)
+    X = dX.cpu().numpy()
+    assert X.min() >= 0
+    scale = np.abs(X_ref).max()
+    assert np.abs(X - X_ref).max() / scale < (2e-4 if dtype == np.float32 else 1e-9)
+
+
+@pytest.mark.parametrize("variant", ["lane", "wave"])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_cd_variants_options(env, dtype, variant):
+    """L1 before the solve, warm start (b -= G x), the iteration-0 quirk (start from X without correction),
+    L1 inside CD (nnls()/predict() semantics), upper bounds, nonneg=False; fixed sweep count (tol=0)."""
+    torch, _abi, ctx = env
+    k, n = 24, 77
+    G, B, X0 = _cd_problem(k, n, dtype, 99)
+    var = _abi.CD_LANE if variant == "lane" else _abi.CD_WAVE
+    dt = _dt(_abi, dtype)
+    tol = 3e-4 if dtype == np.float32 else 1e-9
+
+    def run(**kw):
+        dX = _dev(torch, X0.copy())
+        ctx.solve_cd(dt, _dev(torch, G), _dev(torch, B), dX, k, n, variant=var, **kw)
+        return dX.cpu().numpy()
+
+    def ref(l1_pre=0.0, warm=False, zero=False, l1_cd=0.0, nonneg=True, maxit=7, tolr=0.0, ub=0.0):
+        out = np.empty_like(X0)
+        for j in range(n):
+            b = B[j].copy()
+            if l1_pre > 0:
+                b -= dtype(l1_pre)
+            x = np.zeros(k, dtype) if zero else X0[j].copy()
+            if warm:
+                b = b - G @ x
+            x, _, _ = O.cd_col(G, b, x, L1=l1_cd, nonneg=nonneg, maxit=maxit, ub=ub, tol=tolr)
+            out[j] = x
+        return out
+
+    s = np.abs(ref(warm=True)).max()
+    assert np.abs(run(warm=1, maxit=7, tol=0.0) - ref(warm=True)).max() / s < tol
+    assert np.abs(run(warm=0, maxit=7, tol=0.0) - ref()).max() / s < tol          # iteration-0 quirk
+    assert np.abs(run(l1_pre=0.7, warm=1, maxit=7, tol=0.0) - ref(l1_pre=0.7, warm=True)).max() / s < tol
+    assert np.abs(run(zero_init=1, l1_cd=0.05, maxit=7, tol=0.0) - ref(zero=True, l1_cd=0.05)).max() / s < tol
+    assert np.abs(run(zero_init=1, nonneg=0, maxit=7, tol=0.0) - ref(zero=True, nonneg=False)).max() / s < tol * 10
+    r_ub = run(zero_init=1, ub_cd=0.05, maxit=7, tol=0.0)
+    assert r_ub.max() <= 0.05 + 1e-7
+    assert np.abs(r_ub - ref(zero=True, ub=0.05)).max() / s < tol
+    r_post = run(zero_init=1, ub_post=0.02, maxit=7, tol=0.0)
+    assert np.abs(r_post - np.minimum(ref(zero=True), dtype(0.02))).max() / s < tol
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_cd_lane_equals_wave(env, dtype):
+    """Both mappings execute the reference's sequential sweep exactly (same fma chain, same order):
+    they must agree to the last bit."""
+    torch, _abi, ctx = env
+    k, n = 32, 200
+    G, B, X0 = _cd_problem(k, n, dtype, 5)
+    outs = []
+    for var in (_abi.CD_LANE, _abi.CD_WAVE):
+        dX = _dev(torch, X0.copy())
+        ctx.solve_cd(_dt(_abi, dtype), _dev(torch, G), _dev(torch, B), dX, k, n, warm=1, maxit=30, tol=1e-8, variant=var)
+        outs.append(dX.cpu().numpy())
+    if dtype == np.float64:
+        assert np.array_equal(outs[0], outs[1])
+    else:  # fp32 lane variant uses packed fma + rcp for the tolerance term: same iterates up to exit sweep
+        assert np.abs(outs[0] - outs[1]).max() < 1e-5 * np.abs(outs[1]).max()
+
+
+def test_cd_known_answer(env):
+    """reference tests/cpp/test_nnls.cpp:65-84: G=[[2,1],[1,2]] (+1e-10 I), b=[3,3] -> x=[1,1] (1e-4)."""
+    torch, _abi, ctx = env
+    G = np.array([[2.0, 1.0], [1.0, 2.0]]) + 1e-10 * np.eye(2)
+    B = np.array([[3.0, 3.0]])
+    for var in (_abi.CD_LANE, _abi.CD_WAVE):
+        dX = torch.zeros((1, 2), dtype=torch.float64, device="cuda")
+        ctx.solve_cd(_abi.F64, _dev(torch, G), _dev(torch, B), dX, 2, 1, zero_init=1, maxit=100, tol=1e-8, variant=var)
+        assert np.allclose(dX.cpu().numpy(), [[1.0, 1.0]], atol=1e-4)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("k", [3, 10, 16, 32, 64])
+def test_chol_clip(env, dtype, k):
+    """fused_rhs_cholesky_sparse solve part (reference fused_nnls.hpp:185-219) vs the oracle LLT restatement."""
+    torch, _abi, ctx = env
+    n = 97
+    G, B, _ = _cd_problem(k, n, dtype, 3 * k)
+    G = G + np.eye(k, dtype=dtype) * dtype(0.5)     # well conditioned
+    X_ref = O.chol_clip_batch(G, B - dtype(0.1))
+    dX = torch.empty((n, k), dtype=_tt(torch, dtype), device="cuda")
+    ctx.solve_chol(_dt(_abi, dtype), _dev(torch, G), _dev(torch, B), dX, k, n, l1_pre=0.1, nonneg=1)
+    X = dX.cpu().numpy()
+    assert X.min() >= 0
+    assert np.abs(X - X_ref).max() / np.abs(X_ref).max() < (5e-4 if dtype == np.float32 else 1e-10)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("norm_type", [0, 1, 2])
+@pytest.mark.parametrize("k,c", [(10, 1183), (64, 3000), (7, 5)])
+def test_scaling(env, dtype, norm_type, k, c):
+    torch, _abi, ctx = env
+    X = np.random.default_rng(c).uniform(size=(c, k)).astype(dtype)
+    X[:, 0] = 0   # dead factor -> d = 1e-15
+    Xr, dr = O.extract_scaling(X, norm_type)
+    dX = _dev(torch, X)
+    sums = torch.empty(k, dtype=_tt(torch, dtype), device="cuda")
+    d = torch.empty(k, dtype=_tt(torch, dtype), device="cuda")
+    ctx.row_norms(_dt(_abi, dtype), dX, k, c, norm_type, sums)
+    ctx.apply_scaling(_dt(_abi, dtype), dX, k, c, norm_type, sums, d)
+    assert rel_err(d.cpu().numpy(), dr) < TOL[dtype]
+    assert rel_err(dX.cpu().numpy(), Xr) < TOL[dtype] * 2
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_loss_mse_terms(env, dtype):
+    """trace_AtA + cross term + recon (reference fit_cpu.hpp:1729-1753) against the oracle's explicit pass."""
+    torch, _abi, ctx = env
+    A = lowrank_csc(150, 220, 6, 0.1, seed=1)
+    At = A.transpose()
+    k = 12
+    rng = np.random.default_rng(2)
+    W_T = rng.uniform(size=(A.rows, k)).astype(dtype)
+    H = rng.uniform(size=(A.cols, k)).astype(dtype)
+    d = rng.uniform(0.5, 2.0, size=k).astype(dtype)
+    cross_ref = O.loss_cross(At, W_T.astype(np.float64), H.astype(np.float64), d.astype(np.float64))
+    Gs = O.gram(H.astype(np.float64))
+    Gw = O.gram(W_T.astype(np.float64))
+    recon_ref = float(np.sum(np.outer(d, d).astype(np.float64) * Gw * Gs))
+    tr_ref = O.trace_AtA(A)
+    dt = _dt(_abi, dtype)
+    tt = _tt(torch, dtype)
+    tp, ti, tx = _csc_dev(torch, At, dtype)
+    dH, dW, dd = _dev(torch, H), _dev(torch, W_T), _dev(torch, d)
+    dBw = torch.empty((A.rows, k), dtype=tt, device="cuda")
+    ctx.rhs(dt, tp, ti, tx, At.cols, dH, k, dBw)
+    dGs = torch.empty((k, k), dtype=tt, device="cuda")
+    dGw = torch.empty((k, k), dtype=tt, device="cuda")
+    ctx.gram(dt, dH, k, A.cols, 1e-15, 0.0, dGs)
+    ctx.gram(dt, dW, k, A.rows, 1e-15, 0.0, dGw)
+    tr = torch.empty(1, dtype=torch.float64, device="cuda")
+    ctx.sumsq(dt, _dev(torch, A.values(dtype)), A.nnz, tr)
+    out = torch.empty(4, dtype=torch.float64, device="cuda")
+    ctx.loss_mse(dt, tr, dd, dW, dBw, k, A.rows, dGw, dGs, out)
+    o = out.cpu().numpy()
+    tol = 2e-5 if dtype == np.float32 else 1e-12
+    assert abs(tr.item() - tr_ref) / tr_ref < tol
+    assert abs(o[1] - cross_ref) / abs(cross_ref) < tol
+    assert abs(o[2] - recon_ref) / abs(recon_ref) < tol
+    assert abs(o[0] - (tr_ref - 2 * cross_ref + recon_ref)) / abs(tr_ref) < tol

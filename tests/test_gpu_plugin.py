@@ -1,0 +1,143 @@
+"""GPU parity tests, plugin level: the 73-pointer entry points of RcppML_gpu.so (exactly the call the
+reference bridge makes, inst/include/FactorNet/gpu/bridge_nmf.hpp:310-342) against the CPU oracle's
+restatement of nmf_fit<CPU> on identical inputs (same CSC, same W_init/H_init, explicit solver).
+
+Tolerances: fp64 entry vs fp64 oracle -- loss relative <= 1e-6 (north star) and in practice ~1e-10;
+factors max-abs <= 1e-6 after L1 normalisation.  fp32 entry vs fp32 oracle -- both sides carry fp32
+rounding in different orders, loss relative <= 2e-4, factors <= 2e-3.
+"""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests.util import load_fixture, lowrank_csc, random_csc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def abi():
+    from rcppml_amd import _abi
+    return _abi
+
+
+def _run_gpu(abi, A, W0, H0, entry, **kw):
+    W = W0.astype(np.float64).copy()
+    H = H0.astype(np.float64).copy()
+    res = abi.nmf_unified(A.p, A.i, A.x, A.rows, A.cols, W.shape[1], W, H, entry=entry, **kw)
+    assert res["status"] == 0, res.get("error")
+    res["W_T"], res["H"] = W, H
+    return res
+
+
+def _compare(res, ref, tol_loss, tol_fac):
+    assert res["iter"] == ref.iter
+    assert abs(res["loss"] - ref.loss) / abs(ref.loss) < tol_loss
+    assert np.abs(res["d"] - ref.d).max() / np.abs(ref.d).max() < tol_fac
+    assert np.abs(res["W_T"] - ref.W_T).max() < tol_fac
+    assert np.abs(res["H"] - ref.H).max() < tol_fac
+
+
+def test_detect(abi):
+    devs = abi.detect()
+    assert len(devs) >= 1 and devs[0][0] > 1000.0 and 0 < devs[0][1] <= devs[0][0]
+
+
+@pytest.mark.parametrize("solver", [1, 0])
+def test_hawaiibirds_fp64(abi, solver):
+    """BASELINE config C1: hawaiibirds k=10 (auto solver on CPU = Cholesky+clip; also CD)."""
+    A = load_fixture("hawaiibirds")
+    W0, H0 = O.init_factors(42, 10, A.rows, A.cols, np.float64)
+    ref = O.nmf_fit(A, W0, H0, np.float64, max_iter=30, tol=1e-4, solver_mode=solver)
+    res = _run_gpu(abi, A, W0, H0, "double", max_iter=30, tol=1e-4, solver_mode=solver)
+    _compare(res, ref, 1e-6, 1e-6)
+    assert res["converged"] == ref.converged
+
+
+def test_hawaiibirds_fp32(abi):
+    A = load_fixture("hawaiibirds")
+    W0, H0 = O.init_factors(42, 10, A.rows, A.cols, np.float32)
+    ref = O.nmf_fit(A, W0, H0, np.float32, max_iter=20, tol=0.0, solver_mode=1)
+    res = _run_gpu(abi, A, W0, H0, "float", max_iter=20, tol=0.0, solver_mode=1)
+    _compare(res, ref, 2e-4, 2e-3)
+
+
+def test_movielens_l1(abi):
+    """BASELINE config C3: movielens k=32, L1=c(0,0.1) -> L1_W=0, L1_H=0.1, CD (mask='zeros' is a fit-time no-op)."""
+    A = load_fixture("movielens")
+    k = 32
+    W0, H0 = O.init_factors(7, k, A.rows, A.cols, np.float64)
+    ref = O.nmf_fit(A, W0, H0, np.float64, max_iter=15, tol=1e-4, L1=(0.0, 0.1), solver_mode=0)
+    res = _run_gpu(abi, A, W0, H0, "double", max_iter=15, tol=1e-4, L1_H=0.1, L1_W=0.0, solver_mode=0)
+    _compare(res, ref, 1e-6, 1e-6)
+    assert (res["H"] == 0).mean() > 0.05     # L1 produces exact zeros
+
+
+@pytest.mark.parametrize("k", [5, 16, 64])
+def test_synthetic_cd_history(abi, k):
+    A = lowrank_csc(400, 700, 8, 0.06, seed=k)
+    W0, H0 = O.init_factors(123, k, A.rows, A.cols, np.float64)
+    ref = O.nmf_fit(A, W0, H0, np.float64, max_iter=12, tol=0.0, L2=(0.01, 0.02), solver_mode=0)
+    res = _run_gpu(abi, A, W0, H0, "ex", max_iter=12, tol=0.0, L2_W=0.01, L2_H=0.02, solver_mode=0, precision=1,
+                   want_history=True)
+    _compare(res, ref, 1e-6, 1e-6)
+    h = res["loss_history"]
+    assert np.abs(h - ref.loss_history).max() / ref.loss_history.max() < 1e-8
+    assert np.all(np.diff(h) <= 1e-4 * h[:-1])          # loss non-increasing (reference test_loss_monotonicity.R)
+    assert res["W_T"].min() >= 0 and res["H"].min() >= 0 and np.all(res["d"] > 0)
+    assert np.allclose(res["H"].sum(axis=0), 1.0, atol=1e-9)    # rows of H sum to 1 under L1 norm
+    assert np.all(np.diff(res["d"]) <= 0)                       # sorted by descending d
+
+
+def test_upper_bound_and_norms(abi):
+    A = lowrank_csc(200, 300, 4, 0.1, seed=3)
+    k = 6
+    W0, H0 = O.init_factors(5, k, A.rows, A.cols, np.float64)
+    for norm_type in (1, 2):
+        ref = O.nmf_fit(A, W0, H0, np.float64, max_iter=8, tol=0.0, norm_type=norm_type, ub=(0.5, 0.4))
+        res = _run_gpu(abi, A, W0, H0, "double", max_iter=8, tol=0.0, norm_type=norm_type, ub_W=0.5, ub_H=0.4)
+        _compare(res, ref, 1e-6, 1e-6)
+
+
+def test_explicit_mask(abi):
+    """Explicit-mask path (reference nmf/masked_nnls.hpp) through the build-defined rcppml_gpu_nmf_ex entry."""
+    A = lowrank_csc(120, 160, 4, 0.15, seed=11)
+    M = random_csc(120, 160, 0.05, seed=12)
+    k = 8
+    W0, H0 = O.init_factors(9, k, A.rows, A.cols, np.float64)
+    for solver in (0, 1):
+        ref = O.nmf_fit(A, W0, H0, np.float64, max_iter=10, tol=0.0, mask=M, solver_mode=solver, L1=(0.01, 0.02), L2=(0.03, 0.0))
+        res = _run_gpu(abi, A, W0, H0, "ex", max_iter=10, tol=0.0, mask=(M.p, M.i), solver_mode=solver, precision=1,
+                       L1_W=0.01, L1_H=0.02, L2_W=0.03, L2_H=0.0)
+        _compare(res, ref, 1e-6, 1e-6)
+
+
+def test_unsupported_features_are_rejected(abi):
+    """The plugin must set out_status=-1 (-> caller's CPU fallback) instead of silently dropping a feature."""
+    A = lowrank_csc(50, 60, 3, 0.2, seed=1)
+    W0, H0 = O.init_factors(1, 4, A.rows, A.cols, np.float64)
+    for kw in (dict(L21_H=0.1), dict(ortho_W=0.1), dict(projective=1), dict(symmetric=1), dict(loss_type=3),
+               dict(graph_W_nnz=5), dict(guide_H_count=1), dict(solver_mode=2)):
+        W, H = W0.copy(), H0.copy()
+        r = abi.nmf_unified(A.p, A.i, A.x, A.rows, A.cols, 4, W, H, entry="double", max_iter=2, **kw)
+        assert r["status"] == -1 and r["error"], kw
+
+
+def test_nnls_predict_evaluate(abi):
+    """fp64 nnls()/predict()/evaluate() entries vs src/RcppFunctions_utils.cpp restatement."""
+    A = lowrank_csc(150, 90, 5, 0.2, seed=21)
+    k = 7
+    w_T = np.random.default_rng(0).uniform(size=(A.rows, k))
+    h_ref = O.c_nnls(w_T, A, L1=0.01, L2=0.02)
+    h = np.zeros((A.cols, k))
+    abi.nnls_double(A.p, A.i, A.x, A.rows, A.cols, k, w_T, h, L1=0.01, L2=0.02)
+    assert np.abs(h - h_ref).max() < 1e-9
+    h_warm_ref = O.c_nnls(w_T, A, h0=h_ref * 0.9, cd_maxit=5)
+    h2 = h_ref * 0.9
+    abi.nnls_double(A.p, A.i, A.x, A.rows, A.cols, k, w_T, h2, cd_maxit=5, warm=1)
+    assert np.abs(h2 - h_warm_ref).max() < 1e-9
+    d = np.random.default_rng(1).uniform(0.5, 2, size=k)
+    for mz in (False, True):
+        ref = O.evaluate_mse(w_T, d, h_ref, A, mask_zeros=mz)
+        got = abi.evaluate_mse_double(A.p, A.i, A.x, A.rows, A.cols, k, w_T, d, h_ref, mask_zeros=mz)
+        assert abs(got - ref) / ref < 1e-10
