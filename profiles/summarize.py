@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""profiles/summarize.py <tag> -- condense gpurun_out/<tag>/ (rocprofv3 csv output of profiles/run_rocprof.sh)
+into profiles/<tag>_kernel_stats.csv (the --stats table, our kernels + top torch kernels), profiles/<tag>_pmc.json and
+profiles/<tag>_summary.md.  FETCH_SIZE / WRITE_SIZE are reported in KiB by rocprofv3; on gfx950 FETCH_SIZE tallies
+128-B requests at 64 B for wide (16 B/lane) coalesced reads, so the read side is DOUBLED as
+/opt/skills/guides/MI355X_MICROARCH.md (section HBM) prescribes; WRITE_SIZE is taken as is (uncalibrated)."""
+import collections
+import csv
+import json
+import os
+import sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(root, "gpurun_out", tag)
+dst = os.path.join(root, "profiles")
+
+stats = list(csv.DictReader(open(os.path.join(src, "trace", "trace_kernel_stats.csv"))))
+keep = [r for r in stats if "rk::" in r["Name"]] + [r for r in stats if "rk::" not in r["Name"]][:8]
+with open(os.path.join(dst, tag + "_kernel_stats.csv"), "w", newline="") as f:
+    w = csv.DictWriter(f, fieldnames=list(stats[0].keys()))
+    w.writeheader()
+    for r in keep:
+        w.writerow(r)
+
+
+def pmc(path, name):
+    acc = collections.defaultdict(list)
+    meta = {}
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] == name and "rk::" in r["Kernel_Name"]:
+            acc[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+            meta[r["Kernel_Name"]] = dict(vgpr=r["VGPR_Count"], agpr=r["Accum_VGPR_Count"], sgpr=r["SGPR_Count"],
+                                          lds=r["LDS_Block_Size"], scratch=r["Scratch_Size"], wg=r["Workgroup_Size"])
+    return acc, meta
+
+
+fetch, meta = pmc(os.path.join(src, "pmc_fetch", "fetch_counter_collection.csv"), "FETCH_SIZE")
+write, _ = pmc(os.path.join(src, "pmc_write", "write_counter_collection.csv"), "WRITE_SIZE")
+out = {}
+for k in sorted(set(fetch) | set(write)):
+    fv, wv = fetch.get(k, [0.0]), write.get(k, [0.0])
+    f_kib, w_kib = sum(fv) / len(fv), sum(wv) / len(wv)
+    out[k] = dict(launches=len(fv), fetch_size_kib_avg=f_kib, write_size_kib_avg=w_kib,
+                  hbm_bytes_per_launch=(2.0 * f_kib + w_kib) * 1024.0, resources=meta.get(k, {}))
+json.dump(out, open(os.path.join(dst, tag + "_pmc.json"), "w"), indent=1)
+
+with open(os.path.join(dst, tag + "_summary.md"), "w") as f:
+    f.write("# rocprofv3 summary `%s`\n\nCommand: `python bench.py --steps 10 --warmup 3 --no-cpu-baseline` "
+            "(profiles/run_rocprof.sh; pass 1 `--kernel-trace --stats`, passes 2/3 `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE`).\n\n" % tag)
+    f.write("| kernel | calls | avg us | total ms | % |\n|---|---|---|---|---|\n")
+    for r in keep:
+        f.write("| `%s` | %s | %.1f | %.2f | %s |\n" % (r["Name"][:90], r["Calls"], float(r["AverageNs"]) / 1e3,
+                                                    float(r["TotalDurationNs"]) / 1e6, r["Percentage"]))
+    f.write("\n| kernel | FETCH_SIZE KiB (avg) | WRITE_SIZE KiB (avg) | HBM bytes/launch (2*F+W) | VGPR | SGPR | LDS |\n|---|---|---|---|---|---|---|\n")
+    for k, v in out.items():
+        r = v["resources"]
+        f.write("| `%s` | %.0f | %.0f | %.3e | %s | %s | %s |\n" % (k[:70], v["fetch_size_kib_avg"], v["write_size_kib_avg"],
+                                                              v["hbm_bytes_per_launch"], r.get("vgpr"), r.get("sgpr"), r.get("lds")))
+print(open(os.path.join(dst, tag + "_summary.md")).read())

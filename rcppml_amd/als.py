@@ -1,0 +1,300 @@
+"""Column-sharded alternating-NNLS loop on device-resident data (one process per GPU).
+
+The loop is the reference's nmf_fit<CPU> (inst/include/FactorNet/nmf/fit_cpu.hpp:444-1855, MSE, no
+mask) restated over the device-level C-ABI ops, with the one exchange step the path has when the
+columns of A (and of H) are sharded over ranks:
+
+    H side  : every rank holds all of W_T; columns of A are independent -> no communication.
+    scaling : row L1 (or squared L2) sums of H are sums over ALL columns      -> all-reduce of k values.
+    W side  : H H^T and H A^T are sums over all columns -> each rank forms its partial k x k Gram and
+              k x m right-hand side from its shard and ONE all-reduce carries [G_p | B_p] (fused buffer);
+              every rank then solves all m columns of W_T redundantly and W_T stays replicated.
+
+For world_size == 1 the same code runs with the collectives skipped, so N = 1 and N > 1 share every
+kernel launch.  The compute backend is an `ops` object; the product backend is `HipOps` (HIP kernels
+through rcppml_amd._abi).  Nothing here falls back to PyTorch or CPU math.
+"""
+from dataclasses import dataclass
+
+import numpy as np
+
+
+@dataclass
+class AlsConfig:
+    k: int
+    max_iter: int = 100
+    tol: float = 1e-4
+    L1_W: float = 0.0
+    L1_H: float = 0.0
+    L2_W: float = 0.0
+    L2_H: float = 0.0
+    ub_W: float = 0.0
+    ub_H: float = 0.0
+    cd_maxit: int = 100
+    cd_tol: float = 1e-8
+    patience: int = 5
+    nonneg_W: bool = True
+    nonneg_H: bool = True
+    norm_type: int = 0          # 0 = L1, 1 = L2, 2 = none
+    solver_mode: int = 0        # 0 = CD, 1 = Cholesky + clip
+    cd_variant: int = 0         # 0 = auto, 1 = lane, 2 = wave
+
+
+class HipOps:
+    """Device-level ops on torch CUDA tensors (allocation/stream plumbing only) via the C-ABI."""
+
+    def __init__(self, device, dtype="f32", record_events=False):
+        import torch
+        from . import _abi
+        if not torch.cuda.is_available():
+            raise _abi.BackendError("HipOps needs a GPU: torch.cuda.is_available() is False and there is no CPU fallback")
+        self.torch = torch
+        self._abi = _abi
+        self.device = torch.device("cuda", device)
+        torch.cuda.set_device(self.device)
+        self.dt = _abi.F32 if dtype == "f32" else _abi.F64
+        self.tdtype = torch.float32 if dtype == "f32" else torch.float64
+        self.ndtype = np.float32 if dtype == "f32" else np.float64
+        self.ctx = _abi.Context(device)
+        self.record = record_events
+        self.events = {}
+
+    # -- plumbing
+    def to_device(self, a, dtype=None):
+        t = self.torch.from_numpy(np.ascontiguousarray(a))
+        if dtype is not None:
+            t = t.to(dtype)
+        return t.to(self.device)
+
+    def empty(self, shape, dtype=None):
+        return self.torch.empty(shape, dtype=dtype or self.tdtype, device=self.device)
+
+    def zeros(self, shape, dtype=None):
+        return self.torch.zeros(shape, dtype=dtype or self.tdtype, device=self.device)
+
+    def upload_csc(self, A):
+        return dict(rows=A.rows, cols=A.cols, nnz=A.nnz, p=self.to_device(A.p), i=self.to_device(A.i),
+                    x=self.to_device(A.x, self.tdtype))
+
+    def _timed(self, name):
+        return _EventScope(self, name) if self.record else _NULL
+
+    def reset_events(self):
+        self.events = {}
+
+    def event_ms(self):
+        """name -> (count, total ms); call after a device synchronize."""
+        return {k: (len(v), float(sum(s.elapsed_time(e) for s, e in v))) for k, v in self.events.items()}
+
+    # -- ops
+    def gram(self, F, eps, l2, out=None, tag="gram"):
+        r, k = F.shape
+        G = out if out is not None else self.empty((k, k))
+        with self._timed(tag):
+            self.ctx.gram(self.dt, F, k, r, eps, l2, G)
+        return G
+
+    def rhs(self, csc, F, out=None, tag="rhs"):
+        k = F.shape[1]
+        B = out if out is not None else self.empty((csc["cols"], k))
+        with self._timed(tag):
+            self.ctx.rhs(self.dt, csc["p"], csc["i"], csc["x"], csc["cols"], F, k, B)
+        return B
+
+    def solve(self, G, B, X, cfg, side, warm, tag="solve"):
+        n, k = X.shape
+        l1 = cfg.L1_H if side == "H" else cfg.L1_W
+        ub = cfg.ub_H if side == "H" else cfg.ub_W
+        nonneg = cfg.nonneg_H if side == "H" else cfg.nonneg_W
+        with self._timed(tag):
+            if cfg.solver_mode == 0:
+                self.ctx.solve_cd(self.dt, G, B, X, k, n, l1_pre=l1 if l1 > 0 else 0.0, warm=int(warm), zero_init=0,
+                                  nonneg=int(nonneg), maxit=cfg.cd_maxit, tol=cfg.cd_tol, ub_post=ub,
+                                  variant=cfg.cd_variant)
+            else:
+                self.ctx.solve_chol(self.dt, G, B, X, k, n, l1_pre=l1 if l1 > 0 else 0.0, nonneg=int(nonneg), ub_post=ub)
+
+    def row_norms(self, X, norm_type, out=None):
+        n, k = X.shape
+        s = out if out is not None else self.empty((k,))
+        with self._timed("scale"):
+            self.ctx.row_norms(self.dt, X, k, n, norm_type, s)
+        return s
+
+    def apply_scaling(self, X, sums, norm_type, d):
+        n, k = X.shape
+        with self._timed("scale"):
+            self.ctx.apply_scaling(self.dt, X, k, n, norm_type, sums, d)
+
+    def sumsq(self, x):
+        out = self.empty((1,), self.torch.float64)
+        self.ctx.sumsq(self.dt, x, x.numel(), out)
+        return out
+
+    def loss_mse(self, trAtA, d, W_T, B_w, G_wt, G_saved, out):
+        m, k = W_T.shape
+        with self._timed("loss"):
+            self.ctx.loss_mse(self.dt, trAtA, d, W_T, B_w, k, m, G_wt, G_saved, out)
+
+    def add_diag(self, G, v):
+        if v != 0:
+            G.diagonal().add_(v)        # k scalars; plumbing-level torch op
+
+    def sync(self):
+        self.torch.cuda.synchronize(self.device)
+
+
+class _Null:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+_NULL = _Null()
+
+
+class _EventScope:
+    def __init__(self, ops, name):
+        self.ops, self.name = ops, name
+
+    def __enter__(self):
+        t = self.ops.torch
+        self.s = t.cuda.Event(enable_timing=True)
+        self.e = t.cuda.Event(enable_timing=True)
+        self.s.record()
+        return self
+
+    def __exit__(self, *a):
+        self.e.record()
+        self.ops.events.setdefault(self.name, []).append((self.s, self.e))
+        return False
+
+
+class Comm:
+    """Collectives of the path.  world_size 1: no-ops."""
+
+    def __init__(self, dist=None):
+        self.dist = dist
+        self.world = dist.get_world_size() if dist is not None else 1
+        self.rank = dist.get_rank() if dist is not None else 0
+
+    def all_reduce_sum(self, t):
+        if self.world > 1:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return t
+
+    def barrier(self):
+        if self.world > 1:
+            self.dist.barrier()
+
+
+class ShardedALS:
+    """State of one rank: its column shard A_loc (m x n_loc), A_loc^T, H_loc (n_loc x k), replicated W_T (m x k)."""
+
+    def __init__(self, ops, comm, A_loc, At_loc, W_T0, H0, cfg):
+        self.ops, self.comm, self.cfg = ops, comm, cfg
+        self.m, self.n_loc, self.k = A_loc.rows, A_loc.cols, cfg.k
+        self.A = ops.upload_csc(A_loc)
+        self.At = ops.upload_csc(At_loc)
+        self.W_T = ops.to_device(W_T0, ops.tdtype)
+        self.H = ops.to_device(H0, ops.tdtype)
+        k, m = self.k, self.m
+        self.d = ops.zeros((k,)) + 1
+        self.Bh = ops.empty((self.n_loc, k))
+        # fused exchange buffer [G_p (k*k) | B_p (m*k)]: one all-reduce per iteration
+        self.xbuf = ops.empty((k * k + m * k,))
+        self.Gp = self.xbuf[:k * k].view(k, k)
+        self.Bw = self.xbuf[k * k:].view(m, k)
+        self.G = ops.empty((k, k))
+        self.G_saved = ops.empty((k, k))
+        self.G_wt = ops.empty((k, k))
+        self.sums = ops.empty((k,))
+        self.loss_out = ops.zeros((4,), ops.torch.float64)
+        tr = ops.sumsq(self.A["x"])
+        self.trAtA = comm.all_reduce_sum(tr)
+        self.iter = 0
+        self.eps = 1e-15
+
+    def step(self):
+        """One ALS iteration (H half-update, W half-update, loss).  Returns the device loss tensor."""
+        ops, cfg, comm = self.ops, self.cfg, self.comm
+        warm = self.iter > 0
+        # ---- H half-update (fit_cpu.hpp:486-645)
+        ops.gram(self.W_T, self.eps, cfg.L2_H, out=self.G, tag="gram")
+        ops.rhs(self.A, self.W_T, out=self.Bh, tag="rhs_H")
+        ops.solve(self.G, self.Bh, self.H, cfg, "H", warm, tag="solve_H")
+        ops.row_norms(self.H, cfg.norm_type, out=self.sums)
+        comm.all_reduce_sum(self.sums)
+        ops.apply_scaling(self.H, self.sums, cfg.norm_type, self.d)
+        # ---- W half-update (fit_cpu.hpp:711-893)
+        if comm.world > 1:
+            ops.gram(self.H, 0.0, 0.0, out=self.Gp, tag="gram")             # partial H_loc H_loc^T, eps after the sum
+            ops.rhs(self.At, self.H, out=self.Bw, tag="rhs_W")
+            comm.all_reduce_sum(self.xbuf)
+            ops.add_diag(self.Gp, self.eps)
+        else:
+            ops.gram(self.H, self.eps, 0.0, out=self.Gp, tag="gram")
+            ops.rhs(self.At, self.H, out=self.Bw, tag="rhs_W")
+        self.G_saved.copy_(self.Gp)                                          # :719-722 (before L2)
+        self.G.copy_(self.Gp)
+        ops.add_diag(self.G, cfg.L2_W)                                       # :738
+        ops.solve(self.G, self.Bw, self.W_T, cfg, "W", warm, tag="solve_W")
+        ops.row_norms(self.W_T, cfg.norm_type, out=self.sums)
+        ops.apply_scaling(self.W_T, self.sums, cfg.norm_type, self.d)
+        # ---- loss (fit_cpu.hpp:1729-1753): B_w is the h_at of the reference's third sparse pass
+        ops.gram(self.W_T, self.eps, 0.0, out=self.G_wt, tag="gram")
+        ops.loss_mse(self.trAtA, self.d, self.W_T, self.Bw, self.G_wt, self.G_saved, self.loss_out)
+        self.iter += 1
+        return self.loss_out
+
+    def fit(self):
+        """Full fit with the reference's convergence rule (fit_cpu.hpp:1769-1809).  Returns a dict."""
+        cfg = self.cfg
+        prev = float(np.finfo(self.ops.ndtype).max)
+        patience_counter, converged, final_tol, history = 0, False, 0.0, []
+        iterations = 0
+        for it in range(cfg.max_iter):
+            loss = float(self.step()[0].item())
+            if self.ops.ndtype == np.float32:
+                loss = float(np.float32(loss))
+            history.append(loss)
+            hit = False
+            if it > 0:
+                rel = abs(prev - loss) / (abs(prev) + 1e-15)
+                final_tol = rel
+                hit = rel < cfg.tol
+            prev = loss
+            if it > 0:
+                if hit:
+                    patience_counter += 1
+                    if patience_counter >= cfg.patience:
+                        converged = True
+                        iterations = it + 1
+                        break
+                else:
+                    patience_counter = 0
+            iterations = it + 1
+        return dict(iter=iterations, converged=converged, loss=prev, tol=final_tol, loss_history=history)
+
+    def factors(self):
+        """(W_T (m,k), d (k), H_loc (n_loc,k)) as float64 numpy, unsorted."""
+        c = lambda t: t.detach().cpu().numpy().astype(np.float64)
+        return c(self.W_T), c(self.d), c(self.H)
+
+
+def partition_columns_by_nnz(p, world):
+    """Contiguous column blocks balanced by nnz (prefix sum over col_ptr; SURVEY.md 8e 'Partitioning').
+    Returns world+1 column boundaries."""
+    p = np.asarray(p, dtype=np.int64)
+    n = p.shape[0] - 1
+    nnz = p[-1]
+    bounds = [0]
+    for r in range(1, world):
+        target = nnz * r // world
+        c = int(np.searchsorted(p, target, side="left"))
+        c = max(bounds[-1], min(c, n))
+        bounds.append(c)
+    bounds.append(n)
+    return bounds
