@@ -198,3 +198,31 @@ def simulate_nb_counts(nrow, ncol, k, density=0.02, size=5.0, seed=123, scale=No
     p = np.zeros(ncol + 1, np.int64)
     np.cumsum(np.bincount(cols, minlength=ncol), out=p[1:])
     return CSC((nrow, ncol), p, rows, y), w, h
+
+
+# --------------------------------------------------------------------------------------------
+# R's default RNG (Mersenne-Twister, inversion) -- `set.seed(seed); runif(n)`.
+# nmf(seed = <int>) draws W_init this way (reference R/nmf_thin.R:790-797).  R itself is not part of
+# the reference tree and cannot run here, so this restates R's public algorithm (src/main/RNG.c:
+# 50 + 625 steps of the LCG 69069*s+1, MT19937, scaling by 2.3283064365386963e-10, fixup into (0,1));
+# pinned in tests/ against widely published values (set.seed(42); runif(3) = 0.9148060 0.9370754 0.2861395).
+# --------------------------------------------------------------------------------------------
+def r_runif(seed, n):
+    s = np.uint32(int(seed) & 0xFFFFFFFF)
+    with np.errstate(over="ignore"):
+        for _ in range(50):
+            s = np.uint32(69069) * s + np.uint32(1)
+        key = np.empty(625, np.uint32)
+        for j in range(625):
+            s = np.uint32(69069) * s + np.uint32(1)
+            key[j] = s
+    bg = np.random.MT19937()
+    st = bg.state
+    st["state"]["key"] = key[1:].copy()     # i_seed[0] is the `mti` slot, forced to 624 by FixupSeeds
+    st["state"]["pos"] = 624
+    bg.state = st
+    u = bg.random_raw(int(n)).astype(np.float64) * 2.3283064365386963e-10
+    lo = 2.328306437080797e-10
+    u = np.where(u <= 0.0, 0.5 * lo, u)
+    u = np.where(1.0 - u <= 0.0, 1.0 - 0.5 * lo, u)
+    return u

@@ -1,0 +1,193 @@
+"""Host-side mirror of the reference's R surface for the ALS-NNLS path: nmf(), nnls(), predict(), evaluate().
+
+Same argument names, meaning, defaults and error behaviour as the R functions (R/nmf_thin.R:219-229,
+R/solve.R:84, R/predict_nmf.R:48, R/nmf_methods.R:356), restricted to what the MI355X plugin implements
+(MSE loss, CD or Cholesky+clip, L1/L2/upper bounds, non-negativity flags, explicit mask, L1/L2/no normalisation).
+All compute goes through RcppML_gpu.so (rcppml_amd._abi); anything else raises -- there is no CPU path here.
+"""
+import numpy as np
+
+from . import _abi
+from .data import CSC, r_runif, splitmix64_uniform
+
+_LOSSES = ("mse", "gp", "nb", "gamma", "inverse_gaussian", "tweedie")
+
+
+class NMFModel:
+    """S4 class `nmf` of the reference (R/nmf_methods.R:18-30): w (m x k), d (k), h (k x n), misc."""
+
+    def __init__(self, w, d, h, misc):
+        self.w, self.d, self.h, self.misc = w, d, h, misc
+
+    def __repr__(self):
+        return "<nmf model: %d x %d, k=%d, iter=%s, loss=%.6g>" % (self.w.shape[0], self.h.shape[1], self.d.shape[0],
+                                                                   self.misc.get("iter"), self.misc.get("loss", float("nan")))
+
+
+def _as_csc(data):
+    if isinstance(data, CSC):
+        return data
+    if hasattr(data, "tocsc"):
+        return CSC.from_scipy(data)
+    a = np.asarray(data, dtype=np.float64)
+    if a.ndim != 2:
+        raise ValueError("data must be a matrix")
+    import scipy.sparse as sp
+    return CSC.from_scipy(sp.csc_matrix(a))
+
+
+def _pair(v, name):
+    v = np.atleast_1d(np.asarray(v, dtype=np.float64))
+    if v.shape[0] == 1:
+        v = np.repeat(v, 2)
+    if v.shape[0] != 2:
+        raise ValueError("'%s' must be a vector of length 1 or 2: c(w, h)" % name)
+    return float(v[0]), float(v[1])
+
+
+def gpu_available():
+    """R/gpu_backend.R:68-125."""
+    try:
+        return len(_abi.detect()) > 0
+    except _abi.BackendError:
+        return False
+
+
+def select_solver(solver, k, L1, loss="mse", use_gpu=True):
+    """Auto solver rule of R/nmf_thin.R:363-388."""
+    if solver != "auto":
+        if solver not in ("cd", "cholesky"):
+            raise ValueError("solver must be 'auto', 'cd' or 'cholesky'")
+        return solver
+    if loss != "mse":
+        return "cd"
+    if use_gpu:
+        return "cd" if k <= 32 else "cholesky"
+    return "cholesky" if (k < 32 and all(v == 0 for v in L1)) else "cd"
+
+
+def nmf(data, k, tol=1e-4, maxit=100, L1=(0.0, 0.0), L2=(0.0, 0.0), seed=None, mask=None, loss="mse",
+        nonneg=(True, True), test_fraction=0, verbose=False, projective=False, symmetric=False, zi="none",
+        robust=False, *, solver="auto", upper_bound=(0.0, 0.0), cd_maxit=100, cd_tol=1e-8, norm="L1", sort_model=True,
+        patience=5, h_init=None, precision="fp32", resource="gpu"):
+    """Non-negative matrix factorisation A ~ w diag(d) h by alternating NNLS on the MI355X.
+
+    `L1`, `L2`, `upper_bound`, `nonneg` are c(w, h) pairs (src/RcppFunctions_nmf.cpp:59-62).
+    `seed`: None / int -> W_init = matrix(runif(m*k), m, k) after set.seed(seed) (R/nmf_thin.R:790-797) and
+    H from SplitMix64(seed) (nmf/fit_cpu.hpp:200-207); or an m x k (or k x m) matrix used as W_init.
+    `precision`: "fp32" is what the reference computes in (F1); "fp64" is the parity mode.
+    """
+    if loss not in _LOSSES:
+        raise ValueError("'arg' should be one of %s" % ", ".join(repr(x) for x in _LOSSES))
+    if loss != "mse" or robust or zi != "none":
+        raise NotImplementedError("only loss='mse' (no robust / zero-inflation) is implemented by the MI355X backend")
+    if projective or symmetric:
+        raise NotImplementedError("projective / symmetric NMF are not implemented by the MI355X backend")
+    if test_fraction and test_fraction > 0:
+        raise NotImplementedError("cross-validation (test_fraction > 0) is not implemented by the MI355X backend")
+    if resource != "gpu":
+        raise ValueError("rcppml_amd has no CPU path; resource must be 'gpu'")
+    A = _as_csc(data)
+    m, n = A.shape
+    k = int(k)
+    if k < 1:
+        raise ValueError("k must be a positive integer")
+    L1w, L1h = _pair(L1, "L1")
+    L2w, L2h = _pair(L2, "L2")
+    ubw, ubh = _pair(upper_bound, "upper_bound")
+    if min(L1w, L1h, L2w, L2h) < 0:
+        raise ValueError("L1 and L2 penalties must be non-negative")
+    nn = np.atleast_1d(nonneg)
+    nnw, nnh = (bool(nn[0]), bool(nn[-1]))
+    norm_type = {"L1": 0, "L2": 1, "none": 2, "None": 2}[norm]
+    solver = select_solver(solver, k, (L1w, L1h), loss, use_gpu=True)
+    # ---- initialisation
+    if seed is None:
+        seed_int = int(np.random.SeedSequence().generate_state(1)[0] % (2 ** 31 - 1)) + 1
+        W0 = r_runif(seed_int, m * k).reshape(k, m).T.copy()          # matrix(runif(m*k), m, k): column-major fill
+    elif np.ndim(seed) == 2:
+        s = np.asarray(seed, dtype=np.float64)
+        if s.shape == (m, k):
+            W0 = s.copy()
+        elif s.shape == (k, m):
+            W0 = s.T.copy()
+        else:
+            raise ValueError("Custom init matrix dimensions incompatible with data")
+        seed_int = int(abs(int(np.sum(s * 1e6) % (2 ** 31 - 1))))
+    else:
+        seed_int = int(seed)
+        W0 = r_runif(seed_int, m * k).reshape(k, m).T.copy()
+    W_T = np.ascontiguousarray(W0, dtype=np.float64)                   # (m, k) C-order == column-major k x m
+    if h_init is not None:
+        H = np.ascontiguousarray(np.asarray(h_init, dtype=np.float64).T)   # h_init is k x n
+        if H.shape != (n, k):
+            raise ValueError("h_init must be k x n")
+    else:
+        sdt = np.float32 if precision == "fp32" else np.float64       # the reference fills H in its Scalar type
+        H = splitmix64_uniform(seed_int & 0xFFFFFFFF, 0, k * n, sdt).astype(np.float64).reshape(n, k)
+    mask_arg = None
+    if mask is not None:
+        if isinstance(mask, str):
+            if mask == "zeros":
+                pass            # fit-time no-op in the reference; only evaluate() honours it
+            else:
+                raise NotImplementedError("mask='%s' is not implemented" % mask)
+        else:
+            M = _as_csc(mask)
+            if M.shape != A.shape:
+                raise ValueError("mask dimensions must match data")
+            mask_arg = (M.p, M.i)
+    res = _abi.nmf_unified(A.p, A.i, A.x, m, n, k, W_T, H, entry="ex", max_iter=int(maxit), tol=float(tol), L1_H=L1h,
+                           L1_W=L1w, L2_H=L2h, L2_W=L2w, ub_H=ubh, ub_W=ubw, cd_maxit=int(cd_maxit), verbose=int(verbose),
+                           seed=seed_int & 0x7FFFFFFF, patience=int(patience), nonneg_W=int(nnw), nonneg_H=int(nnh),
+                           norm_type=norm_type, solver_mode=0 if solver == "cd" else 1, mask=mask_arg, cd_tol=float(cd_tol),
+                           sort_model=int(sort_model), precision=_abi.F32 if precision == "fp32" else _abi.F64,
+                           want_history=True)
+    if res["status"] != 0:
+        raise _abi.BackendError("GPU NMF failed: %s" % res.get("error"))
+    misc = dict(tol=res["tol"], iter=res["iter"], loss=res["loss"], loss_history=res.get("loss_history"),
+                converged=res["converged"], solver=solver, solver_mode=0 if solver == "cd" else 1, L1=(L1w, L1h),
+                L2=(L2w, L2h), seed=seed_int, precision=precision, resource="gpu")
+    return NMFModel(w=W_T.copy(), d=res["d"], h=H.T.copy(), misc=misc)
+
+
+def nnls(w=None, h=None, A=None, L1=0.0, L2=0.0, cd_maxit=100, cd_tol=1e-8, upper_bound=0.0, nonneg=True, warm_start=None):
+    """R/solve.R:84-357 (MSE path, fp64): given w (m x k) solve for h (k x n), or given h (k x n) solve for w (m x k)."""
+    if A is None or (w is None) == (h is None):
+        raise ValueError("provide A and exactly one of w, h")
+    Ac = _as_csc(A)
+    if w is not None:
+        w = np.asarray(w, dtype=np.float64)
+        if w.shape[0] != Ac.rows:
+            raise ValueError("dimensions of 'w' and 'A' are incompatible")
+        k = w.shape[1]
+        out = np.zeros((Ac.cols, k)) if warm_start is None else np.ascontiguousarray(np.asarray(warm_start, np.float64).T)
+        _abi.nnls_double(Ac.p, Ac.i, Ac.x, Ac.rows, Ac.cols, k, np.ascontiguousarray(w), out, cd_maxit=cd_maxit, cd_tol=cd_tol,
+                         L1=L1, L2=L2, ub=upper_bound, nonneg=int(nonneg), warm=int(warm_start is not None))
+        return out.T.copy()
+    h = np.asarray(h, dtype=np.float64)                                 # k x n  -> solve on A^T (R/solve.R:326-355)
+    if h.shape[1] != Ac.cols:
+        raise ValueError("dimensions of 'h' and 'A' are incompatible")
+    At = Ac.transpose()
+    k = h.shape[0]
+    out = np.zeros((At.cols, k)) if warm_start is None else np.ascontiguousarray(np.asarray(warm_start, np.float64))
+    _abi.nnls_double(At.p, At.i, At.x, At.rows, At.cols, k, np.ascontiguousarray(h.T), out, cd_maxit=cd_maxit, cd_tol=cd_tol,
+                     L1=L1, L2=L2, ub=upper_bound, nonneg=int(nonneg), warm=int(warm_start is not None))
+    return out
+
+
+def predict(model, data, L1=0.0, L2=0.0, upper_bound=0.0):
+    """R/predict_nmf.R:48-97 -> Rcpp_predict (src/RcppFunctions_utils.cpp:23-52): project new samples onto model.w
+    with cd_maxit = 100, cd_tol = 1e-8, nonneg = TRUE.  Returns h (k x n)."""
+    return nnls(w=model.w, A=data, L1=L1, L2=L2, cd_maxit=100, cd_tol=1e-8, upper_bound=upper_bound, nonneg=True)
+
+
+def evaluate(model, data, mask=None):
+    """R/nmf_methods.R:356-469 -> Rcpp_evaluate_loss: MEAN squared error of w diag(d) h over all entries, or over the
+    nonzeros of `data` if mask == 'zeros'.  (model.misc['loss'] is the SUM)"""
+    A = _as_csc(data)
+    if mask not in (None, "zeros"):
+        raise NotImplementedError("evaluate(): only mask=NULL or mask='zeros'")
+    k = model.d.shape[0]
+    return _abi.evaluate_mse_double(A.p, A.i, A.x, A.rows, A.cols, k, np.ascontiguousarray(model.w),
+                                    model.d, np.ascontiguousarray(model.h.T), mask_zeros=(mask == "zeros"))

@@ -1,0 +1,89 @@
+"""N > 1 path on CPU: the column-sharded ALS loop (rcppml_amd/als.py) under torch.distributed `gloo` with
+world_size 2 and 3, compute supplied by the oracle-backed ops of tests/oracle_ops.py.  Checks the sharded run
+reproduces the single-process oracle fit (nmf_fit<CPU> restatement) -- same loss trajectory and factors up to
+summation-order rounding -- and that nnz-balanced partitioning covers every column exactly once."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import oracle as O
+from rcppml_amd import als, data
+from tests.oracle_ops import OracleOps
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, cfg_kw, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        A, _, _ = data.simulate_nmf_sparse(90, 140, 5, 0.2, seed=17)
+        k = 6
+        bounds = als.partition_columns_by_nnz(A.p, world)
+        c0, c1 = bounds[rank], bounds[rank + 1]
+        A_loc = A.col_slice(c0, c1)
+        W0, H0 = data.init_factors(9, k, A.rows, A.cols)
+        cfg = als.AlsConfig(k=k, **cfg_kw)
+        st = als.ShardedALS(OracleOps("f64"), als.Comm(dist), A_loc, A_loc.transpose(), W0, H0[c0:c1], cfg)
+        res = st.fit()
+        W_T, d, H = st.factors()
+        q.put((rank, c0, c1, res, W_T, d, H))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("cfg_kw", [dict(max_iter=8, tol=0.0, L1_H=0.01, L2_W=0.02),
+                                    dict(max_iter=6, tol=0.0, solver_mode=1, norm_type=1)])
+def test_sharded_als_matches_single_process(world, cfg_kw):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, cfg_kw, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = sorted([q.get(timeout=300) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # single-process reference on the full matrix (unsorted, to compare factor-by-factor)
+    A, _, _ = data.simulate_nmf_sparse(90, 140, 5, 0.2, seed=17)
+    Ao = O.Csc(A.shape, A.p, A.i, A.x)
+    W0, H0 = data.init_factors(9, 6, A.rows, A.cols)
+    ref = O.nmf_fit(Ao, W0, H0, max_iter=cfg_kw["max_iter"], tol=0.0, L1=(cfg_kw.get("L1_W", 0.0), cfg_kw.get("L1_H", 0.0)),
+                    L2=(cfg_kw.get("L2_W", 0.0), cfg_kw.get("L2_H", 0.0)), solver_mode=cfg_kw.get("solver_mode", 0),
+                    norm_type=cfg_kw.get("norm_type", 0), sort_model=False)
+    H_full = np.concatenate([o[6] for o in outs], axis=0)
+    assert outs[0][1] == 0 and outs[-1][2] == A.cols and all(outs[i][2] == outs[i + 1][1] for i in range(world - 1))
+    for o in outs:   # W_T, d and the loss are replicated: identical on every rank
+        assert np.array_equal(o[4], outs[0][4]) and np.array_equal(o[5], outs[0][5])
+        assert o[3]["loss_history"] == outs[0][3]["loss_history"]
+    hist = np.array(outs[0][3]["loss_history"])
+    assert np.abs(hist - ref.loss_history).max() / ref.loss_history.max() < 1e-9
+    assert np.abs(outs[0][4] - ref.W_T).max() < 1e-9
+    assert np.abs(outs[0][5] - ref.d).max() / ref.d.max() < 1e-9
+    assert np.abs(H_full - ref.H).max() < 1e-9
+
+
+def test_partition_by_nnz():
+    A, _, _ = data.simulate_nmf_sparse(300, 1000, 4, 0.05, seed=2)
+    for world in (1, 2, 4, 8):
+        b = als.partition_columns_by_nnz(A.p, world)
+        assert b[0] == 0 and b[-1] == A.cols and len(b) == world + 1 and all(b[i] <= b[i + 1] for i in range(world))
+        per = [int(A.p[b[i + 1]] - A.p[b[i]]) for i in range(world)]
+        assert max(per) - min(per) <= 2 * int(np.diff(A.p).max())
+    # degenerate: more ranks than columns
+    b = als.partition_columns_by_nnz(np.array([0, 3, 5]), 4)
+    assert b[0] == 0 and b[-1] == 2 and all(b[i] <= b[i + 1] for i in range(4))
