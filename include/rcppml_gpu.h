@@ -116,8 +116,10 @@ typedef struct rcppml_hip_ctx rcppml_hip_ctx;
 
 enum { RCPPML_F32 = 0, RCPPML_F64 = 1 };
 /* CD kernel variants (rcppml_hip_solve_cd `variant`) */
-enum { RCPPML_CD_AUTO = 0, RCPPML_CD_LANE = 1 /* one lane per column, G broadcast from SGPRs */,
-       RCPPML_CD_WAVE = 2 /* one wavefront per column, active-coordinate ballot skipping */ };
+enum { RCPPML_CD_AUTO = 0 /* = GROUP unless RCPPML_GPU_CD_VARIANT says otherwise */,
+       RCPPML_CD_LANE = 1 /* one lane per column, residual+iterate in registers, G through the scalar cache (SGPRs) */,
+       RCPPML_CD_WAVE = 2 /* one wavefront per column, active-coordinate ballot skipping, G in LDS */,
+       RCPPML_CD_GROUP = 5 /* 1, 2 or 4 adjacent lanes per column (DPP broadcasts), G from LDS: the default */ };
 
 /* stream: a hipStream_t (NULL = the device's null stream).  The context owns scratch memory only. */
 RCPPML_GPU_API int rcppml_hip_ctx_create(rcppml_hip_ctx** out, int device, void* stream);
@@ -140,12 +142,14 @@ RCPPML_GPU_API int rcppml_hip_rhs(rcppml_hip_ctx* ctx, int dtype, const int* col
  * prologues of fused_nnls.hpp:116-123 / nnls_batch.hpp:167-174:
  *   b = B(:,j); if (l1_pre>0) b -= l1_pre; x = zero_init ? 0 : X(:,j); if (warm) b -= G x;
  *   CD(G, b, x, l1_cd, l2_cd, nonneg, maxit, ub_cd, tol); if (ub_post>0) x = min(x, ub_post).
- * B is NOT modified (the residual lives in registers).  G: k x k. */
+ * B is NOT modified (the residual lives in registers).  G: k x k.
+ * sweeps_out (device, ncols ints, may be NULL): sweeps executed per column = the value cd_nnls_col_fixed
+ * returns (nnls_batch.hpp:127-131). */
 RCPPML_GPU_API int rcppml_hip_solve_cd(rcppml_hip_ctx* ctx, int dtype, const void* G, const void* B,
                                        void* X, int k, int64_t ncols, double l1_pre, int warm,
                                        int zero_init, double l1_cd, double l2_cd, int nonneg,
                                        int maxit, double tol, double ub_cd, double ub_post,
-                                       int variant);
+                                       int variant, int* sweeps_out);
 
 /* Cholesky solve + clip -- reference primitives/cpu/fused_nnls.hpp:185-219:
  *   L = chol(G) once; x = L^-T L^-1 (B(:,j) - l1_pre); clip >= 0 (nonneg); clip <= ub_post. */

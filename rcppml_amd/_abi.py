@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "RcppML_gpu.so")
 _lib = None
 
 F32, F64 = 0, 1
-CD_AUTO, CD_LANE, CD_WAVE = 0, 1, 2
+CD_AUTO, CD_LANE, CD_WAVE, CD_GROUP = 0, 1, 2, 5
 
 # Every symbol include/rcppml_gpu.h declares (tests check the library exports all of them).
 EXPORTED_SYMBOLS = [
@@ -219,11 +219,11 @@ class Context:
                                   _dptr(F), C.c_int(k), _dptr(B)), "rhs")
 
     def solve_cd(self, dt, G, B, X, k, ncols, l1_pre=0.0, warm=0, zero_init=0, l1_cd=0.0, l2_cd=0.0, nonneg=1, maxit=100,
-                 tol=1e-8, ub_cd=0.0, ub_post=0.0, variant=CD_AUTO):
+                 tol=1e-8, ub_cd=0.0, ub_post=0.0, variant=CD_AUTO, sweeps_out=None):
         _chk(lib().rcppml_hip_solve_cd(self._h, C.c_int(dt), _dptr(G), _dptr(B), _dptr(X), C.c_int(k), C.c_int64(ncols),
                                        C.c_double(l1_pre), C.c_int(warm), C.c_int(zero_init), C.c_double(l1_cd),
                                        C.c_double(l2_cd), C.c_int(nonneg), C.c_int(maxit), C.c_double(tol),
-                                       C.c_double(ub_cd), C.c_double(ub_post), C.c_int(variant)), "solve_cd")
+                                       C.c_double(ub_cd), C.c_double(ub_post), C.c_int(variant), _dptr(sweeps_out)), "solve_cd")
 
     def solve_chol(self, dt, G, B, X, k, ncols, l1_pre=0.0, nonneg=1, ub_post=0.0):
         _chk(lib().rcppml_hip_solve_chol(self._h, C.c_int(dt), _dptr(G), _dptr(B), _dptr(X), C.c_int(k), C.c_int64(ncols),

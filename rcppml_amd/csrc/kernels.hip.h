@@ -306,7 +306,8 @@ __global__ __launch_bounds__(64) void cd_lane_kernel(const T* __restrict__ Gp,
                                                       const T* __restrict__ B, T* __restrict__ X,
                                                       int k, int64_t ncols, T l1_pre, int warm,
                                                       int zero_init, T l1_cd, T l2_cd, int nonneg,
-                                                      int maxit, T tol, T ub_cd, T ub_post) {
+                                                      int maxit, T tol, T ub_cd, T ub_post,
+                                                      int* __restrict__ sweeps) {
     const int64_t j = (int64_t)blockIdx.x * 64 + threadIdx.x;
     const bool inb = j < ncols;
     T b[KP], x[KP];
@@ -334,9 +335,11 @@ __global__ __launch_bounds__(64) void cd_lane_kernel(const T* __restrict__ Gp,
     const bool check = tol > T(0);
     const T inv_k = T(1) / static_cast<T>(k);
     bool active = inb;
+    int nsweep = 0;
     for (int it = 0; it < maxit; ++it) {
         if (!__any(active)) break;
         if (active) {
+            ++nsweep;
             T tol_sum = T(0);
 #pragma unroll
             for (int i = 0; i < KP; ++i) {
@@ -371,6 +374,184 @@ __global__ __launch_bounds__(64) void cd_lane_kernel(const T* __restrict__ Gp,
                 if (ub_post > T(0)) v = v < ub_post ? v : ub_post;
                 xj[i] = v;
             }
+        if (sweeps) sweeps[j] = nsweep;   // what cd_nnls_col_fixed returns (nnls_batch.hpp:127-131)
+    }
+}
+
+// ---------------------------------------------------------------------------
+// CD NNLS, LPC adjacent lanes per column ("group" variant): the default solve kernel.
+// Same reference routine (nnls_batch.hpp:70-132).  A column's residual is split over LPC = 1, 2 or 4 adjacent
+// lanes (RPL = KP/LPC rows each, in registers together with the matching slice of x); a wave carries 64/LPC
+// columns.  Per coordinate i the owner lane's b_i and x_i are broadcast inside the group with one DPP
+// quad_perm move each (no LDS, no readlane), every lane of the group evaluates the reference's scalar step
+// redundantly (so `a`, the clamp decisions and the tolerance sum are bit-identical across the group), and each
+// lane applies the rank-1 residual update to its own rows with G(:,i) read from LDS (16-byte reads; lanes with
+// the same sub-index share an address -> broadcast, LPC distinct addresses on distinct banks).
+// Why: the rank-1 update is only KP/LPC fmas per lane, so the sequential per-coordinate dependency chain
+// (the real limiter of CD: measured 460-680 cycles/coordinate for LPC = 1 on MI355X) shrinks, and the number of
+// waves grows LPC-fold, which is what small column counts (the W side: m = 20000 -> 313 waves at LPC = 1)
+// need to fill 1024 SIMDs.  The launcher picks LPC from the column count.
+// Finished columns are frozen by forcing the step to 0.
+// ---------------------------------------------------------------------------
+template <int OWNER, int LPC> __device__ __forceinline__ int dpp_bcast_i32(int v) {
+    if constexpr (LPC == 1) return v;
+    else if constexpr (LPC == 2) {
+        // quad [a b c d] -> owner 0: [a a c c], owner 1: [b b d d]
+        constexpr int ctrl = OWNER == 0 ? (0 | (0 << 2) | (2 << 4) | (2 << 6)) : (1 | (1 << 2) | (3 << 4) | (3 << 6));
+        return __builtin_amdgcn_mov_dpp(v, ctrl, 0xf, 0xf, true);
+    } else {
+        constexpr int ctrl = OWNER | (OWNER << 2) | (OWNER << 4) | (OWNER << 6);
+        return __builtin_amdgcn_mov_dpp(v, ctrl, 0xf, 0xf, true);
+    }
+}
+template <int OWNER, int LPC> __device__ __forceinline__ float dpp_bcast(float v) {
+    return __int_as_float(dpp_bcast_i32<OWNER, LPC>(__float_as_int(v)));
+}
+template <int OWNER, int LPC> __device__ __forceinline__ double dpp_bcast(double v) {
+    const long long bits = __double_as_longlong(v);
+    const int lo = dpp_bcast_i32<OWNER, LPC>((int)(bits & 0xffffffffll));
+    const int hi = dpp_bcast_i32<OWNER, LPC>((int)(bits >> 32));
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+template <class T, int KP, int LPC, bool EXACT, int I>
+struct CdGroupStep {
+    // One coordinate (compile-time index I) of the sweep, then recurse to I+1.  `gcur` holds this lane's rows of
+    // G(:,I) (fetched one coordinate ahead); the rows of G(:,I+1) are requested first thing so their LDS latency
+    // hides behind this coordinate's arithmetic.  A scheduling barrier per coordinate keeps the compiler from
+    // hoisting further ahead (it otherwise floods the register file: 256 VGPRs + scratch on this 5k-instruction block).
+    template <class GV, int NV>
+    static __device__ __forceinline__ void run(T (&b)[KP / LPC], T (&x)[KP / LPC], GV (&gcur)[NV],
+                                               const T* __restrict__ Gs, const T* __restrict__ diag,
+                                               const T* __restrict__ invs, int sub_off, T l1_cd, T l2_cd, T lo, T hi,
+                                               bool active, bool check, T& tol_sum) {
+        constexpr int RPL = KP / LPC;
+        constexpr int OWNER = I / RPL, LI = I % RPL;
+        constexpr int EV = 16 / sizeof(T);
+        constexpr int INEXT = (I + 1) % KP;            // the last coordinate prefetches column 0 for the next sweep
+        GV gnext[NV];
+        const T* gcol = Gs + INEXT * KP + sub_off;
+#pragma unroll
+        for (int q = 0; q < NV; ++q) gnext[q] = *reinterpret_cast<const GV*>(gcol + q * EV);
+        const T bi = dpp_bcast<OWNER, LPC>(b[LI]);
+        const T xo = dpp_bcast<OWNER, LPC>(x[LI]);
+        const T ginv = invs[I];
+        T diff;
+        if constexpr (EXACT) diff = bi / diag[I];
+        else diff = bi * ginv;
+        diff -= l1_cd;                       // reference: `if (L1 != 0) diff -= L1` -- subtracting 0 is exact
+        diff = tfma(l2_cd, xo, diff);        // reference: `if (L2 != 0) diff += L2 * x[i]`
+        const T nv = xo + diff;
+        const bool neg = nv < lo, up = nv > hi;
+        T nx = neg ? lo : (up ? hi : nv);
+        T a = neg ? lo - xo : (up ? hi - xo : diff);
+        const bool on = active && (ginv > T(0));       // reference: `if (g_diag <= 0) continue;`
+        a = on ? a : T(0);
+        nx = on ? nx : xo;
+        x[LI] = (sub_off == OWNER * RPL) ? nx : x[LI];
+        // accumulated unconditionally (it is only READ when cd_tol > 0): a branch here splits the sweep into
+        // basic blocks and LLVM then sinks the residual updates towards their uses, keeping ~KP*RPL values live
+        if constexpr (EXACT) tol_sum += tabs(a) / (tabs(nx) + T(1e-15));
+        else tol_sum += fast_div<T>(tabs(a), tabs(nx) + T(1e-15));
+        const T na = -a;                                 // b -= G(:,I) * a
+#pragma unroll
+        for (int q = 0; q < NV; ++q)
+#pragma unroll
+            for (int e = 0; e < EV; ++e) b[q * EV + e] = tfma(gcur[q][e], na, b[q * EV + e]);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (I + 1 < KP) {
+            CdGroupStep<T, KP, LPC, EXACT, I + 1>::template run<GV, NV>(b, x, gnext, Gs, diag, invs, sub_off, l1_cd, l2_cd,
+                                                                        lo, hi, active, check, tol_sum);
+        } else {
+#pragma unroll
+            for (int q = 0; q < NV; ++q) gcur[q] = gnext[q];   // hand column 0 back to the caller's buffer
+        }
+    }
+};
+
+template <class T, int KP, int LPC, bool EXACT>
+__global__ __launch_bounds__(256) void cd_group_kernel(const T* __restrict__ Gp, const T* __restrict__ invd,
+                                                        const T* __restrict__ B, T* __restrict__ X, int k,
+                                                        int64_t ncols, T l1_pre, int warm, int zero_init, T l1_cd,
+                                                        T l2_cd, int nonneg, int maxit, T tol, T ub_cd, T ub_post,
+                                                        int* __restrict__ sweeps) {
+    constexpr int RPL = KP / LPC;               // rows per lane
+    constexpr int CPW = 64 / LPC;               // columns per wave
+    constexpr int EV = 16 / sizeof(T);
+    constexpr int NV = RPL / EV;
+    static_assert(RPL % EV == 0, "rows per lane must be a multiple of the 16-byte vector");
+    typedef typename VecT<T, EV>::type GV;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    T* Gs = reinterpret_cast<T*>(smem_raw);     // KP*KP, column i contiguous
+    T* diag = Gs + KP * KP;                     // KP
+    T* invs = diag + KP;                        // KP
+    for (int e = threadIdx.x; e < KP * KP; e += blockDim.x) Gs[e] = Gp[e];
+    for (int e = threadIdx.x; e < KP; e += blockDim.x) { diag[e] = Gp[e * KP + e]; invs[e] = invd[e]; }
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int sub = lane % LPC, slot = lane / LPC;
+    const int sub_off = sub * RPL;
+    const int64_t j = ((int64_t)blockIdx.x * (blockDim.x >> 6) + wave) * CPW + slot;
+    const bool inb = j < ncols;
+    T b[RPL], x[RPL];
+    const T* bj = B + j * (int64_t)k;
+    T* xj = X + j * (int64_t)k;
+#pragma unroll
+    for (int r = 0; r < RPL; ++r) {
+        const int row = sub_off + r;
+        T bv = (inb && row < k) ? bj[row] : T(0);
+        if (l1_pre != T(0) && inb && row < k) bv -= l1_pre;
+        b[r] = bv;
+        x[r] = (inb && row < k && !zero_init) ? xj[row] : T(0);
+    }
+    if (warm) {   // b -= G x   (fused_nnls.hpp:121-123): x_c broadcast from its owner, own rows of G(:,c) from LDS
+#pragma unroll 1
+        for (int o = 0; o < LPC; ++o) {
+#pragma unroll
+            for (int li = 0; li < RPL; ++li) {
+                const int c = o * RPL + li;
+                T xc;
+                if constexpr (LPC == 1) xc = x[li];
+                else xc = __shfl(x[li], (lane & ~(LPC - 1)) + o, 64);
+                const T nxc = -xc;
+                const T* gcol = Gs + c * KP + sub_off;
+#pragma unroll
+                for (int q = 0; q < NV; ++q) {
+                    const GV g = *reinterpret_cast<const GV*>(gcol + q * EV);
+#pragma unroll
+                    for (int e = 0; e < EV; ++e) b[q * EV + e] = tfma(g[e], nxc, b[q * EV + e]);
+                }
+            }
+        }
+    }
+    const T lo = nonneg ? T(0) : -INFINITY;
+    const T hi = ub_cd > T(0) ? ub_cd : INFINITY;
+    const bool check = tol > T(0);
+    const T inv_k = T(1) / static_cast<T>(k);
+    bool active = inb;
+    int nsweep = 0;
+    GV g0[NV];                                   // this lane's rows of G(:,0), refreshed by the last coordinate
+#pragma unroll
+    for (int q = 0; q < NV; ++q) g0[q] = *reinterpret_cast<const GV*>(Gs + sub_off + q * EV);
+    for (int it = 0; it < maxit; ++it) {
+        if (!__any(active)) break;
+        nsweep += active ? 1 : 0;
+        T tol_sum = T(0);
+        CdGroupStep<T, KP, LPC, EXACT, 0>::template run<GV, NV>(b, x, g0, Gs, diag, invs, sub_off, l1_cd, l2_cd, lo, hi,
+                                                                active, check, tol_sum);
+        if (check && active && tol_sum * inv_k < tol) active = false;
+    }
+    if (inb) {
+#pragma unroll
+        for (int r = 0; r < RPL; ++r) {
+            const int row = sub_off + r;
+            if (row < k) {
+                T v = x[r];
+                if (ub_post > T(0)) v = v < ub_post ? v : ub_post;
+                xj[row] = v;
+            }
+        }
+        if (sweeps && sub == 0) sweeps[j] = nsweep;
     }
 }
 
@@ -392,7 +573,8 @@ __global__ __launch_bounds__(256) void cd_wave_kernel(const T* __restrict__ Gp,
                                                        const T* __restrict__ B, T* __restrict__ X,
                                                        int k, int64_t ncols, T l1_pre, int warm,
                                                        int zero_init, T l1_cd, T l2_cd, int nonneg,
-                                                       int maxit, T tol, T ub_cd, T ub_post) {
+                                                       int maxit, T tol, T ub_cd, T ub_post,
+                                                      int* __restrict__ sweeps) {
     constexpr int VPL = KP / 64;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     T* Gs = reinterpret_cast<T*>(smem_raw);
@@ -427,7 +609,9 @@ __global__ __launch_bounds__(256) void cd_wave_kernel(const T* __restrict__ Gp,
                 }
             }
         }
+        int nsweep = 0;
         for (int it = 0; it < maxit; ++it) {
+            ++nsweep;
             T tol_sum = T(0);
 #pragma unroll
             for (int v = 0; v < VPL; ++v) {
@@ -471,6 +655,7 @@ __global__ __launch_bounds__(256) void cd_wave_kernel(const T* __restrict__ Gp,
                 xj[f] = val;
             }
         }
+        if (sweeps && lane == 0) sweeps[j] = nsweep;
     }
 }
 

@@ -2,23 +2,23 @@
 #include "solve_common.hip.h"
 void rcppml_solve_cd_f32(rcppml_hip_ctx* c, const float* G, const float* B, float* X, int k, int64_t ncols, float l1_pre,
                          int warm, int zero_init, float l1_cd, float l2_cd, int nonneg, int maxit, float tol, float ub_cd,
-                         float ub_post, int variant);
+                         float ub_post, int variant, int* sweeps);
 void rcppml_solve_cd_f64(rcppml_hip_ctx* c, const double* G, const double* B, double* X, int k, int64_t ncols, double l1_pre,
                          int warm, int zero_init, double l1_cd, double l2_cd, int nonneg, int maxit, double tol, double ub_cd,
-                         double ub_post, int variant);
+                         double ub_post, int variant, int* sweeps);
 extern "C" int rcppml_hip_solve_cd(rcppml_hip_ctx* c, int dtype, const void* G, const void* B, void* X, int k,
                                    int64_t ncols, double l1_pre, int warm, int zero_init, double l1_cd,
                                    double l2_cd, int nonneg, int maxit, double tol, double ub_cd, double ub_post,
-                                   int variant) {
+                                   int variant, int* sweeps_out) {
     try {
         HIPCHK(hipSetDevice(c->device));
         if (dtype == RCPPML_F32)
             rcppml_solve_cd_f32(c, (const float*)G, (const float*)B, (float*)X, k, ncols, (float)l1_pre, warm,
                                  zero_init, (float)l1_cd, (float)l2_cd, nonneg, maxit, (float)tol, (float)ub_cd,
-                                 (float)ub_post, variant);
+                                 (float)ub_post, variant, sweeps_out);
         else
             rcppml_solve_cd_f64(c, (const double*)G, (const double*)B, (double*)X, k, ncols, l1_pre, warm,
-                                  zero_init, l1_cd, l2_cd, nonneg, maxit, tol, ub_cd, ub_post, variant);
+                                  zero_init, l1_cd, l2_cd, nonneg, maxit, tol, ub_cd, ub_post, variant, sweeps_out);
         return 0;
     }
     RCPPML_CATCH_RET

@@ -210,7 +210,7 @@ void fit(FitParams& P) {
             OPCHK(rcppml_hip_rhs(c, dt, dAp.as<int>(), dAi.as<int>(), dAx.p, n, dW.p, k, dBh.p));
             if (P.solver_mode == 0)                                                     // :516-524
                 OPCHK(rcppml_hip_solve_cd(c, dt, dG.p, dBh.p, dH.p, k, n, P.L1_H > 0 ? P.L1_H : 0.0, warm, 0, 0.0, 0.0,
-                                          P.nonneg_H, P.cd_maxit, P.cd_tol, 0.0, P.ub_H, RCPPML_CD_AUTO));
+                                          P.nonneg_H, P.cd_maxit, P.cd_tol, 0.0, P.ub_H, RCPPML_CD_AUTO, nullptr));
             else                                                                        // :527-534
                 OPCHK(rcppml_hip_solve_chol(c, dt, dG.p, dBh.p, dH.p, k, n, P.L1_H > 0 ? P.L1_H : 0.0, P.nonneg_H, P.ub_H));
         }
@@ -230,7 +230,7 @@ void fit(FitParams& P) {
             OPCHK(rcppml_hip_rhs(c, dt, dTp.as<int>(), dTi.as<int>(), dTx.p, m, dH.p, k, dBw.p));
             if (P.solver_mode == 0)
                 OPCHK(rcppml_hip_solve_cd(c, dt, dG.p, dBw.p, dW.p, k, m, P.L1_W > 0 ? P.L1_W : 0.0, warm, 0, 0.0, 0.0,
-                                          P.nonneg_W, P.cd_maxit, P.cd_tol, 0.0, P.ub_W, RCPPML_CD_AUTO));
+                                          P.nonneg_W, P.cd_maxit, P.cd_tol, 0.0, P.ub_W, RCPPML_CD_AUTO, nullptr));
             else
                 OPCHK(rcppml_hip_solve_chol(c, dt, dG.p, dBw.p, dW.p, k, m, P.L1_W > 0 ? P.L1_W : 0.0, P.nonneg_W, P.ub_W));
         }
@@ -423,7 +423,7 @@ extern "C" void rcppml_gpu_nnls_double(const int* col_ptr, const int* row_idx, c
         OPCHK(rcppml_hip_rhs(g.c, RCPPML_F64, dAp.as<int>(), dAi.as<int>(), dAx.p, *n, dW.p, *k, dB.p));
         // warm: B -= G h, CD with default cd_tol = 0 (:349-356); cold: X = 0, CD(cd_tol)
         OPCHK(rcppml_hip_solve_cd(g.c, RCPPML_F64, dG.p, dB.p, dH.p, *k, *n, 0.0, *warm ? 1 : 0, *warm ? 0 : 1, *L1, 0.0,
-                                  *nonneg, *cd_maxit, *warm ? 0.0 : *cd_tol, *ub, 0.0, RCPPML_CD_AUTO));
+                                  *nonneg, *cd_maxit, *warm ? 0.0 : *cd_tol, *ub, 0.0, RCPPML_CD_AUTO, nullptr));
         download_cast<double>(dH, (size_t)*k * *n, h, s);
         *out_status = 0;
     } catch (const std::exception& e) {

@@ -7,17 +7,17 @@
 template <class T, int KP>
 static void cd_lane_launch(rcppml_hip_ctx* c, const T* Gp, const T* invd, const T* B, T* X, int k,
                            int64_t ncols, T l1_pre, int warm, int zero_init, T l1_cd, T l2_cd, int nonneg,
-                           int maxit, T tol, T ub_cd, T ub_post) {
+                           int maxit, T tol, T ub_cd, T ub_post, int* sweeps) {
     constexpr bool EXACT = std::is_same<T, double>::value;
     const int64_t nblk = (ncols + 63) / 64;
     hipLaunchKernelGGL((cd_lane_kernel<T, KP, EXACT>), dim3((unsigned)nblk), dim3(64), 0, c->stream, Gp, invd,
-                       B, X, k, ncols, l1_pre, warm, zero_init, l1_cd, l2_cd, nonneg, maxit, tol, ub_cd, ub_post);
+                       B, X, k, ncols, l1_pre, warm, zero_init, l1_cd, l2_cd, nonneg, maxit, tol, ub_cd, ub_post, sweeps);
     HIPCHK(hipGetLastError());
 }
 template <class T, int KP>
 static void cd_wave_launch(rcppml_hip_ctx* c, const T* Gp, const T* invd, const T* B, T* X, int k,
                            int64_t ncols, T l1_pre, int warm, int zero_init, T l1_cd, T l2_cd, int nonneg,
-                           int maxit, T tol, T ub_cd, T ub_post) {
+                           int maxit, T tol, T ub_cd, T ub_post, int* sweeps) {
     constexpr bool EXACT = std::is_same<T, double>::value;
     const size_t smem = (size_t)KP * KP * sizeof(T);
     auto kern = cd_wave_kernel<T, KP, EXACT>;
@@ -35,37 +35,84 @@ static void cd_wave_launch(rcppml_hip_ctx* c, const T* Gp, const T* invd, const 
     if (nblk > need) nblk = need;
     if (nblk < 1) nblk = 1;
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), smem, c->stream, Gp, invd, B, X, k, ncols, l1_pre,
-                       warm, zero_init, l1_cd, l2_cd, nonneg, maxit, tol, ub_cd, ub_post);
+                       warm, zero_init, l1_cd, l2_cd, nonneg, maxit, tol, ub_cd, ub_post, sweeps);
     HIPCHK(hipGetLastError());
+}
+
+
+// Lane-group variant: LPC lanes per column, 4 waves per block sharing the LDS copy of G.
+template <class T, int KP, int LPC>
+static void cd_group_launch(rcppml_hip_ctx* c, const T* Gp, const T* invd, const T* B, T* X, int k, int64_t ncols,
+                            T l1_pre, int warm, int zero_init, T l1_cd, T l2_cd, int nonneg, int maxit, T tol, T ub_cd,
+                            T ub_post, int* sweeps) {
+    constexpr bool EXACT = std::is_same<T, double>::value;
+    const size_t smem = ((size_t)KP * KP + 2 * KP) * sizeof(T);
+    auto kern = cd_group_kernel<T, KP, LPC, EXACT>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        attr_set = true;
+    }
+    const int64_t per_block = (int64_t)4 * (64 / LPC);
+    const int64_t nblk = (ncols + per_block - 1) / per_block;
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), smem, c->stream, Gp, invd, B, X, k, ncols, l1_pre, warm,
+                       zero_init, l1_cd, l2_cd, nonneg, maxit, tol, ub_cd, ub_post, sweeps);
+    HIPCHK(hipGetLastError());
+}
+// LPC choice (measured on MI355X, k = 64, 20k..100k columns: 32 fp32 rows per lane beat 16 by 4-15 %, and for
+// fp64 16 rows per lane are as good as 32 at half the registers): fp32 -> KP/32 lanes per column, fp64 -> KP/16,
+// clamped to {1, 2, 4}.  RCPPML_GPU_CD_LPC overrides (experiments).
+template <class T>
+static int pick_lpc(int KP) {
+    const int ev = 16 / (int)sizeof(T);
+    const char* e = getenv("RCPPML_GPU_CD_LPC");
+    int lpc = e ? atoi(e) : (std::is_same<T, float>::value ? KP / 32 : KP / 16);
+    if (lpc < 1) lpc = 1;
+    if (lpc > 4) lpc = 4;
+    while (lpc < 4 && KP / lpc > 32) lpc *= 2;          // at most 32 rows per lane
+    while (lpc > 1 && (KP / lpc) % ev != 0) lpc /= 2;   // whole 16-byte vectors per lane
+    return lpc;
 }
 
 template <class T>
 static void solve_cd_impl(rcppml_hip_ctx* c, const T* G, const T* B, T* X, int k, int64_t ncols, T l1_pre,
                           int warm, int zero_init, T l1_cd, T l2_cd, int nonneg, int maxit, T tol, T ub_cd,
-                          T ub_post, int variant) {
+                          T ub_post, int variant, int* sweeps) {
     if (ncols <= 0) return;
     if (k < 1 || k > 128) throw std::runtime_error("solve_cd: k must be in [1,128]");
     int KP = solve_kp(k);
-    // lane variant holds b and x (2*KP values) in registers: fp32 up to KP=64, fp64 up to KP=32
-    const int lane_max = std::is_same<T, float>::value ? 64 : 32;
     if (variant == RCPPML_CD_AUTO) {
         const char* e = getenv("RCPPML_GPU_CD_VARIANT");
         if (e && !strcmp(e, "lane")) variant = RCPPML_CD_LANE;
         else if (e && !strcmp(e, "wave")) variant = RCPPML_CD_WAVE;
-        else variant = (KP <= lane_max) ? RCPPML_CD_LANE : RCPPML_CD_WAVE;
+        else variant = RCPPML_CD_GROUP;
     }
-    if (variant == RCPPML_CD_LANE && KP > 64) variant = RCPPML_CD_WAVE;
+    // register-resident lane kernel (SGPR-fed): fp32 up to KP=64, fp64 up to KP=32 without spilling
+    const int lane_max = std::is_same<T, float>::value ? 64 : 32;
+    if (variant == RCPPML_CD_LANE && KP > lane_max) variant = RCPPML_CD_GROUP;
+    if (variant != RCPPML_CD_LANE && variant != RCPPML_CD_WAVE) variant = RCPPML_CD_GROUP;
     if (variant == RCPPML_CD_WAVE && KP < 64) KP = 64;   // the wave variant pads to a full 64-lane slab
     T *Gp, *invd;
     pad_impl<T>(c, G, k, KP, &Gp, &invd);
-#define CD_ARGS c, Gp, invd, B, X, k, ncols, l1_pre, warm, zero_init, l1_cd, l2_cd, nonneg, maxit, tol, ub_cd, ub_post
+#define CD_ARGS c, Gp, invd, B, X, k, ncols, l1_pre, warm, zero_init, l1_cd, l2_cd, nonneg, maxit, tol, ub_cd, ub_post, sweeps
     if (variant == RCPPML_CD_LANE) {
         switch (KP) {
             case 16: cd_lane_launch<T, 16>(CD_ARGS); break;
             case 32: cd_lane_launch<T, 32>(CD_ARGS); break;
-            case 64: cd_lane_launch<T, 64>(CD_ARGS); break;
-            default: cd_wave_launch<T, 128>(CD_ARGS); break;   // 2*128 residual/iterate registers spill: wave variant
+            default:
+                if constexpr (std::is_same<T, float>::value) cd_lane_launch<T, 64>(CD_ARGS);
+                break;
         }
+    } else if (variant == RCPPML_CD_GROUP) {
+        const int lpc = pick_lpc<T>(KP);
+#define GROUP_CASE(K_, L_) if (KP == K_ && lpc == L_) { cd_group_launch<T, K_, L_>(CD_ARGS); launched = true; }
+        bool launched = false;
+        GROUP_CASE(16, 1) GROUP_CASE(16, 2) GROUP_CASE(16, 4)
+        GROUP_CASE(32, 1) GROUP_CASE(32, 2) GROUP_CASE(32, 4)
+        GROUP_CASE(64, 2) GROUP_CASE(64, 4)
+        GROUP_CASE(128, 4)
+#undef GROUP_CASE
+        if (!launched) throw std::runtime_error("solve_cd: no lane-group configuration for this rank");
     } else {
         if (KP == 64) cd_wave_launch<T, 64>(CD_ARGS);
         else cd_wave_launch<T, 128>(CD_ARGS);
