@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--cd-maxit", type=int, default=100)
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-order", action="store_true", help="disable sweep-count column ordering")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline work (s)")
     return ap.parse_args()
 
@@ -130,7 +131,7 @@ def main():
     W0, H0 = data.init_factors(args.seed, k, m, n_loc, nd, col_offset=rank * n_loc, n_total=n_total)
     cfg = als.AlsConfig(k=k, max_iter=args.warmup + args.steps, tol=0.0, cd_maxit=args.cd_maxit,
                         solver_mode=0 if args.solver == "cd" else 1,
-                        cd_variant={"auto": 0, "lane": 1, "wave": 2}[args.variant])
+                        cd_variant={"auto": 0, "lane": 1, "wave": 2}[args.variant], order_columns=not args.no_order)
     ops = als.HipOps(local_rank, args.dtype, record_events=False)
     st = als.ShardedALS(ops, comm, A_loc, At_loc, W0, H0, cfg)
 

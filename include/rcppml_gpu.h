@@ -144,12 +144,18 @@ RCPPML_GPU_API int rcppml_hip_rhs(rcppml_hip_ctx* ctx, int dtype, const int* col
  *   CD(G, b, x, l1_cd, l2_cd, nonneg, maxit, ub_cd, tol); if (ub_post>0) x = min(x, ub_post).
  * B is NOT modified (the residual lives in registers).  G: k x k.
  * sweeps_out (device, ncols ints, may be NULL): sweeps executed per column = the value cd_nnls_col_fixed
- * returns (nnls_batch.hpp:127-131). */
+ * returns (nnls_batch.hpp:127-131).
+ * col_order (device, ncols ints, may be NULL): work order -- slot s of the launch solves column col_order[s]
+ * (see rcppml_hip_order_columns).  Columns are independent: any permutation gives identical results. */
 RCPPML_GPU_API int rcppml_hip_solve_cd(rcppml_hip_ctx* ctx, int dtype, const void* G, const void* B,
                                        void* X, int k, int64_t ncols, double l1_pre, int warm,
                                        int zero_init, double l1_cd, double l2_cd, int nonneg,
                                        int maxit, double tol, double ub_cd, double ub_post,
-                                       int variant, int* sweeps_out);
+                                       int variant, int* sweeps_out, const int* col_order);
+
+/* order = columns sorted by DESCENDING sweeps (counting sort on the device).  Feeding the sweep counts of the
+ * previous ALS iteration groups columns that converge together into the same wavefront. */
+RCPPML_GPU_API int rcppml_hip_order_columns(rcppml_hip_ctx* ctx, const int* sweeps, int64_t ncols, int* order);
 
 /* Cholesky solve + clip -- reference primitives/cpu/fused_nnls.hpp:185-219:
  *   L = chol(G) once; x = L^-T L^-1 (B(:,j) - l1_pre); clip >= 0 (nonneg); clip <= ub_post. */

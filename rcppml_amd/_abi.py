@@ -20,7 +20,7 @@ EXPORTED_SYMBOLS = [
     "rcppml_gpu_detect", "rcppml_gpu_nmf_unified_float", "rcppml_gpu_nmf_unified_double", "rcppml_gpu_nmf_ex",
     "rcppml_gpu_nnls_double", "rcppml_gpu_evaluate_mse_double", "rcppml_gpu_last_error",
     "rcppml_hip_ctx_create", "rcppml_hip_ctx_destroy", "rcppml_hip_ctx_sync", "rcppml_hip_gram", "rcppml_hip_rhs",
-    "rcppml_hip_solve_cd", "rcppml_hip_solve_chol", "rcppml_hip_row_norms", "rcppml_hip_apply_scaling",
+    "rcppml_hip_solve_cd", "rcppml_hip_order_columns", "rcppml_hip_solve_chol", "rcppml_hip_row_norms", "rcppml_hip_apply_scaling",
     "rcppml_hip_sumsq", "rcppml_hip_loss_mse", "rcppml_hip_solve_masked", "rcppml_hip_loss_nonzeros",
 ]
 
@@ -43,7 +43,8 @@ def lib():
             raise BackendError("cannot load %s: %s" % (LIB_PATH, e))
         _lib.rcppml_gpu_last_error.restype = C.c_char_p
         for name in ("rcppml_hip_ctx_create", "rcppml_hip_ctx_sync", "rcppml_hip_gram", "rcppml_hip_rhs",
-                     "rcppml_hip_solve_cd", "rcppml_hip_solve_chol", "rcppml_hip_row_norms", "rcppml_hip_apply_scaling",
+                     "rcppml_hip_solve_cd", "rcppml_hip_order_columns", "rcppml_hip_solve_chol", "rcppml_hip_row_norms",
+                     "rcppml_hip_apply_scaling",
                      "rcppml_hip_sumsq", "rcppml_hip_loss_mse", "rcppml_hip_solve_masked", "rcppml_hip_loss_nonzeros"):
             getattr(_lib, name).restype = C.c_int
         _lib.rcppml_hip_ctx_destroy.restype = None
@@ -219,11 +220,14 @@ class Context:
                                   _dptr(F), C.c_int(k), _dptr(B)), "rhs")
 
     def solve_cd(self, dt, G, B, X, k, ncols, l1_pre=0.0, warm=0, zero_init=0, l1_cd=0.0, l2_cd=0.0, nonneg=1, maxit=100,
-                 tol=1e-8, ub_cd=0.0, ub_post=0.0, variant=CD_AUTO, sweeps_out=None):
+                 tol=1e-8, ub_cd=0.0, ub_post=0.0, variant=CD_AUTO, sweeps_out=None, col_order=None):
         _chk(lib().rcppml_hip_solve_cd(self._h, C.c_int(dt), _dptr(G), _dptr(B), _dptr(X), C.c_int(k), C.c_int64(ncols),
                                        C.c_double(l1_pre), C.c_int(warm), C.c_int(zero_init), C.c_double(l1_cd),
                                        C.c_double(l2_cd), C.c_int(nonneg), C.c_int(maxit), C.c_double(tol),
-                                       C.c_double(ub_cd), C.c_double(ub_post), C.c_int(variant), _dptr(sweeps_out)), "solve_cd")
+                                       C.c_double(ub_cd), C.c_double(ub_post), C.c_int(variant), _dptr(sweeps_out), _dptr(col_order)), "solve_cd")
+
+    def order_columns(self, sweeps, ncols, order):
+        _chk(lib().rcppml_hip_order_columns(self._h, _dptr(sweeps), C.c_int64(ncols), _dptr(order)), "order_columns")
 
     def solve_chol(self, dt, G, B, X, k, ncols, l1_pre=0.0, nonneg=1, ub_post=0.0):
         _chk(lib().rcppml_hip_solve_chol(self._h, C.c_int(dt), _dptr(G), _dptr(B), _dptr(X), C.c_int(k), C.c_int64(ncols),

@@ -37,7 +37,8 @@ class AlsConfig:
     nonneg_H: bool = True
     norm_type: int = 0          # 0 = L1, 1 = L2, 2 = none
     solver_mode: int = 0        # 0 = CD, 1 = Cholesky + clip
-    cd_variant: int = 0         # 0 = auto, 1 = lane, 2 = wave
+    cd_variant: int = 0         # 0 = auto (lane-group), 1 = lane (SGPR-fed), 2 = wave, 5 = lane-group
+    order_columns: bool = True  # schedule CD columns by the sweep counts of the previous iteration
 
 
 class HipOps:
@@ -58,6 +59,7 @@ class HipOps:
         self.ctx = _abi.Context(device)
         self.record = record_events
         self.events = {}
+        self._order = {}
 
     # -- plumbing
     def to_device(self, a, dtype=None):
@@ -108,9 +110,21 @@ class HipOps:
         nonneg = cfg.nonneg_H if side == "H" else cfg.nonneg_W
         with self._timed(tag):
             if cfg.solver_mode == 0:
+                # work order: columns sorted by the sweeps they needed in the previous ALS iteration (a wave runs
+                # until its slowest column converges); per-column results do not depend on the order
+                st = self._order.get(side) if cfg.order_columns else None
+                if cfg.order_columns and (st is None or st["sweeps"].shape[0] != n):
+                    st = dict(sweeps=self.zeros((n,), self.torch.int32), order=self.empty((n,), self.torch.int32), valid=False)
+                    self._order[side] = st
+                use = st is not None and st["valid"] and cfg.cd_tol > 0
+                if use:
+                    self.ctx.order_columns(st["sweeps"], n, st["order"])
                 self.ctx.solve_cd(self.dt, G, B, X, k, n, l1_pre=l1 if l1 > 0 else 0.0, warm=int(warm), zero_init=0,
                                   nonneg=int(nonneg), maxit=cfg.cd_maxit, tol=cfg.cd_tol, ub_post=ub,
-                                  variant=cfg.cd_variant)
+                                  variant=cfg.cd_variant, sweeps_out=st["sweeps"] if st is not None else None,
+                                  col_order=st["order"] if use else None)
+                if st is not None:
+                    st["valid"] = True
             else:
                 self.ctx.solve_chol(self.dt, G, B, X, k, n, l1_pre=l1 if l1 > 0 else 0.0, nonneg=int(nonneg), ub_post=ub)
 

@@ -78,7 +78,7 @@ static void gram_impl(rcppml_hip_ctx* c, const T* F, int k, int64_t r, T eps, T 
 #undef GRAM64_CASE
     }
     HIPCHK(hipGetLastError());
-    hipLaunchKernelGGL(gram_finalize<T>, dim3((KP * KP + 255) / 256), dim3(256), 0, c->stream, partial,
+    hipLaunchKernelGGL(gram_finalize<T>, dim3((KP * KP + 7) / 8), dim3(256), 0, c->stream, partial,
                        (int)nblk, KP, k, eps, l2, G);
     HIPCHK(hipGetLastError());
 }

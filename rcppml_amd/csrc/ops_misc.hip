@@ -15,7 +15,7 @@ static void row_norms_impl(rcppml_hip_ctx* c, const T* X, int k, int64_t ncols, 
     hipLaunchKernelGGL(row_norm_partial<T>, dim3((unsigned)nblk), dim3(256), 256 * sizeof(T), c->stream, X, k, ncols,
                        norm_type, partial);
     HIPCHK(hipGetLastError());
-    hipLaunchKernelGGL(row_norm_final<T>, dim3((k + 63) / 64), dim3(64), 0, c->stream, partial, (int)nblk, k, out);
+    hipLaunchKernelGGL(row_norm_final<T>, dim3(k), dim3(64), 0, c->stream, partial, (int)nblk, k, out);
     HIPCHK(hipGetLastError());
 }
 extern "C" int rcppml_hip_row_norms(rcppml_hip_ctx* c, int dtype, const void* X, int k, int64_t ncols,

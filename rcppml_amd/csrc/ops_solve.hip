@@ -2,23 +2,23 @@
 #include "solve_common.hip.h"
 void rcppml_solve_cd_f32(rcppml_hip_ctx* c, const float* G, const float* B, float* X, int k, int64_t ncols, float l1_pre,
                          int warm, int zero_init, float l1_cd, float l2_cd, int nonneg, int maxit, float tol, float ub_cd,
-                         float ub_post, int variant, int* sweeps);
+                         float ub_post, int variant, int* sweeps, const int* order);
 void rcppml_solve_cd_f64(rcppml_hip_ctx* c, const double* G, const double* B, double* X, int k, int64_t ncols, double l1_pre,
                          int warm, int zero_init, double l1_cd, double l2_cd, int nonneg, int maxit, double tol, double ub_cd,
-                         double ub_post, int variant, int* sweeps);
+                         double ub_post, int variant, int* sweeps, const int* order);
 extern "C" int rcppml_hip_solve_cd(rcppml_hip_ctx* c, int dtype, const void* G, const void* B, void* X, int k,
                                    int64_t ncols, double l1_pre, int warm, int zero_init, double l1_cd,
                                    double l2_cd, int nonneg, int maxit, double tol, double ub_cd, double ub_post,
-                                   int variant, int* sweeps_out) {
+                                   int variant, int* sweeps_out, const int* col_order) {
     try {
         HIPCHK(hipSetDevice(c->device));
         if (dtype == RCPPML_F32)
             rcppml_solve_cd_f32(c, (const float*)G, (const float*)B, (float*)X, k, ncols, (float)l1_pre, warm,
                                  zero_init, (float)l1_cd, (float)l2_cd, nonneg, maxit, (float)tol, (float)ub_cd,
-                                 (float)ub_post, variant, sweeps_out);
+                                 (float)ub_post, variant, sweeps_out, col_order);
         else
             rcppml_solve_cd_f64(c, (const double*)G, (const double*)B, (double*)X, k, ncols, l1_pre, warm,
-                                  zero_init, l1_cd, l2_cd, nonneg, maxit, tol, ub_cd, ub_post, variant, sweeps_out);
+                                  zero_init, l1_cd, l2_cd, nonneg, maxit, tol, ub_cd, ub_post, variant, sweeps_out, col_order);
         return 0;
     }
     RCPPML_CATCH_RET
@@ -70,3 +70,23 @@ extern "C" int rcppml_hip_solve_chol(rcppml_hip_ctx* c, int dtype, const void* G
     RCPPML_CATCH_RET
 }
 
+
+// ----------------------------------------------------------------------------
+// Column work order (counting sort by descending sweep count)
+// ----------------------------------------------------------------------------
+extern "C" int rcppml_hip_order_columns(rcppml_hip_ctx* c, const int* sweeps, int64_t ncols, int* order) {
+    try {
+        HIPCHK(hipSetDevice(c->device));
+        if (ncols <= 0) return 0;
+        unsigned int* hist = static_cast<unsigned int*>(c->scratch(WS_ORDER, 128 * sizeof(unsigned int)));
+        HIPCHK(hipMemsetAsync(hist, 0, 128 * sizeof(unsigned int), c->stream));
+        int64_t nblk = (ncols + 255) / 256;
+        if (nblk > 2 * (int64_t)c->num_cu) nblk = 2 * c->num_cu;
+        hipLaunchKernelGGL(order_hist_kernel, dim3((unsigned)nblk), dim3(256), 0, c->stream, sweeps, ncols, hist);
+        hipLaunchKernelGGL(order_scan_kernel, dim3(1), dim3(128), 0, c->stream, hist);
+        hipLaunchKernelGGL(order_scatter_kernel, dim3((unsigned)nblk), dim3(256), 0, c->stream, sweeps, ncols, hist, order);
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
+    RCPPML_CATCH_RET
+}

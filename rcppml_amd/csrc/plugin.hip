@@ -187,6 +187,9 @@ void fit(FitParams& P) {
     struct HostFree { double* p; ~HostFree() { (void)hipHostFree(p); } } hf{hloss};
 
     OPCHK(rcppml_hip_sumsq(c, dt, dAx.p, P.nnz, dtr.as<double>()));       // trAtA, primitives.hpp:100-115
+    // CD work order: columns sorted by the sweeps of the previous iteration (results are order-independent)
+    DevBuf dswH((size_t)n * sizeof(int)), dswW((size_t)m * sizeof(int)), dordH((size_t)n * sizeof(int)), dordW((size_t)m * sizeof(int));
+    const bool use_order = P.solver_mode == 0 && !has_mask && P.cd_tol > 0 && !getenv("RCPPML_GPU_NO_ORDER");
 
     const double eps = 1e-15;
     double prev_loss = std::numeric_limits<double>::max();
@@ -208,9 +211,13 @@ void fit(FitParams& P) {
         } else {
             OPCHK(rcppml_hip_gram(c, dt, dW.p, k, m, eps, P.L2_H, dG.p));              // :491,506
             OPCHK(rcppml_hip_rhs(c, dt, dAp.as<int>(), dAi.as<int>(), dAx.p, n, dW.p, k, dBh.p));
-            if (P.solver_mode == 0)                                                     // :516-524
+            if (P.solver_mode == 0) {                                                   // :516-524
+                const bool ord = use_order && iter > 0;
+                if (ord) OPCHK(rcppml_hip_order_columns(c, dswH.as<int>(), n, dordH.as<int>()));
                 OPCHK(rcppml_hip_solve_cd(c, dt, dG.p, dBh.p, dH.p, k, n, P.L1_H > 0 ? P.L1_H : 0.0, warm, 0, 0.0, 0.0,
-                                          P.nonneg_H, P.cd_maxit, P.cd_tol, 0.0, P.ub_H, RCPPML_CD_AUTO, nullptr));
+                                          P.nonneg_H, P.cd_maxit, P.cd_tol, 0.0, P.ub_H, RCPPML_CD_AUTO,
+                                          use_order ? dswH.as<int>() : nullptr, ord ? dordH.as<int>() : nullptr));
+            }
             else                                                                        // :527-534
                 OPCHK(rcppml_hip_solve_chol(c, dt, dG.p, dBh.p, dH.p, k, n, P.L1_H > 0 ? P.L1_H : 0.0, P.nonneg_H, P.ub_H));
         }
@@ -228,9 +235,13 @@ void fit(FitParams& P) {
             if (P.L2_W > 0) OPCHK(rcppml_hip_gram(c, dt, dH.p, k, n, eps, P.L2_W, dG.p)); // :738
             else HIPCHK(hipMemcpyAsync(dG.p, dGs.p, (size_t)k * k * sizeof(T), hipMemcpyDeviceToDevice, s));
             OPCHK(rcppml_hip_rhs(c, dt, dTp.as<int>(), dTi.as<int>(), dTx.p, m, dH.p, k, dBw.p));
-            if (P.solver_mode == 0)
+            if (P.solver_mode == 0) {
+                const bool ord = use_order && iter > 0;
+                if (ord) OPCHK(rcppml_hip_order_columns(c, dswW.as<int>(), m, dordW.as<int>()));
                 OPCHK(rcppml_hip_solve_cd(c, dt, dG.p, dBw.p, dW.p, k, m, P.L1_W > 0 ? P.L1_W : 0.0, warm, 0, 0.0, 0.0,
-                                          P.nonneg_W, P.cd_maxit, P.cd_tol, 0.0, P.ub_W, RCPPML_CD_AUTO, nullptr));
+                                          P.nonneg_W, P.cd_maxit, P.cd_tol, 0.0, P.ub_W, RCPPML_CD_AUTO,
+                                          use_order ? dswW.as<int>() : nullptr, ord ? dordW.as<int>() : nullptr));
+            }
             else
                 OPCHK(rcppml_hip_solve_chol(c, dt, dG.p, dBw.p, dW.p, k, m, P.L1_W > 0 ? P.L1_W : 0.0, P.nonneg_W, P.ub_W));
         }
@@ -423,7 +434,7 @@ extern "C" void rcppml_gpu_nnls_double(const int* col_ptr, const int* row_idx, c
         OPCHK(rcppml_hip_rhs(g.c, RCPPML_F64, dAp.as<int>(), dAi.as<int>(), dAx.p, *n, dW.p, *k, dB.p));
         // warm: B -= G h, CD with default cd_tol = 0 (:349-356); cold: X = 0, CD(cd_tol)
         OPCHK(rcppml_hip_solve_cd(g.c, RCPPML_F64, dG.p, dB.p, dH.p, *k, *n, 0.0, *warm ? 1 : 0, *warm ? 0 : 1, *L1, 0.0,
-                                  *nonneg, *cd_maxit, *warm ? 0.0 : *cd_tol, *ub, 0.0, RCPPML_CD_AUTO, nullptr));
+                                  *nonneg, *cd_maxit, *warm ? 0.0 : *cd_tol, *ub, 0.0, RCPPML_CD_AUTO, nullptr, nullptr));
         download_cast<double>(dH, (size_t)*k * *n, h, s);
         *out_status = 0;
     } catch (const std::exception& e) {

@@ -7,17 +7,17 @@
 template <class T, int KP>
 static void cd_lane_launch(rcppml_hip_ctx* c, const T* Gp, const T* invd, const T* B, T* X, int k,
                            int64_t ncols, T l1_pre, int warm, int zero_init, T l1_cd, T l2_cd, int nonneg,
-                           int maxit, T tol, T ub_cd, T ub_post, int* sweeps) {
+                           int maxit, T tol, T ub_cd, T ub_post, int* sweeps, const int* order) {
     constexpr bool EXACT = std::is_same<T, double>::value;
     const int64_t nblk = (ncols + 63) / 64;
     hipLaunchKernelGGL((cd_lane_kernel<T, KP, EXACT>), dim3((unsigned)nblk), dim3(64), 0, c->stream, Gp, invd,
-                       B, X, k, ncols, l1_pre, warm, zero_init, l1_cd, l2_cd, nonneg, maxit, tol, ub_cd, ub_post, sweeps);
+                       B, X, k, ncols, l1_pre, warm, zero_init, l1_cd, l2_cd, nonneg, maxit, tol, ub_cd, ub_post, sweeps, order);
     HIPCHK(hipGetLastError());
 }
 template <class T, int KP>
 static void cd_wave_launch(rcppml_hip_ctx* c, const T* Gp, const T* invd, const T* B, T* X, int k,
                            int64_t ncols, T l1_pre, int warm, int zero_init, T l1_cd, T l2_cd, int nonneg,
-                           int maxit, T tol, T ub_cd, T ub_post, int* sweeps) {
+                           int maxit, T tol, T ub_cd, T ub_post, int* sweeps, const int* order) {
     constexpr bool EXACT = std::is_same<T, double>::value;
     const size_t smem = (size_t)KP * KP * sizeof(T);
     auto kern = cd_wave_kernel<T, KP, EXACT>;
@@ -35,7 +35,7 @@ static void cd_wave_launch(rcppml_hip_ctx* c, const T* Gp, const T* invd, const 
     if (nblk > need) nblk = need;
     if (nblk < 1) nblk = 1;
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), smem, c->stream, Gp, invd, B, X, k, ncols, l1_pre,
-                       warm, zero_init, l1_cd, l2_cd, nonneg, maxit, tol, ub_cd, ub_post, sweeps);
+                       warm, zero_init, l1_cd, l2_cd, nonneg, maxit, tol, ub_cd, ub_post, sweeps, order);
     HIPCHK(hipGetLastError());
 }
 
@@ -44,7 +44,7 @@ static void cd_wave_launch(rcppml_hip_ctx* c, const T* Gp, const T* invd, const 
 template <class T, int KP, int LPC>
 static void cd_group_launch(rcppml_hip_ctx* c, const T* Gp, const T* invd, const T* B, T* X, int k, int64_t ncols,
                             T l1_pre, int warm, int zero_init, T l1_cd, T l2_cd, int nonneg, int maxit, T tol, T ub_cd,
-                            T ub_post, int* sweeps) {
+                            T ub_post, int* sweeps, const int* order) {
     constexpr bool EXACT = std::is_same<T, double>::value;
     const size_t smem = ((size_t)KP * KP + 2 * KP) * sizeof(T);
     auto kern = cd_group_kernel<T, KP, LPC, EXACT>;
@@ -56,7 +56,7 @@ static void cd_group_launch(rcppml_hip_ctx* c, const T* Gp, const T* invd, const
     const int64_t per_block = (int64_t)4 * (64 / LPC);
     const int64_t nblk = (ncols + per_block - 1) / per_block;
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), smem, c->stream, Gp, invd, B, X, k, ncols, l1_pre, warm,
-                       zero_init, l1_cd, l2_cd, nonneg, maxit, tol, ub_cd, ub_post, sweeps);
+                       zero_init, l1_cd, l2_cd, nonneg, maxit, tol, ub_cd, ub_post, sweeps, order);
     HIPCHK(hipGetLastError());
 }
 // LPC choice (measured on MI355X, k = 64, 20k..100k columns: 32 fp32 rows per lane beat 16 by 4-15 %, and for
@@ -77,7 +77,7 @@ static int pick_lpc(int KP) {
 template <class T>
 static void solve_cd_impl(rcppml_hip_ctx* c, const T* G, const T* B, T* X, int k, int64_t ncols, T l1_pre,
                           int warm, int zero_init, T l1_cd, T l2_cd, int nonneg, int maxit, T tol, T ub_cd,
-                          T ub_post, int variant, int* sweeps) {
+                          T ub_post, int variant, int* sweeps, const int* order) {
     if (ncols <= 0) return;
     if (k < 1 || k > 128) throw std::runtime_error("solve_cd: k must be in [1,128]");
     int KP = solve_kp(k);
@@ -94,7 +94,7 @@ static void solve_cd_impl(rcppml_hip_ctx* c, const T* G, const T* B, T* X, int k
     if (variant == RCPPML_CD_WAVE && KP < 64) KP = 64;   // the wave variant pads to a full 64-lane slab
     T *Gp, *invd;
     pad_impl<T>(c, G, k, KP, &Gp, &invd);
-#define CD_ARGS c, Gp, invd, B, X, k, ncols, l1_pre, warm, zero_init, l1_cd, l2_cd, nonneg, maxit, tol, ub_cd, ub_post, sweeps
+#define CD_ARGS c, Gp, invd, B, X, k, ncols, l1_pre, warm, zero_init, l1_cd, l2_cd, nonneg, maxit, tol, ub_cd, ub_post, sweeps, order
     if (variant == RCPPML_CD_LANE) {
         switch (KP) {
             case 16: cd_lane_launch<T, 16>(CD_ARGS); break;
