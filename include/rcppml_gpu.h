@@ -163,7 +163,7 @@ RCPPML_GPU_API int rcppml_hip_solve_chol(rcppml_hip_ctx* ctx, int dtype, const v
                                          const void* B, void* X, int k, int64_t ncols,
                                          double l1_pre, int nonneg, double ub_post);
 
-/* Row norms of X (k x c): out[i] = sum_j |X_ij| (norm_type 0) or sum_j X_ij^2 (norm_type 1);
+/* Row norms of X (k x c): out[i] = sum_j |X_ij| (norm_type 0), sum_j X_ij^2 (norm_type 1) or sum_j X_ij (norm_type 3);
  * no epsilon, no sqrt -- the distributed harness all-reduces these partial sums. */
 RCPPML_GPU_API int rcppml_hip_row_norms(rcppml_hip_ctx* ctx, int dtype, const void* X, int k,
                                         int64_t ncols, int norm_type, void* out);
@@ -201,6 +201,30 @@ RCPPML_GPU_API int rcppml_hip_loss_nonzeros(rcppml_hip_ctx* ctx, int dtype, cons
                                             const int* mask_p, const int* mask_i, int64_t ncols,
                                             const void* W_T, const void* d, const void* H, int k,
                                             double* out);
+
+/* NB (negative-binomial) IRLS half-update -- reference primitives/cpu/nnls_batch_irls.hpp:465-520,202-329 with the NB
+ * weight of math/loss.hpp:248-256: X = 0; per column up to irls_max_iter passes of
+ *   w_i = min(r/(mu(r+mu)), 1e6) at the column's nonzeros (mu = F(:,i).x, in fp64), G_w = G_base + F_nz diag(w-1) F_nz^T
+ *   (+ l2 on the diagonal), b_w = F_nz (w o a), b = b_w - G_w x, CD(G_w, b, x, L1 inside, cd_maxit sweeps, no tolerance),
+ *   stop when max |dx|/(|x_old|+1e-12) < irls_tol.
+ * theta_row: NB size indexed by the nonzero's row (H side) or theta_col: indexed by the column (W side over A^T);
+ * exactly one is non-NULL.  k <= 64. */
+RCPPML_GPU_API int rcppml_hip_solve_irls_nb(rcppml_hip_ctx* ctx, int dtype, const int* col_ptr, const int* row_idx,
+                                            const void* values, int64_t ncols, const void* F, const void* G_base,
+                                            void* X, int k, double l1, double l2, int nonneg, int cd_maxit,
+                                            int irls_max_iter, double irls_tol, const void* theta_row,
+                                            const void* theta_col);
+/* NB size (r) per ROW of A by the method of moments -- reference nmf/fit_cpu.hpp:1094-1265 (PER_ROW branch, sparse):
+ * r_i = clamp(S mu^2 / (S (y-mu)^2 - S mu), r_min, r_max), else r_max.  Takes CSC(A^T); W_T k x m, H k x n. */
+RCPPML_GPU_API int rcppml_hip_nb_size_update(rcppml_hip_ctx* ctx, int dtype, const int* t_col_ptr,
+                                             const int* t_row_idx, const void* t_values, int64_t m, const void* W_T,
+                                             const void* d, const void* H, int64_t n, int k, double r_min,
+                                             double r_max, void* nb_size);
+/* out[0] = NB negative log-likelihood over the NONZEROS of A with per-row size -- reference nmf/explicit_loss.hpp:53-77,
+ * math/loss.hpp:415-426. */
+RCPPML_GPU_API int rcppml_hip_nb_loss(rcppml_hip_ctx* ctx, int dtype, const int* col_ptr, const int* row_idx,
+                                      const void* values, int64_t ncols, const void* W_T, const void* d, const void* H,
+                                      const void* theta_row, int k, double* out);
 
 #ifdef __cplusplus
 }

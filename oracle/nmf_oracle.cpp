@@ -458,6 +458,33 @@ template <class S> static Csc<S> mk(int rows, int cols, const int* p, const int*
 DEFINE_PRIMS(f32, float)
 DEFINE_PRIMS(f64, double)
 
+
+// NB-IRLS primitives exposed for kernel-level parity tests
+#define DEFINE_NB(SUF, S)                                                                                    \
+    ORACLE_API void oracle_irls_nb_##SUF(int rows, int cols, const int* p, const int* i, const S* x, const S* F, \
+                                         const S* G, S* X, int k, S L1, S L2, int nonneg, int cd_maxit,           \
+                                         int irls_max_iter, S irls_tol, int threads, const S* theta_row,          \
+                                         const S* theta_col) {                                                    \
+        nnls_batch_irls_sparse_nb(mk(rows, cols, p, i, x), F, G, X, k, L1, L2, nonneg != 0, cd_maxit,             \
+                                  irls_max_iter, irls_tol, threads, theta_row, theta_col);                        \
+    }                                                                                                             \
+    ORACLE_API void oracle_nb_size_update_##SUF(int m, int n, const int* p, const int* i, const S* x,             \
+                                                const S* W_T, const S* H, const S* d, int k, int dispersion_mode, \
+                                                S r_min, S r_max, S* nb_size) {                                   \
+        FitConfig<S> c; c.k = k; c.dispersion_mode = dispersion_mode; c.nb_size_min = r_min; c.nb_size_max = r_max; \
+        std::vector<S> v(nb_size, nb_size + m);                                                                   \
+        nb_size_update(mk(m, n, p, i, x), W_T, H, d, k, c, v);                                                    \
+        std::memcpy(nb_size, v.data(), sizeof(S) * m);                                                            \
+    }                                                                                                             \
+    ORACLE_API S oracle_nb_loss_##SUF(int m, int n, const int* p, const int* i, const S* x, const S* W_T,         \
+                                      const S* d, const S* H, int k, const S* theta_row) {                        \
+        std::vector<S> Wd((size_t)k * m);                                                                         \
+        for (int r = 0; r < m; ++r) for (int f = 0; f < k; ++f) Wd[(size_t)r * k + f] = W_T[(size_t)r * k + f] * d[f]; \
+        return explicit_loss_sparse_nb(mk(m, n, p, i, x), Wd.data(), H, k, theta_row, 1);                         \
+    }
+DEFINE_NB(f32, float)
+DEFINE_NB(f64, double)
+
 // ---------------------------------------------------------------------------
 // src/RcppFunctions_utils.cpp:313-366  c_nnls (fp64): h = NNLS(w^T w, w^T A)
 //   w_T: k x m (already transposed), A: m x n CSC.  G gets eps TWICE (gram + :327).

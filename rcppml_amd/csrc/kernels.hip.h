@@ -770,7 +770,7 @@ __global__ __launch_bounds__(256) void row_norm_partial(const T* __restrict__ X,
         T acc = 0;
         for (int64_t c = c0 + slot; c < c1; c += slots) {
             const T v = X[c * (int64_t)k + f];
-            acc += norm_type == 0 ? tabs(v) : v * v;
+            acc += norm_type == 0 ? tabs(v) : (norm_type == 3 ? v : v * v);   // 3 = plain sum (H.rowwise().sum())
         }
         sh[threadIdx.x] = acc;
         __syncthreads();

@@ -1,0 +1,100 @@
+// ops_irls.hip -- NB-IRLS half-update, NB size update and NB loss (device-level C ABI, include/rcppml_gpu.h layer 2)
+#include "common.hip.h"
+#include "kernels_irls.hip.h"
+
+using namespace rk;
+
+template <class T>
+static void irls_impl(rcppml_hip_ctx* c, const int* cp, const int* ri, const T* vals, int64_t ncols, const T* F,
+                      const T* Gbase, T* X, int k, T l1, T l2, int nonneg, int cd_maxit, int irls_max_iter, T irls_tol,
+                      const T* theta_row, const T* theta_col) {
+    if (ncols <= 0) return;
+    if (k < 1 || k > 64) throw std::runtime_error("solve_irls_nb: k must be in [1,64]");
+    const size_t smem = (size_t)4 * 64 * 64 * sizeof(T);
+    auto kern = irls_nb_solve_kernel<T, 64>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        attr_set = true;
+    }
+    const int64_t nblk = (ncols + 3) / 4;
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), smem, c->stream, cp, ri, vals, ncols, F, Gbase, X, k, l1, l2,
+                       nonneg, cd_maxit, irls_max_iter, irls_tol, theta_row, theta_col);
+    HIPCHK(hipGetLastError());
+}
+extern "C" int rcppml_hip_solve_irls_nb(rcppml_hip_ctx* c, int dtype, const int* col_ptr, const int* row_idx,
+                                        const void* values, int64_t ncols, const void* F, const void* G_base, void* X,
+                                        int k, double l1, double l2, int nonneg, int cd_maxit, int irls_max_iter,
+                                        double irls_tol, const void* theta_row, const void* theta_col) {
+    try {
+        HIPCHK(hipSetDevice(c->device));
+        if (dtype == RCPPML_F32)
+            irls_impl<float>(c, col_ptr, row_idx, (const float*)values, ncols, (const float*)F, (const float*)G_base,
+                             (float*)X, k, (float)l1, (float)l2, nonneg, cd_maxit, irls_max_iter, (float)irls_tol,
+                             (const float*)theta_row, (const float*)theta_col);
+        else
+            irls_impl<double>(c, col_ptr, row_idx, (const double*)values, ncols, (const double*)F, (const double*)G_base,
+                              (double*)X, k, l1, l2, nonneg, cd_maxit, irls_max_iter, irls_tol, (const double*)theta_row,
+                              (const double*)theta_col);
+        return 0;
+    }
+    RCPPML_CATCH_RET
+}
+
+template <class T>
+static void nb_size_impl(rcppml_hip_ctx* c, int dtype, const int* tp, const int* ti, const T* tx, int64_t m, const T* W_T,
+                         const T* d, const T* H, int64_t n, int k, double r_min, double r_max, T* nb_size) {
+    if (k < 1 || k > 64) throw std::runtime_error("nb_size_update: k must be in [1,64]");
+    T* tmp = static_cast<T*>(c->scratch(WS_IRLS, ((size_t)k * k + k) * sizeof(T)));
+    T* G_H = tmp;
+    T* h_rs = tmp + (size_t)k * k;
+    if (rcppml_hip_gram(c, dtype, H, k, n, 1e-15, 0.0, G_H) != 0) throw std::runtime_error(rcppml_err());
+    if (rcppml_hip_row_norms(c, dtype, H, k, n, 3, h_rs) != 0) throw std::runtime_error(rcppml_err());
+    const int64_t nblk = (m + 3) / 4;
+    hipLaunchKernelGGL(nb_size_rows_kernel<T>, dim3((unsigned)nblk), dim3(256), 0, c->stream, tp, ti, tx, m, W_T, d, H, h_rs,
+                       G_H, k, r_min, r_max, nb_size);
+    HIPCHK(hipGetLastError());
+}
+extern "C" int rcppml_hip_nb_size_update(rcppml_hip_ctx* c, int dtype, const int* t_col_ptr, const int* t_row_idx,
+                                         const void* t_values, int64_t m, const void* W_T, const void* d, const void* H,
+                                         int64_t n, int k, double r_min, double r_max, void* nb_size) {
+    try {
+        HIPCHK(hipSetDevice(c->device));
+        if (dtype == RCPPML_F32)
+            nb_size_impl<float>(c, dtype, t_col_ptr, t_row_idx, (const float*)t_values, m, (const float*)W_T, (const float*)d,
+                                (const float*)H, n, k, r_min, r_max, (float*)nb_size);
+        else
+            nb_size_impl<double>(c, dtype, t_col_ptr, t_row_idx, (const double*)t_values, m, (const double*)W_T,
+                                 (const double*)d, (const double*)H, n, k, r_min, r_max, (double*)nb_size);
+        return 0;
+    }
+    RCPPML_CATCH_RET
+}
+
+template <class T>
+static void nb_loss_impl(rcppml_hip_ctx* c, const int* cp, const int* ri, const T* vals, int64_t ncols, const T* W_T,
+                         const T* d, const T* H, const T* theta_row, int k, double* out) {
+    const int64_t nblk = ncols > 0 ? (ncols + 3) / 4 : 1;
+    double* partial = static_cast<double*>(c->scratch(WS_RED2, (size_t)nblk * sizeof(double)));
+    hipLaunchKernelGGL(nb_loss_kernel<T>, dim3((unsigned)nblk), dim3(256), 0, c->stream, cp, ri, vals, ncols, W_T, d, H,
+                       theta_row, k, partial);
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(sum_partials, dim3(1), dim3(256), 0, c->stream, partial, (int)nblk, out);
+    HIPCHK(hipGetLastError());
+}
+extern "C" int rcppml_hip_nb_loss(rcppml_hip_ctx* c, int dtype, const int* col_ptr, const int* row_idx, const void* values,
+                                  int64_t ncols, const void* W_T, const void* d, const void* H, const void* theta_row, int k,
+                                  double* out) {
+    try {
+        HIPCHK(hipSetDevice(c->device));
+        if (k < 1 || k > 64) throw std::runtime_error("nb_loss: k must be in [1,64]");
+        if (dtype == RCPPML_F32)
+            nb_loss_impl<float>(c, col_ptr, row_idx, (const float*)values, ncols, (const float*)W_T, (const float*)d,
+                                (const float*)H, (const float*)theta_row, k, out);
+        else
+            nb_loss_impl<double>(c, col_ptr, row_idx, (const double*)values, ncols, (const double*)W_T, (const double*)d,
+                                 (const double*)H, (const double*)theta_row, k, out);
+        return 0;
+    }
+    RCPPML_CATCH_RET
+}

@@ -92,6 +92,11 @@ struct FitParams {
     const int* mask_p; const int* mask_i;   // NULL = no mask
     int sort_model;
     double* loss_history;                    // may be NULL
+    int loss_type = 0;                       // 0 = MSE, 5 = NB
+    int irls_max_iter = 5; double irls_tol = 1e-4;
+    int dispersion_mode = 2;                 // 0 none, 1 global, 2 per-row
+    double nb_size_init = 10, nb_size_max = 1e6, nb_size_min = 0.01;
+    double* out_theta = nullptr; int out_theta_len = 0;
     // outputs
     int out_iter = 0, out_converged = 0; double out_loss = 0, out_tol = 0;
 };
@@ -189,8 +194,16 @@ void fit(FitParams& P) {
     OPCHK(rcppml_hip_sumsq(c, dt, dAx.p, P.nnz, dtr.as<double>()));       // trAtA, primitives.hpp:100-115
     // CD work order: columns sorted by the sweeps of the previous iteration (results are order-independent)
     DevBuf dswH((size_t)n * sizeof(int)), dswW((size_t)m * sizeof(int)), dordH((size_t)n * sizeof(int)), dordW((size_t)m * sizeof(int));
-    const bool use_order = P.solver_mode == 0 && !has_mask && P.cd_tol > 0 && !getenv("RCPPML_GPU_NO_ORDER");
+    const bool use_order = P.solver_mode == 0 && !has_mask && P.loss_type == 0 && P.cd_tol > 0 && !getenv("RCPPML_GPU_NO_ORDER");
 
+    const bool is_nb = P.loss_type == 5;
+    DevBuf dtheta;
+    if (is_nb) {                                                        // fit_cpu.hpp:316-328
+        std::vector<T> th((size_t)m, static_cast<T>(P.dispersion_mode == 0 ? P.nb_size_max : P.nb_size_init));
+        dtheta.alloc((size_t)m * sizeof(T));
+        HIPCHK(hipMemcpyAsync(dtheta.p, th.data(), (size_t)m * sizeof(T), hipMemcpyHostToDevice, s));
+        HIPCHK(hipStreamSynchronize(s));
+    }
     const double eps = 1e-15;
     double prev_loss = std::numeric_limits<double>::max();
     if (std::is_same<T, float>::value) prev_loss = std::numeric_limits<float>::max();
@@ -202,7 +215,12 @@ void fit(FitParams& P) {
     for (int iter = 0; iter < P.max_iter; ++iter) {
         const int warm = iter > 0 ? 1 : 0;
         // ================= H half-update (fit_cpu.hpp:486-645)
-        if (has_mask) {
+        if (is_nb) {                                                                    // :565-606 (G: eps only)
+            OPCHK(rcppml_hip_gram(c, dt, dW.p, k, m, eps, 0.0, dG.p));
+            OPCHK(rcppml_hip_solve_irls_nb(c, dt, dAp.as<int>(), dAi.as<int>(), dAx.p, n, dW.p, dG.p, dH.p, k, P.L1_H, P.L2_H,
+                                           P.nonneg_H, P.cd_maxit, P.irls_max_iter, P.irls_tol, dtheta.p, nullptr));
+            if (P.ub_H > 0) throw std::runtime_error("upper bound with NB loss: not supported");
+        } else if (has_mask) {
             OPCHK(rcppml_hip_gram(c, dt, dW.p, k, m, eps, 0.0, dG.p));                 // :562 unmodified G
             OPCHK(rcppml_hip_solve_masked(c, dt, dAp.as<int>(), dAi.as<int>(), dAx.p, dMp.as<int>(), dMi.as<int>(),
                                           n, dW.p, dG.p, dH.p, k, P.L1_H, P.L2_H, P.nonneg_H, P.cd_maxit, P.cd_tol,
@@ -225,7 +243,11 @@ void fit(FitParams& P) {
         OPCHK(rcppml_hip_apply_scaling(c, dt, dH.p, k, n, P.norm_type, dsums.p, dd.p));
 
         // ================= W half-update (fit_cpu.hpp:711-893)
-        if (has_mask) {
+        if (is_nb) {                                                                    // :811-852 theta_per_col = r of the row
+            OPCHK(rcppml_hip_gram(c, dt, dH.p, k, n, eps, 0.0, dG.p));
+            OPCHK(rcppml_hip_solve_irls_nb(c, dt, dTp.as<int>(), dTi.as<int>(), dTx.p, m, dH.p, dG.p, dW.p, k, P.L1_W, P.L2_W,
+                                           P.nonneg_W, P.cd_maxit, P.irls_max_iter, P.irls_tol, nullptr, dtheta.p));
+        } else if (has_mask) {
             OPCHK(rcppml_hip_gram(c, dt, dH.p, k, n, eps, 0.0, dG.p));
             OPCHK(rcppml_hip_solve_masked(c, dt, dTp.as<int>(), dTi.as<int>(), dTx.p, dMTp.as<int>(), dMTi.as<int>(),
                                           m, dH.p, dG.p, dW.p, k, P.L1_W, P.L2_W, P.nonneg_W, P.cd_maxit, P.cd_tol,
@@ -248,8 +270,24 @@ void fit(FitParams& P) {
         OPCHK(rcppml_hip_row_norms(c, dt, dW.p, k, m, P.norm_type, dsums.p));           // :893
         OPCHK(rcppml_hip_apply_scaling(c, dt, dW.p, k, m, P.norm_type, dsums.p, dd.p));
 
-        // ================= loss (fit_cpu.hpp:1684-1753)
-        if (has_mask) {
+        // ================= NB size update (fit_cpu.hpp:1094-1265), then loss (fit_cpu.hpp:1684-1753)
+        if (is_nb && P.dispersion_mode != 0) {
+            OPCHK(rcppml_hip_nb_size_update(c, dt, dTp.as<int>(), dTi.as<int>(), dTx.p, m, dW.p, dd.p, dH.p, n, k,
+                                            P.nb_size_min, P.nb_size_max, dtheta.p));
+            if (P.dispersion_mode == 1) {          // GLOBAL: median (nth_element at m/2) of the per-row values
+                std::vector<T> th((size_t)m);
+                HIPCHK(hipMemcpyAsync(th.data(), dtheta.p, (size_t)m * sizeof(T), hipMemcpyDeviceToHost, s));
+                HIPCHK(hipStreamSynchronize(s));
+                std::nth_element(th.begin(), th.begin() + m / 2, th.end());
+                const T med = th[m / 2];
+                std::fill(th.begin(), th.end(), med);
+                HIPCHK(hipMemcpyAsync(dtheta.p, th.data(), (size_t)m * sizeof(T), hipMemcpyHostToDevice, s));
+                HIPCHK(hipStreamSynchronize(s));
+            }
+        }
+        if (is_nb) {
+            OPCHK(rcppml_hip_nb_loss(c, dt, dAp.as<int>(), dAi.as<int>(), dAx.p, n, dW.p, dd.p, dH.p, dtheta.p, k, dloss.as<double>()));
+        } else if (has_mask) {
             OPCHK(rcppml_hip_loss_nonzeros(c, dt, dAp.as<int>(), dAi.as<int>(), dAx.p, dMp.as<int>(), dMi.as<int>(), n,
                                            dW.p, dd.p, dH.p, k, dloss.as<double>()));
         } else {
@@ -286,6 +324,11 @@ void fit(FitParams& P) {
     }
     if (!converged) train_loss = last_loss;
 
+    if (is_nb && P.out_theta) {
+        DevBuf& th = dtheta;
+        download_cast<T>(th, (size_t)m, P.out_theta, s);
+        P.out_theta_len = m;
+    }
     // ---- download, sort by descending d (core/result.hpp:169-188)
     download_cast<T>(dW, (size_t)k * m, P.W, s);
     download_cast<T>(dH, (size_t)k * n, P.H, s);
@@ -310,15 +353,20 @@ void nmf_entry(RCPPML_NMF_UNIFIED_ARGS, const int* mask_p, const int* mask_i, do
         rcppml_err().clear();
         *out_status = -1;
         *out_theta_len = 0;
-        (void)seed; (void)loss_every; (void)huber_delta; (void)irls_max_iter; (void)irls_tol;
+        (void)seed; (void)loss_every; (void)huber_delta;
         (void)graph_W_p; (void)graph_W_i; (void)graph_W_x; (void)graph_W_dim; (void)graph_W_lambda;
         (void)graph_H_p; (void)graph_H_i; (void)graph_H_x; (void)graph_H_dim; (void)graph_H_lambda;
-        (void)gp_dispersion_mode; (void)gp_theta_init; (void)gp_theta_max; (void)gp_theta_min;
-        (void)nb_size_init; (void)nb_size_max; (void)nb_size_min; (void)gamma_phi_init; (void)gamma_phi_max;
-        (void)gamma_phi_min; (void)tweedie_power; (void)out_theta; (void)guide_H_labels_flat; (void)guide_H_ns;
+        (void)gp_theta_init; (void)gp_theta_max; (void)gp_theta_min; (void)gamma_phi_init; (void)gamma_phi_max;
+        (void)gamma_phi_min; (void)tweedie_power; (void)guide_H_labels_flat; (void)guide_H_ns;
         (void)guide_H_lambdas; (void)guide_H_ncs;
         // Reject what is not implemented so the caller falls back to CPU (SURVEY.md 8b "Semantics")
-        if (*loss_type != 0) throw std::runtime_error("loss_type != MSE not supported by this plugin build");
+        if (*loss_type != 0 && *loss_type != 5) throw std::runtime_error("loss_type must be MSE (0) or NB (5) for this plugin build");
+        if (*loss_type == 5) {
+            if (*k > 64) throw std::runtime_error("NB loss: k must be <= 64");
+            if (*gp_dispersion_mode == 3) throw std::runtime_error("NB loss: dispersion='per_col' not supported");
+            if (*solver_mode != 0) throw std::runtime_error("NB loss requires the CD solver");      // core/config.hpp:447-452
+            if (mask_p) throw std::runtime_error("NB loss with explicit mask: not supported");
+        }
         if (*robust_delta > 0) throw std::runtime_error("robust loss not supported");
         if (*L21_H != 0 || *L21_W != 0) throw std::runtime_error("L21 not supported");
         if (*ortho_H != 0 || *ortho_W != 0) throw std::runtime_error("angular penalty not supported");
@@ -342,8 +390,12 @@ void nmf_entry(RCPPML_NMF_UNIFIED_ARGS, const int* mask_p, const int* mask_i, do
         P.norm_type = *norm_type; P.solver_mode = *solver_mode;
         P.mask_p = mask_p; P.mask_i = mask_i;
         P.sort_model = sort_model; P.loss_history = loss_history;
+        P.loss_type = *loss_type; P.irls_max_iter = *irls_max_iter; P.irls_tol = *irls_tol;
+        P.dispersion_mode = *gp_dispersion_mode; P.nb_size_init = *nb_size_init; P.nb_size_max = *nb_size_max;
+        P.nb_size_min = *nb_size_min; P.out_theta = out_theta;
         if (precision == RCPPML_F64) fit<double>(P); else fit<float>(P);
         *out_iter = P.out_iter; *out_converged = P.out_converged; *out_loss = P.out_loss; *out_tol = P.out_tol;
+        *out_theta_len = P.out_theta_len;
         *out_status = 0;
     } catch (const std::exception& e) {
         rcppml_err() = e.what();

@@ -2,7 +2,7 @@
 
 Same argument names, meaning, defaults and error behaviour as the R functions (R/nmf_thin.R:219-229,
 R/solve.R:84, R/predict_nmf.R:48, R/nmf_methods.R:356), restricted to what the MI355X plugin implements
-(MSE loss, CD or Cholesky+clip, L1/L2/upper bounds, non-negativity flags, explicit mask, L1/L2/no normalisation).
+(MSE and NB loss, CD or Cholesky+clip, L1/L2/upper bounds, non-negativity flags, explicit mask, L1/L2/no normalisation).
 All compute goes through RcppML_gpu.so (rcppml_amd._abi); anything else raises -- there is no CPU path here.
 """
 import numpy as np
@@ -69,7 +69,8 @@ def select_solver(solver, k, L1, loss="mse", use_gpu=True):
 def nmf(data, k, tol=1e-4, maxit=100, L1=(0.0, 0.0), L2=(0.0, 0.0), seed=None, mask=None, loss="mse",
         nonneg=(True, True), test_fraction=0, verbose=False, projective=False, symmetric=False, zi="none",
         robust=False, *, solver="auto", upper_bound=(0.0, 0.0), cd_maxit=100, cd_tol=1e-8, norm="L1", sort_model=True,
-        patience=5, h_init=None, precision="fp32", resource="gpu"):
+        patience=5, h_init=None, precision="fp32", resource="gpu", dispersion="per_row", irls_max_iter=5, irls_tol=1e-4,
+        nb_size_init=10.0, nb_size_max=1e6, nb_size_min=0.01):
     """Non-negative matrix factorisation A ~ w diag(d) h by alternating NNLS on the MI355X.
 
     `L1`, `L2`, `upper_bound`, `nonneg` are c(w, h) pairs (src/RcppFunctions_nmf.cpp:59-62).
@@ -79,8 +80,10 @@ def nmf(data, k, tol=1e-4, maxit=100, L1=(0.0, 0.0), L2=(0.0, 0.0), seed=None, m
     """
     if loss not in _LOSSES:
         raise ValueError("'arg' should be one of %s" % ", ".join(repr(x) for x in _LOSSES))
-    if loss != "mse" or robust or zi != "none":
-        raise NotImplementedError("only loss='mse' (no robust / zero-inflation) is implemented by the MI355X backend")
+    if loss not in ("mse", "nb") or robust or zi != "none":
+        raise NotImplementedError("only loss='mse' and loss='nb' (no robust / zero-inflation) are implemented by the MI355X backend")
+    if dispersion not in ("none", "global", "per_row"):
+        raise NotImplementedError("dispersion must be 'none', 'global' or 'per_row' on the MI355X backend")
     if projective or symmetric:
         raise NotImplementedError("projective / symmetric NMF are not implemented by the MI355X backend")
     if test_fraction and test_fraction > 0:
@@ -141,13 +144,18 @@ def nmf(data, k, tol=1e-4, maxit=100, L1=(0.0, 0.0), L2=(0.0, 0.0), seed=None, m
                            L1_W=L1w, L2_H=L2h, L2_W=L2w, ub_H=ubh, ub_W=ubw, cd_maxit=int(cd_maxit), verbose=int(verbose),
                            seed=seed_int & 0x7FFFFFFF, patience=int(patience), nonneg_W=int(nnw), nonneg_H=int(nnh),
                            norm_type=norm_type, solver_mode=0 if solver == "cd" else 1, mask=mask_arg, cd_tol=float(cd_tol),
+                           loss_type=5 if loss == "nb" else 0, irls_max_iter=int(irls_max_iter), irls_tol=float(irls_tol),
+                           gp_dispersion_mode={"none": 0, "global": 1, "per_row": 2}[dispersion],
+                           nb_size=(nb_size_init, nb_size_max, nb_size_min),
                            sort_model=int(sort_model), precision=_abi.F32 if precision == "fp32" else _abi.F64,
                            want_history=True)
     if res["status"] != 0:
         raise _abi.BackendError("GPU NMF failed: %s" % res.get("error"))
     misc = dict(tol=res["tol"], iter=res["iter"], loss=res["loss"], loss_history=res.get("loss_history"),
                 converged=res["converged"], solver=solver, solver_mode=0 if solver == "cd" else 1, L1=(L1w, L1h),
-                L2=(L2w, L2h), seed=seed_int, precision=precision, resource="gpu")
+                L2=(L2w, L2h), seed=seed_int, precision=precision, resource="gpu", loss_type=loss)
+    if loss == "nb":
+        misc["theta"] = res["theta"]                                   # R: misc$theta (RcppFunctions_nmf.cpp:156-158)
     return NMFModel(w=W_T.copy(), d=res["d"], h=H.T.copy(), misc=misc)
 
 

@@ -1,0 +1,107 @@
+"""GPU parity tests of the NB (negative-binomial) IRLS path -- BASELINE config 5 shape at test size
+(reference primitives/cpu/nnls_batch_irls.hpp, nmf/fit_cpu.hpp:1094-1265, nmf/explicit_loss.hpp) -- kernel level
+and through the 73-pointer plugin entry with loss_type = 5.
+
+Tolerances: the IRLS weights hit the 1e6 cap on the first pass (x = 0) and the weighted Gram is a sum of up to
+thousands of rank-1 terms with weights spanning 6 orders of magnitude, so fp64 agreement is ~1e-8, fp32 ~1e-2 on
+individual solutions; the NB loss (a sum over all nonzeros) agrees far tighter."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _nb_problem(m, n, k, seed):
+    from rcppml_amd import data
+    A, w, h = data.simulate_nb_counts(m, n, k, density=0.15, size=5.0, seed=seed)
+    return O.Csc(A.shape, A.p, A.i, A.x)
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    from rcppml_amd import _abi
+    return torch, _abi, _abi.Context(0)
+
+
+def _dev(torch, a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-7), (np.float32, 3e-2)])
+@pytest.mark.parametrize("k", [4, 16, 32, 64])
+def test_irls_nb_half_updates(env, dtype, tol, k):
+    torch, _abi, ctx = env
+    A = _nb_problem(150, 220, 4, seed=k)
+    At = A.transpose()
+    rng = np.random.default_rng(k)
+    dt = _abi.F32 if dtype == np.float32 else _abi.F64
+    tt = torch.float32 if dtype == np.float32 else torch.float64
+    for (M, F_rows, by_row) in ((A, A.rows, True), (At, At.rows, False)):
+        F = rng.uniform(0.05, 1.0, size=(F_rows, k)).astype(dtype)
+        F /= F.sum(axis=0, keepdims=True)
+        F *= 30.0
+        G = O.gram(F)
+        theta = rng.uniform(2.0, 20.0, size=(M.rows if by_row else M.cols)).astype(dtype)
+        ref = O.irls_nb(M, F, G, k, L1=0.0, L2=1e-3, theta_row=theta if by_row else None,
+                        theta_col=None if by_row else theta, dtype=dtype)
+        dX = torch.full((M.cols, k), 3.0, dtype=tt, device="cuda")
+        ctx.solve_irls_nb(dt, _dev(torch, M.p), _dev(torch, M.i), _dev(torch, M.values(dtype)), M.cols, _dev(torch, F),
+                          _dev(torch, G), dX, k, l1=0.0, l2=1e-3, theta_row=_dev(torch, theta) if by_row else None,
+                          theta_col=None if by_row else _dev(torch, theta))
+        X = dX.cpu().numpy()
+        assert X.min() >= 0 and np.all(np.isfinite(X))
+        assert np.abs(X - ref).max() / np.abs(ref).max() < tol
+
+
+@pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-9), (np.float32, 2e-3)])
+def test_nb_size_and_loss(env, dtype, tol):
+    torch, _abi, ctx = env
+    A = _nb_problem(120, 180, 3, seed=5)
+    At = A.transpose()
+    k = 8
+    rng = np.random.default_rng(1)
+    W_T = rng.uniform(size=(A.rows, k)).astype(dtype); W_T /= W_T.sum(axis=0, keepdims=True)
+    H = rng.uniform(size=(A.cols, k)).astype(dtype); H /= H.sum(axis=0, keepdims=True)
+    d = rng.uniform(50, 500, size=k).astype(dtype)
+    th0 = np.full(A.rows, 10.0, dtype)
+    ref_r = O.nb_size_update(A, W_T, H, d, th0, dtype=dtype)
+    dt = _abi.F32 if dtype == np.float32 else _abi.F64
+    dth = _dev(torch, th0)
+    ctx.nb_size_update(dt, _dev(torch, At.p), _dev(torch, At.i), _dev(torch, At.values(dtype)), A.rows, _dev(torch, W_T),
+                       _dev(torch, d), _dev(torch, H), A.cols, k, 0.01, 1e6, dth)
+    r = dth.cpu().numpy()
+    assert np.abs(r - ref_r).max() / np.abs(ref_r).max() < tol * 10
+    out = torch.zeros(2, dtype=torch.float64, device="cuda")
+    ctx.nb_loss(dt, _dev(torch, A.p), _dev(torch, A.i), _dev(torch, A.values(dtype)), A.cols, _dev(torch, W_T), _dev(torch, d),
+                _dev(torch, H), _dev(torch, ref_r), k, out)
+    ref_l = O.nb_loss(A, W_T, d, H, ref_r, dtype=dtype)
+    assert abs(out[0].item() - ref_l) / abs(ref_l) < tol
+
+
+@pytest.mark.parametrize("dispersion", [2, 1, 0])
+def test_nb_fit_through_plugin(dispersion):
+    """nmf(loss='nb') through rcppml_gpu_nmf_unified_double (loss_type = 5): theta returned through out_theta."""
+    from rcppml_amd import _abi
+    A = _nb_problem(100, 160, 3, seed=9)
+    k = 5
+    W0, H0 = O.init_factors(11, k, A.rows, A.cols, np.float64)
+    ref = O.nmf_fit(A, W0, H0, np.float64, max_iter=6, tol=0.0, loss_type=5, dispersion_mode=dispersion, threads=1)
+    W, H = W0.copy(), H0.copy()
+    res = _abi.nmf_unified(A.p, A.i, A.x, A.rows, A.cols, k, W, H, entry="double", max_iter=6, tol=0.0, loss_type=5,
+                           gp_dispersion_mode=dispersion)
+    assert res["status"] == 0, res.get("error")
+    assert res["iter"] == ref.iter
+    # NB-IRLS amplifies rounding: first-pass weights sit at the 1e6 cap and the size estimate divides by an
+    # "excess variance" that is a difference of large sums, so individual r_i can move by percents for 1e-6 changes
+    # of the factors.  Loss and factors stay tight; theta is compared in distribution.
+    assert abs(res["loss"] - ref.loss) / abs(ref.loss) < 1e-5
+    assert np.abs(W - ref.W_T).max() < 1e-4 and np.abs(H - ref.H).max() < 1e-4
+    assert np.abs(res["d"] - ref.d).max() / ref.d.max() < 1e-4
+    assert len(res["theta"]) == A.rows
+    rel = np.abs(res["theta"] - ref.theta) / np.abs(ref.theta)
+    print("theta rel err: median %.2e p99 %.2e max %.2e" % (np.median(rel), np.percentile(rel, 99), rel.max()))
+    assert np.median(rel) < 1e-4 and rel.max() < 0.2
+    assert np.all(res["theta"] >= 0.01) and np.all(res["theta"] <= 1e6)
