@@ -37,7 +37,7 @@ inline std::string& rcppml_err() {
         return 1;                                             \
     }
 
-enum { WS_GRAM = 0, WS_GPAD, WS_CHOL, WS_RED, WS_RED2, WS_ORDER, WS_IRLS, WS_COUNT };
+enum { WS_GRAM = 0, WS_GPAD, WS_CHOL, WS_RED, WS_RED2, WS_ORDER, WS_IRLS, WS_MFMA, WS_COUNT };
 
 struct rcppml_hip_ctx {
     int device = 0;

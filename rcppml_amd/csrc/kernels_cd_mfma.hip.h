@@ -1,0 +1,242 @@
+// ============================================================================
+// kernels_cd_mfma.hip.h -- coordinate-descent NNLS with the rank-1 residual updates on the MATRIX cores (fp32).
+//
+// Reference routine: primitives/cpu/nnls_batch.hpp:70-132 (cd_nnls_col_fixed), prologue fused_nnls.hpp:116-123.
+//
+// Idea.  A wave solves 64 columns.  Their residuals B (KP rows x 64 columns) live in MFMA accumulator tiles
+// (v_mfma_f32_32x32x2_f32: RT row tiles x 2 column tiles of 32x32, 16 VGPRs each).  One CD coordinate i changes all
+// residuals by the outer product  B -= G(:,i) a_i^T  (a_i = the 64 columns' steps): exactly the K-slot of an MFMA.
+// Two consecutive coordinates fill the two K-slots of 32x32x2, so ONE instruction per tile applies coordinates i and
+// i+1 (accumulation order inside the instruction is slot 0 then slot 1 = the reference's order, each a single-rounded
+// fma, so results equal the VALU kernels').  What this buys on MI355X:
+//   * G enters LANE-DISTRIBUTED (lane l supplies G[row l&31][coordinate i + (l>>5)]): one conflict-free ds_read_b32 per
+//     row tile and coordinate pair, instead of broadcasting every G element to all lanes (which saturates the LDS);
+//   * the KP fmas per column and coordinate leave the VALU, which keeps only the ~12-op scalar step of the reference;
+//     matrix and vector pipes run concurrently (two waves per SIMD keep the matrix pipe busy).
+// Data placement trick: the logical row <-> accumulator position map is chosen so that logical rows 2q and 2q+1 of a
+// tile sit in the SAME accumulator register q, in the low (lanes 0-31) and high (lanes 32-63) half respectively
+// (C/D map of the 32x32 MFMA: row = (v&3) + 8(v>>2) + 4(lane>>5); we store logical row 32rt + 2v + (lane>>5) there
+// and permute the rows of G to match).  Hence for the coordinate pair (i, i+1) = (32rt+2q, 32rt+2q+1):
+//   low half  holds b_i   for its two columns (column tiles 0/1) in acc[rt][ct][q]  -> computes a_i,
+//   high half holds b_i+1 for the same columns in the same register               -> computes a_i+1 after the lazy
+//   Gauss-Seidel correction  b_i+1 -= G(i+1,i) a_i  (a_i fetched from the low half with one v_permlane32_swap),
+// and the resulting register {a_i | a_i+1} IS the MFMA B operand (B[kk = lane>>5][col = lane&31]) with no data movement.
+// The iterate x uses the same register layout.  Finished columns are frozen (step forced to 0).
+// The per-column tolerance sum is accumulated per half (even / odd coordinates) and added at the end of the sweep --
+// the only reassociation relative to the sequential reference.
+// ============================================================================
+#pragma once
+#include "kernels.hip.h"
+
+namespace rk {
+
+// Gq[i*KP + p] = -G(lrow(p), i) with p = 32*rt + r', lrow = 32*rt + 2*v + h, h = (r'>>2)&1, v = (r'&3) + 4*(r'>>3);
+// gnx[i] = G(i+1, i) (used for even i).  Gp: padded KP x KP Gram, column i contiguous.
+static __global__ void cd_mfma_prep_kernel(const float* __restrict__ Gp, int KP, float* __restrict__ Gq,
+                                           float* __restrict__ gnx) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= KP * KP) return;
+    const int i = e / KP, p = e % KP;
+    const int rt = p >> 5, r = p & 31;
+    const int h = (r >> 2) & 1, v = (r & 3) + 4 * (r >> 3);
+    const int lrow = 32 * rt + 2 * v + h;
+    Gq[e] = -Gp[i * KP + lrow];
+    if (p == 0) gnx[i] = (i + 1 < KP) ? Gp[i * KP + i + 1] : 0.f;
+}
+
+struct CdStepOut { float a, nx, t; };
+
+// The reference's scalar step.  SIMPLE = non-negativity only (no upper bound, no in-CD L1/L2): what every NMF
+// half-update uses; the general form serves nnls()/predict() (L1 inside CD, box constraints, nonneg = FALSE).
+template <bool SIMPLE>
+__device__ __forceinline__ CdStepOut cd_scalar_step(float b, float xo, float ginv, bool active, float l1_cd, float l2_cd,
+                                                    float lo, float hi) {
+    CdStepOut o;
+    if constexpr (SIMPLE) {
+        const float diff = b * ginv;
+        const float nv = xo + diff;
+        const bool neg = nv < 0.f;
+        float nx = neg ? 0.f : nv;
+        float a = neg ? -xo : diff;
+        const bool on = active && (ginv > 0.f);  // reference: `if (g_diag <= 0) continue;`; frozen columns do not move
+        a = on ? a : 0.f;
+        nx = on ? nx : xo;
+        o.a = a;
+        o.nx = nx;
+        o.t = tabs(a) * __builtin_amdgcn_rcpf(tabs(nx) + 1e-15f);
+    } else {
+        float diff = b * ginv;
+        diff -= l1_cd;                        // reference: `if (L1 != 0) diff -= L1` (subtracting 0 is exact)
+        diff = __builtin_fmaf(l2_cd, xo, diff);
+        const float nv = xo + diff;
+        const bool neg = nv < lo, up = nv > hi;
+        float nx = neg ? lo : (up ? hi : nv);
+        float a = neg ? lo - xo : (up ? hi - xo : diff);
+        const bool on = active && (ginv > 0.f);
+        a = on ? a : 0.f;
+        nx = on ? nx : xo;
+        o.a = a;
+        o.nx = nx;
+        o.t = tabs(a) * __builtin_amdgcn_rcpf(tabs(nx) + 1e-15f);
+    }
+    return o;
+}
+
+template <int RT, int CT, bool SIMPLE>   // KP = 32*RT rows (k <= KP), 32*CT columns per wave, 4 waves per block share G
+__global__ __launch_bounds__(256) void cd_mfma_kernel(const float* __restrict__ Gq, const float* __restrict__ invd,
+                                                       const float* __restrict__ gnx, const float* __restrict__ B,
+                                                       float* __restrict__ X, int k, int64_t ncols, float l1_pre,
+                                                       int warm, int zero_init, float l1_cd, float l2_cd, int nonneg,
+                                                       int maxit, float tol, float ub_cd, float ub_post,
+                                                       int* __restrict__ sweeps, const int* __restrict__ order) {
+    constexpr int KP = 32 * RT;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* Gs = reinterpret_cast<float*>(smem_raw);      // KP*KP: Gs[i*KP + p] = -G(lrow(p), i)
+    float* ginv_s = Gs + KP * KP;                         // KP
+    float* gnx_s = ginv_s + KP;                           // KP
+    for (int e = threadIdx.x; e < KP * KP; e += blockDim.x) Gs[e] = Gq[e];
+    for (int e = threadIdx.x; e < KP; e += blockDim.x) { ginv_s[e] = invd[e]; gnx_s[e] = gnx[e]; }
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int half = lane >> 5, cl = lane & 31;
+    const int64_t base = ((int64_t)blockIdx.x * (blockDim.x >> 6) + wave) * (32 * CT);
+    if (base >= ncols) return;
+    int64_t j[CT];
+    bool inb[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        const int64_t slot = base + ct * 32 + cl;
+        inb[ct] = slot < ncols;
+        j[ct] = (inb[ct] && order) ? order[slot] : slot;
+    }
+    f32x16 acc[RT][CT];
+    float xr[RT][CT][16];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            const float* bj = B + j[ct] * (int64_t)k;
+            const float* xj = X + j[ct] * (int64_t)k;
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int row = 32 * rt + 2 * v + half;
+                const bool ok = inb[ct] && row < k;
+                float bv = ok ? bj[row] : 0.f;
+                if (ok && l1_pre != 0.f) bv -= l1_pre;
+                acc[rt][ct][v] = bv;
+                xr[rt][ct][v] = (ok && !zero_init) ? xj[row] : 0.f;
+            }
+        }
+    if (warm) {   // B -= G X (fused_nnls.hpp:121-123): the same MFMA stream with x in place of the steps
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int i = 32 * rt + 2 * q;
+#pragma unroll
+                for (int rt2 = 0; rt2 < RT; ++rt2) {
+                    const float av = Gs[(i + half) * KP + 32 * rt2 + cl];
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct)
+                        acc[rt2][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, xr[rt][ct][q], acc[rt2][ct], 0, 0, 0);
+                }
+            }
+    }
+    const float lo = nonneg ? 0.f : -INFINITY;
+    const float hi = ub_cd > 0.f ? ub_cd : INFINITY;
+    const bool check = tol > 0.f;
+    const float inv_k = 1.f / static_cast<float>(k);
+    bool active[CT];
+    int nsweep[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) { active[ct] = inb[ct]; nsweep[ct] = 0; }
+    // LDS operands of the first pair; every pair then requests the NEXT pair's operands before it starts computing,
+    // so their latency hides behind the current pair (the last pair of a sweep prefetches pair 0 again)
+    float ginv_c = ginv_s[half], gnx_c = gnx_s[0];
+    float av_c[RT];
+#pragma unroll
+    for (int rt2 = 0; rt2 < RT; ++rt2) av_c[rt2] = Gs[half * KP + 32 * rt2 + cl];
+    for (int it = 0; it < maxit; ++it) {
+        bool any_active = false;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) any_active |= active[ct];
+        if (!__any(any_active)) break;
+        float tsum[CT];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) { tsum[ct] = 0.f; nsweep[ct] += active[ct] ? 1 : 0; }
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                // low half: coordinate i = 32rt + 2q, high half: coordinate i + 1
+                constexpr int KPc = KP;
+                const int inext = (32 * rt + 2 * q + 2) % KPc;
+                const float ginv_n = ginv_s[inext + half];
+                const float gnx_n = gnx_s[inext];                 // G(i+1, i) of the next pair, wave-uniform
+                float av_n[RT];
+#pragma unroll
+                for (int rt2 = 0; rt2 < RT; ++rt2) av_n[rt2] = Gs[(inext + half) * KP + 32 * rt2 + cl];
+                const float ginv = ginv_c, g_oe = gnx_c;
+                float aval[CT];
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) {
+                    const float b = acc[rt][ct][q];
+                    const float xo = xr[rt][ct][q];
+                    // even coordinate (meaningful in the low half)
+                    const CdStepOut e = cd_scalar_step<SIMPLE>(b, xo, ginv, active[ct], l1_cd, l2_cd, lo, hi);
+                    // its step, seen from the high half (same column, lane - 32)
+                    const unsigned ae_bits = __float_as_uint(e.a);
+                    const float ae_lo = __uint_as_float(__builtin_amdgcn_permlane32_swap(ae_bits, ae_bits, false, false)[0]);
+                    // odd coordinate (meaningful in the high half): lazy Gauss-Seidel correction, then the step
+                    const float bo = __builtin_fmaf(-g_oe, ae_lo, b);
+                    const CdStepOut o = cd_scalar_step<SIMPLE>(bo, xo, ginv, active[ct], l1_cd, l2_cd, lo, hi);
+                    const bool is_lo = half == 0;
+                    aval[ct] = is_lo ? e.a : o.a;
+                    xr[rt][ct][q] = is_lo ? e.nx : o.nx;
+                    tsum[ct] += is_lo ? e.t : o.t;
+                }
+                // the row tile that holds the NEXT pair's residuals goes first, so its results are back while the
+                // other tiles still occupy the matrix pipe
+#pragma unroll
+                for (int s2 = 0; s2 < RT; ++s2) {
+                    const int rt2 = ((q == 15 ? rt + 1 : rt) + s2) % RT;
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct)
+                        acc[rt2][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(av_c[rt2], aval[ct], acc[rt2][ct], 0, 0, 0);
+                }
+                ginv_c = ginv_n;
+                gnx_c = gnx_n;
+#pragma unroll
+                for (int rt2 = 0; rt2 < RT; ++rt2) av_c[rt2] = av_n[rt2];
+                // one scheduling region per coordinate pair: without it hipcc hoists the LDS reads of many pairs and
+                // spends > 380 registers on this fully unrolled sweep
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        // branch-free on purpose: behind an `if (check)` LLVM sinks all 64 tolerance terms of the sweep into the
+        // branch and keeps every step and iterate of the sweep alive for it (+128 registers)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            const float tot = tsum[ct] + __shfl_xor(tsum[ct], 32, 64);       // even + odd coordinates
+            active[ct] = active[ct] && !(check && tot * inv_k < tol);
+        }
+    }
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        if (!inb[ct]) continue;
+        float* xj = X + j[ct] * (int64_t)k;
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int row = 32 * rt + 2 * v + half;
+                if (row < k) {
+                    float val = xr[rt][ct][v];
+                    if (ub_post > 0.f) val = val < ub_post ? val : ub_post;
+                    xj[row] = val;
+                }
+            }
+        if (sweeps && half == 0) sweeps[j[ct]] = nsweep[ct];
+    }
+}
+
+}  // namespace rk

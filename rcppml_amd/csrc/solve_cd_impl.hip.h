@@ -1,6 +1,7 @@
 // solve_cd_impl.hip.h -- CD solve launch logic (instantiated per dtype in ops_cd_f32.hip / ops_cd_f64.hip)
 #pragma once
 #include "solve_common.hip.h"
+#include "kernels_cd_mfma.hip.h"
 // ----------------------------------------------------------------------------
 // CD solve
 // ----------------------------------------------------------------------------
@@ -59,6 +60,30 @@ static void cd_group_launch(rcppml_hip_ctx* c, const T* Gp, const T* invd, const
                        zero_init, l1_cd, l2_cd, nonneg, maxit, tol, ub_cd, ub_post, sweeps, order);
     HIPCHK(hipGetLastError());
 }
+
+// MFMA variant (fp32, k <= 64): rank-1 residual updates on the matrix cores, 32*CT columns per wave.
+template <int RT, int CT>
+static void cd_mfma_launch(rcppml_hip_ctx* c, const float* Gp, const float* invd, const float* B, float* X, int k,
+                           int64_t ncols, float l1_pre, int warm, int zero_init, float l1_cd, float l2_cd, int nonneg,
+                           int maxit, float tol, float ub_cd, float ub_post, int* sweeps, const int* order) {
+    constexpr int KP = 32 * RT;
+    float* Gq = static_cast<float*>(c->scratch(WS_MFMA, ((size_t)KP * KP + KP) * sizeof(float)));
+    float* gnx = Gq + (size_t)KP * KP;
+    hipLaunchKernelGGL(cd_mfma_prep_kernel, dim3((KP * KP + 255) / 256), dim3(256), 0, c->stream, Gp, KP, Gq, gnx);
+    HIPCHK(hipGetLastError());
+    const size_t smem = ((size_t)KP * KP + 2 * KP) * sizeof(float);
+    const int64_t per_block = 4 * 32 * CT;          // 4 waves per block
+    const int64_t nblk = (ncols + per_block - 1) / per_block;
+    const bool simple = nonneg && ub_cd <= 0.f && l1_cd == 0.f && l2_cd == 0.f;
+    if (simple)
+        hipLaunchKernelGGL((cd_mfma_kernel<RT, CT, true>), dim3((unsigned)nblk), dim3(256), smem, c->stream, Gq, invd, gnx, B, X,
+                           k, ncols, l1_pre, warm, zero_init, l1_cd, l2_cd, nonneg, maxit, tol, ub_cd, ub_post, sweeps, order);
+    else
+        hipLaunchKernelGGL((cd_mfma_kernel<RT, CT, false>), dim3((unsigned)nblk), dim3(256), smem, c->stream, Gq, invd, gnx, B, X,
+                           k, ncols, l1_pre, warm, zero_init, l1_cd, l2_cd, nonneg, maxit, tol, ub_cd, ub_post, sweeps, order);
+    HIPCHK(hipGetLastError());
+}
+
 // LPC choice (measured on MI355X, k = 64, 20k..100k columns: 32 fp32 rows per lane beat 16 by 4-15 %, and for
 // fp64 16 rows per lane are as good as 32 at half the registers): fp32 -> KP/32 lanes per column, fp64 -> KP/16,
 // clamped to {1, 2, 4}.  RCPPML_GPU_CD_LPC overrides (experiments).
@@ -85,12 +110,16 @@ static void solve_cd_impl(rcppml_hip_ctx* c, const T* G, const T* B, T* X, int k
         const char* e = getenv("RCPPML_GPU_CD_VARIANT");
         if (e && !strcmp(e, "lane")) variant = RCPPML_CD_LANE;
         else if (e && !strcmp(e, "wave")) variant = RCPPML_CD_WAVE;
-        else variant = RCPPML_CD_GROUP;
+        else if (e && !strcmp(e, "group")) variant = RCPPML_CD_GROUP;
+        else if (e && !strcmp(e, "mfma")) variant = RCPPML_CD_MFMA;
+        else variant = (std::is_same<T, float>::value && k <= 64) ? RCPPML_CD_MFMA : RCPPML_CD_GROUP;
     }
+    if (variant == RCPPML_CD_MFMA && !(std::is_same<T, float>::value && k <= 64)) variant = RCPPML_CD_GROUP;
+    if (variant == RCPPML_CD_MFMA) KP = k <= 32 ? 32 : 64;
     // register-resident lane kernel (SGPR-fed): fp32 up to KP=64, fp64 up to KP=32 without spilling
     const int lane_max = std::is_same<T, float>::value ? 64 : 32;
     if (variant == RCPPML_CD_LANE && KP > lane_max) variant = RCPPML_CD_GROUP;
-    if (variant != RCPPML_CD_LANE && variant != RCPPML_CD_WAVE) variant = RCPPML_CD_GROUP;
+    if (variant != RCPPML_CD_LANE && variant != RCPPML_CD_WAVE && variant != RCPPML_CD_MFMA) variant = RCPPML_CD_GROUP;
     if (variant == RCPPML_CD_WAVE && KP < 64) KP = 64;   // the wave variant pads to a full 64-lane slab
     T *Gp, *invd;
     pad_impl<T>(c, G, k, KP, &Gp, &invd);
@@ -102,6 +131,13 @@ static void solve_cd_impl(rcppml_hip_ctx* c, const T* G, const T* B, T* X, int k
             default:
                 if constexpr (std::is_same<T, float>::value) cd_lane_launch<T, 64>(CD_ARGS);
                 break;
+        }
+    } else if (variant == RCPPML_CD_MFMA) {
+        if constexpr (std::is_same<T, float>::value) {
+            const char* ce = getenv("RCPPML_GPU_CD_MFMA_CT");
+            const int ct = ce ? atoi(ce) : 1;
+            if (KP == 32) { if (ct == 2) cd_mfma_launch<1, 2>(CD_ARGS); else cd_mfma_launch<1, 1>(CD_ARGS); }
+            else { if (ct == 2) cd_mfma_launch<2, 2>(CD_ARGS); else cd_mfma_launch<2, 1>(CD_ARGS); }
         }
     } else if (variant == RCPPML_CD_GROUP) {
         const int lpc = pick_lpc<T>(KP);

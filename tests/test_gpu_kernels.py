@@ -102,7 +102,14 @@ def _cd_problem(k, n, dtype, seed):
     return G, B, X0
 
 
-@pytest.mark.parametrize("variant", ["lane", "wave"])
+VARIANTS = ["lane", "wave", "group", "mfma"]     # mfma: fp32 k <= 64 (falls back to group otherwise)
+
+
+def _var(_abi, name):
+    return dict(lane=_abi.CD_LANE, wave=_abi.CD_WAVE, group=_abi.CD_GROUP, mfma=_abi.CD_MFMA)[name]
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 @pytest.mark.parametrize("k", [2, 10, 16, 32, 64, 100, 128])
 def test_cd_cold(env, dtype, k, variant):
@@ -113,14 +120,14 @@ def test_cd_cold(env, dtype, k, variant):
     X_ref = O.nnls_batch(G, B, maxit=100, tol=1e-8)
     dX = torch.full((n, k), 5.0, dtype=_tt(torch, dtype), device="cuda")
     ctx.solve_cd(_dt(_abi, dtype), _dev(torch, G), _dev(torch, B), dX, k, n, zero_init=1, maxit=100, tol=1e-8,
-                 variant=_abi.CD_LANE if variant == "lane" else _abi.CD_WAVE)
+                 variant=_var(_abi, variant))
     X = dX.cpu().numpy()
     assert X.min() >= 0
     scale = np.abs(X_ref).max()
     assert np.abs(X - X_ref).max() / scale < (2e-4 if dtype == np.float32 else 1e-9)
 
 
-@pytest.mark.parametrize("variant", ["lane", "wave"])
+@pytest.mark.parametrize("variant", VARIANTS)
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 def test_cd_variants_options(env, dtype, variant):
     """L1 before the solve, warm start (b -= G x), the iteration-0 quirk (start from X without correction),
@@ -128,7 +135,7 @@ def test_cd_variants_options(env, dtype, variant):
     torch, _abi, ctx = env
     k, n = 24, 77
     G, B, X0 = _cd_problem(k, n, dtype, 99)
-    var = _abi.CD_LANE if variant == "lane" else _abi.CD_WAVE
+    var = _var(_abi, variant)
     dt = _dt(_abi, dtype)
     tol = 3e-4 if dtype == np.float32 else 1e-9
 
@@ -171,14 +178,15 @@ def test_cd_lane_equals_wave(env, dtype):
     k, n = 32, 200
     G, B, X0 = _cd_problem(k, n, dtype, 5)
     outs = []
-    for var in (_abi.CD_LANE, _abi.CD_WAVE):
+    for var in (_abi.CD_LANE, _abi.CD_WAVE, _abi.CD_GROUP, _abi.CD_MFMA):
         dX = _dev(torch, X0.copy())
         ctx.solve_cd(_dt(_abi, dtype), _dev(torch, G), _dev(torch, B), dX, k, n, warm=1, maxit=30, tol=1e-8, variant=var)
         outs.append(dX.cpu().numpy())
     if dtype == np.float64:
-        assert np.array_equal(outs[0], outs[1])
-    else:  # fp32 lane variant uses packed fma + rcp for the tolerance term: same iterates up to exit sweep
-        assert np.abs(outs[0] - outs[1]).max() < 1e-5 * np.abs(outs[1]).max()
+        assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+    else:  # fp32 variants use rcp for the tolerance term / reassociate it (mfma): same iterates up to the exit sweep
+        for o in outs[1:]:
+            assert np.abs(outs[0] - o).max() < 1e-5 * np.abs(outs[0]).max()
 
 
 def test_cd_known_answer(env):
@@ -186,7 +194,7 @@ def test_cd_known_answer(env):
     torch, _abi, ctx = env
     G = np.array([[2.0, 1.0], [1.0, 2.0]]) + 1e-10 * np.eye(2)
     B = np.array([[3.0, 3.0]])
-    for var in (_abi.CD_LANE, _abi.CD_WAVE):
+    for var in (_abi.CD_LANE, _abi.CD_WAVE, _abi.CD_GROUP):
         dX = torch.zeros((1, 2), dtype=torch.float64, device="cuda")
         ctx.solve_cd(_abi.F64, _dev(torch, G), _dev(torch, B), dX, 2, 1, zero_init=1, maxit=100, tol=1e-8, variant=var)
         assert np.allclose(dX.cpu().numpy(), [[1.0, 1.0]], atol=1e-4)
