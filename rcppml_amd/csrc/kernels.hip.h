@@ -203,7 +203,7 @@ template <> struct VecT<float, 4> { typedef float type __attribute__((ext_vector
 template <> struct VecT<double, 1> { typedef double type; };
 template <> struct VecT<double, 2> { typedef double type __attribute__((ext_vector_type(2))); };
 
-template <class T, int VEC, int LPN, int U>
+template <class T, int VEC, int LPN, int U, bool NT>
 __global__ __launch_bounds__(256) void rhs_kernel(const int* __restrict__ colptr,
                                                    const int* __restrict__ rowidx,
                                                    const T* __restrict__ vals, int64_t ncols,
@@ -240,7 +240,9 @@ __global__ __launch_bounds__(256) void rhs_kernel(const int* __restrict__ colptr
                     ff[u][0] = src[0];
                 } else {
                     typedef typename VecT<T, VEC>::type V;
-                    const V v = *reinterpret_cast<const V*>(src);
+                    V v;
+                    if constexpr (NT) v = __builtin_nontemporal_load(reinterpret_cast<const V*>(src));
+                    else v = *reinterpret_cast<const V*>(src);
 #pragma unroll
                     for (int e = 0; e < VEC; ++e) ff[u][e] = v[e];
                 }
@@ -267,6 +269,86 @@ __global__ __launch_bounds__(256) void rhs_kernel(const int* __restrict__ colptr
             V v;
 #pragma unroll
             for (int e = 0; e < VEC; ++e) v[e] = acc[e];
+            *reinterpret_cast<V*>(dst) = v;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// RHS, scalarised-index variant for 33 <= k <= 128 ("rhs_wave_kernel").
+// Measured on MI355X the lane-group kernel above is bound by the texture-addresser (TA), not by L2 or HBM: with the
+// gathered factor shrunk to 64 KB (all L1 hits) it still tops out at 17 TB/s, because every group-uniform (row, value)
+// fetch is a full vector-memory instruction.  Here a whole wavefront owns one nonzero at a time, so the column's
+// (row, value) stream is WAVE-UNIFORM and is read with scalar loads (s_load through the scalar cache, no TA traffic);
+// the only vector-memory instructions left are the gathers themselves (one k-vector of F per instruction, EPL = k/64
+// elements per lane).  A side effect: each feature is accumulated by ONE lane in nonzero order -- the reference's
+// summation order (rhs.hpp:59-63) up to fma contraction.
+// ---------------------------------------------------------------------------
+template <class T, int EPL, int U>
+__global__ __launch_bounds__(256) void rhs_wave_kernel(const int* __restrict__ colptr,
+                                                        const int* __restrict__ rowidx,
+                                                        const T* __restrict__ vals, int64_t ncols,
+                                                        const T* __restrict__ F, int k, T* __restrict__ B) {
+    const int64_t j = __builtin_amdgcn_readfirstlane((int)((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)));
+    if (j >= ncols) return;
+    const int lane = threadIdx.x & 63;
+    const bool fok = lane * EPL < k;               // k is a multiple of EPL
+    const int f0 = fok ? lane * EPL : 0;           // lanes beyond k re-read feature 0 and are never stored: no branches
+    const int start = colptr[j], end = colptr[j + 1];
+    T acc[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) acc[e] = T(0);
+    const T* Fl = F + f0;
+    auto gather_fma = [&](const int (&rr)[U], const T (&vv)[U]) {
+        T ff[U][EPL];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const T* src = Fl + (int64_t)rr[u] * k;
+            if constexpr (EPL == 1) ff[u][0] = src[0];
+            else {
+                typedef typename VecT<T, EPL>::type V;
+                const V v = *reinterpret_cast<const V*>(src);
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) ff[u][e] = v[e];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) acc[e] = tfma(vv[u], ff[u][e], acc[e]);
+    };
+    // U consecutive dword-aligned elements as ONE wide scalar load (s_load_dwordx8 only needs 4-byte alignment)
+    struct __attribute__((packed, aligned(4))) IdxPack { int v[U]; };
+    struct __attribute__((packed, aligned(4))) ValPack { T v[U]; };
+    int t = start;
+    for (; t + U <= end; t += U) {               // full batches: contiguous wave-uniform reads -> wide scalar loads
+        const IdxPack ip = *reinterpret_cast<const IdxPack*>(rowidx + t);
+        const ValPack vp = *reinterpret_cast<const ValPack*>(vals + t);
+        int rr[U];
+        T vv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) { rr[u] = ip.v[u]; vv[u] = vp.v[u]; }
+        gather_fma(rr, vv);
+    }
+    if (t < end) {                               // tail batch
+        int rr[U];
+        T vv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const bool ok = t + u < end;
+            rr[u] = ok ? rowidx[t + u] : 0;
+            vv[u] = ok ? vals[t + u] : T(0);
+        }
+        gather_fma(rr, vv);
+    }
+    if (fok) {
+        T* dst = B + j * (int64_t)k + f0;
+        if constexpr (EPL == 1) dst[0] = acc[0];
+        else {
+            typedef typename VecT<T, EPL>::type V;
+            V v;
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) v[e] = acc[e];
             *reinterpret_cast<V*>(dst) = v;
         }
     }

@@ -11,10 +11,19 @@ static int next_pow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 template <class T, int VEC, int LPN>
 static void rhs_launch(rcppml_hip_ctx* c, const int* cp, const int* ri, const T* vals, int64_t ncols,
                        const T* F, int k, T* B) {
-    constexpr int U = 8;
     const int64_t nblk = (ncols + 3) / 4;
-    hipLaunchKernelGGL((rhs_kernel<T, VEC, LPN, U>), dim3((unsigned)nblk), dim3(256), 0, c->stream, cp, ri,
-                       vals, ncols, F, k, B);
+    static int mode = -1;                 // experiment switch: RCPPML_GPU_RHS_VARIANT = u16 | nt | nt16
+    if (mode < 0) {
+        const char* e = getenv("RCPPML_GPU_RHS_VARIANT");
+        mode = !e ? 0 : (!strcmp(e, "u16") ? 1 : (!strcmp(e, "u4") ? 2 : (!strcmp(e, "u2") ? 3 : 0)));
+    }
+    dim3 grid((unsigned)nblk), block(256);
+    switch (mode) {
+        case 1: hipLaunchKernelGGL((rhs_kernel<T, VEC, LPN, 16, false>), grid, block, 0, c->stream, cp, ri, vals, ncols, F, k, B); break;
+        case 2: hipLaunchKernelGGL((rhs_kernel<T, VEC, LPN, 4, false>), grid, block, 0, c->stream, cp, ri, vals, ncols, F, k, B); break;
+        case 3: hipLaunchKernelGGL((rhs_kernel<T, VEC, LPN, 2, false>), grid, block, 0, c->stream, cp, ri, vals, ncols, F, k, B); break;
+        default: hipLaunchKernelGGL((rhs_kernel<T, VEC, LPN, 8, false>), grid, block, 0, c->stream, cp, ri, vals, ncols, F, k, B); break;
+    }
     HIPCHK(hipGetLastError());
 }
 template <class T>
@@ -22,6 +31,25 @@ static void rhs_impl(rcppml_hip_ctx* c, const int* cp, const int* ri, const T* v
                      const T* F, int k, T* B) {
     if (ncols <= 0) return;
     if (ncols > (int64_t)4 * 0x7fffffff) throw std::runtime_error("rhs: too many columns");
+    // RCPPML_GPU_RHS_VARIANT=wave: scalarised-index kernel (one nonzero per wave instruction, reference summation
+    // order).  Measured no faster than the lane-group kernel on MI355X (H 0.475 / W 0.552 ms vs 0.468 / 0.403 ms on C2),
+    // so it is opt-in.
+    {
+        static int wave_mode = -1;
+        if (wave_mode < 0) { const char* e = getenv("RCPPML_GPU_RHS_VARIANT"); wave_mode = (e && !strcmp(e, "wave")) ? 1 : 0; }
+        const int64_t nblk = (ncols + 3) / 4;
+        const bool al8 = (reinterpret_cast<uintptr_t>(F) % 16 == 0) && (reinterpret_cast<uintptr_t>(B) % 16 == 0);
+        if (wave_mode == 1 && k > 32 && k <= 64) {
+            hipLaunchKernelGGL((rhs_wave_kernel<T, 1, 8>), dim3((unsigned)nblk), dim3(256), 0, c->stream, cp, ri, vals, ncols, F, k, B);
+            HIPCHK(hipGetLastError());
+            return;
+        }
+        if (wave_mode == 1 && k > 64 && k <= 128 && k % 2 == 0 && al8) {
+            hipLaunchKernelGGL((rhs_wave_kernel<T, 2, 8>), dim3((unsigned)nblk), dim3(256), 0, c->stream, cp, ri, vals, ncols, F, k, B);
+            HIPCHK(hipGetLastError());
+            return;
+        }
+    }
     constexpr int VMAX = 16 / sizeof(T);   // 16-byte loads
     const bool aligned = (reinterpret_cast<uintptr_t>(F) % 16 == 0) && (reinterpret_cast<uintptr_t>(B) % 16 == 0);
     if (k % VMAX == 0 && aligned && k / VMAX <= 64) {
