@@ -3,7 +3,7 @@
 TAG=${1:-cd}
 REPO=$(pwd); OUT=$REPO/gpurun_out/$TAG; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --output-format csv --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace -d "$OUT/sq" -o sq -- python $REPO/tools/cd_sweep_histogram.py f32 > "$OUT/log.txt" 2>&1
+timeout 300 rocprofv3 --output-format csv --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace -d "$OUT/sq" -o sq -- python $REPO/tools/cd_sweep_histogram.py f32 > "$OUT/log.txt" 2>&1
 find "$OUT" -name "*.db" -delete
 python - <<PY
 import csv, collections

@@ -3,8 +3,7 @@
 TAG=${1:-rhs}
 REPO=$(pwd); OUT=$REPO/gpurun_out/$TAG; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --output-format csv --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum --kernel-trace -d "$OUT/tcc" -o tcc -- python $REPO/tools/rhs_bench.py f32 > "$OUT/log1.txt" 2>&1
-rocprofv3 --output-format csv --pmc TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_PENDING_STALL_CYCLES_sum TA_BUSY_avr TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TCP_READ_TAGCONFLICT_STALL_CYCLES_sum --kernel-trace -d "$OUT/tcp" -o tcp -- python $REPO/tools/rhs_bench.py f32 > "$OUT/log2.txt" 2>&1
+timeout 300 rocprofv3 --output-format csv --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum --kernel-trace -d "$OUT/tcc" -o tcc -- python $REPO/tools/rhs_bench.py f32 > "$OUT/log1.txt" 2>&1
 find "$OUT" -name "*.db" -delete
 python - <<PY
 import csv, collections, glob

@@ -116,7 +116,8 @@ class HipOps:
                 if cfg.order_columns and (st is None or st["sweeps"].shape[0] != n):
                     st = dict(sweeps=self.zeros((n,), self.torch.int32), order=self.empty((n,), self.torch.int32), valid=False)
                     self._order[side] = st
-                use = st is not None and st["valid"] and cfg.cd_tol > 0
+                # (only worth it when there are more wavefronts than the chip holds at once: >= 32768 columns)
+                use = st is not None and st["valid"] and cfg.cd_tol > 0 and n >= 32768
                 if use:
                     self.ctx.order_columns(st["sweeps"], n, st["order"])
                 self.ctx.solve_cd(self.dt, G, B, X, k, n, l1_pre=l1 if l1 > 0 else 0.0, warm=int(warm), zero_init=0,

@@ -1149,11 +1149,30 @@ static __global__ __launch_bounds__(128) void order_scan_kernel(unsigned int* __
 static __global__ __launch_bounds__(256) void order_scatter_kernel(const int* __restrict__ sweeps, int64_t n,
                                                                      unsigned int* __restrict__ offsets /*128*/,
                                                                      int* __restrict__ order) {
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    // Block-aggregated: each block counts its contiguous chunk per bin in LDS, reserves one global range per bin
+    // (128 global atomics per block instead of one per element on a handful of hot bins), then ranks inside LDS.
+    __shared__ unsigned int cnt[128], base[128];
+    const int64_t per = (n + gridDim.x - 1) / gridDim.x;
+    const int64_t i0 = (int64_t)blockIdx.x * per;
+    const int64_t i1 = i0 + per < n ? i0 + per : n;
+    if (threadIdx.x < 128) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) {
         int key = sweeps[i];
         key = key < 0 ? 0 : (key > 127 ? 127 : key);
-        const unsigned int pos = atomicAdd(&offsets[127 - key], 1u);
+        atomicAdd(&cnt[127 - key], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < 128) {
+        const unsigned int c = cnt[threadIdx.x];
+        base[threadIdx.x] = c ? atomicAdd(&offsets[threadIdx.x], c) : 0u;
+        cnt[threadIdx.x] = 0;
+    }
+    __syncthreads();
+    for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) {
+        int key = sweeps[i];
+        key = key < 0 ? 0 : (key > 127 ? 127 : key);
+        const unsigned int pos = base[127 - key] + atomicAdd(&cnt[127 - key], 1u);
         order[pos] = (int)i;
     }
 }

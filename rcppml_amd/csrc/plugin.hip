@@ -230,7 +230,7 @@ void fit(FitParams& P) {
             OPCHK(rcppml_hip_gram(c, dt, dW.p, k, m, eps, P.L2_H, dG.p));              // :491,506
             OPCHK(rcppml_hip_rhs(c, dt, dAp.as<int>(), dAi.as<int>(), dAx.p, n, dW.p, k, dBh.p));
             if (P.solver_mode == 0) {                                                   // :516-524
-                const bool ord = use_order && iter > 0;
+                const bool ord = use_order && iter > 0 && n >= 32768;   // pays once waves outnumber the chip's slots
                 if (ord) OPCHK(rcppml_hip_order_columns(c, dswH.as<int>(), n, dordH.as<int>()));
                 OPCHK(rcppml_hip_solve_cd(c, dt, dG.p, dBh.p, dH.p, k, n, P.L1_H > 0 ? P.L1_H : 0.0, warm, 0, 0.0, 0.0,
                                           P.nonneg_H, P.cd_maxit, P.cd_tol, 0.0, P.ub_H, RCPPML_CD_AUTO,
@@ -258,7 +258,7 @@ void fit(FitParams& P) {
             else HIPCHK(hipMemcpyAsync(dG.p, dGs.p, (size_t)k * k * sizeof(T), hipMemcpyDeviceToDevice, s));
             OPCHK(rcppml_hip_rhs(c, dt, dTp.as<int>(), dTi.as<int>(), dTx.p, m, dH.p, k, dBw.p));
             if (P.solver_mode == 0) {
-                const bool ord = use_order && iter > 0;
+                const bool ord = use_order && iter > 0 && m >= 32768;
                 if (ord) OPCHK(rcppml_hip_order_columns(c, dswW.as<int>(), m, dordW.as<int>()));
                 OPCHK(rcppml_hip_solve_cd(c, dt, dG.p, dBw.p, dW.p, k, m, P.L1_W > 0 ? P.L1_W : 0.0, warm, 0, 0.0, 0.0,
                                           P.nonneg_W, P.cd_maxit, P.cd_tol, 0.0, P.ub_W, RCPPML_CD_AUTO,
