@@ -31,7 +31,7 @@
 namespace rk {
 
 // Gq[i*KP + p] = -G(lrow(p), i) with p = 32*rt + r', lrow = 32*rt + 2*v + h, h = (r'>>2)&1, v = (r'&3) + 4*(r'>>3);
-// gnx[i] = G(i+1, i) (used for even i).  Gp: padded KP x KP Gram, column i contiguous.
+// gnx[i]: see below.  Gp: padded KP x KP Gram, column i contiguous.
 static __global__ void cd_mfma_prep_kernel(const float* __restrict__ Gp, int KP, float* __restrict__ Gq,
                                            float* __restrict__ gnx) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -41,10 +41,12 @@ static __global__ void cd_mfma_prep_kernel(const float* __restrict__ Gp, int KP,
     const int h = (r >> 2) & 1, v = (r & 3) + 4 * (r >> 3);
     const int lrow = 32 * rt + 2 * v + h;
     Gq[e] = -Gp[i * KP + lrow];
-    if (p == 0) gnx[i] = (i + 1 < KP) ? Gp[i * KP + i + 1] : 0.f;
+    // gnx[even] = 0, gnx[odd] = G(odd, odd-1): the high half (odd coordinate) reads its Gauss-Seidel coupling, the low
+    // half reads 0, so ONE evaluation of the second step is right for both halves
+    if (p == 0) gnx[i] = (i & 1) ? Gp[(i - 1) * KP + i] : 0.f;
 }
 
-struct CdStepOut { float a, nx, t; };
+struct CdStepOut { float a, nx; };
 
 // The reference's scalar step.  SIMPLE = non-negativity only (no upper bound, no in-CD L1/L2): what every NMF
 // half-update uses; the general form serves nnls()/predict() (L1 inside CD, box constraints, nonneg = FALSE).
@@ -58,12 +60,10 @@ __device__ __forceinline__ CdStepOut cd_scalar_step(float b, float xo, float gin
         const bool neg = nv < 0.f;
         float nx = neg ? 0.f : nv;
         float a = neg ? -xo : diff;
-        const bool on = active && (ginv > 0.f);  // reference: `if (g_diag <= 0) continue;`; frozen columns do not move
-        a = on ? a : 0.f;
-        nx = on ? nx : xo;
+        // `active` and the reference's `if (g_diag <= 0) continue;` arrive folded into ginv (= 0): then diff = 0,
+        // nv = xo >= 0, so a = 0 and nx = xo without any select
         o.a = a;
         o.nx = nx;
-        o.t = tabs(a) * __builtin_amdgcn_rcpf(tabs(nx) + 1e-15f);
     } else {
         float diff = b * ginv;
         diff -= l1_cd;                        // reference: `if (L1 != 0) diff -= L1` (subtracting 0 is exact)
@@ -77,7 +77,6 @@ __device__ __forceinline__ CdStepOut cd_scalar_step(float b, float xo, float gin
         nx = on ? nx : xo;
         o.a = a;
         o.nx = nx;
-        o.t = tabs(a) * __builtin_amdgcn_rcpf(tabs(nx) + 1e-15f);
     }
     return o;
 }
@@ -152,7 +151,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CT == 1 ? 4
     for (int ct = 0; ct < CT; ++ct) { active[ct] = inb[ct]; nsweep[ct] = 0; }
     // LDS operands of the first pair; every pair then requests the NEXT pair's operands before it starts computing,
     // so their latency hides behind the current pair (the last pair of a sweep prefetches pair 0 again)
-    float ginv_c = ginv_s[half], gnx_c = gnx_s[0];
+    float ginv_c = ginv_s[half], gnx_c = gnx_s[half];
     float av_c[RT];
 #pragma unroll
     for (int rt2 = 0; rt2 < RT; ++rt2) av_c[rt2] = Gs[half * KP + 32 * rt2 + cl];
@@ -172,28 +171,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CT == 1 ? 4
                 constexpr int KPc = KP;
                 const int inext = (32 * rt + 2 * q + 2) % KPc;
                 const float ginv_n = ginv_s[inext + half];
-                const float gnx_n = gnx_s[inext];                 // G(i+1, i) of the next pair, wave-uniform
+                const float gnx_n = gnx_s[inext + half];          // high half: G(i+1, i) of the next pair; low half: 0
                 float av_n[RT];
 #pragma unroll
                 for (int rt2 = 0; rt2 < RT; ++rt2) av_n[rt2] = Gs[(inext + half) * KP + 32 * rt2 + cl];
-                const float ginv = ginv_c, g_oe = gnx_c;
+                const float g_oe = gnx_c;
                 float aval[CT];
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct) {
                     const float b = acc[rt][ct][q];
                     const float xo = xr[rt][ct][q];
+                    // SIMPLE: frozen columns / dead diagonals take ginv = 0 (step 0, iterate unchanged)
+                    const float ginv = SIMPLE ? (active[ct] ? ginv_c : 0.f) : ginv_c;
                     // even coordinate (meaningful in the low half)
                     const CdStepOut e = cd_scalar_step<SIMPLE>(b, xo, ginv, active[ct], l1_cd, l2_cd, lo, hi);
                     // its step, seen from the high half (same column, lane - 32)
                     const unsigned ae_bits = __float_as_uint(e.a);
                     const float ae_lo = __uint_as_float(__builtin_amdgcn_permlane32_swap(ae_bits, ae_bits, false, false)[0]);
-                    // odd coordinate (meaningful in the high half): lazy Gauss-Seidel correction, then the step
+                    // high half: odd coordinate after the lazy Gauss-Seidel correction b -= G(i+1,i) a_i.  Low half:
+                    // g_oe = 0, so this re-evaluates the even step on identical inputs -- the result register is
+                    // {a_i | a_i+1} = the MFMA B operand, and no half-select is needed.
                     const float bo = __builtin_fmaf(-g_oe, ae_lo, b);
                     const CdStepOut o = cd_scalar_step<SIMPLE>(bo, xo, ginv, active[ct], l1_cd, l2_cd, lo, hi);
-                    const bool is_lo = half == 0;
-                    aval[ct] = is_lo ? e.a : o.a;
-                    xr[rt][ct][q] = is_lo ? e.nx : o.nx;
-                    tsum[ct] += is_lo ? e.t : o.t;
+                    aval[ct] = o.a;
+                    xr[rt][ct][q] = o.nx;
+                    // |a| / (|x_new| + 1e-15): one evaluation per pair and half (v_rcp_f32), nnls_batch.hpp:117-120
+                    tsum[ct] = __builtin_fmaf(tabs(o.a), __builtin_amdgcn_rcpf(tabs(o.nx) + 1e-15f), tsum[ct]);
                 }
                 // the row tile that holds the NEXT pair's residuals goes first, so its results are back while the
                 // other tiles still occupy the matrix pipe
