@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "RcppML_gpu.so")
+LIB_PATH = os.environ.get("RCPPML_GPU_LIB_PATH") or os.path.join(_HERE, "lib", "RcppML_gpu.so")
 _lib = None
 
 F32, F64 = 0, 1

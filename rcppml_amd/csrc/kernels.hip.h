@@ -26,7 +26,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 typedef double f64x2 __attribute__((ext_vector_type(2)));
 
-template <class T> __device__ __forceinline__ T tabs(T v) { return v < T(0) ? -v : v; }
+__device__ __forceinline__ float tabs(float v) { return __builtin_fabsf(v); }    // free |x| source modifier
+__device__ __forceinline__ double tabs(double v) { return __builtin_fabs(v); }
 __device__ __forceinline__ float tfma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 __device__ __forceinline__ double tfma(double a, double b, double c) { return __builtin_fma(a, b, c); }
 

@@ -30,20 +30,29 @@
 
 namespace rk {
 
-// Gq[i*KP + p] = -G(lrow(p), i) with p = 32*rt + r', lrow = 32*rt + 2*v + h, h = (r'>>2)&1, v = (r'&3) + 4*(r'>>3);
-// gnx[i]: see below.  Gp: padded KP x KP Gram, column i contiguous.
-static __global__ void cd_mfma_prep_kernel(const float* __restrict__ Gp, int KP, float* __restrict__ Gq,
-                                           float* __restrict__ gnx) {
+// Gq[((i/2)*RT + rt)*64 + (i&1)*32 + r'] = -G(lrow, i), lrow = 32*rt + 2*v + h, h = (r'>>2)&1, v = (r'&3) + 4*(r'>>3).
+// tab[c] (c = coordinate; pair i = c & ~1 is served by lane half h = c & 1) = { 1/G(c,c) (0 if G(c,c) <= 0),
+//   coupling inside the pair: h ? G(i+1, i) : 0 }.
+// Gp: padded KP x KP Gram (identity padding), column i contiguous; invd from pad_gram.
+static __global__ void cd_mfma_prep_kernel(const float* __restrict__ Gp, const float* __restrict__ invd, int KP,
+                                           float* __restrict__ Gq, float2* __restrict__ tab) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= KP * KP) return;
     const int i = e / KP, p = e % KP;
     const int rt = p >> 5, r = p & 31;
     const int h = (r >> 2) & 1, v = (r & 3) + 4 * (r >> 3);
     const int lrow = 32 * rt + 2 * v + h;
-    Gq[e] = -Gp[i * KP + lrow];
-    // gnx[even] = 0, gnx[odd] = G(odd, odd-1): the high half (odd coordinate) reads its Gauss-Seidel coupling, the low
-    // half reads 0, so ONE evaluation of the second step is right for both halves
-    if (p == 0) gnx[i] = (i & 1) ? Gp[(i - 1) * KP + i] : 0.f;
+    // pair-major layout: 64 consecutive floats = one MFMA A operand (both halves of a wave) of pair i/2 and row
+    // tile rt, so every LDS read of the sweep is  <one base register> + <compile-time multiple of 256 bytes>
+    Gq[(((i >> 1) * (KP >> 5) + rt) << 6) + ((i & 1) << 5) + r] = -Gp[i * KP + lrow];
+    if (p == 0) {
+        // the high half (odd coordinate) reads its Gauss-Seidel coupling, the low half reads 0, so ONE evaluation
+        // of the second step serves both halves
+        float2 t;
+        t.x = invd[i];
+        t.y = (i & 1) ? Gp[(i - 1) * KP + i] : 0.f;
+        tab[i] = t;
+    }
 }
 
 struct CdStepOut { float a, nx; };
@@ -82,19 +91,18 @@ __device__ __forceinline__ CdStepOut cd_scalar_step(float b, float xo, float gin
 }
 
 template <int RT, int CT, bool SIMPLE>   // KP = 32*RT rows (k <= KP), 32*CT columns per wave, 4 waves per block share G
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CT == 1 ? 4 : 2, 8))) void cd_mfma_kernel(const float* __restrict__ Gq, const float* __restrict__ invd,
-                                                       const float* __restrict__ gnx, const float* __restrict__ B,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CT == 1 ? 4 : 2, 8))) void cd_mfma_kernel(const float* __restrict__ Gq, const float2* __restrict__ tab,
+                                                       const float* __restrict__ B,
                                                        float* __restrict__ X, int k, int64_t ncols, float l1_pre,
                                                        int warm, int zero_init, float l1_cd, float l2_cd, int nonneg,
                                                        int maxit, float tol, float ub_cd, float ub_post,
                                                        int* __restrict__ sweeps, const int* __restrict__ order) {
     constexpr int KP = 32 * RT;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    float* Gs = reinterpret_cast<float*>(smem_raw);      // KP*KP: Gs[i*KP + p] = -G(lrow(p), i)
-    float* ginv_s = Gs + KP * KP;                         // KP
-    float* gnx_s = ginv_s + KP;                           // KP
+    float* Gs = reinterpret_cast<float*>(smem_raw);      // KP*KP, pair-major (see cd_mfma_prep_kernel)
+    float2* tab_s = reinterpret_cast<float2*>(Gs + KP * KP);   // KP x {1/G_cc, pair coupling}
     for (int e = threadIdx.x; e < KP * KP; e += blockDim.x) Gs[e] = Gq[e];
-    for (int e = threadIdx.x; e < KP; e += blockDim.x) { ginv_s[e] = invd[e]; gnx_s[e] = gnx[e]; }
+    for (int e = threadIdx.x; e < KP; e += blockDim.x) tab_s[e] = tab[e];
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int half = lane >> 5, cl = lane & 31;
@@ -134,7 +142,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CT == 1 ? 4
                 const int i = 32 * rt + 2 * q;
 #pragma unroll
                 for (int rt2 = 0; rt2 < RT; ++rt2) {
-                    const float av = Gs[(i + half) * KP + 32 * rt2 + cl];
+                    const float av = Gs[((i >> 1) * RT + rt2) * 64 + lane];
 #pragma unroll
                     for (int ct = 0; ct < CT; ++ct)
                         acc[rt2][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, xr[rt][ct][q], acc[rt2][ct], 0, 0, 0);
@@ -151,10 +159,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CT == 1 ? 4
     for (int ct = 0; ct < CT; ++ct) { active[ct] = inb[ct]; nsweep[ct] = 0; }
     // LDS operands of the first pair; every pair then requests the NEXT pair's operands before it starts computing,
     // so their latency hides behind the current pair (the last pair of a sweep prefetches pair 0 again)
-    float ginv_c = ginv_s[half], gnx_c = gnx_s[half];
+    float2 tb_c = tab_s[half];
     float av_c[RT];
 #pragma unroll
-    for (int rt2 = 0; rt2 < RT; ++rt2) av_c[rt2] = Gs[half * KP + 32 * rt2 + cl];
+    for (int rt2 = 0; rt2 < RT; ++rt2) av_c[rt2] = Gs[rt2 * 64 + lane];
     for (int it = 0; it < maxit; ++it) {
         bool any_active = false;
 #pragma unroll
@@ -170,24 +178,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CT == 1 ? 4
                 // low half: coordinate i = 32rt + 2q, high half: coordinate i + 1
                 constexpr int KPc = KP;
                 const int inext = (32 * rt + 2 * q + 2) % KPc;
-                const float ginv_n = ginv_s[inext + half];
-                const float gnx_n = gnx_s[inext + half];          // high half: G(i+1, i) of the next pair; low half: 0
+                const int rtn = (q == 15 ? rt + 1 : rt) % RT;   // row tile of the next pair
+                const float2 tb_n = tab_s[inext + half];
                 float av_n[RT];
 #pragma unroll
-                for (int rt2 = 0; rt2 < RT; ++rt2) av_n[rt2] = Gs[(inext + half) * KP + 32 * rt2 + cl];
-                const float g_oe = gnx_c;
+                for (int rt2 = 0; rt2 < RT; ++rt2) av_n[rt2] = Gs[((inext >> 1) * RT + rt2) * 64 + lane];
+                const float g_oe = tb_c.y;
                 float aval[CT];
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct) {
                     const float b = acc[rt][ct][q];
                     const float xo = xr[rt][ct][q];
                     // SIMPLE: frozen columns / dead diagonals take ginv = 0 (step 0, iterate unchanged)
-                    const float ginv = SIMPLE ? (active[ct] ? ginv_c : 0.f) : ginv_c;
+                    const float ginv = SIMPLE ? (active[ct] ? tb_c.x : 0.f) : tb_c.x;
                     // even coordinate (meaningful in the low half)
                     const CdStepOut e = cd_scalar_step<SIMPLE>(b, xo, ginv, active[ct], l1_cd, l2_cd, lo, hi);
-                    // its step, seen from the high half (same column, lane - 32)
-                    const unsigned ae_bits = __float_as_uint(e.a);
-                    const float ae_lo = __uint_as_float(__builtin_amdgcn_permlane32_swap(ae_bits, ae_bits, false, false)[0]);
+                    // its step, seen from the high half (same column, lane - 32).  v_permlane32_swap with
+                    // vdst == src0 exchanges the two halves of one register in place (the builtin would copy the
+                    // operand first); the low half then holds a don't-care that meets g_oe = 0
+                    float ae_lo = e.a;
+                    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %0" : "+v"(ae_lo));
                     // high half: odd coordinate after the lazy Gauss-Seidel correction b -= G(i+1,i) a_i.  Low half:
                     // g_oe = 0, so this re-evaluates the even step on identical inputs -- the result register is
                     // {a_i | a_i+1} = the MFMA B operand, and no half-select is needed.
@@ -198,17 +208,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CT == 1 ? 4
                     // |a| / (|x_new| + 1e-15): one evaluation per pair and half (v_rcp_f32), nnls_batch.hpp:117-120
                     tsum[ct] = __builtin_fmaf(tabs(o.a), __builtin_amdgcn_rcpf(tabs(o.nx) + 1e-15f), tsum[ct]);
                 }
-                // the row tile that holds the NEXT pair's residuals goes first, so its results are back while the
-                // other tiles still occupy the matrix pipe
+                // the row tile that holds the NEXT pair's residuals goes first, so its results are back first
 #pragma unroll
                 for (int s2 = 0; s2 < RT; ++s2) {
-                    const int rt2 = ((q == 15 ? rt + 1 : rt) + s2) % RT;
+                    const int rt2 = (rtn + s2) % RT;
 #pragma unroll
                     for (int ct = 0; ct < CT; ++ct)
                         acc[rt2][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(av_c[rt2], aval[ct], acc[rt2][ct], 0, 0, 0);
                 }
-                ginv_c = ginv_n;
-                gnx_c = gnx_n;
+                tb_c = tb_n;
 #pragma unroll
                 for (int rt2 = 0; rt2 < RT; ++rt2) av_c[rt2] = av_n[rt2];
                 // one scheduling region per coordinate pair: without it hipcc hoists the LDS reads of many pairs and

@@ -67,19 +67,19 @@ static void cd_mfma_launch(rcppml_hip_ctx* c, const float* Gp, const float* invd
                            int64_t ncols, float l1_pre, int warm, int zero_init, float l1_cd, float l2_cd, int nonneg,
                            int maxit, float tol, float ub_cd, float ub_post, int* sweeps, const int* order) {
     constexpr int KP = 32 * RT;
-    float* Gq = static_cast<float*>(c->scratch(WS_MFMA, ((size_t)KP * KP + KP) * sizeof(float)));
-    float* gnx = Gq + (size_t)KP * KP;
-    hipLaunchKernelGGL(cd_mfma_prep_kernel, dim3((KP * KP + 255) / 256), dim3(256), 0, c->stream, Gp, KP, Gq, gnx);
+    float* Gq = static_cast<float*>(c->scratch(WS_MFMA, ((size_t)KP * KP + 2 * KP) * sizeof(float)));
+    float2* tab = reinterpret_cast<float2*>(Gq + (size_t)KP * KP);
+    hipLaunchKernelGGL(cd_mfma_prep_kernel, dim3((KP * KP + 255) / 256), dim3(256), 0, c->stream, Gp, invd, KP, Gq, tab);
     HIPCHK(hipGetLastError());
     const size_t smem = ((size_t)KP * KP + 2 * KP) * sizeof(float);
     const int64_t per_block = 4 * 32 * CT;          // 4 waves per block
     const int64_t nblk = (ncols + per_block - 1) / per_block;
     const bool simple = nonneg && ub_cd <= 0.f && l1_cd == 0.f && l2_cd == 0.f;
     if (simple)
-        hipLaunchKernelGGL((cd_mfma_kernel<RT, CT, true>), dim3((unsigned)nblk), dim3(256), smem, c->stream, Gq, invd, gnx, B, X,
+        hipLaunchKernelGGL((cd_mfma_kernel<RT, CT, true>), dim3((unsigned)nblk), dim3(256), smem, c->stream, Gq, tab, B, X,
                            k, ncols, l1_pre, warm, zero_init, l1_cd, l2_cd, nonneg, maxit, tol, ub_cd, ub_post, sweeps, order);
     else
-        hipLaunchKernelGGL((cd_mfma_kernel<RT, CT, false>), dim3((unsigned)nblk), dim3(256), smem, c->stream, Gq, invd, gnx, B, X,
+        hipLaunchKernelGGL((cd_mfma_kernel<RT, CT, false>), dim3((unsigned)nblk), dim3(256), smem, c->stream, Gq, tab, B, X,
                            k, ncols, l1_pre, warm, zero_init, l1_cd, l2_cd, nonneg, maxit, tol, ub_cd, ub_post, sweeps, order);
     HIPCHK(hipGetLastError());
 }
