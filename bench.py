@@ -141,6 +141,7 @@ def main():
     # ---- timed region: EXACTLY `steps` iterations, barrier + synchronize on both sides
     ops.record = True
     ops.reset_events()
+    ops.ctx.stats(reset=True)          # zero the library's work counters (column-sweeps of the CD kernels)
     comm.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -156,6 +157,7 @@ def main():
     dt = float(tmax.item())
     final_loss = float(loss[0].item())
     ev = ops.event_ms()
+    work = ops.ctx.stats()
 
     if rank == 0:
         sv = 4 if args.dtype == "f32" else 8
@@ -169,6 +171,30 @@ def main():
         avg_bytes = (bytes_h * cnt_h + bytes_w * cnt_w) / max(launches, 1)
         achieved = avg_bytes / max(avg_s, 1e-12) / 1e9
         phases = {name: round(ms / args.steps, 4) for name, (c, ms) in sorted(ev.items())}
+        roof_rhs = {"bound": "hbm", "kernel": "rhs_kernel (SpMM-like B = F * A(:,j), both half-updates)",
+                    "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+                    "traffic": None, "algorithmic_bytes_per_launch": avg_bytes, "avg_launch_ms": avg_s * 1e3,
+                    "rhs_H_ms": ms_h / max(cnt_h, 1), "rhs_W_ms": ms_w / max(cnt_w, 1)}
+        # NNLS solve: algorithmic flops = 2 k^2 per column and sweep (k coordinate steps, each a k-long residual
+        # update; nnls_batch.hpp:96-121), sweeps counted by the kernels themselves.  fp32 k<=64 runs these updates
+        # as v_mfma_f32_32x32x2_f32 (dense f32 MFMA peak 157.3 TFLOP/s = the f32 vector rate); the phase time
+        # also holds the Gram padding/permutation and column-ordering helper kernels (a few us).
+        cnt_sh, ms_sh = ev.get("solve_H", (0, 0.0))
+        cnt_sw, ms_sw = ev.get("solve_W", (0, 0.0))
+        cd_launches = cnt_sh + cnt_sw
+        cd_s = (ms_sh + ms_sw) / max(cd_launches, 1) * 1e-3
+        cd_flops = 2.0 * k * k * work["cd_column_sweeps"] / max(cd_launches, 1)
+        cd_peak = 157.3 if args.dtype == "f32" else 78.6
+        roof_cd = None
+        if args.solver == "cd" and work["cd_columns"] > 0:
+            tf = cd_flops / max(cd_s, 1e-12) / 1e12
+            roof_cd = {"bound": "mfma" if (args.dtype == "f32" and k <= 64 and args.variant == "auto") else "valu",
+                       "kernel": "cd_mfma_kernel / cd_group_kernel (coordinate-descent NNLS, both half-updates)",
+                       "achieved": tf, "peak": cd_peak, "unit": "TFLOP/s", "frac": tf / cd_peak, "traffic": None,
+                       "algorithmic_flops_per_launch": cd_flops, "avg_launch_ms": cd_s * 1e3,
+                       "mean_sweeps_per_column": work["cd_column_sweeps"] / work["cd_columns"],
+                       "solve_H_ms": ms_sh / max(cnt_sh, 1), "solve_W_ms": ms_sw / max(cnt_sw, 1)}
+        cd_dominant = roof_cd is not None and (ms_sh + ms_sw) > (ms_h + ms_w)
         out = {
             "metric": "ALS updates/sec (cols solved/s), k=%d sparse NMF" % k,
             "value": args.steps * (m + n_total) / dt,
@@ -183,11 +209,9 @@ def main():
                                       "coordinate-descent" if args.solver == "cd" else "Cholesky+clip", args.cd_maxit),
                        "rows": m, "cols_per_gpu": n_loc, "nnz_per_gpu": nnz, "k": k, "solver": args.solver,
                        "cd_variant": args.variant, "parallelism": "column-shard x%d" % world},
-            "roofline": {"bound": "hbm", "kernel": "rhs_kernel (SpMM-like B = F * A(:,j), both half-updates)",
-                         "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                         "traffic": None, "algorithmic_bytes_per_launch": avg_bytes,
-                         "avg_launch_ms": avg_s * 1e3,
-                         "rhs_H_ms": ms_h / max(cnt_h, 1), "rhs_W_ms": ms_w / max(cnt_w, 1)},
+            # `roofline` = the kernel the iteration spends most time in; the other regime of SURVEY 8(d) beside it
+            "roofline": roof_cd if cd_dominant else roof_rhs,
+            ("roofline_rhs" if cd_dominant else "roofline_cd"): roof_rhs if cd_dominant else roof_cd,
             "phases_ms_per_step": phases,
             "final_loss": final_loss,
         }

@@ -126,6 +126,11 @@ enum { RCPPML_CD_AUTO = 0 /* = GROUP unless RCPPML_GPU_CD_VARIANT says otherwise
 RCPPML_GPU_API int rcppml_hip_ctx_create(rcppml_hip_ctx** out, int device, void* stream);
 RCPPML_GPU_API void rcppml_hip_ctx_destroy(rcppml_hip_ctx* ctx);
 RCPPML_GPU_API int rcppml_hip_ctx_sync(rcppml_hip_ctx* ctx);
+/* Work counters since creation / the last reset (synchronises the stream): out4[0] = column-sweeps executed by the
+ * coordinate-descent kernels (sum over solved columns of the sweeps cd_nnls_col_fixed ran, nnls_batch.hpp:127-131;
+ * x 2 k_pad^2 = the flops of the residual updates), out4[1] = columns solved, out4[2..3] reserved.  Counted by the
+ * GROUP and MFMA kernels (what RCPPML_CD_AUTO dispatches to). */
+RCPPML_GPU_API int rcppml_hip_ctx_stats(rcppml_hip_ctx* ctx, int reset, unsigned long long* out4);
 
 /* G = F F^T (+ eps on the diagonal, then + l2) -- reference primitives/cpu/gram.hpp:37-67 and
  * nmf/fit_cpu.hpp:506,738.  F: k x r.  MFMA kernel (v_mfma_f32_32x32x2_f32 / v_mfma_f64_16x16x4_f64),

@@ -19,7 +19,7 @@ CD_AUTO, CD_LANE, CD_WAVE, CD_GROUP, CD_MFMA = 0, 1, 2, 5, 6
 EXPORTED_SYMBOLS = [
     "rcppml_gpu_detect", "rcppml_gpu_nmf_unified_float", "rcppml_gpu_nmf_unified_double", "rcppml_gpu_nmf_ex",
     "rcppml_gpu_nnls_double", "rcppml_gpu_evaluate_mse_double", "rcppml_gpu_last_error",
-    "rcppml_hip_ctx_create", "rcppml_hip_ctx_destroy", "rcppml_hip_ctx_sync", "rcppml_hip_gram", "rcppml_hip_rhs",
+    "rcppml_hip_ctx_create", "rcppml_hip_ctx_destroy", "rcppml_hip_ctx_sync", "rcppml_hip_ctx_stats", "rcppml_hip_gram", "rcppml_hip_rhs",
     "rcppml_hip_solve_cd", "rcppml_hip_order_columns", "rcppml_hip_solve_chol", "rcppml_hip_row_norms", "rcppml_hip_apply_scaling",
     "rcppml_hip_sumsq", "rcppml_hip_loss_mse", "rcppml_hip_solve_masked", "rcppml_hip_loss_nonzeros",
     "rcppml_hip_solve_irls_nb", "rcppml_hip_nb_size_update", "rcppml_hip_nb_loss",
@@ -43,7 +43,7 @@ def lib():
         except OSError as e:  # e.g. libamdhip64 missing
             raise BackendError("cannot load %s: %s" % (LIB_PATH, e))
         _lib.rcppml_gpu_last_error.restype = C.c_char_p
-        for name in ("rcppml_hip_ctx_create", "rcppml_hip_ctx_sync", "rcppml_hip_gram", "rcppml_hip_rhs",
+        for name in ("rcppml_hip_ctx_create", "rcppml_hip_ctx_sync", "rcppml_hip_ctx_stats", "rcppml_hip_gram", "rcppml_hip_rhs",
                      "rcppml_hip_solve_cd", "rcppml_hip_order_columns", "rcppml_hip_solve_chol", "rcppml_hip_row_norms",
                      "rcppml_hip_apply_scaling",
                      "rcppml_hip_sumsq", "rcppml_hip_loss_mse", "rcppml_hip_solve_masked", "rcppml_hip_loss_nonzeros",
@@ -211,6 +211,12 @@ class Context:
 
     def sync(self):
         _chk(lib().rcppml_hip_ctx_sync(self._h), "ctx_sync")
+
+    def stats(self, reset=False):
+        """Work counters: dict(cd_column_sweeps, cd_columns) since creation / the last reset (synchronises)."""
+        out = (C.c_ulonglong * 4)()
+        _chk(lib().rcppml_hip_ctx_stats(self._h, C.c_int(1 if reset else 0), out), "ctx_stats")
+        return dict(cd_column_sweeps=int(out[0]), cd_columns=int(out[1]))
 
     # ---- ops (dt: F32/F64; tensors are torch CUDA tensors laid out (cols, k) == column-major k x cols)
     def gram(self, dt, F, k, r, eps, l2, G):

@@ -45,6 +45,8 @@ struct rcppml_hip_ctx {
     int num_cu = 256;
     struct Buf { void* ptr = nullptr; size_t bytes = 0; };
     Buf bufs[WS_COUNT];
+    // device counters read by rcppml_hip_ctx_stats: [0] column-sweeps executed by the CD kernels, [1] columns solved
+    unsigned long long* stats = nullptr;
     // Grow-only scratch.  Growth frees the old block with hipFree, which synchronises the device,
     // so no in-flight kernel can still be using it.
     void* scratch(int slot, size_t bytes) {

@@ -558,12 +558,26 @@ struct CdGroupStep {
     }
 };
 
+
+// one atomic pair per wavefront: sum of the per-lane sweep counts (0 on lanes that own no column) -> ctx counters
+__device__ __forceinline__ void cd_stats_add(unsigned long long* stats, int nsw, int ncol) {
+    if (!stats) return;
+    int v = nsw, c = ncol;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { v += __shfl_xor(v, off, 64); c += __shfl_xor(c, off, 64); }
+    if ((threadIdx.x & 63) == 0 && c > 0) {
+        atomicAdd(stats, (unsigned long long)v);
+        atomicAdd(stats + 1, (unsigned long long)c);
+    }
+}
+
 template <class T, int KP, int LPC, bool EXACT>
 __global__ __launch_bounds__(256) void cd_group_kernel(const T* __restrict__ Gp, const T* __restrict__ invd,
                                                         const T* __restrict__ B, T* __restrict__ X, int k,
                                                         int64_t ncols, T l1_pre, int warm, int zero_init, T l1_cd,
                                                         T l2_cd, int nonneg, int maxit, T tol, T ub_cd, T ub_post,
-                                                        int* __restrict__ sweeps, const int* __restrict__ order) {
+                                                        int* __restrict__ sweeps, const int* __restrict__ order,
+                                                        unsigned long long* __restrict__ stats) {
     constexpr int RPL = KP / LPC;               // rows per lane
     constexpr int CPW = 64 / LPC;               // columns per wave
     constexpr int EV = 16 / sizeof(T);
@@ -644,6 +658,7 @@ __global__ __launch_bounds__(256) void cd_group_kernel(const T* __restrict__ Gp,
         }
         if (sweeps && sub == 0) sweeps[j] = nsweep;
     }
+    cd_stats_add(stats, (inb && sub == 0) ? nsweep : 0, (inb && sub == 0) ? 1 : 0);
 }
 
 // ---------------------------------------------------------------------------

@@ -96,7 +96,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CT == 1 ? 4
                                                        float* __restrict__ X, int k, int64_t ncols, float l1_pre,
                                                        int warm, int zero_init, float l1_cd, float l2_cd, int nonneg,
                                                        int maxit, float tol, float ub_cd, float ub_post,
-                                                       int* __restrict__ sweeps, const int* __restrict__ order) {
+                                                       int* __restrict__ sweeps, const int* __restrict__ order,
+                                                       unsigned long long* __restrict__ stats) {
     constexpr int KP = 32 * RT;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* Gs = reinterpret_cast<float*>(smem_raw);      // KP*KP, pair-major (see cd_mfma_prep_kernel)
@@ -248,6 +249,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CT == 1 ? 4
             }
         if (sweeps && half == 0) sweeps[j[ct]] = nsweep[ct];
     }
+    int nsw = 0, ncol = 0;
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+        if (inb[ct] && half == 0) { nsw += nsweep[ct]; ncol += 1; }
+    cd_stats_add(stats, nsw, ncol);
 }
 
 }  // namespace rk

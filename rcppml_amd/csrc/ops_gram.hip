@@ -19,6 +19,8 @@ extern "C" int rcppml_hip_ctx_create(rcppml_hip_ctx** out, int device, void* str
         hipDeviceProp_t prop;
         HIPCHK(hipGetDeviceProperties(&prop, device));
         c->num_cu = prop.multiProcessorCount;
+        HIPCHK(hipMalloc(&c->stats, 4 * sizeof(unsigned long long)));
+        HIPCHK(hipMemset(c->stats, 0, 4 * sizeof(unsigned long long)));
         *out = c;
         return 0;
     }
@@ -28,10 +30,20 @@ extern "C" void rcppml_hip_ctx_destroy(rcppml_hip_ctx* c) {
     if (!c) return;
     for (auto& b : c->bufs)
         if (b.ptr) (void)hipFree(b.ptr);
+    if (c->stats) (void)hipFree(c->stats);
     delete c;
 }
 extern "C" int rcppml_hip_ctx_sync(rcppml_hip_ctx* c) {
     try { HIPCHK(hipStreamSynchronize(c->stream)); return 0; }
+    RCPPML_CATCH_RET
+}
+extern "C" int rcppml_hip_ctx_stats(rcppml_hip_ctx* c, int reset, unsigned long long* out4) {
+    try {
+        HIPCHK(hipStreamSynchronize(c->stream));
+        if (out4) HIPCHK(hipMemcpy(out4, c->stats, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        if (reset) HIPCHK(hipMemset(c->stats, 0, 4 * sizeof(unsigned long long)));
+        return 0;
+    }
     RCPPML_CATCH_RET
 }
 

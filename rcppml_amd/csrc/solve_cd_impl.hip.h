@@ -57,7 +57,7 @@ static void cd_group_launch(rcppml_hip_ctx* c, const T* Gp, const T* invd, const
     const int64_t per_block = (int64_t)4 * (64 / LPC);
     const int64_t nblk = (ncols + per_block - 1) / per_block;
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), smem, c->stream, Gp, invd, B, X, k, ncols, l1_pre, warm,
-                       zero_init, l1_cd, l2_cd, nonneg, maxit, tol, ub_cd, ub_post, sweeps, order);
+                       zero_init, l1_cd, l2_cd, nonneg, maxit, tol, ub_cd, ub_post, sweeps, order, c->stats);
     HIPCHK(hipGetLastError());
 }
 
@@ -77,10 +77,10 @@ static void cd_mfma_launch(rcppml_hip_ctx* c, const float* Gp, const float* invd
     const bool simple = nonneg && ub_cd <= 0.f && l1_cd == 0.f && l2_cd == 0.f;
     if (simple)
         hipLaunchKernelGGL((cd_mfma_kernel<RT, CT, true>), dim3((unsigned)nblk), dim3(256), smem, c->stream, Gq, tab, B, X,
-                           k, ncols, l1_pre, warm, zero_init, l1_cd, l2_cd, nonneg, maxit, tol, ub_cd, ub_post, sweeps, order);
+                           k, ncols, l1_pre, warm, zero_init, l1_cd, l2_cd, nonneg, maxit, tol, ub_cd, ub_post, sweeps, order, c->stats);
     else
         hipLaunchKernelGGL((cd_mfma_kernel<RT, CT, false>), dim3((unsigned)nblk), dim3(256), smem, c->stream, Gq, tab, B, X,
-                           k, ncols, l1_pre, warm, zero_init, l1_cd, l2_cd, nonneg, maxit, tol, ub_cd, ub_post, sweeps, order);
+                           k, ncols, l1_pre, warm, zero_init, l1_cd, l2_cd, nonneg, maxit, tol, ub_cd, ub_post, sweeps, order, c->stats);
     HIPCHK(hipGetLastError());
 }
 
