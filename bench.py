@@ -199,6 +199,22 @@ def main():
                        "mean_sweeps_per_column": work["cd_column_sweeps"] / work["cd_columns"],
                        "solve_H_ms": ms_sh / max(cnt_sh, 1), "solve_W_ms": ms_sw / max(cnt_sw, 1)}
         cd_dominant = roof_cd is not None and (ms_sh + ms_sw) > (ms_h + ms_w)
+        # HBM/fabric bytes per launch from the committed rocprofv3 PMC passes of this same command (FETCH_SIZE x2 per the
+        # gfx950 correction + WRITE_SIZE, profiles/summarize.py); only meaningful for the default workload
+        default_wl = (m, n_loc, k, args.dtype, world) == (20000, 100000, 64, "f32", 1)
+        pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc.json")
+        if default_wl and os.path.exists(pmc_path):
+            try:
+                pmc = json.load(open(pmc_path))
+                for name, v in pmc.items():
+                    if "rhs_kernel" in name:
+                        roof_rhs["traffic"] = v["hbm_bytes_per_launch"]
+                        roof_rhs["traffic_source"] = "profiles/r01_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
+                    if roof_cd is not None and "cd_mfma_kernel" in name:
+                        roof_cd["traffic"] = v["hbm_bytes_per_launch"]
+                        roof_cd["traffic_source"] = "profiles/r01_pmc.json"
+            except Exception:
+                pass
         out = {
             "metric": "ALS updates/sec (cols solved/s), k=%d sparse NMF" % k,
             "value": args.steps * (m + n_total) / dt,
