@@ -91,7 +91,7 @@ __device__ __forceinline__ CdStepOut cd_scalar_step(float b, float xo, float gin
 }
 
 template <int RT, int CT, bool SIMPLE>   // KP = 32*RT rows (k <= KP), 32*CT columns per wave, 4 waves per block share G
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CT == 1 ? 4 : 2, 8))) void cd_mfma_kernel(const float* __restrict__ Gq, const float2* __restrict__ tab,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((CT == 1 && RT <= 2) ? 4 : 2, 8))) void cd_mfma_kernel(const float* __restrict__ Gq, const float2* __restrict__ tab,
                                                        const float* __restrict__ B,
                                                        float* __restrict__ X, int k, int64_t ncols, float l1_pre,
                                                        int warm, int zero_init, float l1_cd, float l2_cd, int nonneg,

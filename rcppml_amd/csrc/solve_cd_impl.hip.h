@@ -1,5 +1,6 @@
 // solve_cd_impl.hip.h -- CD solve launch logic (instantiated per dtype in ops_cd_f32.hip / ops_cd_f64.hip)
 #pragma once
+#include <cmath>
 #include "solve_common.hip.h"
 #include "kernels_cd_mfma.hip.h"
 // ----------------------------------------------------------------------------
@@ -61,7 +62,7 @@ static void cd_group_launch(rcppml_hip_ctx* c, const T* Gp, const T* invd, const
     HIPCHK(hipGetLastError());
 }
 
-// MFMA variant (fp32, k <= 64): rank-1 residual updates on the matrix cores, 32*CT columns per wave.
+// MFMA variant (fp32, k <= 128): rank-1 residual updates on the matrix cores, 32*CT columns per wave.
 template <int RT, int CT>
 static void cd_mfma_launch(rcppml_hip_ctx* c, const float* Gp, const float* invd, const float* B, float* X, int k,
                            int64_t ncols, float l1_pre, int warm, int zero_init, float l1_cd, float l2_cd, int nonneg,
@@ -71,10 +72,36 @@ static void cd_mfma_launch(rcppml_hip_ctx* c, const float* Gp, const float* invd
     float2* tab = reinterpret_cast<float2*>(Gq + (size_t)KP * KP);
     hipLaunchKernelGGL(cd_mfma_prep_kernel, dim3((KP * KP + 255) / 256), dim3(256), 0, c->stream, Gp, invd, KP, Gq, tab);
     HIPCHK(hipGetLastError());
-    const size_t smem = ((size_t)KP * KP + 2 * KP) * sizeof(float);
+    size_t smem = ((size_t)KP * KP + 2 * KP) * sizeof(float);
     const int64_t per_block = 4 * 32 * CT;          // 4 waves per block
     const int64_t nblk = (ncols + per_block - 1) / per_block;
     const bool simple = nonneg && ub_cd <= 0.f && l1_cd == 0.f && l2_cd == 0.f;
+    // Residency cap.  A SIMD's waves share its (non-overlapping) VALU + f32-MFMA issue, so with all blocks resident
+    // the kernel takes as long as the fullest CU: 782 blocks on 256 CUs = 4 blocks on 14 CUs, 3 on the rest, i.e.
+    // 4/3.05 of the balanced time.  Capping residency at floor(blocks per CU) (by asking for more LDS than a further
+    // block would leave) makes the surplus blocks -- the cheapest ones under the sweep-sorted order -- start when
+    // the first blocks retire.  RCPPML_GPU_CD_CAP overrides (0 = no cap).
+    {
+        const double per_cu = (double)nblk / (double)(c->num_cu > 0 ? c->num_cu : 256);
+        int cap = 0;
+        if (per_cu > 1.0 && per_cu < 4.0 && per_cu - std::floor(per_cu) < 0.5) cap = (int)std::floor(per_cu);
+        if (const char* e = getenv("RCPPML_GPU_CD_CAP")) cap = atoi(e);
+        if (cap > 0) {
+            const size_t lds_cu = 160 * 1024;
+            const size_t want = lds_cu / (size_t)(cap + 1) + 1024;      // cap + 1 blocks no longer fit
+            if (want > smem && want <= lds_cu / (size_t)cap) smem = want;
+        }
+    }
+    static size_t attr_smem[2] = {0, 0};
+    if (smem > 48 * 1024 && smem > attr_smem[simple ? 1 : 0]) {
+        if (simple)
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&cd_mfma_kernel<RT, CT, true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        else
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&cd_mfma_kernel<RT, CT, false>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        attr_smem[simple ? 1 : 0] = smem;
+    }
     if (simple)
         hipLaunchKernelGGL((cd_mfma_kernel<RT, CT, true>), dim3((unsigned)nblk), dim3(256), smem, c->stream, Gq, tab, B, X,
                            k, ncols, l1_pre, warm, zero_init, l1_cd, l2_cd, nonneg, maxit, tol, ub_cd, ub_post, sweeps, order, c->stats);
@@ -112,10 +139,10 @@ static void solve_cd_impl(rcppml_hip_ctx* c, const T* G, const T* B, T* X, int k
         else if (e && !strcmp(e, "wave")) variant = RCPPML_CD_WAVE;
         else if (e && !strcmp(e, "group")) variant = RCPPML_CD_GROUP;
         else if (e && !strcmp(e, "mfma")) variant = RCPPML_CD_MFMA;
-        else variant = (std::is_same<T, float>::value && k <= 64) ? RCPPML_CD_MFMA : RCPPML_CD_GROUP;
+        else variant = std::is_same<T, float>::value ? RCPPML_CD_MFMA : RCPPML_CD_GROUP;
     }
-    if (variant == RCPPML_CD_MFMA && !(std::is_same<T, float>::value && k <= 64)) variant = RCPPML_CD_GROUP;
-    if (variant == RCPPML_CD_MFMA) KP = k <= 32 ? 32 : 64;
+    if (variant == RCPPML_CD_MFMA && !std::is_same<T, float>::value) variant = RCPPML_CD_GROUP;
+    if (variant == RCPPML_CD_MFMA) KP = 32 * ((k + 31) / 32);
     // register-resident lane kernel (SGPR-fed): fp32 up to KP=64, fp64 up to KP=32 without spilling
     const int lane_max = std::is_same<T, float>::value ? 64 : 32;
     if (variant == RCPPML_CD_LANE && KP > lane_max) variant = RCPPML_CD_GROUP;
@@ -134,10 +161,12 @@ static void solve_cd_impl(rcppml_hip_ctx* c, const T* G, const T* B, T* X, int k
         }
     } else if (variant == RCPPML_CD_MFMA) {
         if constexpr (std::is_same<T, float>::value) {
-            const char* ce = getenv("RCPPML_GPU_CD_MFMA_CT");
-            const int ct = ce ? atoi(ce) : 1;
-            if (KP == 32) { if (ct == 2) cd_mfma_launch<1, 2>(CD_ARGS); else cd_mfma_launch<1, 1>(CD_ARGS); }
-            else { if (ct == 2) cd_mfma_launch<2, 2>(CD_ARGS); else cd_mfma_launch<2, 1>(CD_ARGS); }
+            switch (KP) {
+                case 32: cd_mfma_launch<1, 1>(CD_ARGS); break;
+                case 64: cd_mfma_launch<2, 1>(CD_ARGS); break;
+                case 96: cd_mfma_launch<3, 1>(CD_ARGS); break;
+                default: cd_mfma_launch<4, 1>(CD_ARGS); break;
+            }
         }
     } else if (variant == RCPPML_CD_GROUP) {
         const int lpc = pick_lpc<T>(KP);

@@ -111,7 +111,7 @@ def _var(_abi, name):
 
 @pytest.mark.parametrize("variant", VARIANTS)
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
-@pytest.mark.parametrize("k", [2, 10, 16, 32, 64, 100, 128])
+@pytest.mark.parametrize("k", [2, 10, 16, 32, 64, 80, 100, 128])
 def test_cd_cold(env, dtype, k, variant):
     """nnls_batch cold start (X = 0), reference nnls_batch.hpp:150-225, incl. early exit on cd_tol."""
     torch, _abi, ctx = env
