@@ -276,6 +276,100 @@ __global__ __launch_bounds__(256) void rhs_kernel(const int* __restrict__ colptr
 }
 
 // ---------------------------------------------------------------------------
+// RHS, staged-index variant ("rhs_stage_kernel").  Same lane-group mapping and the same summation order as rhs_kernel
+// (bitwise identical results), but the (row, value) stream of the column is fetched COALESCED -- one vector load per
+// NG*U nonzeros instead of one group-uniform load per nonzero -- and handed to the lane groups through the LDS crossbar
+// (ds_bpermute).  rhs_kernel spends a third of its texture-addresser time on those group-uniform index/value loads;
+// here the only per-nonzero vector-memory instruction left is the gather itself.
+// ---------------------------------------------------------------------------
+template <class T, int VEC, int LPN, int U>
+__global__ __launch_bounds__(256) void rhs_stage_kernel(const int* __restrict__ colptr,
+                                                         const int* __restrict__ rowidx,
+                                                         const T* __restrict__ vals, int64_t ncols,
+                                                         const T* __restrict__ F, int k,
+                                                         T* __restrict__ B) {
+    constexpr int NG = 64 / LPN;
+    constexpr int CH = NG * U;              // nonzeros per staged chunk (<= 64)
+    static_assert(CH <= 64, "one lane per staged nonzero");
+    const int64_t j = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (j >= ncols) return;
+    const int lane = threadIdx.x & 63;
+    const int g = lane / LPN, li = lane % LPN;
+    const int f0 = li * VEC;
+    const bool fok = f0 < k;
+    const int start = colptr[j], end = colptr[j + 1];
+    T acc[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) acc[e] = T(0);
+    const T* Fl = F + (fok ? f0 : 0);
+    // The NEXT chunk's (row, value) lanes are requested before the current chunk's gathers are issued.  The loads are
+    // unconditional (address clamped into the column, value masked afterwards): a predicated load becomes a branch,
+    // and hipcc then sinks the prefetch to the end of the iteration where its whole latency is exposed.
+    int ri_n = 0;
+    T vi_n = T(0);
+    if (start < end) {
+        const int tt = start + lane;
+        const int tc = tt < end ? tt : end - 1;
+        const int r0 = rowidx[tc];
+        const T v0 = vals[tc];
+        const bool ok = lane < CH && tt < end;
+        ri_n = ok ? r0 : 0;                           // past the end: row 0 with weight 0, as rhs_kernel does
+        vi_n = ok ? v0 : T(0);
+    }
+    for (int t0 = start; t0 < end; t0 += CH) {
+        const int ri = ri_n;
+        const T vi = vi_n;
+        {
+            const int tt = t0 + CH + lane;
+            const int tc = tt < end ? tt : end - 1;
+            const int r0 = rowidx[tc];
+            const T v0 = vals[tc];
+            __builtin_amdgcn_sched_barrier(0);
+            const bool ok = lane < CH && tt < end;
+            ri_n = ok ? r0 : 0;
+            vi_n = ok ? v0 : T(0);
+        }
+        T ff[U][VEC];
+        T vv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int nz = u * NG + g;               // group g takes nonzeros g, g + NG, ... (rhs_kernel's order)
+            const int r = __shfl(ri, nz, 64);
+            vv[u] = __shfl(vi, nz, 64);
+            const T* src = Fl + (int64_t)r * k;
+            if constexpr (VEC == 1) {
+                ff[u][0] = src[0];
+            } else {
+                typedef typename VecT<T, VEC>::type V;
+                const V v = *reinterpret_cast<const V*>(src);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) ff[u][e] = v[e];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) acc[e] = tfma(vv[u], ff[u][e], acc[e]);
+    }
+#pragma unroll
+    for (int off = LPN; off < 64; off <<= 1)
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) acc[e] += shfl_xor_t(acc[e], off);
+    if (g == 0 && fok) {
+        T* dst = B + j * (int64_t)k + f0;
+        if constexpr (VEC == 1) {
+            dst[0] = acc[0];
+        } else {
+            typedef typename VecT<T, VEC>::type V;
+            V v;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) v[e] = acc[e];
+            *reinterpret_cast<V*>(dst) = v;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // RHS, scalarised-index variant for 33 <= k <= 128 ("rhs_wave_kernel").
 // Measured on MI355X the lane-group kernel above is bound by the texture-addresser (TA), not by L2 or HBM: with the
 // gathered factor shrunk to 64 KB (all L1 hits) it still tops out at 17 TB/s, because every group-uniform (row, value)

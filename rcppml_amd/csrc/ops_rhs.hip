@@ -18,6 +18,24 @@ static void rhs_launch(rcppml_hip_ctx* c, const int* cp, const int* ri, const T*
         mode = !e ? 0 : (!strcmp(e, "u16") ? 1 : (!strcmp(e, "u4") ? 2 : (!strcmp(e, "u2") ? 3 : 0)));
     }
     dim3 grid((unsigned)nblk), block(256);
+    if constexpr (LPN >= 8) {     // staged indices (one coalesced load per 64/LPN*8 nonzeros); RCPPML_GPU_RHS_VARIANT=group opts out
+        static int staged = -1;
+        if (staged < 0) { const char* e = getenv("RCPPML_GPU_RHS_VARIANT"); staged = (e && *e) ? (!strcmp(e, "stage") ? 1 : 0) : 1; }
+        if (staged) {
+            // 16 gathers in flight per lane group and a full wave of staged (row, value) pairs per index load where the
+            // group count allows (measured on C2 fp32: rhs_H 0.41 -> 0.29 ms, rhs_W 0.44 -> 0.31 ms vs rhs_kernel; with
+            // 8 in flight the W side, which gathers from the 25 MB factor, is 20 % SLOWER than rhs_kernel)
+            constexpr int SU = LPN >= 16 ? 16 : 8;
+            static int su = -1;
+            if (su < 0) { const char* e = getenv("RCPPML_GPU_RHS_STAGE_U"); su = e ? atoi(e) : SU; }
+            if (su == 8 || SU == 8)
+                hipLaunchKernelGGL((rhs_stage_kernel<T, VEC, LPN, 8>), grid, block, 0, c->stream, cp, ri, vals, ncols, F, k, B);
+            else
+                hipLaunchKernelGGL((rhs_stage_kernel<T, VEC, LPN, SU>), grid, block, 0, c->stream, cp, ri, vals, ncols, F, k, B);
+            HIPCHK(hipGetLastError());
+            return;
+        }
+    }
     switch (mode) {
         case 1: hipLaunchKernelGGL((rhs_kernel<T, VEC, LPN, 16, false>), grid, block, 0, c->stream, cp, ri, vals, ncols, F, k, B); break;
         case 2: hipLaunchKernelGGL((rhs_kernel<T, VEC, LPN, 4, false>), grid, block, 0, c->stream, cp, ri, vals, ncols, F, k, B); break;
