@@ -34,6 +34,14 @@ __device__ __forceinline__ double tfma(double a, double b, double c) { return __
 __device__ __forceinline__ float shfl_xor_t(float v, int m) { return __shfl_xor(v, m, 64); }
 __device__ __forceinline__ double shfl_xor_t(double v, int m) { return __shfl_xor(v, m, 64); }
 
+// 8/16-byte vector types for whole-vector loads and stores
+template <class T, int VEC> struct VecT;
+template <> struct VecT<float, 1> { typedef float type; };
+template <> struct VecT<float, 2> { typedef float type __attribute__((ext_vector_type(2))); };
+template <> struct VecT<float, 4> { typedef float type __attribute__((ext_vector_type(4))); };
+template <> struct VecT<double, 1> { typedef double type; };
+template <> struct VecT<double, 2> { typedef double type __attribute__((ext_vector_type(2))); };
+
 // ---------------------------------------------------------------------------
 // Gram  G = F F^T  (reference primitives/cpu/gram.hpp:37-67)
 //
@@ -45,7 +53,11 @@ __device__ __forceinline__ double shfl_xor_t(double v, int m) { return __shfl_xo
 // in fixed order (in-block through LDS, then across blocks by gram_finalize) so the result is
 // deterministic and bitwise symmetric.
 // ---------------------------------------------------------------------------
-template <int T_TILES>  // KP = 32 * T_TILES
+// VL (vector loads): with T_TILES in {2, 4} and k % T_TILES == 0 the wave reads each column of F with ONE 8/16-byte load
+// per lane (lane slot s takes rows T*s .. T*s+T-1) and tile t is made of the rows congruent to t mod T -- a row
+// permutation the Gram is indifferent to, undone when the tile is written.  STEPS K-steps of loads are issued before
+// their MFMAs: the loop is bound by HBM latency, not by the matrix pipe (64 cycles per instruction).
+template <int T_TILES, bool VL, int STEPS>  // KP = 32 * T_TILES
 __global__ __launch_bounds__(256) void gram_partial_f32(const float* __restrict__ F, int k, int64_t r,
                                                          float* __restrict__ partial) {
     constexpr int KP = 32 * T_TILES;
@@ -63,22 +75,41 @@ __global__ __launch_bounds__(256) void gram_partial_f32(const float* __restrict_
     for (int t = 0; t < T_TILES; ++t)
 #pragma unroll
         for (int v = 0; v < 16; ++v) acc[t][v] = 0.f;
-    const int rowi = 32 * ti + row;
-#pragma unroll 4
-    for (int64_t p = p0; p < p1; ++p) {
-        const int64_t c = 2 * p + kk;
-        const bool cok = c < r;
-        const float* fc = F + c * (int64_t)k;
-        const float ai = (cok && rowi < k) ? fc[rowi] : 0.f;
-        float a[T_TILES];
+    for (int64_t pb = p0; pb < p1; pb += STEPS) {
+        float a[STEPS][T_TILES];
 #pragma unroll
-        for (int t = 0; t < T_TILES; ++t) {
-            const int rr = 32 * t + row;
-            a[t] = (cok && rr < k) ? fc[rr] : 0.f;
+        for (int s = 0; s < STEPS; ++s) {
+            const int64_t c = 2 * (pb + s) + kk;
+            const bool cok = (pb + s) < p1 && c < r;
+            const float* fc = F + c * (int64_t)k;
+            if constexpr (VL) {
+                typedef typename VecT<float, T_TILES>::type V;
+                const int r0 = T_TILES * row;
+                if (cok && r0 < k) {
+                    const V v = *reinterpret_cast<const V*>(fc + r0);
+#pragma unroll
+                    for (int t = 0; t < T_TILES; ++t) a[s][t] = v[t];
+                } else {
+#pragma unroll
+                    for (int t = 0; t < T_TILES; ++t) a[s][t] = 0.f;
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < T_TILES; ++t) {
+                    const int rr = 32 * t + row;
+                    a[s][t] = (cok && rr < k) ? fc[rr] : 0.f;
+                }
+            }
         }
 #pragma unroll
-        for (int t = 0; t < T_TILES; ++t)
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ai, a[t], acc[t], 0, 0, 0);
+        for (int s = 0; s < STEPS; ++s)
+#pragma unroll
+            for (int t = 0; t < T_TILES; ++t) {
+                float ai = a[s][0];
+#pragma unroll
+                for (int t2 = 1; t2 < T_TILES; ++t2) ai = (ti == t2) ? a[s][t2] : ai;
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ai, a[s][t], acc[t], 0, 0, 0);
+            }
     }
     // in-block reduction, fixed order wave0 + wave1 + wave2 + wave3
     if (wave > 0) {
@@ -99,8 +130,9 @@ __global__ __launch_bounds__(256) void gram_partial_f32(const float* __restrict_
                 s += red[1][t * 1024 + v * 64 + lane];
                 s += red[2][t * 1024 + v * 64 + lane];
                 // C/D map of 32x32 MFMA: col = lane&31, row = (v&3) + 8*(v>>2) + 4*(lane>>5)
-                const int i = 32 * ti + (v & 3) + 8 * (v >> 2) + 4 * (lane >> 5);
-                const int j = 32 * t + (lane & 31);
+                const int is = (v & 3) + 8 * (v >> 2) + 4 * (lane >> 5), js = lane & 31;
+                const int i = VL ? T_TILES * is + ti : 32 * ti + is;
+                const int j = VL ? T_TILES * js + t : 32 * t + js;
                 out[(int64_t)j * KP + i] = s;
             }
     }
@@ -197,13 +229,6 @@ __global__ __launch_bounds__(256) void gram_finalize(const T* __restrict__ parti
 // (consecutive int32 / T, cache-line coalesced).  U independent gathers are kept in flight per lane.
 // Group partial sums are combined with xor-shuffles at the end.
 // ---------------------------------------------------------------------------
-template <class T, int VEC> struct VecT;
-template <> struct VecT<float, 1> { typedef float type; };
-template <> struct VecT<float, 2> { typedef float type __attribute__((ext_vector_type(2))); };
-template <> struct VecT<float, 4> { typedef float type __attribute__((ext_vector_type(4))); };
-template <> struct VecT<double, 1> { typedef double type; };
-template <> struct VecT<double, 2> { typedef double type __attribute__((ext_vector_type(2))); };
-
 template <class T, int VEC, int LPN, int U, bool NT>
 __global__ __launch_bounds__(256) void rhs_kernel(const int* __restrict__ colptr,
                                                    const int* __restrict__ rowidx,

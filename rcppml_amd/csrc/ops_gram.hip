@@ -60,22 +60,31 @@ static void gram_impl(rcppml_hip_ctx* c, const T* F, int k, int64_t r, T eps, T 
     if (KP > 256) throw std::runtime_error("gram: k > 256 not supported");
     // number of blocks: enough waves to fill the chip, each wave >= 64 K-steps
     const int64_t step = std::is_same<T, float>::value ? 2 : 4;
-    int64_t nblk = (r / step + 4 * 64 - 1) / (4 * 64);
+    // enough waves to fill the chip; each wave >= 32 K-steps (more, smaller waves: the loop is latency-bound); the cap
+    // bounds the partial-tile traffic (nblk * KP^2 values written and re-read by gram_finalize)
+    int64_t nblk = (r / step + 4 * 32 - 1) / (4 * 32);
     if (nblk < 1) nblk = 1;
     if (nblk > 2 * (int64_t)c->num_cu) nblk = 2 * c->num_cu;
     T* partial = static_cast<T*>(c->scratch(WS_GRAM, (size_t)nblk * KP * KP * sizeof(T)));
     if constexpr (std::is_same<T, float>::value) {
         const int tt = KP / 32;
         dim3 grid((unsigned)nblk, tt), block(256);
+        const bool vl = (tt == 2 || tt == 4) && k % tt == 0 && reinterpret_cast<uintptr_t>(F) % (4 * tt) == 0;
         switch (tt) {
-            case 1: hipLaunchKernelGGL(gram_partial_f32<1>, grid, block, 0, c->stream, F, k, r, partial); break;
-            case 2: hipLaunchKernelGGL(gram_partial_f32<2>, grid, block, 0, c->stream, F, k, r, partial); break;
-            case 3: hipLaunchKernelGGL(gram_partial_f32<3>, grid, block, 0, c->stream, F, k, r, partial); break;
-            case 4: hipLaunchKernelGGL(gram_partial_f32<4>, grid, block, 0, c->stream, F, k, r, partial); break;
-            case 5: hipLaunchKernelGGL(gram_partial_f32<5>, grid, block, 0, c->stream, F, k, r, partial); break;
-            case 6: hipLaunchKernelGGL(gram_partial_f32<6>, grid, block, 0, c->stream, F, k, r, partial); break;
-            case 7: hipLaunchKernelGGL(gram_partial_f32<7>, grid, block, 0, c->stream, F, k, r, partial); break;
-            default: hipLaunchKernelGGL(gram_partial_f32<8>, grid, block, 0, c->stream, F, k, r, partial); break;
+            case 1: hipLaunchKernelGGL((gram_partial_f32<1, false, 8>), grid, block, 0, c->stream, F, k, r, partial); break;
+            case 2:
+                if (vl) hipLaunchKernelGGL((gram_partial_f32<2, true, 8>), grid, block, 0, c->stream, F, k, r, partial);
+                else hipLaunchKernelGGL((gram_partial_f32<2, false, 8>), grid, block, 0, c->stream, F, k, r, partial);
+                break;
+            case 3: hipLaunchKernelGGL((gram_partial_f32<3, false, 4>), grid, block, 0, c->stream, F, k, r, partial); break;
+            case 4:
+                if (vl) hipLaunchKernelGGL((gram_partial_f32<4, true, 4>), grid, block, 0, c->stream, F, k, r, partial);
+                else hipLaunchKernelGGL((gram_partial_f32<4, false, 4>), grid, block, 0, c->stream, F, k, r, partial);
+                break;
+            case 5: hipLaunchKernelGGL((gram_partial_f32<5, false, 4>), grid, block, 0, c->stream, F, k, r, partial); break;
+            case 6: hipLaunchKernelGGL((gram_partial_f32<6, false, 4>), grid, block, 0, c->stream, F, k, r, partial); break;
+            case 7: hipLaunchKernelGGL((gram_partial_f32<7, false, 2>), grid, block, 0, c->stream, F, k, r, partial); break;
+            default: hipLaunchKernelGGL((gram_partial_f32<8, false, 2>), grid, block, 0, c->stream, F, k, r, partial); break;
         }
     } else {
         const int tt = KP / 16;
