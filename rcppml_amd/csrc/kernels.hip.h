@@ -999,6 +999,50 @@ __global__ __launch_bounds__(256) void row_norm_partial(const T* __restrict__ X,
         __syncthreads();
     }
 }
+// Vectorised form for k % VEC == 0 (16-byte loads, four independent accumulators per lane: the scalar kernel above is
+// one dependent 4-byte load chain per thread and runs at ~1.4 TB/s).  Same partial layout, fixed summation order.
+template <class T, int VEC>
+__global__ __launch_bounds__(256) void row_norm_partial_vec(const T* __restrict__ X, int k, int64_t ncols,
+                                                             int norm_type, T* __restrict__ partial) {
+    typedef typename VecT<T, VEC>::type V;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    T* sh = reinterpret_cast<T*>(smem_raw);          // slots x k
+    const int lpc = k / VEC;                          // lanes per column (<= 256)
+    const int slots = 256 / lpc;
+    const int li = threadIdx.x % lpc, slot = threadIdx.x / lpc;
+    const int64_t per = (ncols + gridDim.x - 1) / gridDim.x;
+    const int64_t c0 = (int64_t)blockIdx.x * per;
+    const int64_t c1 = c0 + per < ncols ? c0 + per : ncols;
+    T acc[4][VEC];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) acc[u][e] = T(0);
+    if (slot < slots) {
+        for (int64_t c = c0 + slot; c < c1; c += 4 * slots) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t cc = c + (int64_t)u * slots;
+                if (cc < c1) {
+                    const V v = *reinterpret_cast<const V*>(X + cc * (int64_t)k + li * VEC);
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) {
+                        const T x = v[e];
+                        acc[u][e] += norm_type == 0 ? tabs(x) : (norm_type == 3 ? x : x * x);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) sh[slot * k + li * VEC + e] = (acc[0][e] + acc[1][e]) + (acc[2][e] + acc[3][e]);
+    }
+    __syncthreads();
+    for (int f = threadIdx.x; f < k; f += 256) {
+        T s = T(0);
+        for (int q = 0; q < slots; ++q) s += sh[q * k + f];
+        partial[(int64_t)blockIdx.x * k + f] = s;
+    }
+}
 template <class T>
 __global__ __launch_bounds__(64) void row_norm_final(const T* __restrict__ partial, int nblk, int k, T* __restrict__ out) {
     const int f = blockIdx.x;            // one wavefront per feature

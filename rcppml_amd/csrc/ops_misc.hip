@@ -12,8 +12,15 @@ static void row_norms_impl(rcppml_hip_ctx* c, const T* X, int k, int64_t ncols, 
     if (nblk > 2 * (int64_t)c->num_cu) nblk = 2 * c->num_cu;
     if (nblk < 1) nblk = 1;
     T* partial = static_cast<T*>(c->scratch(WS_RED, (size_t)nblk * k * sizeof(T)));
-    hipLaunchKernelGGL(row_norm_partial<T>, dim3((unsigned)nblk), dim3(256), 256 * sizeof(T), c->stream, X, k, ncols,
-                       norm_type, partial);
+    constexpr int VEC = 16 / sizeof(T);
+    if (k % VEC == 0 && k / VEC <= 256 && reinterpret_cast<uintptr_t>(X) % 16 == 0) {
+        const int slots = 256 / (k / VEC);
+        hipLaunchKernelGGL((row_norm_partial_vec<T, VEC>), dim3((unsigned)nblk), dim3(256), (size_t)slots * k * sizeof(T),
+                           c->stream, X, k, ncols, norm_type, partial);
+    } else {
+        hipLaunchKernelGGL(row_norm_partial<T>, dim3((unsigned)nblk), dim3(256), 256 * sizeof(T), c->stream, X, k, ncols,
+                           norm_type, partial);
+    }
     HIPCHK(hipGetLastError());
     hipLaunchKernelGGL(row_norm_final<T>, dim3(k), dim3(64), 0, c->stream, partial, (int)nblk, k, out);
     HIPCHK(hipGetLastError());
