@@ -175,7 +175,7 @@ def main():
         avg_bytes = (bytes_h * cnt_h + bytes_w * cnt_w) / max(launches, 1)
         achieved = avg_bytes / max(avg_s, 1e-12) / 1e9
         phases = {name: round(ms / args.steps, 4) for name, (c, ms) in sorted(ev.items())}
-        roof_rhs = {"bound": "hbm", "kernel": "rhs_kernel (SpMM-like B = F * A(:,j), both half-updates)",
+        roof_rhs = {"bound": "hbm", "kernel": "rhs_stage_kernel (SpMM-like B = F * A(:,j), both half-updates)",
                     "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                     "traffic": None, "algorithmic_bytes_per_launch": avg_bytes, "avg_launch_ms": avg_s * 1e3,
                     "rhs_H_ms": ms_h / max(cnt_h, 1), "rhs_W_ms": ms_w / max(cnt_w, 1)}
@@ -207,7 +207,7 @@ def main():
             try:
                 pmc = json.load(open(pmc_path))
                 for name, v in pmc.items():
-                    if "rhs_kernel" in name:
+                    if "rhs_stage_kernel" in name or "rhs_kernel" in name:
                         roof_rhs["traffic"] = v["hbm_bytes_per_launch"]
                         roof_rhs["traffic_source"] = "profiles/r01_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
                     if roof_cd is not None and "cd_mfma_kernel" in name:
