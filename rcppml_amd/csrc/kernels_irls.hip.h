@@ -49,7 +49,7 @@ template <class T> __device__ __forceinline__ T irls_weight_nb_dev(T predicted, 
     return static_cast<T>(w);
 }
 
-template <class T, int KP>   // KP = 64 lanes; k <= 64
+template <class T, int KP>   // KP in {32, 64}: features padded to KP (k <= KP), lane r = feature r
 __global__ __launch_bounds__(256) void irls_nb_solve_kernel(
     const int* __restrict__ colptr, const int* __restrict__ rowidx, const T* __restrict__ vals, int64_t ncols,
     const T* __restrict__ F, const T* __restrict__ Gbase, T* __restrict__ X, int k, T l1, T l2, int nonneg,
@@ -60,6 +60,8 @@ __global__ __launch_bounds__(256) void irls_nb_solve_kernel(
     const int64_t j = (int64_t)blockIdx.x * 4 + wave;
     if (j >= ncols) return;
     const bool fok = lane < k;
+    const bool lin = lane < KP;                  // KP = 32: the upper half of the wave only takes part in shuffles
+    const int ll = lin ? lane : 0;
     // base Gram row r in registers (padded with identity)
     T gb[KP];
 #pragma unroll
@@ -99,11 +101,11 @@ __global__ __launch_bounds__(256) void irls_nb_solve_kernel(
         T b = bw;
 #pragma unroll
         for (int c = 0; c < KP; ++c) {
-            Gl[c * KP + lane] = gw[c];
+            if (lin) Gl[c * KP + lane] = gw[c];
             const T xc = __shfl(x_old, c, 64);
             b = tfma(-gw[c], xc, b);
         }
-        const T gd = Gl[lane * KP + lane];
+        const T gd = Gl[ll * KP + ll];
         // cd_nnls_col_fixed(G_w, b_c, x, L1 inside, L2 = 0, nonneg, cd_maxit, ub = 0, tol = 0): all sweeps
         for (int it = 0; it < cd_maxit; ++it) {
             int cur = 0;
@@ -121,9 +123,9 @@ __global__ __launch_bounds__(256) void irls_nb_solve_kernel(
                 const int i = __builtin_ctzll(mask);
                 const T ad_i = __shfl(ad, i, 64), nx_i = __shfl(nx, i, 64);
                 if (lane == i) x = nx_i;
-                b = tfma(-Gl[i * KP + lane], ad_i, b);
+                b = tfma(-Gl[i * KP + ll], ad_i, b);
                 cur = i + 1;
-                if (cur >= 64) break;
+                if (cur >= KP) break;
             }
             if (!any) break;      // a sweep without any effective step: all remaining sweeps are no-ops too
         }

@@ -10,16 +10,22 @@ static void irls_impl(rcppml_hip_ctx* c, const int* cp, const int* ri, const T* 
                       const T* theta_row, const T* theta_col) {
     if (ncols <= 0) return;
     if (k < 1 || k > 64) throw std::runtime_error("solve_irls_nb: k must be in [1,64]");
-    const size_t smem = (size_t)4 * 64 * 64 * sizeof(T);
-    auto kern = irls_nb_solve_kernel<T, 64>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        attr_set = true;
-    }
     const int64_t nblk = (ncols + 3) / 4;
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), smem, c->stream, cp, ri, vals, ncols, F, Gbase, X, k, l1, l2,
-                       nonneg, cd_maxit, irls_max_iter, irls_tol, theta_row, theta_col);
+    if (k <= 32) {      // 32-wide instantiation: half the rank-1 work per nonzero, 16 KB of LDS per block (8 waves per SIMD)
+        const size_t smem = (size_t)4 * 32 * 32 * sizeof(T);
+        hipLaunchKernelGGL((irls_nb_solve_kernel<T, 32>), dim3((unsigned)nblk), dim3(256), smem, c->stream, cp, ri, vals, ncols,
+                           F, Gbase, X, k, l1, l2, nonneg, cd_maxit, irls_max_iter, irls_tol, theta_row, theta_col);
+    } else {
+        const size_t smem = (size_t)4 * 64 * 64 * sizeof(T);
+        auto kern = irls_nb_solve_kernel<T, 64>;
+        static bool attr_set = false;
+        if (!attr_set) {
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), smem, c->stream, cp, ri, vals, ncols, F, Gbase, X, k, l1, l2,
+                           nonneg, cd_maxit, irls_max_iter, irls_tol, theta_row, theta_col);
+    }
     HIPCHK(hipGetLastError());
 }
 extern "C" int rcppml_hip_solve_irls_nb(rcppml_hip_ctx* c, int dtype, const int* col_ptr, const int* row_idx,
