@@ -37,6 +37,17 @@ template <class T> __device__ __forceinline__ T wave_max(T v) {
     return v;
 }
 
+
+// value of lane i (wave-uniform i) through v_readlane_b32: the result lands in an SGPR, no LDS-crossbar round trip
+__device__ __forceinline__ float lane_value(float v, int i) {
+    return __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), i));
+}
+__device__ __forceinline__ double lane_value(double v, int i) {
+    const unsigned long long u = __double_as_longlong(v);
+    const unsigned lo = __builtin_amdgcn_readlane((unsigned)u, i), hi = __builtin_amdgcn_readlane((unsigned)(u >> 32), i);
+    return __longlong_as_double(((unsigned long long)hi << 32) | lo);
+}
+
 // math/loss.hpp:248-256  irls_weight_nb: computed in double, eps = tiny_num<Scalar>() = Scalar(1e-15)
 template <class T> __device__ __forceinline__ T irls_weight_nb_dev(T predicted, T nb_size) {
     double mu = static_cast<double>(predicted);
@@ -121,7 +132,7 @@ __global__ __launch_bounds__(256) void irls_nb_solve_kernel(
                 if (mask == 0ull) break;
                 any = true;
                 const int i = __builtin_ctzll(mask);
-                const T ad_i = __shfl(ad, i, 64), nx_i = __shfl(nx, i, 64);
+                const T ad_i = lane_value(ad, i), nx_i = lane_value(nx, i);
                 if (lane == i) x = nx_i;
                 b = tfma(-Gl[i * KP + ll], ad_i, b);
                 cur = i + 1;
@@ -132,6 +143,141 @@ __global__ __launch_bounds__(256) void irls_nb_solve_kernel(
         // IRLS convergence: max_i |x_i - x_old_i| / (|x_old_i| + 1e-12) < irls_tol
         T rel = fok ? tabs(x - x_old) / (tabs(x_old) + T(1e-12)) : T(0);
         rel = wave_max(rel);
+        if (rel < irls_tol) break;
+    }
+    if (fok) X[j * (int64_t)k + lane] = x;
+}
+
+// ---------------------------------------------------------------------------
+// fp32, k <= 32 (k % 4 == 0): the same IRLS half-update with the weighted Gram on the MATRIX cores.
+//   G_w = G + F_nz diag(w - 1) F_nz^T  is a rank-nnz_j update of a 32 x 32 tile: two nonzeros fill the two K-slots of one
+//   v_mfma_f32_32x32x2_f32 (A operand = (w_t - 1) f_t, B operand = f_t), against 32 shuffles + 32 fmas per nonzero in the
+//   row-in-registers form above.  The column is processed in chunks of 32 nonzeros:
+//   phase A (lane = nonzero t, half h of its features): coalesced (row, value) load, 16-byte gathers of F(row, :), the
+//     reconstruction f_t . x as 16 in-lane fmas + one half swap, the NB weight in fp64 -- all 32 nonzeros IN PARALLEL
+//     (the wave-per-nonzero form evaluates one weight per 64 lanes) -- and f_t, (w_t - 1), w_t a_t parked in LDS;
+//   phase B (lane = feature r, K-slot kk): one conflict-free ds_read_b32 of f_t[r] per lane feeds both MFMA operands and
+//     the weighted right-hand side b_w[r] += w_t a_t f_t[r].
+//   The CD solve is unchanged (exact sequential sweep with ballot skipping); G_w is written from the accumulator tile
+//   straight into its LDS slab, which aliases the staging buffer.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void irls_nb_mfma32_kernel(
+    const int* __restrict__ colptr, const int* __restrict__ rowidx, const float* __restrict__ vals, int64_t ncols,
+    const float* __restrict__ F, const float* __restrict__ Gbase, float* __restrict__ X, int k, float l1, float l2,
+    int nonneg, int cd_maxit, int irls_max_iter, float irls_tol, const float* __restrict__ theta_row,
+    const float* __restrict__ theta_col) {
+    constexpr int KP = 32, CH = 32, FS = 36;          // FS: padded row stride of the staged F rows (bank spread)
+    constexpr int WAVE_FLOATS = CH * FS + 2 * CH + KP;  // staged rows | (w-1, w a) pairs | x
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float* Fst = reinterpret_cast<float*>(smem_raw) + (size_t)wave * WAVE_FLOATS;
+    float2* sc = reinterpret_cast<float2*>(Fst + CH * FS);
+    float* xs = Fst + CH * FS + 2 * CH;
+    float* Gl = Fst;                                    // [c][r], KP*KP <= CH*FS: reused once the Gram is complete
+    const int64_t j = (int64_t)blockIdx.x * 4 + wave;
+    if (j >= ncols) return;
+    const int r = lane & 31, hh = lane >> 5;            // phase A: nonzero r, feature half hh; phase B: feature r, K-slot hh
+    const bool fok = lane < k;
+    const bool lin = lane < KP;
+    const int ll = lin ? lane : 0;
+    const int as = colptr[j], ae = colptr[j + 1];
+    const float th_col = theta_col ? theta_col[j] : 0.f;
+    float x = 0.f;                                      // nnls_batch_irls.hpp:482-483  H.setZero(): no warm start
+    for (int irls = 0; irls < irls_max_iter; ++irls) {
+        // accumulator tile <- base Gram (identity padding), C/D map: col = lane&31, row = (v&3) + 8(v>>2) + 4(lane>>5)
+        f32x16 acc;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const int gi = (v & 3) + 8 * (v >> 2) + 4 * hh, gj = r;
+            acc[v] = (gi < k && gj < k) ? Gbase[(int64_t)gj * k + gi] : (gi == gj ? 1.f : 0.f);
+        }
+        if (lin) xs[lane] = x;
+        float bw = 0.f;
+        for (int t0 = as; t0 < ae; t0 += CH) {
+            // ---- phase A
+            const int tt = t0 + r;
+            const bool ok = tt < ae;
+            const int row = ok ? rowidx[tt] : 0;
+            const float a = ok ? vals[tt] : 0.f;
+            const float* fsrc = F + (int64_t)row * k + 16 * hh;
+            float4 fv4[4];
+            float part = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int c0 = 16 * hh + 4 * q;
+                fv4[q] = (ok && c0 < k) ? *reinterpret_cast<const float4*>(fsrc + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+                const float4 xv = *reinterpret_cast<const float4*>(xs + c0);
+                part = tfma(fv4[q].x, xv.x, part);
+                part = tfma(fv4[q].y, xv.y, part);
+                part = tfma(fv4[q].z, xv.z, part);
+                part = tfma(fv4[q].w, xv.w, part);
+            }
+            const float recon = part + __shfl_xor(part, 32, 64);                 // W_T.col(row).dot(x)
+            const float th = theta_col ? th_col : (theta_row ? theta_row[row] : 0.f);
+            const float w = irls_weight_nb_dev<float>(recon, th);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(Fst + r * FS + 16 * hh + 4 * q) = fv4[q];
+            if (hh == 0) sc[r] = make_float2(ok ? w - 1.f : 0.f, ok ? w * a : 0.f);
+            __builtin_amdgcn_wave_barrier();
+            // ---- phase B: nonzeros (2s, 2s+1) of the chunk per MFMA
+            const int cnt = ae - t0 < CH ? ae - t0 : CH;
+            const int nst = (cnt + 1) >> 1;
+#pragma unroll 4
+            for (int s2 = 0; s2 < nst; ++s2) {
+                const int t = 2 * s2 + hh;
+                const float fv = Fst[t * FS + r];
+                const float2 ws = sc[t];
+                bw = tfma(ws.y, fv, bw);                                          // b_w += f * (w a)
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ws.x * fv, fv, acc, 0, 0, 0);   // G_w += (f (w-1)) f^T
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        bw += __shfl_xor(bw, 32, 64);
+        // park G_w in LDS ([c][r]; symmetric, so accumulator row i is written as slab row i)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const int gi = (v & 3) + 8 * (v >> 2) + 4 * hh;
+            float val = acc[v];
+            if (l2 > 0.f && gi == r && gi < k) val += l2;
+            Gl[gi * KP + r] = val;
+        }
+        __builtin_amdgcn_wave_barrier();
+        // residual b_c = b_w - G_w x_old
+        const float x_old = x;
+        float b = bw;
+#pragma unroll 8
+        for (int c = 0; c < KP; ++c) {
+            const float xc = __shfl(x_old, c, 64);
+            b = tfma(-Gl[c * KP + ll], xc, b);
+        }
+        const float gd = Gl[ll * KP + ll];
+        const float ginv = gd > 0.f ? 1.f / gd : 0.f;     // one division per pass; the sweep multiplies (as the MSE kernels do)
+        // cd_nnls_col_fixed(G_w, b_c, x, L1 inside, L2 = 0, nonneg, cd_maxit, ub = 0, tol = 0): all sweeps
+        for (int it = 0; it < cd_maxit; ++it) {
+            int cur = 0;
+            bool any = false;
+            while (true) {
+                float diff = b * ginv;
+                if (l1 != 0.f) diff -= l1;
+                const float nv = x + diff;
+                float ad = diff, nx = nv;
+                if (nonneg && nv < 0.f) { ad = -x; nx = 0.f; }
+                const bool moves = fok && (gd > 0.f) && (ad != 0.f) && (lane >= cur);
+                const unsigned long long mask = __ballot(moves);
+                if (mask == 0ull) break;
+                any = true;
+                const int i = __builtin_ctzll(mask);
+                const float ad_i = lane_value(ad, i), nx_i = lane_value(nx, i);
+                if (lane == i) x = nx_i;
+                b = tfma(-Gl[i * KP + ll], ad_i, b);
+                cur = i + 1;
+                if (cur >= KP) break;
+            }
+            if (!any) break;      // a sweep without any effective step: all remaining sweeps are no-ops too
+        }
+        float rel = fok ? tabs(x - x_old) / (tabs(x_old) + 1e-12f) : 0.f;
+        rel = wave_max(rel);
+        __builtin_amdgcn_wave_barrier();
         if (rel < irls_tol) break;
     }
     if (fok) X[j * (int64_t)k + lane] = x;

@@ -1,4 +1,6 @@
 // ops_irls.hip -- NB-IRLS half-update, NB size update and NB loss (device-level C ABI, include/rcppml_gpu.h layer 2)
+#include <type_traits>
+#include <cstring>
 #include "common.hip.h"
 #include "kernels_irls.hip.h"
 
@@ -11,6 +13,18 @@ static void irls_impl(rcppml_hip_ctx* c, const int* cp, const int* ri, const T* 
     if (ncols <= 0) return;
     if (k < 1 || k > 64) throw std::runtime_error("solve_irls_nb: k must be in [1,64]");
     const int64_t nblk = (ncols + 3) / 4;
+    if constexpr (std::is_same<T, float>::value) {
+        // fp32, k <= 32: weighted Gram on the matrix cores (RCPPML_GPU_IRLS_VARIANT=valu keeps the register form)
+        static int use_mfma = -1;
+        if (use_mfma < 0) { const char* e = getenv("RCPPML_GPU_IRLS_VARIANT"); use_mfma = (e && !strcmp(e, "valu")) ? 0 : 1; }
+        if (use_mfma && k <= 32 && k % 4 == 0 && reinterpret_cast<uintptr_t>(F) % 16 == 0) {
+            const size_t smem = (size_t)4 * (32 * 36 + 2 * 32 + 32) * sizeof(float);
+            hipLaunchKernelGGL(irls_nb_mfma32_kernel, dim3((unsigned)nblk), dim3(256), smem, c->stream, cp, ri, vals, ncols, F,
+                               Gbase, X, k, l1, l2, nonneg, cd_maxit, irls_max_iter, irls_tol, theta_row, theta_col);
+            HIPCHK(hipGetLastError());
+            return;
+        }
+    }
     if (k <= 32) {      // 32-wide instantiation: half the rank-1 work per nonzero, 16 KB of LDS per block (8 waves per SIMD)
         const size_t smem = (size_t)4 * 32 * 32 * sizeof(T);
         hipLaunchKernelGGL((irls_nb_solve_kernel<T, 32>), dim3((unsigned)nblk), dim3(256), smem, c->stream, cp, ri, vals, ncols,
