@@ -295,11 +295,27 @@ __global__ __launch_bounds__(256) void nb_size_rows_kernel(
     if (i >= m) return;
     const bool fok = lane < k;
     const T wd = fok ? W_T[i * (int64_t)k + lane] * d[lane] : T(0);     // apply_scaling(W_Td, d)
+    // one lane per nonzero: the row of H is gathered with 16-byte loads and dotted in-lane against Wd_i (LDS broadcast)
+    __shared__ T wds[4][64];
+    wds[wave][lane] = wd;
+    __builtin_amdgcn_wave_barrier();
+    constexpr int VEC = 16 / sizeof(T);
+    typedef typename VecT<T, VEC>::type V;
+    const bool vec_ok = (k % VEC == 0) && (reinterpret_cast<uintptr_t>(H) % 16 == 0);
     double s_mu2 = 0.0, s_res2 = 0.0;
-    for (int t = tp[i]; t < tp[i + 1]; ++t) {
+    for (int t = tp[i] + lane; t < tp[i + 1]; t += 64) {
         const int col = ti[t];
-        const T hv = fok ? H[(int64_t)col * k + lane] : T(0);
-        const T dot = wave_sum(wd * hv);
+        const T* hr = H + (int64_t)col * k;
+        T dot = T(0);
+        if (vec_ok) {
+            for (int c = 0; c < k; c += VEC) {
+                const V v = *reinterpret_cast<const V*>(hr + c);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) dot = tfma(wds[wave][c + e], v[e], dot);
+            }
+        } else {
+            for (int c = 0; c < k; ++c) dot = tfma(wds[wave][c], hr[c], dot);
+        }
         const double y = static_cast<double>(tx[t]);
         double mu = static_cast<double>(dot);
         mu = mu > 1e-10 ? mu : 1e-10;
@@ -307,6 +323,8 @@ __global__ __launch_bounds__(256) void nb_size_rows_kernel(
         s_mu2 += mu * mu;
         s_res2 += resid * resid;
     }
+    s_mu2 = wave_sum(s_mu2);
+    s_res2 = wave_sum(s_res2);
     const T tm = wave_sum(fok ? wd * h_rs[lane] : T(0));
     const double total_mu = static_cast<double>(tm);
     // total_mu_sq = sum_ab Wd_a G_H(a,b) Wd_b  (fp64 accumulation as the reference)
@@ -331,6 +349,56 @@ __global__ __launch_bounds__(256) void nb_size_rows_kernel(
 }
 
 // NB negative log-likelihood over the NONZEROS of A (explicit_loss.hpp:53-77), per-row theta, fp64 partials.
+// One wavefront per column, ONE LANE PER NONZERO: each lane gathers its row of W_T with 16-byte loads, forms the
+// prediction as k in-lane fmas against the column of H (broadcast from LDS) and evaluates the two lgamma / two log terms
+// of its own nonzero -- 64 likelihood terms per wave instruction stream instead of one.
+template <class T>
+__global__ __launch_bounds__(256) void nb_loss_lane_kernel(
+    const int* __restrict__ colptr, const int* __restrict__ rowidx, const T* __restrict__ vals, int64_t ncols,
+    const T* __restrict__ W_T, const T* __restrict__ d, const T* __restrict__ H, const T* __restrict__ theta_row, int k,
+    int vec_ok, double* __restrict__ partial) {
+    constexpr int VEC = 16 / sizeof(T);
+    typedef typename VecT<T, VEC>::type V;
+    __shared__ double sh[4];
+    __shared__ T hs[4][64];
+    __shared__ T dsh[64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t j = (int64_t)blockIdx.x * 4 + wave;
+    if (threadIdx.x < 64) dsh[threadIdx.x] = threadIdx.x < k ? d[threadIdx.x] : T(0);
+    hs[wave][lane] = (j < ncols && lane < k) ? H[j * (int64_t)k + lane] : T(0);
+    __syncthreads();
+    double acc = 0.0;
+    if (j < ncols) {
+        const int as = colptr[j], ae = colptr[j + 1];
+        for (int t = as + lane; t < ae; t += 64) {
+            const int row = rowidx[t];
+            const T* wr = W_T + (int64_t)row * k;
+            T pred = T(0);
+            if (vec_ok) {
+                for (int c = 0; c < k; c += VEC) {
+                    const V v = *reinterpret_cast<const V*>(wr + c);
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) pred = tfma(v[e] * dsh[c + e], hs[wave][c + e], pred);
+                }
+            } else {
+                for (int c = 0; c < k; ++c) pred = tfma(wr[c] * dsh[c], hs[wave][c], pred);
+            }
+            const double y = static_cast<double>(vals[t]);
+            double mu = static_cast<double>(pred);
+            mu = mu > 1e-10 ? mu : 1e-10;
+            double r = static_cast<double>(theta_row ? theta_row[row] : T(0));
+            r = r > 1e-10 ? r : 1e-10;
+            const double nll = -lgamma(y + r) + lgamma(r) - r * log(r / (r + mu)) - y * log(mu / (r + mu));
+            acc += static_cast<double>(static_cast<T>(nll));      // the reference casts each term to Scalar
+        }
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) sh[wave] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+// Wave-per-nonzero form (any k <= 64 layout; kept for reference and as the fallback).
 template <class T>
 __global__ __launch_bounds__(256) void nb_loss_kernel(
     const int* __restrict__ colptr, const int* __restrict__ rowidx, const T* __restrict__ vals, int64_t ncols,

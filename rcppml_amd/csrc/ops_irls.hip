@@ -96,8 +96,10 @@ static void nb_loss_impl(rcppml_hip_ctx* c, const int* cp, const int* ri, const 
                          const T* d, const T* H, const T* theta_row, int k, double* out) {
     const int64_t nblk = ncols > 0 ? (ncols + 3) / 4 : 1;
     double* partial = static_cast<double*>(c->scratch(WS_RED2, (size_t)nblk * sizeof(double)));
-    hipLaunchKernelGGL(nb_loss_kernel<T>, dim3((unsigned)nblk), dim3(256), 0, c->stream, cp, ri, vals, ncols, W_T, d, H,
-                       theta_row, k, partial);
+    constexpr int VEC = 16 / (int)sizeof(T);
+    const int vec_ok = (k % VEC == 0 && reinterpret_cast<uintptr_t>(W_T) % 16 == 0) ? 1 : 0;
+    hipLaunchKernelGGL(nb_loss_lane_kernel<T>, dim3((unsigned)nblk), dim3(256), 0, c->stream, cp, ri, vals, ncols, W_T, d, H,
+                       theta_row, k, vec_ok, partial);
     HIPCHK(hipGetLastError());
     hipLaunchKernelGGL(sum_partials, dim3(1), dim3(256), 0, c->stream, partial, (int)nblk, out);
     HIPCHK(hipGetLastError());

@@ -38,3 +38,8 @@ timeit("irls_H", lambda: ops.ctx.solve_irls_nb(ops.dt, Ad["p"], Ad["i"], Ad["x"]
 G_w = ops.gram(H, 1e-15, 0.0)
 timeit("irls_W", lambda: ops.ctx.solve_irls_nb(ops.dt, Atd["p"], Atd["i"], Atd["x"], m, H, G_w, W, k, 0.0, 0.0, 1, 100, 5, 1e-4,
                                                None, theta_row))
+d = torch.ones((k,), dtype=W.dtype, device="cuda")
+nb_size = torch.full((m,), 10.0, dtype=W.dtype, device="cuda")
+timeit("nb_size", lambda: ops.ctx.nb_size_update(ops.dt, Atd["p"], Atd["i"], Atd["x"], m, W, d, H, n, k, 0.01, 1e6, nb_size))
+out = torch.zeros((1,), dtype=torch.float64, device="cuda")
+timeit("nb_loss", lambda: ops.ctx.nb_loss(ops.dt, Ad["p"], Ad["i"], Ad["x"], n, W, d, H, theta_row, k, out))
