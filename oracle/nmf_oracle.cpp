@@ -459,6 +459,12 @@ DEFINE_PRIMS(f32, float)
 DEFINE_PRIMS(f64, double)
 
 
+// per-element NB pieces (pinned against the reference's math/loss.hpp in tests/test_oracle_ref.py)
+ORACLE_API double oracle_irls_weight_nb_f64(double p, double r) { return irls_weight_nb<double>(p, r); }
+ORACLE_API float oracle_irls_weight_nb_f32(float p, float r) { return irls_weight_nb<float>(p, r); }
+ORACLE_API double oracle_loss_nb_f64(double y, double p, double r) { return loss_contribution_nb<double>(y, p, r); }
+ORACLE_API float oracle_loss_nb_f32(float y, float p, float r) { return loss_contribution_nb<float>(y, p, r); }
+
 // NB-IRLS primitives exposed for kernel-level parity tests
 #define DEFINE_NB(SUF, S)                                                                                    \
     ORACLE_API void oracle_irls_nb_##SUF(int rows, int cols, const int* p, const int* i, const S* x, const S* F, \

@@ -6,7 +6,11 @@
 // this directory, and only as the checker / the timed CPU baseline.  The product
 // path (rcppml_amd/, RcppML_gpu.so) never links, imports or calls it.
 //
-// PARITY STATUS: "parity unpinned" for everything except the known answers the
+// PARITY STATUS: pinned bit-for-bit to the reference itself for SplitMix64 / factor
+// initialisation (rng/rng.hpp) and the NB IRLS weight / NB NLL (math/loss.hpp), whose
+// headers are self-contained and are compiled from /root/reference into oracle/_ref
+// (make ref; tests/test_oracle_ref.py, tests/golden/ref_vectors.npz).
+// "parity unpinned" for everything else except the known answers the
 // reference's own tests hold (tests/cpp/test_nnls.cpp:65-84 2x2 NNLS,
 // tests/cpp/test_rng.cpp:36-39 seed-0 remap, tests/cpp/test_nmf.cpp:14-27
 // reconstruct()==6, tests/cpp/test_gram.cpp:52-66 gram == H*H^T) and the

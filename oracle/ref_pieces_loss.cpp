@@ -1,0 +1,23 @@
+// oracle/ref_pieces_loss.cpp -- TEST INFRASTRUCTURE.  C-ABI harness around the REFERENCE'S OWN per-element loss header
+// (/root/reference/inst/include/FactorNet/math/loss.hpp + core/constants.hpp: plain C++, no Eigen), compiled from where
+// it lies.  Output: oracle/_ref/libref_loss.so.  Pins the oracle's NB IRLS weight and NB negative log-likelihood
+//  against the reference itself.
+#include <FactorNet/math/loss.hpp>
+
+extern "C" {
+__attribute__((visibility("default"))) double ref_irls_weight_nb_f64(double predicted, double nb_size) {
+    return FactorNet::irls_weight_nb<double>(predicted, nb_size);
+}
+__attribute__((visibility("default"))) float ref_irls_weight_nb_f32(float predicted, float nb_size) {
+    return FactorNet::irls_weight_nb<float>(predicted, nb_size);
+}
+__attribute__((visibility("default"))) double ref_loss_nb_f64(double observed, double predicted, double nb_size) {
+    return FactorNet::loss_contribution_nb<double>(observed, predicted, nb_size);
+}
+__attribute__((visibility("default"))) float ref_loss_nb_f32(float observed, float predicted, float nb_size) {
+    return FactorNet::loss_contribution_nb<float>(observed, predicted, nb_size);
+}
+__attribute__((visibility("default"))) double ref_loss_mse_f64(double observed, double predicted) {
+    return FactorNet::loss_contribution_mse<double>(observed, predicted);
+}
+}

@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""tests/golden/make_ref_vectors.py -- golden vectors produced BY THE REFERENCE ITSELF.
+
+Runs the two self-contained reference headers (rng/rng.hpp, math/loss.hpp) through oracle/_ref/libref_rng.so and
+libref_loss.so (built by `make -C oracle ref` from /root/reference, sources never copied) and stores inputs + outputs
+in tests/golden/ref_vectors.npz, so that the parity of the restatement can be checked where the reference tree does not
+exist (the GPU box).  Data only: seeds, shapes, argument grids and the reference's numeric outputs."""
+import ctypes as C
+import os
+import numpy as np
+
+here = os.path.dirname(os.path.abspath(__file__))
+root = os.path.dirname(os.path.dirname(here))
+rng = C.CDLL(os.path.join(root, "oracle", "_ref", "libref_rng.so"))
+loss = C.CDLL(os.path.join(root, "oracle", "_ref", "libref_loss.so"))
+rng.ref_next.restype = C.c_uint64
+rng.ref_hash.restype = C.c_uint64
+for f, t in ((loss.ref_irls_weight_nb_f64, C.c_double), (loss.ref_loss_nb_f64, C.c_double),
+             (loss.ref_irls_weight_nb_f32, C.c_float), (loss.ref_loss_nb_f32, C.c_float)):
+    f.restype = t
+
+out = {}
+seeds = np.array([0, 1, 42, 123, 12345, 2**32 + 7, 2**63 + 5], dtype=np.uint64)
+out["seeds"] = seeds
+k, m, n = 7, 13, 11
+out["init_shape"] = np.array([k, m, n])
+for name, dt, fn in (("f64", np.float64, rng.ref_init_factors_f64), ("f32", np.float32, rng.ref_init_factors_f32)):
+    Ws, Hs = [], []
+    for s in seeds:
+        W = np.zeros((m, k), dt)
+        H = np.zeros((n, k), dt)
+        fn(C.c_uint64(int(s)), k, m, n, W.ctypes.data_as(C.c_void_p), H.ctypes.data_as(C.c_void_p))
+        Ws.append(W)
+        Hs.append(H)
+    out["init_W_" + name] = np.stack(Ws)
+    out["init_H_" + name] = np.stack(Hs)
+# raw 64-bit stream
+nxt = []
+for s in seeds:
+    st = C.c_uint64(12345 if int(s) == 0 else int(s))
+    nxt.append([rng.ref_next(C.byref(st)) for _ in range(8)])
+out["next8"] = np.array(nxt, dtype=np.uint64)
+# CV hash / holdout
+ii, jj = np.meshgrid(np.array([0, 1, 2, 17, 999, 65535, 2**31 - 1], dtype=np.uint32),
+                     np.array([0, 1, 5, 100, 12345, 2**31 - 1], dtype=np.uint32), indexing="ij")
+out["hash_i"], out["hash_j"] = ii.ravel(), jj.ravel()
+for s in (42, 7):
+    out["hash_seed%d" % s] = np.array([rng.ref_hash(C.c_uint64(s), C.c_uint32(int(a)), C.c_uint32(int(b)))
+                                       for a, b in zip(ii.ravel(), jj.ravel())], dtype=np.uint64)
+    out["holdout_seed%d_inv10" % s] = np.array([rng.ref_is_holdout(C.c_uint64(s), C.c_uint32(int(a)), C.c_uint32(int(b)), C.c_uint64(10))
+                                                 for a, b in zip(ii.ravel(), jj.ravel())], dtype=np.int32)
+# NB weight and NLL grids
+pred = np.array([0.0, 1e-20, 1e-12, 1e-6, 0.01, 0.5, 1.0, 3.7, 25.0, 1e3, 1e6])
+size = np.array([0.0, 1e-12, 0.01, 0.5, 1.0, 5.0, 10.0, 1e3, 1e6])
+obs = np.array([0.0, 1.0, 2.0, 7.0, 50.0, 1000.0])
+P, R = np.meshgrid(pred, size, indexing="ij")
+out["nb_pred"], out["nb_size"] = P.ravel(), R.ravel()
+out["nb_weight_f64"] = np.array([loss.ref_irls_weight_nb_f64(C.c_double(a), C.c_double(b)) for a, b in zip(P.ravel(), R.ravel())])
+out["nb_weight_f32"] = np.array([loss.ref_irls_weight_nb_f32(C.c_float(a), C.c_float(b)) for a, b in zip(P.ravel(), R.ravel())], dtype=np.float32)
+Y, P3, R3 = np.meshgrid(obs, pred, size, indexing="ij")
+out["nll_obs"], out["nll_pred"], out["nll_size"] = Y.ravel(), P3.ravel(), R3.ravel()
+out["nll_f64"] = np.array([loss.ref_loss_nb_f64(C.c_double(y), C.c_double(a), C.c_double(b)) for y, a, b in zip(Y.ravel(), P3.ravel(), R3.ravel())])
+out["nll_f32"] = np.array([loss.ref_loss_nb_f32(C.c_float(y), C.c_float(a), C.c_float(b)) for y, a, b in zip(Y.ravel(), P3.ravel(), R3.ravel())], dtype=np.float32)
+np.savez_compressed(os.path.join(here, "ref_vectors.npz"), **out)
+print("wrote ref_vectors.npz:", {k2: v.shape for k2, v in out.items()})
