@@ -7,6 +7,8 @@ relative; fp32 the same effects at fp32 epsilon -> <= 5e-5 relative.  CD results
 the same number of sweeps with the same early-exit rule, so they inherit those bounds times a small
 amplification; integer outputs (none here) would be exact.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -269,3 +271,50 @@ def test_loss_mse_terms(env, dtype):
     assert abs(o[1] - cross_ref) / abs(cross_ref) < tol
     assert abs(o[2] - recon_ref) / abs(recon_ref) < tol
     assert abs(o[0] - (tr_ref - 2 * cross_ref + recon_ref)) / abs(tr_ref) < tol
+
+
+def test_ctx_stats_counts_column_sweeps(env):
+    """rcppml_hip_ctx_stats: the CD kernels count the sweeps they run (what cd_nnls_col_fixed returns, summed over
+    columns); must agree with the per-column sweeps_out array for both AUTO kernels (MFMA fp32, lane-group fp64)."""
+    torch, _abi, ctx = env
+    k, n = 24, 300
+    for dtype in (np.float32, np.float64):
+        G, B, _ = _cd_problem(k, n, dtype, 3)
+        dX = torch.zeros((n, k), dtype=_tt(torch, dtype), device="cuda")
+        sw = torch.zeros((n,), dtype=torch.int32, device="cuda")
+        ctx.stats(reset=True)
+        ctx.solve_cd(_dt(_abi, dtype), _dev(torch, G), _dev(torch, B), dX, k, n, zero_init=1, maxit=100, tol=1e-8,
+                     sweeps_out=sw)
+        st = ctx.stats()
+        assert st["cd_columns"] == n
+        assert st["cd_column_sweeps"] == int(sw.sum().item()) and st["cd_column_sweeps"] >= n
+
+
+def test_rhs_staged_equals_group_kernel():
+    """The staged-index SpMM kernel keeps rhs_kernel's lane-group mapping and summation order: bitwise equal results.
+    (The launcher reads RCPPML_GPU_RHS_VARIANT once per process, hence two subprocesses.)"""
+    import hashlib, subprocess, sys
+    code = r'''
+import hashlib, numpy as np, torch
+from rcppml_amd import _abi
+from tests.util import random_csc
+ctx = _abi.Context(0)
+h = hashlib.sha256()
+for dtype, dt in ((np.float32, _abi.F32), (np.float64, _abi.F64)):
+    for k in (32, 64, 128):
+        A = random_csc(500, 300, 0.05, seed=k)
+        F = np.random.default_rng(k).uniform(size=(500, k)).astype(dtype)
+        dB = torch.zeros((300, k), dtype=torch.float32 if dtype == np.float32 else torch.float64, device="cuda")
+        ctx.rhs(dt, torch.from_numpy(A.p.astype(np.int32)).cuda(), torch.from_numpy(A.i.astype(np.int32)).cuda(),
+                torch.from_numpy(A.x.astype(dtype)).cuda(), 300, torch.from_numpy(F).cuda(), k, dB)
+        h.update(dB.cpu().numpy().tobytes())
+print("DIGEST", h.hexdigest())
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    digests = []
+    for variant in ("stage", "group"):
+        env2 = dict(os.environ, RCPPML_GPU_RHS_VARIANT=variant, PYTHONPATH=root)
+        out = subprocess.run([sys.executable, "-c", code], env=env2, cwd=root, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        digests.append([l for l in out.stdout.splitlines() if l.startswith("DIGEST")][0])
+    assert digests[0] == digests[1]
