@@ -1,0 +1,228 @@
+// ============================================================================
+// kernels_cd_mfma64.hip.h -- coordinate-descent NNLS with the rank-1 residual updates on the MATRIX cores, fp64.
+//
+// Reference routine: primitives/cpu/nnls_batch.hpp:70-132 (cd_nnls_col_fixed), prologue fused_nnls.hpp:116-123.
+//
+// Same idea as kernels_cd_mfma.hip.h with v_mfma_f64_16x16x4_f64: 16 columns per wavefront, the KP x 16 residual block
+// lives in KP/16 accumulator tiles (C/D map: col = lane&15, row = (lane>>4) + 4v), and FOUR consecutive coordinates fill
+// the four K-slots of one instruction per tile.  The map needs no row permutation here: coordinates 16t+4v+g
+// (g = lane>>4 = 0..3) sit in accumulator element v of tile t, one per 16-lane row group, and the B operand
+// B[kk = lane>>4][col] is exactly "step of coordinate 4q+kk for this lane's column".  A quad is solved in four phases:
+// every lane evaluates the reference's scalar step on its own residual, the step of group p is broadcast to the other
+// groups (v_permlane16_swap / v_permlane32_swap, no LDS) and applied as the lazy Gauss-Seidel correction
+// b_g -= G(c_g, c_p) a_p with a per-lane coefficient that is ZERO for groups g <= p -- so groups that are already done
+// re-evaluate their step on unchanged inputs and the last evaluation leaves {a_0|a_1|a_2|a_3} = the MFMA B operand in
+// place.  G enters lane-distributed (one conflict-free ds_read_b64 per tile and quad, quad-major LDS layout).
+// Arithmetic: the fma chain per accumulator element is the reference's, in the reference's order; the step uses
+// b * (1/G_cc) (one rounding more than b / G_cc) and the tolerance term a Newton-refined v_rcp_f64.
+// ============================================================================
+#pragma once
+#include "kernels.hip.h"
+
+namespace rk {
+
+// Gq[((q*NT + t) << 6) + lane] = -G(16t + (lane&15), 4q + (lane>>4)), q = quad of coordinates, NT = KP/16.
+// tab[c] (c = 4q + g) = { 1/G(c,c) (0 if G(c,c) <= 0),  g > 0 ? G(c, 4q) : 0,  g > 1 ? G(c, 4q+1) : 0,  g > 2 ? G(c, 4q+2) : 0 }.
+static __global__ void cd_mfma64_prep_kernel(const double* __restrict__ Gp, const double* __restrict__ invd, int KP,
+                                             double* __restrict__ Gq, double4* __restrict__ tab) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= KP * KP) return;
+    const int i = e / KP, r = e % KP;
+    const int NT = KP >> 4;
+    const int q = i >> 2, kk = i & 3, t = r >> 4, rl = r & 15;
+    Gq[((q * NT + t) << 6) + (kk << 4) + rl] = -Gp[i * KP + r];
+    if (r == 0) {
+        const int c = i, g = c & 3, qb = c & ~3;
+        double4 v;
+        v.x = invd[c];
+        v.y = g > 0 ? Gp[(qb + 0) * KP + c] : 0.0;
+        v.z = g > 1 ? Gp[(qb + 1) * KP + c] : 0.0;
+        v.w = g > 2 ? Gp[(qb + 2) * KP + c] : 0.0;
+        tab[c] = v;
+    }
+}
+
+// Row-group broadcasts.  v_permlane16_swap_b32 vdst, src: vdst rows 1,3 <-> src rows 0,2 (16-lane rows);
+// v_permlane32_swap_b32 vdst, src: vdst rows 2,3 <-> src rows 0,1; with vdst == src the exchange is in place
+// (probed on gfx950: tools/probe/permlane_probe.hip).  Only the groups BEHIND row P need the value; the others may
+// receive anything finite (their coefficient is zero).
+template <int P> __device__ __forceinline__ unsigned bcast_row32(unsigned a) {
+    if constexpr (P == 2) {                 // row 3 <- row 2
+        unsigned x = a;
+        asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %0" : "+v"(x));
+        return x;
+    } else {
+        unsigned t = a, u = a;
+        asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(t), "+v"(u));   // t = [r0 r0 r2 r2], u = [r1 r1 r3 r3]
+        if constexpr (P == 0) {             // rows 1,2,3 <- row 0
+            unsigned v = t;
+            asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(t), "+v"(v));   // t = [r0 r0 r0 r0]
+            return t;
+        } else {                            // rows 2,3 <- row 1
+            asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %0" : "+v"(u));            // u = [r3 r3 r1 r1]
+            return u;
+        }
+    }
+}
+template <int P> __device__ __forceinline__ double bcast_row(double a) {
+    const unsigned long long u = __double_as_longlong(a);
+    const unsigned lo = bcast_row32<P>((unsigned)u), hi = bcast_row32<P>((unsigned)(u >> 32));
+    return __longlong_as_double(((unsigned long long)hi << 32) | lo);
+}
+
+struct CdStepOut64 { double a, nx; };
+
+template <bool SIMPLE>
+__device__ __forceinline__ CdStepOut64 cd_step64(double b, double xo, double ginv, bool active, double l1_cd, double l2_cd,
+                                                 double lo, double hi) {
+    CdStepOut64 o;
+    if constexpr (SIMPLE) {
+        // `active` and `if (g_diag <= 0) continue;` arrive folded into ginv (= 0): diff = 0, nv = xo >= 0, a = 0, nx = xo
+        const double diff = b * ginv;
+        const double nv = xo + diff;
+        const bool neg = nv < 0.0;
+        o.nx = neg ? 0.0 : nv;
+        o.a = neg ? -xo : diff;
+    } else {
+        double diff = b * ginv;
+        diff -= l1_cd;
+        diff = __builtin_fma(l2_cd, xo, diff);
+        const double nv = xo + diff;
+        const bool neg = nv < lo, up = nv > hi;
+        double nx = neg ? lo : (up ? hi : nv);
+        double a = neg ? lo - xo : (up ? hi - xo : diff);
+        const bool on = active && (ginv > 0.0);
+        o.a = on ? a : 0.0;
+        o.nx = on ? nx : xo;
+    }
+    return o;
+}
+
+template <int NT, bool SIMPLE>   // KP = 16*NT rows (k <= KP), 16 columns per wave, 4 waves per block share G
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NT <= 2 ? 4 : 2, 8)))
+void cd_mfma64_kernel(const double* __restrict__ Gq, const double4* __restrict__ tab, const double* __restrict__ B,
+                      double* __restrict__ X, int k, int64_t ncols, double l1_pre, int warm, int zero_init, double l1_cd,
+                      double l2_cd, int nonneg, int maxit, double tol, double ub_cd, double ub_post,
+                      int* __restrict__ sweeps, const int* __restrict__ order, unsigned long long* __restrict__ stats) {
+    constexpr int KP = 16 * NT;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    double* Gs = reinterpret_cast<double*>(smem_raw);               // KP*KP, quad-major (see cd_mfma64_prep_kernel)
+    double4* tab_s = reinterpret_cast<double4*>(Gs + KP * KP);     // KP x {1/G_cc, 3 in-quad couplings}
+    for (int e = threadIdx.x; e < KP * KP; e += blockDim.x) Gs[e] = Gq[e];
+    for (int e = threadIdx.x; e < KP; e += blockDim.x) tab_s[e] = tab[e];
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int g = lane >> 4, cl = lane & 15;
+    const int64_t base = ((int64_t)blockIdx.x * (blockDim.x >> 6) + wave) * 16;
+    if (base >= ncols) return;
+    const int64_t slot = base + cl;
+    const bool inb = slot < ncols;
+    const int64_t j = (inb && order) ? order[slot] : slot;
+    f64x4 acc[NT];
+    double xr[NT][4];
+    {
+        const double* bj = B + j * (int64_t)k;
+        const double* xj = X + j * (int64_t)k;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int row = 16 * t + 4 * v + g;
+                const bool ok = inb && row < k;
+                double bv = ok ? bj[row] : 0.0;
+                if (ok && l1_pre != 0.0) bv -= l1_pre;
+                acc[t][v] = bv;
+                xr[t][v] = (ok && !zero_init) ? xj[row] : 0.0;
+            }
+    }
+    if (warm) {   // B -= G X (fused_nnls.hpp:121-123): the same MFMA stream with x in place of the steps
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int q = 4 * t + v;
+#pragma unroll
+                for (int t2 = 0; t2 < NT; ++t2) {
+                    const double av = Gs[((q * NT + t2) << 6) + lane];
+                    acc[t2] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, xr[t][v], acc[t2], 0, 0, 0);
+                }
+            }
+    }
+    const double lo = nonneg ? 0.0 : -INFINITY;
+    const double hi = ub_cd > 0.0 ? ub_cd : INFINITY;
+    const bool check = tol > 0.0;
+    const double inv_k = 1.0 / static_cast<double>(k);
+    bool active = inb;
+    int nsweep = 0;
+    // operands of the first quad; every quad then requests the NEXT quad's operands before it starts computing
+    double4 tb_c = tab_s[g];
+    double av_c[NT];
+#pragma unroll
+    for (int t2 = 0; t2 < NT; ++t2) av_c[t2] = Gs[(t2 << 6) + lane];
+    for (int it = 0; it < maxit; ++it) {
+        if (!__any(active)) break;
+        double tsum = 0.0;
+        nsweep += active ? 1 : 0;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                constexpr int NQ = KP / 4;
+                const int qn = (4 * t + v + 1) % NQ;
+                const int tn = (v == 3 ? t + 1 : t) % NT;          // row tile of the next quad
+                const double4 tb_n = tab_s[4 * qn + g];
+                double av_n[NT];
+#pragma unroll
+                for (int t2 = 0; t2 < NT; ++t2) av_n[t2] = Gs[((qn * NT + t2) << 6) + lane];
+                const double b0 = acc[t][v];
+                const double xo = xr[t][v];
+                const double ginv = SIMPLE ? (active ? tb_c.x : 0.0) : tb_c.x;
+                // phase p: group p's step is final; the groups behind it take the lazy correction, the others keep b
+                const CdStepOut64 s0 = cd_step64<SIMPLE>(b0, xo, ginv, active, l1_cd, l2_cd, lo, hi);
+                const double b1 = __builtin_fma(-tb_c.y, bcast_row<0>(s0.a), b0);
+                const CdStepOut64 s1 = cd_step64<SIMPLE>(b1, xo, ginv, active, l1_cd, l2_cd, lo, hi);
+                const double b2 = __builtin_fma(-tb_c.z, bcast_row<1>(s1.a), b1);
+                const CdStepOut64 s2 = cd_step64<SIMPLE>(b2, xo, ginv, active, l1_cd, l2_cd, lo, hi);
+                const double b3 = __builtin_fma(-tb_c.w, bcast_row<2>(s2.a), b2);
+                const CdStepOut64 s3 = cd_step64<SIMPLE>(b3, xo, ginv, active, l1_cd, l2_cd, lo, hi);
+                xr[t][v] = s3.nx;
+                // |a| / (|x_new| + 1e-15)  (nnls_batch.hpp:117-120): v_rcp_f64 + one Newton step
+                const double den = tabs(s3.nx) + 1e-15;
+                double rc = __builtin_amdgcn_rcp(den);
+                rc = __builtin_fma(__builtin_fma(-den, rc, 1.0), rc, rc);
+                tsum = __builtin_fma(tabs(s3.a), rc, tsum);
+                // the row tile that holds the NEXT quad's residuals goes first
+#pragma unroll
+                for (int s = 0; s < NT; ++s) {
+                    const int t2 = (tn + s) % NT;
+                    acc[t2] = __builtin_amdgcn_mfma_f64_16x16x4f64(av_c[t2], s3.a, acc[t2], 0, 0, 0);
+                }
+                tb_c = tb_n;
+#pragma unroll
+                for (int t2 = 0; t2 < NT; ++t2) av_c[t2] = av_n[t2];
+                __builtin_amdgcn_sched_barrier(0);      // one scheduling region per quad (see kernels_cd_mfma.hip.h)
+            }
+        // branch-free activity update (see kernels_cd_mfma.hip.h); the four row groups hold the four coordinate classes
+        double tot = tsum + __shfl_xor(tsum, 16, 64);
+        tot += __shfl_xor(tot, 32, 64);
+        active = active && !(check && tot * inv_k < tol);
+    }
+    if (inb) {
+        double* xj = X + j * (int64_t)k;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int row = 16 * t + 4 * v + g;
+                if (row < k) {
+                    double val = xr[t][v];
+                    if (ub_post > 0.0) val = val < ub_post ? val : ub_post;
+                    xj[row] = val;
+                }
+            }
+        if (sweeps && g == 0) sweeps[j] = nsweep;
+    }
+    cd_stats_add(stats, (inb && g == 0) ? nsweep : 0, (inb && g == 0) ? 1 : 0);
+}
+
+}  // namespace rk

@@ -3,6 +3,7 @@
 #include <cmath>
 #include "solve_common.hip.h"
 #include "kernels_cd_mfma.hip.h"
+#include "kernels_cd_mfma64.hip.h"
 // ----------------------------------------------------------------------------
 // CD solve
 // ----------------------------------------------------------------------------
@@ -111,6 +112,28 @@ static void cd_mfma_launch(rcppml_hip_ctx* c, const float* Gp, const float* invd
     HIPCHK(hipGetLastError());
 }
 
+// fp64 MFMA variant (k <= 64): v_mfma_f64_16x16x4_f64, 16 columns per wave, four coordinates per instruction.
+template <int NT>
+static void cd_mfma64_launch(rcppml_hip_ctx* c, const double* Gp, const double* invd, const double* B, double* X, int k,
+                             int64_t ncols, double l1_pre, int warm, int zero_init, double l1_cd, double l2_cd, int nonneg,
+                             int maxit, double tol, double ub_cd, double ub_post, int* sweeps, const int* order) {
+    constexpr int KP = 16 * NT;
+    double* Gq = static_cast<double*>(c->scratch(WS_MFMA, ((size_t)KP * KP + 4 * KP) * sizeof(double)));
+    double4* tab = reinterpret_cast<double4*>(Gq + (size_t)KP * KP);
+    hipLaunchKernelGGL(cd_mfma64_prep_kernel, dim3((KP * KP + 255) / 256), dim3(256), 0, c->stream, Gp, invd, KP, Gq, tab);
+    HIPCHK(hipGetLastError());
+    const size_t smem = ((size_t)KP * KP + 4 * KP) * sizeof(double);
+    const int64_t nblk = (ncols + 63) / 64;          // 4 waves x 16 columns per block
+    const bool simple = nonneg && ub_cd <= 0.0 && l1_cd == 0.0 && l2_cd == 0.0;
+    if (simple)
+        hipLaunchKernelGGL((cd_mfma64_kernel<NT, true>), dim3((unsigned)nblk), dim3(256), smem, c->stream, Gq, tab, B, X, k,
+                           ncols, l1_pre, warm, zero_init, l1_cd, l2_cd, nonneg, maxit, tol, ub_cd, ub_post, sweeps, order, c->stats);
+    else
+        hipLaunchKernelGGL((cd_mfma64_kernel<NT, false>), dim3((unsigned)nblk), dim3(256), smem, c->stream, Gq, tab, B, X, k,
+                           ncols, l1_pre, warm, zero_init, l1_cd, l2_cd, nonneg, maxit, tol, ub_cd, ub_post, sweeps, order, c->stats);
+    HIPCHK(hipGetLastError());
+}
+
 // LPC choice (measured on MI355X, k = 64, 20k..100k columns: 32 fp32 rows per lane beat 16 by 4-15 %, and for
 // fp64 16 rows per lane are as good as 32 at half the registers): fp32 -> KP/32 lanes per column, fp64 -> KP/16,
 // clamped to {1, 2, 4}.  RCPPML_GPU_CD_LPC overrides (experiments).
@@ -139,10 +162,10 @@ static void solve_cd_impl(rcppml_hip_ctx* c, const T* G, const T* B, T* X, int k
         else if (e && !strcmp(e, "wave")) variant = RCPPML_CD_WAVE;
         else if (e && !strcmp(e, "group")) variant = RCPPML_CD_GROUP;
         else if (e && !strcmp(e, "mfma")) variant = RCPPML_CD_MFMA;
-        else variant = std::is_same<T, float>::value ? RCPPML_CD_MFMA : RCPPML_CD_GROUP;
+        else variant = (std::is_same<T, float>::value || k <= 64) ? RCPPML_CD_MFMA : RCPPML_CD_GROUP;
     }
-    if (variant == RCPPML_CD_MFMA && !std::is_same<T, float>::value) variant = RCPPML_CD_GROUP;
-    if (variant == RCPPML_CD_MFMA) KP = 32 * ((k + 31) / 32);
+    if (variant == RCPPML_CD_MFMA && !std::is_same<T, float>::value && k > 64) variant = RCPPML_CD_GROUP;
+    if (variant == RCPPML_CD_MFMA) KP = std::is_same<T, float>::value ? 32 * ((k + 31) / 32) : 16 * ((k + 15) / 16);
     // register-resident lane kernel (SGPR-fed): fp32 up to KP=64, fp64 up to KP=32 without spilling
     const int lane_max = std::is_same<T, float>::value ? 64 : 32;
     if (variant == RCPPML_CD_LANE && KP > lane_max) variant = RCPPML_CD_GROUP;
@@ -166,6 +189,13 @@ static void solve_cd_impl(rcppml_hip_ctx* c, const T* G, const T* B, T* X, int k
                 case 64: cd_mfma_launch<2, 1>(CD_ARGS); break;
                 case 96: cd_mfma_launch<3, 1>(CD_ARGS); break;
                 default: cd_mfma_launch<4, 1>(CD_ARGS); break;
+            }
+        } else {
+            switch (KP) {
+                case 16: cd_mfma64_launch<1>(CD_ARGS); break;
+                case 32: cd_mfma64_launch<2>(CD_ARGS); break;
+                case 48: cd_mfma64_launch<3>(CD_ARGS); break;
+                default: cd_mfma64_launch<4>(CD_ARGS); break;
             }
         }
     } else if (variant == RCPPML_CD_GROUP) {

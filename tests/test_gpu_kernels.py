@@ -186,6 +186,8 @@ def test_cd_lane_equals_wave(env, dtype):
         outs.append(dX.cpu().numpy())
     if dtype == np.float64:
         assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+        # the fp64 MFMA kernel multiplies by 1/G_ii and refines a hardware reciprocal in the tolerance term
+        assert np.abs(outs[0] - outs[3]).max() < 1e-11 * np.abs(outs[0]).max()
     else:  # fp32 variants use rcp for the tolerance term / reassociate it (mfma): same iterates up to the exit sweep
         for o in outs[1:]:
             assert np.abs(outs[0] - o).max() < 1e-5 * np.abs(outs[0]).max()
@@ -196,7 +198,7 @@ def test_cd_known_answer(env):
     torch, _abi, ctx = env
     G = np.array([[2.0, 1.0], [1.0, 2.0]]) + 1e-10 * np.eye(2)
     B = np.array([[3.0, 3.0]])
-    for var in (_abi.CD_LANE, _abi.CD_WAVE, _abi.CD_GROUP):
+    for var in (_abi.CD_LANE, _abi.CD_WAVE, _abi.CD_GROUP, _abi.CD_MFMA):
         dX = torch.zeros((1, 2), dtype=torch.float64, device="cuda")
         ctx.solve_cd(_abi.F64, _dev(torch, G), _dev(torch, B), dX, 2, 1, zero_init=1, maxit=100, tol=1e-8, variant=var)
         assert np.allclose(dX.cpu().numpy(), [[1.0, 1.0]], atol=1e-4)
