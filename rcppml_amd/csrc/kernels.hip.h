@@ -301,6 +301,39 @@ __global__ __launch_bounds__(256) void rhs_kernel(const int* __restrict__ colptr
 }
 
 // ---------------------------------------------------------------------------
+// RHS, general-rank fallback (k > 64 with k not a multiple of the 16-byte vector): one wavefront per column, lane l owns
+// features l, l+64, ... (EPL per lane), nonzeros in order -- the reference's summation order (rhs.hpp:59-63).
+// ---------------------------------------------------------------------------
+template <class T, int EPL>
+__global__ __launch_bounds__(256) void rhs_generic_kernel(const int* __restrict__ colptr, const int* __restrict__ rowidx,
+                                                           const T* __restrict__ vals, int64_t ncols,
+                                                           const T* __restrict__ F, int k, T* __restrict__ B) {
+    const int64_t j = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (j >= ncols) return;
+    const int lane = threadIdx.x & 63;
+    T acc[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) acc[e] = T(0);
+    const int start = colptr[j], end = colptr[j + 1];
+#pragma unroll 4
+    for (int t = start; t < end; ++t) {
+        const int row = rowidx[t];
+        const T v = vals[t];
+        const T* src = F + (int64_t)row * k;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+            const int f = lane + 64 * e;
+            if (f < k) acc[e] = tfma(v, src[f], acc[e]);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+        const int f = lane + 64 * e;
+        if (f < k) B[j * (int64_t)k + f] = acc[e];
+    }
+}
+
+// ---------------------------------------------------------------------------
 // RHS, staged-index variant ("rhs_stage_kernel").  Same lane-group mapping and the same summation order as rhs_kernel
 // (bitwise identical results), but the (row, value) stream of the column is fetched COALESCED -- one vector load per
 // NG*U nonzeros instead of one group-uniform load per nonzero -- and handed to the lane groups through the LDS crossbar

@@ -76,7 +76,14 @@ static void rhs_impl(rcppml_hip_ctx* c, const int* cp, const int* ri, const T* v
         switch (lpn) { RHS_CASE(1) RHS_CASE(2) RHS_CASE(4) RHS_CASE(8) RHS_CASE(16) RHS_CASE(32) RHS_CASE(64) }
 #undef RHS_CASE
     } else {
-        if (k > 64) throw std::runtime_error("rhs: k > 64 requires k % (16/sizeof(T)) == 0");
+        if (k > 64) {      // odd ranks above 64 (or unaligned factors): general one-wave-per-column kernel
+            if (k > 256) throw std::runtime_error("rhs: k > 256 not supported");
+            const int64_t nblk = (ncols + 3) / 4;
+            if (k <= 128) hipLaunchKernelGGL((rhs_generic_kernel<T, 2>), dim3((unsigned)nblk), dim3(256), 0, c->stream, cp, ri, vals, ncols, F, k, B);
+            else hipLaunchKernelGGL((rhs_generic_kernel<T, 4>), dim3((unsigned)nblk), dim3(256), 0, c->stream, cp, ri, vals, ncols, F, k, B);
+            HIPCHK(hipGetLastError());
+            return;
+        }
         const int lpn = next_pow2(k);
 #define RHS_CASE(L) case L: rhs_launch<T, 1, L>(c, cp, ri, vals, ncols, F, k, B); break;
         switch (lpn) { RHS_CASE(1) RHS_CASE(2) RHS_CASE(4) RHS_CASE(8) RHS_CASE(16) RHS_CASE(32) RHS_CASE(64) }
