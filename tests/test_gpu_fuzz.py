@@ -104,3 +104,34 @@ def test_fuzz_irls_nb(env, dtype, tol):
         X = dX.cpu().numpy()
         assert np.all(np.isfinite(X)) and X.min() >= 0
         assert np.abs(X - ref).max() / max(np.abs(ref).max(), 1e-30) < tol, ("irls", k, rows, cols, dens)
+
+
+def test_fuzz_plugin_fits_fp64():
+    """73-pointer entry (fp64) vs the oracle's nmf_fit on random small problems with random options: odd ranks,
+    L1/L2 on either side, upper bounds, L2 normalisation, both solvers, early stopping.  Five iterations: with k above
+    the data's rank, bounds and Cholesky+clip the ALS map is not contractive and rounding differences grow ~30x per
+    iteration (1e-14 after one iteration, 1e-9 after five, 1e-3 after fifteen -- tools/probe/dbg_fuzz.py)."""
+    from rcppml_amd import _abi
+    from tests.util import lowrank_csc
+    rs = np.random.default_rng(31337)
+    for trial in range(10):
+        k = int(rs.choice([2, 3, 7, 9, 16, 17, 33]))
+        m, n = int(rs.integers(k + 5, 120)), int(rs.integers(k + 5, 150))
+        A = lowrank_csc(m, n, max(2, k // 2), float(rs.choice([0.15, 0.5])), seed=trial)
+        W0, H0 = O.init_factors(int(rs.integers(1, 1000)), k, m, n, np.float64)
+        solver = int(rs.integers(0, 2))
+        L1 = (float(rs.choice([0.0, 0.01])), float(rs.choice([0.0, 0.05])))
+        L2 = (float(rs.choice([0.0, 0.1])), float(rs.choice([0.0, 0.01])))
+        ub = (0.0, float(rs.choice([0.0, 0.0, 0.2])))
+        norm_type = int(rs.choice([0, 0, 1]))
+        tol = float(rs.choice([0.0, 1e-4]))
+        ref = O.nmf_fit(A, W0, H0, np.float64, max_iter=5, tol=tol, solver_mode=solver, L1=L1, L2=L2, ub=ub, norm_type=norm_type)
+        W, H = W0.copy(), H0.copy()
+        res = _abi.nmf_unified(A.p, A.i, A.x, m, n, k, W, H, entry="double", max_iter=5, tol=tol, solver_mode=solver,
+                               L1_W=L1[0], L1_H=L1[1], L2_W=L2[0], L2_H=L2[1], ub_W=ub[0], ub_H=ub[1], norm_type=norm_type)
+        cfg = (trial, k, m, n, solver, L1, L2, ub, norm_type, tol)
+        assert res["status"] == 0, cfg
+        assert res["iter"] == ref.iter, cfg
+        assert abs(res["loss"] - ref.loss) <= 1e-6 * abs(ref.loss) + 1e-12, cfg
+        assert np.abs(res["d"] - ref.d).max() <= 1e-6 * np.abs(ref.d).max(), cfg
+        assert np.abs(W - ref.W_T).max() < 1e-6 and np.abs(H - ref.H).max() < 1e-6, cfg
