@@ -132,6 +132,18 @@ RCPPML_GPU_API int rcppml_hip_ctx_sync(rcppml_hip_ctx* ctx);
  * GROUP and MFMA kernels (what RCPPML_CD_AUTO dispatches to). */
 RCPPML_GPU_API int rcppml_hip_ctx_stats(rcppml_hip_ctx* ctx, int reset, unsigned long long* out4);
 
+/* One-time setup of a fit, on the device.
+ * rcppml_hip_transpose_csc: CSC of A^T from the CSC of A (rows x cols; all pointers device memory; t_col_ptr rows+1 ints,
+ *   t_row_idx / t_values nnz entries; values / t_values may be NULL for a pattern-only matrix such as a mask).  Replaces the
+ *   reference's host-side `At = A.transpose()` (nmf/fit_cpu.hpp:251-253): a stable sort by row index, so the column
+ *   indices inside each row of A come out ascending, as Eigen produces them.  Synchronises the stream.
+ * rcppml_hip_cast: elementwise precision cast between device buffers (the plugin boundary hands over doubles,
+ *   gpu/bridge_nmf.hpp:310-342; the fp32 entry computes in fp32). */
+RCPPML_GPU_API int rcppml_hip_transpose_csc(rcppml_hip_ctx* ctx, int dtype, int rows, int cols, const int* col_ptr,
+                                            const int* row_idx, const void* values, int* t_col_ptr, int* t_row_idx,
+                                            void* t_values);
+RCPPML_GPU_API int rcppml_hip_cast(rcppml_hip_ctx* ctx, int dtype_src, const void* src, int dtype_dst, void* dst, int64_t n);
+
 /* G = F F^T (+ eps on the diagonal, then + l2) -- reference primitives/cpu/gram.hpp:37-67 and
  * nmf/fit_cpu.hpp:506,738.  F: k x r.  MFMA kernel (v_mfma_f32_32x32x2_f32 / v_mfma_f64_16x16x4_f64),
  * split over r with a deterministic two-pass reduction. */

@@ -19,7 +19,7 @@ CD_AUTO, CD_LANE, CD_WAVE, CD_GROUP, CD_MFMA = 0, 1, 2, 5, 6
 EXPORTED_SYMBOLS = [
     "rcppml_gpu_detect", "rcppml_gpu_nmf_unified_float", "rcppml_gpu_nmf_unified_double", "rcppml_gpu_nmf_ex",
     "rcppml_gpu_nnls_double", "rcppml_gpu_evaluate_mse_double", "rcppml_gpu_last_error",
-    "rcppml_hip_ctx_create", "rcppml_hip_ctx_destroy", "rcppml_hip_ctx_sync", "rcppml_hip_ctx_stats", "rcppml_hip_gram", "rcppml_hip_rhs",
+    "rcppml_hip_ctx_create", "rcppml_hip_ctx_destroy", "rcppml_hip_ctx_sync", "rcppml_hip_ctx_stats", "rcppml_hip_transpose_csc", "rcppml_hip_cast", "rcppml_hip_gram", "rcppml_hip_rhs",
     "rcppml_hip_solve_cd", "rcppml_hip_order_columns", "rcppml_hip_solve_chol", "rcppml_hip_row_norms", "rcppml_hip_apply_scaling",
     "rcppml_hip_sumsq", "rcppml_hip_loss_mse", "rcppml_hip_solve_masked", "rcppml_hip_loss_nonzeros",
     "rcppml_hip_solve_irls_nb", "rcppml_hip_nb_size_update", "rcppml_hip_nb_loss",
@@ -43,7 +43,7 @@ def lib():
         except OSError as e:  # e.g. libamdhip64 missing
             raise BackendError("cannot load %s: %s" % (LIB_PATH, e))
         _lib.rcppml_gpu_last_error.restype = C.c_char_p
-        for name in ("rcppml_hip_ctx_create", "rcppml_hip_ctx_sync", "rcppml_hip_ctx_stats", "rcppml_hip_gram", "rcppml_hip_rhs",
+        for name in ("rcppml_hip_ctx_create", "rcppml_hip_ctx_sync", "rcppml_hip_ctx_stats", "rcppml_hip_transpose_csc", "rcppml_hip_cast", "rcppml_hip_gram", "rcppml_hip_rhs",
                      "rcppml_hip_solve_cd", "rcppml_hip_order_columns", "rcppml_hip_solve_chol", "rcppml_hip_row_norms",
                      "rcppml_hip_apply_scaling",
                      "rcppml_hip_sumsq", "rcppml_hip_loss_mse", "rcppml_hip_solve_masked", "rcppml_hip_loss_nonzeros",
@@ -217,6 +217,13 @@ class Context:
         out = (C.c_ulonglong * 4)()
         _chk(lib().rcppml_hip_ctx_stats(self._h, C.c_int(1 if reset else 0), out), "ctx_stats")
         return dict(cd_column_sweeps=int(out[0]), cd_columns=int(out[1]))
+
+    def transpose_csc(self, dt, rows, cols, col_ptr, row_idx, values, t_col_ptr, t_row_idx, t_values):
+        _chk(lib().rcppml_hip_transpose_csc(self._h, C.c_int(dt), C.c_int(rows), C.c_int(cols), _dptr(col_ptr), _dptr(row_idx),
+                                            _dptr(values), _dptr(t_col_ptr), _dptr(t_row_idx), _dptr(t_values)), "transpose_csc")
+
+    def cast(self, dt_src, src, dt_dst, dst, n):
+        _chk(lib().rcppml_hip_cast(self._h, C.c_int(dt_src), _dptr(src), C.c_int(dt_dst), _dptr(dst), C.c_int64(n)), "cast")
 
     # ---- ops (dt: F32/F64; tensors are torch CUDA tensors laid out (cols, k) == column-major k x cols)
     def gram(self, dt, F, k, r, eps, l2, G):

@@ -60,26 +60,6 @@ int env_device() {
     return e ? atoi(e) : 0;
 }
 
-// CSC(A^T) on the host: counting sort, rows stay sorted within each column
-// (reference nmf/fit_cpu.hpp:251-253 At = A.transpose()).
-template <class T>
-void transpose_csc_host(int rows, int cols, const int* p, const int* i, const T* x, std::vector<int>& tp,
-                        std::vector<int>& ti, std::vector<T>* tx) {
-    const int64_t nnz = p[cols];
-    tp.assign((size_t)rows + 1, 0);
-    ti.resize((size_t)nnz);
-    if (tx) tx->resize((size_t)nnz);
-    for (int64_t t = 0; t < nnz; ++t) tp[(size_t)i[t] + 1]++;
-    for (int r = 0; r < rows; ++r) tp[r + 1] += tp[r];
-    std::vector<int> cur(tp.begin(), tp.end() - 1);
-    for (int j = 0; j < cols; ++j)
-        for (int t = p[j]; t < p[j + 1]; ++t) {
-            const int dst = cur[i[t]]++;
-            ti[dst] = j;
-            if (tx) (*tx)[dst] = x[t];
-        }
-}
-
 struct FitParams {
     int m, n, k;
     int64_t nnz;
@@ -105,29 +85,31 @@ template <class T> struct DT;
 template <> struct DT<float> { static constexpr int id = RCPPML_F32; };
 template <> struct DT<double> { static constexpr int id = RCPPML_F64; };
 
+// The boundary hands over double buffers (bridge_nmf.hpp:310-342).  They are uploaded as they are and cast on the
+// device (no host-side temporaries, no host loops over nnz).
 template <class T>
-void upload_cast(const double* src, size_t n, DevBuf& dst, hipStream_t s) {
+void upload_cast(rcppml_hip_ctx* c, const double* src, size_t n, DevBuf& dst, hipStream_t s) {
     dst.alloc(n * sizeof(T));
     if constexpr (std::is_same<T, double>::value) {
         HIPCHK(hipMemcpyAsync(dst.p, src, n * sizeof(T), hipMemcpyHostToDevice, s));
         HIPCHK(hipStreamSynchronize(s));
     } else {
-        std::vector<T> tmp(n);
-        for (size_t t = 0; t < n; ++t) tmp[t] = static_cast<T>(src[t]);
-        HIPCHK(hipMemcpyAsync(dst.p, tmp.data(), n * sizeof(T), hipMemcpyHostToDevice, s));
+        DevBuf stage(n * sizeof(double));
+        HIPCHK(hipMemcpyAsync(stage.p, src, n * sizeof(double), hipMemcpyHostToDevice, s));
+        OPCHK(rcppml_hip_cast(c, RCPPML_F64, stage.p, RCPPML_F32, dst.p, (int64_t)n));
         HIPCHK(hipStreamSynchronize(s));
     }
 }
 template <class T>
-void download_cast(const DevBuf& src, size_t n, double* dst, hipStream_t s) {
+void download_cast(rcppml_hip_ctx* c, const DevBuf& src, size_t n, double* dst, hipStream_t s) {
     if constexpr (std::is_same<T, double>::value) {
         HIPCHK(hipMemcpyAsync(dst, src.p, n * sizeof(T), hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
     } else {
-        std::vector<T> tmp(n);
-        HIPCHK(hipMemcpyAsync(tmp.data(), src.p, n * sizeof(T), hipMemcpyDeviceToHost, s));
+        DevBuf stage(n * sizeof(double));
+        OPCHK(rcppml_hip_cast(c, RCPPML_F32, src.p, RCPPML_F64, stage.p, (int64_t)n));
+        HIPCHK(hipMemcpyAsync(dst, stage.p, n * sizeof(double), hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
-        for (size_t t = 0; t < n; ++t) dst[t] = static_cast<double>(tmp[t]);
     }
 }
 void upload_ints(const int* src, size_t n, DevBuf& dst, hipStream_t s) {
@@ -151,32 +133,27 @@ void fit(FitParams& P) {
     DevBuf dAp, dAi, dAx, dTp, dTi, dTx;
     upload_ints(P.col_ptr, (size_t)n + 1, dAp, s);
     upload_ints(P.row_idx, (size_t)P.nnz, dAi, s);
-    upload_cast<T>(P.values, (size_t)P.nnz, dAx, s);
-    {
-        std::vector<int> tp, ti;
-        std::vector<double> tx;
-        transpose_csc_host<double>(m, n, P.col_ptr, P.row_idx, P.values, tp, ti, &tx);
-        upload_ints(tp.data(), tp.size(), dTp, s);
-        upload_ints(ti.data(), ti.size(), dTi, s);
-        upload_cast<T>(tx.data(), tx.size(), dTx, s);
-    }
+    upload_cast<T>(c, P.values, (size_t)P.nnz, dAx, s);
+    // A^T on the device (stable sort by row index): rcppml_hip_transpose_csc
+    dTp.alloc(((size_t)m + 1) * sizeof(int));
+    dTi.alloc((size_t)P.nnz * sizeof(int));
+    dTx.alloc((size_t)P.nnz * sizeof(T));
+    OPCHK(rcppml_hip_transpose_csc(c, dt, m, n, dAp.as<int>(), dAi.as<int>(), dAx.p, dTp.as<int>(), dTi.as<int>(), dTx.p));
     const bool has_mask = P.mask_p != nullptr;
     DevBuf dMp, dMi, dMTp, dMTi;
     if (has_mask) {
         const int mnnz = P.mask_p[n];
         upload_ints(P.mask_p, (size_t)n + 1, dMp, s);
         upload_ints(P.mask_i, (size_t)std::max(mnnz, 1), dMi, s);
-        std::vector<int> tp, ti;
-        transpose_csc_host<double>(m, n, P.mask_p, P.mask_i, nullptr, tp, ti, nullptr);
-        upload_ints(tp.data(), tp.size(), dMTp, s);
-        if (ti.empty()) ti.push_back(0);
-        upload_ints(ti.data(), ti.size(), dMTi, s);
+        dMTp.alloc(((size_t)m + 1) * sizeof(int));
+        dMTi.alloc((size_t)std::max(mnnz, 1) * sizeof(int));
+        OPCHK(rcppml_hip_transpose_csc(c, dt, m, n, dMp.as<int>(), dMi.as<int>(), nullptr, dMTp.as<int>(), dMTi.as<int>(), nullptr));
     }
 
     // ---- factors
     DevBuf dW, dH, dd;
-    upload_cast<T>(P.W, (size_t)k * m, dW, s);
-    upload_cast<T>(P.H, (size_t)k * n, dH, s);
+    upload_cast<T>(c, P.W, (size_t)k * m, dW, s);
+    upload_cast<T>(c, P.H, (size_t)k * n, dH, s);
     dd.alloc((size_t)k * sizeof(T));
     {
         std::vector<T> ones(k, T(1));                       // fit_cpu.hpp:198 d = 1
@@ -326,13 +303,13 @@ void fit(FitParams& P) {
 
     if (is_nb && P.out_theta) {
         DevBuf& th = dtheta;
-        download_cast<T>(th, (size_t)m, P.out_theta, s);
+        download_cast<T>(c, th, (size_t)m, P.out_theta, s);
         P.out_theta_len = m;
     }
     // ---- download, sort by descending d (core/result.hpp:169-188)
-    download_cast<T>(dW, (size_t)k * m, P.W, s);
-    download_cast<T>(dH, (size_t)k * n, P.H, s);
-    download_cast<T>(dd, (size_t)k, P.d, s);
+    download_cast<T>(c, dW, (size_t)k * m, P.W, s);
+    download_cast<T>(c, dH, (size_t)k * n, P.H, s);
+    download_cast<T>(c, dd, (size_t)k, P.d, s);
     if (P.sort_model) {
         std::vector<int> idx(k);
         std::iota(idx.begin(), idx.end(), 0);
@@ -477,9 +454,9 @@ extern "C" void rcppml_gpu_nnls_double(const int* col_ptr, const int* row_idx, c
         DevBuf dAp, dAi, dAx, dW, dH;
         upload_ints(col_ptr, (size_t)*n + 1, dAp, s);
         upload_ints(row_idx, (size_t)std::max(*nnz, 1), dAi, s);
-        upload_cast<double>(values, (size_t)std::max(*nnz, 1), dAx, s);
-        upload_cast<double>(w_T, (size_t)*k * *m, dW, s);
-        upload_cast<double>(h, (size_t)*k * *n, dH, s);
+        upload_cast<double>(g.c, values, (size_t)std::max(*nnz, 1), dAx, s);
+        upload_cast<double>(g.c, w_T, (size_t)*k * *m, dW, s);
+        upload_cast<double>(g.c, h, (size_t)*k * *n, dH, s);
         DevBuf dG((size_t)*k * *k * 8), dB((size_t)*k * *n * 8);
         // gram adds eps; c_nnls adds eps a second time (:327), then L2
         OPCHK(rcppml_hip_gram(g.c, RCPPML_F64, dW.p, *k, *m, 2e-15, *L2 > 0 ? *L2 : 0.0, dG.p));
@@ -487,7 +464,7 @@ extern "C" void rcppml_gpu_nnls_double(const int* col_ptr, const int* row_idx, c
         // warm: B -= G h, CD with default cd_tol = 0 (:349-356); cold: X = 0, CD(cd_tol)
         OPCHK(rcppml_hip_solve_cd(g.c, RCPPML_F64, dG.p, dB.p, dH.p, *k, *n, 0.0, *warm ? 1 : 0, *warm ? 0 : 1, *L1, 0.0,
                                   *nonneg, *cd_maxit, *warm ? 0.0 : *cd_tol, *ub, 0.0, RCPPML_CD_AUTO, nullptr, nullptr));
-        download_cast<double>(dH, (size_t)*k * *n, h, s);
+        download_cast<double>(g.c, dH, (size_t)*k * *n, h, s);
         *out_status = 0;
     } catch (const std::exception& e) {
         rcppml_err() = e.what();
@@ -507,10 +484,10 @@ extern "C" void rcppml_gpu_evaluate_mse_double(const int* col_ptr, const int* ro
         DevBuf dAp, dAi, dAx, dW, dH, dd;
         upload_ints(col_ptr, (size_t)*n + 1, dAp, s);
         upload_ints(row_idx, (size_t)std::max(*nnz, 1), dAi, s);
-        upload_cast<double>(values, (size_t)std::max(*nnz, 1), dAx, s);
-        upload_cast<double>(W_T, (size_t)*k * *m, dW, s);
-        upload_cast<double>(H, (size_t)*k * *n, dH, s);
-        upload_cast<double>(d, (size_t)*k, dd, s);
+        upload_cast<double>(g.c, values, (size_t)std::max(*nnz, 1), dAx, s);
+        upload_cast<double>(g.c, W_T, (size_t)*k * *m, dW, s);
+        upload_cast<double>(g.c, H, (size_t)*k * *n, dH, s);
+        upload_cast<double>(g.c, d, (size_t)*k, dd, s);
         DevBuf dout(4 * sizeof(double));
         OPCHK(rcppml_hip_loss_nonzeros(g.c, RCPPML_F64, dAp.as<int>(), dAi.as<int>(), dAx.p, nullptr, nullptr, *n, dW.p,
                                        dd.p, dH.p, *k, dout.as<double>()));

@@ -320,3 +320,31 @@ print("DIGEST", h.hexdigest())
         assert out.returncode == 0, out.stderr[-2000:]
         digests.append([l for l in out.stdout.splitlines() if l.startswith("DIGEST")][0])
     assert digests[0] == digests[1]
+
+
+def test_transpose_csc_and_cast(env):
+    """rcppml_hip_transpose_csc (stable radix sort by row): identical to the host transpose -- integer arrays and the
+    moved values bit for bit, column indices ascending inside every row; pattern-only (mask) form; empty matrix."""
+    torch, _abi, ctx = env
+    for (m, n, dens, seed) in ((300, 257, 0.08, 1), (5, 900, 0.4, 2), (1000, 3, 0.5, 3), (64, 64, 0.0, 4)):
+        A = random_csc(m, n, dens, seed=seed)
+        At = A.transpose()
+        for dtype, dt, tt in ((np.float32, _abi.F32, torch.float32), (np.float64, _abi.F64, torch.float64)):
+            dp, di, dx = _csc_dev(torch, A, dtype)
+            tp = torch.full((m + 1,), -1, dtype=torch.int32, device="cuda")
+            ti = torch.full((max(A.nnz, 1),), -1, dtype=torch.int32, device="cuda")
+            tx = torch.zeros((max(A.nnz, 1),), dtype=tt, device="cuda")
+            ctx.transpose_csc(dt, m, n, dp, di, dx, tp, ti, tx)
+            assert np.array_equal(tp.cpu().numpy(), At.p.astype(np.int32))
+            assert np.array_equal(ti.cpu().numpy()[:A.nnz], At.i.astype(np.int32))
+            assert np.array_equal(tx.cpu().numpy()[:A.nnz], At.values(dtype))
+        ti2 = torch.full((max(A.nnz, 1),), -1, dtype=torch.int32, device="cuda")
+        ctx.transpose_csc(_abi.F64, m, n, dp, di, None, tp, ti2, None)
+        assert np.array_equal(ti2.cpu().numpy()[:A.nnz], At.i.astype(np.int32))
+    src = torch.from_numpy(np.random.default_rng(0).standard_normal(1000)).cuda()
+    dst = torch.empty((1000,), dtype=torch.float32, device="cuda")
+    ctx.cast(_abi.F64, src, _abi.F32, dst, 1000)
+    assert np.array_equal(dst.cpu().numpy(), src.cpu().numpy().astype(np.float32))
+    back = torch.empty((1000,), dtype=torch.float64, device="cuda")
+    ctx.cast(_abi.F32, dst, _abi.F64, back, 1000)
+    assert np.array_equal(back.cpu().numpy(), dst.cpu().numpy().astype(np.float64))
