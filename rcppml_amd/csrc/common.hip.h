@@ -39,6 +39,19 @@ inline std::string& rcppml_err() {
 
 enum { WS_GRAM = 0, WS_GPAD, WS_CHOL, WS_RED, WS_RED2, WS_ORDER, WS_IRLS, WS_MFMA, WS_COUNT };
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-DEVICE property of a kernel: remember the largest size
+// requested per device (one static instance per kernel instantiation) instead of a process-wide "done" flag.
+struct DynSmemOnce {
+    size_t set_bytes[32] = {};
+    void ensure(const void* fn, size_t smem, int device) {
+        const int d = device & 31;
+        if (smem > 48 * 1024 && smem > set_bytes[d]) {
+            HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            set_bytes[d] = smem;
+        }
+    }
+};
+
 struct rcppml_hip_ctx {
     int device = 0;
     hipStream_t stream = nullptr;

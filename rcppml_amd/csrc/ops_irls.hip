@@ -32,11 +32,8 @@ static void irls_impl(rcppml_hip_ctx* c, const int* cp, const int* ri, const T* 
     } else {
         const size_t smem = (size_t)4 * 64 * 64 * sizeof(T);
         auto kern = irls_nb_solve_kernel<T, 64>;
-        static bool attr_set = false;
-        if (!attr_set) {
-            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-            attr_set = true;
-        }
+        static DynSmemOnce once;
+        once.ensure(reinterpret_cast<const void*>(kern), smem, c->device);
         hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), smem, c->stream, cp, ri, vals, ncols, F, Gbase, X, k, l1, l2,
                            nonneg, cd_maxit, irls_max_iter, irls_tol, theta_row, theta_col);
     }

@@ -120,11 +120,8 @@ static void solve_masked_impl(rcppml_hip_ctx* c, const int* cp, const int* ri, c
     if (k > 64) throw std::runtime_error("solve_masked: k > 64 not supported");
     const size_t smem = (size_t)4 * 64 * 64 * sizeof(T);
     auto kern = masked_solve_kernel<T, 64>;
-    static bool attr_set = false;
-    if (!attr_set && smem > 48 * 1024) {
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        attr_set = true;
-    }
+    static DynSmemOnce once;
+    once.ensure(reinterpret_cast<const void*>(kern), smem, c->device);
     const int64_t nblk = (ncols + 3) / 4;
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), smem, c->stream, cp, ri, vals, mp, mi, ncols, F, Gfull, X,
                        k, l1, l2, nonneg, maxit, tol, solver_mode, warm);

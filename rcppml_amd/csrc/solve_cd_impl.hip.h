@@ -24,11 +24,8 @@ static void cd_wave_launch(rcppml_hip_ctx* c, const T* Gp, const T* invd, const 
     constexpr bool EXACT = std::is_same<T, double>::value;
     const size_t smem = (size_t)KP * KP * sizeof(T);
     auto kern = cd_wave_kernel<T, KP, EXACT>;
-    static bool attr_set = false;
-    if (!attr_set && smem > 48 * 1024) {
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        attr_set = true;
-    }
+    static DynSmemOnce once;
+    once.ensure(reinterpret_cast<const void*>(kern), smem, c->device);
     // persistent blocks: as many 256-thread blocks per CU as LDS allows (<= 8), capped by the work
     int per_cu = (int)((160 * 1024) / (smem + 256));
     if (per_cu > 8) per_cu = 8;
@@ -51,11 +48,8 @@ static void cd_group_launch(rcppml_hip_ctx* c, const T* Gp, const T* invd, const
     constexpr bool EXACT = std::is_same<T, double>::value;
     const size_t smem = ((size_t)KP * KP + 2 * KP) * sizeof(T);
     auto kern = cd_group_kernel<T, KP, LPC, EXACT>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        attr_set = true;
-    }
+    static DynSmemOnce once;
+    once.ensure(reinterpret_cast<const void*>(kern), smem, c->device);
     const int64_t per_block = (int64_t)4 * (64 / LPC);
     const int64_t nblk = (ncols + per_block - 1) / per_block;
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), smem, c->stream, Gp, invd, B, X, k, ncols, l1_pre, warm,
@@ -93,16 +87,9 @@ static void cd_mfma_launch(rcppml_hip_ctx* c, const float* Gp, const float* invd
             if (want > smem && want <= lds_cu / (size_t)cap) smem = want;
         }
     }
-    static size_t attr_smem[2] = {0, 0};
-    if (smem > 48 * 1024 && smem > attr_smem[simple ? 1 : 0]) {
-        if (simple)
-            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&cd_mfma_kernel<RT, CT, true>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        else
-            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&cd_mfma_kernel<RT, CT, false>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        attr_smem[simple ? 1 : 0] = smem;
-    }
+    static DynSmemOnce once_simple, once_general;
+    if (simple) once_simple.ensure(reinterpret_cast<const void*>(&cd_mfma_kernel<RT, CT, true>), smem, c->device);
+    else once_general.ensure(reinterpret_cast<const void*>(&cd_mfma_kernel<RT, CT, false>), smem, c->device);
     if (simple)
         hipLaunchKernelGGL((cd_mfma_kernel<RT, CT, true>), dim3((unsigned)nblk), dim3(256), smem, c->stream, Gq, tab, B, X,
                            k, ncols, l1_pre, warm, zero_init, l1_cd, l2_cd, nonneg, maxit, tol, ub_cd, ub_post, sweeps, order, c->stats);
