@@ -189,7 +189,8 @@ void fit(FitParams& P) {
     bool converged = false;
     double final_tol = 0, train_loss = 0, last_loss = 0;
 
-    for (int iter = 0; iter < P.max_iter; ++iter) {
+    // All device work of one ALS iteration, enqueued on the fit's stream (ends with the loss terms in dloss).
+    auto enqueue_iteration = [&](int iter) {
         const int warm = iter > 0 ? 1 : 0;
         // ================= H half-update (fit_cpu.hpp:486-645)
         if (is_nb) {                                                                    // :565-606 (G: eps only)
@@ -273,6 +274,39 @@ void fit(FitParams& P) {
             // (fused_nnls.hpp:305-362): the third O(nnz k) pass of the reference is not needed.
             OPCHK(rcppml_hip_loss_mse(c, dt, dtr.as<double>(), dd.p, dW.p, dBw.p, k, m, dGwt.p, dGs.p, dloss.as<double>()));
         }
+    };
+
+    // From the third iteration on the launch sequence is identical every time (same kernels, same arguments, scratch
+    // sizes settled), so it is captured once into a hipGraph and replayed: small inputs (hawaiibirds: ~27 launches for
+    // < 50 us of GPU work) are bound by the host's launch rate, not by the kernels.  Plain MSE path only; any capture
+    // failure falls back to eager launches.  RCPPML_GPU_NO_GRAPH=1 disables.
+    const bool graph_ok = !is_nb && !has_mask && !getenv("RCPPML_GPU_NO_GRAPH");
+    struct GraphHolder {
+        hipGraph_t g = nullptr; hipGraphExec_t e = nullptr; bool failed = false;
+        ~GraphHolder() { if (e) (void)hipGraphExecDestroy(e); if (g) (void)hipGraphDestroy(g); }
+    } gh;
+
+    for (int iter = 0; iter < P.max_iter; ++iter) {
+        bool launched = false;
+        if (graph_ok && !gh.failed && iter >= 2) {
+            if (!gh.e) {
+                if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+                    bool body_ok = true;
+                    try { enqueue_iteration(iter); } catch (...) { body_ok = false; }
+                    const hipError_t ec = hipStreamEndCapture(s, &gh.g);
+                    if (!body_ok || ec != hipSuccess || gh.g == nullptr ||
+                        hipGraphInstantiate(&gh.e, gh.g, nullptr, nullptr, 0) != hipSuccess) {
+                        gh.failed = true; gh.e = nullptr;
+                        (void)hipGetLastError();
+                    }
+                } else {
+                    gh.failed = true;
+                    (void)hipGetLastError();
+                }
+            }
+            if (gh.e) { HIPCHK(hipGraphLaunch(gh.e, s)); launched = true; }
+        }
+        if (!launched) enqueue_iteration(iter);
         HIPCHK(hipMemcpyAsync(hloss, dloss.p, 4 * sizeof(double), hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
         double loss_val = hloss[0];
