@@ -120,6 +120,7 @@ enum { RCPPML_CD_AUTO = 0 /* = GROUP unless RCPPML_GPU_CD_VARIANT says otherwise
        RCPPML_CD_LANE = 1 /* one lane per column, residual+iterate in registers, G through the scalar cache (SGPRs) */,
        RCPPML_CD_WAVE = 2 /* one wavefront per column, active-coordinate ballot skipping, G in LDS */,
        RCPPML_CD_GROUP = 5 /* 1, 2 or 4 adjacent lanes per column (DPP broadcasts), G from LDS */,
+       RCPPML_CD_MFMA16 = 7 /* k <= 64, fp32 or fp64: 16 columns per wave, four coordinates per v_mfma_*_16x16x4 (the fp64 default) */,
        RCPPML_CD_MFMA = 6 /* fp32, k <= 128: residual tiles in MFMA accumulators, two coordinates per v_mfma_f32_32x32x2_f32 */ };
 
 /* stream: a hipStream_t (NULL = the device's null stream).  The context owns scratch memory only. */

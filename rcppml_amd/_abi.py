@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("RCPPML_GPU_LIB_PATH") or os.path.join(_HERE, "lib", "
 _lib = None
 
 F32, F64 = 0, 1
-CD_AUTO, CD_LANE, CD_WAVE, CD_GROUP, CD_MFMA = 0, 1, 2, 5, 6
+CD_AUTO, CD_LANE, CD_WAVE, CD_GROUP, CD_MFMA, CD_MFMA16 = 0, 1, 2, 5, 6, 7
 
 # Every symbol include/rcppml_gpu.h declares (tests check the library exports all of them).
 EXPORTED_SYMBOLS = [

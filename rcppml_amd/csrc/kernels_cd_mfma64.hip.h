@@ -23,21 +23,30 @@ namespace rk {
 
 // Gq[((q*NT + t) << 6) + lane] = -G(16t + (lane&15), 4q + (lane>>4)), q = quad of coordinates, NT = KP/16.
 // tab[c] (c = 4q + g) = { 1/G(c,c) (0 if G(c,c) <= 0),  g > 0 ? G(c, 4q) : 0,  g > 1 ? G(c, 4q+1) : 0,  g > 2 ? G(c, 4q+2) : 0 }.
-static __global__ void cd_mfma64_prep_kernel(const double* __restrict__ Gp, const double* __restrict__ invd, int KP,
-                                             double* __restrict__ Gq, double4* __restrict__ tab) {
+// PERM (f32 form): the f32 16x16x4 C/D map is row = 4*(lane>>4) + v (four CONSECUTIVE rows per lane), so the logical
+// rows are permuted, logical 4v+g <-> physical 4g+v inside every tile, to keep "coordinate 4q+g in row group g".
+template <class T> struct Vec4T;
+template <> struct Vec4T<float> { typedef float4 type; };
+template <> struct Vec4T<double> { typedef double4 type; };
+template <class T>
+static __global__ void cd_mfma64_prep_kernel(const T* __restrict__ Gp, const T* __restrict__ invd, int KP,
+                                             T* __restrict__ Gq, typename Vec4T<T>::type* __restrict__ tab) {
+    constexpr bool PERM = sizeof(T) == 4;
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= KP * KP) return;
     const int i = e / KP, r = e % KP;
     const int NT = KP >> 4;
     const int q = i >> 2, kk = i & 3, t = r >> 4, rl = r & 15;
-    Gq[((q * NT + t) << 6) + (kk << 4) + rl] = -Gp[i * KP + r];
+    // physical row slot of logical row rl inside its tile
+    const int ps = PERM ? 4 * (rl & 3) + (rl >> 2) : rl;
+    Gq[((q * NT + t) << 6) + (kk << 4) + ps] = -Gp[i * KP + r];
     if (r == 0) {
         const int c = i, g = c & 3, qb = c & ~3;
-        double4 v;
+        typename Vec4T<T>::type v;
         v.x = invd[c];
-        v.y = g > 0 ? Gp[(qb + 0) * KP + c] : 0.0;
-        v.z = g > 1 ? Gp[(qb + 1) * KP + c] : 0.0;
-        v.w = g > 2 ? Gp[(qb + 2) * KP + c] : 0.0;
+        v.y = g > 0 ? Gp[(qb + 0) * KP + c] : T(0);
+        v.z = g > 1 ? Gp[(qb + 1) * KP + c] : T(0);
+        v.w = g > 2 ? Gp[(qb + 2) * KP + c] : T(0);
         tab[c] = v;
     }
 }
@@ -64,50 +73,67 @@ template <int P> __device__ __forceinline__ unsigned bcast_row32(unsigned a) {
         }
     }
 }
+template <int P> __device__ __forceinline__ float bcast_row(float a) {
+    return __uint_as_float(bcast_row32<P>(__float_as_uint(a)));
+}
 template <int P> __device__ __forceinline__ double bcast_row(double a) {
     const unsigned long long u = __double_as_longlong(a);
     const unsigned lo = bcast_row32<P>((unsigned)u), hi = bcast_row32<P>((unsigned)(u >> 32));
     return __longlong_as_double(((unsigned long long)hi << 32) | lo);
 }
 
-struct CdStepOut64 { double a, nx; };
+template <class T> struct CdStepOut64 { T a, nx; };
 
-template <bool SIMPLE>
-__device__ __forceinline__ CdStepOut64 cd_step64(double b, double xo, double ginv, bool active, double l1_cd, double l2_cd,
-                                                 double lo, double hi) {
-    CdStepOut64 o;
+template <bool SIMPLE, class T>
+__device__ __forceinline__ CdStepOut64<T> cd_step64(T b, T xo, T ginv, bool active, T l1_cd, T l2_cd, T lo, T hi) {
+    CdStepOut64<T> o;
     if constexpr (SIMPLE) {
         // `active` and `if (g_diag <= 0) continue;` arrive folded into ginv (= 0): diff = 0, nv = xo >= 0, a = 0, nx = xo
-        const double diff = b * ginv;
-        const double nv = xo + diff;
-        const bool neg = nv < 0.0;
-        o.nx = neg ? 0.0 : nv;
+        const T diff = b * ginv;
+        const T nv = xo + diff;
+        const bool neg = nv < T(0);
+        o.nx = neg ? T(0) : nv;
         o.a = neg ? -xo : diff;
     } else {
-        double diff = b * ginv;
+        T diff = b * ginv;
         diff -= l1_cd;
-        diff = __builtin_fma(l2_cd, xo, diff);
-        const double nv = xo + diff;
+        diff = tfma(l2_cd, xo, diff);
+        const T nv = xo + diff;
         const bool neg = nv < lo, up = nv > hi;
-        double nx = neg ? lo : (up ? hi : nv);
-        double a = neg ? lo - xo : (up ? hi - xo : diff);
-        const bool on = active && (ginv > 0.0);
-        o.a = on ? a : 0.0;
+        T nx = neg ? lo : (up ? hi : nv);
+        T a = neg ? lo - xo : (up ? hi - xo : diff);
+        const bool on = active && (ginv > T(0));
+        o.a = on ? a : T(0);
         o.nx = on ? nx : xo;
     }
     return o;
 }
 
-template <int NT, bool SIMPLE>   // KP = 16*NT rows (k <= KP), 16 columns per wave, 4 waves per block share G
+__device__ __forceinline__ f64x4 mfma16(double a, double b, f64x4 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+template <class T> struct Acc4T;
+template <> struct Acc4T<float> { typedef f32x4 type; };
+template <> struct Acc4T<double> { typedef f64x4 type; };
+// |a| / den with a hardware reciprocal: v_rcp_f32 (fp32, as the 32-column kernel) or v_rcp_f64 + one Newton step
+__device__ __forceinline__ float fast_recip(float den) { return __builtin_amdgcn_rcpf(den); }
+__device__ __forceinline__ double fast_recip(double den) {
+    const double rc = __builtin_amdgcn_rcp(den);
+    return __builtin_fma(__builtin_fma(-den, rc, 1.0), rc, rc);
+}
+
+template <class T, int NT, bool SIMPLE>   // KP = 16*NT rows (k <= KP), 16 columns per wave, 4 waves per block share G
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NT <= 2 ? 4 : 2, 8)))
-void cd_mfma64_kernel(const double* __restrict__ Gq, const double4* __restrict__ tab, const double* __restrict__ B,
-                      double* __restrict__ X, int k, int64_t ncols, double l1_pre, int warm, int zero_init, double l1_cd,
-                      double l2_cd, int nonneg, int maxit, double tol, double ub_cd, double ub_post,
+void cd_mfma64_kernel(const T* __restrict__ Gq, const typename Vec4T<T>::type* __restrict__ tab, const T* __restrict__ B,
+                      T* __restrict__ X, int k, int64_t ncols, T l1_pre, int warm, int zero_init, T l1_cd,
+                      T l2_cd, int nonneg, int maxit, T tol, T ub_cd, T ub_post,
                       int* __restrict__ sweeps, const int* __restrict__ order, unsigned long long* __restrict__ stats) {
+    typedef typename Vec4T<T>::type Tab4;
+    typedef typename Acc4T<T>::type Acc4;
     constexpr int KP = 16 * NT;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    double* Gs = reinterpret_cast<double*>(smem_raw);               // KP*KP, quad-major (see cd_mfma64_prep_kernel)
-    double4* tab_s = reinterpret_cast<double4*>(Gs + KP * KP);     // KP x {1/G_cc, 3 in-quad couplings}
+    T* Gs = reinterpret_cast<T*>(smem_raw);               // KP*KP, quad-major (see cd_mfma64_prep_kernel)
+    Tab4* tab_s = reinterpret_cast<Tab4*>(Gs + KP * KP);     // KP x {1/G_cc, 3 in-quad couplings}
     for (int e = threadIdx.x; e < KP * KP; e += blockDim.x) Gs[e] = Gq[e];
     for (int e = threadIdx.x; e < KP; e += blockDim.x) tab_s[e] = tab[e];
     __syncthreads();
@@ -118,21 +144,21 @@ void cd_mfma64_kernel(const double* __restrict__ Gq, const double4* __restrict__
     const int64_t slot = base + cl;
     const bool inb = slot < ncols;
     const int64_t j = (inb && order) ? order[slot] : slot;
-    f64x4 acc[NT];
-    double xr[NT][4];
+    Acc4 acc[NT];
+    T xr[NT][4];
     {
-        const double* bj = B + j * (int64_t)k;
-        const double* xj = X + j * (int64_t)k;
+        const T* bj = B + j * (int64_t)k;
+        const T* xj = X + j * (int64_t)k;
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
                 const int row = 16 * t + 4 * v + g;
                 const bool ok = inb && row < k;
-                double bv = ok ? bj[row] : 0.0;
-                if (ok && l1_pre != 0.0) bv -= l1_pre;
+                T bv = ok ? bj[row] : T(0);
+                if (ok && l1_pre != T(0)) bv -= l1_pre;
                 acc[t][v] = bv;
-                xr[t][v] = (ok && !zero_init) ? xj[row] : 0.0;
+                xr[t][v] = (ok && !zero_init) ? xj[row] : T(0);
             }
     }
     if (warm) {   // B -= G X (fused_nnls.hpp:121-123): the same MFMA stream with x in place of the steps
@@ -143,25 +169,25 @@ void cd_mfma64_kernel(const double* __restrict__ Gq, const double4* __restrict__
                 const int q = 4 * t + v;
 #pragma unroll
                 for (int t2 = 0; t2 < NT; ++t2) {
-                    const double av = Gs[((q * NT + t2) << 6) + lane];
-                    acc[t2] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, xr[t][v], acc[t2], 0, 0, 0);
+                    const T av = Gs[((q * NT + t2) << 6) + lane];
+                    acc[t2] = mfma16(av, xr[t][v], acc[t2]);
                 }
             }
     }
-    const double lo = nonneg ? 0.0 : -INFINITY;
-    const double hi = ub_cd > 0.0 ? ub_cd : INFINITY;
-    const bool check = tol > 0.0;
-    const double inv_k = 1.0 / static_cast<double>(k);
+    const T lo = nonneg ? T(0) : -INFINITY;
+    const T hi = ub_cd > T(0) ? ub_cd : INFINITY;
+    const bool check = tol > T(0);
+    const T inv_k = T(1) / static_cast<T>(k);
     bool active = inb;
     int nsweep = 0;
     // operands of the first quad; every quad then requests the NEXT quad's operands before it starts computing
-    double4 tb_c = tab_s[g];
-    double av_c[NT];
+    Tab4 tb_c = tab_s[g];
+    T av_c[NT];
 #pragma unroll
     for (int t2 = 0; t2 < NT; ++t2) av_c[t2] = Gs[(t2 << 6) + lane];
     for (int it = 0; it < maxit; ++it) {
         if (!__any(active)) break;
-        double tsum = 0.0;
+        T tsum = T(0);
         nsweep += active ? 1 : 0;
 #pragma unroll
         for (int t = 0; t < NT; ++t)
@@ -170,32 +196,29 @@ void cd_mfma64_kernel(const double* __restrict__ Gq, const double4* __restrict__
                 constexpr int NQ = KP / 4;
                 const int qn = (4 * t + v + 1) % NQ;
                 const int tn = (v == 3 ? t + 1 : t) % NT;          // row tile of the next quad
-                const double4 tb_n = tab_s[4 * qn + g];
-                double av_n[NT];
+                const Tab4 tb_n = tab_s[4 * qn + g];
+                T av_n[NT];
 #pragma unroll
                 for (int t2 = 0; t2 < NT; ++t2) av_n[t2] = Gs[((qn * NT + t2) << 6) + lane];
-                const double b0 = acc[t][v];
-                const double xo = xr[t][v];
-                const double ginv = SIMPLE ? (active ? tb_c.x : 0.0) : tb_c.x;
+                const T b0 = acc[t][v];
+                const T xo = xr[t][v];
+                const T ginv = SIMPLE ? (active ? tb_c.x : T(0)) : tb_c.x;
                 // phase p: group p's step is final; the groups behind it take the lazy correction, the others keep b
-                const CdStepOut64 s0 = cd_step64<SIMPLE>(b0, xo, ginv, active, l1_cd, l2_cd, lo, hi);
-                const double b1 = __builtin_fma(-tb_c.y, bcast_row<0>(s0.a), b0);
-                const CdStepOut64 s1 = cd_step64<SIMPLE>(b1, xo, ginv, active, l1_cd, l2_cd, lo, hi);
-                const double b2 = __builtin_fma(-tb_c.z, bcast_row<1>(s1.a), b1);
-                const CdStepOut64 s2 = cd_step64<SIMPLE>(b2, xo, ginv, active, l1_cd, l2_cd, lo, hi);
-                const double b3 = __builtin_fma(-tb_c.w, bcast_row<2>(s2.a), b2);
-                const CdStepOut64 s3 = cd_step64<SIMPLE>(b3, xo, ginv, active, l1_cd, l2_cd, lo, hi);
+                const CdStepOut64<T> s0 = cd_step64<SIMPLE, T>(b0, xo, ginv, active, l1_cd, l2_cd, lo, hi);
+                const T b1 = tfma(-tb_c.y, bcast_row<0>(s0.a), b0);
+                const CdStepOut64<T> s1 = cd_step64<SIMPLE, T>(b1, xo, ginv, active, l1_cd, l2_cd, lo, hi);
+                const T b2 = tfma(-tb_c.z, bcast_row<1>(s1.a), b1);
+                const CdStepOut64<T> s2 = cd_step64<SIMPLE, T>(b2, xo, ginv, active, l1_cd, l2_cd, lo, hi);
+                const T b3 = tfma(-tb_c.w, bcast_row<2>(s2.a), b2);
+                const CdStepOut64<T> s3 = cd_step64<SIMPLE, T>(b3, xo, ginv, active, l1_cd, l2_cd, lo, hi);
                 xr[t][v] = s3.nx;
                 // |a| / (|x_new| + 1e-15)  (nnls_batch.hpp:117-120): v_rcp_f64 + one Newton step
-                const double den = tabs(s3.nx) + 1e-15;
-                double rc = __builtin_amdgcn_rcp(den);
-                rc = __builtin_fma(__builtin_fma(-den, rc, 1.0), rc, rc);
-                tsum = __builtin_fma(tabs(s3.a), rc, tsum);
+                tsum = tfma(tabs(s3.a), fast_recip(tabs(s3.nx) + T(1e-15)), tsum);
                 // the row tile that holds the NEXT quad's residuals goes first
 #pragma unroll
                 for (int s = 0; s < NT; ++s) {
                     const int t2 = (tn + s) % NT;
-                    acc[t2] = __builtin_amdgcn_mfma_f64_16x16x4f64(av_c[t2], s3.a, acc[t2], 0, 0, 0);
+                    acc[t2] = mfma16(av_c[t2], s3.a, acc[t2]);
                 }
                 tb_c = tb_n;
 #pragma unroll
@@ -203,20 +226,20 @@ void cd_mfma64_kernel(const double* __restrict__ Gq, const double4* __restrict__
                 __builtin_amdgcn_sched_barrier(0);      // one scheduling region per quad (see kernels_cd_mfma.hip.h)
             }
         // branch-free activity update (see kernels_cd_mfma.hip.h); the four row groups hold the four coordinate classes
-        double tot = tsum + __shfl_xor(tsum, 16, 64);
+        T tot = tsum + __shfl_xor(tsum, 16, 64);
         tot += __shfl_xor(tot, 32, 64);
         active = active && !(check && tot * inv_k < tol);
     }
     if (inb) {
-        double* xj = X + j * (int64_t)k;
+        T* xj = X + j * (int64_t)k;
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
                 const int row = 16 * t + 4 * v + g;
                 if (row < k) {
-                    double val = xr[t][v];
-                    if (ub_post > 0.0) val = val < ub_post ? val : ub_post;
+                    T val = xr[t][v];
+                    if (ub_post > T(0)) val = val < ub_post ? val : ub_post;
                     xj[row] = val;
                 }
             }

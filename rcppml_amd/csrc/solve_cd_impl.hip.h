@@ -99,24 +99,25 @@ static void cd_mfma_launch(rcppml_hip_ctx* c, const float* Gp, const float* invd
     HIPCHK(hipGetLastError());
 }
 
-// fp64 MFMA variant (k <= 64): v_mfma_f64_16x16x4_f64, 16 columns per wave, four coordinates per instruction.
-template <int NT>
-static void cd_mfma64_launch(rcppml_hip_ctx* c, const double* Gp, const double* invd, const double* B, double* X, int k,
-                             int64_t ncols, double l1_pre, int warm, int zero_init, double l1_cd, double l2_cd, int nonneg,
-                             int maxit, double tol, double ub_cd, double ub_post, int* sweeps, const int* order) {
+// 16-column MFMA variant (k <= 64): v_mfma_f64_16x16x4_f64 / v_mfma_f32_16x16x4_f32, four coordinates per instruction.
+template <class T, int NT>
+static void cd_mfma64_launch(rcppml_hip_ctx* c, const T* Gp, const T* invd, const T* B, T* X, int k,
+                             int64_t ncols, T l1_pre, int warm, int zero_init, T l1_cd, T l2_cd, int nonneg,
+                             int maxit, T tol, T ub_cd, T ub_post, int* sweeps, const int* order) {
     constexpr int KP = 16 * NT;
-    double* Gq = static_cast<double*>(c->scratch(WS_MFMA, ((size_t)KP * KP + 4 * KP) * sizeof(double)));
-    double4* tab = reinterpret_cast<double4*>(Gq + (size_t)KP * KP);
-    hipLaunchKernelGGL(cd_mfma64_prep_kernel, dim3((KP * KP + 255) / 256), dim3(256), 0, c->stream, Gp, invd, KP, Gq, tab);
+    typedef typename Vec4T<T>::type Tab4;
+    T* Gq = static_cast<T*>(c->scratch(WS_MFMA, ((size_t)KP * KP + 4 * KP) * sizeof(T)));
+    Tab4* tab = reinterpret_cast<Tab4*>(Gq + (size_t)KP * KP);
+    hipLaunchKernelGGL(cd_mfma64_prep_kernel<T>, dim3((KP * KP + 255) / 256), dim3(256), 0, c->stream, Gp, invd, KP, Gq, tab);
     HIPCHK(hipGetLastError());
-    const size_t smem = ((size_t)KP * KP + 4 * KP) * sizeof(double);
+    const size_t smem = ((size_t)KP * KP + 4 * KP) * sizeof(T);
     const int64_t nblk = (ncols + 63) / 64;          // 4 waves x 16 columns per block
-    const bool simple = nonneg && ub_cd <= 0.0 && l1_cd == 0.0 && l2_cd == 0.0;
+    const bool simple = nonneg && ub_cd <= T(0) && l1_cd == T(0) && l2_cd == T(0);
     if (simple)
-        hipLaunchKernelGGL((cd_mfma64_kernel<NT, true>), dim3((unsigned)nblk), dim3(256), smem, c->stream, Gq, tab, B, X, k,
+        hipLaunchKernelGGL((cd_mfma64_kernel<T, NT, true>), dim3((unsigned)nblk), dim3(256), smem, c->stream, Gq, tab, B, X, k,
                            ncols, l1_pre, warm, zero_init, l1_cd, l2_cd, nonneg, maxit, tol, ub_cd, ub_post, sweeps, order, c->stats);
     else
-        hipLaunchKernelGGL((cd_mfma64_kernel<NT, false>), dim3((unsigned)nblk), dim3(256), smem, c->stream, Gq, tab, B, X, k,
+        hipLaunchKernelGGL((cd_mfma64_kernel<T, NT, false>), dim3((unsigned)nblk), dim3(256), smem, c->stream, Gq, tab, B, X, k,
                            ncols, l1_pre, warm, zero_init, l1_cd, l2_cd, nonneg, maxit, tol, ub_cd, ub_post, sweeps, order, c->stats);
     HIPCHK(hipGetLastError());
 }
@@ -149,14 +150,17 @@ static void solve_cd_impl(rcppml_hip_ctx* c, const T* G, const T* B, T* X, int k
         else if (e && !strcmp(e, "wave")) variant = RCPPML_CD_WAVE;
         else if (e && !strcmp(e, "group")) variant = RCPPML_CD_GROUP;
         else if (e && !strcmp(e, "mfma")) variant = RCPPML_CD_MFMA;
+        else if (e && !strcmp(e, "mfma16")) variant = RCPPML_CD_MFMA16;
         else variant = (std::is_same<T, float>::value || k <= 64) ? RCPPML_CD_MFMA : RCPPML_CD_GROUP;
     }
-    if (variant == RCPPML_CD_MFMA && !std::is_same<T, float>::value && k > 64) variant = RCPPML_CD_GROUP;
-    if (variant == RCPPML_CD_MFMA) KP = std::is_same<T, float>::value ? 32 * ((k + 31) / 32) : 16 * ((k + 15) / 16);
+    if (variant == RCPPML_CD_MFMA && !std::is_same<T, float>::value) variant = k <= 64 ? RCPPML_CD_MFMA16 : RCPPML_CD_GROUP;
+    if (variant == RCPPML_CD_MFMA16 && k > 64) variant = std::is_same<T, float>::value ? RCPPML_CD_MFMA : RCPPML_CD_GROUP;
+    if (variant == RCPPML_CD_MFMA) KP = 32 * ((k + 31) / 32);
+    if (variant == RCPPML_CD_MFMA16) KP = 16 * ((k + 15) / 16);
     // register-resident lane kernel (SGPR-fed): fp32 up to KP=64, fp64 up to KP=32 without spilling
     const int lane_max = std::is_same<T, float>::value ? 64 : 32;
     if (variant == RCPPML_CD_LANE && KP > lane_max) variant = RCPPML_CD_GROUP;
-    if (variant != RCPPML_CD_LANE && variant != RCPPML_CD_WAVE && variant != RCPPML_CD_MFMA) variant = RCPPML_CD_GROUP;
+    if (variant != RCPPML_CD_LANE && variant != RCPPML_CD_WAVE && variant != RCPPML_CD_MFMA && variant != RCPPML_CD_MFMA16) variant = RCPPML_CD_GROUP;
     if (variant == RCPPML_CD_WAVE && KP < 64) KP = 64;   // the wave variant pads to a full 64-lane slab
     T *Gp, *invd;
     pad_impl<T>(c, G, k, KP, &Gp, &invd);
@@ -177,13 +181,13 @@ static void solve_cd_impl(rcppml_hip_ctx* c, const T* G, const T* B, T* X, int k
                 case 96: cd_mfma_launch<3, 1>(CD_ARGS); break;
                 default: cd_mfma_launch<4, 1>(CD_ARGS); break;
             }
-        } else {
-            switch (KP) {
-                case 16: cd_mfma64_launch<1>(CD_ARGS); break;
-                case 32: cd_mfma64_launch<2>(CD_ARGS); break;
-                case 48: cd_mfma64_launch<3>(CD_ARGS); break;
-                default: cd_mfma64_launch<4>(CD_ARGS); break;
-            }
+        }
+    } else if (variant == RCPPML_CD_MFMA16) {
+        switch (KP) {
+            case 16: cd_mfma64_launch<T, 1>(CD_ARGS); break;
+            case 32: cd_mfma64_launch<T, 2>(CD_ARGS); break;
+            case 48: cd_mfma64_launch<T, 3>(CD_ARGS); break;
+            default: cd_mfma64_launch<T, 4>(CD_ARGS); break;
         }
     } else if (variant == RCPPML_CD_GROUP) {
         const int lpc = pick_lpc<T>(KP);

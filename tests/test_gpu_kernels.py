@@ -104,11 +104,11 @@ def _cd_problem(k, n, dtype, seed):
     return G, B, X0
 
 
-VARIANTS = ["lane", "wave", "group", "mfma"]     # mfma: fp32 k <= 64 (falls back to group otherwise)
+VARIANTS = ["lane", "wave", "group", "mfma", "mfma16"]     # mfma: fp32 k <= 64 (falls back to group otherwise)
 
 
 def _var(_abi, name):
-    return dict(lane=_abi.CD_LANE, wave=_abi.CD_WAVE, group=_abi.CD_GROUP, mfma=_abi.CD_MFMA)[name]
+    return dict(lane=_abi.CD_LANE, wave=_abi.CD_WAVE, group=_abi.CD_GROUP, mfma=_abi.CD_MFMA, mfma16=_abi.CD_MFMA16)[name]
 
 
 @pytest.mark.parametrize("variant", VARIANTS)
@@ -180,7 +180,7 @@ def test_cd_lane_equals_wave(env, dtype):
     k, n = 32, 200
     G, B, X0 = _cd_problem(k, n, dtype, 5)
     outs = []
-    for var in (_abi.CD_LANE, _abi.CD_WAVE, _abi.CD_GROUP, _abi.CD_MFMA):
+    for var in (_abi.CD_LANE, _abi.CD_WAVE, _abi.CD_GROUP, _abi.CD_MFMA, _abi.CD_MFMA16):
         dX = _dev(torch, X0.copy())
         ctx.solve_cd(_dt(_abi, dtype), _dev(torch, G), _dev(torch, B), dX, k, n, warm=1, maxit=30, tol=1e-8, variant=var)
         outs.append(dX.cpu().numpy())
@@ -188,6 +188,7 @@ def test_cd_lane_equals_wave(env, dtype):
         assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
         # the fp64 MFMA kernel multiplies by 1/G_ii and refines a hardware reciprocal in the tolerance term
         assert np.abs(outs[0] - outs[3]).max() < 1e-11 * np.abs(outs[0]).max()
+        assert np.abs(outs[0] - outs[4]).max() < 1e-11 * np.abs(outs[0]).max()
     else:  # fp32 variants use rcp for the tolerance term / reassociate it (mfma): same iterates up to the exit sweep
         for o in outs[1:]:
             assert np.abs(outs[0] - o).max() < 1e-5 * np.abs(outs[0]).max()

@@ -16,7 +16,7 @@ G = ops.gram(F, 1e-15, 0.0)
 for n in (20000, 100000, 400000):
     X = torch.rand((n, k), device="cuda", dtype=td, generator=g)
     B = X @ G + 0.1 * torch.randn((n, k), device="cuda", dtype=td, generator=g)
-    for variant, name in ((_abi.CD_AUTO, "auto"), (_abi.CD_GROUP, "group")):
+    for variant, name in ((_abi.CD_AUTO, "auto"), (_abi.CD_MFMA16, "mfma16"), (_abi.CD_GROUP, "group")):
         Xw = torch.zeros_like(X)
         def run():
             ops.ctx.solve_cd(ops.dt, G, B, Xw, k, n, 0.0, 0, 1, 0.0, 0.0, 1, sweeps, 0.0, 0.0, 0.0, variant)
