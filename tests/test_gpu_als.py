@@ -153,3 +153,29 @@ def test_full_size_spot_columns_exact(dtype, tol):
             ops.row_norms(X, 0, out=sums)
             ops.apply_scaling(X, sums, 0, d)
     print("worst relative deviation of sampled columns (%s): %.3e" % (dtype, worst))
+
+
+def test_full_size_c2_fit_matches_oracle_fp64():
+    """The north star's parity bar at FULL size: BASELINE configs[1] (20 000 x 100 000, 1 %, k = 64, CD) through the
+    73-pointer fp64 entry vs the CPU oracle's fp64 fit on identical inputs and iteration count: relative loss deviation
+    <= 1e-6 (observed 3e-14), d / W / H to 1e-8.  The oracle runs OpenMP over the host's cores (~0.7 s per iteration on
+    the 128-thread GPU box)."""
+    import torch
+    from oracle.oracle import Csc
+    from rcppml_amd import _abi, data
+    m, n, k, iters = 20000, 100000, 64, 5
+    A, _, _ = data.simulate_nmf_sparse(m, n, k, 0.0115, seed=123, device=torch.device("cuda", 0))
+    W0, H0 = data.init_factors(42, k, m, n, np.float64)
+    W, H = W0.copy(), H0.copy()
+    res = _abi.nmf_unified(A.p.astype(np.int32), A.i.astype(np.int32), A.x.astype(np.float64), m, n, k, W, H, entry="double",
+                           max_iter=iters, tol=0.0, solver_mode=0)
+    assert res["status"] == 0 and res["iter"] == iters
+    try:
+        O.build(native=True)
+        native = True
+    except Exception:
+        native = False
+    ref = O.nmf_fit(Csc((m, n), A.p, A.i, A.x), W0, H0, np.float64, max_iter=iters, tol=0.0, solver_mode=0, threads=0, native=native)
+    assert abs(res["loss"] - ref.loss) <= 1e-6 * abs(ref.loss)
+    assert np.abs(res["d"] - ref.d).max() <= 1e-8 * np.abs(ref.d).max()
+    assert np.abs(W - ref.W_T).max() < 1e-8 and np.abs(H - ref.H).max() < 1e-8
