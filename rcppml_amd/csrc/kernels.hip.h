@@ -1185,7 +1185,17 @@ __global__ __launch_bounds__(256) void loss_mse_final(const double* __restrict__
 // lists are sorted).  Solve: CD exactly as the wave variant above (sequential visit, in-order), or
 // in-LDS Cholesky + clip for solver_mode 1.
 // ---------------------------------------------------------------------------
-template <class T, int KP>   // KP = 64 only (k <= 64)
+// value of lane i (wave-uniform i) through v_readlane_b32: the result lands in an SGPR, no LDS-crossbar round trip
+__device__ __forceinline__ float lane_value(float v, int i) {
+    return __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), i));
+}
+__device__ __forceinline__ double lane_value(double v, int i) {
+    const unsigned long long u = __double_as_longlong(v);
+    const unsigned lo = __builtin_amdgcn_readlane((unsigned)u, i), hi = __builtin_amdgcn_readlane((unsigned)(u >> 32), i);
+    return __longlong_as_double(((unsigned long long)hi << 32) | lo);
+}
+
+template <class T, int KP>   // KP in {32, 64}: features padded to KP (k <= KP), lane r = feature r
 __global__ __launch_bounds__(256) void masked_solve_kernel(
     const int* __restrict__ colptr, const int* __restrict__ rowidx, const T* __restrict__ vals,
     const int* __restrict__ mask_p, const int* __restrict__ mask_i, int64_t ncols,
@@ -1197,10 +1207,12 @@ __global__ __launch_bounds__(256) void masked_solve_kernel(
     const int64_t j = (int64_t)blockIdx.x * 4 + wave;
     if (j >= ncols) return;
     const bool fok = lane < k;
+    const bool lin = lane < KP;                 // KP = 32: the upper half of the wave only takes part in shuffles
+    const int ll = lin ? lane : 0;
     // G_loc = G_full (padded with identity)
     for (int c = 0; c < KP; ++c) {
         T v = (fok && c < k) ? Gfull[(int64_t)c * k + lane] : (c == lane ? T(1) : T(0));
-        Gl[c * KP + lane] = v;
+        if (lin) Gl[c * KP + lane] = v;
     }
     // b over unmasked nonzeros; delta-G over ALL masked rows
     T b = T(0);
@@ -1218,40 +1230,40 @@ __global__ __launch_bounds__(256) void masked_solve_kernel(
         const T fr = fok ? F[(int64_t)row * k + lane] : T(0);
         for (int c = 0; c < k; ++c) {
             const T fc = __shfl(fr, c, 64);
-            Gl[c * KP + lane] -= fr * fc;
+            if (lin) Gl[c * KP + lane] -= fr * fc;
         }
     }
-    if (fok) { b -= l1; Gl[lane * KP + lane] += l2; }
+    if (fok) { b -= l1; Gl[lane * KP + lane] += l2; }   // fok implies lane < KP
     RK_WAVE_SYNC();
     T x = (warm && fok) ? X[j * (int64_t)k + lane] : T(0);
     if (solver_mode == 1) {
         // in-LDS Cholesky (left-looking) then forward/back substitution; x = clip(G_loc^-1 b)
         for (int c = 0; c < KP; ++c) {
-            T s = Gl[c * KP + lane];
-            for (int p = 0; p < c; ++p) s -= Gl[p * KP + lane] * Gl[p * KP + c];
+            T s = Gl[c * KP + ll];
+            for (int p = 0; p < c; ++p) s -= Gl[p * KP + ll] * Gl[p * KP + c];
             T dcc = __shfl(s, c, 64);
             if (!(dcc > T(0))) dcc = tabs(dcc) + T(1e-30);
             const T lcc = sqrt(dcc);
-            Gl[c * KP + lane] = lane == c ? lcc : (lane > c ? s / lcc : T(0));
+            if (lin) Gl[c * KP + lane] = lane == c ? lcc : (lane > c ? s / lcc : T(0));
             RK_WAVE_SYNC();
         }
         T y = b;
         for (int i = 0; i < k; ++i) {   // forward: y_i = (b_i - sum_{p<i} L_ip y_p) / L_ii
             const T yi = __shfl(y, i, 64) / Gl[i * KP + i];
             if (lane == i) y = yi;
-            else if (lane > i) y -= Gl[i * KP + lane] * yi;
+            else if (lane > i) y -= Gl[i * KP + ll] * yi;
         }
         for (int i = k - 1; i >= 0; --i) {  // backward: x_i = (y_i - sum_{p>i} L_pi x_p) / L_ii
             const T xi = __shfl(y, i, 64) / Gl[i * KP + i];
             if (lane == i) y = xi;
-            else if (lane < i) y -= Gl[lane * KP + i] * xi;
+            else if (lane < i) y -= Gl[ll * KP + i] * xi;
         }
         x = y;
         if (nonneg) x = x > T(0) ? x : T(0);
     } else {
         const bool check = tol > T(0);
         const T inv_k = T(1) / static_cast<T>(k);
-        const T gd = Gl[lane * KP + lane];
+        const T gd = Gl[ll * KP + ll];
         for (int it = 0; it < maxit; ++it) {
             T tol_sum = T(0);
             int cur = 0;
@@ -1264,12 +1276,12 @@ __global__ __launch_bounds__(256) void masked_solve_kernel(
                 const unsigned long long mask = __ballot(moves);
                 if (mask == 0ull) break;
                 const int i = __builtin_ctzll(mask);
-                const T ad_i = __shfl(ad, i, 64), nx_i = __shfl(nx, i, 64);
+                const T ad_i = lane_value(ad, i), nx_i = lane_value(nx, i);
                 if (lane == i) x = nx_i;
                 if (check) tol_sum += tabs(ad_i) / (tabs(nx_i) + T(1e-15));
-                b = tfma(-Gl[i * KP + lane], ad_i, b);
+                b = tfma(-Gl[i * KP + ll], ad_i, b);
                 cur = i + 1;
-                if (cur >= 64) break;
+                if (cur >= KP) break;
             }
             if (check && tol_sum * inv_k < tol) break;
         }

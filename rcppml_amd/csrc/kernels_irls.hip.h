@@ -38,16 +38,6 @@ template <class T> __device__ __forceinline__ T wave_max(T v) {
 }
 
 
-// value of lane i (wave-uniform i) through v_readlane_b32: the result lands in an SGPR, no LDS-crossbar round trip
-__device__ __forceinline__ float lane_value(float v, int i) {
-    return __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), i));
-}
-__device__ __forceinline__ double lane_value(double v, int i) {
-    const unsigned long long u = __double_as_longlong(v);
-    const unsigned lo = __builtin_amdgcn_readlane((unsigned)u, i), hi = __builtin_amdgcn_readlane((unsigned)(u >> 32), i);
-    return __longlong_as_double(((unsigned long long)hi << 32) | lo);
-}
-
 // math/loss.hpp:248-256  irls_weight_nb: computed in double, eps = tiny_num<Scalar>() = Scalar(1e-15)
 template <class T> __device__ __forceinline__ T irls_weight_nb_dev(T predicted, T nb_size) {
     double mu = static_cast<double>(predicted);

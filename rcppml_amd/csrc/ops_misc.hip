@@ -118,13 +118,19 @@ static void solve_masked_impl(rcppml_hip_ctx* c, const int* cp, const int* ri, c
                               int nonneg, int maxit, T tol, int solver_mode, int warm) {
     if (ncols <= 0) return;
     if (k > 64) throw std::runtime_error("solve_masked: k > 64 not supported");
-    const size_t smem = (size_t)4 * 64 * 64 * sizeof(T);
-    auto kern = masked_solve_kernel<T, 64>;
-    static DynSmemOnce once;
-    once.ensure(reinterpret_cast<const void*>(kern), smem, c->device);
     const int64_t nblk = (ncols + 3) / 4;
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), smem, c->stream, cp, ri, vals, mp, mi, ncols, F, Gfull, X,
-                       k, l1, l2, nonneg, maxit, tol, solver_mode, warm);
+    if (k <= 32) {     // 32-wide instantiation: 16 KB of LDS per block instead of 64 KB (8 waves per SIMD)
+        const size_t smem = (size_t)4 * 32 * 32 * sizeof(T);
+        hipLaunchKernelGGL((masked_solve_kernel<T, 32>), dim3((unsigned)nblk), dim3(256), smem, c->stream, cp, ri, vals, mp, mi,
+                           ncols, F, Gfull, X, k, l1, l2, nonneg, maxit, tol, solver_mode, warm);
+    } else {
+        const size_t smem = (size_t)4 * 64 * 64 * sizeof(T);
+        auto kern = masked_solve_kernel<T, 64>;
+        static DynSmemOnce once;
+        once.ensure(reinterpret_cast<const void*>(kern), smem, c->device);
+        hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), smem, c->stream, cp, ri, vals, mp, mi, ncols, F, Gfull, X,
+                           k, l1, l2, nonneg, maxit, tol, solver_mode, warm);
+    }
     HIPCHK(hipGetLastError());
 }
 extern "C" int rcppml_hip_solve_masked(rcppml_hip_ctx* c, int dtype, const int* col_ptr, const int* row_idx,
