@@ -99,11 +99,12 @@ def test_upper_bound_and_norms(abi):
         _compare(res, ref, 1e-6, 1e-6)
 
 
-def test_explicit_mask(abi):
-    """Explicit-mask path (reference nmf/masked_nnls.hpp) through the build-defined rcppml_gpu_nmf_ex entry."""
+@pytest.mark.parametrize("k", [8, 40])
+def test_explicit_mask(abi, k):
+    """Explicit-mask path (reference nmf/masked_nnls.hpp) through the build-defined rcppml_gpu_nmf_ex entry
+    (k = 8: 32-wide kernel instantiation, k = 40: 64-wide)."""
     A = lowrank_csc(120, 160, 4, 0.15, seed=11)
     M = random_csc(120, 160, 0.05, seed=12)
-    k = 8
     W0, H0 = O.init_factors(9, k, A.rows, A.cols, np.float64)
     for solver in (0, 1):
         ref = O.nmf_fit(A, W0, H0, np.float64, max_iter=10, tol=0.0, mask=M, solver_mode=solver, L1=(0.01, 0.02), L2=(0.03, 0.0))
