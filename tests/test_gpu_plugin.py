@@ -205,3 +205,44 @@ def test_degenerate_inputs(abi, entry):
     assert res["status"] in (0, -1)
     if res["status"] == 0:
         assert np.all(np.isfinite(W)) and np.all(np.isfinite(H))
+
+
+def test_reference_properties_on_gpu(abi):
+    """Properties the reference's own test-suite asserts, on the GPU path:
+    same inputs -> bitwise identical factors (test_nmf.R:58-71; here: run-to-run determinism of the kernels, including
+    the sweep-sorted work order whose scatter uses atomics), loss non-increasing within +1e-5 relative without
+    regularisation (test_loss_monotonicity.R:6-25), higher rank -> lower-or-equal loss (test_convergence.R:158-173),
+    non-negativity (test_nmf.R:13-18)."""
+    A = load_fixture("movielens")
+    losses = {}
+    for k in (4, 12):
+        W0, H0 = O.init_factors(3, k, A.rows, A.cols, np.float64)
+        runs = []
+        for rep in range(2):
+            W, H = W0.copy(), H0.copy()
+            res = abi.nmf_unified(A.p, A.i, A.x, A.rows, A.cols, k, W, H, entry="ex", max_iter=25, tol=0.0, solver_mode=0,
+                                  precision=0, want_history=True)
+            assert res["status"] == 0
+            runs.append((W, H, res))
+        assert np.array_equal(runs[0][0], runs[1][0]) and np.array_equal(runs[0][1], runs[1][1])
+        assert np.array_equal(runs[0][2]["d"], runs[1][2]["d"]) and runs[0][2]["loss"] == runs[1][2]["loss"]
+        hist = np.asarray(runs[0][2]["loss_history"][:25])
+        assert np.all(hist[2:] <= hist[1:-1] * (1 + 1e-5)), hist      # iteration 1 is the F7 quirk's starting point
+        assert runs[0][0].min() >= 0 and runs[0][1].min() >= 0
+        losses[k] = runs[0][2]["loss"]
+    assert losses[12] <= losses[4] * (1 + 1e-6)
+
+
+def test_run_to_run_determinism_with_work_order(abi):
+    """Large enough (> 32768 columns) for the sweep-sorted column order to be active: two fits, identical bits."""
+    A = lowrank_csc(300, 40000, 6, 0.02, seed=21)
+    k = 16
+    W0, H0 = O.init_factors(5, k, A.rows, A.cols, np.float64)
+    outs = []
+    for rep in range(2):
+        W, H = W0.copy(), H0.copy()
+        res = abi.nmf_unified(A.p, A.i, A.x, A.rows, A.cols, k, W, H, entry="float", max_iter=6, tol=0.0, solver_mode=0)
+        assert res["status"] == 0
+        outs.append((W, H, res["d"].copy(), res["loss"]))
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    assert np.array_equal(outs[0][2], outs[1][2]) and outs[0][3] == outs[1][3]
