@@ -273,6 +273,148 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     if (fok) X[j * (int64_t)k + lane] = x;
 }
 
+// ---------------------------------------------------------------------------
+// fp64, k <= 32 (k % 2 == 0): the same kernel on v_mfma_f64_16x16x4_f64 -- the 32 x 32 weighted Gram is 2 x 2 tiles of
+// 16 x 16, FOUR nonzeros fill the four K-slots of an instruction (A operand = (w_t - 1) f_t[16 ti + r], B operand =
+// f_t[16 tj + r], lane (r = lane&15, kk = lane>>4) serves nonzero 4s + kk), C/D map col = lane&15, row = (lane>>4) + 4v.
+// Phase A / CD solve as in irls_nb_mfma32_kernel (16-byte gathers = 2 doubles).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void irls_nb_mfma64_kernel(
+    const int* __restrict__ colptr, const int* __restrict__ rowidx, const double* __restrict__ vals, int64_t ncols,
+    const double* __restrict__ F, const double* __restrict__ Gbase, double* __restrict__ X, int k, double l1, double l2,
+    int nonneg, int cd_maxit, int irls_max_iter, double irls_tol, const double* __restrict__ theta_row,
+    const double* __restrict__ theta_col) {
+    constexpr int KP = 32, CH = 32, FS = 34;          // FS: padded row stride (doubles) of the staged F rows
+    constexpr int WAVE_DOUBLES = CH * FS + 2 * CH + KP;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    double* Fst = reinterpret_cast<double*>(smem_raw) + (size_t)wave * WAVE_DOUBLES;
+    double2* sc = reinterpret_cast<double2*>(Fst + CH * FS);
+    double* xs = Fst + CH * FS + 2 * CH;
+    double* Gl = Fst;                                   // [c][r], KP*KP <= CH*FS
+    const int64_t j = (int64_t)blockIdx.x * 4 + wave;
+    if (j >= ncols) return;
+    const int r = lane & 31, hh = lane >> 5;            // phase A: nonzero r, feature half hh
+    const int r16 = lane & 15, kk = lane >> 4;          // phase B: feature slot r16, K-slot kk
+    const bool fok = lane < k;
+    const bool lin = lane < KP;
+    const int ll = lin ? lane : 0;
+    const int as = colptr[j], ae = colptr[j + 1];
+    const double th_col = theta_col ? theta_col[j] : 0.0;
+    double x = 0.0;
+    for (int irls = 0; irls < irls_max_iter; ++irls) {
+        f64x4 acc[2][2];
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+            for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int gi = 16 * ti + kk + 4 * v, gj = 16 * tj + r16;
+                    acc[ti][tj][v] = (gi < k && gj < k) ? Gbase[(int64_t)gj * k + gi] : (gi == gj ? 1.0 : 0.0);
+                }
+        if (lin) xs[lane] = x;
+        double bw[2] = {0.0, 0.0};
+        for (int t0 = as; t0 < ae; t0 += CH) {
+            // ---- phase A
+            const int tt = t0 + r;
+            const bool ok = tt < ae;
+            const int row = ok ? rowidx[tt] : 0;
+            const double a = ok ? vals[tt] : 0.0;
+            const double* fsrc = F + (int64_t)row * k + 16 * hh;
+            double2 fv2[8];
+            double part = 0.0;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int c0 = 16 * hh + 2 * q;
+                fv2[q] = (ok && c0 < k) ? *reinterpret_cast<const double2*>(fsrc + 2 * q) : make_double2(0.0, 0.0);
+                const double2 xv = *reinterpret_cast<const double2*>(xs + c0);
+                part = tfma(fv2[q].x, xv.x, part);
+                part = tfma(fv2[q].y, xv.y, part);
+            }
+            const double recon = part + __shfl_xor(part, 32, 64);
+            const double th = theta_col ? th_col : (theta_row ? theta_row[row] : 0.0);
+            const double w = irls_weight_nb_dev<double>(recon, th);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) *reinterpret_cast<double2*>(Fst + r * FS + 16 * hh + 2 * q) = fv2[q];
+            if (hh == 0) sc[r] = make_double2(ok ? w - 1.0 : 0.0, ok ? w * a : 0.0);
+            __builtin_amdgcn_wave_barrier();
+            // ---- phase B: nonzeros 4s .. 4s+3 of the chunk per MFMA step
+            const int cnt = ae - t0 < CH ? ae - t0 : CH;
+            const int nst = (cnt + 3) >> 2;
+#pragma unroll 2
+            for (int s4 = 0; s4 < nst; ++s4) {
+                const int t = 4 * s4 + kk;
+                const double f0 = Fst[t * FS + r16], f1 = Fst[t * FS + 16 + r16];
+                const double2 ws = sc[t];
+                bw[0] = tfma(ws.y, f0, bw[0]);
+                bw[1] = tfma(ws.y, f1, bw[1]);
+                const double a0 = ws.x * f0, a1 = ws.x * f1;
+                acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, f0, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, f1, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, f0, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, f1, acc[1][1], 0, 0, 0);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        // b_w[16 ti + r16]: sum over the four K-slot groups, then gather both halves into lane = feature order
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti) {
+            bw[ti] += __shfl_xor(bw[ti], 16, 64);
+            bw[ti] += __shfl_xor(bw[ti], 32, 64);
+        }
+        const double bwt = (lane & 16) ? bw[1] : bw[0];     // own registers: lane l < 32 has r16 = l & 15 and wants feature l
+        // park G_w in LDS ([c][r]; symmetric)
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+            for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int gi = 16 * ti + kk + 4 * v, gj = 16 * tj + r16;
+                    double val = acc[ti][tj][v];
+                    if (l2 > 0.0 && gi == gj && gi < k) val += l2;
+                    Gl[gi * KP + gj] = val;
+                }
+        __builtin_amdgcn_wave_barrier();
+        const double x_old = x;
+        double b = bwt;
+#pragma unroll 8
+        for (int c = 0; c < KP; ++c) {
+            const double xc = __shfl(x_old, c, 64);
+            b = tfma(-Gl[c * KP + ll], xc, b);
+        }
+        const double gd = Gl[ll * KP + ll];
+        for (int it = 0; it < cd_maxit; ++it) {
+            int cur = 0;
+            bool any = false;
+            while (true) {
+                double diff = b / gd;
+                if (l1 != 0.0) diff -= l1;
+                const double nv = x + diff;
+                double ad = diff, nx = nv;
+                if (nonneg && nv < 0.0) { ad = -x; nx = 0.0; }
+                const bool moves = fok && (gd > 0.0) && (ad != 0.0) && (lane >= cur);
+                const unsigned long long mask = __ballot(moves);
+                if (mask == 0ull) break;
+                any = true;
+                const int i = __builtin_ctzll(mask);
+                const double ad_i = lane_value(ad, i), nx_i = lane_value(nx, i);
+                if (lane == i) x = nx_i;
+                b = tfma(-Gl[i * KP + ll], ad_i, b);
+                cur = i + 1;
+                if (cur >= KP) break;
+            }
+            if (!any) break;
+        }
+        double rel = fok ? tabs(x - x_old) / (tabs(x_old) + 1e-12) : 0.0;
+        rel = wave_max(rel);
+        __builtin_amdgcn_wave_barrier();
+        if (rel < irls_tol) break;
+    }
+    if (fok) X[j * (int64_t)k + lane] = x;
+}
+
 // NB size (r) method-of-moments update, one wavefront per ROW i of A (= column i of A^T):
 //   nonzero sums of mu^2 and (y-mu)^2 in fp64, totals via  Wd_i . h_rs  and  Wd_i^T G_H Wd_i.
 template <class T>

@@ -25,6 +25,17 @@ static void irls_impl(rcppml_hip_ctx* c, const int* cp, const int* ri, const T* 
             return;
         }
     }
+    if constexpr (std::is_same<T, double>::value) {
+        static int use_mfma64 = -1;
+        if (use_mfma64 < 0) { const char* e = getenv("RCPPML_GPU_IRLS_VARIANT"); use_mfma64 = (e && !strcmp(e, "valu")) ? 0 : 1; }
+        if (use_mfma64 && k <= 32 && k % 2 == 0 && reinterpret_cast<uintptr_t>(F) % 16 == 0) {
+            const size_t smem = (size_t)4 * (32 * 34 + 2 * 32 + 32) * sizeof(double);
+            hipLaunchKernelGGL(irls_nb_mfma64_kernel, dim3((unsigned)nblk), dim3(256), smem, c->stream, cp, ri, vals, ncols, F,
+                               Gbase, X, k, l1, l2, nonneg, cd_maxit, irls_max_iter, irls_tol, theta_row, theta_col);
+            HIPCHK(hipGetLastError());
+            return;
+        }
+    }
     if (k <= 32) {      // 32-wide instantiation: half the rank-1 work per nonzero, 16 KB of LDS per block (8 waves per SIMD)
         const size_t smem = (size_t)4 * 32 * 32 * sizeof(T);
         hipLaunchKernelGGL((irls_nb_solve_kernel<T, 32>), dim3((unsigned)nblk), dim3(256), smem, c->stream, cp, ri, vals, ncols,
