@@ -36,6 +36,34 @@ template <class S> static inline S loss_contribution_nb(S observed, S predicted,
     return static_cast<S>(nll);
 }
 
+// math/loss.hpp:176-179  irls_weight_kl (eps = 1e-4, Scalar arithmetic) -- the weight the GP loss uses for W/H
+// (fit_cpu.hpp:568-574: "GP strategy: use KL weights for W/H updates")
+template <class S> static inline S irls_weight_kl(S predicted) {
+    return static_cast<S>(1) / std::max(predicted, static_cast<S>(1e-4));
+}
+// math/loss.hpp:382-398  loss_contribution_gp (fp64 inside)
+template <class S> static inline S loss_contribution_gp(S observed, S predicted, S theta) {
+    double s = std::max(static_cast<double>(predicted), 1e-10);
+    double y = static_cast<double>(observed);
+    double th = static_cast<double>(theta);
+    double one_plus_theta = 1.0 + th;
+    double loss = -std::log(s / one_plus_theta);
+    if (y >= 1.0) {
+        double inner = (s + th * y) / one_plus_theta;
+        inner = std::max(inner, 1e-10);
+        loss -= (y - 1.0) * std::log(inner);
+    }
+    loss += (s + th * y) / one_plus_theta;
+    return static_cast<S>(loss);
+}
+// nnls_batch_irls.hpp:57-83 distribution_weight for the two implemented distributions: 5 = NB, 4 = GP (-> KL weight)
+template <class S> static inline S irls_weight(int loss_type, S predicted, S theta) {
+    return loss_type == 4 ? irls_weight_kl(predicted) : irls_weight_nb(predicted, theta);
+}
+template <class S> static inline S loss_contribution(int loss_type, S observed, S predicted, S theta) {
+    return loss_type == 4 ? loss_contribution_gp(observed, predicted, theta) : loss_contribution_nb(observed, predicted, theta);
+}
+
 // nmf/masked_nnls.hpp:96-154 (H side) / :177-242 (W side): same routine, data = A or A^T
 template <class S>
 static void masked_nnls(const Csc<S>& A, const S* F, const S* G_full, S* X, const Csc<S>& mask,
@@ -123,7 +151,7 @@ template <class S>
 static void nnls_batch_irls_sparse_nb(const Csc<S>& A, const S* F, const S* G_base, S* X, int k,
                                       S L1, S L2, bool nonneg, int cd_maxit, int irls_max_iter,
                                       S irls_tol, int threads, const S* theta_row,
-                                      const S* theta_col) {
+                                      const S* theta_col, int loss_type = 5) {
     const int nt = eff_threads(threads); (void)nt;
     std::fill(X, X + (size_t)k * A.cols, S(0));   // H.setZero(): no warm start across ALS iters
 #pragma omp parallel num_threads(nt)
@@ -141,7 +169,7 @@ static void nnls_batch_irls_sparse_nb(const Csc<S>& A, const S* F, const S* G_ba
                     S recon = 0;
                     for (int f = 0; f < k; ++f) recon += fr[f] * x[f];
                     const S th = theta_col ? theta_col[j] : (theta_row ? theta_row[row] : S(0));
-                    const S w = irls_weight_nb(recon, th);
+                    const S w = irls_weight(loss_type, recon, th);
                     const S dw = w - S(1);
                     const S wv = w * A.x[t];
                     // G_w += dw * f f^T  (reference: W_nnz_scaled * W_block^T)
@@ -227,7 +255,7 @@ static void nb_size_update(const Csc<S>& A, const S* W_T, const S* H, const S* d
 // nmf/explicit_loss.hpp:53-77   NB NLL over NONZEROS only (per-row theta)
 template <class S>
 static S explicit_loss_sparse_nb(const Csc<S>& A, const S* W_Td, const S* H, int k,
-                                 const S* theta_row, int threads) {
+                                 const S* theta_row, int threads, int loss_type = 5) {
     const int nt = eff_threads(threads); (void)nt;
     S total = 0;
 #pragma omp parallel for reduction(+ : total) num_threads(nt) schedule(dynamic, 64)
@@ -237,7 +265,7 @@ static S explicit_loss_sparse_nb(const Csc<S>& A, const S* W_Td, const S* H, int
             const S* w = W_Td + (size_t)A.i[t] * k;
             S pred = 0;
             for (int f = 0; f < k; ++f) pred += w[f] * h[f];
-            total += loss_contribution_nb(A.x[t], pred, theta_row ? theta_row[A.i[t]] : S(0));
+            total += loss_contribution(loss_type, A.x[t], pred, theta_row ? theta_row[A.i[t]] : S(0));
         }
     }
     return total;
@@ -262,10 +290,12 @@ FitResult<S> nmf_fit(const Csc<S>& A, const FitConfig<S>& cfg, S* W_T, S* H, S* 
     CscOwned<S> maskT_own;
     if (cfg.has_mask) maskT_own = transpose_csc(cfg.mask);   // fit_cpu.hpp:276-280
     const bool is_nb = cfg.loss_type == 5;
-    const bool irls = is_nb;
+    const bool is_gp = cfg.loss_type == 4;                    // dispersion NONE only: theta = 0 (fit_cpu.hpp:297-304)
+    const bool irls = is_nb || is_gp;
     std::vector<S> nb_size;
     if (is_nb)                                                // fit_cpu.hpp:316-328 (PER_ROW/GLOBAL/NONE)
         nb_size.assign(m, cfg.dispersion_mode == 0 ? cfg.nb_size_max : cfg.nb_size_init);
+    if (is_gp) nb_size.assign(m, S(0));                       // theta_vec = Zero(m); the IRLS itself gets no theta
 
     std::vector<S> G((size_t)k * k), G_saved((size_t)k * k), G_wt((size_t)k * k);
     S prev_loss = std::numeric_limits<S>::max();
@@ -282,7 +312,7 @@ FitResult<S> nmf_fit(const Csc<S>& A, const FitConfig<S>& cfg, S* W_T, S* H, S* 
             // :565-606 gram recomputed (eps only); L1 inside CD, L2 on G_w
             nnls_batch_irls_sparse_nb(A, W_T, G.data(), H, k, cfg.L1_H, cfg.L2_H, cfg.nonneg_H,
                                       cfg.cd_maxit, cfg.irls_max_iter, cfg.irls_tol, cfg.threads,
-                                      nb_size.data(), (const S*)nullptr);
+                                      is_nb ? nb_size.data() : (const S*)nullptr, (const S*)nullptr, cfg.loss_type);
         } else {
             if (cfg.L2_H > 0) for (int i = 0; i < k; ++i) G[(size_t)i * k + i] += cfg.L2_H;   // :506
             if (cfg.solver_mode == 0)
@@ -305,7 +335,7 @@ FitResult<S> nmf_fit(const Csc<S>& A, const FitConfig<S>& cfg, S* W_T, S* H, S* 
             // :811-852: theta_per_col = nb_size (row of A == column of A^T)
             nnls_batch_irls_sparse_nb(At, H, G.data(), W_T, k, cfg.L1_W, cfg.L2_W, cfg.nonneg_W,
                                       cfg.cd_maxit, cfg.irls_max_iter, cfg.irls_tol, cfg.threads,
-                                      (const S*)nullptr, nb_size.data());
+                                      (const S*)nullptr, is_nb ? nb_size.data() : (const S*)nullptr, cfg.loss_type);
         } else {
             if (cfg.L2_W > 0) for (int i = 0; i < k; ++i) G[(size_t)i * k + i] += cfg.L2_W;   // :738
             if (cfg.solver_mode == 0)
@@ -326,7 +356,7 @@ FitResult<S> nmf_fit(const Csc<S>& A, const FitConfig<S>& cfg, S* W_T, S* H, S* 
             std::vector<S> Wd((size_t)k * m);
             for (int i = 0; i < m; ++i) for (int f = 0; f < k; ++f) Wd[(size_t)i * k + f] = W_T[(size_t)i * k + f] * d[f];
             loss_val = cfg.has_mask ? masked_loss(A, Wd.data(), H, cfg.mask, k, threads)
-                                    : explicit_loss_sparse_nb(A, Wd.data(), H, k, nb_size.data(), cfg.threads > 0 ? cfg.threads : 1);
+                                    : explicit_loss_sparse_nb(A, Wd.data(), H, k, nb_size.data(), cfg.threads > 0 ? cfg.threads : 1, cfg.loss_type);
         } else {
             gram(W_T, k, m, G_wt.data());                                                   // :1734-1735
             const S cross = loss_cross_term_sparse_via_At(At, W_T, H, d, k, threads);        // :1740-1741
@@ -465,6 +495,11 @@ ORACLE_API float oracle_irls_weight_nb_f32(float p, float r) { return irls_weigh
 ORACLE_API double oracle_loss_nb_f64(double y, double p, double r) { return loss_contribution_nb<double>(y, p, r); }
 ORACLE_API float oracle_loss_nb_f32(float y, float p, float r) { return loss_contribution_nb<float>(y, p, r); }
 
+ORACLE_API double oracle_irls_weight_kl_f64(double p) { return irls_weight_kl<double>(p); }
+ORACLE_API float oracle_irls_weight_kl_f32(float p) { return irls_weight_kl<float>(p); }
+ORACLE_API double oracle_loss_gp_f64(double y, double p, double th) { return loss_contribution_gp<double>(y, p, th); }
+ORACLE_API float oracle_loss_gp_f32(float y, float p, float th) { return loss_contribution_gp<float>(y, p, th); }
+
 // NB-IRLS primitives exposed for kernel-level parity tests
 #define DEFINE_NB(SUF, S)                                                                                    \
     ORACLE_API void oracle_irls_nb_##SUF(int rows, int cols, const int* p, const int* i, const S* x, const S* F, \
@@ -487,6 +522,20 @@ ORACLE_API float oracle_loss_nb_f32(float y, float p, float r) { return loss_con
         std::vector<S> Wd((size_t)k * m);                                                                         \
         for (int r = 0; r < m; ++r) for (int f = 0; f < k; ++f) Wd[(size_t)r * k + f] = W_T[(size_t)r * k + f] * d[f]; \
         return explicit_loss_sparse_nb(mk(m, n, p, i, x), Wd.data(), H, k, theta_row, 1);                         \
+    }                                                                                                             \
+    /* generic forms: loss_type 5 = NB, 4 = GP (KL weights for the half-updates, GP likelihood for the loss) */   \
+    ORACLE_API void oracle_irls_##SUF(int loss_type, int rows, int cols, const int* p, const int* i, const S* x,  \
+                                      const S* F, const S* G, S* X, int k, S L1, S L2, int nonneg, int cd_maxit,  \
+                                      int irls_max_iter, S irls_tol, int threads, const S* theta_row,             \
+                                      const S* theta_col) {                                                       \
+        nnls_batch_irls_sparse_nb(mk(rows, cols, p, i, x), F, G, X, k, L1, L2, nonneg != 0, cd_maxit,             \
+                                  irls_max_iter, irls_tol, threads, theta_row, theta_col, loss_type);             \
+    }                                                                                                             \
+    ORACLE_API S oracle_irls_loss_##SUF(int loss_type, int m, int n, const int* p, const int* i, const S* x,      \
+                                        const S* W_T, const S* d, const S* H, int k, const S* theta_row) {        \
+        std::vector<S> Wd((size_t)k * m);                                                                         \
+        for (int r = 0; r < m; ++r) for (int f = 0; f < k; ++f) Wd[(size_t)r * k + f] = W_T[(size_t)r * k + f] * d[f]; \
+        return explicit_loss_sparse_nb(mk(m, n, p, i, x), Wd.data(), H, k, theta_row, 1, loss_type);              \
     }
 DEFINE_NB(f32, float)
 DEFINE_NB(f64, double)

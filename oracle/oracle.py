@@ -329,6 +329,32 @@ def num_threads():
 
 
 # ----------------------------------------------------------------------------- NB-IRLS primitives
+def irls(loss_type, A, F, G, k, L1=0.0, L2=0.0, nonneg=True, cd_maxit=100, irls_max_iter=5, irls_tol=1e-4, threads=1,
+         theta_row=None, theta_col=None, dtype=np.float64):
+    """Generic IRLS half-update: loss_type 5 = NB, 4 = GP (KL weights, fit_cpu.hpp:568-574)."""
+    suf, ct = _suf(dtype)
+    F, G = _f(F, dtype), _f(G, dtype)
+    X = np.zeros((A.cols, k), dtype)
+    x = A.values(dtype)
+    tr = _f(theta_row, dtype) if theta_row is not None else None
+    tc = _f(theta_col, dtype) if theta_col is not None else None
+    getattr(lib(), "oracle_irls_" + suf)(C.c_int(loss_type), C.c_int(A.rows), C.c_int(A.cols), _p(A.p), _p(A.i), _p(x), _p(F),
+                                         _p(G), _p(X), C.c_int(k), ct(L1), ct(L2), C.c_int(int(nonneg)), C.c_int(cd_maxit),
+                                         C.c_int(irls_max_iter), ct(irls_tol), C.c_int(threads),
+                                         _p(tr) if tr is not None else None, _p(tc) if tc is not None else None)
+    return X
+
+
+def irls_loss(loss_type, A, W_T, d, H, theta_row, dtype=np.float64):
+    suf, ct = _suf(dtype)
+    fn = getattr(lib(), "oracle_irls_loss_" + suf)
+    fn.restype = ct
+    W_T, H, d, th = _f(W_T, dtype), _f(H, dtype), _f(d, dtype), _f(theta_row, dtype)
+    x = A.values(dtype)
+    return float(fn(C.c_int(loss_type), C.c_int(A.rows), C.c_int(A.cols), _p(A.p), _p(A.i), _p(x), _p(W_T), _p(d), _p(H),
+                    C.c_int(W_T.shape[1]), _p(th)))
+
+
 def irls_nb(A, F, G, k, L1=0.0, L2=0.0, nonneg=True, cd_maxit=100, irls_max_iter=5, irls_tol=1e-4, threads=1,
             theta_row=None, theta_col=None, dtype=np.float64):
     suf, ct = _suf(dtype)

@@ -17,6 +17,14 @@ __attribute__((visibility("default"))) double ref_loss_nb_f64(double observed, d
 __attribute__((visibility("default"))) float ref_loss_nb_f32(float observed, float predicted, float nb_size) {
     return FactorNet::loss_contribution_nb<float>(observed, predicted, nb_size);
 }
+__attribute__((visibility("default"))) double ref_irls_weight_kl_f64(double predicted) { return FactorNet::irls_weight_kl<double>(predicted); }
+__attribute__((visibility("default"))) float ref_irls_weight_kl_f32(float predicted) { return FactorNet::irls_weight_kl<float>(predicted); }
+__attribute__((visibility("default"))) double ref_loss_gp_f64(double observed, double predicted, double theta) {
+    return FactorNet::loss_contribution_gp<double>(observed, predicted, theta);
+}
+__attribute__((visibility("default"))) float ref_loss_gp_f32(float observed, float predicted, float theta) {
+    return FactorNet::loss_contribution_gp<float>(observed, predicted, theta);
+}
 __attribute__((visibility("default"))) double ref_loss_mse_f64(double observed, double predicted) {
     return FactorNet::loss_contribution_mse<double>(observed, predicted);
 }

@@ -22,7 +22,7 @@ EXPORTED_SYMBOLS = [
     "rcppml_hip_ctx_create", "rcppml_hip_ctx_destroy", "rcppml_hip_ctx_sync", "rcppml_hip_ctx_stats", "rcppml_hip_transpose_csc", "rcppml_hip_cast", "rcppml_hip_gram", "rcppml_hip_rhs",
     "rcppml_hip_solve_cd", "rcppml_hip_order_columns", "rcppml_hip_solve_chol", "rcppml_hip_row_norms", "rcppml_hip_apply_scaling",
     "rcppml_hip_sumsq", "rcppml_hip_loss_mse", "rcppml_hip_solve_masked", "rcppml_hip_loss_nonzeros",
-    "rcppml_hip_solve_irls_nb", "rcppml_hip_nb_size_update", "rcppml_hip_nb_loss",
+    "rcppml_hip_solve_irls_nb", "rcppml_hip_nb_size_update", "rcppml_hip_nb_loss", "rcppml_hip_solve_irls", "rcppml_hip_irls_loss",
 ]
 
 
@@ -282,6 +282,18 @@ class Context:
                                             C.c_int64(ncols), _dptr(F), _dptr(G_base), _dptr(X), C.c_int(k), C.c_double(l1),
                                             C.c_double(l2), C.c_int(nonneg), C.c_int(cd_maxit), C.c_int(irls_max_iter),
                                             C.c_double(irls_tol), _dptr(theta_row), _dptr(theta_col)), "solve_irls_nb")
+
+    def solve_irls(self, dt, loss_type, col_ptr, row_idx, values, ncols, F, G_base, X, k, l1=0.0, l2=0.0, nonneg=1, cd_maxit=100,
+                   irls_max_iter=5, irls_tol=1e-4, theta_row=None, theta_col=None):
+        _chk(lib().rcppml_hip_solve_irls(self._h, C.c_int(dt), C.c_int(loss_type), _dptr(col_ptr), _dptr(row_idx), _dptr(values),
+                                         C.c_int64(ncols), _dptr(F), _dptr(G_base), _dptr(X), C.c_int(k), C.c_double(l1),
+                                         C.c_double(l2), C.c_int(nonneg), C.c_int(cd_maxit), C.c_int(irls_max_iter),
+                                         C.c_double(irls_tol), _dptr(theta_row), _dptr(theta_col)), "solve_irls")
+
+    def irls_loss(self, dt, loss_type, col_ptr, row_idx, values, ncols, W_T, d, H, theta_row, k, out):
+        _chk(lib().rcppml_hip_irls_loss(self._h, C.c_int(dt), C.c_int(loss_type), _dptr(col_ptr), _dptr(row_idx), _dptr(values),
+                                        C.c_int64(ncols), _dptr(W_T), _dptr(d), _dptr(H), _dptr(theta_row), C.c_int(k),
+                                        _dptr(out)), "irls_loss")
 
     def nb_size_update(self, dt, t_col_ptr, t_row_idx, t_values, m, W_T, d, H, n, k, r_min, r_max, nb_size):
         _chk(lib().rcppml_hip_nb_size_update(self._h, C.c_int(dt), _dptr(t_col_ptr), _dptr(t_row_idx), _dptr(t_values),

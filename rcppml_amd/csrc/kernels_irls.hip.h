@@ -50,11 +50,19 @@ template <class T> __device__ __forceinline__ T irls_weight_nb_dev(T predicted, 
     return static_cast<T>(w);
 }
 
+// distribution weight of the two implemented IRLS losses (nnls_batch_irls.hpp:57-83): 5 = NB; 4 = GP, whose W/H
+// updates use the KL weight 1 / max(mu, 1e-4) in Scalar arithmetic (fit_cpu.hpp:568-574, math/loss.hpp:176-179)
+template <class T> __device__ __forceinline__ T irls_weight_dev(int loss_type, T predicted, T theta) {
+    if (loss_type == 4) return T(1) / (predicted > T(1e-4) ? predicted : T(1e-4));
+    return irls_weight_nb_dev<T>(predicted, theta);
+}
+
 template <class T, int KP>   // KP in {32, 64}: features padded to KP (k <= KP), lane r = feature r
 __global__ __launch_bounds__(256) void irls_nb_solve_kernel(
     const int* __restrict__ colptr, const int* __restrict__ rowidx, const T* __restrict__ vals, int64_t ncols,
     const T* __restrict__ F, const T* __restrict__ Gbase, T* __restrict__ X, int k, T l1, T l2, int nonneg,
-    int cd_maxit, int irls_max_iter, T irls_tol, const T* __restrict__ theta_row, const T* __restrict__ theta_col) {
+    int cd_maxit, int irls_max_iter, T irls_tol, const T* __restrict__ theta_row, const T* __restrict__ theta_col,
+    int loss_type) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     T* Gl = reinterpret_cast<T*>(smem_raw) + (size_t)wave * KP * KP;    // [c][r]
@@ -81,7 +89,7 @@ __global__ __launch_bounds__(256) void irls_nb_solve_kernel(
             const T fr = fok ? F[(int64_t)row * k + lane] : T(0);
             const T recon = wave_sum(fr * x);                                   // W_T.col(row).dot(x)
             const T th = theta_col ? th_col : (theta_row ? theta_row[row] : T(0));
-            const T w = irls_weight_nb_dev<T>(recon, th);
+            const T w = irls_weight_dev<T>(loss_type, recon, th);
             const T dw = w - T(1);
             const T wv = w * a;
             const T frd = fr * dw;                                              // W_nnz_scaled.col = W_block.col * dw
@@ -155,7 +163,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     const int* __restrict__ colptr, const int* __restrict__ rowidx, const float* __restrict__ vals, int64_t ncols,
     const float* __restrict__ F, const float* __restrict__ Gbase, float* __restrict__ X, int k, float l1, float l2,
     int nonneg, int cd_maxit, int irls_max_iter, float irls_tol, const float* __restrict__ theta_row,
-    const float* __restrict__ theta_col) {
+    const float* __restrict__ theta_col, int loss_type) {
     constexpr int KP = 32, CH = 32, FS = 36;          // FS: padded row stride of the staged F rows (bank spread)
     constexpr int WAVE_FLOATS = CH * FS + 2 * CH + KP;  // staged rows | (w-1, w a) pairs | x
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -204,7 +212,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
             }
             const float recon = part + __shfl_xor(part, 32, 64);                 // W_T.col(row).dot(x)
             const float th = theta_col ? th_col : (theta_row ? theta_row[row] : 0.f);
-            const float w = irls_weight_nb_dev<float>(recon, th);
+            const float w = irls_weight_dev<float>(loss_type, recon, th);
 #pragma unroll
             for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(Fst + r * FS + 16 * hh + 4 * q) = fv4[q];
             if (hh == 0) sc[r] = make_float2(ok ? w - 1.f : 0.f, ok ? w * a : 0.f);
@@ -283,7 +291,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     const int* __restrict__ colptr, const int* __restrict__ rowidx, const double* __restrict__ vals, int64_t ncols,
     const double* __restrict__ F, const double* __restrict__ Gbase, double* __restrict__ X, int k, double l1, double l2,
     int nonneg, int cd_maxit, int irls_max_iter, double irls_tol, const double* __restrict__ theta_row,
-    const double* __restrict__ theta_col) {
+    const double* __restrict__ theta_col, int loss_type) {
     constexpr int KP = 32, CH = 32, FS = 34;          // FS: padded row stride (doubles) of the staged F rows
     constexpr int WAVE_DOUBLES = CH * FS + 2 * CH + KP;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -334,7 +342,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
             }
             const double recon = part + __shfl_xor(part, 32, 64);
             const double th = theta_col ? th_col : (theta_row ? theta_row[row] : 0.0);
-            const double w = irls_weight_nb_dev<double>(recon, th);
+            const double w = irls_weight_dev<double>(loss_type, recon, th);
 #pragma unroll
             for (int q = 0; q < 8; ++q) *reinterpret_cast<double2*>(Fst + r * FS + 16 * hh + 2 * q) = fv2[q];
             if (hh == 0) sc[r] = make_double2(ok ? w - 1.0 : 0.0, ok ? w * a : 0.0);
@@ -488,7 +496,7 @@ template <class T>
 __global__ __launch_bounds__(256) void nb_loss_lane_kernel(
     const int* __restrict__ colptr, const int* __restrict__ rowidx, const T* __restrict__ vals, int64_t ncols,
     const T* __restrict__ W_T, const T* __restrict__ d, const T* __restrict__ H, const T* __restrict__ theta_row, int k,
-    int vec_ok, double* __restrict__ partial) {
+    int vec_ok, int loss_type, double* __restrict__ partial) {
     constexpr int VEC = 16 / sizeof(T);
     typedef typename VecT<T, VEC>::type V;
     __shared__ double sh[4];
@@ -518,9 +526,21 @@ __global__ __launch_bounds__(256) void nb_loss_lane_kernel(
             const double y = static_cast<double>(vals[t]);
             double mu = static_cast<double>(pred);
             mu = mu > 1e-10 ? mu : 1e-10;
-            double r = static_cast<double>(theta_row ? theta_row[row] : T(0));
-            r = r > 1e-10 ? r : 1e-10;
-            const double nll = -lgamma(y + r) + lgamma(r) - r * log(r / (r + mu)) - y * log(mu / (r + mu));
+            const double th = static_cast<double>(theta_row ? theta_row[row] : T(0));
+            double nll;
+            if (loss_type == 4) {                  // math/loss.hpp:382-398  loss_contribution_gp
+                const double opt = 1.0 + th;
+                nll = -log(mu / opt);
+                if (y >= 1.0) {
+                    double inner = (mu + th * y) / opt;
+                    inner = inner > 1e-10 ? inner : 1e-10;
+                    nll -= (y - 1.0) * log(inner);
+                }
+                nll += (mu + th * y) / opt;
+            } else {                               // math/loss.hpp:415-426  loss_contribution_nb
+                const double r = th > 1e-10 ? th : 1e-10;
+                nll = -lgamma(y + r) + lgamma(r) - r * log(r / (r + mu)) - y * log(mu / (r + mu));
+            }
             acc += static_cast<double>(static_cast<T>(nll));      // the reference casts each term to Scalar
         }
     }

@@ -72,7 +72,7 @@ struct FitParams {
     const int* mask_p; const int* mask_i;   // NULL = no mask
     int sort_model;
     double* loss_history;                    // may be NULL
-    int loss_type = 0;                       // 0 = MSE, 5 = NB
+    int loss_type = 0;                       // 0 = MSE, 4 = GP (dispersion none), 5 = NB
     int irls_max_iter = 5; double irls_tol = 1e-4;
     int dispersion_mode = 2;                 // 0 none, 1 global, 2 per-row
     double nb_size_init = 10, nb_size_max = 1e6, nb_size_min = 0.01;
@@ -173,10 +173,11 @@ void fit(FitParams& P) {
     DevBuf dswH((size_t)n * sizeof(int)), dswW((size_t)m * sizeof(int)), dordH((size_t)n * sizeof(int)), dordW((size_t)m * sizeof(int));
     const bool use_order = P.solver_mode == 0 && !has_mask && P.loss_type == 0 && P.cd_tol > 0 && !getenv("RCPPML_GPU_NO_ORDER");
 
-    const bool is_nb = P.loss_type == 5;
+    const bool is_gp = P.loss_type == 4;                                // theta_vec = Zero(m) (fit_cpu.hpp:297-304)
+    const bool is_nb = P.loss_type == 5 || is_gp;                       // "is_irls": both run the IRLS half-updates
     DevBuf dtheta;
     if (is_nb) {                                                        // fit_cpu.hpp:316-328
-        std::vector<T> th((size_t)m, static_cast<T>(P.dispersion_mode == 0 ? P.nb_size_max : P.nb_size_init));
+        std::vector<T> th((size_t)m, is_gp ? T(0) : static_cast<T>(P.dispersion_mode == 0 ? P.nb_size_max : P.nb_size_init));
         dtheta.alloc((size_t)m * sizeof(T));
         HIPCHK(hipMemcpyAsync(dtheta.p, th.data(), (size_t)m * sizeof(T), hipMemcpyHostToDevice, s));
         HIPCHK(hipStreamSynchronize(s));
@@ -195,8 +196,9 @@ void fit(FitParams& P) {
         // ================= H half-update (fit_cpu.hpp:486-645)
         if (is_nb) {                                                                    // :565-606 (G: eps only)
             OPCHK(rcppml_hip_gram(c, dt, dW.p, k, m, eps, 0.0, dG.p));
-            OPCHK(rcppml_hip_solve_irls_nb(c, dt, dAp.as<int>(), dAi.as<int>(), dAx.p, n, dW.p, dG.p, dH.p, k, P.L1_H, P.L2_H,
-                                           P.nonneg_H, P.cd_maxit, P.irls_max_iter, P.irls_tol, dtheta.p, nullptr));
+            OPCHK(rcppml_hip_solve_irls(c, dt, P.loss_type, dAp.as<int>(), dAi.as<int>(), dAx.p, n, dW.p, dG.p, dH.p, k, P.L1_H,
+                                        P.L2_H, P.nonneg_H, P.cd_maxit, P.irls_max_iter, P.irls_tol,
+                                        is_gp ? nullptr : dtheta.p, nullptr));
             if (P.ub_H > 0) throw std::runtime_error("upper bound with NB loss: not supported");
         } else if (has_mask) {
             OPCHK(rcppml_hip_gram(c, dt, dW.p, k, m, eps, 0.0, dG.p));                 // :562 unmodified G
@@ -223,8 +225,9 @@ void fit(FitParams& P) {
         // ================= W half-update (fit_cpu.hpp:711-893)
         if (is_nb) {                                                                    // :811-852 theta_per_col = r of the row
             OPCHK(rcppml_hip_gram(c, dt, dH.p, k, n, eps, 0.0, dG.p));
-            OPCHK(rcppml_hip_solve_irls_nb(c, dt, dTp.as<int>(), dTi.as<int>(), dTx.p, m, dH.p, dG.p, dW.p, k, P.L1_W, P.L2_W,
-                                           P.nonneg_W, P.cd_maxit, P.irls_max_iter, P.irls_tol, nullptr, dtheta.p));
+            OPCHK(rcppml_hip_solve_irls(c, dt, P.loss_type, dTp.as<int>(), dTi.as<int>(), dTx.p, m, dH.p, dG.p, dW.p, k, P.L1_W,
+                                        P.L2_W, P.nonneg_W, P.cd_maxit, P.irls_max_iter, P.irls_tol, nullptr,
+                                        is_gp ? nullptr : dtheta.p));
         } else if (has_mask) {
             OPCHK(rcppml_hip_gram(c, dt, dH.p, k, n, eps, 0.0, dG.p));
             OPCHK(rcppml_hip_solve_masked(c, dt, dTp.as<int>(), dTi.as<int>(), dTx.p, dMTp.as<int>(), dMTi.as<int>(),
@@ -249,7 +252,7 @@ void fit(FitParams& P) {
         OPCHK(rcppml_hip_apply_scaling(c, dt, dW.p, k, m, P.norm_type, dsums.p, dd.p));
 
         // ================= NB size update (fit_cpu.hpp:1094-1265), then loss (fit_cpu.hpp:1684-1753)
-        if (is_nb && P.dispersion_mode != 0) {
+        if (is_nb && !is_gp && P.dispersion_mode != 0) {
             OPCHK(rcppml_hip_nb_size_update(c, dt, dTp.as<int>(), dTi.as<int>(), dTx.p, m, dW.p, dd.p, dH.p, n, k,
                                             P.nb_size_min, P.nb_size_max, dtheta.p));
             if (P.dispersion_mode == 1) {          // GLOBAL: median (nth_element at m/2) of the per-row values
@@ -264,7 +267,7 @@ void fit(FitParams& P) {
             }
         }
         if (is_nb) {
-            OPCHK(rcppml_hip_nb_loss(c, dt, dAp.as<int>(), dAi.as<int>(), dAx.p, n, dW.p, dd.p, dH.p, dtheta.p, k, dloss.as<double>()));
+            OPCHK(rcppml_hip_irls_loss(c, dt, P.loss_type, dAp.as<int>(), dAi.as<int>(), dAx.p, n, dW.p, dd.p, dH.p, dtheta.p, k, dloss.as<double>()));
         } else if (has_mask) {
             OPCHK(rcppml_hip_loss_nonzeros(c, dt, dAp.as<int>(), dAi.as<int>(), dAx.p, dMp.as<int>(), dMi.as<int>(), n,
                                            dW.p, dd.p, dH.p, k, dloss.as<double>()));
@@ -371,7 +374,14 @@ void nmf_entry(RCPPML_NMF_UNIFIED_ARGS, const int* mask_p, const int* mask_i, do
         (void)gamma_phi_min; (void)tweedie_power; (void)guide_H_labels_flat; (void)guide_H_ns;
         (void)guide_H_lambdas; (void)guide_H_ncs;
         // Reject what is not implemented so the caller falls back to CPU (SURVEY.md 8b "Semantics")
-        if (*loss_type != 0 && *loss_type != 5) throw std::runtime_error("loss_type must be MSE (0) or NB (5) for this plugin build");
+        if (*loss_type != 0 && *loss_type != 5 && *loss_type != 4)
+            throw std::runtime_error("loss_type must be MSE (0), GP (4, dispersion none) or NB (5) for this plugin build");
+        if (*loss_type == 4) {      // Poisson / KL NMF: GP likelihood with theta = 0, KL-weighted half-updates
+            if (*gp_dispersion_mode != 0) throw std::runtime_error("GP loss: only dispersion='none' is supported");
+            if (*k > 64) throw std::runtime_error("GP loss: k must be <= 64");
+            if (*solver_mode != 0) throw std::runtime_error("GP loss requires the CD solver");
+            if (mask_p) throw std::runtime_error("GP loss with explicit mask: not supported");
+        }
         if (*loss_type == 5) {
             if (*k > 64) throw std::runtime_error("NB loss: k must be <= 64");
             if (*gp_dispersion_mode == 3) throw std::runtime_error("NB loss: dispersion='per_col' not supported");

@@ -80,8 +80,11 @@ def nmf(data, k, tol=1e-4, maxit=100, L1=(0.0, 0.0), L2=(0.0, 0.0), seed=None, m
     """
     if loss not in _LOSSES:
         raise ValueError("'arg' should be one of %s" % ", ".join(repr(x) for x in _LOSSES))
-    if loss not in ("mse", "nb") or robust or zi != "none":
-        raise NotImplementedError("only loss='mse' and loss='nb' (no robust / zero-inflation) are implemented by the MI355X backend")
+    if loss not in ("mse", "nb", "gp") or robust or zi != "none":
+        raise NotImplementedError("only loss='mse', loss='nb' and loss='gp' with dispersion='none' (no robust / zero-inflation) "
+                                  "are implemented by the MI355X backend")
+    if loss == "gp" and dispersion != "none":
+        raise NotImplementedError("loss='gp' is implemented for dispersion='none' (Poisson / KL-divergence NMF) only")
     if dispersion not in ("none", "global", "per_row"):
         raise NotImplementedError("dispersion must be 'none', 'global' or 'per_row' on the MI355X backend")
     if projective or symmetric:
@@ -144,7 +147,7 @@ def nmf(data, k, tol=1e-4, maxit=100, L1=(0.0, 0.0), L2=(0.0, 0.0), seed=None, m
                            L1_W=L1w, L2_H=L2h, L2_W=L2w, ub_H=ubh, ub_W=ubw, cd_maxit=int(cd_maxit), verbose=int(verbose),
                            seed=seed_int & 0x7FFFFFFF, patience=int(patience), nonneg_W=int(nnw), nonneg_H=int(nnh),
                            norm_type=norm_type, solver_mode=0 if solver == "cd" else 1, mask=mask_arg, cd_tol=float(cd_tol),
-                           loss_type=5 if loss == "nb" else 0, irls_max_iter=int(irls_max_iter), irls_tol=float(irls_tol),
+                           loss_type={"mse": 0, "gp": 4, "nb": 5}[loss], irls_max_iter=int(irls_max_iter), irls_tol=float(irls_tol),
                            gp_dispersion_mode={"none": 0, "global": 1, "per_row": 2}[dispersion],
                            nb_size=(nb_size_init, nb_size_max, nb_size_min),
                            sort_model=int(sort_model), precision=_abi.F32 if precision == "fp32" else _abi.F64,
@@ -154,7 +157,7 @@ def nmf(data, k, tol=1e-4, maxit=100, L1=(0.0, 0.0), L2=(0.0, 0.0), seed=None, m
     misc = dict(tol=res["tol"], iter=res["iter"], loss=res["loss"], loss_history=res.get("loss_history"),
                 converged=res["converged"], solver=solver, solver_mode=0 if solver == "cd" else 1, L1=(L1w, L1h),
                 L2=(L2w, L2h), seed=seed_int, precision=precision, resource="gpu", loss_type=loss)
-    if loss == "nb":
+    if loss in ("nb", "gp"):
         misc["theta"] = res["theta"]                                   # R: misc$theta (RcppFunctions_nmf.cpp:156-158)
     return NMFModel(w=W_T.copy(), d=res["d"], h=H.T.copy(), misc=misc)
 

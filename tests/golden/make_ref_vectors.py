@@ -16,7 +16,9 @@ loss = C.CDLL(os.path.join(root, "oracle", "_ref", "libref_loss.so"))
 rng.ref_next.restype = C.c_uint64
 rng.ref_hash.restype = C.c_uint64
 for f, t in ((loss.ref_irls_weight_nb_f64, C.c_double), (loss.ref_loss_nb_f64, C.c_double),
-             (loss.ref_irls_weight_nb_f32, C.c_float), (loss.ref_loss_nb_f32, C.c_float)):
+             (loss.ref_irls_weight_nb_f32, C.c_float), (loss.ref_loss_nb_f32, C.c_float),
+             (loss.ref_irls_weight_kl_f64, C.c_double), (loss.ref_irls_weight_kl_f32, C.c_float),
+             (loss.ref_loss_gp_f64, C.c_double), (loss.ref_loss_gp_f32, C.c_float)):
     f.restype = t
 
 out = {}
@@ -61,5 +63,14 @@ Y, P3, R3 = np.meshgrid(obs, pred, size, indexing="ij")
 out["nll_obs"], out["nll_pred"], out["nll_size"] = Y.ravel(), P3.ravel(), R3.ravel()
 out["nll_f64"] = np.array([loss.ref_loss_nb_f64(C.c_double(y), C.c_double(a), C.c_double(b)) for y, a, b in zip(Y.ravel(), P3.ravel(), R3.ravel())])
 out["nll_f32"] = np.array([loss.ref_loss_nb_f32(C.c_float(y), C.c_float(a), C.c_float(b)) for y, a, b in zip(Y.ravel(), P3.ravel(), R3.ravel())], dtype=np.float32)
+# GP: KL weight (what the GP half-updates use) and GP likelihood (theta = 0 and a few positive values)
+out["kl_pred"] = pred
+out["kl_weight_f64"] = np.array([loss.ref_irls_weight_kl_f64(C.c_double(a)) for a in pred])
+out["kl_weight_f32"] = np.array([loss.ref_irls_weight_kl_f32(C.c_float(a)) for a in pred], dtype=np.float32)
+theta = np.array([0.0, 0.1, 1.5])
+Yg, Pg, Tg = np.meshgrid(obs, pred, theta, indexing="ij")
+out["gp_obs"], out["gp_pred"], out["gp_theta"] = Yg.ravel(), Pg.ravel(), Tg.ravel()
+out["gp_loss_f64"] = np.array([loss.ref_loss_gp_f64(C.c_double(y), C.c_double(a), C.c_double(b)) for y, a, b in zip(Yg.ravel(), Pg.ravel(), Tg.ravel())])
+out["gp_loss_f32"] = np.array([loss.ref_loss_gp_f32(C.c_float(y), C.c_float(a), C.c_float(b)) for y, a, b in zip(Yg.ravel(), Pg.ravel(), Tg.ravel())], dtype=np.float32)
 np.savez_compressed(os.path.join(here, "ref_vectors.npz"), **out)
 print("wrote ref_vectors.npz:", {k2: v.shape for k2, v in out.items()})

@@ -105,3 +105,66 @@ def test_nb_fit_through_plugin(dispersion):
     print("theta rel err: median %.2e p99 %.2e max %.2e" % (np.median(rel), np.percentile(rel, 99), rel.max()))
     assert np.median(rel) < 1e-4 and rel.max() < 0.2
     assert np.all(res["theta"] >= 0.01) and np.all(res["theta"] <= 1e6)
+
+
+@pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-7), (np.float32, 3e-2)])
+@pytest.mark.parametrize("k", [4, 12, 32, 33])
+def test_irls_gp_half_update_and_loss(env, dtype, tol, k):
+    """loss = "gp" (LossType 4): half-updates with the KL weight 1/max(mu, 1e-4) (fit_cpu.hpp:568-574) and the GP
+    likelihood over the nonzeros (math/loss.hpp:382-398), vs the oracle (whose per-element pieces are pinned to the
+    reference's math/loss.hpp bit for bit, tests/test_oracle_ref.py)."""
+    torch, _abi, ctx = env
+    A = _nb_problem(150, 220, 4, seed=k + 100)
+    rng = np.random.default_rng(k)
+    dt = _abi.F32 if dtype == np.float32 else _abi.F64
+    tt = torch.float32 if dtype == np.float32 else torch.float64
+    F = rng.uniform(0.05, 1.0, size=(A.rows, k)).astype(dtype)
+    F /= F.sum(axis=0, keepdims=True)
+    F *= 30.0
+    G = O.gram(F)
+    ref = O.irls(4, A, F, G, k, L1=0.0, L2=1e-3, dtype=dtype)
+    dX = torch.full((A.cols, k), 3.0, dtype=tt, device="cuda")
+    ctx.solve_irls(dt, 4, _dev(torch, A.p), _dev(torch, A.i), _dev(torch, A.values(dtype)), A.cols, _dev(torch, F), _dev(torch, G),
+                   dX, k, l1=0.0, l2=1e-3)
+    X = dX.cpu().numpy()
+    assert X.min() >= 0 and np.all(np.isfinite(X))
+    assert np.abs(X - ref).max() / np.abs(ref).max() < tol
+    # GP likelihood with theta = 0 and with a positive theta
+    d = rng.uniform(0.5, 2.0, size=k).astype(dtype)
+    for th_val in (0.0, 0.3):
+        theta = np.full(A.rows, th_val, dtype)
+        lref = O.irls_loss(4, A, F, d, X.astype(dtype), theta, dtype=dtype)
+        out = torch.zeros((1,), dtype=torch.float64, device="cuda")
+        ctx.irls_loss(dt, 4, _dev(torch, A.p), _dev(torch, A.i), _dev(torch, A.values(dtype)), A.cols, _dev(torch, F), _dev(torch, d),
+                      _dev(torch, X.astype(dtype)), _dev(torch, theta), k, out)
+        assert abs(float(out.item()) - lref) <= (1e-9 if dtype == np.float64 else 2e-3) * abs(lref)
+
+
+def test_gp_fit_through_plugin_and_python_surface():
+    """nmf(loss = "gp", dispersion = "none") = Poisson / KL-divergence NMF: 73-pointer entry (loss_type 4) vs the oracle
+    fit; dispersion other than none is refused (out_status = -1); the Python mirror accepts loss = "gp"."""
+    from rcppml_amd import _abi, nmf as N
+    A = _nb_problem(100, 160, 3, seed=19)
+    k = 6
+    W0, H0 = O.init_factors(11, k, A.rows, A.cols, np.float64)
+    ref = O.nmf_fit(A, W0, H0, np.float64, max_iter=6, tol=0.0, loss_type=4, dispersion_mode=0, threads=1)
+    W, H = W0.copy(), H0.copy()
+    res = _abi.nmf_unified(A.p, A.i, A.x, A.rows, A.cols, k, W, H, entry="double", max_iter=6, tol=0.0, loss_type=4,
+                           gp_dispersion_mode=0)
+    assert res["status"] == 0, res.get("error")
+    assert res["iter"] == ref.iter
+    # IRLS amplifies rounding (weights 1/mu with mu near the 1e-4 floor in the first passes): same bars as the NB fit
+    assert abs(res["loss"] - ref.loss) / abs(ref.loss) < 2e-5
+    assert np.abs(W - ref.W_T).max() < 1e-4 and np.abs(H - ref.H).max() < 1e-4
+    assert np.abs(res["d"] - ref.d).max() / ref.d.max() < 1e-4
+    assert np.all(res["theta"] == 0)
+    W, H = W0.copy(), H0.copy()
+    bad = _abi.nmf_unified(A.p, A.i, A.x, A.rows, A.cols, k, W, H, entry="double", max_iter=2, tol=0.0, loss_type=4,
+                           gp_dispersion_mode=2)
+    assert bad["status"] == -1
+    from rcppml_amd.data import CSC
+    Ap = CSC((A.rows, A.cols), A.p, A.i, A.x)
+    model = N.nmf(Ap, k, loss="gp", dispersion="none", seed=3, maxit=5, tol=0.0)
+    assert model.misc["loss_type"] == "gp" and np.isfinite(model.misc["loss"]) and model.w.min() >= 0 and model.h.min() >= 0
+    with pytest.raises(NotImplementedError):
+        N.nmf(Ap, k, loss="gp", dispersion="per_row", seed=3, maxit=2)
