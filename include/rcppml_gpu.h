@@ -233,18 +233,21 @@ RCPPML_GPU_API int rcppml_hip_solve_irls_nb(rcppml_hip_ctx* ctx, int dtype, cons
                                             void* X, int k, double l1, double l2, int nonneg, int cd_maxit,
                                             int irls_max_iter, double irls_tol, const void* theta_row,
                                             const void* theta_col);
-/* Generic forms: loss_type = the reference's LossType (math/loss.hpp:36-47), implemented: 5 = NB, 4 = GP.  The GP loss
- * updates W and H with the KL weight 1/max(mu, 1e-4) (nmf/fit_cpu.hpp:568-574: "GP strategy: use KL weights for W/H
- * updates"; theta pointers are ignored, pass NULL) and evaluates the GP likelihood (math/loss.hpp:382-398) with
- * theta_row (zeros for dispersion = "none", which is what the plugin implements: Poisson / KL-divergence NMF). */
+/* Generic forms: loss_type = the reference's LossType (math/loss.hpp:36-47), implemented: 5 = NB, 4 = GP, 6 = Gamma,
+ * 7 = inverse Gaussian, 8 = Tweedie (loss_param = the variance power p; ignored otherwise).  The GP loss updates W and H
+ * with the KL weight 1/max(mu, 1e-4) (nmf/fit_cpu.hpp:568-574: "GP strategy: use KL weights for W/H updates") and
+ * evaluates the GP likelihood (math/loss.hpp:382-398) with theta_row (zeros for dispersion = "none": Poisson /
+ * KL-divergence NMF); 6-8 use the power-variance weight min(1/mu^p, 1e6) (:270-278) and the deviance terms (:439-505).
+ * theta pointers are read by NB only (pass NULL otherwise).  The plugin implements 4 and 6-8 for dispersion = "none". */
 RCPPML_GPU_API int rcppml_hip_solve_irls(rcppml_hip_ctx* ctx, int dtype, int loss_type, const int* col_ptr,
                                          const int* row_idx, const void* values, int64_t ncols, const void* F,
                                          const void* G_base, void* X, int k, double l1, double l2, int nonneg,
                                          int cd_maxit, int irls_max_iter, double irls_tol, const void* theta_row,
-                                         const void* theta_col);
+                                         const void* theta_col, double loss_param);
 RCPPML_GPU_API int rcppml_hip_irls_loss(rcppml_hip_ctx* ctx, int dtype, int loss_type, const int* col_ptr,
                                         const int* row_idx, const void* values, int64_t ncols, const void* W_T,
-                                        const void* d, const void* H, const void* theta_row, int k, double* out);
+                                        const void* d, const void* H, const void* theta_row, int k, double loss_param,
+                                        double* out);
 /* NB size (r) per ROW of A by the method of moments -- reference nmf/fit_cpu.hpp:1094-1265 (PER_ROW branch, sparse):
  * r_i = clamp(S mu^2 / (S (y-mu)^2 - S mu), r_min, r_max), else r_max.  Takes CSC(A^T); W_T k x m, H k x n. */
 RCPPML_GPU_API int rcppml_hip_nb_size_update(rcppml_hip_ctx* ctx, int dtype, const int* t_col_ptr,

@@ -56,12 +56,56 @@ template <class S> static inline S loss_contribution_gp(S observed, S predicted,
     loss += (s + th * y) / one_plus_theta;
     return static_cast<S>(loss);
 }
-// nnls_batch_irls.hpp:57-83 distribution_weight for the two implemented distributions: 5 = NB, 4 = GP (-> KL weight)
-template <class S> static inline S irls_weight(int loss_type, S predicted, S theta) {
-    return loss_type == 4 ? irls_weight_kl(predicted) : irls_weight_nb(predicted, theta);
+// math/loss.hpp:270-278  irls_weight_power: V(mu) = mu^p (Gamma p = 2, inverse Gaussian p = 3, Tweedie p free)
+template <class S> static inline S irls_weight_power(S predicted, S power) {
+    double mu = std::max(static_cast<double>(predicted), static_cast<double>(static_cast<S>(1e-15)));
+    double w = 1.0 / std::pow(mu, static_cast<double>(power));
+    w = std::min(w, 1e6);
+    return static_cast<S>(w);
 }
-template <class S> static inline S loss_contribution(int loss_type, S observed, S predicted, S theta) {
-    return loss_type == 4 ? loss_contribution_gp(observed, predicted, theta) : loss_contribution_nb(observed, predicted, theta);
+// math/loss.hpp:439-505  deviance contributions
+template <class S> static inline S loss_contribution_gamma(S observed, S predicted) {
+    double y = std::max(static_cast<double>(observed), 1e-10);
+    double mu = std::max(static_cast<double>(predicted), 1e-10);
+    return static_cast<S>(2.0 * (-std::log(y / mu) + (y - mu) / mu));
+}
+template <class S> static inline S loss_contribution_invgauss(S observed, S predicted) {
+    double y = std::max(static_cast<double>(observed), 1e-10);
+    double mu = std::max(static_cast<double>(predicted), 1e-10);
+    double diff = y - mu;
+    return static_cast<S>(diff * diff / (mu * mu * y));
+}
+template <class S> static inline S loss_contribution_tweedie(S observed, S predicted, S p) {
+    double y = std::max(static_cast<double>(observed), 1e-10);
+    double mu = std::max(static_cast<double>(predicted), 1e-10);
+    double pp = static_cast<double>(p);
+    if (std::abs(pp - 1.0) < 1e-6) return static_cast<S>(2.0 * (y * std::log(y / mu) - (y - mu)));
+    if (std::abs(pp - 2.0) < 1e-6) return static_cast<S>(2.0 * (-std::log(y / mu) + (y - mu) / mu));
+    double omp = 1.0 - pp, tmp = 2.0 - pp;
+    double term1 = std::pow(y, tmp) / (omp * tmp);
+    double term2 = y * std::pow(mu, omp) / omp;
+    double term3 = std::pow(mu, tmp) / tmp;
+    return static_cast<S>(2.0 * (term1 - term2 + term3));
+}
+// nnls_batch_irls.hpp:57-83 distribution_weight: 5 = NB, 4 = GP (-> KL weight), 6 = Gamma, 7 = inverse Gaussian,
+// 8 = Tweedie(power); math/loss.hpp:511-535 compute_loss
+template <class S> static inline S irls_weight(int loss_type, S predicted, S theta, S power = S(1.5)) {
+    switch (loss_type) {
+        case 4: return irls_weight_kl(predicted);
+        case 6: return irls_weight_power(predicted, S(2));
+        case 7: return irls_weight_power(predicted, S(3));
+        case 8: return irls_weight_power(predicted, power);
+        default: return irls_weight_nb(predicted, theta);
+    }
+}
+template <class S> static inline S loss_contribution(int loss_type, S observed, S predicted, S theta, S power = S(1.5)) {
+    switch (loss_type) {
+        case 4: return loss_contribution_gp(observed, predicted, theta);
+        case 6: return loss_contribution_gamma(observed, predicted);
+        case 7: return loss_contribution_invgauss(observed, predicted);
+        case 8: return loss_contribution_tweedie(observed, predicted, power);
+        default: return loss_contribution_nb(observed, predicted, theta);
+    }
 }
 
 // nmf/masked_nnls.hpp:96-154 (H side) / :177-242 (W side): same routine, data = A or A^T
@@ -151,7 +195,7 @@ template <class S>
 static void nnls_batch_irls_sparse_nb(const Csc<S>& A, const S* F, const S* G_base, S* X, int k,
                                       S L1, S L2, bool nonneg, int cd_maxit, int irls_max_iter,
                                       S irls_tol, int threads, const S* theta_row,
-                                      const S* theta_col, int loss_type = 5) {
+                                      const S* theta_col, int loss_type = 5, S power = S(1.5)) {
     const int nt = eff_threads(threads); (void)nt;
     std::fill(X, X + (size_t)k * A.cols, S(0));   // H.setZero(): no warm start across ALS iters
 #pragma omp parallel num_threads(nt)
@@ -169,7 +213,7 @@ static void nnls_batch_irls_sparse_nb(const Csc<S>& A, const S* F, const S* G_ba
                     S recon = 0;
                     for (int f = 0; f < k; ++f) recon += fr[f] * x[f];
                     const S th = theta_col ? theta_col[j] : (theta_row ? theta_row[row] : S(0));
-                    const S w = irls_weight(loss_type, recon, th);
+                    const S w = irls_weight(loss_type, recon, th, power);
                     const S dw = w - S(1);
                     const S wv = w * A.x[t];
                     // G_w += dw * f f^T  (reference: W_nnz_scaled * W_block^T)
@@ -255,7 +299,7 @@ static void nb_size_update(const Csc<S>& A, const S* W_T, const S* H, const S* d
 // nmf/explicit_loss.hpp:53-77   NB NLL over NONZEROS only (per-row theta)
 template <class S>
 static S explicit_loss_sparse_nb(const Csc<S>& A, const S* W_Td, const S* H, int k,
-                                 const S* theta_row, int threads, int loss_type = 5) {
+                                 const S* theta_row, int threads, int loss_type = 5, S power = S(1.5)) {
     const int nt = eff_threads(threads); (void)nt;
     S total = 0;
 #pragma omp parallel for reduction(+ : total) num_threads(nt) schedule(dynamic, 64)
@@ -265,7 +309,7 @@ static S explicit_loss_sparse_nb(const Csc<S>& A, const S* W_Td, const S* H, int
             const S* w = W_Td + (size_t)A.i[t] * k;
             S pred = 0;
             for (int f = 0; f < k; ++f) pred += w[f] * h[f];
-            total += loss_contribution(loss_type, A.x[t], pred, theta_row ? theta_row[A.i[t]] : S(0));
+            total += loss_contribution(loss_type, A.x[t], pred, theta_row ? theta_row[A.i[t]] : S(0), power);
         }
     }
     return total;
@@ -291,11 +335,12 @@ FitResult<S> nmf_fit(const Csc<S>& A, const FitConfig<S>& cfg, S* W_T, S* H, S* 
     if (cfg.has_mask) maskT_own = transpose_csc(cfg.mask);   // fit_cpu.hpp:276-280
     const bool is_nb = cfg.loss_type == 5;
     const bool is_gp = cfg.loss_type == 4;                    // dispersion NONE only: theta = 0 (fit_cpu.hpp:297-304)
-    const bool irls = is_nb || is_gp;
+    const bool is_pow = cfg.loss_type == 6 || cfg.loss_type == 7 || cfg.loss_type == 8;   // dispersion NONE: phi = 1, unused
+    const bool irls = is_nb || is_gp || is_pow;
     std::vector<S> nb_size;
     if (is_nb)                                                // fit_cpu.hpp:316-328 (PER_ROW/GLOBAL/NONE)
         nb_size.assign(m, cfg.dispersion_mode == 0 ? cfg.nb_size_max : cfg.nb_size_init);
-    if (is_gp) nb_size.assign(m, S(0));                       // theta_vec = Zero(m); the IRLS itself gets no theta
+    if (is_gp || is_pow) nb_size.assign(m, is_gp ? S(0) : S(1));   // theta_vec = Zero(m) / phi_vec = 1; the IRLS itself gets no theta
 
     std::vector<S> G((size_t)k * k), G_saved((size_t)k * k), G_wt((size_t)k * k);
     S prev_loss = std::numeric_limits<S>::max();
@@ -312,7 +357,7 @@ FitResult<S> nmf_fit(const Csc<S>& A, const FitConfig<S>& cfg, S* W_T, S* H, S* 
             // :565-606 gram recomputed (eps only); L1 inside CD, L2 on G_w
             nnls_batch_irls_sparse_nb(A, W_T, G.data(), H, k, cfg.L1_H, cfg.L2_H, cfg.nonneg_H,
                                       cfg.cd_maxit, cfg.irls_max_iter, cfg.irls_tol, cfg.threads,
-                                      is_nb ? nb_size.data() : (const S*)nullptr, (const S*)nullptr, cfg.loss_type);
+                                      is_nb ? nb_size.data() : (const S*)nullptr, (const S*)nullptr, cfg.loss_type, cfg.tweedie_power);
         } else {
             if (cfg.L2_H > 0) for (int i = 0; i < k; ++i) G[(size_t)i * k + i] += cfg.L2_H;   // :506
             if (cfg.solver_mode == 0)
@@ -335,7 +380,7 @@ FitResult<S> nmf_fit(const Csc<S>& A, const FitConfig<S>& cfg, S* W_T, S* H, S* 
             // :811-852: theta_per_col = nb_size (row of A == column of A^T)
             nnls_batch_irls_sparse_nb(At, H, G.data(), W_T, k, cfg.L1_W, cfg.L2_W, cfg.nonneg_W,
                                       cfg.cd_maxit, cfg.irls_max_iter, cfg.irls_tol, cfg.threads,
-                                      (const S*)nullptr, is_nb ? nb_size.data() : (const S*)nullptr, cfg.loss_type);
+                                      (const S*)nullptr, is_nb ? nb_size.data() : (const S*)nullptr, cfg.loss_type, cfg.tweedie_power);
         } else {
             if (cfg.L2_W > 0) for (int i = 0; i < k; ++i) G[(size_t)i * k + i] += cfg.L2_W;   // :738
             if (cfg.solver_mode == 0)
@@ -356,7 +401,7 @@ FitResult<S> nmf_fit(const Csc<S>& A, const FitConfig<S>& cfg, S* W_T, S* H, S* 
             std::vector<S> Wd((size_t)k * m);
             for (int i = 0; i < m; ++i) for (int f = 0; f < k; ++f) Wd[(size_t)i * k + f] = W_T[(size_t)i * k + f] * d[f];
             loss_val = cfg.has_mask ? masked_loss(A, Wd.data(), H, cfg.mask, k, threads)
-                                    : explicit_loss_sparse_nb(A, Wd.data(), H, k, nb_size.data(), cfg.threads > 0 ? cfg.threads : 1, cfg.loss_type);
+                                    : explicit_loss_sparse_nb(A, Wd.data(), H, k, nb_size.data(), cfg.threads > 0 ? cfg.threads : 1, cfg.loss_type, cfg.tweedie_power);
         } else {
             gram(W_T, k, m, G_wt.data());                                                   // :1734-1735
             const S cross = loss_cross_term_sparse_via_At(At, W_T, H, d, k, threads);        // :1740-1741
@@ -385,7 +430,7 @@ FitResult<S> nmf_fit(const Csc<S>& A, const FitConfig<S>& cfg, S* W_T, S* H, S* 
         res.iterations = iter + 1;
     }
     if (res.train_loss == 0 && !res.loss_history.empty()) res.train_loss = res.loss_history.back();
-    if (is_nb) res.theta = nb_size;
+    if (irls) res.theta = nb_size;      // NB sizes / GP theta (zeros) / phi (ones)
     if (cfg.sort_model) sort_by_d(W_T, H, d, k, m, n);                    // :1847
     return res;
 }
@@ -468,7 +513,7 @@ template <class S> static Csc<S> mk(int rows, int cols, const int* p, const int*
         int nonneg_W, int nonneg_H, int norm_type, int solver_mode, int loss_type, int irls_max_iter,     \
         S irls_tol, int dispersion_mode, S nb_size_init, S nb_size_max, S nb_size_min, int sort_model,    \
         int threads, const int* mask_p, const int* mask_i, const S* mask_x, int* out_iter,                \
-        int* out_converged, S* out_loss, S* out_tol, S* loss_hist, S* out_theta) {                        \
+        int* out_converged, S* out_loss, S* out_tol, S* loss_hist, S* out_theta, S tweedie_power) {       \
         FitConfig<S> c;                                                                                   \
         c.k = k; c.max_iter = max_iter; c.tol = tol; c.L1_H = L1_H; c.L1_W = L1_W; c.L2_H = L2_H;         \
         c.L2_W = L2_W; c.ub_H = ub_H; c.ub_W = ub_W; c.cd_maxit = cd_maxit; c.cd_tol = cd_tol;            \
@@ -476,7 +521,7 @@ template <class S> static Csc<S> mk(int rows, int cols, const int* p, const int*
         c.norm_type = norm_type; c.solver_mode = solver_mode; c.loss_type = loss_type;                    \
         c.irls_max_iter = irls_max_iter; c.irls_tol = irls_tol; c.dispersion_mode = dispersion_mode;      \
         c.nb_size_init = nb_size_init; c.nb_size_max = nb_size_max; c.nb_size_min = nb_size_min;          \
-        c.sort_model = sort_model != 0; c.threads = threads;                                              \
+        c.sort_model = sort_model != 0; c.threads = threads; c.tweedie_power = tweedie_power;             \
         if (mask_p) { c.has_mask = true; c.mask = mk(m, n, mask_p, mask_i, mask_x); }                     \
         FitResult<S> r = nmf_fit(mk(m, n, p, i, x), c, W_T, H, d);                                        \
         *out_iter = r.iterations; *out_converged = r.converged ? 1 : 0; *out_loss = r.train_loss;         \
@@ -495,6 +540,10 @@ ORACLE_API float oracle_irls_weight_nb_f32(float p, float r) { return irls_weigh
 ORACLE_API double oracle_loss_nb_f64(double y, double p, double r) { return loss_contribution_nb<double>(y, p, r); }
 ORACLE_API float oracle_loss_nb_f32(float y, float p, float r) { return loss_contribution_nb<float>(y, p, r); }
 
+ORACLE_API double oracle_irls_weight_power_f64(double p, double pw) { return irls_weight_power<double>(p, pw); }
+ORACLE_API float oracle_irls_weight_power_f32(float p, float pw) { return irls_weight_power<float>(p, pw); }
+ORACLE_API double oracle_loss_dev_f64(int loss_type, double y, double p, double pw) { return loss_contribution<double>(loss_type, y, p, 0.0, pw); }
+ORACLE_API float oracle_loss_dev_f32(int loss_type, float y, float p, float pw) { return loss_contribution<float>(loss_type, y, p, 0.f, pw); }
 ORACLE_API double oracle_irls_weight_kl_f64(double p) { return irls_weight_kl<double>(p); }
 ORACLE_API float oracle_irls_weight_kl_f32(float p) { return irls_weight_kl<float>(p); }
 ORACLE_API double oracle_loss_gp_f64(double y, double p, double th) { return loss_contribution_gp<double>(y, p, th); }
@@ -527,15 +576,15 @@ ORACLE_API float oracle_loss_gp_f32(float y, float p, float th) { return loss_co
     ORACLE_API void oracle_irls_##SUF(int loss_type, int rows, int cols, const int* p, const int* i, const S* x,  \
                                       const S* F, const S* G, S* X, int k, S L1, S L2, int nonneg, int cd_maxit,  \
                                       int irls_max_iter, S irls_tol, int threads, const S* theta_row,             \
-                                      const S* theta_col) {                                                       \
+                                      const S* theta_col, S power) {                                              \
         nnls_batch_irls_sparse_nb(mk(rows, cols, p, i, x), F, G, X, k, L1, L2, nonneg != 0, cd_maxit,             \
-                                  irls_max_iter, irls_tol, threads, theta_row, theta_col, loss_type);             \
+                                  irls_max_iter, irls_tol, threads, theta_row, theta_col, loss_type, power);      \
     }                                                                                                             \
     ORACLE_API S oracle_irls_loss_##SUF(int loss_type, int m, int n, const int* p, const int* i, const S* x,      \
-                                        const S* W_T, const S* d, const S* H, int k, const S* theta_row) {        \
+                                        const S* W_T, const S* d, const S* H, int k, const S* theta_row, S power) { \
         std::vector<S> Wd((size_t)k * m);                                                                         \
         for (int r = 0; r < m; ++r) for (int f = 0; f < k; ++f) Wd[(size_t)r * k + f] = W_T[(size_t)r * k + f] * d[f]; \
-        return explicit_loss_sparse_nb(mk(m, n, p, i, x), Wd.data(), H, k, theta_row, 1, loss_type);              \
+        return explicit_loss_sparse_nb(mk(m, n, p, i, x), Wd.data(), H, k, theta_row, 1, loss_type, power);       \
     }
 DEFINE_NB(f32, float)
 DEFINE_NB(f64, double)

@@ -388,6 +388,7 @@ template <class S> struct FitConfig {
     S irls_tol = S(1e-4);
     int dispersion_mode = 2;       // PER_ROW
     S nb_size_init = 10, nb_size_max = S(1e6), nb_size_min = S(0.01);
+    S tweedie_power = S(1.5);                 // LossConfig::power_param (math/loss.hpp:99-104), loss_type 8 only
     bool sort_model = true;
     int threads = 0;
     // explicit mask (nonzero = masked), 0 cols => absent  (core/config.hpp:411-413)

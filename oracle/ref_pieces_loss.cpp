@@ -25,6 +25,19 @@ __attribute__((visibility("default"))) double ref_loss_gp_f64(double observed, d
 __attribute__((visibility("default"))) float ref_loss_gp_f32(float observed, float predicted, float theta) {
     return FactorNet::loss_contribution_gp<float>(observed, predicted, theta);
 }
+__attribute__((visibility("default"))) double ref_irls_weight_power_f64(double predicted, double power) { return FactorNet::irls_weight_power<double>(predicted, power); }
+__attribute__((visibility("default"))) float ref_irls_weight_power_f32(float predicted, float power) { return FactorNet::irls_weight_power<float>(predicted, power); }
+// deviance terms: loss_type 6 = Gamma, 7 = inverse Gaussian, 8 = Tweedie(power)
+__attribute__((visibility("default"))) double ref_loss_dev_f64(int loss_type, double y, double mu, double power) {
+    return loss_type == 6 ? FactorNet::loss_contribution_gamma<double>(y, mu)
+         : loss_type == 7 ? FactorNet::loss_contribution_invgauss<double>(y, mu)
+                          : FactorNet::loss_contribution_tweedie<double>(y, mu, power);
+}
+__attribute__((visibility("default"))) float ref_loss_dev_f32(int loss_type, float y, float mu, float power) {
+    return loss_type == 6 ? FactorNet::loss_contribution_gamma<float>(y, mu)
+         : loss_type == 7 ? FactorNet::loss_contribution_invgauss<float>(y, mu)
+                          : FactorNet::loss_contribution_tweedie<float>(y, mu, power);
+}
 __attribute__((visibility("default"))) double ref_loss_mse_f64(double observed, double predicted) {
     return FactorNet::loss_contribution_mse<double>(observed, predicted);
 }

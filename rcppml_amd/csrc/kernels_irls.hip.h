@@ -52,8 +52,18 @@ template <class T> __device__ __forceinline__ T irls_weight_nb_dev(T predicted, 
 
 // distribution weight of the two implemented IRLS losses (nnls_batch_irls.hpp:57-83): 5 = NB; 4 = GP, whose W/H
 // updates use the KL weight 1 / max(mu, 1e-4) in Scalar arithmetic (fit_cpu.hpp:568-574, math/loss.hpp:176-179)
-template <class T> __device__ __forceinline__ T irls_weight_dev(int loss_type, T predicted, T theta) {
+// 6 / 7 / 8 = Gamma / inverse Gaussian / Tweedie: power-variance weight min(1/mu^p, 1e6) in fp64 (math/loss.hpp:270-278)
+template <class T> __device__ __forceinline__ T irls_weight_dev(int loss_type, T predicted, T theta, T power) {
     if (loss_type == 4) return T(1) / (predicted > T(1e-4) ? predicted : T(1e-4));
+    if (loss_type >= 6) {
+        double mu = static_cast<double>(predicted);
+        const double eps = static_cast<double>(static_cast<T>(1e-15));
+        mu = mu > eps ? mu : eps;
+        const double p = loss_type == 6 ? 2.0 : (loss_type == 7 ? 3.0 : static_cast<double>(power));
+        double w = 1.0 / pow(mu, p);
+        w = w < 1e6 ? w : 1e6;
+        return static_cast<T>(w);
+    }
     return irls_weight_nb_dev<T>(predicted, theta);
 }
 
@@ -62,7 +72,7 @@ __global__ __launch_bounds__(256) void irls_nb_solve_kernel(
     const int* __restrict__ colptr, const int* __restrict__ rowidx, const T* __restrict__ vals, int64_t ncols,
     const T* __restrict__ F, const T* __restrict__ Gbase, T* __restrict__ X, int k, T l1, T l2, int nonneg,
     int cd_maxit, int irls_max_iter, T irls_tol, const T* __restrict__ theta_row, const T* __restrict__ theta_col,
-    int loss_type) {
+    int loss_type, T power) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     T* Gl = reinterpret_cast<T*>(smem_raw) + (size_t)wave * KP * KP;    // [c][r]
@@ -89,7 +99,7 @@ __global__ __launch_bounds__(256) void irls_nb_solve_kernel(
             const T fr = fok ? F[(int64_t)row * k + lane] : T(0);
             const T recon = wave_sum(fr * x);                                   // W_T.col(row).dot(x)
             const T th = theta_col ? th_col : (theta_row ? theta_row[row] : T(0));
-            const T w = irls_weight_dev<T>(loss_type, recon, th);
+            const T w = irls_weight_dev<T>(loss_type, recon, th, power);
             const T dw = w - T(1);
             const T wv = w * a;
             const T frd = fr * dw;                                              // W_nnz_scaled.col = W_block.col * dw
@@ -163,7 +173,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     const int* __restrict__ colptr, const int* __restrict__ rowidx, const float* __restrict__ vals, int64_t ncols,
     const float* __restrict__ F, const float* __restrict__ Gbase, float* __restrict__ X, int k, float l1, float l2,
     int nonneg, int cd_maxit, int irls_max_iter, float irls_tol, const float* __restrict__ theta_row,
-    const float* __restrict__ theta_col, int loss_type) {
+    const float* __restrict__ theta_col, int loss_type, float power) {
     constexpr int KP = 32, CH = 32, FS = 36;          // FS: padded row stride of the staged F rows (bank spread)
     constexpr int WAVE_FLOATS = CH * FS + 2 * CH + KP;  // staged rows | (w-1, w a) pairs | x
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -212,7 +222,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
             }
             const float recon = part + __shfl_xor(part, 32, 64);                 // W_T.col(row).dot(x)
             const float th = theta_col ? th_col : (theta_row ? theta_row[row] : 0.f);
-            const float w = irls_weight_dev<float>(loss_type, recon, th);
+            const float w = irls_weight_dev<float>(loss_type, recon, th, power);
 #pragma unroll
             for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(Fst + r * FS + 16 * hh + 4 * q) = fv4[q];
             if (hh == 0) sc[r] = make_float2(ok ? w - 1.f : 0.f, ok ? w * a : 0.f);
@@ -291,7 +301,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     const int* __restrict__ colptr, const int* __restrict__ rowidx, const double* __restrict__ vals, int64_t ncols,
     const double* __restrict__ F, const double* __restrict__ Gbase, double* __restrict__ X, int k, double l1, double l2,
     int nonneg, int cd_maxit, int irls_max_iter, double irls_tol, const double* __restrict__ theta_row,
-    const double* __restrict__ theta_col, int loss_type) {
+    const double* __restrict__ theta_col, int loss_type, double power) {
     constexpr int KP = 32, CH = 32, FS = 34;          // FS: padded row stride (doubles) of the staged F rows
     constexpr int WAVE_DOUBLES = CH * FS + 2 * CH + KP;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -342,7 +352,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
             }
             const double recon = part + __shfl_xor(part, 32, 64);
             const double th = theta_col ? th_col : (theta_row ? theta_row[row] : 0.0);
-            const double w = irls_weight_dev<double>(loss_type, recon, th);
+            const double w = irls_weight_dev<double>(loss_type, recon, th, power);
 #pragma unroll
             for (int q = 0; q < 8; ++q) *reinterpret_cast<double2*>(Fst + r * FS + 16 * hh + 2 * q) = fv2[q];
             if (hh == 0) sc[r] = make_double2(ok ? w - 1.0 : 0.0, ok ? w * a : 0.0);
@@ -496,7 +506,7 @@ template <class T>
 __global__ __launch_bounds__(256) void nb_loss_lane_kernel(
     const int* __restrict__ colptr, const int* __restrict__ rowidx, const T* __restrict__ vals, int64_t ncols,
     const T* __restrict__ W_T, const T* __restrict__ d, const T* __restrict__ H, const T* __restrict__ theta_row, int k,
-    int vec_ok, int loss_type, double* __restrict__ partial) {
+    int vec_ok, int loss_type, double power, double* __restrict__ partial) {
     constexpr int VEC = 16 / sizeof(T);
     typedef typename VecT<T, VEC>::type V;
     __shared__ double sh[4];
@@ -537,6 +547,20 @@ __global__ __launch_bounds__(256) void nb_loss_lane_kernel(
                     nll -= (y - 1.0) * log(inner);
                 }
                 nll += (mu + th * y) / opt;
+            } else if (loss_type >= 6) {           // math/loss.hpp:439-505  Gamma / inverse Gaussian / Tweedie deviance terms
+                const double yy = y > 1e-10 ? y : 1e-10;
+                const double pp = loss_type == 6 ? 2.0 : (loss_type == 7 ? 3.0 : power);
+                if (loss_type == 7) {
+                    const double df = yy - mu;
+                    nll = df * df / (mu * mu * yy);
+                } else if (fabs(pp - 1.0) < 1e-6) {
+                    nll = 2.0 * (yy * log(yy / mu) - (yy - mu));
+                } else if (fabs(pp - 2.0) < 1e-6) {
+                    nll = 2.0 * (-log(yy / mu) + (yy - mu) / mu);
+                } else {
+                    const double omp = 1.0 - pp, tmp = 2.0 - pp;
+                    nll = 2.0 * (pow(yy, tmp) / (omp * tmp) - yy * pow(mu, omp) / omp + pow(mu, tmp) / tmp);
+                }
             } else {                               // math/loss.hpp:415-426  loss_contribution_nb
                 const double r = th > 1e-10 ? th : 1e-10;
                 nll = -lgamma(y + r) + lgamma(r) - r * log(r / (r + mu)) - y * log(mu / (r + mu));

@@ -72,7 +72,8 @@ struct FitParams {
     const int* mask_p; const int* mask_i;   // NULL = no mask
     int sort_model;
     double* loss_history;                    // may be NULL
-    int loss_type = 0;                       // 0 = MSE, 4 = GP (dispersion none), 5 = NB
+    int loss_type = 0;                       // 0 = MSE, 4 = GP, 5 = NB, 6 = Gamma, 7 = inverse Gaussian, 8 = Tweedie
+    double tweedie_power = 1.5;
     int irls_max_iter = 5; double irls_tol = 1e-4;
     int dispersion_mode = 2;                 // 0 none, 1 global, 2 per-row
     double nb_size_init = 10, nb_size_max = 1e6, nb_size_min = 0.01;
@@ -173,11 +174,12 @@ void fit(FitParams& P) {
     DevBuf dswH((size_t)n * sizeof(int)), dswW((size_t)m * sizeof(int)), dordH((size_t)n * sizeof(int)), dordW((size_t)m * sizeof(int));
     const bool use_order = P.solver_mode == 0 && !has_mask && P.loss_type == 0 && P.cd_tol > 0 && !getenv("RCPPML_GPU_NO_ORDER");
 
-    const bool is_gp = P.loss_type == 4;                                // theta_vec = Zero(m) (fit_cpu.hpp:297-304)
-    const bool is_nb = P.loss_type == 5 || is_gp;                       // "is_irls": both run the IRLS half-updates
+    const bool is_pow = P.loss_type >= 6;                               // phi_vec = 1 for dispersion none (fit_cpu.hpp:336-347)
+    const bool is_gp = P.loss_type == 4 || is_pow;                      // theta_vec = Zero(m) (:297-304); "no theta in the solve"
+    const bool is_nb = P.loss_type == 5 || is_gp;                       // "is_irls": all of them run the IRLS half-updates
     DevBuf dtheta;
     if (is_nb) {                                                        // fit_cpu.hpp:316-328
-        std::vector<T> th((size_t)m, is_gp ? T(0) : static_cast<T>(P.dispersion_mode == 0 ? P.nb_size_max : P.nb_size_init));
+        std::vector<T> th((size_t)m, is_pow ? T(1) : is_gp ? T(0) : static_cast<T>(P.dispersion_mode == 0 ? P.nb_size_max : P.nb_size_init));
         dtheta.alloc((size_t)m * sizeof(T));
         HIPCHK(hipMemcpyAsync(dtheta.p, th.data(), (size_t)m * sizeof(T), hipMemcpyHostToDevice, s));
         HIPCHK(hipStreamSynchronize(s));
@@ -198,7 +200,7 @@ void fit(FitParams& P) {
             OPCHK(rcppml_hip_gram(c, dt, dW.p, k, m, eps, 0.0, dG.p));
             OPCHK(rcppml_hip_solve_irls(c, dt, P.loss_type, dAp.as<int>(), dAi.as<int>(), dAx.p, n, dW.p, dG.p, dH.p, k, P.L1_H,
                                         P.L2_H, P.nonneg_H, P.cd_maxit, P.irls_max_iter, P.irls_tol,
-                                        is_gp ? nullptr : dtheta.p, nullptr));
+                                        is_gp ? nullptr : dtheta.p, nullptr, P.tweedie_power));
             if (P.ub_H > 0) throw std::runtime_error("upper bound with NB loss: not supported");
         } else if (has_mask) {
             OPCHK(rcppml_hip_gram(c, dt, dW.p, k, m, eps, 0.0, dG.p));                 // :562 unmodified G
@@ -227,7 +229,7 @@ void fit(FitParams& P) {
             OPCHK(rcppml_hip_gram(c, dt, dH.p, k, n, eps, 0.0, dG.p));
             OPCHK(rcppml_hip_solve_irls(c, dt, P.loss_type, dTp.as<int>(), dTi.as<int>(), dTx.p, m, dH.p, dG.p, dW.p, k, P.L1_W,
                                         P.L2_W, P.nonneg_W, P.cd_maxit, P.irls_max_iter, P.irls_tol, nullptr,
-                                        is_gp ? nullptr : dtheta.p));
+                                        is_gp ? nullptr : dtheta.p, P.tweedie_power));
         } else if (has_mask) {
             OPCHK(rcppml_hip_gram(c, dt, dH.p, k, n, eps, 0.0, dG.p));
             OPCHK(rcppml_hip_solve_masked(c, dt, dTp.as<int>(), dTi.as<int>(), dTx.p, dMTp.as<int>(), dMTi.as<int>(),
@@ -267,7 +269,7 @@ void fit(FitParams& P) {
             }
         }
         if (is_nb) {
-            OPCHK(rcppml_hip_irls_loss(c, dt, P.loss_type, dAp.as<int>(), dAi.as<int>(), dAx.p, n, dW.p, dd.p, dH.p, dtheta.p, k, dloss.as<double>()));
+            OPCHK(rcppml_hip_irls_loss(c, dt, P.loss_type, dAp.as<int>(), dAi.as<int>(), dAx.p, n, dW.p, dd.p, dH.p, dtheta.p, k, P.tweedie_power, dloss.as<double>()));
         } else if (has_mask) {
             OPCHK(rcppml_hip_loss_nonzeros(c, dt, dAp.as<int>(), dAi.as<int>(), dAx.p, dMp.as<int>(), dMi.as<int>(), n,
                                            dW.p, dd.p, dH.p, k, dloss.as<double>()));
@@ -371,16 +373,18 @@ void nmf_entry(RCPPML_NMF_UNIFIED_ARGS, const int* mask_p, const int* mask_i, do
         (void)graph_W_p; (void)graph_W_i; (void)graph_W_x; (void)graph_W_dim; (void)graph_W_lambda;
         (void)graph_H_p; (void)graph_H_i; (void)graph_H_x; (void)graph_H_dim; (void)graph_H_lambda;
         (void)gp_theta_init; (void)gp_theta_max; (void)gp_theta_min; (void)gamma_phi_init; (void)gamma_phi_max;
-        (void)gamma_phi_min; (void)tweedie_power; (void)guide_H_labels_flat; (void)guide_H_ns;
+        (void)gamma_phi_min; (void)guide_H_labels_flat; (void)guide_H_ns;
         (void)guide_H_lambdas; (void)guide_H_ncs;
         // Reject what is not implemented so the caller falls back to CPU (SURVEY.md 8b "Semantics")
-        if (*loss_type != 0 && *loss_type != 5 && *loss_type != 4)
-            throw std::runtime_error("loss_type must be MSE (0), GP (4, dispersion none) or NB (5) for this plugin build");
-        if (*loss_type == 4) {      // Poisson / KL NMF: GP likelihood with theta = 0, KL-weighted half-updates
-            if (*gp_dispersion_mode != 0) throw std::runtime_error("GP loss: only dispersion='none' is supported");
-            if (*k > 64) throw std::runtime_error("GP loss: k must be <= 64");
-            if (*solver_mode != 0) throw std::runtime_error("GP loss requires the CD solver");
-            if (mask_p) throw std::runtime_error("GP loss with explicit mask: not supported");
+        if (*loss_type != 0 && (*loss_type < 4 || *loss_type > 8))
+            throw std::runtime_error("loss_type must be MSE (0), GP (4), NB (5), Gamma (6), inverse Gaussian (7) or Tweedie (8) for this plugin build");
+        if (*loss_type == 4 || *loss_type >= 6) {
+            // GP with theta = 0 (Poisson / KL NMF) and the power-variance family with phi = 1: IRLS half-updates with
+            // parameter-free weights; the dispersion estimators (theta MM update, phi) are not implemented
+            if (*gp_dispersion_mode != 0) throw std::runtime_error("GP / Gamma / inverse-Gaussian / Tweedie loss: only dispersion='none' is supported");
+            if (*k > 64) throw std::runtime_error("IRLS losses: k must be <= 64");
+            if (*solver_mode != 0) throw std::runtime_error("IRLS losses require the CD solver");
+            if (mask_p) throw std::runtime_error("IRLS losses with explicit mask: not supported");
         }
         if (*loss_type == 5) {
             if (*k > 64) throw std::runtime_error("NB loss: k must be <= 64");
@@ -413,7 +417,7 @@ void nmf_entry(RCPPML_NMF_UNIFIED_ARGS, const int* mask_p, const int* mask_i, do
         P.sort_model = sort_model; P.loss_history = loss_history;
         P.loss_type = *loss_type; P.irls_max_iter = *irls_max_iter; P.irls_tol = *irls_tol;
         P.dispersion_mode = *gp_dispersion_mode; P.nb_size_init = *nb_size_init; P.nb_size_max = *nb_size_max;
-        P.nb_size_min = *nb_size_min; P.out_theta = out_theta;
+        P.nb_size_min = *nb_size_min; P.out_theta = out_theta; P.tweedie_power = *tweedie_power;
         if (precision == RCPPML_F64) fit<double>(P); else fit<float>(P);
         *out_iter = P.out_iter; *out_converged = P.out_converged; *out_loss = P.out_loss; *out_tol = P.out_tol;
         *out_theta_len = P.out_theta_len;

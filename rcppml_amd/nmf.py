@@ -70,7 +70,7 @@ def nmf(data, k, tol=1e-4, maxit=100, L1=(0.0, 0.0), L2=(0.0, 0.0), seed=None, m
         nonneg=(True, True), test_fraction=0, verbose=False, projective=False, symmetric=False, zi="none",
         robust=False, *, solver="auto", upper_bound=(0.0, 0.0), cd_maxit=100, cd_tol=1e-8, norm="L1", sort_model=True,
         patience=5, h_init=None, precision="fp32", resource="gpu", dispersion="per_row", irls_max_iter=5, irls_tol=1e-4,
-        nb_size_init=10.0, nb_size_max=1e6, nb_size_min=0.01):
+        nb_size_init=10.0, nb_size_max=1e6, nb_size_min=0.01, tweedie_power=1.5):
     """Non-negative matrix factorisation A ~ w diag(d) h by alternating NNLS on the MI355X.
 
     `L1`, `L2`, `upper_bound`, `nonneg` are c(w, h) pairs (src/RcppFunctions_nmf.cpp:59-62).
@@ -80,11 +80,11 @@ def nmf(data, k, tol=1e-4, maxit=100, L1=(0.0, 0.0), L2=(0.0, 0.0), seed=None, m
     """
     if loss not in _LOSSES:
         raise ValueError("'arg' should be one of %s" % ", ".join(repr(x) for x in _LOSSES))
-    if loss not in ("mse", "nb", "gp") or robust or zi != "none":
-        raise NotImplementedError("only loss='mse', loss='nb' and loss='gp' with dispersion='none' (no robust / zero-inflation) "
-                                  "are implemented by the MI355X backend")
-    if loss == "gp" and dispersion != "none":
-        raise NotImplementedError("loss='gp' is implemented for dispersion='none' (Poisson / KL-divergence NMF) only")
+    if robust or zi != "none":
+        raise NotImplementedError("robust / zero-inflated losses are not implemented by the MI355X backend")
+    if loss in ("gp", "gamma", "inverse_gaussian", "tweedie") and dispersion != "none":
+        raise NotImplementedError("loss='%s' is implemented for dispersion='none' only (no dispersion estimation on the "
+                                  "MI355X backend)" % loss)
     if dispersion not in ("none", "global", "per_row"):
         raise NotImplementedError("dispersion must be 'none', 'global' or 'per_row' on the MI355X backend")
     if projective or symmetric:
@@ -147,7 +147,8 @@ def nmf(data, k, tol=1e-4, maxit=100, L1=(0.0, 0.0), L2=(0.0, 0.0), seed=None, m
                            L1_W=L1w, L2_H=L2h, L2_W=L2w, ub_H=ubh, ub_W=ubw, cd_maxit=int(cd_maxit), verbose=int(verbose),
                            seed=seed_int & 0x7FFFFFFF, patience=int(patience), nonneg_W=int(nnw), nonneg_H=int(nnh),
                            norm_type=norm_type, solver_mode=0 if solver == "cd" else 1, mask=mask_arg, cd_tol=float(cd_tol),
-                           loss_type={"mse": 0, "gp": 4, "nb": 5}[loss], irls_max_iter=int(irls_max_iter), irls_tol=float(irls_tol),
+                           loss_type={"mse": 0, "gp": 4, "nb": 5, "gamma": 6, "inverse_gaussian": 7, "tweedie": 8}[loss],
+                           tweedie_power=float(tweedie_power), irls_max_iter=int(irls_max_iter), irls_tol=float(irls_tol),
                            gp_dispersion_mode={"none": 0, "global": 1, "per_row": 2}[dispersion],
                            nb_size=(nb_size_init, nb_size_max, nb_size_min),
                            sort_model=int(sort_model), precision=_abi.F32 if precision == "fp32" else _abi.F64,
@@ -157,7 +158,7 @@ def nmf(data, k, tol=1e-4, maxit=100, L1=(0.0, 0.0), L2=(0.0, 0.0), seed=None, m
     misc = dict(tol=res["tol"], iter=res["iter"], loss=res["loss"], loss_history=res.get("loss_history"),
                 converged=res["converged"], solver=solver, solver_mode=0 if solver == "cd" else 1, L1=(L1w, L1h),
                 L2=(L2w, L2h), seed=seed_int, precision=precision, resource="gpu", loss_type=loss)
-    if loss in ("nb", "gp"):
+    if loss != "mse":
         misc["theta"] = res["theta"]                                   # R: misc$theta (RcppFunctions_nmf.cpp:156-158)
     return NMFModel(w=W_T.copy(), d=res["d"], h=H.T.copy(), misc=misc)
 

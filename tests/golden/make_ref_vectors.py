@@ -18,7 +18,9 @@ rng.ref_hash.restype = C.c_uint64
 for f, t in ((loss.ref_irls_weight_nb_f64, C.c_double), (loss.ref_loss_nb_f64, C.c_double),
              (loss.ref_irls_weight_nb_f32, C.c_float), (loss.ref_loss_nb_f32, C.c_float),
              (loss.ref_irls_weight_kl_f64, C.c_double), (loss.ref_irls_weight_kl_f32, C.c_float),
-             (loss.ref_loss_gp_f64, C.c_double), (loss.ref_loss_gp_f32, C.c_float)):
+             (loss.ref_loss_gp_f64, C.c_double), (loss.ref_loss_gp_f32, C.c_float),
+             (loss.ref_irls_weight_power_f64, C.c_double), (loss.ref_irls_weight_power_f32, C.c_float),
+             (loss.ref_loss_dev_f64, C.c_double), (loss.ref_loss_dev_f32, C.c_float)):
     f.restype = t
 
 out = {}
@@ -72,5 +74,18 @@ Yg, Pg, Tg = np.meshgrid(obs, pred, theta, indexing="ij")
 out["gp_obs"], out["gp_pred"], out["gp_theta"] = Yg.ravel(), Pg.ravel(), Tg.ravel()
 out["gp_loss_f64"] = np.array([loss.ref_loss_gp_f64(C.c_double(y), C.c_double(a), C.c_double(b)) for y, a, b in zip(Yg.ravel(), Pg.ravel(), Tg.ravel())])
 out["gp_loss_f32"] = np.array([loss.ref_loss_gp_f32(C.c_float(y), C.c_float(a), C.c_float(b)) for y, a, b in zip(Yg.ravel(), Pg.ravel(), Tg.ravel())], dtype=np.float32)
+# power-variance family: weight 1/mu^p and the Gamma / inverse-Gaussian / Tweedie deviance terms
+powers = np.array([1.0, 1.5, 2.0, 2.5, 3.0])
+Pp, Pw = np.meshgrid(pred, powers, indexing="ij")
+out["pow_pred"], out["pow_power"] = Pp.ravel(), Pw.ravel()
+out["pow_weight_f64"] = np.array([loss.ref_irls_weight_power_f64(C.c_double(a), C.c_double(b)) for a, b in zip(Pp.ravel(), Pw.ravel())])
+out["pow_weight_f32"] = np.array([loss.ref_irls_weight_power_f32(C.c_float(a), C.c_float(b)) for a, b in zip(Pp.ravel(), Pw.ravel())], dtype=np.float32)
+yv = np.array([0.0, 0.3, 1.0, 2.5, 40.0])
+LT, Yd, Pd, Wd = np.meshgrid(np.array([6, 7, 8]), yv, pred, np.array([1.0, 1.5, 2.0, 2.7]), indexing="ij")
+out["dev_type"], out["dev_obs"], out["dev_pred"], out["dev_power"] = LT.ravel(), Yd.ravel(), Pd.ravel(), Wd.ravel()
+out["dev_f64"] = np.array([loss.ref_loss_dev_f64(C.c_int(int(t)), C.c_double(y), C.c_double(a), C.c_double(b))
+                           for t, y, a, b in zip(LT.ravel(), Yd.ravel(), Pd.ravel(), Wd.ravel())])
+out["dev_f32"] = np.array([loss.ref_loss_dev_f32(C.c_int(int(t)), C.c_float(y), C.c_float(a), C.c_float(b))
+                           for t, y, a, b in zip(LT.ravel(), Yd.ravel(), Pd.ravel(), Wd.ravel())], dtype=np.float32)
 np.savez_compressed(os.path.join(here, "ref_vectors.npz"), **out)
 print("wrote ref_vectors.npz:", {k2: v.shape for k2, v in out.items()})
