@@ -221,6 +221,15 @@ RCPPML_GPU_API int rcppml_hip_loss_nonzeros(rcppml_hip_ctx* ctx, int dtype, cons
                                             const void* W_T, const void* d, const void* H, int k,
                                             double* out);
 
+/* k x k feature layer, fused-path placement of nmf/fit_cpu.hpp:505-511,636-639 / :738-745,884-887:
+ * rcppml_hip_apply_l21: G(i,i) += lambda / ||X.row(i)||_2 for rows with norm > 1e-10 (features/L21.hpp:38-51); X is the
+ *   CURRENT factor (k x ncols), applied to the Gram before the solve.
+ * rcppml_hip_angular_posthoc: X <- max(0, X - lambda * diag(norms) * offdiag(Xh Xh^T) Xh), Xh = rows of X scaled to unit
+ *   norm (features/angular.hpp:67-103); applied after the solve and the upper bound, before scaling.  k <= 64. */
+RCPPML_GPU_API int rcppml_hip_apply_l21(rcppml_hip_ctx* ctx, int dtype, void* G, const void* X, int k, int64_t ncols,
+                                        double lambda);
+RCPPML_GPU_API int rcppml_hip_angular_posthoc(rcppml_hip_ctx* ctx, int dtype, void* X, int k, int64_t ncols, double lambda);
+
 /* NB (negative-binomial) IRLS half-update -- reference primitives/cpu/nnls_batch_irls.hpp:465-520,202-329 with the NB
  * weight of math/loss.hpp:248-256: X = 0; per column up to irls_max_iter passes of
  *   w_i = min(r/(mu(r+mu)), 1e6) at the column's nonzeros (mu = F(:,i).x, in fp64), G_w = G_base + F_nz diag(w-1) F_nz^T

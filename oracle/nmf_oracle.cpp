@@ -360,6 +360,7 @@ FitResult<S> nmf_fit(const Csc<S>& A, const FitConfig<S>& cfg, S* W_T, S* H, S* 
                                       is_nb ? nb_size.data() : (const S*)nullptr, (const S*)nullptr, cfg.loss_type, cfg.tweedie_power);
         } else {
             if (cfg.L2_H > 0) for (int i = 0; i < k; ++i) G[(size_t)i * k + i] += cfg.L2_H;   // :506
+            apply_L21(G.data(), H, k, (int64_t)n, cfg.L21_H);                                  // :509-510 (current H)
             if (cfg.solver_mode == 0)
                 fused_rhs_nnls_sparse(A, W_T, G.data(), H, k, cfg.cd_maxit, cfg.cd_tol, cfg.L1_H,
                                       cfg.nonneg_H, threads, iter > 0, S(0));                // :516-524
@@ -367,6 +368,7 @@ FitResult<S> nmf_fit(const Csc<S>& A, const FitConfig<S>& cfg, S* W_T, S* H, S* 
                 fused_rhs_cholesky_sparse(A, W_T, G.data(), H, k, cfg.L1_H, cfg.nonneg_H, threads, S(0));
         }
         if (cfg.ub_H > 0) apply_upper_bound(H, (size_t)k * n, cfg.ub_H);  // :636-637
+        apply_angular_posthoc(H, k, (int64_t)n, cfg.angular_H);              // :638-639
         extract_scaling(H, k, n, d, cfg.norm_type);                       // :645
 
         // ------------------------------------------------ W half-update
@@ -383,6 +385,7 @@ FitResult<S> nmf_fit(const Csc<S>& A, const FitConfig<S>& cfg, S* W_T, S* H, S* 
                                       (const S*)nullptr, is_nb ? nb_size.data() : (const S*)nullptr, cfg.loss_type, cfg.tweedie_power);
         } else {
             if (cfg.L2_W > 0) for (int i = 0; i < k; ++i) G[(size_t)i * k + i] += cfg.L2_W;   // :738
+            apply_L21(G.data(), W_T, k, (int64_t)m, cfg.L21_W);                                // :741-745 (current W_T)
             if (cfg.solver_mode == 0)
                 fused_rhs_nnls_sparse(At, H, G.data(), W_T, k, cfg.cd_maxit, cfg.cd_tol, cfg.L1_W,
                                       cfg.nonneg_W, threads, iter > 0, S(0));                // :748-757
@@ -390,6 +393,7 @@ FitResult<S> nmf_fit(const Csc<S>& A, const FitConfig<S>& cfg, S* W_T, S* H, S* 
                 fused_rhs_cholesky_sparse(At, H, G.data(), W_T, k, cfg.L1_W, cfg.nonneg_W, threads, S(0));
         }
         if (cfg.ub_W > 0) apply_upper_bound(W_T, (size_t)k * m, cfg.ub_W);  // :884-885
+        apply_angular_posthoc(W_T, k, (int64_t)m, cfg.angular_W);              // :886-887
         extract_scaling(W_T, k, m, d, cfg.norm_type);                       // :893
 
         // ------------------------------------------------ NB dispersion (:1094-1265)
@@ -513,7 +517,8 @@ template <class S> static Csc<S> mk(int rows, int cols, const int* p, const int*
         int nonneg_W, int nonneg_H, int norm_type, int solver_mode, int loss_type, int irls_max_iter,     \
         S irls_tol, int dispersion_mode, S nb_size_init, S nb_size_max, S nb_size_min, int sort_model,    \
         int threads, const int* mask_p, const int* mask_i, const S* mask_x, int* out_iter,                \
-        int* out_converged, S* out_loss, S* out_tol, S* loss_hist, S* out_theta, S tweedie_power) {       \
+        int* out_converged, S* out_loss, S* out_tol, S* loss_hist, S* out_theta, S tweedie_power,         \
+        S L21_H, S L21_W, S angular_H, S angular_W) {                                                     \
         FitConfig<S> c;                                                                                   \
         c.k = k; c.max_iter = max_iter; c.tol = tol; c.L1_H = L1_H; c.L1_W = L1_W; c.L2_H = L2_H;         \
         c.L2_W = L2_W; c.ub_H = ub_H; c.ub_W = ub_W; c.cd_maxit = cd_maxit; c.cd_tol = cd_tol;            \
@@ -522,6 +527,7 @@ template <class S> static Csc<S> mk(int rows, int cols, const int* p, const int*
         c.irls_max_iter = irls_max_iter; c.irls_tol = irls_tol; c.dispersion_mode = dispersion_mode;      \
         c.nb_size_init = nb_size_init; c.nb_size_max = nb_size_max; c.nb_size_min = nb_size_min;          \
         c.sort_model = sort_model != 0; c.threads = threads; c.tweedie_power = tweedie_power;             \
+        c.L21_H = L21_H; c.L21_W = L21_W; c.angular_H = angular_H; c.angular_W = angular_W;               \
         if (mask_p) { c.has_mask = true; c.mask = mk(m, n, mask_p, mask_i, mask_x); }                     \
         FitResult<S> r = nmf_fit(mk(m, n, p, i, x), c, W_T, H, d);                                        \
         *out_iter = r.iterations; *out_converged = r.converged ? 1 : 0; *out_loss = r.train_loss;         \

@@ -323,6 +323,50 @@ void cholesky_clip_batch(const S* G, const S* B, S* X, int k, int n, bool nonneg
     }
 }
 
+// features/L21.hpp:38-51   apply_L21: G(i,i) += lambda / ||factor.row(i)||_2 for rows with norm > 1e-10.
+// X: k x len column-major (X[f + j*k]).
+template <class S> void apply_L21(S* G, const S* X, int k, int64_t len, S lambda) {
+    if (lambda <= 0) return;
+    for (int i = 0; i < k; ++i) {
+        S ss = 0;
+        for (int64_t j = 0; j < len; ++j) ss += X[i + j * k] * X[i + j * k];
+        const S row_norm = std::sqrt(ss);
+        if (row_norm > static_cast<S>(1e-10)) G[(size_t)i * k + i] += lambda / row_norm;
+    }
+}
+
+// features/angular.hpp:67-103   apply_angular_posthoc: Factor -= lambda * diag(norms) * (offdiag(F_hat F_hat^T) F_hat),
+// F_hat = rows scaled to unit norm (rows with norm <= 1e-15 stay as they are), then clamp at 0.
+template <class S> void apply_angular_posthoc(S* X, int k, int64_t len, S lambda) {
+    if (lambda <= 0) return;
+    std::vector<S> norms(k), Fh((size_t)k * len), cosm((size_t)k * k, S(0));
+    for (int i = 0; i < k; ++i) {
+        S ss = 0;
+        for (int64_t j = 0; j < len; ++j) ss += X[i + j * k] * X[i + j * k];
+        norms[i] = std::sqrt(ss);
+    }
+    for (int64_t j = 0; j < len; ++j)
+        for (int i = 0; i < k; ++i) Fh[i + j * k] = norms[i] > S(1e-15) ? X[i + j * k] / norms[i] : X[i + j * k];
+    for (int64_t j = 0; j < len; ++j)                      // rankUpdate: lower triangle, then mirrored
+        for (int a = 0; a < k; ++a)
+            for (int b = 0; b <= a; ++b) cosm[(size_t)b * k + a] += Fh[a + j * k] * Fh[b + j * k];
+    for (int a = 0; a < k; ++a)
+        for (int b = 0; b < a; ++b) cosm[(size_t)a * k + b] = cosm[(size_t)b * k + a];
+    for (int a = 0; a < k; ++a) cosm[(size_t)a * k + a] = 0;
+    std::vector<S> g(k);
+    for (int64_t j = 0; j < len; ++j) {
+        for (int a = 0; a < k; ++a) {
+            S acc = 0;
+            for (int b = 0; b < k; ++b) acc += cosm[(size_t)b * k + a] * Fh[b + j * k];
+            g[a] = acc * norms[a];
+        }
+        for (int a = 0; a < k; ++a) {
+            const S v = X[a + j * k] - lambda * g[a];
+            X[a + j * k] = v > S(0) ? v : S(0);
+        }
+    }
+}
+
 // features/bounds.hpp:38-42   apply_upper_bound
 template <class S> void apply_upper_bound(S* X, size_t len, S ub) {
     for (size_t t = 0; t < len; ++t) X[t] = std::min(X[t], ub);
@@ -377,6 +421,7 @@ template <class S> struct FitConfig {
     int max_iter = 100;            // config.hpp max_iter
     S tol = S(1e-4);
     S L1_H = 0, L1_W = 0, L2_H = 0, L2_W = 0, ub_H = 0, ub_W = 0;
+    S L21_H = 0, L21_W = 0, angular_H = 0, angular_W = 0;   // features/L21.hpp, features/angular.hpp (post-hoc form)
     int cd_maxit = 100;
     S cd_tol = S(1e-8);
     int patience = 5;

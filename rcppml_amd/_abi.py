@@ -22,7 +22,7 @@ EXPORTED_SYMBOLS = [
     "rcppml_hip_ctx_create", "rcppml_hip_ctx_destroy", "rcppml_hip_ctx_sync", "rcppml_hip_ctx_stats", "rcppml_hip_transpose_csc", "rcppml_hip_cast", "rcppml_hip_gram", "rcppml_hip_rhs",
     "rcppml_hip_solve_cd", "rcppml_hip_order_columns", "rcppml_hip_solve_chol", "rcppml_hip_row_norms", "rcppml_hip_apply_scaling",
     "rcppml_hip_sumsq", "rcppml_hip_loss_mse", "rcppml_hip_solve_masked", "rcppml_hip_loss_nonzeros",
-    "rcppml_hip_solve_irls_nb", "rcppml_hip_nb_size_update", "rcppml_hip_nb_loss", "rcppml_hip_solve_irls", "rcppml_hip_irls_loss",
+    "rcppml_hip_solve_irls_nb", "rcppml_hip_nb_size_update", "rcppml_hip_nb_loss", "rcppml_hip_solve_irls", "rcppml_hip_irls_loss", "rcppml_hip_apply_l21", "rcppml_hip_angular_posthoc",
 ]
 
 
@@ -294,6 +294,12 @@ class Context:
         _chk(lib().rcppml_hip_irls_loss(self._h, C.c_int(dt), C.c_int(loss_type), _dptr(col_ptr), _dptr(row_idx), _dptr(values),
                                         C.c_int64(ncols), _dptr(W_T), _dptr(d), _dptr(H), _dptr(theta_row), C.c_int(k),
                                         C.c_double(loss_param), _dptr(out)), "irls_loss")
+
+    def apply_l21(self, dt, G, X, k, ncols, lam):
+        _chk(lib().rcppml_hip_apply_l21(self._h, C.c_int(dt), _dptr(G), _dptr(X), C.c_int(k), C.c_int64(ncols), C.c_double(lam)), "apply_l21")
+
+    def angular_posthoc(self, dt, X, k, ncols, lam):
+        _chk(lib().rcppml_hip_angular_posthoc(self._h, C.c_int(dt), _dptr(X), C.c_int(k), C.c_int64(ncols), C.c_double(lam)), "angular_posthoc")
 
     def nb_size_update(self, dt, t_col_ptr, t_row_idx, t_values, m, W_T, d, H, n, k, r_min, r_max, nb_size):
         _chk(lib().rcppml_hip_nb_size_update(self._h, C.c_int(dt), _dptr(t_col_ptr), _dptr(t_row_idx), _dptr(t_values),

@@ -1185,6 +1185,52 @@ __global__ __launch_bounds__(256) void loss_mse_final(const double* __restrict__
 // lists are sorted).  Solve: CD exactly as the wave variant above (sequential visit, in-order), or
 // in-LDS Cholesky + clip for solver_mode 1.
 // ---------------------------------------------------------------------------
+// ---------------------------------------------------------------------------
+// k x k feature layer (reference features/L21.hpp:38-51, features/angular.hpp:67-103)
+// ---------------------------------------------------------------------------
+// L21: G(i,i) += lambda / ||factor.row(i)||_2 for rows with norm > 1e-10; sumsq[i] = sum_j X(i,j)^2
+template <class T>
+__global__ void l21_diag_kernel(T* __restrict__ G, const T* __restrict__ sumsq, int k, T lambda) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= k) return;
+    const T nrm = sqrt(sumsq[i]);
+    if (nrm > T(1e-10)) G[(int64_t)i * k + i] += lambda / nrm;
+}
+// angular, step 1: M(i,l) = norm_i * cos(i,l) / norm_l with cos = offdiag of the Gram of the row-normalised factor
+// (rows with norm <= 1e-15 are left unscaled); Gf = factor factor^T (no eps).  grad(:,j) = M x_j.
+template <class T>
+__global__ void angular_matrix_kernel(const T* __restrict__ Gf, int k, T* __restrict__ M) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= k * k) return;
+    const int l = e / k, i = e % k;                 // M stored [l][i]: column l contiguous in i
+    const T ni = sqrt(Gf[(int64_t)i * k + i]), nl = sqrt(Gf[(int64_t)l * k + l]);
+    const T inv_i = ni > T(1e-15) ? T(1) / ni : T(1), inv_l = nl > T(1e-15) ? T(1) / nl : T(1);
+    M[e] = (i == l) ? T(0) : ni * (Gf[(int64_t)l * k + i] * inv_i * inv_l) * inv_l;
+}
+// angular, step 2: x_j <- max(0, x_j - lambda M x_j), one wavefront per column, lane = feature (k <= 64)
+template <class T>
+__global__ __launch_bounds__(256) void angular_apply_kernel(T* __restrict__ X, int k, int64_t ncols, const T* __restrict__ M,
+                                                            T lambda) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    T* Ms = reinterpret_cast<T*>(smem_raw);          // k*k, [l][i]
+    for (int e = threadIdx.x; e < k * k; e += blockDim.x) Ms[e] = M[e];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int64_t wid = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t nw = (int64_t)gridDim.x * 4;
+    const bool fok = lane < k;
+    const int li = fok ? lane : 0;
+    for (int64_t j = wid; j < ncols; j += nw) {
+        const T x = fok ? X[j * (int64_t)k + lane] : T(0);
+        T g = T(0);
+        for (int l = 0; l < k; ++l) g = tfma(Ms[l * k + li], __shfl(x, l, 64), g);
+        if (fok) {
+            const T v = x - lambda * g;
+            X[j * (int64_t)k + lane] = v > T(0) ? v : T(0);
+        }
+    }
+}
+
 // value of lane i (wave-uniform i) through v_readlane_b32: the result lands in an SGPR, no LDS-crossbar round trip
 __device__ __forceinline__ float lane_value(float v, int i) {
     return __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), i));

@@ -47,6 +47,55 @@ static void apply_scaling_impl(rcppml_hip_ctx* c, T* X, int k, int64_t ncols, in
     hipLaunchKernelGGL(scale_rows<T>, dim3((unsigned)nblk), dim3(256), 0, c->stream, X, k, total, d);
     HIPCHK(hipGetLastError());
 }
+// ----------------------------------------------------------------------------
+// k x k feature layer
+// ----------------------------------------------------------------------------
+extern "C" int rcppml_hip_row_norms(rcppml_hip_ctx* c, int dtype, const void* X, int k, int64_t ncols, int norm_type, void* out);
+extern "C" int rcppml_hip_gram(rcppml_hip_ctx* c, int dtype, const void* F, int k, int64_t r, double eps, double l2, void* G);
+
+template <class T>
+static void apply_l21_impl(rcppml_hip_ctx* c, int dtype, T* G, const T* X, int k, int64_t ncols, T lambda) {
+    if (!(lambda > T(0))) return;
+    T* ss = static_cast<T*>(c->scratch(WS_FEAT, ((size_t)2 * k * k + k) * sizeof(T)));
+    if (rcppml_hip_row_norms(c, dtype, X, k, ncols, 1, ss) != 0) throw std::runtime_error(rcppml_err());
+    hipLaunchKernelGGL(l21_diag_kernel<T>, dim3((k + 63) / 64), dim3(64), 0, c->stream, G, ss, k, lambda);
+    HIPCHK(hipGetLastError());
+}
+extern "C" int rcppml_hip_apply_l21(rcppml_hip_ctx* c, int dtype, void* G, const void* X, int k, int64_t ncols, double lambda) {
+    try {
+        HIPCHK(hipSetDevice(c->device));
+        if (dtype == RCPPML_F32) apply_l21_impl<float>(c, dtype, (float*)G, (const float*)X, k, ncols, (float)lambda);
+        else apply_l21_impl<double>(c, dtype, (double*)G, (const double*)X, k, ncols, lambda);
+        return 0;
+    }
+    RCPPML_CATCH_RET
+}
+template <class T>
+static void angular_impl(rcppml_hip_ctx* c, int dtype, T* X, int k, int64_t ncols, T lambda) {
+    if (!(lambda > T(0)) || ncols <= 0) return;
+    if (k > 64) throw std::runtime_error("angular_posthoc: k > 64 not supported");
+    T* buf = static_cast<T*>(c->scratch(WS_FEAT, ((size_t)2 * k * k + k) * sizeof(T)));
+    T* Gf = buf + k;
+    T* M = Gf + (size_t)k * k;
+    if (rcppml_hip_gram(c, dtype, X, k, ncols, 0.0, 0.0, Gf) != 0) throw std::runtime_error(rcppml_err());
+    hipLaunchKernelGGL(angular_matrix_kernel<T>, dim3((k * k + 255) / 256), dim3(256), 0, c->stream, Gf, k, M);
+    HIPCHK(hipGetLastError());
+    int64_t nblk = (ncols + 3) / 4;
+    if (nblk > 8 * (int64_t)c->num_cu) nblk = 8 * c->num_cu;
+    hipLaunchKernelGGL(angular_apply_kernel<T>, dim3((unsigned)nblk), dim3(256), (size_t)k * k * sizeof(T), c->stream, X, k, ncols,
+                       M, lambda);
+    HIPCHK(hipGetLastError());
+}
+extern "C" int rcppml_hip_angular_posthoc(rcppml_hip_ctx* c, int dtype, void* X, int k, int64_t ncols, double lambda) {
+    try {
+        HIPCHK(hipSetDevice(c->device));
+        if (dtype == RCPPML_F32) angular_impl<float>(c, dtype, (float*)X, k, ncols, (float)lambda);
+        else angular_impl<double>(c, dtype, (double*)X, k, ncols, lambda);
+        return 0;
+    }
+    RCPPML_CATCH_RET
+}
+
 extern "C" int rcppml_hip_apply_scaling(rcppml_hip_ctx* c, int dtype, void* X, int k, int64_t ncols, int norm_type,
                                         const void* sums, void* d) {
     try {

@@ -67,6 +67,7 @@ struct FitParams {
     double *W, *H, *d;            // in/out (host, double)
     int max_iter; double tol;
     double L1_H, L1_W, L2_H, L2_W, ub_H, ub_W;
+    double L21_H = 0, L21_W = 0, angular_H = 0, angular_W = 0;
     int cd_maxit; double cd_tol;
     int verbose, patience, nonneg_W, nonneg_H, norm_type, solver_mode;
     const int* mask_p; const int* mask_i;   // NULL = no mask
@@ -210,6 +211,7 @@ void fit(FitParams& P) {
             if (P.ub_H > 0) throw std::runtime_error("upper bound with explicit mask: not supported");
         } else {
             OPCHK(rcppml_hip_gram(c, dt, dW.p, k, m, eps, P.L2_H, dG.p));              // :491,506
+            if (P.L21_H > 0) OPCHK(rcppml_hip_apply_l21(c, dt, dG.p, dH.p, k, n, P.L21_H));   // :509-510 (current H)
             OPCHK(rcppml_hip_rhs(c, dt, dAp.as<int>(), dAi.as<int>(), dAx.p, n, dW.p, k, dBh.p));
             if (P.solver_mode == 0) {                                                   // :516-524
                 const bool ord = use_order && iter > 0 && n >= 32768;   // pays once waves outnumber the chip's slots
@@ -221,6 +223,7 @@ void fit(FitParams& P) {
             else                                                                        // :527-534
                 OPCHK(rcppml_hip_solve_chol(c, dt, dG.p, dBh.p, dH.p, k, n, P.L1_H > 0 ? P.L1_H : 0.0, P.nonneg_H, P.ub_H));
         }
+        if (P.angular_H > 0) OPCHK(rcppml_hip_angular_posthoc(c, dt, dH.p, k, n, P.angular_H));   // :638-639
         OPCHK(rcppml_hip_row_norms(c, dt, dH.p, k, n, P.norm_type, dsums.p));           // :645 extract_scaling
         OPCHK(rcppml_hip_apply_scaling(c, dt, dH.p, k, n, P.norm_type, dsums.p, dd.p));
 
@@ -239,6 +242,7 @@ void fit(FitParams& P) {
             OPCHK(rcppml_hip_gram(c, dt, dH.p, k, n, eps, 0.0, dGs.p));                 // :715-722 G_w_saved
             if (P.L2_W > 0) OPCHK(rcppml_hip_gram(c, dt, dH.p, k, n, eps, P.L2_W, dG.p)); // :738
             else HIPCHK(hipMemcpyAsync(dG.p, dGs.p, (size_t)k * k * sizeof(T), hipMemcpyDeviceToDevice, s));
+            if (P.L21_W > 0) OPCHK(rcppml_hip_apply_l21(c, dt, dG.p, dW.p, k, m, P.L21_W));   // :741-745 (current W_T)
             OPCHK(rcppml_hip_rhs(c, dt, dTp.as<int>(), dTi.as<int>(), dTx.p, m, dH.p, k, dBw.p));
             if (P.solver_mode == 0) {
                 const bool ord = use_order && iter > 0 && m >= 32768;
@@ -250,6 +254,7 @@ void fit(FitParams& P) {
             else
                 OPCHK(rcppml_hip_solve_chol(c, dt, dG.p, dBw.p, dW.p, k, m, P.L1_W > 0 ? P.L1_W : 0.0, P.nonneg_W, P.ub_W));
         }
+        if (P.angular_W > 0) OPCHK(rcppml_hip_angular_posthoc(c, dt, dW.p, k, m, P.angular_W));   // :886-887
         OPCHK(rcppml_hip_row_norms(c, dt, dW.p, k, m, P.norm_type, dsums.p));           // :893
         OPCHK(rcppml_hip_apply_scaling(c, dt, dW.p, k, m, P.norm_type, dsums.p, dd.p));
 
@@ -393,8 +398,10 @@ void nmf_entry(RCPPML_NMF_UNIFIED_ARGS, const int* mask_p, const int* mask_i, do
             if (mask_p) throw std::runtime_error("NB loss with explicit mask: not supported");
         }
         if (*robust_delta > 0) throw std::runtime_error("robust loss not supported");
-        if (*L21_H != 0 || *L21_W != 0) throw std::runtime_error("L21 not supported");
-        if (*ortho_H != 0 || *ortho_W != 0) throw std::runtime_error("angular penalty not supported");
+        if ((*L21_H != 0 || *L21_W != 0 || *ortho_H != 0 || *ortho_W != 0) && (*loss_type != 0 || mask_p))
+            throw std::runtime_error("L21 / angular penalties are implemented for the MSE path without explicit mask");
+        if ((*ortho_H != 0 || *ortho_W != 0) && *k > 64) throw std::runtime_error("angular penalty: k must be <= 64");
+        if (*L21_H < 0 || *L21_W < 0 || *ortho_H < 0 || *ortho_W < 0) throw std::runtime_error("negative L21 / angular penalty");
         if (*graph_W_nnz > 0 || *graph_H_nnz > 0) throw std::runtime_error("graph regularisation not supported");
         if (*guide_H_count > 0) throw std::runtime_error("classifier guides not supported");
         if (*projective != 0 || *symmetric != 0) throw std::runtime_error("projective/symmetric NMF not supported");
@@ -409,6 +416,7 @@ void nmf_entry(RCPPML_NMF_UNIFIED_ARGS, const int* mask_p, const int* mask_i, do
         P.W = W; P.H = H; P.d = d;
         P.max_iter = *max_iter; P.tol = *tol;
         P.L1_H = *L1_H; P.L1_W = *L1_W; P.L2_H = *L2_H; P.L2_W = *L2_W; P.ub_H = *ub_H; P.ub_W = *ub_W;
+        P.L21_H = *L21_H; P.L21_W = *L21_W; P.angular_H = *ortho_H; P.angular_W = *ortho_W;
         P.cd_maxit = *cd_maxit > 0 ? *cd_maxit : 10;          // src/RcppFunctions_nmf.cpp:22-95
         P.cd_tol = cd_tol > 0 ? cd_tol : 1e-8;
         P.verbose = *verbose; P.patience = *patience; P.nonneg_W = *nonneg_W; P.nonneg_H = *nonneg_H;

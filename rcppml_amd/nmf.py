@@ -70,7 +70,7 @@ def nmf(data, k, tol=1e-4, maxit=100, L1=(0.0, 0.0), L2=(0.0, 0.0), seed=None, m
         nonneg=(True, True), test_fraction=0, verbose=False, projective=False, symmetric=False, zi="none",
         robust=False, *, solver="auto", upper_bound=(0.0, 0.0), cd_maxit=100, cd_tol=1e-8, norm="L1", sort_model=True,
         patience=5, h_init=None, precision="fp32", resource="gpu", dispersion="per_row", irls_max_iter=5, irls_tol=1e-4,
-        nb_size_init=10.0, nb_size_max=1e6, nb_size_min=0.01, tweedie_power=1.5):
+        nb_size_init=10.0, nb_size_max=1e6, nb_size_min=0.01, tweedie_power=1.5, L21=(0.0, 0.0), angular=(0.0, 0.0)):
     """Non-negative matrix factorisation A ~ w diag(d) h by alternating NNLS on the MI355X.
 
     `L1`, `L2`, `upper_bound`, `nonneg` are c(w, h) pairs (src/RcppFunctions_nmf.cpp:59-62).
@@ -100,6 +100,8 @@ def nmf(data, k, tol=1e-4, maxit=100, L1=(0.0, 0.0), L2=(0.0, 0.0), seed=None, m
         raise ValueError("k must be a positive integer")
     L1w, L1h = _pair(L1, "L1")
     L2w, L2h = _pair(L2, "L2")
+    L21w, L21h = _pair(L21, "L21")
+    angw, angh = _pair(angular, "angular")
     ubw, ubh = _pair(upper_bound, "upper_bound")
     if min(L1w, L1h, L2w, L2h) < 0:
         raise ValueError("L1 and L2 penalties must be non-negative")
@@ -144,7 +146,7 @@ def nmf(data, k, tol=1e-4, maxit=100, L1=(0.0, 0.0), L2=(0.0, 0.0), seed=None, m
                 raise ValueError("mask dimensions must match data")
             mask_arg = (M.p, M.i)
     res = _abi.nmf_unified(A.p, A.i, A.x, m, n, k, W_T, H, entry="ex", max_iter=int(maxit), tol=float(tol), L1_H=L1h,
-                           L1_W=L1w, L2_H=L2h, L2_W=L2w, ub_H=ubh, ub_W=ubw, cd_maxit=int(cd_maxit), verbose=int(verbose),
+                           L1_W=L1w, L2_H=L2h, L2_W=L2w, L21_H=L21h, L21_W=L21w, ortho_H=angh, ortho_W=angw, ub_H=ubh, ub_W=ubw, cd_maxit=int(cd_maxit), verbose=int(verbose),
                            seed=seed_int & 0x7FFFFFFF, patience=int(patience), nonneg_W=int(nnw), nonneg_H=int(nnh),
                            norm_type=norm_type, solver_mode=0 if solver == "cd" else 1, mask=mask_arg, cd_tol=float(cd_tol),
                            loss_type={"mse": 0, "gp": 4, "nb": 5, "gamma": 6, "inverse_gaussian": 7, "tweedie": 8}[loss],

@@ -117,7 +117,8 @@ def test_unsupported_features_are_rejected(abi):
     """The plugin must set out_status=-1 (-> caller's CPU fallback) instead of silently dropping a feature."""
     A = lowrank_csc(50, 60, 3, 0.2, seed=1)
     W0, H0 = O.init_factors(1, 4, A.rows, A.cols, np.float64)
-    for kw in (dict(L21_H=0.1), dict(ortho_W=0.1), dict(projective=1), dict(symmetric=1), dict(loss_type=3), dict(loss_type=5, solver_mode=1),
+    for kw in (dict(L21_H=0.1, loss_type=5), dict(ortho_W=-0.1), dict(projective=1), dict(symmetric=1), dict(loss_type=3),
+               dict(loss_type=1), dict(loss_type=4, gp_dispersion_mode=2), dict(loss_type=6, gp_dispersion_mode=2), dict(loss_type=5, solver_mode=1),
                dict(graph_W_nnz=5), dict(guide_H_count=1), dict(solver_mode=2)):
         W, H = W0.copy(), H0.copy()
         r = abi.nmf_unified(A.p, A.i, A.x, A.rows, A.cols, 4, W, H, entry="double", max_iter=2, **kw)
@@ -246,3 +247,23 @@ def test_run_to_run_determinism_with_work_order(abi):
         outs.append((W, H, res["d"].copy(), res["loss"]))
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
     assert np.array_equal(outs[0][2], outs[1][2]) and outs[0][3] == outs[1][3]
+
+
+@pytest.mark.parametrize("entry,tol_loss,tol_fac", [("double", 1e-6, 1e-6), ("float", 5e-4, 5e-3)])
+def test_l21_and_angular_features(abi, entry, tol_loss, tol_fac):
+    """k x k feature layer: L21 (features/L21.hpp) on the Gram before the solve and the post-hoc
+    angular decorrelation (features/angular.hpp) after it, on either side, vs the oracle fit."""
+    A = lowrank_csc(90, 140, 5, 0.25, seed=31)
+    k = 7
+    dtype = np.float64 if entry == "double" else np.float32
+    W0, H0 = O.init_factors(13, k, A.rows, A.cols, np.float64)
+    for L21, ang in (((0.05, 0.0), (0.0, 0.0)), ((0.0, 0.2), (0.0, 0.0)), ((0.0, 0.0), (0.03, 0.0)), ((0.0, 0.0), (0.0, 0.05)),
+                     ((0.02, 0.04), (0.01, 0.02))):
+        ref = O.nmf_fit(A, W0, H0, dtype, max_iter=6, tol=0.0, solver_mode=0, L21=L21, angular=ang)
+        res = _run_gpu(abi, A, W0, H0, entry, max_iter=6, tol=0.0, solver_mode=0, L21_W=L21[0], L21_H=L21[1],
+                       ortho_W=ang[0], ortho_H=ang[1])
+        _compare(res, ref, tol_loss, tol_fac)
+    # features change the fit (guards against silently ignored arguments)
+    base = O.nmf_fit(A, W0, H0, dtype, max_iter=6, tol=0.0, solver_mode=0)
+    pen = O.nmf_fit(A, W0, H0, dtype, max_iter=6, tol=0.0, solver_mode=0, L21=(0.05, 0.2), angular=(0.03, 0.05))
+    assert abs(pen.loss - base.loss) > 1e-3 * abs(base.loss)
