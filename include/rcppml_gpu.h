@@ -247,16 +247,19 @@ RCPPML_GPU_API int rcppml_hip_solve_irls_nb(rcppml_hip_ctx* ctx, int dtype, cons
  * with the KL weight 1/max(mu, 1e-4) (nmf/fit_cpu.hpp:568-574: "GP strategy: use KL weights for W/H updates") and
  * evaluates the GP likelihood (math/loss.hpp:382-398) with theta_row (zeros for dispersion = "none": Poisson /
  * KL-divergence NMF); 6-8 use the power-variance weight min(1/mu^p, 1e6) (:270-278) and the deviance terms (:439-505).
- * theta pointers are read by NB only (pass NULL otherwise).  The plugin implements 4 and 6-8 for dispersion = "none". */
+ * theta pointers are read by NB only (pass NULL otherwise).  The plugin implements 4 and 6-8 for dispersion = "none".
+ * robust_delta > 0 multiplies every weight by the Huber modifier of the Pearson residual (math/loss.hpp:294-303,
+ * nnls_batch_irls.hpp:95-120) and makes the loss the Huber rho of that residual (:549-607); with it loss_type 0 (MSE,
+ * distribution weight 1) is accepted too -- the reference routes robust MSE through the IRLS path. */
 RCPPML_GPU_API int rcppml_hip_solve_irls(rcppml_hip_ctx* ctx, int dtype, int loss_type, const int* col_ptr,
                                          const int* row_idx, const void* values, int64_t ncols, const void* F,
                                          const void* G_base, void* X, int k, double l1, double l2, int nonneg,
                                          int cd_maxit, int irls_max_iter, double irls_tol, const void* theta_row,
-                                         const void* theta_col, double loss_param);
+                                         const void* theta_col, double loss_param, double robust_delta);
 RCPPML_GPU_API int rcppml_hip_irls_loss(rcppml_hip_ctx* ctx, int dtype, int loss_type, const int* col_ptr,
                                         const int* row_idx, const void* values, int64_t ncols, const void* W_T,
                                         const void* d, const void* H, const void* theta_row, int k, double loss_param,
-                                        double* out);
+                                        double robust_delta, double* out);
 /* NB size (r) per ROW of A by the method of moments -- reference nmf/fit_cpu.hpp:1094-1265 (PER_ROW branch, sparse):
  * r_i = clamp(S mu^2 / (S (y-mu)^2 - S mu), r_min, r_max), else r_max.  Takes CSC(A^T); W_T k x m, H k x n. */
 RCPPML_GPU_API int rcppml_hip_nb_size_update(rcppml_hip_ctx* ctx, int dtype, const int* t_col_ptr,

@@ -108,6 +108,44 @@ template <class S> static inline S loss_contribution(int loss_type, S observed, 
     }
 }
 
+// math/loss.hpp:294-303  robust_huber_modifier (eps = tiny_num = 1e-15)
+template <class S> static inline S robust_huber_modifier(S pearson_residual, S delta) {
+    const S abs_r = std::abs(pearson_residual);
+    if (abs_r <= delta) return static_cast<S>(1);
+    return delta / (abs_r + static_cast<S>(1e-15));
+}
+// nnls_batch_irls.hpp:95-120  compute_irls_weight: distribution weight x optional Huber modifier on the Pearson residual
+// (loss_type 0 = MSE: distribution weight 1, only reached with robust_delta > 0)
+template <class S> static inline S compute_irls_weight(int loss_type, S residual, S predicted, S theta, S power, S robust_delta) {
+    const S w_dist = loss_type == 0 ? S(1) : irls_weight(loss_type, predicted, theta, power);
+    if (robust_delta > S(0)) {
+        const S sd_inv = std::sqrt(std::max(w_dist, static_cast<S>(1e-15)));
+        return w_dist * robust_huber_modifier(residual * sd_inv, robust_delta);
+    }
+    return w_dist;
+}
+// math/loss.hpp:549-607  compute_robust_loss: Huber rho of the Pearson residual (variance function per distribution)
+template <class S> static inline S compute_robust_loss(int loss_type, S observed, S predicted, S theta, S power, S robust_delta) {
+    if (robust_delta <= S(0)) return loss_type == 0 ? (observed - predicted) * (observed - predicted)
+                                                    : loss_contribution(loss_type, observed, predicted, theta, power);
+    const S mu = std::max(predicted, static_cast<S>(1e-10));
+    const S residual = observed - mu;
+    S var_mu;
+    switch (loss_type) {
+        case 4: case 3: var_mu = mu; break;
+        case 5: { const S r = std::max(theta, static_cast<S>(1e-10)); var_mu = mu + mu * mu / r; break; }
+        case 6: var_mu = mu * mu; break;
+        case 7: var_mu = mu * mu * mu; break;
+        case 8: var_mu = static_cast<S>(std::pow(static_cast<double>(mu), static_cast<double>(power))); break;
+        default: var_mu = S(1); break;
+    }
+    const S sd = std::sqrt(std::max(var_mu, static_cast<S>(1e-20)));
+    const S pearson_r = residual / sd;
+    const S abs_pr = std::abs(pearson_r);
+    if (abs_pr <= robust_delta) return static_cast<S>(0.5) * pearson_r * pearson_r;
+    return robust_delta * abs_pr - static_cast<S>(0.5) * robust_delta * robust_delta;
+}
+
 // nmf/masked_nnls.hpp:96-154 (H side) / :177-242 (W side): same routine, data = A or A^T
 template <class S>
 static void masked_nnls(const Csc<S>& A, const S* F, const S* G_full, S* X, const Csc<S>& mask,
@@ -195,7 +233,7 @@ template <class S>
 static void nnls_batch_irls_sparse_nb(const Csc<S>& A, const S* F, const S* G_base, S* X, int k,
                                       S L1, S L2, bool nonneg, int cd_maxit, int irls_max_iter,
                                       S irls_tol, int threads, const S* theta_row,
-                                      const S* theta_col, int loss_type = 5, S power = S(1.5)) {
+                                      const S* theta_col, int loss_type = 5, S power = S(1.5), S robust = S(0)) {
     const int nt = eff_threads(threads); (void)nt;
     std::fill(X, X + (size_t)k * A.cols, S(0));   // H.setZero(): no warm start across ALS iters
 #pragma omp parallel num_threads(nt)
@@ -213,7 +251,7 @@ static void nnls_batch_irls_sparse_nb(const Csc<S>& A, const S* F, const S* G_ba
                     S recon = 0;
                     for (int f = 0; f < k; ++f) recon += fr[f] * x[f];
                     const S th = theta_col ? theta_col[j] : (theta_row ? theta_row[row] : S(0));
-                    const S w = irls_weight(loss_type, recon, th, power);
+                    const S w = compute_irls_weight(loss_type, A.x[t] - recon, recon, th, power, robust);
                     const S dw = w - S(1);
                     const S wv = w * A.x[t];
                     // G_w += dw * f f^T  (reference: W_nnz_scaled * W_block^T)
@@ -299,7 +337,7 @@ static void nb_size_update(const Csc<S>& A, const S* W_T, const S* H, const S* d
 // nmf/explicit_loss.hpp:53-77   NB NLL over NONZEROS only (per-row theta)
 template <class S>
 static S explicit_loss_sparse_nb(const Csc<S>& A, const S* W_Td, const S* H, int k,
-                                 const S* theta_row, int threads, int loss_type = 5, S power = S(1.5)) {
+                                 const S* theta_row, int threads, int loss_type = 5, S power = S(1.5), S robust = S(0)) {
     const int nt = eff_threads(threads); (void)nt;
     S total = 0;
 #pragma omp parallel for reduction(+ : total) num_threads(nt) schedule(dynamic, 64)
@@ -309,7 +347,7 @@ static S explicit_loss_sparse_nb(const Csc<S>& A, const S* W_Td, const S* H, int
             const S* w = W_Td + (size_t)A.i[t] * k;
             S pred = 0;
             for (int f = 0; f < k; ++f) pred += w[f] * h[f];
-            total += loss_contribution(loss_type, A.x[t], pred, theta_row ? theta_row[A.i[t]] : S(0), power);
+            total += compute_robust_loss(loss_type, A.x[t], pred, theta_row ? theta_row[A.i[t]] : S(0), power, robust);
         }
     }
     return total;
@@ -336,11 +374,11 @@ FitResult<S> nmf_fit(const Csc<S>& A, const FitConfig<S>& cfg, S* W_T, S* H, S* 
     const bool is_nb = cfg.loss_type == 5;
     const bool is_gp = cfg.loss_type == 4;                    // dispersion NONE only: theta = 0 (fit_cpu.hpp:297-304)
     const bool is_pow = cfg.loss_type == 6 || cfg.loss_type == 7 || cfg.loss_type == 8;   // dispersion NONE: phi = 1, unused
-    const bool irls = is_nb || is_gp || is_pow;
+    const bool irls = is_nb || is_gp || is_pow || cfg.robust_delta > 0;   // requires_irls() (math/loss.hpp:106-108)
     std::vector<S> nb_size;
     if (is_nb)                                                // fit_cpu.hpp:316-328 (PER_ROW/GLOBAL/NONE)
         nb_size.assign(m, cfg.dispersion_mode == 0 ? cfg.nb_size_max : cfg.nb_size_init);
-    if (is_gp || is_pow) nb_size.assign(m, is_gp ? S(0) : S(1));   // theta_vec = Zero(m) / phi_vec = 1; the IRLS itself gets no theta
+    if (is_gp || is_pow || cfg.loss_type == 0) nb_size.assign(m, is_pow ? S(1) : S(0));   // theta_vec = Zero(m) / phi_vec = 1; the IRLS itself gets no theta
 
     std::vector<S> G((size_t)k * k), G_saved((size_t)k * k), G_wt((size_t)k * k);
     S prev_loss = std::numeric_limits<S>::max();
@@ -357,7 +395,7 @@ FitResult<S> nmf_fit(const Csc<S>& A, const FitConfig<S>& cfg, S* W_T, S* H, S* 
             // :565-606 gram recomputed (eps only); L1 inside CD, L2 on G_w
             nnls_batch_irls_sparse_nb(A, W_T, G.data(), H, k, cfg.L1_H, cfg.L2_H, cfg.nonneg_H,
                                       cfg.cd_maxit, cfg.irls_max_iter, cfg.irls_tol, cfg.threads,
-                                      is_nb ? nb_size.data() : (const S*)nullptr, (const S*)nullptr, cfg.loss_type, cfg.tweedie_power);
+                                      is_nb ? nb_size.data() : (const S*)nullptr, (const S*)nullptr, cfg.loss_type, cfg.tweedie_power, cfg.robust_delta);
         } else {
             if (cfg.L2_H > 0) for (int i = 0; i < k; ++i) G[(size_t)i * k + i] += cfg.L2_H;   // :506
             apply_L21(G.data(), H, k, (int64_t)n, cfg.L21_H);                                  // :509-510 (current H)
@@ -382,7 +420,7 @@ FitResult<S> nmf_fit(const Csc<S>& A, const FitConfig<S>& cfg, S* W_T, S* H, S* 
             // :811-852: theta_per_col = nb_size (row of A == column of A^T)
             nnls_batch_irls_sparse_nb(At, H, G.data(), W_T, k, cfg.L1_W, cfg.L2_W, cfg.nonneg_W,
                                       cfg.cd_maxit, cfg.irls_max_iter, cfg.irls_tol, cfg.threads,
-                                      (const S*)nullptr, is_nb ? nb_size.data() : (const S*)nullptr, cfg.loss_type, cfg.tweedie_power);
+                                      (const S*)nullptr, is_nb ? nb_size.data() : (const S*)nullptr, cfg.loss_type, cfg.tweedie_power, cfg.robust_delta);
         } else {
             if (cfg.L2_W > 0) for (int i = 0; i < k; ++i) G[(size_t)i * k + i] += cfg.L2_W;   // :738
             apply_L21(G.data(), W_T, k, (int64_t)m, cfg.L21_W);                                // :741-745 (current W_T)
@@ -405,7 +443,7 @@ FitResult<S> nmf_fit(const Csc<S>& A, const FitConfig<S>& cfg, S* W_T, S* H, S* 
             std::vector<S> Wd((size_t)k * m);
             for (int i = 0; i < m; ++i) for (int f = 0; f < k; ++f) Wd[(size_t)i * k + f] = W_T[(size_t)i * k + f] * d[f];
             loss_val = cfg.has_mask ? masked_loss(A, Wd.data(), H, cfg.mask, k, threads)
-                                    : explicit_loss_sparse_nb(A, Wd.data(), H, k, nb_size.data(), cfg.threads > 0 ? cfg.threads : 1, cfg.loss_type, cfg.tweedie_power);
+                                    : explicit_loss_sparse_nb(A, Wd.data(), H, k, nb_size.data(), cfg.threads > 0 ? cfg.threads : 1, cfg.loss_type, cfg.tweedie_power, cfg.robust_delta);
         } else {
             gram(W_T, k, m, G_wt.data());                                                   // :1734-1735
             const S cross = loss_cross_term_sparse_via_At(At, W_T, H, d, k, threads);        // :1740-1741
@@ -518,7 +556,7 @@ template <class S> static Csc<S> mk(int rows, int cols, const int* p, const int*
         S irls_tol, int dispersion_mode, S nb_size_init, S nb_size_max, S nb_size_min, int sort_model,    \
         int threads, const int* mask_p, const int* mask_i, const S* mask_x, int* out_iter,                \
         int* out_converged, S* out_loss, S* out_tol, S* loss_hist, S* out_theta, S tweedie_power,         \
-        S L21_H, S L21_W, S angular_H, S angular_W) {                                                     \
+        S L21_H, S L21_W, S angular_H, S angular_W, S robust_delta) {                                     \
         FitConfig<S> c;                                                                                   \
         c.k = k; c.max_iter = max_iter; c.tol = tol; c.L1_H = L1_H; c.L1_W = L1_W; c.L2_H = L2_H;         \
         c.L2_W = L2_W; c.ub_H = ub_H; c.ub_W = ub_W; c.cd_maxit = cd_maxit; c.cd_tol = cd_tol;            \
@@ -527,7 +565,7 @@ template <class S> static Csc<S> mk(int rows, int cols, const int* p, const int*
         c.irls_max_iter = irls_max_iter; c.irls_tol = irls_tol; c.dispersion_mode = dispersion_mode;      \
         c.nb_size_init = nb_size_init; c.nb_size_max = nb_size_max; c.nb_size_min = nb_size_min;          \
         c.sort_model = sort_model != 0; c.threads = threads; c.tweedie_power = tweedie_power;             \
-        c.L21_H = L21_H; c.L21_W = L21_W; c.angular_H = angular_H; c.angular_W = angular_W;               \
+        c.L21_H = L21_H; c.L21_W = L21_W; c.angular_H = angular_H; c.angular_W = angular_W; c.robust_delta = robust_delta; \
         if (mask_p) { c.has_mask = true; c.mask = mk(m, n, mask_p, mask_i, mask_x); }                     \
         FitResult<S> r = nmf_fit(mk(m, n, p, i, x), c, W_T, H, d);                                        \
         *out_iter = r.iterations; *out_converged = r.converged ? 1 : 0; *out_loss = r.train_loss;         \
@@ -546,6 +584,10 @@ ORACLE_API float oracle_irls_weight_nb_f32(float p, float r) { return irls_weigh
 ORACLE_API double oracle_loss_nb_f64(double y, double p, double r) { return loss_contribution_nb<double>(y, p, r); }
 ORACLE_API float oracle_loss_nb_f32(float y, float p, float r) { return loss_contribution_nb<float>(y, p, r); }
 
+ORACLE_API double oracle_robust_modifier_f64(double r, double delta) { return robust_huber_modifier<double>(r, delta); }
+ORACLE_API float oracle_robust_modifier_f32(float r, float delta) { return robust_huber_modifier<float>(r, delta); }
+ORACLE_API double oracle_robust_loss_f64(int lt, double y, double p, double th, double pw, double delta) { return compute_robust_loss<double>(lt, y, p, th, pw, delta); }
+ORACLE_API float oracle_robust_loss_f32(int lt, float y, float p, float th, float pw, float delta) { return compute_robust_loss<float>(lt, y, p, th, pw, delta); }
 ORACLE_API double oracle_irls_weight_power_f64(double p, double pw) { return irls_weight_power<double>(p, pw); }
 ORACLE_API float oracle_irls_weight_power_f32(float p, float pw) { return irls_weight_power<float>(p, pw); }
 ORACLE_API double oracle_loss_dev_f64(int loss_type, double y, double p, double pw) { return loss_contribution<double>(loss_type, y, p, 0.0, pw); }
@@ -582,15 +624,15 @@ ORACLE_API float oracle_loss_gp_f32(float y, float p, float th) { return loss_co
     ORACLE_API void oracle_irls_##SUF(int loss_type, int rows, int cols, const int* p, const int* i, const S* x,  \
                                       const S* F, const S* G, S* X, int k, S L1, S L2, int nonneg, int cd_maxit,  \
                                       int irls_max_iter, S irls_tol, int threads, const S* theta_row,             \
-                                      const S* theta_col, S power) {                                              \
+                                      const S* theta_col, S power, S robust) {                                    \
         nnls_batch_irls_sparse_nb(mk(rows, cols, p, i, x), F, G, X, k, L1, L2, nonneg != 0, cd_maxit,             \
-                                  irls_max_iter, irls_tol, threads, theta_row, theta_col, loss_type, power);      \
+                                  irls_max_iter, irls_tol, threads, theta_row, theta_col, loss_type, power, robust); \
     }                                                                                                             \
     ORACLE_API S oracle_irls_loss_##SUF(int loss_type, int m, int n, const int* p, const int* i, const S* x,      \
-                                        const S* W_T, const S* d, const S* H, int k, const S* theta_row, S power) { \
+                                        const S* W_T, const S* d, const S* H, int k, const S* theta_row, S power, S robust) { \
         std::vector<S> Wd((size_t)k * m);                                                                         \
         for (int r = 0; r < m; ++r) for (int f = 0; f < k; ++f) Wd[(size_t)r * k + f] = W_T[(size_t)r * k + f] * d[f]; \
-        return explicit_loss_sparse_nb(mk(m, n, p, i, x), Wd.data(), H, k, theta_row, 1, loss_type, power);       \
+        return explicit_loss_sparse_nb(mk(m, n, p, i, x), Wd.data(), H, k, theta_row, 1, loss_type, power, robust); \
     }
 DEFINE_NB(f32, float)
 DEFINE_NB(f64, double)

@@ -263,7 +263,7 @@ class FitResult:
 def nmf_fit(A, W_T, H, dtype=np.float64, max_iter=100, tol=1e-4, L1=(0.0, 0.0), L2=(0.0, 0.0), ub=(0.0, 0.0),
             cd_maxit=100, cd_tol=1e-8, patience=5, nonneg=(True, True), norm_type=0, solver_mode=0, loss_type=0,
             irls_max_iter=5, irls_tol=1e-4, dispersion_mode=2, nb_size=(10.0, 1e6, 0.01), sort_model=True, threads=1,
-            mask=None, native=False, tweedie_power=1.5, L21=(0.0, 0.0), angular=(0.0, 0.0)):
+            mask=None, native=False, tweedie_power=1.5, L21=(0.0, 0.0), angular=(0.0, 0.0), robust_delta=0.0):
     """CPU restatement of nmf_fit<CPU> (reference nmf/fit_cpu.hpp).  L1/L2/ub/nonneg are (W, H) pairs as in R
     (src/RcppFunctions_nmf.cpp:59-62).  W_T: (m, k) array = column-major k x m; H: (n, k)."""
     suf, ct = _suf(dtype)
@@ -289,7 +289,7 @@ def nmf_fit(A, W_T, H, dtype=np.float64, max_iter=100, tol=1e-4, L1=(0.0, 0.0), 
         C.c_int(int(nonneg[0])), C.c_int(int(nonneg[1])), C.c_int(norm_type), C.c_int(solver_mode), C.c_int(loss_type),
         C.c_int(irls_max_iter), ct(irls_tol), C.c_int(dispersion_mode), ct(nb_size[0]), ct(nb_size[1]), ct(nb_size[2]),
         C.c_int(int(sort_model)), C.c_int(threads), mp, mi, mxp, C.byref(it), C.byref(conv), C.byref(loss), C.byref(ftol),
-        _p(hist), _p(theta), ct(tweedie_power), ct(L21[1]), ct(L21[0]), ct(angular[1]), ct(angular[0]))
+        _p(hist), _p(theta), ct(tweedie_power), ct(L21[1]), ct(L21[0]), ct(angular[1]), ct(angular[0]), ct(robust_delta))
     r = FitResult()
     r.W_T, r.H, r.d = W_T, H, d
     r.iter, r.converged, r.loss, r.tol = it.value, bool(conv.value), float(loss.value), float(ftol.value)
@@ -330,7 +330,7 @@ def num_threads():
 
 # ----------------------------------------------------------------------------- NB-IRLS primitives
 def irls(loss_type, A, F, G, k, L1=0.0, L2=0.0, nonneg=True, cd_maxit=100, irls_max_iter=5, irls_tol=1e-4, threads=1,
-         theta_row=None, theta_col=None, dtype=np.float64, power=1.5):
+         theta_row=None, theta_col=None, dtype=np.float64, power=1.5, robust=0.0):
     """Generic IRLS half-update: loss_type 5 = NB, 4 = GP (KL weights, fit_cpu.hpp:568-574), 6 = Gamma, 7 = inverse
     Gaussian, 8 = Tweedie(power)."""
     suf, ct = _suf(dtype)
@@ -342,18 +342,18 @@ def irls(loss_type, A, F, G, k, L1=0.0, L2=0.0, nonneg=True, cd_maxit=100, irls_
     getattr(lib(), "oracle_irls_" + suf)(C.c_int(loss_type), C.c_int(A.rows), C.c_int(A.cols), _p(A.p), _p(A.i), _p(x), _p(F),
                                          _p(G), _p(X), C.c_int(k), ct(L1), ct(L2), C.c_int(int(nonneg)), C.c_int(cd_maxit),
                                          C.c_int(irls_max_iter), ct(irls_tol), C.c_int(threads),
-                                         _p(tr) if tr is not None else None, _p(tc) if tc is not None else None, ct(power))
+                                         _p(tr) if tr is not None else None, _p(tc) if tc is not None else None, ct(power), ct(robust))
     return X
 
 
-def irls_loss(loss_type, A, W_T, d, H, theta_row, dtype=np.float64, power=1.5):
+def irls_loss(loss_type, A, W_T, d, H, theta_row, dtype=np.float64, power=1.5, robust=0.0):
     suf, ct = _suf(dtype)
     fn = getattr(lib(), "oracle_irls_loss_" + suf)
     fn.restype = ct
     W_T, H, d, th = _f(W_T, dtype), _f(H, dtype), _f(d, dtype), _f(theta_row, dtype)
     x = A.values(dtype)
     return float(fn(C.c_int(loss_type), C.c_int(A.rows), C.c_int(A.cols), _p(A.p), _p(A.i), _p(x), _p(W_T), _p(d), _p(H),
-                    C.c_int(W_T.shape[1]), _p(th), ct(power)))
+                    C.c_int(W_T.shape[1]), _p(th), ct(power), ct(robust)))
 
 
 def irls_nb(A, F, G, k, L1=0.0, L2=0.0, nonneg=True, cd_maxit=100, irls_max_iter=5, irls_tol=1e-4, threads=1,

@@ -38,6 +38,19 @@ __attribute__((visibility("default"))) float ref_loss_dev_f32(int loss_type, flo
          : loss_type == 7 ? FactorNet::loss_contribution_invgauss<float>(y, mu)
                           : FactorNet::loss_contribution_tweedie<float>(y, mu, power);
 }
+__attribute__((visibility("default"))) double ref_robust_modifier_f64(double r, double delta) { return FactorNet::robust_huber_modifier<double>(r, delta); }
+__attribute__((visibility("default"))) float ref_robust_modifier_f32(float r, float delta) { return FactorNet::robust_huber_modifier<float>(r, delta); }
+// compute_robust_loss through the reference's own LossConfig (type = LossType value, robust_delta, power_param)
+__attribute__((visibility("default"))) double ref_robust_loss_f64(int loss_type, double y, double mu, double theta, double power, double delta) {
+    FactorNet::LossConfig<double> c;
+    c.type = static_cast<FactorNet::LossType>(loss_type); c.robust_delta = delta; c.power_param = power;
+    return FactorNet::compute_robust_loss<double>(y, mu, c, theta);
+}
+__attribute__((visibility("default"))) float ref_robust_loss_f32(int loss_type, float y, float mu, float theta, float power, float delta) {
+    FactorNet::LossConfig<float> c;
+    c.type = static_cast<FactorNet::LossType>(loss_type); c.robust_delta = delta; c.power_param = power;
+    return FactorNet::compute_robust_loss<float>(y, mu, c, theta);
+}
 __attribute__((visibility("default"))) double ref_loss_mse_f64(double observed, double predicted) {
     return FactorNet::loss_contribution_mse<double>(observed, predicted);
 }

@@ -91,7 +91,7 @@ def nmf_unified(p, i, x, m, n, k, W_T, H, *, entry="float", max_iter=100, tol=1e
                 seed=0, loss_every=1, patience=5, nonneg_W=1, nonneg_H=1, loss_type=0, huber_delta=1.0, irls_max_iter=5,
                 irls_tol=1e-4, norm_type=0, projective=0, symmetric=0, solver_mode=0, gp_dispersion_mode=2,
                 nb_size=(10.0, 1e6, 0.01), mask=None, cd_tol=1e-8, sort_model=1, precision=F64, want_history=False,
-                graph_W_nnz=0, guide_H_count=0, tweedie_power=1.5):
+                graph_W_nnz=0, guide_H_count=0, tweedie_power=1.5, robust_delta=0.0):
     """Call the 73-pointer plugin entry exactly as reference gpu/bridge_nmf.hpp:310-342 does.
 
     p, i: int32 CSC arrays; x: float64 values.  W_T (m, k) and H (n, k) float64 arrays (memory = column-major
@@ -120,7 +120,7 @@ def nmf_unified(p, i, x, m, n, k, W_T, H, *, entry="float", max_iter=100, tol=1e
         _np_ptr(dummy_i), _np_ptr(dummy_i), _np_ptr(dummy_d), _ci(0), _ci(graph_W_nnz), _cd(0.0),
         _np_ptr(dummy_i), _np_ptr(dummy_i), _np_ptr(dummy_d), _ci(0), _ci(0), _cd(0.0),
         _ci(gp_dispersion_mode), _cd(0.1), _cd(5.0), _cd(0.0), _cd(nb_size[0]), _cd(nb_size[1]), _cd(nb_size[2]),
-        _cd(1.0), _cd(1e4), _cd(1e-6), _cd(0.0), _cd(tweedie_power),
+        _cd(1.0), _cd(1e4), _cd(1e-6), _cd(robust_delta), _cd(tweedie_power),
         _np_ptr(theta), C.byref(out_theta_len),
         _np_ptr(dummy_i), _np_ptr(dummy_i), _np_ptr(dummy_d), _np_ptr(dummy_i), _ci(guide_H_count),
         C.byref(out_iter), C.byref(out_conv), C.byref(out_loss), C.byref(out_status), C.byref(out_tol),
@@ -284,16 +284,17 @@ class Context:
                                             C.c_double(irls_tol), _dptr(theta_row), _dptr(theta_col)), "solve_irls_nb")
 
     def solve_irls(self, dt, loss_type, col_ptr, row_idx, values, ncols, F, G_base, X, k, l1=0.0, l2=0.0, nonneg=1, cd_maxit=100,
-                   irls_max_iter=5, irls_tol=1e-4, theta_row=None, theta_col=None, loss_param=0.0):
+                   irls_max_iter=5, irls_tol=1e-4, theta_row=None, theta_col=None, loss_param=0.0, robust_delta=0.0):
         _chk(lib().rcppml_hip_solve_irls(self._h, C.c_int(dt), C.c_int(loss_type), _dptr(col_ptr), _dptr(row_idx), _dptr(values),
                                          C.c_int64(ncols), _dptr(F), _dptr(G_base), _dptr(X), C.c_int(k), C.c_double(l1),
                                          C.c_double(l2), C.c_int(nonneg), C.c_int(cd_maxit), C.c_int(irls_max_iter),
-                                         C.c_double(irls_tol), _dptr(theta_row), _dptr(theta_col), C.c_double(loss_param)), "solve_irls")
+                                         C.c_double(irls_tol), _dptr(theta_row), _dptr(theta_col), C.c_double(loss_param),
+                                         C.c_double(robust_delta)), "solve_irls")
 
-    def irls_loss(self, dt, loss_type, col_ptr, row_idx, values, ncols, W_T, d, H, theta_row, k, out, loss_param=0.0):
+    def irls_loss(self, dt, loss_type, col_ptr, row_idx, values, ncols, W_T, d, H, theta_row, k, out, loss_param=0.0, robust_delta=0.0):
         _chk(lib().rcppml_hip_irls_loss(self._h, C.c_int(dt), C.c_int(loss_type), _dptr(col_ptr), _dptr(row_idx), _dptr(values),
                                         C.c_int64(ncols), _dptr(W_T), _dptr(d), _dptr(H), _dptr(theta_row), C.c_int(k),
-                                        C.c_double(loss_param), _dptr(out)), "irls_loss")
+                                        C.c_double(loss_param), C.c_double(robust_delta), _dptr(out)), "irls_loss")
 
     def apply_l21(self, dt, G, X, k, ncols, lam):
         _chk(lib().rcppml_hip_apply_l21(self._h, C.c_int(dt), _dptr(G), _dptr(X), C.c_int(k), C.c_int64(ncols), C.c_double(lam)), "apply_l21")

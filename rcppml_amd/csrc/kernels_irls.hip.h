@@ -67,12 +67,25 @@ template <class T> __device__ __forceinline__ T irls_weight_dev(int loss_type, T
     return irls_weight_nb_dev<T>(predicted, theta);
 }
 
+// nnls_batch_irls.hpp:95-120  compute_irls_weight: distribution weight (1 for loss_type 0 = MSE) x Huber modifier of
+// the Pearson residual when robust_delta > 0 (math/loss.hpp:294-303)
+template <class T> __device__ __forceinline__ T irls_weight_full_dev(int loss_type, T residual, T predicted, T theta, T power,
+                                                                     T robust) {
+    const T w_dist = loss_type == 0 ? T(1) : irls_weight_dev<T>(loss_type, predicted, theta, power);
+    if (robust > T(0)) {
+        const T wd = w_dist > T(1e-15) ? w_dist : T(1e-15);
+        const T abs_r = tabs(residual * sqrt(wd));
+        return abs_r <= robust ? w_dist : w_dist * (robust / (abs_r + T(1e-15)));
+    }
+    return w_dist;
+}
+
 template <class T, int KP>   // KP in {32, 64}: features padded to KP (k <= KP), lane r = feature r
 __global__ __launch_bounds__(256) void irls_nb_solve_kernel(
     const int* __restrict__ colptr, const int* __restrict__ rowidx, const T* __restrict__ vals, int64_t ncols,
     const T* __restrict__ F, const T* __restrict__ Gbase, T* __restrict__ X, int k, T l1, T l2, int nonneg,
     int cd_maxit, int irls_max_iter, T irls_tol, const T* __restrict__ theta_row, const T* __restrict__ theta_col,
-    int loss_type, T power) {
+    int loss_type, T power, T robust) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     T* Gl = reinterpret_cast<T*>(smem_raw) + (size_t)wave * KP * KP;    // [c][r]
@@ -99,7 +112,7 @@ __global__ __launch_bounds__(256) void irls_nb_solve_kernel(
             const T fr = fok ? F[(int64_t)row * k + lane] : T(0);
             const T recon = wave_sum(fr * x);                                   // W_T.col(row).dot(x)
             const T th = theta_col ? th_col : (theta_row ? theta_row[row] : T(0));
-            const T w = irls_weight_dev<T>(loss_type, recon, th, power);
+            const T w = irls_weight_full_dev<T>(loss_type, a - recon, recon, th, power, robust);
             const T dw = w - T(1);
             const T wv = w * a;
             const T frd = fr * dw;                                              // W_nnz_scaled.col = W_block.col * dw
@@ -173,7 +186,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     const int* __restrict__ colptr, const int* __restrict__ rowidx, const float* __restrict__ vals, int64_t ncols,
     const float* __restrict__ F, const float* __restrict__ Gbase, float* __restrict__ X, int k, float l1, float l2,
     int nonneg, int cd_maxit, int irls_max_iter, float irls_tol, const float* __restrict__ theta_row,
-    const float* __restrict__ theta_col, int loss_type, float power) {
+    const float* __restrict__ theta_col, int loss_type, float power, float robust) {
     constexpr int KP = 32, CH = 32, FS = 36;          // FS: padded row stride of the staged F rows (bank spread)
     constexpr int WAVE_FLOATS = CH * FS + 2 * CH + KP;  // staged rows | (w-1, w a) pairs | x
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -222,7 +235,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
             }
             const float recon = part + __shfl_xor(part, 32, 64);                 // W_T.col(row).dot(x)
             const float th = theta_col ? th_col : (theta_row ? theta_row[row] : 0.f);
-            const float w = irls_weight_dev<float>(loss_type, recon, th, power);
+            const float w = irls_weight_full_dev<float>(loss_type, a - recon, recon, th, power, robust);
 #pragma unroll
             for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(Fst + r * FS + 16 * hh + 4 * q) = fv4[q];
             if (hh == 0) sc[r] = make_float2(ok ? w - 1.f : 0.f, ok ? w * a : 0.f);
@@ -301,7 +314,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     const int* __restrict__ colptr, const int* __restrict__ rowidx, const double* __restrict__ vals, int64_t ncols,
     const double* __restrict__ F, const double* __restrict__ Gbase, double* __restrict__ X, int k, double l1, double l2,
     int nonneg, int cd_maxit, int irls_max_iter, double irls_tol, const double* __restrict__ theta_row,
-    const double* __restrict__ theta_col, int loss_type, double power) {
+    const double* __restrict__ theta_col, int loss_type, double power, double robust) {
     constexpr int KP = 32, CH = 32, FS = 34;          // FS: padded row stride (doubles) of the staged F rows
     constexpr int WAVE_DOUBLES = CH * FS + 2 * CH + KP;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -352,7 +365,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
             }
             const double recon = part + __shfl_xor(part, 32, 64);
             const double th = theta_col ? th_col : (theta_row ? theta_row[row] : 0.0);
-            const double w = irls_weight_dev<double>(loss_type, recon, th, power);
+            const double w = irls_weight_full_dev<double>(loss_type, a - recon, recon, th, power, robust);
 #pragma unroll
             for (int q = 0; q < 8; ++q) *reinterpret_cast<double2*>(Fst + r * FS + 16 * hh + 2 * q) = fv2[q];
             if (hh == 0) sc[r] = make_double2(ok ? w - 1.0 : 0.0, ok ? w * a : 0.0);
@@ -506,7 +519,7 @@ template <class T>
 __global__ __launch_bounds__(256) void nb_loss_lane_kernel(
     const int* __restrict__ colptr, const int* __restrict__ rowidx, const T* __restrict__ vals, int64_t ncols,
     const T* __restrict__ W_T, const T* __restrict__ d, const T* __restrict__ H, const T* __restrict__ theta_row, int k,
-    int vec_ok, int loss_type, double power, double* __restrict__ partial) {
+    int vec_ok, int loss_type, double power, double robust, double* __restrict__ partial) {
     constexpr int VEC = 16 / sizeof(T);
     typedef typename VecT<T, VEC>::type V;
     __shared__ double sh[4];
@@ -538,7 +551,24 @@ __global__ __launch_bounds__(256) void nb_loss_lane_kernel(
             mu = mu > 1e-10 ? mu : 1e-10;
             const double th = static_cast<double>(theta_row ? theta_row[row] : T(0));
             double nll;
-            if (loss_type == 4) {                  // math/loss.hpp:382-398  loss_contribution_gp
+            if (robust > 0.0) {                    // math/loss.hpp:549-607  compute_robust_loss, in Scalar arithmetic
+                const T muS = pred > T(1e-10) ? pred : T(1e-10);
+                const T resid = vals[t] - muS;
+                const T thS = theta_row ? theta_row[row] : T(0);
+                T var_mu;
+                if (loss_type == 4 || loss_type == 3) var_mu = muS;
+                else if (loss_type == 5) { const T r = thS > T(1e-10) ? thS : T(1e-10); var_mu = muS + muS * muS / r; }
+                else if (loss_type == 6) var_mu = muS * muS;
+                else if (loss_type == 7) var_mu = muS * muS * muS;
+                else if (loss_type == 8) var_mu = static_cast<T>(pow(static_cast<double>(muS), power));
+                else var_mu = T(1);
+                const T sd = sqrt(var_mu > T(1e-20) ? var_mu : T(1e-20));
+                const T pr = resid / sd;
+                const T apr = tabs(pr);
+                const T dl = static_cast<T>(robust);
+                const T rho = apr <= dl ? T(0.5) * pr * pr : dl * apr - T(0.5) * dl * dl;
+                nll = static_cast<double>(rho);
+            } else if (loss_type == 4) {           // math/loss.hpp:382-398  loss_contribution_gp
                 const double opt = 1.0 + th;
                 nll = -log(mu / opt);
                 if (y >= 1.0) {

@@ -9,9 +9,10 @@ using namespace rk;
 template <class T>
 static void irls_impl(rcppml_hip_ctx* c, const int* cp, const int* ri, const T* vals, int64_t ncols, const T* F,
                       const T* Gbase, T* X, int k, T l1, T l2, int nonneg, int cd_maxit, int irls_max_iter, T irls_tol,
-                      const T* theta_row, const T* theta_col, int loss_type, T power) {
+                      const T* theta_row, const T* theta_col, int loss_type, T power, T robust) {
     if (ncols <= 0) return;
-    if (loss_type < 4 || loss_type > 8) throw std::runtime_error("solve_irls: loss_type must be 4 (GP), 5 (NB), 6 (Gamma), 7 (inverse Gaussian) or 8 (Tweedie)");
+    if (!((loss_type >= 4 && loss_type <= 8) || (loss_type == 0 && robust > T(0))))
+        throw std::runtime_error("solve_irls: loss_type must be 4 (GP), 5 (NB), 6 (Gamma), 7 (inverse Gaussian), 8 (Tweedie), or 0 (MSE) with robust_delta > 0");
     if (k < 1 || k > 64) throw std::runtime_error("solve_irls_nb: k must be in [1,64]");
     const int64_t nblk = (ncols + 3) / 4;
     if constexpr (std::is_same<T, float>::value) {
@@ -21,7 +22,7 @@ static void irls_impl(rcppml_hip_ctx* c, const int* cp, const int* ri, const T* 
         if (use_mfma && k <= 32 && k % 4 == 0 && reinterpret_cast<uintptr_t>(F) % 16 == 0) {
             const size_t smem = (size_t)4 * (32 * 36 + 2 * 32 + 32) * sizeof(float);
             hipLaunchKernelGGL(irls_nb_mfma32_kernel, dim3((unsigned)nblk), dim3(256), smem, c->stream, cp, ri, vals, ncols, F,
-                               Gbase, X, k, l1, l2, nonneg, cd_maxit, irls_max_iter, irls_tol, theta_row, theta_col, loss_type, power);
+                               Gbase, X, k, l1, l2, nonneg, cd_maxit, irls_max_iter, irls_tol, theta_row, theta_col, loss_type, power, robust);
             HIPCHK(hipGetLastError());
             return;
         }
@@ -32,7 +33,7 @@ static void irls_impl(rcppml_hip_ctx* c, const int* cp, const int* ri, const T* 
         if (use_mfma64 && k <= 32 && k % 2 == 0 && reinterpret_cast<uintptr_t>(F) % 16 == 0) {
             const size_t smem = (size_t)4 * (32 * 34 + 2 * 32 + 32) * sizeof(double);
             hipLaunchKernelGGL(irls_nb_mfma64_kernel, dim3((unsigned)nblk), dim3(256), smem, c->stream, cp, ri, vals, ncols, F,
-                               Gbase, X, k, l1, l2, nonneg, cd_maxit, irls_max_iter, irls_tol, theta_row, theta_col, loss_type, power);
+                               Gbase, X, k, l1, l2, nonneg, cd_maxit, irls_max_iter, irls_tol, theta_row, theta_col, loss_type, power, robust);
             HIPCHK(hipGetLastError());
             return;
         }
@@ -40,31 +41,32 @@ static void irls_impl(rcppml_hip_ctx* c, const int* cp, const int* ri, const T* 
     if (k <= 32) {      // 32-wide instantiation: half the rank-1 work per nonzero, 16 KB of LDS per block (8 waves per SIMD)
         const size_t smem = (size_t)4 * 32 * 32 * sizeof(T);
         hipLaunchKernelGGL((irls_nb_solve_kernel<T, 32>), dim3((unsigned)nblk), dim3(256), smem, c->stream, cp, ri, vals, ncols,
-                           F, Gbase, X, k, l1, l2, nonneg, cd_maxit, irls_max_iter, irls_tol, theta_row, theta_col, loss_type, power);
+                           F, Gbase, X, k, l1, l2, nonneg, cd_maxit, irls_max_iter, irls_tol, theta_row, theta_col, loss_type, power, robust);
     } else {
         const size_t smem = (size_t)4 * 64 * 64 * sizeof(T);
         auto kern = irls_nb_solve_kernel<T, 64>;
         static DynSmemOnce once;
         once.ensure(reinterpret_cast<const void*>(kern), smem, c->device);
         hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), smem, c->stream, cp, ri, vals, ncols, F, Gbase, X, k, l1, l2,
-                           nonneg, cd_maxit, irls_max_iter, irls_tol, theta_row, theta_col, loss_type, power);
+                           nonneg, cd_maxit, irls_max_iter, irls_tol, theta_row, theta_col, loss_type, power, robust);
     }
     HIPCHK(hipGetLastError());
 }
 extern "C" int rcppml_hip_solve_irls(rcppml_hip_ctx* c, int dtype, int loss_type, const int* col_ptr, const int* row_idx,
                                      const void* values, int64_t ncols, const void* F, const void* G_base, void* X,
                                      int k, double l1, double l2, int nonneg, int cd_maxit, int irls_max_iter,
-                                     double irls_tol, const void* theta_row, const void* theta_col, double loss_param) {
+                                     double irls_tol, const void* theta_row, const void* theta_col, double loss_param,
+                                     double robust_delta) {
     try {
         HIPCHK(hipSetDevice(c->device));
         if (dtype == RCPPML_F32)
             irls_impl<float>(c, col_ptr, row_idx, (const float*)values, ncols, (const float*)F, (const float*)G_base,
                              (float*)X, k, (float)l1, (float)l2, nonneg, cd_maxit, irls_max_iter, (float)irls_tol,
-                             (const float*)theta_row, (const float*)theta_col, loss_type, (float)loss_param);
+                             (const float*)theta_row, (const float*)theta_col, loss_type, (float)loss_param, (float)robust_delta);
         else
             irls_impl<double>(c, col_ptr, row_idx, (const double*)values, ncols, (const double*)F, (const double*)G_base,
                               (double*)X, k, l1, l2, nonneg, cd_maxit, irls_max_iter, irls_tol, (const double*)theta_row,
-                              (const double*)theta_col, loss_type, loss_param);
+                              (const double*)theta_col, loss_type, loss_param, robust_delta);
         return 0;
     }
     RCPPML_CATCH_RET
@@ -74,7 +76,7 @@ extern "C" int rcppml_hip_solve_irls_nb(rcppml_hip_ctx* c, int dtype, const int*
                                         int k, double l1, double l2, int nonneg, int cd_maxit, int irls_max_iter,
                                         double irls_tol, const void* theta_row, const void* theta_col) {
     return rcppml_hip_solve_irls(c, dtype, 5, col_ptr, row_idx, values, ncols, F, G_base, X, k, l1, l2, nonneg, cd_maxit,
-                                 irls_max_iter, irls_tol, theta_row, theta_col, 0.0);
+                                 irls_max_iter, irls_tol, theta_row, theta_col, 0.0, 0.0);
 }
 
 template <class T>
@@ -109,30 +111,31 @@ extern "C" int rcppml_hip_nb_size_update(rcppml_hip_ctx* c, int dtype, const int
 
 template <class T>
 static void nb_loss_impl(rcppml_hip_ctx* c, const int* cp, const int* ri, const T* vals, int64_t ncols, const T* W_T,
-                         const T* d, const T* H, const T* theta_row, int k, double* out, int loss_type, double power) {
+                         const T* d, const T* H, const T* theta_row, int k, double* out, int loss_type, double power, double robust) {
     const int64_t nblk = ncols > 0 ? (ncols + 3) / 4 : 1;
     double* partial = static_cast<double*>(c->scratch(WS_RED2, (size_t)nblk * sizeof(double)));
     constexpr int VEC = 16 / (int)sizeof(T);
     const int vec_ok = (k % VEC == 0 && reinterpret_cast<uintptr_t>(W_T) % 16 == 0) ? 1 : 0;
     hipLaunchKernelGGL(nb_loss_lane_kernel<T>, dim3((unsigned)nblk), dim3(256), 0, c->stream, cp, ri, vals, ncols, W_T, d, H,
-                       theta_row, k, vec_ok, loss_type, power, partial);
+                       theta_row, k, vec_ok, loss_type, power, robust, partial);
     HIPCHK(hipGetLastError());
     hipLaunchKernelGGL(sum_partials, dim3(1), dim3(256), 0, c->stream, partial, (int)nblk, out);
     HIPCHK(hipGetLastError());
 }
 extern "C" int rcppml_hip_irls_loss(rcppml_hip_ctx* c, int dtype, int loss_type, const int* col_ptr, const int* row_idx,
                                     const void* values, int64_t ncols, const void* W_T, const void* d, const void* H,
-                                    const void* theta_row, int k, double loss_param, double* out) {
+                                    const void* theta_row, int k, double loss_param, double robust_delta, double* out) {
     try {
         HIPCHK(hipSetDevice(c->device));
         if (k < 1 || k > 64) throw std::runtime_error("irls_loss: k must be in [1,64]");
-        if (loss_type < 4 || loss_type > 8) throw std::runtime_error("irls_loss: loss_type must be in 4..8");
+        if (!((loss_type >= 4 && loss_type <= 8) || (loss_type == 0 && robust_delta > 0)))
+            throw std::runtime_error("irls_loss: loss_type must be in 4..8, or 0 with robust_delta > 0");
         if (dtype == RCPPML_F32)
             nb_loss_impl<float>(c, col_ptr, row_idx, (const float*)values, ncols, (const float*)W_T, (const float*)d,
-                                (const float*)H, (const float*)theta_row, k, out, loss_type, loss_param);
+                                (const float*)H, (const float*)theta_row, k, out, loss_type, loss_param, robust_delta);
         else
             nb_loss_impl<double>(c, col_ptr, row_idx, (const double*)values, ncols, (const double*)W_T, (const double*)d,
-                                 (const double*)H, (const double*)theta_row, k, out, loss_type, loss_param);
+                                 (const double*)H, (const double*)theta_row, k, out, loss_type, loss_param, robust_delta);
         return 0;
     }
     RCPPML_CATCH_RET
@@ -140,5 +143,5 @@ extern "C" int rcppml_hip_irls_loss(rcppml_hip_ctx* c, int dtype, int loss_type,
 extern "C" int rcppml_hip_nb_loss(rcppml_hip_ctx* c, int dtype, const int* col_ptr, const int* row_idx, const void* values,
                                   int64_t ncols, const void* W_T, const void* d, const void* H, const void* theta_row, int k,
                                   double* out) {
-    return rcppml_hip_irls_loss(c, dtype, 5, col_ptr, row_idx, values, ncols, W_T, d, H, theta_row, k, 0.0, out);
+    return rcppml_hip_irls_loss(c, dtype, 5, col_ptr, row_idx, values, ncols, W_T, d, H, theta_row, k, 0.0, 0.0, out);
 }

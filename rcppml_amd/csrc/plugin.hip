@@ -75,6 +75,7 @@ struct FitParams {
     double* loss_history;                    // may be NULL
     int loss_type = 0;                       // 0 = MSE, 4 = GP, 5 = NB, 6 = Gamma, 7 = inverse Gaussian, 8 = Tweedie
     double tweedie_power = 1.5;
+    double robust_delta = 0;                 // > 0: Huber modifier on Pearson residuals (all losses -> IRLS path)
     int irls_max_iter = 5; double irls_tol = 1e-4;
     int dispersion_mode = 2;                 // 0 none, 1 global, 2 per-row
     double nb_size_init = 10, nb_size_max = 1e6, nb_size_min = 0.01;
@@ -176,8 +177,8 @@ void fit(FitParams& P) {
     const bool use_order = P.solver_mode == 0 && !has_mask && P.loss_type == 0 && P.cd_tol > 0 && !getenv("RCPPML_GPU_NO_ORDER");
 
     const bool is_pow = P.loss_type >= 6;                               // phi_vec = 1 for dispersion none (fit_cpu.hpp:336-347)
-    const bool is_gp = P.loss_type == 4 || is_pow;                      // theta_vec = Zero(m) (:297-304); "no theta in the solve"
-    const bool is_nb = P.loss_type == 5 || is_gp;                       // "is_irls": all of them run the IRLS half-updates
+    const bool is_gp = P.loss_type == 4 || is_pow || P.loss_type == 0;  // theta_vec = Zero(m) (:297-304); "no theta in the solve"
+    const bool is_nb = P.loss_type == 5 || (is_gp && (P.loss_type != 0 || P.robust_delta > 0));   // "is_irls": requires_irls()
     DevBuf dtheta;
     if (is_nb) {                                                        // fit_cpu.hpp:316-328
         std::vector<T> th((size_t)m, is_pow ? T(1) : is_gp ? T(0) : static_cast<T>(P.dispersion_mode == 0 ? P.nb_size_max : P.nb_size_init));
@@ -201,7 +202,7 @@ void fit(FitParams& P) {
             OPCHK(rcppml_hip_gram(c, dt, dW.p, k, m, eps, 0.0, dG.p));
             OPCHK(rcppml_hip_solve_irls(c, dt, P.loss_type, dAp.as<int>(), dAi.as<int>(), dAx.p, n, dW.p, dG.p, dH.p, k, P.L1_H,
                                         P.L2_H, P.nonneg_H, P.cd_maxit, P.irls_max_iter, P.irls_tol,
-                                        is_gp ? nullptr : dtheta.p, nullptr, P.tweedie_power));
+                                        is_gp ? nullptr : dtheta.p, nullptr, P.tweedie_power, P.robust_delta));
             if (P.ub_H > 0) throw std::runtime_error("upper bound with NB loss: not supported");
         } else if (has_mask) {
             OPCHK(rcppml_hip_gram(c, dt, dW.p, k, m, eps, 0.0, dG.p));                 // :562 unmodified G
@@ -232,7 +233,7 @@ void fit(FitParams& P) {
             OPCHK(rcppml_hip_gram(c, dt, dH.p, k, n, eps, 0.0, dG.p));
             OPCHK(rcppml_hip_solve_irls(c, dt, P.loss_type, dTp.as<int>(), dTi.as<int>(), dTx.p, m, dH.p, dG.p, dW.p, k, P.L1_W,
                                         P.L2_W, P.nonneg_W, P.cd_maxit, P.irls_max_iter, P.irls_tol, nullptr,
-                                        is_gp ? nullptr : dtheta.p, P.tweedie_power));
+                                        is_gp ? nullptr : dtheta.p, P.tweedie_power, P.robust_delta));
         } else if (has_mask) {
             OPCHK(rcppml_hip_gram(c, dt, dH.p, k, n, eps, 0.0, dG.p));
             OPCHK(rcppml_hip_solve_masked(c, dt, dTp.as<int>(), dTi.as<int>(), dTx.p, dMTp.as<int>(), dMTi.as<int>(),
@@ -274,7 +275,7 @@ void fit(FitParams& P) {
             }
         }
         if (is_nb) {
-            OPCHK(rcppml_hip_irls_loss(c, dt, P.loss_type, dAp.as<int>(), dAi.as<int>(), dAx.p, n, dW.p, dd.p, dH.p, dtheta.p, k, P.tweedie_power, dloss.as<double>()));
+            OPCHK(rcppml_hip_irls_loss(c, dt, P.loss_type, dAp.as<int>(), dAi.as<int>(), dAx.p, n, dW.p, dd.p, dH.p, dtheta.p, k, P.tweedie_power, P.robust_delta, dloss.as<double>()));
         } else if (has_mask) {
             OPCHK(rcppml_hip_loss_nonzeros(c, dt, dAp.as<int>(), dAi.as<int>(), dAx.p, dMp.as<int>(), dMi.as<int>(), n,
                                            dW.p, dd.p, dH.p, k, dloss.as<double>()));
@@ -397,7 +398,12 @@ void nmf_entry(RCPPML_NMF_UNIFIED_ARGS, const int* mask_p, const int* mask_i, do
             if (*solver_mode != 0) throw std::runtime_error("NB loss requires the CD solver");      // core/config.hpp:447-452
             if (mask_p) throw std::runtime_error("NB loss with explicit mask: not supported");
         }
-        if (*robust_delta > 0) throw std::runtime_error("robust loss not supported");
+        if (*robust_delta > 0) {   // Huber on Pearson residuals: every loss (MSE included) goes through the IRLS path
+            if (*k > 64) throw std::runtime_error("robust loss: k must be <= 64");
+            if (*solver_mode != 0) throw std::runtime_error("robust loss requires the CD solver");
+            if (mask_p) throw std::runtime_error("robust loss with explicit mask: not supported");
+            if (*L21_H != 0 || *L21_W != 0 || *ortho_H != 0 || *ortho_W != 0) throw std::runtime_error("robust loss with L21 / angular: not supported");
+        }
         if ((*L21_H != 0 || *L21_W != 0 || *ortho_H != 0 || *ortho_W != 0) && (*loss_type != 0 || mask_p))
             throw std::runtime_error("L21 / angular penalties are implemented for the MSE path without explicit mask");
         if ((*ortho_H != 0 || *ortho_W != 0) && *k > 64) throw std::runtime_error("angular penalty: k must be <= 64");
@@ -425,7 +431,7 @@ void nmf_entry(RCPPML_NMF_UNIFIED_ARGS, const int* mask_p, const int* mask_i, do
         P.sort_model = sort_model; P.loss_history = loss_history;
         P.loss_type = *loss_type; P.irls_max_iter = *irls_max_iter; P.irls_tol = *irls_tol;
         P.dispersion_mode = *gp_dispersion_mode; P.nb_size_init = *nb_size_init; P.nb_size_max = *nb_size_max;
-        P.nb_size_min = *nb_size_min; P.out_theta = out_theta; P.tweedie_power = *tweedie_power;
+        P.nb_size_min = *nb_size_min; P.out_theta = out_theta; P.tweedie_power = *tweedie_power; P.robust_delta = *robust_delta;
         if (precision == RCPPML_F64) fit<double>(P); else fit<float>(P);
         *out_iter = P.out_iter; *out_converged = P.out_converged; *out_loss = P.out_loss; *out_tol = P.out_tol;
         *out_theta_len = P.out_theta_len;

@@ -20,7 +20,9 @@ for f, t in ((loss.ref_irls_weight_nb_f64, C.c_double), (loss.ref_loss_nb_f64, C
              (loss.ref_irls_weight_kl_f64, C.c_double), (loss.ref_irls_weight_kl_f32, C.c_float),
              (loss.ref_loss_gp_f64, C.c_double), (loss.ref_loss_gp_f32, C.c_float),
              (loss.ref_irls_weight_power_f64, C.c_double), (loss.ref_irls_weight_power_f32, C.c_float),
-             (loss.ref_loss_dev_f64, C.c_double), (loss.ref_loss_dev_f32, C.c_float)):
+             (loss.ref_loss_dev_f64, C.c_double), (loss.ref_loss_dev_f32, C.c_float),
+             (loss.ref_robust_modifier_f64, C.c_double), (loss.ref_robust_modifier_f32, C.c_float),
+             (loss.ref_robust_loss_f64, C.c_double), (loss.ref_robust_loss_f32, C.c_float)):
     f.restype = t
 
 out = {}
@@ -87,5 +89,19 @@ out["dev_f64"] = np.array([loss.ref_loss_dev_f64(C.c_int(int(t)), C.c_double(y),
                            for t, y, a, b in zip(LT.ravel(), Yd.ravel(), Pd.ravel(), Wd.ravel())])
 out["dev_f32"] = np.array([loss.ref_loss_dev_f32(C.c_int(int(t)), C.c_float(y), C.c_float(a), C.c_float(b))
                            for t, y, a, b in zip(LT.ravel(), Yd.ravel(), Pd.ravel(), Wd.ravel())], dtype=np.float32)
+# robust: Huber modifier of the Pearson residual and the robust loss for every implemented distribution (0 = MSE)
+rr = np.array([-50.0, -1.345, -0.3, 0.0, 1e-9, 0.7, 1.345, 2.0, 1e4])
+dl = np.array([1e-4, 1.345, 3.0])
+Rr, Dl = np.meshgrid(rr, dl, indexing="ij")
+out["rob_r"], out["rob_delta"] = Rr.ravel(), Dl.ravel()
+out["rob_mod_f64"] = np.array([loss.ref_robust_modifier_f64(C.c_double(a), C.c_double(b)) for a, b in zip(Rr.ravel(), Dl.ravel())])
+out["rob_mod_f32"] = np.array([loss.ref_robust_modifier_f32(C.c_float(a), C.c_float(b)) for a, b in zip(Rr.ravel(), Dl.ravel())], dtype=np.float32)
+T_, Y_, P_, D_ = np.meshgrid(np.array([0, 4, 5, 6, 7, 8]), np.array([0.0, 1.0, 3.0, 40.0]), np.array([1e-12, 0.01, 1.0, 3.7, 1e3]),
+                             np.array([0.5, 1.345]), indexing="ij")
+out["rl_type"], out["rl_obs"], out["rl_pred"], out["rl_delta"] = T_.ravel(), Y_.ravel(), P_.ravel(), D_.ravel()
+out["rl_f64"] = np.array([loss.ref_robust_loss_f64(C.c_int(int(t)), C.c_double(y), C.c_double(p_), C.c_double(5.0), C.c_double(1.5), C.c_double(d_))
+                          for t, y, p_, d_ in zip(T_.ravel(), Y_.ravel(), P_.ravel(), D_.ravel())])
+out["rl_f32"] = np.array([loss.ref_robust_loss_f32(C.c_int(int(t)), C.c_float(y), C.c_float(p_), C.c_float(5.0), C.c_float(1.5), C.c_float(d_))
+                          for t, y, p_, d_ in zip(T_.ravel(), Y_.ravel(), P_.ravel(), D_.ravel())], dtype=np.float32)
 np.savez_compressed(os.path.join(here, "ref_vectors.npz"), **out)
 print("wrote ref_vectors.npz:", {k2: v.shape for k2, v in out.items()})

@@ -234,3 +234,53 @@ def test_power_family_fit_through_plugin(loss, loss_type, power):
     assert model.misc["loss_type"] == loss and np.isfinite(model.misc["loss"])
     with pytest.raises(NotImplementedError):
         N.nmf(CSC((A.rows, A.cols), A.p, A.i, A.x), k, loss=loss, dispersion="per_row", seed=3, maxit=2)
+
+
+@pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-6), (np.float32, 3e-2)])
+@pytest.mark.parametrize("loss_type", [0, 4, 5, 6])
+def test_irls_robust_half_update_and_loss(env, dtype, tol, loss_type):
+    """robust_delta > 0: every distribution weight is multiplied by the Huber modifier of the Pearson residual
+    (nnls_batch_irls.hpp:95-120) and the loss becomes the Huber rho of that residual (math/loss.hpp:549-607); loss_type 0
+    (MSE) is routed through the IRLS path.  Oracle pieces pinned to the reference in tests/test_oracle_ref.py."""
+    torch, _abi, ctx = env
+    k, delta = 12, 1.345
+    A = _positive_problem(150, 220, seed=40 + loss_type)
+    rng = np.random.default_rng(loss_type + 7)
+    dt = _abi.F32 if dtype == np.float32 else _abi.F64
+    tt = torch.float32 if dtype == np.float32 else torch.float64
+    F = rng.uniform(0.05, 1.0, size=(A.rows, k)).astype(dtype)
+    F /= F.sum(axis=0, keepdims=True)
+    F *= 30.0
+    G = O.gram(F)
+    theta = rng.uniform(2.0, 20.0, size=A.rows).astype(dtype)
+    th_arg = theta if loss_type == 5 else None
+    ref = O.irls(loss_type, A, F, G, k, L1=0.0, L2=1e-3, theta_row=th_arg, dtype=dtype, robust=delta)
+    dX = torch.full((A.cols, k), 3.0, dtype=tt, device="cuda")
+    ctx.solve_irls(dt, loss_type, _dev(torch, A.p), _dev(torch, A.i), _dev(torch, A.values(dtype)), A.cols, _dev(torch, F),
+                   _dev(torch, G), dX, k, l1=0.0, l2=1e-3, theta_row=_dev(torch, theta) if loss_type == 5 else None,
+                   robust_delta=delta)
+    X = dX.cpu().numpy()
+    assert X.min() >= 0 and np.all(np.isfinite(X))
+    assert np.abs(X - ref).max() / np.abs(ref).max() < tol
+    d = rng.uniform(0.5, 2.0, size=k).astype(dtype)
+    lref = O.irls_loss(loss_type, A, F, d, X.astype(dtype), theta, dtype=dtype, robust=delta)
+    out = torch.zeros((1,), dtype=torch.float64, device="cuda")
+    ctx.irls_loss(dt, loss_type, _dev(torch, A.p), _dev(torch, A.i), _dev(torch, A.values(dtype)), A.cols, _dev(torch, F),
+                  _dev(torch, d), _dev(torch, X.astype(dtype)), _dev(torch, theta), k, out, robust_delta=delta)
+    assert abs(float(out.item()) - lref) <= (1e-9 if dtype == np.float64 else 2e-3) * abs(lref)
+
+
+@pytest.mark.parametrize("loss_type", [0, 5])
+def test_robust_fit_through_plugin(loss_type):
+    from rcppml_amd import _abi
+    A = _nb_problem(100, 160, 3, seed=23)
+    k = 5
+    W0, H0 = O.init_factors(11, k, A.rows, A.cols, np.float64)
+    ref = O.nmf_fit(A, W0, H0, np.float64, max_iter=5, tol=0.0, loss_type=loss_type, dispersion_mode=2, threads=1, robust_delta=1.345)
+    W, H = W0.copy(), H0.copy()
+    res = _abi.nmf_unified(A.p, A.i, A.x, A.rows, A.cols, k, W, H, entry="double", max_iter=5, tol=0.0, loss_type=loss_type,
+                           gp_dispersion_mode=2, robust_delta=1.345)
+    assert res["status"] == 0, res.get("error")
+    assert res["iter"] == ref.iter
+    assert abs(res["loss"] - ref.loss) / abs(ref.loss) < 1e-4
+    assert np.abs(W - ref.W_T).max() < 1e-3 and np.abs(H - ref.H).max() < 1e-3
