@@ -221,6 +221,25 @@ RCPPML_GPU_API int rcppml_hip_loss_nonzeros(rcppml_hip_ctx* ctx, int dtype, cons
                                             const void* W_T, const void* d, const void* H, int k,
                                             double* out);
 
+/* Cross-validation (reference nmf/fit_cv.hpp, nmf/cv_detail.hpp, nmf/speckled_cv.hpp).  The held-out
+ * set is the lazy speckled mask  SplitMix64::hash(seed, i, j) < UINT64_MAX / floor(1 / holdout_fraction)  with
+ * seed = (uint32) cv_seed (0 -> 12345) and (i, j) the coordinates in A (rng/rng.hpp:129-170); no mask matrix exists.
+ * rcppml_hip_solve_cv: one CV half-update over the columns of the CSC handed in (A for H, A^T with transposed = 1 for
+ *   W; nrows = its row count): b = sum over the column's TRAIN nonzeros, G_local = G - sum over its TEST rows f f^T
+ *   (mask_zeros = 1: held-out nonzeros only; 0: every held-out row, zeros included), then Cholesky+clip (solver_mode 1,
+ *   L1 subtracted from b) or CD (solver_mode 0: L1 inside, cd_maxit sweeps, no tolerance) started from the current X
+ *   without a warm-start correction -- fit_cv.hpp:420-478,591-830.  k <= 64.
+ * rcppml_hip_cv_test_error: out2[0] = sum of squared errors, out2[1] = count over the held-out entries of A
+ *   (prediction W diag(d) H; fit_cv.hpp:1444-1494). */
+RCPPML_GPU_API int rcppml_hip_solve_cv(rcppml_hip_ctx* ctx, int dtype, const int* col_ptr, const int* row_idx,
+                                       const void* values, int64_t ncols, int nrows, const void* F, const void* G, void* X,
+                                       int k, double holdout_fraction, unsigned long long cv_seed, int mask_zeros,
+                                       int transposed, double l1, int nonneg, int cd_maxit, int solver_mode);
+RCPPML_GPU_API int rcppml_hip_cv_test_error(rcppml_hip_ctx* ctx, int dtype, const int* col_ptr, const int* row_idx,
+                                            const void* values, int64_t ncols, int nrows, const void* W_T, const void* d,
+                                            const void* H, int k, double holdout_fraction, unsigned long long cv_seed,
+                                            int mask_zeros, double* out2);
+
 /* k x k feature layer, fused-path placement of nmf/fit_cpu.hpp:505-511,636-639 / :738-745,884-887:
  * rcppml_hip_apply_l21: G(i,i) += lambda / ||X.row(i)||_2 for rows with norm > 1e-10 (features/L21.hpp:38-51); X is the
  *   CURRENT factor (k x ncols), applied to the Gram before the solve.

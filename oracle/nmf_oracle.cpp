@@ -198,6 +198,218 @@ static void masked_nnls(const Csc<S>& A, const S* F, const S* G_full, S* X, cons
     }
 }
 
+// ---------------------------------------------------------------------------
+// Cross-validation path (nmf/fit_cv.hpp, nmf/cv_detail.hpp, nmf/speckled_cv.hpp), MSE, sparse A, no user mask.
+// ---------------------------------------------------------------------------
+// rng/rng.hpp:129-170  SplitMix64::hash / is_holdout; speckled_cv.hpp:57-83 LazySpeckledMask (no subsampling)
+struct SpeckledMask {
+    uint64_t seed, inv_prob, threshold;
+    bool mask_zeros;
+    SpeckledMask(double holdout_fraction, uint64_t cv_seed, bool mz) {
+        seed = static_cast<uint32_t>(cv_seed) == 0 ? 12345ULL : static_cast<uint32_t>(cv_seed);
+        inv_prob = holdout_fraction > 0 ? static_cast<uint64_t>(1.0 / holdout_fraction) : 0;
+        threshold = inv_prob ? UINT64_MAX / inv_prob : 0;
+        mask_zeros = mz;
+    }
+    static uint64_t hash(uint64_t seed, uint32_t i, uint32_t j) {
+        uint64_t h = seed + static_cast<uint64_t>(i) * 0x9e3779b97f4a7c15ULL + static_cast<uint64_t>(j) * 0x6c62272e07bb0142ULL;
+        h = (h ^ (h >> 30)) * 0xbf58476d1ce4e5b9ULL;
+        h = (h ^ (h >> 27)) * 0x94d049bb133111ebULL;
+        return h ^ (h >> 31);
+    }
+    // (i, j) always in the coordinates of A, also on the W side
+    bool is_holdout(int i, int j) const { return inv_prob != 0 && hash(seed, (uint32_t)i, (uint32_t)j) < threshold; }
+};
+
+// One half-update of the CV path: fit_cv.hpp:420-478 (H side: data = A, columns j, F = W_T) / :591-830 (W side:
+// data = A^T, "columns" = rows i of A, F = H; `transposed` swaps the arguments of the mask).
+// Per column: b = train right-hand side (cv_detail.hpp:304-352 / :355-405), G_local = G - sum_test f f^T (:66-85),
+// then cholesky_clip_col(G_local, b, x, L1) or cd_nnls_col_fixed(G_local, b, x, L1 inside, cd_maxit sweeps, no
+// tolerance) started from the current column WITHOUT a warm-start correction of b -- as the reference does.
+template <class S>
+static void cv_half_update(const Csc<S>& D, const S* F, const S* G_full, S* X, int k, const SpeckledMask& mask,
+                           bool transposed, S L1, bool nonneg, int cd_maxit, int solver_mode, int threads) {
+    const int nt = eff_threads(threads); (void)nt;
+    const int nrow = D.rows;
+#pragma omp parallel num_threads(nt)
+    {
+        std::vector<S> b(k), x(k), Gl((size_t)k * k), L((size_t)k * k);
+        std::vector<int> test;
+#pragma omp for schedule(dynamic, 64)
+        for (int j = 0; j < D.cols; ++j) {
+            test.clear();
+            for (int f = 0; f < k; ++f) b[f] = 0;
+            auto held = [&](int r) { return transposed ? mask.is_holdout(j, r) : mask.is_holdout(r, j); };
+            if (mask.mask_zeros) {
+                for (int t = D.p[j]; t < D.p[j + 1]; ++t) {
+                    const int r = D.i[t];
+                    if (held(r)) test.push_back(r);
+                    else { const S a = D.x[t]; const S* fc = F + (size_t)r * k; for (int f = 0; f < k; ++f) b[f] += a * fc[f]; }
+                }
+            } else {
+                int t = D.p[j];
+                const int te = D.p[j + 1];
+                for (int r = 0; r < nrow; ++r) {
+                    S val = 0;
+                    if (t < te && D.i[t] == r) { val = D.x[t]; ++t; }
+                    if (held(r)) test.push_back(r);
+                    else if (val != S(0)) { const S* fc = F + (size_t)r * k; for (int f = 0; f < k; ++f) b[f] += val * fc[f]; }
+                }
+            }
+            std::memcpy(Gl.data(), G_full, sizeof(S) * k * k);
+            for (int r : test) {
+                const S* fr = F + (size_t)r * k;
+                for (int c = 0; c < k; ++c) {
+                    const S fc = fr[c];
+                    S* g = Gl.data() + (size_t)c * k;
+                    for (int a2 = 0; a2 < k; ++a2) g[a2] -= fr[a2] * fc;
+                }
+            }
+            S* xj = X + (size_t)j * k;
+            for (int i = 0; i < k; ++i) x[i] = xj[i];
+            if (solver_mode == 1) {                      // cholesky_clip.hpp:64-106
+                if (L1 > 0) for (int i = 0; i < k; ++i) b[i] -= L1;
+                llt_factor(Gl.data(), k, L.data());
+                for (int i = 0; i < k; ++i) x[i] = b[i];
+                llt_solve(L.data(), k, x.data());
+                if (nonneg) for (int i = 0; i < k; ++i) x[i] = std::max(x[i], S(0));
+            } else {
+                cd_nnls_col_fixed(Gl.data(), b.data(), x.data(), k, L1, S(0), nonneg, cd_maxit, S(0), S(0));
+            }
+            for (int i = 0; i < k; ++i) xj[i] = x[i];
+        }
+    }
+}
+
+// fit_cv.hpp:1444-1494  squared error and count over the held-out entries (zeros included unless mask_zeros)
+template <class S>
+static void cv_test_error(const Csc<S>& A, const S* W_Td, const S* H, int k, const SpeckledMask& mask, int threads,
+                          S* sq_err, int64_t* n_test) {
+    const int nt = eff_threads(threads); (void)nt;
+    S total = 0;
+    int64_t cnt = 0;
+#pragma omp parallel for reduction(+ : total, cnt) num_threads(nt) schedule(dynamic, 64)
+    for (int j = 0; j < A.cols; ++j) {
+        const S* h = H + (size_t)j * k;
+        if (mask.mask_zeros) {
+            for (int t = A.p[j]; t < A.p[j + 1]; ++t) {
+                if (!mask.is_holdout(A.i[t], j)) continue;
+                const S* w = W_Td + (size_t)A.i[t] * k;
+                S pred = 0;
+                for (int f = 0; f < k; ++f) pred += w[f] * h[f];
+                const S diff = A.x[t] - pred;
+                total += diff * diff; ++cnt;
+            }
+        } else {
+            int t = A.p[j];
+            const int te = A.p[j + 1];
+            for (int i = 0; i < A.rows; ++i) {
+                S actual = 0;
+                const bool nz = t < te && A.i[t] == i;
+                if (nz) { actual = A.x[t]; ++t; }
+                if (!mask.is_holdout(i, j)) continue;
+                const S* w = W_Td + (size_t)i * k;
+                S pred = 0;
+                for (int f = 0; f < k; ++f) pred += w[f] * h[f];
+                const S diff = actual - pred;
+                total += diff * diff; ++cnt;
+            }
+        }
+    }
+    *sq_err = total; *n_test = cnt;
+}
+
+template <class S> struct CvResult {
+    int iterations = 0, best_iter = 0; bool converged = false;
+    S train_loss = 0, test_loss = 0, best_test_loss = 0, final_tol = 0;
+    std::vector<S> train_hist, test_hist;
+};
+
+// nmf/fit_cv.hpp:123-1667  nmf_fit_cv, MSE / sparse / standard updates / no user mask / no IRLS.
+// W_T (k x m) and H (k x n) hold the initial factors on entry; on exit W_T is normalised, H carries d ("absorb d
+// into H", :1636-1638) and d is ALSO returned, exactly as the reference packages it.
+template <class S>
+static CvResult<S> nmf_fit_cv(const Csc<S>& A, const FitConfig<S>& cfg, double holdout_fraction, uint64_t cv_seed,
+                              bool mask_zeros, int cv_patience, S* W_T, S* H, S* d) {
+    const int m = A.rows, n = A.cols, k = cfg.k;
+    for (int i = 0; i < k; ++i) d[i] = S(1);
+    const SpeckledMask mask(holdout_fraction, cv_seed, mask_zeros);
+    CscOwned<S> At_own = transpose_csc(A);
+    const Csc<S> At = At_own.view();
+    const int threads = eff_threads(cfg.threads);
+    S trAtA = 0;
+    for (int t = 0; t < A.p[n]; ++t) trAtA += A.x[t] * A.x[t];
+    std::vector<S> G((size_t)k * k), G_H_saved((size_t)k * k), G_W_new((size_t)k * k), B_W_full((size_t)k * m), Wd((size_t)k * m);
+    CvResult<S> res;
+    S best_test = std::numeric_limits<S>::max(), prev_conv = std::numeric_limits<S>::max();
+    int best_iter = 0, patience_count = 0;
+    for (int iter = 0; iter < cfg.max_iter; ++iter) {
+        // ---- H update (:408-535)
+        gram(W_T, k, m, G.data());
+        for (int i = 0; i < k; ++i) G[(size_t)i * k + i] += static_cast<S>(1e-15);        // :410 (on top of gram's own eps)
+        if (cfg.L2_H > 0) for (int i = 0; i < k; ++i) G[(size_t)i * k + i] += cfg.L2_H;   // apply_cv_features
+        apply_L21(G.data(), H, k, (int64_t)n, cfg.L21_H);
+        cv_half_update(A, W_T, G.data(), H, k, mask, false, cfg.L1_H, cfg.nonneg_H, cfg.cd_maxit, cfg.solver_mode, threads);
+        if (cfg.ub_H > 0) apply_upper_bound(H, (size_t)k * n, cfg.ub_H);
+        apply_angular_posthoc(H, k, (int64_t)n, cfg.angular_H);
+        extract_scaling(H, k, n, d, cfg.norm_type);                                        // :538-550
+        // ---- W update (:555-860)
+        gram(H, k, n, G.data());
+        G_H_saved = G;                                                                     // :574-576 (with gram's eps)
+        for (int i = 0; i < k; ++i) G[(size_t)i * k + i] += static_cast<S>(1e-15);        // :578
+        if (cfg.L2_W > 0) for (int i = 0; i < k; ++i) G[(size_t)i * k + i] += cfg.L2_W;
+        apply_L21(G.data(), W_T, k, (int64_t)m, cfg.L21_W);
+        // B_W_full.col(i) = sum_j A(i,j) H(:,j) over ALL nonzeros (train + test), :617-655
+        for (int i = 0; i < m; ++i) {
+            S* bw = B_W_full.data() + (size_t)i * k;
+            for (int f = 0; f < k; ++f) bw[f] = 0;
+            for (int t = At.p[i]; t < At.p[i + 1]; ++t) {
+                const S a = At.x[t]; const S* hc = H + (size_t)At.i[t] * k;
+                for (int f = 0; f < k; ++f) bw[f] += a * hc[f];
+            }
+        }
+        cv_half_update(At, H, G.data(), W_T, k, mask, true, cfg.L1_W, cfg.nonneg_W, cfg.cd_maxit, cfg.solver_mode, threads);
+        if (cfg.ub_W > 0) apply_upper_bound(W_T, (size_t)k * m, cfg.ub_W);
+        apply_angular_posthoc(W_T, k, (int64_t)m, cfg.angular_W);
+        extract_scaling(W_T, k, m, d, cfg.norm_type);                                      // :848-859
+        // ---- loss (:1345-1550): every iteration (cv_patience > 0 / history)
+        for (int i = 0; i < m; ++i) for (int f = 0; f < k; ++f) Wd[(size_t)i * k + f] = W_T[(size_t)i * k + f] * d[f];
+        S test_sq = 0; int64_t n_test = 0;
+        cv_test_error(A, Wd.data(), H, k, mask, threads, &test_sq, &n_test);
+        S cross = 0;
+        for (int r = 0; r < k; ++r) {
+            S dot = 0;
+            for (int i = 0; i < m; ++i) dot += W_T[(size_t)i * k + r] * B_W_full[(size_t)i * k + r];
+            cross += d[r] * dot;
+        }
+        gram(W_T, k, m, G_W_new.data());
+        S recon = 0;
+        for (int r = 0; r < k; ++r) for (int c = 0; c < k; ++c) recon += d[r] * d[c] * G_W_new[(size_t)c * k + r] * G_H_saved[(size_t)c * k + r];
+        const S total_sq = std::max(trAtA - S(2) * cross + recon, S(0));
+        const S train_sq = std::max(total_sq - test_sq, S(0));
+        const int64_t total_entries = mask_zeros ? (int64_t)A.p[n] : (int64_t)m * n;
+        const int64_t n_train = total_entries - n_test;
+        const S train_loss = n_train > 0 ? train_sq / static_cast<S>(n_train) : S(0);
+        const S test_loss = n_test > 0 ? test_sq / static_cast<S>(n_test) : S(0);
+        res.train_hist.push_back(train_loss); res.test_hist.push_back(test_loss);
+        res.train_loss = train_loss; res.test_loss = test_loss;
+        S rel = 0;
+        if (iter > 0) rel = std::abs(prev_conv - test_loss) / (std::abs(prev_conv) + static_cast<S>(1e-15));
+        if (test_loss < best_test) { best_test = test_loss; best_iter = iter; patience_count = 0; }
+        else ++patience_count;
+        if (cv_patience > 0 && patience_count >= cv_patience) { res.iterations = iter + 1; res.converged = false; break; }
+        if (iter > 0) {
+            res.final_tol = rel;
+            if (rel < cfg.tol) { res.iterations = iter + 1; res.converged = true; break; }
+        }
+        prev_conv = test_loss;
+        res.iterations = iter + 1;
+    }
+    res.best_test_loss = best_test; res.best_iter = best_iter;
+    for (int j = 0; j < n; ++j) for (int f = 0; f < k; ++f) H[(size_t)j * k + f] *= d[f];   // :1636-1638
+    return res;
+}
+
 // nmf/masked_nnls.hpp:250-282   masked_loss (sparse A: unmasked NONZEROS only, MSE)
 template <class S>
 static S masked_loss(const Csc<S>& A, const S* W_Td, const S* H, const Csc<S>& mask, int k,
@@ -636,6 +848,42 @@ ORACLE_API float oracle_loss_gp_f32(float y, float p, float th) { return loss_co
     }
 DEFINE_NB(f32, float)
 DEFINE_NB(f64, double)
+
+// Cross-validation pieces (kernel-level parity) and the CV fit
+ORACLE_API uint64_t oracle_cv_hash(uint64_t seed, uint32_t i, uint32_t j) { return SpeckledMask::hash(seed, i, j); }
+ORACLE_API int oracle_cv_is_holdout(double frac, uint64_t cv_seed, int i, int j) { return SpeckledMask(frac, cv_seed, false).is_holdout(i, j) ? 1 : 0; }
+#define DEFINE_CV(SUF, S)                                                                                         \
+    ORACLE_API void oracle_cv_half_update_##SUF(int rows, int cols, const int* p, const int* i, const S* x, const S* F, \
+                                                const S* G, S* X, int k, double frac, uint64_t cv_seed, int mask_zeros, \
+                                                int transposed, S L1, int nonneg, int cd_maxit, int solver_mode,   \
+                                                int threads) {                                                     \
+        cv_half_update(mk(rows, cols, p, i, x), F, G, X, k, SpeckledMask(frac, cv_seed, mask_zeros != 0),          \
+                       transposed != 0, L1, nonneg != 0, cd_maxit, solver_mode, threads);                          \
+    }                                                                                                              \
+    ORACLE_API void oracle_cv_test_error_##SUF(int m, int n, const int* p, const int* i, const S* x, const S* W_T, \
+                                               const S* d, const S* H, int k, double frac, uint64_t cv_seed,       \
+                                               int mask_zeros, S* sq_err, int64_t* n_test) {                       \
+        std::vector<S> Wd((size_t)k * m);                                                                          \
+        for (int r = 0; r < m; ++r) for (int f = 0; f < k; ++f) Wd[(size_t)r * k + f] = W_T[(size_t)r * k + f] * d[f]; \
+        cv_test_error(mk(m, n, p, i, x), Wd.data(), H, k, SpeckledMask(frac, cv_seed, mask_zeros != 0), 1, sq_err, n_test); \
+    }                                                                                                              \
+    ORACLE_API void oracle_nmf_fit_cv_##SUF(int m, int n, const int* p, const int* i, const S* x, int k, S* W_T, S* H, \
+                                            S* d, int max_iter, S tol, S L1_H, S L1_W, S L2_H, S L2_W, int cd_maxit, \
+                                            int nonneg_W, int nonneg_H, int norm_type, int solver_mode, double frac, \
+                                            uint64_t cv_seed, int mask_zeros, int cv_patience, int threads,         \
+                                            int* out_iter, int* out_converged, S* out_train, S* out_test,           \
+                                            S* out_best_test, int* out_best_iter, S* train_hist, S* test_hist) {    \
+        FitConfig<S> c;                                                                                            \
+        c.k = k; c.max_iter = max_iter; c.tol = tol; c.L1_H = L1_H; c.L1_W = L1_W; c.L2_H = L2_H; c.L2_W = L2_W;    \
+        c.cd_maxit = cd_maxit; c.nonneg_W = nonneg_W != 0; c.nonneg_H = nonneg_H != 0; c.norm_type = norm_type;     \
+        c.solver_mode = solver_mode; c.threads = threads;                                                          \
+        CvResult<S> r = nmf_fit_cv(mk(m, n, p, i, x), c, frac, cv_seed, mask_zeros != 0, cv_patience, W_T, H, d);   \
+        *out_iter = r.iterations; *out_converged = r.converged ? 1 : 0; *out_train = r.train_loss;                 \
+        *out_test = r.test_loss; *out_best_test = r.best_test_loss; *out_best_iter = r.best_iter;                   \
+        for (size_t t = 0; t < r.train_hist.size(); ++t) { if (train_hist) train_hist[t] = r.train_hist[t]; if (test_hist) test_hist[t] = r.test_hist[t]; } \
+    }
+DEFINE_CV(f32, float)
+DEFINE_CV(f64, double)
 
 // ---------------------------------------------------------------------------
 // src/RcppFunctions_utils.cpp:313-366  c_nnls (fp64): h = NNLS(w^T w, w^T A)

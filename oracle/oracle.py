@@ -390,3 +390,71 @@ def nb_loss(A, W_T, d, H, theta_row, dtype=np.float64):
     x = A.values(dtype)
     return float(fn(C.c_int(A.rows), C.c_int(A.cols), _p(A.p), _p(A.i), _p(x), _p(W_T), _p(d), _p(H), C.c_int(W_T.shape[1]),
                     _p(th)))
+
+
+# --------------------------------------------------------------------------------------------
+# Cross-validation path (nmf/fit_cv.hpp): speckled holdout mask, per-column Gram correction
+# --------------------------------------------------------------------------------------------
+def cv_hash(seed, i, j):
+    fn = lib().oracle_cv_hash
+    fn.restype = C.c_uint64
+    return int(fn(C.c_uint64(seed), C.c_uint32(i), C.c_uint32(j)))
+
+
+def cv_half_update(A, F, G, X, k, frac, cv_seed, mask_zeros=False, transposed=False, L1=0.0, nonneg=True, cd_maxit=100,
+                   solver_mode=0, threads=1, dtype=np.float64):
+    """One CV half-update over the columns of A (the W side passes A^T with transposed=True)."""
+    suf, ct = _suf(dtype)
+    F, G = _f(F, dtype), _f(G, dtype)
+    X = _f(X, dtype).copy()
+    x = A.values(dtype)
+    getattr(lib(), "oracle_cv_half_update_" + suf)(C.c_int(A.rows), C.c_int(A.cols), _p(A.p), _p(A.i), _p(x), _p(F), _p(G), _p(X),
+                                                   C.c_int(k), C.c_double(frac), C.c_uint64(cv_seed), C.c_int(int(mask_zeros)),
+                                                   C.c_int(int(transposed)), ct(L1), C.c_int(int(nonneg)), C.c_int(cd_maxit),
+                                                   C.c_int(solver_mode), C.c_int(threads))
+    return X
+
+
+def cv_test_error(A, W_T, d, H, frac, cv_seed, mask_zeros=False, dtype=np.float64):
+    suf, ct = _suf(dtype)
+    W_T, H, d = _f(W_T, dtype), _f(H, dtype), _f(d, dtype)
+    x = A.values(dtype)
+    sq, cnt = ct(0), C.c_int64(0)
+    getattr(lib(), "oracle_cv_test_error_" + suf)(C.c_int(A.rows), C.c_int(A.cols), _p(A.p), _p(A.i), _p(x), _p(W_T), _p(d), _p(H),
+                                                  C.c_int(W_T.shape[1]), C.c_double(frac), C.c_uint64(cv_seed),
+                                                  C.c_int(int(mask_zeros)), C.byref(sq), C.byref(cnt))
+    return float(sq.value), int(cnt.value)
+
+
+class CvFitResult:
+    pass
+
+
+def nmf_fit_cv(A, W_T, H, dtype=np.float64, max_iter=100, tol=1e-4, L1=(0.0, 0.0), L2=(0.0, 0.0), cd_maxit=100,
+               nonneg=(True, True), norm_type=0, solver_mode=0, holdout_fraction=0.1, cv_seed=0, mask_zeros=False,
+               cv_patience=5, threads=1, native=False):
+    """CPU restatement of nmf_fit_cv (reference nmf/fit_cv.hpp), MSE / sparse.  Returns W_T (normalised), H WITH d
+    absorbed and d, as the reference packages them."""
+    suf, ct = _suf(dtype)
+    W_T = _f(W_T, dtype).copy()
+    H = _f(H, dtype).copy()
+    m, k = W_T.shape
+    n = H.shape[0]
+    d = np.ones(k, dtype)
+    x = A.values(dtype)
+    th = np.full(max(max_iter, 1), np.nan, dtype)
+    eh = np.full(max(max_iter, 1), np.nan, dtype)
+    it, conv, bi = C.c_int(0), C.c_int(0), C.c_int(0)
+    tr, te, bt = ct(0), ct(0), ct(0)
+    getattr(lib(native), "oracle_nmf_fit_cv_" + suf)(
+        C.c_int(m), C.c_int(n), _p(A.p), _p(A.i), _p(x), C.c_int(k), _p(W_T), _p(H), _p(d), C.c_int(max_iter), ct(tol),
+        ct(L1[1]), ct(L1[0]), ct(L2[1]), ct(L2[0]), C.c_int(cd_maxit), C.c_int(int(nonneg[0])), C.c_int(int(nonneg[1])),
+        C.c_int(norm_type), C.c_int(solver_mode), C.c_double(holdout_fraction), C.c_uint64(cv_seed), C.c_int(int(mask_zeros)),
+        C.c_int(cv_patience), C.c_int(threads), C.byref(it), C.byref(conv), C.byref(tr), C.byref(te), C.byref(bt), C.byref(bi),
+        _p(th), _p(eh))
+    r = CvFitResult()
+    r.W_T, r.H, r.d = W_T, H, d
+    r.iter, r.converged = it.value, bool(conv.value)
+    r.train_loss, r.test_loss, r.best_test_loss, r.best_iter = float(tr.value), float(te.value), float(bt.value), bi.value
+    r.train_history, r.test_history = th[:it.value].copy(), eh[:it.value].copy()
+    return r

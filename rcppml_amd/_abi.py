@@ -22,7 +22,7 @@ EXPORTED_SYMBOLS = [
     "rcppml_hip_ctx_create", "rcppml_hip_ctx_destroy", "rcppml_hip_ctx_sync", "rcppml_hip_ctx_stats", "rcppml_hip_transpose_csc", "rcppml_hip_cast", "rcppml_hip_gram", "rcppml_hip_rhs",
     "rcppml_hip_solve_cd", "rcppml_hip_order_columns", "rcppml_hip_solve_chol", "rcppml_hip_row_norms", "rcppml_hip_apply_scaling",
     "rcppml_hip_sumsq", "rcppml_hip_loss_mse", "rcppml_hip_solve_masked", "rcppml_hip_loss_nonzeros",
-    "rcppml_hip_solve_irls_nb", "rcppml_hip_nb_size_update", "rcppml_hip_nb_loss", "rcppml_hip_solve_irls", "rcppml_hip_irls_loss", "rcppml_hip_apply_l21", "rcppml_hip_angular_posthoc",
+    "rcppml_hip_solve_irls_nb", "rcppml_hip_nb_size_update", "rcppml_hip_nb_loss", "rcppml_hip_solve_irls", "rcppml_hip_irls_loss", "rcppml_hip_apply_l21", "rcppml_hip_angular_posthoc", "rcppml_hip_solve_cv", "rcppml_hip_cv_test_error",
 ]
 
 
@@ -295,6 +295,18 @@ class Context:
         _chk(lib().rcppml_hip_irls_loss(self._h, C.c_int(dt), C.c_int(loss_type), _dptr(col_ptr), _dptr(row_idx), _dptr(values),
                                         C.c_int64(ncols), _dptr(W_T), _dptr(d), _dptr(H), _dptr(theta_row), C.c_int(k),
                                         C.c_double(loss_param), C.c_double(robust_delta), _dptr(out)), "irls_loss")
+
+    def solve_cv(self, dt, col_ptr, row_idx, values, ncols, nrows, F, G, X, k, frac, cv_seed, mask_zeros=0, transposed=0, l1=0.0,
+                 nonneg=1, cd_maxit=100, solver_mode=0):
+        _chk(lib().rcppml_hip_solve_cv(self._h, C.c_int(dt), _dptr(col_ptr), _dptr(row_idx), _dptr(values), C.c_int64(ncols),
+                                       C.c_int(nrows), _dptr(F), _dptr(G), _dptr(X), C.c_int(k), C.c_double(frac),
+                                       C.c_ulonglong(cv_seed), C.c_int(mask_zeros), C.c_int(transposed), C.c_double(l1),
+                                       C.c_int(nonneg), C.c_int(cd_maxit), C.c_int(solver_mode)), "solve_cv")
+
+    def cv_test_error(self, dt, col_ptr, row_idx, values, ncols, nrows, W_T, d, H, k, frac, cv_seed, mask_zeros, out2):
+        _chk(lib().rcppml_hip_cv_test_error(self._h, C.c_int(dt), _dptr(col_ptr), _dptr(row_idx), _dptr(values), C.c_int64(ncols),
+                                            C.c_int(nrows), _dptr(W_T), _dptr(d), _dptr(H), C.c_int(k), C.c_double(frac),
+                                            C.c_ulonglong(cv_seed), C.c_int(mask_zeros), _dptr(out2)), "cv_test_error")
 
     def apply_l21(self, dt, G, X, k, ncols, lam):
         _chk(lib().rcppml_hip_apply_l21(self._h, C.c_int(dt), _dptr(G), _dptr(X), C.c_int(k), C.c_int64(ncols), C.c_double(lam)), "apply_l21")

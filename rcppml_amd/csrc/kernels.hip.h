@@ -31,6 +31,16 @@ __device__ __forceinline__ double tabs(double v) { return __builtin_fabs(v); }
 __device__ __forceinline__ float tfma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 __device__ __forceinline__ double tfma(double a, double b, double c) { return __builtin_fma(a, b, c); }
 
+// value of lane i (wave-uniform i) through v_readlane_b32: the result lands in an SGPR, no LDS-crossbar round trip
+__device__ __forceinline__ float lane_value(float v, int i) {
+    return __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), i));
+}
+__device__ __forceinline__ double lane_value(double v, int i) {
+    const unsigned long long u = __double_as_longlong(v);
+    const unsigned lo = __builtin_amdgcn_readlane((unsigned)u, i), hi = __builtin_amdgcn_readlane((unsigned)(u >> 32), i);
+    return __longlong_as_double(((unsigned long long)hi << 32) | lo);
+}
+
 __device__ __forceinline__ float shfl_xor_t(float v, int m) { return __shfl_xor(v, m, 64); }
 __device__ __forceinline__ double shfl_xor_t(double v, int m) { return __shfl_xor(v, m, 64); }
 
@@ -1186,6 +1196,189 @@ __global__ __launch_bounds__(256) void loss_mse_final(const double* __restrict__
 // in-LDS Cholesky + clip for solver_mode 1.
 // ---------------------------------------------------------------------------
 // ---------------------------------------------------------------------------
+// Cross-validation half-update (reference nmf/fit_cv.hpp:420-478 / :591-830, nmf/cv_detail.hpp:66-85,304-405,
+// nmf/speckled_cv.hpp): speckled holdout mask defined by SplitMix64::hash(seed, i, j) < UINT64_MAX / inv_prob
+// (rng/rng.hpp:129-170), no mask matrix.  One wavefront per column j of D (D = A on the H side, A^T with
+// transposed = 1 on the W side; the mask is always asked in the coordinates of A):
+//   b       = sum over the column's TRAIN nonzeros  a F(row, :)
+//   G_local = G - sum over the column's TEST rows  F(row, :) F(row, :)^T   (mask_zeros: held-out nonzeros only;
+//             otherwise every held-out row, zeros included -- the 64 lanes hash 64 rows at a time)
+//   x       = cholesky_clip(G_local, b - L1) or CD(G_local, b, x; L1 inside, cd_maxit sweeps, no tolerance), started from
+//             the current column without a warm-start correction of b, exactly as the reference does.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long cv_hash_dev(unsigned long long seed, unsigned i, unsigned j) {
+    unsigned long long h = seed + (unsigned long long)i * 0x9e3779b97f4a7c15ULL + (unsigned long long)j * 0x6c62272e07bb0142ULL;
+    h = (h ^ (h >> 30)) * 0xbf58476d1ce4e5b9ULL;
+    h = (h ^ (h >> 27)) * 0x94d049bb133111ebULL;
+    return h ^ (h >> 31);
+}
+
+template <class T, int KP>   // KP in {32, 64}
+__global__ __launch_bounds__(256) void cv_solve_kernel(
+    const int* __restrict__ colptr, const int* __restrict__ rowidx, const T* __restrict__ vals, int64_t ncols, int nrows,
+    const T* __restrict__ F, const T* __restrict__ Gfull, T* __restrict__ X, int k, unsigned long long seed,
+    unsigned long long threshold, int mask_zeros, int transposed, T l1, int nonneg, int maxit, int solver_mode) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    T* Gl = reinterpret_cast<T*>(smem_raw) + (size_t)wave * KP * KP;   // [c][r]
+    const int64_t j = (int64_t)blockIdx.x * 4 + wave;
+    if (j >= ncols) return;
+    const bool fok = lane < k;
+    const bool lin = lane < KP;
+    const int ll = lin ? lane : 0;
+    for (int c = 0; c < KP; ++c) {
+        T v = (fok && c < k) ? Gfull[(int64_t)c * k + lane] : (c == lane ? T(1) : T(0));
+        if (lin) Gl[c * KP + lane] = v;
+    }
+    const unsigned col = (unsigned)j;
+    // train right-hand side (and, with mask_zeros, the Gram correction of the held-out nonzeros)
+    T b = T(0);
+    for (int t = colptr[j]; t < colptr[j + 1]; ++t) {
+        const int row = rowidx[t];
+        const bool held = (transposed ? cv_hash_dev(seed, col, (unsigned)row) : cv_hash_dev(seed, (unsigned)row, col)) < threshold;
+        const T fr = fok ? F[(int64_t)row * k + lane] : T(0);
+        if (!held) {
+            b = tfma(vals[t], fr, b);
+        } else if (mask_zeros) {
+            for (int c = 0; c < k; ++c) {
+                const T fc = __shfl(fr, c, 64);
+                if (lin) Gl[c * KP + lane] -= fr * fc;
+            }
+        }
+    }
+    if (!mask_zeros) {      // every held-out row of this column, zeros included
+        for (int r0 = 0; r0 < nrows; r0 += 64) {
+            const int r = r0 + lane;
+            const bool held = r < nrows &&
+                (transposed ? cv_hash_dev(seed, col, (unsigned)r) : cv_hash_dev(seed, (unsigned)r, col)) < threshold;
+            unsigned long long m = __ballot(held);
+            while (m) {
+                const int bit = __builtin_ctzll(m);
+                m &= m - 1;
+                const int row = r0 + bit;
+                const T fr = fok ? F[(int64_t)row * k + lane] : T(0);
+                for (int c = 0; c < k; ++c) {
+                    const T fc = __shfl(fr, c, 64);
+                    if (lin) Gl[c * KP + lane] -= fr * fc;
+                }
+            }
+        }
+    }
+    RK_WAVE_SYNC();
+    T x = fok ? X[j * (int64_t)k + lane] : T(0);
+    if (solver_mode == 1) {
+        if (l1 > T(0) && fok) b -= l1;
+        for (int c = 0; c < KP; ++c) {
+            T s = Gl[c * KP + ll];
+            for (int p = 0; p < c; ++p) s -= Gl[p * KP + ll] * Gl[p * KP + c];
+            T dcc = __shfl(s, c, 64);
+            if (!(dcc > T(0))) dcc = tabs(dcc) + T(1e-30);
+            const T lcc = sqrt(dcc);
+            if (lin) Gl[c * KP + lane] = lane == c ? lcc : (lane > c ? s / lcc : T(0));
+            RK_WAVE_SYNC();
+        }
+        T y = b;
+        for (int i = 0; i < k; ++i) {
+            const T yi = __shfl(y, i, 64) / Gl[i * KP + i];
+            if (lane == i) y = yi;
+            else if (lane > i) y -= Gl[i * KP + ll] * yi;
+        }
+        for (int i = k - 1; i >= 0; --i) {
+            const T xi = __shfl(y, i, 64) / Gl[i * KP + i];
+            if (lane == i) y = xi;
+            else if (lane < i) y -= Gl[ll * KP + i] * xi;
+        }
+        x = y;
+        if (nonneg) x = x > T(0) ? x : T(0);
+    } else {
+        const T gd = Gl[ll * KP + ll];
+        for (int it = 0; it < maxit; ++it) {
+            int cur = 0;
+            bool any = false;
+            while (true) {
+                T diff = b / gd;
+                if (l1 != T(0)) diff -= l1;
+                const T nv = x + diff;
+                T ad = diff, nx = nv;
+                if (nonneg && nv < T(0)) { ad = -x; nx = T(0); }
+                const bool moves = fok && (gd > T(0)) && (ad != T(0)) && (lane >= cur);
+                const unsigned long long mask = __ballot(moves);
+                if (mask == 0ull) break;
+                any = true;
+                const int i = __builtin_ctzll(mask);
+                const T ad_i = lane_value(ad, i), nx_i = lane_value(nx, i);
+                if (lane == i) x = nx_i;
+                b = tfma(-Gl[i * KP + ll], ad_i, b);
+                cur = i + 1;
+                if (cur >= KP) break;
+            }
+            if (!any) break;
+        }
+    }
+    if (fok) X[j * (int64_t)k + lane] = x;
+}
+
+// Squared error and count over the held-out entries (fit_cv.hpp:1444-1494), one wavefront per column of A.
+// out partials: [block] = {sum of squared errors (fp64), count}
+template <class T>
+__global__ __launch_bounds__(256) void cv_test_error_kernel(
+    const int* __restrict__ colptr, const int* __restrict__ rowidx, const T* __restrict__ vals, int64_t ncols, int nrows,
+    const T* __restrict__ W_T, const T* __restrict__ d, const T* __restrict__ H, int k, unsigned long long seed,
+    unsigned long long threshold, int mask_zeros, double* __restrict__ partial_sq, unsigned long long* __restrict__ partial_n) {
+    __shared__ double shs[4];
+    __shared__ unsigned long long shn[4];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t j = (int64_t)blockIdx.x * 4 + wave;
+    double acc = 0.0;
+    unsigned long long cnt = 0;
+    if (j < ncols) {
+        const bool fok = lane < k;
+        // k <= 64: lane f holds d_f * H(f, j); a held-out entry costs one gather of W_T(row, :) and a wave reduction
+        const T hd = fok ? H[j * (int64_t)k + lane] * d[lane] : T(0);
+        const unsigned col = (unsigned)j;
+        if (mask_zeros) {
+            for (int t = colptr[j]; t < colptr[j + 1]; ++t) {
+                const int row = rowidx[t];
+                if (!(cv_hash_dev(seed, (unsigned)row, col) < threshold)) continue;
+                T p = fok ? W_T[(int64_t)row * k + lane] * hd : T(0);
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) p += shfl_xor_t(p, off);
+                const T diff = vals[t] - p;
+                acc += static_cast<double>(diff * diff);
+                ++cnt;
+            }
+        } else {
+            int t = colptr[j];
+            const int te = colptr[j + 1];
+            for (int r0 = 0; r0 < nrows; r0 += 64) {
+                const int r = r0 + lane;
+                const bool held = r < nrows && cv_hash_dev(seed, (unsigned)r, col) < threshold;
+                unsigned long long m = __ballot(held);
+                while (m) {
+                    const int bit = __builtin_ctzll(m);
+                    m &= m - 1;
+                    const int row = r0 + bit;
+                    while (t < te && rowidx[t] < row) ++t;
+                    const T actual = (t < te && rowidx[t] == row) ? vals[t] : T(0);
+                    T p = fok ? W_T[(int64_t)row * k + lane] * hd : T(0);
+#pragma unroll
+                    for (int off = 32; off > 0; off >>= 1) p += shfl_xor_t(p, off);
+                    const T diff = actual - p;
+                    acc += static_cast<double>(diff * diff);
+                    ++cnt;
+                }
+            }
+        }
+    }
+    if (lane == 0) { shs[wave] = acc; shn[wave] = cnt; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        partial_sq[blockIdx.x] = shs[0] + shs[1] + shs[2] + shs[3];
+        partial_n[blockIdx.x] = shn[0] + shn[1] + shn[2] + shn[3];
+    }
+}
+
+// ---------------------------------------------------------------------------
 // k x k feature layer (reference features/L21.hpp:38-51, features/angular.hpp:67-103)
 // ---------------------------------------------------------------------------
 // L21: G(i,i) += lambda / ||factor.row(i)||_2 for rows with norm > 1e-10; sumsq[i] = sum_j X(i,j)^2
@@ -1229,16 +1422,6 @@ __global__ __launch_bounds__(256) void angular_apply_kernel(T* __restrict__ X, i
             X[j * (int64_t)k + lane] = v > T(0) ? v : T(0);
         }
     }
-}
-
-// value of lane i (wave-uniform i) through v_readlane_b32: the result lands in an SGPR, no LDS-crossbar round trip
-__device__ __forceinline__ float lane_value(float v, int i) {
-    return __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), i));
-}
-__device__ __forceinline__ double lane_value(double v, int i) {
-    const unsigned long long u = __double_as_longlong(v);
-    const unsigned lo = __builtin_amdgcn_readlane((unsigned)u, i), hi = __builtin_amdgcn_readlane((unsigned)(u >> 32), i);
-    return __longlong_as_double(((unsigned long long)hi << 32) | lo);
 }
 
 template <class T, int KP>   // KP in {32, 64}: features padded to KP (k <= KP), lane r = feature r

@@ -1,0 +1,107 @@
+// ops_cv.hip -- cross-validation half-update and held-out error (device-level C ABI, include/rcppml_gpu.h layer 2)
+#include "common.hip.h"
+#include "kernels.hip.h"
+
+using namespace rk;
+
+namespace {
+// speckled_cv.hpp:57-68: seed = (uint32) cv_seed, 0 -> 12345; inv_prob = (uint64)(1 / fraction); threshold = UINT64_MAX / inv_prob
+void mask_params(double holdout_fraction, unsigned long long cv_seed, unsigned long long* seed, unsigned long long* threshold) {
+    if (!(holdout_fraction > 0.0 && holdout_fraction < 1.0)) throw std::runtime_error("cv: holdout_fraction must be in (0, 1)");
+    const unsigned s32 = static_cast<unsigned>(cv_seed);
+    *seed = s32 == 0 ? 12345ULL : static_cast<unsigned long long>(s32);
+    const unsigned long long inv_prob = static_cast<unsigned long long>(1.0 / holdout_fraction);
+    if (inv_prob == 0) throw std::runtime_error("cv: holdout_fraction too large");
+    *threshold = 0xFFFFFFFFFFFFFFFFULL / inv_prob;
+}
+
+template <class T>
+void cv_solve_impl(rcppml_hip_ctx* c, const int* cp, const int* ri, const T* vals, int64_t ncols, int nrows, const T* F,
+                   const T* G, T* X, int k, double frac, unsigned long long cv_seed, int mask_zeros, int transposed, T l1,
+                   int nonneg, int maxit, int solver_mode) {
+    if (ncols <= 0) return;
+    if (k < 1 || k > 64) throw std::runtime_error("solve_cv: k must be in [1,64]");
+    if (solver_mode != 0 && solver_mode != 1) throw std::runtime_error("solve_cv: solver_mode must be 0 (CD) or 1 (Cholesky+clip)");
+    unsigned long long seed, thr;
+    mask_params(frac, cv_seed, &seed, &thr);
+    const int64_t nblk = (ncols + 3) / 4;
+    if (k <= 32) {
+        hipLaunchKernelGGL((cv_solve_kernel<T, 32>), dim3((unsigned)nblk), dim3(256), (size_t)4 * 32 * 32 * sizeof(T), c->stream, cp, ri,
+                           vals, ncols, nrows, F, G, X, k, seed, thr, mask_zeros, transposed, l1, nonneg, maxit, solver_mode);
+    } else {
+        const size_t smem = (size_t)4 * 64 * 64 * sizeof(T);
+        auto kern = cv_solve_kernel<T, 64>;
+        static DynSmemOnce once;
+        once.ensure(reinterpret_cast<const void*>(kern), smem, c->device);
+        hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), smem, c->stream, cp, ri, vals, ncols, nrows, F, G, X, k, seed, thr,
+                           mask_zeros, transposed, l1, nonneg, maxit, solver_mode);
+    }
+    HIPCHK(hipGetLastError());
+}
+
+__global__ void cv_sum_partials_kernel(const double* __restrict__ ps, const unsigned long long* __restrict__ pn, int n,
+                                       double* __restrict__ out2) {
+    __shared__ double ss[256];
+    __shared__ unsigned long long sn[256];
+    double a = 0.0;
+    unsigned long long b = 0;
+    for (int i = threadIdx.x; i < n; i += 256) { a += ps[i]; b += pn[i]; }
+    ss[threadIdx.x] = a; sn[threadIdx.x] = b;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) { ss[threadIdx.x] += ss[threadIdx.x + off]; sn[threadIdx.x] += sn[threadIdx.x + off]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { out2[0] = ss[0]; out2[1] = static_cast<double>(sn[0]); }
+}
+
+template <class T>
+void cv_test_impl(rcppml_hip_ctx* c, const int* cp, const int* ri, const T* vals, int64_t ncols, int nrows, const T* W_T,
+                  const T* d, const T* H, int k, double frac, unsigned long long cv_seed, int mask_zeros, double* out2) {
+    if (k < 1 || k > 64) throw std::runtime_error("cv_test_error: k must be in [1,64]");
+    unsigned long long seed, thr;
+    mask_params(frac, cv_seed, &seed, &thr);
+    const int64_t nblk = ncols > 0 ? (ncols + 3) / 4 : 1;
+    char* buf = static_cast<char*>(c->scratch(WS_RED2, (size_t)nblk * 16));
+    double* ps = reinterpret_cast<double*>(buf);
+    unsigned long long* pn = reinterpret_cast<unsigned long long*>(buf + (size_t)nblk * 8);
+    hipLaunchKernelGGL(cv_test_error_kernel<T>, dim3((unsigned)nblk), dim3(256), 0, c->stream, cp, ri, vals, ncols, nrows, W_T, d, H, k,
+                       seed, thr, mask_zeros, ps, pn);
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(cv_sum_partials_kernel, dim3(1), dim3(256), 0, c->stream, ps, pn, (int)nblk, out2);
+    HIPCHK(hipGetLastError());
+}
+}  // namespace
+
+extern "C" int rcppml_hip_solve_cv(rcppml_hip_ctx* c, int dtype, const int* col_ptr, const int* row_idx, const void* values,
+                                   int64_t ncols, int nrows, const void* F, const void* G, void* X, int k,
+                                   double holdout_fraction, unsigned long long cv_seed, int mask_zeros, int transposed,
+                                   double l1, int nonneg, int cd_maxit, int solver_mode) {
+    try {
+        HIPCHK(hipSetDevice(c->device));
+        if (dtype == RCPPML_F32)
+            cv_solve_impl<float>(c, col_ptr, row_idx, (const float*)values, ncols, nrows, (const float*)F, (const float*)G, (float*)X, k,
+                                 holdout_fraction, cv_seed, mask_zeros, transposed, (float)l1, nonneg, cd_maxit, solver_mode);
+        else
+            cv_solve_impl<double>(c, col_ptr, row_idx, (const double*)values, ncols, nrows, (const double*)F, (const double*)G,
+                                  (double*)X, k, holdout_fraction, cv_seed, mask_zeros, transposed, l1, nonneg, cd_maxit, solver_mode);
+        return 0;
+    }
+    RCPPML_CATCH_RET
+}
+
+extern "C" int rcppml_hip_cv_test_error(rcppml_hip_ctx* c, int dtype, const int* col_ptr, const int* row_idx, const void* values,
+                                        int64_t ncols, int nrows, const void* W_T, const void* d, const void* H, int k,
+                                        double holdout_fraction, unsigned long long cv_seed, int mask_zeros, double* out2) {
+    try {
+        HIPCHK(hipSetDevice(c->device));
+        if (dtype == RCPPML_F32)
+            cv_test_impl<float>(c, col_ptr, row_idx, (const float*)values, ncols, nrows, (const float*)W_T, (const float*)d,
+                                (const float*)H, k, holdout_fraction, cv_seed, mask_zeros, out2);
+        else
+            cv_test_impl<double>(c, col_ptr, row_idx, (const double*)values, ncols, nrows, (const double*)W_T, (const double*)d,
+                                 (const double*)H, k, holdout_fraction, cv_seed, mask_zeros, out2);
+        return 0;
+    }
+    RCPPML_CATCH_RET
+}

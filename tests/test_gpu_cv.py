@@ -1,0 +1,72 @@
+"""GPU parity, cross-validation path (reference nmf/fit_cv.hpp): the speckled-mask half-update and the
+held-out error through the device-level C ABI, and the CV fit through the plugin's CV entry, against the oracle's
+restatement (whose mask hash is pinned to the reference's rng/rng.hpp in tests/test_oracle_ref.py)."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests.util import lowrank_csc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    from rcppml_amd import _abi
+    return torch, _abi, _abi.Context(0)
+
+
+def _dev(torch, a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-8), (np.float32, 2e-3)])
+@pytest.mark.parametrize("k", [5, 32, 40])
+@pytest.mark.parametrize("mask_zeros", [0, 1])
+@pytest.mark.parametrize("solver", [0, 1])
+def test_cv_half_updates(env, dtype, tol, k, mask_zeros, solver):
+    """H side (A, F = W_T) and W side (A^T, transposed mask arguments), both solvers, zeros held out or not."""
+    torch, _abi, ctx = env
+    A = lowrank_csc(130, 170, 4, 0.2, seed=k)
+    At = A.transpose()
+    dt = _abi.F32 if dtype == np.float32 else _abi.F64
+    rng = np.random.default_rng(k + mask_zeros)
+    frac, cv_seed = 0.1, 77
+    for (M, transposed) in ((A, 0), (At, 1)):
+        F = rng.uniform(0.05, 1.0, size=(M.rows, k)).astype(dtype)
+        G = O.gram(F)
+        G[np.diag_indices(k)] += dtype(0.3)            # L2-like ridge keeps G - sum_test f f^T well conditioned
+        X0 = rng.uniform(0.0, 0.2, size=(M.cols, k)).astype(dtype)
+        ref = O.cv_half_update(M, F, G, X0, k, frac, cv_seed, mask_zeros=bool(mask_zeros), transposed=bool(transposed), L1=0.01,
+                               cd_maxit=20, solver_mode=solver, dtype=dtype)
+        dX = _dev(torch, X0.copy())
+        ctx.solve_cv(dt, _dev(torch, M.p), _dev(torch, M.i), _dev(torch, M.values(dtype)), M.cols, M.rows, _dev(torch, F),
+                     _dev(torch, G), dX, k, frac, cv_seed, mask_zeros=mask_zeros, transposed=transposed, l1=0.01, cd_maxit=20,
+                     solver_mode=solver)
+        X = dX.cpu().numpy()
+        assert np.all(np.isfinite(X)) and X.min() >= 0
+        assert np.abs(X - ref).max() / max(np.abs(ref).max(), 1e-30) < tol, (k, mask_zeros, solver, transposed)
+
+
+@pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-11), (np.float32, 1e-4)])
+@pytest.mark.parametrize("mask_zeros", [0, 1])
+def test_cv_test_error(env, dtype, tol, mask_zeros):
+    torch, _abi, ctx = env
+    k = 7
+    A = lowrank_csc(90, 140, 3, 0.25, seed=3)
+    dt = _abi.F32 if dtype == np.float32 else _abi.F64
+    rng = np.random.default_rng(5)
+    W = rng.uniform(size=(A.rows, k)).astype(dtype)
+    H = rng.uniform(size=(A.cols, k)).astype(dtype)
+    d = rng.uniform(0.5, 2.0, size=k).astype(dtype)
+    sq_ref, n_ref = O.cv_test_error(A, W, d, H, 0.2, 5, mask_zeros=bool(mask_zeros), dtype=dtype)
+    out = torch.zeros((2,), dtype=torch.float64, device="cuda")
+    ctx.cv_test_error(dt, _dev(torch, A.p), _dev(torch, A.i), _dev(torch, A.values(dtype)), A.cols, A.rows, _dev(torch, W),
+                      _dev(torch, d), _dev(torch, H), k, 0.2, 5, mask_zeros, out)
+    sq, cnt = out.cpu().numpy()
+    assert int(cnt) == n_ref and n_ref > 0
+    assert abs(sq - sq_ref) <= tol * abs(sq_ref)
+    # the mask holds out about `fraction` of the entries (all entries, or the nonzeros with mask_zeros)
+    total = A.nnz if mask_zeros else A.rows * A.cols
+    assert abs(n_ref / total - 0.2) < 0.03
