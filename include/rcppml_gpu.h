@@ -74,6 +74,32 @@ RCPPML_GPU_API void rcppml_gpu_detect(int* num_gpus, double* total_mem_mb, doubl
         const int* guide_H_ncs, int* guide_H_count, int* out_iter, int* out_converged,             \
         double* out_loss, int* out_status, double* out_tol
 
+/* Cross-validation NMF.  Replaces reference `rcppml_gpu_nmf_cv_unified_float` (type
+ * inst/include/FactorNet/gpu/bridge_nmf.hpp:77-99, resolved and called at :407-497 by bridge_nmf_cv_sparse): 51 pointer
+ * arguments, W (k x m) and H (k x n) are initialised by the caller, d = 1.  Implemented: MSE loss, CD and Cholesky+clip,
+ * L1 / L2, both mask_zeros settings, k <= 64; anything else sets out_status = -1 (CPU fallback).  The held-out set is
+ * the speckled mask of rcppml_hip_solve_cv with cv_seed, or seed when cv_seed = 0 (core/config.hpp:415-418).  Early
+ * stopping: cv_patience = NMF_PATIENCE = 5 (not transmitted by the bridge; RCPPML_GPU_CV_PATIENCE overrides).  On
+ * return H carries d and d is returned too (nmf/fit_cv.hpp:1636-1647). */
+#define RCPPML_NMF_CV_ARGS                                                                         \
+    const int *col_ptr, const int *row_idx, const double *values, int *m, int *n, int *nnz, int *k, \
+        double *W, double *H, double *d, int *max_iter, double *tol, double *L1_H, double *L1_W,    \
+        double *L2_H, double *L2_W, int *cd_maxit, int *verbose,                                    \
+        int *seed_only_used_for_cv_seed_fallback, double *holdout_frac, int *cv_seed,               \
+        int *mask_zeros, int *nonneg_W, int *nonneg_H, int *norm_type, int *loss_type,              \
+        double *huber_delta, int *irls_max_iter, double *irls_tol, const int *graph_W_p,            \
+        const int *graph_W_i, const double *graph_W_x, int *graph_W_dim, int *graph_W_nnz,          \
+        double *graph_W_lambda, const int *graph_H_p, const int *graph_H_i,                         \
+        const double *graph_H_x, int *graph_H_dim, int *graph_H_nnz, double *graph_H_lambda,        \
+        int *projective, int *symmetric, int *solver_mode, int *out_iter, int *out_converged,       \
+        double *out_train_loss, double *out_test_loss, double *out_best_test, int *out_best_iter,   \
+        int *out_status
+RCPPML_GPU_API void rcppml_gpu_nmf_cv_unified_float(RCPPML_NMF_CV_ARGS);
+RCPPML_GPU_API void rcppml_gpu_nmf_cv_unified_double(RCPPML_NMF_CV_ARGS);
+/* Build-defined: + sort flag, precision (RCPPML_F32/F64), cv_patience, train / test loss histories (may be NULL). */
+RCPPML_GPU_API void rcppml_gpu_nmf_cv_ex(RCPPML_NMF_CV_ARGS, int* sort_model, int* precision, int* cv_patience,
+                                         double* train_history, double* test_history);
+
 RCPPML_GPU_API void rcppml_gpu_nmf_unified_float(RCPPML_NMF_UNIFIED_ARGS);
 RCPPML_GPU_API void rcppml_gpu_nmf_unified_double(RCPPML_NMF_UNIFIED_ARGS);
 

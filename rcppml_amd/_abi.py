@@ -18,6 +18,7 @@ CD_AUTO, CD_LANE, CD_WAVE, CD_GROUP, CD_MFMA, CD_MFMA16 = 0, 1, 2, 5, 6, 7
 # Every symbol include/rcppml_gpu.h declares (tests check the library exports all of them).
 EXPORTED_SYMBOLS = [
     "rcppml_gpu_detect", "rcppml_gpu_nmf_unified_float", "rcppml_gpu_nmf_unified_double", "rcppml_gpu_nmf_ex",
+    "rcppml_gpu_nmf_cv_unified_float", "rcppml_gpu_nmf_cv_unified_double", "rcppml_gpu_nmf_cv_ex",
     "rcppml_gpu_nnls_double", "rcppml_gpu_evaluate_mse_double", "rcppml_gpu_last_error",
     "rcppml_hip_ctx_create", "rcppml_hip_ctx_destroy", "rcppml_hip_ctx_sync", "rcppml_hip_ctx_stats", "rcppml_hip_transpose_csc", "rcppml_hip_cast", "rcppml_hip_gram", "rcppml_hip_rhs",
     "rcppml_hip_solve_cd", "rcppml_hip_order_columns", "rcppml_hip_solve_chol", "rcppml_hip_row_norms", "rcppml_hip_apply_scaling",
@@ -185,6 +186,56 @@ def _dptr(t):
     if isinstance(t, int):
         return C.c_void_p(t)
     return C.c_void_p(t.data_ptr())
+
+
+def nmf_cv(p, i, x, m, n, k, W_T, H, *, entry="ex", max_iter=100, tol=1e-4, L1_H=0.0, L1_W=0.0, L2_H=0.0, L2_W=0.0, cd_maxit=100,
+           verbose=0, seed=0, holdout_fraction=0.1, cv_seed=0, mask_zeros=0, nonneg_W=1, nonneg_H=1, norm_type=0, loss_type=0,
+           solver_mode=0, projective=0, symmetric=0, graph_W_nnz=0, sort_model=1, precision=F64, cv_patience=5):
+    """Call the CV plugin entry as reference gpu/bridge_nmf.hpp:407-497 does (51 pointers; entry "float" | "double"), or
+    the build-defined "ex" form (+ sort flag, precision, patience, loss histories).  W_T (m, k) and H (n, k) float64
+    arrays are updated IN PLACE (H returns with d absorbed)."""
+    L = lib()
+    p = np.ascontiguousarray(p, np.int32)
+    i = np.ascontiguousarray(i, np.int32)
+    x = np.ascontiguousarray(x, np.float64)
+    assert W_T.dtype == np.float64 and H.dtype == np.float64 and W_T.flags.c_contiguous and H.flags.c_contiguous
+    assert W_T.shape == (m, k) and H.shape == (n, k)
+    d = np.ones(k, np.float64)
+    dummy_i = np.zeros(2, np.int32)
+    dummy_d = np.zeros(2, np.float64)
+    out_iter, out_conv, out_best_iter, out_status = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(-99)
+    out_train, out_test, out_best = C.c_double(0), C.c_double(0), C.c_double(0)
+    args = [
+        _np_ptr(p), _np_ptr(i), _np_ptr(x), _ci(m), _ci(n), _ci(x.shape[0]), _ci(k),
+        _np_ptr(W_T), _np_ptr(H), _np_ptr(d), _ci(max_iter), _cd(tol),
+        _cd(L1_H), _cd(L1_W), _cd(L2_H), _cd(L2_W), _ci(cd_maxit), _ci(verbose), _ci(seed),
+        _cd(holdout_fraction), _ci(cv_seed), _ci(mask_zeros), _ci(nonneg_W), _ci(nonneg_H), _ci(norm_type),
+        _ci(loss_type), _cd(1.0), _ci(5), _cd(1e-4),
+        _np_ptr(dummy_i), _np_ptr(dummy_i), _np_ptr(dummy_d), _ci(0), _ci(graph_W_nnz), _cd(0.0),
+        _np_ptr(dummy_i), _np_ptr(dummy_i), _np_ptr(dummy_d), _ci(0), _ci(0), _cd(0.0),
+        _ci(projective), _ci(symmetric), _ci(solver_mode),
+        C.byref(out_iter), C.byref(out_conv), C.byref(out_train), C.byref(out_test), C.byref(out_best), C.byref(out_best_iter),
+        C.byref(out_status),
+    ]
+    assert len(args) == 51
+    th = eh = None
+    if entry == "ex":
+        th = np.full(max(max_iter, 1), np.nan)
+        eh = np.full(max(max_iter, 1), np.nan)
+        fn = L.rcppml_gpu_nmf_cv_ex
+        fn.restype = None
+        fn(*args, _ci(sort_model), _ci(precision), _ci(cv_patience), _np_ptr(th), _np_ptr(eh))
+    else:
+        fn = getattr(L, "rcppml_gpu_nmf_cv_unified_" + entry)
+        fn.restype = None
+        fn(*args)
+    res = dict(status=out_status.value, iter=out_iter.value, converged=bool(out_conv.value), train_loss=out_train.value,
+               test_loss=out_test.value, best_test_loss=out_best.value, best_iter=out_best_iter.value, d=d)
+    if out_status.value != 0:
+        res["error"] = last_error()
+    if th is not None:
+        res["train_history"], res["test_history"] = th[:out_iter.value].copy(), eh[:out_iter.value].copy()
+    return res
 
 
 class Context:

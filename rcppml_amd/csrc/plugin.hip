@@ -486,6 +486,202 @@ extern "C" void rcppml_gpu_detect(int* num_gpus, double* total_mem_mb, double* f
     *num_gpus = cnt;
 }
 
+#define RCPPML_NMF_CV_PASS                                                                                  \
+    col_ptr, row_idx, values, m, n, nnz, k, W, H, d, max_iter, tol, L1_H, L1_W, L2_H, L2_W, cd_maxit, verbose,      \
+        seed_only_used_for_cv_seed_fallback, holdout_frac, cv_seed, mask_zeros, nonneg_W, nonneg_H, norm_type,      \
+        loss_type, huber_delta, irls_max_iter, irls_tol, graph_W_p, graph_W_i, graph_W_x, graph_W_dim, graph_W_nnz, \
+        graph_W_lambda, graph_H_p, graph_H_i, graph_H_x, graph_H_dim, graph_H_nnz, graph_H_lambda, projective,      \
+        symmetric, solver_mode, out_iter, out_converged, out_train_loss, out_test_loss, out_best_test,              \
+        out_best_iter, out_status
+
+// ----------------------------------------------------------------------------
+// Cross-validation fit (reference nmf/fit_cv.hpp:123-1667, MSE / sparse / standard updates / no user mask):
+// speckled holdout mask, per-column Gram correction in both half-updates, held-out error + Gram-trick train loss every
+// iteration, early stopping on the test loss (cv_patience = NMF_PATIENCE = 5: the bridge does not transmit it) and the
+// relative-change convergence test on the test loss.  On return H carries d ("absorb d into H", :1636-1638) and d is
+// returned as well, as the reference packages its result.
+// ----------------------------------------------------------------------------
+namespace {
+int env_sort();
+struct CvParams {
+    int m, n, k; int64_t nnz;
+    const int* col_ptr; const int* row_idx; const double* values;
+    double *W, *H, *d;
+    int max_iter; double tol;
+    double L1_H, L1_W, L2_H, L2_W;
+    int cd_maxit, verbose, nonneg_W, nonneg_H, norm_type, solver_mode;
+    double holdout_fraction; unsigned long long cv_seed; int mask_zeros; int cv_patience; int sort_model;
+    double* train_history = nullptr; double* test_history = nullptr;     // optional, max_iter entries each
+    int out_iter = 0, out_converged = 0, out_best_iter = 0; double out_train = 0, out_test = 0, out_best_test = 0;
+};
+
+template <class T>
+void fit_cv(CvParams& P) {
+    constexpr int dt = DT<T>::id;
+    const int m = P.m, n = P.n, k = P.k;
+    CtxGuard g(env_device());
+    rcppml_hip_ctx* c = g.c;
+    hipStream_t s = g.s;
+    DevBuf dAp, dAi, dAx, dTp, dTi, dTx;
+    upload_ints(P.col_ptr, (size_t)n + 1, dAp, s);
+    upload_ints(P.row_idx, (size_t)std::max<int64_t>(P.nnz, 1), dAi, s);
+    upload_cast<T>(c, P.values, (size_t)std::max<int64_t>(P.nnz, 1), dAx, s);
+    dTp.alloc(((size_t)m + 1) * sizeof(int));
+    dTi.alloc((size_t)std::max<int64_t>(P.nnz, 1) * sizeof(int));
+    dTx.alloc((size_t)std::max<int64_t>(P.nnz, 1) * sizeof(T));
+    OPCHK(rcppml_hip_transpose_csc(c, dt, m, n, dAp.as<int>(), dAi.as<int>(), dAx.p, dTp.as<int>(), dTi.as<int>(), dTx.p));
+    DevBuf dW, dH, dd;
+    upload_cast<T>(c, P.W, (size_t)k * m, dW, s);
+    upload_cast<T>(c, P.H, (size_t)k * n, dH, s);
+    dd.alloc((size_t)k * sizeof(T));
+    {
+        std::vector<T> ones(k, T(1));
+        HIPCHK(hipMemcpyAsync(dd.p, ones.data(), k * sizeof(T), hipMemcpyHostToDevice, s));
+        HIPCHK(hipStreamSynchronize(s));
+    }
+    DevBuf dBw((size_t)k * m * sizeof(T)), dG((size_t)k * k * sizeof(T)), dGs((size_t)k * k * sizeof(T)), dGwt((size_t)k * k * sizeof(T));
+    DevBuf dsums((size_t)k * sizeof(T)), dtr(sizeof(double)), dloss(4 * sizeof(double)), dtest(2 * sizeof(double));
+    double* hbuf = nullptr;
+    HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&hbuf), 6 * sizeof(double)));
+    struct HostFree { double* p; ~HostFree() { (void)hipHostFree(p); } } hf{hbuf};
+    OPCHK(rcppml_hip_sumsq(c, dt, dAx.p, P.nnz, dtr.as<double>()));
+    const double eps = 1e-15;
+    double best_test = std::numeric_limits<double>::max(), prev_conv = std::numeric_limits<double>::max();
+    if (std::is_same<T, float>::value) { best_test = std::numeric_limits<float>::max(); prev_conv = best_test; }
+    int best_iter = 0, patience_count = 0, iterations = 0;
+    bool converged = false;
+    double train_loss = 0, test_loss = 0, final_tol = 0;
+    auto as_scalar = [](double v) { return std::is_same<T, float>::value ? static_cast<double>(static_cast<float>(v)) : v; };
+
+    for (int iter = 0; iter < P.max_iter; ++iter) {
+        // ---- H half-update (:408-550): G = gram(W) (eps) + 1e-15 (:410) + L2
+        OPCHK(rcppml_hip_gram(c, dt, dW.p, k, m, 2 * eps, P.L2_H, dG.p));
+        OPCHK(rcppml_hip_solve_cv(c, dt, dAp.as<int>(), dAi.as<int>(), dAx.p, n, m, dW.p, dG.p, dH.p, k, P.holdout_fraction,
+                                  P.cv_seed, P.mask_zeros, 0, P.L1_H, P.nonneg_H, P.cd_maxit, P.solver_mode));
+        OPCHK(rcppml_hip_row_norms(c, dt, dH.p, k, n, P.norm_type, dsums.p));
+        OPCHK(rcppml_hip_apply_scaling(c, dt, dH.p, k, n, P.norm_type, dsums.p, dd.p));
+        // ---- W half-update (:555-860): G_H_saved = gram(H) (eps); G = G_H_saved + 1e-15 + L2
+        OPCHK(rcppml_hip_gram(c, dt, dH.p, k, n, eps, 0.0, dGs.p));
+        OPCHK(rcppml_hip_gram(c, dt, dH.p, k, n, 2 * eps, P.L2_W, dG.p));
+        OPCHK(rcppml_hip_rhs(c, dt, dTp.as<int>(), dTi.as<int>(), dTx.p, m, dH.p, k, dBw.p));      // B_W_full: train + test
+        OPCHK(rcppml_hip_solve_cv(c, dt, dTp.as<int>(), dTi.as<int>(), dTx.p, m, n, dH.p, dG.p, dW.p, k, P.holdout_fraction,
+                                  P.cv_seed, P.mask_zeros, 1, P.L1_W, P.nonneg_W, P.cd_maxit, P.solver_mode));
+        OPCHK(rcppml_hip_row_norms(c, dt, dW.p, k, m, P.norm_type, dsums.p));
+        OPCHK(rcppml_hip_apply_scaling(c, dt, dW.p, k, m, P.norm_type, dsums.p, dd.p));
+        // ---- losses (:1345-1550): held-out squared error; total squared error by the Gram trick with B_W_full
+        OPCHK(rcppml_hip_cv_test_error(c, dt, dAp.as<int>(), dAi.as<int>(), dAx.p, n, m, dW.p, dd.p, dH.p, k, P.holdout_fraction,
+                                       P.cv_seed, P.mask_zeros, dtest.as<double>()));
+        OPCHK(rcppml_hip_gram(c, dt, dW.p, k, m, eps, 0.0, dGwt.p));
+        OPCHK(rcppml_hip_loss_mse(c, dt, dtr.as<double>(), dd.p, dW.p, dBw.p, k, m, dGwt.p, dGs.p, dloss.as<double>()));
+        HIPCHK(hipMemcpyAsync(hbuf, dloss.p, 4 * sizeof(double), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(hbuf + 4, dtest.p, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        const double total_sq = std::max(as_scalar(hbuf[0]), 0.0);
+        const double test_sq = as_scalar(hbuf[4]);
+        const int64_t n_test = (int64_t)hbuf[5];
+        const double train_sq = std::max(as_scalar(total_sq - test_sq), 0.0);
+        const int64_t total_entries = P.mask_zeros ? P.nnz : (int64_t)m * n;
+        const int64_t n_train = total_entries - n_test;
+        train_loss = n_train > 0 ? as_scalar(train_sq / (double)n_train) : 0.0;
+        test_loss = n_test > 0 ? as_scalar(test_sq / (double)n_test) : 0.0;
+        if (P.train_history) P.train_history[iter] = train_loss;
+        if (P.test_history) P.test_history[iter] = test_loss;
+        double rel = 0;
+        if (iter > 0) rel = std::fabs(prev_conv - test_loss) / (std::fabs(prev_conv) + 1e-15);
+        if (test_loss < best_test) { best_test = test_loss; best_iter = iter; patience_count = 0; }
+        else ++patience_count;
+        if (P.verbose) fprintf(stderr, "[rcppml_gpu cv] iter %d train %.9g test %.9g best %.9g\n", iter + 1, train_loss, test_loss, best_test);
+        iterations = iter + 1;
+        if (P.cv_patience > 0 && patience_count >= P.cv_patience) { converged = false; break; }
+        if (iter > 0) {
+            final_tol = rel;
+            if (rel < P.tol) { converged = true; break; }
+        }
+        prev_conv = test_loss;
+    }
+    (void)final_tol;
+    download_cast<T>(c, dW, (size_t)k * m, P.W, s);
+    download_cast<T>(c, dH, (size_t)k * n, P.H, s);
+    download_cast<T>(c, dd, (size_t)k, P.d, s);
+    for (int j = 0; j < n; ++j) {                                // absorb d into H (:1636-1638), in the Scalar type
+        double* h = P.H + (size_t)j * k;
+        for (int i = 0; i < k; ++i) h[i] = static_cast<double>(static_cast<T>(h[i]) * static_cast<T>(P.d[i]));
+    }
+    if (P.sort_model) {                                          // core/result.hpp:169-188
+        std::vector<int> idx(k);
+        std::iota(idx.begin(), idx.end(), 0);
+        std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return P.d[a] > P.d[b]; });
+        std::vector<double> tmp(k);
+        for (int j = 0; j < m; ++j) { double* w = P.W + (size_t)j * k; for (int i = 0; i < k; ++i) tmp[i] = w[idx[i]]; std::copy(tmp.begin(), tmp.end(), w); }
+        for (int j = 0; j < n; ++j) { double* h = P.H + (size_t)j * k; for (int i = 0; i < k; ++i) tmp[i] = h[idx[i]]; std::copy(tmp.begin(), tmp.end(), h); }
+        for (int i = 0; i < k; ++i) tmp[i] = P.d[idx[i]];
+        std::copy(tmp.begin(), tmp.end(), P.d);
+    }
+    P.out_iter = iterations; P.out_converged = converged ? 1 : 0; P.out_train = train_loss; P.out_test = test_loss;
+    P.out_best_test = best_test; P.out_best_iter = best_iter;
+}
+
+void nmf_cv_entry(RCPPML_NMF_CV_ARGS, int sort_model, int precision, int cv_patience, double* train_history, double* test_history) {
+    try {
+        rcppml_err().clear();
+        *out_status = -1;
+        (void)seed_only_used_for_cv_seed_fallback; (void)huber_delta; (void)irls_max_iter; (void)irls_tol;
+        (void)graph_W_p; (void)graph_W_i; (void)graph_W_x; (void)graph_W_dim; (void)graph_W_lambda;
+        (void)graph_H_p; (void)graph_H_i; (void)graph_H_x; (void)graph_H_dim; (void)graph_H_lambda;
+        if (*loss_type != 0) throw std::runtime_error("CV: only the MSE loss is implemented");
+        if (*graph_W_nnz > 0 || *graph_H_nnz > 0) throw std::runtime_error("CV: graph regularisation not supported");
+        if (*projective != 0 || *symmetric != 0) throw std::runtime_error("CV: projective/symmetric NMF not supported");
+        if (*solver_mode != 0 && *solver_mode != 1) throw std::runtime_error("CV: solver_mode must be 0 (CD) or 1 (Cholesky+clip)");
+        if (*k < 1 || *k > 64) throw std::runtime_error("CV: k must be in [1,64]");
+        if (*m < 1 || *n < 1) throw std::runtime_error("empty matrix");
+        if (*norm_type < 0 || *norm_type > 2) throw std::runtime_error("bad norm_type");
+        if (!(*holdout_frac > 0 && *holdout_frac < 1)) throw std::runtime_error("CV: holdout fraction must be in (0, 1)");
+        if (col_ptr[*n] != *nnz) throw std::runtime_error("col_ptr[n] != nnz");
+        CvParams P;
+        P.m = *m; P.n = *n; P.k = *k; P.nnz = *nnz;
+        P.col_ptr = col_ptr; P.row_idx = row_idx; P.values = values;
+        P.W = W; P.H = H; P.d = d;
+        P.max_iter = *max_iter; P.tol = *tol;
+        P.L1_H = *L1_H; P.L1_W = *L1_W; P.L2_H = *L2_H; P.L2_W = *L2_W;
+        P.cd_maxit = *cd_maxit > 0 ? *cd_maxit : 10;
+        P.verbose = *verbose; P.nonneg_W = *nonneg_W; P.nonneg_H = *nonneg_H; P.norm_type = *norm_type;
+        P.solver_mode = *solver_mode;
+        P.holdout_fraction = *holdout_frac;
+        // config.effective_cv_seed(): cv_seed unless 0, then seed (core/config.hpp:415-418)
+        P.cv_seed = *cv_seed != 0 ? (unsigned long long)(unsigned)*cv_seed : (unsigned long long)(unsigned)*seed_only_used_for_cv_seed_fallback;
+        P.mask_zeros = *mask_zeros != 0 ? 1 : 0;
+        P.cv_patience = cv_patience; P.sort_model = sort_model;
+        P.train_history = train_history; P.test_history = test_history;
+        if (precision == RCPPML_F64) fit_cv<double>(P); else fit_cv<float>(P);
+        *out_iter = P.out_iter; *out_converged = P.out_converged; *out_train_loss = P.out_train; *out_test_loss = P.out_test;
+        *out_best_test = P.out_best_test; *out_best_iter = P.out_best_iter;
+        *out_status = 0;
+    } catch (const std::exception& e) {
+        rcppml_err() = e.what();
+        if (getenv("RCPPML_GPU_VERBOSE")) fprintf(stderr, "[rcppml_gpu cv] %s\n", e.what());
+        *out_status = -1;
+    } catch (...) {
+        rcppml_err() = "unknown error";
+        *out_status = -1;
+    }
+}
+int env_cv_patience() { const char* e = getenv("RCPPML_GPU_CV_PATIENCE"); return e ? atoi(e) : 5; }   // NMF_PATIENCE
+}  // namespace
+
+extern "C" void rcppml_gpu_nmf_cv_unified_float(RCPPML_NMF_CV_ARGS) {
+    const char* e = getenv("RCPPML_GPU_PRECISION");
+    nmf_cv_entry(RCPPML_NMF_CV_PASS, env_sort(), (e && !strcmp(e, "fp64")) ? RCPPML_F64 : RCPPML_F32, env_cv_patience(), nullptr, nullptr);
+}
+extern "C" void rcppml_gpu_nmf_cv_unified_double(RCPPML_NMF_CV_ARGS) {
+    const char* e = getenv("RCPPML_GPU_PRECISION");
+    nmf_cv_entry(RCPPML_NMF_CV_PASS, env_sort(), (e && !strcmp(e, "fp32")) ? RCPPML_F32 : RCPPML_F64, env_cv_patience(), nullptr, nullptr);
+}
+// build-defined: + sort flag, precision, patience, loss histories (max_iter entries each, may be NULL)
+extern "C" void rcppml_gpu_nmf_cv_ex(RCPPML_NMF_CV_ARGS, int* sort_model, int* precision, int* cv_patience, double* train_history,
+                                     double* test_history) {
+    nmf_cv_entry(RCPPML_NMF_CV_PASS, *sort_model, *precision, *cv_patience, train_history, test_history);
+}
+
 extern "C" void rcppml_gpu_nmf_unified_float(RCPPML_NMF_UNIFIED_ARGS) {
     const char* e = getenv("RCPPML_GPU_PRECISION");
     const int prec = (e && !strcmp(e, "fp64")) ? RCPPML_F64 : RCPPML_F32;

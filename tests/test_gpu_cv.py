@@ -70,3 +70,55 @@ def test_cv_test_error(env, dtype, tol, mask_zeros):
     # the mask holds out about `fraction` of the entries (all entries, or the nonzeros with mask_zeros)
     total = A.nnz if mask_zeros else A.rows * A.cols
     assert abs(n_ref / total - 0.2) < 0.03
+
+
+@pytest.mark.parametrize("precision,tol_loss,tol_fac", [("f64", 1e-7, 1e-6), ("f32", 2e-3, 5e-3)])
+@pytest.mark.parametrize("solver", [1, 0])
+@pytest.mark.parametrize("mask_zeros", [0, 1])
+def test_cv_fit_through_plugin(precision, tol_loss, tol_fac, solver, mask_zeros):
+    """rcppml_gpu_nmf_cv_* (the reference's CV plugin boundary) vs the oracle's nmf_fit_cv: same iteration count, same
+    early-stopping decision, train / test / best-test losses, factors (H returned with d absorbed)."""
+    from rcppml_amd import _abi
+    A = lowrank_csc(80, 110, 3, 0.3, seed=2)
+    k = 4
+    dtype = np.float64 if precision == "f64" else np.float32
+    W0, H0 = O.init_factors(5, k, A.rows, A.cols, np.float64)
+    ref = O.nmf_fit_cv(A, W0, H0, dtype, max_iter=12, tol=1e-6, L1=(0.0, 0.01), L2=(0.02, 0.0), solver_mode=solver,
+                       holdout_fraction=0.1, cv_seed=3, mask_zeros=bool(mask_zeros), cv_patience=5)
+    W, H = W0.copy(), H0.copy()
+    res = _abi.nmf_cv(A.p, A.i, A.x, A.rows, A.cols, k, W, H, entry="ex", max_iter=12, tol=1e-6, L1_H=0.01, L2_W=0.02,
+                      solver_mode=solver, holdout_fraction=0.1, cv_seed=3, mask_zeros=mask_zeros, sort_model=0,
+                      precision=_abi.F64 if precision == "f64" else _abi.F32, cv_patience=5)
+    assert res["status"] == 0, res.get("error")
+    assert res["iter"] == ref.iter and res["converged"] == ref.converged and res["best_iter"] == ref.best_iter
+    assert np.allclose(res["test_history"], ref.test_history, rtol=tol_loss, atol=0)
+    assert np.allclose(res["train_history"], ref.train_history, rtol=tol_loss * 10, atol=0)
+    assert abs(res["best_test_loss"] - ref.best_test_loss) <= tol_loss * abs(ref.best_test_loss)
+    assert np.abs(res["d"] - ref.d).max() <= tol_fac * np.abs(ref.d).max()
+    assert np.abs(W - ref.W_T).max() < tol_fac and np.abs(H - ref.H).max() < tol_fac * max(1.0, np.abs(ref.H).max())
+
+
+def test_cv_reference_entry_points_and_rejections():
+    """The two reference symbols (51 pointers, cv_seed = 0 falls back to seed) and the refusals (out_status = -1)."""
+    from rcppml_amd import _abi
+    A = lowrank_csc(60, 70, 3, 0.3, seed=4)
+    k = 3
+    W0, H0 = O.init_factors(9, k, A.rows, A.cols, np.float64)
+    ref = O.nmf_fit_cv(A, W0, H0, np.float64, max_iter=8, tol=1e-6, solver_mode=1, holdout_fraction=0.2, cv_seed=17, cv_patience=5,
+                       )
+    for entry, kw in (("double", dict(cv_seed=17, seed=99)), ("double", dict(cv_seed=0, seed=17))):
+        W, H = W0.copy(), H0.copy()
+        res = _abi.nmf_cv(A.p, A.i, A.x, A.rows, A.cols, k, W, H, entry=entry, max_iter=8, tol=1e-6, solver_mode=1,
+                          holdout_fraction=0.2, **kw)
+        assert res["status"] == 0 and res["iter"] == ref.iter
+        assert abs(res["test_loss"] - ref.test_loss) <= 1e-7 * abs(ref.test_loss)
+        assert abs(res["train_loss"] - ref.train_loss) <= 1e-6 * abs(ref.train_loss)
+    W, H = W0.copy(), H0.copy()
+    res32 = _abi.nmf_cv(A.p, A.i, A.x, A.rows, A.cols, k, W, H, entry="float", max_iter=8, tol=1e-6, solver_mode=1,
+                        holdout_fraction=0.2, cv_seed=17)
+    assert res32["status"] == 0 and abs(res32["test_loss"] - ref.test_loss) <= 5e-3 * abs(ref.test_loss)
+    for kw in (dict(loss_type=5), dict(projective=1), dict(symmetric=1), dict(graph_W_nnz=3), dict(solver_mode=2),
+               dict(holdout_fraction=0.0), dict(holdout_fraction=1.5)):
+        W, H = W0.copy(), H0.copy()
+        r = _abi.nmf_cv(A.p, A.i, A.x, A.rows, A.cols, k, W, H, entry="double", max_iter=2, **kw)
+        assert r["status"] == -1 and r["error"], kw
