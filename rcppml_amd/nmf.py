@@ -89,8 +89,12 @@ def nmf(data, k, tol=1e-4, maxit=100, L1=(0.0, 0.0), L2=(0.0, 0.0), seed=None, m
         raise NotImplementedError("dispersion must be 'none', 'global' or 'per_row' on the MI355X backend")
     if projective or symmetric:
         raise NotImplementedError("projective / symmetric NMF are not implemented by the MI355X backend")
-    if test_fraction and test_fraction > 0:
-        raise NotImplementedError("cross-validation (test_fraction > 0) is not implemented by the MI355X backend")
+    cv = bool(test_fraction) and test_fraction > 0
+    if cv:
+        if not (0 < test_fraction < 1):
+            raise ValueError("test_fraction must be in [0, 1)")
+        if loss != "mse" or (mask is not None and not isinstance(mask, str)):
+            raise NotImplementedError("cross-validation is implemented for loss='mse' without an explicit mask")
     if resource != "gpu":
         raise ValueError("rcppml_amd has no CPU path; resource must be 'gpu'")
     A = _as_csc(data)
@@ -145,6 +149,25 @@ def nmf(data, k, tol=1e-4, maxit=100, L1=(0.0, 0.0), L2=(0.0, 0.0), seed=None, m
             if M.shape != A.shape:
                 raise ValueError("mask dimensions must match data")
             mask_arg = (M.p, M.i)
+    if cv:
+        # nmf/fit_cv.hpp: speckled holdout mask (seed = the fit's seed), per-column Gram correction, early stopping on the
+        # test loss with `patience`; mask = "zeros" <=> mask_zeros (only nonzeros can be held out)
+        if max(L21w, L21h, angw, angh, ubw, ubh) > 0:
+            raise NotImplementedError("cross-validation with L21 / angular / upper bounds is not implemented by the MI355X backend")
+        res = _abi.nmf_cv(A.p, A.i, A.x, m, n, k, W_T, H, entry="ex", max_iter=int(maxit), tol=float(tol), L1_H=L1h, L1_W=L1w,
+                          L2_H=L2h, L2_W=L2w, cd_maxit=int(cd_maxit), verbose=int(verbose), seed=seed_int & 0x7FFFFFFF,
+                          holdout_fraction=float(test_fraction), cv_seed=seed_int & 0x7FFFFFFF,
+                          mask_zeros=int(isinstance(mask, str) and mask == "zeros"), nonneg_W=int(nnw), nonneg_H=int(nnh),
+                          norm_type=norm_type, solver_mode=0 if solver == "cd" else 1, sort_model=int(sort_model),
+                          precision=_abi.F32 if precision == "fp32" else _abi.F64, cv_patience=int(patience))
+        if res["status"] != 0:
+            raise _abi.BackendError("GPU CV NMF failed: %s" % res.get("error"))
+        misc = dict(iter=res["iter"], converged=res["converged"], loss=res["train_loss"], test_loss=res["test_loss"],
+                    best_test_loss=res["best_test_loss"], best_iter=res["best_iter"], loss_history=res.get("train_history"),
+                    test_loss_history=res.get("test_history"), solver=solver, solver_mode=0 if solver == "cd" else 1,
+                    L1=(L1w, L1h), L2=(L2w, L2h), seed=seed_int, precision=precision, resource="gpu", loss_type=loss,
+                    test_fraction=float(test_fraction))
+        return NMFModel(w=W_T.copy(), d=res["d"], h=H.T.copy(), misc=misc)
     res = _abi.nmf_unified(A.p, A.i, A.x, m, n, k, W_T, H, entry="ex", max_iter=int(maxit), tol=float(tol), L1_H=L1h,
                            L1_W=L1w, L2_H=L2h, L2_W=L2w, L21_H=L21h, L21_W=L21w, ortho_H=angh, ortho_W=angw, ub_H=ubh, ub_W=ubw, cd_maxit=int(cd_maxit), verbose=int(verbose),
                            seed=seed_int & 0x7FFFFFFF, patience=int(patience), nonneg_W=int(nnw), nonneg_H=int(nnh),

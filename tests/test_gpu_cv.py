@@ -122,3 +122,20 @@ def test_cv_reference_entry_points_and_rejections():
         W, H = W0.copy(), H0.copy()
         r = _abi.nmf_cv(A.p, A.i, A.x, A.rows, A.cols, k, W, H, entry="double", max_iter=2, **kw)
         assert r["status"] == -1 and r["error"], kw
+
+
+def test_cv_python_surface():
+    """nmf(test_fraction = ...) mirrors the R call: test / train losses and histories in misc, patience-based stop."""
+    from rcppml_amd import nmf as N
+    from rcppml_amd.data import CSC
+    A = lowrank_csc(80, 110, 3, 0.3, seed=2)
+    Ap = CSC((A.rows, A.cols), A.p, A.i, A.x)
+    mod = N.nmf(Ap, 4, test_fraction=0.1, seed=3, maxit=15, tol=1e-6, patience=3)
+    assert mod.misc["test_fraction"] == 0.1 and np.isfinite(mod.misc["test_loss"]) and np.isfinite(mod.misc["loss"])
+    assert len(mod.misc["test_loss_history"]) == mod.misc["iter"] <= 15
+    assert mod.misc["best_test_loss"] <= mod.misc["test_loss_history"].min() * (1 + 1e-6)
+    assert mod.w.min() >= 0 and mod.h.min() >= 0
+    mz = N.nmf(Ap, 4, test_fraction=0.1, seed=3, maxit=5, mask="zeros")
+    assert np.isfinite(mz.misc["test_loss"])
+    with pytest.raises(NotImplementedError):
+        N.nmf(Ap, 4, test_fraction=0.1, seed=3, loss="nb")
