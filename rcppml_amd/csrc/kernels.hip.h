@@ -1318,6 +1318,162 @@ __global__ __launch_bounds__(256) void cv_solve_kernel(
     if (fok) X[j * (int64_t)k + lane] = x;
 }
 
+// fp32, k <= 32 (k % 4 == 0): the same half-update with the Gram correction on the MATRIX cores.  Held-out rows are
+// collected in a small LDS queue (ballot + prefix popcount); every 32 of them are gathered with 16-byte loads (lane =
+// row t, feature half hh), parked in LDS and applied as 16 rank-2 updates  G_local -= f f^T  with
+// v_mfma_f32_32x32x2_f32 (A operand = -f, B operand = f; accumulator tile initialised with G) -- against 32 shuffles
+// and 32 LDS read-modify-writes per held-out row in cv_solve_kernel.  With zeros held out a column of a 20 000-row
+// matrix has ~2 000 such rows.
+static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void cv_solve_mfma32_kernel(
+    const int* __restrict__ colptr, const int* __restrict__ rowidx, const float* __restrict__ vals, int64_t ncols, int nrows,
+    const float* __restrict__ F, const float* __restrict__ Gfull, float* __restrict__ X, int k, unsigned long long seed,
+    unsigned long long threshold, int mask_zeros, int transposed, float l1, int nonneg, int maxit, int solver_mode) {
+    constexpr int KP = 32, FS = 36, QCAP = 96;
+    constexpr int WAVE_FLOATS = 32 * FS + QCAP;       // staged rows (aliased by G_local afterwards) | row queue
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float* Fst = reinterpret_cast<float*>(smem_raw) + (size_t)wave * WAVE_FLOATS;
+    int* hq = reinterpret_cast<int*>(Fst + 32 * FS);
+    float* Gl = Fst;                                  // [c][r]
+    const int64_t j = (int64_t)blockIdx.x * 4 + wave;
+    if (j >= ncols) return;
+    const int r = lane & 31, hh = lane >> 5;
+    const bool fok = lane < k;
+    const bool lin = lane < KP;
+    const int ll = lin ? lane : 0;
+    const unsigned col = (unsigned)j;
+    f32x16 acc;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+        const int gi = (v & 3) + 8 * (v >> 2) + 4 * hh, gj = r;
+        acc[v] = (gi < k && gj < k) ? Gfull[(int64_t)gj * k + gi] : (gi == gj ? 1.f : 0.f);
+    }
+    int qn = 0;                                       // rows waiting in hq (wave-uniform)
+    // apply the first `cnt` (<= 32) queued rows to the accumulator tile
+    auto flush = [&](int cnt) {
+        const bool ok = r < cnt;
+        const int row = ok ? hq[r] : 0;
+        const float* fsrc = F + (int64_t)row * k + 16 * hh;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int c0 = 16 * hh + 4 * q;
+            const float4 v = (ok && c0 < k) ? *reinterpret_cast<const float4*>(fsrc + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4*>(Fst + r * FS + c0) = v;
+        }
+        __builtin_amdgcn_wave_barrier();
+        const int nst = (cnt + 1) >> 1;
+#pragma unroll 4
+        for (int s2 = 0; s2 < nst; ++s2) {
+            const float fv = Fst[(2 * s2 + hh) * FS + r];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(-fv, fv, acc, 0, 0, 0);
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
+    // append the rows flagged in `held` (one per lane, row index `row`) to the queue; flush while >= 32 are waiting
+    auto push = [&](bool held, int row) {
+        const unsigned long long m = __ballot(held);
+        if (m == 0ull) return;
+        const int rank = __popcll(m & ((1ull << lane) - 1ull));
+        if (held) hq[qn + rank] = row;
+        qn += __popcll(m);
+        __builtin_amdgcn_wave_barrier();
+        while (qn >= 32) {
+            flush(32);
+            const int rest = qn - 32;
+            const int moved = lane < rest ? hq[32 + lane] : 0;      // rest <= 63
+            __builtin_amdgcn_wave_barrier();
+            if (lane < rest) hq[lane] = moved;
+            __builtin_amdgcn_wave_barrier();
+            qn = rest;
+        }
+    };
+    float b = 0.f;
+    for (int t0 = colptr[j]; t0 < colptr[j + 1]; t0 += 64) {       // 64 nonzeros per step: lane-parallel hashing
+        const int t = t0 + lane;
+        const bool valid = t < colptr[j + 1];
+        const int row = valid ? rowidx[t] : 0;
+        const float a = valid ? vals[t] : 0.f;
+        const bool held = valid && (transposed ? cv_hash_dev(seed, col, (unsigned)row) : cv_hash_dev(seed, (unsigned)row, col)) < threshold;
+        // train right-hand side: lane = feature again, one nonzero at a time
+        unsigned long long tm = __ballot(valid && !held);
+        while (tm) {
+            const int bit = __builtin_ctzll(tm);
+            tm &= tm - 1;
+            const int rw = __builtin_amdgcn_readlane(row, bit);
+            const float av = lane_value(a, bit);
+            if (fok) b = tfma(av, F[(int64_t)rw * k + lane], b);
+        }
+        if (mask_zeros) push(held, row);
+    }
+    if (!mask_zeros) {
+        for (int r0 = 0; r0 < nrows; r0 += 64) {
+            const int rw = r0 + lane;
+            const bool held = rw < nrows &&
+                (transposed ? cv_hash_dev(seed, col, (unsigned)rw) : cv_hash_dev(seed, (unsigned)rw, col)) < threshold;
+            push(held, rw);
+        }
+    }
+    if (qn > 0) flush(qn);
+    // park G_local in LDS ([c][r]; symmetric)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+        const int gi = (v & 3) + 8 * (v >> 2) + 4 * hh;
+        Gl[gi * KP + r] = acc[v];
+    }
+    __builtin_amdgcn_wave_barrier();
+    float x = fok ? X[j * (int64_t)k + lane] : 0.f;
+    if (solver_mode == 1) {
+        if (l1 > 0.f && fok) b -= l1;
+        for (int c = 0; c < KP; ++c) {
+            float s = Gl[c * KP + ll];
+            for (int p = 0; p < c; ++p) s -= Gl[p * KP + ll] * Gl[p * KP + c];
+            float dcc = __shfl(s, c, 64);
+            if (!(dcc > 0.f)) dcc = tabs(dcc) + 1e-30f;
+            const float lcc = sqrt(dcc);
+            if (lin) Gl[c * KP + lane] = lane == c ? lcc : (lane > c ? s / lcc : 0.f);
+            RK_WAVE_SYNC();
+        }
+        float y = b;
+        for (int i = 0; i < k; ++i) {
+            const float yi = __shfl(y, i, 64) / Gl[i * KP + i];
+            if (lane == i) y = yi;
+            else if (lane > i) y -= Gl[i * KP + ll] * yi;
+        }
+        for (int i = k - 1; i >= 0; --i) {
+            const float xi = __shfl(y, i, 64) / Gl[i * KP + i];
+            if (lane == i) y = xi;
+            else if (lane < i) y -= Gl[ll * KP + i] * xi;
+        }
+        x = y;
+        if (nonneg) x = x > 0.f ? x : 0.f;
+    } else {
+        const float gd = Gl[ll * KP + ll];
+        for (int it = 0; it < maxit; ++it) {
+            int cur = 0;
+            bool any = false;
+            while (true) {
+                float diff = b / gd;
+                if (l1 != 0.f) diff -= l1;
+                const float nv = x + diff;
+                float ad = diff, nx = nv;
+                if (nonneg && nv < 0.f) { ad = -x; nx = 0.f; }
+                const bool moves = fok && (gd > 0.f) && (ad != 0.f) && (lane >= cur);
+                const unsigned long long mask = __ballot(moves);
+                if (mask == 0ull) break;
+                any = true;
+                const int i = __builtin_ctzll(mask);
+                const float ad_i = lane_value(ad, i), nx_i = lane_value(nx, i);
+                if (lane == i) x = nx_i;
+                b = tfma(-Gl[i * KP + ll], ad_i, b);
+                cur = i + 1;
+                if (cur >= KP) break;
+            }
+            if (!any) break;
+        }
+    }
+    if (fok) X[j * (int64_t)k + lane] = x;
+}
+
 // Squared error and count over the held-out entries (fit_cv.hpp:1444-1494), one wavefront per column of A.
 // out partials: [block] = {sum of squared errors (fp64), count}
 template <class T>

@@ -1,4 +1,6 @@
 // ops_cv.hip -- cross-validation half-update and held-out error (device-level C ABI, include/rcppml_gpu.h layer 2)
+#include <type_traits>
+#include <cstring>
 #include "common.hip.h"
 #include "kernels.hip.h"
 
@@ -25,6 +27,18 @@ void cv_solve_impl(rcppml_hip_ctx* c, const int* cp, const int* ri, const T* val
     unsigned long long seed, thr;
     mask_params(frac, cv_seed, &seed, &thr);
     const int64_t nblk = (ncols + 3) / 4;
+    if constexpr (std::is_same<T, float>::value) {
+        // fp32, k <= 32: Gram correction on the matrix cores (RCPPML_GPU_CV_VARIANT=valu keeps the LDS read-modify-write form)
+        static int use_mfma = -1;
+        if (use_mfma < 0) { const char* e = getenv("RCPPML_GPU_CV_VARIANT"); use_mfma = (e && !strcmp(e, "valu")) ? 0 : 1; }
+        if (use_mfma && k <= 32 && k % 4 == 0 && reinterpret_cast<uintptr_t>(F) % 16 == 0) {
+            const size_t smem = (size_t)4 * (32 * 36 + 96) * sizeof(float);
+            hipLaunchKernelGGL(cv_solve_mfma32_kernel, dim3((unsigned)nblk), dim3(256), smem, c->stream, cp, ri, vals, ncols, nrows, F, G,
+                               X, k, seed, thr, mask_zeros, transposed, l1, nonneg, maxit, solver_mode);
+            HIPCHK(hipGetLastError());
+            return;
+        }
+    }
     if (k <= 32) {
         hipLaunchKernelGGL((cv_solve_kernel<T, 32>), dim3((unsigned)nblk), dim3(256), (size_t)4 * 32 * 32 * sizeof(T), c->stream, cp, ri,
                            vals, ncols, nrows, F, G, X, k, seed, thr, mask_zeros, transposed, l1, nonneg, maxit, solver_mode);
