@@ -1474,6 +1474,168 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8
     if (fok) X[j * (int64_t)k + lane] = x;
 }
 
+// fp64, k <= 32 (k % 2 == 0): the same with v_mfma_f64_16x16x4_f64 (2 x 2 tiles of 16 x 16, four held-out rows per
+// instruction step, C/D map col = lane&15, row = (lane>>4) + 4v).
+static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void cv_solve_mfma64_kernel(
+    const int* __restrict__ colptr, const int* __restrict__ rowidx, const double* __restrict__ vals, int64_t ncols, int nrows,
+    const double* __restrict__ F, const double* __restrict__ Gfull, double* __restrict__ X, int k, unsigned long long seed,
+    unsigned long long threshold, int mask_zeros, int transposed, double l1, int nonneg, int maxit, int solver_mode) {
+    constexpr int KP = 32, FS = 34, QCAP = 96;
+    constexpr int WAVE_DOUBLES = 32 * FS + QCAP / 2;   // staged rows (aliased by G_local afterwards) | row queue (ints)
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    double* Fst = reinterpret_cast<double*>(smem_raw) + (size_t)wave * WAVE_DOUBLES;
+    int* hq = reinterpret_cast<int*>(Fst + 32 * FS);
+    double* Gl = Fst;                                  // [c][r]
+    const int64_t j = (int64_t)blockIdx.x * 4 + wave;
+    if (j >= ncols) return;
+    const int r = lane & 31, hh = lane >> 5;
+    const bool fok = lane < k;
+    const bool lin = lane < KP;
+    const int ll = lin ? lane : 0;
+    const unsigned col = (unsigned)j;
+    const int r16 = lane & 15, kk = lane >> 4;        // MFMA phase: feature slot r16, K-slot kk (16x16x4 f64)
+    f64x4 acc[2][2];
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int gi = 16 * ti + kk + 4 * v, gj = 16 * tj + r16;
+                acc[ti][tj][v] = (gi < k && gj < k) ? Gfull[(int64_t)gj * k + gi] : (gi == gj ? 1.0 : 0.0);
+            }
+    int qn = 0;                                       // rows waiting in hq (wave-uniform)
+    // apply the first `cnt` (<= 32) queued rows to the accumulator tile
+    auto flush = [&](int cnt) {
+        const bool ok = r < cnt;
+        const int row = ok ? hq[r] : 0;
+        const double* fsrc = F + (int64_t)row * k + 16 * hh;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int c0 = 16 * hh + 2 * q;
+            const double2 v = (ok && c0 < k) ? *reinterpret_cast<const double2*>(fsrc + 2 * q) : make_double2(0.0, 0.0);
+            *reinterpret_cast<double2*>(Fst + r * FS + c0) = v;
+        }
+        __builtin_amdgcn_wave_barrier();
+        const int nst = (cnt + 3) >> 2;
+#pragma unroll 2
+        for (int s4 = 0; s4 < nst; ++s4) {
+            const int t = 4 * s4 + kk;
+            const double f0 = Fst[t * FS + r16], f1 = Fst[t * FS + 16 + r16];
+            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(-f0, f0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(-f0, f1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(-f1, f0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(-f1, f1, acc[1][1], 0, 0, 0);
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
+    // append the rows flagged in `held` (one per lane, row index `row`) to the queue; flush while >= 32 are waiting
+    auto push = [&](bool held, int row) {
+        const unsigned long long m = __ballot(held);
+        if (m == 0ull) return;
+        const int rank = __popcll(m & ((1ull << lane) - 1ull));
+        if (held) hq[qn + rank] = row;
+        qn += __popcll(m);
+        __builtin_amdgcn_wave_barrier();
+        while (qn >= 32) {
+            flush(32);
+            const int rest = qn - 32;
+            const int moved = lane < rest ? hq[32 + lane] : 0;      // rest <= 63
+            __builtin_amdgcn_wave_barrier();
+            if (lane < rest) hq[lane] = moved;
+            __builtin_amdgcn_wave_barrier();
+            qn = rest;
+        }
+    };
+    double b = 0.0;
+    for (int t0 = colptr[j]; t0 < colptr[j + 1]; t0 += 64) {       // 64 nonzeros per step: lane-parallel hashing
+        const int t = t0 + lane;
+        const bool valid = t < colptr[j + 1];
+        const int row = valid ? rowidx[t] : 0;
+        const double a = valid ? vals[t] : 0.0;
+        const bool held = valid && (transposed ? cv_hash_dev(seed, col, (unsigned)row) : cv_hash_dev(seed, (unsigned)row, col)) < threshold;
+        // train right-hand side: lane = feature again, one nonzero at a time
+        unsigned long long tm = __ballot(valid && !held);
+        while (tm) {
+            const int bit = __builtin_ctzll(tm);
+            tm &= tm - 1;
+            const int rw = __builtin_amdgcn_readlane(row, bit);
+            const double av = lane_value(a, bit);
+            if (fok) b = tfma(av, F[(int64_t)rw * k + lane], b);
+        }
+        if (mask_zeros) push(held, row);
+    }
+    if (!mask_zeros) {
+        for (int r0 = 0; r0 < nrows; r0 += 64) {
+            const int rw = r0 + lane;
+            const bool held = rw < nrows &&
+                (transposed ? cv_hash_dev(seed, col, (unsigned)rw) : cv_hash_dev(seed, (unsigned)rw, col)) < threshold;
+            push(held, rw);
+        }
+    }
+    if (qn > 0) flush(qn);
+    // park G_local in LDS ([c][r]; symmetric)
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) Gl[(16 * ti + kk + 4 * v) * KP + 16 * tj + r16] = acc[ti][tj][v];
+    __builtin_amdgcn_wave_barrier();
+    double x = fok ? X[j * (int64_t)k + lane] : 0.0;
+    if (solver_mode == 1) {
+        if (l1 > 0.0 && fok) b -= l1;
+        for (int c = 0; c < KP; ++c) {
+            double s = Gl[c * KP + ll];
+            for (int p = 0; p < c; ++p) s -= Gl[p * KP + ll] * Gl[p * KP + c];
+            double dcc = __shfl(s, c, 64);
+            if (!(dcc > 0.0)) dcc = tabs(dcc) + 1e-30;
+            const double lcc = sqrt(dcc);
+            if (lin) Gl[c * KP + lane] = lane == c ? lcc : (lane > c ? s / lcc : 0.0);
+            RK_WAVE_SYNC();
+        }
+        double y = b;
+        for (int i = 0; i < k; ++i) {
+            const double yi = __shfl(y, i, 64) / Gl[i * KP + i];
+            if (lane == i) y = yi;
+            else if (lane > i) y -= Gl[i * KP + ll] * yi;
+        }
+        for (int i = k - 1; i >= 0; --i) {
+            const double xi = __shfl(y, i, 64) / Gl[i * KP + i];
+            if (lane == i) y = xi;
+            else if (lane < i) y -= Gl[ll * KP + i] * xi;
+        }
+        x = y;
+        if (nonneg) x = x > 0.0 ? x : 0.0;
+    } else {
+        const double gd = Gl[ll * KP + ll];
+        for (int it = 0; it < maxit; ++it) {
+            int cur = 0;
+            bool any = false;
+            while (true) {
+                double diff = b / gd;
+                if (l1 != 0.0) diff -= l1;
+                const double nv = x + diff;
+                double ad = diff, nx = nv;
+                if (nonneg && nv < 0.0) { ad = -x; nx = 0.0; }
+                const bool moves = fok && (gd > 0.0) && (ad != 0.0) && (lane >= cur);
+                const unsigned long long mask = __ballot(moves);
+                if (mask == 0ull) break;
+                any = true;
+                const int i = __builtin_ctzll(mask);
+                const double ad_i = lane_value(ad, i), nx_i = lane_value(nx, i);
+                if (lane == i) x = nx_i;
+                b = tfma(-Gl[i * KP + ll], ad_i, b);
+                cur = i + 1;
+                if (cur >= KP) break;
+            }
+            if (!any) break;
+        }
+    }
+    if (fok) X[j * (int64_t)k + lane] = x;
+}
+
 // Squared error and count over the held-out entries (fit_cv.hpp:1444-1494), one wavefront per column of A.
 // out partials: [block] = {sum of squared errors (fp64), count}
 template <class T>

@@ -39,6 +39,17 @@ void cv_solve_impl(rcppml_hip_ctx* c, const int* cp, const int* ri, const T* val
             return;
         }
     }
+    if constexpr (std::is_same<T, double>::value) {
+        static int use_mfma64 = -1;
+        if (use_mfma64 < 0) { const char* e = getenv("RCPPML_GPU_CV_VARIANT"); use_mfma64 = (e && !strcmp(e, "valu")) ? 0 : 1; }
+        if (use_mfma64 && k <= 32 && k % 2 == 0 && reinterpret_cast<uintptr_t>(F) % 16 == 0) {
+            const size_t smem = (size_t)4 * (32 * 34 + 48) * sizeof(double);
+            hipLaunchKernelGGL(cv_solve_mfma64_kernel, dim3((unsigned)nblk), dim3(256), smem, c->stream, cp, ri, vals, ncols, nrows, F, G,
+                               X, k, seed, thr, mask_zeros, transposed, l1, nonneg, maxit, solver_mode);
+            HIPCHK(hipGetLastError());
+            return;
+        }
+    }
     if (k <= 32) {
         hipLaunchKernelGGL((cv_solve_kernel<T, 32>), dim3((unsigned)nblk), dim3(256), (size_t)4 * 32 * 32 * sizeof(T), c->stream, cp, ri,
                            vals, ncols, nrows, F, G, X, k, seed, thr, mask_zeros, transposed, l1, nonneg, maxit, solver_mode);
