@@ -266,6 +266,10 @@ RCPPML_GPU_API int rcppml_hip_cv_test_error(rcppml_hip_ctx* ctx, int dtype, cons
                                             const void* H, int k, double holdout_fraction, unsigned long long cv_seed,
                                             int mask_zeros, double* out2);
 
+/* Y = diag(d) X for a k x ncols factor (variant_helpers.hpp:265-272 apply_scaling): W diag(d) of the projective H
+ * update  H = (diag(d) W_T) A  (nmf/fit_cpu.hpp:462-472, variant_helpers.hpp:308-325). */
+RCPPML_GPU_API int rcppml_hip_mul_rows(rcppml_hip_ctx* ctx, int dtype, const void* X, int k, int64_t ncols, const void* d, void* Y);
+
 /* k x k feature layer, fused-path placement of nmf/fit_cpu.hpp:505-511,636-639 / :738-745,884-887:
  * rcppml_hip_apply_l21: G(i,i) += lambda / ||X.row(i)||_2 for rows with norm > 1e-10 (features/L21.hpp:38-51); X is the
  *   CURRENT factor (k x ncols), applied to the Gram before the solve.

@@ -598,6 +598,13 @@ FitResult<S> nmf_fit(const Csc<S>& A, const FitConfig<S>& cfg, S* W_T, S* H, S* 
 
     for (int iter = 0; iter < cfg.max_iter; ++iter) {
         // ------------------------------------------------ H half-update
+        if (cfg.projective) {
+            // variant_helpers.hpp:308-325  projective_h_update: H = (diag(d) W_T) A, then H -> d (fit_cpu.hpp:462-472)
+            std::vector<S> Wd((size_t)k * m);
+            for (int i = 0; i < m; ++i) for (int f = 0; f < k; ++f) Wd[(size_t)i * k + f] = W_T[(size_t)i * k + f] * d[f];
+            rhs(A, Wd.data(), k, H, threads);
+            extract_scaling(H, k, n, d, cfg.norm_type);
+        } else {
         gram(W_T, k, m, G.data());                                       // :491
         if (cfg.has_mask) {
             // :560-564 G rebuilt unmodified (eps only); L1/L2 per column inside
@@ -620,6 +627,7 @@ FitResult<S> nmf_fit(const Csc<S>& A, const FitConfig<S>& cfg, S* W_T, S* H, S* 
         if (cfg.ub_H > 0) apply_upper_bound(H, (size_t)k * n, cfg.ub_H);  // :636-637
         apply_angular_posthoc(H, k, (int64_t)n, cfg.angular_H);              // :638-639
         extract_scaling(H, k, n, d, cfg.norm_type);                       // :645
+        }   // standard H update
 
         // ------------------------------------------------ W half-update
         gram(H, k, n, G.data());                                          // :715
@@ -768,7 +776,7 @@ template <class S> static Csc<S> mk(int rows, int cols, const int* p, const int*
         S irls_tol, int dispersion_mode, S nb_size_init, S nb_size_max, S nb_size_min, int sort_model,    \
         int threads, const int* mask_p, const int* mask_i, const S* mask_x, int* out_iter,                \
         int* out_converged, S* out_loss, S* out_tol, S* loss_hist, S* out_theta, S tweedie_power,         \
-        S L21_H, S L21_W, S angular_H, S angular_W, S robust_delta) {                                     \
+        S L21_H, S L21_W, S angular_H, S angular_W, S robust_delta, int projective) {                     \
         FitConfig<S> c;                                                                                   \
         c.k = k; c.max_iter = max_iter; c.tol = tol; c.L1_H = L1_H; c.L1_W = L1_W; c.L2_H = L2_H;         \
         c.L2_W = L2_W; c.ub_H = ub_H; c.ub_W = ub_W; c.cd_maxit = cd_maxit; c.cd_tol = cd_tol;            \
@@ -777,7 +785,7 @@ template <class S> static Csc<S> mk(int rows, int cols, const int* p, const int*
         c.irls_max_iter = irls_max_iter; c.irls_tol = irls_tol; c.dispersion_mode = dispersion_mode;      \
         c.nb_size_init = nb_size_init; c.nb_size_max = nb_size_max; c.nb_size_min = nb_size_min;          \
         c.sort_model = sort_model != 0; c.threads = threads; c.tweedie_power = tweedie_power;             \
-        c.L21_H = L21_H; c.L21_W = L21_W; c.angular_H = angular_H; c.angular_W = angular_W; c.robust_delta = robust_delta; \
+        c.L21_H = L21_H; c.L21_W = L21_W; c.angular_H = angular_H; c.angular_W = angular_W; c.robust_delta = robust_delta; c.projective = projective != 0; \
         if (mask_p) { c.has_mask = true; c.mask = mk(m, n, mask_p, mask_i, mask_x); }                     \
         FitResult<S> r = nmf_fit(mk(m, n, p, i, x), c, W_T, H, d);                                        \
         *out_iter = r.iterations; *out_converged = r.converged ? 1 : 0; *out_loss = r.train_loss;         \

@@ -433,6 +433,7 @@ template <class S> struct FitConfig {
     S irls_tol = S(1e-4);
     int dispersion_mode = 2;       // PER_ROW
     S nb_size_init = 10, nb_size_max = S(1e6), nb_size_min = S(0.01);
+    bool projective = false;                  // NMFConfig::projective: H = diag(d) W_T A instead of an NNLS solve
     S robust_delta = 0;                       // LossConfig::robust_delta (math/loss.hpp:89-96): > 0 -> Huber on Pearson residuals
     S tweedie_power = S(1.5);                 // LossConfig::power_param (math/loss.hpp:99-104), loss_type 8 only
     bool sort_model = true;

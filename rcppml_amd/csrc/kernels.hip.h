@@ -1113,6 +1113,14 @@ __global__ __launch_bounds__(256) void scale_rows(T* __restrict__ X, int k, int6
         X[e] = X[e] / d[e % k];
 }
 
+// Y = diag(d) X (rows scaled UP; variant_helpers.hpp:265-272 apply_scaling) -- the projective H update's W_Td
+template <class T>
+__global__ __launch_bounds__(256) void mul_rows(const T* __restrict__ X, int k, int64_t total, const T* __restrict__ d,
+                                                 T* __restrict__ Y) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) Y[e] = X[e] * d[e % k];
+}
+
 // ---------------------------------------------------------------------------
 // fp64 reductions for the loss (reference primitives/primitives.hpp:100-115 trace_AtA;
 // nmf/fit_cpu.hpp:1740-1753 cross term and recon norm).  Block partials then a fixed-order sum.

@@ -96,6 +96,22 @@ extern "C" int rcppml_hip_angular_posthoc(rcppml_hip_ctx* c, int dtype, void* X,
     RCPPML_CATCH_RET
 }
 
+extern "C" int rcppml_hip_mul_rows(rcppml_hip_ctx* c, int dtype, const void* X, int k, int64_t ncols, const void* d, void* Y) {
+    try {
+        HIPCHK(hipSetDevice(c->device));
+        const int64_t total = (int64_t)k * ncols;
+        if (total <= 0) return 0;
+        int64_t nblk = (total + 255) / 256;
+        if (nblk > 8 * (int64_t)c->num_cu) nblk = 8 * c->num_cu;
+        if (dtype == RCPPML_F32)
+            hipLaunchKernelGGL(mul_rows<float>, dim3((unsigned)nblk), dim3(256), 0, c->stream, (const float*)X, k, total, (const float*)d, (float*)Y);
+        else
+            hipLaunchKernelGGL(mul_rows<double>, dim3((unsigned)nblk), dim3(256), 0, c->stream, (const double*)X, k, total, (const double*)d, (double*)Y);
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
+    RCPPML_CATCH_RET
+}
 extern "C" int rcppml_hip_apply_scaling(rcppml_hip_ctx* c, int dtype, void* X, int k, int64_t ncols, int norm_type,
                                         const void* sums, void* d) {
     try {

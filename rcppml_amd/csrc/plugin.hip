@@ -68,6 +68,7 @@ struct FitParams {
     int max_iter; double tol;
     double L1_H, L1_W, L2_H, L2_W, ub_H, ub_W;
     double L21_H = 0, L21_W = 0, angular_H = 0, angular_W = 0;
+    int projective = 0;                      // H = (diag(d) W_T) A instead of the NNLS half-update (variant_helpers.hpp:308-325)
     int cd_maxit; double cd_tol;
     int verbose, patience, nonneg_W, nonneg_H, norm_type, solver_mode;
     const int* mask_p; const int* mask_i;   // NULL = no mask
@@ -164,6 +165,7 @@ void fit(FitParams& P) {
         HIPCHK(hipStreamSynchronize(s));
     }
     DevBuf dBh((size_t)k * n * sizeof(T)), dBw((size_t)k * m * sizeof(T));
+    DevBuf dWd(P.projective ? (size_t)k * m * sizeof(T) : 16);
     DevBuf dG((size_t)k * k * sizeof(T)), dGs((size_t)k * k * sizeof(T)), dGwt((size_t)k * k * sizeof(T));
     DevBuf dsums((size_t)k * sizeof(T));
     DevBuf dtr(sizeof(double)), dloss(4 * sizeof(double));
@@ -198,7 +200,10 @@ void fit(FitParams& P) {
     auto enqueue_iteration = [&](int iter) {
         const int warm = iter > 0 ? 1 : 0;
         // ================= H half-update (fit_cpu.hpp:486-645)
-        if (is_nb) {                                                                    // :565-606 (G: eps only)
+        if (P.projective) {                                                             // :462-472
+            OPCHK(rcppml_hip_mul_rows(c, dt, dW.p, k, m, dd.p, dWd.p));
+            OPCHK(rcppml_hip_rhs(c, dt, dAp.as<int>(), dAi.as<int>(), dAx.p, n, dWd.p, k, dH.p));
+        } else if (is_nb) {                                                                    // :565-606 (G: eps only)
             OPCHK(rcppml_hip_gram(c, dt, dW.p, k, m, eps, 0.0, dG.p));
             OPCHK(rcppml_hip_solve_irls(c, dt, P.loss_type, dAp.as<int>(), dAi.as<int>(), dAx.p, n, dW.p, dG.p, dH.p, k, P.L1_H,
                                         P.L2_H, P.nonneg_H, P.cd_maxit, P.irls_max_iter, P.irls_tol,
@@ -224,7 +229,7 @@ void fit(FitParams& P) {
             else                                                                        // :527-534
                 OPCHK(rcppml_hip_solve_chol(c, dt, dG.p, dBh.p, dH.p, k, n, P.L1_H > 0 ? P.L1_H : 0.0, P.nonneg_H, P.ub_H));
         }
-        if (P.angular_H > 0) OPCHK(rcppml_hip_angular_posthoc(c, dt, dH.p, k, n, P.angular_H));   // :638-639
+        if (P.angular_H > 0 && !P.projective) OPCHK(rcppml_hip_angular_posthoc(c, dt, dH.p, k, n, P.angular_H));   // :638-639 (standard branch only)
         OPCHK(rcppml_hip_row_norms(c, dt, dH.p, k, n, P.norm_type, dsums.p));           // :645 extract_scaling
         OPCHK(rcppml_hip_apply_scaling(c, dt, dH.p, k, n, P.norm_type, dsums.p, dd.p));
 
@@ -410,7 +415,8 @@ void nmf_entry(RCPPML_NMF_UNIFIED_ARGS, const int* mask_p, const int* mask_i, do
         if (*L21_H < 0 || *L21_W < 0 || *ortho_H < 0 || *ortho_W < 0) throw std::runtime_error("negative L21 / angular penalty");
         if (*graph_W_nnz > 0 || *graph_H_nnz > 0) throw std::runtime_error("graph regularisation not supported");
         if (*guide_H_count > 0) throw std::runtime_error("classifier guides not supported");
-        if (*projective != 0 || *symmetric != 0) throw std::runtime_error("projective/symmetric NMF not supported");
+        if (*symmetric != 0) throw std::runtime_error("symmetric NMF not supported");
+        if (*projective != 0 && (*loss_type != 0 || *robust_delta > 0 || mask_p)) throw std::runtime_error("projective NMF: MSE path without explicit mask only");
         if (*solver_mode != 0 && *solver_mode != 1) throw std::runtime_error("solver_mode must be 0 (CD) or 1 (Cholesky+clip)");
         if (*k < 1 || *k > 128) throw std::runtime_error("k must be in [1,128]");
         if (*m < 1 || *n < 1) throw std::runtime_error("empty matrix");
@@ -431,7 +437,7 @@ void nmf_entry(RCPPML_NMF_UNIFIED_ARGS, const int* mask_p, const int* mask_i, do
         P.sort_model = sort_model; P.loss_history = loss_history;
         P.loss_type = *loss_type; P.irls_max_iter = *irls_max_iter; P.irls_tol = *irls_tol;
         P.dispersion_mode = *gp_dispersion_mode; P.nb_size_init = *nb_size_init; P.nb_size_max = *nb_size_max;
-        P.nb_size_min = *nb_size_min; P.out_theta = out_theta; P.tweedie_power = *tweedie_power; P.robust_delta = *robust_delta;
+        P.nb_size_min = *nb_size_min; P.out_theta = out_theta; P.tweedie_power = *tweedie_power; P.robust_delta = *robust_delta; P.projective = *projective != 0 ? 1 : 0;
         if (precision == RCPPML_F64) fit<double>(P); else fit<float>(P);
         *out_iter = P.out_iter; *out_converged = P.out_converged; *out_loss = P.out_loss; *out_tol = P.out_tol;
         *out_theta_len = P.out_theta_len;

@@ -117,7 +117,7 @@ def test_unsupported_features_are_rejected(abi):
     """The plugin must set out_status=-1 (-> caller's CPU fallback) instead of silently dropping a feature."""
     A = lowrank_csc(50, 60, 3, 0.2, seed=1)
     W0, H0 = O.init_factors(1, 4, A.rows, A.cols, np.float64)
-    for kw in (dict(L21_H=0.1, loss_type=5), dict(ortho_W=-0.1), dict(projective=1), dict(symmetric=1), dict(loss_type=3),
+    for kw in (dict(L21_H=0.1, loss_type=5), dict(ortho_W=-0.1), dict(projective=1, loss_type=5), dict(symmetric=1), dict(loss_type=3),
                dict(loss_type=1), dict(loss_type=4, gp_dispersion_mode=2), dict(loss_type=6, gp_dispersion_mode=2), dict(loss_type=5, solver_mode=1),
                dict(graph_W_nnz=5), dict(guide_H_count=1), dict(solver_mode=2)):
         W, H = W0.copy(), H0.copy()
@@ -267,3 +267,19 @@ def test_l21_and_angular_features(abi, entry, tol_loss, tol_fac):
     base = O.nmf_fit(A, W0, H0, dtype, max_iter=6, tol=0.0, solver_mode=0)
     pen = O.nmf_fit(A, W0, H0, dtype, max_iter=6, tol=0.0, solver_mode=0, L21=(0.05, 0.2), angular=(0.03, 0.05))
     assert abs(pen.loss - base.loss) > 1e-3 * abs(base.loss)
+
+
+@pytest.mark.parametrize("entry,tol_loss,tol_fac", [("double", 1e-6, 1e-6), ("float", 5e-4, 5e-3)])
+def test_projective_nmf(abi, entry, tol_loss, tol_fac):
+    """projective = TRUE: H = (diag(d) W_T) A instead of an NNLS half-update (variant_helpers.hpp:308-325), W standard."""
+    A = lowrank_csc(90, 140, 5, 0.25, seed=41)
+    k = 6
+    dtype = np.float64 if entry == "double" else np.float32
+    W0, H0 = O.init_factors(13, k, A.rows, A.cols, np.float64)
+    for solver in (0, 1):
+        ref = O.nmf_fit(A, W0, H0, dtype, max_iter=8, tol=0.0, solver_mode=solver, L1=(0.01, 0.0), projective=True)
+        res = _run_gpu(abi, A, W0, H0, entry, max_iter=8, tol=0.0, solver_mode=solver, L1_W=0.01, projective=1)
+        _compare(res, ref, tol_loss, tol_fac)
+    base = O.nmf_fit(A, W0, H0, dtype, max_iter=8, tol=0.0, solver_mode=0)
+    proj = O.nmf_fit(A, W0, H0, dtype, max_iter=8, tol=0.0, solver_mode=0, projective=True)
+    assert abs(proj.loss - base.loss) > 1e-6 * abs(base.loss)
