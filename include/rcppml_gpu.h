@@ -74,6 +74,21 @@ RCPPML_GPU_API void rcppml_gpu_detect(int* num_gpus, double* total_mem_mb, doubl
         const int* guide_H_ncs, int* guide_H_count, int* out_iter, int* out_converged,             \
         double* out_loss, int* out_status, double* out_tol
 
+/* Zero-copy NMF on a device-resident CSC.  Replaces reference `rcppml_gpu_nmf_zerocopy_double`
+ * (src/gpu_bridge_nmf.cu:879-967, called from R/sp_gpu.R through .C()): col_ptr (int32), row_idx (int32) and values
+ * (double) are DEVICE pointers whose addresses are passed as doubles (R has no 64-bit integer); W (k x m), H (k x n), d are
+ * host buffers, in/out.  MSE loss, CD solver (the entry carries no solver argument), L1 / L2 / L21 / angular / bounds.
+ * No upload of A: only the transpose, the factors and the per-iteration loss touch PCIe. */
+RCPPML_GPU_API void rcppml_gpu_nmf_zerocopy_double(double* d_col_ptr_addr, double* d_row_idx_addr, double* d_values_addr,
+                                                   int* m, int* n, double* nnz_d, int* k, double* W, double* H, double* d,
+                                                   int* max_iter, double* tol, double* L1_H, double* L1_W, double* L2_H,
+                                                   double* L2_W, double* L21_H, double* L21_W, double* ortho_H,
+                                                   double* ortho_W, double* ub_H, double* ub_W, int* cd_maxit, int* verbose,
+                                                   int* seed, int* loss_every, int* patience, int* nonneg_W, int* nonneg_H,
+                                                   int* loss_type, double* huber_delta, int* irls_max_iter, double* irls_tol,
+                                                   int* norm_type, int* out_iter, int* out_converged, double* out_loss,
+                                                   int* out_status, double* out_tol);
+
 /* Cross-validation NMF.  Replaces reference `rcppml_gpu_nmf_cv_unified_float` (type
  * inst/include/FactorNet/gpu/bridge_nmf.hpp:77-99, resolved and called at :407-497 by bridge_nmf_cv_sparse): 51 pointer
  * arguments, W (k x m) and H (k x n) are initialised by the caller, d = 1.  Implemented: MSE loss, CD and Cholesky+clip,

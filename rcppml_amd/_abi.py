@@ -18,7 +18,7 @@ CD_AUTO, CD_LANE, CD_WAVE, CD_GROUP, CD_MFMA, CD_MFMA16 = 0, 1, 2, 5, 6, 7
 # Every symbol include/rcppml_gpu.h declares (tests check the library exports all of them).
 EXPORTED_SYMBOLS = [
     "rcppml_gpu_detect", "rcppml_gpu_nmf_unified_float", "rcppml_gpu_nmf_unified_double", "rcppml_gpu_nmf_ex",
-    "rcppml_gpu_nmf_cv_unified_float", "rcppml_gpu_nmf_cv_unified_double", "rcppml_gpu_nmf_cv_ex",
+    "rcppml_gpu_nmf_cv_unified_float", "rcppml_gpu_nmf_cv_unified_double", "rcppml_gpu_nmf_cv_ex", "rcppml_gpu_nmf_zerocopy_double",
     "rcppml_gpu_nnls_double", "rcppml_gpu_evaluate_mse_double", "rcppml_gpu_last_error",
     "rcppml_hip_ctx_create", "rcppml_hip_ctx_destroy", "rcppml_hip_ctx_sync", "rcppml_hip_ctx_stats", "rcppml_hip_transpose_csc", "rcppml_hip_cast", "rcppml_hip_gram", "rcppml_hip_rhs",
     "rcppml_hip_solve_cd", "rcppml_hip_order_columns", "rcppml_hip_solve_chol", "rcppml_hip_row_norms", "rcppml_hip_apply_scaling",
@@ -235,6 +235,32 @@ def nmf_cv(p, i, x, m, n, k, W_T, H, *, entry="ex", max_iter=100, tol=1e-4, L1_H
         res["error"] = last_error()
     if th is not None:
         res["train_history"], res["test_history"] = th[:out_iter.value].copy(), eh[:out_iter.value].copy()
+    return res
+
+
+def nmf_zerocopy(d_col_ptr, d_row_idx, d_values, m, n, nnz, k, W_T, H, *, max_iter=100, tol=1e-4, L1_H=0.0, L1_W=0.0, L2_H=0.0,
+                 L2_W=0.0, L21_H=0.0, L21_W=0.0, ortho_H=0.0, ortho_W=0.0, ub_H=0.0, ub_W=0.0, cd_maxit=100, verbose=0, seed=0,
+                 patience=5, nonneg_W=1, nonneg_H=1, loss_type=0, norm_type=0):
+    """Call rcppml_gpu_nmf_zerocopy_double as R/sp_gpu.R does: d_col_ptr / d_row_idx (int32) and d_values (float64) are
+    DEVICE tensors (torch) or raw device addresses; addresses travel as doubles."""
+    L = lib()
+
+    def addr(t):
+        return float(t.data_ptr()) if hasattr(t, "data_ptr") else float(t)
+
+    d = np.ones(k, np.float64)
+    out_iter, out_conv, out_status = C.c_int(0), C.c_int(0), C.c_int(-99)
+    out_loss, out_tol = C.c_double(0), C.c_double(0)
+    fn = L.rcppml_gpu_nmf_zerocopy_double
+    fn.restype = None
+    fn(_cd(addr(d_col_ptr)), _cd(addr(d_row_idx)), _cd(addr(d_values)), _ci(m), _ci(n), _cd(float(nnz)), _ci(k),
+       _np_ptr(W_T), _np_ptr(H), _np_ptr(d), _ci(max_iter), _cd(tol), _cd(L1_H), _cd(L1_W), _cd(L2_H), _cd(L2_W), _cd(L21_H),
+       _cd(L21_W), _cd(ortho_H), _cd(ortho_W), _cd(ub_H), _cd(ub_W), _ci(cd_maxit), _ci(verbose), _ci(seed), _ci(1),
+       _ci(patience), _ci(nonneg_W), _ci(nonneg_H), _ci(loss_type), _cd(1.0), _ci(5), _cd(1e-4), _ci(norm_type),
+       C.byref(out_iter), C.byref(out_conv), C.byref(out_loss), C.byref(out_status), C.byref(out_tol))
+    res = dict(status=out_status.value, iter=out_iter.value, converged=bool(out_conv.value), loss=out_loss.value, tol=out_tol.value, d=d)
+    if out_status.value != 0:
+        res["error"] = last_error()
     return res
 
 

@@ -31,7 +31,9 @@ struct DevBuf {
         bytes = b < 16 ? 16 : b;
         HIPCHK(hipMalloc(&p, bytes));
     }
-    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+    bool owned = true;
+    void borrow(const void* ptr) { release(); p = const_cast<void*>(ptr); owned = false; }   // caller-owned device memory
+    void release() { if (p && owned) (void)hipFree(p); p = nullptr; bytes = 0; owned = true; }
     ~DevBuf() { release(); }
     DevBuf(const DevBuf&) = delete;
     DevBuf& operator=(const DevBuf&) = delete;
@@ -68,6 +70,7 @@ struct FitParams {
     int max_iter; double tol;
     double L1_H, L1_W, L2_H, L2_W, ub_H, ub_W;
     double L21_H = 0, L21_W = 0, angular_H = 0, angular_W = 0;
+    int csc_on_device = 0;                   // col_ptr / row_idx / values are DEVICE pointers (zero-copy entry)
     int projective = 0;                      // H = (diag(d) W_T) A instead of the NNLS half-update (variant_helpers.hpp:308-325)
     int cd_maxit; double cd_tol;
     int verbose, patience, nonneg_W, nonneg_H, norm_type, solver_mode;
@@ -135,9 +138,19 @@ void fit(FitParams& P) {
 
     // ---- upload A, build and upload A^T (one-time setup, fit_cpu.hpp:237-254)
     DevBuf dAp, dAi, dAx, dTp, dTi, dTx;
-    upload_ints(P.col_ptr, (size_t)n + 1, dAp, s);
-    upload_ints(P.row_idx, (size_t)P.nnz, dAi, s);
-    upload_cast<T>(c, P.values, (size_t)P.nnz, dAx, s);
+    if (P.csc_on_device) {          // zero-copy: the CSC already lives in device memory (values double)
+        dAp.borrow(P.col_ptr);
+        dAi.borrow(P.row_idx);
+        if constexpr (std::is_same<T, double>::value) dAx.borrow(P.values);
+        else {
+            dAx.alloc((size_t)std::max<int64_t>(P.nnz, 1) * sizeof(T));
+            OPCHK(rcppml_hip_cast(c, RCPPML_F64, P.values, RCPPML_F32, dAx.p, P.nnz));
+        }
+    } else {
+        upload_ints(P.col_ptr, (size_t)n + 1, dAp, s);
+        upload_ints(P.row_idx, (size_t)P.nnz, dAi, s);
+        upload_cast<T>(c, P.values, (size_t)P.nnz, dAx, s);
+    }
     // A^T on the device (stable sort by row index): rcppml_hip_transpose_csc
     dTp.alloc(((size_t)m + 1) * sizeof(int));
     dTi.alloc((size_t)P.nnz * sizeof(int));
@@ -686,6 +699,56 @@ extern "C" void rcppml_gpu_nmf_cv_unified_double(RCPPML_NMF_CV_ARGS) {
 extern "C" void rcppml_gpu_nmf_cv_ex(RCPPML_NMF_CV_ARGS, int* sort_model, int* precision, int* cv_patience, double* train_history,
                                      double* test_history) {
     nmf_cv_entry(RCPPML_NMF_CV_PASS, *sort_model, *precision, *cv_patience, train_history, test_history);
+}
+
+// Zero-copy entry (reference src/gpu_bridge_nmf.cu:879-967, R/sp_gpu.R): the CSC arrays are DEVICE pointers whose
+// addresses arrive as doubles (R has no int64); values are double; W (k x m), H (k x n), d are host buffers.
+extern "C" void rcppml_gpu_nmf_zerocopy_double(double* d_col_ptr_addr, double* d_row_idx_addr, double* d_values_addr, int* m, int* n,
+                                               double* nnz_d, int* k, double* W, double* H, double* d, int* max_iter, double* tol,
+                                               double* L1_H, double* L1_W, double* L2_H, double* L2_W, double* L21_H, double* L21_W,
+                                               double* ortho_H, double* ortho_W, double* ub_H, double* ub_W, int* cd_maxit,
+                                               int* verbose, int* seed, int* loss_every, int* patience, int* nonneg_W,
+                                               int* nonneg_H, int* loss_type, double* huber_delta, int* irls_max_iter,
+                                               double* irls_tol, int* norm_type, int* out_iter, int* out_converged,
+                                               double* out_loss, int* out_status, double* out_tol) {
+    try {
+        rcppml_err().clear();
+        *out_status = -1;
+        (void)seed; (void)loss_every; (void)huber_delta; (void)irls_max_iter; (void)irls_tol;
+        auto to_ptr = [](double addr) { return reinterpret_cast<void*>(static_cast<uintptr_t>(addr)); };
+        if (*loss_type != 0) throw std::runtime_error("zero-copy entry: only the MSE loss is implemented");
+        if (*k < 1 || *k > 128) throw std::runtime_error("k must be in [1,128]");
+        if ((*ortho_H != 0 || *ortho_W != 0) && *k > 64) throw std::runtime_error("angular penalty: k must be <= 64");
+        if (*m < 1 || *n < 1) throw std::runtime_error("empty matrix");
+        if (*norm_type < 0 || *norm_type > 2) throw std::runtime_error("bad norm_type");
+        FitParams P;
+        P.m = *m; P.n = *n; P.k = *k; P.nnz = static_cast<int64_t>(*nnz_d);
+        P.csc_on_device = 1;
+        P.col_ptr = static_cast<const int*>(to_ptr(*d_col_ptr_addr));
+        P.row_idx = static_cast<const int*>(to_ptr(*d_row_idx_addr));
+        P.values = static_cast<const double*>(to_ptr(*d_values_addr));
+        P.W = W; P.H = H; P.d = d;
+        P.max_iter = *max_iter; P.tol = *tol;
+        P.L1_H = *L1_H; P.L1_W = *L1_W; P.L2_H = *L2_H; P.L2_W = *L2_W; P.ub_H = *ub_H; P.ub_W = *ub_W;
+        P.L21_H = *L21_H; P.L21_W = *L21_W; P.angular_H = *ortho_H; P.angular_W = *ortho_W;
+        P.cd_maxit = *cd_maxit > 0 ? *cd_maxit : 10;
+        P.cd_tol = 1e-8;
+        P.verbose = *verbose; P.patience = *patience; P.nonneg_W = *nonneg_W; P.nonneg_H = *nonneg_H;
+        P.norm_type = *norm_type;
+        P.solver_mode = 0;                                   // the entry has no solver argument: CD (config default)
+        P.mask_p = nullptr; P.mask_i = nullptr; P.sort_model = env_sort(); P.loss_history = nullptr;
+        const char* e = getenv("RCPPML_GPU_PRECISION");
+        if (e && !strcmp(e, "fp32")) fit<float>(P); else fit<double>(P);
+        *out_iter = P.out_iter; *out_converged = P.out_converged; *out_loss = P.out_loss; *out_tol = P.out_tol;
+        *out_status = 0;
+    } catch (const std::exception& e) {
+        rcppml_err() = e.what();
+        if (getenv("RCPPML_GPU_VERBOSE")) fprintf(stderr, "[rcppml_gpu] zero-copy NMF error: %s\n", e.what());
+        *out_status = -1;
+    } catch (...) {
+        rcppml_err() = "unknown error";
+        *out_status = -1;
+    }
 }
 
 extern "C" void rcppml_gpu_nmf_unified_float(RCPPML_NMF_UNIFIED_ARGS) {

@@ -283,3 +283,26 @@ def test_projective_nmf(abi, entry, tol_loss, tol_fac):
     base = O.nmf_fit(A, W0, H0, dtype, max_iter=8, tol=0.0, solver_mode=0)
     proj = O.nmf_fit(A, W0, H0, dtype, max_iter=8, tol=0.0, solver_mode=0, projective=True)
     assert abs(proj.loss - base.loss) > 1e-6 * abs(base.loss)
+
+
+def test_zerocopy_entry_matches_host_entry(abi):
+    """rcppml_gpu_nmf_zerocopy_double (reference src/gpu_bridge_nmf.cu:879-967): the CSC is handed over as device
+    pointers encoded in doubles; the fit must be bit-identical to the 73-pointer fp64 entry on the same inputs."""
+    import torch
+    A = load_fixture("hawaiibirds")
+    k = 8
+    W0, H0 = O.init_factors(21, k, A.rows, A.cols, np.float64)
+    W1, H1 = W0.copy(), H0.copy()
+    r1 = abi.nmf_unified(A.p, A.i, A.x, A.rows, A.cols, k, W1, H1, entry="double", max_iter=12, tol=0.0, solver_mode=0, L1_H=0.01)
+    dp = torch.from_numpy(A.p.astype(np.int32)).cuda()
+    di = torch.from_numpy(A.i.astype(np.int32)).cuda()
+    dx = torch.from_numpy(A.x.astype(np.float64)).cuda()
+    W2, H2 = W0.copy(), H0.copy()
+    r2 = abi.nmf_zerocopy(dp, di, dx, A.rows, A.cols, A.nnz, k, W2, H2, max_iter=12, tol=0.0, L1_H=0.01)
+    assert r1["status"] == 0 and r2["status"] == 0, (r1.get("error"), r2.get("error"))
+    assert r2["iter"] == r1["iter"] and r2["loss"] == r1["loss"]
+    assert np.array_equal(W1, W2) and np.array_equal(H1, H2) and np.array_equal(r1["d"], r2["d"])
+    # the caller's device arrays are untouched
+    assert np.array_equal(dx.cpu().numpy(), A.x) and np.array_equal(di.cpu().numpy(), A.i.astype(np.int32))
+    bad = abi.nmf_zerocopy(dp, di, dx, A.rows, A.cols, A.nnz, k, W2, H2, max_iter=2, loss_type=5)
+    assert bad["status"] == -1
