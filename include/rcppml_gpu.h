@@ -281,6 +281,13 @@ RCPPML_GPU_API int rcppml_hip_cv_test_error(rcppml_hip_ctx* ctx, int dtype, cons
                                             const void* H, int k, double holdout_fraction, unsigned long long cv_seed,
                                             int mask_zeros, double* out2);
 
+/* Graph (Laplacian) regularisation -- reference features/graph_reg.hpp:38-50 at its fused-path place
+ * (nmf/fit_cpu.hpp:508-509,741-742):  G += lambda * (X L) X^T  for the CURRENT factor X (k x ncols) and a sparse
+ * ncols x ncols Laplacian L in CSC (device).  X L is formed by the SpMM kernel, the k x k product by a blocked reduction
+ * with a fixed summation order.  k <= 64. */
+RCPPML_GPU_API int rcppml_hip_apply_graph_reg(rcppml_hip_ctx* ctx, int dtype, void* G, const int* lap_p, const int* lap_i,
+                                              const void* lap_x, const void* X, int k, int64_t ncols, double lambda);
+
 /* Y = diag(d) X for a k x ncols factor (variant_helpers.hpp:265-272 apply_scaling): W diag(d) of the projective H
  * update  H = (diag(d) W_T) A  (nmf/fit_cpu.hpp:462-472, variant_helpers.hpp:308-325). */
 RCPPML_GPU_API int rcppml_hip_mul_rows(rcppml_hip_ctx* ctx, int dtype, const void* X, int k, int64_t ncols, const void* d, void* Y);

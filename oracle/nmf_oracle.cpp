@@ -617,6 +617,7 @@ FitResult<S> nmf_fit(const Csc<S>& A, const FitConfig<S>& cfg, S* W_T, S* H, S* 
                                       is_nb ? nb_size.data() : (const S*)nullptr, (const S*)nullptr, cfg.loss_type, cfg.tweedie_power, cfg.robust_delta);
         } else {
             if (cfg.L2_H > 0) for (int i = 0; i < k; ++i) G[(size_t)i * k + i] += cfg.L2_H;   // :506
+            if (cfg.has_graph_H) apply_graph_reg(G.data(), cfg.graph_H, H, k, cfg.graph_H_lambda);      // :508-509
             apply_L21(G.data(), H, k, (int64_t)n, cfg.L21_H);                                  // :509-510 (current H)
             if (cfg.solver_mode == 0)
                 fused_rhs_nnls_sparse(A, W_T, G.data(), H, k, cfg.cd_maxit, cfg.cd_tol, cfg.L1_H,
@@ -643,6 +644,7 @@ FitResult<S> nmf_fit(const Csc<S>& A, const FitConfig<S>& cfg, S* W_T, S* H, S* 
                                       (const S*)nullptr, is_nb ? nb_size.data() : (const S*)nullptr, cfg.loss_type, cfg.tweedie_power, cfg.robust_delta);
         } else {
             if (cfg.L2_W > 0) for (int i = 0; i < k; ++i) G[(size_t)i * k + i] += cfg.L2_W;   // :738
+            if (cfg.has_graph_W) apply_graph_reg(G.data(), cfg.graph_W, W_T, k, cfg.graph_W_lambda);    // :740-741
             apply_L21(G.data(), W_T, k, (int64_t)m, cfg.L21_W);                                // :741-745 (current W_T)
             if (cfg.solver_mode == 0)
                 fused_rhs_nnls_sparse(At, H, G.data(), W_T, k, cfg.cd_maxit, cfg.cd_tol, cfg.L1_W,
@@ -776,7 +778,9 @@ template <class S> static Csc<S> mk(int rows, int cols, const int* p, const int*
         S irls_tol, int dispersion_mode, S nb_size_init, S nb_size_max, S nb_size_min, int sort_model,    \
         int threads, const int* mask_p, const int* mask_i, const S* mask_x, int* out_iter,                \
         int* out_converged, S* out_loss, S* out_tol, S* loss_hist, S* out_theta, S tweedie_power,         \
-        S L21_H, S L21_W, S angular_H, S angular_W, S robust_delta, int projective) {                     \
+        S L21_H, S L21_W, S angular_H, S angular_W, S robust_delta, int projective,                       \
+        const int* gH_p, const int* gH_i, const S* gH_x, S gH_lambda, const int* gW_p, const int* gW_i,   \
+        const S* gW_x, S gW_lambda) {                                                                     \
         FitConfig<S> c;                                                                                   \
         c.k = k; c.max_iter = max_iter; c.tol = tol; c.L1_H = L1_H; c.L1_W = L1_W; c.L2_H = L2_H;         \
         c.L2_W = L2_W; c.ub_H = ub_H; c.ub_W = ub_W; c.cd_maxit = cd_maxit; c.cd_tol = cd_tol;            \
@@ -786,6 +790,8 @@ template <class S> static Csc<S> mk(int rows, int cols, const int* p, const int*
         c.nb_size_init = nb_size_init; c.nb_size_max = nb_size_max; c.nb_size_min = nb_size_min;          \
         c.sort_model = sort_model != 0; c.threads = threads; c.tweedie_power = tweedie_power;             \
         c.L21_H = L21_H; c.L21_W = L21_W; c.angular_H = angular_H; c.angular_W = angular_W; c.robust_delta = robust_delta; c.projective = projective != 0; \
+        if (gH_p) { c.has_graph_H = true; c.graph_H = mk(n, n, gH_p, gH_i, gH_x); c.graph_H_lambda = gH_lambda; } \
+        if (gW_p) { c.has_graph_W = true; c.graph_W = mk(m, m, gW_p, gW_i, gW_x); c.graph_W_lambda = gW_lambda; } \
         if (mask_p) { c.has_mask = true; c.mask = mk(m, n, mask_p, mask_i, mask_x); }                     \
         FitResult<S> r = nmf_fit(mk(m, n, p, i, x), c, W_T, H, d);                                        \
         *out_iter = r.iterations; *out_converged = r.converged ? 1 : 0; *out_loss = r.train_loss;         \

@@ -323,6 +323,24 @@ void cholesky_clip_batch(const S* G, const S* B, S* X, int k, int n, bool nonneg
     }
 }
 
+// features/graph_reg.hpp:38-50   apply_graph_reg:  G += lambda * (X L) X^T,  L sparse (len x len, CSC), X k x len
+template <class S> void apply_graph_reg(S* G, const Csc<S>& L, const S* X, int k, S lambda) {
+    if (lambda <= 0) return;
+    const int64_t len = L.cols;
+    std::vector<S> FL((size_t)k * len, S(0));
+    for (int64_t j = 0; j < len; ++j)
+        for (int t = L.p[j]; t < L.p[j + 1]; ++t) {
+            const S l = L.x[t]; const S* xi = X + (size_t)L.i[t] * k; S* fj = FL.data() + (size_t)j * k;
+            for (int f = 0; f < k; ++f) fj[f] += l * xi[f];
+        }
+    for (int b = 0; b < k; ++b)
+        for (int a = 0; a < k; ++a) {
+            S acc = 0;
+            for (int64_t j = 0; j < len; ++j) acc += FL[a + j * k] * X[b + j * k];
+            G[(size_t)b * k + a] += lambda * acc;
+        }
+}
+
 // features/L21.hpp:38-51   apply_L21: G(i,i) += lambda / ||factor.row(i)||_2 for rows with norm > 1e-10.
 // X: k x len column-major (X[f + j*k]).
 template <class S> void apply_L21(S* G, const S* X, int k, int64_t len, S lambda) {
@@ -433,6 +451,8 @@ template <class S> struct FitConfig {
     S irls_tol = S(1e-4);
     int dispersion_mode = 2;       // PER_ROW
     S nb_size_init = 10, nb_size_max = S(1e6), nb_size_min = S(0.01);
+    bool has_graph_H = false, has_graph_W = false;   // FactorConfig::graph (Laplacians), graph_lambda
+    Csc<S> graph_H, graph_W; S graph_H_lambda = 0, graph_W_lambda = 0;
     bool projective = false;                  // NMFConfig::projective: H = diag(d) W_T A instead of an NNLS solve
     S robust_delta = 0;                       // LossConfig::robust_delta (math/loss.hpp:89-96): > 0 -> Huber on Pearson residuals
     S tweedie_power = S(1.5);                 // LossConfig::power_param (math/loss.hpp:99-104), loss_type 8 only

@@ -260,12 +260,22 @@ class FitResult:
     pass
 
 
+def _graph_args(g, dtype, ct):
+    if g is None:
+        return [None, None, None, ct(0)]
+    L, lam = g
+    x = L.values(dtype)
+    _graph_args.keep = getattr(_graph_args, 'keep', []) + [x]          # keep the converted values alive for the call
+    return [_p(L.p), _p(L.i), _p(x), ct(lam)]
+
+
 def nmf_fit(A, W_T, H, dtype=np.float64, max_iter=100, tol=1e-4, L1=(0.0, 0.0), L2=(0.0, 0.0), ub=(0.0, 0.0),
             cd_maxit=100, cd_tol=1e-8, patience=5, nonneg=(True, True), norm_type=0, solver_mode=0, loss_type=0,
             irls_max_iter=5, irls_tol=1e-4, dispersion_mode=2, nb_size=(10.0, 1e6, 0.01), sort_model=True, threads=1,
-            mask=None, native=False, tweedie_power=1.5, L21=(0.0, 0.0), angular=(0.0, 0.0), robust_delta=0.0, projective=False):
+            mask=None, native=False, tweedie_power=1.5, L21=(0.0, 0.0), angular=(0.0, 0.0), robust_delta=0.0, projective=False, graph_H=None, graph_W=None):
     """CPU restatement of nmf_fit<CPU> (reference nmf/fit_cpu.hpp).  L1/L2/ub/nonneg are (W, H) pairs as in R
-    (src/RcppFunctions_nmf.cpp:59-62).  W_T: (m, k) array = column-major k x m; H: (n, k)."""
+    (src/RcppFunctions_nmf.cpp:59-62).  W_T: (m, k) array = column-major k x m; H: (n, k).
+    graph_H / graph_W: (Csc Laplacian, lambda) over the columns of H / W_T (features/graph_reg.hpp)."""
     suf, ct = _suf(dtype)
     W_T = _f(W_T, dtype).copy()
     H = _f(H, dtype).copy()
@@ -289,7 +299,8 @@ def nmf_fit(A, W_T, H, dtype=np.float64, max_iter=100, tol=1e-4, L1=(0.0, 0.0), 
         C.c_int(int(nonneg[0])), C.c_int(int(nonneg[1])), C.c_int(norm_type), C.c_int(solver_mode), C.c_int(loss_type),
         C.c_int(irls_max_iter), ct(irls_tol), C.c_int(dispersion_mode), ct(nb_size[0]), ct(nb_size[1]), ct(nb_size[2]),
         C.c_int(int(sort_model)), C.c_int(threads), mp, mi, mxp, C.byref(it), C.byref(conv), C.byref(loss), C.byref(ftol),
-        _p(hist), _p(theta), ct(tweedie_power), ct(L21[1]), ct(L21[0]), ct(angular[1]), ct(angular[0]), ct(robust_delta), C.c_int(int(projective)))
+        _p(hist), _p(theta), ct(tweedie_power), ct(L21[1]), ct(L21[0]), ct(angular[1]), ct(angular[0]), ct(robust_delta), C.c_int(int(projective)),
+        *_graph_args(graph_H, dtype, ct), *_graph_args(graph_W, dtype, ct))
     r = FitResult()
     r.W_T, r.H, r.d = W_T, H, d
     r.iter, r.converged, r.loss, r.tol = it.value, bool(conv.value), float(loss.value), float(ftol.value)

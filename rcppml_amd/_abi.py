@@ -23,7 +23,7 @@ EXPORTED_SYMBOLS = [
     "rcppml_hip_ctx_create", "rcppml_hip_ctx_destroy", "rcppml_hip_ctx_sync", "rcppml_hip_ctx_stats", "rcppml_hip_transpose_csc", "rcppml_hip_cast", "rcppml_hip_gram", "rcppml_hip_rhs",
     "rcppml_hip_solve_cd", "rcppml_hip_order_columns", "rcppml_hip_solve_chol", "rcppml_hip_row_norms", "rcppml_hip_apply_scaling",
     "rcppml_hip_sumsq", "rcppml_hip_loss_mse", "rcppml_hip_solve_masked", "rcppml_hip_loss_nonzeros",
-    "rcppml_hip_solve_irls_nb", "rcppml_hip_nb_size_update", "rcppml_hip_nb_loss", "rcppml_hip_solve_irls", "rcppml_hip_irls_loss", "rcppml_hip_apply_l21", "rcppml_hip_angular_posthoc", "rcppml_hip_solve_cv", "rcppml_hip_cv_test_error", "rcppml_hip_mul_rows",
+    "rcppml_hip_solve_irls_nb", "rcppml_hip_nb_size_update", "rcppml_hip_nb_loss", "rcppml_hip_solve_irls", "rcppml_hip_irls_loss", "rcppml_hip_apply_l21", "rcppml_hip_angular_posthoc", "rcppml_hip_solve_cv", "rcppml_hip_cv_test_error", "rcppml_hip_mul_rows", "rcppml_hip_apply_graph_reg",
 ]
 
 
@@ -92,7 +92,7 @@ def nmf_unified(p, i, x, m, n, k, W_T, H, *, entry="float", max_iter=100, tol=1e
                 seed=0, loss_every=1, patience=5, nonneg_W=1, nonneg_H=1, loss_type=0, huber_delta=1.0, irls_max_iter=5,
                 irls_tol=1e-4, norm_type=0, projective=0, symmetric=0, solver_mode=0, gp_dispersion_mode=2,
                 nb_size=(10.0, 1e6, 0.01), mask=None, cd_tol=1e-8, sort_model=1, precision=F64, want_history=False,
-                graph_W_nnz=0, guide_H_count=0, tweedie_power=1.5, robust_delta=0.0):
+                graph_W_nnz=0, guide_H_count=0, tweedie_power=1.5, robust_delta=0.0, graph_W=None, graph_H=None):
     """Call the 73-pointer plugin entry exactly as reference gpu/bridge_nmf.hpp:310-342 does.
 
     p, i: int32 CSC arrays; x: float64 values.  W_T (m, k) and H (n, k) float64 arrays (memory = column-major
@@ -126,6 +126,15 @@ def nmf_unified(p, i, x, m, n, k, W_T, H, *, entry="float", max_iter=100, tol=1e
         _np_ptr(dummy_i), _np_ptr(dummy_i), _np_ptr(dummy_d), _np_ptr(dummy_i), _ci(guide_H_count),
         C.byref(out_iter), C.byref(out_conv), C.byref(out_loss), C.byref(out_status), C.byref(out_tol),
     ]
+    # graph_W / graph_H: (p, i, x, lambda) CSC Laplacians (m x m / n x n), reference bridge_nmf.hpp graph_* slots
+    for slot, g, dim in ((37, graph_W, m), (43, graph_H, n)):
+        if g is not None:
+            gp, gi, gx, lam = g
+            gp = np.ascontiguousarray(gp, np.int32); gi = np.ascontiguousarray(gi, np.int32); gx = np.ascontiguousarray(gx, np.float64)
+            args[slot:slot + 6] = [_np_ptr(gp), _np_ptr(gi), _np_ptr(gx), _ci(gp.shape[0] - 1), _ci(gx.shape[0]), _cd(lam)]
+            args.append((gp, gi, gx))          # keep alive; popped below
+    keep = args[73:]
+    del args[73:]
     assert len(args) == 73
     hist = None
     if entry == "float":
@@ -384,6 +393,10 @@ class Context:
         _chk(lib().rcppml_hip_cv_test_error(self._h, C.c_int(dt), _dptr(col_ptr), _dptr(row_idx), _dptr(values), C.c_int64(ncols),
                                             C.c_int(nrows), _dptr(W_T), _dptr(d), _dptr(H), C.c_int(k), C.c_double(frac),
                                             C.c_ulonglong(cv_seed), C.c_int(mask_zeros), _dptr(out2)), "cv_test_error")
+
+    def apply_graph_reg(self, dt, G, lap_p, lap_i, lap_x, X, k, ncols, lam):
+        _chk(lib().rcppml_hip_apply_graph_reg(self._h, C.c_int(dt), _dptr(G), _dptr(lap_p), _dptr(lap_i), _dptr(lap_x), _dptr(X),
+                                              C.c_int(k), C.c_int64(ncols), C.c_double(lam)), "apply_graph_reg")
 
     def apply_l21(self, dt, G, X, k, ncols, lam):
         _chk(lib().rcppml_hip_apply_l21(self._h, C.c_int(dt), _dptr(G), _dptr(X), C.c_int(k), C.c_int64(ncols), C.c_double(lam)), "apply_l21")

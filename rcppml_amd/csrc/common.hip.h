@@ -37,7 +37,7 @@ inline std::string& rcppml_err() {
         return 1;                                             \
     }
 
-enum { WS_GRAM = 0, WS_GPAD, WS_CHOL, WS_RED, WS_RED2, WS_ORDER, WS_IRLS, WS_MFMA, WS_FEAT, WS_COUNT };
+enum { WS_GRAM = 0, WS_GPAD, WS_CHOL, WS_RED, WS_RED2, WS_ORDER, WS_IRLS, WS_MFMA, WS_FEAT, WS_GRAPH, WS_COUNT };
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-DEVICE property of a kernel: remember the largest size
 // requested per device (one static instance per kernel instantiation) instead of a process-wide "done" flag.

@@ -1113,6 +1113,54 @@ __global__ __launch_bounds__(256) void scale_rows(T* __restrict__ X, int k, int6
         X[e] = X[e] / d[e % k];
 }
 
+// Graph regularisation (features/graph_reg.hpp:38-50):  G += lambda * (F L) F^T  with FL = F L formed by the SpMM kernel.
+// cross_gram_partial: per block, P[b*k + a] = sum over its columns j of X(a, j) Y(b, j)  (k <= 64; tiles of 32 columns in LDS);
+// cross_gram_axpy: G += lambda * (fixed-order sum of the block partials).
+template <class T>
+__global__ __launch_bounds__(256) void cross_gram_partial(const T* __restrict__ X, const T* __restrict__ Y, int k, int64_t ncols,
+                                                           T* __restrict__ partial) {
+    __shared__ T xs[32 * 64], ys[32 * 64];
+    const int64_t per = (ncols + gridDim.x - 1) / gridDim.x;
+    const int64_t c0 = (int64_t)blockIdx.x * per;
+    const int64_t c1 = c0 + per < ncols ? c0 + per : ncols;
+    T acc[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) acc[u] = T(0);
+    for (int64_t cb = c0; cb < c1; cb += 32) {
+        const int nc = (int)(c1 - cb < 32 ? c1 - cb : 32);
+        for (int e = threadIdx.x; e < 32 * k; e += 256) {
+            const int cc = e / k, f = e % k;
+            xs[cc * 64 + f] = cc < nc ? X[(cb + cc) * (int64_t)k + f] : T(0);
+            ys[cc * 64 + f] = cc < nc ? Y[(cb + cc) * (int64_t)k + f] : T(0);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int e = threadIdx.x + 256 * u;
+            if (e < k * k) {
+                const int a = e % k, b = e / k;
+                T s = acc[u];
+                for (int cc = 0; cc < 32; ++cc) s = tfma(xs[cc * 64 + a], ys[cc * 64 + b], s);
+                acc[u] = s;
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        const int e = threadIdx.x + 256 * u;
+        if (e < k * k) partial[(int64_t)blockIdx.x * k * k + e] = acc[u];
+    }
+}
+template <class T>
+__global__ void cross_gram_axpy(const T* __restrict__ partial, int nblk, int kk, T lambda, T* __restrict__ G) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= kk) return;
+    T s = T(0);
+    for (int b = 0; b < nblk; ++b) s += partial[(int64_t)b * kk + e];
+    G[e] += lambda * s;
+}
+
 // Y = diag(d) X (rows scaled UP; variant_helpers.hpp:265-272 apply_scaling) -- the projective H update's W_Td
 template <class T>
 __global__ __launch_bounds__(256) void mul_rows(const T* __restrict__ X, int k, int64_t total, const T* __restrict__ d,

@@ -96,6 +96,35 @@ extern "C" int rcppml_hip_angular_posthoc(rcppml_hip_ctx* c, int dtype, void* X,
     RCPPML_CATCH_RET
 }
 
+extern "C" int rcppml_hip_rhs(rcppml_hip_ctx* c, int dtype, const int* col_ptr, const int* row_idx, const void* values, int64_t ncols,
+                              const void* F, int k, void* B);
+template <class T>
+static void graph_reg_impl(rcppml_hip_ctx* c, int dtype, T* G, const int* lp, const int* li, const T* lx, const T* X, int k, int64_t ncols,
+                           T lambda) {
+    if (!(lambda > T(0)) || ncols <= 0) return;
+    if (k > 64) throw std::runtime_error("apply_graph_reg: k > 64 not supported");
+    int64_t nblk = (ncols + 511) / 512;
+    if (nblk > 2 * (int64_t)c->num_cu) nblk = 2 * c->num_cu;
+    if (nblk < 1) nblk = 1;
+    // FL (k x ncols) | block partials (nblk x k x k)
+    T* FL = static_cast<T*>(c->scratch(WS_GRAPH, ((size_t)k * ncols + (size_t)nblk * k * k) * sizeof(T)));
+    T* part = FL + (size_t)k * ncols;
+    if (rcppml_hip_rhs(c, dtype, lp, li, lx, ncols, X, k, FL) != 0) throw std::runtime_error(rcppml_err());    // FL(:,j) = sum_i L(i,j) X(:,i)
+    hipLaunchKernelGGL(cross_gram_partial<T>, dim3((unsigned)nblk), dim3(256), 0, c->stream, FL, X, k, ncols, part);
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(cross_gram_axpy<T>, dim3((k * k + 255) / 256), dim3(256), 0, c->stream, part, (int)nblk, k * k, lambda, G);
+    HIPCHK(hipGetLastError());
+}
+extern "C" int rcppml_hip_apply_graph_reg(rcppml_hip_ctx* c, int dtype, void* G, const int* lap_p, const int* lap_i, const void* lap_x,
+                                          const void* X, int k, int64_t ncols, double lambda) {
+    try {
+        HIPCHK(hipSetDevice(c->device));
+        if (dtype == RCPPML_F32) graph_reg_impl<float>(c, dtype, (float*)G, lap_p, lap_i, (const float*)lap_x, (const float*)X, k, ncols, (float)lambda);
+        else graph_reg_impl<double>(c, dtype, (double*)G, lap_p, lap_i, (const double*)lap_x, (const double*)X, k, ncols, lambda);
+        return 0;
+    }
+    RCPPML_CATCH_RET
+}
 extern "C" int rcppml_hip_mul_rows(rcppml_hip_ctx* c, int dtype, const void* X, int k, int64_t ncols, const void* d, void* Y) {
     try {
         HIPCHK(hipSetDevice(c->device));

@@ -70,6 +70,9 @@ struct FitParams {
     int max_iter; double tol;
     double L1_H, L1_W, L2_H, L2_W, ub_H, ub_W;
     double L21_H = 0, L21_W = 0, angular_H = 0, angular_W = 0;
+    // graph Laplacians (host CSC, dim x dim): graph_H over the columns of H (dim = n), graph_W over the columns of W_T (dim = m)
+    const int* gH_p = nullptr; const int* gH_i = nullptr; const double* gH_x = nullptr; int gH_nnz = 0; double gH_lambda = 0;
+    const int* gW_p = nullptr; const int* gW_i = nullptr; const double* gW_x = nullptr; int gW_nnz = 0; double gW_lambda = 0;
     int csc_on_device = 0;                   // col_ptr / row_idx / values are DEVICE pointers (zero-copy entry)
     int projective = 0;                      // H = (diag(d) W_T) A instead of the NNLS half-update (variant_helpers.hpp:308-325)
     int cd_maxit; double cd_tol;
@@ -167,6 +170,17 @@ void fit(FitParams& P) {
         OPCHK(rcppml_hip_transpose_csc(c, dt, m, n, dMp.as<int>(), dMi.as<int>(), nullptr, dMTp.as<int>(), dMTi.as<int>(), nullptr));
     }
 
+    // ---- graph Laplacians (features/graph_reg.hpp), uploaded once
+    DevBuf dGHp, dGHi, dGHx, dGWp, dGWi, dGWx;
+    const bool graph_H = P.gH_p && P.gH_nnz > 0 && P.gH_lambda > 0, graph_W = P.gW_p && P.gW_nnz > 0 && P.gW_lambda > 0;
+    if (graph_H) {
+        upload_ints(P.gH_p, (size_t)n + 1, dGHp, s); upload_ints(P.gH_i, (size_t)P.gH_nnz, dGHi, s);
+        upload_cast<T>(c, P.gH_x, (size_t)P.gH_nnz, dGHx, s);
+    }
+    if (graph_W) {
+        upload_ints(P.gW_p, (size_t)m + 1, dGWp, s); upload_ints(P.gW_i, (size_t)P.gW_nnz, dGWi, s);
+        upload_cast<T>(c, P.gW_x, (size_t)P.gW_nnz, dGWx, s);
+    }
     // ---- factors
     DevBuf dW, dH, dd;
     upload_cast<T>(c, P.W, (size_t)k * m, dW, s);
@@ -230,6 +244,7 @@ void fit(FitParams& P) {
             if (P.ub_H > 0) throw std::runtime_error("upper bound with explicit mask: not supported");
         } else {
             OPCHK(rcppml_hip_gram(c, dt, dW.p, k, m, eps, P.L2_H, dG.p));              // :491,506
+            if (graph_H) OPCHK(rcppml_hip_apply_graph_reg(c, dt, dG.p, dGHp.as<int>(), dGHi.as<int>(), dGHx.p, dH.p, k, n, P.gH_lambda));   // :508-509
             if (P.L21_H > 0) OPCHK(rcppml_hip_apply_l21(c, dt, dG.p, dH.p, k, n, P.L21_H));   // :509-510 (current H)
             OPCHK(rcppml_hip_rhs(c, dt, dAp.as<int>(), dAi.as<int>(), dAx.p, n, dW.p, k, dBh.p));
             if (P.solver_mode == 0) {                                                   // :516-524
@@ -261,6 +276,7 @@ void fit(FitParams& P) {
             OPCHK(rcppml_hip_gram(c, dt, dH.p, k, n, eps, 0.0, dGs.p));                 // :715-722 G_w_saved
             if (P.L2_W > 0) OPCHK(rcppml_hip_gram(c, dt, dH.p, k, n, eps, P.L2_W, dG.p)); // :738
             else HIPCHK(hipMemcpyAsync(dG.p, dGs.p, (size_t)k * k * sizeof(T), hipMemcpyDeviceToDevice, s));
+            if (graph_W) OPCHK(rcppml_hip_apply_graph_reg(c, dt, dG.p, dGWp.as<int>(), dGWi.as<int>(), dGWx.p, dW.p, k, m, P.gW_lambda));   // :740-741
             if (P.L21_W > 0) OPCHK(rcppml_hip_apply_l21(c, dt, dG.p, dW.p, k, m, P.L21_W));   // :741-745 (current W_T)
             OPCHK(rcppml_hip_rhs(c, dt, dTp.as<int>(), dTi.as<int>(), dTx.p, m, dH.p, k, dBw.p));
             if (P.solver_mode == 0) {
@@ -394,8 +410,6 @@ void nmf_entry(RCPPML_NMF_UNIFIED_ARGS, const int* mask_p, const int* mask_i, do
         *out_status = -1;
         *out_theta_len = 0;
         (void)seed; (void)loss_every; (void)huber_delta;
-        (void)graph_W_p; (void)graph_W_i; (void)graph_W_x; (void)graph_W_dim; (void)graph_W_lambda;
-        (void)graph_H_p; (void)graph_H_i; (void)graph_H_x; (void)graph_H_dim; (void)graph_H_lambda;
         (void)gp_theta_init; (void)gp_theta_max; (void)gp_theta_min; (void)gamma_phi_init; (void)gamma_phi_max;
         (void)gamma_phi_min; (void)guide_H_labels_flat; (void)guide_H_ns;
         (void)guide_H_lambdas; (void)guide_H_ncs;
@@ -426,7 +440,11 @@ void nmf_entry(RCPPML_NMF_UNIFIED_ARGS, const int* mask_p, const int* mask_i, do
             throw std::runtime_error("L21 / angular penalties are implemented for the MSE path without explicit mask");
         if ((*ortho_H != 0 || *ortho_W != 0) && *k > 64) throw std::runtime_error("angular penalty: k must be <= 64");
         if (*L21_H < 0 || *L21_W < 0 || *ortho_H < 0 || *ortho_W < 0) throw std::runtime_error("negative L21 / angular penalty");
-        if (*graph_W_nnz > 0 || *graph_H_nnz > 0) throw std::runtime_error("graph regularisation not supported");
+        if (*graph_W_nnz > 0 || *graph_H_nnz > 0) {
+            if (*loss_type != 0 || *robust_delta > 0 || mask_p) throw std::runtime_error("graph regularisation: MSE path without explicit mask only");
+            if (*k > 64) throw std::runtime_error("graph regularisation: k must be <= 64");
+            if ((*graph_H_nnz > 0 && *graph_H_dim != *n) || (*graph_W_nnz > 0 && *graph_W_dim != *m)) throw std::runtime_error("graph Laplacian dimension mismatch");
+        }
         if (*guide_H_count > 0) throw std::runtime_error("classifier guides not supported");
         if (*symmetric != 0) throw std::runtime_error("symmetric NMF not supported");
         if (*projective != 0 && (*loss_type != 0 || *robust_delta > 0 || mask_p)) throw std::runtime_error("projective NMF: MSE path without explicit mask only");
@@ -451,6 +469,8 @@ void nmf_entry(RCPPML_NMF_UNIFIED_ARGS, const int* mask_p, const int* mask_i, do
         P.loss_type = *loss_type; P.irls_max_iter = *irls_max_iter; P.irls_tol = *irls_tol;
         P.dispersion_mode = *gp_dispersion_mode; P.nb_size_init = *nb_size_init; P.nb_size_max = *nb_size_max;
         P.nb_size_min = *nb_size_min; P.out_theta = out_theta; P.tweedie_power = *tweedie_power; P.robust_delta = *robust_delta; P.projective = *projective != 0 ? 1 : 0;
+        P.gH_p = graph_H_p; P.gH_i = graph_H_i; P.gH_x = graph_H_x; P.gH_nnz = *graph_H_nnz; P.gH_lambda = *graph_H_lambda;
+        P.gW_p = graph_W_p; P.gW_i = graph_W_i; P.gW_x = graph_W_x; P.gW_nnz = *graph_W_nnz; P.gW_lambda = *graph_W_lambda;
         if (precision == RCPPML_F64) fit<double>(P); else fit<float>(P);
         *out_iter = P.out_iter; *out_converged = P.out_converged; *out_loss = P.out_loss; *out_tol = P.out_tol;
         *out_theta_len = P.out_theta_len;

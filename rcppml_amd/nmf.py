@@ -70,18 +70,33 @@ def nmf(data, k, tol=1e-4, maxit=100, L1=(0.0, 0.0), L2=(0.0, 0.0), seed=None, m
         nonneg=(True, True), test_fraction=0, verbose=False, projective=False, symmetric=False, zi="none",
         robust=False, *, solver="auto", upper_bound=(0.0, 0.0), cd_maxit=100, cd_tol=1e-8, norm="L1", sort_model=True,
         patience=5, h_init=None, precision="fp32", resource="gpu", dispersion="per_row", irls_max_iter=5, irls_tol=1e-4,
-        nb_size_init=10.0, nb_size_max=1e6, nb_size_min=0.01, tweedie_power=1.5, L21=(0.0, 0.0), angular=(0.0, 0.0)):
+        nb_size_init=10.0, nb_size_max=1e6, nb_size_min=0.01, tweedie_power=1.5, L21=(0.0, 0.0), angular=(0.0, 0.0),
+        graph_W=None, graph_H=None, graph_lambda=(0.0, 0.0)):
     """Non-negative matrix factorisation A ~ w diag(d) h by alternating NNLS on the MI355X.
 
     `L1`, `L2`, `upper_bound`, `nonneg` are c(w, h) pairs (src/RcppFunctions_nmf.cpp:59-62).
     `seed`: None / int -> W_init = matrix(runif(m*k), m, k) after set.seed(seed) (R/nmf_thin.R:790-797) and
     H from SplitMix64(seed) (nmf/fit_cpu.hpp:200-207); or an m x k (or k x m) matrix used as W_init.
     `precision`: "fp32" is what the reference computes in (F1); "fp64" is the parity mode.
+    `robust`: False | True (Huber delta 1.345) | "mae" (1e-4) | positive delta (R/nmf_thin.R:343-352).
+    `graph_W` (m x m) / `graph_H` (n x n): sparse graph Laplacians, `graph_lambda` = c(w, h) (R/nmf_thin.R:67-68, 500-506).
     """
     if loss not in _LOSSES:
         raise ValueError("'arg' should be one of %s" % ", ".join(repr(x) for x in _LOSSES))
-    if robust or zi != "none":
-        raise NotImplementedError("robust / zero-inflated losses are not implemented by the MI355X backend")
+    if zi != "none":
+        raise NotImplementedError("zero-inflated losses are not implemented by the MI355X backend")
+    if isinstance(robust, (bool, np.bool_)):
+        robust_delta = 1.345 if robust else 0.0
+    elif isinstance(robust, str) and robust.lower() == "mae":
+        robust_delta = 1e-4
+    elif isinstance(robust, (int, float)):
+        robust_delta = float(robust)
+    else:
+        raise ValueError("'robust' must be FALSE, TRUE, 'mae', or a positive numeric Huber delta.")
+    if robust_delta < 0:
+        raise ValueError("'robust' must be FALSE, TRUE, 'mae', or a positive numeric Huber delta.")
+    if robust_delta > 0 and solver == "cholesky":
+        raise ValueError("solver='cholesky' is not supported with robust IRLS (robust_delta > 0). Use solver='cd' for robust estimation.")
     if loss in ("gp", "gamma", "inverse_gaussian", "tweedie") and dispersion != "none":
         raise NotImplementedError("loss='%s' is implemented for dispersion='none' only (no dispersion estimation on the "
                                   "MI355X backend)" % loss)
@@ -89,13 +104,13 @@ def nmf(data, k, tol=1e-4, maxit=100, L1=(0.0, 0.0), L2=(0.0, 0.0), seed=None, m
         raise NotImplementedError("dispersion must be 'none', 'global' or 'per_row' on the MI355X backend")
     if symmetric:
         raise NotImplementedError("symmetric NMF is not implemented by the MI355X backend")
-    if projective and (loss != "mse" or (test_fraction and test_fraction > 0) or (mask is not None and not isinstance(mask, str))):
+    if projective and (robust_delta > 0 or loss != "mse" or (test_fraction and test_fraction > 0) or (mask is not None and not isinstance(mask, str))):
         raise NotImplementedError("projective NMF is implemented for the plain MSE path")
     cv = bool(test_fraction) and test_fraction > 0
     if cv:
         if not (0 < test_fraction < 1):
             raise ValueError("test_fraction must be in [0, 1)")
-        if loss != "mse" or (mask is not None and not isinstance(mask, str)):
+        if loss != "mse" or robust_delta > 0 or (mask is not None and not isinstance(mask, str)):
             raise NotImplementedError("cross-validation is implemented for loss='mse' without an explicit mask")
     if resource != "gpu":
         raise ValueError("rcppml_amd has no CPU path; resource must be 'gpu'")
@@ -114,7 +129,18 @@ def nmf(data, k, tol=1e-4, maxit=100, L1=(0.0, 0.0), L2=(0.0, 0.0), seed=None, m
     nn = np.atleast_1d(nonneg)
     nnw, nnh = (bool(nn[0]), bool(nn[-1]))
     norm_type = {"L1": 0, "L2": 1, "none": 2, "None": 2}[norm]
-    solver = select_solver(solver, k, (L1w, L1h), loss, use_gpu=True)
+    solver = select_solver(solver, k, (L1w, L1h), loss if robust_delta == 0 else "robust", use_gpu=True)
+    glw, glh = _pair(graph_lambda, "graph_lambda")
+    graph_args = {}
+    for name, g, dim, lam in (("graph_W", graph_W, m, glw), ("graph_H", graph_H, n, glh)):
+        if g is None or lam <= 0:
+            continue
+        Lg = _as_csc(g)
+        if Lg.shape != (dim, dim):
+            raise ValueError("%s must be %d x %d" % (name, dim, dim))
+        graph_args[name] = (Lg.p, Lg.i, Lg.x, float(lam))
+    if graph_args and (loss != "mse" or robust_delta > 0 or cv or (mask is not None and not isinstance(mask, str)) or k > 64):
+        raise NotImplementedError("graph regularisation is implemented for the plain MSE path, k <= 64")
     # ---- initialisation
     if seed is None:
         seed_int = int(np.random.SeedSequence().generate_state(1)[0] % (2 ** 31 - 1)) + 1
@@ -175,11 +201,11 @@ def nmf(data, k, tol=1e-4, maxit=100, L1=(0.0, 0.0), L2=(0.0, 0.0), seed=None, m
                            seed=seed_int & 0x7FFFFFFF, patience=int(patience), nonneg_W=int(nnw), nonneg_H=int(nnh),
                            norm_type=norm_type, solver_mode=0 if solver == "cd" else 1, mask=mask_arg, cd_tol=float(cd_tol),
                            loss_type={"mse": 0, "gp": 4, "nb": 5, "gamma": 6, "inverse_gaussian": 7, "tweedie": 8}[loss], projective=int(bool(projective)),
-                           tweedie_power=float(tweedie_power), irls_max_iter=int(irls_max_iter), irls_tol=float(irls_tol),
+                           tweedie_power=float(tweedie_power), robust_delta=robust_delta, irls_max_iter=int(irls_max_iter), irls_tol=float(irls_tol),
                            gp_dispersion_mode={"none": 0, "global": 1, "per_row": 2}[dispersion],
                            nb_size=(nb_size_init, nb_size_max, nb_size_min),
                            sort_model=int(sort_model), precision=_abi.F32 if precision == "fp32" else _abi.F64,
-                           want_history=True)
+                           want_history=True, **graph_args)
     if res["status"] != 0:
         raise _abi.BackendError("GPU NMF failed: %s" % res.get("error"))
     misc = dict(tol=res["tol"], iter=res["iter"], loss=res["loss"], loss_history=res.get("loss_history"),

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 from oracle import oracle as O
-from tests.util import load_fixture
+from tests.util import load_fixture, lowrank_csc
 
 pytestmark = pytest.mark.gpu
 
@@ -62,6 +62,36 @@ def test_nmf_surface_matches_reference_semantics():
     # auto solver with a GPU visible: CD for k <= 32 (R/nmf_thin.R:369)
     assert nmf.nmf(A, k, seed=1, maxit=2).misc["solver"] == "cd"
     assert nmf.gpu_available()
+
+
+def test_nmf_surface_robust_and_graph():
+    """nmf(robust = TRUE) -> Huber delta 1.345 (R/nmf_thin.R:343-352); nmf(graph_W, graph_H, graph_lambda = c(w, h))
+    (R/nmf_thin.R:67-68, 500-506) -> the plugin's graph_* slots; both against the oracle fit from the same init."""
+    import scipy.sparse as sp
+    from rcppml_amd import data, nmf
+    Ao = lowrank_csc(80, 110, 4, 0.3, seed=5)
+    A = data.CSC((Ao.rows, Ao.cols), Ao.p, Ao.i, Ao.x)
+    k, m, n = 5, Ao.rows, Ao.cols
+    W0 = data.r_runif(7, m * k).reshape(k, m).T.copy()
+    H0 = data.splitmix64_uniform(7, 0, k * n, np.float64).reshape(n, k)
+    mod = nmf.nmf(A, k, seed=7, maxit=6, tol=0.0, precision="fp64", robust=True)
+    ref = O.nmf_fit(Ao, W0, H0, np.float64, max_iter=6, tol=0.0, robust_delta=1.345, dispersion_mode=2)
+    assert mod.misc["solver"] == "cd" and abs(mod.misc["loss"] - ref.loss) / abs(ref.loss) < 1e-6
+    assert np.abs(mod.w - ref.W_T).max() < 1e-6
+
+    def chain(dim):
+        Adj = sp.diags([np.ones(dim - 1), np.ones(dim - 1)], [-1, 1], format="csc")
+        return sp.csc_matrix(sp.diags(np.asarray(Adj.sum(axis=0)).ravel()) - Adj)
+    LW, LH = chain(m), chain(n)
+    mod = nmf.nmf(A, k, seed=7, maxit=6, tol=0.0, precision="fp64", solver="cd", graph_W=LW, graph_H=LH, graph_lambda=(0.05, 0.1))
+    oc = lambda L: O.Csc(L.shape, L.indptr, L.indices, L.data)
+    ref = O.nmf_fit(Ao, W0, H0, np.float64, max_iter=6, tol=0.0, graph_W=(oc(LW), 0.05), graph_H=(oc(LH), 0.1))
+    assert abs(mod.misc["loss"] - ref.loss) / abs(ref.loss) < 1e-6
+    assert np.abs(mod.w - ref.W_T).max() < 1e-6 and np.abs(mod.h.T - ref.H).max() < 1e-6
+    with pytest.raises(ValueError):
+        nmf.nmf(A, k, seed=7, maxit=2, graph_W=LH, graph_lambda=(0.1, 0.0))
+    with pytest.raises(NotImplementedError):
+        nmf.nmf(A, k, seed=7, maxit=2, graph_W=LW, graph_lambda=(0.1, 0.0), loss="nb")
 
 
 @pytest.mark.parametrize("dtype", ["f32", "f64"])

@@ -349,3 +349,31 @@ def test_transpose_csc_and_cast(env):
     back = torch.empty((1000,), dtype=torch.float64, device="cuda")
     ctx.cast(_abi.F32, dst, _abi.F64, back, 1000)
     assert np.array_equal(back.cpu().numpy(), dst.cpu().numpy().astype(np.float64))
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("k,dim", [(3, 37), (10, 500), (16, 64), (33, 1200), (64, 3001)])
+def test_apply_graph_reg(env, dtype, k, dim):
+    """rcppml_hip_apply_graph_reg: G += lambda (X L) X^T (features/graph_reg.hpp:52-66) with a non-symmetric sparse L
+    (catches a transposed product), against a float64 dense evaluation of the same expression."""
+    torch, _abi, ctx = env
+    rng = np.random.default_rng(k * 7 + dim)
+    L = random_csc(dim, dim, min(1.0, 6.0 / dim), seed=dim + k)
+    L.x[:] = L.x * rng.choice([-1.0, 1.0], size=L.x.shape[0])
+    X = rng.uniform(0, 1, (dim, k)).astype(dtype)               # (dim, k) = column-major k x dim
+    G0 = rng.standard_normal((k, k)).astype(dtype)
+    lam = 0.37
+    Ld = np.zeros((dim, dim))
+    for j in range(dim):
+        Ld[L.i[L.p[j]:L.p[j + 1]], j] += L.x[L.p[j]:L.p[j + 1]].astype(dtype).astype(np.float64)
+    Xd = X.astype(np.float64).T                                   # k x dim
+    upd = lam * (Xd @ Ld) @ Xd.T                                  # element (a, b)
+    dG = _dev(torch, G0)
+    lp, li, lx = _csc_dev(torch, L, dtype)
+    ctx.apply_graph_reg(_dt(_abi, dtype), dG, lp, li, lx, _dev(torch, X), k, dim, lam)
+    got = dG.cpu().numpy().astype(np.float64) - G0.astype(np.float64)   # memory [b*k + a] = column-major (a, b)
+    assert rel_err(got.T, upd) < TOL[dtype] * 20
+    # lambda = 0 leaves G untouched
+    dG2 = _dev(torch, G0)
+    ctx.apply_graph_reg(_dt(_abi, dtype), dG2, lp, li, lx, _dev(torch, X), k, dim, 0.0)
+    assert np.array_equal(dG2.cpu().numpy(), G0)

@@ -119,7 +119,7 @@ def test_unsupported_features_are_rejected(abi):
     W0, H0 = O.init_factors(1, 4, A.rows, A.cols, np.float64)
     for kw in (dict(L21_H=0.1, loss_type=5), dict(ortho_W=-0.1), dict(projective=1, loss_type=5), dict(symmetric=1), dict(loss_type=3),
                dict(loss_type=1), dict(loss_type=4, gp_dispersion_mode=2), dict(loss_type=6, gp_dispersion_mode=2), dict(loss_type=5, solver_mode=1),
-               dict(graph_W_nnz=5), dict(guide_H_count=1), dict(solver_mode=2)):
+               dict(graph_W_nnz=5, loss_type=5), dict(guide_H_count=1), dict(solver_mode=2)):
         W, H = W0.copy(), H0.copy()
         r = abi.nmf_unified(A.p, A.i, A.x, A.rows, A.cols, 4, W, H, entry="double", max_iter=2, **kw)
         assert r["status"] == -1 and r["error"], kw
@@ -267,6 +267,46 @@ def test_l21_and_angular_features(abi, entry, tol_loss, tol_fac):
     base = O.nmf_fit(A, W0, H0, dtype, max_iter=6, tol=0.0, solver_mode=0)
     pen = O.nmf_fit(A, W0, H0, dtype, max_iter=6, tol=0.0, solver_mode=0, L21=(0.05, 0.2), angular=(0.03, 0.05))
     assert abs(pen.loss - base.loss) > 1e-3 * abs(base.loss)
+
+
+def _ring_laplacian(dim, seed, hops=2):
+    """Symmetric graph Laplacian L = D - A of a weighted ring with `hops` neighbours on each side (CSC)."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(seed)
+    rows, cols, vals = [], [], []
+    for h in range(1, hops + 1):
+        w = rng.uniform(0.2, 1.0, dim)
+        i = np.arange(dim); j = (i + h) % dim
+        rows += [i, j]; cols += [j, i]; vals += [w, w]
+    Adj = sp.csc_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(dim, dim))
+    Lap = sp.csc_matrix(sp.diags(np.asarray(Adj.sum(axis=0)).ravel()) - Adj)
+    Lap.sort_indices()
+    return O.Csc((dim, dim), Lap.indptr.astype(np.int32), Lap.indices.astype(np.int32), Lap.data.astype(np.float64))
+
+
+@pytest.mark.parametrize("entry,tol_loss,tol_fac", [("double", 1e-6, 1e-6), ("float", 5e-4, 5e-3)])
+def test_graph_regularisation(abi, entry, tol_loss, tol_fac):
+    """Graph-Laplacian smoothness (features/graph_reg.hpp:52-66, fit_cpu.hpp:508-509 / :740-741): G += lambda (F L) F^T on
+    either side, through the 73-pointer entry's graph_W_* / graph_H_* slots, vs the oracle fit."""
+    A = lowrank_csc(90, 140, 5, 0.25, seed=51)
+    k = 7
+    dtype = np.float64 if entry == "double" else np.float32
+    W0, H0 = O.init_factors(17, k, A.rows, A.cols, np.float64)
+    LW, LH = _ring_laplacian(A.rows, 1), _ring_laplacian(A.cols, 2, hops=3)
+    for lw, lh in ((0.05, 0.0), (0.0, 0.08), (0.03, 0.02)):
+        for solver in (0, 1):
+            ref = O.nmf_fit(A, W0, H0, dtype, max_iter=6, tol=0.0, solver_mode=solver, L2=(0.01, 0.0),
+                            graph_W=(LW, lw) if lw else None, graph_H=(LH, lh) if lh else None)
+            res = _run_gpu(abi, A, W0, H0, entry, max_iter=6, tol=0.0, solver_mode=solver, L2_W=0.01,
+                           graph_W=(LW.p, LW.i, LW.x, lw) if lw else None, graph_H=(LH.p, LH.i, LH.x, lh) if lh else None)
+            _compare(res, ref, tol_loss, tol_fac)
+    base = O.nmf_fit(A, W0, H0, dtype, max_iter=6, tol=0.0, solver_mode=0)
+    pen = O.nmf_fit(A, W0, H0, dtype, max_iter=6, tol=0.0, solver_mode=0, graph_W=(LW, 0.05), graph_H=(LH, 0.08))
+    assert abs(pen.loss - base.loss) > 1e-3 * abs(base.loss)
+    # dimension mismatch is rejected, not read out of bounds
+    W, H = W0.copy(), H0.copy()
+    r = abi.nmf_unified(A.p, A.i, A.x, A.rows, A.cols, k, W, H, entry="double", max_iter=2, graph_W=(LH.p, LH.i, LH.x, 0.1))
+    assert r["status"] == -1 and "graph" in r["error"]
 
 
 @pytest.mark.parametrize("entry,tol_loss,tol_fac", [("double", 1e-6, 1e-6), ("float", 5e-4, 5e-3)])
