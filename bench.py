@@ -9,7 +9,8 @@ column solves per second = steps * (m + n_total) / wall.
 
 N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL): columns are sharded, every rank
 owns a fresh 100000-column shard (weak scaling), W_T is replicated; per iteration one k-vector
-all-reduce and one fused [H H^T | H A^T] all-reduce (rcppml_amd/als.py).
+all-reduce, one fused [H H^T | H A^T] all-reduce, and -- the m columns of W being solved in row blocks,
+one per rank -- one all-gather of W_T (rcppml_amd/als.py).
 
 Prints ONE JSON line on rank 0.
 """
@@ -120,9 +121,17 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..." % (args.gpus, args.gpus))
+    # functional smoke of the N > 1 loop on a one-GPU box: RCPPML_BENCH_BACKEND=gloo RCPPML_BENCH_SHARE_GPU=1 maps every
+    # rank onto cuda:0 (RCCL refuses two ranks per device); never used for reported numbers
+    backend = os.environ.get("RCPPML_BENCH_BACKEND", "nccl")
+    if os.environ.get("RCPPML_BENCH_SHARE_GPU"):
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
     comm = als.Comm(dist if world > 1 else None)
 
     m, n_loc, k = args.rows, args.cols, args.k

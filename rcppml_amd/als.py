@@ -200,6 +200,17 @@ class Comm:
             self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
         return t
 
+    def all_gather_rows(self, full, rows_per):
+        """In-place all-gather of equal row blocks: rank r's block full[r*rows_per:(r+1)*rows_per] goes to every rank."""
+        if self.world > 1:
+            mine = full[self.rank * rows_per:(self.rank + 1) * rows_per]
+            if self.dist.get_backend() == "gloo":          # CPU tests: gloo has no in-place tensor all-gather
+                parts = [full[r * rows_per:(r + 1) * rows_per] for r in range(self.world)]
+                self.dist.all_gather(parts, mine.clone())
+            else:
+                self.dist.all_gather_into_tensor(full, mine)
+        return full
+
     def barrier(self):
         if self.world > 1:
             self.dist.barrier()
@@ -213,9 +224,17 @@ class ShardedALS:
         self.m, self.n_loc, self.k = A_loc.rows, A_loc.cols, cfg.k
         self.A = ops.upload_csc(A_loc)
         self.At = ops.upload_csc(At_loc)
-        self.W_T = ops.to_device(W_T0, ops.tdtype)
-        self.H = ops.to_device(H0, ops.tdtype)
         k, m = self.k, self.m
+        # W_T is replicated; for world > 1 its m columns (rows of the (m, k) array) are SOLVED in contiguous blocks of
+        # rows_per per rank and all-gathered, so the W solve shrinks with the world size instead of being repeated.
+        # rows_per is a multiple of 4 so every block starts 16-byte aligned for any k; the pad rows stay zero.
+        self.rows_per = ((m + comm.world - 1) // comm.world + 3) // 4 * 4 if comm.world > 1 else m
+        self.W_pad = ops.zeros((self.rows_per * comm.world, k))
+        self.W_T = self.W_pad[:m]
+        self.W_T.copy_(ops.to_device(W_T0, ops.tdtype))
+        self.row_lo = min(m, comm.rank * self.rows_per)
+        self.row_hi = min(m, self.row_lo + self.rows_per)
+        self.H = ops.to_device(H0, ops.tdtype)
         self.d = ops.zeros((k,)) + 1
         self.Bh = ops.empty((self.n_loc, k))
         # fused exchange buffer [G_p (k*k) | B_p (m*k)]: one all-reduce per iteration
@@ -255,7 +274,12 @@ class ShardedALS:
         self.G_saved.copy_(self.Gp)                                          # :719-722 (before L2)
         self.G.copy_(self.Gp)
         ops.add_diag(self.G, cfg.L2_W)                                       # :738
-        ops.solve(self.G, self.Bw, self.W_T, cfg, "W", warm, tag="solve_W")
+        if comm.world > 1:
+            if self.row_hi > self.row_lo:
+                ops.solve(self.G, self.Bw[self.row_lo:self.row_hi], self.W_T[self.row_lo:self.row_hi], cfg, "W", warm, tag="solve_W")
+            comm.all_gather_rows(self.W_pad, self.rows_per)
+        else:
+            ops.solve(self.G, self.Bw, self.W_T, cfg, "W", warm, tag="solve_W")
         ops.row_norms(self.W_T, cfg.norm_type, out=self.sums)
         ops.apply_scaling(self.W_T, self.sums, cfg.norm_type, self.d)
         # ---- loss (fit_cpu.hpp:1729-1753): B_w is the h_at of the reference's third sparse pass
