@@ -331,6 +331,20 @@ RCPPML_GPU_API int rcppml_hip_irls_loss(rcppml_hip_ctx* ctx, int dtype, int loss
                                         const int* row_idx, const void* values, int64_t ncols, const void* W_T,
                                         const void* d, const void* H, const void* theta_row, int k, double loss_param,
                                         double robust_delta, double* out);
+/* Dispersion estimators of the other IRLS losses, per ROW of A (takes CSC(A^T), nnz = its nonzero count):
+ *   loss_type 4        GP theta by the auxiliary-function (MM) update, five inner passes -- reference
+ *                      nmf/fit_cpu.hpp:914-1008 (PER_ROW / GLOBAL, sparse branch); hi = gp_theta_max, lo unused;
+ *   loss_type 6 / 7 / 8  Gamma / inverse-Gaussian / Tweedie phi by the Pearson method of moments over the positive
+ *                      nonzeros, clamped to [lo, hi] -- nmf/fit_cpu.hpp:1561-1670; power = Tweedie variance power.
+ * mode 2 = PER_ROW, 1 = GLOBAL (GP: mean of the per-row values; phi: the median sorted[m/2]).  theta (m) is updated in
+ * place (rows without usable nonzeros keep their value). */
+RCPPML_GPU_API int rcppml_hip_dispersion_update(rcppml_hip_ctx* ctx, int dtype, int loss_type, int mode,
+                                                const int* t_col_ptr, const int* t_row_idx, const void* t_values,
+                                                int64_t m, int64_t nnz, const void* W_T, const void* d, const void* H,
+                                                int64_t n, int k, double power, double lo, double hi, void* theta);
+/* GLOBAL dispersion: x[0..m) <- mean(x) (stat 0; fit_cpu.hpp:1005-1008) or <- sorted(x)[m/2] (stat 1: the reference's
+ * nth_element at m/2; NB fit_cpu.hpp:1257-1262, phi :1664-1669). */
+RCPPML_GPU_API int rcppml_hip_vec_global(rcppml_hip_ctx* ctx, int dtype, int stat, void* x, int64_t m);
 /* NB size (r) per ROW of A by the method of moments -- reference nmf/fit_cpu.hpp:1094-1265 (PER_ROW branch, sparse):
  * r_i = clamp(S mu^2 / (S (y-mu)^2 - S mu), r_min, r_max), else r_max.  Takes CSC(A^T); W_T k x m, H k x n. */
 RCPPML_GPU_API int rcppml_hip_nb_size_update(rcppml_hip_ctx* ctx, int dtype, const int* t_col_ptr,

@@ -546,6 +546,107 @@ static void nb_size_update(const Csc<S>& A, const S* W_T, const S* H, const S* d
     }
 }
 
+// nmf/fit_cpu.hpp:914-1008   GP theta: auxiliary-function (MM) update, PER_ROW / GLOBAL, sparse branch.  Five inner MM
+// passes over the cached (row, y, s) of the nonzeros; everything in fp64 except s (a Scalar dot) and theta (stored Scalar).
+template <class S>
+static void gp_theta_update(const Csc<S>& A, const S* W_T, const S* H, const S* d, int k, const FitConfig<S>& cfg,
+                            std::vector<S>& theta) {
+    const int m = A.rows, n = A.cols;
+    std::vector<S> Wd((size_t)k * m);
+    for (int i = 0; i < m; ++i) for (int f = 0; f < k; ++f) Wd[(size_t)i * k + f] = W_T[(size_t)i * k + f] * d[f];
+    std::vector<double> sum_y(m, 0.0), sum_s(m, 0.0);
+    std::vector<int> n_nz(m, 0);
+    std::vector<S> h_rs(k, S(0));                                                                    // :935
+    for (int j = 0; j < n; ++j) { const S* h = H + (size_t)j * k; for (int f = 0; f < k; ++f) h_rs[f] += h[f]; }
+    for (int i = 0; i < m; ++i) {                                                                    // :936-938
+        S t = 0; const S* w = Wd.data() + (size_t)i * k;
+        for (int f = 0; f < k; ++f) t += w[f] * h_rs[f];
+        sum_s[i] = static_cast<double>(t);
+    }
+    struct Nz { int row; double y, s; };
+    std::vector<Nz> cache; cache.reserve((size_t)A.p[n]);
+    for (int j = 0; j < n; ++j) {                                                                    // :941-952
+        const S* h = H + (size_t)j * k;
+        for (int t = A.p[j]; t < A.p[j + 1]; ++t) {
+            const int i = A.i[t]; const S* w = Wd.data() + (size_t)i * k;
+            S dot = 0; for (int f = 0; f < k; ++f) dot += w[f] * h[f];
+            const double y = static_cast<double>(A.x[t]);
+            const double sv = std::max(static_cast<double>(dot), 1e-10);
+            sum_y[i] += y;
+            if (y >= 1.0) n_nz[i]++;
+            cache.push_back({i, y, sv});
+        }
+    }
+    const double cap = static_cast<double>(cfg.gp_theta_max);
+    std::vector<double> alpha(m), gamma(m);
+    for (int mm = 0; mm < 5; ++mm) {                                                                 // :972-1001
+        std::fill(alpha.begin(), alpha.end(), 0.0); std::fill(gamma.begin(), gamma.end(), 0.0);
+        for (const Nz& z : cache)
+            if (z.y >= 1.0) {
+                const double th = static_cast<double>(theta[z.row]);
+                const double denom = std::max(z.s + th * z.y, 1e-10);
+                const double eta1 = z.s / denom;
+                alpha[z.row] += (z.y - 1.0) * eta1;
+                gamma[z.row] += (z.y - 1.0) * (1.0 - eta1);
+            }
+        for (int i = 0; i < m; ++i) {
+            const double a = alpha[i] + static_cast<double>(n_nz[i]);
+            const double b = (sum_y[i] - sum_s[i]) - gamma[i] + a;
+            if (a > 1e-15) {
+                const double disc = b * b + 4.0 * a * gamma[i];
+                if (disc > 0.0 && std::isfinite(disc)) {
+                    const double nt = (-b + std::sqrt(disc)) / (2.0 * a);
+                    if (std::isfinite(nt) && nt >= 0.0) theta[i] = static_cast<S>(std::min(nt, cap));
+                }
+            }
+        }
+    }
+    if (cfg.dispersion_mode == 1) {                                                                  // :1005-1008 GLOBAL: mean
+        S acc = 0; for (int i = 0; i < m; ++i) acc += theta[i];
+        std::fill(theta.begin(), theta.end(), acc / static_cast<S>(m));
+    }
+}
+
+// nmf/fit_cpu.hpp:1561-1670   Gamma / inverse Gaussian / Tweedie dispersion phi: Pearson method of moments over the
+// positive nonzeros of each row, PER_ROW / GLOBAL (median), sparse branch.  Diagnostic: the W/H updates do not use it.
+template <class S>
+static void phi_update(const Csc<S>& A, const S* W_T, const S* H, const S* d, int k, const FitConfig<S>& cfg,
+                       std::vector<S>& phi) {
+    const int m = A.rows, n = A.cols;
+    std::vector<S> Wd((size_t)k * m);
+    for (int i = 0; i < m; ++i) for (int f = 0; f < k; ++f) Wd[(size_t)i * k + f] = W_T[(size_t)i * k + f] * d[f];
+    const double var_power = cfg.loss_type == 8 ? static_cast<double>(cfg.tweedie_power) : (cfg.loss_type == 6 ? 2.0 : 3.0);
+    const double phi_min = static_cast<double>(cfg.gamma_phi_min), phi_max = static_cast<double>(cfg.gamma_phi_max);
+    std::vector<double> sum_p(m, 0.0);
+    std::vector<int> cnt(m, 0);
+    for (int j = 0; j < n; ++j) {
+        const S* h = H + (size_t)j * k;
+        for (int t = A.p[j]; t < A.p[j + 1]; ++t) {
+            const int i = A.i[t];
+            const double y = static_cast<double>(A.x[t]);
+            if (y <= 0.0) continue;
+            const S* w = Wd.data() + (size_t)i * k;
+            S dot = 0; for (int f = 0; f < k; ++f) dot += w[f] * h[f];
+            const double mu = std::max(static_cast<double>(dot), 1e-10);
+            const double resid = y - mu;
+            const double v_mu = std::pow(mu, var_power);
+            sum_p[i] += (resid * resid) / std::max(v_mu, 1e-20);
+            cnt[i]++;
+        }
+    }
+    for (int i = 0; i < m; ++i)
+        if (cnt[i] > 0) {
+            double pn = sum_p[i] / static_cast<double>(cnt[i]);
+            pn = std::max(phi_min, std::min(pn, phi_max));
+            if (std::isfinite(pn)) phi[i] = static_cast<S>(pn);
+        }
+    if (cfg.dispersion_mode == 1) {                                                                  // :1664-1669 GLOBAL: median
+        std::vector<S> v(phi.begin(), phi.begin() + m);
+        std::nth_element(v.begin(), v.begin() + m / 2, v.end());
+        std::fill(phi.begin(), phi.end(), v[m / 2]);
+    }
+}
+
 // nmf/explicit_loss.hpp:53-77   NB NLL over NONZEROS only (per-row theta)
 template <class S>
 static S explicit_loss_sparse_nb(const Csc<S>& A, const S* W_Td, const S* H, int k,
@@ -584,13 +685,15 @@ FitResult<S> nmf_fit(const Csc<S>& A, const FitConfig<S>& cfg, S* W_T, S* H, S* 
     CscOwned<S> maskT_own;
     if (cfg.has_mask) maskT_own = transpose_csc(cfg.mask);   // fit_cpu.hpp:276-280
     const bool is_nb = cfg.loss_type == 5;
-    const bool is_gp = cfg.loss_type == 4;                    // dispersion NONE only: theta = 0 (fit_cpu.hpp:297-304)
-    const bool is_pow = cfg.loss_type == 6 || cfg.loss_type == 7 || cfg.loss_type == 8;   // dispersion NONE: phi = 1, unused
+    const bool is_gp = cfg.loss_type == 4;                    // theta: gp_theta_init (PER_ROW/GLOBAL) or 0 (NONE) (fit_cpu.hpp:297-307)
+    const bool is_pow = cfg.loss_type == 6 || cfg.loss_type == 7 || cfg.loss_type == 8;   // phi: gamma_phi_init or 1 (:337-347)
     const bool irls = is_nb || is_gp || is_pow || cfg.robust_delta > 0;   // requires_irls() (math/loss.hpp:106-108)
     std::vector<S> nb_size;
     if (is_nb)                                                // fit_cpu.hpp:316-328 (PER_ROW/GLOBAL/NONE)
         nb_size.assign(m, cfg.dispersion_mode == 0 ? cfg.nb_size_max : cfg.nb_size_init);
-    if (is_gp || is_pow || cfg.loss_type == 0) nb_size.assign(m, is_pow ? S(1) : S(0));   // theta_vec = Zero(m) / phi_vec = 1; the IRLS itself gets no theta
+    if (is_gp) nb_size.assign(m, cfg.dispersion_mode == 0 ? S(0) : cfg.gp_theta_init);
+    if (is_pow) nb_size.assign(m, cfg.dispersion_mode == 0 ? S(1) : cfg.gamma_phi_init);
+    if (cfg.loss_type == 0) nb_size.assign(m, S(0));          // robust MSE: no dispersion; the IRLS of GP / power losses gets no theta
 
     std::vector<S> G((size_t)k * k), G_saved((size_t)k * k), G_wt((size_t)k * k);
     S prev_loss = std::numeric_limits<S>::max();
@@ -657,7 +760,9 @@ FitResult<S> nmf_fit(const Csc<S>& A, const FitConfig<S>& cfg, S* W_T, S* H, S* 
         extract_scaling(W_T, k, m, d, cfg.norm_type);                       // :893
 
         // ------------------------------------------------ NB dispersion (:1094-1265)
+        if (is_gp && cfg.dispersion_mode != 0) gp_theta_update(A, W_T, H, d, k, cfg, nb_size);        // :914-1008
         if (is_nb && cfg.dispersion_mode != 0) nb_size_update(A, W_T, H, d, k, cfg, nb_size);
+        if (is_pow && cfg.dispersion_mode != 0) phi_update(A, W_T, H, d, k, cfg, nb_size);            // :1561-1670
 
         // ------------------------------------------------ loss (:1684-1767)
         S loss_val;
@@ -780,7 +885,8 @@ template <class S> static Csc<S> mk(int rows, int cols, const int* p, const int*
         int* out_converged, S* out_loss, S* out_tol, S* loss_hist, S* out_theta, S tweedie_power,         \
         S L21_H, S L21_W, S angular_H, S angular_W, S robust_delta, int projective,                       \
         const int* gH_p, const int* gH_i, const S* gH_x, S gH_lambda, const int* gW_p, const int* gW_i,   \
-        const S* gW_x, S gW_lambda) {                                                                     \
+        const S* gW_x, S gW_lambda, S gp_theta_init, S gp_theta_max, S gamma_phi_init, S gamma_phi_max,   \
+        S gamma_phi_min) {                                                                                \
         FitConfig<S> c;                                                                                   \
         c.k = k; c.max_iter = max_iter; c.tol = tol; c.L1_H = L1_H; c.L1_W = L1_W; c.L2_H = L2_H;         \
         c.L2_W = L2_W; c.ub_H = ub_H; c.ub_W = ub_W; c.cd_maxit = cd_maxit; c.cd_tol = cd_tol;            \
@@ -790,6 +896,8 @@ template <class S> static Csc<S> mk(int rows, int cols, const int* p, const int*
         c.nb_size_init = nb_size_init; c.nb_size_max = nb_size_max; c.nb_size_min = nb_size_min;          \
         c.sort_model = sort_model != 0; c.threads = threads; c.tweedie_power = tweedie_power;             \
         c.L21_H = L21_H; c.L21_W = L21_W; c.angular_H = angular_H; c.angular_W = angular_W; c.robust_delta = robust_delta; c.projective = projective != 0; \
+        c.gp_theta_init = gp_theta_init; c.gp_theta_max = gp_theta_max; c.gamma_phi_init = gamma_phi_init;  \
+        c.gamma_phi_max = gamma_phi_max; c.gamma_phi_min = gamma_phi_min;                                 \
         if (gH_p) { c.has_graph_H = true; c.graph_H = mk(n, n, gH_p, gH_i, gH_x); c.graph_H_lambda = gH_lambda; } \
         if (gW_p) { c.has_graph_W = true; c.graph_W = mk(m, m, gW_p, gW_i, gW_x); c.graph_W_lambda = gW_lambda; } \
         if (mask_p) { c.has_mask = true; c.mask = mk(m, n, mask_p, mask_i, mask_x); }                     \
@@ -839,6 +947,17 @@ ORACLE_API float oracle_loss_gp_f32(float y, float p, float th) { return loss_co
         std::vector<S> v(nb_size, nb_size + m);                                                                   \
         nb_size_update(mk(m, n, p, i, x), W_T, H, d, k, c, v);                                                    \
         std::memcpy(nb_size, v.data(), sizeof(S) * m);                                                            \
+    }                                                                                                             \
+    /* loss_type 4: GP theta (hi = cap); 6 / 7 / 8: Pearson phi in [lo, hi]; mode 1 = GLOBAL, 2 = PER_ROW */       \
+    ORACLE_API void oracle_dispersion_update_##SUF(int loss_type, int m, int n, const int* p, const int* i,       \
+                                                   const S* x, const S* W_T, const S* H, const S* d, int k,       \
+                                                   int dispersion_mode, S power, S lo, S hi, S* theta) {          \
+        FitConfig<S> c; c.k = k; c.dispersion_mode = dispersion_mode; c.loss_type = loss_type;                    \
+        c.tweedie_power = power; c.gp_theta_max = hi; c.gamma_phi_min = lo; c.gamma_phi_max = hi;                 \
+        std::vector<S> v(theta, theta + m);                                                                       \
+        if (loss_type == 4) gp_theta_update(mk(m, n, p, i, x), W_T, H, d, k, c, v);                               \
+        else phi_update(mk(m, n, p, i, x), W_T, H, d, k, c, v);                                                   \
+        std::memcpy(theta, v.data(), sizeof(S) * m);                                                              \
     }                                                                                                             \
     ORACLE_API S oracle_nb_loss_##SUF(int m, int n, const int* p, const int* i, const S* x, const S* W_T,         \
                                       const S* d, const S* H, int k, const S* theta_row) {                        \

@@ -451,6 +451,8 @@ template <class S> struct FitConfig {
     S irls_tol = S(1e-4);
     int dispersion_mode = 2;       // PER_ROW
     S nb_size_init = 10, nb_size_max = S(1e6), nb_size_min = S(0.01);
+    S gp_theta_init = S(0.1), gp_theta_max = S(5.0);                        // core/config.hpp:169-172
+    S gamma_phi_init = S(1.0), gamma_phi_max = S(1e4), gamma_phi_min = S(1e-6);   // core/config.hpp:201-207
     bool has_graph_H = false, has_graph_W = false;   // FactorConfig::graph (Laplacians), graph_lambda
     Csc<S> graph_H, graph_W; S graph_H_lambda = 0, graph_W_lambda = 0;
     bool projective = false;                  // NMFConfig::projective: H = diag(d) W_T A instead of an NNLS solve

@@ -23,7 +23,7 @@ EXPORTED_SYMBOLS = [
     "rcppml_hip_ctx_create", "rcppml_hip_ctx_destroy", "rcppml_hip_ctx_sync", "rcppml_hip_ctx_stats", "rcppml_hip_transpose_csc", "rcppml_hip_cast", "rcppml_hip_gram", "rcppml_hip_rhs",
     "rcppml_hip_solve_cd", "rcppml_hip_order_columns", "rcppml_hip_solve_chol", "rcppml_hip_row_norms", "rcppml_hip_apply_scaling",
     "rcppml_hip_sumsq", "rcppml_hip_loss_mse", "rcppml_hip_solve_masked", "rcppml_hip_loss_nonzeros",
-    "rcppml_hip_solve_irls_nb", "rcppml_hip_nb_size_update", "rcppml_hip_nb_loss", "rcppml_hip_solve_irls", "rcppml_hip_irls_loss", "rcppml_hip_apply_l21", "rcppml_hip_angular_posthoc", "rcppml_hip_solve_cv", "rcppml_hip_cv_test_error", "rcppml_hip_mul_rows", "rcppml_hip_apply_graph_reg",
+    "rcppml_hip_solve_irls_nb", "rcppml_hip_nb_size_update", "rcppml_hip_nb_loss", "rcppml_hip_solve_irls", "rcppml_hip_irls_loss", "rcppml_hip_apply_l21", "rcppml_hip_angular_posthoc", "rcppml_hip_solve_cv", "rcppml_hip_cv_test_error", "rcppml_hip_mul_rows", "rcppml_hip_apply_graph_reg", "rcppml_hip_dispersion_update", "rcppml_hip_vec_global",
 ]
 
 
@@ -92,7 +92,8 @@ def nmf_unified(p, i, x, m, n, k, W_T, H, *, entry="float", max_iter=100, tol=1e
                 seed=0, loss_every=1, patience=5, nonneg_W=1, nonneg_H=1, loss_type=0, huber_delta=1.0, irls_max_iter=5,
                 irls_tol=1e-4, norm_type=0, projective=0, symmetric=0, solver_mode=0, gp_dispersion_mode=2,
                 nb_size=(10.0, 1e6, 0.01), mask=None, cd_tol=1e-8, sort_model=1, precision=F64, want_history=False,
-                graph_W_nnz=0, guide_H_count=0, tweedie_power=1.5, robust_delta=0.0, graph_W=None, graph_H=None):
+                graph_W_nnz=0, guide_H_count=0, tweedie_power=1.5, robust_delta=0.0, graph_W=None, graph_H=None,
+                gp_theta=(0.1, 5.0, 0.0), gamma_phi=(1.0, 1e4, 1e-6)):
     """Call the 73-pointer plugin entry exactly as reference gpu/bridge_nmf.hpp:310-342 does.
 
     p, i: int32 CSC arrays; x: float64 values.  W_T (m, k) and H (n, k) float64 arrays (memory = column-major
@@ -120,8 +121,8 @@ def nmf_unified(p, i, x, m, n, k, W_T, H, *, entry="float", max_iter=100, tol=1e
         _ci(norm_type), _ci(projective), _ci(symmetric), _ci(solver_mode),
         _np_ptr(dummy_i), _np_ptr(dummy_i), _np_ptr(dummy_d), _ci(0), _ci(graph_W_nnz), _cd(0.0),
         _np_ptr(dummy_i), _np_ptr(dummy_i), _np_ptr(dummy_d), _ci(0), _ci(0), _cd(0.0),
-        _ci(gp_dispersion_mode), _cd(0.1), _cd(5.0), _cd(0.0), _cd(nb_size[0]), _cd(nb_size[1]), _cd(nb_size[2]),
-        _cd(1.0), _cd(1e4), _cd(1e-6), _cd(robust_delta), _cd(tweedie_power),
+        _ci(gp_dispersion_mode), _cd(gp_theta[0]), _cd(gp_theta[1]), _cd(gp_theta[2]), _cd(nb_size[0]), _cd(nb_size[1]), _cd(nb_size[2]),
+        _cd(gamma_phi[0]), _cd(gamma_phi[1]), _cd(gamma_phi[2]), _cd(robust_delta), _cd(tweedie_power),
         _np_ptr(theta), C.byref(out_theta_len),
         _np_ptr(dummy_i), _np_ptr(dummy_i), _np_ptr(dummy_d), _np_ptr(dummy_i), _ci(guide_H_count),
         C.byref(out_iter), C.byref(out_conv), C.byref(out_loss), C.byref(out_status), C.byref(out_tol),
@@ -403,6 +404,15 @@ class Context:
 
     def angular_posthoc(self, dt, X, k, ncols, lam):
         _chk(lib().rcppml_hip_angular_posthoc(self._h, C.c_int(dt), _dptr(X), C.c_int(k), C.c_int64(ncols), C.c_double(lam)), "angular_posthoc")
+
+    def dispersion_update(self, dt, loss_type, mode, t_col_ptr, t_row_idx, t_values, m, nnz, W_T, d, H, n, k, power, lo, hi, theta):
+        _chk(lib().rcppml_hip_dispersion_update(self._h, C.c_int(dt), C.c_int(loss_type), C.c_int(mode), _dptr(t_col_ptr),
+                                                _dptr(t_row_idx), _dptr(t_values), C.c_int64(m), C.c_int64(nnz), _dptr(W_T), _dptr(d),
+                                                _dptr(H), C.c_int64(n), C.c_int(k), C.c_double(power), C.c_double(lo),
+                                                C.c_double(hi), _dptr(theta)), "dispersion_update")
+
+    def vec_global(self, dt, stat, x, m):
+        _chk(lib().rcppml_hip_vec_global(self._h, C.c_int(dt), C.c_int(stat), _dptr(x), C.c_int64(m)), "vec_global")
 
     def nb_size_update(self, dt, t_col_ptr, t_row_idx, t_values, m, W_T, d, H, n, k, r_min, r_max, nb_size):
         _chk(lib().rcppml_hip_nb_size_update(self._h, C.c_int(dt), _dptr(t_col_ptr), _dptr(t_row_idx), _dptr(t_values),

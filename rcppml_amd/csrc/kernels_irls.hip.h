@@ -511,6 +511,123 @@ __global__ __launch_bounds__(256) void nb_size_rows_kernel(
     }
 }
 
+// Dispersion estimators of the other IRLS losses, one wavefront per ROW i of A (= column i of A^T), one lane per nonzero
+// (the gather / in-lane dot of nb_size_rows_kernel):
+//   loss_type 4      GP theta, auxiliary-function (MM) update, nmf/fit_cpu.hpp:914-1001: the Scalar predictions s of the
+//                    row's nonzeros are parked in s_cache (each lane re-reads what it wrote), then five inner passes
+//                    accumulate alpha / gamma in fp64 with theta rounded through Scalar between passes, as the reference;
+//   loss_type 6/7/8  Pearson phi over the positive nonzeros, nmf/fit_cpu.hpp:1561-1661, clamped to [lo, hi].
+template <class T>
+__global__ __launch_bounds__(256) void dispersion_rows_kernel(
+    const int* __restrict__ tp, const int* __restrict__ ti, const T* __restrict__ tx, int64_t m,
+    const T* __restrict__ W_T, const T* __restrict__ d, const T* __restrict__ H, const T* __restrict__ h_rs, int k,
+    int loss_type, double power, double lo, double hi, T* __restrict__ s_cache, T* __restrict__ theta) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * 4 + wave;
+    if (i >= m) return;
+    const bool fok = lane < k;
+    const T wd = fok ? W_T[i * (int64_t)k + lane] * d[lane] : T(0);     // apply_scaling(W_Td, d)
+    __shared__ T wds[4][64];
+    wds[wave][lane] = wd;
+    __builtin_amdgcn_wave_barrier();
+    constexpr int VEC = 16 / sizeof(T);
+    typedef typename VecT<T, VEC>::type V;
+    const bool vec_ok = (k % VEC == 0) && (reinterpret_cast<uintptr_t>(H) % 16 == 0);
+    const int ts = tp[i], te = tp[i + 1];
+    const bool is_gp = loss_type == 4;
+    const double var_power = loss_type == 8 ? power : (loss_type == 6 ? 2.0 : 3.0);
+    double acc0 = 0.0, acc1 = 0.0;      // GP: sum_y, n_nz      phi: sum of Pearson terms, count
+    for (int t = ts + lane; t < te; t += 64) {
+        const int col = ti[t];
+        const T* hr = H + (int64_t)col * k;
+        T dot = T(0);
+        if (vec_ok) {
+            for (int c = 0; c < k; c += VEC) {
+                const V v = *reinterpret_cast<const V*>(hr + c);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) dot = tfma(wds[wave][c + e], v[e], dot);
+            }
+        } else {
+            for (int c = 0; c < k; ++c) dot = tfma(wds[wave][c], hr[c], dot);
+        }
+        const double y = static_cast<double>(tx[t]);
+        if (is_gp) {
+            s_cache[t] = dot;
+            acc0 += y;
+            if (y >= 1.0) acc1 += 1.0;
+        } else if (y > 0.0) {
+            double mu = static_cast<double>(dot);
+            mu = mu > 1e-10 ? mu : 1e-10;
+            const double resid = y - mu;
+            double v_mu = pow(mu, var_power);
+            v_mu = v_mu > 1e-20 ? v_mu : 1e-20;
+            acc0 += (resid * resid) / v_mu;
+            acc1 += 1.0;
+        }
+    }
+    acc0 = wave_sum(acc0);
+    acc1 = wave_sum(acc1);
+    if (!is_gp) {
+        if (lane == 0 && acc1 > 0.0) {
+            double pn = acc0 / acc1;
+            pn = pn < hi ? pn : hi;
+            pn = pn > lo ? pn : lo;
+            if (isfinite(pn)) theta[i] = static_cast<T>(pn);
+        }
+        return;
+    }
+    const double sum_s = static_cast<double>(wave_sum(fok ? wd * h_rs[lane] : T(0)));       // Gram trick, :935-938
+    T th_s = theta[i];
+    for (int mm = 0; mm < 5; ++mm) {                                                          // THETA_INNER_ITERS
+        const double th = static_cast<double>(th_s);
+        double alpha = 0.0, gamma = 0.0;
+        for (int t = ts + lane; t < te; t += 64) {
+            const double y = static_cast<double>(tx[t]);
+            if (y >= 1.0) {
+                double sv = static_cast<double>(s_cache[t]);
+                sv = sv > 1e-10 ? sv : 1e-10;
+                double denom = sv + th * y;
+                denom = denom > 1e-10 ? denom : 1e-10;
+                const double eta1 = sv / denom;
+                alpha += (y - 1.0) * eta1;
+                gamma += (y - 1.0) * (1.0 - eta1);
+            }
+        }
+        alpha = wave_sum(alpha);
+        gamma = wave_sum(gamma);
+        const double a = alpha + acc1;
+        const double b = (acc0 - sum_s) - gamma + a;
+        if (a > 1e-15) {
+            const double disc = b * b + 4.0 * a * gamma;
+            if (disc > 0.0 && isfinite(disc)) {
+                const double nt = (-b + sqrt(disc)) / (2.0 * a);
+                if (isfinite(nt) && nt >= 0.0) th_s = static_cast<T>(nt < hi ? nt : hi);
+            }
+        }
+    }
+    if (lane == 0) theta[i] = th_s;
+}
+
+// GLOBAL dispersion: every entry <- the mean (stat 0; GP, fit_cpu.hpp:1005-1008) or <- src[m/2] of the SORTED copy
+// (stat 1: nth_element at m/2; NB :1257-1262, phi :1664-1669).  Single block.
+template <class T>
+__global__ __launch_bounds__(256) void vec_global_fill_kernel(T* __restrict__ x, const T* __restrict__ sorted, int64_t m, int stat) {
+    __shared__ double red[256];
+    T val;
+    if (stat == 1) {
+        val = sorted[m / 2];
+    } else {
+        double acc = 0.0;
+        for (int64_t i = threadIdx.x; i < m; i += 256) acc += static_cast<double>(x[i]);
+        red[threadIdx.x] = acc;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+        val = static_cast<T>(red[0] / static_cast<double>(m));
+    }
+    __syncthreads();
+    for (int64_t i = threadIdx.x; i < m; i += 256) x[i] = val;
+}
+
 // NB negative log-likelihood over the NONZEROS of A (explicit_loss.hpp:53-77), per-row theta, fp64 partials.
 // One wavefront per column, ONE LANE PER NONZERO: each lane gathers its row of W_T with 16-byte loads, forms the
 // prediction as k in-lane fmas against the column of H (broadcast from LDS) and evaluates the two lgamma / two log terms

@@ -3,6 +3,7 @@
 #include <cstring>
 #include "common.hip.h"
 #include "kernels_irls.hip.h"
+#include <hipcub/hipcub.hpp>
 
 using namespace rk;
 
@@ -104,6 +105,67 @@ extern "C" int rcppml_hip_nb_size_update(rcppml_hip_ctx* c, int dtype, const int
         else
             nb_size_impl<double>(c, dtype, t_col_ptr, t_row_idx, (const double*)t_values, m, (const double*)W_T,
                                  (const double*)d, (const double*)H, n, k, r_min, r_max, (double*)nb_size);
+        return 0;
+    }
+    RCPPML_CATCH_RET
+}
+
+template <class T>
+static void vec_global_impl(rcppml_hip_ctx* c, int stat, T* x, int64_t m) {
+    if (m <= 0) return;
+    T* sorted = nullptr;
+    if (stat == 1) {
+        size_t tmp_bytes = 0;
+        HIPCHK(hipcub::DeviceRadixSort::SortKeys(nullptr, tmp_bytes, x, x, (int)m, 0, (int)sizeof(T) * 8, c->stream));
+        const size_t key_bytes = ((size_t)m * sizeof(T) + 255) / 256 * 256;
+        char* buf = static_cast<char*>(c->scratch(WS_RED2, key_bytes + tmp_bytes));
+        sorted = reinterpret_cast<T*>(buf);
+        HIPCHK(hipcub::DeviceRadixSort::SortKeys(buf + key_bytes, tmp_bytes, x, sorted, (int)m, 0, (int)sizeof(T) * 8, c->stream));
+    }
+    hipLaunchKernelGGL(vec_global_fill_kernel<T>, dim3(1), dim3(256), 0, c->stream, x, sorted, m, stat);
+    HIPCHK(hipGetLastError());
+}
+extern "C" int rcppml_hip_vec_global(rcppml_hip_ctx* c, int dtype, int stat, void* x, int64_t m) {
+    try {
+        HIPCHK(hipSetDevice(c->device));
+        if (stat != 0 && stat != 1) throw std::runtime_error("vec_global: stat must be 0 (mean) or 1 (median = sorted[m/2])");
+        if (dtype == RCPPML_F32) vec_global_impl<float>(c, stat, (float*)x, m);
+        else vec_global_impl<double>(c, stat, (double*)x, m);
+        return 0;
+    }
+    RCPPML_CATCH_RET
+}
+
+template <class T>
+static void dispersion_impl(rcppml_hip_ctx* c, int dtype, int loss_type, int mode, const int* tp, const int* ti, const T* tx,
+                            int64_t m, int64_t nnz, const T* W_T, const T* d, const T* H, int64_t n, int k, double power,
+                            double lo, double hi, T* theta) {
+    if (k < 1 || k > 64) throw std::runtime_error("dispersion_update: k must be in [1,64]");
+    if (!(loss_type == 4 || (loss_type >= 6 && loss_type <= 8))) throw std::runtime_error("dispersion_update: loss_type must be 4 (GP) or 6 / 7 / 8 (Gamma / inverse Gaussian / Tweedie)");
+    if (mode != 1 && mode != 2) throw std::runtime_error("dispersion_update: mode must be 1 (global) or 2 (per row)");
+    if (m <= 0) return;
+    const size_t head = ((size_t)k * sizeof(T) + 255) / 256 * 256;
+    char* buf = static_cast<char*>(c->scratch(WS_IRLS, head + (loss_type == 4 ? (size_t)nnz * sizeof(T) : 0)));
+    T* h_rs = reinterpret_cast<T*>(buf);
+    T* s_cache = reinterpret_cast<T*>(buf + head);
+    if (loss_type == 4 && rcppml_hip_row_norms(c, dtype, H, k, n, 3, h_rs) != 0) throw std::runtime_error(rcppml_err());
+    hipLaunchKernelGGL(dispersion_rows_kernel<T>, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, c->stream, tp, ti, tx, m, W_T, d, H,
+                       h_rs, k, loss_type, power, lo, hi, s_cache, theta);
+    HIPCHK(hipGetLastError());
+    if (mode == 1) vec_global_impl<T>(c, loss_type == 4 ? 0 : 1, theta, m);
+}
+extern "C" int rcppml_hip_dispersion_update(rcppml_hip_ctx* c, int dtype, int loss_type, int mode, const int* t_col_ptr,
+                                            const int* t_row_idx, const void* t_values, int64_t m, int64_t nnz, const void* W_T,
+                                            const void* d, const void* H, int64_t n, int k, double power, double lo, double hi,
+                                            void* theta) {
+    try {
+        HIPCHK(hipSetDevice(c->device));
+        if (dtype == RCPPML_F32)
+            dispersion_impl<float>(c, dtype, loss_type, mode, t_col_ptr, t_row_idx, (const float*)t_values, m, nnz, (const float*)W_T,
+                                   (const float*)d, (const float*)H, n, k, power, lo, hi, (float*)theta);
+        else
+            dispersion_impl<double>(c, dtype, loss_type, mode, t_col_ptr, t_row_idx, (const double*)t_values, m, nnz,
+                                    (const double*)W_T, (const double*)d, (const double*)H, n, k, power, lo, hi, (double*)theta);
         return 0;
     }
     RCPPML_CATCH_RET

@@ -86,6 +86,8 @@ struct FitParams {
     int irls_max_iter = 5; double irls_tol = 1e-4;
     int dispersion_mode = 2;                 // 0 none, 1 global, 2 per-row
     double nb_size_init = 10, nb_size_max = 1e6, nb_size_min = 0.01;
+    double gp_theta_init = 0.1, gp_theta_max = 5.0;                       // core/config.hpp:169-172
+    double gamma_phi_init = 1.0, gamma_phi_max = 1e4, gamma_phi_min = 1e-6;   // core/config.hpp:201-207
     double* out_theta = nullptr; int out_theta_len = 0;
     // outputs
     int out_iter = 0, out_converged = 0; double out_loss = 0, out_tol = 0;
@@ -210,7 +212,11 @@ void fit(FitParams& P) {
     const bool is_nb = P.loss_type == 5 || (is_gp && (P.loss_type != 0 || P.robust_delta > 0));   // "is_irls": requires_irls()
     DevBuf dtheta;
     if (is_nb) {                                                        // fit_cpu.hpp:316-328
-        std::vector<T> th((size_t)m, is_pow ? T(1) : is_gp ? T(0) : static_cast<T>(P.dispersion_mode == 0 ? P.nb_size_max : P.nb_size_init));
+        // GP theta: gp_theta_init or 0 (:297-307); phi: gamma_phi_init or 1 (:337-347); robust MSE: unused
+        const double t0 = is_pow ? (P.dispersion_mode == 0 ? 1.0 : P.gamma_phi_init)
+                        : P.loss_type == 4 ? (P.dispersion_mode == 0 ? 0.0 : P.gp_theta_init)
+                        : is_gp ? 0.0 : (P.dispersion_mode == 0 ? P.nb_size_max : P.nb_size_init);
+        std::vector<T> th((size_t)m, static_cast<T>(t0));
         dtheta.alloc((size_t)m * sizeof(T));
         HIPCHK(hipMemcpyAsync(dtheta.p, th.data(), (size_t)m * sizeof(T), hipMemcpyHostToDevice, s));
         HIPCHK(hipStreamSynchronize(s));
@@ -297,17 +303,13 @@ void fit(FitParams& P) {
         if (is_nb && !is_gp && P.dispersion_mode != 0) {
             OPCHK(rcppml_hip_nb_size_update(c, dt, dTp.as<int>(), dTi.as<int>(), dTx.p, m, dW.p, dd.p, dH.p, n, k,
                                             P.nb_size_min, P.nb_size_max, dtheta.p));
-            if (P.dispersion_mode == 1) {          // GLOBAL: median (nth_element at m/2) of the per-row values
-                std::vector<T> th((size_t)m);
-                HIPCHK(hipMemcpyAsync(th.data(), dtheta.p, (size_t)m * sizeof(T), hipMemcpyDeviceToHost, s));
-                HIPCHK(hipStreamSynchronize(s));
-                std::nth_element(th.begin(), th.begin() + m / 2, th.end());
-                const T med = th[m / 2];
-                std::fill(th.begin(), th.end(), med);
-                HIPCHK(hipMemcpyAsync(dtheta.p, th.data(), (size_t)m * sizeof(T), hipMemcpyHostToDevice, s));
-                HIPCHK(hipStreamSynchronize(s));
-            }
+            if (P.dispersion_mode == 1) OPCHK(rcppml_hip_vec_global(c, dt, 1, dtheta.p, m));   // GLOBAL: median (nth_element at m/2), :1257-1262
         }
+        // GP theta (fit_cpu.hpp:914-1008) / Gamma, inverse-Gaussian, Tweedie phi (:1561-1670), PER_ROW or GLOBAL
+        if ((P.loss_type == 4 || is_pow) && P.dispersion_mode != 0)
+            OPCHK(rcppml_hip_dispersion_update(c, dt, P.loss_type, P.dispersion_mode, dTp.as<int>(), dTi.as<int>(), dTx.p, m, P.nnz,
+                                               dW.p, dd.p, dH.p, n, k, P.tweedie_power, P.gamma_phi_min,
+                                               P.loss_type == 4 ? P.gp_theta_max : P.gamma_phi_max, dtheta.p));
         if (is_nb) {
             OPCHK(rcppml_hip_irls_loss(c, dt, P.loss_type, dAp.as<int>(), dAi.as<int>(), dAx.p, n, dW.p, dd.p, dH.p, dtheta.p, k, P.tweedie_power, P.robust_delta, dloss.as<double>()));
         } else if (has_mask) {
@@ -410,16 +412,16 @@ void nmf_entry(RCPPML_NMF_UNIFIED_ARGS, const int* mask_p, const int* mask_i, do
         *out_status = -1;
         *out_theta_len = 0;
         (void)seed; (void)loss_every; (void)huber_delta;
-        (void)gp_theta_init; (void)gp_theta_max; (void)gp_theta_min; (void)gamma_phi_init; (void)gamma_phi_max;
-        (void)gamma_phi_min; (void)guide_H_labels_flat; (void)guide_H_ns;
+        (void)gp_theta_min; (void)guide_H_labels_flat; (void)guide_H_ns;
         (void)guide_H_lambdas; (void)guide_H_ncs;
         // Reject what is not implemented so the caller falls back to CPU (SURVEY.md 8b "Semantics")
         if (*loss_type != 0 && (*loss_type < 4 || *loss_type > 8))
             throw std::runtime_error("loss_type must be MSE (0), GP (4), NB (5), Gamma (6), inverse Gaussian (7) or Tweedie (8) for this plugin build");
         if (*loss_type == 4 || *loss_type >= 6) {
             // GP with theta = 0 (Poisson / KL NMF) and the power-variance family with phi = 1: IRLS half-updates with
-            // parameter-free weights; the dispersion estimators (theta MM update, phi) are not implemented
-            if (*gp_dispersion_mode != 0) throw std::runtime_error("GP / Gamma / inverse-Gaussian / Tweedie loss: only dispersion='none' is supported");
+            // parameter-free weights; theta / phi (dispersion global or per row) only enter the GP likelihood and the output
+            if (*gp_dispersion_mode == 3) throw std::runtime_error("GP / Gamma / inverse-Gaussian / Tweedie loss: dispersion='per_col' not supported");
+            if (*gp_dispersion_mode < 0 || *gp_dispersion_mode > 3) throw std::runtime_error("bad dispersion mode");
             if (*k > 64) throw std::runtime_error("IRLS losses: k must be <= 64");
             if (*solver_mode != 0) throw std::runtime_error("IRLS losses require the CD solver");
             if (mask_p) throw std::runtime_error("IRLS losses with explicit mask: not supported");
@@ -468,6 +470,8 @@ void nmf_entry(RCPPML_NMF_UNIFIED_ARGS, const int* mask_p, const int* mask_i, do
         P.sort_model = sort_model; P.loss_history = loss_history;
         P.loss_type = *loss_type; P.irls_max_iter = *irls_max_iter; P.irls_tol = *irls_tol;
         P.dispersion_mode = *gp_dispersion_mode; P.nb_size_init = *nb_size_init; P.nb_size_max = *nb_size_max;
+        P.gp_theta_init = *gp_theta_init; P.gp_theta_max = *gp_theta_max; P.gamma_phi_init = *gamma_phi_init;
+        P.gamma_phi_max = *gamma_phi_max; P.gamma_phi_min = *gamma_phi_min;
         P.nb_size_min = *nb_size_min; P.out_theta = out_theta; P.tweedie_power = *tweedie_power; P.robust_delta = *robust_delta; P.projective = *projective != 0 ? 1 : 0;
         P.gH_p = graph_H_p; P.gH_i = graph_H_i; P.gH_x = graph_H_x; P.gH_nnz = *graph_H_nnz; P.gH_lambda = *graph_H_lambda;
         P.gW_p = graph_W_p; P.gW_i = graph_W_i; P.gW_x = graph_W_x; P.gW_nnz = *graph_W_nnz; P.gW_lambda = *graph_W_lambda;

@@ -97,9 +97,6 @@ def nmf(data, k, tol=1e-4, maxit=100, L1=(0.0, 0.0), L2=(0.0, 0.0), seed=None, m
         raise ValueError("'robust' must be FALSE, TRUE, 'mae', or a positive numeric Huber delta.")
     if robust_delta > 0 and solver == "cholesky":
         raise ValueError("solver='cholesky' is not supported with robust IRLS (robust_delta > 0). Use solver='cd' for robust estimation.")
-    if loss in ("gp", "gamma", "inverse_gaussian", "tweedie") and dispersion != "none":
-        raise NotImplementedError("loss='%s' is implemented for dispersion='none' only (no dispersion estimation on the "
-                                  "MI355X backend)" % loss)
     if dispersion not in ("none", "global", "per_row"):
         raise NotImplementedError("dispersion must be 'none', 'global' or 'per_row' on the MI355X backend")
     if symmetric:

@@ -160,14 +160,16 @@ def test_gp_fit_through_plugin_and_python_surface():
     assert np.all(res["theta"] == 0)
     W, H = W0.copy(), H0.copy()
     bad = _abi.nmf_unified(A.p, A.i, A.x, A.rows, A.cols, k, W, H, entry="double", max_iter=2, tol=0.0, loss_type=4,
-                           gp_dispersion_mode=2)
-    assert bad["status"] == -1
+                           gp_dispersion_mode=3)
+    assert bad["status"] == -1                       # per-column dispersion is handed back
     from rcppml_amd.data import CSC
     Ap = CSC((A.rows, A.cols), A.p, A.i, A.x)
     model = N.nmf(Ap, k, loss="gp", dispersion="none", seed=3, maxit=5, tol=0.0)
     assert model.misc["loss_type"] == "gp" and np.isfinite(model.misc["loss"]) and model.w.min() >= 0 and model.h.min() >= 0
     with pytest.raises(NotImplementedError):
-        N.nmf(Ap, k, loss="gp", dispersion="per_row", seed=3, maxit=2)
+        N.nmf(Ap, k, loss="gp", dispersion="per_col", seed=3, maxit=2)
+    disp = N.nmf(Ap, k, loss="gp", seed=3, maxit=5, tol=0.0)          # the R default: dispersion = "per_row"
+    assert disp.misc["theta"].shape == (A.rows,) and disp.misc["theta"].max() > 0 and disp.misc["theta"].max() <= 5.0
 
 
 def _positive_problem(m, n, seed):
@@ -233,7 +235,7 @@ def test_power_family_fit_through_plugin(loss, loss_type, power):
     model = N.nmf(CSC((A.rows, A.cols), A.p, A.i, A.x), k, loss=loss, dispersion="none", seed=3, maxit=4, tol=0.0, tweedie_power=power)
     assert model.misc["loss_type"] == loss and np.isfinite(model.misc["loss"])
     with pytest.raises(NotImplementedError):
-        N.nmf(CSC((A.rows, A.cols), A.p, A.i, A.x), k, loss=loss, dispersion="per_row", seed=3, maxit=2)
+        N.nmf(CSC((A.rows, A.cols), A.p, A.i, A.x), k, loss=loss, dispersion="per_col", seed=3, maxit=2)
 
 
 @pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-6), (np.float32, 3e-2)])
@@ -284,3 +286,71 @@ def test_robust_fit_through_plugin(loss_type):
     assert res["iter"] == ref.iter
     assert abs(res["loss"] - ref.loss) / abs(ref.loss) < 1e-4
     assert np.abs(W - ref.W_T).max() < 1e-3 and np.abs(H - ref.H).max() < 1e-3
+
+
+@pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-10), (np.float32, 2e-4)])
+@pytest.mark.parametrize("loss_type,power", [(4, 0.0), (6, 0.0), (7, 0.0), (8, 1.4)])
+@pytest.mark.parametrize("mode", [2, 1])
+def test_dispersion_update(env, dtype, tol, loss_type, power, mode):
+    """rcppml_hip_dispersion_update: GP theta by five MM passes (fit_cpu.hpp:914-1008) and Gamma / inverse-Gaussian /
+    Tweedie phi by Pearson moments (:1561-1670), PER_ROW and GLOBAL (mean / median), vs the oracle restatement.  The
+    per-row sums are fp64 on both sides; the GPU's wave-tree order differs from the oracle's sequential one."""
+    torch, _abi, ctx = env
+    A = _nb_problem(130, 190, 3, seed=5 + loss_type)
+    At = A.transpose()
+    k = 8
+    rng = np.random.default_rng(loss_type)
+    W_T = rng.uniform(size=(A.rows, k)).astype(dtype); W_T /= W_T.sum(axis=0, keepdims=True)
+    H = rng.uniform(size=(A.cols, k)).astype(dtype); H /= H.sum(axis=0, keepdims=True)
+    d = (rng.uniform(50, 500, size=k) * (1 if loss_type == 4 else 40)).astype(dtype)     # phi: predictions of the size of the data
+    th0 = np.full(A.rows, 0.1 if loss_type == 4 else 1.0, dtype)
+    lo, hi = (0.0, 5.0) if loss_type == 4 else (1e-6, 1e4)
+    ref = O.dispersion_update(loss_type, A, W_T, H, d, th0, dispersion_mode=mode, power=power, lo=lo, hi=hi, dtype=dtype)
+    dt = _abi.F32 if dtype == np.float32 else _abi.F64
+    dth = _dev(torch, th0)
+    ctx.dispersion_update(dt, loss_type, mode, _dev(torch, At.p), _dev(torch, At.i), _dev(torch, At.values(dtype)), A.rows, A.nnz,
+                          _dev(torch, W_T), _dev(torch, d), _dev(torch, H), A.cols, k, power, lo, hi, dth)
+    got = dth.cpu().numpy()
+    assert np.abs(got - ref).max() / np.abs(ref).max() < tol
+    assert ref.min() >= lo and ref.max() <= hi and (mode == 1) == (np.unique(ref).size == 1)
+    if mode == 2:
+        assert np.unique(ref).size > A.rows // 4           # a real per-row estimate, not the clamp everywhere
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_vec_global(env, dtype):
+    torch, _abi, ctx = env
+    dt = _abi.F32 if dtype == np.float32 else _abi.F64
+    for m in (1, 2, 7, 1000, 4097):
+        x = np.random.default_rng(m).standard_normal(m).astype(dtype) * 100
+        dx = _dev(torch, x)
+        ctx.vec_global(dt, 1, dx, m)
+        assert np.array_equal(dx.cpu().numpy(), np.full(m, np.sort(x)[m // 2], dtype))      # nth_element at m/2: exact
+        dx = _dev(torch, x)
+        ctx.vec_global(dt, 0, dx, m)
+        assert np.allclose(dx.cpu().numpy(), x.astype(np.float64).mean(), rtol=1e-6 if dtype == np.float32 else 1e-14, atol=1e-4 if dtype == np.float32 else 1e-12)
+
+
+@pytest.mark.parametrize("loss_type,power", [(4, 1.5), (6, 1.5), (8, 1.3)])
+@pytest.mark.parametrize("dispersion", [2, 1])
+def test_dispersion_fit_through_plugin(loss_type, power, dispersion):
+    """GP / Gamma / Tweedie with dispersion = per_row / global through the 73-pointer entry: theta / phi come back through
+    out_theta; for GP theta enters the likelihood (so the loss and the stopping rule depend on it)."""
+    from rcppml_amd import _abi
+    A = _nb_problem(100, 160, 3, seed=9) if loss_type == 4 else _positive_problem(100, 160, seed=loss_type)
+    k = 5
+    W0, H0 = O.init_factors(11, k, A.rows, A.cols, np.float64)
+    ref = O.nmf_fit(A, W0, H0, np.float64, max_iter=5, tol=0.0, loss_type=loss_type, dispersion_mode=dispersion, threads=1, tweedie_power=power)
+    none = O.nmf_fit(A, W0, H0, np.float64, max_iter=5, tol=0.0, loss_type=loss_type, dispersion_mode=0, threads=1, tweedie_power=power)
+    W, H = W0.copy(), H0.copy()
+    res = _abi.nmf_unified(A.p, A.i, A.x, A.rows, A.cols, k, W, H, entry="double", max_iter=5, tol=0.0, loss_type=loss_type,
+                           gp_dispersion_mode=dispersion, tweedie_power=power)
+    assert res["status"] == 0, res.get("error")
+    assert res["iter"] == ref.iter
+    assert abs(res["loss"] - ref.loss) / abs(ref.loss) < 1e-3
+    rel = np.abs(res["theta"] - ref.theta) / np.abs(ref.theta)
+    print("theta rel err: median %.2e max %.2e" % (np.median(rel), rel.max()))
+    assert np.median(rel) < 1e-3 and rel.max() < 0.2
+    assert not np.array_equal(ref.theta, none.theta)                      # the estimator ran
+    if loss_type == 4:
+        assert abs(ref.loss - none.loss) > 1e-3 * abs(none.loss)          # and theta changed the GP likelihood

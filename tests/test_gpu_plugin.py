@@ -118,7 +118,7 @@ def test_unsupported_features_are_rejected(abi):
     A = lowrank_csc(50, 60, 3, 0.2, seed=1)
     W0, H0 = O.init_factors(1, 4, A.rows, A.cols, np.float64)
     for kw in (dict(L21_H=0.1, loss_type=5), dict(ortho_W=-0.1), dict(projective=1, loss_type=5), dict(symmetric=1), dict(loss_type=3),
-               dict(loss_type=1), dict(loss_type=4, gp_dispersion_mode=2), dict(loss_type=6, gp_dispersion_mode=2), dict(loss_type=5, solver_mode=1),
+               dict(loss_type=1), dict(loss_type=4, gp_dispersion_mode=3), dict(loss_type=6, gp_dispersion_mode=3), dict(loss_type=5, solver_mode=1),
                dict(graph_W_nnz=5, loss_type=5), dict(guide_H_count=1), dict(solver_mode=2)):
         W, H = W0.copy(), H0.copy()
         r = abi.nmf_unified(A.p, A.i, A.x, A.rows, A.cols, 4, W, H, entry="double", max_iter=2, **kw)
