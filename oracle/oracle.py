@@ -483,3 +483,39 @@ def nmf_fit_cv(A, W_T, H, dtype=np.float64, max_iter=100, tol=1e-4, L1=(0.0, 0.0
     r.train_loss, r.test_loss, r.best_test_loss, r.best_iter = float(tr.value), float(te.value), float(bt.value), bi.value
     r.train_history, r.test_history = th[:it.value].copy(), eh[:it.value].copy()
     return r
+
+
+# ----------------------------------------------------------------------------- StreamPress v2 decoder (spz_oracle.cpp)
+_spz = None
+
+
+def spz_lib():
+    global _spz
+    if _spz is None:
+        path = os.path.join(_HERE, "libspz_oracle.so")
+        if not os.path.exists(path):
+            build()
+        _spz = C.CDLL(path)
+    return _spz
+
+
+def spz_info(buf):
+    """(status, m, n, nnz, value_type) of a .spz v2 byte stream (uint8 array).  status 5 = row-sorted file."""
+    buf = np.ascontiguousarray(buf, np.uint8)
+    m, n, nnz, vt = C.c_uint32(), C.c_uint32(), C.c_uint64(), C.c_int()
+    st = spz_lib().oracle_spz_info(buf.ctypes.data_as(C.c_void_p), C.c_uint64(buf.size), C.byref(m), C.byref(n), C.byref(nnz), C.byref(vt))
+    return st, m.value, n.value, nnz.value, vt.value
+
+
+def spz_decode(buf):
+    """Decode a .spz v2 byte stream -> (p uint32 (n+1), i uint32 (nnz), x float64 (nnz)); raises on a bad file."""
+    buf = np.ascontiguousarray(buf, np.uint8)
+    st, m, n, nnz, vt = spz_info(buf)
+    if st != 0:
+        raise ValueError("spz_info status %d" % st)
+    p, i, x = np.zeros(n + 1, np.uint32), np.zeros(nnz, np.uint32), np.zeros(nnz, np.float64)
+    st = spz_lib().oracle_spz_decode(buf.ctypes.data_as(C.c_void_p), C.c_uint64(buf.size), p.ctypes.data_as(C.c_void_p),
+                                     i.ctypes.data_as(C.c_void_p), x.ctypes.data_as(C.c_void_p))
+    if st != 0:
+        raise ValueError("spz_decode status %d" % st)
+    return p, i, x
