@@ -74,6 +74,17 @@ RCPPML_GPU_API void rcppml_gpu_detect(int* num_gpus, double* total_mem_mb, doubl
         const int* guide_H_ncs, int* guide_H_count, int* out_iter, int* out_converged,             \
         double* out_loss, int* out_status, double* out_tol
 
+/* StreamPress / SparsePress v2 `.spz` reader.  Replaces reference `rcppml_sp_read_gpu` /
+ * `rcppml_sp_free_gpu` (src/sp_gpu_bridge.cu:41-123, :132-155; bound by R/sp_gpu.R through .C()): reads the file,
+ * entropy-decodes it ON THE DEVICE (one wavefront per rANS stream) and returns device pointers to int32 col_ptr (n+1),
+ * int32 row_idx (nnz) and double values (nnz) -- the arrays rcppml_gpu_nmf_zerocopy_double takes -- with the addresses
+ * stored in doubles (R has no 64-bit integer).  out_status: 0 ok, 1 cannot open, 2 short read, 3 file too small,
+ * 4 not a v2 file, 5 decode error (incl. row-sorted files: the stored row permutation is not applied by this build).
+ * The caller releases the three arrays with rcppml_sp_free_gpu, which also zeroes the addresses. */
+RCPPML_GPU_API void rcppml_sp_read_gpu(const char** path_ptr, int* device_id, double* out_col_ptr_addr,
+                                       double* out_row_idx_addr, double* out_values_addr, int* out_m, int* out_n,
+                                       double* out_nnz, int* out_status);
+RCPPML_GPU_API void rcppml_sp_free_gpu(double* col_ptr_addr, double* row_idx_addr, double* values_addr, int* out_status);
 /* Zero-copy NMF on a device-resident CSC.  Replaces reference `rcppml_gpu_nmf_zerocopy_double`
  * (src/gpu_bridge_nmf.cu:879-967, called from R/sp_gpu.R through .C()): col_ptr (int32), row_idx (int32) and values
  * (double) are DEVICE pointers whose addresses are passed as doubles (R has no 64-bit integer); W (k x m), H (k x n), d are
@@ -331,6 +342,13 @@ RCPPML_GPU_API int rcppml_hip_irls_loss(rcppml_hip_ctx* ctx, int dtype, int loss
                                         const int* row_idx, const void* values, int64_t ncols, const void* W_T,
                                         const void* d, const void* H, const void* theta_row, int k, double loss_param,
                                         double robust_delta, double* out);
+/* Same decoder on a byte buffer in host memory, into caller-allocated device arrays (layer 2; what the parity tests
+ * call).  Format restated from streampress/sparsepress_v2.hpp:897-1090, codec/rans.hpp:128-247, codec/varint.hpp:43-52.
+ * rcppml_hip_spz_info parses the 128-byte header only (host).  Both return the out_status codes above. */
+RCPPML_GPU_API int rcppml_hip_spz_info(const void* file_bytes, uint64_t size, int* m, int* n, int64_t* nnz, int* value_type);
+RCPPML_GPU_API int rcppml_hip_spz_decode(rcppml_hip_ctx* ctx, const void* file_bytes, uint64_t size, int* d_col_ptr,
+                                         int* d_row_idx, double* d_values);
+
 /* Dispersion estimators of the other IRLS losses, per ROW of A (takes CSC(A^T), nnz = its nonzero count):
  *   loss_type 4        GP theta by the auxiliary-function (MM) update, five inner passes -- reference
  *                      nmf/fit_cpu.hpp:914-1008 (PER_ROW / GLOBAL, sparse branch); hi = gp_theta_max, lo unused;

@@ -23,7 +23,8 @@ EXPORTED_SYMBOLS = [
     "rcppml_hip_ctx_create", "rcppml_hip_ctx_destroy", "rcppml_hip_ctx_sync", "rcppml_hip_ctx_stats", "rcppml_hip_transpose_csc", "rcppml_hip_cast", "rcppml_hip_gram", "rcppml_hip_rhs",
     "rcppml_hip_solve_cd", "rcppml_hip_order_columns", "rcppml_hip_solve_chol", "rcppml_hip_row_norms", "rcppml_hip_apply_scaling",
     "rcppml_hip_sumsq", "rcppml_hip_loss_mse", "rcppml_hip_solve_masked", "rcppml_hip_loss_nonzeros",
-    "rcppml_hip_solve_irls_nb", "rcppml_hip_nb_size_update", "rcppml_hip_nb_loss", "rcppml_hip_solve_irls", "rcppml_hip_irls_loss", "rcppml_hip_apply_l21", "rcppml_hip_angular_posthoc", "rcppml_hip_solve_cv", "rcppml_hip_cv_test_error", "rcppml_hip_mul_rows", "rcppml_hip_apply_graph_reg", "rcppml_hip_dispersion_update", "rcppml_hip_vec_global",
+    "rcppml_hip_solve_irls_nb", "rcppml_hip_nb_size_update", "rcppml_hip_nb_loss", "rcppml_hip_solve_irls", "rcppml_hip_irls_loss", "rcppml_hip_apply_l21", "rcppml_hip_angular_posthoc", "rcppml_hip_solve_cv", "rcppml_hip_cv_test_error", "rcppml_hip_mul_rows", "rcppml_hip_apply_graph_reg", "rcppml_hip_dispersion_update", "rcppml_hip_vec_global", "rcppml_hip_spz_info", "rcppml_hip_spz_decode",
+    "rcppml_sp_read_gpu", "rcppml_sp_free_gpu",
 ]
 
 
@@ -414,6 +415,14 @@ class Context:
     def vec_global(self, dt, stat, x, m):
         _chk(lib().rcppml_hip_vec_global(self._h, C.c_int(dt), C.c_int(stat), _dptr(x), C.c_int64(m)), "vec_global")
 
+    def spz_decode(self, file_bytes, d_col_ptr, d_row_idx, d_values):
+        """file_bytes: uint8 numpy array (host); outputs: device int32 (n+1), int32 (nnz), float64 (nnz)."""
+        buf = np.ascontiguousarray(file_bytes, np.uint8)
+        st = lib().rcppml_hip_spz_decode(self._h, buf.ctypes.data_as(C.c_void_p), C.c_uint64(buf.size), _dptr(d_col_ptr),
+                                         _dptr(d_row_idx), _dptr(d_values))
+        if st != 0:
+            raise BackendError("spz_decode failed (status %d): %s" % (st, last_error()))
+
     def nb_size_update(self, dt, t_col_ptr, t_row_idx, t_values, m, W_T, d, H, n, k, r_min, r_max, nb_size):
         _chk(lib().rcppml_hip_nb_size_update(self._h, C.c_int(dt), _dptr(t_col_ptr), _dptr(t_row_idx), _dptr(t_values),
                                              C.c_int64(m), _dptr(W_T), _dptr(d), _dptr(H), C.c_int64(n), C.c_int(k),
@@ -422,3 +431,31 @@ class Context:
     def nb_loss(self, dt, col_ptr, row_idx, values, ncols, W_T, d, H, theta_row, k, out):
         _chk(lib().rcppml_hip_nb_loss(self._h, C.c_int(dt), _dptr(col_ptr), _dptr(row_idx), _dptr(values), C.c_int64(ncols),
                                       _dptr(W_T), _dptr(d), _dptr(H), _dptr(theta_row), C.c_int(k), _dptr(out)), "nb_loss")
+
+
+def spz_info(file_bytes):
+    """Header of a .spz v2 byte stream: (status, m, n, nnz, value_type); host only."""
+    buf = np.ascontiguousarray(file_bytes, np.uint8)
+    m, n, vt, nnz = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int64(0)
+    st = lib().rcppml_hip_spz_info(buf.ctypes.data_as(C.c_void_p), C.c_uint64(buf.size), C.byref(m), C.byref(n), C.byref(nnz), C.byref(vt))
+    return st, m.value, n.value, nnz.value, vt.value
+
+
+def sp_read_gpu(path, device=0):
+    """reference R/sp_gpu.R sp_read_gpu -> rcppml_sp_read_gpu: dict(status, m, n, nnz, col_ptr, row_idx, values) with the
+    three device addresses as floats, exactly as the .C() call returns them."""
+    pth = C.c_char_p(os.fsencode(path))
+    dev = C.c_int(device)
+    a, b, c = C.c_double(0), C.c_double(0), C.c_double(0)
+    m, n, st = C.c_int(0), C.c_int(0), C.c_int(-99)
+    nnz = C.c_double(0)
+    lib().rcppml_sp_read_gpu(C.byref(pth), C.byref(dev), C.byref(a), C.byref(b), C.byref(c), C.byref(m), C.byref(n), C.byref(nnz), C.byref(st))
+    return dict(status=st.value, m=m.value, n=n.value, nnz=int(nnz.value), col_ptr=a.value, row_idx=b.value, values=c.value,
+                error=last_error() if st.value != 0 else "")
+
+
+def sp_free_gpu(h):
+    a, b, c, st = C.c_double(h["col_ptr"]), C.c_double(h["row_idx"]), C.c_double(h["values"]), C.c_int(-99)
+    lib().rcppml_sp_free_gpu(C.byref(a), C.byref(b), C.byref(c), C.byref(st))
+    h["col_ptr"], h["row_idx"], h["values"] = a.value, b.value, c.value
+    return st.value

@@ -1,0 +1,413 @@
+// ops_spz.hip -- StreamPress / SparsePress **v2** `.spz` reader for gfx950: file bytes -> device-resident
+// CSC (int32 col_ptr, int32 row_idx, double values), the arrays rcppml_gpu_nmf_zerocopy_double consumes.
+// Replaces reference src/sp_gpu_bridge.cu:41-157 (rcppml_sp_read_gpu / rcppml_sp_free_gpu, bound by R/sp_gpu.R); the format
+// is the one streampress/sparsepress_v2.hpp:897-1090 decodes (256..2048-column chunks, per chunk one gap stream and one
+// value stream, each byte-renormalised rANS with a 14-bit probability scale + varint escapes, floats byte-shuffled).
+//
+// Split of the work:
+//   host    header, chunk index, per-column nonzero counts (varints, n of them) -> col_ptr; a table of rANS streams
+//           ("jobs": where the frequency table, the encoded bytes and the escape bytes of each stream lie in the file)
+//   device  the whole file is uploaded once; spz_rans_kernel decodes one stream per wavefront (rANS is a serial
+//           recurrence on a 32-bit state: no parallelism inside a stream, all of it across the 2..9 streams of each
+//           chunk); the 16384-slot decode table {symbol, freq, slot - cum} is built by the wave in LDS (128 KB, one
+//           ds_read_b64 per symbol); symbols are scattered straight into their final place (gaps, doubles, or the byte
+//           plane of a shuffled float).  spz_rows_kernel then turns gaps into row indices (wave prefix sums per
+//           column) and spz_float_kernel widens shuffled fp32 / fp16 / fp64 payloads to double.
+// Nothing here falls back to a host decoder: the entropy decoding itself runs on the GPU.
+#include <cstdio>
+#include <cstring>
+#include <algorithm>
+#include <vector>
+#include "common.hip.h"
+
+
+
+namespace {
+
+constexpr int SPZ_PROB_BITS = 14;
+constexpr uint32_t SPZ_SLOTS = 1u << SPZ_PROB_BITS;
+constexpr uint32_t SPZ_L = 1u << 23;
+
+struct SpzHeader {                   // streampress/format/header_v2.hpp:118-154 (128 bytes, little endian)
+    uint8_t magic[4]; uint16_t version, header_size; uint32_t m, n; uint64_t nnz; uint32_t chunk_cols, num_chunks,
+        num_tables, table_log; uint8_t value_type, compression_level, row_sorted, col_sorted; uint32_t most_common_value;
+    uint64_t chunk_index_offset, tables_offset, data_offset, transpose_offset, metadata_offset; uint32_t max_value;
+    float density; uint8_t reserved[32];
+};
+static_assert(sizeof(SpzHeader) == 128, "v2 header is 128 bytes");
+struct SpzChunk {                    // header_v2.hpp:229-247 (48 bytes)
+    uint32_t col_start, num_cols, nnz, stream_offset[2], stream_size[2], decoded_gap_bytes, decoded_value_bytes;
+    float quant_scale, quant_offset; uint32_t reserved;
+};
+static_assert(sizeof(SpzChunk) == 48, "v2 chunk descriptor is 48 bytes");
+
+enum { JOB_GAPS = 0, JOB_INT = 1, JOB_QUANT = 2, JOB_PLANE = 3 };
+struct SpzJob {                      // one rANS stream
+    uint64_t table_off;              // serialized table: u16 n_symbols, then n_symbols u16 frequencies (rans.hpp:139-166)
+    uint64_t enc_off;                // encoded bytes
+    uint64_t ov_off;                 // varint escapes (valid when ov_size > 0)
+    uint64_t out_off;                // first output element
+    uint32_t enc_size, ov_size, count, kind, plane, bpv;
+    float qscale, qoff;
+};
+
+struct ParseError { int status; const char* what; };
+
+inline uint32_t rd32(const uint8_t* p) { uint32_t v; std::memcpy(&v, p, 4); return v; }
+
+// rANS + escape block (sparsepress_v2.hpp:404-439): [table][enc_sz u32][enc bytes][ov_sz u32][varints]
+void add_escape_job(const uint8_t* data, uint64_t size, uint64_t off, uint64_t len, uint32_t count, int kind, uint64_t out_off,
+                    float qs, float qo, std::vector<SpzJob>& jobs) {
+    if (len == 0 || count == 0) return;                                    // :407-408 -> zeros (outputs are pre-zeroed)
+    if (off + 2 > size) throw ParseError{5, "rANS table beyond end of file"};
+    const uint32_t ns = data[off] | (data[off + 1] << 8);
+    if (ns > 256) throw ParseError{5, "rANS table with more than 256 symbols"};
+    uint64_t o = 2 + 2ull * ns;
+    if (o + 4 > len) throw ParseError{5, "truncated rANS block"};          // the reference returns an empty vector and then indexes it
+    SpzJob j{};
+    j.table_off = off; j.count = count; j.kind = kind; j.out_off = out_off; j.qscale = qs; j.qoff = qo;
+    j.enc_size = rd32(data + off + o); o += 4;
+    j.enc_off = off + o; o += j.enc_size;
+    if (off + o > size || j.enc_size < 4) throw ParseError{5, "rANS payload beyond end of file"};
+    if (o + 4 <= len) { j.ov_size = rd32(data + off + o); o += 4; j.ov_off = off + o; }
+    if (j.ov_size && j.ov_off + j.ov_size > size) throw ParseError{5, "escape bytes beyond end of file"};
+    jobs.push_back(j);
+}
+// byte-shuffled floats (sparsepress_v2.hpp:442-476): [n_streams u8] then per plane [table_sz u32][table][enc_sz u32][enc]
+void add_plane_jobs(const uint8_t* data, uint64_t size, uint64_t off, uint64_t len, uint32_t count, uint32_t bpv, uint64_t out_off,
+                    std::vector<SpzJob>& jobs) {
+    if (len == 0 || count == 0) return;
+    uint64_t o = 0;
+    const uint32_t ns = data[off + o++];
+    if (ns > bpv) throw ParseError{5, "more byte planes than bytes per value"};
+    for (uint32_t s = 0; s < ns; ++s) {
+        if (o + 4 > len) return;                                            // :453 (remaining planes stay zero)
+        const uint32_t tsz = rd32(data + off + o); o += 4;
+        SpzJob j{};
+        j.table_off = off + o; j.count = count; j.kind = JOB_PLANE; j.plane = s; j.bpv = bpv; j.out_off = out_off;
+        if (j.table_off + 2 > size || (data[j.table_off] | (data[j.table_off + 1] << 8)) > 256) throw ParseError{5, "bad byte-plane table"};
+        o += tsz;
+        if (o + 4 > len) return;                                            // :460
+        j.enc_size = rd32(data + off + o); o += 4;
+        j.enc_off = off + o; o += j.enc_size;
+        if (off + o > size || j.enc_size < 4) throw ParseError{5, "byte-plane payload beyond end of file"};
+        jobs.push_back(j);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------- kernels
+// quant8 dequantisation offset + scale * q in fp32 as the reference's host code evaluates it: two roundings, never an fma
+// (HIP's __fmul_rn / __fadd_rn are plain operators and contract under the default -ffp-contract=fast)
+__device__ __forceinline__ float spz_dequant(float off, float scale, uint32_t q) {
+#pragma clang fp contract(off)
+    const float prod = scale * (float)q;
+    return off + prod;
+}
+// One wavefront per rANS stream.  LDS: 16384 x u64 decode table  {symbol (8) | freq (15) << 8 | slot - cum (14) << 23}.
+__global__ __launch_bounds__(64) void spz_rans_kernel(const uint8_t* __restrict__ file, const SpzJob* __restrict__ jobs,
+                                                      uint32_t* __restrict__ gaps, double* __restrict__ values,
+                                                      uint8_t* __restrict__ raw) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    uint64_t* tab = reinterpret_cast<uint64_t*>(smem_raw);
+    __shared__ uint32_t cum[257];
+    const SpzJob job = jobs[blockIdx.x];
+    const int lane = threadIdx.x;
+    const uint8_t* tb = file + job.table_off;
+    const uint32_t ns = tb[0] | (tb[1] << 8);
+    // cumulative frequencies (rans.hpp:157-163): lanes load, lane 0 accumulates (<= 256 terms)
+    for (uint32_t s = lane; s < ns; s += 64) cum[s + 1] = tb[2 + 2 * s] | (tb[3 + 2 * s] << 8);
+    __syncthreads();
+    if (lane == 0) {
+        uint32_t c = 0;
+        for (uint32_t s = 0; s < ns; ++s) { const uint32_t f = cum[s + 1]; cum[s] = c; c += f; }
+        cum[ns] = c;
+    }
+    __syncthreads();
+    // slot -> symbol by binary search over the cumulative table (rans.hpp:128-136 build_lookup); slots past the total stay 0
+    const uint32_t total = cum[ns];
+    for (uint32_t slot = lane; slot < SPZ_SLOTS; slot += 64) {
+        uint64_t e = 0;
+        if (slot < total) {
+            uint32_t lo = 0, hi = ns;                   // last s with cum[s] <= slot (zero-frequency symbols share a cum: take the last)
+            while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (cum[mid] <= slot) lo = mid; else hi = mid; }
+            const uint32_t f = cum[lo + 1] - cum[lo];
+            e = (uint64_t)lo | ((uint64_t)f << 8) | ((uint64_t)(slot - cum[lo]) << 23);
+        }
+        tab[slot] = e;
+    }
+    __syncthreads();
+    if (lane != 0) return;
+    // ---- serial decode (rans.hpp:216-247), bytes fetched through an 8-byte window with the next word prefetched
+    const uint8_t* enc = file + job.enc_off;
+    const uint64_t* wp = reinterpret_cast<const uint64_t*>(reinterpret_cast<uintptr_t>(enc) & ~uintptr_t(7));
+    int skip = (int)(reinterpret_cast<uintptr_t>(enc) & 7);
+    uint64_t cur = __builtin_bswap64(wp[0]) << (8 * skip);
+    uint64_t nxt = wp[1];
+    int nav = 8 - skip;
+    wp += 1;
+    uint32_t left = job.enc_size;                       // bytes not yet consumed
+    auto next_byte = [&]() -> uint32_t {
+        if (nav == 0) { cur = __builtin_bswap64(nxt); ++wp; nxt = wp[0]; nav = 8; }
+        const uint32_t b = (uint32_t)(cur >> 56);
+        cur <<= 8; --nav; --left;
+        return b;
+    };
+    uint32_t x = 0;
+    for (int b = 0; b < 4; ++b) x = (x << 8) | next_byte();
+    const uint8_t* ov = file + job.ov_off;
+    const bool has_ov = job.ov_size > 0;
+    for (uint32_t i = 0; i < job.count; ++i) {
+        const uint32_t slot = x & (SPZ_SLOTS - 1);
+        const uint64_t e = tab[slot];
+        uint32_t sym = (uint32_t)(e & 255);
+        x = (uint32_t)((e >> 8) & 0x7FFF) * (x >> SPZ_PROB_BITS) + (uint32_t)(e >> 23);
+        while (x < SPZ_L && left > 0) x = (x << 8) | next_byte();
+        if (job.kind != JOB_PLANE && has_ov && sym == 255) {               // sparsepress_v2.hpp:430-436: varint escape
+            uint64_t v = 0; int sh = 0; uint8_t byte;
+            do { byte = *ov++; v |= (uint64_t)(byte & 0x7F) << sh; sh += 7; } while (byte & 0x80);
+            sym = (uint32_t)v;
+        }
+        const uint64_t o = job.out_off + i;
+        if (job.kind == JOB_GAPS) gaps[o] = sym;
+        else if (job.kind == JOB_INT) values[o] = (double)sym;                                              // :1042-1044
+        else if (job.kind == JOB_QUANT) values[o] = (double)spz_dequant(job.qoff, job.qscale, sym);                  // :1066-1068
+        else raw[o * job.bpv + job.plane] = (uint8_t)sym;                                                   // :471-473
+    }
+}
+
+// gaps -> row indices, one wavefront per column: row_t = sum_{u <= t} gap_u + t (prev = row + 1; sparsepress_v2.hpp:1017-1025)
+__global__ __launch_bounds__(256) void spz_rows_kernel(const int* __restrict__ colptr, int64_t ncols, int* __restrict__ rows) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t j = (int64_t)blockIdx.x * 4 + wave;
+    if (j >= ncols) return;
+    const int s = colptr[j], e = colptr[j + 1];
+    uint32_t carry = 0;
+    for (int t0 = s; t0 < e; t0 += 64) {
+        const int t = t0 + lane;
+        uint32_t v = t < e ? (uint32_t)rows[t] + (t > s ? 1u : 0u) : 0u;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t o = __shfl_up(v, off, 64);
+            if (lane >= off) v += o;
+        }
+        v += carry;
+        if (t < e) rows[t] = (int)v;
+        carry = __shfl(v, 63, 64);
+    }
+}
+
+__device__ __forceinline__ float spz_half_to_float(uint32_t h) {             // format/header_v2.hpp:661-686 (exact widening)
+    const uint32_t sign = (h >> 15) & 1;
+    uint32_t exp = (h >> 10) & 0x1F, frac = h & 0x3FF, bits;
+    if (exp == 0) {
+        if (frac == 0) bits = sign << 31;
+        else { exp = 1; while (!(frac & 0x400)) { frac <<= 1; exp--; } frac &= 0x3FF; bits = (sign << 31) | ((exp + 112) << 23) | (frac << 13); }
+    } else if (exp == 31) bits = (sign << 31) | 0x7F800000u | (frac << 13);
+    else bits = (sign << 31) | ((exp + 112) << 23) | (frac << 13);
+    return __uint_as_float(bits);
+}
+// de-shuffled payload -> double (sparsepress_v2.hpp:1046-1078)
+__global__ __launch_bounds__(256) void spz_float_kernel(const uint8_t* __restrict__ raw, int64_t nnz, int bpv, double* __restrict__ values) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= nnz) return;
+    if (bpv == 4) { uint32_t b; memcpy(&b, raw + t * 4, 4); values[t] = (double)__uint_as_float(b); }
+    else if (bpv == 2) { const uint32_t b = raw[t * 2] | (raw[t * 2 + 1] << 8); values[t] = (double)spz_half_to_float(b); }
+    else { double d; memcpy(&d, raw + t * 8, 8); values[t] = d; }
+}
+
+// col_ptr: what the reference decoder returns; seg_ptr: where each column's gaps actually lie in the chunk's output range
+// (identical for well-formed files; they differ only when a chunk's count section is garbage -- the reference encoder
+// omits its size prefix for chunks without nonzeros, sparsepress_v2.hpp:94 vs :988-991 -- and then seg_ptr keeps the
+// prefix-sum kernel inside the chunk)
+struct SpzParsed { SpzHeader h; std::vector<int> col_ptr, seg_ptr; std::vector<SpzJob> jobs; uint32_t bpv = 0; };
+
+int check_header(const uint8_t* data, uint64_t size, SpzHeader& h) {
+    if (size < 6) return 3;                                                  // sp_gpu_bridge.cu:69-73
+    uint16_t version; std::memcpy(&version, data + 4, 2);
+    if (version != 2) return 4;                                              // :75-81
+    if (size < 128 || std::memcmp(data, "SPRZ", 4) != 0) return 5;
+    std::memcpy(&h, data, 128);
+    return 0;
+}
+
+SpzParsed parse_file(const uint8_t* data, uint64_t size) {
+    SpzParsed P;
+    const int st = check_header(data, size, P.h);
+    if (st) throw ParseError{st, "not a v2 .spz file"};
+    const SpzHeader& h = P.h;
+    if (h.row_sorted) throw ParseError{5, "row-sorted .spz files (stored row permutation) are not supported"};
+    if (h.nnz > 0x7FFFFFFFull || h.n > 0x7FFFFFFEu) throw ParseError{5, "matrix too large for int32 CSC indices"};
+    if (size < h.chunk_index_offset + (uint64_t)h.num_chunks * 48) throw ParseError{5, "truncated chunk index"};   // sparsepress_v2.hpp:913-914
+    std::vector<SpzChunk> ch(h.num_chunks);
+    if (h.num_chunks) std::memcpy(ch.data(), data + h.chunk_index_offset, (size_t)h.num_chunks * 48);
+    P.col_ptr.assign((size_t)h.n + 1, 0);
+    P.seg_ptr.assign((size_t)h.n + 1, 0);
+    const int vt = h.value_type;
+    P.bpv = vt == 3 ? 4 : vt == 4 ? 2 : vt == 6 ? 8 : 0;
+    if (vt > 6) throw ParseError{5, "unknown value type"};
+    uint64_t out = 0;
+    for (uint32_t c = 0; c < h.num_chunks; ++c) {                            // sparsepress_v2.hpp:976-1084
+        const SpzChunk& d = ch[c];
+        if ((uint64_t)d.col_start + d.num_cols > h.n || out + d.nnz > h.nnz) throw ParseError{5, "chunk outside the matrix"};
+        const uint64_t gp = h.data_offset + d.stream_offset[0], gs = d.stream_size[0];
+        if (gs >= 4) {
+            if (gp + 4 > size) throw ParseError{5, "gap stream beyond end of file"};
+            const uint32_t cc = rd32(data + gp);
+            const uint8_t* ccp = data + gp + 4;
+            uint64_t run = out;
+            for (uint32_t j = 0; j < d.num_cols; ++j) {                      // varint column counts (:994-997)
+                uint64_t v = 0; int sh = 0; uint8_t byte;
+                do {
+                    if (ccp >= data + size) throw ParseError{5, "column counts beyond end of file"};
+                    byte = *ccp++; v |= (uint64_t)(byte & 0x7F) << sh; sh += 7;
+                } while (byte & 0x80);
+                P.col_ptr[d.col_start + j] = (int)(uint32_t)run;
+                P.seg_ptr[d.col_start + j] = (int)(d.nnz > 0 ? std::min<uint64_t>(run, out + d.nnz) : out);
+                run += (uint32_t)v;
+            }
+            if (d.nnz > 0) {
+                if (gs < 4ull + cc) throw ParseError{5, "column-count section longer than the gap stream"};
+                add_escape_job(data, size, gp + 4 + cc, gs - 4 - cc, d.nnz, JOB_GAPS, out, 0.f, 0.f, P.jobs);
+            }
+        } else {
+            for (uint32_t j = 0; j < d.num_cols; ++j) P.col_ptr[d.col_start + j] = P.seg_ptr[d.col_start + j] = (int)(uint32_t)out;
+        }
+        const uint64_t vp = h.data_offset + d.stream_offset[1], vs = d.stream_size[1];
+        if (vs && vp + vs > size) throw ParseError{5, "value stream beyond end of file"};
+        if (vt <= 2) add_escape_job(data, size, vp, vs, d.nnz, JOB_INT, out, 0.f, 0.f, P.jobs);
+        else if (vt == 5) add_escape_job(data, size, vp, vs, d.nnz, JOB_QUANT, out, d.quant_scale, d.quant_offset, P.jobs);
+        else add_plane_jobs(data, size, vp, vs, d.nnz, P.bpv, out, P.jobs);
+        out += d.nnz;
+    }
+    P.col_ptr[h.n] = P.seg_ptr[h.n] = (int)(uint32_t)h.nnz;                    // :1087
+    for (size_t j = h.n; j-- > 0;) P.seg_ptr[j] = std::min(P.seg_ptr[j], P.seg_ptr[j + 1]);   // monotone
+    return P;
+}
+
+void decode_to_device(rcppml_hip_ctx* c, const uint8_t* data, uint64_t size, const SpzParsed& P, int* d_col_ptr, int* d_row_idx,
+                      double* d_values) {
+    const SpzHeader& h = P.h;
+    hipStream_t s = c->stream;
+    HIPCHK(hipMemcpyAsync(d_col_ptr, P.col_ptr.data(), ((size_t)h.n + 1) * sizeof(int), hipMemcpyHostToDevice, s));
+    if (h.nnz == 0) { HIPCHK(hipStreamSynchronize(s)); return; }
+    // scratch: file bytes (+16 so the 8-byte window may read past the last stream), jobs, de-shuffle staging
+    const size_t file_bytes = (size + 16 + 255) / 256 * 256;
+    const size_t job_bytes = (P.jobs.size() * sizeof(SpzJob) + 255) / 256 * 256;
+    const size_t raw_bytes = ((size_t)h.nnz * P.bpv + 255) / 256 * 256;
+    const bool own_seg = P.seg_ptr != P.col_ptr;
+    const size_t seg_bytes = own_seg ? ((size_t)h.n + 1) * sizeof(int) : 0;
+    char* buf = static_cast<char*>(c->scratch(WS_GRAPH, file_bytes + job_bytes + raw_bytes + seg_bytes + 256));
+    uint8_t* d_file = reinterpret_cast<uint8_t*>(buf);
+    SpzJob* d_jobs = reinterpret_cast<SpzJob*>(buf + file_bytes);
+    uint8_t* d_raw = reinterpret_cast<uint8_t*>(buf + file_bytes + job_bytes);
+    int* d_seg = own_seg ? reinterpret_cast<int*>(buf + file_bytes + job_bytes + raw_bytes) : d_col_ptr;
+    if (own_seg) HIPCHK(hipMemcpyAsync(d_seg, P.seg_ptr.data(), seg_bytes, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemsetAsync(d_file + size, 0, file_bytes - size, s));
+    HIPCHK(hipMemcpyAsync(d_file, data, size, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemsetAsync(d_row_idx, 0, (size_t)h.nnz * sizeof(int), s));     // streams the file omits decode to zeros
+    HIPCHK(hipMemsetAsync(d_values, 0, (size_t)h.nnz * sizeof(double), s));
+    if (raw_bytes) HIPCHK(hipMemsetAsync(d_raw, 0, raw_bytes, s));
+    if (!P.jobs.empty()) {
+        HIPCHK(hipMemcpyAsync(d_jobs, P.jobs.data(), P.jobs.size() * sizeof(SpzJob), hipMemcpyHostToDevice, s));
+        const size_t smem = (size_t)SPZ_SLOTS * sizeof(uint64_t);
+        static DynSmemOnce once;
+        once.ensure(reinterpret_cast<const void*>(spz_rans_kernel), smem, c->device);
+        hipLaunchKernelGGL(spz_rans_kernel, dim3((unsigned)P.jobs.size()), dim3(64), smem, s, d_file, d_jobs,
+                           reinterpret_cast<uint32_t*>(d_row_idx), d_values, d_raw);
+        HIPCHK(hipGetLastError());
+    }
+    hipLaunchKernelGGL(spz_rows_kernel, dim3((unsigned)(((int64_t)h.n + 3) / 4)), dim3(256), 0, s, d_seg, (int64_t)h.n, d_row_idx);
+    HIPCHK(hipGetLastError());
+    if (P.bpv) {
+        hipLaunchKernelGGL(spz_float_kernel, dim3((unsigned)((h.nnz + 255) / 256)), dim3(256), 0, s, d_raw, (int64_t)h.nnz, (int)P.bpv, d_values);
+        HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipStreamSynchronize(s));          // the host buffers (jobs, col_ptr) die with the caller's frame
+}
+
+}  // namespace
+
+extern "C" int rcppml_hip_spz_info(const void* file_bytes, uint64_t size, int* m, int* n, int64_t* nnz, int* value_type) {
+    try {
+        SpzHeader h;
+        const int st = check_header(static_cast<const uint8_t*>(file_bytes), size, h);
+        if (st) { rcppml_err() = "spz_info: not a v2 .spz file"; return st; }
+        if (h.row_sorted) { rcppml_err() = "spz_info: row-sorted .spz files are not supported"; return 5; }
+        *m = (int)h.m; *n = (int)h.n; *nnz = (int64_t)h.nnz; *value_type = h.value_type;
+        return 0;
+    }
+    RCPPML_CATCH_RET
+}
+
+extern "C" int rcppml_hip_spz_decode(rcppml_hip_ctx* c, const void* file_bytes, uint64_t size, int* d_col_ptr, int* d_row_idx,
+                                     double* d_values) {
+    try {
+        HIPCHK(hipSetDevice(c->device));
+        const uint8_t* data = static_cast<const uint8_t*>(file_bytes);
+        SpzParsed P;
+        try { P = parse_file(data, size); }
+        catch (const ParseError& e) { rcppml_err() = std::string("spz_decode: ") + e.what; return e.status; }
+        decode_to_device(c, data, size, P, d_col_ptr, d_row_idx, d_values);
+        return 0;
+    }
+    RCPPML_CATCH_RET
+}
+
+// reference src/sp_gpu_bridge.cu:41-123.  out_status: 0 ok, 1 cannot open, 2 short read, 3 too small, 4 not v2, 5 decode error.
+extern "C" void rcppml_sp_read_gpu(const char** path_ptr, int* device_id, double* out_col_ptr_addr, double* out_row_idx_addr,
+                                   double* out_values_addr, int* out_m, int* out_n, double* out_nnz, int* out_status) {
+    *out_status = -1;
+    void *dp = nullptr, *di = nullptr, *dx = nullptr;
+    try {
+        FILE* f = std::fopen(*path_ptr, "rb");
+        if (!f) { *out_status = 1; rcppml_err() = "sp_read_gpu: cannot open file"; return; }
+        std::fseek(f, 0, SEEK_END);
+        const size_t size = (size_t)std::ftell(f);
+        std::fseek(f, 0, SEEK_SET);
+        std::vector<uint8_t> bytes(size);
+        const size_t got = size ? std::fread(bytes.data(), 1, size, f) : 0;
+        std::fclose(f);
+        if (got != size) { *out_status = 2; rcppml_err() = "sp_read_gpu: short read"; return; }
+        SpzParsed P;
+        try { P = parse_file(bytes.data(), size); }
+        catch (const ParseError& e) { *out_status = e.status; rcppml_err() = std::string("sp_read_gpu: ") + e.what; return; }
+        HIPCHK(hipSetDevice(*device_id));
+        hipStream_t s = nullptr;
+        HIPCHK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        rcppml_hip_ctx* c = nullptr;
+        if (rcppml_hip_ctx_create(&c, *device_id, s) != 0) { (void)hipStreamDestroy(s); *out_status = 5; return; }
+        try {
+            const size_t nnz = (size_t)P.h.nnz;
+            HIPCHK(hipMalloc(&dp, ((size_t)P.h.n + 1) * sizeof(int)));
+            HIPCHK(hipMalloc(&di, (nnz ? nnz : 1) * sizeof(int)));
+            HIPCHK(hipMalloc(&dx, (nnz ? nnz : 1) * sizeof(double)));
+            decode_to_device(c, bytes.data(), size, P, (int*)dp, (int*)di, (double*)dx);
+        } catch (...) {
+            rcppml_hip_ctx_destroy(c); (void)hipStreamDestroy(s);
+            throw;
+        }
+        rcppml_hip_ctx_destroy(c);
+        (void)hipStreamDestroy(s);
+        *out_m = (int)P.h.m; *out_n = (int)P.h.n; *out_nnz = (double)P.h.nnz;
+        // device pointers travel as doubles: R has no 64-bit integer (sp_gpu_bridge.cu:101-105)
+        *out_col_ptr_addr = (double)reinterpret_cast<uintptr_t>(dp);
+        *out_row_idx_addr = (double)reinterpret_cast<uintptr_t>(di);
+        *out_values_addr = (double)reinterpret_cast<uintptr_t>(dx);
+        *out_status = 0;
+    } catch (const std::exception& e) {
+        if (dp) (void)hipFree(dp);
+        if (di) (void)hipFree(di);
+        if (dx) (void)hipFree(dx);
+        rcppml_err() = std::string("sp_read_gpu: ") + e.what();
+        *out_status = 5;
+    }
+}
+
+// reference src/sp_gpu_bridge.cu:132-155
+extern "C" void rcppml_sp_free_gpu(double* col_ptr_addr, double* row_idx_addr, double* values_addr, int* out_status) {
+    *out_status = 0;
+    for (double* a : {col_ptr_addr, row_idx_addr, values_addr}) {
+        if (*a != 0.0) (void)hipFree(reinterpret_cast<void*>(static_cast<uintptr_t>(*a)));
+        *a = 0.0;
+    }
+}

@@ -1,0 +1,104 @@
+"""GPU parity tests of the StreamPress v2 `.spz` reader (rcppml_amd/csrc/ops_spz.hip) through the C-ABI:
+bit-exact against the CPU oracle (oracle/spz_oracle.cpp, itself pinned to the reference codec) and against the golden
+fixtures -- files written by the reference ENCODER with the CSC its DECODER returns -- including the bundled
+pbmc3k.spz; then the reference's end-to-end use: sp_read_gpu -> rcppml_gpu_nmf_zerocopy_double -> sp_free_gpu."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = np.load(os.path.join(HERE, "golden", "spz_vectors.npz"))
+PBMC = os.path.join(HERE, "golden", "pbmc3k.spz")
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    from rcppml_amd import _abi
+    return torch, _abi, _abi.Context(0)
+
+
+def _decode(env, buf):
+    torch, _abi, ctx = env
+    st, m, n, nnz, vt = _abi.spz_info(buf)
+    assert st == 0
+    dp = torch.full((n + 1,), -7, dtype=torch.int32, device="cuda")
+    di = torch.full((max(nnz, 1),), -7, dtype=torch.int32, device="cuda")
+    dx = torch.full((max(nnz, 1),), -7.0, dtype=torch.float64, device="cuda")
+    ctx.spz_decode(buf, dp, di, dx)
+    return m, n, nnz, vt, dp.cpu().numpy(), di.cpu().numpy()[:nnz], dx.cpu().numpy()[:nnz]
+
+
+@pytest.mark.parametrize("name", [str(n) for n in GOLD["names"]])
+def test_decode_matches_reference_and_oracle(env, name):
+    """Every value type (uint8 / uint16 with both escape paths / fp32 / fp16 / quant8 / fp64), empty columns, a heavy
+    column, a one-column file, and a file with nonzero-free chunks (whose column pointers are the reference decoder's
+    reading of the bytes that follow -- replicated).  Integer / byte work: bit-exact."""
+    buf = GOLD[name + "_spz"]
+    m, n, nnz, vt, p, i, x = _decode(env, buf)
+    assert [m, n, nnz, vt] == list(GOLD[name + "_info"][:4])
+    po, io, xo = O.spz_decode(buf)
+    assert np.array_equal(p.view(np.uint32), po) and np.array_equal(i.view(np.uint32), io) and np.array_equal(x, xo)
+    assert np.array_equal(p.view(np.uint32), GOLD[name + "_p"]) and np.array_equal(i.view(np.uint32), GOLD[name + "_i"])
+    assert np.array_equal(x.view(np.uint64), GOLD[name + "_x"].view(np.uint64))
+
+
+def test_bundled_pbmc3k(env):
+    """inst/extdata/pbmc3k.spz (13714 x 2700, 2.28 M nonzeros, uint16 counts, 11 chunks): SHA-256 of the decoded arrays
+    = the reference decoder's, and equal to the oracle's arrays."""
+    buf = np.fromfile(PBMC, np.uint8)
+    m, n, nnz, vt, p, i, x = _decode(env, buf)
+    assert [m, n, nnz, vt] == list(GOLD["pbmc3k_info"][:4])
+    sha = lambda a: np.frombuffer(hashlib.sha256(np.ascontiguousarray(a).tobytes()).digest(), np.uint8)
+    assert np.array_equal(sha(p.view(np.uint32)), GOLD["pbmc3k_sha_p"])
+    assert np.array_equal(sha(i.view(np.uint32)), GOLD["pbmc3k_sha_i"])
+    assert np.array_equal(sha(x), GOLD["pbmc3k_sha_x"])
+    po, io, xo = O.spz_decode(buf)
+    assert np.array_equal(p.view(np.uint32), po) and np.array_equal(i.view(np.uint32), io) and np.array_equal(x, xo)
+    # size-independent properties of a CSC
+    assert p[0] == 0 and p[-1] == nnz and np.all(np.diff(p) >= 0) and i.min() >= 0 and i.max() < m
+    seg = np.repeat(np.arange(n), np.diff(p))
+    assert np.all((np.diff(i) > 0) | (np.diff(seg) > 0))             # rows strictly increasing inside every column
+
+
+def test_bad_files_are_rejected(env):
+    torch, _abi, ctx = env
+    buf = GOLD["u8_spz"].copy()
+    assert _abi.spz_info(buf[:4])[0] == 3                            # too small (sp_gpu_bridge.cu:69-73)
+    v3 = buf.copy(); v3[4] = 3
+    assert _abi.spz_info(v3)[0] == 4                                 # not v2 (:75-81)
+    rs = buf.copy(); rs[42] = 1
+    assert _abi.spz_info(rs)[0] == 5                                 # row-sorted: not supported by this build
+    trunc = buf[: buf.size // 2]
+    d = torch.zeros(4096, dtype=torch.int32, device="cuda")
+    dx = torch.zeros(4096, dtype=torch.float64, device="cuda")
+    with pytest.raises(_abi.BackendError):
+        ctx.spz_decode(trunc, d, d.clone(), dx)
+    r = _abi.sp_read_gpu("/nonexistent/file.spz")
+    assert r["status"] == 1 and r["col_ptr"] == 0.0
+
+
+def test_read_then_zero_copy_fit(env):
+    """R/sp_gpu.R: h <- sp_read_gpu(path); nmf on the device-resident CSC; sp_free_gpu(h).  The fit must equal the
+    73-pointer fit on the host copy of the same matrix."""
+    torch, _abi, ctx = env
+    h = _abi.sp_read_gpu(PBMC)
+    assert h["status"] == 0, h["error"]
+    m, n, nnz = h["m"], h["n"], h["nnz"]
+    assert [m, n, nnz] == list(GOLD["pbmc3k_info"][:3]) and h["col_ptr"] != 0.0
+    po, io, xo = O.spz_decode(np.fromfile(PBMC, np.uint8))
+    k = 8
+    W0, H0 = O.init_factors(3, k, m, n, np.float64)
+    W1, H1 = W0.copy(), H0.copy()
+    r1 = _abi.nmf_zerocopy(h["col_ptr"], h["row_idx"], h["values"], m, n, nnz, k, W1, H1, max_iter=4, tol=0.0)
+    assert r1["status"] == 0, r1.get("error")
+    W2, H2 = W0.copy(), H0.copy()
+    r2 = _abi.nmf_unified(po.astype(np.int32), io.astype(np.int32), xo, m, n, k, W2, H2, entry="double", max_iter=4, tol=0.0, solver_mode=0)
+    assert r2["status"] == 0
+    assert r1["loss"] == r2["loss"] and np.array_equal(W1, W2) and np.array_equal(H1, H2)
+    assert _abi.sp_free_gpu(h) == 0 and h["col_ptr"] == 0.0 and h["row_idx"] == 0.0 and h["values"] == 0.0
