@@ -103,12 +103,28 @@ __device__ __forceinline__ float spz_dequant(float off, float scale, uint32_t q)
     const float prod = scale * (float)q;
     return off + prod;
 }
-// One wavefront per rANS stream.  LDS: 16384 x u64 decode table  {symbol (8) | freq (15) << 8 | slot - cum (14) << 23}.
-__global__ __launch_bounds__(64) void spz_rans_kernel(const uint8_t* __restrict__ file, const SpzJob* __restrict__ jobs,
-                                                      uint32_t* __restrict__ gaps, double* __restrict__ values,
-                                                      uint8_t* __restrict__ raw) {
+// One wavefront per rANS stream.  LDS: the 16384 x u64 decode table {symbol (8) | freq (15) << 8 | slot - cum (14) << 23},
+// a block of SPZ_B decoded symbols and the input bytes that block can consume.
+//
+// rANS is a serial recurrence, so one lane decodes; the other 63 do the memory traffic around it, block by block:
+//   all lanes   copy the next <= 2*SPZ_B + 4 encoded bytes (the most SPZ_B symbols can consume) global -> LDS
+//   lane 0      decodes SPZ_B symbols.  Dependent chain per symbol: mask -> ds_read_b64 (table) -> unpack -> 24-bit
+//               multiply-add -> at most two renormalisation bytes (after a step x >= freq * 2^9 >= 2^9) taken from an
+//               8-byte big-endian register window whose successor word is already on its way from LDS.  No global
+//               access sits on the chain (on gfx9 loads and stores share vmcnt: a global store per symbol made every
+//               window refill wait for the newest store), escapes excepted (rare varints read from the file).
+//   all lanes   flush the block to its final place, coalesced: gaps (u32), values (double, optionally de-quantised),
+//               or one byte plane of a shuffled float.
+constexpr int SPZ_B = 2048;
+constexpr int SPZ_IN_WORDS = (2 * SPZ_B + 4 + 7) / 8 + 3;
+
+__global__ __launch_bounds__(64) void spz_rans_kernel(const uint8_t* __restrict__ file, uint64_t file_padded,
+                                                      const SpzJob* __restrict__ jobs, uint32_t* __restrict__ gaps,
+                                                      double* __restrict__ values, uint8_t* __restrict__ raw) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     uint64_t* tab = reinterpret_cast<uint64_t*>(smem_raw);
+    uint32_t* obuf = reinterpret_cast<uint32_t*>(smem_raw + (size_t)SPZ_SLOTS * 8);
+    uint64_t* ibuf = reinterpret_cast<uint64_t*>(smem_raw + (size_t)SPZ_SLOTS * 8 + (size_t)SPZ_B * 4);
     __shared__ uint32_t cum[257];
     const SpzJob job = jobs[blockIdx.x];
     const int lane = threadIdx.x;
@@ -135,43 +151,63 @@ __global__ __launch_bounds__(64) void spz_rans_kernel(const uint8_t* __restrict_
         }
         tab[slot] = e;
     }
-    __syncthreads();
-    if (lane != 0) return;
-    // ---- serial decode (rans.hpp:216-247), bytes fetched through an 8-byte window with the next word prefetched
     const uint8_t* enc = file + job.enc_off;
-    const uint64_t* wp = reinterpret_cast<const uint64_t*>(reinterpret_cast<uintptr_t>(enc) & ~uintptr_t(7));
-    int skip = (int)(reinterpret_cast<uintptr_t>(enc) & 7);
-    uint64_t cur = __builtin_bswap64(wp[0]) << (8 * skip);
-    uint64_t nxt = wp[1];
-    int nav = 8 - skip;
-    wp += 1;
-    uint32_t left = job.enc_size;                       // bytes not yet consumed
-    auto next_byte = [&]() -> uint32_t {
-        if (nav == 0) { cur = __builtin_bswap64(nxt); ++wp; nxt = wp[0]; nav = 8; }
-        const uint32_t b = (uint32_t)(cur >> 56);
-        cur <<= 8; --nav; --left;
-        return b;
-    };
-    uint32_t x = 0;
-    for (int b = 0; b < 4; ++b) x = (x << 8) | next_byte();
+    const uint64_t* fend = reinterpret_cast<const uint64_t*>(file + file_padded);
+    const bool has_ov = job.kind != JOB_PLANE && job.ov_size > 0;
+    // decoder state: UNIFORM -- every lane runs the same scalar program on the same data, so the recurrence lives in
+    // SGPRs on the scalar ALU (v_readfirstlane after each LDS read tells the compiler so) and its branches are plain
+    // s_cbranch_scc, not exec-mask sequences
+    auto rfl = [](uint32_t v) -> uint32_t { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
+    uint32_t x = 0, left = job.enc_size;                // left: bytes not yet consumed (rans.hpp:240: ptr_ < end_)
     const uint8_t* ov = file + job.ov_off;
-    const bool has_ov = job.ov_size > 0;
-    for (uint32_t i = 0; i < job.count; ++i) {
-        const uint32_t slot = x & (SPZ_SLOTS - 1);
-        const uint64_t e = tab[slot];
-        uint32_t sym = (uint32_t)(e & 255);
-        x = (uint32_t)((e >> 8) & 0x7FFF) * (x >> SPZ_PROB_BITS) + (uint32_t)(e >> 23);
-        while (x < SPZ_L && left > 0) x = (x << 8) | next_byte();
-        if (job.kind != JOB_PLANE && has_ov && sym == 255) {               // sparsepress_v2.hpp:430-436: varint escape
-            uint64_t v = 0; int sh = 0; uint8_t byte;
-            do { byte = *ov++; v |= (uint64_t)(byte & 0x7F) << sh; sh += 7; } while (byte & 0x80);
-            sym = (uint32_t)v;
+    for (uint32_t base = 0; base < job.count; base += SPZ_B) {
+        const uint32_t cnt = min((uint32_t)SPZ_B, job.count - base);
+        // ---- stage the input this block can consume, already byte-swapped to big-endian words
+        const uint8_t* pos = enc + (job.enc_size - left);
+        const uint64_t* gw = reinterpret_cast<const uint64_t*>(reinterpret_cast<uintptr_t>(pos) & ~uintptr_t(7));
+        const int skip = (int)(reinterpret_cast<uintptr_t>(pos) & 7);
+        __syncthreads();                                // the previous flush has read obuf
+        for (int w = lane; w < SPZ_IN_WORDS; w += 64) ibuf[w] = (gw + w < fend) ? __builtin_bswap64(gw[w]) : 0ull;
+        __syncthreads();
+        {
+            auto lds_word = [&](int w) -> uint64_t { const uint64_t v = ibuf[w]; return (uint64_t)rfl((uint32_t)v) | ((uint64_t)rfl((uint32_t)(v >> 32)) << 32); };
+            uint64_t cur = lds_word(0) << (8 * skip);
+            uint64_t nxt = lds_word(1);
+            int nav = 8 - skip, widx = 1;
+            auto next_byte = [&]() -> uint32_t {
+                if (nav == 0) { cur = nxt; ++widx; nxt = lds_word(widx); nav = 8; }
+                const uint32_t b = (uint32_t)(cur >> 56);
+                cur <<= 8; --nav; --left;
+                return b;
+            };
+            if (base == 0) {
+#pragma unroll
+                for (int b = 0; b < 4; ++b) x = (x << 8) | next_byte();
+            }
+            for (uint32_t i = 0; i < cnt; ++i) {
+                const uint64_t e = tab[x & (SPZ_SLOTS - 1)];
+                const uint32_t elo = rfl((uint32_t)e), ehi = rfl((uint32_t)(e >> 32));
+                uint32_t sym = elo & 255u;
+                x = ((elo >> 8) & 0x7FFFu) * (x >> SPZ_PROB_BITS) + ((elo >> 23) | (ehi << 9));
+                if (x < SPZ_L && left > 0) {
+                    x = (x << 8) | next_byte();
+                    if (x < SPZ_L && left > 0) x = (x << 8) | next_byte();
+                }
+                if (has_ov && sym == 255) {                                  // sparsepress_v2.hpp:430-436: varint escape
+                    uint32_t v = 0, sh = 0, byte;
+                    do { byte = rfl((uint32_t)*ov++); if (sh < 32) v |= (byte & 0x7F) << sh; sh += 7; } while (byte & 0x80);
+                    sym = v;
+                }
+                obuf[i] = sym;                                               // all lanes, same value, same address
+            }
         }
-        const uint64_t o = job.out_off + i;
-        if (job.kind == JOB_GAPS) gaps[o] = sym;
-        else if (job.kind == JOB_INT) values[o] = (double)sym;                                              // :1042-1044
-        else if (job.kind == JOB_QUANT) values[o] = (double)spz_dequant(job.qoff, job.qscale, sym);                  // :1066-1068
-        else raw[o * job.bpv + job.plane] = (uint8_t)sym;                                                   // :471-473
+        __syncthreads();
+        // ---- flush, coalesced
+        const uint64_t o0 = job.out_off + base;
+        if (job.kind == JOB_GAPS) { for (uint32_t i = lane; i < cnt; i += 64) gaps[o0 + i] = obuf[i]; }
+        else if (job.kind == JOB_INT) { for (uint32_t i = lane; i < cnt; i += 64) values[o0 + i] = (double)obuf[i]; }                    // :1042-1044
+        else if (job.kind == JOB_QUANT) { for (uint32_t i = lane; i < cnt; i += 64) values[o0 + i] = (double)spz_dequant(job.qoff, job.qscale, obuf[i]); }   // :1066-1068
+        else { for (uint32_t i = lane; i < cnt; i += 64) raw[(o0 + i) * job.bpv + job.plane] = (uint8_t)obuf[i]; }                          // :471-473
     }
 }
 
@@ -309,10 +345,10 @@ void decode_to_device(rcppml_hip_ctx* c, const uint8_t* data, uint64_t size, con
     if (raw_bytes) HIPCHK(hipMemsetAsync(d_raw, 0, raw_bytes, s));
     if (!P.jobs.empty()) {
         HIPCHK(hipMemcpyAsync(d_jobs, P.jobs.data(), P.jobs.size() * sizeof(SpzJob), hipMemcpyHostToDevice, s));
-        const size_t smem = (size_t)SPZ_SLOTS * sizeof(uint64_t);
+        const size_t smem = (size_t)SPZ_SLOTS * sizeof(uint64_t) + (size_t)SPZ_B * 4 + (size_t)SPZ_IN_WORDS * 8;
         static DynSmemOnce once;
         once.ensure(reinterpret_cast<const void*>(spz_rans_kernel), smem, c->device);
-        hipLaunchKernelGGL(spz_rans_kernel, dim3((unsigned)P.jobs.size()), dim3(64), smem, s, d_file, d_jobs,
+        hipLaunchKernelGGL(spz_rans_kernel, dim3((unsigned)P.jobs.size()), dim3(64), smem, s, d_file, (uint64_t)file_bytes, d_jobs,
                            reinterpret_cast<uint32_t*>(d_row_idx), d_values, d_raw);
         HIPCHK(hipGetLastError());
     }
