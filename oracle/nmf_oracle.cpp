@@ -701,7 +701,10 @@ FitResult<S> nmf_fit(const Csc<S>& A, const FitConfig<S>& cfg, S* W_T, S* H, S* 
 
     for (int iter = 0; iter < cfg.max_iter; ++iter) {
         // ------------------------------------------------ H half-update
-        if (cfg.projective) {
+        std::vector<S> B_sym;                                             // symmetric: B_w_saved (:671)
+        if (cfg.symmetric) {
+            // :474-477  SYMMETRIC_SKIP: no H update, no H scaling
+        } else if (cfg.projective) {
             // variant_helpers.hpp:308-325  projective_h_update: H = (diag(d) W_T) A, then H -> d (fit_cpu.hpp:462-472)
             std::vector<S> Wd((size_t)k * m);
             for (int i = 0; i < m; ++i) for (int f = 0; f < k; ++f) Wd[(size_t)i * k + f] = W_T[(size_t)i * k + f] * d[f];
@@ -734,8 +737,22 @@ FitResult<S> nmf_fit(const Csc<S>& A, const FitConfig<S>& cfg, S* W_T, S* H, S* 
         }   // standard H update
 
         // ------------------------------------------------ W half-update
-        gram(H, k, n, G.data());                                          // :715
         const bool saved_for_loss = !cfg.has_mask && !irls;
+        if (cfg.symmetric) {
+            // :659-704  Gram = W_T W_T^T, RHS = W_T A (A = A^T); the saved pair is the one of the OLD W_T
+            gram(W_T, k, m, G.data());
+            B_sym.assign((size_t)k * n, S(0));
+            rhs(A, W_T, k, B_sym.data(), threads);
+            G_saved = G;                                                  // :669-673
+            std::vector<S> B = B_sym;
+            if (cfg.L2_W > 0) for (int i = 0; i < k; ++i) G[(size_t)i * k + i] += cfg.L2_W;   // apply_w_features: sparsity.hpp:46-47
+            if (cfg.L1_W > 0) for (auto& b : B) b -= cfg.L1_W;
+            if (cfg.has_graph_W) apply_graph_reg(G.data(), cfg.graph_W, W_T, k, cfg.graph_W_lambda);
+            apply_L21(G.data(), W_T, k, (int64_t)m, cfg.L21_W);
+            if (cfg.solver_mode == 1) cholesky_clip_batch(G.data(), B.data(), W_T, k, m, cfg.nonneg_W, threads);   // :679-683
+            else nnls_batch(G.data(), B.data(), W_T, k, m, cfg.cd_maxit, cfg.cd_tol, S(0), S(0), cfg.nonneg_W, threads, S(0), iter > 0);   // :684-692
+        } else {
+        gram(H, k, n, G.data());                                          // :715
         if (saved_for_loss) G_saved = G;                                  // :719-722
         if (cfg.has_mask) {
             masked_nnls(At, H, G.data(), W_T, maskT_own.view(), k, cfg.L1_W, cfg.L2_W, cfg.nonneg_W,
@@ -755,9 +772,11 @@ FitResult<S> nmf_fit(const Csc<S>& A, const FitConfig<S>& cfg, S* W_T, S* H, S* 
             else
                 fused_rhs_cholesky_sparse(At, H, G.data(), W_T, k, cfg.L1_W, cfg.nonneg_W, threads, S(0));
         }
-        if (cfg.ub_W > 0) apply_upper_bound(W_T, (size_t)k * m, cfg.ub_W);  // :884-885
-        apply_angular_posthoc(W_T, k, (int64_t)m, cfg.angular_W);              // :886-887
-        extract_scaling(W_T, k, m, d, cfg.norm_type);                       // :893
+        }   // standard / projective W update
+        if (cfg.ub_W > 0) apply_upper_bound(W_T, (size_t)k * m, cfg.ub_W);  // :884-885 (symmetric: :694-695)
+        apply_angular_posthoc(W_T, k, (int64_t)m, cfg.angular_W);              // :886-887 (:696-697)
+        extract_scaling(W_T, k, m, d, cfg.norm_type);                       // :893 (:700)
+        if (cfg.symmetric) std::memcpy(H, W_T, sizeof(S) * (size_t)k * m);  // :704 symmetric_enforce_h
 
         // ------------------------------------------------ NB dispersion (:1094-1265)
         if (is_gp && cfg.dispersion_mode != 0) gp_theta_update(A, W_T, H, d, k, cfg, nb_size);        // :914-1008
@@ -773,7 +792,15 @@ FitResult<S> nmf_fit(const Csc<S>& A, const FitConfig<S>& cfg, S* W_T, S* H, S* 
                                     : explicit_loss_sparse_nb(A, Wd.data(), H, k, nb_size.data(), cfg.threads > 0 ? cfg.threads : 1, cfg.loss_type, cfg.tweedie_power, cfg.robust_delta);
         } else {
             gram(W_T, k, m, G_wt.data());                                                   // :1734-1735
-            const S cross = loss_cross_term_sparse_via_At(At, W_T, H, d, k, threads);        // :1740-1741
+            S cross;
+            if (cfg.symmetric) {                                                            // :1717-1720 (B_w_saved materialised)
+                cross = 0;
+                for (int f = 0; f < k; ++f) {
+                    S rowdot = 0;
+                    for (int j = 0; j < m; ++j) rowdot += W_T[(size_t)j * k + f] * B_sym[(size_t)j * k + f];
+                    cross += d[f] * rowdot;
+                }
+            } else cross = loss_cross_term_sparse_via_At(At, W_T, H, d, k, threads);        // :1740-1741
             S recon = 0;
             for (int i = 0; i < k; ++i)
                 for (int j = 0; j < k; ++j)
@@ -886,7 +913,7 @@ template <class S> static Csc<S> mk(int rows, int cols, const int* p, const int*
         S L21_H, S L21_W, S angular_H, S angular_W, S robust_delta, int projective,                       \
         const int* gH_p, const int* gH_i, const S* gH_x, S gH_lambda, const int* gW_p, const int* gW_i,   \
         const S* gW_x, S gW_lambda, S gp_theta_init, S gp_theta_max, S gamma_phi_init, S gamma_phi_max,   \
-        S gamma_phi_min) {                                                                                \
+        S gamma_phi_min, int symmetric) {                                                                 \
         FitConfig<S> c;                                                                                   \
         c.k = k; c.max_iter = max_iter; c.tol = tol; c.L1_H = L1_H; c.L1_W = L1_W; c.L2_H = L2_H;         \
         c.L2_W = L2_W; c.ub_H = ub_H; c.ub_W = ub_W; c.cd_maxit = cd_maxit; c.cd_tol = cd_tol;            \
@@ -897,7 +924,7 @@ template <class S> static Csc<S> mk(int rows, int cols, const int* p, const int*
         c.sort_model = sort_model != 0; c.threads = threads; c.tweedie_power = tweedie_power;             \
         c.L21_H = L21_H; c.L21_W = L21_W; c.angular_H = angular_H; c.angular_W = angular_W; c.robust_delta = robust_delta; c.projective = projective != 0; \
         c.gp_theta_init = gp_theta_init; c.gp_theta_max = gp_theta_max; c.gamma_phi_init = gamma_phi_init;  \
-        c.gamma_phi_max = gamma_phi_max; c.gamma_phi_min = gamma_phi_min;                                 \
+        c.gamma_phi_max = gamma_phi_max; c.gamma_phi_min = gamma_phi_min; c.symmetric = symmetric != 0;   \
         if (gH_p) { c.has_graph_H = true; c.graph_H = mk(n, n, gH_p, gH_i, gH_x); c.graph_H_lambda = gH_lambda; } \
         if (gW_p) { c.has_graph_W = true; c.graph_W = mk(m, m, gW_p, gW_i, gW_x); c.graph_W_lambda = gW_lambda; } \
         if (mask_p) { c.has_mask = true; c.mask = mk(m, n, mask_p, mask_i, mask_x); }                     \

@@ -73,6 +73,7 @@ struct FitParams {
     // graph Laplacians (host CSC, dim x dim): graph_H over the columns of H (dim = n), graph_W over the columns of W_T (dim = m)
     const int* gH_p = nullptr; const int* gH_i = nullptr; const double* gH_x = nullptr; int gH_nnz = 0; double gH_lambda = 0;
     const int* gW_p = nullptr; const int* gW_i = nullptr; const double* gW_x = nullptr; int gW_nnz = 0; double gW_lambda = 0;
+    int symmetric = 0;                       // A ~ W diag(d) W^T (A square): only W is solved, H = W_T
     int csc_on_device = 0;                   // col_ptr / row_idx / values are DEVICE pointers (zero-copy entry)
     int projective = 0;                      // H = (diag(d) W_T) A instead of the NNLS half-update (variant_helpers.hpp:308-325)
     int cd_maxit; double cd_tol;
@@ -233,7 +234,9 @@ void fit(FitParams& P) {
     auto enqueue_iteration = [&](int iter) {
         const int warm = iter > 0 ? 1 : 0;
         // ================= H half-update (fit_cpu.hpp:486-645)
-        if (P.projective) {                                                             // :462-472
+        if (P.symmetric) {
+            // :474-477 SYMMETRIC_SKIP: H is not updated and not scaled; it is set to W_T after the W update
+        } else if (P.projective) {                                                             // :462-472
             OPCHK(rcppml_hip_mul_rows(c, dt, dW.p, k, m, dd.p, dWd.p));
             OPCHK(rcppml_hip_rhs(c, dt, dAp.as<int>(), dAi.as<int>(), dAx.p, n, dWd.p, k, dH.p));
         } else if (is_nb) {                                                                    // :565-606 (G: eps only)
@@ -263,12 +266,28 @@ void fit(FitParams& P) {
             else                                                                        // :527-534
                 OPCHK(rcppml_hip_solve_chol(c, dt, dG.p, dBh.p, dH.p, k, n, P.L1_H > 0 ? P.L1_H : 0.0, P.nonneg_H, P.ub_H));
         }
-        if (P.angular_H > 0 && !P.projective) OPCHK(rcppml_hip_angular_posthoc(c, dt, dH.p, k, n, P.angular_H));   // :638-639 (standard branch only)
-        OPCHK(rcppml_hip_row_norms(c, dt, dH.p, k, n, P.norm_type, dsums.p));           // :645 extract_scaling
-        OPCHK(rcppml_hip_apply_scaling(c, dt, dH.p, k, n, P.norm_type, dsums.p, dd.p));
+        if (P.angular_H > 0 && !P.projective && !P.symmetric) OPCHK(rcppml_hip_angular_posthoc(c, dt, dH.p, k, n, P.angular_H));   // :638-639 (standard branch only)
+        if (!P.symmetric) {
+            OPCHK(rcppml_hip_row_norms(c, dt, dH.p, k, n, P.norm_type, dsums.p));       // :645 extract_scaling
+            OPCHK(rcppml_hip_apply_scaling(c, dt, dH.p, k, n, P.norm_type, dsums.p, dd.p));
+        }
 
         // ================= W half-update (fit_cpu.hpp:711-893)
-        if (is_nb) {                                                                    // :811-852 theta_per_col = r of the row
+        if (P.symmetric) {
+            // :659-704  Gram = W_T W_T^T, RHS = W_T A (forward product: A = A^T); both saved for the loss before the
+            // features; nnls_batch semantics: zero start at iteration 0, residual-corrected warm start afterwards
+            OPCHK(rcppml_hip_gram(c, dt, dW.p, k, m, eps, 0.0, dGs.p));                 // :664, :669-673
+            if (P.L2_W > 0) OPCHK(rcppml_hip_gram(c, dt, dW.p, k, m, eps, P.L2_W, dG.p));
+            else HIPCHK(hipMemcpyAsync(dG.p, dGs.p, (size_t)k * k * sizeof(T), hipMemcpyDeviceToDevice, s));
+            if (graph_W) OPCHK(rcppml_hip_apply_graph_reg(c, dt, dG.p, dGWp.as<int>(), dGWi.as<int>(), dGWx.p, dW.p, k, m, P.gW_lambda));
+            if (P.L21_W > 0) OPCHK(rcppml_hip_apply_l21(c, dt, dG.p, dW.p, k, m, P.L21_W));
+            OPCHK(rcppml_hip_rhs(c, dt, dAp.as<int>(), dAi.as<int>(), dAx.p, n, dW.p, k, dBw.p));   // :665
+            if (P.solver_mode == 0)
+                OPCHK(rcppml_hip_solve_cd(c, dt, dG.p, dBw.p, dW.p, k, m, P.L1_W > 0 ? P.L1_W : 0.0, warm, warm ? 0 : 1, 0.0, 0.0,
+                                          P.nonneg_W, P.cd_maxit, P.cd_tol, 0.0, P.ub_W, RCPPML_CD_AUTO, nullptr, nullptr));   // :684-692
+            else
+                OPCHK(rcppml_hip_solve_chol(c, dt, dG.p, dBw.p, dW.p, k, m, P.L1_W > 0 ? P.L1_W : 0.0, P.nonneg_W, P.ub_W));   // :679-683
+        } else if (is_nb) {                                                             // :811-852 theta_per_col = r of the row
             OPCHK(rcppml_hip_gram(c, dt, dH.p, k, n, eps, 0.0, dG.p));
             OPCHK(rcppml_hip_solve_irls(c, dt, P.loss_type, dTp.as<int>(), dTi.as<int>(), dTx.p, m, dH.p, dG.p, dW.p, k, P.L1_W,
                                         P.L2_W, P.nonneg_W, P.cd_maxit, P.irls_max_iter, P.irls_tol, nullptr,
@@ -298,6 +317,7 @@ void fit(FitParams& P) {
         if (P.angular_W > 0) OPCHK(rcppml_hip_angular_posthoc(c, dt, dW.p, k, m, P.angular_W));   // :886-887
         OPCHK(rcppml_hip_row_norms(c, dt, dW.p, k, m, P.norm_type, dsums.p));           // :893
         OPCHK(rcppml_hip_apply_scaling(c, dt, dW.p, k, m, P.norm_type, dsums.p, dd.p));
+        if (P.symmetric) HIPCHK(hipMemcpyAsync(dH.p, dW.p, (size_t)k * m * sizeof(T), hipMemcpyDeviceToDevice, s));   // :704 H = W_T
 
         // ================= NB size update (fit_cpu.hpp:1094-1265), then loss (fit_cpu.hpp:1684-1753)
         if (is_nb && !is_gp && P.dispersion_mode != 0) {
@@ -448,7 +468,10 @@ void nmf_entry(RCPPML_NMF_UNIFIED_ARGS, const int* mask_p, const int* mask_i, do
             if ((*graph_H_nnz > 0 && *graph_H_dim != *n) || (*graph_W_nnz > 0 && *graph_W_dim != *m)) throw std::runtime_error("graph Laplacian dimension mismatch");
         }
         if (*guide_H_count > 0) throw std::runtime_error("classifier guides not supported");
-        if (*symmetric != 0) throw std::runtime_error("symmetric NMF not supported");
+        if (*symmetric != 0) {
+            if (*loss_type != 0 || *robust_delta > 0 || mask_p || *projective != 0) throw std::runtime_error("symmetric NMF: plain MSE path only");
+            if (*m != *n) throw std::runtime_error("symmetric NMF needs a square matrix");
+        }
         if (*projective != 0 && (*loss_type != 0 || *robust_delta > 0 || mask_p)) throw std::runtime_error("projective NMF: MSE path without explicit mask only");
         if (*solver_mode != 0 && *solver_mode != 1) throw std::runtime_error("solver_mode must be 0 (CD) or 1 (Cholesky+clip)");
         if (*k < 1 || *k > 128) throw std::runtime_error("k must be in [1,128]");
@@ -472,7 +495,7 @@ void nmf_entry(RCPPML_NMF_UNIFIED_ARGS, const int* mask_p, const int* mask_i, do
         P.dispersion_mode = *gp_dispersion_mode; P.nb_size_init = *nb_size_init; P.nb_size_max = *nb_size_max;
         P.gp_theta_init = *gp_theta_init; P.gp_theta_max = *gp_theta_max; P.gamma_phi_init = *gamma_phi_init;
         P.gamma_phi_max = *gamma_phi_max; P.gamma_phi_min = *gamma_phi_min;
-        P.nb_size_min = *nb_size_min; P.out_theta = out_theta; P.tweedie_power = *tweedie_power; P.robust_delta = *robust_delta; P.projective = *projective != 0 ? 1 : 0;
+        P.nb_size_min = *nb_size_min; P.out_theta = out_theta; P.tweedie_power = *tweedie_power; P.robust_delta = *robust_delta; P.projective = *projective != 0 ? 1 : 0; P.symmetric = *symmetric != 0 ? 1 : 0;
         P.gH_p = graph_H_p; P.gH_i = graph_H_i; P.gH_x = graph_H_x; P.gH_nnz = *graph_H_nnz; P.gH_lambda = *graph_H_lambda;
         P.gW_p = graph_W_p; P.gW_i = graph_W_i; P.gW_x = graph_W_x; P.gW_nnz = *graph_W_nnz; P.gW_lambda = *graph_W_lambda;
         if (precision == RCPPML_F64) fit<double>(P); else fit<float>(P);

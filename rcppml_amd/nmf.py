@@ -99,8 +99,9 @@ def nmf(data, k, tol=1e-4, maxit=100, L1=(0.0, 0.0), L2=(0.0, 0.0), seed=None, m
         raise ValueError("solver='cholesky' is not supported with robust IRLS (robust_delta > 0). Use solver='cd' for robust estimation.")
     if dispersion not in ("none", "global", "per_row"):
         raise NotImplementedError("dispersion must be 'none', 'global' or 'per_row' on the MI355X backend")
-    if symmetric:
-        raise NotImplementedError("symmetric NMF is not implemented by the MI355X backend")
+    if symmetric and (robust_delta > 0 or loss != "mse" or projective or (test_fraction and test_fraction > 0)
+                      or (mask is not None and not isinstance(mask, str))):
+        raise NotImplementedError("symmetric NMF is implemented for the plain MSE path")
     if projective and (robust_delta > 0 or loss != "mse" or (test_fraction and test_fraction > 0) or (mask is not None and not isinstance(mask, str))):
         raise NotImplementedError("projective NMF is implemented for the plain MSE path")
     cv = bool(test_fraction) and test_fraction > 0
@@ -113,6 +114,8 @@ def nmf(data, k, tol=1e-4, maxit=100, L1=(0.0, 0.0), L2=(0.0, 0.0), seed=None, m
         raise ValueError("rcppml_amd has no CPU path; resource must be 'gpu'")
     A = _as_csc(data)
     m, n = A.shape
+    if symmetric and m != n:
+        raise ValueError('symmetric = TRUE requires a square matrix')
     k = int(k)
     if k < 1:
         raise ValueError("k must be a positive integer")
@@ -197,7 +200,7 @@ def nmf(data, k, tol=1e-4, maxit=100, L1=(0.0, 0.0), L2=(0.0, 0.0), seed=None, m
                            L1_W=L1w, L2_H=L2h, L2_W=L2w, L21_H=L21h, L21_W=L21w, ortho_H=angh, ortho_W=angw, ub_H=ubh, ub_W=ubw, cd_maxit=int(cd_maxit), verbose=int(verbose),
                            seed=seed_int & 0x7FFFFFFF, patience=int(patience), nonneg_W=int(nnw), nonneg_H=int(nnh),
                            norm_type=norm_type, solver_mode=0 if solver == "cd" else 1, mask=mask_arg, cd_tol=float(cd_tol),
-                           loss_type={"mse": 0, "gp": 4, "nb": 5, "gamma": 6, "inverse_gaussian": 7, "tweedie": 8}[loss], projective=int(bool(projective)),
+                           loss_type={"mse": 0, "gp": 4, "nb": 5, "gamma": 6, "inverse_gaussian": 7, "tweedie": 8}[loss], projective=int(bool(projective)), symmetric=int(bool(symmetric)),
                            tweedie_power=float(tweedie_power), robust_delta=robust_delta, irls_max_iter=int(irls_max_iter), irls_tol=float(irls_tol),
                            gp_dispersion_mode={"none": 0, "global": 1, "per_row": 2}[dispersion],
                            nb_size=(nb_size_init, nb_size_max, nb_size_min),

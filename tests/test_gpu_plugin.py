@@ -117,7 +117,7 @@ def test_unsupported_features_are_rejected(abi):
     """The plugin must set out_status=-1 (-> caller's CPU fallback) instead of silently dropping a feature."""
     A = lowrank_csc(50, 60, 3, 0.2, seed=1)
     W0, H0 = O.init_factors(1, 4, A.rows, A.cols, np.float64)
-    for kw in (dict(L21_H=0.1, loss_type=5), dict(ortho_W=-0.1), dict(projective=1, loss_type=5), dict(symmetric=1), dict(loss_type=3),
+    for kw in (dict(L21_H=0.1, loss_type=5), dict(ortho_W=-0.1), dict(projective=1, loss_type=5), dict(symmetric=1), dict(symmetric=1, projective=1), dict(loss_type=3),
                dict(loss_type=1), dict(loss_type=4, gp_dispersion_mode=3), dict(loss_type=6, gp_dispersion_mode=3), dict(loss_type=5, solver_mode=1),
                dict(graph_W_nnz=5, loss_type=5), dict(guide_H_count=1), dict(solver_mode=2)):
         W, H = W0.copy(), H0.copy()
@@ -267,6 +267,37 @@ def test_l21_and_angular_features(abi, entry, tol_loss, tol_fac):
     base = O.nmf_fit(A, W0, H0, dtype, max_iter=6, tol=0.0, solver_mode=0)
     pen = O.nmf_fit(A, W0, H0, dtype, max_iter=6, tol=0.0, solver_mode=0, L21=(0.05, 0.2), angular=(0.03, 0.05))
     assert abs(pen.loss - base.loss) > 1e-3 * abs(base.loss)
+
+
+@pytest.mark.parametrize("entry,tol_loss,tol_fac", [("double", 1e-6, 1e-6), ("float", 5e-4, 5e-3)])
+def test_symmetric_nmf(abi, entry, tol_loss, tol_fac):
+    """symmetric = TRUE (A ~ W diag(d) W^T, fit_cpu.hpp:659-704): H is never solved, W is solved against its own Gram and
+    W_T A with nnls_batch semantics (zero start, then residual-corrected warm start), H = W_T; the loss pairs the new W_T
+    with the Gram / RHS of the old one.  Both solvers and the k x k features, vs the oracle."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(5)
+    n, k = 120, 6
+    F = rng.uniform(0, 1, (n, 4)) * (rng.random((n, 4)) < 0.4)
+    S = sp.csc_matrix((F @ F.T) * (rng.random((n, n)) < 0.4))
+    S = sp.csc_matrix((S + S.T) / 2)
+    S.sort_indices()
+    A = O.Csc(S.shape, S.indptr, S.indices, S.data)
+    dtype = np.float64 if entry == "double" else np.float32
+    W0, H0 = O.init_factors(7, k, n, n, np.float64)
+    for solver, kw_o, kw_g in ((0, {}, {}), (1, {}, {}), (0, dict(L1=(0.01, 0.0), L2=(0.02, 0.0), L21=(0.03, 0.0)), dict(L1_W=0.01, L2_W=0.02, L21_W=0.03)),
+                               (0, dict(ub=(0.05, 0.0), angular=(0.02, 0.0)), dict(ub_W=0.05, ortho_W=0.02))):
+        ref = O.nmf_fit(A, W0, H0, dtype, max_iter=8, tol=0.0, solver_mode=solver, symmetric=True, **kw_o)
+        res = _run_gpu(abi, A, W0, H0, entry, max_iter=8, tol=0.0, solver_mode=solver, symmetric=1, **kw_g)
+        _compare(res, ref, tol_loss, tol_fac)
+        assert np.array_equal(res["W_T"], res["H"])
+    std = O.nmf_fit(A, W0, H0, dtype, max_iter=8, tol=0.0, solver_mode=0)
+    sym = O.nmf_fit(A, W0, H0, dtype, max_iter=8, tol=0.0, solver_mode=0, symmetric=True)
+    assert abs(sym.loss - std.loss) > 1e-6 * abs(std.loss) and sym.loss_history[-1] < sym.loss_history[0]
+    # a non-square matrix is handed back
+    B = lowrank_csc(50, 60, 3, 0.2, seed=1)
+    W1, H1 = O.init_factors(1, 4, B.rows, B.cols, np.float64)
+    r = abi.nmf_unified(B.p, B.i, B.x, B.rows, B.cols, 4, W1, H1, entry="double", max_iter=2, symmetric=1)
+    assert r["status"] == -1 and "square" in r["error"]
 
 
 def _ring_laplacian(dim, seed, hops=2):
