@@ -347,7 +347,8 @@ static CvResult<S> nmf_fit_cv(const Csc<S>& A, const FitConfig<S>& cfg, double h
         // ---- H update (:408-535)
         gram(W_T, k, m, G.data());
         for (int i = 0; i < k; ++i) G[(size_t)i * k + i] += static_cast<S>(1e-15);        // :410 (on top of gram's own eps)
-        if (cfg.L2_H > 0) for (int i = 0; i < k; ++i) G[(size_t)i * k + i] += cfg.L2_H;   // apply_cv_features
+        if (cfg.L2_H > 0) for (int i = 0; i < k; ++i) G[(size_t)i * k + i] += cfg.L2_H;   // apply_cv_features (variant_helpers.hpp:174-189)
+        if (cfg.has_graph_H) apply_graph_reg(G.data(), cfg.graph_H, H, k, cfg.graph_H_lambda);
         apply_L21(G.data(), H, k, (int64_t)n, cfg.L21_H);
         cv_half_update(A, W_T, G.data(), H, k, mask, false, cfg.L1_H, cfg.nonneg_H, cfg.cd_maxit, cfg.solver_mode, threads);
         if (cfg.ub_H > 0) apply_upper_bound(H, (size_t)k * n, cfg.ub_H);
@@ -358,6 +359,7 @@ static CvResult<S> nmf_fit_cv(const Csc<S>& A, const FitConfig<S>& cfg, double h
         G_H_saved = G;                                                                     // :574-576 (with gram's eps)
         for (int i = 0; i < k; ++i) G[(size_t)i * k + i] += static_cast<S>(1e-15);        // :578
         if (cfg.L2_W > 0) for (int i = 0; i < k; ++i) G[(size_t)i * k + i] += cfg.L2_W;
+        if (cfg.has_graph_W) apply_graph_reg(G.data(), cfg.graph_W, W_T, k, cfg.graph_W_lambda);
         apply_L21(G.data(), W_T, k, (int64_t)m, cfg.L21_W);
         // B_W_full.col(i) = sum_j A(i,j) H(:,j) over ALL nonzeros (train + test), :617-655
         for (int i = 0; i < m; ++i) {
@@ -1032,11 +1034,15 @@ ORACLE_API int oracle_cv_is_holdout(double frac, uint64_t cv_seed, int i, int j)
                                             int nonneg_W, int nonneg_H, int norm_type, int solver_mode, double frac, \
                                             uint64_t cv_seed, int mask_zeros, int cv_patience, int threads,         \
                                             int* out_iter, int* out_converged, S* out_train, S* out_test,           \
-                                            S* out_best_test, int* out_best_iter, S* train_hist, S* test_hist) {    \
+                                            S* out_best_test, int* out_best_iter, S* train_hist, S* test_hist,     \
+                                            const int* gH_p, const int* gH_i, const S* gH_x, S gH_lambda,           \
+                                            const int* gW_p, const int* gW_i, const S* gW_x, S gW_lambda) {         \
         FitConfig<S> c;                                                                                            \
         c.k = k; c.max_iter = max_iter; c.tol = tol; c.L1_H = L1_H; c.L1_W = L1_W; c.L2_H = L2_H; c.L2_W = L2_W;    \
         c.cd_maxit = cd_maxit; c.nonneg_W = nonneg_W != 0; c.nonneg_H = nonneg_H != 0; c.norm_type = norm_type;     \
         c.solver_mode = solver_mode; c.threads = threads;                                                          \
+        if (gH_p) { c.has_graph_H = true; c.graph_H = mk(n, n, gH_p, gH_i, gH_x); c.graph_H_lambda = gH_lambda; }  \
+        if (gW_p) { c.has_graph_W = true; c.graph_W = mk(m, m, gW_p, gW_i, gW_x); c.graph_W_lambda = gW_lambda; }  \
         CvResult<S> r = nmf_fit_cv(mk(m, n, p, i, x), c, frac, cv_seed, mask_zeros != 0, cv_patience, W_T, H, d);   \
         *out_iter = r.iterations; *out_converged = r.converged ? 1 : 0; *out_train = r.train_loss;                 \
         *out_test = r.test_loss; *out_best_test = r.best_test_loss; *out_best_iter = r.best_iter;                   \

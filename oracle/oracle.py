@@ -457,7 +457,7 @@ class CvFitResult:
 
 def nmf_fit_cv(A, W_T, H, dtype=np.float64, max_iter=100, tol=1e-4, L1=(0.0, 0.0), L2=(0.0, 0.0), cd_maxit=100,
                nonneg=(True, True), norm_type=0, solver_mode=0, holdout_fraction=0.1, cv_seed=0, mask_zeros=False,
-               cv_patience=5, threads=1, native=False):
+               cv_patience=5, threads=1, native=False, graph_H=None, graph_W=None):
     """CPU restatement of nmf_fit_cv (reference nmf/fit_cv.hpp), MSE / sparse.  Returns W_T (normalised), H WITH d
     absorbed and d, as the reference packages them."""
     suf, ct = _suf(dtype)
@@ -476,7 +476,7 @@ def nmf_fit_cv(A, W_T, H, dtype=np.float64, max_iter=100, tol=1e-4, L1=(0.0, 0.0
         ct(L1[1]), ct(L1[0]), ct(L2[1]), ct(L2[0]), C.c_int(cd_maxit), C.c_int(int(nonneg[0])), C.c_int(int(nonneg[1])),
         C.c_int(norm_type), C.c_int(solver_mode), C.c_double(holdout_fraction), C.c_uint64(cv_seed), C.c_int(int(mask_zeros)),
         C.c_int(cv_patience), C.c_int(threads), C.byref(it), C.byref(conv), C.byref(tr), C.byref(te), C.byref(bt), C.byref(bi),
-        _p(th), _p(eh))
+        _p(th), _p(eh), *_graph_args(graph_H, dtype, ct), *_graph_args(graph_W, dtype, ct))
     r = CvFitResult()
     r.W_T, r.H, r.d = W_T, H, d
     r.iter, r.converged = it.value, bool(conv.value)

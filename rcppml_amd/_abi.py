@@ -201,7 +201,8 @@ def _dptr(t):
 
 def nmf_cv(p, i, x, m, n, k, W_T, H, *, entry="ex", max_iter=100, tol=1e-4, L1_H=0.0, L1_W=0.0, L2_H=0.0, L2_W=0.0, cd_maxit=100,
            verbose=0, seed=0, holdout_fraction=0.1, cv_seed=0, mask_zeros=0, nonneg_W=1, nonneg_H=1, norm_type=0, loss_type=0,
-           solver_mode=0, projective=0, symmetric=0, graph_W_nnz=0, sort_model=1, precision=F64, cv_patience=5):
+           solver_mode=0, projective=0, symmetric=0, graph_W_nnz=0, sort_model=1, precision=F64, cv_patience=5,
+           graph_W=None, graph_H=None):
     """Call the CV plugin entry as reference gpu/bridge_nmf.hpp:407-497 does (51 pointers; entry "float" | "double"), or
     the build-defined "ex" form (+ sort flag, precision, patience, loss histories).  W_T (m, k) and H (n, k) float64
     arrays are updated IN PLACE (H returns with d absorbed)."""
@@ -228,6 +229,13 @@ def nmf_cv(p, i, x, m, n, k, W_T, H, *, entry="ex", max_iter=100, tol=1e-4, L1_H
         C.byref(out_iter), C.byref(out_conv), C.byref(out_train), C.byref(out_test), C.byref(out_best), C.byref(out_best_iter),
         C.byref(out_status),
     ]
+    keep = []
+    for slot, g in ((29, graph_W), (35, graph_H)):          # (p, i, x, lambda) CSC Laplacians, as in nmf_unified
+        if g is not None:
+            gp, gi, gx, lam = g
+            gp = np.ascontiguousarray(gp, np.int32); gi = np.ascontiguousarray(gi, np.int32); gx = np.ascontiguousarray(gx, np.float64)
+            args[slot:slot + 6] = [_np_ptr(gp), _np_ptr(gi), _np_ptr(gx), _ci(gp.shape[0] - 1), _ci(gx.shape[0]), _cd(lam)]
+            keep.append((gp, gi, gx))
     assert len(args) == 51
     th = eh = None
     if entry == "ex":

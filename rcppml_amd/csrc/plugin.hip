@@ -578,6 +578,8 @@ struct CvParams {
     int cd_maxit, verbose, nonneg_W, nonneg_H, norm_type, solver_mode;
     double holdout_fraction; unsigned long long cv_seed; int mask_zeros; int cv_patience; int sort_model;
     double* train_history = nullptr; double* test_history = nullptr;     // optional, max_iter entries each
+    const int* gH_p = nullptr; const int* gH_i = nullptr; const double* gH_x = nullptr; int gH_nnz = 0; double gH_lambda = 0;
+    const int* gW_p = nullptr; const int* gW_i = nullptr; const double* gW_x = nullptr; int gW_nnz = 0; double gW_lambda = 0;
     int out_iter = 0, out_converged = 0, out_best_iter = 0; double out_train = 0, out_test = 0, out_best_test = 0;
 };
 
@@ -619,9 +621,21 @@ void fit_cv(CvParams& P) {
     double train_loss = 0, test_loss = 0, final_tol = 0;
     auto as_scalar = [](double v) { return std::is_same<T, float>::value ? static_cast<double>(static_cast<float>(v)) : v; };
 
+    // graph Laplacians (apply_cv_features, variant_helpers.hpp:174-189), uploaded once
+    DevBuf dGHp, dGHi, dGHx, dGWp, dGWi, dGWx;
+    const bool graph_H = P.gH_p && P.gH_nnz > 0 && P.gH_lambda > 0, graph_W = P.gW_p && P.gW_nnz > 0 && P.gW_lambda > 0;
+    if (graph_H) {
+        upload_ints(P.gH_p, (size_t)n + 1, dGHp, s); upload_ints(P.gH_i, (size_t)P.gH_nnz, dGHi, s);
+        upload_cast<T>(c, P.gH_x, (size_t)P.gH_nnz, dGHx, s);
+    }
+    if (graph_W) {
+        upload_ints(P.gW_p, (size_t)m + 1, dGWp, s); upload_ints(P.gW_i, (size_t)P.gW_nnz, dGWi, s);
+        upload_cast<T>(c, P.gW_x, (size_t)P.gW_nnz, dGWx, s);
+    }
     for (int iter = 0; iter < P.max_iter; ++iter) {
         // ---- H half-update (:408-550): G = gram(W) (eps) + 1e-15 (:410) + L2
         OPCHK(rcppml_hip_gram(c, dt, dW.p, k, m, 2 * eps, P.L2_H, dG.p));
+        if (graph_H) OPCHK(rcppml_hip_apply_graph_reg(c, dt, dG.p, dGHp.as<int>(), dGHi.as<int>(), dGHx.p, dH.p, k, n, P.gH_lambda));   // :416-417
         OPCHK(rcppml_hip_solve_cv(c, dt, dAp.as<int>(), dAi.as<int>(), dAx.p, n, m, dW.p, dG.p, dH.p, k, P.holdout_fraction,
                                   P.cv_seed, P.mask_zeros, 0, P.L1_H, P.nonneg_H, P.cd_maxit, P.solver_mode));
         OPCHK(rcppml_hip_row_norms(c, dt, dH.p, k, n, P.norm_type, dsums.p));
@@ -629,6 +643,7 @@ void fit_cv(CvParams& P) {
         // ---- W half-update (:555-860): G_H_saved = gram(H) (eps); G = G_H_saved + 1e-15 + L2
         OPCHK(rcppml_hip_gram(c, dt, dH.p, k, n, eps, 0.0, dGs.p));
         OPCHK(rcppml_hip_gram(c, dt, dH.p, k, n, 2 * eps, P.L2_W, dG.p));
+        if (graph_W) OPCHK(rcppml_hip_apply_graph_reg(c, dt, dG.p, dGWp.as<int>(), dGWi.as<int>(), dGWx.p, dW.p, k, m, P.gW_lambda));   // :580-581
         OPCHK(rcppml_hip_rhs(c, dt, dTp.as<int>(), dTi.as<int>(), dTx.p, m, dH.p, k, dBw.p));      // B_W_full: train + test
         OPCHK(rcppml_hip_solve_cv(c, dt, dTp.as<int>(), dTi.as<int>(), dTx.p, m, n, dH.p, dG.p, dW.p, k, P.holdout_fraction,
                                   P.cv_seed, P.mask_zeros, 1, P.L1_W, P.nonneg_W, P.cd_maxit, P.solver_mode));
@@ -692,10 +707,8 @@ void nmf_cv_entry(RCPPML_NMF_CV_ARGS, int sort_model, int precision, int cv_pati
         rcppml_err().clear();
         *out_status = -1;
         (void)seed_only_used_for_cv_seed_fallback; (void)huber_delta; (void)irls_max_iter; (void)irls_tol;
-        (void)graph_W_p; (void)graph_W_i; (void)graph_W_x; (void)graph_W_dim; (void)graph_W_lambda;
-        (void)graph_H_p; (void)graph_H_i; (void)graph_H_x; (void)graph_H_dim; (void)graph_H_lambda;
         if (*loss_type != 0) throw std::runtime_error("CV: only the MSE loss is implemented");
-        if (*graph_W_nnz > 0 || *graph_H_nnz > 0) throw std::runtime_error("CV: graph regularisation not supported");
+        if ((*graph_H_nnz > 0 && *graph_H_dim != *n) || (*graph_W_nnz > 0 && *graph_W_dim != *m)) throw std::runtime_error("CV: graph Laplacian dimension mismatch");
         if (*projective != 0 || *symmetric != 0) throw std::runtime_error("CV: projective/symmetric NMF not supported");
         if (*solver_mode != 0 && *solver_mode != 1) throw std::runtime_error("CV: solver_mode must be 0 (CD) or 1 (Cholesky+clip)");
         if (*k < 1 || *k > 64) throw std::runtime_error("CV: k must be in [1,64]");
@@ -718,6 +731,8 @@ void nmf_cv_entry(RCPPML_NMF_CV_ARGS, int sort_model, int precision, int cv_pati
         P.mask_zeros = *mask_zeros != 0 ? 1 : 0;
         P.cv_patience = cv_patience; P.sort_model = sort_model;
         P.train_history = train_history; P.test_history = test_history;
+        P.gH_p = graph_H_p; P.gH_i = graph_H_i; P.gH_x = graph_H_x; P.gH_nnz = *graph_H_nnz; P.gH_lambda = *graph_H_lambda;
+        P.gW_p = graph_W_p; P.gW_i = graph_W_i; P.gW_x = graph_W_x; P.gW_nnz = *graph_W_nnz; P.gW_lambda = *graph_W_lambda;
         if (precision == RCPPML_F64) fit_cv<double>(P); else fit_cv<float>(P);
         *out_iter = P.out_iter; *out_converged = P.out_converged; *out_train_loss = P.out_train; *out_test_loss = P.out_test;
         *out_best_test = P.out_best_test; *out_best_iter = P.out_best_iter;

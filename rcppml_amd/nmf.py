@@ -139,7 +139,7 @@ def nmf(data, k, tol=1e-4, maxit=100, L1=(0.0, 0.0), L2=(0.0, 0.0), seed=None, m
         if Lg.shape != (dim, dim):
             raise ValueError("%s must be %d x %d" % (name, dim, dim))
         graph_args[name] = (Lg.p, Lg.i, Lg.x, float(lam))
-    if graph_args and (loss != "mse" or robust_delta > 0 or cv or (mask is not None and not isinstance(mask, str)) or k > 64):
+    if graph_args and (loss != "mse" or robust_delta > 0 or (mask is not None and not isinstance(mask, str)) or k > 64):
         raise NotImplementedError("graph regularisation is implemented for the plain MSE path, k <= 64")
     # ---- initialisation
     if seed is None:
@@ -187,7 +187,7 @@ def nmf(data, k, tol=1e-4, maxit=100, L1=(0.0, 0.0), L2=(0.0, 0.0), seed=None, m
                           holdout_fraction=float(test_fraction), cv_seed=seed_int & 0x7FFFFFFF,
                           mask_zeros=int(isinstance(mask, str) and mask == "zeros"), nonneg_W=int(nnw), nonneg_H=int(nnh),
                           norm_type=norm_type, solver_mode=0 if solver == "cd" else 1, sort_model=int(sort_model),
-                          precision=_abi.F32 if precision == "fp32" else _abi.F64, cv_patience=int(patience))
+                          precision=_abi.F32 if precision == "fp32" else _abi.F64, cv_patience=int(patience), **graph_args)
         if res["status"] != 0:
             raise _abi.BackendError("GPU CV NMF failed: %s" % res.get("error"))
         misc = dict(iter=res["iter"], converged=res["converged"], loss=res["train_loss"], test_loss=res["test_loss"],
