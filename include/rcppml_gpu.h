@@ -126,6 +126,26 @@ RCPPML_GPU_API void rcppml_gpu_nmf_cv_unified_double(RCPPML_NMF_CV_ARGS);
 RCPPML_GPU_API void rcppml_gpu_nmf_cv_ex(RCPPML_NMF_CV_ARGS, int* sort_model, int* precision, int* cv_patience,
                                          double* train_history, double* test_history);
 
+/* Dense-input NMF.  Replaces reference `rcppml_gpu_nmf_dense_unified_float` (resolved by
+ * inst/include/FactorNet/gpu/bridge_nmf.hpp:544-545; 52 pointers, typedef :101-126): A_data is the m x n column-major
+ * matrix as doubles on the host; W (k x m), H (k x n), d in/out as in the sparse entry.  Semantics: the reference's
+ * STANDARD path (separate RHS -> features -> nnls_batch / cholesky_clip_batch, nmf/fit_cpu.hpp:540-631, :774-881) --
+ * zero start at iteration 0, residual-corrected warm start afterwards -- MSE loss; L1, L2, L21, angular, bounds,
+ * projective, symmetric.  `_double` is build-defined (fp64 compute). */
+#define RCPPML_NMF_DENSE_ARGS                                                                       \
+    const double* A_data, int* m, int* n, int* k, double* W, double* H, double* d, int* max_iter,   \
+        double* tol, double* L1_H, double* L1_W, double* L2_H, double* L2_W, double* L21_H,         \
+        double* L21_W, double* ortho_H, double* ortho_W, double* ub_H, double* ub_W, int* cd_maxit, \
+        int* verbose, int* seed, int* loss_every, int* patience, int* nonneg_W, int* nonneg_H,      \
+        int* loss_type, double* huber_delta, int* irls_max_iter, double* irls_tol, int* norm_type,  \
+        int* gp_dispersion_mode, double* gp_theta_init, double* gp_theta_max, double* gp_theta_min, \
+        double* nb_size_init, double* nb_size_max, double* nb_size_min, double* robust_delta,       \
+        double* tweedie_power, int* projective, int* symmetric, int* solver_mode, double* out_theta,\
+        int* out_theta_len, int* out_iter, int* out_converged, double* out_loss, int* out_status,   \
+        double* out_tol
+RCPPML_GPU_API void rcppml_gpu_nmf_dense_unified_float(RCPPML_NMF_DENSE_ARGS);
+RCPPML_GPU_API void rcppml_gpu_nmf_dense_unified_double(RCPPML_NMF_DENSE_ARGS);
+
 RCPPML_GPU_API void rcppml_gpu_nmf_unified_float(RCPPML_NMF_UNIFIED_ARGS);
 RCPPML_GPU_API void rcppml_gpu_nmf_unified_double(RCPPML_NMF_UNIFIED_ARGS);
 
@@ -342,6 +362,11 @@ RCPPML_GPU_API int rcppml_hip_irls_loss(rcppml_hip_ctx* ctx, int dtype, int loss
                                         const int* row_idx, const void* values, int64_t ncols, const void* W_T,
                                         const void* d, const void* H, const void* theta_row, int k, double loss_param,
                                         double robust_delta, double* out);
+/* Dense-input right-hand sides (reference primitives::rhs<CPU> on a dense A and detail::rhs_transpose,
+ * nmf/fit_cpu.hpp:547-549 / :783): transposed = 0: B (k x n) = F (k x m) A;  1: B (k x m) = F (k x n) A^T.
+ * A column-major m x n on the device; F, B column-major with leading dimension k.  rocBLAS GEMM. */
+RCPPML_GPU_API int rcppml_hip_rhs_dense(rcppml_hip_ctx* ctx, int dtype, const void* A, int64_t m, int64_t n,
+                                        int transposed, const void* F, int k, void* B);
 /* Same decoder on a byte buffer in host memory, into caller-allocated device arrays (layer 2; what the parity tests
  * call).  Format restated from streampress/sparsepress_v2.hpp:897-1090, codec/rans.hpp:128-247, codec/varint.hpp:43-52.
  * rcppml_hip_spz_info parses the 128-byte header only (host).  Both return the out_status codes above. */

@@ -727,6 +727,14 @@ FitResult<S> nmf_fit(const Csc<S>& A, const FitConfig<S>& cfg, S* W_T, S* H, S* 
             if (cfg.L2_H > 0) for (int i = 0; i < k; ++i) G[(size_t)i * k + i] += cfg.L2_H;   // :506
             if (cfg.has_graph_H) apply_graph_reg(G.data(), cfg.graph_H, H, k, cfg.graph_H_lambda);      // :508-509
             apply_L21(G.data(), H, k, (int64_t)n, cfg.L21_H);                                  // :509-510 (current H)
+            if (cfg.unfused) {
+                // :540-631 STANDARD PATH (dense data): B = W_T A, L1 on B (sparsity.hpp:47), nnls_batch / cholesky_clip_batch
+                std::vector<S> B((size_t)k * n);
+                rhs(A, W_T, k, B.data(), threads);
+                if (cfg.L1_H > 0) for (auto& b : B) b -= cfg.L1_H;
+                if (cfg.solver_mode == 1) cholesky_clip_batch(G.data(), B.data(), H, k, n, cfg.nonneg_H, threads);
+                else nnls_batch(G.data(), B.data(), H, k, n, cfg.cd_maxit, cfg.cd_tol, S(0), S(0), cfg.nonneg_H, threads, S(0), iter > 0);
+            } else
             if (cfg.solver_mode == 0)
                 fused_rhs_nnls_sparse(A, W_T, G.data(), H, k, cfg.cd_maxit, cfg.cd_tol, cfg.L1_H,
                                       cfg.nonneg_H, threads, iter > 0, S(0));                // :516-524
@@ -768,6 +776,15 @@ FitResult<S> nmf_fit(const Csc<S>& A, const FitConfig<S>& cfg, S* W_T, S* H, S* 
             if (cfg.L2_W > 0) for (int i = 0; i < k; ++i) G[(size_t)i * k + i] += cfg.L2_W;   // :738
             if (cfg.has_graph_W) apply_graph_reg(G.data(), cfg.graph_W, W_T, k, cfg.graph_W_lambda);    // :740-741
             apply_L21(G.data(), W_T, k, (int64_t)m, cfg.L21_W);                                // :741-745 (current W_T)
+            if (cfg.unfused) {
+                // :774-881 STANDARD PATH: B = H A^T saved BEFORE the features (:786-789), then as on the H side
+                B_sym.assign((size_t)k * m, S(0));
+                rhs(At, H, k, B_sym.data(), threads);
+                std::vector<S> B = B_sym;
+                if (cfg.L1_W > 0) for (auto& b : B) b -= cfg.L1_W;
+                if (cfg.solver_mode == 1) cholesky_clip_batch(G.data(), B.data(), W_T, k, m, cfg.nonneg_W, threads);
+                else nnls_batch(G.data(), B.data(), W_T, k, m, cfg.cd_maxit, cfg.cd_tol, S(0), S(0), cfg.nonneg_W, threads, S(0), iter > 0);
+            } else
             if (cfg.solver_mode == 0)
                 fused_rhs_nnls_sparse(At, H, G.data(), W_T, k, cfg.cd_maxit, cfg.cd_tol, cfg.L1_W,
                                       cfg.nonneg_W, threads, iter > 0, S(0));                // :748-757
@@ -795,7 +812,7 @@ FitResult<S> nmf_fit(const Csc<S>& A, const FitConfig<S>& cfg, S* W_T, S* H, S* 
         } else {
             gram(W_T, k, m, G_wt.data());                                                   // :1734-1735
             S cross;
-            if (cfg.symmetric) {                                                            // :1717-1720 (B_w_saved materialised)
+            if (cfg.symmetric || cfg.unfused) {                                             // :1717-1720 (B_w_saved materialised)
                 cross = 0;
                 for (int f = 0; f < k; ++f) {
                     S rowdot = 0;
@@ -915,7 +932,7 @@ template <class S> static Csc<S> mk(int rows, int cols, const int* p, const int*
         S L21_H, S L21_W, S angular_H, S angular_W, S robust_delta, int projective,                       \
         const int* gH_p, const int* gH_i, const S* gH_x, S gH_lambda, const int* gW_p, const int* gW_i,   \
         const S* gW_x, S gW_lambda, S gp_theta_init, S gp_theta_max, S gamma_phi_init, S gamma_phi_max,   \
-        S gamma_phi_min, int symmetric) {                                                                 \
+        S gamma_phi_min, int symmetric, int unfused) {                                                    \
         FitConfig<S> c;                                                                                   \
         c.k = k; c.max_iter = max_iter; c.tol = tol; c.L1_H = L1_H; c.L1_W = L1_W; c.L2_H = L2_H;         \
         c.L2_W = L2_W; c.ub_H = ub_H; c.ub_W = ub_W; c.cd_maxit = cd_maxit; c.cd_tol = cd_tol;            \
@@ -927,6 +944,7 @@ template <class S> static Csc<S> mk(int rows, int cols, const int* p, const int*
         c.L21_H = L21_H; c.L21_W = L21_W; c.angular_H = angular_H; c.angular_W = angular_W; c.robust_delta = robust_delta; c.projective = projective != 0; \
         c.gp_theta_init = gp_theta_init; c.gp_theta_max = gp_theta_max; c.gamma_phi_init = gamma_phi_init;  \
         c.gamma_phi_max = gamma_phi_max; c.gamma_phi_min = gamma_phi_min; c.symmetric = symmetric != 0;   \
+        c.unfused = unfused != 0;                                                                         \
         if (gH_p) { c.has_graph_H = true; c.graph_H = mk(n, n, gH_p, gH_i, gH_x); c.graph_H_lambda = gH_lambda; } \
         if (gW_p) { c.has_graph_W = true; c.graph_W = mk(m, m, gW_p, gW_i, gW_x); c.graph_W_lambda = gW_lambda; } \
         if (mask_p) { c.has_mask = true; c.mask = mk(m, n, mask_p, mask_i, mask_x); }                     \

@@ -24,7 +24,8 @@ EXPORTED_SYMBOLS = [
     "rcppml_hip_solve_cd", "rcppml_hip_order_columns", "rcppml_hip_solve_chol", "rcppml_hip_row_norms", "rcppml_hip_apply_scaling",
     "rcppml_hip_sumsq", "rcppml_hip_loss_mse", "rcppml_hip_solve_masked", "rcppml_hip_loss_nonzeros",
     "rcppml_hip_solve_irls_nb", "rcppml_hip_nb_size_update", "rcppml_hip_nb_loss", "rcppml_hip_solve_irls", "rcppml_hip_irls_loss", "rcppml_hip_apply_l21", "rcppml_hip_angular_posthoc", "rcppml_hip_solve_cv", "rcppml_hip_cv_test_error", "rcppml_hip_mul_rows", "rcppml_hip_apply_graph_reg", "rcppml_hip_dispersion_update", "rcppml_hip_vec_global", "rcppml_hip_spz_info", "rcppml_hip_spz_decode",
-    "rcppml_sp_read_gpu", "rcppml_sp_free_gpu",
+    "rcppml_sp_read_gpu", "rcppml_sp_free_gpu", "rcppml_hip_rhs_dense", "rcppml_gpu_nmf_dense_unified_float",
+    "rcppml_gpu_nmf_dense_unified_double",
 ]
 
 
@@ -423,6 +424,10 @@ class Context:
     def vec_global(self, dt, stat, x, m):
         _chk(lib().rcppml_hip_vec_global(self._h, C.c_int(dt), C.c_int(stat), _dptr(x), C.c_int64(m)), "vec_global")
 
+    def rhs_dense(self, dt, A, m, n, transposed, F, k, B):
+        _chk(lib().rcppml_hip_rhs_dense(self._h, C.c_int(dt), _dptr(A), C.c_int64(m), C.c_int64(n), C.c_int(transposed), _dptr(F),
+                                        C.c_int(k), _dptr(B)), "rhs_dense")
+
     def spz_decode(self, file_bytes, d_col_ptr, d_row_idx, d_values):
         """file_bytes: uint8 numpy array (host); outputs: device int32 (n+1), int32 (nnz), float64 (nnz)."""
         buf = np.ascontiguousarray(file_bytes, np.uint8)
@@ -467,3 +472,31 @@ def sp_free_gpu(h):
     lib().rcppml_sp_free_gpu(C.byref(a), C.byref(b), C.byref(c), C.byref(st))
     h["col_ptr"], h["row_idx"], h["values"] = a.value, b.value, c.value
     return st.value
+
+
+def nmf_dense(A, k, W_T, H, *, entry="float", max_iter=100, tol=1e-4, L1_H=0.0, L1_W=0.0, L2_H=0.0, L2_W=0.0, L21_H=0.0,
+              L21_W=0.0, ortho_H=0.0, ortho_W=0.0, ub_H=0.0, ub_W=0.0, cd_maxit=100, verbose=0, seed=0, patience=5, nonneg_W=1,
+              nonneg_H=1, loss_type=0, norm_type=0, projective=0, symmetric=0, solver_mode=0, robust_delta=0.0):
+    """Call the dense plugin entry as reference gpu/bridge_nmf.hpp:537-690 does.  A: (m, n) float64 array (any layout: it
+    is handed over column-major).  W_T (m, k), H (n, k) float64, updated IN PLACE.  entry: "float" | "double"."""
+    L = lib()
+    A = np.asfortranarray(A, dtype=np.float64)
+    m, n = A.shape
+    assert W_T.dtype == np.float64 and H.dtype == np.float64 and W_T.flags.c_contiguous and H.flags.c_contiguous
+    assert W_T.shape == (m, k) and H.shape == (n, k)
+    d = np.ones(k, np.float64)
+    theta = np.zeros(max(m, 1), np.float64)
+    out_iter, out_conv, out_status, out_theta_len = C.c_int(0), C.c_int(0), C.c_int(-99), C.c_int(0)
+    out_loss, out_tol = C.c_double(0), C.c_double(0)
+    args = [
+        A.ctypes.data_as(C.POINTER(C.c_double)), _ci(m), _ci(n), _ci(k), _np_ptr(W_T), _np_ptr(H), _np_ptr(d), _ci(max_iter), _cd(tol),
+        _cd(L1_H), _cd(L1_W), _cd(L2_H), _cd(L2_W), _cd(L21_H), _cd(L21_W), _cd(ortho_H), _cd(ortho_W), _cd(ub_H), _cd(ub_W),
+        _ci(cd_maxit), _ci(verbose), _ci(seed), _ci(1), _ci(patience), _ci(nonneg_W), _ci(nonneg_H), _ci(loss_type), _cd(1.0),
+        _ci(5), _cd(1e-4), _ci(norm_type), _ci(2), _cd(0.1), _cd(5.0), _cd(0.0), _cd(10.0), _cd(1e6), _cd(0.01),
+        _cd(robust_delta), _cd(1.5), _ci(projective), _ci(symmetric), _ci(solver_mode), _np_ptr(theta), C.byref(out_theta_len),
+        C.byref(out_iter), C.byref(out_conv), C.byref(out_loss), C.byref(out_status), C.byref(out_tol),
+    ]
+    assert len(args) == 50
+    getattr(L, "rcppml_gpu_nmf_dense_unified_" + entry)(*args)
+    return dict(d=d, iter=out_iter.value, converged=bool(out_conv.value), loss=out_loss.value, tol=out_tol.value,
+                status=out_status.value, error=last_error() if out_status.value != 0 else "")

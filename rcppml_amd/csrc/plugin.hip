@@ -74,6 +74,7 @@ struct FitParams {
     const int* gH_p = nullptr; const int* gH_i = nullptr; const double* gH_x = nullptr; int gH_nnz = 0; double gH_lambda = 0;
     const int* gW_p = nullptr; const int* gW_i = nullptr; const double* gW_x = nullptr; int gW_nnz = 0; double gW_lambda = 0;
     int symmetric = 0;                       // A ~ W diag(d) W^T (A square): only W is solved, H = W_T
+    const double* dense = nullptr;           // dense input (column-major m x n): the unfused standard path of fit_cpu.hpp
     int csc_on_device = 0;                   // col_ptr / row_idx / values are DEVICE pointers (zero-copy entry)
     int projective = 0;                      // H = (diag(d) W_T) A instead of the NNLS half-update (variant_helpers.hpp:308-325)
     int cd_maxit; double cd_tol;
@@ -144,7 +145,10 @@ void fit(FitParams& P) {
 
     // ---- upload A, build and upload A^T (one-time setup, fit_cpu.hpp:237-254)
     DevBuf dAp, dAi, dAx, dTp, dTi, dTx;
-    if (P.csc_on_device) {          // zero-copy: the CSC already lives in device memory (values double)
+    const bool dense = P.dense != nullptr;
+    if (dense) {                    // dense input: A itself (m x n, column-major) in the compute precision; no CSC, no transpose
+        upload_cast<T>(c, P.dense, (size_t)m * n, dAx, s);
+    } else if (P.csc_on_device) {          // zero-copy: the CSC already lives in device memory (values double)
         dAp.borrow(P.col_ptr);
         dAi.borrow(P.row_idx);
         if constexpr (std::is_same<T, double>::value) dAx.borrow(P.values);
@@ -158,10 +162,12 @@ void fit(FitParams& P) {
         upload_cast<T>(c, P.values, (size_t)P.nnz, dAx, s);
     }
     // A^T on the device (stable sort by row index): rcppml_hip_transpose_csc
+    if (!dense) {
     dTp.alloc(((size_t)m + 1) * sizeof(int));
     dTi.alloc((size_t)P.nnz * sizeof(int));
     dTx.alloc((size_t)P.nnz * sizeof(T));
     OPCHK(rcppml_hip_transpose_csc(c, dt, m, n, dAp.as<int>(), dAi.as<int>(), dAx.p, dTp.as<int>(), dTi.as<int>(), dTx.p));
+    }
     const bool has_mask = P.mask_p != nullptr;
     DevBuf dMp, dMi, dMTp, dMTi;
     if (has_mask) {
@@ -203,7 +209,7 @@ void fit(FitParams& P) {
     HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&hloss), 4 * sizeof(double)));
     struct HostFree { double* p; ~HostFree() { (void)hipHostFree(p); } } hf{hloss};
 
-    OPCHK(rcppml_hip_sumsq(c, dt, dAx.p, P.nnz, dtr.as<double>()));       // trAtA, primitives.hpp:100-115
+    OPCHK(rcppml_hip_sumsq(c, dt, dAx.p, dense ? (int64_t)m * n : P.nnz, dtr.as<double>()));       // trAtA, primitives.hpp:100-115
     // CD work order: columns sorted by the sweeps of the previous iteration (results are order-independent)
     DevBuf dswH((size_t)n * sizeof(int)), dswW((size_t)m * sizeof(int)), dordH((size_t)n * sizeof(int)), dordW((size_t)m * sizeof(int));
     const bool use_order = P.solver_mode == 0 && !has_mask && P.loss_type == 0 && P.cd_tol > 0 && !getenv("RCPPML_GPU_NO_ORDER");
@@ -231,14 +237,27 @@ void fit(FitParams& P) {
     double final_tol = 0, train_loss = 0, last_loss = 0;
 
     // All device work of one ALS iteration, enqueued on the fit's stream (ends with the loss terms in dloss).
+    // B = F * A (columns of A) / B = F * A^T (rows of A): CSC gather kernels, or GEMMs for a dense A
+    auto rhs_fwd = [&](const void* F, void* B) {
+        if (dense) OPCHK(rcppml_hip_rhs_dense(c, dt, dAx.p, m, n, 0, F, k, B));
+        else OPCHK(rcppml_hip_rhs(c, dt, dAp.as<int>(), dAi.as<int>(), dAx.p, n, F, k, B));
+    };
+    auto rhs_bwd = [&](const void* F, void* B) {
+        if (dense) OPCHK(rcppml_hip_rhs_dense(c, dt, dAx.p, m, n, 1, F, k, B));
+        else OPCHK(rcppml_hip_rhs(c, dt, dTp.as<int>(), dTi.as<int>(), dTx.p, m, F, k, B));
+    };
     auto enqueue_iteration = [&](int iter) {
         const int warm = iter > 0 ? 1 : 0;
+        // dense input runs the reference's STANDARD path (fit_cpu.hpp:540-631, :774-881): nnls_batch starts from zero at
+        // iteration 0 and from the residual-corrected previous solution afterwards; the sparse fused path starts
+        // iteration 0 from the initial factor without correction
+        const int zinit = (dense && !warm) ? 1 : 0;
         // ================= H half-update (fit_cpu.hpp:486-645)
         if (P.symmetric) {
             // :474-477 SYMMETRIC_SKIP: H is not updated and not scaled; it is set to W_T after the W update
         } else if (P.projective) {                                                             // :462-472
             OPCHK(rcppml_hip_mul_rows(c, dt, dW.p, k, m, dd.p, dWd.p));
-            OPCHK(rcppml_hip_rhs(c, dt, dAp.as<int>(), dAi.as<int>(), dAx.p, n, dWd.p, k, dH.p));
+            rhs_fwd(dWd.p, dH.p);
         } else if (is_nb) {                                                                    // :565-606 (G: eps only)
             OPCHK(rcppml_hip_gram(c, dt, dW.p, k, m, eps, 0.0, dG.p));
             OPCHK(rcppml_hip_solve_irls(c, dt, P.loss_type, dAp.as<int>(), dAi.as<int>(), dAx.p, n, dW.p, dG.p, dH.p, k, P.L1_H,
@@ -255,11 +274,11 @@ void fit(FitParams& P) {
             OPCHK(rcppml_hip_gram(c, dt, dW.p, k, m, eps, P.L2_H, dG.p));              // :491,506
             if (graph_H) OPCHK(rcppml_hip_apply_graph_reg(c, dt, dG.p, dGHp.as<int>(), dGHi.as<int>(), dGHx.p, dH.p, k, n, P.gH_lambda));   // :508-509
             if (P.L21_H > 0) OPCHK(rcppml_hip_apply_l21(c, dt, dG.p, dH.p, k, n, P.L21_H));   // :509-510 (current H)
-            OPCHK(rcppml_hip_rhs(c, dt, dAp.as<int>(), dAi.as<int>(), dAx.p, n, dW.p, k, dBh.p));
+            rhs_fwd(dW.p, dBh.p);
             if (P.solver_mode == 0) {                                                   // :516-524
                 const bool ord = use_order && iter > 0 && n >= 32768;   // pays once waves outnumber the chip's slots
                 if (ord) OPCHK(rcppml_hip_order_columns(c, dswH.as<int>(), n, dordH.as<int>()));
-                OPCHK(rcppml_hip_solve_cd(c, dt, dG.p, dBh.p, dH.p, k, n, P.L1_H > 0 ? P.L1_H : 0.0, warm, 0, 0.0, 0.0,
+                OPCHK(rcppml_hip_solve_cd(c, dt, dG.p, dBh.p, dH.p, k, n, P.L1_H > 0 ? P.L1_H : 0.0, warm, zinit, 0.0, 0.0,
                                           P.nonneg_H, P.cd_maxit, P.cd_tol, 0.0, P.ub_H, RCPPML_CD_AUTO,
                                           use_order ? dswH.as<int>() : nullptr, ord ? dordH.as<int>() : nullptr));
             }
@@ -281,7 +300,7 @@ void fit(FitParams& P) {
             else HIPCHK(hipMemcpyAsync(dG.p, dGs.p, (size_t)k * k * sizeof(T), hipMemcpyDeviceToDevice, s));
             if (graph_W) OPCHK(rcppml_hip_apply_graph_reg(c, dt, dG.p, dGWp.as<int>(), dGWi.as<int>(), dGWx.p, dW.p, k, m, P.gW_lambda));
             if (P.L21_W > 0) OPCHK(rcppml_hip_apply_l21(c, dt, dG.p, dW.p, k, m, P.L21_W));
-            OPCHK(rcppml_hip_rhs(c, dt, dAp.as<int>(), dAi.as<int>(), dAx.p, n, dW.p, k, dBw.p));   // :665
+            rhs_fwd(dW.p, dBw.p);                                                       // :665
             if (P.solver_mode == 0)
                 OPCHK(rcppml_hip_solve_cd(c, dt, dG.p, dBw.p, dW.p, k, m, P.L1_W > 0 ? P.L1_W : 0.0, warm, warm ? 0 : 1, 0.0, 0.0,
                                           P.nonneg_W, P.cd_maxit, P.cd_tol, 0.0, P.ub_W, RCPPML_CD_AUTO, nullptr, nullptr));   // :684-692
@@ -303,11 +322,11 @@ void fit(FitParams& P) {
             else HIPCHK(hipMemcpyAsync(dG.p, dGs.p, (size_t)k * k * sizeof(T), hipMemcpyDeviceToDevice, s));
             if (graph_W) OPCHK(rcppml_hip_apply_graph_reg(c, dt, dG.p, dGWp.as<int>(), dGWi.as<int>(), dGWx.p, dW.p, k, m, P.gW_lambda));   // :740-741
             if (P.L21_W > 0) OPCHK(rcppml_hip_apply_l21(c, dt, dG.p, dW.p, k, m, P.L21_W));   // :741-745 (current W_T)
-            OPCHK(rcppml_hip_rhs(c, dt, dTp.as<int>(), dTi.as<int>(), dTx.p, m, dH.p, k, dBw.p));
+            rhs_bwd(dH.p, dBw.p);
             if (P.solver_mode == 0) {
                 const bool ord = use_order && iter > 0 && m >= 32768;
                 if (ord) OPCHK(rcppml_hip_order_columns(c, dswW.as<int>(), m, dordW.as<int>()));
-                OPCHK(rcppml_hip_solve_cd(c, dt, dG.p, dBw.p, dW.p, k, m, P.L1_W > 0 ? P.L1_W : 0.0, warm, 0, 0.0, 0.0,
+                OPCHK(rcppml_hip_solve_cd(c, dt, dG.p, dBw.p, dW.p, k, m, P.L1_W > 0 ? P.L1_W : 0.0, warm, zinit, 0.0, 0.0,
                                           P.nonneg_W, P.cd_maxit, P.cd_tol, 0.0, P.ub_W, RCPPML_CD_AUTO,
                                           use_order ? dswW.as<int>() : nullptr, ord ? dordW.as<int>() : nullptr));
             }
@@ -347,7 +366,7 @@ void fit(FitParams& P) {
     // sizes settled), so it is captured once into a hipGraph and replayed: small inputs (hawaiibirds: ~27 launches for
     // < 50 us of GPU work) are bound by the host's launch rate, not by the kernels.  Plain MSE path only; any capture
     // failure falls back to eager launches.  RCPPML_GPU_NO_GRAPH=1 disables.
-    const bool graph_ok = !is_nb && !has_mask && !getenv("RCPPML_GPU_NO_GRAPH");
+    const bool graph_ok = !is_nb && !has_mask && !dense && !getenv("RCPPML_GPU_NO_GRAPH");   // (rocBLAS calls are not captured)
     struct GraphHolder {
         hipGraph_t g = nullptr; hipGraphExec_t e = nullptr; bool failed = false;
         ~GraphHolder() { if (e) (void)hipGraphExecDestroy(e); if (g) (void)hipGraphDestroy(g); }
@@ -512,6 +531,12 @@ void nmf_entry(RCPPML_NMF_UNIFIED_ARGS, const int* mask_p, const int* mask_i, do
     }
 }
 
+#define RCPPML_NMF_DENSE_PASS                                                                               \
+    A_data, m, n, k, W, H, d, max_iter, tol, L1_H, L1_W, L2_H, L2_W, L21_H, L21_W, ortho_H, ortho_W, ub_H, ub_W, cd_maxit,    \
+        verbose, seed, loss_every, patience, nonneg_W, nonneg_H, loss_type, huber_delta, irls_max_iter, irls_tol, norm_type,   \
+        gp_dispersion_mode, gp_theta_init, gp_theta_max, gp_theta_min, nb_size_init, nb_size_max, nb_size_min, robust_delta,   \
+        tweedie_power, projective, symmetric, solver_mode, out_theta, out_theta_len, out_iter, out_converged, out_loss,        \
+        out_status, out_tol
 #define RCPPML_NMF_UNIFIED_PASS                                                                              \
     col_ptr, row_idx, values, m, n, nnz, k, W, H, d, max_iter, tol, L1_H, L1_W, L2_H, L2_W, L21_H, L21_W,    \
         ortho_H, ortho_W, ub_H, ub_W, cd_maxit, verbose, seed, loss_every, patience, nonneg_W, nonneg_H,     \
@@ -811,6 +836,62 @@ extern "C" void rcppml_gpu_nmf_zerocopy_double(double* d_col_ptr_addr, double* d
         rcppml_err() = "unknown error";
         *out_status = -1;
     }
+}
+
+// Dense-input NMF (reference bridge: gpu/bridge_nmf.hpp:101-126, 537-690; CUDA side src/gpu_bridge_nmf.cu).  A is an m x n
+// column-major double array on the host; the fit is the reference's STANDARD (unfused) path with GEMM right-hand sides.
+namespace {
+void nmf_dense_entry(RCPPML_NMF_DENSE_ARGS, int precision) {
+    try {
+        rcppml_err().clear();
+        *out_status = -1;
+        (void)seed; (void)loss_every; (void)huber_delta; (void)irls_max_iter; (void)irls_tol; (void)gp_dispersion_mode;
+        (void)gp_theta_init; (void)gp_theta_max; (void)gp_theta_min; (void)nb_size_init; (void)nb_size_max; (void)nb_size_min;
+        (void)tweedie_power; (void)out_theta;
+        if (*loss_type != 0 || *robust_delta > 0) throw std::runtime_error("dense entry: only the MSE loss is implemented");
+        if (*projective != 0 && *symmetric != 0) throw std::runtime_error("projective and symmetric cannot both be true");
+        if (*symmetric != 0 && *m != *n) throw std::runtime_error("symmetric NMF needs a square matrix");
+        if (*solver_mode != 0 && *solver_mode != 1) throw std::runtime_error("solver_mode must be 0 (CD) or 1 (Cholesky+clip)");
+        if (*k < 1 || *k > 128) throw std::runtime_error("k must be in [1,128]");
+        if ((*ortho_H != 0 || *ortho_W != 0) && *k > 64) throw std::runtime_error("angular penalty: k must be <= 64");
+        if (*L21_H < 0 || *L21_W < 0 || *ortho_H < 0 || *ortho_W < 0) throw std::runtime_error("negative L21 / angular penalty");
+        if (*m < 1 || *n < 1) throw std::runtime_error("empty matrix");
+        if (*norm_type < 0 || *norm_type > 2) throw std::runtime_error("bad norm_type");
+        FitParams P;
+        P.m = *m; P.n = *n; P.k = *k; P.nnz = (int64_t)*m * *n;
+        P.dense = A_data;
+        P.col_ptr = nullptr; P.row_idx = nullptr; P.values = nullptr;
+        P.W = W; P.H = H; P.d = d;
+        P.max_iter = *max_iter; P.tol = *tol;
+        P.L1_H = *L1_H; P.L1_W = *L1_W; P.L2_H = *L2_H; P.L2_W = *L2_W; P.ub_H = *ub_H; P.ub_W = *ub_W;
+        P.L21_H = *L21_H; P.L21_W = *L21_W; P.angular_H = *ortho_H; P.angular_W = *ortho_W;
+        P.cd_maxit = *cd_maxit > 0 ? *cd_maxit : 10;
+        P.cd_tol = 1e-8;
+        P.verbose = *verbose; P.patience = *patience; P.nonneg_W = *nonneg_W; P.nonneg_H = *nonneg_H;
+        P.norm_type = *norm_type; P.solver_mode = *solver_mode;
+        P.projective = *projective != 0 ? 1 : 0; P.symmetric = *symmetric != 0 ? 1 : 0;
+        P.mask_p = nullptr; P.mask_i = nullptr; P.sort_model = env_sort(); P.loss_history = nullptr;
+        if (precision == RCPPML_F64) fit<double>(P); else fit<float>(P);
+        if (out_theta_len) *out_theta_len = 0;
+        *out_iter = P.out_iter; *out_converged = P.out_converged; *out_loss = P.out_loss; *out_tol = P.out_tol;
+        *out_status = 0;
+    } catch (const std::exception& e) {
+        rcppml_err() = e.what();
+        if (getenv("RCPPML_GPU_VERBOSE")) fprintf(stderr, "[rcppml_gpu] dense NMF error: %s\n", e.what());
+        *out_status = -1;
+    } catch (...) {
+        rcppml_err() = "unknown error";
+        *out_status = -1;
+    }
+}
+}  // namespace
+extern "C" void rcppml_gpu_nmf_dense_unified_float(RCPPML_NMF_DENSE_ARGS) {
+    const char* e = getenv("RCPPML_GPU_PRECISION");
+    nmf_dense_entry(RCPPML_NMF_DENSE_PASS, (e && !strcmp(e, "fp64")) ? RCPPML_F64 : RCPPML_F32);
+}
+extern "C" void rcppml_gpu_nmf_dense_unified_double(RCPPML_NMF_DENSE_ARGS) {
+    const char* e = getenv("RCPPML_GPU_PRECISION");
+    nmf_dense_entry(RCPPML_NMF_DENSE_PASS, (e && !strcmp(e, "fp32")) ? RCPPML_F32 : RCPPML_F64);
 }
 
 extern "C" void rcppml_gpu_nmf_unified_float(RCPPML_NMF_UNIFIED_ARGS) {

@@ -112,6 +112,7 @@ def nmf(data, k, tol=1e-4, maxit=100, L1=(0.0, 0.0), L2=(0.0, 0.0), seed=None, m
             raise NotImplementedError("cross-validation is implemented for loss='mse' without an explicit mask")
     if resource != "gpu":
         raise ValueError("rcppml_amd has no CPU path; resource must be 'gpu'")
+    dense_in = isinstance(data, np.ndarray) and data.ndim == 2        # a base R matrix: the reference's dense path
     A = _as_csc(data)
     m, n = A.shape
     if symmetric and m != n:
@@ -195,6 +196,20 @@ def nmf(data, k, tol=1e-4, maxit=100, L1=(0.0, 0.0), L2=(0.0, 0.0), seed=None, m
                     test_loss_history=res.get("test_history"), solver=solver, solver_mode=0 if solver == "cd" else 1,
                     L1=(L1w, L1h), L2=(L2w, L2h), seed=seed_int, precision=precision, resource="gpu", loss_type=loss,
                     test_fraction=float(test_fraction))
+        return NMFModel(w=W_T.copy(), d=res["d"], h=H.T.copy(), misc=misc)
+    if dense_in and loss == "mse" and robust_delta == 0 and mask_arg is None and not graph_args and sort_model:
+        # dense input -> rcppml_gpu_nmf_dense_unified_* (GEMM right-hand sides, the reference's unfused update order)
+        res = _abi.nmf_dense(np.asarray(data, np.float64), k, W_T, H, entry="float" if precision == "fp32" else "double",
+                             max_iter=int(maxit), tol=float(tol), L1_H=L1h, L1_W=L1w, L2_H=L2h, L2_W=L2w, L21_H=L21h, L21_W=L21w,
+                             ortho_H=angh, ortho_W=angw, ub_H=ubh, ub_W=ubw, cd_maxit=int(cd_maxit), verbose=int(verbose),
+                             seed=seed_int & 0x7FFFFFFF, patience=int(patience), nonneg_W=int(nnw), nonneg_H=int(nnh),
+                             norm_type=norm_type, projective=int(bool(projective)), symmetric=int(bool(symmetric)),
+                             solver_mode=0 if solver == "cd" else 1)
+        if res["status"] != 0:
+            raise _abi.BackendError("GPU dense NMF failed: %s" % res.get("error"))
+        misc = dict(tol=res["tol"], iter=res["iter"], loss=res["loss"], converged=res["converged"], solver=solver,
+                    solver_mode=0 if solver == "cd" else 1, L1=(L1w, L1h), L2=(L2w, L2h), seed=seed_int, precision=precision,
+                    resource="gpu", loss_type=loss, input="dense")
         return NMFModel(w=W_T.copy(), d=res["d"], h=H.T.copy(), misc=misc)
     res = _abi.nmf_unified(A.p, A.i, A.x, m, n, k, W_T, H, entry="ex", max_iter=int(maxit), tol=float(tol), L1_H=L1h,
                            L1_W=L1w, L2_H=L2h, L2_W=L2w, L21_H=L21h, L21_W=L21w, ortho_H=angh, ortho_W=angw, ub_H=ubh, ub_W=ubw, cd_maxit=int(cd_maxit), verbose=int(verbose),

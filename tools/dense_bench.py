@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""tools/dense_bench.py -- dense-input NMF through the plugin's dense entry (host buffers in and out), fp32, k = 64:
+ms per ALS iteration from two fits of different length (setup / PCIe amortised out), and the GEMM share measured with
+the device-level op.  Prints one JSON line."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+from rcppml_amd import _abi  # noqa: E402
+
+m, n, k = 8192, 32768, 64
+rng = np.random.default_rng(0)
+M = (rng.uniform(0, 1, (m, 8)).astype(np.float32) @ rng.uniform(0, 1, (8, n)).astype(np.float32)).astype(np.float64)
+W0 = rng.uniform(0, 1, (m, k)); H0 = rng.uniform(0, 1, (n, k))
+
+
+def fit(iters):
+    W, H = W0.copy(), H0.copy()
+    t0 = time.perf_counter()
+    r = _abi.nmf_dense(M, k, W, H, entry="float", max_iter=iters, tol=0.0)
+    assert r["status"] == 0, r["error"]
+    return time.perf_counter() - t0, r["loss"]
+
+
+fit(2)
+t_a, _ = fit(3)
+t_b, loss = fit(13)
+per_iter = (t_b - t_a) / 10
+ctx = _abi.Context(0)
+dA = torch.from_numpy(np.asfortranarray(M.astype(np.float32)).T.copy()).cuda()
+F = torch.rand((m, k), device="cuda"); B = torch.zeros((n, k), device="cuda")
+F2 = torch.rand((n, k), device="cuda"); B2 = torch.zeros((m, k), device="cuda")
+for _ in range(3):
+    ctx.rhs_dense(_abi.F32, dA, m, n, 0, F, k, B); ctx.rhs_dense(_abi.F32, dA, m, n, 1, F2, k, B2)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(10):
+    ctx.rhs_dense(_abi.F32, dA, m, n, 0, F, k, B); ctx.rhs_dense(_abi.F32, dA, m, n, 1, F2, k, B2)
+ctx.sync(); torch.cuda.synchronize()
+gemm = (time.perf_counter() - t0) / 10
+flops = 2 * 2.0 * m * n * k
+print(json.dumps(dict(m=m, n=n, k=k, dtype="f32", ms_per_iteration=per_iter * 1e3, setup_plus_3_iters_s=t_a, final_loss=loss,
+                      gemm_pair_ms=gemm * 1e3, gemm_tflops=flops / gemm / 1e12, gemm_GBps_of_A=2 * 4.0 * m * n / gemm / 1e9,
+                      cols_per_s=(m + n) / per_iter)))
