@@ -16,7 +16,8 @@
 
 namespace rk {
 
-constexpr int DENSE_KC = 32;          // reduction indices per chunk
+constexpr int DENSE_KC = 32;          // reduction indices per chunk (forward)
+constexpr int DENSE_KC_BWD = 16;      // ... (backward)
 
 // ---- forward: one wavefront = 32 output columns j (lane & 31), the two lane halves take rows i0 + 16 h + s (s = 0..15).
 // Block = 4 waves = 128 consecutive columns sharing the F chunk (32 rows x k, contiguous in memory) through LDS; the
@@ -99,7 +100,8 @@ template <int RT>
 __global__ __launch_bounds__(256) void dense_rhs_bwd_f32(const float* __restrict__ A, int64_t m, int64_t n,
                                                          const float* __restrict__ F, int k, int64_t jchunk,
                                                          float* __restrict__ part) {
-    __shared__ __attribute__((aligned(16))) float Fs[2][DENSE_KC * 32 * RT];
+    constexpr int KCB = DENSE_KC_BWD;              // 16 columns j per chunk: 32 + 32 VGPRs of A in flight -> two waves per SIMD
+    __shared__ __attribute__((aligned(16))) float Fs[2][KCB * 32 * RT];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, c = lane & 31, half = lane >> 5;
     const int64_t i0 = ((int64_t)blockIdx.x * 4 + wave) * 128 + 4 * c;            // this lane's rows i0 .. i0+3
     const int64_t jbeg = (int64_t)blockIdx.y * jchunk, jend = min(n, jbeg + jchunk);
@@ -111,9 +113,9 @@ __global__ __launch_bounds__(256) void dense_rhs_bwd_f32(const float* __restrict
         for (int e = 0; e < 4; ++e)
 #pragma unroll
             for (int v = 0; v < 16; ++v) acc[r][e][v] = 0.f;
-    auto load_a = [&](int64_t j0, float4 (&a)[16]) {            // step s: column j0 + 2 s + half
+    auto load_a = [&](int64_t j0, float4 (&a)[KCB / 2]) {            // step s: column j0 + 2 s + half
 #pragma unroll
-        for (int s = 0; s < 16; ++s) {
+        for (int s = 0; s < KCB / 2; ++s) {
             const int64_t j = j0 + 2 * s + half;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (j < jend) {
@@ -125,22 +127,22 @@ __global__ __launch_bounds__(256) void dense_rhs_bwd_f32(const float* __restrict
         }
     };
     auto stage_f = [&](int64_t j0, int buf) {
-        for (int t = threadIdx.x; t < DENSE_KC * 32 * RT; t += 256) {
+        for (int t = threadIdx.x; t < KCB * 32 * RT; t += 256) {
             const int row = t / (32 * RT), f = t % (32 * RT);
             Fs[buf][t] = (f < k && j0 + row < jend) ? F[(j0 + row) * k + f] : 0.f;
         }
     };
-    float4 a[16], an[16];
+    float4 a[KCB / 2], an[KCB / 2];
     load_a(jbeg, a);
     stage_f(jbeg, 0);
     __syncthreads();
     int buf = 0;
-    for (int64_t j0 = jbeg; j0 < jend; j0 += DENSE_KC) {
-        const bool more = j0 + DENSE_KC < jend;
-        if (more) { load_a(j0 + DENSE_KC, an); stage_f(j0 + DENSE_KC, buf ^ 1); }
+    for (int64_t j0 = jbeg; j0 < jend; j0 += KCB) {
+        const bool more = j0 + KCB < jend;
+        if (more) { load_a(j0 + KCB, an); stage_f(j0 + KCB, buf ^ 1); }
         const float* fs = Fs[buf] + half * (32 * RT) + c;
 #pragma unroll
-        for (int s = 0; s < 16; ++s)
+        for (int s = 0; s < KCB / 2; ++s)
 #pragma unroll
             for (int r = 0; r < RT; ++r) {
                 const float fv = fs[(2 * s) * (32 * RT) + 32 * r];
@@ -152,7 +154,7 @@ __global__ __launch_bounds__(256) void dense_rhs_bwd_f32(const float* __restrict
         __syncthreads();
         if (more) {
 #pragma unroll
-            for (int s = 0; s < 16; ++s) a[s] = an[s];
+            for (int s = 0; s < KCB / 2; ++s) a[s] = an[s];
         }
         buf ^= 1;
     }

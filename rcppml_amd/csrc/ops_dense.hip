@@ -62,11 +62,11 @@ extern "C" int rcppml_hip_rhs_dense(rcppml_hip_ctx* c, int dtype, const void* A,
             } else {
                 // split the reduction over j so that about 2 waves per SIMD are in flight; slices are multiples of the chunk
                 const int64_t row_blocks = (m + 511) / 512;
-                int64_t slices = (2048 + row_blocks * 4 - 1) / (row_blocks * 4);
-                const int64_t chunks = (n + rk::DENSE_KC - 1) / rk::DENSE_KC;
+                int64_t slices = (4096 + row_blocks * 4 - 1) / (row_blocks * 4);
+                const int64_t chunks = (n + rk::DENSE_KC_BWD - 1) / rk::DENSE_KC_BWD;
                 if (slices > chunks) slices = chunks;
                 if (slices < 1) slices = 1;
-                const int64_t jchunk = (chunks + slices - 1) / slices * rk::DENSE_KC;
+                const int64_t jchunk = (chunks + slices - 1) / slices * rk::DENSE_KC_BWD;
                 slices = (n + jchunk - 1) / jchunk;
                 float* part = slices == 1 ? Bf : static_cast<float*>(c->scratch(WS_GRAPH, (size_t)slices * k * m * sizeof(float)));
                 const dim3 grid((unsigned)row_blocks, (unsigned)slices);

@@ -29,9 +29,12 @@ def fit(iters):
 
 
 fit(2)
-t_a, _ = fit(3)
-t_b, loss = fit(13)
-per_iter = (t_b - t_a) / 10
+diffs = []
+for _ in range(3):                       # setup (2 GB over PCIe + casts) dominates a single fit: difference long and short fits
+    t_a, _ = fit(3)
+    t_b, loss = fit(43)
+    diffs.append((t_b - t_a) / 40)
+per_iter = float(np.median(diffs))
 ctx = _abi.Context(0)
 dA = torch.from_numpy(np.asfortranarray(M.astype(np.float32)).T.copy()).cuda()
 F = torch.rand((m, k), device="cuda"); B = torch.zeros((n, k), device="cuda")
