@@ -152,6 +152,13 @@ static void solve_cd_impl(rcppml_hip_ctx* c, const T* G, const T* B, T* X, int k
         else if (e && !strcmp(e, "mfma")) variant = RCPPML_CD_MFMA;
         else if (e && !strcmp(e, "mfma16")) variant = RCPPML_CD_MFMA16;
         else variant = (std::is_same<T, float>::value || k <= 64) ? RCPPML_CD_MFMA : RCPPML_CD_GROUP;
+        // fp32: 32-column tiles leave SIMDs idle when there are fewer tiles than SIMDs (C2's W side: 20 000 columns =
+        // 625 tiles on 1024 SIMDs); 16-column tiles double the wavefronts there (RCPPML_GPU_CD_SMALL16=0 disables)
+        if (variant == RCPPML_CD_MFMA && std::is_same<T, float>::value && k <= 64 && !e) {
+            static int small16 = -1;
+            if (small16 < 0) { const char* s16 = getenv("RCPPML_GPU_CD_SMALL16"); small16 = (s16 && !strcmp(s16, "0")) ? 0 : 1; }
+            if (small16 && (ncols + 31) / 32 < (int64_t)4 * c->num_cu) variant = RCPPML_CD_MFMA16;
+        }
     }
     if (variant == RCPPML_CD_MFMA && !std::is_same<T, float>::value) variant = k <= 64 ? RCPPML_CD_MFMA16 : RCPPML_CD_GROUP;
     if (variant == RCPPML_CD_MFMA16 && k > 64) variant = std::is_same<T, float>::value ? RCPPML_CD_MFMA : RCPPML_CD_GROUP;
