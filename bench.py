@@ -200,13 +200,34 @@ def main():
         cd_peak = 157.3 if args.dtype == "f32" else 78.6
         roof_cd = None
         if args.solver == "cd" and work["cd_columns"] > 0:
+            # the two launches run different kernels at the default sizes (32-column MFMA tiles for H, 16-column tiles for
+            # the W side, which has fewer tiles than SIMDs): `roofline` is the H-side kernel, the longer of the two; the
+            # counted column-sweeps are split between the sides in the proportion of the last iteration's per-column sweeps
+            share_h = ms_sh / max(ms_sh + ms_sw, 1e-12)
+            try:
+                sw_h = float(st.ops._order["H"]["sweeps"].sum().item())
+                sw_w = float(st.ops._order["W"]["sweeps"].sum().item())
+                if sw_h + sw_w > 0:
+                    share_h = sw_h / (sw_h + sw_w)
+            except Exception:
+                pass
+            mfma = args.dtype == "f32" and k <= 64 and args.variant == "auto"
+            flops_h = 2.0 * k * k * work["cd_column_sweeps"] * share_h / max(cnt_sh, 1)
+            flops_w = 2.0 * k * k * work["cd_column_sweeps"] * (1.0 - share_h) / max(cnt_sw, 1)
+            s_h, s_w = ms_sh / max(cnt_sh, 1) * 1e-3, ms_sw / max(cnt_sw, 1) * 1e-3
+            tf_h, tf_w = flops_h / max(s_h, 1e-12) / 1e12, flops_w / max(s_w, 1e-12) / 1e12
             tf = cd_flops / max(cd_s, 1e-12) / 1e12
-            roof_cd = {"bound": "mfma" if (args.dtype == "f32" and k <= 64 and args.variant == "auto") else "valu",
-                       "kernel": "cd_mfma_kernel / cd_group_kernel (coordinate-descent NNLS, both half-updates)",
-                       "achieved": tf, "peak": cd_peak, "unit": "TFLOP/s", "frac": tf / cd_peak, "traffic": None,
-                       "algorithmic_flops_per_launch": cd_flops, "avg_launch_ms": cd_s * 1e3,
+            roof_cd = {"bound": "mfma" if mfma else "valu",
+                       "kernel": ("cd_mfma_kernel (coordinate-descent NNLS on 32-column MFMA tiles, H half-update)" if mfma
+                                  else "coordinate-descent NNLS kernel, H half-update"),
+                       "achieved": tf_h, "peak": cd_peak, "unit": "TFLOP/s", "frac": tf_h / cd_peak, "traffic": None,
+                       "algorithmic_flops_per_launch": flops_h, "avg_launch_ms": s_h * 1e3,
                        "mean_sweeps_per_column": work["cd_column_sweeps"] / work["cd_columns"],
-                       "solve_H_ms": ms_sh / max(cnt_sh, 1), "solve_W_ms": ms_sw / max(cnt_sw, 1)}
+                       "solve_H_ms": s_h * 1e3, "solve_W_ms": s_w * 1e3,
+                       "w_side": {"kernel": "cd_mfma64_kernel<float> (16-column MFMA tiles)" if mfma else "same kernel",
+                                  "achieved": tf_w, "frac": tf_w / cd_peak, "avg_launch_ms": s_w * 1e3,
+                                  "algorithmic_flops_per_launch": flops_w},
+                       "both_sides": {"achieved": tf, "frac": tf / cd_peak, "avg_launch_ms": cd_s * 1e3}}
         cd_dominant = roof_cd is not None and (ms_sh + ms_sw) > (ms_h + ms_w)
         # HBM/fabric bytes per launch from the committed rocprofv3 PMC passes of this same command (FETCH_SIZE x2 per the
         # gfx950 correction + WRITE_SIZE, profiles/summarize.py); only meaningful for the default workload

@@ -57,4 +57,19 @@ with open(os.path.join(dst, tag + "_summary.md"), "w") as f:
         r = v["resources"]
         f.write("| `%s` | %.0f | %.0f | %.3e | %s | %s | %s |\n" % (k[:70], v["fetch_size_kib_avg"], v["write_size_kib_avg"],
                                                               v["hbm_bytes_per_launch"], r.get("vgpr"), r.get("sgpr"), r.get("lds")))
+# the --stats averages include the warm-up launches (iteration 0 runs every column to cd_maxit); bench.py times the last
+# `steps` iterations only, so give the kernel-trace average over exactly those launches as well
+trace = os.path.join(src, "trace", "trace_kernel_trace.csv")
+if os.path.exists(trace):
+    by = collections.defaultdict(list)
+    for r in csv.DictReader(open(trace)):
+        if "rk::cd_mfma" in r["Kernel_Name"] and "prep" not in r["Kernel_Name"] or "rk::rhs_stage" in r["Kernel_Name"]:
+            by[r["Kernel_Name"]].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+    with open(os.path.join(dst, tag + "_summary.md"), "a") as f:
+        f.write("\nTimed launches only (the last 10 iterations of the 13; from the kernel trace):\n\n| kernel | launches | avg us (all) | avg us (timed) |\n|---|---|---|---|\n")
+        for k, v in by.items():
+            v.sort()
+            d = [x[1] for x in v]
+            nt = 20 if "rhs_stage" in k else 10
+            f.write("| `%s` | %d | %.1f | %.1f |\n" % (k[:70], len(d), sum(d) / len(d) / 1e3, sum(d[-nt:]) / nt / 1e3))
 print(open(os.path.join(dst, tag + "_summary.md")).read())
