@@ -37,7 +37,7 @@ class AlsConfig:
     nonneg_H: bool = True
     norm_type: int = 0          # 0 = L1, 1 = L2, 2 = none
     solver_mode: int = 0        # 0 = CD, 1 = Cholesky + clip
-    cd_variant: int = 0         # 0 = auto (lane-group), 1 = lane (SGPR-fed), 2 = wave, 5 = lane-group
+    cd_variant: int = 0         # 0 = auto (fp32: MFMA tiles, fp64 k <= 64: 16-column MFMA tiles, else lane-group), 1 = lane, 2 = wave, 5 = lane-group
     order_columns: bool = True  # schedule CD columns by the sweep counts of the previous iteration
 
 
