@@ -53,26 +53,36 @@ __global__ __launch_bounds__(256) void dense_rhs_fwd_f32(const float* __restrict
             for (int s = 0; s < 16; ++s) a[s] = (jok && base + s < iend) ? acol[base + s] : 0.f;
         }
     };
-    auto stage_f = [&](int64_t i0, int buf) {        // rows i0 .. i0+31 of F^T = 32 k contiguous floats, padded to 32 RT per row
-        for (int t = threadIdx.x; t < DENSE_KC * 32 * RT; t += 256) {
-            const int row = t / (32 * RT), f = t % (32 * RT);
-            Fs[buf][t] = (f < k && i0 + row < iend) ? F[(i0 + row) * k + f] : 0.f;
+    // rows i0 .. i0+31 of F^T (32 k contiguous floats, padded to 32 RT per row): fetched into registers while the MFMAs of
+    // the current chunk run and parked in LDS after them, so their latency is never waited for
+    constexpr int FPT = DENSE_KC * 32 * RT / 256;
+    auto fetch_f = [&](int64_t i0, float (&fr)[FPT]) {
+#pragma unroll
+        for (int q = 0; q < FPT; ++q) {
+            const int t = threadIdx.x + 256 * q, row = t / (32 * RT), f = t % (32 * RT);
+            fr[q] = (f < k && i0 + row < iend) ? F[(i0 + row) * k + f] : 0.f;
         }
     };
-    float a[16], an[16];
+    auto park_f = [&](const float (&fr)[FPT], int buf) {
+#pragma unroll
+        for (int q = 0; q < FPT; ++q) Fs[buf][threadIdx.x + 256 * q] = fr[q];
+    };
+    float a[16], an[16], fr[FPT];
     load_a(ibeg, a);
-    stage_f(ibeg, 0);
+    fetch_f(ibeg, fr);
+    park_f(fr, 0);
     __syncthreads();
     int buf = 0;
     for (int64_t i0 = ibeg; i0 < iend; i0 += DENSE_KC) {
         const bool more = i0 + DENSE_KC < iend;
-        if (more) { load_a(i0 + DENSE_KC, an); stage_f(i0 + DENSE_KC, buf ^ 1); }     // next chunk in flight during the MFMAs
+        if (more) { load_a(i0 + DENSE_KC, an); fetch_f(i0 + DENSE_KC, fr); }          // next chunk in flight during the MFMAs
         const float* fs = Fs[buf] + (16 * half) * (32 * RT) + col;
 #pragma unroll
         for (int s = 0; s < 16; ++s)
 #pragma unroll
             for (int r = 0; r < RT; ++r)
                 acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(fs[s * (32 * RT) + 32 * r], a[s], acc[r], 0, 0, 0);
+        if (more) park_f(fr, buf ^ 1);
         __syncthreads();
         if (more) {
 #pragma unroll
@@ -126,20 +136,28 @@ __global__ __launch_bounds__(256) void dense_rhs_bwd_f32(const float* __restrict
             a[s] = v;
         }
     };
-    auto stage_f = [&](int64_t j0, int buf) {
-        for (int t = threadIdx.x; t < KCB * 32 * RT; t += 256) {
-            const int row = t / (32 * RT), f = t % (32 * RT);
-            Fs[buf][t] = (f < k && j0 + row < jend) ? F[(j0 + row) * k + f] : 0.f;
+    constexpr int FPT = KCB * 32 * RT / 256;
+    auto fetch_f = [&](int64_t j0, float (&fr)[FPT]) {
+#pragma unroll
+        for (int q = 0; q < FPT; ++q) {
+            const int t = threadIdx.x + 256 * q, row = t / (32 * RT), f = t % (32 * RT);
+            fr[q] = (f < k && j0 + row < jend) ? F[(j0 + row) * k + f] : 0.f;
         }
     };
+    auto park_f = [&](const float (&fr)[FPT], int buf) {
+#pragma unroll
+        for (int q = 0; q < FPT; ++q) Fs[buf][threadIdx.x + 256 * q] = fr[q];
+    };
     float4 a[KCB / 2], an[KCB / 2];
+    float fr[FPT];
     load_a(jbeg, a);
-    stage_f(jbeg, 0);
+    fetch_f(jbeg, fr);
+    park_f(fr, 0);
     __syncthreads();
     int buf = 0;
     for (int64_t j0 = jbeg; j0 < jend; j0 += KCB) {
         const bool more = j0 + KCB < jend;
-        if (more) { load_a(j0 + KCB, an); stage_f(j0 + KCB, buf ^ 1); }
+        if (more) { load_a(j0 + KCB, an); fetch_f(j0 + KCB, fr); }
         const float* fs = Fs[buf] + half * (32 * RT) + c;
 #pragma unroll
         for (int s = 0; s < KCB / 2; ++s)
@@ -151,6 +169,7 @@ __global__ __launch_bounds__(256) void dense_rhs_bwd_f32(const float* __restrict
                 acc[r][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(fv, a[s].z, acc[r][2], 0, 0, 0);
                 acc[r][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(fv, a[s].w, acc[r][3], 0, 0, 0);
             }
+        if (more) park_f(fr, buf ^ 1);
         __syncthreads();
         if (more) {
 #pragma unroll
