@@ -265,7 +265,7 @@ def _graph_args(g, dtype, ct):
         return [None, None, None, ct(0)]
     L, lam = g
     x = L.values(dtype)
-    _graph_args.keep = getattr(_graph_args, 'keep', []) + [x]          # keep the converted values alive for the call
+    _graph_args.keep = (getattr(_graph_args, 'keep', []) + [x])[-4:]   # keep the converted values alive for the call (2 per fit)
     return [_p(L.p), _p(L.i), _p(x), ct(lam)]
 
 
