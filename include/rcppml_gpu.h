@@ -364,7 +364,8 @@ RCPPML_GPU_API int rcppml_hip_irls_loss(rcppml_hip_ctx* ctx, int dtype, int loss
                                         double robust_delta, double* out);
 /* Dense-input right-hand sides (reference primitives::rhs<CPU> on a dense A and detail::rhs_transpose,
  * nmf/fit_cpu.hpp:547-549 / :783): transposed = 0: B (k x n) = F (k x m) A;  1: B (k x m) = F (k x n) A^T.
- * A column-major m x n on the device; F, B column-major with leading dimension k.  rocBLAS GEMM. */
+ * A column-major m x n on the device; F, B column-major with leading dimension k, k <= 128.  Hand-written skinny MFMA GEMMs
+ * (fp32 32x32x2 tiles, fp64 16x16x4 tiles) that stream A once; no BLAS library. */
 RCPPML_GPU_API int rcppml_hip_rhs_dense(rcppml_hip_ctx* ctx, int dtype, const void* A, int64_t m, int64_t n,
                                         int transposed, const void* F, int k, void* B);
 /* Same decoder on a byte buffer in host memory, into caller-allocated device arrays (layer 2; what the parity tests

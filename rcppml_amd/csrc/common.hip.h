@@ -60,9 +60,6 @@ struct rcppml_hip_ctx {
     Buf bufs[WS_COUNT];
     // device counters read by rcppml_hip_ctx_stats: [0] column-sweeps executed by the CD kernels, [1] columns solved
     unsigned long long* stats = nullptr;
-    // rocBLAS handle of the dense-input GEMMs (ops_dense.hip creates it on first use and installs the destroyer)
-    void* blas = nullptr;
-    void (*blas_destroy)(void*) = nullptr;
     // Grow-only scratch.  Growth frees the old block with hipFree, which synchronises the device,
     // so no in-flight kernel can still be using it.
     void* scratch(int slot, size_t bytes) {

@@ -193,6 +193,185 @@ __global__ __launch_bounds__(256) void dense_rhs_bwd_f32(const float* __restrict
     }
 }
 
+// ============================================================================ fp64 (parity mode)
+// Same two products on v_mfma_f64_16x16x4_f64 tiles (M = 16 factor rows, N = 16 output columns, K = 4 reduction indices):
+// lane l supplies A-operand[M = l & 15][K = l >> 4] and B-operand[K = l >> 4][N = l & 15]; D row = (l >> 4) + 4 v,
+// column = l & 15.  2 k flops per 8 bytes of A = 16 flop/B at k = 64 against a 78.6 TF / 8 TB/s = 10 flop/B ridge.
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+// forward: 16 output columns per wave; quarter q = lane >> 4 keeps rows i0 + 8 q + s (s = 0..7: one 64-byte line).
+template <int RT>                       // k <= 16 RT
+__global__ __launch_bounds__(256) void dense_rhs_fwd_f64(const double* __restrict__ A, int64_t m, int64_t n,
+                                                         const double* __restrict__ F, int k, int64_t ichunk,
+                                                         double* __restrict__ part) {
+    __shared__ __attribute__((aligned(16))) double Fs[2][DENSE_KC * 16 * RT];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, col = lane & 15, q4 = lane >> 4;
+    const int64_t j = ((int64_t)blockIdx.x * 4 + wave) * 16 + col;
+    const bool jok = j < n;
+    const double* acol = A + (jok ? j : 0) * m;
+    const bool vec_ok = (m % 2 == 0) && (reinterpret_cast<uintptr_t>(A) % 16 == 0);
+    const int64_t ibeg = (int64_t)blockIdx.y * ichunk, iend = min(m, ibeg + ichunk);
+    double* B = part + (int64_t)blockIdx.y * k * n;
+    f64x4 acc[RT];
+#pragma unroll
+    for (int r = 0; r < RT; ++r)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) acc[r][v] = 0.0;
+    auto load_a = [&](int64_t i0, double (&a)[8]) {
+        const int64_t base = i0 + 8 * q4;
+        if (jok && vec_ok && base + 8 <= iend) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const double2 v = *reinterpret_cast<const double2*>(acol + base + 2 * t);
+                a[2 * t] = v.x; a[2 * t + 1] = v.y;
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < 8; ++s) a[s] = (jok && base + s < iend) ? acol[base + s] : 0.0;
+        }
+    };
+    constexpr int FPT = DENSE_KC * 16 * RT / 256;
+    auto fetch_f = [&](int64_t i0, double (&fr)[FPT]) {
+#pragma unroll
+        for (int t = 0; t < FPT; ++t) {
+            const int e = threadIdx.x + 256 * t, row = e / (16 * RT), f = e % (16 * RT);
+            fr[t] = (f < k && i0 + row < iend) ? F[(i0 + row) * k + f] : 0.0;
+        }
+    };
+    auto park_f = [&](const double (&fr)[FPT], int buf) {
+#pragma unroll
+        for (int t = 0; t < FPT; ++t) Fs[buf][threadIdx.x + 256 * t] = fr[t];
+    };
+    double a[8], an[8], fr[FPT];
+    load_a(ibeg, a);
+    fetch_f(ibeg, fr);
+    park_f(fr, 0);
+    __syncthreads();
+    int buf = 0;
+    for (int64_t i0 = ibeg; i0 < iend; i0 += DENSE_KC) {
+        const bool more = i0 + DENSE_KC < iend;
+        if (more) { load_a(i0 + DENSE_KC, an); fetch_f(i0 + DENSE_KC, fr); }
+        const double* fs = Fs[buf] + (8 * q4) * (16 * RT) + col;
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+#pragma unroll
+            for (int r = 0; r < RT; ++r)
+                acc[r] = __builtin_amdgcn_mfma_f64_16x16x4f64(fs[s * (16 * RT) + 16 * r], a[s], acc[r], 0, 0, 0);
+        if (more) park_f(fr, buf ^ 1);
+        __syncthreads();
+        if (more) {
+#pragma unroll
+            for (int s = 0; s < 8; ++s) a[s] = an[s];
+        }
+        buf ^= 1;
+    }
+    if (jok) {
+#pragma unroll
+        for (int r = 0; r < RT; ++r)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int f = 16 * r + q4 + 4 * v;
+                if (f < k) B[j * k + f] = acc[r][v];
+            }
+    }
+}
+
+// backward: one 16-byte load = 2 consecutive rows i = i0 + 2 c + e feeding two interleaved column tiles; the lane quarters
+// take the columns j0 + 4 s + q.  A wave covers 32 rows, a block 128.
+template <int RT>
+__global__ __launch_bounds__(256) void dense_rhs_bwd_f64(const double* __restrict__ A, int64_t m, int64_t n,
+                                                         const double* __restrict__ F, int k, int64_t jchunk,
+                                                         double* __restrict__ part) {
+    constexpr int KCB = DENSE_KC_BWD;
+    __shared__ __attribute__((aligned(16))) double Fs[2][KCB * 16 * RT];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, c = lane & 15, q4 = lane >> 4;
+    const int64_t i0 = ((int64_t)blockIdx.x * 4 + wave) * 32 + 2 * c;
+    const int64_t jbeg = (int64_t)blockIdx.y * jchunk, jend = min(n, jbeg + jchunk);
+    const bool vec_ok = (m % 2 == 0) && (reinterpret_cast<uintptr_t>(A) % 16 == 0) && i0 + 2 <= m;
+    f64x4 acc[RT][2];
+#pragma unroll
+    for (int r = 0; r < RT; ++r)
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) acc[r][e][v] = 0.0;
+    auto load_a = [&](int64_t j0, double2 (&a)[KCB / 4]) {
+#pragma unroll
+        for (int s = 0; s < KCB / 4; ++s) {
+            const int64_t j = j0 + 4 * s + q4;
+            double2 v = make_double2(0.0, 0.0);
+            if (j < jend) {
+                const double* p = A + j * m + i0;
+                if (vec_ok) v = *reinterpret_cast<const double2*>(p);
+                else { if (i0 < m) v.x = p[0]; if (i0 + 1 < m) v.y = p[1]; }
+            }
+            a[s] = v;
+        }
+    };
+    constexpr int FPT = KCB * 16 * RT / 256;
+    auto fetch_f = [&](int64_t j0, double (&fr)[FPT]) {
+#pragma unroll
+        for (int t = 0; t < FPT; ++t) {
+            const int e = threadIdx.x + 256 * t, row = e / (16 * RT), f = e % (16 * RT);
+            fr[t] = (f < k && j0 + row < jend) ? F[(j0 + row) * k + f] : 0.0;
+        }
+    };
+    auto park_f = [&](const double (&fr)[FPT], int buf) {
+#pragma unroll
+        for (int t = 0; t < FPT; ++t) Fs[buf][threadIdx.x + 256 * t] = fr[t];
+    };
+    double2 a[KCB / 4], an[KCB / 4];
+    double fr[FPT];
+    load_a(jbeg, a);
+    fetch_f(jbeg, fr);
+    park_f(fr, 0);
+    __syncthreads();
+    int buf = 0;
+    for (int64_t j0 = jbeg; j0 < jend; j0 += KCB) {
+        const bool more = j0 + KCB < jend;
+        if (more) { load_a(j0 + KCB, an); fetch_f(j0 + KCB, fr); }
+        const double* fs = Fs[buf] + q4 * (16 * RT) + c;
+#pragma unroll
+        for (int s = 0; s < KCB / 4; ++s)
+#pragma unroll
+            for (int r = 0; r < RT; ++r) {
+                const double fv = fs[(4 * s) * (16 * RT) + 16 * r];
+                acc[r][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(fv, a[s].x, acc[r][0], 0, 0, 0);
+                acc[r][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(fv, a[s].y, acc[r][1], 0, 0, 0);
+            }
+        if (more) park_f(fr, buf ^ 1);
+        __syncthreads();
+        if (more) {
+#pragma unroll
+            for (int s = 0; s < KCB / 4; ++s) a[s] = an[s];
+        }
+        buf ^= 1;
+    }
+    double* out = part + (int64_t)blockIdx.y * k * m;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int64_t i = i0 + e;
+        if (i < m) {
+#pragma unroll
+            for (int r = 0; r < RT; ++r)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int f = 16 * r + q4 + 4 * v;
+                    if (f < k) out[i * k + f] = acc[r][e][v];
+                }
+        }
+    }
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void dense_reduce(const T* __restrict__ part, int64_t count, int slices, T* __restrict__ B) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= count) return;
+    T s = T(0);
+    for (int q = 0; q < slices; ++q) s += part[(int64_t)q * count + t];
+    B[t] = s;
+}
+
 __global__ __launch_bounds__(256) void dense_reduce_f32(const float* __restrict__ part, int64_t count, int slices, float* __restrict__ B) {
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (t >= count) return;

@@ -1,26 +1,13 @@
 // ops_dense.hip -- dense-input right-hand sides of the ALS update (device-level C ABI, include/rcppml_gpu.h layer 2).
 // Reference: primitives::rhs<CPU> on a dense A (B = W_T * A, Eigen GEMM) and detail::rhs_transpose (B = H * A^T),
-// nmf/fit_cpu.hpp:547-549 / :783; the reference's GPU build calls cuBLAS for them (nmf/fit_gpu_dense.cuh).  These are
-// fp32 (the precision the reference computes in): hand-written skinny MFMA GEMMs (kernels_dense.hip.h) that stream A once
-// per product; fp64 (the parity mode) and RCPPML_GPU_DENSE_VARIANT=blas: rocBLAS.  Everything around them (Gram, features,
+// nmf/fit_cpu.hpp:547-549 / :783; the reference's GPU build calls cuBLAS for them (nmf/fit_gpu_dense.cuh).
+// Hand-written skinny MFMA GEMMs (kernels_dense.hip.h: fp32 on 32x32x2 tiles, fp64 on 16x16x4 tiles) that stream A once per
+// product; no BLAS library is linked (tools/probe/dense_check.py times torch.matmul = rocBLAS/hipBLASLt beside them).  Everything around them (Gram, features,
 // NNLS solve, scaling, loss) is the hand-written path shared with the sparse input.
-#include <rocblas/rocblas.h>
 #include "common.hip.h"
 #include "kernels_dense.hip.h"
 #include <cstring>
 
-namespace {
-rocblas_handle blas_of(rcppml_hip_ctx* c) {
-    if (!c->blas) {
-        rocblas_handle h = nullptr;
-        if (rocblas_create_handle(&h) != rocblas_status_success) throw std::runtime_error("rocblas_create_handle failed");
-        if (rocblas_set_stream(h, c->stream) != rocblas_status_success) { rocblas_destroy_handle(h); throw std::runtime_error("rocblas_set_stream failed"); }
-        c->blas = h;
-        c->blas_destroy = [](void* p) { (void)rocblas_destroy_handle(static_cast<rocblas_handle>(p)); };
-    }
-    return static_cast<rocblas_handle>(c->blas);
-}
-}  // namespace
 
 // transposed = 0:  B (k x n) = F (k x m) * A (m x n)       transposed = 1:  B (k x m) = F (k x n) * A^T
 // A is column-major m x n; F and B are column-major with leading dimension k.
@@ -30,9 +17,8 @@ extern "C" int rcppml_hip_rhs_dense(rcppml_hip_ctx* c, int dtype, const void* A,
         HIPCHK(hipSetDevice(c->device));
         if (m <= 0 || n <= 0 || k <= 0) return 0;
         if (m > 0x7FFFFFFF || n > 0x7FFFFFFF) throw std::runtime_error("rhs_dense: dimension exceeds int32");
-        static int use_blas = -1;
-        if (use_blas < 0) { const char* e = getenv("RCPPML_GPU_DENSE_VARIANT"); use_blas = (e && !strcmp(e, "blas")) ? 1 : 0; }
-        if (dtype == RCPPML_F32 && k <= 128 && !use_blas) {
+        if (k > 128) throw std::runtime_error("rhs_dense: k must be <= 128");
+        if (dtype == RCPPML_F32) {
             const float* Af = (const float*)A; const float* Ff = (const float*)F; float* Bf = (float*)B;
             const int RT = (k + 31) / 32;
             if (!transposed) {
@@ -85,19 +71,36 @@ extern "C" int rcppml_hip_rhs_dense(rcppml_hip_ctx* c, int dtype, const void* A,
             HIPCHK(hipGetLastError());
             return 0;
         }
-        rocblas_handle h = blas_of(c);
-        const rocblas_operation tb = transposed ? rocblas_operation_transpose : rocblas_operation_none;
-        const rocblas_int N = (rocblas_int)(transposed ? m : n), K = (rocblas_int)(transposed ? n : m);
-        rocblas_status st;
-        if (dtype == RCPPML_F32) {
-            const float one = 1.f, zero = 0.f;
-            st = rocblas_sgemm(h, rocblas_operation_none, tb, k, N, K, &one, (const float*)F, k, (const float*)A, (rocblas_int)m, &zero, (float*)B, k);
-        } else {
-            const double one = 1.0, zero = 0.0;
-            st = rocblas_dgemm(h, rocblas_operation_none, tb, k, N, K, &one, (const double*)F, k, (const double*)A, (rocblas_int)m, &zero, (double*)B, k);
+        {
+            const double* Ad = (const double*)A; const double* Fd = (const double*)F; double* Bd = (double*)B;
+            const int RT = k <= 16 ? 1 : k <= 32 ? 2 : k <= 64 ? 4 : 8;
+            const int64_t out_cols = transposed ? m : n, red = transposed ? n : m;
+            const int64_t per_block = transposed ? 128 : 64, kc = transposed ? rk::DENSE_KC_BWD : rk::DENSE_KC;
+            const int64_t blocks = (out_cols + per_block - 1) / per_block, chunks = (red + kc - 1) / kc;
+            int64_t slices = (4096 + blocks * 4 - 1) / (blocks * 4);
+            if (slices > chunks) slices = chunks;
+            if (slices < 1) slices = 1;
+            const int64_t rchunk = (chunks + slices - 1) / slices * kc;
+            slices = (red + rchunk - 1) / rchunk;
+            double* part = slices == 1 ? Bd : static_cast<double*>(c->scratch(WS_GRAPH, (size_t)slices * k * out_cols * sizeof(double)));
+            const dim3 grid((unsigned)blocks, (unsigned)slices);
+#define RCPPML_DENSE64(KERN)                                                                                                   \
+            switch (RT) {                                                                                                      \
+                case 1: hipLaunchKernelGGL((rk::KERN<1>), grid, dim3(256), 0, c->stream, Ad, m, n, Fd, k, rchunk, part); break; \
+                case 2: hipLaunchKernelGGL((rk::KERN<2>), grid, dim3(256), 0, c->stream, Ad, m, n, Fd, k, rchunk, part); break; \
+                case 4: hipLaunchKernelGGL((rk::KERN<4>), grid, dim3(256), 0, c->stream, Ad, m, n, Fd, k, rchunk, part); break; \
+                default: hipLaunchKernelGGL((rk::KERN<8>), grid, dim3(256), 0, c->stream, Ad, m, n, Fd, k, rchunk, part); break; \
+            }
+            if (!transposed) { RCPPML_DENSE64(dense_rhs_fwd_f64) } else { RCPPML_DENSE64(dense_rhs_bwd_f64) }
+#undef RCPPML_DENSE64
+            HIPCHK(hipGetLastError());
+            if (slices > 1) {
+                const int64_t count = (int64_t)k * out_cols;
+                hipLaunchKernelGGL(rk::dense_reduce<double>, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, c->stream, part, count, (int)slices, Bd);
+                HIPCHK(hipGetLastError());
+            }
+            return 0;
         }
-        if (st != rocblas_status_success) throw std::runtime_error(std::string("rocblas gemm failed: ") + rocblas_status_to_string(st));
-        return 0;
     }
     RCPPML_CATCH_RET
 }

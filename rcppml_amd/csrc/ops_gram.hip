@@ -31,7 +31,6 @@ extern "C" void rcppml_hip_ctx_destroy(rcppml_hip_ctx* c) {
     for (auto& b : c->bufs)
         if (b.ptr) (void)hipFree(b.ptr);
     if (c->stats) (void)hipFree(c->stats);
-    if (c->blas && c->blas_destroy) c->blas_destroy(c->blas);
     delete c;
 }
 extern "C" int rcppml_hip_ctx_sync(rcppml_hip_ctx* c) {

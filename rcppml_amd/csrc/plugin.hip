@@ -366,7 +366,7 @@ void fit(FitParams& P) {
     // sizes settled), so it is captured once into a hipGraph and replayed: small inputs (hawaiibirds: ~27 launches for
     // < 50 us of GPU work) are bound by the host's launch rate, not by the kernels.  Plain MSE path only; any capture
     // failure falls back to eager launches.  RCPPML_GPU_NO_GRAPH=1 disables.
-    const bool graph_ok = !is_nb && !has_mask && !dense && !getenv("RCPPML_GPU_NO_GRAPH");   // (rocBLAS calls are not captured)
+    const bool graph_ok = !is_nb && !has_mask && !dense && !getenv("RCPPML_GPU_NO_GRAPH");   // (dense input: a few large launches, eager)
     struct GraphHolder {
         hipGraph_t g = nullptr; hipGraphExec_t e = nullptr; bool failed = false;
         ~GraphHolder() { if (e) (void)hipGraphExecDestroy(e); if (g) (void)hipGraphDestroy(g); }
