@@ -229,6 +229,24 @@ RCPPML_GPU_API int rcppml_hip_rhs(rcppml_hip_ctx* ctx, int dtype, const int* col
                                   const int* row_idx, const void* values, int64_t ncols,
                                   const void* F, int k, void* B);
 
+/* Planned form of the same product for large inputs (build-defined; the reference has one CPU loop, rhs.hpp:52-70).
+ * A plan is a tile-partitioned, slot-padded device copy of ONE CSC matrix for one rank k and precision: the rows of F
+ * are staged through LDS in 64 KiB tiles, the output columns stay in registers (kernels_rhs_tiled.hip.h).
+ *   plan_create: nrows = rows of the sparse matrix (= number of k-vectors in F).  partitions: 0 = automatic (one row
+ *     partition per XCD when F is far larger than an XCD's L2, else one).  slots: 0 = chosen from the data.
+ *     *out_plan stays NULL (return 0) when the shape is not eligible (k * sizeof(T) not 256 or 512 bytes, rows not
+ *     sorted inside a column, more than 35 % of the nonzeros would spill): call rcppml_hip_rhs then.
+ *   rhs_planned: B = F * A(:, j) for all columns, same numbers as rcppml_hip_rhs up to summation order; deterministic.
+ *   plan_info: {P, waves per workgroup, rounds per wave, slots, workgroups per partition, tiles, slot count,
+ *     spilled nonzeros, slot fill fraction, slot stream bytes}. */
+typedef struct rcppml_rhs_plan rcppml_rhs_plan;
+RCPPML_GPU_API int rcppml_hip_rhs_plan_create(rcppml_hip_ctx* ctx, int dtype, const int* col_ptr, const int* row_idx,
+                                              const void* values, int64_t ncols, int64_t nrows, int k, int partitions,
+                                              int slots, rcppml_rhs_plan** out_plan);
+RCPPML_GPU_API void rcppml_hip_rhs_plan_destroy(rcppml_rhs_plan* plan);
+RCPPML_GPU_API int rcppml_hip_rhs_plan_info(const rcppml_rhs_plan* plan, double* out10);
+RCPPML_GPU_API int rcppml_hip_rhs_planned(rcppml_hip_ctx* ctx, const rcppml_rhs_plan* plan, const void* F, void* B);
+
 /* Per-column CD NNLS -- reference primitives/cpu/nnls_batch.hpp:70-132 (cd_nnls_col_fixed) with the
  * prologues of fused_nnls.hpp:116-123 / nnls_batch.hpp:167-174:
  *   b = B(:,j); if (l1_pre>0) b -= l1_pre; x = zero_init ? 0 : X(:,j); if (warm) b -= G x;

@@ -26,11 +26,37 @@ EXPORTED_SYMBOLS = [
     "rcppml_hip_solve_irls_nb", "rcppml_hip_nb_size_update", "rcppml_hip_nb_loss", "rcppml_hip_solve_irls", "rcppml_hip_irls_loss", "rcppml_hip_apply_l21", "rcppml_hip_angular_posthoc", "rcppml_hip_solve_cv", "rcppml_hip_cv_test_error", "rcppml_hip_mul_rows", "rcppml_hip_apply_graph_reg", "rcppml_hip_dispersion_update", "rcppml_hip_vec_global", "rcppml_hip_spz_info", "rcppml_hip_spz_decode",
     "rcppml_sp_read_gpu", "rcppml_sp_free_gpu", "rcppml_hip_rhs_dense", "rcppml_gpu_nmf_dense_unified_float",
     "rcppml_gpu_nmf_dense_unified_double",
+    "rcppml_hip_rhs_plan_create", "rcppml_hip_rhs_plan_destroy", "rcppml_hip_rhs_plan_info", "rcppml_hip_rhs_planned",
 ]
 
 
 class BackendError(RuntimeError):
     pass
+
+
+class RhsPlan:
+    """Owner of a rcppml_rhs_plan handle (device memory: free it with close() or let the GC do it)."""
+
+    def __init__(self, handle):
+        self._h = handle
+
+    def info(self):
+        out = (C.c_double * 10)()
+        lib().rcppml_hip_rhs_plan_info(self._h, out)
+        keys = ("partitions", "waves", "rounds", "slots", "workgroups_per_partition", "tiles", "slot_count", "spilled_nnz",
+                "fill", "stream_bytes")
+        return {k: (float(out[i]) if k == "fill" else int(out[i])) for i, k in enumerate(keys)}
+
+    def close(self):
+        if self._h is not None and self._h.value:
+            lib().rcppml_hip_rhs_plan_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def lib():
@@ -53,6 +79,11 @@ def lib():
                      "rcppml_hip_solve_irls_nb", "rcppml_hip_nb_size_update", "rcppml_hip_nb_loss"):
             getattr(_lib, name).restype = C.c_int
         _lib.rcppml_hip_ctx_destroy.restype = None
+        _lib.rcppml_hip_rhs_plan_destroy.restype = None
+        _lib.rcppml_hip_rhs_plan_destroy.argtypes = [C.c_void_p]
+        for name in ("rcppml_hip_rhs_plan_create", "rcppml_hip_rhs_plan_info", "rcppml_hip_rhs_planned"):
+            getattr(_lib, name).restype = C.c_int
+        _lib.rcppml_hip_rhs_plan_info.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
     return _lib
 
 
@@ -330,6 +361,17 @@ class Context:
     def rhs(self, dt, col_ptr, row_idx, values, ncols, F, k, B):
         _chk(lib().rcppml_hip_rhs(self._h, C.c_int(dt), _dptr(col_ptr), _dptr(row_idx), _dptr(values), C.c_int64(ncols),
                                   _dptr(F), C.c_int(k), _dptr(B)), "rhs")
+
+    def rhs_plan(self, dt, col_ptr, row_idx, values, ncols, nrows, k, partitions=0, slots=0):
+        """Tile-partitioned slot copy of one CSC matrix for the LDS row-tiled kernel; None when the shape is not eligible
+        (the caller then keeps using rhs())."""
+        h = C.c_void_p()
+        _chk(lib().rcppml_hip_rhs_plan_create(self._h, C.c_int(dt), _dptr(col_ptr), _dptr(row_idx), _dptr(values), C.c_int64(ncols),
+                                              C.c_int64(nrows), C.c_int(k), C.c_int(partitions), C.c_int(slots), C.byref(h)), "rhs_plan_create")
+        return RhsPlan(h) if h.value else None
+
+    def rhs_planned(self, plan, F, B):
+        _chk(lib().rcppml_hip_rhs_planned(self._h, plan._h, _dptr(F), _dptr(B)), "rhs_planned")
 
     def solve_cd(self, dt, G, B, X, k, ncols, l1_pre=0.0, warm=0, zero_init=0, l1_cd=0.0, l2_cd=0.0, nonneg=1, maxit=100,
                  tol=1e-8, ub_cd=0.0, ub_post=0.0, variant=CD_AUTO, sweeps_out=None, col_order=None):

@@ -16,6 +16,8 @@ through rcppml_amd._abi).  Nothing here falls back to PyTorch or CPU math.
 """
 from dataclasses import dataclass
 
+import os
+
 import numpy as np
 
 
@@ -99,9 +101,22 @@ class HipOps:
     def rhs(self, csc, F, out=None, tag="rhs"):
         k = F.shape[1]
         B = out if out is not None else self.empty((csc["cols"], k))
+        plan = csc.get("plans", {}).get(k)
         with self._timed(tag):
-            self.ctx.rhs(self.dt, csc["p"], csc["i"], csc["x"], csc["cols"], F, k, B)
+            if plan is not None:
+                self.ctx.rhs_planned(plan, F, B)
+            else:
+                self.ctx.rhs(self.dt, csc["p"], csc["i"], csc["x"], csc["cols"], F, k, B)
         return B
+
+    def plan_rhs(self, csc, k, min_nnz=1 << 20, partitions=0, slots=0):
+        """Build the LDS row-tiled plan of csc for rank k (large inputs only; kept in csc["plans"], used by rhs())."""
+        if os.environ.get("RCPPML_GPU_RHS_TILED", "1") == "0" or csc["nnz"] < min_nnz:
+            return None
+        plan = self.ctx.rhs_plan(self.dt, csc["p"], csc["i"], csc["x"], csc["cols"], csc["rows"], k, partitions, slots)
+        if plan is not None:
+            csc.setdefault("plans", {})[k] = plan
+        return plan
 
     def solve(self, G, B, X, cfg, side, warm, tag="solve"):
         n, k = X.shape
@@ -225,6 +240,8 @@ class ShardedALS:
         self.A = ops.upload_csc(A_loc)
         self.At = ops.upload_csc(At_loc)
         k, m = self.k, self.m
+        ops.plan_rhs(self.A, k)
+        ops.plan_rhs(self.At, k)
         # W_T is replicated; for world > 1 its m columns (rows of the (m, k) array) are SOLVED in contiguous blocks of
         # rows_per per rank and all-gathered, so the W solve shrinks with the world size instead of being repeated.
         # rows_per is a multiple of 4 so every block starts 16-byte aligned for any k; the pad rows stay zero.

@@ -40,6 +40,9 @@ class OracleOps:
         out.copy_(torch.from_numpy(O.rhs(csc["csc"], F.numpy(), self.ndtype)))
         return out
 
+    def plan_rhs(self, csc, k, **kw):        # the LDS row-tiled plan is a device-side optimisation: nothing to do here
+        return None
+
     def solve(self, G, B, X, cfg, side, warm, tag=None):
         l1 = cfg.L1_H if side == "H" else cfg.L1_W
         ub = cfg.ub_H if side == "H" else cfg.ub_W

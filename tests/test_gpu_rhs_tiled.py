@@ -1,0 +1,106 @@
+"""GPU parity tests of the LDS row-tiled right-hand side (rcppml_hip_rhs_plan_create / rcppml_hip_rhs_planned,
+rcppml_amd/csrc/kernels_rhs_tiled.hip.h) against the CPU oracle's rhs (reference primitives/cpu/rhs.hpp:52-70).
+
+What is exercised: both row sizes the kernel is compiled for (256 and 512 bytes: fp32 k = 64 / 128, fp64 k = 32 / 64), every
+slot count (forced), automatic slot choice, one and several row partitions, spills (segments longer than the slot
+count), empty columns, a last tile shorter than 64 KiB, more workgroups than one, ineligible shapes (plan is None) and
+run-to-run bitwise determinism.  Tolerances: fp64 1e-11, fp32 5e-5 relative to the largest entry (summation order
+differs from the oracle's sequential loop: spilled nonzeros first, then tile by tile)."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests.util import random_csc, rel_err
+
+pytestmark = pytest.mark.gpu
+
+TOL = {np.float32: 5e-5, np.float64: 1e-11}
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    from rcppml_amd import _abi
+    return torch, _abi, _abi.Context(0)
+
+
+def _dev(torch, a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _run(env, A, k, dtype, partitions=0, slots=0, expect_plan=True):
+    torch, _abi, ctx = env
+    dt = _abi.F32 if dtype == np.float32 else _abi.F64
+    tt = torch.float32 if dtype == np.float32 else torch.float64
+    F = np.random.default_rng(k + A.rows).standard_normal((A.rows, k)).astype(dtype)
+    dp, di, dx = _dev(torch, A.p), _dev(torch, A.i), _dev(torch, A.values(dtype))
+    plan = ctx.rhs_plan(dt, dp, di, dx, A.cols, A.rows, k, partitions, slots)
+    if not expect_plan:
+        assert plan is None
+        return None
+    assert plan is not None
+    info = plan.info()
+    dF = _dev(torch, F)
+    dB = torch.full((A.cols, k), 7.0, dtype=tt, device="cuda")
+    ctx.rhs_planned(plan, dF, dB)
+    B = dB.cpu().numpy()
+    assert rel_err(B, O.rhs(A, F, dtype)) < TOL[dtype], info
+    dB2 = torch.full((A.cols, k), -3.0, dtype=tt, device="cuda")
+    ctx.rhs_planned(plan, dF, dB2)
+    assert np.array_equal(B, dB2.cpu().numpy()), "planned rhs must be bitwise reproducible"
+    return info
+
+
+@pytest.mark.parametrize("dtype,k", [(np.float32, 64), (np.float32, 128), (np.float64, 32), (np.float64, 64)])
+@pytest.mark.parametrize("slots", [0, 2, 3, 4, 5, 6, 8])
+def test_planned_rhs_slots(env, dtype, k, slots):
+    # 700 rows: 2.7 tiles of 256 rows (k*s = 256 B) / 5.5 tiles of 128 rows; the last tile is short
+    A = random_csc(700, 1500, 0.012, seed=slots + k)
+    info = _run(env, A, k, dtype, slots=slots)
+    if slots:
+        assert info["slots"] == slots
+
+
+@pytest.mark.parametrize("partitions", [1, 2, 3, 8])
+def test_planned_rhs_partitions(env, partitions):
+    A = random_csc(3000, 900, 0.004, seed=partitions)
+    info = _run(env, A, 64, np.float32, partitions=partitions)
+    assert info["partitions"] == min(partitions, info["tiles"])
+
+
+def test_planned_rhs_spills_and_empty_columns(env):
+    # dense-ish columns: every (column, tile) segment holds ~25 nonzeros, far beyond any slot count -> most spill
+    A = random_csc(512, 300, 0.10, seed=5)
+    # empty columns in the middle and at the end
+    p = A.p.copy()
+    keep = np.ones(A.cols, bool)
+    keep[[3, 4, 100, 299]] = False
+    cnt = np.diff(p) * keep
+    sel = np.repeat(keep, np.diff(p))
+    A2 = O.Csc((A.rows, A.cols), np.concatenate([[0], np.cumsum(cnt)]).astype(np.int32), A.i[sel], A.x[sel])
+    info = _run(env, A2, 64, np.float32, slots=2)
+    assert info["spilled_nnz"] > 0
+    info = _run(env, A2, 32, np.float64, slots=8)
+    assert info["spilled_nnz"] > 0
+
+
+def test_planned_rhs_many_workgroups(env):
+    # 40 000 columns on 256 CUs: several rounds per wave, short last workgroup
+    A = random_csc(600, 40000, 0.004, seed=9)
+    info = _run(env, A, 64, np.float32)
+    assert info["workgroups_per_partition"] >= 1
+    _run(env, A.transpose(), 64, np.float32, partitions=2)
+
+
+def test_planned_rhs_ineligible_shapes(env):
+    A = random_csc(300, 200, 0.05, seed=1)
+    _run(env, A, 10, np.float32, expect_plan=False)      # 40-byte rows
+    _run(env, A, 100, np.float64, expect_plan=False)     # 800-byte rows
+    # unsorted rows inside a column
+    i = A.i.copy()
+    s, e = A.p[7], A.p[8]
+    if e - s >= 2:
+        i[s], i[s + 1] = i[s + 1], i[s]
+    B = O.Csc((A.rows, A.cols), A.p, i, A.x)
+    torch, _abi, ctx = env
+    assert ctx.rhs_plan(_abi.F32, _dev(torch, B.p), _dev(torch, B.i), _dev(torch, B.values(np.float32)), B.cols, B.rows, 64) is None
