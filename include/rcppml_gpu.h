@@ -237,14 +237,16 @@ RCPPML_GPU_API int rcppml_hip_rhs(rcppml_hip_ctx* ctx, int dtype, const int* col
  *     *out_plan stays NULL (return 0) when the shape is not eligible (k * sizeof(T) not 256 or 512 bytes, rows not
  *     sorted inside a column, more than 35 % of the nonzeros would spill): call rcppml_hip_rhs then.
  *   rhs_planned: B = F * A(:, j) for all columns, same numbers as rcppml_hip_rhs up to summation order; deterministic.
- *   plan_info: {P, waves per workgroup, rounds per wave, slots, workgroups per partition, tiles, slot count,
- *     spilled nonzeros, slot fill fraction, slot stream bytes}. */
+ *     The plan keeps the col_ptr / row_idx / values POINTERS (columns that would only part-fill a last round of
+ *     workgroups are left to the gather kernel): the CSC must outlive the plan.
+ *   plan_info (11 doubles): {P, waves per workgroup, rounds per wave, slots, workgroups per partition, tiles, slot count,
+ *     spilled nonzeros, slot fill fraction, slot stream bytes, columns handled by the tiled kernel}. */
 typedef struct rcppml_rhs_plan rcppml_rhs_plan;
 RCPPML_GPU_API int rcppml_hip_rhs_plan_create(rcppml_hip_ctx* ctx, int dtype, const int* col_ptr, const int* row_idx,
                                               const void* values, int64_t ncols, int64_t nrows, int k, int partitions,
                                               int slots, rcppml_rhs_plan** out_plan);
 RCPPML_GPU_API void rcppml_hip_rhs_plan_destroy(rcppml_rhs_plan* plan);
-RCPPML_GPU_API int rcppml_hip_rhs_plan_info(const rcppml_rhs_plan* plan, double* out10);
+RCPPML_GPU_API int rcppml_hip_rhs_plan_info(const rcppml_rhs_plan* plan, double* out11);
 RCPPML_GPU_API int rcppml_hip_rhs_planned(rcppml_hip_ctx* ctx, const rcppml_rhs_plan* plan, const void* F, void* B);
 
 /* Per-column CD NNLS -- reference primitives/cpu/nnls_batch.hpp:70-132 (cd_nnls_col_fixed) with the

@@ -7,7 +7,7 @@ OUT=gpurun_out/r02/prof_tiled
 mkdir -p $OUT
 rocprofv3 --output-format csv --kernel-trace --stats -d $OUT -o tb -- python tools/rhs_tiled_bench.py "$@" > $OUT/bench.log 2>&1
 grep -v simple_timer $OUT/bench.log | tail -8
-python - <<PY
+python profiles/sumtrace.py $OUT/tb_kernel_trace.csv; python - <<PY
 import csv, glob
 f = glob.glob("$OUT/**/*kernel_stats.csv", recursive=True)[0]
 for r in list(csv.DictReader(open(f)))[:14]:

@@ -41,10 +41,10 @@ class RhsPlan:
         self._h = handle
 
     def info(self):
-        out = (C.c_double * 10)()
+        out = (C.c_double * 11)()
         lib().rcppml_hip_rhs_plan_info(self._h, out)
         keys = ("partitions", "waves", "rounds", "slots", "workgroups_per_partition", "tiles", "slot_count", "spilled_nnz",
-                "fill", "stream_bytes")
+                "fill", "stream_bytes", "tiled_columns")
         return {k: (float(out[i]) if k == "fill" else int(out[i])) for i, k in enumerate(keys)}
 
     def close(self):

@@ -38,6 +38,7 @@ constexpr int RT_MAX_HIST = 32;
 
 struct RhsTiledGeom {
     int64_t ncols;        // columns of the sparse matrix = output columns
+    int64_t ncols_tiled;  // columns [0, ncols_tiled) go through the tiled kernel, the rest through the gather kernel
     int64_t nrows;        // rows of the sparse matrix = rows (k-vectors) of F
     int rowb;             // bytes per row of F (k * sizeof(T)), 256 or 512 ... multiple of 256
     int rshift;           // log2(rows per tile), rows per tile = 65536 / rowb
@@ -47,10 +48,10 @@ struct RhsTiledGeom {
     int nr;               // rounds per wave (4 columns each)
     int S;                // slots per (column, tile)
     int ncb;              // column blocks = workgroups per partition
-    int dbg;              // experiments: 1 = no compute, 2 = no LDS-DMA, 4 = no slot loads
+    int dbg;              // -DRCPPML_EXPERIMENTS builds only: 1 = no compute, 2 = no LDS-DMA, 4 = no slot loads
 };
 
-__device__ __forceinline__ int64_t rt_slot_index(const RhsTiledGeom& G, int64_t j, int tile, int rank) {
+__device__ __forceinline__ int64_t rt_slot_index(const RhsTiledGeom& G, int64_t j, int tile, int rank) {   // j < G.ncols_tiled
     const int cpw = 4 * G.nr;                 // columns per wave
     const int cpb = cpw * G.NW;               // columns per workgroup
     const int64_t cb = j / cpb;
@@ -97,7 +98,7 @@ __device__ __forceinline__ void rt_walk_column(const int* __restrict__ rowidx, i
 }
 
 // histogram of segment lengths (bins 1..RT_MAX_HIST-1, longer segments clamp into the last bin) + sortedness flag
-__global__ __launch_bounds__(256) void rhs_tiled_hist_kernel(const int* __restrict__ colptr, const int* __restrict__ rowidx,
+static __global__ __launch_bounds__(256) void rhs_tiled_hist_kernel(const int* __restrict__ colptr, const int* __restrict__ rowidx,
                                                              int64_t ncols, int rshift, unsigned long long* __restrict__ hist,
                                                              int* __restrict__ unsorted) {
     __shared__ unsigned int lh[RT_MAX_HIST];
@@ -118,7 +119,7 @@ __global__ __launch_bounds__(256) void rhs_tiled_hist_kernel(const int* __restri
 }
 
 // overflow nonzeros per column for a given S (feeds the exclusive scan that makes the overflow column pointers)
-__global__ __launch_bounds__(256) void rhs_tiled_ovcount_kernel(const int* __restrict__ colptr, const int* __restrict__ rowidx,
+static __global__ __launch_bounds__(256) void rhs_tiled_ovcount_kernel(const int* __restrict__ colptr, const int* __restrict__ rowidx,
                                                                 int64_t ncols, int rshift, int S, int* __restrict__ ovcnt) {
     const int64_t j = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (j >= ncols) return;
@@ -140,7 +141,7 @@ __global__ __launch_bounds__(256) void rhs_tiled_fill_kernel(const int* __restri
                                                              const int* __restrict__ ovptr, int* __restrict__ ovrow,
                                                              T* __restrict__ ovval) {
     const int64_t j = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (j >= G.ncols) return;
+    if (j >= G.ncols_tiled) return;
     const int start = colptr[j], end = colptr[j + 1];
     const int ob = ovptr ? ovptr[j] : 0;
     const int rmask = (1 << G.rshift) - 1;
@@ -182,26 +183,75 @@ template <class T> struct RtVec;
 template <> struct RtVec<float> { typedef float type __attribute__((ext_vector_type(4))); static constexpr int N = 4; };
 template <> struct RtVec<double> { typedef double type __attribute__((ext_vector_type(2))); static constexpr int N = 2; };
 
-__device__ __forceinline__ void rt_glds16(const char* gsrc, char* lds_dst_uniform) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                     (__attribute__((address_space(3))) void*)lds_dst_uniform, 16, 0, 0);
+// ---------------------------------------------------------------------------
+// Vector-memory traffic of the tile loop is issued from inline asm so that hipcc keeps NO vmcnt bookkeeping for it: with
+// compiler-visible loads it drains vmcnt(0) in the middle of the compute phase (observed: second batch of every tile),
+// which serialises the LDS-DMA of the next tile and the slot prefetch with the FMAs.  The waits are placed by hand
+// (rt_wait_vm<N>: loads return in order, so "all but the newest N" = the next tile's F and slots have landed while the
+// slots of the tile after it stay in flight).
+// ---------------------------------------------------------------------------
+// 16 bytes per lane, global (uniform base + per-lane 32-bit offset) -> LDS (uniform address in M0, lane-linear).
+// M0 is saved once before a run of these and restored after it (rt_m0_save / rt_m0_restore).
+__device__ __forceinline__ void rt_glds16(const char* base_uniform, unsigned lane_off, unsigned lds_addr_uniform) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                 :: "v"(lane_off), "s"(base_uniform), "s"(lds_addr_uniform) : "memory");
+}
+__device__ __forceinline__ unsigned rt_m0_save() {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0" : "=s"(keep));
+    return keep;
+}
+__device__ __forceinline__ void rt_m0_restore(unsigned keep) { asm volatile("s_mov_b32 m0, %0" ::"s"(keep)); }
+__device__ __forceinline__ void rt_load_val(float& dst, const char* base_uniform, unsigned lane_off) {
+    asm volatile("global_load_dword %0, %1, %2" : "=v"(dst) : "v"(lane_off), "s"(base_uniform) : "memory");
+}
+__device__ __forceinline__ void rt_load_val(double& dst, const char* base_uniform, unsigned lane_off) {
+    asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(dst) : "v"(lane_off), "s"(base_uniform) : "memory");
+}
+__device__ __forceinline__ void rt_load_u16(unsigned& dst, const char* base_uniform, unsigned lane_off) {
+    asm volatile("global_load_ushort %0, %1, %2" : "=v"(dst) : "v"(lane_off), "s"(base_uniform) : "memory");
+}
+template <int N> __device__ __forceinline__ void rt_wait_vm() {
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+// the registers of a slot set become readable only after the wait: tie them to it so no read can be hoisted above
+template <int N, class T, int NB> __device__ __forceinline__ void rt_wait_vm_tied(T (&v)[NB], unsigned (&o)[NB]) {
+    rt_wait_vm<N>();
+#pragma unroll
+    for (int b = 0; b < NB; ++b) asm volatile("" : "+v"(v[b]), "+v"(o[b]));
+}
+// s_waitcnt lgkmcnt(N) only
+template <int N> __device__ __forceinline__ void rt_wait_lgkm() {
+    static_assert(N >= 0 && N < 16, "lgkmcnt is a 4-bit counter");
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
 }
 
 // ---------------------------------------------------------------------------
 // The kernel.  NV = 256-byte slices per row of F (row bytes = 256 NV), S slots per (column, tile), NR = rounds per wave
 // (compile time: a runtime round count would put branches between the batches, and hipcc then sinks the FMAs of every
-// batch below them and spills), UB = steps per batch of LDS reads (UB reads in flight per wave and slice).
+// batch below them and spills), NW = waves per workgroup (12 or 16: whole waves per SIMD; register budget 168 / 128).
 // grid = P * ncb workgroups of 64*NW threads, 128 KiB of dynamic LDS (one workgroup per CU).
+//
+// Tile t of a partition: [slots(t) -> working copy] [issue LDS-DMA of tile t+1 into the other buffer: every wave copies
+// its own contiguous run of KiB-chunks] [issue the slot loads of tile t+2] [compute tile t: LDS reads of batch b+1 are
+// issued before the FMAs of batch b, one lgkmcnt wait per batch] [vmcnt: tile t+1 and slots(t+1) landed] [barrier].
+// The loop is issue-bound (rocprofv3: SIMDs > 85 % busy), so everything around the five instructions of a step is kept
+// off the per-tile path: no guards or clamps in the copy (a short last tile takes a separate branch), no M0 save per
+// chunk, one LDS wait per batch.
 // ---------------------------------------------------------------------------
-template <class T, int NV, int S, int NR, int UB>
-__global__ __launch_bounds__(1024) void rhs_tiled_kernel(const T* __restrict__ svals, const uint16_t* __restrict__ soffs,
-                                                         const T* __restrict__ F, RhsTiledGeom G,
-                                                         const T* __restrict__ Binit, T* __restrict__ Bout) {
+template <class T, int NV, int S, int NR, int NW>
+__global__ __launch_bounds__(64 * NW) void rhs_tiled_kernel(const T* __restrict__ svals, const uint16_t* __restrict__ soffs,
+                                                            const T* __restrict__ F, RhsTiledGeom G,
+                                                            const T* __restrict__ Binit, T* __restrict__ Bout) {
     typedef typename RtVec<T>::type V;
     constexpr int VN = RtVec<T>::N;
     constexpr int NST = NR * S;                 // steps per (wave, tile)
     constexpr int NB = (NST + 15) / 16;         // coalesced slot loads per (wave, tile)
-    static_assert(NST % UB == 0, "whole batches");
+    constexpr int UB = NV == 1 ? 4 : 2;         // steps per batch of LDS reads; two batches in flight
+    constexpr int NBATCH = (NST + UB - 1) / UB;
+    constexpr int NCH = RT_SLAB_BYTES / 1024;   // KiB-chunks per tile
+    constexpr int CBASE = NCH / NW, CEXTRA = NCH % NW;
     extern __shared__ char rt_slab[];           // 2 x 64 KiB
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -209,17 +259,18 @@ __global__ __launch_bounds__(1024) void rhs_tiled_kernel(const T* __restrict__ s
     const int p = blockIdx.x % G.P;
     const int64_t cb = blockIdx.x / G.P;
     const int t0 = (int)((int64_t)G.ntiles * p / G.P), t1 = (int)((int64_t)G.ntiles * (p + 1) / G.P);
-    const int64_t col0 = (cb * G.NW + w) * (int64_t)(4 * NR);       // first column of this wave
+    const int64_t col0 = (cb * NW + w) * (int64_t)(4 * NR);       // first column of this wave
     const int k = G.rowb / (int)sizeof(T);
     const int64_t fbytes = G.nrows * (int64_t)G.rowb;
     const char* Fb = reinterpret_cast<const char*>(F);
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)rt_slab;
 
     V acc[NR][NV];
     if (Binit != nullptr) {
 #pragma unroll
         for (int q = 0; q < NR; ++q) {
             int64_t j = col0 + 4 * q + g;
-            j = j < G.ncols ? j : G.ncols - 1;          // columns past the end are never stored
+            j = j < G.ncols_tiled ? j : G.ncols_tiled - 1;          // columns past the end are never stored
 #pragma unroll
             for (int v = 0; v < NV; ++v) acc[q][v] = *reinterpret_cast<const V*>(Binit + j * k + (64 * v + 4 * u) * 4 / (int)sizeof(T));
         }
@@ -231,99 +282,193 @@ __global__ __launch_bounds__(1024) void rhs_tiled_kernel(const T* __restrict__ s
 #pragma unroll
                 for (int e = 0; e < VN; ++e) acc[q][v][e] = T(0);
     }
+    // Make hipcc settle its OWN vmcnt bookkeeping here: a use of every accumulator forces its wait for the Binit loads now.
+    // Left pending, that bookkeeping follows the accumulators into the tile loop as `s_waitcnt vmcnt(7..4)` before the first
+    // FMA of every batch -- which, with the asm loads below in flight (invisible to hipcc), waits for the next tile's LDS-DMA
+    // in the middle of the compute phase.
+#pragma unroll
+    for (int q = 0; q < NR; ++q)
+#pragma unroll
+        for (int v = 0; v < NV; ++v) asm volatile("" : "+v"(acc[q][v]));
+    rt_wait_vm<0>();
 
-    const int lane16 = lane * 16;
+    // this wave's run of KiB-chunks of every tile: CBASE of them, one more for the first CEXTRA waves
+    const int cstart = w * CBASE + (w < CEXTRA ? w : CEXTRA);
+    const unsigned choff = (unsigned)cstart * 1024u + (unsigned)lane * 16u;
+    const unsigned m0keep = rt_m0_save();
     auto slab_load = [&](int tile, int buf) {
         const int64_t base = (int64_t)tile * RT_SLAB_BYTES;
-        const int64_t left = fbytes - base;                                 // the last tile may be short: stay inside F
-        const int lim = (int)(left < RT_SLAB_BYTES ? left : RT_SLAB_BYTES) - 16;
         const char* src0 = Fb + base;
+        const unsigned ldst = lds0 + buf * RT_SLAB_BYTES + cstart * 1024;
+        if (fbytes - base >= RT_SLAB_BYTES) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {                                       // NW >= 8: at most 8 KiB-chunks per wave
-            const int c = w + i * G.NW;
-            if (c < RT_SLAB_BYTES / 1024) {
-                int o = c * 1024 + lane16;
-                o = o < lim ? o : lim;
-                rt_glds16(src0 + o, rt_slab + buf * RT_SLAB_BYTES + c * 1024);
+            for (int i = 0; i < CBASE; ++i) rt_glds16(src0, choff + i * 1024, ldst + i * 1024);
+            if (CEXTRA > 0 && w < CEXTRA) rt_glds16(src0, choff + CBASE * 1024, ldst + CBASE * 1024);
+        } else {                                                            // short last tile: stay inside F
+            const unsigned lim = (unsigned)(fbytes - base) - 16u;
+#pragma unroll
+            for (int i = 0; i < CBASE + (CEXTRA > 0 ? 1 : 0); ++i) {
+                if (i < CBASE || w < CEXTRA) {
+                    unsigned o = choff + i * 1024;
+                    o = o < lim ? o : lim;
+                    rt_glds16(src0, o, ldst + i * 1024);
+                }
             }
         }
     };
-    // slot stream: [column block][tile][wave][step][lane group]; one tile further = NW * NST * 4 slots further
-    const int64_t tstride = (int64_t)G.NW * NST * 4;
-    const T* svp = svals + ((cb * G.ntiles + t0) * G.NW + w) * (int64_t)(NST * 4) + g;
-    const uint16_t* sop = soffs + ((cb * G.ntiles + t0) * G.NW + w) * (int64_t)(NST * 4) + g;
-    int loff[NB];
-#pragma unroll
-    for (int b = 0; b < NB; ++b) {
-        const int step = 16 * b + u;
-        loff[b] = (step < NST ? step : 0) * 4;      // lanes past the last step re-read step 0; their rounds do not exist
-    }
-    T sv[NB];
-    int so[NB];
-    auto slots_load = [&]() {
-        // the values are NOT touched here -- any use would make hipcc drain vmcnt (and with it the LDS-DMA) on the spot
+    // slot stream: [column block][tile][wave][step][lane group]; one tile further = NW * NST * 4 slots further.
+    // Lanes of a block past the wave's last step read into the next wave's slots (the allocation is padded by one block);
+    // those steps are never executed.
+    constexpr int64_t tstride = (int64_t)NW * NST * 4;
+    const int64_t slot0 = ((cb * G.ntiles + t0) * NW + w) * (int64_t)(NST * 4);
+    const char* svp = reinterpret_cast<const char*>(svals + slot0);
+    const char* sop = reinterpret_cast<const char*>(soffs + slot0);
+    const unsigned lv = (u * 4 + g) * (unsigned)sizeof(T), lo = (u * 4 + g) * 2u;
+    auto slots_issue = [&](T (&v)[NB], unsigned (&o)[NB]) {
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
-            sv[b] = svp[loff[b]];
-            so[b] = sop[loff[b]];
+            rt_load_val(v[b], svp + b * 64 * (int)sizeof(T), lv);
+            rt_load_u16(o[b], sop + b * 64 * 2, lo);
         }
-        svp += tstride;
-        sop += tstride;
+        svp += tstride * (int64_t)sizeof(T);
+        sop += tstride * 2;
     };
-
-    if (t0 < t1) {
-        slab_load(t0, 0);
-        slots_load();
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    for (int t = t0; t < t1; ++t) {
-        const int buf = (t - t0) & 1;
-        T cv[NB];
-        int co[NB];
-#pragma unroll
-        for (int b = 0; b < NB; ++b) { cv[b] = sv[b]; co[b] = so[b]; }
-        if (t + 1 < t1) {
-            if (!(G.dbg & 2)) slab_load(t + 1, buf ^ 1);
-            if (!(G.dbg & 4)) slots_load();
-        }
+    auto compute = [&](const T (&cv)[NB], const unsigned (&co)[NB], int buf) {
         const int lbase = buf * RT_SLAB_BYTES + u * 16;
-        if (!(G.dbg & 1))
-        rt_static_for<0, NST / UB>([&](auto QB) {
-            constexpr int s0 = decltype(QB)::value * UB;
-            V f[UB][NV];
+        V f[2][UB][NV];
+        auto reads = [&](auto QB) {
+            constexpr int b = decltype(QB)::value;
             rt_static_for<0, UB>([&](auto I) {
                 constexpr int i = decltype(I)::value;
-                constexpr int step = s0 + i;
-                const int a = lbase + rt_bc<(step & 15)>(co[step >> 4]);
+                constexpr int step = b * UB + i;
+                if constexpr (step < NST) {
+                    const int a = lbase + rt_bc<(step & 15)>((int)co[step >> 4]);
 #pragma unroll
-                for (int v = 0; v < NV; ++v) f[i][v] = *reinterpret_cast<const V*>(rt_slab + a + 256 * v);
+                    for (int v = 0; v < NV; ++v) f[b & 1][i][v] = *reinterpret_cast<const V*>(rt_slab + a + 256 * v);
+                }
             });
+        };
+        reads(std::integral_constant<int, 0>{});
+        rt_static_for<0, NBATCH>([&](auto QB) {
+            constexpr int b = decltype(QB)::value;
+            constexpr int nnext = (b + 1 < NBATCH) ? ((NST - (b + 1) * UB) < UB ? (NST - (b + 1) * UB) : UB) * NV : 0;
+            if constexpr (b + 1 < NBATCH) reads(std::integral_constant<int, b + 1>{});
             __builtin_amdgcn_sched_barrier(0);
+            rt_wait_lgkm<nnext>();                  // LDS returns in order: everything but the reads just issued is back
             rt_static_for<0, UB>([&](auto I) {
                 constexpr int i = decltype(I)::value;
-                constexpr int step = s0 + i;
-                const T val = rt_bcast_val<(step & 15)>(cv[step >> 4]);
+                constexpr int step = b * UB + i;
+                if constexpr (step < NST) {
+                    const T val = rt_bcast_val<(step & 15)>(cv[step >> 4]);
 #pragma unroll
-                for (int v = 0; v < NV; ++v)
+                    for (int v = 0; v < NV; ++v)
 #pragma unroll
-                    for (int e = 0; e < VN; ++e) acc[step / S][v][e] = rt_fma(val, f[i][v][e], acc[step / S][v][e]);
+                        for (int e = 0; e < VN; ++e) acc[step / S][v][e] = rt_fma(val, f[b & 1][i][v][e], acc[step / S][v][e]);
+                }
             });
             __builtin_amdgcn_sched_barrier(0);
         });
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next tile (LDS-DMA) and the next slots have landed
-        __syncthreads();
+    };
+
+    T sv0[NB], sv1[NB];
+    unsigned so0[NB], so1[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) { sv0[b] = sv1[b] = T(0); so0[b] = so1[b] = 0; }
+    if (t0 < t1) {
+        slab_load(t0, 0);
+        slots_issue(sv0, so0);
+        if (t0 + 1 < t1) slots_issue(sv1, so1);
     }
+    rt_wait_vm_tied<0>(sv0, so0);
+    rt_wait_vm_tied<0>(sv1, so1);
+    __builtin_amdgcn_s_barrier();
+    // one tile; `cur` holds its slots (landed), `nxt` the following tile's (landed at the end of this tile)
+    auto tile = [&](int t, int buf, T (&cur_v)[NB], unsigned (&cur_o)[NB], T (&nxt_v)[NB], unsigned (&nxt_o)[NB]) {
+        T cv[NB];
+        unsigned co[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) { cv[b] = cur_v[b]; co[b] = cur_o[b]; }
+#pragma unroll
+        for (int b = 0; b < NB; ++b) asm volatile("" : "+v"(cv[b]), "+v"(co[b]));      // the copy is made HERE, before the reload
+#ifdef RCPPML_EXPERIMENTS
+        if (t + 1 < t1 && !(G.dbg & 2)) slab_load(t + 1, buf ^ 1);
+        const bool more = t + 2 < t1 && !(G.dbg & 4);
+        if (more) slots_issue(cur_v, cur_o);
+        if (!(G.dbg & 1)) compute(cv, co, buf);
+#else
+        if (t + 1 < t1) slab_load(t + 1, buf ^ 1);
+        const bool more = t + 2 < t1;
+        if (more) slots_issue(cur_v, cur_o);
+        compute(cv, co, buf);
+#endif
+        if (more) rt_wait_vm_tied<2 * NB>(nxt_v, nxt_o);
+        else rt_wait_vm_tied<0>(nxt_v, nxt_o);
+        rt_wait_lgkm<0>();
+        __builtin_amdgcn_s_barrier();
+    };
+    for (int t = t0; t < t1; t += 2) {
+        tile(t, 0, sv0, so0, sv1, so1);
+        if (t + 1 < t1) tile(t + 1, 1, sv1, so1, sv0, so0);
+    }
+    rt_m0_restore(m0keep);
 
 #pragma unroll
     for (int q = 0; q < NR; ++q) {
         const int64_t j = col0 + 4 * q + g;
-        if (j < G.ncols) {
-            T* dst = Bout + (int64_t)p * G.ncols * k + j * k;
+        if (j < G.ncols_tiled) {
+            T* dst = Bout + (int64_t)p * G.ncols_tiled * k + j * k;
 #pragma unroll
             for (int v = 0; v < NV; ++v) *reinterpret_cast<V*>(dst + (64 * v + 4 * u) * 4 / (int)sizeof(T)) = acc[q][v];
         }
     }
+}
+
+// ---------------------------------------------------------------------------
+// The spilled nonzeros (overflow CSC: about a dozen per column at C2).  One 16-lane group per column -- a whole row of
+// F per gather, no cross-lane reduction -- and U gathers in flight per lane; writes every column of B (zeros where
+// nothing spilled), which then seeds the accumulators of rhs_tiled_kernel.
+// ---------------------------------------------------------------------------
+template <class T, int NV, int U>
+__global__ __launch_bounds__(256) void rhs_tiled_spill_kernel(const int* __restrict__ ovptr, const int* __restrict__ ovrow,
+                                                              const T* __restrict__ ovval, int64_t ncols,
+                                                              const T* __restrict__ F, int k, T* __restrict__ B) {
+    typedef typename RtVec<T>::type V;
+    constexpr int VN = RtVec<T>::N;
+    const int64_t j = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+    if (j >= ncols) return;
+    const int u = threadIdx.x & 15;
+    const int start = ovptr[j], end = ovptr[j + 1];
+    V acc[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+#pragma unroll
+        for (int e = 0; e < VN; ++e) acc[v][e] = T(0);
+    const T* Fl = F + (4 * u) * 4 / (int)sizeof(T);
+    for (int i = start; i < end; i += U) {
+        int r[U];
+        T a[U];
+#pragma unroll
+        for (int x = 0; x < U; ++x) {
+            const int ii = i + x < end ? i + x : end - 1;
+            r[x] = ovrow[ii];
+            const T av = ovval[ii];
+            a[x] = i + x < end ? av : T(0);
+        }
+        V f[U][NV];
+#pragma unroll
+        for (int x = 0; x < U; ++x)
+#pragma unroll
+            for (int v = 0; v < NV; ++v) f[x][v] = *reinterpret_cast<const V*>(Fl + (int64_t)r[x] * k + 64 * v * 4 / (int)sizeof(T));
+#pragma unroll
+        for (int x = 0; x < U; ++x)
+#pragma unroll
+            for (int v = 0; v < NV; ++v)
+#pragma unroll
+                for (int e = 0; e < VN; ++e) acc[v][e] = rt_fma(a[x], f[x][v][e], acc[v][e]);
+    }
+    T* dst = B + j * k + (4 * u) * 4 / (int)sizeof(T);
+#pragma unroll
+    for (int v = 0; v < NV; ++v) *reinterpret_cast<V*>(dst + 64 * v * 4 / (int)sizeof(T)) = acc[v];
 }
 
 // B (+)= sum_p Bp[p], partition order (deterministic)

@@ -5,27 +5,9 @@
 #include <hipcub/hipcub.hpp>
 #include <memory>
 #include <mutex>
-#include "common.hip.h"
-#include "kernels_rhs_tiled.hip.h"
+#include "rhs_tiled_launch.hip.h"
 
 using namespace rk;
-
-struct rcppml_rhs_plan {
-    int dtype = 0, k = 0, device = 0;
-    RhsTiledGeom G{};
-    void* svals = nullptr;
-    uint16_t* soffs = nullptr;
-    int* ovptr = nullptr;
-    int* ovrow = nullptr;
-    void* ovval = nullptr;
-    void* Bp = nullptr;          // P > 1: per-partition partial outputs
-    int64_t ovnnz = 0, nnz = 0, nslots = 0;
-    double ov_fraction = 0.0, fill = 0.0;
-    ~rcppml_rhs_plan() {
-        for (void* p : {svals, (void*)soffs, (void*)ovptr, (void*)ovrow, ovval, Bp})
-            if (p) (void)hipFree(p);
-    }
-};
 
 namespace {
 
@@ -35,93 +17,31 @@ struct Tmp {
     ~Tmp() { if (p) (void)hipFree(p); }
 };
 
-constexpr int RT_DYN_LDS = 2 * RT_SLAB_BYTES;
-
-template <class K>
-void set_lds_once(K kernel, int device) {
-    // per-device attribute, set to the one size this kernel ever asks for; serialised (concurrent fits from host threads)
-    static std::mutex mu;
-    static bool done[64] = {};
-    std::lock_guard<std::mutex> lk(mu);
-    if (!done[device & 63]) {
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, RT_DYN_LDS));
-        done[device & 63] = true;
-    }
-}
-
-// compiled (S, NR) shapes.  NV = 1 (256-byte rows): S in {2,3,4,5} x NR in {4,6,8,10,12}, S in {6,8} x NR in {4,6,8};
-// NV = 2 (512-byte rows): S in {2,3,4,5,6,8} x NR in {2,4,6}.  UB = steps per batch of LDS reads: 8 reads of 16 bytes in flight per lane where the step count divides.
-constexpr int rt_ub(int S, int NR, int NV) {
-    int best = 1;
-    for (int d = 1; d <= NR * S; ++d)
-        if ((NR * S) % d == 0 && d * NV <= (NV == 1 ? (S == 5 && NR == 12 ? 5 : 8) : 6)) best = d;
-    return best;
-}
-inline bool rt_shape_ok(int NV, int S, int NR) {
-    const bool s_ok = S == 2 || S == 3 || S == 4 || S == 5 || S == 6 || S == 8;
-    if (!s_ok) return false;
-    if (NV == 1) return (S <= 5) ? (NR == 4 || NR == 6 || NR == 8 || NR == 10 || NR == 12) : (NR == 4 || NR == 6 || NR == 8);
-    if (NV == 2) return NR == 2 || NR == 4 || NR == 6;
-    return false;
-}
-
-template <class T, int NV, int S, int NR>
-void launch_tiled(rcppml_hip_ctx* c, const rcppml_rhs_plan* pl, const T* F, const T* Binit, T* Bout) {
-    constexpr int UB = rt_ub(S, NR, NV);
-    auto kern = rhs_tiled_kernel<T, NV, S, NR, UB>;
-    set_lds_once(kern, c->device);
-    const RhsTiledGeom& G = pl->G;
-    hipLaunchKernelGGL(kern, dim3((unsigned)(G.P * G.ncb)), dim3(64 * G.NW), RT_DYN_LDS, c->stream,
-                       (const T*)pl->svals, (const uint16_t*)pl->soffs, F, G, Binit, Bout);
-    HIPCHK(hipGetLastError());
-}
-template <class T, int NV, int S>
-void launch_tiled_nr(rcppml_hip_ctx* c, const rcppml_rhs_plan* pl, const T* F, const T* Binit, T* Bout) {
-    const int nr = pl->G.nr;
-    if constexpr (NV == 1) {
-        if (nr == 4) return launch_tiled<T, NV, S, 4>(c, pl, F, Binit, Bout);
-        if (nr == 6) return launch_tiled<T, NV, S, 6>(c, pl, F, Binit, Bout);
-        if (nr == 8) return launch_tiled<T, NV, S, 8>(c, pl, F, Binit, Bout);
-        if constexpr (S <= 5) {
-            if (nr == 10) return launch_tiled<T, NV, S, 10>(c, pl, F, Binit, Bout);
-            if (nr == 12) return launch_tiled<T, NV, S, 12>(c, pl, F, Binit, Bout);
-        }
-    } else {
-        if (nr == 2) return launch_tiled<T, NV, S, 2>(c, pl, F, Binit, Bout);
-        if (nr == 4) return launch_tiled<T, NV, S, 4>(c, pl, F, Binit, Bout);
-        if (nr == 6) return launch_tiled<T, NV, S, 6>(c, pl, F, Binit, Bout);
-    }
-    throw std::runtime_error("rhs_planned: unsupported round count");
-}
-template <class T, int NV>
-void launch_tiled_s(rcppml_hip_ctx* c, const rcppml_rhs_plan* pl, const T* F, const T* Binit, T* Bout) {
-    switch (pl->G.S) {
-        case 2: launch_tiled_nr<T, NV, 2>(c, pl, F, Binit, Bout); break;
-        case 3: launch_tiled_nr<T, NV, 3>(c, pl, F, Binit, Bout); break;
-        case 4: launch_tiled_nr<T, NV, 4>(c, pl, F, Binit, Bout); break;
-        case 5: launch_tiled_nr<T, NV, 5>(c, pl, F, Binit, Bout); break;
-        case 6: launch_tiled_nr<T, NV, 6>(c, pl, F, Binit, Bout); break;
-        case 8: launch_tiled_nr<T, NV, 8>(c, pl, F, Binit, Bout); break;
-        default: throw std::runtime_error("rhs_planned: unsupported slot count");
-    }
-}
-
 template <class T>
 void run_plan(rcppml_hip_ctx* c, const rcppml_rhs_plan* pl, const T* F, T* B) {
     const RhsTiledGeom& G = pl->G;
     const bool ov = pl->ovnnz > 0;
-    if (ov) {          // the spilled nonzeros first: their sums seed the accumulators
-        if (rcppml_hip_rhs(c, pl->dtype, pl->ovptr, pl->ovrow, pl->ovval, G.ncols, F, pl->k, B) != 0)
-            throw std::runtime_error("rhs_planned: overflow pass: " + rcppml_err());
+    const int64_t nt = G.ncols_tiled;
+    if (nt < G.ncols) {          // tail columns (those that do not fill a whole round of workgroups): gather kernel
+        if (rcppml_hip_rhs(c, pl->dtype, pl->colptr + nt, pl->rowidx, pl->vals, G.ncols - nt, F, pl->k, B + nt * pl->k) != 0)
+            throw std::runtime_error("rhs_planned: tail columns: " + rcppml_err());
     }
-    const int NV = G.rowb / 256;
+    if (ov) {          // the spilled nonzeros first: their sums seed the accumulators
+        const unsigned grid = (unsigned)((nt + 15) / 16);
+        if (G.rowb == 256)
+            hipLaunchKernelGGL((rhs_tiled_spill_kernel<T, 1, 4>), dim3(grid), dim3(256), 0, c->stream, (const int*)pl->ovptr,
+                               (const int*)pl->ovrow, (const T*)pl->ovval, nt, F, pl->k, B);
+        else
+            hipLaunchKernelGGL((rhs_tiled_spill_kernel<T, 2, 4>), dim3(grid), dim3(256), 0, c->stream, (const int*)pl->ovptr,
+                               (const int*)pl->ovrow, (const T*)pl->ovval, nt, F, pl->k, B);
+        HIPCHK(hipGetLastError());
+    }
     const T* Binit = (G.P == 1 && ov) ? B : nullptr;
     T* Bout = G.P == 1 ? B : (T*)pl->Bp;
-    if (NV == 1) launch_tiled_s<T, 1>(c, pl, F, Binit, Bout);
-    else if (NV == 2) launch_tiled_s<T, 2>(c, pl, F, Binit, Bout);
-    else throw std::runtime_error("rhs_planned: unsupported row size");
+    if constexpr (std::is_same<T, float>::value) rcppml_rt_launch_f32(c, pl, F, Binit, Bout);
+    else rcppml_rt_launch_f64(c, pl, F, Binit, Bout);
     if (G.P > 1) {
-        const int64_t n4 = G.ncols * pl->k / RtVec<T>::N;
+        const int64_t n4 = nt * pl->k / RtVec<T>::N;
         hipLaunchKernelGGL(rhs_tiled_reduce_kernel<T>, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, c->stream,
                            (const T*)pl->Bp, G.P, n4, ov ? 1 : 0, B);
         HIPCHK(hipGetLastError());
@@ -129,8 +49,9 @@ void run_plan(rcppml_hip_ctx* c, const rcppml_rhs_plan* pl, const T* F, T* B) {
 }
 
 template <class T>
-rcppml_rhs_plan* build_plan(rcppml_hip_ctx* c, int dtype, const int* colptr, const int* rowidx, const T* vals, int64_t ncols,
+rcppml_rhs_plan* build_plan(rcppml_hip_ctx* c, int dtype, const int* colptr, const int* rowidx, const T* vals, int64_t ncols_in,
                             int64_t nrows, int k, int partitions, int force_S) {
+    int64_t ncols = ncols_in;
     const int rowb = k * (int)sizeof(T);
     if (rowb != 256 && rowb != 512) return nullptr;               // rows of one or two 256-byte slices
     if (ncols <= 0 || nrows <= 0) return nullptr;
@@ -182,29 +103,60 @@ rcppml_rhs_plan* build_plan(rcppml_hip_ctx* c, int dtype, const int* colptr, con
         S = force_S;
     }
     G.S = S;
+    G.dbg = 0;
+#ifdef RCPPML_EXPERIMENTS
     { const char* e = getenv("RCPPML_RT_DBG"); G.dbg = e ? atoi(e) : 0; }
-    // workgroup shape: as close to one workgroup per CU (per partition: num_cu / P) as the column count allows
+#endif
+    // Workgroup shape (NW waves x NR rounds, 4 NR NW columns per workgroup) and how many columns go through the tiles.
+    // Model (cycles per SIMD and tile, fitted to rocprofv3 on C2): waves per SIMD x (fixed 250 + 24 per step); workgroups
+    // run in rounds of num_cu / P.  Columns that would only fill part of a last round are cheaper in the gather kernel
+    // (12.5 ps per nonzero on the whole chip) than as a round of their own.
     const int NV = rowb / 256;
-    const int64_t want_wg = std::max<int64_t>(1, c->num_cu / P);
-    const int64_t need = (ncols + want_wg - 1) / want_wg;         // columns per workgroup
+    const int64_t conc = std::max<int64_t>(1, c->num_cu / P);                 // workgroups of one partition resident at once
+    const double tiles_pp = (double)G.ntiles / P;
+    const double nnz_per_col = (double)pl->nnz / (double)ncols;
+    double best_t = -1;
     int bestNW = 0, bestnr = 0;
-    int64_t bestcap = -1, maxcap = -1;
-    int maxNW = 0, maxnr = 0;
-    for (int NW = 16; NW >= 8; --NW)
-        for (int nr = 1; nr <= 12; ++nr) {
-            if (!rt_shape_ok(NV, S, nr)) continue;
+    int64_t best_tiled = 0;
+    for (int NW = 16; NW >= 12; NW -= 4)
+        for (int nr = 2; nr <= 20; ++nr) {
+            if (!rt_launch::shape_ok(NV, S, NW, nr)) continue;
             const int64_t cap = 4ll * nr * NW;
-            if (cap >= need && (bestcap < 0 || cap < bestcap)) { bestcap = cap; bestNW = NW; bestnr = nr; }
-            if (cap > maxcap) { maxcap = cap; maxNW = NW; maxnr = nr; }
+            const double t_wg = tiles_pp * (NW / 4) * (250.0 + 24.0 * nr * S) / 2400.0 + 15.0;       // microseconds
+            const int64_t full_rounds = ncols / (cap * conc);
+            for (int opt = 0; opt < 2; ++opt) {
+                int64_t tiled;
+                double t;
+                if (opt == 0) {                       // every column through the tiles
+                    tiled = ncols;
+                    const int64_t ncb = (ncols + cap - 1) / cap;
+                    t = (double)((ncb + conc - 1) / conc) * t_wg;
+                } else {                              // whole rounds only, the rest to the gather kernel
+                    if (full_rounds < 1) continue;
+                    tiled = full_rounds * cap * conc;
+                    t = (double)full_rounds * t_wg + 5.0 + (double)(ncols - tiled) * nnz_per_col * 12.5e-6;
+                }
+                if (best_t < 0 || t < best_t) { best_t = t; bestNW = NW; bestnr = nr; best_tiled = tiled; }
+            }
         }
-    if (bestcap < 0) { bestNW = maxNW; bestnr = maxnr; bestcap = maxcap; }        // more workgroups than CUs
+    if (best_t < 0) return nullptr;
+#ifdef RCPPML_EXPERIMENTS
+    { const char* e1 = getenv("RCPPML_RT_NW"); const char* e2 = getenv("RCPPML_RT_NR");
+      if (e1 && e2 && rt_launch::shape_ok(NV, S, atoi(e1), atoi(e2))) { bestNW = atoi(e1); bestnr = atoi(e2); best_tiled = ncols; } }
+#endif
+    const int64_t bestcap = 4ll * bestnr * bestNW;
     G.NW = bestNW; G.nr = bestnr;
-    G.ncb = (int)((ncols + bestcap - 1) / bestcap);
+    G.ncols_tiled = best_tiled;
+    G.ncb = (int)((best_tiled + bestcap - 1) / bestcap);
+    pl->colptr = colptr; pl->rowidx = rowidx; pl->vals = vals;
+    const int64_t ncols_all = ncols;
+    ncols = best_tiled;                                   // from here on: the tiled columns only
+    const unsigned gcol2 = (unsigned)((ncols + 3) / 4);
 
     // overflow column pointers
     Tmp cnt(((size_t)ncols + 1) * sizeof(int));
     HIPCHK(hipMemsetAsync(cnt.p, 0, ((size_t)ncols + 1) * sizeof(int), c->stream));
-    hipLaunchKernelGGL(rhs_tiled_ovcount_kernel, dim3(gcol), dim3(256), 0, c->stream, colptr, rowidx, ncols, G.rshift, S, (int*)cnt.p);
+    hipLaunchKernelGGL(rhs_tiled_ovcount_kernel, dim3(gcol2), dim3(256), 0, c->stream, colptr, rowidx, ncols, G.rshift, S, (int*)cnt.p);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMalloc((void**)&pl->ovptr, ((size_t)ncols + 1) * sizeof(int)));
     {
@@ -217,25 +169,32 @@ rcppml_rhs_plan* build_plan(rcppml_hip_ctx* c, int dtype, const int* colptr, con
         HIPCHK(hipStreamSynchronize(c->stream));
         pl->ovnnz = ovn;
     }
+    (void)ncols_all;
     pl->ov_fraction = (double)pl->ovnnz / (double)pl->nnz;
     if (force_S <= 0 && pl->ov_fraction > 0.35) return nullptr;   // too irregular for fixed slots: the gather kernel is the better tool
     pl->nslots = (int64_t)G.ncb * G.ntiles * G.NW * (int64_t)(G.nr * S) * 4;
     pl->fill = (double)(pl->nnz - pl->ovnnz) / (double)pl->nslots;
-    HIPCHK(hipMalloc(&pl->svals, (size_t)pl->nslots * sizeof(T)));
-    HIPCHK(hipMalloc((void**)&pl->soffs, (size_t)pl->nslots * sizeof(uint16_t)));
-    HIPCHK(hipMemsetAsync(pl->svals, 0, (size_t)pl->nslots * sizeof(T), c->stream));
-    HIPCHK(hipMemsetAsync(pl->soffs, 0, (size_t)pl->nslots * sizeof(uint16_t), c->stream));
+    // one block of 64 slots of padding: the last wave's partial block loads run past its last step (never consumed)
+    const size_t nalloc = (size_t)pl->nslots + 64;
+    HIPCHK(hipMalloc(&pl->svals, nalloc * sizeof(T)));
+    HIPCHK(hipMalloc((void**)&pl->soffs, nalloc * sizeof(uint16_t)));
+    HIPCHK(hipMemsetAsync(pl->svals, 0, nalloc * sizeof(T), c->stream));
+    HIPCHK(hipMemsetAsync(pl->soffs, 0, nalloc * sizeof(uint16_t), c->stream));
     HIPCHK(hipMalloc((void**)&pl->ovrow, (size_t)std::max<int64_t>(pl->ovnnz, 1) * sizeof(int)));
     HIPCHK(hipMalloc(&pl->ovval, (size_t)std::max<int64_t>(pl->ovnnz, 1) * sizeof(T)));
-    hipLaunchKernelGGL(rhs_tiled_fill_kernel<T>, dim3(gcol), dim3(256), 0, c->stream, colptr, rowidx, vals, G, (T*)pl->svals,
+    hipLaunchKernelGGL(rhs_tiled_fill_kernel<T>, dim3(gcol2), dim3(256), 0, c->stream, colptr, rowidx, vals, G, (T*)pl->svals,
                        pl->soffs, (const int*)pl->ovptr, pl->ovrow, (T*)pl->ovval);
     HIPCHK(hipGetLastError());
-    if (G.P > 1) HIPCHK(hipMalloc(&pl->Bp, (size_t)G.P * (size_t)ncols * (size_t)k * sizeof(T)));
+    if (G.P > 1) HIPCHK(hipMalloc(&pl->Bp, (size_t)G.P * (size_t)ncols * (size_t)k * sizeof(T)));     // ncols = tiled columns
     HIPCHK(hipStreamSynchronize(c->stream));          // temporaries die here
     return pl.release();
 }
 
 }  // namespace
+
+void rcppml_rt_launch_f32(rcppml_hip_ctx* c, const rcppml_rhs_plan* pl, const float* F, const float* Binit, float* Bout) {
+    rt_launch::launch_tiled_any<float>(c, pl, F, Binit, Bout);
+}
 
 extern "C" int rcppml_hip_rhs_plan_create(rcppml_hip_ctx* c, int dtype, const int* col_ptr, const int* row_idx,
                                           const void* values, int64_t ncols, int64_t nrows, int k, int partitions, int slots,
@@ -254,11 +213,12 @@ extern "C" int rcppml_hip_rhs_plan_create(rcppml_hip_ctx* c, int dtype, const in
 
 extern "C" void rcppml_hip_rhs_plan_destroy(rcppml_rhs_plan* plan) { delete plan; }
 
-extern "C" int rcppml_hip_rhs_plan_info(const rcppml_rhs_plan* pl, double* out10) {
+extern "C" int rcppml_hip_rhs_plan_info(const rcppml_rhs_plan* pl, double* out10 /* 11 doubles */) {
     if (!pl || !out10) return 1;
     const RhsTiledGeom& G = pl->G;
     out10[0] = G.P; out10[1] = G.NW; out10[2] = G.nr; out10[3] = G.S; out10[4] = G.ncb; out10[5] = G.ntiles;
     out10[6] = (double)pl->nslots; out10[7] = (double)pl->ovnnz; out10[8] = pl->fill;
+    out10[10] = (double)G.ncols_tiled;
     out10[9] = (double)pl->nslots * ((pl->dtype == RCPPML_F32 ? 4 : 8) + 2);      // bytes of the slot stream
     return 0;
 }

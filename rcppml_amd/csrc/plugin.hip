@@ -238,12 +238,21 @@ void fit(FitParams& P) {
 
     // All device work of one ALS iteration, enqueued on the fit's stream (ends with the loss terms in dloss).
     // B = F * A (columns of A) / B = F * A^T (rows of A): CSC gather kernels, or GEMMs for a dense A
+    // Large sparse inputs: the LDS row-tiled form (kernels_rhs_tiled.hip.h), planned once per fit for each side; NULL
+    // plans (small input, rank or layout the kernel is not compiled for) keep the gather kernel.
+    struct PlanGuard { rcppml_rhs_plan* p = nullptr; ~PlanGuard() { rcppml_hip_rhs_plan_destroy(p); } } planA, planT;
+    if (!dense && P.nnz >= (1 << 20)) {
+        OPCHK(rcppml_hip_rhs_plan_create(c, dt, dAp.as<int>(), dAi.as<int>(), dAx.p, n, m, k, 0, 0, &planA.p));
+        OPCHK(rcppml_hip_rhs_plan_create(c, dt, dTp.as<int>(), dTi.as<int>(), dTx.p, m, n, k, 0, 0, &planT.p));
+    }
     auto rhs_fwd = [&](const void* F, void* B) {
         if (dense) OPCHK(rcppml_hip_rhs_dense(c, dt, dAx.p, m, n, 0, F, k, B));
+        else if (planA.p) OPCHK(rcppml_hip_rhs_planned(c, planA.p, F, B));
         else OPCHK(rcppml_hip_rhs(c, dt, dAp.as<int>(), dAi.as<int>(), dAx.p, n, F, k, B));
     };
     auto rhs_bwd = [&](const void* F, void* B) {
         if (dense) OPCHK(rcppml_hip_rhs_dense(c, dt, dAx.p, m, n, 1, F, k, B));
+        else if (planT.p) OPCHK(rcppml_hip_rhs_planned(c, planT.p, F, B));
         else OPCHK(rcppml_hip_rhs(c, dt, dTp.as<int>(), dTi.as<int>(), dTx.p, m, F, k, B));
     };
     auto enqueue_iteration = [&](int iter) {

@@ -1,0 +1,109 @@
+// rhs_tiled_launch.hip.h -- compiled shapes of rhs_tiled_kernel and their dispatch (included by one translation unit per
+// precision so the two sets of instantiations build in parallel).
+#pragma once
+#include <mutex>
+#include "common.hip.h"
+#include "kernels_rhs_tiled.hip.h"
+
+struct rcppml_rhs_plan {
+    int dtype = 0, k = 0, device = 0;
+    rk::RhsTiledGeom G{};
+    void* svals = nullptr;
+    uint16_t* soffs = nullptr;
+    int* ovptr = nullptr;
+    int* ovrow = nullptr;
+    void* ovval = nullptr;
+    void* Bp = nullptr;          // P > 1: per-partition partial outputs
+    const int* colptr = nullptr; // the caller's CSC (not owned): the tail columns go through the gather kernel
+    const int* rowidx = nullptr;
+    const void* vals = nullptr;
+    int64_t ovnnz = 0, nnz = 0, nslots = 0;
+    double ov_fraction = 0.0, fill = 0.0;
+    ~rcppml_rhs_plan() {
+        for (void* p : {svals, (void*)soffs, (void*)ovptr, (void*)ovrow, ovval, Bp})
+            if (p) (void)hipFree(p);
+    }
+};
+
+namespace rt_launch {
+using namespace rk;
+
+constexpr int RT_DYN_LDS = 2 * RT_SLAB_BYTES;
+
+// Compiled shapes (NV, S, NW, NR).  NW = waves per workgroup: 16 (four per SIMD, 128 VGPRs) or 12 (three per SIMD, 168
+// VGPRs: more rounds per wave = more output columns per workgroup = fewer bytes of F streamed per multiply-add and less
+// per-tile overhead per step).  Columns per workgroup = 4 NR NW.
+//   NV = 1 (256-byte rows): NW 16: NR in {4,6,8,10,12} (NR >= 10 only for S <= 5);  NW 12: NR in {8,12,16,20} (S <= 6 / S <= 4 for NR >= 16 / 20)
+//   NV = 2 (512-byte rows): NW 16: NR in {2,4,6};                                     NW 12: NR in {4,6,8,10} (NR 8 / 10 only for S <= 6 / S <= 4)
+inline bool shape_ok(int NV, int S, int NW, int NR) {
+    const bool s_ok = S == 2 || S == 3 || S == 4 || S == 5 || S == 6 || S == 8;
+    if (!s_ok) return false;
+    if (NV == 1 && NW == 16) return NR == 4 || NR == 6 || NR == 8 || ((NR == 10 || NR == 12) && S <= 5);
+    if (NV == 1 && NW == 12) return NR == 8 || NR == 12 || (NR == 16 && S <= 6) || (NR == 20 && S <= 4);
+    if (NV == 2 && NW == 16) return NR == 2 || NR == 4 || NR == 6;
+    if (NV == 2 && NW == 12) return NR == 4 || NR == 6 || (NR == 8 && S <= 6) || (NR == 10 && S <= 4);
+    return false;
+}
+
+template <class K>
+void set_lds_once(K kernel, int device) {
+    // per-device attribute, set to the one size this kernel ever asks for; serialised (concurrent fits from host threads)
+    static std::mutex mu;
+    static bool done[64] = {};
+    std::lock_guard<std::mutex> lk(mu);
+    if (!done[device & 63]) {
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, RT_DYN_LDS));
+        done[device & 63] = true;
+    }
+}
+
+template <class T, int NV, int S, int NW, int NR>
+void launch_tiled(rcppml_hip_ctx* c, const rcppml_rhs_plan* pl, const T* F, const T* Binit, T* Bout) {
+    auto kern = rhs_tiled_kernel<T, NV, S, NR, NW>;
+    set_lds_once(kern, c->device);
+    const RhsTiledGeom& G = pl->G;
+    hipLaunchKernelGGL(kern, dim3((unsigned)(G.P * G.ncb)), dim3(64 * NW), RT_DYN_LDS, c->stream,
+                       (const T*)pl->svals, (const uint16_t*)pl->soffs, F, G, Binit, Bout);
+    HIPCHK(hipGetLastError());
+}
+template <class T, int NV, int S>
+void launch_tiled_nr(rcppml_hip_ctx* c, const rcppml_rhs_plan* pl, const T* F, const T* Binit, T* Bout) {
+    const int nr = pl->G.nr, nw = pl->G.NW;
+#define RT_SH(W, N) if (nw == W && nr == N) return launch_tiled<T, NV, S, W, N>(c, pl, F, Binit, Bout);
+    if constexpr (NV == 1) {
+        RT_SH(16, 4) RT_SH(16, 6) RT_SH(16, 8) RT_SH(12, 8) RT_SH(12, 12)
+        if constexpr (S <= 5) { RT_SH(16, 10) RT_SH(16, 12) }
+        if constexpr (S <= 6) { RT_SH(12, 16) }
+        if constexpr (S <= 4) { RT_SH(12, 20) }
+    } else {
+        RT_SH(16, 2) RT_SH(16, 4) RT_SH(16, 6) RT_SH(12, 4) RT_SH(12, 6)
+        if constexpr (S <= 6) { RT_SH(12, 8) }
+        if constexpr (S <= 4) { RT_SH(12, 10) }
+    }
+#undef RT_SH
+    throw std::runtime_error("rhs_planned: shape not compiled");
+}
+template <class T, int NV>
+void launch_tiled_s(rcppml_hip_ctx* c, const rcppml_rhs_plan* pl, const T* F, const T* Binit, T* Bout) {
+    switch (pl->G.S) {
+        case 2: launch_tiled_nr<T, NV, 2>(c, pl, F, Binit, Bout); break;
+        case 3: launch_tiled_nr<T, NV, 3>(c, pl, F, Binit, Bout); break;
+        case 4: launch_tiled_nr<T, NV, 4>(c, pl, F, Binit, Bout); break;
+        case 5: launch_tiled_nr<T, NV, 5>(c, pl, F, Binit, Bout); break;
+        case 6: launch_tiled_nr<T, NV, 6>(c, pl, F, Binit, Bout); break;
+        case 8: launch_tiled_nr<T, NV, 8>(c, pl, F, Binit, Bout); break;
+        default: throw std::runtime_error("rhs_planned: unsupported slot count");
+    }
+}
+template <class T>
+void launch_tiled_any(rcppml_hip_ctx* c, const rcppml_rhs_plan* pl, const T* F, const T* Binit, T* Bout) {
+    const int NV = pl->G.rowb / 256;
+    if (NV == 1) launch_tiled_s<T, 1>(c, pl, F, Binit, Bout);
+    else if (NV == 2) launch_tiled_s<T, 2>(c, pl, F, Binit, Bout);
+    else throw std::runtime_error("rhs_planned: unsupported row size");
+}
+}  // namespace rt_launch
+
+// defined in ops_rhs_tiled.hip (float) and ops_rhs_tiled_f64.hip (double)
+void rcppml_rt_launch_f32(rcppml_hip_ctx* c, const rcppml_rhs_plan* pl, const float* F, const float* Binit, float* Bout);
+void rcppml_rt_launch_f64(rcppml_hip_ctx* c, const rcppml_rhs_plan* pl, const double* F, const double* Binit, double* Bout);

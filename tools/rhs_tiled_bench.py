@@ -26,7 +26,7 @@ def timeit(fn, n=20):
 
 
 def main():
-    m, n, k = 20000, 100000, 64
+    m, n, k = int(os.environ.get("M", "20000")), int(os.environ.get("N", "100000")), 64
     dens = float(os.environ.get("DENS", "0.01"))
     dtype = np.float32 if os.environ.get("DT", "f32") == "f32" else np.float64
     k = int(os.environ.get("K", "64"))
