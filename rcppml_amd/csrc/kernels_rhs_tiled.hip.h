@@ -202,24 +202,15 @@ __device__ __forceinline__ unsigned rt_m0_save() {
     return keep;
 }
 __device__ __forceinline__ void rt_m0_restore(unsigned keep) { asm volatile("s_mov_b32 m0, %0" ::"s"(keep)); }
-__device__ __forceinline__ void rt_load_val(float& dst, const char* base_uniform, unsigned lane_off) {
-    asm volatile("global_load_dword %0, %1, %2" : "=v"(dst) : "v"(lane_off), "s"(base_uniform) : "memory");
-}
-__device__ __forceinline__ void rt_load_val(double& dst, const char* base_uniform, unsigned lane_off) {
-    asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(dst) : "v"(lane_off), "s"(base_uniform) : "memory");
-}
-__device__ __forceinline__ void rt_load_u16(unsigned& dst, const char* base_uniform, unsigned lane_off) {
-    asm volatile("global_load_ushort %0, %1, %2" : "=v"(dst) : "v"(lane_off), "s"(base_uniform) : "memory");
+// 4 bytes per lane, global -> LDS (the slot prefetch: no VGPR is in flight, so there is nothing hipcc could copy or
+// spill before the data has landed -- with register destinations it did exactly that once the loop was unrolled)
+__device__ __forceinline__ void rt_glds4(const char* base_uniform, unsigned lane_off, unsigned lds_addr_uniform) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1"
+                 :: "v"(lane_off), "s"(base_uniform), "s"(lds_addr_uniform) : "memory");
 }
 template <int N> __device__ __forceinline__ void rt_wait_vm() {
     static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-// the registers of a slot set become readable only after the wait: tie them to it so no read can be hoisted above
-template <int N, class T, int NB> __device__ __forceinline__ void rt_wait_vm_tied(T (&v)[NB], unsigned (&o)[NB]) {
-    rt_wait_vm<N>();
-#pragma unroll
-    for (int b = 0; b < NB; ++b) asm volatile("" : "+v"(v[b]), "+v"(o[b]));
 }
 // s_waitcnt lgkmcnt(N) only
 template <int N> __device__ __forceinline__ void rt_wait_lgkm() {
@@ -247,12 +238,12 @@ __global__ __launch_bounds__(64 * NW) void rhs_tiled_kernel(const T* __restrict_
     typedef typename RtVec<T>::type V;
     constexpr int VN = RtVec<T>::N;
     constexpr int NST = NR * S;                 // steps per (wave, tile)
-    constexpr int NB = (NST + 15) / 16;         // coalesced slot loads per (wave, tile)
+    constexpr int NB = (NST + 15) / 16;         // slot registers (value, offset) per lane and tile
     constexpr int UB = NV == 1 ? 4 : 2;         // steps per batch of LDS reads; two batches in flight
     constexpr int NBATCH = (NST + UB - 1) / UB;
     constexpr int NCH = RT_SLAB_BYTES / 1024;   // KiB-chunks per tile
     constexpr int CBASE = NCH / NW, CEXTRA = NCH % NW;
-    extern __shared__ char rt_slab[];           // 2 x 64 KiB
+    extern __shared__ char rt_slab[];           // 2 x 64 KiB of F + the two-stage slot ring
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = lane >> 4, u = lane & 15;
@@ -317,21 +308,39 @@ __global__ __launch_bounds__(64 * NW) void rhs_tiled_kernel(const T* __restrict_
         }
     };
     // slot stream: [column block][tile][wave][step][lane group]; one tile further = NW * NST * 4 slots further.
-    // Lanes of a block past the wave's last step read into the next wave's slots (the allocation is padded by one block);
-    // those steps are never executed.
+    // Prefetched by LDS-DMA into a two-stage ring behind the two F tiles (each wave owns VB + OB bytes per stage).
     constexpr int64_t tstride = (int64_t)NW * NST * 4;
+    constexpr int VB = NST * 4 * (int)sizeof(T), OB = NST * 4 * 2;             // bytes of values / offsets per (wave, tile)
+    constexpr int NCV = (VB + 255) / 256, NCO = (OB + 255) / 256;             // dword copies per (wave, tile)
+    constexpr int STAGE = NW * (VB + OB);
     const int64_t slot0 = ((cb * G.ntiles + t0) * NW + w) * (int64_t)(NST * 4);
     const char* svp = reinterpret_cast<const char*>(svals + slot0);
     const char* sop = reinterpret_cast<const char*>(soffs + slot0);
-    const unsigned lv = (u * 4 + g) * (unsigned)sizeof(T), lo = (u * 4 + g) * 2u;
-    auto slots_issue = [&](T (&v)[NB], unsigned (&o)[NB]) {
+    const unsigned sl0 = lds0 + 2 * RT_SLAB_BYTES + w * (VB + OB);             // this wave's slot area of stage 0
+    char* const slp = rt_slab + 2 * RT_SLAB_BYTES + w * (VB + OB);
+    auto slots_issue = [&](int stage) {
+        const unsigned dst = sl0 + stage * STAGE;
 #pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            rt_load_val(v[b], svp + b * 64 * (int)sizeof(T), lv);
-            rt_load_u16(o[b], sop + b * 64 * 2, lo);
-        }
+        for (int i = 0; i < NCV; ++i)
+            if (256 * i + 4 * lane < VB) rt_glds4(svp + 256 * i, 4u * lane, dst + 256 * i);
+#pragma unroll
+        for (int i = 0; i < NCO; ++i)          // offsets travel as dwords too (two per lane): sub-dword LDS-DMA pads every lane to a dword
+            if (256 * i + 4 * lane < OB) rt_glds4(sop + 256 * i, 4u * lane, dst + VB + 256 * i);
         svp += tstride * (int64_t)sizeof(T);
         sop += tstride * 2;
+    };
+    // the wave's slots of one stage -> registers (lane 16 g' + i' of block b holds slot (16 b + i') * 4 + g' ... i.e. the
+    // lanes read the stream in order: lane l of block b = slot 64 b + l, which is step 16 b + l / 4, lane group l % 4;
+    // the kernel wants step 16 b + u for group g in lane 16 g + u)
+    auto slots_read = [&](int stage, T (&cv)[NB], unsigned (&co)[NB]) {
+        const char* src = slp + stage * STAGE;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const int step = 16 * b + u;
+            const int sidx = (step < NST ? step : 0) * 4 + g;             // lanes past the last step re-read step 0 (never consumed)
+            cv[b] = *reinterpret_cast<const T*>(src + sidx * (int)sizeof(T));
+            co[b] = *reinterpret_cast<const uint16_t*>(src + VB + sidx * 2);
+        }
     };
     auto compute = [&](const T (&cv)[NB], const unsigned (&co)[NB], int buf) {
         const int lbase = buf * RT_SLAB_BYTES + u * 16;
@@ -368,47 +377,45 @@ __global__ __launch_bounds__(64 * NW) void rhs_tiled_kernel(const T* __restrict_
             });
             __builtin_amdgcn_sched_barrier(0);
         });
+        // every FMA of this tile is done HERE: without the tie hipcc rotates the tail of the compute phase below the
+        // barrier into the next tile, and the extra live ranges spill
+#pragma unroll
+        for (int q = 0; q < NR; ++q)
+#pragma unroll
+            for (int v = 0; v < NV; ++v) asm volatile("" : "+v"(acc[q][v]));
     };
 
-    T sv0[NB], sv1[NB];
-    unsigned so0[NB], so1[NB];
-#pragma unroll
-    for (int b = 0; b < NB; ++b) { sv0[b] = sv1[b] = T(0); so0[b] = so1[b] = 0; }
     if (t0 < t1) {
         slab_load(t0, 0);
-        slots_issue(sv0, so0);
-        if (t0 + 1 < t1) slots_issue(sv1, so1);
+        slots_issue(0);
+        if (t0 + 1 < t1) slots_issue(1);
     }
-    rt_wait_vm_tied<0>(sv0, so0);
-    rt_wait_vm_tied<0>(sv1, so1);
+    rt_wait_vm<0>();
     __builtin_amdgcn_s_barrier();
-    // one tile; `cur` holds its slots (landed), `nxt` the following tile's (landed at the end of this tile)
-    auto tile = [&](int t, int buf, T (&cur_v)[NB], unsigned (&cur_o)[NB], T (&nxt_v)[NB], unsigned (&nxt_o)[NB]) {
+    for (int t = t0; t < t1; ++t) {
+        const int buf = (t - t0) & 1;
         T cv[NB];
         unsigned co[NB];
+        slots_read(buf, cv, co);                   // slots(t): landed (waited for at the end of the previous tile)
 #pragma unroll
-        for (int b = 0; b < NB; ++b) { cv[b] = cur_v[b]; co[b] = cur_o[b]; }
-#pragma unroll
-        for (int b = 0; b < NB; ++b) asm volatile("" : "+v"(cv[b]), "+v"(co[b]));      // the copy is made HERE, before the reload
+        for (int b = 0; b < NB; ++b) asm volatile("" : "+v"(cv[b]), "+v"(co[b]));
+        rt_wait_lgkm<0>();                         // ... and in registers before their stage is refilled
 #ifdef RCPPML_EXPERIMENTS
         if (t + 1 < t1 && !(G.dbg & 2)) slab_load(t + 1, buf ^ 1);
         const bool more = t + 2 < t1 && !(G.dbg & 4);
-        if (more) slots_issue(cur_v, cur_o);
+        if (more) slots_issue(buf);
         if (!(G.dbg & 1)) compute(cv, co, buf);
 #else
         if (t + 1 < t1) slab_load(t + 1, buf ^ 1);
         const bool more = t + 2 < t1;
-        if (more) slots_issue(cur_v, cur_o);
+        if (more) slots_issue(buf);
         compute(cv, co, buf);
 #endif
-        if (more) rt_wait_vm_tied<2 * NB>(nxt_v, nxt_o);
-        else rt_wait_vm_tied<0>(nxt_v, nxt_o);
+        if (more) rt_wait_vm<NCV + NCO>();         // all but the slot copies just issued: tile t+1 and slots(t+1) have landed
+        else rt_wait_vm<0>();
         rt_wait_lgkm<0>();
         __builtin_amdgcn_s_barrier();
-    };
-    for (int t = t0; t < t1; t += 2) {
-        tile(t, 0, sv0, so0, sv1, so1);
-        if (t + 1 < t1) tile(t + 1, 1, sv1, so1, sv0, so0);
+        asm volatile("" ::: "memory");
     }
     rt_m0_restore(m0keep);
 

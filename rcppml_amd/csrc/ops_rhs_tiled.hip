@@ -120,7 +120,7 @@ rcppml_rhs_plan* build_plan(rcppml_hip_ctx* c, int dtype, const int* colptr, con
     int64_t best_tiled = 0;
     for (int NW = 16; NW >= 12; NW -= 4)
         for (int nr = 2; nr <= 20; ++nr) {
-            if (!rt_launch::shape_ok(NV, S, NW, nr)) continue;
+            if (!rt_launch::shape_ok(NV, S, NW, nr, (int)sizeof(T))) continue;
             const int64_t cap = 4ll * nr * NW;
             const double t_wg = tiles_pp * (NW / 4) * (250.0 + 24.0 * nr * S) / 2400.0 + 15.0;       // microseconds
             const int64_t full_rounds = ncols / (cap * conc);
@@ -142,7 +142,7 @@ rcppml_rhs_plan* build_plan(rcppml_hip_ctx* c, int dtype, const int* colptr, con
     if (best_t < 0) return nullptr;
 #ifdef RCPPML_EXPERIMENTS
     { const char* e1 = getenv("RCPPML_RT_NW"); const char* e2 = getenv("RCPPML_RT_NR");
-      if (e1 && e2 && rt_launch::shape_ok(NV, S, atoi(e1), atoi(e2))) { bestNW = atoi(e1); bestnr = atoi(e2); best_tiled = ncols; } }
+      if (e1 && e2 && rt_launch::shape_ok(NV, S, atoi(e1), atoi(e2), (int)sizeof(T))) { bestNW = atoi(e1); bestnr = atoi(e2); best_tiled = ncols; } }
 #endif
     const int64_t bestcap = 4ll * bestnr * bestNW;
     G.NW = bestNW; G.nr = bestnr;
@@ -174,7 +174,6 @@ rcppml_rhs_plan* build_plan(rcppml_hip_ctx* c, int dtype, const int* colptr, con
     if (force_S <= 0 && pl->ov_fraction > 0.35) return nullptr;   // too irregular for fixed slots: the gather kernel is the better tool
     pl->nslots = (int64_t)G.ncb * G.ntiles * G.NW * (int64_t)(G.nr * S) * 4;
     pl->fill = (double)(pl->nnz - pl->ovnnz) / (double)pl->nslots;
-    // one block of 64 slots of padding: the last wave's partial block loads run past its last step (never consumed)
     const size_t nalloc = (size_t)pl->nslots + 64;
     HIPCHK(hipMalloc(&pl->svals, nalloc * sizeof(T)));
     HIPCHK(hipMalloc((void**)&pl->soffs, nalloc * sizeof(uint16_t)));

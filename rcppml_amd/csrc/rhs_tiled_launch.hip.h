@@ -28,17 +28,20 @@ struct rcppml_rhs_plan {
 namespace rt_launch {
 using namespace rk;
 
-constexpr int RT_DYN_LDS = 2 * RT_SLAB_BYTES;
+constexpr int RT_MAX_LDS = 160 * 1024;          // two 64 KiB tiles of F + the two-stage slot ring
+inline int rt_dyn_lds(int NW, int NR, int S, int tsize) { return 2 * RT_SLAB_BYTES + 2 * NW * NR * S * 4 * (tsize + 2); }
 
 // Compiled shapes (NV, S, NW, NR).  NW = waves per workgroup: 16 (four per SIMD, 128 VGPRs) or 12 (three per SIMD, 168
 // VGPRs: more rounds per wave = more output columns per workgroup = fewer bytes of F streamed per multiply-add and less
-// per-tile overhead per step).  Columns per workgroup = 4 NR NW.
-//   NV = 1 (256-byte rows): NW 16: NR in {4,6,8,10,12} (NR >= 10 only for S <= 5);  NW 12: NR in {8,12,16,20} (S <= 6 / S <= 4 for NR >= 16 / 20)
+// per-tile overhead per step).  Columns per workgroup = 4 NR NW.  A shape must also fit its slot ring into the 32 KiB
+// of LDS behind the two tiles of F (rt_dyn_lds).
+//   NV = 1 (256-byte rows): NW 16: NR in {2,4,6,8,10,12} (NR >= 10 only for S <= 5);  NW 12: NR in {8,12,16,20} (S <= 6 / S <= 4 for NR >= 16 / 20)
 //   NV = 2 (512-byte rows): NW 16: NR in {2,4,6};                                     NW 12: NR in {4,6,8,10} (NR 8 / 10 only for S <= 6 / S <= 4)
-inline bool shape_ok(int NV, int S, int NW, int NR) {
+inline bool shape_ok(int NV, int S, int NW, int NR, int tsize) {
+    if (rt_dyn_lds(NW, NR, S, tsize) > RT_MAX_LDS) return false;
     const bool s_ok = S == 2 || S == 3 || S == 4 || S == 5 || S == 6 || S == 8;
     if (!s_ok) return false;
-    if (NV == 1 && NW == 16) return NR == 4 || NR == 6 || NR == 8 || ((NR == 10 || NR == 12) && S <= 5);
+    if (NV == 1 && NW == 16) return NR == 2 || NR == 4 || NR == 6 || NR == 8 || ((NR == 10 || NR == 12) && S <= 5);
     if (NV == 1 && NW == 12) return NR == 8 || NR == 12 || (NR == 16 && S <= 6) || (NR == 20 && S <= 4);
     if (NV == 2 && NW == 16) return NR == 2 || NR == 4 || NR == 6;
     if (NV == 2 && NW == 12) return NR == 4 || NR == 6 || (NR == 8 && S <= 6) || (NR == 10 && S <= 4);
@@ -52,7 +55,7 @@ void set_lds_once(K kernel, int device) {
     static bool done[64] = {};
     std::lock_guard<std::mutex> lk(mu);
     if (!done[device & 63]) {
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, RT_DYN_LDS));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, RT_MAX_LDS));
         done[device & 63] = true;
     }
 }
@@ -62,7 +65,8 @@ void launch_tiled(rcppml_hip_ctx* c, const rcppml_rhs_plan* pl, const T* F, cons
     auto kern = rhs_tiled_kernel<T, NV, S, NR, NW>;
     set_lds_once(kern, c->device);
     const RhsTiledGeom& G = pl->G;
-    hipLaunchKernelGGL(kern, dim3((unsigned)(G.P * G.ncb)), dim3(64 * NW), RT_DYN_LDS, c->stream,
+    if (!shape_ok(NV, S, NW, NR, (int)sizeof(T))) throw std::runtime_error("rhs_planned: shape exceeds the LDS");
+    hipLaunchKernelGGL(kern, dim3((unsigned)(G.P * G.ncb)), dim3(64 * NW), rt_dyn_lds(NW, NR, S, (int)sizeof(T)), c->stream,
                        (const T*)pl->svals, (const uint16_t*)pl->soffs, F, G, Binit, Bout);
     HIPCHK(hipGetLastError());
 }
@@ -71,7 +75,7 @@ void launch_tiled_nr(rcppml_hip_ctx* c, const rcppml_rhs_plan* pl, const T* F, c
     const int nr = pl->G.nr, nw = pl->G.NW;
 #define RT_SH(W, N) if (nw == W && nr == N) return launch_tiled<T, NV, S, W, N>(c, pl, F, Binit, Bout);
     if constexpr (NV == 1) {
-        RT_SH(16, 4) RT_SH(16, 6) RT_SH(16, 8) RT_SH(12, 8) RT_SH(12, 12)
+        RT_SH(16, 2) RT_SH(16, 4) RT_SH(16, 6) RT_SH(16, 8) RT_SH(12, 8) RT_SH(12, 12)
         if constexpr (S <= 5) { RT_SH(16, 10) RT_SH(16, 12) }
         if constexpr (S <= 6) { RT_SH(12, 16) }
         if constexpr (S <= 4) { RT_SH(12, 20) }
