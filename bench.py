@@ -32,10 +32,13 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--rows", type=int, default=20000)
-    ap.add_argument("--cols", type=int, default=100000, help="columns PER GPU")
-    ap.add_argument("--density", type=float, default=0.01)
-    ap.add_argument("--k", type=int, default=64)
+    ap.add_argument("--config", choices=["c2", "c4"], default="c2",
+                    help="BASELINE.json configs[1] (20000 x 100000 per GPU, 1 %%, k = 64: the headline) or configs[3] "
+                         "(pbmc3k-shaped 30000 x 162500 per GPU = 1.3 M columns over 8 GPUs, 3 %%, k = 128)")
+    ap.add_argument("--rows", type=int, default=None)
+    ap.add_argument("--cols", type=int, default=None, help="columns PER GPU")
+    ap.add_argument("--density", type=float, default=None)
+    ap.add_argument("--k", type=int, default=None)
     ap.add_argument("--dtype", choices=["f32", "f64"], default="f32")
     ap.add_argument("--solver", choices=["cd", "chol"], default="cd")
     ap.add_argument("--variant", choices=["auto", "lane", "wave"], default="auto")
@@ -44,7 +47,28 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-order", action="store_true", help="disable sweep-count column ordering")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline work (s)")
-    return ap.parse_args()
+    ap.add_argument("--no-plugin-figure", action="store_true", help="skip the PCIe-inclusive 73-pointer plugin call")
+    args = ap.parse_args()
+    preset = {"c2": (20000, 100000, 0.01, 64), "c4": (30000, 162500, 0.03, 128)}[args.config]
+    args.rows = args.rows or preset[0]
+    args.cols = args.cols or preset[1]
+    args.density = args.density or preset[2]
+    args.k = args.k or preset[3]
+    return args
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: re-exec under torch.distributed.run, one rank per GPU (127.0.0.1
+    rendezvous on a free port), and hand its exit code back."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
 
 
 def calibrated_density(rows, k, target, seed):
@@ -118,9 +142,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(self_launch(args))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..." % (args.gpus, args.gpus))
+        raise SystemExit("bench.py --gpus %d launched with WORLD_SIZE=%d" % (args.gpus, world))
     # functional smoke of the N > 1 loop on a one-GPU box: RCPPML_BENCH_BACKEND=gloo RCPPML_BENCH_SHARE_GPU=1 maps every
     # rank onto cuda:0 (RCCL refuses two ranks per device); never used for reported numbers
     backend = os.environ.get("RCPPML_BENCH_BACKEND", "nccl")
@@ -132,7 +157,7 @@ def main():
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend=backend)
-    comm = als.Comm(dist if world > 1 else None)
+    comm = als.Comm(dist if world > 1 else None, time_collectives=world > 1)
 
     m, n_loc, k = args.rows, args.cols, args.k
     n_total = n_loc * world
@@ -154,6 +179,7 @@ def main():
     # ---- timed region: EXACTLY `steps` iterations, barrier + synchronize on both sides
     ops.record = True
     ops.reset_events()
+    comm.reset_events()
     ops.ctx.stats(reset=True)          # zero the library's work counters (column-sweeps of the CD kernels)
     comm.barrier()
     torch.cuda.synchronize()
@@ -171,6 +197,7 @@ def main():
     final_loss = float(loss[0].item())
     ev = ops.event_ms()
     work = ops.ctx.stats()
+    coll = comm.collective_ms()
 
     if rank == 0:
         sv = 4 if args.dtype == "f32" else 8
@@ -184,10 +211,22 @@ def main():
         avg_bytes = (bytes_h * cnt_h + bytes_w * cnt_w) / max(launches, 1)
         achieved = avg_bytes / max(avg_s, 1e-12) / 1e9
         phases = {name: round(ms / args.steps, 4) for name, (c, ms) in sorted(ev.items())}
-        roof_rhs = {"bound": "hbm", "kernel": "rhs_stage_kernel (SpMM-like B = F * A(:,j), both half-updates)",
+        planned = bool(st.A.get("plans")) and bool(st.At.get("plans"))
+        plan_info = {side: csc["plans"][k].info() for side, csc in (("H", st.A), ("W", st.At)) if csc.get("plans", {}).get(k)}
+        # delivery rate of the gathered k-rows of F (nnz * k * s_v per launch: not compulsory HBM traffic) against
+        # the two on-chip ceilings: vector L1 (64 B/clk/CU) for the gather kernel, LDS (256 B/clk/CU, ds_read_b128) for the
+        # row-tiled kernel
+        gather_bytes = float(nnz) * k * sv
+        deliv = gather_bytes / max(avg_s, 1e-12) / 1e12
+        roof_rhs = {"bound": "hbm",
+                    "kernel": ("rhs_tiled_kernel + rhs_tiled_spill_kernel (+ reduce / tail): LDS row-tiled SpMM-like B = F * A(:,j), both half-updates"
+                               if planned else "rhs_stage_kernel (SpMM-like B = F * A(:,j), both half-updates)"),
                     "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                     "traffic": None, "algorithmic_bytes_per_launch": avg_bytes, "avg_launch_ms": avg_s * 1e3,
-                    "rhs_H_ms": ms_h / max(cnt_h, 1), "rhs_W_ms": ms_w / max(cnt_w, 1)}
+                    "rhs_H_ms": ms_h / max(cnt_h, 1), "rhs_W_ms": ms_w / max(cnt_w, 1),
+                    "gathered_row_delivery": {"achieved_TBps": deliv, "bytes_per_launch": gather_bytes,
+                                              "frac_of_L1_39.3TBps": deliv / 39.3, "frac_of_LDS_157TBps": deliv / 157.3},
+                    "plan": plan_info}
         # NNLS solve: algorithmic flops = 2 k^2 per column and sweep (k coordinate steps, each a k-long residual
         # update; nnls_batch.hpp:96-121), sweeps counted by the kernels themselves.  fp32 k<=64 runs these updates
         # as v_mfma_f32_32x32x2_f32 (dense f32 MFMA peak 157.3 TFLOP/s = the f32 vector rate); the phase time
@@ -232,17 +271,18 @@ def main():
         # HBM/fabric bytes per launch from the committed rocprofv3 PMC passes of this same command (FETCH_SIZE x2 per the
         # gfx950 correction + WRITE_SIZE, profiles/summarize.py); only meaningful for the default workload
         default_wl = (m, n_loc, k, args.dtype, world) == (20000, 100000, 64, "f32", 1)
-        pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc.json")
+        pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc.json")
         if default_wl and os.path.exists(pmc_path):
             try:
                 pmc = json.load(open(pmc_path))
-                for name, v in pmc.items():
-                    if "rhs_stage_kernel" in name or "rhs_kernel" in name:
-                        roof_rhs["traffic"] = v["hbm_bytes_per_launch"]
-                        roof_rhs["traffic_source"] = "profiles/r01_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
+                if "rhs_per_launch" in pmc:
+                    roof_rhs["traffic"] = pmc["rhs_per_launch"]["hbm_bytes_per_launch"]
+                    roof_rhs["traffic_over_algorithmic"] = roof_rhs["traffic"] / avg_bytes
+                    roof_rhs["traffic_source"] = "profiles/r02_pmc.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes; all kernels of one rhs call, mean of both sides)"
+                for name, v in pmc.get("kernels", {}).items():
                     if roof_cd is not None and "cd_mfma_kernel" in name:
                         roof_cd["traffic"] = v["hbm_bytes_per_launch"]
-                        roof_cd["traffic_source"] = "profiles/r01_pmc.json"
+                        roof_cd["traffic_source"] = "profiles/r02_pmc.json"
             except Exception:
                 pass
         out = {
@@ -253,9 +293,10 @@ def main():
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": "configs[1]: simulateNMF %dx%d (x%d GPUs, column shards) %.3g%%-dense CSC, k=%d, MSE, %s NNLS "
+            "config": {"workload": "%s: simulateNMF %dx%d (x%d GPUs, column shards) %.3g%%-dense CSC, k=%d, MSE, %s NNLS "
                                    "(cd_maxit=%d, cd_tol=1e-8), L1 row normalisation, loss every iteration"
-                                   % (m, n_loc, world, 100.0 * nnz / (m * float(n_loc)), k,
+                                   % ("configs[1]" if args.config == "c2" else "configs[3] (one GPU's share)", m, n_loc, world,
+                                      100.0 * nnz / (m * float(n_loc)), k,
                                       "coordinate-descent" if args.solver == "cd" else "Cholesky+clip", args.cd_maxit),
                        "rows": m, "cols_per_gpu": n_loc, "nnz_per_gpu": nnz, "k": k, "solver": args.solver,
                        "cd_variant": args.variant, "parallelism": "column-shard x%d" % world},
@@ -264,7 +305,16 @@ def main():
             ("roofline_rhs" if cd_dominant else "roofline_cd"): roof_rhs if cd_dominant else roof_cd,
             "phases_ms_per_step": phases,
             "final_loss": final_loss,
+            "world_size_seen": world,
+            "backend": (dist.get_backend() if world > 1 else None),
+            "collectives_ms_per_step": {name: dict(ms=round(v["total_ms"] / args.steps, 4), calls_per_step=v["count"] / args.steps,
+                                                   bytes=v["bytes"]) for name, v in sorted(coll.items())},
         }
+        if world == 1 and not args.no_plugin_figure and args.config == "c2":
+            try:
+                out["plugin_pcie_inclusive"] = plugin_figure(A_loc, m, n_loc, k, args.seed)
+            except Exception as e:
+                out["plugin_pcie_inclusive"] = {"error": repr(e)}
         if not args.no_cpu_baseline and world == 1:
             try:
                 W_T, dvec, H = st.factors()
@@ -280,6 +330,26 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def plugin_figure(A, m, n, k, seed):
+    """The 73-pointer plugin call (rcppml_gpu_nmf_unified_float: host buffers in, host buffers out -- what R reaches) on the
+    same matrix: total time of 1- and 11-iteration fits -> setup (upload, device transpose, plans, download) and ms per
+    iteration.  Never `value`: the timed region of this bench starts with the data in HBM."""
+    from rcppml_amd import _abi, data
+    W0, H0 = data.init_factors(seed, k, m, n, np.float64)
+    p, i, x = A.p.astype(np.int32), A.i.astype(np.int32), A.x.astype(np.float64)
+    t = {}
+    for iters in (1, 1, 11):
+        W, H = W0.copy(), H0.copy()
+        t0 = time.perf_counter()
+        r = _abi.nmf_unified(p, i, x, m, n, k, W, H, entry="float", max_iter=iters, tol=0.0, solver_mode=0)
+        t[iters] = time.perf_counter() - t0
+        if r["status"] != 0:
+            raise RuntimeError(r.get("error"))
+    slope = (t[11] - t[1]) / 10
+    return {"entry": "rcppml_gpu_nmf_unified_float", "ms_per_iteration": slope * 1e3, "setup_ms": (t[1] - slope) * 1e3,
+            "fit_11_iterations_ms": t[11] * 1e3, "cols_per_s_11_iterations": 11 * (m + n) / t[11]}
 
 
 def _to_oracle(A):

@@ -202,28 +202,61 @@ class _EventScope:
         return False
 
 
+class _CommScope:
+    def __init__(self, comm, name, torch, nbytes):
+        self.comm, self.name, self.torch, self.nbytes = comm, name, torch, nbytes
+
+    def __enter__(self):
+        self.s = self.torch.cuda.Event(enable_timing=True)
+        self.e = self.torch.cuda.Event(enable_timing=True)
+        self.s.record()
+
+    def __exit__(self, *a):
+        self.e.record()
+        self.comm.events.setdefault(self.name, []).append((self.s, self.e, self.nbytes))
+
+
 class Comm:
     """Collectives of the path.  world_size 1: no-ops."""
 
-    def __init__(self, dist=None):
+    def __init__(self, dist=None, time_collectives=False):
         self.dist = dist
         self.world = dist.get_world_size() if dist is not None else 1
         self.rank = dist.get_rank() if dist is not None else 0
+        self.timed = bool(time_collectives) and self.world > 1
+        self.events = {}
 
-    def all_reduce_sum(self, t):
+    def _scope(self, name, t):
+        """Device-side timing of one collective (events on the current stream; GPU tensors only)."""
+        if not (self.timed and t.is_cuda):
+            return _NULL
+        import torch
+        return _CommScope(self, name, torch, t.numel() * t.element_size())
+
+    def reset_events(self):
+        self.events = {}
+
+    def collective_ms(self):
+        """name -> dict(count, total_ms, bytes) of the timed collectives; call after a device synchronize."""
+        return {k: dict(count=len(v), total_ms=float(sum(s.elapsed_time(e) for s, e, _ in v)), bytes=int(v[0][2]) if v else 0)
+                for k, v in self.events.items()}
+
+    def all_reduce_sum(self, t, tag="all_reduce"):
         if self.world > 1:
-            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+            with self._scope(tag, t):
+                self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
         return t
 
-    def all_gather_rows(self, full, rows_per):
+    def all_gather_rows(self, full, rows_per, tag="all_gather_W"):
         """In-place all-gather of equal row blocks: rank r's block full[r*rows_per:(r+1)*rows_per] goes to every rank."""
         if self.world > 1:
             mine = full[self.rank * rows_per:(self.rank + 1) * rows_per]
-            if self.dist.get_backend() == "gloo":          # CPU tests: gloo has no in-place tensor all-gather
-                parts = [full[r * rows_per:(r + 1) * rows_per] for r in range(self.world)]
-                self.dist.all_gather(parts, mine.clone())
-            else:
-                self.dist.all_gather_into_tensor(full, mine)
+            with self._scope(tag, full):
+                if self.dist.get_backend() == "gloo":          # CPU tests: gloo has no in-place tensor all-gather
+                    parts = [full[r * rows_per:(r + 1) * rows_per] for r in range(self.world)]
+                    self.dist.all_gather(parts, mine.clone())
+                else:
+                    self.dist.all_gather_into_tensor(full, mine)
         return full
 
     def barrier(self):
@@ -277,13 +310,13 @@ class ShardedALS:
         ops.rhs(self.A, self.W_T, out=self.Bh, tag="rhs_H")
         ops.solve(self.G, self.Bh, self.H, cfg, "H", warm, tag="solve_H")
         ops.row_norms(self.H, cfg.norm_type, out=self.sums)
-        comm.all_reduce_sum(self.sums)
+        comm.all_reduce_sum(self.sums, tag="all_reduce_rowsums")
         ops.apply_scaling(self.H, self.sums, cfg.norm_type, self.d)
         # ---- W half-update (fit_cpu.hpp:711-893)
         if comm.world > 1:
             ops.gram(self.H, 0.0, 0.0, out=self.Gp, tag="gram")             # partial H_loc H_loc^T, eps after the sum
             ops.rhs(self.At, self.H, out=self.Bw, tag="rhs_W")
-            comm.all_reduce_sum(self.xbuf)
+            comm.all_reduce_sum(self.xbuf, tag="all_reduce_gram_rhs")
             ops.add_diag(self.Gp, self.eps)
         else:
             ops.gram(self.H, self.eps, 0.0, out=self.Gp, tag="gram")
