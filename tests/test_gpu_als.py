@@ -209,3 +209,57 @@ def test_full_size_c2_fit_matches_oracle_fp64():
     assert abs(res["loss"] - ref.loss) <= 1e-6 * abs(ref.loss)
     assert np.abs(res["d"] - ref.d).max() <= 1e-8 * np.abs(ref.d).max()
     assert np.abs(W - ref.W_T).max() < 1e-8 and np.abs(H - ref.H).max() < 1e-8
+
+
+def test_full_size_c4_shard_properties():
+    """BASELINE configs[3], one GPU's share at FULL size: 30 000 x 162 500 (1.3 M columns over 8 GPUs), 3 %-dense
+    (nnz ~ 1.46e8), k = 128, fp32, CD.  Two ALS iterations through the sharded loop, then the size-independent properties:
+    rows of H and columns of W sum to 1, non-negativity, loss finite and non-increasing, the linearity checksum of the
+    SpMM-like kernel on both sides (sum_j B(:,j) = F (A 1)), and 128 sampled columns of each half-update against the
+    oracle's fused RHS + CD from the device's own inputs (same tolerance reasoning as the C2 spot test)."""
+    import torch
+    from rcppml_amd import als, data
+    m, n, k = 30000, 162500, 128
+    A, _, _ = data.simulate_nmf_sparse(m, n, k, 0.031, seed=11, device=torch.device("cuda", 0))
+    assert abs(A.nnz / (m * float(n)) - 0.03) < 0.003
+    At = A.transpose()
+    W0, H0 = data.init_factors(42, k, m, n, np.float32)
+    ops = als.HipOps(0, "f32")
+    cfg = als.AlsConfig(k=k, max_iter=3, tol=0.0)
+    st = als.ShardedALS(ops, als.Comm(None), A, At, W0, H0, cfg)
+    assert st.A.get("plans", {}).get(k) is not None and st.At.get("plans", {}).get(k) is not None   # the row-tiled kernel runs
+    losses = []
+    for it in range(2):
+        losses.append(float(st.step()[0].item()))
+        rs = ops.row_norms(st.H, 0).cpu().numpy()
+        assert np.allclose(rs, 1.0, atol=2e-4)
+    assert np.all(np.isfinite(losses)) and losses[1] <= losses[0] * (1 + 1e-5)
+    W_T, d, H = st.factors()
+    assert W_T.min() >= 0 and H.min() >= 0 and np.all(d > 0)
+    assert np.allclose(W_T.sum(axis=0), 1.0, atol=2e-4)
+    # linearity checksums (fp32 kernels, fp64 reference): both the planned and the gather form
+    rowsum = np.bincount(A.i, weights=A.x, minlength=m)
+    colsum = np.add.reduceat(A.x, A.p[:-1].astype(np.int64)) * (np.diff(A.p) > 0)
+    for csc, F, ref in ((st.A, st.W_T, W_T.T @ rowsum), (st.At, st.H, H.T @ colsum)):
+        B = ops.rhs(csc, F)
+        s = B.double().sum(dim=0).cpu().numpy()
+        assert np.abs(s - ref).max() / np.abs(s).max() < 2e-4
+        B2 = ops.empty(tuple(B.shape))
+        ops.ctx.rhs(ops.dt, csc["p"], csc["i"], csc["x"], csc["cols"], F, k, B2)
+        assert float((B - B2).abs().max() / B2.abs().max()) < 5e-5          # planned == gather kernel up to summation order
+    # sampled columns of both half-updates vs the oracle (third iteration, driven op by op)
+    sums, dd = ops.empty((k,)), ops.empty((k,))
+    for side in ("H", "W"):
+        F, X, csc, host = (st.W_T, st.H, st.A, A) if side == "H" else (st.H, st.W_T, st.At, At)
+        G = ops.gram(F, 1e-15, 0.0)
+        B = ops.rhs(csc, F)
+        X_prev, F_host, G_host = X.cpu().numpy(), F.cpu().numpy(), G.cpu().numpy()
+        ops.solve(G, B, X, cfg, side, True)
+        X_new = X.cpu().numpy()
+        cols = np.sort(np.random.default_rng(5 + (side == "W")).choice(host.cols, size=128, replace=False))
+        ref = O.fused_cd(_pick_columns(host, cols), F_host, G_host, X_prev[cols], maxit=100, tol=1e-8, warm=True)
+        err = np.abs(X_new[cols] - ref).max() / np.abs(ref).max()
+        assert err < 2e-2, (side, err)
+        assert X_new.min() >= 0
+        ops.row_norms(X, 0, out=sums)
+        ops.apply_scaling(X, sums, 0, dd)
