@@ -250,6 +250,21 @@ def main():
                     share_h = sw_h / (sw_h + sw_w)
             except Exception:
                 pass
+            # idle-slot fraction of the MFMA tiles: a wave sweeps until its slowest column has converged, so a tile of T
+            # columns spends T * max(sweeps) column-sweeps for sum(sweeps) useful ones (last iteration's counts, in the
+            # work order the kernel used: sweep-sorted for the H side, natural for the W side)
+            idle = {}
+            try:
+                for side, tile in (("H", 32), ("W", 16 if n_loc >= 0 and m <= 32 * 1024 else 32)):
+                    o = st.ops._order[side]
+                    sw = o["sweeps"].cpu().numpy().astype(np.int64)
+                    use_order = o["valid"] and cfg.cd_tol > 0 and sw.shape[0] >= 32768
+                    sq = sw[o["order"].cpu().numpy()] if use_order else sw
+                    pad = (-len(sq)) % tile
+                    tl = np.concatenate([sq, np.zeros(pad, np.int64)]).reshape(-1, tile)
+                    idle[side] = float(1.0 - tl.sum() / max(1, (tl.max(axis=1) * tile).sum()))
+            except Exception:
+                pass
             mfma = args.dtype == "f32" and k <= 64 and args.variant == "auto"
             flops_h = 2.0 * k * k * work["cd_column_sweeps"] * share_h / max(cnt_sh, 1)
             flops_w = 2.0 * k * k * work["cd_column_sweeps"] * (1.0 - share_h) / max(cnt_sw, 1)
@@ -262,6 +277,7 @@ def main():
                        "achieved": tf_h, "peak": cd_peak, "unit": "TFLOP/s", "frac": tf_h / cd_peak, "traffic": None,
                        "algorithmic_flops_per_launch": flops_h, "avg_launch_ms": s_h * 1e3,
                        "mean_sweeps_per_column": work["cd_column_sweeps"] / work["cd_columns"],
+                       "idle_slot_fraction": idle,
                        "solve_H_ms": s_h * 1e3, "solve_W_ms": s_w * 1e3,
                        "w_side": {"kernel": "cd_mfma64_kernel<float> (16-column MFMA tiles)" if mfma else "same kernel",
                                   "achieved": tf_w, "frac": tf_w / cd_peak, "avg_launch_ms": s_w * 1e3,

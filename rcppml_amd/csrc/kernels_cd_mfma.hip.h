@@ -64,15 +64,15 @@ __device__ __forceinline__ CdStepOut cd_scalar_step(float b, float xo, float gin
                                                     float lo, float hi) {
     CdStepOut o;
     if constexpr (SIMPLE) {
-        const float diff = b * ginv;
-        const float nv = xo + diff;
-        const bool neg = nv < 0.f;
-        float nx = neg ? 0.f : nv;
-        float a = neg ? -xo : diff;
+        // reference: nv = xo + diff; if (nv < 0) { a = -xo; x = 0 } else { a = diff; x = nv }.  nv < 0 <=> diff < -xo (the
+        // sum of two floats keeps its sign through rounding: tiny sums are exact), so a = max(diff, -xo) and
+        // x = max(nv, 0) -- the same values with a two-instruction dependent chain (v_mul, v_max) in front of the MFMA
+        // instead of four (v_mul, v_add, v_cmp, v_cndmask): the sweep is a serial chain of these steps.
         // `active` and the reference's `if (g_diag <= 0) continue;` arrive folded into ginv (= 0): then diff = 0,
-        // nv = xo >= 0, so a = 0 and nx = xo without any select
-        o.a = a;
-        o.nx = nx;
+        // a = max(0, -xo) = 0 and nx = xo for the non-negative iterates of this mode
+        const float diff = b * ginv;
+        o.a = __builtin_fmaxf(diff, -xo);
+        o.nx = __builtin_fmaxf(xo + diff, 0.f);
     } else {
         float diff = b * ginv;
         diff -= l1_cd;                        // reference: `if (L1 != 0) diff -= L1` (subtracting 0 is exact)

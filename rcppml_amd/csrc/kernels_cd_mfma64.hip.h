@@ -88,17 +88,19 @@ template <int P> __device__ __forceinline__ double bcast_row(double a) {
 }
 
 template <class T> struct CdStepOut64 { T a, nx; };
+__device__ __forceinline__ float tmax(float a, float b) { return __builtin_fmaxf(a, b); }
+__device__ __forceinline__ double tmax(double a, double b) { return __builtin_fmax(a, b); }
 
 template <bool SIMPLE, class T>
 __device__ __forceinline__ CdStepOut64<T> cd_step64(T b, T xo, T ginv, bool active, T l1_cd, T l2_cd, T lo, T hi) {
     CdStepOut64<T> o;
     if constexpr (SIMPLE) {
-        // `active` and `if (g_diag <= 0) continue;` arrive folded into ginv (= 0): diff = 0, nv = xo >= 0, a = 0, nx = xo
+        // a = max(diff, -xo), x = max(xo + diff, 0): the reference's clamped step with a two-instruction dependent chain
+        // (see cd_scalar_step in kernels_cd_mfma.hip.h).  `active` and `if (g_diag <= 0) continue;` arrive folded into
+        // ginv (= 0): diff = 0, a = 0, nx = xo
         const T diff = b * ginv;
-        const T nv = xo + diff;
-        const bool neg = nv < T(0);
-        o.nx = neg ? T(0) : nv;
-        o.a = neg ? -xo : diff;
+        o.a = tmax(diff, -xo);
+        o.nx = tmax(xo + diff, T(0));
     } else {
         T diff = b * ginv;
         diff -= l1_cd;
