@@ -1,0 +1,134 @@
+// plugin_common.hip.h -- helpers shared by the plugin's translation units (plugin.hip: the single-device ALS loop and the
+// entry points; plugin_multi.hip: the multi-device loop): device buffers, context guard, the parameter carrier of a fit
+// and the host<->device conversions of the boundary's double buffers.
+#pragma once
+#include "common.hip.h"
+
+#include <algorithm>
+#include <cmath>
+#include <numeric>
+
+namespace rcppml_plugin {
+
+#define OPCHK(expr)                                                                  \
+    do {                                                                             \
+        if ((expr) != 0) throw std::runtime_error(std::string(#expr) + ": " + rcppml_err()); \
+    } while (0)
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    DevBuf() {}
+    explicit DevBuf(size_t b) { alloc(b); }
+    void alloc(size_t b) {
+        release();
+        bytes = b < 16 ? 16 : b;
+        HIPCHK(hipMalloc(&p, bytes));
+    }
+    bool owned = true;
+    void borrow(const void* ptr) { release(); p = const_cast<void*>(ptr); owned = false; }   // caller-owned device memory
+    void release() { if (p && owned) (void)hipFree(p); p = nullptr; bytes = 0; owned = true; }
+    ~DevBuf() { release(); }
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    template <class U> U* as() const { return static_cast<U*>(p); }
+};
+
+struct CtxGuard {
+    rcppml_hip_ctx* c = nullptr;
+    hipStream_t s = nullptr;
+    explicit CtxGuard(int device) {
+        HIPCHK(hipSetDevice(device));
+        HIPCHK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        if (rcppml_hip_ctx_create(&c, device, s) != 0) {
+            (void)hipStreamDestroy(s);
+            throw std::runtime_error("ctx_create: " + rcppml_err());
+        }
+    }
+    ~CtxGuard() {
+        if (c) rcppml_hip_ctx_destroy(c);
+        if (s) (void)hipStreamDestroy(s);
+    }
+};
+
+inline int env_device() {
+    const char* e = getenv("RCPPML_GPU_DEVICE");
+    return e ? atoi(e) : 0;
+}
+
+struct FitParams {
+    int m, n, k;
+    int64_t nnz;
+    const int* col_ptr; const int* row_idx; const double* values;
+    double *W, *H, *d;            // in/out (host, double)
+    int max_iter; double tol;
+    double L1_H, L1_W, L2_H, L2_W, ub_H, ub_W;
+    double L21_H = 0, L21_W = 0, angular_H = 0, angular_W = 0;
+    // graph Laplacians (host CSC, dim x dim): graph_H over the columns of H (dim = n), graph_W over the columns of W_T (dim = m)
+    const int* gH_p = nullptr; const int* gH_i = nullptr; const double* gH_x = nullptr; int gH_nnz = 0; double gH_lambda = 0;
+    const int* gW_p = nullptr; const int* gW_i = nullptr; const double* gW_x = nullptr; int gW_nnz = 0; double gW_lambda = 0;
+    int symmetric = 0;                       // A ~ W diag(d) W^T (A square): only W is solved, H = W_T
+    const double* dense = nullptr;           // dense input (column-major m x n): the unfused standard path of fit_cpu.hpp
+    int csc_on_device = 0;                   // col_ptr / row_idx / values are DEVICE pointers (zero-copy entry)
+    int projective = 0;                      // H = (diag(d) W_T) A instead of the NNLS half-update (variant_helpers.hpp:308-325)
+    int cd_maxit; double cd_tol;
+    int verbose, patience, nonneg_W, nonneg_H, norm_type, solver_mode;
+    const int* mask_p; const int* mask_i;   // NULL = no mask
+    int sort_model;
+    double* loss_history;                    // may be NULL
+    int loss_type = 0;                       // 0 = MSE, 4 = GP, 5 = NB, 6 = Gamma, 7 = inverse Gaussian, 8 = Tweedie
+    double tweedie_power = 1.5;
+    double robust_delta = 0;                 // > 0: Huber modifier on Pearson residuals (all losses -> IRLS path)
+    int irls_max_iter = 5; double irls_tol = 1e-4;
+    int dispersion_mode = 2;                 // 0 none, 1 global, 2 per-row
+    double nb_size_init = 10, nb_size_max = 1e6, nb_size_min = 0.01;
+    double gp_theta_init = 0.1, gp_theta_max = 5.0;                       // core/config.hpp:169-172
+    double gamma_phi_init = 1.0, gamma_phi_max = 1e4, gamma_phi_min = 1e-6;   // core/config.hpp:201-207
+    double* out_theta = nullptr; int out_theta_len = 0;
+    // outputs
+    int out_iter = 0, out_converged = 0; double out_loss = 0, out_tol = 0;
+};
+
+template <class T> struct DT;
+template <> struct DT<float> { static constexpr int id = RCPPML_F32; };
+template <> struct DT<double> { static constexpr int id = RCPPML_F64; };
+
+// The boundary hands over double buffers (bridge_nmf.hpp:310-342).  They are uploaded as they are and cast on the
+// device (no host-side temporaries, no host loops over nnz).
+template <class T>
+inline void upload_cast(rcppml_hip_ctx* c, const double* src, size_t n, DevBuf& dst, hipStream_t s) {
+    dst.alloc(n * sizeof(T));
+    if constexpr (std::is_same<T, double>::value) {
+        HIPCHK(hipMemcpyAsync(dst.p, src, n * sizeof(T), hipMemcpyHostToDevice, s));
+        HIPCHK(hipStreamSynchronize(s));
+    } else {
+        DevBuf stage(n * sizeof(double));
+        HIPCHK(hipMemcpyAsync(stage.p, src, n * sizeof(double), hipMemcpyHostToDevice, s));
+        OPCHK(rcppml_hip_cast(c, RCPPML_F64, stage.p, RCPPML_F32, dst.p, (int64_t)n));
+        HIPCHK(hipStreamSynchronize(s));
+    }
+}
+template <class T>
+inline void download_cast(rcppml_hip_ctx* c, const DevBuf& src, size_t n, double* dst, hipStream_t s) {
+    if constexpr (std::is_same<T, double>::value) {
+        HIPCHK(hipMemcpyAsync(dst, src.p, n * sizeof(T), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+    } else {
+        DevBuf stage(n * sizeof(double));
+        OPCHK(rcppml_hip_cast(c, RCPPML_F32, src.p, RCPPML_F64, stage.p, (int64_t)n));
+        HIPCHK(hipMemcpyAsync(dst, stage.p, n * sizeof(double), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+    }
+}
+inline void upload_ints(const int* src, size_t n, DevBuf& dst, hipStream_t s) {
+    dst.alloc(n * sizeof(int));
+    HIPCHK(hipMemcpyAsync(dst.p, src, n * sizeof(int), hipMemcpyHostToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));
+}
+
+}  // namespace rcppml_plugin
+using namespace rcppml_plugin;
+
+// Multi-device fit (plugin_multi.hip): plain sparse MSE fits sharded over `ndev` devices of this process, RCCL between
+// them.  Returns false when the configuration is not one it handles (the caller then runs the single-device loop).
+bool rcppml_fit_multi(FitParams& P, int precision, int ndev);

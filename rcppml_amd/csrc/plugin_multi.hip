@@ -1,0 +1,366 @@
+// ============================================================================
+// plugin_multi.hip -- the ALS loop of the plugin over several devices of ONE process (RCPPML_GPU_DEVICES=n), so that the R
+// caller's 73-pointer call shards without any change on its side.  The reference is single-GPU (core/resources.hpp:
+// 205-210, config.max_gpus is never read): this is the north star's design, SURVEY.md 8(e), the same scheme as the
+// harness loop in rcppml_amd/als.py:
+//   * columns of A and H in contiguous, nnz-balanced shards, one per device; W_T replicated;
+//   * H half-update: no communication; its row scaling needs the k row sums over all shards: one all-reduce of k values;
+//   * W half-update: every device forms H_loc H_loc^T and H_loc A_loc^T into ONE buffer [G_p | B_p] -> one all-reduce
+//     (RCCL over xGMI; 5.1 MB fp32 at C2) -> every device holds the full Gram and right-hand side and solves the m columns
+//     of W redundantly (m << n): identical inputs and deterministic kernels give bitwise identical W_T on every device,
+//     which the loop relies on (no broadcast) and tests/test_gpu_plugin_multi.py asserts;
+//   * loss: Gram trick from replicated quantities, read from device 0.
+// N devices differ from one device only by the summation order of the two reduced buffers.
+// Scope: the plain sparse MSE fit (CD or Cholesky, L1/L2/bounds, any norm).  Masks, IRLS losses, graph / L21 / angular
+// terms, dense input, projective and symmetric fits need whole rows or other global state on the W side: the caller keeps
+// the single-device loop for them (rcppml_fit_multi returns false).
+// RCCL is loaded at run time (dlopen) -- the single-device plugin has no dependency on it.
+// RCPPML_GPU_DEVICES_SHARE=1 maps every shard onto device 0 and replaces the collectives by a local sum kernel: the
+// sharded loop can then be exercised on a one-GPU box (RCCL refuses two ranks on one device).
+// ============================================================================
+#include "plugin_common.hip.h"
+
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <memory>
+
+namespace {
+
+template <class T>
+__global__ void mg_diag_add_kernel(T* __restrict__ G, int k, T v) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < k) G[(size_t)i * k + i] += v;
+}
+// out[r][i] = sum_r in[r][i] for every replica r (shared-device stand-in of the all-reduce; fixed order)
+template <class T>
+__global__ void mg_local_sum_kernel(T* const* __restrict__ bufs, int n, size_t count) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    T s = bufs[0][i];
+    for (int r = 1; r < n; ++r) s += bufs[r][i];
+    for (int r = 0; r < n; ++r) bufs[r][i] = s;
+}
+
+struct Rccl {
+    void* h = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    void load() {
+        if (h) return;
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (h) break;
+        }
+        if (!h) throw std::runtime_error(std::string("RCPPML_GPU_DEVICES: cannot load RCCL: ") + dlerror());
+        auto sym = [&](const char* s) {
+            void* p = dlsym(h, s);
+            if (!p) throw std::runtime_error(std::string("RCCL symbol missing: ") + s);
+            return p;
+        };
+        CommInitAll = reinterpret_cast<decltype(CommInitAll)>(sym("ncclCommInitAll"));
+        CommDestroy = reinterpret_cast<decltype(CommDestroy)>(sym("ncclCommDestroy"));
+        AllReduce = reinterpret_cast<decltype(AllReduce)>(sym("ncclAllReduce"));
+        GroupStart = reinterpret_cast<decltype(GroupStart)>(sym("ncclGroupStart"));
+        GroupEnd = reinterpret_cast<decltype(GroupEnd)>(sym("ncclGroupEnd"));
+        GetErrorString = reinterpret_cast<decltype(GetErrorString)>(sym("ncclGetErrorString"));
+    }
+    void chk(ncclResult_t r, const char* what) {
+        if (r != ncclSuccess) throw std::runtime_error(std::string(what) + ": " + (GetErrorString ? GetErrorString(r) : "RCCL error"));
+    }
+};
+Rccl& rccl() { static Rccl r; return r; }
+
+// all-reduce(sum) of one buffer per device; `shared`: all shards live on one device (test mode)
+struct Exchange {
+    int n = 0;
+    bool shared = false;
+    std::vector<ncclComm_t> comms;
+    std::vector<hipStream_t> streams;
+    std::vector<int> devs;
+    DevBuf ptrs;                       // shared mode: device array of the n buffer pointers
+    std::vector<hipEvent_t> ev;
+    ~Exchange() {
+        for (auto c : comms) if (c) (void)rccl().CommDestroy(c);
+        for (auto e : ev) if (e) (void)hipEventDestroy(e);
+    }
+    void init(const std::vector<int>& devices, const std::vector<hipStream_t>& st, bool share) {
+        n = (int)devices.size(); devs = devices; streams = st; shared = share;
+        if (shared) {
+            HIPCHK(hipSetDevice(devs[0]));
+            ptrs.alloc((size_t)n * sizeof(void*));
+            ev.resize(n + 1, nullptr);
+            for (auto& e : ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        } else {
+            rccl().load();
+            comms.assign(n, nullptr);
+            rccl().chk(rccl().CommInitAll(comms.data(), n, devs.data()), "ncclCommInitAll");
+        }
+    }
+    template <class T>
+    void all_reduce(const std::vector<void*>& bufs, size_t count) {
+        if (n == 1) return;
+        if (shared) {
+            // every stream's work on its buffer -> stream 0 sums -> every stream waits for the sum
+            HIPCHK(hipSetDevice(devs[0]));
+            for (int r = 1; r < n; ++r) { HIPCHK(hipEventRecord(ev[r], streams[r])); HIPCHK(hipStreamWaitEvent(streams[0], ev[r], 0)); }
+            HIPCHK(hipMemcpyAsync(ptrs.p, bufs.data(), (size_t)n * sizeof(void*), hipMemcpyHostToDevice, streams[0]));
+            hipLaunchKernelGGL(mg_local_sum_kernel<T>, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, streams[0],
+                               (T* const*)ptrs.p, n, count);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipEventRecord(ev[n], streams[0]));
+            for (int r = 1; r < n; ++r) HIPCHK(hipStreamWaitEvent(streams[r], ev[n], 0));
+            HIPCHK(hipStreamSynchronize(streams[0]));       // `bufs.data()` (host vector) was the copy source
+            return;
+        }
+        const ncclDataType_t ty = std::is_same<T, float>::value ? ncclFloat : ncclDouble;
+        rccl().chk(rccl().GroupStart(), "ncclGroupStart");
+        for (int r = 0; r < n; ++r)
+            rccl().chk(rccl().AllReduce(bufs[r], bufs[r], count, ty, ncclSum, comms[r], streams[r]), "ncclAllReduce");
+        rccl().chk(rccl().GroupEnd(), "ncclGroupEnd");
+    }
+};
+
+template <class T>
+struct Shard {
+    int dev = 0;
+    std::unique_ptr<CtxGuard> g;
+    int c0 = 0, n_loc = 0;
+    int64_t nnz_loc = 0;
+    DevBuf Ap, Ai, Ax, Tp, Ti, Tx;
+    DevBuf W, H, d, Bh, xbuf, G, Gs, Gwt, sums, tr, loss, swH, ordH, swW;
+    rcppml_rhs_plan* planA = nullptr;
+    rcppml_rhs_plan* planT = nullptr;
+    ~Shard() {
+        if (g) (void)hipSetDevice(dev);
+        rcppml_hip_rhs_plan_destroy(planA);
+        rcppml_hip_rhs_plan_destroy(planT);
+    }
+};
+
+template <class T>
+void fit_multi(FitParams& P, const std::vector<int>& devices, bool shared) {
+    constexpr int dt = DT<T>::id;
+    const int m = P.m, n = P.n, k = P.k, nd = (int)devices.size();
+    const double eps = 1e-15;
+    // ---- contiguous column shards balanced by nonzeros (als.partition_columns_by_nnz)
+    std::vector<int> cut(nd + 1, 0);
+    cut[nd] = n;
+    {
+        int j = 0;
+        for (int r = 1; r < nd; ++r) {
+            const int64_t target = P.nnz * r / nd;
+            while (j < n && P.col_ptr[j] < target) ++j;
+            cut[r] = std::max(cut[r - 1], std::min(j, n));
+        }
+    }
+    std::vector<std::unique_ptr<Shard<T>>> S(nd);
+    std::vector<hipStream_t> streams(nd);
+    for (int r = 0; r < nd; ++r) {
+        S[r].reset(new Shard<T>());
+        Shard<T>& s = *S[r];
+        s.dev = devices[r];
+        s.g.reset(new CtxGuard(s.dev));
+        streams[r] = s.g->s;
+        rcppml_hip_ctx* c = s.g->c;
+        s.c0 = cut[r]; s.n_loc = cut[r + 1] - cut[r];
+        const int e0 = P.col_ptr[s.c0], e1 = P.col_ptr[cut[r + 1]];
+        s.nnz_loc = e1 - e0;
+        const size_t nz = (size_t)std::max<int64_t>(s.nnz_loc, 1);
+        std::vector<int> p((size_t)s.n_loc + 1);
+        for (int j = 0; j <= s.n_loc; ++j) p[j] = P.col_ptr[s.c0 + j] - e0;
+        upload_ints(p.data(), p.size(), s.Ap, s.g->s);
+        upload_ints(P.row_idx + e0, nz, s.Ai, s.g->s);
+        upload_cast<T>(c, P.values + e0, nz, s.Ax, s.g->s);
+        s.Tp.alloc(((size_t)m + 1) * sizeof(int));
+        s.Ti.alloc(nz * sizeof(int));
+        s.Tx.alloc(nz * sizeof(T));
+        OPCHK(rcppml_hip_transpose_csc(c, dt, m, s.n_loc, s.Ap.template as<int>(), s.Ai.template as<int>(), s.Ax.p, s.Tp.template as<int>(), s.Ti.template as<int>(), s.Tx.p));
+        upload_cast<T>(c, P.W, (size_t)k * m, s.W, s.g->s);
+        upload_cast<T>(c, P.H + (size_t)k * s.c0, (size_t)k * std::max(s.n_loc, 1), s.H, s.g->s);
+        s.d.alloc((size_t)k * sizeof(T));
+        {
+            std::vector<T> ones(k, T(1));
+            HIPCHK(hipMemcpyAsync(s.d.p, ones.data(), k * sizeof(T), hipMemcpyHostToDevice, s.g->s));
+            HIPCHK(hipStreamSynchronize(s.g->s));
+        }
+        s.Bh.alloc((size_t)k * std::max(s.n_loc, 1) * sizeof(T));
+        s.xbuf.alloc(((size_t)k * k + (size_t)k * m) * sizeof(T));           // [G_p | B_p]: one all-reduce
+        s.G.alloc((size_t)k * k * sizeof(T)); s.Gs.alloc((size_t)k * k * sizeof(T)); s.Gwt.alloc((size_t)k * k * sizeof(T));
+        s.sums.alloc((size_t)k * sizeof(T));
+        s.tr.alloc(sizeof(double)); s.loss.alloc(4 * sizeof(double));
+        s.swH.alloc((size_t)std::max(s.n_loc, 1) * sizeof(int)); s.ordH.alloc((size_t)std::max(s.n_loc, 1) * sizeof(int));
+        s.swW.alloc((size_t)m * sizeof(int));
+        if (s.nnz_loc >= (1 << 20)) {
+            OPCHK(rcppml_hip_rhs_plan_create(c, dt, s.Ap.template as<int>(), s.Ai.template as<int>(), s.Ax.p, s.n_loc, m, k, 0, 0, &s.planA));
+            OPCHK(rcppml_hip_rhs_plan_create(c, dt, s.Tp.template as<int>(), s.Ti.template as<int>(), s.Tx.p, m, s.n_loc, k, 0, 0, &s.planT));
+        }
+    }
+    Exchange X;
+    X.init(devices, streams, shared);
+
+    // ---- ||A||^2 over all shards
+    double trAtA = 0;
+    for (int r = 0; r < nd; ++r) {
+        Shard<T>& s = *S[r];
+        OPCHK(rcppml_hip_sumsq(s.g->c, dt, s.Ax.p, s.nnz_loc, s.tr.template as<double>()));
+        double v = 0;
+        HIPCHK(hipMemcpyAsync(&v, s.tr.p, sizeof(double), hipMemcpyDeviceToHost, s.g->s));
+        HIPCHK(hipStreamSynchronize(s.g->s));
+        trAtA += v;
+    }
+    for (int r = 0; r < nd; ++r) {
+        HIPCHK(hipSetDevice(S[r]->dev));
+        HIPCHK(hipMemcpyAsync(S[r]->tr.p, &trAtA, sizeof(double), hipMemcpyHostToDevice, S[r]->g->s));
+        HIPCHK(hipStreamSynchronize(S[r]->g->s));
+    }
+    const bool use_order = P.solver_mode == 0 && P.cd_tol > 0;
+    std::vector<void*> bufs(nd);
+    auto T_ptr = [](DevBuf& b, size_t off) { return static_cast<void*>(static_cast<T*>(b.p) + off); };
+
+    double prev_loss = std::is_same<T, float>::value ? (double)std::numeric_limits<float>::max() : std::numeric_limits<double>::max();
+    int patience_counter = 0, iterations = 0;
+    bool converged = false;
+    double final_tol = 0, train_loss = 0, last_loss = 0;
+    double* hloss = nullptr;
+    HIPCHK(hipSetDevice(S[0]->dev));
+    HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&hloss), 4 * sizeof(double)));
+    struct HostFree { double* p; ~HostFree() { (void)hipHostFree(p); } } hf{hloss};
+
+    for (int iter = 0; iter < P.max_iter; ++iter) {
+        const int warm = iter > 0 ? 1 : 0;
+        // ================= H half-update on every shard (fit_cpu.hpp:486-645): no communication
+        for (int r = 0; r < nd; ++r) {
+            Shard<T>& s = *S[r];
+            rcppml_hip_ctx* c = s.g->c;
+            if (s.n_loc == 0) { HIPCHK(hipSetDevice(s.dev)); HIPCHK(hipMemsetAsync(s.sums.p, 0, (size_t)k * sizeof(T), s.g->s)); continue; }
+            OPCHK(rcppml_hip_gram(c, dt, s.W.p, k, m, eps, P.L2_H, s.G.p));
+            if (s.planA) OPCHK(rcppml_hip_rhs_planned(c, s.planA, s.W.p, s.Bh.p));
+            else OPCHK(rcppml_hip_rhs(c, dt, s.Ap.template as<int>(), s.Ai.template as<int>(), s.Ax.p, s.n_loc, s.W.p, k, s.Bh.p));
+            if (P.solver_mode == 0) {
+                const bool ord = use_order && iter > 0 && s.n_loc >= 32768;
+                if (ord) OPCHK(rcppml_hip_order_columns(c, s.swH.template as<int>(), s.n_loc, s.ordH.template as<int>()));
+                OPCHK(rcppml_hip_solve_cd(c, dt, s.G.p, s.Bh.p, s.H.p, k, s.n_loc, P.L1_H > 0 ? P.L1_H : 0.0, warm, 0, 0.0, 0.0,
+                                          P.nonneg_H, P.cd_maxit, P.cd_tol, 0.0, P.ub_H, RCPPML_CD_AUTO,
+                                          use_order ? s.swH.template as<int>() : nullptr, ord ? s.ordH.template as<int>() : nullptr));
+            } else {
+                OPCHK(rcppml_hip_solve_chol(c, dt, s.G.p, s.Bh.p, s.H.p, k, s.n_loc, P.L1_H > 0 ? P.L1_H : 0.0, P.nonneg_H, P.ub_H));
+            }
+            OPCHK(rcppml_hip_row_norms(c, dt, s.H.p, k, s.n_loc, P.norm_type, s.sums.p));   // partial sums (L1: sum |h|; L2: sum h^2)
+        }
+        // the scaling needs the sums over ALL columns (variant_helpers.hpp:286-305): k values
+        for (int r = 0; r < nd; ++r) bufs[r] = S[r]->sums.p;
+        X.template all_reduce<T>(bufs, (size_t)k);
+        // ================= W half-update (fit_cpu.hpp:711-893): partial Gram and right-hand side, one all-reduce
+        for (int r = 0; r < nd; ++r) {
+            Shard<T>& s = *S[r];
+            rcppml_hip_ctx* c = s.g->c;
+            HIPCHK(hipSetDevice(s.dev));
+            if (s.n_loc > 0) {
+                OPCHK(rcppml_hip_apply_scaling(c, dt, s.H.p, k, s.n_loc, P.norm_type, s.sums.p, s.d.p));
+                OPCHK(rcppml_hip_gram(c, dt, s.H.p, k, s.n_loc, 0.0, 0.0, s.xbuf.p));               // eps after the sum
+                if (s.planT) OPCHK(rcppml_hip_rhs_planned(c, s.planT, s.H.p, T_ptr(s.xbuf, (size_t)k * k)));
+                else OPCHK(rcppml_hip_rhs(c, dt, s.Tp.template as<int>(), s.Ti.template as<int>(), s.Tx.p, m, s.H.p, k, T_ptr(s.xbuf, (size_t)k * k)));
+            } else {
+                OPCHK(rcppml_hip_apply_scaling(c, dt, s.H.p, k, 0, P.norm_type, s.sums.p, s.d.p));   // d from the global sums
+                HIPCHK(hipMemsetAsync(s.xbuf.p, 0, s.xbuf.bytes, s.g->s));
+            }
+        }
+        for (int r = 0; r < nd; ++r) bufs[r] = S[r]->xbuf.p;
+        X.template all_reduce<T>(bufs, (size_t)k * k + (size_t)k * m);
+        for (int r = 0; r < nd; ++r) {
+            Shard<T>& s = *S[r];
+            rcppml_hip_ctx* c = s.g->c;
+            HIPCHK(hipSetDevice(s.dev));
+            hipStream_t st = s.g->s;
+            hipLaunchKernelGGL(mg_diag_add_kernel<T>, dim3((k + 63) / 64), dim3(64), 0, st, (T*)s.xbuf.p, k, (T)eps);   // gram.hpp:50-52
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipMemcpyAsync(s.Gs.p, s.xbuf.p, (size_t)k * k * sizeof(T), hipMemcpyDeviceToDevice, st));           // G_saved (:719-722)
+            HIPCHK(hipMemcpyAsync(s.G.p, s.xbuf.p, (size_t)k * k * sizeof(T), hipMemcpyDeviceToDevice, st));
+            if (P.L2_W > 0) {
+                hipLaunchKernelGGL(mg_diag_add_kernel<T>, dim3((k + 63) / 64), dim3(64), 0, st, (T*)s.G.p, k, (T)P.L2_W);   // :738
+                HIPCHK(hipGetLastError());
+            }
+            void* Bw = T_ptr(s.xbuf, (size_t)k * k);
+            if (P.solver_mode == 0)
+                OPCHK(rcppml_hip_solve_cd(c, dt, s.G.p, Bw, s.W.p, k, m, P.L1_W > 0 ? P.L1_W : 0.0, warm, 0, 0.0, 0.0, P.nonneg_W,
+                                          P.cd_maxit, P.cd_tol, 0.0, P.ub_W, RCPPML_CD_AUTO, use_order ? s.swW.template as<int>() : nullptr, nullptr));
+            else
+                OPCHK(rcppml_hip_solve_chol(c, dt, s.G.p, Bw, s.W.p, k, m, P.L1_W > 0 ? P.L1_W : 0.0, P.nonneg_W, P.ub_W));
+            OPCHK(rcppml_hip_row_norms(c, dt, s.W.p, k, m, P.norm_type, s.sums.p));
+            OPCHK(rcppml_hip_apply_scaling(c, dt, s.W.p, k, m, P.norm_type, s.sums.p, s.d.p));
+            // ---- loss (fit_cpu.hpp:1729-1753) from replicated quantities: identical on every device
+            OPCHK(rcppml_hip_gram(c, dt, s.W.p, k, m, eps, 0.0, s.Gwt.p));
+            OPCHK(rcppml_hip_loss_mse(c, dt, s.tr.template as<double>(), s.d.p, s.W.p, Bw, k, m, s.Gwt.p, s.Gs.p, s.loss.template as<double>()));
+        }
+        HIPCHK(hipSetDevice(S[0]->dev));
+        HIPCHK(hipMemcpyAsync(hloss, S[0]->loss.p, 4 * sizeof(double), hipMemcpyDeviceToHost, S[0]->g->s));
+        for (int r = 0; r < nd; ++r) { HIPCHK(hipSetDevice(S[r]->dev)); HIPCHK(hipStreamSynchronize(S[r]->g->s)); }
+        double loss_val = hloss[0];
+        if (std::is_same<T, float>::value) loss_val = static_cast<double>(static_cast<float>(loss_val));
+        last_loss = loss_val;
+        if (P.loss_history) P.loss_history[iter] = loss_val;
+        bool loss_converged = false;
+        double rel = 0;
+        if (iter > 0) {                                                                 // fit_cpu.hpp:1769-1775
+            rel = std::fabs(prev_loss - loss_val) / (std::fabs(prev_loss) + 1e-15);
+            final_tol = rel;
+            if (rel < P.tol) loss_converged = true;
+        }
+        prev_loss = loss_val;
+        if (P.verbose) fprintf(stderr, "[rcppml_gpu x%d] iter %d loss %.9g rel %.3g\n", nd, iter + 1, loss_val, rel);
+        if (iter > 0) {                                                                 // :1797-1809
+            if (loss_converged) {
+                if (++patience_counter >= P.patience) { converged = true; train_loss = prev_loss; iterations = iter + 1; break; }
+            } else patience_counter = 0;
+        }
+        iterations = iter + 1;
+    }
+    if (!converged) train_loss = last_loss;
+
+    // ---- download (W, d from device 0; every shard's H) and sort by descending d (core/result.hpp:169-188)
+    download_cast<T>(S[0]->g->c, S[0]->W, (size_t)k * m, P.W, S[0]->g->s);
+    download_cast<T>(S[0]->g->c, S[0]->d, (size_t)k, P.d, S[0]->g->s);
+    for (int r = 0; r < nd; ++r)
+        if (S[r]->n_loc > 0) download_cast<T>(S[r]->g->c, S[r]->H, (size_t)k * S[r]->n_loc, P.H + (size_t)k * S[r]->c0, S[r]->g->s);
+    if (P.sort_model) {
+        std::vector<int> idx(k);
+        std::iota(idx.begin(), idx.end(), 0);
+        std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return P.d[a] > P.d[b]; });
+        std::vector<double> tmp(k);
+        for (int j = 0; j < m; ++j) { double* w = P.W + (size_t)j * k; for (int i = 0; i < k; ++i) tmp[i] = w[idx[i]]; std::copy(tmp.begin(), tmp.end(), w); }
+        for (int j = 0; j < n; ++j) { double* h = P.H + (size_t)j * k; for (int i = 0; i < k; ++i) tmp[i] = h[idx[i]]; std::copy(tmp.begin(), tmp.end(), h); }
+        for (int i = 0; i < k; ++i) tmp[i] = P.d[idx[i]];
+        std::copy(tmp.begin(), tmp.end(), P.d);
+    }
+    P.out_iter = iterations; P.out_converged = converged ? 1 : 0; P.out_loss = train_loss; P.out_tol = final_tol;
+}
+
+}  // namespace
+
+bool rcppml_fit_multi(FitParams& P, int precision, int ndev) {
+    // what the sharded loop covers (see the header of this file)
+    if (P.dense || P.csc_on_device || P.mask_p || P.loss_type != 0 || P.robust_delta > 0 || P.projective || P.symmetric) return false;
+    if (P.L21_H > 0 || P.L21_W > 0 || P.angular_H > 0 || P.angular_W > 0) return false;
+    if ((P.gH_p && P.gH_nnz > 0 && P.gH_lambda > 0) || (P.gW_p && P.gW_nnz > 0 && P.gW_lambda > 0)) return false;
+    if (ndev < 2 || P.n < ndev) return false;
+    const char* sh = getenv("RCPPML_GPU_DEVICES_SHARE");
+    const bool shared = sh && atoi(sh) != 0;
+    int have = 0;
+    HIPCHK(hipGetDeviceCount(&have));
+    std::vector<int> devices(ndev);
+    if (shared) {
+        for (int r = 0; r < ndev; ++r) devices[r] = env_device();
+    } else {
+        if (have < ndev) throw std::runtime_error("RCPPML_GPU_DEVICES=" + std::to_string(ndev) + " but only " + std::to_string(have) +
+                                                  " device(s) visible (RCPPML_GPU_DEVICES_SHARE=1 maps the shards onto one device for testing)");
+        for (int r = 0; r < ndev; ++r) devices[r] = r;
+    }
+    if (precision == RCPPML_F64) fit_multi<double>(P, devices, shared);
+    else fit_multi<float>(P, devices, shared);
+    return true;
+}
