@@ -158,6 +158,18 @@ RCPPML_GPU_API void rcppml_gpu_nmf_ex(RCPPML_NMF_UNIFIED_ARGS, const int* mask_p
                                       int* mask_nnz, double* cd_tol, int* sort_model,
                                       int* precision, double* loss_history);
 
+/* rcppml_gpu_nmf_ex plus TARGET regularisation (nmf/variant_helpers.hpp:107-146, not carried by the
+ * 73-pointer ABI): target_H (k x n) / target_W (k x m) column-major with k leading, NULL = none, and their lambdas.
+ *   lambda > 0  enrichment: G.diagonal() += lambda, B += lambda * target;
+ *   lambda < 0  PROJ_ADV:   G -= |lambda| * (trace G / trace TG) * TG with TG = target target^T / ncols (nmf/fit.hpp:259-271),
+ *               then the eigenvalues of G below 1e-8 are raised to 1e-8 (B untouched).
+ * As in the reference (fit_cpu.hpp:430-433) a fit with a target runs the STANDARD path: B materialised, features on
+ * (G, B), nnls_batch from zero at iteration 0 and residual-corrected afterwards.  Plain MSE fits only. */
+RCPPML_GPU_API void rcppml_gpu_nmf_target(RCPPML_NMF_UNIFIED_ARGS, const int* mask_p, const int* mask_i,
+                                          int* mask_nnz, double* cd_tol, int* sort_model, int* precision,
+                                          double* loss_history, const double* target_H, double* target_lambda_H,
+                                          const double* target_W, double* target_lambda_W);
+
 /* fp64 projection h = NNLS(w^T w, w^T A): GPU entry for R nnls()/predict(), which have no GPU
  * hook in the reference (src/RcppFunctions_utils.cpp:313-366 c_nnls, :23-52 Rcpp_predict).
  * w_T: k x m, A: m x n CSC (host pointers), h: k x n in/out (warm start if *warm != 0). */
@@ -342,6 +354,11 @@ RCPPML_GPU_API int rcppml_hip_apply_graph_reg(rcppml_hip_ctx* ctx, int dtype, vo
 /* Y = diag(d) X for a k x ncols factor (variant_helpers.hpp:265-272 apply_scaling): W diag(d) of the projective H
  * update  H = (diag(d) W_T) A  (nmf/fit_cpu.hpp:462-472, variant_helpers.hpp:308-325). */
 RCPPML_GPU_API int rcppml_hip_mul_rows(rcppml_hip_ctx* ctx, int dtype, const void* X, int k, int64_t ncols, const void* d, void* Y);
+
+/* Y = X + alpha * T elementwise (n entries) and G(i,i) += v: the two device-side pieces of target regularisation
+ * (nmf/variant_helpers.hpp:107-111: G.diagonal() += lambda; B += lambda * target). */
+RCPPML_GPU_API int rcppml_hip_axpy(rcppml_hip_ctx* ctx, int dtype, const void* X, const void* T, double alpha, int64_t n, void* Y);
+RCPPML_GPU_API int rcppml_hip_add_diag(rcppml_hip_ctx* ctx, int dtype, void* G, int k, double v);
 
 /* k x k feature layer, fused-path placement of nmf/fit_cpu.hpp:505-511,636-639 / :738-745,884-887:
  * rcppml_hip_apply_l21: G(i,i) += lambda / ||X.row(i)||_2 for rows with norm > 1e-10 (features/L21.hpp:38-51); X is the

@@ -673,6 +673,73 @@ static S explicit_loss_sparse_nb(const Csc<S>& A, const S* W_Td, const S* H, int
 // W_T (k x m) and H (k x n) hold the initial factors on entry (the harness builds them:
 // fit_cpu.hpp:195-207 / nmf_init.hpp:166-182) and the result on exit (W_T not transposed).
 // ---------------------------------------------------------------------------
+// ---------------------------------------------------------------------------
+// Target regularisation -- nmf/variant_helpers.hpp:107-146 (the `fc.target` block of apply_features).
+// PROJ_ADV uses Eigen::SelfAdjointEigenSolver in the reference (third-party, absent here): its published algorithm is a
+// symmetric eigen-decomposition G = V L V^T; the clipped matrix V max(L, eps) V^T is a function of G alone, so the cyclic
+// Jacobi iteration below reproduces it to rounding (pinned against numpy.linalg.eigh in tests/test_oracle.py).
+// ---------------------------------------------------------------------------
+template <class S> void proj_adv_gram(S* G, const S* TG, int k, S abs_lambda) {
+    S trG = 0, trT = 0;
+    for (int i = 0; i < k; ++i) { trG += G[(size_t)i * k + i]; trT += TG[(size_t)i * k + i]; }          // :123-124
+    const S scale = trT > static_cast<S>(1e-10) ? trG / trT : static_cast<S>(0);                      // :125-126
+    for (size_t e = 0; e < (size_t)k * k; ++e) G[e] -= abs_lambda * scale * TG[e];                    // :127
+    // eigen-decomposition in double (Jacobi rotations on the upper triangle, eigenvectors accumulated in V)
+    std::vector<double> A((size_t)k * k), V((size_t)k * k, 0.0);
+    for (int i = 0; i < k; ++i) for (int j = 0; j < k; ++j) A[(size_t)j * k + i] = 0.5 * ((double)G[(size_t)j * k + i] + (double)G[(size_t)i * k + j]);
+    for (int i = 0; i < k; ++i) V[(size_t)i * k + i] = 1.0;
+    for (int sweep = 0; sweep < 200; ++sweep) {
+        double off = 0, diag = 0;
+        for (int i = 0; i < k; ++i) { diag += A[(size_t)i * k + i] * A[(size_t)i * k + i]; for (int j = i + 1; j < k; ++j) off += A[(size_t)j * k + i] * A[(size_t)j * k + i]; }
+        if (off <= 1e-32 * (diag + off) || off == 0) break;
+        for (int p = 0; p + 1 < k; ++p)
+            for (int q = p + 1; q < k; ++q) {
+                const double apq = A[(size_t)q * k + p];
+                if (apq == 0.0) continue;
+                const double tau = (A[(size_t)q * k + q] - A[(size_t)p * k + p]) / (2.0 * apq);
+                const double t = (tau >= 0 ? 1.0 : -1.0) / (std::abs(tau) + std::sqrt(1.0 + tau * tau));
+                const double c = 1.0 / std::sqrt(1.0 + t * t), sn = t * c;
+                for (int r = 0; r < k; ++r) {          // A <- A J (columns p, q)
+                    const double x = A[(size_t)p * k + r], y = A[(size_t)q * k + r];
+                    A[(size_t)p * k + r] = c * x - sn * y; A[(size_t)q * k + r] = sn * x + c * y;
+                }
+                for (int r = 0; r < k; ++r) {          // A <- J^T A (rows p, q)
+                    const double x = A[(size_t)r * k + p], y = A[(size_t)r * k + q];
+                    A[(size_t)r * k + p] = c * x - sn * y; A[(size_t)r * k + q] = sn * x + c * y;
+                }
+                for (int r = 0; r < k; ++r) {          // V <- V J
+                    const double x = V[(size_t)p * k + r], y = V[(size_t)q * k + r];
+                    V[(size_t)p * k + r] = c * x - sn * y; V[(size_t)q * k + r] = sn * x + c * y;
+                }
+            }
+    }
+    constexpr double eps = 1e-8;                                                                       // :133
+    bool has_neg = false;
+    std::vector<double> ev(k);
+    for (int i = 0; i < k; ++i) { ev[i] = A[(size_t)i * k + i]; if (ev[i] < eps) { ev[i] = eps; has_neg = true; } }   // :135-140
+    if (!has_neg) return;                                                                              // :141
+    for (int i = 0; i < k; ++i)
+        for (int j = 0; j < k; ++j) {
+            double s = 0;
+            for (int e = 0; e < k; ++e) s += V[(size_t)e * k + i] * ev[e] * V[(size_t)e * k + j];
+            G[(size_t)j * k + i] = static_cast<S>(s);                                                  // :142-143
+        }
+}
+template <class S> void apply_target(S* G, S* B, const S* target, const S* target_gram, int k, int64_t ncols, S lambda) {
+    if (!target || lambda == 0) return;                                                                // :105
+    if (lambda > 0) {                                                                                  // :106-110 enrichment
+        for (int i = 0; i < k; ++i) G[(size_t)i * k + i] += lambda;
+        for (int64_t e = 0; e < (int64_t)k * ncols; ++e) B[e] += lambda * target[e];
+    } else {
+        proj_adv_gram(G, target_gram, k, static_cast<S>(-lambda));                                     // :111-145 (B untouched)
+    }
+}
+template void proj_adv_gram<float>(float*, const float*, int, float);
+template void proj_adv_gram<double>(double*, const double*, int, double);
+template void apply_target<float>(float*, float*, const float*, const float*, int, int64_t, float);
+template void apply_target<double>(double*, double*, const double*, const double*, int, int64_t, double);
+
+
 template <class S>
 FitResult<S> nmf_fit(const Csc<S>& A, const FitConfig<S>& cfg, S* W_T, S* H, S* d) {
     const int m = A.rows, n = A.cols, k = cfg.k;
@@ -698,6 +765,20 @@ FitResult<S> nmf_fit(const Csc<S>& A, const FitConfig<S>& cfg, S* W_T, S* H, S* 
     if (cfg.loss_type == 0) nb_size.assign(m, S(0));          // robust MSE: no dispersion; the IRLS of GP / power losses gets no theta
 
     std::vector<S> G((size_t)k * k), G_saved((size_t)k * k), G_wt((size_t)k * k);
+    // target regularisation: nmf/fit.hpp:259-271 pre-computes T T^T / ncols for PROJ_ADV; a target forces the standard path
+    // (fit_cpu.hpp:430-433 can_fuse = ... && !config.has_target())
+    const bool tgt_H = cfg.target_H && cfg.target_lambda_H != 0, tgt_W = cfg.target_W && cfg.target_lambda_W != 0;
+    const bool unfused = cfg.unfused || tgt_H || tgt_W;
+    std::vector<S> TG_H, TG_W;
+    auto target_gram = [&](const S* Tm, int64_t ncols, std::vector<S>& out) {
+        out.assign((size_t)k * k, S(0));
+        for (int64_t j = 0; j < ncols; ++j)
+            for (int a = 0; a < k; ++a)
+                for (int b = 0; b < k; ++b) out[(size_t)b * k + a] += Tm[(size_t)j * k + a] * Tm[(size_t)j * k + b];
+        for (auto& v : out) v /= static_cast<S>(ncols);
+    };
+    if (tgt_H && cfg.target_lambda_H < 0) target_gram(cfg.target_H, n, TG_H);
+    if (tgt_W && cfg.target_lambda_W < 0) target_gram(cfg.target_W, m, TG_W);
     S prev_loss = std::numeric_limits<S>::max();
     int patience_counter = 0;
 
@@ -727,11 +808,12 @@ FitResult<S> nmf_fit(const Csc<S>& A, const FitConfig<S>& cfg, S* W_T, S* H, S* 
             if (cfg.L2_H > 0) for (int i = 0; i < k; ++i) G[(size_t)i * k + i] += cfg.L2_H;   // :506
             if (cfg.has_graph_H) apply_graph_reg(G.data(), cfg.graph_H, H, k, cfg.graph_H_lambda);      // :508-509
             apply_L21(G.data(), H, k, (int64_t)n, cfg.L21_H);                                  // :509-510 (current H)
-            if (cfg.unfused) {
-                // :540-631 STANDARD PATH (dense data): B = W_T A, L1 on B (sparsity.hpp:47), nnls_batch / cholesky_clip_batch
+            if (unfused) {
+                // :540-631 STANDARD PATH (dense data / target): B = W_T A, L1 on B (sparsity.hpp:47), target, nnls_batch / cholesky_clip_batch
                 std::vector<S> B((size_t)k * n);
                 rhs(A, W_T, k, B.data(), threads);
                 if (cfg.L1_H > 0) for (auto& b : B) b -= cfg.L1_H;
+                if (tgt_H) apply_target(G.data(), B.data(), cfg.target_H, TG_H.data(), k, (int64_t)n, cfg.target_lambda_H);   // variant_helpers.hpp:105-146
                 if (cfg.solver_mode == 1) cholesky_clip_batch(G.data(), B.data(), H, k, n, cfg.nonneg_H, threads);
                 else nnls_batch(G.data(), B.data(), H, k, n, cfg.cd_maxit, cfg.cd_tol, S(0), S(0), cfg.nonneg_H, threads, S(0), iter > 0);
             } else
@@ -776,12 +858,13 @@ FitResult<S> nmf_fit(const Csc<S>& A, const FitConfig<S>& cfg, S* W_T, S* H, S* 
             if (cfg.L2_W > 0) for (int i = 0; i < k; ++i) G[(size_t)i * k + i] += cfg.L2_W;   // :738
             if (cfg.has_graph_W) apply_graph_reg(G.data(), cfg.graph_W, W_T, k, cfg.graph_W_lambda);    // :740-741
             apply_L21(G.data(), W_T, k, (int64_t)m, cfg.L21_W);                                // :741-745 (current W_T)
-            if (cfg.unfused) {
+            if (unfused) {
                 // :774-881 STANDARD PATH: B = H A^T saved BEFORE the features (:786-789), then as on the H side
                 B_sym.assign((size_t)k * m, S(0));
                 rhs(At, H, k, B_sym.data(), threads);
                 std::vector<S> B = B_sym;
                 if (cfg.L1_W > 0) for (auto& b : B) b -= cfg.L1_W;
+                if (tgt_W) apply_target(G.data(), B.data(), cfg.target_W, TG_W.data(), k, (int64_t)m, cfg.target_lambda_W);
                 if (cfg.solver_mode == 1) cholesky_clip_batch(G.data(), B.data(), W_T, k, m, cfg.nonneg_W, threads);
                 else nnls_batch(G.data(), B.data(), W_T, k, m, cfg.cd_maxit, cfg.cd_tol, S(0), S(0), cfg.nonneg_W, threads, S(0), iter > 0);
             } else
@@ -812,7 +895,7 @@ FitResult<S> nmf_fit(const Csc<S>& A, const FitConfig<S>& cfg, S* W_T, S* H, S* 
         } else {
             gram(W_T, k, m, G_wt.data());                                                   // :1734-1735
             S cross;
-            if (cfg.symmetric || cfg.unfused) {                                             // :1717-1720 (B_w_saved materialised)
+            if (cfg.symmetric || unfused) {                                             // :1717-1720 (B_w_saved materialised)
                 cross = 0;
                 for (int f = 0; f < k; ++f) {
                     S rowdot = 0;
@@ -932,7 +1015,8 @@ template <class S> static Csc<S> mk(int rows, int cols, const int* p, const int*
         S L21_H, S L21_W, S angular_H, S angular_W, S robust_delta, int projective,                       \
         const int* gH_p, const int* gH_i, const S* gH_x, S gH_lambda, const int* gW_p, const int* gW_i,   \
         const S* gW_x, S gW_lambda, S gp_theta_init, S gp_theta_max, S gamma_phi_init, S gamma_phi_max,   \
-        S gamma_phi_min, int symmetric, int unfused) {                                                    \
+        S gamma_phi_min, int symmetric, int unfused, const S* target_H, S target_lambda_H,                \
+        const S* target_W, S target_lambda_W) {                                                           \
         FitConfig<S> c;                                                                                   \
         c.k = k; c.max_iter = max_iter; c.tol = tol; c.L1_H = L1_H; c.L1_W = L1_W; c.L2_H = L2_H;         \
         c.L2_W = L2_W; c.ub_H = ub_H; c.ub_W = ub_W; c.cd_maxit = cd_maxit; c.cd_tol = cd_tol;            \
@@ -945,6 +1029,7 @@ template <class S> static Csc<S> mk(int rows, int cols, const int* p, const int*
         c.gp_theta_init = gp_theta_init; c.gp_theta_max = gp_theta_max; c.gamma_phi_init = gamma_phi_init;  \
         c.gamma_phi_max = gamma_phi_max; c.gamma_phi_min = gamma_phi_min; c.symmetric = symmetric != 0;   \
         c.unfused = unfused != 0;                                                                         \
+        c.target_H = target_H; c.target_lambda_H = target_lambda_H; c.target_W = target_W; c.target_lambda_W = target_lambda_W; \
         if (gH_p) { c.has_graph_H = true; c.graph_H = mk(n, n, gH_p, gH_i, gH_x); c.graph_H_lambda = gH_lambda; } \
         if (gW_p) { c.has_graph_W = true; c.graph_W = mk(m, m, gW_p, gW_i, gW_x); c.graph_W_lambda = gW_lambda; } \
         if (mask_p) { c.has_mask = true; c.mask = mk(m, n, mask_p, mask_i, mask_x); }                     \
@@ -954,6 +1039,8 @@ template <class S> static Csc<S> mk(int rows, int cols, const int* p, const int*
         if (loss_hist) for (size_t t = 0; t < r.loss_history.size(); ++t) loss_hist[t] = r.loss_history[t]; \
         if (out_theta) for (size_t t = 0; t < r.theta.size(); ++t) out_theta[t] = r.theta[t];             \
     }
+
+ORACLE_API void oracle_proj_adv_f64(double* G, const double* TG, int k, double abs_lambda) { proj_adv_gram<double>(G, TG, k, abs_lambda); }
 
 DEFINE_PRIMS(f32, float)
 DEFINE_PRIMS(f64, double)

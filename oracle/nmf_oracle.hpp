@@ -460,12 +460,18 @@ template <class S> struct FitConfig {
     bool symmetric = false;        // A ~ W diag(d) W^T, A square: only W is solved, H = W_T (fit_cpu.hpp:659-704)                  // NMFConfig::projective: H = diag(d) W_T A instead of an NNLS solve
     S robust_delta = 0;                       // LossConfig::robust_delta (math/loss.hpp:89-96): > 0 -> Huber on Pearson residuals
     S tweedie_power = S(1.5);                 // LossConfig::power_param (math/loss.hpp:99-104), loss_type 8 only
+    // target regularisation (core/factor_config.hpp:80-102; nmf/variant_helpers.hpp:107-146): k x n / k x m, nullptr = none
+    const S* target_H = nullptr; S target_lambda_H = 0;
+    const S* target_W = nullptr; S target_lambda_W = 0;
     bool sort_model = true;
     int threads = 0;
     // explicit mask (nonzero = masked), 0 cols => absent  (core/config.hpp:411-413)
     Csc<S> mask;
     bool has_mask = false;
 };
+// nmf/variant_helpers.hpp:107-146 (target part of apply_features).  target_gram = T T^T / ncols (nmf/fit.hpp:259-271).
+template <class S> void proj_adv_gram(S* G, const S* target_gram, int k, S abs_lambda);
+template <class S> void apply_target(S* G, S* B, const S* target, const S* target_gram, int k, int64_t ncols, S lambda);
 template <class S> struct FitResult {
     int iterations = 0;
     bool converged = false;

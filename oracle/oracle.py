@@ -277,14 +277,35 @@ def dense_as_csc(M):
     return Csc((m, n), np.arange(0, m * n + 1, m, dtype=np.int32), np.tile(np.arange(m, dtype=np.int32), n), M.T.reshape(-1))
 
 
+_KEEP_TARGETS = []
+
+
+def _target_args(t, dtype, ct):
+    if t is None:
+        return None, ct(0)
+    M = _f(t[0], dtype)
+    _KEEP_TARGETS.append(M)
+    del _KEEP_TARGETS[:-8]
+    return _p(M), ct(t[1])
+
+
+def proj_adv(G, TG, abs_lambda):
+    """PROJ_ADV Gram modification (variant_helpers.hpp:112-146), fp64: returns the modified copy of G."""
+    G = _f(G, np.float64).copy()
+    TG = _f(TG, np.float64)
+    lib().oracle_proj_adv_f64(_p(G), _p(TG), C.c_int(G.shape[0]), C.c_double(abs_lambda))
+    return G
+
+
 def nmf_fit(A, W_T, H, dtype=np.float64, max_iter=100, tol=1e-4, L1=(0.0, 0.0), L2=(0.0, 0.0), ub=(0.0, 0.0),
             cd_maxit=100, cd_tol=1e-8, patience=5, nonneg=(True, True), norm_type=0, solver_mode=0, loss_type=0,
             irls_max_iter=5, irls_tol=1e-4, dispersion_mode=2, nb_size=(10.0, 1e6, 0.01), sort_model=True, threads=1,
             mask=None, native=False, tweedie_power=1.5, L21=(0.0, 0.0), angular=(0.0, 0.0), robust_delta=0.0, projective=False, graph_H=None, graph_W=None,
-            gp_theta=(0.1, 5.0), gamma_phi=(1.0, 1e4, 1e-6), symmetric=False, unfused=False):
+            gp_theta=(0.1, 5.0), gamma_phi=(1.0, 1e4, 1e-6), symmetric=False, unfused=False, target_H=None, target_W=None):
     """CPU restatement of nmf_fit<CPU> (reference nmf/fit_cpu.hpp).  L1/L2/ub/nonneg are (W, H) pairs as in R
     (src/RcppFunctions_nmf.cpp:59-62).  W_T: (m, k) array = column-major k x m; H: (n, k).
-    graph_H / graph_W: (Csc Laplacian, lambda) over the columns of H / W_T (features/graph_reg.hpp)."""
+    graph_H / graph_W: (Csc Laplacian, lambda) over the columns of H / W_T (features/graph_reg.hpp).
+    target_H / target_W: (matrix (n, k) / (m, k), lambda): target regularisation (nmf/variant_helpers.hpp:107-146)."""
     suf, ct = _suf(dtype)
     W_T = _f(W_T, dtype).copy()
     H = _f(H, dtype).copy()
@@ -310,7 +331,8 @@ def nmf_fit(A, W_T, H, dtype=np.float64, max_iter=100, tol=1e-4, L1=(0.0, 0.0), 
         C.c_int(int(sort_model)), C.c_int(threads), mp, mi, mxp, C.byref(it), C.byref(conv), C.byref(loss), C.byref(ftol),
         _p(hist), _p(theta), ct(tweedie_power), ct(L21[1]), ct(L21[0]), ct(angular[1]), ct(angular[0]), ct(robust_delta), C.c_int(int(projective)),
         *_graph_args(graph_H, dtype, ct), *_graph_args(graph_W, dtype, ct),
-        ct(gp_theta[0]), ct(gp_theta[1]), ct(gamma_phi[0]), ct(gamma_phi[1]), ct(gamma_phi[2]), C.c_int(int(symmetric)), C.c_int(int(unfused)))
+        ct(gp_theta[0]), ct(gp_theta[1]), ct(gamma_phi[0]), ct(gamma_phi[1]), ct(gamma_phi[2]), C.c_int(int(symmetric)), C.c_int(int(unfused)),
+        *_target_args(target_H, dtype, ct), *_target_args(target_W, dtype, ct))
     r = FitResult()
     r.W_T, r.H, r.d = W_T, H, d
     r.iter, r.converged, r.loss, r.tol = it.value, bool(conv.value), float(loss.value), float(ftol.value)

@@ -27,6 +27,7 @@ EXPORTED_SYMBOLS = [
     "rcppml_sp_read_gpu", "rcppml_sp_free_gpu", "rcppml_hip_rhs_dense", "rcppml_gpu_nmf_dense_unified_float",
     "rcppml_gpu_nmf_dense_unified_double",
     "rcppml_hip_rhs_plan_create", "rcppml_hip_rhs_plan_destroy", "rcppml_hip_rhs_plan_info", "rcppml_hip_rhs_planned",
+    "rcppml_gpu_nmf_target", "rcppml_hip_axpy", "rcppml_hip_add_diag",
 ]
 
 
@@ -126,12 +127,14 @@ def nmf_unified(p, i, x, m, n, k, W_T, H, *, entry="float", max_iter=100, tol=1e
                 irls_tol=1e-4, norm_type=0, projective=0, symmetric=0, solver_mode=0, gp_dispersion_mode=2,
                 nb_size=(10.0, 1e6, 0.01), mask=None, cd_tol=1e-8, sort_model=1, precision=F64, want_history=False,
                 graph_W_nnz=0, guide_H_count=0, tweedie_power=1.5, robust_delta=0.0, graph_W=None, graph_H=None,
-                gp_theta=(0.1, 5.0, 0.0), gamma_phi=(1.0, 1e4, 1e-6)):
+                gp_theta=(0.1, 5.0, 0.0), gamma_phi=(1.0, 1e4, 1e-6), target_H=None, target_W=None):
     """Call the 73-pointer plugin entry exactly as reference gpu/bridge_nmf.hpp:310-342 does.
 
     p, i: int32 CSC arrays; x: float64 values.  W_T (m, k) and H (n, k) float64 arrays (memory = column-major
     k x m / k x n) are updated IN PLACE.  entry: "float" | "double" (the reference symbols) or "ex" (build-defined,
-    adds mask / cd_tol / sort / precision / loss history).  Returns dict(d, iter, converged, loss, tol, status, ...).
+    adds mask / cd_tol / sort / precision / loss history).  target_H / target_W = (matrix (n, k) / (m, k), lambda): target
+    regularisation through the build-defined rcppml_gpu_nmf_target (entry "ex" arguments + targets).
+    Returns dict(d, iter, converged, loss, tol, status, ...).
     """
     L = lib()
     p = np.ascontiguousarray(p, np.int32)
@@ -183,8 +186,18 @@ def nmf_unified(p, i, x, m, n, k, W_T, H, *, entry="float", max_iter=100, tol=1e
         else:
             mp, mi, mnnz = dummy_i, dummy_i, 0
         hist = np.full(max(max_iter, 1), np.nan) if want_history else None
-        L.rcppml_gpu_nmf_ex(*args, _np_ptr(mp), _np_ptr(mi), _ci(mnnz), _cd(cd_tol), _ci(sort_model), _ci(precision),
-                            _np_ptr(hist) if hist is not None else None)
+        if target_H is not None or target_W is not None:
+            tH = np.ascontiguousarray(target_H[0], np.float64) if target_H is not None else None
+            tW = np.ascontiguousarray(target_W[0], np.float64) if target_W is not None else None
+            assert tH is None or tH.shape == (n, k)
+            assert tW is None or tW.shape == (m, k)
+            L.rcppml_gpu_nmf_target(*args, _np_ptr(mp), _np_ptr(mi), _ci(mnnz), _cd(cd_tol), _ci(sort_model), _ci(precision),
+                                    _np_ptr(hist) if hist is not None else None,
+                                    _np_ptr(tH) if tH is not None else None, _cd(target_H[1] if target_H is not None else 0.0),
+                                    _np_ptr(tW) if tW is not None else None, _cd(target_W[1] if target_W is not None else 0.0))
+        else:
+            L.rcppml_gpu_nmf_ex(*args, _np_ptr(mp), _np_ptr(mi), _ci(mnnz), _cd(cd_tol), _ci(sort_model), _ci(precision),
+                                _np_ptr(hist) if hist is not None else None)
     else:
         raise ValueError(entry)
     res = dict(d=d, iter=out_iter.value, converged=bool(out_conv.value), loss=out_loss.value, tol=out_tol.value,

@@ -271,3 +271,44 @@ extern "C" int rcppml_hip_loss_nonzeros(rcppml_hip_ctx* c, int dtype, const int*
     }
     RCPPML_CATCH_RET
 }
+
+// ----------------------------------------------------------------------------
+// Small helpers of the k x k feature layer: Y = X + alpha * T (target regularisation, variant_helpers.hpp:107-111:
+// B += lambda * target) and G(i,i) += v.
+// ----------------------------------------------------------------------------
+template <class T>
+static __global__ void axpy_kernel(const T* __restrict__ x, const T* __restrict__ t, T alpha, int64_t n, T* __restrict__ y) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        y[i] = tfma(alpha, t[i], x[i]);
+}
+template <class T>
+static __global__ void add_diag_kernel(T* __restrict__ G, int k, T v) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < k) G[(size_t)i * k + i] += v;
+}
+extern "C" int rcppml_hip_axpy(rcppml_hip_ctx* c, int dtype, const void* X, const void* Tm, double alpha, int64_t n, void* Y) {
+    try {
+        HIPCHK(hipSetDevice(c->device));
+        if (n <= 0) return 0;
+        int64_t nblk = (n + 255) / 256;
+        if (nblk > 8 * (int64_t)c->num_cu) nblk = 8 * c->num_cu;
+        if (dtype == RCPPML_F32)
+            hipLaunchKernelGGL(axpy_kernel<float>, dim3((unsigned)nblk), dim3(256), 0, c->stream, (const float*)X, (const float*)Tm, (float)alpha, n, (float*)Y);
+        else
+            hipLaunchKernelGGL(axpy_kernel<double>, dim3((unsigned)nblk), dim3(256), 0, c->stream, (const double*)X, (const double*)Tm, alpha, n, (double*)Y);
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
+    RCPPML_CATCH_RET
+}
+extern "C" int rcppml_hip_add_diag(rcppml_hip_ctx* c, int dtype, void* G, int k, double v) {
+    try {
+        HIPCHK(hipSetDevice(c->device));
+        if (k <= 0) return 0;
+        if (dtype == RCPPML_F32) hipLaunchKernelGGL(add_diag_kernel<float>, dim3((k + 63) / 64), dim3(64), 0, c->stream, (float*)G, k, (float)v);
+        else hipLaunchKernelGGL(add_diag_kernel<double>, dim3((k + 63) / 64), dim3(64), 0, c->stream, (double*)G, k, v);
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
+    RCPPML_CATCH_RET
+}

@@ -12,6 +12,59 @@ extern "C" const char* rcppml_gpu_last_error(void) { return rcppml_err().c_str()
 
 namespace {
 
+
+// PROJ_ADV (nmf/variant_helpers.hpp:112-146) on a k x k Gram held in `G` (host, double, symmetric):
+//   G -= |lambda| * (trace G / trace TG) * TG;  eigenvalues below 1e-8 are raised to 1e-8 (G = V max(L, eps) V^T, only if
+//   one was).  The eigen-decomposition is a cyclic Jacobi iteration: the clipped matrix is a function of G alone, so any
+//   convergent symmetric eigensolver reproduces the reference's SelfAdjointEigenSolver result up to rounding.
+void proj_adv_host(std::vector<double>& G, const std::vector<double>& TG, int k, double abs_lambda) {
+    double trG = 0, trT = 0;
+    for (int i = 0; i < k; ++i) { trG += G[(size_t)i * k + i]; trT += TG[(size_t)i * k + i]; }
+    const double scale = trT > 1e-10 ? trG / trT : 0.0;
+    for (size_t e = 0; e < (size_t)k * k; ++e) G[e] -= abs_lambda * scale * TG[e];
+    std::vector<double> A = G, V((size_t)k * k, 0.0);
+    for (int i = 0; i < k; ++i) V[(size_t)i * k + i] = 1.0;
+    for (int sweep = 0; sweep < 100; ++sweep) {
+        double off = 0;
+        for (int p = 0; p < k; ++p) for (int q = p + 1; q < k; ++q) off += A[(size_t)q * k + p] * A[(size_t)q * k + p];
+        if (off < 1e-300) break;
+        for (int p = 0; p < k; ++p)
+            for (int q = p + 1; q < k; ++q) {
+                const double apq = A[(size_t)q * k + p];
+                if (std::fabs(apq) < 1e-300) continue;
+                const double app = A[(size_t)p * k + p], aqq = A[(size_t)q * k + q];
+                const double theta = (aqq - app) / (2.0 * apq);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+                const double cs = 1.0 / std::sqrt(t * t + 1.0), sn = t * cs;
+                for (int r = 0; r < k; ++r) {                       // columns p, q
+                    const double arp = A[(size_t)p * k + r], arq = A[(size_t)q * k + r];
+                    A[(size_t)p * k + r] = cs * arp - sn * arq;
+                    A[(size_t)q * k + r] = sn * arp + cs * arq;
+                }
+                for (int r = 0; r < k; ++r) {                       // rows p, q
+                    const double apr = A[(size_t)r * k + p], aqr = A[(size_t)r * k + q];
+                    A[(size_t)r * k + p] = cs * apr - sn * aqr;
+                    A[(size_t)r * k + q] = sn * apr + cs * aqr;
+                }
+                for (int r = 0; r < k; ++r) {
+                    const double vrp = V[(size_t)p * k + r], vrq = V[(size_t)q * k + r];
+                    V[(size_t)p * k + r] = cs * vrp - sn * vrq;
+                    V[(size_t)q * k + r] = sn * vrp + cs * vrq;
+                }
+            }
+    }
+    bool clipped = false;
+    std::vector<double> ev(k);
+    for (int i = 0; i < k; ++i) { ev[i] = A[(size_t)i * k + i]; if (ev[i] < 1e-8) { ev[i] = 1e-8; clipped = true; } }
+    if (!clipped) return;
+    for (int i = 0; i < k; ++i)
+        for (int j = 0; j < k; ++j) {
+            double s = 0;
+            for (int e = 0; e < k; ++e) s += V[(size_t)e * k + i] * ev[e] * V[(size_t)e * k + j];      // V stored column e = eigenvector e
+            G[(size_t)j * k + i] = s;
+        }
+}
+
 // ----------------------------------------------------------------------------
 // The ALS loop (MSE; fused-path semantics of fit_cpu.hpp, or the explicit-mask path).
 // ----------------------------------------------------------------------------
@@ -125,6 +178,41 @@ void fit(FitParams& P) {
         OPCHK(rcppml_hip_rhs_plan_create(c, dt, dAp.as<int>(), dAi.as<int>(), dAx.p, n, m, k, 0, 0, &planA.p));
         OPCHK(rcppml_hip_rhs_plan_create(c, dt, dTp.as<int>(), dTi.as<int>(), dTx.p, m, n, k, 0, 0, &planT.p));
     }
+    // ---- target regularisation (variant_helpers.hpp:107-146): standard (unfused) path, as in the reference (fit_cpu.hpp:430-433)
+    const bool tgtH = P.target_H && P.target_lambda_H != 0, tgtW = P.target_W && P.target_lambda_W != 0;
+    const bool unfused = dense || tgtH || tgtW;
+    DevBuf dTH, dTW, dBt;
+    std::vector<double> TG_H, TG_W;                 // PROJ_ADV: target target^T / ncols (nmf/fit.hpp:259-271), host copy
+    if (tgtH || tgtW) dBt.alloc((size_t)k * std::max(m, n) * sizeof(T));
+    auto target_setup = [&](const double* Th, int ncols, double lambda, DevBuf& dT, std::vector<double>& TG) {
+        upload_cast<T>(c, Th, (size_t)k * ncols, dT, s);
+        if (lambda < 0) {
+            DevBuf g((size_t)k * k * sizeof(T));
+            OPCHK(rcppml_hip_gram(c, dt, dT.p, k, ncols, 0.0, 0.0, g.p));
+            TG.resize((size_t)k * k);
+            download_cast<T>(c, g, (size_t)k * k, TG.data(), s);
+            for (auto& v : TG) v /= (double)ncols;
+        }
+    };
+    if (tgtH) target_setup(P.target_H, n, P.target_lambda_H, dTH, TG_H);
+    if (tgtW) target_setup(P.target_W, m, P.target_lambda_W, dTW, TG_W);
+    // applies the target terms to (G, B) after L1/L2, graph and L21 (apply_features order); returns the B to solve with
+    auto apply_target = [&](double lambda, DevBuf& dT, const std::vector<double>& TG, void* Gd, void* Bd, int ncols) -> void* {
+        if (lambda > 0) {
+            OPCHK(rcppml_hip_add_diag(c, dt, Gd, k, lambda));
+            OPCHK(rcppml_hip_axpy(c, dt, Bd, dT.p, lambda, (int64_t)k * ncols, dBt.p));
+            return dBt.p;
+        }
+        std::vector<double> Gh((size_t)k * k);
+        DevBuf gview; gview.borrow(Gd);
+        download_cast<T>(c, gview, (size_t)k * k, Gh.data(), s);
+        proj_adv_host(Gh, TG, k, -lambda);
+        DevBuf up;
+        upload_cast<T>(c, Gh.data(), (size_t)k * k, up, s);
+        HIPCHK(hipMemcpyAsync(Gd, up.p, (size_t)k * k * sizeof(T), hipMemcpyDeviceToDevice, s));
+        HIPCHK(hipStreamSynchronize(s));
+        return Bd;
+    };
     auto rhs_fwd = [&](const void* F, void* B) {
         if (dense) OPCHK(rcppml_hip_rhs_dense(c, dt, dAx.p, m, n, 0, F, k, B));
         else if (planA.p) OPCHK(rcppml_hip_rhs_planned(c, planA.p, F, B));
@@ -140,7 +228,7 @@ void fit(FitParams& P) {
         // dense input runs the reference's STANDARD path (fit_cpu.hpp:540-631, :774-881): nnls_batch starts from zero at
         // iteration 0 and from the residual-corrected previous solution afterwards; the sparse fused path starts
         // iteration 0 from the initial factor without correction
-        const int zinit = (dense && !warm) ? 1 : 0;
+        const int zinit = (unfused && !warm) ? 1 : 0;
         // ================= H half-update (fit_cpu.hpp:486-645)
         if (P.symmetric) {
             // :474-477 SYMMETRIC_SKIP: H is not updated and not scaled; it is set to W_T after the W update
@@ -164,15 +252,16 @@ void fit(FitParams& P) {
             if (graph_H) OPCHK(rcppml_hip_apply_graph_reg(c, dt, dG.p, dGHp.as<int>(), dGHi.as<int>(), dGHx.p, dH.p, k, n, P.gH_lambda));   // :508-509
             if (P.L21_H > 0) OPCHK(rcppml_hip_apply_l21(c, dt, dG.p, dH.p, k, n, P.L21_H));   // :509-510 (current H)
             rhs_fwd(dW.p, dBh.p);
+            void* Bh_use = tgtH ? apply_target(P.target_lambda_H, dTH, TG_H, dG.p, dBh.p, n) : dBh.p;
             if (P.solver_mode == 0) {                                                   // :516-524
                 const bool ord = use_order && iter > 0 && n >= 32768;   // pays once waves outnumber the chip's slots
                 if (ord) OPCHK(rcppml_hip_order_columns(c, dswH.as<int>(), n, dordH.as<int>()));
-                OPCHK(rcppml_hip_solve_cd(c, dt, dG.p, dBh.p, dH.p, k, n, P.L1_H > 0 ? P.L1_H : 0.0, warm, zinit, 0.0, 0.0,
+                OPCHK(rcppml_hip_solve_cd(c, dt, dG.p, Bh_use, dH.p, k, n, P.L1_H > 0 ? P.L1_H : 0.0, warm, zinit, 0.0, 0.0,
                                           P.nonneg_H, P.cd_maxit, P.cd_tol, 0.0, P.ub_H, RCPPML_CD_AUTO,
                                           use_order ? dswH.as<int>() : nullptr, ord ? dordH.as<int>() : nullptr));
             }
             else                                                                        // :527-534
-                OPCHK(rcppml_hip_solve_chol(c, dt, dG.p, dBh.p, dH.p, k, n, P.L1_H > 0 ? P.L1_H : 0.0, P.nonneg_H, P.ub_H));
+                OPCHK(rcppml_hip_solve_chol(c, dt, dG.p, Bh_use, dH.p, k, n, P.L1_H > 0 ? P.L1_H : 0.0, P.nonneg_H, P.ub_H));
         }
         if (P.angular_H > 0 && !P.projective && !P.symmetric) OPCHK(rcppml_hip_angular_posthoc(c, dt, dH.p, k, n, P.angular_H));   // :638-639 (standard branch only)
         if (!P.symmetric) {
@@ -212,15 +301,16 @@ void fit(FitParams& P) {
             if (graph_W) OPCHK(rcppml_hip_apply_graph_reg(c, dt, dG.p, dGWp.as<int>(), dGWi.as<int>(), dGWx.p, dW.p, k, m, P.gW_lambda));   // :740-741
             if (P.L21_W > 0) OPCHK(rcppml_hip_apply_l21(c, dt, dG.p, dW.p, k, m, P.L21_W));   // :741-745 (current W_T)
             rhs_bwd(dH.p, dBw.p);
+            void* Bw_use = tgtW ? apply_target(P.target_lambda_W, dTW, TG_W, dG.p, dBw.p, m) : dBw.p;   // the loss keeps the raw B_w (:786-789)
             if (P.solver_mode == 0) {
                 const bool ord = use_order && iter > 0 && m >= 32768;
                 if (ord) OPCHK(rcppml_hip_order_columns(c, dswW.as<int>(), m, dordW.as<int>()));
-                OPCHK(rcppml_hip_solve_cd(c, dt, dG.p, dBw.p, dW.p, k, m, P.L1_W > 0 ? P.L1_W : 0.0, warm, zinit, 0.0, 0.0,
+                OPCHK(rcppml_hip_solve_cd(c, dt, dG.p, Bw_use, dW.p, k, m, P.L1_W > 0 ? P.L1_W : 0.0, warm, zinit, 0.0, 0.0,
                                           P.nonneg_W, P.cd_maxit, P.cd_tol, 0.0, P.ub_W, RCPPML_CD_AUTO,
                                           use_order ? dswW.as<int>() : nullptr, ord ? dordW.as<int>() : nullptr));
             }
             else
-                OPCHK(rcppml_hip_solve_chol(c, dt, dG.p, dBw.p, dW.p, k, m, P.L1_W > 0 ? P.L1_W : 0.0, P.nonneg_W, P.ub_W));
+                OPCHK(rcppml_hip_solve_chol(c, dt, dG.p, Bw_use, dW.p, k, m, P.L1_W > 0 ? P.L1_W : 0.0, P.nonneg_W, P.ub_W));
         }
         if (P.angular_W > 0) OPCHK(rcppml_hip_angular_posthoc(c, dt, dW.p, k, m, P.angular_W));   // :886-887
         OPCHK(rcppml_hip_row_norms(c, dt, dW.p, k, m, P.norm_type, dsums.p));           // :893
@@ -255,7 +345,7 @@ void fit(FitParams& P) {
     // sizes settled), so it is captured once into a hipGraph and replayed: small inputs (hawaiibirds: ~27 launches for
     // < 50 us of GPU work) are bound by the host's launch rate, not by the kernels.  Plain MSE path only; any capture
     // failure falls back to eager launches.  RCPPML_GPU_NO_GRAPH=1 disables.
-    const bool graph_ok = !is_nb && !has_mask && !dense && !getenv("RCPPML_GPU_NO_GRAPH");   // (dense input: a few large launches, eager)
+    const bool graph_ok = !is_nb && !has_mask && !unfused && !getenv("RCPPML_GPU_NO_GRAPH");   // (dense input: a few large launches, eager)
     struct GraphHolder {
         hipGraph_t g = nullptr; hipGraphExec_t e = nullptr; bool failed = false;
         ~GraphHolder() { if (e) (void)hipGraphExecDestroy(e); if (g) (void)hipGraphDestroy(g); }
@@ -334,7 +424,8 @@ void fit(FitParams& P) {
 
 // Shared body of the three NMF entry points
 void nmf_entry(RCPPML_NMF_UNIFIED_ARGS, const int* mask_p, const int* mask_i, double cd_tol, int sort_model,
-               int precision, double* loss_history) {
+               int precision, double* loss_history, const double* target_H = nullptr, double target_lambda_H = 0,
+               const double* target_W = nullptr, double target_lambda_W = 0) {
     try {
         rcppml_err().clear();
         *out_status = -1;
@@ -406,6 +497,12 @@ void nmf_entry(RCPPML_NMF_UNIFIED_ARGS, const int* mask_p, const int* mask_i, do
         P.nb_size_min = *nb_size_min; P.out_theta = out_theta; P.tweedie_power = *tweedie_power; P.robust_delta = *robust_delta; P.projective = *projective != 0 ? 1 : 0; P.symmetric = *symmetric != 0 ? 1 : 0;
         P.gH_p = graph_H_p; P.gH_i = graph_H_i; P.gH_x = graph_H_x; P.gH_nnz = *graph_H_nnz; P.gH_lambda = *graph_H_lambda;
         P.gW_p = graph_W_p; P.gW_i = graph_W_i; P.gW_x = graph_W_x; P.gW_nnz = *graph_W_nnz; P.gW_lambda = *graph_W_lambda;
+        P.target_H = target_H; P.target_lambda_H = target_H ? target_lambda_H : 0;
+        P.target_W = target_W; P.target_lambda_W = target_W ? target_lambda_W : 0;
+        if ((P.target_H && P.target_lambda_H != 0) || (P.target_W && P.target_lambda_W != 0)) {
+            if (*loss_type != 0 || *robust_delta > 0 || mask_p || *projective != 0 || *symmetric != 0)
+                throw std::runtime_error("target regularisation: plain MSE fits only");
+        }
         // RCPPML_GPU_DEVICES=n (build-defined: the reference bridge never transmits config.max_gpus, core/config.hpp:86):
         // plain sparse MSE fits shard their columns over n devices of this process (plugin_multi.hip); everything else,
         // and n <= 1, runs the single-device loop
@@ -806,6 +903,16 @@ extern "C" void rcppml_gpu_nmf_ex(RCPPML_NMF_UNIFIED_ARGS, const int* mask_p, co
     const bool use_mask = mask_p && mask_nnz && *mask_nnz > 0;
     nmf_entry(RCPPML_NMF_UNIFIED_PASS, use_mask ? mask_p : nullptr, use_mask ? mask_i : nullptr, *cd_tol, *sort_model,
               *precision, loss_history);
+}
+
+extern "C" void rcppml_gpu_nmf_target(RCPPML_NMF_UNIFIED_ARGS, const int* mask_p, const int* mask_i, int* mask_nnz,
+                                      double* cd_tol, int* sort_model, int* precision, double* loss_history,
+                                      const double* target_H, double* target_lambda_H, const double* target_W,
+                                      double* target_lambda_W) {
+    const bool use_mask = mask_p && mask_nnz && *mask_nnz > 0;
+    nmf_entry(RCPPML_NMF_UNIFIED_PASS, use_mask ? mask_p : nullptr, use_mask ? mask_i : nullptr, *cd_tol, *sort_model,
+              *precision, loss_history, target_H, target_lambda_H ? *target_lambda_H : 0.0, target_W,
+              target_lambda_W ? *target_lambda_W : 0.0);
 }
 
 // nnls()/predict() projection in fp64 (src/RcppFunctions_utils.cpp:313-366)

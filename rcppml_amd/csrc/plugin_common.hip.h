@@ -71,6 +71,9 @@ struct FitParams {
     const double* dense = nullptr;           // dense input (column-major m x n): the unfused standard path of fit_cpu.hpp
     int csc_on_device = 0;                   // col_ptr / row_idx / values are DEVICE pointers (zero-copy entry)
     int projective = 0;                      // H = (diag(d) W_T) A instead of the NNLS half-update (variant_helpers.hpp:308-325)
+    // target regularisation (variant_helpers.hpp:107-146): host matrices k x n / k x m (k leading), NULL = none
+    const double* target_H = nullptr; double target_lambda_H = 0;
+    const double* target_W = nullptr; double target_lambda_W = 0;
     int cd_maxit; double cd_tol;
     int verbose, patience, nonneg_W, nonneg_H, norm_type, solver_mode;
     const int* mask_p; const int* mask_i;   // NULL = no mask

@@ -346,6 +346,7 @@ bool rcppml_fit_multi(FitParams& P, int precision, int ndev) {
     // what the sharded loop covers (see the header of this file)
     if (P.dense || P.csc_on_device || P.mask_p || P.loss_type != 0 || P.robust_delta > 0 || P.projective || P.symmetric) return false;
     if (P.L21_H > 0 || P.L21_W > 0 || P.angular_H > 0 || P.angular_W > 0) return false;
+    if ((P.target_H && P.target_lambda_H != 0) || (P.target_W && P.target_lambda_W != 0)) return false;
     if ((P.gH_p && P.gH_nnz > 0 && P.gH_lambda > 0) || (P.gW_p && P.gW_nnz > 0 && P.gW_lambda > 0)) return false;
     if (ndev < 2 || P.n < ndev) return false;
     const char* sh = getenv("RCPPML_GPU_DEVICES_SHARE");

@@ -71,7 +71,7 @@ def nmf(data, k, tol=1e-4, maxit=100, L1=(0.0, 0.0), L2=(0.0, 0.0), seed=None, m
         robust=False, *, solver="auto", upper_bound=(0.0, 0.0), cd_maxit=100, cd_tol=1e-8, norm="L1", sort_model=True,
         patience=5, h_init=None, precision="fp32", resource="gpu", dispersion="per_row", irls_max_iter=5, irls_tol=1e-4,
         nb_size_init=10.0, nb_size_max=1e6, nb_size_min=0.01, tweedie_power=1.5, L21=(0.0, 0.0), angular=(0.0, 0.0),
-        graph_W=None, graph_H=None, graph_lambda=(0.0, 0.0)):
+        graph_W=None, graph_H=None, graph_lambda=(0.0, 0.0), target_H=None, target_lambda=0.0):
     """Non-negative matrix factorisation A ~ w diag(d) h by alternating NNLS on the MI355X.
 
     `L1`, `L2`, `upper_bound`, `nonneg` are c(w, h) pairs (src/RcppFunctions_nmf.cpp:59-62).
@@ -80,6 +80,7 @@ def nmf(data, k, tol=1e-4, maxit=100, L1=(0.0, 0.0), L2=(0.0, 0.0), seed=None, m
     `precision`: "fp32" is what the reference computes in (F1); "fp64" is the parity mode.
     `robust`: False | True (Huber delta 1.345) | "mae" (1e-4) | positive delta (R/nmf_thin.R:343-352).
     `graph_W` (m x m) / `graph_H` (n x n): sparse graph Laplacians, `graph_lambda` = c(w, h) (R/nmf_thin.R:67-68, 500-506).
+    `target_H` (k x n) with `target_lambda` (a scalar is the H side, as R/nmf_thin.R:646-648; > 0 enrichment, < 0 PROJ_ADV).
     """
     if loss not in _LOSSES:
         raise ValueError("'arg' should be one of %s" % ", ".join(repr(x) for x in _LOSSES))
@@ -211,6 +212,16 @@ def nmf(data, k, tol=1e-4, maxit=100, L1=(0.0, 0.0), L2=(0.0, 0.0), seed=None, m
                     solver_mode=0 if solver == "cd" else 1, L1=(L1w, L1h), L2=(L2w, L2h), seed=seed_int, precision=precision,
                     resource="gpu", loss_type=loss, input="dense")
         return NMFModel(w=W_T.copy(), d=res["d"], h=H.T.copy(), misc=misc)
+    target_args = {}
+    if target_H is not None:
+        tl = (0.0, float(target_lambda)) if np.ndim(target_lambda) == 0 else tuple(float(v) for v in target_lambda)   # R/nmf_thin.R:646-648
+        TH = np.asarray(target_H, np.float64)
+        if TH.shape == (k, n):
+            TH = TH.T
+        if TH.shape != (n, k):
+            raise ValueError("target_H must be k x n")
+        if tl[1] != 0:
+            target_args["target_H"] = (np.ascontiguousarray(TH), tl[1])
     res = _abi.nmf_unified(A.p, A.i, A.x, m, n, k, W_T, H, entry="ex", max_iter=int(maxit), tol=float(tol), L1_H=L1h,
                            L1_W=L1w, L2_H=L2h, L2_W=L2w, L21_H=L21h, L21_W=L21w, ortho_H=angh, ortho_W=angw, ub_H=ubh, ub_W=ubw, cd_maxit=int(cd_maxit), verbose=int(verbose),
                            seed=seed_int & 0x7FFFFFFF, patience=int(patience), nonneg_W=int(nnw), nonneg_H=int(nnh),
@@ -220,7 +231,7 @@ def nmf(data, k, tol=1e-4, maxit=100, L1=(0.0, 0.0), L2=(0.0, 0.0), seed=None, m
                            gp_dispersion_mode={"none": 0, "global": 1, "per_row": 2}[dispersion],
                            nb_size=(nb_size_init, nb_size_max, nb_size_min),
                            sort_model=int(sort_model), precision=_abi.F32 if precision == "fp32" else _abi.F64,
-                           want_history=True, **graph_args)
+                           want_history=True, **graph_args, **target_args)
     if res["status"] != 0:
         raise _abi.BackendError("GPU NMF failed: %s" % res.get("error"))
     misc = dict(tol=res["tol"], iter=res["iter"], loss=res["loss"], loss_history=res.get("loss_history"),

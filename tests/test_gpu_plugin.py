@@ -103,6 +103,50 @@ def test_fit_at_c4_ranks(abi, k, precision, tol):
     _compare(res, ref, tol if precision == 1 else 2e-4, tol)
 
 
+@pytest.mark.parametrize("solver", [0, 1])
+@pytest.mark.parametrize("lam_w,lam_h", [(0.5, 0.0), (0.0, 0.8), (0.3, 0.4), (-0.4, 0.0), (0.0, -0.6), (-0.3, 0.5)])
+def test_target_regularisation(abi, solver, lam_w, lam_h):
+    """Target regularisation (nmf/variant_helpers.hpp:107-146) through the build-defined
+    rcppml_gpu_nmf_target entry: enrichment (lambda > 0: ridge toward the target) and PROJ_ADV (lambda < 0: trace-scaled
+    target Gram removed from G, eigenvalues clipped at 1e-8) on either or both factors, standard (unfused) path, fp64,
+    against the oracle's restatement: loss <= 1e-6, factors <= 1e-6."""
+    if solver == 1:
+        # Cholesky on a Gram whose small eigenvalues were clipped to 1e-8 amplifies rounding by 1e8 (the reference's own
+        # result is unstable there): PROJ_ADV is exercised with the Cholesky solver at a strength that keeps G well conditioned
+        lam_w, lam_h = (lam_w * 0.1 if lam_w < 0 else lam_w), (lam_h * 0.1 if lam_h < 0 else lam_h)
+    A = lowrank_csc(140, 190, 5, 0.15, seed=21)
+    k = 7
+    rng = np.random.default_rng(4)
+    W0, H0 = O.init_factors(13, k, A.rows, A.cols, np.float64)
+    TW = rng.uniform(0, 2.0 / A.rows, size=(A.rows, k))
+    TH = rng.uniform(0, 2.0 / A.cols, size=(A.cols, k))
+    tw = (TW, lam_w) if lam_w != 0 else None
+    th = (TH, lam_h) if lam_h != 0 else None
+    ref = O.nmf_fit(A, W0, H0, np.float64, max_iter=8, tol=0.0, solver_mode=solver, L1=(0.001, 0.002), L2=(0.01, 0.0),
+                    target_W=tw, target_H=th)
+    res = _run_gpu(abi, A, W0, H0, "ex", max_iter=8, tol=0.0, solver_mode=solver, precision=1, L1_W=0.001, L1_H=0.002,
+                   L2_W=0.01, L2_H=0.0, target_W=tw, target_H=th)
+    _compare(res, ref, 1e-6, 1e-6)
+    # the target changes the fit (the test would pass trivially if it were dropped)
+    plain = O.nmf_fit(A, W0, H0, np.float64, max_iter=8, tol=0.0, solver_mode=solver, L1=(0.001, 0.002), L2=(0.01, 0.0), unfused=True)
+    assert np.abs(plain.W_T - ref.W_T).max() > 1e-5 or np.abs(plain.H - ref.H).max() > 1e-5
+
+
+def test_target_regularisation_fp32_and_refusals(abi):
+    A = lowrank_csc(140, 190, 5, 0.15, seed=22)
+    k = 6
+    rng = np.random.default_rng(5)
+    W0, H0 = O.init_factors(3, k, A.rows, A.cols, np.float64)
+    TH = rng.uniform(0, 2.0 / A.cols, size=(A.cols, k))
+    ref = O.nmf_fit(A, W0, H0, np.float64, max_iter=6, tol=0.0, target_H=(TH, 0.7))
+    res = _run_gpu(abi, A, W0, H0, "ex", max_iter=6, tol=0.0, precision=0, target_H=(TH, 0.7))
+    _compare(res, ref, 2e-4, 2e-3)
+    # not combinable with IRLS losses / masks: rejected (status -1), never silently dropped
+    W, H = W0.copy(), H0.copy()
+    bad = abi.nmf_unified(A.p, A.i, A.x, A.rows, A.cols, k, W, H, entry="ex", max_iter=2, loss_type=5, target_H=(TH, 0.7))
+    assert bad["status"] != 0 and "target" in bad["error"]
+
+
 def test_upper_bound_and_norms(abi):
     A = lowrank_csc(200, 300, 4, 0.1, seed=3)
     k = 6

@@ -262,3 +262,22 @@ def test_c_nnls_and_predict_semantics():
     assert h_l1.sum() < h.sum()
     hw = O.c_nnls(w, A, h0=h)
     assert np.allclose(hw, h, atol=1e-6)
+
+
+def test_proj_adv_gram_matches_numpy_eigh():
+    """PROJ_ADV (nmf/variant_helpers.hpp:112-146): G - |lambda| (tr G / tr TG) TG with eigenvalues below 1e-8 raised to 1e-8.
+    The reference uses Eigen's SelfAdjointEigenSolver (third-party, absent); the clipped matrix is a function of G alone, so
+    the oracle's Jacobi iteration is pinned against LAPACK (numpy.linalg.eigh): 1e-11, clipped and unclipped cases."""
+    rng = np.random.default_rng(0)
+    for k in (3, 12, 40):
+        F = rng.standard_normal((3 * k + 5, k))
+        G = F.T @ F
+        T = rng.standard_normal((2 * k, k))
+        TG = T.T @ T / (2 * k)
+        for lam in (1e-3, 0.3, 2.5):
+            got = O.proj_adv(G, TG, lam)
+            G2 = G - lam * (np.trace(G) / np.trace(TG)) * TG
+            w, V = np.linalg.eigh(G2)
+            ref = G2 if w.min() >= 1e-8 else (V * np.maximum(w, 1e-8)) @ V.T
+            assert np.abs(got - ref).max() <= 1e-11 * np.abs(ref).max()
+            assert np.allclose(got, got.T, atol=1e-12 * np.abs(got).max())
