@@ -246,7 +246,7 @@ RCPPML_GPU_API int rcppml_hip_rhs(rcppml_hip_ctx* ctx, int dtype, const int* col
  * are staged through LDS in 64 KiB tiles, the output columns stay in registers (kernels_rhs_tiled.hip.h).
  *   plan_create: nrows = rows of the sparse matrix (= number of k-vectors in F).  partitions: 0 = automatic (one row
  *     partition per XCD when F is far larger than an XCD's L2, else one).  slots: 0 = chosen from the data.
- *     *out_plan stays NULL (return 0) when the shape is not eligible (k * sizeof(T) not 256 or 512 bytes, rows not
+ *     *out_plan stays NULL (return 0) when the shape is not eligible (k * sizeof(T) not 256 or 512 bytes -- or 1024 in fp64 --, rows not
  *     sorted inside a column, more than 35 % of the nonzeros would spill): call rcppml_hip_rhs then.
  *   rhs_planned: B = F * A(:, j) for all columns, same numbers as rcppml_hip_rhs up to summation order; deterministic.
  *     The plan keeps the col_ptr / row_idx / values POINTERS (columns that would only part-fill a last round of

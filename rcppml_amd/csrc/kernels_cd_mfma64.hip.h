@@ -130,7 +130,7 @@ __device__ __forceinline__ double fast_recip(double den) {
 }
 
 template <class T, int NT, bool SIMPLE>   // KP = 16*NT rows (k <= KP), 16 columns per wave, 4 waves per block share G
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NT <= 2 ? 4 : 2, 8)))
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NT <= 2 ? 4 : (NT <= 4 ? 2 : 1), 8)))
 void cd_mfma64_kernel(const T* __restrict__ Gq, const typename Vec4T<T>::type* __restrict__ tab, const T* __restrict__ B,
                       T* __restrict__ X, int k, int64_t ncols, T l1_pre, int warm, int zero_init, T l1_cd,
                       T l2_cd, int nonneg, int maxit, T tol, T ub_cd, T ub_post,

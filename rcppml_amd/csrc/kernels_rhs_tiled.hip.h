@@ -239,7 +239,7 @@ __global__ __launch_bounds__(64 * NW) void rhs_tiled_kernel(const T* __restrict_
     constexpr int VN = RtVec<T>::N;
     constexpr int NST = NR * S;                 // steps per (wave, tile)
     constexpr int NB = (NST + 15) / 16;         // slot registers (value, offset) per lane and tile
-    constexpr int UB = NV == 1 ? 4 : 2;         // steps per batch of LDS reads; two batches in flight
+    constexpr int UB = NV == 1 ? 4 : (NV == 2 ? 2 : 1);     // steps per batch of LDS reads; two batches in flight
     constexpr int NBATCH = (NST + UB - 1) / UB;
     constexpr int NCH = RT_SLAB_BYTES / 1024;   // KiB-chunks per tile
     constexpr int CBASE = NCH / NW, CEXTRA = NCH % NW;

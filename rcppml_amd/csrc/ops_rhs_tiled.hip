@@ -31,6 +31,9 @@ void run_plan(rcppml_hip_ctx* c, const rcppml_rhs_plan* pl, const T* F, T* B) {
         if (G.rowb == 256)
             hipLaunchKernelGGL((rhs_tiled_spill_kernel<T, 1, 4>), dim3(grid), dim3(256), 0, c->stream, (const int*)pl->ovptr,
                                (const int*)pl->ovrow, (const T*)pl->ovval, nt, F, pl->k, B);
+        else if (G.rowb == 1024)
+            hipLaunchKernelGGL((rhs_tiled_spill_kernel<T, 4, 2>), dim3(grid), dim3(256), 0, c->stream, (const int*)pl->ovptr,
+                               (const int*)pl->ovrow, (const T*)pl->ovval, nt, F, pl->k, B);
         else
             hipLaunchKernelGGL((rhs_tiled_spill_kernel<T, 2, 4>), dim3(grid), dim3(256), 0, c->stream, (const int*)pl->ovptr,
                                (const int*)pl->ovrow, (const T*)pl->ovval, nt, F, pl->k, B);
@@ -53,7 +56,7 @@ rcppml_rhs_plan* build_plan(rcppml_hip_ctx* c, int dtype, const int* colptr, con
                             int64_t nrows, int k, int partitions, int force_S) {
     int64_t ncols = ncols_in;
     const int rowb = k * (int)sizeof(T);
-    if (rowb != 256 && rowb != 512) return nullptr;               // rows of one or two 256-byte slices
+    if (rowb != 256 && rowb != 512 && !(rowb == 1024 && sizeof(T) == 8)) return nullptr;   // rows of one, two (or, fp64 k = 128, four) 256-byte slices
     if (ncols <= 0 || nrows <= 0) return nullptr;
     if (nrows * (int64_t)rowb < 16) return nullptr;
     int nnz_i = 0;

@@ -36,6 +36,7 @@ inline int rt_dyn_lds(int NW, int NR, int S, int tsize) { return 2 * RT_SLAB_BYT
 // per-tile overhead per step).  Columns per workgroup = 4 NR NW.  A shape must also fit its slot ring into the 32 KiB
 // of LDS behind the two tiles of F (rt_dyn_lds).
 //   NV = 1 (256-byte rows): NW 16: NR in {2,4,6,8,10,12} (NR >= 10 only for S <= 5);  NW 12: NR in {8,12,16,20} (S <= 6 / S <= 4 for NR >= 16 / 20)
+//   NV = 4 (1 KiB rows: fp64 k = 128): NW 16: NR in {1,2,3}; NW 12: NR in {2,4}
 //   NV = 2 (512-byte rows): NW 16: NR in {2,4,6};                                     NW 12: NR in {4,6,8,10} (NR 8 / 10 only for S <= 6 / S <= 4)
 inline bool shape_ok(int NV, int S, int NW, int NR, int tsize) {
     if (rt_dyn_lds(NW, NR, S, tsize) > RT_MAX_LDS) return false;
@@ -45,6 +46,8 @@ inline bool shape_ok(int NV, int S, int NW, int NR, int tsize) {
     if (NV == 1 && NW == 12) return NR == 8 || NR == 12 || (NR == 16 && S <= 6) || (NR == 20 && S <= 4);
     if (NV == 2 && NW == 16) return NR == 2 || NR == 4 || NR == 6;
     if (NV == 2 && NW == 12) return NR == 4 || NR == 6 || (NR == 8 && S <= 6) || (NR == 10 && S <= 4);
+    if (NV == 4 && NW == 16) return NR == 1 || NR == 2 || NR == 3;
+    if (NV == 4 && NW == 12) return NR == 2 || NR == 4;
     return false;
 }
 
@@ -79,10 +82,12 @@ void launch_tiled_nr(rcppml_hip_ctx* c, const rcppml_rhs_plan* pl, const T* F, c
         if constexpr (S <= 5) { RT_SH(16, 10) RT_SH(16, 12) }
         if constexpr (S <= 6) { RT_SH(12, 16) }
         if constexpr (S <= 4) { RT_SH(12, 20) }
-    } else {
+    } else if constexpr (NV == 2) {
         RT_SH(16, 2) RT_SH(16, 4) RT_SH(16, 6) RT_SH(12, 4) RT_SH(12, 6)
         if constexpr (S <= 6) { RT_SH(12, 8) }
         if constexpr (S <= 4) { RT_SH(12, 10) }
+    } else {
+        RT_SH(16, 1) RT_SH(16, 2) RT_SH(16, 3) RT_SH(12, 2) RT_SH(12, 4)
     }
 #undef RT_SH
     throw std::runtime_error("rhs_planned: shape not compiled");
@@ -104,7 +109,10 @@ void launch_tiled_any(rcppml_hip_ctx* c, const rcppml_rhs_plan* pl, const T* F, 
     const int NV = pl->G.rowb / 256;
     if (NV == 1) launch_tiled_s<T, 1>(c, pl, F, Binit, Bout);
     else if (NV == 2) launch_tiled_s<T, 2>(c, pl, F, Binit, Bout);
-    else throw std::runtime_error("rhs_planned: unsupported row size");
+    else if (NV == 4) {
+        if constexpr (std::is_same<T, double>::value) launch_tiled_s<T, 4>(c, pl, F, Binit, Bout);      // 1 KiB rows: fp64 k = 128
+        else throw std::runtime_error("rhs_planned: unsupported row size");
+    } else throw std::runtime_error("rhs_planned: unsupported row size");
 }
 }  // namespace rt_launch
 

@@ -99,7 +99,7 @@ static void cd_mfma_launch(rcppml_hip_ctx* c, const float* Gp, const float* invd
     HIPCHK(hipGetLastError());
 }
 
-// 16-column MFMA variant (k <= 64): v_mfma_f64_16x16x4_f64 / v_mfma_f32_16x16x4_f32, four coordinates per instruction.
+// 16-column MFMA variant: v_mfma_f64_16x16x4_f64 (k <= 128) / v_mfma_f32_16x16x4_f32 (k <= 64), four coordinates per instruction.
 template <class T, int NT>
 static void cd_mfma64_launch(rcppml_hip_ctx* c, const T* Gp, const T* invd, const T* B, T* X, int k,
                              int64_t ncols, T l1_pre, int warm, int zero_init, T l1_cd, T l2_cd, int nonneg,
@@ -113,6 +113,9 @@ static void cd_mfma64_launch(rcppml_hip_ctx* c, const T* Gp, const T* invd, cons
     const size_t smem = ((size_t)KP * KP + 4 * KP) * sizeof(T);
     const int64_t nblk = (ncols + 63) / 64;          // 4 waves x 16 columns per block
     const bool simple = nonneg && ub_cd <= T(0) && l1_cd == T(0) && l2_cd == T(0);
+    static DynSmemOnce once_simple, once_general;    // fp64 above k = 64: the LDS copy of G passes 64 KiB (128 KiB at KP = 128)
+    if (simple) once_simple.ensure(reinterpret_cast<const void*>(&cd_mfma64_kernel<T, NT, true>), smem, c->device);
+    else once_general.ensure(reinterpret_cast<const void*>(&cd_mfma64_kernel<T, NT, false>), smem, c->device);
     if (simple)
         hipLaunchKernelGGL((cd_mfma64_kernel<T, NT, true>), dim3((unsigned)nblk), dim3(256), smem, c->stream, Gq, tab, B, X, k,
                            ncols, l1_pre, warm, zero_init, l1_cd, l2_cd, nonneg, maxit, tol, ub_cd, ub_post, sweeps, order, c->stats);
@@ -151,7 +154,7 @@ static void solve_cd_impl(rcppml_hip_ctx* c, const T* G, const T* B, T* X, int k
         else if (e && !strcmp(e, "group")) variant = RCPPML_CD_GROUP;
         else if (e && !strcmp(e, "mfma")) variant = RCPPML_CD_MFMA;
         else if (e && !strcmp(e, "mfma16")) variant = RCPPML_CD_MFMA16;
-        else variant = (std::is_same<T, float>::value || k <= 64) ? RCPPML_CD_MFMA : RCPPML_CD_GROUP;
+        else variant = RCPPML_CD_MFMA;          // fp32: 32-column tiles; fp64: 16-column tiles (below)
         // fp32: 32-column tiles leave SIMDs idle when there are fewer tiles than SIMDs (C2's W side: 20 000 columns =
         // 625 tiles on 1024 SIMDs); 16-column tiles double the wavefronts there (RCPPML_GPU_CD_SMALL16=0 disables)
         if (variant == RCPPML_CD_MFMA && std::is_same<T, float>::value && k <= 64 && !e) {
@@ -160,8 +163,8 @@ static void solve_cd_impl(rcppml_hip_ctx* c, const T* G, const T* B, T* X, int k
             if (small16 && (ncols + 31) / 32 < (int64_t)4 * c->num_cu) variant = RCPPML_CD_MFMA16;
         }
     }
-    if (variant == RCPPML_CD_MFMA && !std::is_same<T, float>::value) variant = k <= 64 ? RCPPML_CD_MFMA16 : RCPPML_CD_GROUP;
-    if (variant == RCPPML_CD_MFMA16 && k > 64) variant = std::is_same<T, float>::value ? RCPPML_CD_MFMA : RCPPML_CD_GROUP;
+    if (variant == RCPPML_CD_MFMA && !std::is_same<T, float>::value) variant = RCPPML_CD_MFMA16;      // fp64 MFMA = the 16-column form
+    if (variant == RCPPML_CD_MFMA16 && k > 64 && std::is_same<T, float>::value) variant = RCPPML_CD_MFMA;   // fp32 16-column tiles: k <= 64
     if (variant == RCPPML_CD_MFMA) KP = 32 * ((k + 31) / 32);
     if (variant == RCPPML_CD_MFMA16) KP = 16 * ((k + 15) / 16);
     // register-resident lane kernel (SGPR-fed): fp32 up to KP=64, fp64 up to KP=32 without spilling
@@ -194,7 +197,17 @@ static void solve_cd_impl(rcppml_hip_ctx* c, const T* G, const T* B, T* X, int k
             case 16: cd_mfma64_launch<T, 1>(CD_ARGS); break;
             case 32: cd_mfma64_launch<T, 2>(CD_ARGS); break;
             case 48: cd_mfma64_launch<T, 3>(CD_ARGS); break;
-            default: cd_mfma64_launch<T, 4>(CD_ARGS); break;
+            case 64: cd_mfma64_launch<T, 4>(CD_ARGS); break;
+            default:
+                if constexpr (std::is_same<T, double>::value) {        // fp64, 64 < k <= 128 (C4 in parity mode)
+                    switch (KP) {
+                        case 80: cd_mfma64_launch<T, 5>(CD_ARGS); break;
+                        case 96: cd_mfma64_launch<T, 6>(CD_ARGS); break;
+                        case 112: cd_mfma64_launch<T, 7>(CD_ARGS); break;
+                        default: cd_mfma64_launch<T, 8>(CD_ARGS); break;
+                    }
+                } else cd_mfma64_launch<T, 4>(CD_ARGS);
+                break;
         }
     } else if (variant == RCPPML_CD_GROUP) {
         const int lpc = pick_lpc<T>(KP);

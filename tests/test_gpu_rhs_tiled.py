@@ -51,7 +51,7 @@ def _run(env, A, k, dtype, partitions=0, slots=0, expect_plan=True):
     return info
 
 
-@pytest.mark.parametrize("dtype,k", [(np.float32, 64), (np.float32, 128), (np.float64, 32), (np.float64, 64)])
+@pytest.mark.parametrize("dtype,k", [(np.float32, 64), (np.float32, 128), (np.float64, 32), (np.float64, 64), (np.float64, 128)])
 @pytest.mark.parametrize("slots", [0, 2, 3, 4, 5, 6, 8])
 def test_planned_rhs_slots(env, dtype, k, slots):
     # 700 rows: 2.7 tiles of 256 rows (k*s = 256 B) / 5.5 tiles of 128 rows; the last tile is short
@@ -96,6 +96,7 @@ def test_planned_rhs_ineligible_shapes(env):
     A = random_csc(300, 200, 0.05, seed=1)
     _run(env, A, 10, np.float32, expect_plan=False)      # 40-byte rows
     _run(env, A, 100, np.float64, expect_plan=False)     # 800-byte rows
+    _run(env, A, 256, np.float32, expect_plan=False)     # 1 KiB rows are compiled for fp64 only
     # unsorted rows inside a column
     i = A.i.copy()
     s, e = A.p[7], A.p[8]
