@@ -359,6 +359,8 @@ RCPPML_GPU_API int rcppml_hip_mul_rows(rcppml_hip_ctx* ctx, int dtype, const voi
  * (nmf/variant_helpers.hpp:107-111: G.diagonal() += lambda; B += lambda * target). */
 RCPPML_GPU_API int rcppml_hip_axpy(rcppml_hip_ctx* ctx, int dtype, const void* X, const void* T, double alpha, int64_t n, void* Y);
 RCPPML_GPU_API int rcppml_hip_add_diag(rcppml_hip_ctx* ctx, int dtype, void* G, int k, double v);
+/* X = min(X, ub) over n entries (features/bounds.hpp apply_upper_bound; nmf/fit_cpu.hpp:636-637, 884-885). */
+RCPPML_GPU_API int rcppml_hip_clip_upper(rcppml_hip_ctx* ctx, int dtype, void* X, int64_t n, double ub);
 
 /* k x k feature layer, fused-path placement of nmf/fit_cpu.hpp:505-511,636-639 / :738-745,884-887:
  * rcppml_hip_apply_l21: G(i,i) += lambda / ||X.row(i)||_2 for rows with norm > 1e-10 (features/L21.hpp:38-51); X is the

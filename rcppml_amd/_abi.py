@@ -27,7 +27,7 @@ EXPORTED_SYMBOLS = [
     "rcppml_sp_read_gpu", "rcppml_sp_free_gpu", "rcppml_hip_rhs_dense", "rcppml_gpu_nmf_dense_unified_float",
     "rcppml_gpu_nmf_dense_unified_double",
     "rcppml_hip_rhs_plan_create", "rcppml_hip_rhs_plan_destroy", "rcppml_hip_rhs_plan_info", "rcppml_hip_rhs_planned",
-    "rcppml_gpu_nmf_target", "rcppml_hip_axpy", "rcppml_hip_add_diag",
+    "rcppml_gpu_nmf_target", "rcppml_hip_axpy", "rcppml_hip_add_diag", "rcppml_hip_clip_upper",
 ]
 
 

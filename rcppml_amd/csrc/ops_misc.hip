@@ -312,3 +312,26 @@ extern "C" int rcppml_hip_add_diag(rcppml_hip_ctx* c, int dtype, void* G, int k,
     }
     RCPPML_CATCH_RET
 }
+
+// X = min(X, ub) elementwise -- features/bounds.hpp apply_upper_bound, applied after every half-update branch
+// (nmf/fit_cpu.hpp:636-637, :884-885); the CD / Cholesky ops fuse it (ub_post), the IRLS and explicit-mask solves call this.
+template <class T>
+static __global__ void clip_upper_kernel(T* __restrict__ x, int64_t n, T ub) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const T v = x[i];
+        if (v > ub) x[i] = ub;
+    }
+}
+extern "C" int rcppml_hip_clip_upper(rcppml_hip_ctx* c, int dtype, void* X, int64_t n, double ub) {
+    try {
+        HIPCHK(hipSetDevice(c->device));
+        if (n <= 0 || !(ub > 0)) return 0;
+        int64_t nblk = (n + 255) / 256;
+        if (nblk > 8 * (int64_t)c->num_cu) nblk = 8 * c->num_cu;
+        if (dtype == RCPPML_F32) hipLaunchKernelGGL(clip_upper_kernel<float>, dim3((unsigned)nblk), dim3(256), 0, c->stream, (float*)X, n, (float)ub);
+        else hipLaunchKernelGGL(clip_upper_kernel<double>, dim3((unsigned)nblk), dim3(256), 0, c->stream, (double*)X, n, ub);
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
+    RCPPML_CATCH_RET
+}

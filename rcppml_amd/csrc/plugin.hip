@@ -240,13 +240,13 @@ void fit(FitParams& P) {
             OPCHK(rcppml_hip_solve_irls(c, dt, P.loss_type, dAp.as<int>(), dAi.as<int>(), dAx.p, n, dW.p, dG.p, dH.p, k, P.L1_H,
                                         P.L2_H, P.nonneg_H, P.cd_maxit, P.irls_max_iter, P.irls_tol,
                                         is_gp ? nullptr : dtheta.p, nullptr, P.tweedie_power, P.robust_delta));
-            if (P.ub_H > 0) throw std::runtime_error("upper bound with NB loss: not supported");
+            if (P.ub_H > 0) OPCHK(rcppml_hip_clip_upper(c, dt, dH.p, (int64_t)k * n, P.ub_H));      // :636-637
         } else if (has_mask) {
             OPCHK(rcppml_hip_gram(c, dt, dW.p, k, m, eps, 0.0, dG.p));                 // :562 unmodified G
             OPCHK(rcppml_hip_solve_masked(c, dt, dAp.as<int>(), dAi.as<int>(), dAx.p, dMp.as<int>(), dMi.as<int>(),
                                           n, dW.p, dG.p, dH.p, k, P.L1_H, P.L2_H, P.nonneg_H, P.cd_maxit, P.cd_tol,
                                           P.solver_mode, warm));
-            if (P.ub_H > 0) throw std::runtime_error("upper bound with explicit mask: not supported");
+            if (P.ub_H > 0) OPCHK(rcppml_hip_clip_upper(c, dt, dH.p, (int64_t)k * n, P.ub_H));      // :636-637
         } else {
             OPCHK(rcppml_hip_gram(c, dt, dW.p, k, m, eps, P.L2_H, dG.p));              // :491,506
             if (graph_H) OPCHK(rcppml_hip_apply_graph_reg(c, dt, dG.p, dGHp.as<int>(), dGHi.as<int>(), dGHx.p, dH.p, k, n, P.gH_lambda));   // :508-509
@@ -289,11 +289,13 @@ void fit(FitParams& P) {
             OPCHK(rcppml_hip_solve_irls(c, dt, P.loss_type, dTp.as<int>(), dTi.as<int>(), dTx.p, m, dH.p, dG.p, dW.p, k, P.L1_W,
                                         P.L2_W, P.nonneg_W, P.cd_maxit, P.irls_max_iter, P.irls_tol, nullptr,
                                         is_gp ? nullptr : dtheta.p, P.tweedie_power, P.robust_delta));
+            if (P.ub_W > 0) OPCHK(rcppml_hip_clip_upper(c, dt, dW.p, (int64_t)k * m, P.ub_W));      // :884-885
         } else if (has_mask) {
             OPCHK(rcppml_hip_gram(c, dt, dH.p, k, n, eps, 0.0, dG.p));
             OPCHK(rcppml_hip_solve_masked(c, dt, dTp.as<int>(), dTi.as<int>(), dTx.p, dMTp.as<int>(), dMTi.as<int>(),
                                           m, dH.p, dG.p, dW.p, k, P.L1_W, P.L2_W, P.nonneg_W, P.cd_maxit, P.cd_tol,
                                           P.solver_mode, warm));
+            if (P.ub_W > 0) OPCHK(rcppml_hip_clip_upper(c, dt, dW.p, (int64_t)k * m, P.ub_W));      // :884-885
         } else {
             OPCHK(rcppml_hip_gram(c, dt, dH.p, k, n, eps, 0.0, dGs.p));                 // :715-722 G_w_saved
             if (P.L2_W > 0) OPCHK(rcppml_hip_gram(c, dt, dH.p, k, n, eps, P.L2_W, dG.p)); // :738

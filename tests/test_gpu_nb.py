@@ -412,3 +412,18 @@ def test_full_size_c5_nb_properties(env):
         ops.ctx.nb_loss(ops.dt, Ad["p"], Ad["i"], Ad["x"], n, W, d, H, theta, k, out)
         losses.append(float(out[0].item()))
     assert np.all(np.isfinite(losses)) and losses[1] <= losses[0] * (1 + 1e-3)
+
+
+def test_nb_fit_with_upper_bounds():
+    """upper_bound with an IRLS loss: clipped after both half-updates as the reference does (fit_cpu.hpp:636-637, 884-885)."""
+    from rcppml_amd import _abi
+    A = _nb_problem(90, 130, 3, seed=8)
+    k = 4
+    W0, H0 = O.init_factors(4, k, A.rows, A.cols, np.float64)
+    ref = O.nmf_fit(A, W0, H0, np.float64, max_iter=5, tol=0.0, loss_type=5, ub=(0.05, 0.03))
+    W, H = W0.copy(), H0.copy()
+    res = _abi.nmf_unified(A.p, A.i, A.x, A.rows, A.cols, k, W, H, entry="ex", max_iter=5, tol=0.0, loss_type=5, precision=1,
+                           ub_W=0.05, ub_H=0.03)
+    assert res["status"] == 0, res.get("error")
+    assert abs(res["loss"] - ref.loss) / abs(ref.loss) < 1e-6
+    assert np.abs(W - ref.W_T).max() < 1e-6 and np.abs(H - ref.H).max() < 1e-6

@@ -147,6 +147,21 @@ def test_target_regularisation_fp32_and_refusals(abi):
     assert bad["status"] != 0 and "target" in bad["error"]
 
 
+@pytest.mark.parametrize("solver", [0, 1])
+def test_upper_bound_with_explicit_mask(abi, solver):
+    """upper_bound on the explicit-mask path: the reference clips after every half-update branch (fit_cpu.hpp:636-637,
+    884-885); an earlier build ignored ub_W there and refused ub_H."""
+    A = lowrank_csc(120, 160, 4, 0.15, seed=31)
+    M = random_csc(120, 160, 0.05, seed=32)
+    k = 5
+    W0, H0 = O.init_factors(9, k, A.rows, A.cols, np.float64)
+    ref = O.nmf_fit(A, W0, H0, np.float64, max_iter=7, tol=0.0, mask=M, solver_mode=solver, ub=(0.02, 0.015))
+    res = _run_gpu(abi, A, W0, H0, "ex", max_iter=7, tol=0.0, mask=(M.p, M.i), solver_mode=solver, precision=1, ub_W=0.02, ub_H=0.015)
+    _compare(res, ref, 1e-6, 1e-6)
+    raw = O.nmf_fit(A, W0, H0, np.float64, max_iter=7, tol=0.0, mask=M, solver_mode=solver)
+    assert np.abs(raw.W_T - ref.W_T).max() > 1e-4          # the bounds bite
+
+
 def test_upper_bound_and_norms(abi):
     A = lowrank_csc(200, 300, 4, 0.1, seed=3)
     k = 6
