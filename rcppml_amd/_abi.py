@@ -522,6 +522,14 @@ def sp_read_gpu(path, device=0):
                 error=last_error() if st.value != 0 else "")
 
 
+def copy_from_device_address(dst, addr, nbytes):
+    """Copy nbytes from a raw device address (as sp_read_gpu returns them: a float) into a torch CUDA tensor."""
+    hip = C.CDLL("libamdhip64.so")
+    rc = hip.hipMemcpy(C.c_void_p(dst.data_ptr()), C.c_void_p(int(addr)), C.c_size_t(int(nbytes)), C.c_int(3))   # device to device
+    if rc != 0:
+        raise BackendError("hipMemcpy failed: %d" % rc)
+
+
 def sp_free_gpu(h):
     a, b, c, st = C.c_double(h["col_ptr"]), C.c_double(h["row_idx"]), C.c_double(h["values"]), C.c_int(-99)
     lib().rcppml_sp_free_gpu(C.byref(a), C.byref(b), C.byref(c), C.byref(st))

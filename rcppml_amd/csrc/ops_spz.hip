@@ -56,10 +56,14 @@ struct ParseError { int status; const char* what; };
 inline uint32_t rd32(const uint8_t* p) { uint32_t v; std::memcpy(&v, p, 4); return v; }
 
 // rANS + escape block (sparsepress_v2.hpp:404-439): [table][enc_sz u32][enc bytes][ov_sz u32][varints]
+// `in_file(off, len)`: the byte range [off, off + len) lies inside the file -- written so that it cannot wrap
+inline bool in_file(uint64_t size, uint64_t off, uint64_t len) { return off <= size && len <= size - off; }
+
 void add_escape_job(const uint8_t* data, uint64_t size, uint64_t off, uint64_t len, uint32_t count, int kind, uint64_t out_off,
                     float qs, float qo, std::vector<SpzJob>& jobs) {
     if (len == 0 || count == 0) return;                                    // :407-408 -> zeros (outputs are pre-zeroed)
-    if (off + 2 > size) throw ParseError{5, "rANS table beyond end of file"};
+    if (!in_file(size, off, len)) throw ParseError{5, "rANS block beyond end of file"};
+    if (len < 2) throw ParseError{5, "truncated rANS block"};
     const uint32_t ns = data[off] | (data[off + 1] << 8);
     if (ns > 256) throw ParseError{5, "rANS table with more than 256 symbols"};
     uint64_t o = 2 + 2ull * ns;
@@ -67,16 +71,20 @@ void add_escape_job(const uint8_t* data, uint64_t size, uint64_t off, uint64_t l
     SpzJob j{};
     j.table_off = off; j.count = count; j.kind = kind; j.out_off = out_off; j.qscale = qs; j.qoff = qo;
     j.enc_size = rd32(data + off + o); o += 4;
-    j.enc_off = off + o; o += j.enc_size;
-    if (off + o > size || j.enc_size < 4) throw ParseError{5, "rANS payload beyond end of file"};
-    if (o + 4 <= len) { j.ov_size = rd32(data + off + o); o += 4; j.ov_off = off + o; }
-    if (j.ov_size && j.ov_off + j.ov_size > size) throw ParseError{5, "escape bytes beyond end of file"};
+    j.enc_off = off + o;
+    if (j.enc_size < 4 || j.enc_size > len - o) throw ParseError{5, "rANS payload beyond its block"};
+    o += j.enc_size;
+    if (o + 4 <= len) {
+        j.ov_size = rd32(data + off + o); o += 4; j.ov_off = off + o;
+        if (j.ov_size > len - o) throw ParseError{5, "escape bytes beyond their block"};
+    }
     jobs.push_back(j);
 }
 // byte-shuffled floats (sparsepress_v2.hpp:442-476): [n_streams u8] then per plane [table_sz u32][table][enc_sz u32][enc]
 void add_plane_jobs(const uint8_t* data, uint64_t size, uint64_t off, uint64_t len, uint32_t count, uint32_t bpv, uint64_t out_off,
                     std::vector<SpzJob>& jobs) {
     if (len == 0 || count == 0) return;
+    if (!in_file(size, off, len)) throw ParseError{5, "byte-plane block beyond end of file"};
     uint64_t o = 0;
     const uint32_t ns = data[off + o++];
     if (ns > bpv) throw ParseError{5, "more byte planes than bytes per value"};
@@ -85,12 +93,15 @@ void add_plane_jobs(const uint8_t* data, uint64_t size, uint64_t off, uint64_t l
         const uint32_t tsz = rd32(data + off + o); o += 4;
         SpzJob j{};
         j.table_off = off + o; j.count = count; j.kind = JOB_PLANE; j.plane = s; j.bpv = bpv; j.out_off = out_off;
-        if (j.table_off + 2 > size || (data[j.table_off] | (data[j.table_off + 1] << 8)) > 256) throw ParseError{5, "bad byte-plane table"};
+        if (tsz < 2 || tsz > len - o) throw ParseError{5, "bad byte-plane table"};
+        const uint32_t nsym = data[j.table_off] | (data[j.table_off + 1] << 8);
+        if (nsym > 256 || 2ull + 2ull * nsym > tsz) throw ParseError{5, "bad byte-plane table"};
         o += tsz;
         if (o + 4 > len) return;                                            // :460
         j.enc_size = rd32(data + off + o); o += 4;
-        j.enc_off = off + o; o += j.enc_size;
-        if (off + o > size || j.enc_size < 4) throw ParseError{5, "byte-plane payload beyond end of file"};
+        j.enc_off = off + o;
+        if (j.enc_size < 4 || j.enc_size > len - o) throw ParseError{5, "byte-plane payload beyond its block"};
+        o += j.enc_size;
         jobs.push_back(j);
     }
 }
@@ -160,6 +171,7 @@ __global__ __launch_bounds__(64) void spz_rans_kernel(const uint8_t* __restrict_
     auto rfl = [](uint32_t v) -> uint32_t { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
     uint32_t x = 0, left = job.enc_size;                // left: bytes not yet consumed (rans.hpp:240: ptr_ < end_)
     const uint8_t* ov = file + job.ov_off;
+    const uint8_t* const ov_end = ov + job.ov_size;
     for (uint32_t base = 0; base < job.count; base += SPZ_B) {
         const uint32_t cnt = min((uint32_t)SPZ_B, job.count - base);
         // ---- stage the input this block can consume, already byte-swapped to big-endian words
@@ -195,7 +207,11 @@ __global__ __launch_bounds__(64) void spz_rans_kernel(const uint8_t* __restrict_
                 }
                 if (has_ov && sym == 255) {                                  // sparsepress_v2.hpp:430-436: varint escape
                     uint32_t v = 0, sh = 0, byte;
-                    do { byte = rfl((uint32_t)*ov++); if (sh < 32) v |= (byte & 0x7F) << sh; sh += 7; } while (byte & 0x80);
+                    do {                                                     // never past the escape section (malformed files)
+                        byte = ov < ov_end ? rfl((uint32_t)*ov++) : 0u;
+                        if (sh < 32) v |= (byte & 0x7F) << sh;
+                        sh += 7;
+                    } while (byte & 0x80);
                     sym = v;
                 }
                 obuf[i] = sym;                                               // all lanes, same value, same address
@@ -251,6 +267,16 @@ __global__ __launch_bounds__(256) void spz_float_kernel(const uint8_t* __restric
     else { double d; memcpy(&d, raw + t * 8, 8); values[t] = d; }
 }
 
+// rows of a decoded matrix must lie in [0, m): a malformed gap stream would otherwise send the transpose's histogram
+// (atomicAdd on counts[row]) out of bounds in the zero-copy fit
+__global__ __launch_bounds__(256) void spz_check_rows_kernel(const int* __restrict__ rows, int64_t nnz, int m, int* __restrict__ bad) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t < nnz) {
+        const int r = rows[t];
+        if (r < 0 || r >= m) *bad = 1;
+    }
+}
+
 // col_ptr: what the reference decoder returns; seg_ptr: where each column's gaps actually lie in the chunk's output range
 // (identical for well-formed files; they differ only when a chunk's count section is garbage -- the reference encoder
 // omits its size prefix for chunks without nonzeros, sparsepress_v2.hpp:94 vs :988-991 -- and then seg_ptr keeps the
@@ -272,8 +298,9 @@ SpzParsed parse_file(const uint8_t* data, uint64_t size) {
     if (st) throw ParseError{st, "not a v2 .spz file"};
     const SpzHeader& h = P.h;
     if (h.row_sorted) throw ParseError{5, "row-sorted .spz files (stored row permutation) are not supported"};
-    if (h.nnz > 0x7FFFFFFFull || h.n > 0x7FFFFFFEu) throw ParseError{5, "matrix too large for int32 CSC indices"};
-    if (size < h.chunk_index_offset + (uint64_t)h.num_chunks * 48) throw ParseError{5, "truncated chunk index"};   // sparsepress_v2.hpp:913-914
+    if (h.nnz > 0x7FFFFFFFull || h.n > 0x7FFFFFFEu || h.m > 0x7FFFFFFFu) throw ParseError{5, "matrix too large for int32 CSC indices"};
+    if (!in_file(size, h.chunk_index_offset, (uint64_t)h.num_chunks * 48)) throw ParseError{5, "truncated chunk index"};   // sparsepress_v2.hpp:913-914
+    if (h.data_offset > size) throw ParseError{5, "data section beyond end of file"};
     std::vector<SpzChunk> ch(h.num_chunks);
     if (h.num_chunks) std::memcpy(ch.data(), data + h.chunk_index_offset, (size_t)h.num_chunks * 48);
     P.col_ptr.assign((size_t)h.n + 1, 0);
@@ -285,23 +312,28 @@ SpzParsed parse_file(const uint8_t* data, uint64_t size) {
     for (uint32_t c = 0; c < h.num_chunks; ++c) {                            // sparsepress_v2.hpp:976-1084
         const SpzChunk& d = ch[c];
         if ((uint64_t)d.col_start + d.num_cols > h.n || out + d.nnz > h.nnz) throw ParseError{5, "chunk outside the matrix"};
+        if (d.stream_offset[0] > size - h.data_offset || d.stream_offset[1] > size - h.data_offset) throw ParseError{5, "stream offset beyond end of file"};
         const uint64_t gp = h.data_offset + d.stream_offset[0], gs = d.stream_size[0];
         if (gs >= 4) {
-            if (gp + 4 > size) throw ParseError{5, "gap stream beyond end of file"};
+            if (!in_file(size, gp, gs)) throw ParseError{5, "gap stream beyond end of file"};
             const uint32_t cc = rd32(data + gp);
             const uint8_t* ccp = data + gp + 4;
             uint64_t run = out;
             for (uint32_t j = 0; j < d.num_cols; ++j) {                      // varint column counts (:994-997)
                 uint64_t v = 0; int sh = 0; uint8_t byte;
                 do {
-                    if (ccp >= data + size) throw ParseError{5, "column counts beyond end of file"};
-                    byte = *ccp++; v |= (uint64_t)(byte & 0x7F) << sh; sh += 7;
+                    // (a chunk without nonzeros has no count section: the reference decoder reads whatever bytes follow --
+                    //  replicated, but never past the end of the file)
+                    if (ccp >= (d.nnz > 0 ? data + gp + gs : data + size)) throw ParseError{5, "column counts beyond their stream"};
+                    byte = *ccp++; if (sh < 64) v |= (uint64_t)(byte & 0x7F) << sh; sh += 7;
                 } while (byte & 0x80);
+                if (d.nnz > 0 && (v > d.nnz || run - out > d.nnz - v)) throw ParseError{5, "column counts exceed the chunk's nonzeros"};
                 P.col_ptr[d.col_start + j] = (int)(uint32_t)run;
                 P.seg_ptr[d.col_start + j] = (int)(d.nnz > 0 ? std::min<uint64_t>(run, out + d.nnz) : out);
                 run += (uint32_t)v;
             }
             if (d.nnz > 0) {
+                if (run - out != d.nnz) throw ParseError{5, "column counts do not add up to the chunk's nonzeros"};
                 if (gs < 4ull + cc) throw ParseError{5, "column-count section longer than the gap stream"};
                 add_escape_job(data, size, gp + 4 + cc, gs - 4 - cc, d.nnz, JOB_GAPS, out, 0.f, 0.f, P.jobs);
             }
@@ -309,7 +341,7 @@ SpzParsed parse_file(const uint8_t* data, uint64_t size) {
             for (uint32_t j = 0; j < d.num_cols; ++j) P.col_ptr[d.col_start + j] = P.seg_ptr[d.col_start + j] = (int)(uint32_t)out;
         }
         const uint64_t vp = h.data_offset + d.stream_offset[1], vs = d.stream_size[1];
-        if (vs && vp + vs > size) throw ParseError{5, "value stream beyond end of file"};
+        if (vs && !in_file(size, vp, vs)) throw ParseError{5, "value stream beyond end of file"};
         if (vt <= 2) add_escape_job(data, size, vp, vs, d.nnz, JOB_INT, out, 0.f, 0.f, P.jobs);
         else if (vt == 5) add_escape_job(data, size, vp, vs, d.nnz, JOB_QUANT, out, d.quant_scale, d.quant_offset, P.jobs);
         else add_plane_jobs(data, size, vp, vs, d.nnz, P.bpv, out, P.jobs);
@@ -395,14 +427,14 @@ extern "C" void rcppml_sp_read_gpu(const char** path_ptr, int* device_id, double
     *out_status = -1;
     void *dp = nullptr, *di = nullptr, *dx = nullptr;
     try {
-        FILE* f = std::fopen(*path_ptr, "rb");
-        if (!f) { *out_status = 1; rcppml_err() = "sp_read_gpu: cannot open file"; return; }
-        std::fseek(f, 0, SEEK_END);
-        const size_t size = (size_t)std::ftell(f);
-        std::fseek(f, 0, SEEK_SET);
+        struct File { FILE* f; ~File() { if (f) std::fclose(f); } } file{std::fopen(*path_ptr, "rb")};      // closed on every path
+        if (!file.f) { *out_status = 1; rcppml_err() = "sp_read_gpu: cannot open file"; return; }
+        long fsz = -1;
+        if (std::fseek(file.f, 0, SEEK_END) == 0) fsz = std::ftell(file.f);
+        if (fsz < 0 || std::fseek(file.f, 0, SEEK_SET) != 0) { *out_status = 1; rcppml_err() = "sp_read_gpu: cannot determine the file size"; return; }
+        const size_t size = (size_t)fsz;
         std::vector<uint8_t> bytes(size);
-        const size_t got = size ? std::fread(bytes.data(), 1, size, f) : 0;
-        std::fclose(f);
+        const size_t got = size ? std::fread(bytes.data(), 1, size, file.f) : 0;
         if (got != size) { *out_status = 2; rcppml_err() = "sp_read_gpu: short read"; return; }
         SpzParsed P;
         try { P = parse_file(bytes.data(), size); }
@@ -418,6 +450,21 @@ extern "C" void rcppml_sp_read_gpu(const char** path_ptr, int* device_id, double
             HIPCHK(hipMalloc(&di, (nnz ? nnz : 1) * sizeof(int)));
             HIPCHK(hipMalloc(&dx, (nnz ? nnz : 1) * sizeof(double)));
             decode_to_device(c, bytes.data(), size, P, (int*)dp, (int*)di, (double*)dx);
+            // what leaves this entry feeds the zero-copy fit: insist on a well-formed CSC (the low-level decode op keeps
+            // the reference decoder's output bit for bit, garbage column pointers of nonzero-free chunks included)
+            bool ok = P.col_ptr[0] == 0 && (uint64_t)(uint32_t)P.col_ptr[P.h.n] == P.h.nnz;
+            for (size_t j = 0; ok && j < P.h.n; ++j) ok = P.col_ptr[j] >= 0 && P.col_ptr[j] <= P.col_ptr[j + 1];
+            if (ok && nnz) {
+                int* dbad = static_cast<int*>(c->scratch(WS_RED, sizeof(int)));
+                HIPCHK(hipMemsetAsync(dbad, 0, sizeof(int), s));
+                hipLaunchKernelGGL(spz_check_rows_kernel, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, s, (const int*)di, (int64_t)nnz, (int)P.h.m, dbad);
+                HIPCHK(hipGetLastError());
+                int bad = 0;
+                HIPCHK(hipMemcpyAsync(&bad, dbad, sizeof(int), hipMemcpyDeviceToHost, s));
+                HIPCHK(hipStreamSynchronize(s));
+                ok = bad == 0;
+            }
+            if (!ok) throw std::runtime_error("decoded arrays are not a well-formed CSC (column pointers not monotone, or a row index outside the matrix)");
         } catch (...) {
             rcppml_hip_ctx_destroy(c); (void)hipStreamDestroy(s);
             throw;

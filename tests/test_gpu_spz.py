@@ -102,3 +102,38 @@ def test_read_then_zero_copy_fit(env):
     assert r2["status"] == 0
     assert r1["loss"] == r2["loss"] and np.array_equal(W1, W2) and np.array_equal(H1, H2)
     assert _abi.sp_free_gpu(h) == 0 and h["col_ptr"] == 0.0 and h["row_idx"] == 0.0 and h["values"] == 0.0
+
+
+def test_malformed_files_never_read_out_of_bounds(env):
+    """Fuzz of the host parser: truncations at every 97th byte and 600 single-byte corruptions of a valid file (header,
+    chunk index, count sections, stream sizes) either decode or are rejected with a status -- never a crash, and whatever
+    sp_read_gpu hands out is a well-formed CSC (monotone column pointers ending at nnz, rows inside the matrix)."""
+    import os, tempfile
+    torch, _abi, ctx = env
+    good = GOLD["u16_escape_spz"].copy() if "u16_escape_spz" in GOLD.files else GOLD["u8_spz"].copy()
+    rng = np.random.default_rng(0)
+    cases = [good[:cut] for cut in range(6, good.size, 97)]
+    for _ in range(600):
+        b = good.copy()
+        pos = int(rng.integers(0, min(b.size, 4096)))
+        b[pos] = rng.integers(0, 256)
+        cases.append(b)
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "f.spz")
+        for b in cases:
+            b.tofile(path)
+            r = _abi.sp_read_gpu(path)
+            if r["status"] == 0:
+                m, n, nnz = r["m"], r["n"], r["nnz"]
+                p = torch.empty(n + 1, dtype=torch.int32, device="cuda")
+                _abi.copy_from_device_address(p, r["col_ptr"], (n + 1) * 4)
+                pp = p.cpu().numpy()
+                assert pp[0] == 0 and pp[-1] == nnz and np.all(np.diff(pp) >= 0)
+                if nnz:
+                    i = torch.empty(nnz, dtype=torch.int32, device="cuda")
+                    _abi.copy_from_device_address(i, r["row_idx"], nnz * 4)
+                    ii = i.cpu().numpy()
+                    assert ii.min() >= 0 and ii.max() < m
+                assert _abi.sp_free_gpu(r) == 0
+            else:
+                assert r["status"] in (2, 3, 4, 5) and r["col_ptr"] == 0.0
