@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <type_traits>
@@ -37,14 +38,26 @@ inline std::string& rcppml_err() {
         return 1;                                             \
     }
 
+// Experiment switches (kernel variants kept for probes) exist only in -DRCPPML_EXPERIMENTS builds; the shipping library
+// never reads them.
+#ifdef RCPPML_EXPERIMENTS
+inline bool exp_flag(const char* name, const char* value) { const char* e = getenv(name); return e && !strcmp(e, value); }
+inline const char* exp_env(const char* name) { return getenv(name); }
+#else
+inline bool exp_flag(const char*, const char*) { return false; }
+inline const char* exp_env(const char*) { return nullptr; }
+#endif
+
 enum { WS_GRAM = 0, WS_GPAD, WS_CHOL, WS_RED, WS_RED2, WS_ORDER, WS_IRLS, WS_MFMA, WS_FEAT, WS_GRAPH, WS_COUNT };
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-DEVICE property of a kernel: remember the largest size
 // requested per device (one static instance per kernel instantiation) instead of a process-wide "done" flag.
 struct DynSmemOnce {
     size_t set_bytes[32] = {};
+    std::mutex mu;                  // fits may run concurrently from several host threads (rcppml_err is thread_local)
     void ensure(const void* fn, size_t smem, int device) {
         const int d = device & 31;
+        std::lock_guard<std::mutex> lk(mu);
         if (smem > 48 * 1024 && smem > set_bytes[d]) {
             HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
             set_bytes[d] = smem;

@@ -30,7 +30,7 @@ void cv_solve_impl(rcppml_hip_ctx* c, const int* cp, const int* ri, const T* val
     if constexpr (std::is_same<T, float>::value) {
         // fp32, k <= 32: Gram correction on the matrix cores (RCPPML_GPU_CV_VARIANT=valu keeps the LDS read-modify-write form)
         static int use_mfma = -1;
-        if (use_mfma < 0) { const char* e = getenv("RCPPML_GPU_CV_VARIANT"); use_mfma = (e && !strcmp(e, "valu")) ? 0 : 1; }
+        if (use_mfma < 0) use_mfma = exp_flag("RCPPML_GPU_CV_VARIANT", "valu") ? 0 : 1;
         if (use_mfma && k <= 32 && k % 4 == 0 && reinterpret_cast<uintptr_t>(F) % 16 == 0) {
             const size_t smem = (size_t)4 * (32 * 36 + 96) * sizeof(float);
             hipLaunchKernelGGL(cv_solve_mfma32_kernel, dim3((unsigned)nblk), dim3(256), smem, c->stream, cp, ri, vals, ncols, nrows, F, G,
@@ -41,7 +41,7 @@ void cv_solve_impl(rcppml_hip_ctx* c, const int* cp, const int* ri, const T* val
     }
     if constexpr (std::is_same<T, double>::value) {
         static int use_mfma64 = -1;
-        if (use_mfma64 < 0) { const char* e = getenv("RCPPML_GPU_CV_VARIANT"); use_mfma64 = (e && !strcmp(e, "valu")) ? 0 : 1; }
+        if (use_mfma64 < 0) use_mfma64 = exp_flag("RCPPML_GPU_CV_VARIANT", "valu") ? 0 : 1;
         if (use_mfma64 && k <= 32 && k % 2 == 0 && reinterpret_cast<uintptr_t>(F) % 16 == 0) {
             const size_t smem = (size_t)4 * (32 * 34 + 48) * sizeof(double);
             hipLaunchKernelGGL(cv_solve_mfma64_kernel, dim3((unsigned)nblk), dim3(256), smem, c->stream, cp, ri, vals, ncols, nrows, F, G,

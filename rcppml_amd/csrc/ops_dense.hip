@@ -26,7 +26,7 @@ extern "C" int rcppml_hip_rhs_dense(rcppml_hip_ctx* c, int dtype, const void* A,
                 const int64_t col_blocks = (n + 127) / 128;
                 int64_t slices = (4096 + col_blocks * 4 - 1) / (col_blocks * 4);
                 const int64_t chunks = (m + rk::DENSE_KC - 1) / rk::DENSE_KC;
-                const char* es = getenv("RCPPML_GPU_DENSE_SLICES");
+                const char* es = exp_env("RCPPML_GPU_DENSE_SLICES");
                 if (es) slices = atoi(es);
                 if (slices > chunks) slices = chunks;
                 if (slices < 1) slices = 1;

@@ -19,7 +19,7 @@ static void irls_impl(rcppml_hip_ctx* c, const int* cp, const int* ri, const T* 
     if constexpr (std::is_same<T, float>::value) {
         // fp32, k <= 32: weighted Gram on the matrix cores (RCPPML_GPU_IRLS_VARIANT=valu keeps the register form)
         static int use_mfma = -1;
-        if (use_mfma < 0) { const char* e = getenv("RCPPML_GPU_IRLS_VARIANT"); use_mfma = (e && !strcmp(e, "valu")) ? 0 : 1; }
+        if (use_mfma < 0) use_mfma = exp_flag("RCPPML_GPU_IRLS_VARIANT", "valu") ? 0 : 1;
         if (use_mfma && k <= 32 && k % 4 == 0 && reinterpret_cast<uintptr_t>(F) % 16 == 0) {
             const size_t smem = (size_t)4 * (32 * 36 + 2 * 32 + 32) * sizeof(float);
             hipLaunchKernelGGL(irls_nb_mfma32_kernel, dim3((unsigned)nblk), dim3(256), smem, c->stream, cp, ri, vals, ncols, F,
@@ -30,7 +30,7 @@ static void irls_impl(rcppml_hip_ctx* c, const int* cp, const int* ri, const T* 
     }
     if constexpr (std::is_same<T, double>::value) {
         static int use_mfma64 = -1;
-        if (use_mfma64 < 0) { const char* e = getenv("RCPPML_GPU_IRLS_VARIANT"); use_mfma64 = (e && !strcmp(e, "valu")) ? 0 : 1; }
+        if (use_mfma64 < 0) use_mfma64 = exp_flag("RCPPML_GPU_IRLS_VARIANT", "valu") ? 0 : 1;
         if (use_mfma64 && k <= 32 && k % 2 == 0 && reinterpret_cast<uintptr_t>(F) % 16 == 0) {
             const size_t smem = (size_t)4 * (32 * 34 + 2 * 32 + 32) * sizeof(double);
             hipLaunchKernelGGL(irls_nb_mfma64_kernel, dim3((unsigned)nblk), dim3(256), smem, c->stream, cp, ri, vals, ncols, F,

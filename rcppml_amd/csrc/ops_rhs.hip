@@ -12,35 +12,35 @@ template <class T, int VEC, int LPN>
 static void rhs_launch(rcppml_hip_ctx* c, const int* cp, const int* ri, const T* vals, int64_t ncols,
                        const T* F, int k, T* B) {
     const int64_t nblk = (ncols + 3) / 4;
-    static int mode = -1;                 // experiment switch: RCPPML_GPU_RHS_VARIANT = u16 | nt | nt16
+    dim3 grid((unsigned)nblk), block(256);
+#ifdef RCPPML_EXPERIMENTS
+    // probes only (-DRCPPML_EXPERIMENTS): RCPPML_GPU_RHS_VARIANT = u16 | u4 | u2 | group | stage, RCPPML_GPU_RHS_STAGE_U
+    static int mode = -1, staged = -1;
     if (mode < 0) {
         const char* e = getenv("RCPPML_GPU_RHS_VARIANT");
         mode = !e ? 0 : (!strcmp(e, "u16") ? 1 : (!strcmp(e, "u4") ? 2 : (!strcmp(e, "u2") ? 3 : 0)));
+        staged = (e && *e) ? (!strcmp(e, "stage") ? 1 : 0) : 1;
     }
-    dim3 grid((unsigned)nblk), block(256);
-    if constexpr (LPN >= 8) {     // staged indices (one coalesced load per 64/LPN*8 nonzeros); RCPPML_GPU_RHS_VARIANT=group opts out
-        static int staged = -1;
-        if (staged < 0) { const char* e = getenv("RCPPML_GPU_RHS_VARIANT"); staged = (e && *e) ? (!strcmp(e, "stage") ? 1 : 0) : 1; }
-        if (staged) {
-            // 16 gathers in flight per lane group and a full wave of staged (row, value) pairs per index load where the
-            // group count allows (measured on C2 fp32: rhs_H 0.41 -> 0.29 ms, rhs_W 0.44 -> 0.31 ms vs rhs_kernel; with
-            // 8 in flight the W side, which gathers from the 25 MB factor, is 20 % SLOWER than rhs_kernel)
-            constexpr int SU = LPN >= 16 ? 16 : 8;
-            static int su = -1;
-            if (su < 0) { const char* e = getenv("RCPPML_GPU_RHS_STAGE_U"); su = e ? atoi(e) : SU; }
-            if (su == 8 || SU == 8)
-                hipLaunchKernelGGL((rhs_stage_kernel<T, VEC, LPN, 8>), grid, block, 0, c->stream, cp, ri, vals, ncols, F, k, B);
-            else
-                hipLaunchKernelGGL((rhs_stage_kernel<T, VEC, LPN, SU>), grid, block, 0, c->stream, cp, ri, vals, ncols, F, k, B);
-            HIPCHK(hipGetLastError());
-            return;
+    if (!staged || LPN < 8) {
+        switch (mode) {
+            case 1: hipLaunchKernelGGL((rhs_kernel<T, VEC, LPN, 16, false>), grid, block, 0, c->stream, cp, ri, vals, ncols, F, k, B); break;
+            case 2: hipLaunchKernelGGL((rhs_kernel<T, VEC, LPN, 4, false>), grid, block, 0, c->stream, cp, ri, vals, ncols, F, k, B); break;
+            case 3: hipLaunchKernelGGL((rhs_kernel<T, VEC, LPN, 2, false>), grid, block, 0, c->stream, cp, ri, vals, ncols, F, k, B); break;
+            default: hipLaunchKernelGGL((rhs_kernel<T, VEC, LPN, 8, false>), grid, block, 0, c->stream, cp, ri, vals, ncols, F, k, B); break;
         }
+        HIPCHK(hipGetLastError());
+        return;
     }
-    switch (mode) {
-        case 1: hipLaunchKernelGGL((rhs_kernel<T, VEC, LPN, 16, false>), grid, block, 0, c->stream, cp, ri, vals, ncols, F, k, B); break;
-        case 2: hipLaunchKernelGGL((rhs_kernel<T, VEC, LPN, 4, false>), grid, block, 0, c->stream, cp, ri, vals, ncols, F, k, B); break;
-        case 3: hipLaunchKernelGGL((rhs_kernel<T, VEC, LPN, 2, false>), grid, block, 0, c->stream, cp, ri, vals, ncols, F, k, B); break;
-        default: hipLaunchKernelGGL((rhs_kernel<T, VEC, LPN, 8, false>), grid, block, 0, c->stream, cp, ri, vals, ncols, F, k, B); break;
+#endif
+    if constexpr (LPN >= 8) {
+        // staged indices: one coalesced load per 64 (row, value) pairs, handed to the lane groups through ds_bpermute;
+        // 16 gathers in flight per lane group where a row spans 16 lanes (measured on C2 fp32: rhs_H 0.41 -> 0.29 ms,
+        // rhs_W 0.44 -> 0.31 ms vs the group-uniform index loads of rhs_kernel; with 8 in flight the W side, which gathers
+        // from the 25 MB factor, is 20 % SLOWER than rhs_kernel)
+        constexpr int SU = LPN >= 16 ? 16 : 8;
+        hipLaunchKernelGGL((rhs_stage_kernel<T, VEC, LPN, SU>), grid, block, 0, c->stream, cp, ri, vals, ncols, F, k, B);
+    } else {
+        hipLaunchKernelGGL((rhs_kernel<T, VEC, LPN, 8, false>), grid, block, 0, c->stream, cp, ri, vals, ncols, F, k, B);
     }
     HIPCHK(hipGetLastError());
 }
@@ -49,9 +49,9 @@ static void rhs_impl(rcppml_hip_ctx* c, const int* cp, const int* ri, const T* v
                      const T* F, int k, T* B) {
     if (ncols <= 0) return;
     if (ncols > (int64_t)4 * 0x7fffffff) throw std::runtime_error("rhs: too many columns");
+#ifdef RCPPML_EXPERIMENTS
     // RCPPML_GPU_RHS_VARIANT=wave: scalarised-index kernel (one nonzero per wave instruction, reference summation
-    // order).  Measured no faster than the lane-group kernel on MI355X (H 0.475 / W 0.552 ms vs 0.468 / 0.403 ms on C2),
-    // so it is opt-in.
+    // order).  Measured no faster than the lane-group kernel on MI355X (H 0.475 / W 0.552 ms vs 0.468 / 0.403 ms on C2).
     {
         static int wave_mode = -1;
         if (wave_mode < 0) { const char* e = getenv("RCPPML_GPU_RHS_VARIANT"); wave_mode = (e && !strcmp(e, "wave")) ? 1 : 0; }
@@ -68,6 +68,7 @@ static void rhs_impl(rcppml_hip_ctx* c, const int* cp, const int* ri, const T* v
             return;
         }
     }
+#endif
     constexpr int VMAX = 16 / sizeof(T);   // 16-byte loads
     const bool aligned = (reinterpret_cast<uintptr_t>(F) % 16 == 0) && (reinterpret_cast<uintptr_t>(B) % 16 == 0);
     if (k % VMAX == 0 && aligned && k / VMAX <= 64) {

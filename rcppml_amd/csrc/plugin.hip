@@ -72,7 +72,7 @@ template <class T>
 void fit(FitParams& P) {
     constexpr int dt = DT<T>::id;
     const int m = P.m, n = P.n, k = P.k;
-    CtxGuard g(env_device());
+    CtxGuard g(P.device >= 0 ? P.device : env_device());
     rcppml_hip_ctx* c = g.c;
     hipStream_t s = g.s;
 
@@ -145,7 +145,7 @@ void fit(FitParams& P) {
     OPCHK(rcppml_hip_sumsq(c, dt, dAx.p, dense ? (int64_t)m * n : P.nnz, dtr.as<double>()));       // trAtA, primitives.hpp:100-115
     // CD work order: columns sorted by the sweeps of the previous iteration (results are order-independent)
     DevBuf dswH((size_t)n * sizeof(int)), dswW((size_t)m * sizeof(int)), dordH((size_t)n * sizeof(int)), dordW((size_t)m * sizeof(int));
-    const bool use_order = P.solver_mode == 0 && !has_mask && P.loss_type == 0 && P.cd_tol > 0 && !getenv("RCPPML_GPU_NO_ORDER");
+    const bool use_order = P.solver_mode == 0 && !has_mask && P.loss_type == 0 && P.cd_tol > 0 && !exp_env("RCPPML_GPU_NO_ORDER");
 
     const bool is_pow = P.loss_type >= 6;                               // phi_vec = 1 for dispersion none (fit_cpu.hpp:336-347)
     const bool is_gp = P.loss_type == 4 || is_pow || P.loss_type == 0;  // theta_vec = Zero(m) (:297-304); "no theta in the solve"
@@ -807,6 +807,11 @@ extern "C" void rcppml_gpu_nmf_zerocopy_double(double* d_col_ptr_addr, double* d
         FitParams P;
         P.m = *m; P.n = *n; P.k = *k; P.nnz = static_cast<int64_t>(*nnz_d);
         P.csc_on_device = 1;
+        {   // run where the CSC lives (rcppml_sp_read_gpu allocates on the device it was given, R/sp_gpu.R), not on RCPPML_GPU_DEVICE
+            hipPointerAttribute_t at;
+            if (hipPointerGetAttributes(&at, P.col_ptr) == hipSuccess) P.device = at.device;
+            else (void)hipGetLastError();
+        }
         P.col_ptr = static_cast<const int*>(to_ptr(*d_col_ptr_addr));
         P.row_idx = static_cast<const int*>(to_ptr(*d_row_idx_addr));
         P.values = static_cast<const double*>(to_ptr(*d_values_addr));

@@ -70,6 +70,7 @@ struct FitParams {
     int symmetric = 0;                       // A ~ W diag(d) W^T (A square): only W is solved, H = W_T
     const double* dense = nullptr;           // dense input (column-major m x n): the unfused standard path of fit_cpu.hpp
     int csc_on_device = 0;                   // col_ptr / row_idx / values are DEVICE pointers (zero-copy entry)
+    int device = -1;                         // >= 0: run on this device (zero-copy: the device that owns the CSC); -1: RCPPML_GPU_DEVICE
     int projective = 0;                      // H = (diag(d) W_T) A instead of the NNLS half-update (variant_helpers.hpp:308-325)
     // target regularisation (variant_helpers.hpp:107-146): host matrices k x n / k x m (k leading), NULL = none
     const double* target_H = nullptr; double target_lambda_H = 0;

@@ -75,12 +75,12 @@ static void cd_mfma_launch(rcppml_hip_ctx* c, const float* Gp, const float* invd
     // the kernel takes as long as the fullest CU: 782 blocks on 256 CUs = 4 blocks on 14 CUs, 3 on the rest, i.e.
     // 4/3.05 of the balanced time.  Capping residency at floor(blocks per CU) (by asking for more LDS than a further
     // block would leave) makes the surplus blocks -- the cheapest ones under the sweep-sorted order -- start when
-    // the first blocks retire.  RCPPML_GPU_CD_CAP overrides (0 = no cap).
+    // the first blocks retire.  RCPPML_GPU_CD_CAP overrides in experiment builds (0 = no cap).
     {
         const double per_cu = (double)nblk / (double)(c->num_cu > 0 ? c->num_cu : 256);
         int cap = 0;
         if (per_cu > 1.0 && per_cu < 4.0 && per_cu - std::floor(per_cu) < 0.5) cap = (int)std::floor(per_cu);
-        if (const char* e = getenv("RCPPML_GPU_CD_CAP")) cap = atoi(e);
+        if (const char* e = exp_env("RCPPML_GPU_CD_CAP")) cap = atoi(e);
         if (cap > 0) {
             const size_t lds_cu = 160 * 1024;
             const size_t want = lds_cu / (size_t)(cap + 1) + 1024;      // cap + 1 blocks no longer fit
@@ -131,7 +131,7 @@ static void cd_mfma64_launch(rcppml_hip_ctx* c, const T* Gp, const T* invd, cons
 template <class T>
 static int pick_lpc(int KP) {
     const int ev = 16 / (int)sizeof(T);
-    const char* e = getenv("RCPPML_GPU_CD_LPC");
+    const char* e = exp_env("RCPPML_GPU_CD_LPC");
     int lpc = e ? atoi(e) : (std::is_same<T, float>::value ? KP / 32 : KP / 16);
     if (lpc < 1) lpc = 1;
     if (lpc > 4) lpc = 4;
@@ -148,7 +148,7 @@ static void solve_cd_impl(rcppml_hip_ctx* c, const T* G, const T* B, T* X, int k
     if (k < 1 || k > 128) throw std::runtime_error("solve_cd: k must be in [1,128]");
     int KP = solve_kp(k);
     if (variant == RCPPML_CD_AUTO) {
-        const char* e = getenv("RCPPML_GPU_CD_VARIANT");
+        const char* e = exp_env("RCPPML_GPU_CD_VARIANT");
         if (e && !strcmp(e, "lane")) variant = RCPPML_CD_LANE;
         else if (e && !strcmp(e, "wave")) variant = RCPPML_CD_WAVE;
         else if (e && !strcmp(e, "group")) variant = RCPPML_CD_GROUP;
@@ -159,7 +159,7 @@ static void solve_cd_impl(rcppml_hip_ctx* c, const T* G, const T* B, T* X, int k
         // 625 tiles on 1024 SIMDs); 16-column tiles double the wavefronts there (RCPPML_GPU_CD_SMALL16=0 disables)
         if (variant == RCPPML_CD_MFMA && std::is_same<T, float>::value && k <= 64 && !e) {
             static int small16 = -1;
-            if (small16 < 0) { const char* s16 = getenv("RCPPML_GPU_CD_SMALL16"); small16 = (s16 && !strcmp(s16, "0")) ? 0 : 1; }
+            if (small16 < 0) small16 = exp_flag("RCPPML_GPU_CD_SMALL16", "0") ? 0 : 1;
             if (small16 && (ncols + 31) / 32 < (int64_t)4 * c->num_cu) variant = RCPPML_CD_MFMA16;
         }
     }

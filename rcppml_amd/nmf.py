@@ -198,8 +198,11 @@ def nmf(data, k, tol=1e-4, maxit=100, L1=(0.0, 0.0), L2=(0.0, 0.0), seed=None, m
                     L1=(L1w, L1h), L2=(L2w, L2h), seed=seed_int, precision=precision, resource="gpu", loss_type=loss,
                     test_fraction=float(test_fraction))
         return NMFModel(w=W_T.copy(), d=res["d"], h=H.T.copy(), misc=misc)
-    if dense_in and loss == "mse" and robust_delta == 0 and mask_arg is None and not graph_args and sort_model:
-        # dense input -> rcppml_gpu_nmf_dense_unified_* (GEMM right-hand sides, the reference's unfused update order)
+    if dense_in and loss == "mse" and robust_delta == 0 and mask_arg is None and not graph_args and sort_model and target_H is None \
+            and float(cd_tol) == 1e-8:
+        # dense input -> rcppml_gpu_nmf_dense_unified_* (GEMM right-hand sides, the reference's unfused update order).
+        # The dense ABI (bridge_nmf.hpp:101-126) has no slot for cd_tol (the plugin uses the reference default 1e-8) and
+        # returns no loss history: any other cd_tol keeps the sparse entry, which honours it; misc says which entry ran.
         res = _abi.nmf_dense(np.asarray(data, np.float64), k, W_T, H, entry="float" if precision == "fp32" else "double",
                              max_iter=int(maxit), tol=float(tol), L1_H=L1h, L1_W=L1w, L2_H=L2h, L2_W=L2w, L21_H=L21h, L21_W=L21w,
                              ortho_H=angh, ortho_W=angw, ub_H=ubh, ub_W=ubw, cd_maxit=int(cd_maxit), verbose=int(verbose),
@@ -210,7 +213,7 @@ def nmf(data, k, tol=1e-4, maxit=100, L1=(0.0, 0.0), L2=(0.0, 0.0), seed=None, m
             raise _abi.BackendError("GPU dense NMF failed: %s" % res.get("error"))
         misc = dict(tol=res["tol"], iter=res["iter"], loss=res["loss"], converged=res["converged"], solver=solver,
                     solver_mode=0 if solver == "cd" else 1, L1=(L1w, L1h), L2=(L2w, L2h), seed=seed_int, precision=precision,
-                    resource="gpu", loss_type=loss, input="dense")
+                    resource="gpu", loss_type=loss, input="dense", loss_history=None)
         return NMFModel(w=W_T.copy(), d=res["d"], h=H.T.copy(), misc=misc)
     target_args = {}
     if target_H is not None:

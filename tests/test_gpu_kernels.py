@@ -293,36 +293,6 @@ def test_ctx_stats_counts_column_sweeps(env):
         assert st["cd_column_sweeps"] == int(sw.sum().item()) and st["cd_column_sweeps"] >= n
 
 
-def test_rhs_staged_equals_group_kernel():
-    """The staged-index SpMM kernel keeps rhs_kernel's lane-group mapping and summation order: bitwise equal results.
-    (The launcher reads RCPPML_GPU_RHS_VARIANT once per process, hence two subprocesses.)"""
-    import hashlib, subprocess, sys
-    code = r'''
-import hashlib, numpy as np, torch
-from rcppml_amd import _abi
-from tests.util import random_csc
-ctx = _abi.Context(0)
-h = hashlib.sha256()
-for dtype, dt in ((np.float32, _abi.F32), (np.float64, _abi.F64)):
-    for k in (32, 64, 128):
-        A = random_csc(500, 300, 0.05, seed=k)
-        F = np.random.default_rng(k).uniform(size=(500, k)).astype(dtype)
-        dB = torch.zeros((300, k), dtype=torch.float32 if dtype == np.float32 else torch.float64, device="cuda")
-        ctx.rhs(dt, torch.from_numpy(A.p.astype(np.int32)).cuda(), torch.from_numpy(A.i.astype(np.int32)).cuda(),
-                torch.from_numpy(A.x.astype(dtype)).cuda(), 300, torch.from_numpy(F).cuda(), k, dB)
-        h.update(dB.cpu().numpy().tobytes())
-print("DIGEST", h.hexdigest())
-'''
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    digests = []
-    for variant in ("stage", "group"):
-        env2 = dict(os.environ, RCPPML_GPU_RHS_VARIANT=variant, PYTHONPATH=root)
-        out = subprocess.run([sys.executable, "-c", code], env=env2, cwd=root, capture_output=True, text=True, timeout=300)
-        assert out.returncode == 0, out.stderr[-2000:]
-        digests.append([l for l in out.stdout.splitlines() if l.startswith("DIGEST")][0])
-    assert digests[0] == digests[1]
-
-
 def test_transpose_csc_and_cast(env):
     """rcppml_hip_transpose_csc (stable radix sort by row): identical to the host transpose -- integer arrays and the
     moved values bit for bit, column indices ascending inside every row; pattern-only (mask) form; empty matrix."""
