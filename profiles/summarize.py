@@ -43,10 +43,22 @@ for k in sorted(set(fetch) | set(write)):
     f_kib, w_kib = sum(fv) / len(fv), sum(wv) / len(wv)
     out[k] = dict(launches=len(fv), fetch_size_kib_avg=f_kib, write_size_kib_avg=w_kib,
                   hbm_bytes_per_launch=(2.0 * f_kib + w_kib) * 1024.0, resources=meta.get(k, {}))
-json.dump(out, open(os.path.join(dst, tag + "_pmc.json"), "w"), indent=1)
+# one rhs CALL = spill kernel + tiled kernel (+ partial reduce, + gather kernel on the tail columns): traffic of everything one
+# rcppml_hip_rhs_planned launches, averaged over the two sides (H and W) -- what bench.py's roofline_rhs.traffic quotes
+def is_rhs(k):
+    return "rhs_tiled_kernel" in k or "rhs_tiled_spill" in k or "rhs_tiled_reduce" in k or "rhs_stage_kernel" in k or "rhs_kernel" in k
+rhs_total = sum(v["hbm_bytes_per_launch"] * v["launches"] for k, v in out.items() if is_rhs(k))
+tiled_launches = sum(v["launches"] for k, v in out.items() if "rhs_tiled_kernel" in k)
+gather_launches = sum(v["launches"] for k, v in out.items() if "rhs_stage_kernel" in k or "rhs_kernel<" in k)
+calls = tiled_launches if tiled_launches else gather_launches
+doc = dict(kernels=out)
+if calls:
+    doc["rhs_per_launch"] = dict(calls=calls, hbm_bytes_per_launch=rhs_total / calls,
+                                 note="sum over every kernel of one rhs call (spill + tiled + reduce + tail gather), mean of both sides")
+json.dump(doc, open(os.path.join(dst, tag + "_pmc.json"), "w"), indent=1)
 
 with open(os.path.join(dst, tag + "_summary.md"), "w") as f:
-    f.write("# rocprofv3 summary `%s`\n\nCommand: `python bench.py --steps 10 --warmup 3 --no-cpu-baseline` "
+    f.write("# rocprofv3 summary `%s`\n\nCommand: `python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-plugin-figure` "
             "(profiles/run_rocprof.sh; pass 1 `--kernel-trace --stats`, passes 2/3 `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE`).\n\n" % tag)
     f.write("| kernel | calls | avg us | total ms | % |\n|---|---|---|---|---|\n")
     for r in keep:
@@ -63,13 +75,15 @@ trace = os.path.join(src, "trace", "trace_kernel_trace.csv")
 if os.path.exists(trace):
     by = collections.defaultdict(list)
     for r in csv.DictReader(open(trace)):
-        if "rk::cd_mfma" in r["Kernel_Name"] and "prep" not in r["Kernel_Name"] or "rk::rhs_stage" in r["Kernel_Name"]:
+        if "rk::cd_mfma" in r["Kernel_Name"] and "prep" not in r["Kernel_Name"] or "rk::rhs_stage" in r["Kernel_Name"] or "rk::rhs_tiled" in r["Kernel_Name"]:
             by[r["Kernel_Name"]].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
     with open(os.path.join(dst, tag + "_summary.md"), "a") as f:
         f.write("\nTimed launches only (the last 10 iterations of the 13; from the kernel trace):\n\n| kernel | launches | avg us (all) | avg us (timed) |\n|---|---|---|---|\n")
+        # kernels that run once per side share a name when both sides pick the same shape: split by grid size
         for k, v in by.items():
             v.sort()
             d = [x[1] for x in v]
             nt = 20 if "rhs_stage" in k else 10
+            nt = min(nt, len(d))
             f.write("| `%s` | %d | %.1f | %.1f |\n" % (k[:70], len(d), sum(d) / len(d) / 1e3, sum(d[-nt:]) / nt / 1e3))
 print(open(os.path.join(dst, tag + "_summary.md")).read())
