@@ -258,7 +258,7 @@ def main():
                 for side, tile in (("H", 32), ("W", 16 if n_loc >= 0 and m <= 32 * 1024 else 32)):
                     o = st.ops._order[side]
                     sw = o["sweeps"].cpu().numpy().astype(np.int64)
-                    use_order = o["valid"] and cfg.cd_tol > 0 and sw.shape[0] >= 32768
+                    use_order = o["valid"] and cfg.cd_tol > 0 and sw.shape[0] >= als.ORDER_MIN_COLUMNS
                     sq = sw[o["order"].cpu().numpy()] if use_order else sw
                     pad = (-len(sq)) % tile
                     tl = np.concatenate([sq, np.zeros(pad, np.int64)]).reshape(-1, tile)

@@ -21,6 +21,8 @@ import os
 import numpy as np
 
 
+ORDER_MIN_COLUMNS = 16384   # sides with at least this many columns solve them in sweep-sorted order (plugin: kOrderMinColumns)
+
 @dataclass
 class AlsConfig:
     k: int
@@ -131,8 +133,9 @@ class HipOps:
                 if cfg.order_columns and (st is None or st["sweeps"].shape[0] != n):
                     st = dict(sweeps=self.zeros((n,), self.torch.int32), order=self.empty((n,), self.torch.int32), valid=False)
                     self._order[side] = st
-                # (only worth it when there are more wavefronts than the chip holds at once: >= 32768 columns)
-                use = st is not None and st["valid"] and cfg.cd_tol > 0 and n >= 32768
+                # (worth its three small kernels from one 16-column wavefront per SIMD: C2's 20 000-column W side, whose
+                # slowest columns set the kernel's time, goes 0.350 -> 0.313 ms)
+                use = st is not None and st["valid"] and cfg.cd_tol > 0 and n >= ORDER_MIN_COLUMNS
                 if use:
                     self.ctx.order_columns(st["sweeps"], n, st["order"])
                 self.ctx.solve_cd(self.dt, G, B, X, k, n, l1_pre=l1 if l1 > 0 else 0.0, warm=int(warm), zero_init=0,

@@ -1962,23 +1962,25 @@ static __global__ __launch_bounds__(256) void order_hist_kernel(const int* __res
     __syncthreads();
     if (threadIdx.x < 128 && sh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], sh[threadIdx.x]);
 }
-static __global__ __launch_bounds__(128) void order_scan_kernel(unsigned int* __restrict__ hist /*128 in, offsets out*/) {
-    __shared__ unsigned int sh[128];
-    sh[threadIdx.x] = hist[threadIdx.x];
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned int run = 0;
-        for (int b = 0; b < 128; ++b) { const unsigned int c = sh[b]; sh[b] = run; run += c; }
-    }
-    __syncthreads();
-    hist[threadIdx.x] = sh[threadIdx.x];
-}
 static __global__ __launch_bounds__(256) void order_scatter_kernel(const int* __restrict__ sweeps, int64_t n,
-                                                                     unsigned int* __restrict__ offsets /*128*/,
+                                                                     const unsigned int* __restrict__ hist /*128 bin counts*/,
+                                                                     unsigned int* __restrict__ cursor /*128, zeroed*/,
                                                                      int* __restrict__ order) {
     // Block-aggregated: each block counts its contiguous chunk per bin in LDS, reserves one global range per bin
     // (128 global atomics per block instead of one per element on a handful of hot bins), then ranks inside LDS.
-    __shared__ unsigned int cnt[128], base[128];
+    // every block scans the 128 bin counts itself (two waves, shuffle scan) -- cheaper than a kernel of its own
+    __shared__ unsigned int cnt[128], base[128], start[128];
+    if (threadIdx.x < 128) {
+        const unsigned int h = hist[threadIdx.x];
+        unsigned int incl = h;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const unsigned int t = __shfl_up(incl, d, 64); if ((threadIdx.x & 63) >= d) incl += t; }
+        if (threadIdx.x == 63) base[0] = incl;          // total of bins 0..63 (base[] is free until the ranking phase)
+        start[threadIdx.x] = incl - h;
+    }
+    __syncthreads();
+    if (threadIdx.x >= 64 && threadIdx.x < 128) start[threadIdx.x] += base[0];
+    __syncthreads();
     const int64_t per = (n + gridDim.x - 1) / gridDim.x;
     const int64_t i0 = (int64_t)blockIdx.x * per;
     const int64_t i1 = i0 + per < n ? i0 + per : n;
@@ -1992,7 +1994,7 @@ static __global__ __launch_bounds__(256) void order_scatter_kernel(const int* __
     __syncthreads();
     if (threadIdx.x < 128) {
         const unsigned int c = cnt[threadIdx.x];
-        base[threadIdx.x] = c ? atomicAdd(&offsets[threadIdx.x], c) : 0u;
+        base[threadIdx.x] = c ? start[threadIdx.x] + atomicAdd(&cursor[threadIdx.x], c) : 0u;
         cnt[threadIdx.x] = 0;
     }
     __syncthreads();

@@ -78,13 +78,12 @@ extern "C" int rcppml_hip_order_columns(rcppml_hip_ctx* c, const int* sweeps, in
     try {
         HIPCHK(hipSetDevice(c->device));
         if (ncols <= 0) return 0;
-        unsigned int* hist = static_cast<unsigned int*>(c->scratch(WS_ORDER, 128 * sizeof(unsigned int)));
-        HIPCHK(hipMemsetAsync(hist, 0, 128 * sizeof(unsigned int), c->stream));
+        unsigned int* hist = static_cast<unsigned int*>(c->scratch(WS_ORDER, 256 * sizeof(unsigned int)));   // bin counts | cursors
+        HIPCHK(hipMemsetAsync(hist, 0, 256 * sizeof(unsigned int), c->stream));
         int64_t nblk = (ncols + 255) / 256;
         if (nblk > 2 * (int64_t)c->num_cu) nblk = 2 * c->num_cu;
         hipLaunchKernelGGL(order_hist_kernel, dim3((unsigned)nblk), dim3(256), 0, c->stream, sweeps, ncols, hist);
-        hipLaunchKernelGGL(order_scan_kernel, dim3(1), dim3(128), 0, c->stream, hist);
-        hipLaunchKernelGGL(order_scatter_kernel, dim3((unsigned)nblk), dim3(256), 0, c->stream, sweeps, ncols, hist, order);
+        hipLaunchKernelGGL(order_scatter_kernel, dim3((unsigned)nblk), dim3(256), 0, c->stream, sweeps, ncols, hist, hist + 128, order);
         HIPCHK(hipGetLastError());
         return 0;
     }

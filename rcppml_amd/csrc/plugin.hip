@@ -254,7 +254,7 @@ void fit(FitParams& P) {
             rhs_fwd(dW.p, dBh.p);
             void* Bh_use = tgtH ? apply_target(P.target_lambda_H, dTH, TG_H, dG.p, dBh.p, n) : dBh.p;
             if (P.solver_mode == 0) {                                                   // :516-524
-                const bool ord = use_order && iter > 0 && n >= 32768;   // pays once waves outnumber the chip's slots
+                const bool ord = use_order && iter > 0 && n >= kOrderMinColumns;
                 if (ord) OPCHK(rcppml_hip_order_columns(c, dswH.as<int>(), n, dordH.as<int>()));
                 OPCHK(rcppml_hip_solve_cd(c, dt, dG.p, Bh_use, dH.p, k, n, P.L1_H > 0 ? P.L1_H : 0.0, warm, zinit, 0.0, 0.0,
                                           P.nonneg_H, P.cd_maxit, P.cd_tol, 0.0, P.ub_H, RCPPML_CD_AUTO,
@@ -305,7 +305,7 @@ void fit(FitParams& P) {
             rhs_bwd(dH.p, dBw.p);
             void* Bw_use = tgtW ? apply_target(P.target_lambda_W, dTW, TG_W, dG.p, dBw.p, m) : dBw.p;   // the loss keeps the raw B_w (:786-789)
             if (P.solver_mode == 0) {
-                const bool ord = use_order && iter > 0 && m >= 32768;
+                const bool ord = use_order && iter > 0 && m >= kOrderMinColumns;
                 if (ord) OPCHK(rcppml_hip_order_columns(c, dswW.as<int>(), m, dordW.as<int>()));
                 OPCHK(rcppml_hip_solve_cd(c, dt, dG.p, Bw_use, dW.p, k, m, P.L1_W > 0 ? P.L1_W : 0.0, warm, zinit, 0.0, 0.0,
                                           P.nonneg_W, P.cd_maxit, P.cd_tol, 0.0, P.ub_W, RCPPML_CD_AUTO,

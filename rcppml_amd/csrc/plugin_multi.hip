@@ -132,7 +132,7 @@ struct Shard {
     int c0 = 0, n_loc = 0;
     int64_t nnz_loc = 0;
     DevBuf Ap, Ai, Ax, Tp, Ti, Tx;
-    DevBuf W, H, d, Bh, xbuf, G, Gs, Gwt, sums, tr, loss, swH, ordH, swW;
+    DevBuf W, H, d, Bh, xbuf, G, Gs, Gwt, sums, tr, loss, swH, ordH, swW, ordW;
     rcppml_rhs_plan* planA = nullptr;
     rcppml_rhs_plan* planT = nullptr;
     ~Shard() {
@@ -194,7 +194,7 @@ void fit_multi(FitParams& P, const std::vector<int>& devices, bool shared) {
         s.sums.alloc((size_t)k * sizeof(T));
         s.tr.alloc(sizeof(double)); s.loss.alloc(4 * sizeof(double));
         s.swH.alloc((size_t)std::max(s.n_loc, 1) * sizeof(int)); s.ordH.alloc((size_t)std::max(s.n_loc, 1) * sizeof(int));
-        s.swW.alloc((size_t)m * sizeof(int));
+        s.swW.alloc((size_t)m * sizeof(int)); s.ordW.alloc((size_t)m * sizeof(int));
         if (s.nnz_loc >= (1 << 20)) {
             OPCHK(rcppml_hip_rhs_plan_create(c, dt, s.Ap.template as<int>(), s.Ai.template as<int>(), s.Ax.p, s.n_loc, m, k, 0, 0, &s.planA));
             OPCHK(rcppml_hip_rhs_plan_create(c, dt, s.Tp.template as<int>(), s.Ti.template as<int>(), s.Tx.p, m, s.n_loc, k, 0, 0, &s.planT));
@@ -242,7 +242,7 @@ void fit_multi(FitParams& P, const std::vector<int>& devices, bool shared) {
             if (s.planA) OPCHK(rcppml_hip_rhs_planned(c, s.planA, s.W.p, s.Bh.p));
             else OPCHK(rcppml_hip_rhs(c, dt, s.Ap.template as<int>(), s.Ai.template as<int>(), s.Ax.p, s.n_loc, s.W.p, k, s.Bh.p));
             if (P.solver_mode == 0) {
-                const bool ord = use_order && iter > 0 && s.n_loc >= 32768;
+                const bool ord = use_order && iter > 0 && s.n_loc >= kOrderMinColumns;
                 if (ord) OPCHK(rcppml_hip_order_columns(c, s.swH.template as<int>(), s.n_loc, s.ordH.template as<int>()));
                 OPCHK(rcppml_hip_solve_cd(c, dt, s.G.p, s.Bh.p, s.H.p, k, s.n_loc, P.L1_H > 0 ? P.L1_H : 0.0, warm, 0, 0.0, 0.0,
                                           P.nonneg_H, P.cd_maxit, P.cd_tol, 0.0, P.ub_H, RCPPML_CD_AUTO,
@@ -286,10 +286,13 @@ void fit_multi(FitParams& P, const std::vector<int>& devices, bool shared) {
                 HIPCHK(hipGetLastError());
             }
             void* Bw = T_ptr(s.xbuf, (size_t)k * k);
-            if (P.solver_mode == 0)
+            if (P.solver_mode == 0) {
+                const bool ord = use_order && iter > 0 && m >= kOrderMinColumns;
+                if (ord) OPCHK(rcppml_hip_order_columns(c, s.swW.template as<int>(), m, s.ordW.template as<int>()));
                 OPCHK(rcppml_hip_solve_cd(c, dt, s.G.p, Bw, s.W.p, k, m, P.L1_W > 0 ? P.L1_W : 0.0, warm, 0, 0.0, 0.0, P.nonneg_W,
-                                          P.cd_maxit, P.cd_tol, 0.0, P.ub_W, RCPPML_CD_AUTO, use_order ? s.swW.template as<int>() : nullptr, nullptr));
-            else
+                                          P.cd_maxit, P.cd_tol, 0.0, P.ub_W, RCPPML_CD_AUTO, use_order ? s.swW.template as<int>() : nullptr,
+                                          ord ? s.ordW.template as<int>() : nullptr));
+            } else
                 OPCHK(rcppml_hip_solve_chol(c, dt, s.G.p, Bw, s.W.p, k, m, P.L1_W > 0 ? P.L1_W : 0.0, P.nonneg_W, P.ub_W));
             OPCHK(rcppml_hip_row_norms(c, dt, s.W.p, k, m, P.norm_type, s.sums.p));
             OPCHK(rcppml_hip_apply_scaling(c, dt, s.W.p, k, m, P.norm_type, s.sums.p, s.d.p));

@@ -15,7 +15,7 @@ for it in range(12):
         for side, tile in (("H", 32), ("W", 16)):
             o = ops._order[side]
             sw = o["sweeps"].cpu().numpy().astype(np.int64)
-            order = o["order"].cpu().numpy() if side == "H" else np.arange(sw.shape[0])       # W side: < 32768 columns, natural order
+            order = o["order"].cpu().numpy() if sw.shape[0] >= als.ORDER_MIN_COLUMNS else np.arange(sw.shape[0])
             s = sw[order]
             pad = (-len(s)) % tile
             t = np.concatenate([s, np.zeros(pad, np.int64)]).reshape(-1, tile)
