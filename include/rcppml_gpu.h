@@ -53,9 +53,14 @@ RCPPML_GPU_API void rcppml_gpu_detect(int* num_gpus, double* total_mem_mb, doubl
  * RCPPML_GPU_PRECISION=fp64 to force fp64), `_double` computes in fp64.  Arrays at the ABI are
  * always double.  W (k x m), H (k x n), d (k) are in/out.  Unlike the reference plugin this one
  * sorts factors by descending d before returning (what CPU nmf() returns) unless env
- * RCPPML_GPU_SORT=0.  Features it does not implement (L21, angular, graph, guides, projective,
- * symmetric, losses other than MSE/NB) are REJECTED with *out_status = -1 so the caller falls back
- * to CPU rather than silently dropping them. */
+ * RCPPML_GPU_SORT=0.  Implemented: losses MSE / NB / GP(KL) / Gamma / inverse Gaussian / Tweedie with
+ * dispersion none, global or per-row and the robust (Huber) modifier; L1, L2, L21, angular, graph
+ * Laplacians, upper bounds, nonneg, projective and symmetric NMF (MSE path); CD and Cholesky+clip;
+ * env RCPPML_GPU_DEVICES=n shards plain MSE fits over n devices (plugin_multi.hip).  Not implemented
+ * -- REJECTED with *out_status = -1 so the caller falls back to CPU rather than silently dropping
+ * them: classifier guides, dispersion = per_col, zero-inflated losses, k > 128 (k > 64 for IRLS losses,
+ * angular and graph penalties).  Target regularisation has no slot in these 73 arguments: see
+ * rcppml_gpu_nmf_target below. */
 #define RCPPML_NMF_UNIFIED_ARGS                                                                    \
     const int* col_ptr, const int* row_idx, const double* values, int* m, int* n, int* nnz, int* k, \
         double* W, double* H, double* d, int* max_iter, double* tol, double* L1_H, double* L1_W,   \
