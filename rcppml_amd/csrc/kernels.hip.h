@@ -835,7 +835,10 @@ __global__ __launch_bounds__(256) void cd_group_kernel(const T* __restrict__ Gp,
 // variant win when the solution is sparse and for ranks the lane variant cannot hold in registers.
 // Persistent blocks: each wave strides over columns, G is staged into LDS once per block.
 // ---------------------------------------------------------------------------
-template <class T, int KP, bool EXACT>
+// GLDS = false (ranks above 128): the padded Gram stays in global memory (256 KiB in fp32 at KP = 256: L2-resident) and the
+// moving coordinate's column is read coalesced from there -- the correct-if-slower path for any rank the MFMA tiles do
+// not cover (reference gpu/batch_nnls.cuh:325-378 hands such ranks to a parallel general kernel as well).
+template <class T, int KP, bool EXACT, bool GLDS = true>
 __global__ __launch_bounds__(256) void cd_wave_kernel(const T* __restrict__ Gp,
                                                        const T* __restrict__ invd,
                                                        const T* __restrict__ B, T* __restrict__ X,
@@ -845,9 +848,13 @@ __global__ __launch_bounds__(256) void cd_wave_kernel(const T* __restrict__ Gp,
                                                       int* __restrict__ sweeps, const int* __restrict__ order) {
     constexpr int VPL = KP / 64;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    T* Gs = reinterpret_cast<T*>(smem_raw);
-    for (int e = threadIdx.x; e < KP * KP; e += blockDim.x) Gs[e] = Gp[e];
-    __syncthreads();
+    const T* Gs = Gp;
+    if constexpr (GLDS) {
+        T* Gl = reinterpret_cast<T*>(smem_raw);
+        for (int e = threadIdx.x; e < KP * KP; e += blockDim.x) Gl[e] = Gp[e];
+        __syncthreads();
+        Gs = Gl;
+    }
     const int lane = threadIdx.x & 63;
     const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
     const bool has_upper = ub_cd > T(0);

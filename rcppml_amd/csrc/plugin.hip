@@ -475,7 +475,7 @@ void nmf_entry(RCPPML_NMF_UNIFIED_ARGS, const int* mask_p, const int* mask_i, do
         }
         if (*projective != 0 && (*loss_type != 0 || *robust_delta > 0 || mask_p)) throw std::runtime_error("projective NMF: MSE path without explicit mask only");
         if (*solver_mode != 0 && *solver_mode != 1) throw std::runtime_error("solver_mode must be 0 (CD) or 1 (Cholesky+clip)");
-        if (*k < 1 || *k > 128) throw std::runtime_error("k must be in [1,128]");
+        if (*k < 1 || *k > 256) throw std::runtime_error("k must be in [1,256]");
         if (*m < 1 || *n < 1) throw std::runtime_error("empty matrix");
         if (*norm_type < 0 || *norm_type > 2) throw std::runtime_error("bad norm_type");
         if (col_ptr[*n] != *nnz) throw std::runtime_error("col_ptr[n] != nnz");
@@ -800,7 +800,7 @@ extern "C" void rcppml_gpu_nmf_zerocopy_double(double* d_col_ptr_addr, double* d
         (void)seed; (void)loss_every; (void)huber_delta; (void)irls_max_iter; (void)irls_tol;
         auto to_ptr = [](double addr) { return reinterpret_cast<void*>(static_cast<uintptr_t>(addr)); };
         if (*loss_type != 0) throw std::runtime_error("zero-copy entry: only the MSE loss is implemented");
-        if (*k < 1 || *k > 128) throw std::runtime_error("k must be in [1,128]");
+        if (*k < 1 || *k > 256) throw std::runtime_error("k must be in [1,256]");
         if ((*ortho_H != 0 || *ortho_W != 0) && *k > 64) throw std::runtime_error("angular penalty: k must be <= 64");
         if (*m < 1 || *n < 1) throw std::runtime_error("empty matrix");
         if (*norm_type < 0 || *norm_type > 2) throw std::runtime_error("bad norm_type");
@@ -929,7 +929,7 @@ extern "C" void rcppml_gpu_nnls_double(const int* col_ptr, const int* row_idx, c
     try {
         rcppml_err().clear();
         *out_status = -1;
-        if (*k < 1 || *k > 128) throw std::runtime_error("k must be in [1,128]");
+        if (*k < 1 || *k > 256) throw std::runtime_error("k must be in [1,256]");
         CtxGuard g(env_device());
         hipStream_t s = g.s;
         DevBuf dAp, dAi, dAx, dW, dH;

@@ -17,13 +17,13 @@ static void cd_lane_launch(rcppml_hip_ctx* c, const T* Gp, const T* invd, const 
                        B, X, k, ncols, l1_pre, warm, zero_init, l1_cd, l2_cd, nonneg, maxit, tol, ub_cd, ub_post, sweeps, order);
     HIPCHK(hipGetLastError());
 }
-template <class T, int KP>
+template <class T, int KP, bool GLDS = true>
 static void cd_wave_launch(rcppml_hip_ctx* c, const T* Gp, const T* invd, const T* B, T* X, int k,
                            int64_t ncols, T l1_pre, int warm, int zero_init, T l1_cd, T l2_cd, int nonneg,
                            int maxit, T tol, T ub_cd, T ub_post, int* sweeps, const int* order) {
     constexpr bool EXACT = std::is_same<T, double>::value;
-    const size_t smem = (size_t)KP * KP * sizeof(T);
-    auto kern = cd_wave_kernel<T, KP, EXACT>;
+    const size_t smem = GLDS ? (size_t)KP * KP * sizeof(T) : 0;
+    auto kern = cd_wave_kernel<T, KP, EXACT, GLDS>;
     static DynSmemOnce once;
     once.ensure(reinterpret_cast<const void*>(kern), smem, c->device);
     // persistent blocks: as many 256-thread blocks per CU as LDS allows (<= 8), capped by the work
@@ -145,7 +145,16 @@ static void solve_cd_impl(rcppml_hip_ctx* c, const T* G, const T* B, T* X, int k
                           int warm, int zero_init, T l1_cd, T l2_cd, int nonneg, int maxit, T tol, T ub_cd,
                           T ub_post, int variant, int* sweeps, const int* order) {
     if (ncols <= 0) return;
-    if (k < 1 || k > 128) throw std::runtime_error("solve_cd: k must be in [1,128]");
+    if (k < 1 || k > 256) throw std::runtime_error("solve_cd: k must be in [1,256]");
+    if (k > 128) {
+        // general-rank path: one wavefront per column, four coordinates per lane, the Gram read from L2 (cd_wave_kernel
+        // with GLDS = false); every `variant` lands here
+        T *Gp, *invd;
+        pad_impl<T>(c, G, k, 256, &Gp, &invd);
+        cd_wave_launch<T, 256, false>(c, Gp, invd, B, X, k, ncols, l1_pre, warm, zero_init, l1_cd, l2_cd, nonneg, maxit, tol, ub_cd,
+                                      ub_post, sweeps, order);
+        return;
+    }
     int KP = solve_kp(k);
     if (variant == RCPPML_CD_AUTO) {
         const char* e = exp_env("RCPPML_GPU_CD_VARIANT");

@@ -21,7 +21,7 @@ def _dev(torch, a):
     return torch.from_numpy(np.ascontiguousarray(a)).cuda()
 
 
-RANKS = [1, 2, 5, 7, 12, 15, 16, 17, 24, 31, 32, 33, 40, 47, 48, 49, 63, 64, 65, 80, 96, 97, 127, 128]
+RANKS = [1, 2, 5, 7, 12, 15, 16, 17, 24, 31, 32, 33, 40, 47, 48, 49, 63, 64, 65, 80, 96, 97, 127, 128, 129, 160, 200, 256]
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
@@ -54,8 +54,8 @@ def test_fuzz_rhs_gram_scaling(env, dtype):
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 def test_fuzz_cd_auto(env, dtype):
-    """The AUTO solve (MFMA kernels for fp32 k<=128 / fp64 k<=64, lane groups beyond) on odd ranks and column counts,
-    cold and warm, with and without the early exit."""
+    """The AUTO solve (MFMA kernels for k <= 128, the general-rank wave-per-column kernel up to 256) on odd ranks and
+    column counts, cold and warm, with and without the early exit."""
     torch, _abi, ctx = env
     dt = _abi.F32 if dtype == np.float32 else _abi.F64
     tol = 3e-4 if dtype == np.float32 else 1e-9
@@ -75,7 +75,7 @@ def test_fuzz_cd_auto(env, dtype):
             X = dX.cpu().numpy()
             assert X.min() >= 0
             # fp32 at k > 64: 4k+5 uniform samples give a Gram with condition ~1e4, a few sweeps amplify rounding
-            tk = tol * (4 if (dtype == np.float32 and k > 64) else 1)
+            tk = tol * ((16 if k > 128 else 4) if (dtype == np.float32 and k > 64) else 1)
             assert np.abs(X - ref).max() / max(np.abs(ref).max(), 1e-30) < tk, ("cd", k, n, warm)
 
 

@@ -103,6 +103,24 @@ def test_fit_at_c4_ranks(abi, k, precision, tol):
     _compare(res, ref, tol if precision == 1 else 2e-4, tol)
 
 
+@pytest.mark.parametrize("k", [129, 160, 256])
+def test_fit_above_rank_128(abi, k):
+    """Ranks the MFMA tiles do not cover (128 < k <= 256) are not handed back: general-rank CD kernel (one wavefront per
+    column, Gram from L2), generic rhs / Gram / scaling kernels.  fp64 entry vs the oracle's fp64 fit; fp32 entry vs the
+    fp64 oracle as in test_fit_at_c4_ranks.  k = 257 is rejected loudly."""
+    A = lowrank_csc(420, 640, 10, 0.1, seed=k)
+    W0, H0 = O.init_factors(5, k, A.rows, A.cols, np.float64)
+    ref = O.nmf_fit(A, W0, H0, np.float64, max_iter=5, tol=0.0, solver_mode=0, L1=(0.0, 0.01))
+    res = _run_gpu(abi, A, W0, H0, "ex", max_iter=5, tol=0.0, solver_mode=0, L1_H=0.01, precision=1)
+    _compare(res, ref, 1e-6, 1e-6)
+    res32 = _run_gpu(abi, A, W0, H0, "ex", max_iter=5, tol=0.0, solver_mode=0, L1_H=0.01, precision=0)
+    _compare(res32, ref, 5e-4, 5e-3)
+    if k == 256:
+        W1, H1 = O.init_factors(5, 257, A.rows, A.cols, np.float64)
+        r = abi.nmf_unified(A.p, A.i, A.x, A.rows, A.cols, 257, W1, H1, entry="double", max_iter=2)
+        assert r["status"] == -1 and "256" in r["error"]
+
+
 @pytest.mark.parametrize("solver", [0, 1])
 @pytest.mark.parametrize("lam_w,lam_h", [(0.5, 0.0), (0.0, 0.8), (0.3, 0.4), (-0.4, 0.0), (0.0, -0.6), (-0.3, 0.5)])
 def test_target_regularisation(abi, solver, lam_w, lam_h):
