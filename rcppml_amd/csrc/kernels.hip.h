@@ -2008,7 +2008,16 @@ static __global__ __launch_bounds__(256) void order_scatter_kernel(const int* __
     for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) {
         int key = sweeps[i];
         key = key < 0 ? 0 : (key > 127 ? 127 : key);
-        const unsigned int pos = base[127 - key] + atomicAdd(&cnt[127 - key], 1u);
+        unsigned int pos = base[127 - key] + atomicAdd(&cnt[127 - key], 1u);
+        // Serpentine: positions are handed out longest-first; every second group of 16 workgroups (128 slots each: four
+        // 32-column or eight 16-column wavefronts) is laid out in reverse, so that neighbouring workgroups -- which the
+        // dispatcher places on the same XCD / CU one after the other -- mix long and short tiles instead of stacking the
+        // longest ones (measured on C2's H side: 494 -> 470 us, tools/probe/cd_order_probe.py; any period from 8 to 128
+        // workgroups gives the same).  Only whole groups of full blocks are reversed: a bijection on the positions.
+        {
+            const unsigned int blk = pos >> 7, grp = blk >> 4;
+            if ((grp & 1u) && (uint64_t)(grp + 1u) * 16u <= (uint64_t)(n >> 7)) pos = (((grp << 4) + 15u - (blk & 15u)) << 7) | (pos & 127u);
+        }
         order[pos] = (int)i;
     }
 }

@@ -208,6 +208,24 @@ __device__ __forceinline__ void rt_glds4(const char* base_uniform, unsigned lane
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1"
                  :: "v"(lane_off), "s"(base_uniform), "s"(lds_addr_uniform) : "memory");
 }
+// The same two copies for use INSIDE the compute loop: no "memory" clobber (the LDS they fill is not read before the next
+// barrier, and a clobber between the batches would pin hipcc's own LDS reads around it), and the partial last piece of a
+// slot copy is predicated inside the asm (a compiler-visible `if` between the batches makes hipcc sink the FMAs and spill).
+__device__ __forceinline__ void rt_glds16_nc(const char* base_uniform, unsigned lane_off, unsigned lds_addr_uniform) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                 :: "v"(lane_off), "s"(base_uniform), "s"(lds_addr_uniform));
+}
+template <int LIMIT>   // lanes with lane_off >= LIMIT do not take part
+__device__ __forceinline__ void rt_glds4_nc(const char* base_uniform, unsigned lane_off, unsigned lds_addr_uniform) {
+    if constexpr (LIMIT >= 256) {
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1"
+                     :: "v"(lane_off), "s"(base_uniform), "s"(lds_addr_uniform));
+    } else {
+        unsigned long long keep;
+        asm volatile("s_mov_b32 m0, %3\n\tv_cmp_gt_u32 vcc, %4, %1\n\ts_and_saveexec_b64 %0, vcc\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b64 exec, %0"
+                     : "=&s"(keep) : "v"(lane_off), "s"(base_uniform), "s"(lds_addr_uniform), "n"(LIMIT) : "vcc");
+    }
+}
 template <int N> __device__ __forceinline__ void rt_wait_vm() {
     static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -318,16 +336,57 @@ __global__ __launch_bounds__(64 * NW) void rhs_tiled_kernel(const T* __restrict_
     const char* sop = reinterpret_cast<const char*>(soffs + slot0);
     const unsigned sl0 = lds0 + 2 * RT_SLAB_BYTES + w * (VB + OB);             // this wave's slot area of stage 0
     char* const slp = rt_slab + 2 * RT_SLAB_BYTES + w * (VB + OB);
-    auto slots_issue = [&](int stage) {
+    auto slots_issue = [&](int stage, int ord /* tile - t0 */) {
         const unsigned dst = sl0 + stage * STAGE;
+        const char* sv = svp + (int64_t)ord * tstride * (int64_t)sizeof(T);
+        const char* so = sop + (int64_t)ord * tstride * 2;
 #pragma unroll
         for (int i = 0; i < NCV; ++i)
-            if (256 * i + 4 * lane < VB) rt_glds4(svp + 256 * i, 4u * lane, dst + 256 * i);
+            if (256 * i + 4 * lane < VB) rt_glds4(sv + 256 * i, 4u * lane, dst + 256 * i);
 #pragma unroll
         for (int i = 0; i < NCO; ++i)          // offsets travel as dwords too (two per lane): sub-dword LDS-DMA pads every lane to a dword
-            if (256 * i + 4 * lane < OB) rt_glds4(sop + 256 * i, 4u * lane, dst + VB + 256 * i);
-        svp += tstride * (int64_t)sizeof(T);
-        sop += tstride * 2;
+            if (256 * i + 4 * lane < OB) rt_glds4(so + 256 * i, 4u * lane, dst + VB + 256 * i);
+    };
+    // The copies of the NEXT tiles are not issued in one burst at the top of a tile (a wave stalls ~100 cycles per LDS-DMA
+    // instruction while the CU's address path is busy with the other waves' bursts): they are spread over the batches of
+    // the compute loop, one piece at a time -- F pieces first, the slot pieces of tile t+2 last, so that "all but the
+    // newest NCV + NCO" at the end of the tile still means "tile t+1 and slots(t+1) have landed".  No guards: past the end
+    // of the partition the same last tile / slots are fetched again (harmless), offsets are clamped into F.
+    constexpr int NPF = CBASE + (CEXTRA > 0 ? 1 : 0);
+    constexpr int NPT = NPF + NCV + NCO;
+    const char* nx_src0 = Fb; unsigned nx_ldst = 0, nx_lim = 0, nx_sdst = 0;
+    const char* nx_sv = svp; const char* nx_so = sop;
+#ifdef RCPPML_EXPERIMENTS
+    const bool nx_slab = !(G.dbg & 2), nx_slots = !(G.dbg & 4);
+#else
+    constexpr bool nx_slab = true, nx_slots = true;
+#endif
+    // piece CBASE exists for the first CEXTRA waves only; the others copy their own last piece once more (same bytes to the
+    // same place) rather than branch
+    const unsigned xpiece = (unsigned)(w < CEXTRA ? CBASE : CBASE - 1) * 1024u;
+    auto issue_piece = [&](auto PI) {
+        constexpr int pi = decltype(PI)::value;
+        if constexpr (pi < NPF) {
+            const unsigned po = pi < CBASE ? (unsigned)pi * 1024u : xpiece;
+            unsigned o = choff + po;
+            o = o < nx_lim ? o : nx_lim;
+#ifdef RCPPML_EXPERIMENTS
+            if (nx_slab)
+#endif
+            rt_glds16_nc(nx_src0, o, nx_ldst + po);
+        } else if constexpr (pi < NPF + NCV) {
+            constexpr int i = pi - NPF;
+#ifdef RCPPML_EXPERIMENTS
+            if (nx_slots)
+#endif
+            rt_glds4_nc<VB - 256 * i>(nx_sv + 256 * i, 4u * lane, nx_sdst + 256 * i);
+        } else {
+            constexpr int i = pi - NPF - NCV;
+#ifdef RCPPML_EXPERIMENTS
+            if (nx_slots)
+#endif
+            rt_glds4_nc<OB - 256 * i>(nx_so + 256 * i, 4u * lane, nx_sdst + VB + 256 * i);
+        }
     };
     // the wave's slots of one stage -> registers (lane 16 g' + i' of block b holds slot (16 b + i') * 4 + g' ... i.e. the
     // lanes read the stream in order: lane l of block b = slot 64 b + l, which is step 16 b + l / 4, lane group l % 4;
@@ -376,6 +435,9 @@ __global__ __launch_bounds__(64 * NW) void rhs_tiled_kernel(const T* __restrict_
                 }
             });
             __builtin_amdgcn_sched_barrier(0);
+            rt_static_for<0, NPT>([&](auto PI) {
+                if constexpr (decltype(PI)::value * NBATCH / NPT == b) issue_piece(PI);
+            });
         });
         // every FMA of this tile is done HERE: without the tie hipcc rotates the tail of the compute phase below the
         // barrier into the next tile, and the extra live ranges spill
@@ -387,8 +449,8 @@ __global__ __launch_bounds__(64 * NW) void rhs_tiled_kernel(const T* __restrict_
 
     if (t0 < t1) {
         slab_load(t0, 0);
-        slots_issue(0);
-        if (t0 + 1 < t1) slots_issue(1);
+        slots_issue(0, 0);
+        slots_issue(1, t0 + 1 < t1 ? 1 : 0);
     }
     rt_wait_vm<0>();
     __builtin_amdgcn_s_barrier();
@@ -400,23 +462,30 @@ __global__ __launch_bounds__(64 * NW) void rhs_tiled_kernel(const T* __restrict_
 #pragma unroll
         for (int b = 0; b < NB; ++b) asm volatile("" : "+v"(cv[b]), "+v"(co[b]));
         rt_wait_lgkm<0>();                         // ... and in registers before their stage is refilled
+        {   // what the compute loop copies meanwhile: tile t+1 -> the other buffer, slots(t+2) -> the stage just read
+            const int tn = t + 1 < t1 ? t + 1 : t1 - 1, ts = t + 2 < t1 ? t + 2 : t1 - 1;
+            const int64_t base = (int64_t)tn * RT_SLAB_BYTES;
+            const int64_t left = fbytes - base;
+            nx_src0 = Fb + base;
+            nx_ldst = lds0 + (buf ^ 1) * RT_SLAB_BYTES + cstart * 1024;
+            nx_lim = (unsigned)(left < RT_SLAB_BYTES ? left : RT_SLAB_BYTES) - 16u;
+            nx_sdst = sl0 + buf * STAGE;
+            nx_sv = svp + (int64_t)(ts - t0) * tstride * (int64_t)sizeof(T);
+            nx_so = sop + (int64_t)(ts - t0) * tstride * 2;
+        }
 #ifdef RCPPML_EXPERIMENTS
-        if (t + 1 < t1 && !(G.dbg & 2)) slab_load(t + 1, buf ^ 1);
-        const bool more = t + 2 < t1 && !(G.dbg & 4);
-        if (more) slots_issue(buf);
         if (!(G.dbg & 1)) compute(cv, co, buf);
+        else rt_static_for<0, NPT>([&](auto PI) { issue_piece(PI); });
 #else
-        if (t + 1 < t1) slab_load(t + 1, buf ^ 1);
-        const bool more = t + 2 < t1;
-        if (more) slots_issue(buf);
         compute(cv, co, buf);
 #endif
-        if (more) rt_wait_vm<NCV + NCO>();         // all but the slot copies just issued: tile t+1 and slots(t+1) have landed
+        if (nx_slots) rt_wait_vm<NCV + NCO>();     // all but the slot copies just issued: tile t+1 and slots(t+1) have landed
         else rt_wait_vm<0>();
         rt_wait_lgkm<0>();
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     }
+    rt_wait_vm<0>();                               // nothing may still be landing in LDS when the workgroup retires
     rt_m0_restore(m0keep);
 
 #pragma unroll

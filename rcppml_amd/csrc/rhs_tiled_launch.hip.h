@@ -44,7 +44,7 @@ inline bool shape_ok(int NV, int S, int NW, int NR, int tsize) {
     if (!s_ok) return false;
     if (NV == 1 && NW == 16) return NR == 2 || NR == 4 || NR == 6 || NR == 8 || ((NR == 10 || NR == 12) && S <= 5);
     if (NV == 1 && NW == 12) return NR == 8 || NR == 12 || (NR == 16 && S <= 6) || (NR == 20 && S <= 4);
-    if (NV == 2 && NW == 16) return NR == 2 || NR == 4 || NR == 6;
+    if (NV == 2 && NW == 16) return NR == 2 || (NR == 4 && S <= 6) || (NR == 6 && S <= 4);   // (beyond: fp32 spills)
     if (NV == 2 && NW == 12) return NR == 4 || NR == 6 || (NR == 8 && S <= 6) || (NR == 10 && S <= 4);
     if (NV == 4 && NW == 16) return NR == 1 || NR == 2 || NR == 3;
     if (NV == 4 && NW == 12) return NR == 2 || NR == 4;
@@ -83,8 +83,9 @@ void launch_tiled_nr(rcppml_hip_ctx* c, const rcppml_rhs_plan* pl, const T* F, c
         if constexpr (S <= 6) { RT_SH(12, 16) }
         if constexpr (S <= 4) { RT_SH(12, 20) }
     } else if constexpr (NV == 2) {
-        RT_SH(16, 2) RT_SH(16, 4) RT_SH(16, 6) RT_SH(12, 4) RT_SH(12, 6)
-        if constexpr (S <= 6) { RT_SH(12, 8) }
+        RT_SH(16, 2) RT_SH(12, 4) RT_SH(12, 6)
+        if constexpr (S <= 6) { RT_SH(16, 4) RT_SH(12, 8) }
+        if constexpr (S <= 4) { RT_SH(16, 6) }
         if constexpr (S <= 4) { RT_SH(12, 10) }
     } else {
         RT_SH(16, 1) RT_SH(16, 2) RT_SH(16, 3) RT_SH(12, 2) RT_SH(12, 4)
