@@ -58,8 +58,8 @@ RCPPML_GPU_API void rcppml_gpu_detect(int* num_gpus, double* total_mem_mb, doubl
  * Laplacians, upper bounds, nonneg, projective and symmetric NMF (MSE path); CD and Cholesky+clip;
  * env RCPPML_GPU_DEVICES=n shards plain MSE fits over n devices (plugin_multi.hip).  Not implemented
  * -- REJECTED with *out_status = -1 so the caller falls back to CPU rather than silently dropping
- * them: classifier guides, dispersion = per_col, zero-inflated losses, k > 256 (k > 64 for IRLS losses,
- * explicit masks, angular and graph penalties).  Target regularisation has no slot in these 73 arguments: see
+ * them: classifier guides, dispersion = per_col, zero-inflated losses, k > 256 (k > 64 for IRLS losses
+ * and explicit masks, k > 128 for angular and graph penalties).  Target regularisation has no slot in these 73 arguments: see
  * rcppml_gpu_nmf_target below. */
 #define RCPPML_NMF_UNIFIED_ARGS                                                                    \
     const int* col_ptr, const int* row_idx, const double* values, int* m, int* n, int* nnz, int* k, \

@@ -1121,40 +1121,41 @@ __global__ __launch_bounds__(256) void scale_rows(T* __restrict__ X, int k, int6
 }
 
 // Graph regularisation (features/graph_reg.hpp:38-50):  G += lambda * (F L) F^T  with FL = F L formed by the SpMM kernel.
-// cross_gram_partial: per block, P[b*k + a] = sum over its columns j of X(a, j) Y(b, j)  (k <= 64; tiles of 32 columns in LDS);
-// cross_gram_axpy: G += lambda * (fixed-order sum of the block partials).
-template <class T>
+// cross_gram_partial: per block, P[b*k + a] = sum over its columns j of X(a, j) Y(b, j)  (k <= KMAX = 64 or 128; tiles of 32
+// columns in LDS); cross_gram_axpy: G += lambda * (fixed-order sum of the block partials).
+template <class T, int KMAX>
 __global__ __launch_bounds__(256) void cross_gram_partial(const T* __restrict__ X, const T* __restrict__ Y, int k, int64_t ncols,
                                                            T* __restrict__ partial) {
-    __shared__ T xs[32 * 64], ys[32 * 64];
+    constexpr int NA = KMAX * KMAX / 256;          // accumulators per thread
+    __shared__ T xs[32 * KMAX], ys[32 * KMAX];
     const int64_t per = (ncols + gridDim.x - 1) / gridDim.x;
     const int64_t c0 = (int64_t)blockIdx.x * per;
     const int64_t c1 = c0 + per < ncols ? c0 + per : ncols;
-    T acc[16];
+    T acc[NA];
 #pragma unroll
-    for (int u = 0; u < 16; ++u) acc[u] = T(0);
+    for (int u = 0; u < NA; ++u) acc[u] = T(0);
     for (int64_t cb = c0; cb < c1; cb += 32) {
         const int nc = (int)(c1 - cb < 32 ? c1 - cb : 32);
         for (int e = threadIdx.x; e < 32 * k; e += 256) {
             const int cc = e / k, f = e % k;
-            xs[cc * 64 + f] = cc < nc ? X[(cb + cc) * (int64_t)k + f] : T(0);
-            ys[cc * 64 + f] = cc < nc ? Y[(cb + cc) * (int64_t)k + f] : T(0);
+            xs[cc * KMAX + f] = cc < nc ? X[(cb + cc) * (int64_t)k + f] : T(0);
+            ys[cc * KMAX + f] = cc < nc ? Y[(cb + cc) * (int64_t)k + f] : T(0);
         }
         __syncthreads();
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
+        for (int u = 0; u < NA; ++u) {
             const int e = threadIdx.x + 256 * u;
             if (e < k * k) {
                 const int a = e % k, b = e / k;
                 T s = acc[u];
-                for (int cc = 0; cc < 32; ++cc) s = tfma(xs[cc * 64 + a], ys[cc * 64 + b], s);
+                for (int cc = 0; cc < 32; ++cc) s = tfma(xs[cc * KMAX + a], ys[cc * KMAX + b], s);
                 acc[u] = s;
             }
         }
         __syncthreads();
     }
 #pragma unroll
-    for (int u = 0; u < 16; ++u) {
+    for (int u = 0; u < NA; ++u) {
         const int e = threadIdx.x + 256 * u;
         if (e < k * k) partial[(int64_t)blockIdx.x * k * k + e] = acc[u];
     }
@@ -1782,7 +1783,7 @@ __global__ void angular_matrix_kernel(const T* __restrict__ Gf, int k, T* __rest
     M[e] = (i == l) ? T(0) : ni * (Gf[(int64_t)l * k + i] * inv_i * inv_l) * inv_l;
 }
 // angular, step 2: x_j <- max(0, x_j - lambda M x_j), one wavefront per column, lane = feature (k <= 64)
-template <class T>
+template <class T, int VPL>   // VPL features per lane: k <= 64 * VPL
 __global__ __launch_bounds__(256) void angular_apply_kernel(T* __restrict__ X, int k, int64_t ncols, const T* __restrict__ M,
                                                             T lambda) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -1792,15 +1793,22 @@ __global__ __launch_bounds__(256) void angular_apply_kernel(T* __restrict__ X, i
     const int lane = threadIdx.x & 63;
     const int64_t wid = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int64_t nw = (int64_t)gridDim.x * 4;
-    const bool fok = lane < k;
-    const int li = fok ? lane : 0;
     for (int64_t j = wid; j < ncols; j += nw) {
-        const T x = fok ? X[j * (int64_t)k + lane] : T(0);
-        T g = T(0);
-        for (int l = 0; l < k; ++l) g = tfma(Ms[l * k + li], __shfl(x, l, 64), g);
-        if (fok) {
-            const T v = x - lambda * g;
-            X[j * (int64_t)k + lane] = v > T(0) ? v : T(0);
+        T x[VPL], g[VPL];
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) { const int f = lane + 64 * v; x[v] = f < k ? X[j * (int64_t)k + f] : T(0); g[v] = T(0); }
+        for (int l = 0; l < k; ++l) {           // features in order: the reference's M x_j accumulation
+            const T xl = __shfl(x[l >> 6], l & 63, 64);
+#pragma unroll
+            for (int v = 0; v < VPL; ++v) { const int f = lane + 64 * v; g[v] = tfma(Ms[l * k + (f < k ? f : 0)], xl, g[v]); }
+        }
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) {
+            const int f = lane + 64 * v;
+            if (f < k) {
+                const T val = x[v] - lambda * g[v];
+                X[j * (int64_t)k + f] = val > T(0) ? val : T(0);
+            }
         }
     }
 }

@@ -73,7 +73,7 @@ extern "C" int rcppml_hip_apply_l21(rcppml_hip_ctx* c, int dtype, void* G, const
 template <class T>
 static void angular_impl(rcppml_hip_ctx* c, int dtype, T* X, int k, int64_t ncols, T lambda) {
     if (!(lambda > T(0)) || ncols <= 0) return;
-    if (k > 64) throw std::runtime_error("angular_posthoc: k > 64 not supported");
+    if (k > 128) throw std::runtime_error("angular_posthoc: k > 128 not supported");
     T* buf = static_cast<T*>(c->scratch(WS_FEAT, ((size_t)2 * k * k + k) * sizeof(T)));
     T* Gf = buf + k;
     T* M = Gf + (size_t)k * k;
@@ -82,8 +82,14 @@ static void angular_impl(rcppml_hip_ctx* c, int dtype, T* X, int k, int64_t ncol
     HIPCHK(hipGetLastError());
     int64_t nblk = (ncols + 3) / 4;
     if (nblk > 8 * (int64_t)c->num_cu) nblk = 8 * c->num_cu;
-    hipLaunchKernelGGL(angular_apply_kernel<T>, dim3((unsigned)nblk), dim3(256), (size_t)k * k * sizeof(T), c->stream, X, k, ncols,
-                       M, lambda);
+    const size_t smem = (size_t)k * k * sizeof(T);          // up to 128 KiB (fp64, k = 128)
+    if (k <= 64) {
+        hipLaunchKernelGGL((angular_apply_kernel<T, 1>), dim3((unsigned)nblk), dim3(256), smem, c->stream, X, k, ncols, M, lambda);
+    } else {
+        static DynSmemOnce once;
+        once.ensure(reinterpret_cast<const void*>(&angular_apply_kernel<T, 2>), smem, c->device);
+        hipLaunchKernelGGL((angular_apply_kernel<T, 2>), dim3((unsigned)nblk), dim3(256), smem, c->stream, X, k, ncols, M, lambda);
+    }
     HIPCHK(hipGetLastError());
 }
 extern "C" int rcppml_hip_angular_posthoc(rcppml_hip_ctx* c, int dtype, void* X, int k, int64_t ncols, double lambda) {
@@ -102,7 +108,7 @@ template <class T>
 static void graph_reg_impl(rcppml_hip_ctx* c, int dtype, T* G, const int* lp, const int* li, const T* lx, const T* X, int k, int64_t ncols,
                            T lambda) {
     if (!(lambda > T(0)) || ncols <= 0) return;
-    if (k > 64) throw std::runtime_error("apply_graph_reg: k > 64 not supported");
+    if (k > 128) throw std::runtime_error("apply_graph_reg: k > 128 not supported");
     int64_t nblk = (ncols + 511) / 512;
     if (nblk > 2 * (int64_t)c->num_cu) nblk = 2 * c->num_cu;
     if (nblk < 1) nblk = 1;
@@ -110,7 +116,8 @@ static void graph_reg_impl(rcppml_hip_ctx* c, int dtype, T* G, const int* lp, co
     T* FL = static_cast<T*>(c->scratch(WS_GRAPH, ((size_t)k * ncols + (size_t)nblk * k * k) * sizeof(T)));
     T* part = FL + (size_t)k * ncols;
     if (rcppml_hip_rhs(c, dtype, lp, li, lx, ncols, X, k, FL) != 0) throw std::runtime_error(rcppml_err());    // FL(:,j) = sum_i L(i,j) X(:,i)
-    hipLaunchKernelGGL(cross_gram_partial<T>, dim3((unsigned)nblk), dim3(256), 0, c->stream, FL, X, k, ncols, part);
+    if (k <= 64) hipLaunchKernelGGL((cross_gram_partial<T, 64>), dim3((unsigned)nblk), dim3(256), 0, c->stream, FL, X, k, ncols, part);
+    else hipLaunchKernelGGL((cross_gram_partial<T, 128>), dim3((unsigned)nblk), dim3(256), 0, c->stream, FL, X, k, ncols, part);
     HIPCHK(hipGetLastError());
     hipLaunchKernelGGL(cross_gram_axpy<T>, dim3((k * k + 255) / 256), dim3(256), 0, c->stream, part, (int)nblk, k * k, lambda, G);
     HIPCHK(hipGetLastError());

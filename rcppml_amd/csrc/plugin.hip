@@ -461,11 +461,11 @@ void nmf_entry(RCPPML_NMF_UNIFIED_ARGS, const int* mask_p, const int* mask_i, do
         }
         if ((*L21_H != 0 || *L21_W != 0 || *ortho_H != 0 || *ortho_W != 0) && (*loss_type != 0 || mask_p))
             throw std::runtime_error("L21 / angular penalties are implemented for the MSE path without explicit mask");
-        if ((*ortho_H != 0 || *ortho_W != 0) && *k > 64) throw std::runtime_error("angular penalty: k must be <= 64");
+        if ((*ortho_H != 0 || *ortho_W != 0) && *k > 128) throw std::runtime_error("angular penalty: k must be <= 128");
         if (*L21_H < 0 || *L21_W < 0 || *ortho_H < 0 || *ortho_W < 0) throw std::runtime_error("negative L21 / angular penalty");
         if (*graph_W_nnz > 0 || *graph_H_nnz > 0) {
             if (*loss_type != 0 || *robust_delta > 0 || mask_p) throw std::runtime_error("graph regularisation: MSE path without explicit mask only");
-            if (*k > 64) throw std::runtime_error("graph regularisation: k must be <= 64");
+            if (*k > 128) throw std::runtime_error("graph regularisation: k must be <= 128");
             if ((*graph_H_nnz > 0 && *graph_H_dim != *n) || (*graph_W_nnz > 0 && *graph_W_dim != *m)) throw std::runtime_error("graph Laplacian dimension mismatch");
         }
         if (*guide_H_count > 0) throw std::runtime_error("classifier guides not supported");
@@ -801,7 +801,7 @@ extern "C" void rcppml_gpu_nmf_zerocopy_double(double* d_col_ptr_addr, double* d
         auto to_ptr = [](double addr) { return reinterpret_cast<void*>(static_cast<uintptr_t>(addr)); };
         if (*loss_type != 0) throw std::runtime_error("zero-copy entry: only the MSE loss is implemented");
         if (*k < 1 || *k > 256) throw std::runtime_error("k must be in [1,256]");
-        if ((*ortho_H != 0 || *ortho_W != 0) && *k > 64) throw std::runtime_error("angular penalty: k must be <= 64");
+        if ((*ortho_H != 0 || *ortho_W != 0) && *k > 128) throw std::runtime_error("angular penalty: k must be <= 128");
         if (*m < 1 || *n < 1) throw std::runtime_error("empty matrix");
         if (*norm_type < 0 || *norm_type > 2) throw std::runtime_error("bad norm_type");
         FitParams P;
@@ -854,7 +854,7 @@ void nmf_dense_entry(RCPPML_NMF_DENSE_ARGS, int precision) {
         if (*symmetric != 0 && *m != *n) throw std::runtime_error("symmetric NMF needs a square matrix");
         if (*solver_mode != 0 && *solver_mode != 1) throw std::runtime_error("solver_mode must be 0 (CD) or 1 (Cholesky+clip)");
         if (*k < 1 || *k > 128) throw std::runtime_error("k must be in [1,128]");
-        if ((*ortho_H != 0 || *ortho_W != 0) && *k > 64) throw std::runtime_error("angular penalty: k must be <= 64");
+        if ((*ortho_H != 0 || *ortho_W != 0) && *k > 128) throw std::runtime_error("angular penalty: k must be <= 128");
         if (*L21_H < 0 || *L21_W < 0 || *ortho_H < 0 || *ortho_W < 0) throw std::runtime_error("negative L21 / angular penalty");
         if (*m < 1 || *n < 1) throw std::runtime_error("empty matrix");
         if (*norm_type < 0 || *norm_type > 2) throw std::runtime_error("bad norm_type");

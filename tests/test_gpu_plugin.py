@@ -360,6 +360,25 @@ def test_l21_and_angular_features(abi, entry, tol_loss, tol_fac):
     assert abs(pen.loss - base.loss) > 1e-3 * abs(base.loss)
 
 
+@pytest.mark.parametrize("k", [65, 100, 128])
+def test_features_at_ranks_above_64(abi, k):
+    """L21, angular and graph-Laplacian features for 64 < k <= 128 (two features per lane in the angular kernel, 128-wide
+    tiles in the cross-Gram of the graph term), fp64 entry vs the oracle fit; k = 129 with these features is rejected."""
+    A = lowrank_csc(300, 420, 9, 0.12, seed=k)
+    W0, H0 = O.init_factors(21, k, A.rows, A.cols, np.float64)
+    LW, LH = _ring_laplacian(A.rows, 1), _ring_laplacian(A.cols, 2, hops=3)
+    ref = O.nmf_fit(A, W0, H0, np.float64, max_iter=4, tol=0.0, solver_mode=0, L21=(0.02, 0.04), angular=(0.01, 0.02),
+                    graph_W=(LW, 0.03), graph_H=(LH, 0.02))
+    res = _run_gpu(abi, A, W0, H0, "double", max_iter=4, tol=0.0, solver_mode=0, L21_W=0.02, L21_H=0.04, ortho_W=0.01, ortho_H=0.02,
+                   graph_W=(LW.p, LW.i, LW.x, 0.03), graph_H=(LH.p, LH.i, LH.x, 0.02))
+    _compare(res, ref, 1e-6, 1e-6)
+    if k == 128:
+        W1, H1 = O.init_factors(21, 129, A.rows, A.cols, np.float64)
+        for kw in (dict(ortho_H=0.02), dict(graph_W=(LW.p, LW.i, LW.x, 0.03))):
+            r = abi.nmf_unified(A.p, A.i, A.x, A.rows, A.cols, 129, W1.copy(), H1.copy(), entry="double", max_iter=2, **kw)
+            assert r["status"] == -1 and "128" in r["error"], kw
+
+
 @pytest.mark.parametrize("entry,tol_loss,tol_fac", [("double", 1e-6, 1e-6), ("float", 5e-4, 5e-3)])
 def test_symmetric_nmf(abi, entry, tol_loss, tol_fac):
     """symmetric = TRUE (A ~ W diag(d) W^T, fit_cpu.hpp:659-704): H is never solved, W is solved against its own Gram and
