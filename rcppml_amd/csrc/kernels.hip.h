@@ -1119,6 +1119,24 @@ __global__ __launch_bounds__(256) void scale_rows(T* __restrict__ X, int k, int6
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride)
         X[e] = X[e] / d[e % k];
 }
+// scaling_finalize + scale_rows in one launch (norm_type 0 / 1): every thread forms d_f from the row sums exactly as
+// scaling_finalize does, block 0 also stores d
+template <class T>
+__global__ __launch_bounds__(256) void scale_rows_from_sums(T* __restrict__ X, int k, int64_t total, const T* __restrict__ sums,
+                                                            int norm_type, T* __restrict__ d) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    if (blockIdx.x == 0)
+        for (int f = threadIdx.x; f < k; f += blockDim.x) {
+            T s = sums[f];
+            if (norm_type == 1) s = sqrt(s);
+            d[f] = s + T(1e-15);
+        }
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+        T s = sums[e % k];
+        if (norm_type == 1) s = sqrt(s);
+        X[e] = X[e] / (s + T(1e-15));
+    }
+}
 
 // Graph regularisation (features/graph_reg.hpp:38-50):  G += lambda * (F L) F^T  with FL = F L formed by the SpMM kernel.
 // cross_gram_partial: per block, P[b*k + a] = sum over its columns j of X(a, j) Y(b, j)  (k <= KMAX = 64 or 128; tiles of 32

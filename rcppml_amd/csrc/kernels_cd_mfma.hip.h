@@ -33,24 +33,27 @@ namespace rk {
 // Gq[((i/2)*RT + rt)*64 + (i&1)*32 + r'] = -G(lrow, i), lrow = 32*rt + 2*v + h, h = (r'>>2)&1, v = (r'&3) + 4*(r'>>3).
 // tab[c] (c = coordinate; pair i = c & ~1 is served by lane half h = c & 1) = { 1/G(c,c) (0 if G(c,c) <= 0),
 //   coupling inside the pair: h ? G(i+1, i) : 0 }.
-// Gp: padded KP x KP Gram (identity padding), column i contiguous; invd from pad_gram.
-static __global__ void cd_mfma_prep_kernel(const float* __restrict__ Gp, const float* __restrict__ invd, int KP,
+// Reads the k x k Gram directly; the identity padding to KP and 1/G_ii (pad_gram's job for the other variants) are formed
+// on the fly -- one kernel boundary less per solve.
+static __global__ void cd_mfma_prep_kernel(const float* __restrict__ G, int k, int KP,
                                            float* __restrict__ Gq, float2* __restrict__ tab) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= KP * KP) return;
+    auto gp = [&](int col, int row) { return (row < k && col < k) ? G[(int64_t)col * k + row] : (row == col ? 1.f : 0.f); };
     const int i = e / KP, p = e % KP;
     const int rt = p >> 5, r = p & 31;
     const int h = (r >> 2) & 1, v = (r & 3) + 4 * (r >> 3);
     const int lrow = 32 * rt + 2 * v + h;
     // pair-major layout: 64 consecutive floats = one MFMA A operand (both halves of a wave) of pair i/2 and row
     // tile rt, so every LDS read of the sweep is  <one base register> + <compile-time multiple of 256 bytes>
-    Gq[(((i >> 1) * (KP >> 5) + rt) << 6) + ((i & 1) << 5) + r] = -Gp[i * KP + lrow];
+    Gq[(((i >> 1) * (KP >> 5) + rt) << 6) + ((i & 1) << 5) + r] = -gp(i, lrow);
     if (p == 0) {
         // the high half (odd coordinate) reads its Gauss-Seidel coupling, the low half reads 0, so ONE evaluation
         // of the second step serves both halves
         float2 t;
-        t.x = invd[i];
-        t.y = (i & 1) ? Gp[(i - 1) * KP + i] : 0.f;
+        const float gd = gp(i, i);
+        t.x = gd > 0.f ? 1.f / gd : 0.f;
+        t.y = (i & 1) ? gp(i - 1, i) : 0.f;
         tab[i] = t;
     }
 }

@@ -34,24 +34,27 @@ template <class T> struct Vec4T;
 template <> struct Vec4T<float> { typedef float4 type; };
 template <> struct Vec4T<double> { typedef double4 type; };
 template <class T>
-static __global__ void cd_mfma64_prep_kernel(const T* __restrict__ Gp, const T* __restrict__ invd, int KP,
+static __global__ void cd_mfma64_prep_kernel(const T* __restrict__ G, int k, int KP,
                                              T* __restrict__ Gq, typename Vec4T<T>::type* __restrict__ tab) {
     constexpr bool PERM = sizeof(T) == 4;
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= KP * KP) return;
+    // the k x k Gram is read directly: identity padding to KP and 1/G_cc formed here (no pad_gram launch in front)
+    auto gp = [&](int col, int row) { return (row < k && col < k) ? G[(int64_t)col * k + row] : (row == col ? T(1) : T(0)); };
     const int i = e / KP, r = e % KP;
     const int NT = KP >> 4;
     const int q = i >> 2, kk = i & 3, t = r >> 4, rl = r & 15;
     // physical row slot of logical row rl inside its tile
     const int ps = PERM ? 4 * (rl & 3) + (rl >> 2) : rl;
-    Gq[((q * NT + t) << 6) + (kk << 4) + ps] = -Gp[i * KP + r];
+    Gq[((q * NT + t) << 6) + (kk << 4) + ps] = -gp(i, r);
     if (r == 0) {
         const int c = i, g = c & 3, qb = c & ~3;
         typename Vec4T<T>::type v;
-        v.x = invd[c];
-        v.y = g > 0 ? Gp[(qb + 0) * KP + c] : T(0);
-        v.z = g > 1 ? Gp[(qb + 1) * KP + c] : T(0);
-        v.w = g > 2 ? Gp[(qb + 2) * KP + c] : T(0);
+        const T gd = gp(c, c);
+        v.x = gd > T(0) ? T(1) / gd : T(0);
+        v.y = g > 0 ? gp(qb + 0, c) : T(0);
+        v.z = g > 1 ? gp(qb + 1, c) : T(0);
+        v.w = g > 2 ? gp(qb + 2, c) : T(0);
         tab[c] = v;
     }
 }

@@ -37,14 +37,16 @@ extern "C" int rcppml_hip_row_norms(rcppml_hip_ctx* c, int dtype, const void* X,
 }
 template <class T>
 static void apply_scaling_impl(rcppml_hip_ctx* c, T* X, int k, int64_t ncols, int norm_type, const T* sums, T* d) {
-    hipLaunchKernelGGL(scaling_finalize<T>, dim3((k + 63) / 64), dim3(64), 0, c->stream, sums, k, norm_type, d);
-    HIPCHK(hipGetLastError());
-    if (norm_type == 2) return;
     const int64_t total = (int64_t)k * ncols;
+    if (norm_type == 2 || total <= 0) {          // no scaling (d = 1), or only d wanted (the sharded loop's d from the global sums)
+        hipLaunchKernelGGL(scaling_finalize<T>, dim3((k + 63) / 64), dim3(64), 0, c->stream, sums, k, norm_type, d);
+        HIPCHK(hipGetLastError());
+        return;
+    }
     int64_t nblk = (total + 255) / 256;
     if (nblk > 8 * (int64_t)c->num_cu) nblk = 8 * c->num_cu;
     if (nblk < 1) nblk = 1;
-    hipLaunchKernelGGL(scale_rows<T>, dim3((unsigned)nblk), dim3(256), 0, c->stream, X, k, total, d);
+    hipLaunchKernelGGL(scale_rows_from_sums<T>, dim3((unsigned)nblk), dim3(256), 0, c->stream, X, k, total, sums, norm_type, d);
     HIPCHK(hipGetLastError());
 }
 // ----------------------------------------------------------------------------

@@ -59,13 +59,13 @@ static void cd_group_launch(rcppml_hip_ctx* c, const T* Gp, const T* invd, const
 
 // MFMA variant (fp32, k <= 128): rank-1 residual updates on the matrix cores, 32*CT columns per wave.
 template <int RT, int CT>
-static void cd_mfma_launch(rcppml_hip_ctx* c, const float* Gp, const float* invd, const float* B, float* X, int k,
+static void cd_mfma_launch(rcppml_hip_ctx* c, const float* G, const float* /*unused*/, const float* B, float* X, int k,
                            int64_t ncols, float l1_pre, int warm, int zero_init, float l1_cd, float l2_cd, int nonneg,
                            int maxit, float tol, float ub_cd, float ub_post, int* sweeps, const int* order) {
     constexpr int KP = 32 * RT;
     float* Gq = static_cast<float*>(c->scratch(WS_MFMA, ((size_t)KP * KP + 2 * KP) * sizeof(float)));
     float2* tab = reinterpret_cast<float2*>(Gq + (size_t)KP * KP);
-    hipLaunchKernelGGL(cd_mfma_prep_kernel, dim3((KP * KP + 255) / 256), dim3(256), 0, c->stream, Gp, invd, KP, Gq, tab);
+    hipLaunchKernelGGL(cd_mfma_prep_kernel, dim3((KP * KP + 255) / 256), dim3(256), 0, c->stream, G, k, KP, Gq, tab);
     HIPCHK(hipGetLastError());
     size_t smem = ((size_t)KP * KP + 2 * KP) * sizeof(float);
     const int64_t per_block = 4 * 32 * CT;          // 4 waves per block
@@ -101,14 +101,14 @@ static void cd_mfma_launch(rcppml_hip_ctx* c, const float* Gp, const float* invd
 
 // 16-column MFMA variant: v_mfma_f64_16x16x4_f64 (k <= 128) / v_mfma_f32_16x16x4_f32 (k <= 64), four coordinates per instruction.
 template <class T, int NT>
-static void cd_mfma64_launch(rcppml_hip_ctx* c, const T* Gp, const T* invd, const T* B, T* X, int k,
+static void cd_mfma64_launch(rcppml_hip_ctx* c, const T* G, const T* /*unused*/, const T* B, T* X, int k,
                              int64_t ncols, T l1_pre, int warm, int zero_init, T l1_cd, T l2_cd, int nonneg,
                              int maxit, T tol, T ub_cd, T ub_post, int* sweeps, const int* order) {
     constexpr int KP = 16 * NT;
     typedef typename Vec4T<T>::type Tab4;
     T* Gq = static_cast<T*>(c->scratch(WS_MFMA, ((size_t)KP * KP + 4 * KP) * sizeof(T)));
     Tab4* tab = reinterpret_cast<Tab4*>(Gq + (size_t)KP * KP);
-    hipLaunchKernelGGL(cd_mfma64_prep_kernel<T>, dim3((KP * KP + 255) / 256), dim3(256), 0, c->stream, Gp, invd, KP, Gq, tab);
+    hipLaunchKernelGGL(cd_mfma64_prep_kernel<T>, dim3((KP * KP + 255) / 256), dim3(256), 0, c->stream, G, k, KP, Gq, tab);
     HIPCHK(hipGetLastError());
     const size_t smem = ((size_t)KP * KP + 4 * KP) * sizeof(T);
     const int64_t nblk = (ncols + 63) / 64;          // 4 waves x 16 columns per block
@@ -181,8 +181,9 @@ static void solve_cd_impl(rcppml_hip_ctx* c, const T* G, const T* B, T* X, int k
     if (variant == RCPPML_CD_LANE && KP > lane_max) variant = RCPPML_CD_GROUP;
     if (variant != RCPPML_CD_LANE && variant != RCPPML_CD_WAVE && variant != RCPPML_CD_MFMA && variant != RCPPML_CD_MFMA16) variant = RCPPML_CD_GROUP;
     if (variant == RCPPML_CD_WAVE && KP < 64) KP = 64;   // the wave variant pads to a full 64-lane slab
-    T *Gp, *invd;
-    pad_impl<T>(c, G, k, KP, &Gp, &invd);
+    // the MFMA variants read the k x k Gram themselves (their prep kernels pad it); the others take pad_gram's copy
+    T *Gp = const_cast<T*>(G), *invd = nullptr;
+    if (variant != RCPPML_CD_MFMA && variant != RCPPML_CD_MFMA16) pad_impl<T>(c, G, k, KP, &Gp, &invd);
 #define CD_ARGS c, Gp, invd, B, X, k, ncols, l1_pre, warm, zero_init, l1_cd, l2_cd, nonneg, maxit, tol, ub_cd, ub_post, sweeps, order
     if (variant == RCPPML_CD_LANE) {
         switch (KP) {
