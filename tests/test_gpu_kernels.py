@@ -347,3 +347,37 @@ def test_apply_graph_reg(env, dtype, k, dim):
     dG2 = _dev(torch, G0)
     ctx.apply_graph_reg(_dt(_abi, dtype), dG2, lp, li, lx, _dev(torch, X), k, dim, 0.0)
     assert np.array_equal(dG2.cpu().numpy(), G0)
+
+
+@pytest.mark.parametrize("n", [1, 127, 2048, 2049, 5000, 40001])
+def test_order_columns_permutation_and_order_invariance(env, n):
+    """rcppml_hip_order_columns: the work order is a permutation of the columns, longest-first up to the serpentine
+    layout (every group of 16 x 128 slots holds exactly the columns the descending sort puts there), and the CD kernels
+    (32- and 16-column MFMA tiles) return bit-identical solutions with and without it -- columns are independent
+    (reference nnls_batch.hpp:70-132 solves them one by one)."""
+    torch, _abi, ctx = env
+    rs = np.random.default_rng(n)
+    sw = rs.integers(0, 140, size=n).astype(np.int32)            # counts above 127 share the last bin
+    d_sw = _dev(torch, sw)
+    d_order = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+    ctx.order_columns(d_sw, n, d_order)
+    order = d_order.cpu().numpy()
+    assert np.array_equal(np.sort(order), np.arange(n))
+    key = np.minimum(sw, 127)
+    want = np.sort(key)[::-1]
+    got = key[order]
+    for g0 in range(0, n, 2048):
+        assert np.array_equal(np.sort(got[g0:g0 + 2048]), np.sort(want[g0:g0 + 2048])), g0
+    assert np.all(np.diff(got[:128]) <= 0)                        # inside a block: still descending
+    k = 24
+    Fm = rs.uniform(size=(4 * k, k))
+    G = (Fm.T @ Fm).astype(np.float32)
+    B = (rs.standard_normal((n, k)) * 2 + 1).astype(np.float32)
+    for variant in (_abi.CD_MFMA, _abi.CD_MFMA16):
+        outs = []
+        for use in (False, True):
+            dX = torch.zeros((n, k), dtype=torch.float32, device="cuda")
+            ctx.solve_cd(_abi.F32, _dev(torch, G), _dev(torch, B), dX, k, n, zero_init=1, maxit=30, tol=1e-6, variant=variant,
+                           col_order=d_order if use else None)
+            outs.append(dX.cpu().numpy())
+        assert np.array_equal(outs[0], outs[1]), variant
