@@ -84,7 +84,7 @@ RCPPML_GPU_API void rcppml_gpu_detect(int* num_gpus, double* total_mem_mb, doubl
  * entropy-decodes it ON THE DEVICE (one wavefront per rANS stream) and returns device pointers to int32 col_ptr (n+1),
  * int32 row_idx (nnz) and double values (nnz) -- the arrays rcppml_gpu_nmf_zerocopy_double takes -- with the addresses
  * stored in doubles (R has no 64-bit integer).  out_status: 0 ok, 1 cannot open, 2 short read, 3 file too small,
- * 4 not a v2 file, 5 decode error (incl. row-sorted files: the stored row permutation is not applied by this build).
+ * 4 not a v2 file, 5 decode error.  Row-sorted files: the stored row permutation is applied as the reference decoder applies it.
  * The caller releases the three arrays with rcppml_sp_free_gpu, which also zeroes the addresses. */
 RCPPML_GPU_API void rcppml_sp_read_gpu(const char** path_ptr, int* device_id, double* out_col_ptr_addr,
                                        double* out_row_idx_addr, double* out_values_addr, int* out_m, int* out_n,

@@ -530,7 +530,7 @@ def spz_lib():
 
 
 def spz_info(buf):
-    """(status, m, n, nnz, value_type) of a .spz v2 byte stream (uint8 array).  status 5 = row-sorted file."""
+    """(status, m, n, nnz, value_type) of a .spz v2 byte stream (uint8 array)."""
     buf = np.ascontiguousarray(buf, np.uint8)
     m, n, nnz, vt = C.c_uint32(), C.c_uint32(), C.c_uint64(), C.c_int()
     st = spz_lib().oracle_spz_info(buf.ctypes.data_as(C.c_void_p), C.c_uint64(buf.size), C.byref(m), C.byref(n), C.byref(nnz), C.byref(vt))

@@ -45,4 +45,19 @@ __attribute__((visibility("default"))) uint64_t ref_spz_encode(uint32_t m, uint3
         return buf.size();
     } catch (...) { return 0; }
 }
+// the same with the encoder's row_sort option (rows renumbered by descending nonzero count, permutation in the metadata)
+__attribute__((visibility("default"))) uint64_t ref_spz_encode_rowsort(uint32_t m, uint32_t n, uint64_t nnz, const uint32_t* p,
+                                                                       const uint32_t* i, const double* x, const char* precision,
+                                                                       uint32_t chunk_cols, uint8_t* out, uint64_t cap) {
+    try {
+        CSCMatrix M(m, n, nnz);
+        std::memcpy(M.p.data(), p, sizeof(uint32_t) * (n + 1));
+        std::memcpy(M.i.data(), i, sizeof(uint32_t) * nnz);
+        std::memcpy(M.x.data(), x, sizeof(double) * nnz);
+        v2::CompressConfig_v2 cfg; cfg.precision = precision; cfg.chunk_cols = chunk_cols; cfg.row_sort = true;
+        std::vector<uint8_t> buf = v2::compress_v2(M, cfg);
+        if (out && buf.size() <= cap) std::memcpy(out, buf.data(), buf.size());
+        return buf.size();
+    } catch (...) { return 0; }
+}
 }

@@ -9,7 +9,7 @@
 //   rANS + escape block       streampress/sparsepress_v2.hpp:404-439
 //   byte-shuffled floats      streampress/sparsepress_v2.hpp:442-476
 //   chunk loop                streampress/sparsepress_v2.hpp:897-1090 (no partial reads; row permutation NOT restated:
-//                             files with row_sorted = 1 are rejected)
+//                             row-sorted files: the stored permutation is applied to the decoded rows)
 #include <cstdint>
 #include <cstring>
 #include <vector>
@@ -96,13 +96,13 @@ inline float half_to_float(uint16_t h) {   // IEEE 754 binary16 -> binary32 (for
 }
 }  // namespace
 
-// 0 = ok; 1 = too small / bad magic / not v2; 3 = truncated; 5 = row-sorted file (permutation not restated)
+// 0 = ok; 1 = too small / bad magic / not v2; 3 = truncated
 SPZ_API int oracle_spz_info(const uint8_t* data, uint64_t size, uint32_t* m, uint32_t* n, uint64_t* nnz, int* value_type) {
     if (size < 128 || std::memcmp(data, "SPRZ", 4) != 0) return 1;
     Hdr h; std::memcpy(&h, data, 128);
     if (h.version != 2) return 1;
     *m = h.m; *n = h.n; *nnz = h.nnz; *value_type = h.value_type;
-    return h.row_sorted ? 5 : 0;
+    return 0;
 }
 SPZ_API int oracle_spz_decode(const uint8_t* data, uint64_t size, uint32_t* P, uint32_t* I, double* X) {
     uint32_t m, n; uint64_t nnz; int vt;
@@ -148,5 +148,28 @@ SPZ_API int oracle_spz_decode(const uint8_t* data, uint64_t size, uint32_t* P, u
         out += d.nnz;
     }
     P[n] = (uint32_t)nnz;
+    // Row-sorted files: undo the permutation (sparsepress_v2.hpp:1089-1103).  Metadata section (header_v2.hpp:405-457): u32
+    // entry count, then {u8 key, u32 length, bytes} per entry, ending 16 bytes (the footer) before the end of the file;
+    // key 2 = ROW_PERMUTATION (u32 array); every decoded row r < perm.size() becomes perm[r].
+    if (h.row_sorted && h.metadata_offset > 0 && h.metadata_offset < size && size >= 16 + h.metadata_offset) {
+        const uint8_t* p = data + h.metadata_offset;
+        const uint8_t* end = data + size - 16;
+        if (end - p >= 4) {
+            const uint32_t ne = rd32(p); p += 4;
+            for (uint32_t e = 0; e < ne && p < end; ++e) {
+                const uint8_t key = *p++;
+                if (end - p < 4) break;
+                const uint32_t len = rd32(p); p += 4;
+                if ((uint64_t)(end - p) < len) break;
+                if (key == 2) {
+                    const uint32_t cnt = len / 4;
+                    for (uint64_t q = 0; q < nnz; ++q)
+                        if (I[q] < cnt) I[q] = rd32(p + 4 * (size_t)I[q]);
+                    break;
+                }
+                p += len;
+            }
+        }
+    }
     return 0;
 }

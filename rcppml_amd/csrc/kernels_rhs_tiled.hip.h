@@ -226,6 +226,20 @@ __device__ __forceinline__ void rt_glds4_nc(const char* base_uniform, unsigned l
                      : "=&s"(keep) : "v"(lane_off), "s"(base_uniform), "s"(lds_addr_uniform), "n"(LIMIT) : "vcc");
     }
 }
+#ifdef RCPPML_EXPERIMENTS
+// probe build: the same copies with a RUN-TIME lane limit (0 = nobody takes part), so that the ablation switches of
+// profiles/ablate_rhs_tiled.sh need no branch between the batches either
+__device__ __forceinline__ void rt_glds16_rt(const char* base_uniform, unsigned lane_off, unsigned lds_addr_uniform, unsigned limit) {
+    unsigned long long keep;
+    asm volatile("s_mov_b32 m0, %3\n\tv_cmp_gt_u32 vcc, %4, %1\n\ts_and_saveexec_b64 %0, vcc\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b64 exec, %0"
+                 : "=&s"(keep) : "v"(lane_off), "s"(base_uniform), "s"(lds_addr_uniform), "s"(limit) : "vcc");
+}
+__device__ __forceinline__ void rt_glds4_rt(const char* base_uniform, unsigned lane_off, unsigned lds_addr_uniform, unsigned limit) {
+    unsigned long long keep;
+    asm volatile("s_mov_b32 m0, %3\n\tv_cmp_gt_u32 vcc, %4, %1\n\ts_and_saveexec_b64 %0, vcc\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b64 exec, %0"
+                 : "=&s"(keep) : "v"(lane_off), "s"(base_uniform), "s"(lds_addr_uniform), "s"(limit) : "vcc");
+}
+#endif
 template <int N> __device__ __forceinline__ void rt_wait_vm() {
     static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -371,21 +385,24 @@ __global__ __launch_bounds__(64 * NW) void rhs_tiled_kernel(const T* __restrict_
             unsigned o = choff + po;
             o = o < nx_lim ? o : nx_lim;
 #ifdef RCPPML_EXPERIMENTS
-            if (nx_slab)
-#endif
+            rt_glds16_rt(nx_src0, o, nx_ldst + po, nx_slab ? 0xffffffffu : 0u);     // ablation switch without a branch
+#else
             rt_glds16_nc(nx_src0, o, nx_ldst + po);
+#endif
         } else if constexpr (pi < NPF + NCV) {
             constexpr int i = pi - NPF;
 #ifdef RCPPML_EXPERIMENTS
-            if (nx_slots)
-#endif
+            rt_glds4_rt(nx_sv + 256 * i, 4u * lane, nx_sdst + 256 * i, nx_slots ? (unsigned)(VB - 256 * i) : 0u);
+#else
             rt_glds4_nc<VB - 256 * i>(nx_sv + 256 * i, 4u * lane, nx_sdst + 256 * i);
+#endif
         } else {
             constexpr int i = pi - NPF - NCV;
 #ifdef RCPPML_EXPERIMENTS
-            if (nx_slots)
-#endif
+            rt_glds4_rt(nx_so + 256 * i, 4u * lane, nx_sdst + VB + 256 * i, nx_slots ? (unsigned)(OB - 256 * i) : 0u);
+#else
             rt_glds4_nc<OB - 256 * i>(nx_so + 256 * i, 4u * lane, nx_sdst + VB + 256 * i);
+#endif
         }
     };
     // the wave's slots of one stage -> registers (lane 16 g' + i' of block b holds slot (16 b + i') * 4 + g' ... i.e. the
@@ -454,14 +471,16 @@ __global__ __launch_bounds__(64 * NW) void rhs_tiled_kernel(const T* __restrict_
     }
     rt_wait_vm<0>();
     __builtin_amdgcn_s_barrier();
+    T cv[NB];
+    unsigned co[NB];
+    if (t0 < t1) slots_read(0, cv, co);
     for (int t = t0; t < t1; ++t) {
         const int buf = (t - t0) & 1;
-        T cv[NB];
-        unsigned co[NB];
-        slots_read(buf, cv, co);                   // slots(t): landed (waited for at the end of the previous tile)
+        // slots(t) were requested from the ring at the end of the previous tile (this wave's own LDS-DMA data, complete by
+        // its vmcnt wait), so their LDS latency ran under the barrier; they must be in registers before their stage is refilled
 #pragma unroll
         for (int b = 0; b < NB; ++b) asm volatile("" : "+v"(cv[b]), "+v"(co[b]));
-        rt_wait_lgkm<0>();                         // ... and in registers before their stage is refilled
+        rt_wait_lgkm<0>();
         {   // what the compute loop copies meanwhile: tile t+1 -> the other buffer, slots(t+2) -> the stage just read
             const int tn = t + 1 < t1 ? t + 1 : t1 - 1, ts = t + 2 < t1 ? t + 2 : t1 - 1;
             const int64_t base = (int64_t)tn * RT_SLAB_BYTES;
@@ -479,9 +498,8 @@ __global__ __launch_bounds__(64 * NW) void rhs_tiled_kernel(const T* __restrict_
 #else
         compute(cv, co, buf);
 #endif
-        if (nx_slots) rt_wait_vm<NCV + NCO>();     // all but the slot copies just issued: tile t+1 and slots(t+1) have landed
-        else rt_wait_vm<0>();
-        rt_wait_lgkm<0>();
+        rt_wait_vm<NCV + NCO>();                   // all but the slot copies just issued: tile t+1 and slots(t+1) have landed
+        slots_read(buf ^ 1, cv, co);               // slots(t+1) (past the last tile: a harmless re-read)
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     }

@@ -269,6 +269,15 @@ __global__ __launch_bounds__(256) void spz_float_kernel(const uint8_t* __restric
 
 // rows of a decoded matrix must lie in [0, m): a malformed gap stream would otherwise send the transpose's histogram
 // (atomicAdd on counts[row]) out of bounds in the zero-copy fit
+// undo the row sort of a row-sorted file: i[k] = perm[i[k]] for i[k] < perm_len (sparsepress_v2.hpp:1098-1102)
+__global__ __launch_bounds__(256) void spz_unpermute_rows_kernel(int* __restrict__ rows, int64_t nnz, const uint32_t* __restrict__ perm,
+                                                                 uint32_t perm_len) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t < nnz) {
+        const uint32_t r = (uint32_t)rows[t];
+        if (r < perm_len) rows[t] = (int)perm[r];
+    }
+}
 __global__ __launch_bounds__(256) void spz_check_rows_kernel(const int* __restrict__ rows, int64_t nnz, int m, int* __restrict__ bad) {
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (t < nnz) {
@@ -281,7 +290,32 @@ __global__ __launch_bounds__(256) void spz_check_rows_kernel(const int* __restri
 // (identical for well-formed files; they differ only when a chunk's count section is garbage -- the reference encoder
 // omits its size prefix for chunks without nonzeros, sparsepress_v2.hpp:94 vs :988-991 -- and then seg_ptr keeps the
 // prefix-sum kernel inside the chunk)
-struct SpzParsed { SpzHeader h; std::vector<int> col_ptr, seg_ptr; std::vector<SpzJob> jobs; uint32_t bpv = 0; };
+// row_perm: the stored row permutation of a row-sorted file (metadata entry ROW_PERMUTATION, header_v2.hpp:107-112,
+// :347-359); the reference decoder maps every decoded row through it, i[k] = perm[i[k]] where i[k] < perm.size()
+// (sparsepress_v2.hpp:1089-1103) -- rows then need not ascend inside a column any more
+struct SpzParsed { SpzHeader h; std::vector<int> col_ptr, seg_ptr; std::vector<SpzJob> jobs; uint32_t bpv = 0; std::vector<uint32_t> row_perm; };
+
+// Metadata section: u32 entry count, then per entry {u8 key, u32 length, bytes} (header_v2.hpp:405-457); it ends 16 bytes
+// (the footer) before the end of the file (sparsepress_v2.hpp:1089-1091).  Returns the FIRST row permutation, as the
+// reference's getter does; a file that is flagged row_sorted but carries none decodes unpermuted (:1094).
+std::vector<uint32_t> read_row_permutation(const uint8_t* data, uint64_t size, const SpzHeader& h) {
+    std::vector<uint32_t> perm;
+    if (!(h.metadata_offset > 0 && h.metadata_offset < size)) return perm;
+    if (size < 16 + h.metadata_offset) return perm;                       // (the reference's size_t difference would wrap here)
+    const uint8_t* p = data + h.metadata_offset;
+    const uint8_t* end = data + size - 16;
+    if (end - p < 4) return perm;
+    const uint32_t n = rd32(p); p += 4;
+    for (uint32_t e = 0; e < n && p < end; ++e) {
+        const uint8_t key = *p++;
+        if (end - p < 4) break;
+        const uint32_t len = rd32(p); p += 4;
+        if ((uint64_t)(end - p) < len) break;
+        if (key == 2) { perm.resize(len / 4); if (len / 4) std::memcpy(perm.data(), p, (size_t)(len / 4) * 4); return perm; }
+        p += len;
+    }
+    return perm;
+}
 
 int check_header(const uint8_t* data, uint64_t size, SpzHeader& h) {
     if (size < 6) return 3;                                                  // sp_gpu_bridge.cu:69-73
@@ -297,7 +331,7 @@ SpzParsed parse_file(const uint8_t* data, uint64_t size) {
     const int st = check_header(data, size, P.h);
     if (st) throw ParseError{st, "not a v2 .spz file"};
     const SpzHeader& h = P.h;
-    if (h.row_sorted) throw ParseError{5, "row-sorted .spz files (stored row permutation) are not supported"};
+    if (h.row_sorted) P.row_perm = read_row_permutation(data, size, h);
     if (h.nnz > 0x7FFFFFFFull || h.n > 0x7FFFFFFEu || h.m > 0x7FFFFFFFu) throw ParseError{5, "matrix too large for int32 CSC indices"};
     if (!in_file(size, h.chunk_index_offset, (uint64_t)h.num_chunks * 48)) throw ParseError{5, "truncated chunk index"};   // sparsepress_v2.hpp:913-914
     if (h.data_offset > size) throw ParseError{5, "data section beyond end of file"};
@@ -390,6 +424,14 @@ void decode_to_device(rcppml_hip_ctx* c, const uint8_t* data, uint64_t size, con
         hipLaunchKernelGGL(spz_float_kernel, dim3((unsigned)((h.nnz + 255) / 256)), dim3(256), 0, s, d_raw, (int64_t)h.nnz, (int)P.bpv, d_values);
         HIPCHK(hipGetLastError());
     }
+    if (!P.row_perm.empty()) {                // row-sorted file: map the rows back (the file bytes on the device are done with)
+        uint32_t* d_perm = reinterpret_cast<uint32_t*>(d_file);
+        if (P.row_perm.size() * 4 > file_bytes) throw std::runtime_error("spz: row permutation larger than the file");   // cannot happen: it was read from it
+        HIPCHK(hipMemcpyAsync(d_perm, P.row_perm.data(), P.row_perm.size() * 4, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(spz_unpermute_rows_kernel, dim3((unsigned)((h.nnz + 255) / 256)), dim3(256), 0, s, d_row_idx, (int64_t)h.nnz,
+                           d_perm, (uint32_t)P.row_perm.size());
+        HIPCHK(hipGetLastError());
+    }
     HIPCHK(hipStreamSynchronize(s));          // the host buffers (jobs, col_ptr) die with the caller's frame
 }
 
@@ -400,7 +442,6 @@ extern "C" int rcppml_hip_spz_info(const void* file_bytes, uint64_t size, int* m
         SpzHeader h;
         const int st = check_header(static_cast<const uint8_t*>(file_bytes), size, h);
         if (st) { rcppml_err() = "spz_info: not a v2 .spz file"; return st; }
-        if (h.row_sorted) { rcppml_err() = "spz_info: row-sorted .spz files are not supported"; return 5; }
         *m = (int)h.m; *n = (int)h.n; *nnz = (int64_t)h.nnz; *value_type = h.value_type;
         return 0;
     }

@@ -32,10 +32,13 @@ def ref_decode(buf):
     return dict(m=m.value, n=n.value, nnz=nnz.value, vt=vt.value, row_sorted=rs.value, chunks=nc.value, p=p, i=i, x=x)
 
 
-def ref_encode(m, n, p, i, x, precision, chunk_cols):
-    cap = 64 + 16 * x.size + 4096 * (n // chunk_cols + 2) + 8 * n
+L.ref_spz_encode_rowsort.restype = C.c_uint64
+
+
+def ref_encode(m, n, p, i, x, precision, chunk_cols, row_sort=False):
+    cap = 64 + 16 * x.size + 4096 * (n // chunk_cols + 2) + 8 * n + 8 * m
     out = np.zeros(cap, np.uint8)
-    sz = L.ref_spz_encode(C.c_uint32(m), C.c_uint32(n), C.c_uint64(x.size), vp(p), vp(i), vp(x), precision.encode(), C.c_uint32(chunk_cols), u8p(out), C.c_uint64(cap))
+    sz = (L.ref_spz_encode_rowsort if row_sort else L.ref_spz_encode)(C.c_uint32(m), C.c_uint32(n), C.c_uint64(x.size), vp(p), vp(i), vp(x), precision.encode(), C.c_uint32(chunk_cols), u8p(out), C.c_uint64(cap))
     assert 0 < sz <= cap, (sz, cap)
     return out[:sz].copy()
 
@@ -72,15 +75,25 @@ cases = [  # name, m, n, density, kind, precision, chunk_cols
     # while its decoder expects it (:988-991), so the decoded column pointers of such a chunk are whatever the following
     # bytes spell.  The fixture records what the reference decoder returns; a faithful decoder returns the same.
     ("empty_chunk_quirk", 40, 9, 0.0, "bytes", "auto", 4),
+    # row_sort = TRUE (st_convert's default, R/streampress.R:306-309): rows renumbered by the encoder, the permutation
+    # stored in the metadata section and applied by the decoder (sparsepress_v2.hpp:1089-1103) -- the fixture records
+    # what the reference decoder returns for what the reference encoder wrote
+    ("rowsort_u8", 300, 90, 0.05, "bytes", "auto", 32),
+    ("rowsort_f32", 257, 70, 0.08, "real", "fp32", 16),
 ]
 out = {}
 names = []
 for name, m, n, dens, kind, prec, cc in cases:
     p, i, x = random_csc(m, n, dens, seed=len(names) + 11, kind=kind)
-    buf = ref_encode(m, n, p, i, x, prec, cc)
+    buf = ref_encode(m, n, p, i, x, prec, cc, row_sort=name.startswith("rowsort"))
     dec = ref_decode(buf)
     assert dec["m"] == m and dec["n"] == n
-    if name != "empty_chunk_quirk":
+    assert dec["row_sorted"] == (1 if name.startswith("rowsort") else 0)
+    if name.startswith("rowsort"):
+        assert np.array_equal(dec["p"], p)
+        print("   row-sorted round trip returns the input rows:", bool(np.array_equal(dec["i"], i)),
+              "| as sets per column:", all(set(dec["i"][p[j]:p[j + 1]]) == set(i[p[j]:p[j + 1]]) for j in range(n)))
+    elif name != "empty_chunk_quirk":
         assert np.array_equal(dec["p"], p) and np.array_equal(dec["i"], i)
     if prec in ("auto", "fp64"):
         assert np.array_equal(dec["x"], x)

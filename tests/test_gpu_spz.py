@@ -73,7 +73,10 @@ def test_bad_files_are_rejected(env):
     v3 = buf.copy(); v3[4] = 3
     assert _abi.spz_info(v3)[0] == 4                                 # not v2 (:75-81)
     rs = buf.copy(); rs[42] = 1
-    assert _abi.spz_info(rs)[0] == 5                                 # row-sorted: not supported by this build
+    assert _abi.spz_info(rs)[0] == 0                                 # flagged row-sorted without a stored permutation: decodes
+    m0, n0, nnz0, vt0, p0, i0, x0 = _decode(env, buf)                # unpermuted, as the reference does (sparsepress_v2.hpp:1094)
+    m1, n1, nnz1, vt1, p1, i1, x1 = _decode(env, rs)
+    assert np.array_equal(p0, p1) and np.array_equal(i0, i1) and np.array_equal(x0, x1)
     trunc = buf[: buf.size // 2]
     d = torch.zeros(4096, dtype=torch.int32, device="cuda")
     dx = torch.zeros(4096, dtype=torch.float64, device="cuda")
@@ -137,3 +140,39 @@ def test_malformed_files_never_read_out_of_bounds(env):
                 assert _abi.sp_free_gpu(r) == 0
             else:
                 assert r["status"] in (2, 3, 4, 5) and r["col_ptr"] == 0.0
+
+
+def test_row_sorted_file_through_reader_and_zero_copy_fit(env, tmp_path):
+    """A row_sort = TRUE file (st_convert's default) through rcppml_sp_read_gpu: the device CSC equals what the reference
+    decoder returns (rows mapped through the stored permutation, no longer ascending inside a column), and the zero-copy
+    fit on it equals the 73-pointer fit on the host copy of the same arrays."""
+    torch, _abi, ctx = env
+    buf = GOLD["rowsort_u8_spz"]
+    path = str(tmp_path / "rowsort.spz")
+    buf.tofile(path)
+    h = _abi.sp_read_gpu(path)
+    assert h["status"] == 0 and [h["m"], h["n"], h["nnz"]] == list(GOLD["rowsort_u8_info"][:3])
+    try:
+        n, nnz = h["n"], h["nnz"]
+        dp = torch.empty(n + 1, dtype=torch.int32, device="cuda")
+        di = torch.empty(nnz, dtype=torch.int32, device="cuda")
+        dx = torch.empty(nnz, dtype=torch.float64, device="cuda")
+        _abi.copy_from_device_address(dp, h["col_ptr"], 4 * (n + 1))
+        _abi.copy_from_device_address(di, h["row_idx"], 4 * nnz)
+        _abi.copy_from_device_address(dx, h["values"], 8 * nnz)
+        p, i, x = dp.cpu().numpy(), di.cpu().numpy(), dx.cpu().numpy()
+        assert np.array_equal(p.view(np.uint32), GOLD["rowsort_u8_p"]) and np.array_equal(i.view(np.uint32), GOLD["rowsort_u8_i"])
+        assert np.array_equal(x, GOLD["rowsort_u8_x"])
+        k = 5
+        W0, H0 = O.init_factors(3, k, h["m"], n, np.float64)
+        W1, H1 = W0.copy(), H0.copy()
+        r1 = _abi.nmf_unified(p, i, x, h["m"], n, k, W1, H1, entry="double", max_iter=4, tol=0.0, solver_mode=0)
+        W2, H2 = W0.copy(), H0.copy()
+        r2 = _abi.nmf_zerocopy(h["col_ptr"], h["row_idx"], h["values"], h["m"], n, nnz, k, W2, H2, max_iter=4, tol=0.0)
+        assert r1["status"] == 0 and r2["status"] == 0
+        assert r1["loss"] == r2["loss"] and np.array_equal(W1, W2) and np.array_equal(H1, H2)
+        A = O.Csc((h["m"], n), p, i, x)
+        ref = O.nmf_fit(A, W0, H0, np.float64, max_iter=4, tol=0.0, solver_mode=0)
+        assert abs(r1["loss"] - ref.loss) <= 1e-6 * abs(ref.loss)
+    finally:
+        _abi.sp_free_gpu(h)
