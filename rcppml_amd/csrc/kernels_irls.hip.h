@@ -153,8 +153,8 @@ __global__ __launch_bounds__(256) void irls_nb_solve_kernel(
                 if (mask == 0ull) break;
                 any = true;
                 const int i = __builtin_ctzll(mask);
-                const T ad_i = lane_value(ad, i), nx_i = lane_value(nx, i);
-                if (lane == i) x = nx_i;
+                const T ad_i = lane_value(ad, i);
+                if (lane == i) x = nx;
                 b = tfma(-Gl[i * KP + ll], ad_i, b);
                 cur = i + 1;
                 if (cur >= KP) break;
@@ -264,12 +264,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         }
         __builtin_amdgcn_wave_barrier();
         // residual b_c = b_w - G_w x_old
+        // (the lane keeps ITS column of G_w -- G_w(c, ll), c = 0..31 -- in registers: the sweep below picks row i of it with a
+        //  wave-uniform index, i.e. a register-indexed move instead of an LDS read on the dependent chain of every step)
         const float x_old = x;
         float b = bw;
-#pragma unroll 8
+        typedef float f32x32 __attribute__((ext_vector_type(32)));
+        f32x32 gcol;
+#pragma unroll
         for (int c = 0; c < KP; ++c) {
             const float xc = __shfl(x_old, c, 64);
-            b = tfma(-Gl[c * KP + ll], xc, b);
+            const float gv = Gl[c * KP + ll];
+            gcol[c] = gv;
+            b = tfma(-gv, xc, b);
         }
         const float gd = Gl[ll * KP + ll];
         const float ginv = gd > 0.f ? 1.f / gd : 0.f;     // one division per pass; the sweep multiplies (as the MSE kernels do)
@@ -288,9 +294,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
                 if (mask == 0ull) break;
                 any = true;
                 const int i = __builtin_ctzll(mask);
-                const float ad_i = lane_value(ad, i), nx_i = lane_value(nx, i);
-                if (lane == i) x = nx_i;
-                b = tfma(-Gl[i * KP + ll], ad_i, b);
+                const float ad_i = lane_value(ad, i);
+                if (lane == i) x = nx;
+                b = tfma(-gcol[i], ad_i, b);
                 cur = i + 1;
                 if (cur >= KP) break;
             }
@@ -430,8 +436,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
                 if (mask == 0ull) break;
                 any = true;
                 const int i = __builtin_ctzll(mask);
-                const double ad_i = lane_value(ad, i), nx_i = lane_value(nx, i);
-                if (lane == i) x = nx_i;
+                const double ad_i = lane_value(ad, i);
+                if (lane == i) x = nx;
                 b = tfma(-Gl[i * KP + ll], ad_i, b);
                 cur = i + 1;
                 if (cur >= KP) break;

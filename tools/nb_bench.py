@@ -6,7 +6,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from rcppml_amd import als, data, _abi
-m, n, k = 10000, int(sys.argv[1]) if len(sys.argv) > 1 else 200000, 32
+m, n, k = 10000, int(sys.argv[1]) if len(sys.argv) > 1 else 200000, int(os.environ.get("K", "32"))
 dtype = sys.argv[2] if len(sys.argv) > 2 else "f32"
 t0 = time.time()
 A, _, _ = data.simulate_nb_counts(m, n, k, density=0.02, size=5.0, seed=123)
