@@ -32,6 +32,11 @@ __device__ __forceinline__ float tfma(float a, float b, float c) { return __buil
 __device__ __forceinline__ double tfma(double a, double b, double c) { return __builtin_fma(a, b, c); }
 
 // value of lane i (wave-uniform i) through v_readlane_b32: the result lands in an SGPR, no LDS-crossbar round trip
+// b / G_cc inside a coordinate-descent sweep: fp64 divides as the reference writes it (parity mode), fp32 multiplies by the
+// reciprocal formed once per column (one rounding more; the same choice as EXACT = false in the MSE kernels) -- an IEEE fp32
+// division is ~10 dependent instructions on the chain of every step
+__device__ __forceinline__ float sweep_quotient(float b, float /*gd*/, float ginv) { return b * ginv; }
+__device__ __forceinline__ double sweep_quotient(double b, double gd, double /*ginv*/) { return b / gd; }
 __device__ __forceinline__ float lane_value(float v, int i) {
     return __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), i));
 }
@@ -1374,11 +1379,12 @@ __global__ __launch_bounds__(256) void cv_solve_kernel(
         if (nonneg) x = x > T(0) ? x : T(0);
     } else {
         const T gd = Gl[ll * KP + ll];
+        const T ginv = gd > T(0) ? T(1) / gd : T(0);
         for (int it = 0; it < maxit; ++it) {
             int cur = 0;
             bool any = false;
             while (true) {
-                T diff = b / gd;
+                T diff = sweep_quotient(b, gd, ginv);
                 if (l1 != T(0)) diff -= l1;
                 const T nv = x + diff;
                 T ad = diff, nx = nv;
@@ -1530,11 +1536,18 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8
         if (nonneg) x = x > 0.f ? x : 0.f;
     } else {
         const float gd = Gl[ll * KP + ll];
+        // the lane's column of the corrected Gram in registers: the sweep picks row i with a wave-uniform register-indexed
+        // move instead of an LDS read on the dependent chain of every step (as irls_nb_mfma32_kernel does)
+        typedef float f32x32 __attribute__((ext_vector_type(32)));
+        f32x32 gcol;
+#pragma unroll
+        for (int c = 0; c < KP; ++c) gcol[c] = Gl[c * KP + ll];
+        const float ginv = gd > 0.f ? 1.f / gd : 0.f;   // one division per column; the sweep multiplies (as the MSE and IRLS fp32 kernels do)
         for (int it = 0; it < maxit; ++it) {
             int cur = 0;
             bool any = false;
             while (true) {
-                float diff = b / gd;
+                float diff = b * ginv;
                 if (l1 != 0.f) diff -= l1;
                 const float nv = x + diff;
                 float ad = diff, nx = nv;
@@ -1544,9 +1557,9 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8
                 if (mask == 0ull) break;
                 any = true;
                 const int i = __builtin_ctzll(mask);
-                const float ad_i = lane_value(ad, i), nx_i = lane_value(nx, i);
-                if (lane == i) x = nx_i;
-                b = tfma(-Gl[i * KP + ll], ad_i, b);
+                const float ad_i = lane_value(ad, i);
+                if (lane == i) x = nx;
+                b = tfma(-gcol[i], ad_i, b);
                 cur = i + 1;
                 if (cur >= KP) break;
             }
@@ -1900,11 +1913,12 @@ __global__ __launch_bounds__(256) void masked_solve_kernel(
         const bool check = tol > T(0);
         const T inv_k = T(1) / static_cast<T>(k);
         const T gd = Gl[ll * KP + ll];
+        const T ginv = gd > T(0) ? T(1) / gd : T(0);
         for (int it = 0; it < maxit; ++it) {
             T tol_sum = T(0);
             int cur = 0;
             while (true) {
-                const T diff = b / gd;
+                const T diff = sweep_quotient(b, gd, ginv);
                 const T nv = x + diff;
                 T ad = diff, nx = nv;
                 if (nonneg && nv < T(0)) { ad = -x; nx = T(0); }

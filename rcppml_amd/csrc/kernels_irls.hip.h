@@ -138,12 +138,13 @@ __global__ __launch_bounds__(256) void irls_nb_solve_kernel(
             b = tfma(-gw[c], xc, b);
         }
         const T gd = Gl[ll * KP + ll];
+        const T ginv = gd > T(0) ? T(1) / gd : T(0);
         // cd_nnls_col_fixed(G_w, b_c, x, L1 inside, L2 = 0, nonneg, cd_maxit, ub = 0, tol = 0): all sweeps
         for (int it = 0; it < cd_maxit; ++it) {
             int cur = 0;
             bool any = false;
             while (true) {
-                T diff = b / gd;
+                T diff = sweep_quotient(b, gd, ginv);
                 if (l1 != T(0)) diff -= l1;
                 const T nv = x + diff;
                 T ad = diff, nx = nv;
