@@ -312,6 +312,159 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 }
 
 // ---------------------------------------------------------------------------
+// fp32, 32 < k <= 64 (k % 4 == 0): the same on a 2 x 2 grid of 32 x 32 accumulator tiles (the lower-left tile is the
+// transpose of the upper-right one and is never computed: three MFMAs per pair of nonzeros).  Lane = feature in the sweep
+// (all 64 lanes busy); in phase A a lane takes nonzero r and the 32 features of half hh (eight 16-byte gathers, the
+// reconstruction f . x as 32 in-lane fmas + one half swap).  16 KiB of LDS per wave for G_w (the staged rows alias it):
+// two blocks per CU -- an order of magnitude above the row-in-registers form this rank range used before (64 shuffles +
+// 64 fmas per nonzero and lane), not the occupancy of the k <= 32 kernel.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void irls_nb_mfma32x2_kernel(
+    const int* __restrict__ colptr, const int* __restrict__ rowidx, const float* __restrict__ vals, int64_t ncols,
+    const float* __restrict__ F, const float* __restrict__ Gbase, float* __restrict__ X, int k, float l1, float l2,
+    int nonneg, int cd_maxit, int irls_max_iter, float irls_tol, const float* __restrict__ theta_row,
+    const float* __restrict__ theta_col, int loss_type, float power, float robust) {
+    constexpr int KP = 64, CH = 32, FS = 68;          // FS: padded stride of a staged F row (64 features + bank spread)
+    constexpr int GW = KP * KP;                        // G_w slab; the staged rows (CH * FS = 2176 floats) alias its head
+    constexpr int WAVE_FLOATS = GW + 2 * CH + KP;      // G_w | (w-1, w a) pairs | x
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float* Gl = reinterpret_cast<float*>(smem_raw) + (size_t)wave * WAVE_FLOATS;   // [c][r]
+    float* Fst = Gl;
+    float2* sc = reinterpret_cast<float2*>(Gl + GW);
+    float* xs = Gl + GW + 2 * CH;
+    const int64_t j = (int64_t)blockIdx.x * 4 + wave;
+    if (j >= ncols) return;
+    const int r = lane & 31, hh = lane >> 5;            // phase A: nonzero r, feature half hh; phase B: feature r (+32), K-slot hh
+    const bool fok = lane < k;
+    const int as = colptr[j], ae = colptr[j + 1];
+    const float th_col = theta_col ? theta_col[j] : 0.f;
+    float x = 0.f;                                      // nnls_batch_irls.hpp:482-483  H.setZero(): no warm start
+    for (int irls = 0; irls < irls_max_iter; ++irls) {
+        // accumulator tiles <- base Gram (identity padding); C/D map of a tile: col = lane&31, row = (v&3) + 8(v>>2) + 4(lane>>5)
+        f32x16 a00, a01, a11;                           // rows 0-31 x cols 0-31 | rows 0-31 x cols 32-63 | rows 32-63 x cols 32-63
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const int gi = (v & 3) + 8 * (v >> 2) + 4 * hh, gj = r;
+            auto base = [&](int i2, int j2) { return (i2 < k && j2 < k) ? Gbase[(int64_t)j2 * k + i2] : (i2 == j2 ? 1.f : 0.f); };
+            a00[v] = base(gi, gj); a01[v] = base(gi, gj + 32); a11[v] = base(gi + 32, gj + 32);
+        }
+        xs[lane] = x;
+        float bw0 = 0.f, bw1 = 0.f;                     // b_w of feature r and of feature 32 + r (this lane's K-slot share)
+        __builtin_amdgcn_wave_barrier();
+        for (int t0 = as; t0 < ae; t0 += CH) {
+            // ---- phase A
+            const int tt = t0 + r;
+            const bool ok = tt < ae;
+            const int row = ok ? rowidx[tt] : 0;
+            const float a = ok ? vals[tt] : 0.f;
+            const float* fsrc = F + (int64_t)row * k + 32 * hh;
+            float4 fv4[8];
+            float part = 0.f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int c0 = 32 * hh + 4 * q;
+                fv4[q] = (ok && c0 < k) ? *reinterpret_cast<const float4*>(fsrc + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+                const float4 xv = *reinterpret_cast<const float4*>(xs + c0);
+                part = tfma(fv4[q].x, xv.x, part);
+                part = tfma(fv4[q].y, xv.y, part);
+                part = tfma(fv4[q].z, xv.z, part);
+                part = tfma(fv4[q].w, xv.w, part);
+            }
+            const float recon = part + __shfl_xor(part, 32, 64);                 // W_T.col(row).dot(x)
+            const float th = theta_col ? th_col : (theta_row ? theta_row[row] : 0.f);
+            const float w = irls_weight_full_dev<float>(loss_type, a - recon, recon, th, power, robust);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) *reinterpret_cast<float4*>(Fst + r * FS + 32 * hh + 4 * q) = fv4[q];
+            if (hh == 0) sc[r] = make_float2(ok ? w - 1.f : 0.f, ok ? w * a : 0.f);
+            __builtin_amdgcn_wave_barrier();
+            // ---- phase B: nonzeros (2s, 2s+1) of the chunk per MFMA triple
+            const int cnt = ae - t0 < CH ? ae - t0 : CH;
+            const int nst = (cnt + 1) >> 1;
+#pragma unroll 2
+            for (int s2 = 0; s2 < nst; ++s2) {
+                const int t = 2 * s2 + hh;
+                const float f0 = Fst[t * FS + r], f1 = Fst[t * FS + 32 + r];
+                const float2 ws = sc[t];
+                bw0 = tfma(ws.y, f0, bw0);                                        // b_w += f * (w a)
+                bw1 = tfma(ws.y, f1, bw1);
+                const float s0 = ws.x * f0, s1 = ws.x * f1;
+                a00 = __builtin_amdgcn_mfma_f32_32x32x2f32(s0, f0, a00, 0, 0, 0);   // G_w += (f (w-1)) f^T, tile by tile
+                a01 = __builtin_amdgcn_mfma_f32_32x32x2f32(s0, f1, a01, 0, 0, 0);
+                a11 = __builtin_amdgcn_mfma_f32_32x32x2f32(s1, f1, a11, 0, 0, 0);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        bw0 += __shfl_xor(bw0, 32, 64);
+        bw1 += __shfl_xor(bw1, 32, 64);
+        const float bw = hh ? bw1 : bw0;                 // lane = feature from here on
+        // park G_w in LDS ([c][r]); the lower-left tile is the transpose of a01
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const int gi = (v & 3) + 8 * (v >> 2) + 4 * hh;      // row inside the tile; column inside the tile = r
+            float d00 = a00[v], d11 = a11[v];
+            if (l2 > 0.f && gi == r) { if (gi < k) d00 += l2; if (gi + 32 < k) d11 += l2; }
+            Gl[gi * KP + r] = d00;                               // symmetric tile: stored as computed
+            Gl[(gi + 32) * KP + 32 + r] = d11;
+            Gl[(32 + r) * KP + gi] = a01[v];                     // G_w(row gi, col 32 + r) at [c = 32 + r][r' = gi]
+            Gl[gi * KP + 32 + r] = a01[v];                       // and its mirror G_w(row 32 + r, col gi) at [c = gi][r' = 32 + r]
+        }
+        __builtin_amdgcn_wave_barrier();
+        // residual b_c = b_w - G_w x_old; the lane keeps its column of G_w in registers for the sweep
+        const float x_old = x;
+        float b = bw;
+        // (two 32-element vectors: hipcc indexes a 32-element vector with s_set_gpr_idx, a 64-element one through scratch)
+        typedef float f32x32 __attribute__((ext_vector_type(32)));
+        f32x32 gcol0, gcol1;
+#pragma unroll
+        for (int c = 0; c < 32; ++c) {
+            const float xc = __shfl(x_old, c, 64);
+            const float gv = Gl[c * KP + lane];
+            gcol0[c] = gv;
+            b = tfma(-gv, xc, b);
+        }
+#pragma unroll
+        for (int c = 0; c < 32; ++c) {
+            const float xc = __shfl(x_old, 32 + c, 64);
+            const float gv = Gl[(32 + c) * KP + lane];
+            gcol1[c] = gv;
+            b = tfma(-gv, xc, b);
+        }
+        const float gd = Gl[lane * KP + lane];
+        const float ginv = gd > 0.f ? 1.f / gd : 0.f;
+        // cd_nnls_col_fixed(G_w, b_c, x, L1 inside, L2 = 0, nonneg, cd_maxit, ub = 0, tol = 0): all sweeps
+        for (int it = 0; it < cd_maxit; ++it) {
+            int cur = 0;
+            bool any = false;
+            while (true) {
+                float diff = b * ginv;
+                if (l1 != 0.f) diff -= l1;
+                const float nv = x + diff;
+                float ad = diff, nx = nv;
+                if (nonneg && nv < 0.f) { ad = -x; nx = 0.f; }
+                const bool moves = fok && (gd > 0.f) && (ad != 0.f) && (lane >= cur);
+                const unsigned long long mask = __ballot(moves);
+                if (mask == 0ull) break;
+                any = true;
+                const int i = __builtin_ctzll(mask);
+                const float ad_i = lane_value(ad, i);
+                if (lane == i) x = nx;
+                const float g_lo = gcol0[i & 31], g_hi = gcol1[i & 31];
+                b = tfma(-(i < 32 ? g_lo : g_hi), ad_i, b);
+                cur = i + 1;
+                if (cur >= KP) break;
+            }
+            if (!any) break;
+        }
+        float rel = fok ? tabs(x - x_old) / (tabs(x_old) + 1e-12f) : 0.f;
+        rel = wave_max(rel);
+        __builtin_amdgcn_wave_barrier();
+        if (rel < irls_tol) break;
+    }
+    if (fok) X[j * (int64_t)k + lane] = x;
+}
+
+// ---------------------------------------------------------------------------
 // fp64, k <= 32 (k % 2 == 0): the same kernel on v_mfma_f64_16x16x4_f64 -- the 32 x 32 weighted Gram is 2 x 2 tiles of
 // 16 x 16, FOUR nonzeros fill the four K-slots of an instruction (A operand = (w_t - 1) f_t[16 ti + r], B operand =
 // f_t[16 tj + r], lane (r = lane&15, kk = lane>>4) serves nonzero 4s + kk), C/D map col = lane&15, row = (lane>>4) + 4v.

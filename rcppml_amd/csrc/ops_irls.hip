@@ -27,6 +27,15 @@ static void irls_impl(rcppml_hip_ctx* c, const int* cp, const int* ri, const T* 
             HIPCHK(hipGetLastError());
             return;
         }
+        if (use_mfma && k <= 64 && k % 4 == 0 && reinterpret_cast<uintptr_t>(F) % 16 == 0) {      // 32 < k <= 64: 2 x 2 tiles
+            const size_t smem = (size_t)4 * (64 * 64 + 2 * 32 + 64) * sizeof(float);
+            static DynSmemOnce once;
+            once.ensure(reinterpret_cast<const void*>(&irls_nb_mfma32x2_kernel), smem, c->device);
+            hipLaunchKernelGGL(irls_nb_mfma32x2_kernel, dim3((unsigned)nblk), dim3(256), smem, c->stream, cp, ri, vals, ncols, F,
+                               Gbase, X, k, l1, l2, nonneg, cd_maxit, irls_max_iter, irls_tol, theta_row, theta_col, loss_type, power, robust);
+            HIPCHK(hipGetLastError());
+            return;
+        }
     }
     if constexpr (std::is_same<T, double>::value) {
         static int use_mfma64 = -1;
