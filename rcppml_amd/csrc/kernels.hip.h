@@ -1569,6 +1569,174 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8
     if (fok) X[j * (int64_t)k + lane] = x;
 }
 
+// fp32, 32 < k <= 64 (k % 4 == 0): the same on a 2 x 2 grid of 32 x 32 accumulator tiles (three MFMAs per pair of held-out
+// rows), lane = feature over the whole wave in the solve; 16 KiB of LDS per wave for G_local (two blocks per CU).
+static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void cv_solve_mfma32x2_kernel(
+    const int* __restrict__ colptr, const int* __restrict__ rowidx, const float* __restrict__ vals, int64_t ncols, int nrows,
+    const float* __restrict__ F, const float* __restrict__ Gfull, float* __restrict__ X, int k, unsigned long long seed,
+    unsigned long long threshold, int mask_zeros, int transposed, float l1, int nonneg, int maxit, int solver_mode) {
+    constexpr int KP = 64, FS = 68, QCAP = 96;
+    constexpr int WAVE_FLOATS = KP * KP + QCAP;       // G_local (its head doubles as the 32 x FS staging area) | row queue
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float* Fst = reinterpret_cast<float*>(smem_raw) + (size_t)wave * WAVE_FLOATS;
+    int* hq = reinterpret_cast<int*>(Fst + KP * KP);
+    float* Gl = Fst;                                  // [c][r]
+    const int64_t j = (int64_t)blockIdx.x * 4 + wave;
+    if (j >= ncols) return;
+    const int r = lane & 31, hh = lane >> 5;
+    const bool fok = lane < k;
+    const bool lin = lane < KP;
+    const int ll = lin ? lane : 0;
+    const unsigned col = (unsigned)j;
+    // 2 x 2 tiles of 32 x 32; the lower-left one is the transpose of the upper-right one and is never computed
+    f32x16 a00, a01, a11;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+        const int gi = (v & 3) + 8 * (v >> 2) + 4 * hh, gj = r;
+        auto base = [&](int i2, int j2) { return (i2 < k && j2 < k) ? Gfull[(int64_t)j2 * k + i2] : (i2 == j2 ? 1.f : 0.f); };
+        a00[v] = base(gi, gj); a01[v] = base(gi, gj + 32); a11[v] = base(gi + 32, gj + 32);
+    }
+    int qn = 0;                                       // rows waiting in hq (wave-uniform)
+    // apply the first `cnt` (<= 32) queued rows to the accumulator tile
+    auto flush = [&](int cnt) {
+        const bool ok = r < cnt;
+        const int row = ok ? hq[r] : 0;
+        const float* fsrc = F + (int64_t)row * k + 32 * hh;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int c0 = 32 * hh + 4 * q;
+            const float4 v = (ok && c0 < k) ? *reinterpret_cast<const float4*>(fsrc + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4*>(Fst + r * FS + c0) = v;
+        }
+        __builtin_amdgcn_wave_barrier();
+        const int nst = (cnt + 1) >> 1;
+#pragma unroll 2
+        for (int s2 = 0; s2 < nst; ++s2) {
+            const float f0 = Fst[(2 * s2 + hh) * FS + r], f1 = Fst[(2 * s2 + hh) * FS + 32 + r];
+            a00 = __builtin_amdgcn_mfma_f32_32x32x2f32(-f0, f0, a00, 0, 0, 0);
+            a01 = __builtin_amdgcn_mfma_f32_32x32x2f32(-f0, f1, a01, 0, 0, 0);
+            a11 = __builtin_amdgcn_mfma_f32_32x32x2f32(-f1, f1, a11, 0, 0, 0);
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
+    // append the rows flagged in `held` (one per lane, row index `row`) to the queue; flush while >= 32 are waiting
+    auto push = [&](bool held, int row) {
+        const unsigned long long m = __ballot(held);
+        if (m == 0ull) return;
+        const int rank = __popcll(m & ((1ull << lane) - 1ull));
+        if (held) hq[qn + rank] = row;
+        qn += __popcll(m);
+        __builtin_amdgcn_wave_barrier();
+        while (qn >= 32) {
+            flush(32);
+            const int rest = qn - 32;
+            const int moved = lane < rest ? hq[32 + lane] : 0;      // rest <= 63
+            __builtin_amdgcn_wave_barrier();
+            if (lane < rest) hq[lane] = moved;
+            __builtin_amdgcn_wave_barrier();
+            qn = rest;
+        }
+    };
+    float b = 0.f;
+    for (int t0 = colptr[j]; t0 < colptr[j + 1]; t0 += 64) {       // 64 nonzeros per step: lane-parallel hashing
+        const int t = t0 + lane;
+        const bool valid = t < colptr[j + 1];
+        const int row = valid ? rowidx[t] : 0;
+        const float a = valid ? vals[t] : 0.f;
+        const bool held = valid && (transposed ? cv_hash_dev(seed, col, (unsigned)row) : cv_hash_dev(seed, (unsigned)row, col)) < threshold;
+        // train right-hand side: lane = feature again, one nonzero at a time
+        unsigned long long tm = __ballot(valid && !held);
+        while (tm) {
+            const int bit = __builtin_ctzll(tm);
+            tm &= tm - 1;
+            const int rw = __builtin_amdgcn_readlane(row, bit);
+            const float av = lane_value(a, bit);
+            if (fok) b = tfma(av, F[(int64_t)rw * k + lane], b);
+        }
+        if (mask_zeros) push(held, row);
+    }
+    if (!mask_zeros) {
+        for (int r0 = 0; r0 < nrows; r0 += 64) {
+            const int rw = r0 + lane;
+            const bool held = rw < nrows &&
+                (transposed ? cv_hash_dev(seed, col, (unsigned)rw) : cv_hash_dev(seed, (unsigned)rw, col)) < threshold;
+            push(held, rw);
+        }
+    }
+    if (qn > 0) flush(qn);
+    // park G_local in LDS ([c][r]; symmetric)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+        const int gi = (v & 3) + 8 * (v >> 2) + 4 * hh;
+        Gl[gi * KP + r] = a00[v];
+        Gl[(gi + 32) * KP + 32 + r] = a11[v];
+        Gl[(32 + r) * KP + gi] = a01[v];                  // G(row gi, col 32 + r) and its mirror
+        Gl[gi * KP + 32 + r] = a01[v];
+    }
+    __builtin_amdgcn_wave_barrier();
+    float x = fok ? X[j * (int64_t)k + lane] : 0.f;
+    if (solver_mode == 1) {
+        if (l1 > 0.f && fok) b -= l1;
+        for (int c = 0; c < KP; ++c) {
+            float s = Gl[c * KP + ll];
+            for (int p = 0; p < c; ++p) s -= Gl[p * KP + ll] * Gl[p * KP + c];
+            float dcc = __shfl(s, c, 64);
+            if (!(dcc > 0.f)) dcc = tabs(dcc) + 1e-30f;
+            const float lcc = sqrt(dcc);
+            if (lin) Gl[c * KP + lane] = lane == c ? lcc : (lane > c ? s / lcc : 0.f);
+            RK_WAVE_SYNC();
+        }
+        float y = b;
+        for (int i = 0; i < k; ++i) {
+            const float yi = __shfl(y, i, 64) / Gl[i * KP + i];
+            if (lane == i) y = yi;
+            else if (lane > i) y -= Gl[i * KP + ll] * yi;
+        }
+        for (int i = k - 1; i >= 0; --i) {
+            const float xi = __shfl(y, i, 64) / Gl[i * KP + i];
+            if (lane == i) y = xi;
+            else if (lane < i) y -= Gl[ll * KP + i] * xi;
+        }
+        x = y;
+        if (nonneg) x = x > 0.f ? x : 0.f;
+    } else {
+        const float gd = Gl[ll * KP + ll];
+        // the lane's column of the corrected Gram in registers: the sweep picks row i with a wave-uniform register-indexed
+        // move instead of an LDS read on the dependent chain of every step (as irls_nb_mfma32_kernel does)
+        typedef float f32x32 __attribute__((ext_vector_type(32)));      // (two halves: hipcc indexes 32-element vectors with
+        f32x32 gcol0, gcol1;                                            //  s_set_gpr_idx, 64-element ones through scratch)
+#pragma unroll
+        for (int c = 0; c < 32; ++c) { gcol0[c] = Gl[c * KP + ll]; gcol1[c] = Gl[(32 + c) * KP + ll]; }
+        const float ginv = gd > 0.f ? 1.f / gd : 0.f;   // one division per column; the sweep multiplies (as the MSE and IRLS fp32 kernels do)
+        for (int it = 0; it < maxit; ++it) {
+            int cur = 0;
+            bool any = false;
+            while (true) {
+                float diff = b * ginv;
+                if (l1 != 0.f) diff -= l1;
+                const float nv = x + diff;
+                float ad = diff, nx = nv;
+                if (nonneg && nv < 0.f) { ad = -x; nx = 0.f; }
+                const bool moves = fok && (gd > 0.f) && (ad != 0.f) && (lane >= cur);
+                const unsigned long long mask = __ballot(moves);
+                if (mask == 0ull) break;
+                any = true;
+                const int i = __builtin_ctzll(mask);
+                const float ad_i = lane_value(ad, i);
+                if (lane == i) x = nx;
+                const float g_lo = gcol0[i & 31], g_hi = gcol1[i & 31];
+                b = tfma(-(i < 32 ? g_lo : g_hi), ad_i, b);
+                cur = i + 1;
+                if (cur >= KP) break;
+            }
+            if (!any) break;
+        }
+    }
+    if (fok) X[j * (int64_t)k + lane] = x;
+}
+
+
 // fp64, k <= 32 (k % 2 == 0): the same with v_mfma_f64_16x16x4_f64 (2 x 2 tiles of 16 x 16, four held-out rows per
 // instruction step, C/D map col = lane&15, row = (lane>>4) + 4v).
 static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void cv_solve_mfma64_kernel(

@@ -38,6 +38,15 @@ void cv_solve_impl(rcppml_hip_ctx* c, const int* cp, const int* ri, const T* val
             HIPCHK(hipGetLastError());
             return;
         }
+        if (use_mfma && k <= 64 && k % 4 == 0 && reinterpret_cast<uintptr_t>(F) % 16 == 0) {      // 32 < k <= 64: 2 x 2 tiles
+            const size_t smem = (size_t)4 * (64 * 64 + 96) * sizeof(float);
+            static DynSmemOnce once;
+            once.ensure(reinterpret_cast<const void*>(&cv_solve_mfma32x2_kernel), smem, c->device);
+            hipLaunchKernelGGL(cv_solve_mfma32x2_kernel, dim3((unsigned)nblk), dim3(256), smem, c->stream, cp, ri, vals, ncols, nrows, F, G,
+                               X, k, seed, thr, mask_zeros, transposed, l1, nonneg, maxit, solver_mode);
+            HIPCHK(hipGetLastError());
+            return;
+        }
     }
     if constexpr (std::is_same<T, double>::value) {
         static int use_mfma64 = -1;
