@@ -15,6 +15,7 @@ one per rank -- one all-gather of W_T (rcppml_amd/als.py).
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import contextlib
 import json
 import os
 import subprocess
@@ -48,6 +49,7 @@ def parse():
     ap.add_argument("--no-order", action="store_true", help="disable sweep-count column ordering")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline work (s)")
     ap.add_argument("--no-plugin-figure", action="store_true", help="skip the PCIe-inclusive 73-pointer plugin call")
+    ap.add_argument("--no-graph", action="store_true", help="time an eager launch loop instead of replays of one captured hipGraph")
     args = ap.parse_args()
     preset = {"c2": (20000, 100000, 0.01, 64), "c4": (30000, 162500, 0.03, 128)}[args.config]
     args.rows = args.rows or preset[0]
@@ -170,33 +172,98 @@ def main():
     cfg = als.AlsConfig(k=k, max_iter=args.warmup + args.steps, tol=0.0, cd_maxit=args.cd_maxit,
                         solver_mode=0 if args.solver == "cd" else 1,
                         cd_variant={"auto": 0, "lane": 1, "wave": 2}[args.variant], order_columns=not args.no_order)
-    ops = als.HipOps(local_rank, args.dtype, record_events=False)
-    st = als.ShardedALS(ops, comm, A_loc, At_loc, W0, H0, cfg)
+    # One GPU: the K timed iterations are replays of ONE captured hipGraph of the iteration -- how the plugin's loop
+    # (rcppml_amd/csrc/plugin.hip) issues its steady-state iterations; an eager loop pays ~3 us of launch gap per kernel, ~35
+    # kernels per iteration.  Everything then lives on a side stream (a capture cannot run on the default stream); the device
+    # library is bound to it through the context's stream.  N > 1 (collectives in the loop) and --no-graph time the eager loop.
+    use_graph = world == 1 and not args.no_graph
+    side = torch.cuda.Stream(device=local_rank) if use_graph else None
+    stream_ctx = torch.cuda.stream(side) if use_graph else contextlib.nullcontext()
+    with stream_ctx:
+        ops = als.HipOps(local_rank, args.dtype, record_events=False)
+        st = als.ShardedALS(ops, comm, A_loc, At_loc, W0, H0, cfg)
+        for _ in range(args.warmup):
+            st.step()
+        ops.sync()
+        torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        st.step()
-    ops.sync()
-    # ---- timed region: EXACTLY `steps` iterations, barrier + synchronize on both sides
-    ops.record = True
-    ops.reset_events()
-    comm.reset_events()
-    ops.ctx.stats(reset=True)          # zero the library's work counters (column-sweeps of the CD kernels)
-    comm.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = st.step()
-    torch.cuda.synchronize()
-    comm.barrier()
-    dt = time.perf_counter() - t0
-    ops.record = False
+        def snapshot():
+            return dict(W=st.W_T.clone(), H=st.H.clone(), d=st.d.clone(), it=st.iter,
+                        order={sd: {key: (v.clone() if hasattr(v, "clone") else v) for key, v in o.items()} for sd, o in ops._order.items()})
+
+        def restore(snap):
+            st.W_T.copy_(snap["W"]); st.H.copy_(snap["H"]); st.d.copy_(snap["d"]); st.iter = snap["it"]
+            for sd, o in snap["order"].items():
+                for key, v in o.items():
+                    if hasattr(v, "clone"):
+                        ops._order[sd][key].copy_(v)
+                    else:
+                        ops._order[sd][key] = v
+
+        graph, launch_mode = None, "eager"
+        if use_graph:
+            snap = snapshot()
+            try:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=side):
+                    st.step()
+                torch.cuda.synchronize()
+                graph, launch_mode = g, "hipGraph replay (one captured ALS iteration)"
+            except Exception as exc:                      # capture not available: time the eager loop, and say so
+                sys.stderr.write("bench: graph capture failed (%s); timing the eager loop\n" % (exc,))
+                torch.cuda.synchronize()
+            restore(snap)                                  # the capture pass does not execute; state is as after the warm-up
+            torch.cuda.synchronize()
+        # ---- timed region: EXACTLY `steps` iterations, barrier + synchronize on both sides
+        ops.record = graph is None
+        ops.reset_events()
+        comm.reset_events()
+        ops.ctx.stats(reset=True)          # zero the library's work counters (column-sweeps of the CD kernels)
+        comm.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        if graph is not None:
+            for _ in range(args.steps):
+                graph.replay()
+            loss = st.loss_out
+        else:
+            for _ in range(args.steps):
+                loss = st.step()
+        torch.cuda.synchronize()
+        comm.barrier()
+        dt = time.perf_counter() - t0
+        ops.record = False
+        final_loss_t = loss.clone()
+        work = ops.ctx.stats()
+        eager_ms_per_step = None
+        if graph is not None:
+            # per-phase HIP events cannot sit inside a replayed graph: the SAME K iterations are run once more, eagerly, from the
+            # state the timed region started from, with an event pair around every phase (kernel durations do not depend on how
+            # the launch was issued; the eager pass's own wall time is reported as `eager_ms_per_step`)
+            st.iter += args.steps
+            sweeps_after = {sd: o["sweeps"].clone() for sd, o in ops._order.items()}
+            restore(snap)
+            ops.record = True
+            ops.reset_events()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                st.step()
+            torch.cuda.synchronize()
+            eager_ms_per_step = (time.perf_counter() - t1) / args.steps * 1e3
+            ops.record = False
+            for sd, v in sweeps_after.items():          # same iterations, same arithmetic: the two passes must agree bit for bit
+                if not torch.equal(v, ops._order[sd]["sweeps"]):
+                    raise RuntimeError("bench: graph replay and eager pass disagree on the %s-side sweep counts" % sd)
+            if not torch.equal(final_loss_t, st.loss_out):
+                raise RuntimeError("bench: graph replay and eager pass disagree on the loss")
+        loss = final_loss_t
     tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
     final_loss = float(loss[0].item())
     ev = ops.event_ms()
-    work = ops.ctx.stats()
     coll = comm.collective_ms()
 
     if rank == 0:
@@ -320,6 +387,10 @@ def main():
             "roofline": roof_cd if cd_dominant else roof_rhs,
             ("roofline_rhs" if cd_dominant else "roofline_cd"): roof_rhs if cd_dominant else roof_cd,
             "phases_ms_per_step": phases,
+            # how the timed iterations were issued; with graph replay the per-phase / per-kernel HIP-event durations above
+            # come from an eager re-run of the same K iterations (checked bit-identical) right after the timed region
+            "launch": launch_mode,
+            "eager_ms_per_step": eager_ms_per_step,
             "final_loss": final_loss,
             "world_size_seen": world,
             "backend": (dist.get_backend() if world > 1 else None),
