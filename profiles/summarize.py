@@ -69,8 +69,9 @@ with open(os.path.join(dst, tag + "_summary.md"), "w") as f:
         r = v["resources"]
         f.write("| `%s` | %.0f | %.0f | %.3e | %s | %s | %s |\n" % (k[:70], v["fetch_size_kib_avg"], v["write_size_kib_avg"],
                                                               v["hbm_bytes_per_launch"], r.get("vgpr"), r.get("sgpr"), r.get("lds")))
-# the --stats averages include the warm-up launches (iteration 0 runs every column to cd_maxit); bench.py times the last
-# `steps` iterations only, so give the kernel-trace average over exactly those launches as well
+# the --stats averages include the warm-up launches (iteration 0 runs every column to cd_maxit); bench.py times `steps`
+# iterations after them (graph replays) and re-runs the same iterations eagerly for its per-phase events, so give the
+# kernel-trace average over exactly those last launches as well
 trace = os.path.join(src, "trace", "trace_kernel_trace.csv")
 if os.path.exists(trace):
     by = collections.defaultdict(list)
@@ -78,7 +79,7 @@ if os.path.exists(trace):
         if "rk::cd_mfma" in r["Kernel_Name"] and "prep" not in r["Kernel_Name"] or "rk::rhs_stage" in r["Kernel_Name"] or "rk::rhs_tiled" in r["Kernel_Name"]:
             by[r["Kernel_Name"]].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
     with open(os.path.join(dst, tag + "_summary.md"), "a") as f:
-        f.write("\nTimed launches only (the last 10 iterations of the 13; from the kernel trace):\n\n| kernel | launches | avg us (all) | avg us (timed) |\n|---|---|---|---|\n")
+        f.write("\nLaunches of the timed iterations only (the run issues 3 warm-up iterations, the 10 timed ones as hipGraph replays, and the same 10 once more eagerly for the per-phase events: the column averages the last 10 launches of each kernel, i.e. that eager re-run; from the kernel trace):\n\n| kernel | launches | avg us (all) | avg us (timed) |\n|---|---|---|---|\n")
         # kernels that run once per side share a name when both sides pick the same shape: split by grid size
         for k, v in by.items():
             v.sort()
