@@ -12,6 +12,10 @@ owns a fresh 100000-column shard (weak scaling), W_T is replicated; per iteratio
 all-reduce, one fused [H H^T | H A^T] all-reduce, and -- the m columns of W being solved in row blocks,
 one per rank -- one all-gather of W_T (rcppml_amd/als.py).
 
+Launch: at N = 1 the K timed iterations are K replays of one captured hipGraph of the iteration (the plugin's loop does
+the same); the per-phase HIP-event durations in the line come from an eager re-run of the same K iterations, checked
+bit-identical (--no-graph times the eager loop; N > 1 always does).
+
 Prints ONE JSON line on rank 0.
 """
 import argparse
