@@ -410,7 +410,7 @@ def main():
             try:
                 W_T, dvec, H = st.factors()
                 G_h = st.ops.gram(st.W_T, 1e-15, 0.0).cpu().numpy()
-                G_w = st.G.cpu().numpy()
+                G_w = st.ops.gram(st.H, 1e-15, 0.0).cpu().numpy()
                 out["cpu_baseline"] = cpu_baseline(_to_oracle(A_loc), _to_oracle(At_loc), W_T, H, G_h, G_w, k, args.dtype,
                                                    args.cpu_seconds, args.cd_maxit)
                 out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]

@@ -324,20 +324,26 @@ class ShardedALS:
         else:
             ops.gram(self.H, self.eps, 0.0, out=self.Gp, tag="gram")
             ops.rhs(self.At, self.H, out=self.Bw, tag="rhs_W")
-        self.G_saved.copy_(self.Gp)                                          # :719-722 (before L2)
-        self.G.copy_(self.Gp)
-        ops.add_diag(self.G, cfg.L2_W)                                       # :738
+        # G_saved = Gram of H before L2 (:719-722), G = G_saved + L2_W I (:738).  Without an L2 penalty on W both are the
+        # buffer the Gram kernel just wrote (it stays untouched until the next iteration's Gram of H): no copies
+        if cfg.L2_W > 0:
+            self.G_saved.copy_(self.Gp)
+            self.G.copy_(self.Gp)
+            ops.add_diag(self.G, cfg.L2_W)
+            G_w, G_saved = self.G, self.G_saved
+        else:
+            G_w, G_saved = self.Gp, self.Gp
         if comm.world > 1:
             if self.row_hi > self.row_lo:
-                ops.solve(self.G, self.Bw[self.row_lo:self.row_hi], self.W_T[self.row_lo:self.row_hi], cfg, "W", warm, tag="solve_W")
+                ops.solve(G_w, self.Bw[self.row_lo:self.row_hi], self.W_T[self.row_lo:self.row_hi], cfg, "W", warm, tag="solve_W")
             comm.all_gather_rows(self.W_pad, self.rows_per)
         else:
-            ops.solve(self.G, self.Bw, self.W_T, cfg, "W", warm, tag="solve_W")
+            ops.solve(G_w, self.Bw, self.W_T, cfg, "W", warm, tag="solve_W")
         ops.row_norms(self.W_T, cfg.norm_type, out=self.sums)
         ops.apply_scaling(self.W_T, self.sums, cfg.norm_type, self.d)
         # ---- loss (fit_cpu.hpp:1729-1753): B_w is the h_at of the reference's third sparse pass
         ops.gram(self.W_T, self.eps, 0.0, out=self.G_wt, tag="gram")
-        ops.loss_mse(self.trAtA, self.d, self.W_T, self.Bw, self.G_wt, self.G_saved, self.loss_out)
+        ops.loss_mse(self.trAtA, self.d, self.W_T, self.Bw, self.G_wt, G_saved, self.loss_out)
         self.iter += 1
         return self.loss_out
 
