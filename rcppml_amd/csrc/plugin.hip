@@ -298,8 +298,11 @@ void fit(FitParams& P) {
             if (P.ub_W > 0) OPCHK(rcppml_hip_clip_upper(c, dt, dW.p, (int64_t)k * m, P.ub_W));      // :884-885
         } else {
             OPCHK(rcppml_hip_gram(c, dt, dH.p, k, n, eps, 0.0, dGs.p));                 // :715-722 G_w_saved
+            // the solve's Gram: G_saved itself when nothing is added to it (no copy: one kernel boundary less per iteration)
+            const bool gw_modified = P.L2_W > 0 || graph_W || P.L21_W > 0 || tgtW;
+            void* const Gw = gw_modified ? dG.p : dGs.p;
             if (P.L2_W > 0) OPCHK(rcppml_hip_gram(c, dt, dH.p, k, n, eps, P.L2_W, dG.p)); // :738
-            else HIPCHK(hipMemcpyAsync(dG.p, dGs.p, (size_t)k * k * sizeof(T), hipMemcpyDeviceToDevice, s));
+            else if (gw_modified) HIPCHK(hipMemcpyAsync(dG.p, dGs.p, (size_t)k * k * sizeof(T), hipMemcpyDeviceToDevice, s));
             if (graph_W) OPCHK(rcppml_hip_apply_graph_reg(c, dt, dG.p, dGWp.as<int>(), dGWi.as<int>(), dGWx.p, dW.p, k, m, P.gW_lambda));   // :740-741
             if (P.L21_W > 0) OPCHK(rcppml_hip_apply_l21(c, dt, dG.p, dW.p, k, m, P.L21_W));   // :741-745 (current W_T)
             rhs_bwd(dH.p, dBw.p);
@@ -307,12 +310,12 @@ void fit(FitParams& P) {
             if (P.solver_mode == 0) {
                 const bool ord = use_order && iter > 0 && m >= kOrderMinColumns;
                 if (ord) OPCHK(rcppml_hip_order_columns(c, dswW.as<int>(), m, dordW.as<int>()));
-                OPCHK(rcppml_hip_solve_cd(c, dt, dG.p, Bw_use, dW.p, k, m, P.L1_W > 0 ? P.L1_W : 0.0, warm, zinit, 0.0, 0.0,
+                OPCHK(rcppml_hip_solve_cd(c, dt, Gw, Bw_use, dW.p, k, m, P.L1_W > 0 ? P.L1_W : 0.0, warm, zinit, 0.0, 0.0,
                                           P.nonneg_W, P.cd_maxit, P.cd_tol, 0.0, P.ub_W, RCPPML_CD_AUTO,
                                           use_order ? dswW.as<int>() : nullptr, ord ? dordW.as<int>() : nullptr));
             }
             else
-                OPCHK(rcppml_hip_solve_chol(c, dt, dG.p, Bw_use, dW.p, k, m, P.L1_W > 0 ? P.L1_W : 0.0, P.nonneg_W, P.ub_W));
+                OPCHK(rcppml_hip_solve_chol(c, dt, Gw, Bw_use, dW.p, k, m, P.L1_W > 0 ? P.L1_W : 0.0, P.nonneg_W, P.ub_W));
         }
         if (P.angular_W > 0) OPCHK(rcppml_hip_angular_posthoc(c, dt, dW.p, k, m, P.angular_W));   // :886-887
         OPCHK(rcppml_hip_row_norms(c, dt, dW.p, k, m, P.norm_type, dsums.p));           // :893
