@@ -2163,56 +2163,54 @@ static __global__ __launch_bounds__(256) void sum_partials2(const double* __rest
 // per column but 54 per 64-column wave), so grouping columns that need similar sweep counts removes ~30 % of the
 // wasted lane-sweeps, and long-running waves start first.  Columns are independent, so any order gives identical results.
 // ---------------------------------------------------------------------------
+// Two launches, no global atomics, nothing to zero beforehand: block b counts ITS contiguous chunk of the columns per bin
+// (order_hist_kernel -> part[b][128]); order_scatter_kernel, launched with the same grid, turns the table into "where
+// does bin x of block b start" (exclusive scan over bins of the totals + the counts of the blocks before b) and ranks
+// its chunk inside LDS.  The position of a column depends on the block decomposition only (inside one bin and block the
+// LDS atomics decide), so the layout is reproducible run to run up to that.
+constexpr int ORDER_BLOCKS_MAX = 128;
 static __global__ __launch_bounds__(256) void order_hist_kernel(const int* __restrict__ sweeps, int64_t n,
-                                                                  unsigned int* __restrict__ hist /*128*/) {
+                                                                  unsigned int* __restrict__ part /*gridDim.x x 128*/) {
     __shared__ unsigned int sh[128];
     if (threadIdx.x < 128) sh[threadIdx.x] = 0;
     __syncthreads();
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const int64_t per = (n + gridDim.x - 1) / gridDim.x;
+    const int64_t i0 = (int64_t)blockIdx.x * per;
+    const int64_t i1 = i0 + per < n ? i0 + per : n;
+    for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) {
         int key = sweeps[i];
         key = key < 0 ? 0 : (key > 127 ? 127 : key);
         atomicAdd(&sh[127 - key], 1u);
     }
     __syncthreads();
-    if (threadIdx.x < 128 && sh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], sh[threadIdx.x]);
+    if (threadIdx.x < 128) part[(size_t)blockIdx.x * 128 + threadIdx.x] = sh[threadIdx.x];
 }
 static __global__ __launch_bounds__(256) void order_scatter_kernel(const int* __restrict__ sweeps, int64_t n,
-                                                                     const unsigned int* __restrict__ hist /*128 bin counts*/,
-                                                                     unsigned int* __restrict__ cursor /*128, zeroed*/,
+                                                                     const unsigned int* __restrict__ part /*gridDim.x x 128*/,
                                                                      int* __restrict__ order) {
-    // Block-aggregated: each block counts its contiguous chunk per bin in LDS, reserves one global range per bin
-    // (128 global atomics per block instead of one per element on a handful of hot bins), then ranks inside LDS.
-    // every block scans the 128 bin counts itself (two waves, shuffle scan) -- cheaper than a kernel of its own
-    __shared__ unsigned int cnt[128], base[128], start[128];
+    __shared__ unsigned int cnt[128], base[128], half_total;
+    // bin totals over all blocks, and the part of them that lies in blocks before this one
     if (threadIdx.x < 128) {
-        const unsigned int h = hist[threadIdx.x];
-        unsigned int incl = h;
+        unsigned int tot = 0, before = 0;
+        for (unsigned int b = 0; b < gridDim.x; ++b) {
+            const unsigned int c = part[(size_t)b * 128 + threadIdx.x];
+            if (b < blockIdx.x) before += c;
+            tot += c;
+        }
+        // exclusive scan of the totals over the 128 bins (two waves, shuffle scan)
+        unsigned int incl = tot;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) { const unsigned int t = __shfl_up(incl, d, 64); if ((threadIdx.x & 63) >= d) incl += t; }
-        if (threadIdx.x == 63) base[0] = incl;          // total of bins 0..63 (base[] is free until the ranking phase)
-        start[threadIdx.x] = incl - h;
+        if (threadIdx.x == 63) half_total = incl;        // total of bins 0..63
+        base[threadIdx.x] = incl - tot + before;
+        cnt[threadIdx.x] = 0;
     }
     __syncthreads();
-    if (threadIdx.x >= 64 && threadIdx.x < 128) start[threadIdx.x] += base[0];
+    if (threadIdx.x >= 64 && threadIdx.x < 128) base[threadIdx.x] += half_total;
     __syncthreads();
     const int64_t per = (n + gridDim.x - 1) / gridDim.x;
     const int64_t i0 = (int64_t)blockIdx.x * per;
     const int64_t i1 = i0 + per < n ? i0 + per : n;
-    if (threadIdx.x < 128) cnt[threadIdx.x] = 0;
-    __syncthreads();
-    for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) {
-        int key = sweeps[i];
-        key = key < 0 ? 0 : (key > 127 ? 127 : key);
-        atomicAdd(&cnt[127 - key], 1u);
-    }
-    __syncthreads();
-    if (threadIdx.x < 128) {
-        const unsigned int c = cnt[threadIdx.x];
-        base[threadIdx.x] = c ? start[threadIdx.x] + atomicAdd(&cursor[threadIdx.x], c) : 0u;
-        cnt[threadIdx.x] = 0;
-    }
-    __syncthreads();
     for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) {
         int key = sweeps[i];
         key = key < 0 ? 0 : (key > 127 ? 127 : key);

@@ -78,12 +78,12 @@ extern "C" int rcppml_hip_order_columns(rcppml_hip_ctx* c, const int* sweeps, in
     try {
         HIPCHK(hipSetDevice(c->device));
         if (ncols <= 0) return 0;
-        unsigned int* hist = static_cast<unsigned int*>(c->scratch(WS_ORDER, 256 * sizeof(unsigned int)));   // bin counts | cursors
-        HIPCHK(hipMemsetAsync(hist, 0, 256 * sizeof(unsigned int), c->stream));
-        int64_t nblk = (ncols + 255) / 256;
-        if (nblk > 2 * (int64_t)c->num_cu) nblk = 2 * c->num_cu;
-        hipLaunchKernelGGL(order_hist_kernel, dim3((unsigned)nblk), dim3(256), 0, c->stream, sweeps, ncols, hist);
-        hipLaunchKernelGGL(order_scatter_kernel, dim3((unsigned)nblk), dim3(256), 0, c->stream, sweeps, ncols, hist, hist + 128, order);
+        int64_t nblk = (ncols + 1023) / 1024;                       // >= 1024 columns per block; both kernels use the same grid
+        if (nblk > ORDER_BLOCKS_MAX) nblk = ORDER_BLOCKS_MAX;
+        if (nblk < 1) nblk = 1;
+        unsigned int* part = static_cast<unsigned int*>(c->scratch(WS_ORDER, (size_t)ORDER_BLOCKS_MAX * 128 * sizeof(unsigned int)));
+        hipLaunchKernelGGL(order_hist_kernel, dim3((unsigned)nblk), dim3(256), 0, c->stream, sweeps, ncols, part);
+        hipLaunchKernelGGL(order_scatter_kernel, dim3((unsigned)nblk), dim3(256), 0, c->stream, sweeps, ncols, part, order);
         HIPCHK(hipGetLastError());
         return 0;
     }
