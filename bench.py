@@ -192,11 +192,12 @@ def main():
         torch.cuda.synchronize()
 
         def snapshot():
-            return dict(W=st.W_T.clone(), H=st.H.clone(), d=st.d.clone(), it=st.iter,
+            return dict(W=st.W_T.clone(), H=st.H.clone(), d=st.d.clone(), it=st.iter, Gwt=st.G_wt.clone(), gwt_ok=st._gwt_of_current_w,
                         order={sd: {key: (v.clone() if hasattr(v, "clone") else v) for key, v in o.items()} for sd, o in ops._order.items()})
 
         def restore(snap):
             st.W_T.copy_(snap["W"]); st.H.copy_(snap["H"]); st.d.copy_(snap["d"]); st.iter = snap["it"]
+            st.G_wt.copy_(snap["Gwt"]); st._gwt_of_current_w = snap["gwt_ok"]     # (the loss Gram doubles as the next H-side Gram)
             for sd, o in snap["order"].items():
                 for key, v in o.items():
                     if hasattr(v, "clone"):

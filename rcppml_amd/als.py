@@ -296,6 +296,7 @@ class ShardedALS:
         self.Bw = self.xbuf[k * k:].view(m, k)
         self.G = ops.empty((k, k))
         self.G_saved = ops.empty((k, k))
+        self._gwt_of_current_w = False    # G_wt holds the Gram of the current W_T (set by step(); cleared by set_factors)
         self.G_wt = ops.empty((k, k))
         self.sums = ops.empty((k,))
         self.loss_out = ops.zeros((4,), ops.torch.float64)
@@ -309,9 +310,15 @@ class ShardedALS:
         ops, cfg, comm = self.ops, self.cfg, self.comm
         warm = self.iter > 0
         # ---- H half-update (fit_cpu.hpp:486-645)
-        ops.gram(self.W_T, self.eps, cfg.L2_H, out=self.G, tag="gram")
+        # W_T^T W_T + eps I: the previous iteration's loss formed exactly this Gram from exactly this W_T (same kernel, same
+        # input: bitwise the same matrix), so it is reused when nothing is added to it
+        if self.iter > 0 and cfg.L2_H == 0 and self._gwt_of_current_w:
+            G_h = self.G_wt
+        else:
+            ops.gram(self.W_T, self.eps, cfg.L2_H, out=self.G, tag="gram")
+            G_h = self.G
         ops.rhs(self.A, self.W_T, out=self.Bh, tag="rhs_H")
-        ops.solve(self.G, self.Bh, self.H, cfg, "H", warm, tag="solve_H")
+        ops.solve(G_h, self.Bh, self.H, cfg, "H", warm, tag="solve_H")
         ops.row_norms(self.H, cfg.norm_type, out=self.sums)
         comm.all_reduce_sum(self.sums, tag="all_reduce_rowsums")
         ops.apply_scaling(self.H, self.sums, cfg.norm_type, self.d)
@@ -343,6 +350,7 @@ class ShardedALS:
         ops.apply_scaling(self.W_T, self.sums, cfg.norm_type, self.d)
         # ---- loss (fit_cpu.hpp:1729-1753): B_w is the h_at of the reference's third sparse pass
         ops.gram(self.W_T, self.eps, 0.0, out=self.G_wt, tag="gram")
+        self._gwt_of_current_w = True
         ops.loss_mse(self.trAtA, self.d, self.W_T, self.Bw, self.G_wt, G_saved, self.loss_out)
         self.iter += 1
         return self.loss_out

@@ -248,7 +248,11 @@ void fit(FitParams& P) {
                                           P.solver_mode, warm));
             if (P.ub_H > 0) OPCHK(rcppml_hip_clip_upper(c, dt, dH.p, (int64_t)k * n, P.ub_H));      // :636-637
         } else {
-            OPCHK(rcppml_hip_gram(c, dt, dW.p, k, m, eps, P.L2_H, dG.p));              // :491,506
+            // W_T^T W_T + eps I is what the previous iteration's loss formed from this very W_T (dGwt: same kernel, same
+            // input, bitwise the same matrix): reused when nothing is added to it -- one Gram less per iteration
+            const bool reuse_gwt = iter > 0 && !is_nb && P.L2_H == 0 && !graph_H && P.L21_H == 0 && !tgtH;
+            void* const Gh = reuse_gwt ? dGwt.p : dG.p;
+            if (!reuse_gwt) OPCHK(rcppml_hip_gram(c, dt, dW.p, k, m, eps, P.L2_H, dG.p));              // :491,506
             if (graph_H) OPCHK(rcppml_hip_apply_graph_reg(c, dt, dG.p, dGHp.as<int>(), dGHi.as<int>(), dGHx.p, dH.p, k, n, P.gH_lambda));   // :508-509
             if (P.L21_H > 0) OPCHK(rcppml_hip_apply_l21(c, dt, dG.p, dH.p, k, n, P.L21_H));   // :509-510 (current H)
             rhs_fwd(dW.p, dBh.p);
@@ -256,12 +260,12 @@ void fit(FitParams& P) {
             if (P.solver_mode == 0) {                                                   // :516-524
                 const bool ord = use_order && iter > 0 && n >= kOrderMinColumns;
                 if (ord) OPCHK(rcppml_hip_order_columns(c, dswH.as<int>(), n, dordH.as<int>()));
-                OPCHK(rcppml_hip_solve_cd(c, dt, dG.p, Bh_use, dH.p, k, n, P.L1_H > 0 ? P.L1_H : 0.0, warm, zinit, 0.0, 0.0,
+                OPCHK(rcppml_hip_solve_cd(c, dt, Gh, Bh_use, dH.p, k, n, P.L1_H > 0 ? P.L1_H : 0.0, warm, zinit, 0.0, 0.0,
                                           P.nonneg_H, P.cd_maxit, P.cd_tol, 0.0, P.ub_H, RCPPML_CD_AUTO,
                                           use_order ? dswH.as<int>() : nullptr, ord ? dordH.as<int>() : nullptr));
             }
             else                                                                        // :527-534
-                OPCHK(rcppml_hip_solve_chol(c, dt, dG.p, Bh_use, dH.p, k, n, P.L1_H > 0 ? P.L1_H : 0.0, P.nonneg_H, P.ub_H));
+                OPCHK(rcppml_hip_solve_chol(c, dt, Gh, Bh_use, dH.p, k, n, P.L1_H > 0 ? P.L1_H : 0.0, P.nonneg_H, P.ub_H));
         }
         if (P.angular_H > 0 && !P.projective && !P.symmetric) OPCHK(rcppml_hip_angular_posthoc(c, dt, dH.p, k, n, P.angular_H));   // :638-639 (standard branch only)
         if (!P.symmetric) {
