@@ -1126,6 +1126,31 @@ __global__ __launch_bounds__(256) void scale_rows(T* __restrict__ X, int k, int6
 }
 // scaling_finalize + scale_rows in one launch (norm_type 0 / 1): every thread forms d_f from the row sums exactly as
 // scaling_finalize does, block 0 also stores d
+// 16-byte form of the same (k a multiple of the vector width, X 16-byte aligned): one vector load / store per VEC elements
+template <class T, int VEC>
+__global__ __launch_bounds__(256) void scale_rows_from_sums_vec(T* __restrict__ X, int k, int64_t total, const T* __restrict__ sums,
+                                                                int norm_type, T* __restrict__ d) {
+    typedef typename VecT<T, VEC>::type V;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    if (blockIdx.x == 0)
+        for (int f = threadIdx.x; f < k; f += blockDim.x) {
+            T s = sums[f];
+            if (norm_type == 1) s = sqrt(s);
+            d[f] = s + T(1e-15);
+        }
+    const int64_t nvec = total / VEC;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < nvec; e += stride) {
+        const int f0 = (int)((e * VEC) % k);
+        V x = reinterpret_cast<V*>(X)[e];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            T s = sums[f0 + v];
+            if (norm_type == 1) s = sqrt(s);
+            x[v] = x[v] / (s + T(1e-15));
+        }
+        reinterpret_cast<V*>(X)[e] = x;
+    }
+}
 template <class T>
 __global__ __launch_bounds__(256) void scale_rows_from_sums(T* __restrict__ X, int k, int64_t total, const T* __restrict__ sums,
                                                             int norm_type, T* __restrict__ d) {

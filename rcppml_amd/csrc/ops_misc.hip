@@ -43,10 +43,13 @@ static void apply_scaling_impl(rcppml_hip_ctx* c, T* X, int k, int64_t ncols, in
         HIPCHK(hipGetLastError());
         return;
     }
-    int64_t nblk = (total + 255) / 256;
+    constexpr int VEC = 16 / sizeof(T);
+    const bool vec = k % VEC == 0 && reinterpret_cast<uintptr_t>(X) % 16 == 0;
+    int64_t nblk = ((vec ? total / VEC : total) + 255) / 256;
     if (nblk > 8 * (int64_t)c->num_cu) nblk = 8 * c->num_cu;
     if (nblk < 1) nblk = 1;
-    hipLaunchKernelGGL(scale_rows_from_sums<T>, dim3((unsigned)nblk), dim3(256), 0, c->stream, X, k, total, sums, norm_type, d);
+    if (vec) hipLaunchKernelGGL((scale_rows_from_sums_vec<T, VEC>), dim3((unsigned)nblk), dim3(256), 0, c->stream, X, k, total, sums, norm_type, d);
+    else hipLaunchKernelGGL(scale_rows_from_sums<T>, dim3((unsigned)nblk), dim3(256), 0, c->stream, X, k, total, sums, norm_type, d);
     HIPCHK(hipGetLastError());
 }
 // ----------------------------------------------------------------------------
