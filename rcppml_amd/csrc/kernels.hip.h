@@ -153,6 +153,76 @@ __global__ __launch_bounds__(256) void gram_partial_f32(const float* __restrict_
     }
 }
 
+// k = 64 fp32 (two 32-row tiles, 8-byte vector loads: the headline shape): all four output tiles in ONE block, so every
+// slice of F is read once instead of once per tile row.  Same waves, same column pairs, same in-block and across-block
+// summation order as gram_partial_f32<2, true, STEPS> on a (nblk, 2) grid -- bitwise the same partial tiles.
+template <int STEPS>
+__global__ __launch_bounds__(256) void gram_partial_f32_k64(const float* __restrict__ F, int k, int64_t r,
+                                                             float* __restrict__ partial) {
+    constexpr int KP = 64;
+    __shared__ float red[3][4 * 1024];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t nw = (int64_t)gridDim.x * 4, wid = (int64_t)blockIdx.x * 4 + wave;
+    const int64_t npairs = (r + 1) / 2;
+    const int64_t per = (npairs + nw - 1) / nw;
+    const int64_t p0 = wid * per;
+    const int64_t p1 = p0 + per < npairs ? p0 + per : npairs;
+    const int kk = lane >> 5, row = lane & 31;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[a][b][v] = 0.f;
+    typedef VecT<float, 2>::type V;
+    for (int64_t pb = p0; pb < p1; pb += STEPS) {
+        float a[STEPS][2];
+#pragma unroll
+        for (int s = 0; s < STEPS; ++s) {
+            const int64_t c = 2 * (pb + s) + kk;
+            const bool cok = (pb + s) < p1 && c < r;
+            const int r0 = 2 * row;
+            if (cok && r0 < k) {
+                const V v = *reinterpret_cast<const V*>(F + c * (int64_t)k + r0);
+                a[s][0] = v[0]; a[s][1] = v[1];
+            } else { a[s][0] = 0.f; a[s][1] = 0.f; }
+        }
+#pragma unroll
+        for (int s = 0; s < STEPS; ++s)
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+                    acc[ti][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s][ti], a[s][t], acc[ti][t], 0, 0, 0);
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) red[wave - 1][(ti * 2 + t) * 1024 + v * 64 + lane] = acc[ti][t][v];
+    }
+    __syncthreads();
+    if (wave == 0) {
+        float* out = partial + ((int64_t)blockIdx.x * KP * KP);
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    float s = acc[ti][t][v];
+                    s += red[0][(ti * 2 + t) * 1024 + v * 64 + lane];
+                    s += red[1][(ti * 2 + t) * 1024 + v * 64 + lane];
+                    s += red[2][(ti * 2 + t) * 1024 + v * 64 + lane];
+                    const int is = (v & 3) + 8 * (v >> 2) + 4 * (lane >> 5), js = lane & 31;
+                    out[(int64_t)(2 * js + t) * KP + (2 * is + ti)] = s;
+                }
+    }
+}
+
 template <int T_TILES>  // KP = 16 * T_TILES  (v_mfma_f64_16x16x4_f64)
 __global__ __launch_bounds__(256) void gram_partial_f64(const double* __restrict__ F, int k, int64_t r,
                                                          double* __restrict__ partial) {

@@ -73,7 +73,7 @@ static void gram_impl(rcppml_hip_ctx* c, const T* F, int k, int64_t r, T eps, T 
         switch (tt) {
             case 1: hipLaunchKernelGGL((gram_partial_f32<1, false, 8>), grid, block, 0, c->stream, F, k, r, partial); break;
             case 2:
-                if (vl) hipLaunchKernelGGL((gram_partial_f32<2, true, 8>), grid, block, 0, c->stream, F, k, r, partial);
+                if (vl) hipLaunchKernelGGL((gram_partial_f32_k64<8>), dim3((unsigned)nblk), block, 0, c->stream, F, k, r, partial);   // all four tiles per block: F read once
                 else hipLaunchKernelGGL((gram_partial_f32<2, false, 8>), grid, block, 0, c->stream, F, k, r, partial);
                 break;
             case 3: hipLaunchKernelGGL((gram_partial_f32<3, false, 4>), grid, block, 0, c->stream, F, k, r, partial); break;
