@@ -64,20 +64,16 @@ static __global__ void cd_mfma64_prep_kernel(const T* __restrict__ G, int k, int
 // (probed on gfx950: tools/probe/permlane_probe.hip).  Only the groups BEHIND row P need the value; the others may
 // receive anything finite (their coefficient is zero).
 template <int P> __device__ __forceinline__ unsigned bcast_row32(unsigned a) {
+    // builtins, not inline asm: hipcc then knows the instruction's hazards and needs one s_nop per swap instead of two (a
+    // lone wave -- the W side of C2 -- pays an issue slot for every one of them)
     if constexpr (P == 2) {                 // row 3 <- row 2
-        unsigned x = a;
-        asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %0" : "+v"(x));
-        return x;
+        return __builtin_amdgcn_permlane16_swap(a, a, false, false)[0];
     } else {
-        unsigned t = a, u = a;
-        asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(t), "+v"(u));   // t = [r0 r0 r2 r2], u = [r1 r1 r3 r3]
+        const auto tu = __builtin_amdgcn_permlane16_swap(a, a, false, false);   // [0] = [r0 r0 r2 r2], [1] = [r1 r1 r3 r3]
         if constexpr (P == 0) {             // rows 1,2,3 <- row 0
-            unsigned v = t;
-            asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(t), "+v"(v));   // t = [r0 r0 r0 r0]
-            return t;
+            return __builtin_amdgcn_permlane32_swap(tu[0], tu[0], false, false)[0];   // [r0 r0 r0 r0]
         } else {                            // rows 2,3 <- row 1
-            asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %0" : "+v"(u));            // u = [r3 r3 r1 r1]
-            return u;
+            return __builtin_amdgcn_permlane32_swap(tu[1], tu[1], false, false)[0];   // [r3 r3 r1 r1]
         }
     }
 }
