@@ -210,7 +210,9 @@ enum { RCPPML_CD_AUTO = 0 /* = GROUP unless RCPPML_GPU_CD_VARIANT says otherwise
        RCPPML_CD_WAVE = 2 /* one wavefront per column, active-coordinate ballot skipping, G in LDS */,
        RCPPML_CD_GROUP = 5 /* 1, 2 or 4 adjacent lanes per column (DPP broadcasts), G from LDS */,
        RCPPML_CD_MFMA16 = 7 /* k <= 64, fp32 or fp64: 16 columns per wave, four coordinates per v_mfma_*_16x16x4 (the fp64 default) */,
-       RCPPML_CD_MFMA = 6 /* fp32, k <= 128: residual tiles in MFMA accumulators, two coordinates per v_mfma_f32_32x32x2_f32 */ };
+       RCPPML_CD_MFMA = 6 /* fp32, k <= 128: residual tiles in MFMA accumulators, two coordinates per v_mfma_f32_32x32x2_f32 */,
+       RCPPML_CD_LMF = 8 /* fp32, k <= 64, non-negativity only: lane = column, rank-1 updates as v_mfma_f32_4x4x1_16B blocks, persistent
+                            waves with column refill (the fp32 default for NMF half-updates) */ };
 
 /* stream: a hipStream_t (NULL = the device's null stream).  The context owns scratch memory only. */
 RCPPML_GPU_API int rcppml_hip_ctx_create(rcppml_hip_ctx** out, int device, void* stream);
@@ -218,9 +220,18 @@ RCPPML_GPU_API void rcppml_hip_ctx_destroy(rcppml_hip_ctx* ctx);
 RCPPML_GPU_API int rcppml_hip_ctx_sync(rcppml_hip_ctx* ctx);
 /* Work counters since creation / the last reset (synchronises the stream): out4[0] = column-sweeps executed by the
  * coordinate-descent kernels (sum over solved columns of the sweeps cd_nnls_col_fixed ran, nnls_batch.hpp:127-131;
- * x 2 k_pad^2 = the flops of the residual updates), out4[1] = columns solved, out4[2..3] reserved.  Counted by the
- * GROUP and MFMA kernels (what RCPPML_CD_AUTO dispatches to). */
+ * x 2 k_pad^2 = the flops of the residual updates), out4[1] = columns solved, out4[2] = slot-sweeps the persistent LMF
+ * kernel executed (column slots x sweeps of their wave: idle slots and warm-start correction sweeps included, so
+ * 1 - out4[0] / out4[2] is its idle fraction), out4[3] = coordinate steps of that kernel in which NO column of the wave
+ * moved (only with RCPPML_OPT_CD_COUNT_NOOP; a step is one coordinate of one wave-sweep).  Counted by the GROUP, MFMA and
+ * LMF kernels (what RCPPML_CD_AUTO dispatches to). */
 RCPPML_GPU_API int rcppml_hip_ctx_stats(rcppml_hip_ctx* ctx, int reset, unsigned long long* out4);
+/* Tuning / diagnostic switches of a context (0 = default behaviour for all of them). */
+enum { RCPPML_OPT_CD_COUNT_NOOP = 1 /* LMF kernel counts all-zero coordinate steps into stats[3] (slower) */,
+       RCPPML_OPT_CD_LMF_LANE_GROUPS = 2 /* 1, 2 or 4 lane groups per column instead of the size heuristic */,
+       RCPPML_OPT_CD_LMF_WAVES_PER_SIMD = 3 /* resident persistent waves per SIMD instead of the heuristic */,
+       RCPPML_OPT_CD_NO_LMF = 4 /* RCPPML_CD_AUTO falls back to the 32- / 16-column MFMA kernels */ };
+RCPPML_GPU_API int rcppml_hip_ctx_set_option(rcppml_hip_ctx* ctx, int option, int value);
 
 /* One-time setup of a fit, on the device.
  * rcppml_hip_transpose_csc: CSC of A^T from the CSC of A (rows x cols; all pointers device memory; t_col_ptr rows+1 ints,

@@ -13,14 +13,16 @@ LIB_PATH = os.environ.get("RCPPML_GPU_LIB_PATH") or os.path.join(_HERE, "lib", "
 _lib = None
 
 F32, F64 = 0, 1
-CD_AUTO, CD_LANE, CD_WAVE, CD_GROUP, CD_MFMA, CD_MFMA16 = 0, 1, 2, 5, 6, 7
+CD_AUTO, CD_LANE, CD_WAVE, CD_GROUP, CD_MFMA, CD_MFMA16, CD_LMF = 0, 1, 2, 5, 6, 7, 8
+# rcppml_hip_ctx_set_option
+OPT_CD_COUNT_NOOP, OPT_CD_LMF_LANE_GROUPS, OPT_CD_LMF_WAVES_PER_SIMD, OPT_CD_NO_LMF = 1, 2, 3, 4
 
 # Every symbol include/rcppml_gpu.h declares (tests check the library exports all of them).
 EXPORTED_SYMBOLS = [
     "rcppml_gpu_detect", "rcppml_gpu_nmf_unified_float", "rcppml_gpu_nmf_unified_double", "rcppml_gpu_nmf_ex",
     "rcppml_gpu_nmf_cv_unified_float", "rcppml_gpu_nmf_cv_unified_double", "rcppml_gpu_nmf_cv_ex", "rcppml_gpu_nmf_zerocopy_double",
     "rcppml_gpu_nnls_double", "rcppml_gpu_evaluate_mse_double", "rcppml_gpu_last_error",
-    "rcppml_hip_ctx_create", "rcppml_hip_ctx_destroy", "rcppml_hip_ctx_sync", "rcppml_hip_ctx_stats", "rcppml_hip_transpose_csc", "rcppml_hip_cast", "rcppml_hip_gram", "rcppml_hip_rhs",
+    "rcppml_hip_ctx_create", "rcppml_hip_ctx_destroy", "rcppml_hip_ctx_sync", "rcppml_hip_ctx_stats", "rcppml_hip_ctx_set_option", "rcppml_hip_transpose_csc", "rcppml_hip_cast", "rcppml_hip_gram", "rcppml_hip_rhs",
     "rcppml_hip_solve_cd", "rcppml_hip_order_columns", "rcppml_hip_solve_chol", "rcppml_hip_row_norms", "rcppml_hip_apply_scaling",
     "rcppml_hip_sumsq", "rcppml_hip_loss_mse", "rcppml_hip_solve_masked", "rcppml_hip_loss_nonzeros",
     "rcppml_hip_solve_irls_nb", "rcppml_hip_nb_size_update", "rcppml_hip_nb_loss", "rcppml_hip_solve_irls", "rcppml_hip_irls_loss", "rcppml_hip_apply_l21", "rcppml_hip_angular_posthoc", "rcppml_hip_solve_cv", "rcppml_hip_cv_test_error", "rcppml_hip_mul_rows", "rcppml_hip_apply_graph_reg", "rcppml_hip_dispersion_update", "rcppml_hip_vec_global", "rcppml_hip_spz_info", "rcppml_hip_spz_decode",
@@ -73,7 +75,7 @@ def lib():
         except OSError as e:  # e.g. libamdhip64 missing
             raise BackendError("cannot load %s: %s" % (LIB_PATH, e))
         _lib.rcppml_gpu_last_error.restype = C.c_char_p
-        for name in ("rcppml_hip_ctx_create", "rcppml_hip_ctx_sync", "rcppml_hip_ctx_stats", "rcppml_hip_transpose_csc", "rcppml_hip_cast", "rcppml_hip_gram", "rcppml_hip_rhs",
+        for name in ("rcppml_hip_ctx_create", "rcppml_hip_ctx_sync", "rcppml_hip_ctx_stats", "rcppml_hip_ctx_set_option", "rcppml_hip_transpose_csc", "rcppml_hip_cast", "rcppml_hip_gram", "rcppml_hip_rhs",
                      "rcppml_hip_solve_cd", "rcppml_hip_order_columns", "rcppml_hip_solve_chol", "rcppml_hip_row_norms",
                      "rcppml_hip_apply_scaling",
                      "rcppml_hip_sumsq", "rcppml_hip_loss_mse", "rcppml_hip_solve_masked", "rcppml_hip_loss_nonzeros",
@@ -353,11 +355,15 @@ class Context:
     def sync(self):
         _chk(lib().rcppml_hip_ctx_sync(self._h), "ctx_sync")
 
+    def set_option(self, option, value):
+        _chk(lib().rcppml_hip_ctx_set_option(self._h, C.c_int(option), C.c_int(value)), "ctx_set_option")
+
     def stats(self, reset=False):
-        """Work counters: dict(cd_column_sweeps, cd_columns) since creation / the last reset (synchronises)."""
+        """Work counters since creation / the last reset (synchronises): cd_column_sweeps, cd_columns; cd_slot_sweeps (persistent
+        LMF kernel: column slots x wave sweeps, idle and correction sweeps included) and cd_noop_steps (OPT_CD_COUNT_NOOP)."""
         out = (C.c_ulonglong * 4)()
         _chk(lib().rcppml_hip_ctx_stats(self._h, C.c_int(1 if reset else 0), out), "ctx_stats")
-        return dict(cd_column_sweeps=int(out[0]), cd_columns=int(out[1]))
+        return dict(cd_column_sweeps=int(out[0]), cd_columns=int(out[1]), cd_slot_sweeps=int(out[2]), cd_noop_steps=int(out[3]))
 
     def transpose_csc(self, dt, rows, cols, col_ptr, row_idx, values, t_col_ptr, t_row_idx, t_values):
         _chk(lib().rcppml_hip_transpose_csc(self._h, C.c_int(dt), C.c_int(rows), C.c_int(cols), _dptr(col_ptr), _dptr(row_idx),

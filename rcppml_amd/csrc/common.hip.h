@@ -72,7 +72,11 @@ struct rcppml_hip_ctx {
     struct Buf { void* ptr = nullptr; size_t bytes = 0; };
     Buf bufs[WS_COUNT];
     // device counters read by rcppml_hip_ctx_stats: [0] column-sweeps executed by the CD kernels, [1] columns solved
+    //   [2] slot-sweeps executed by the persistent CD kernel (idle and correction sweeps included), [3] coordinate steps of
+    //   that kernel in which no column of the wave moved (only counted when opt_cd_count is set)
     unsigned long long* stats = nullptr;
+    // rcppml_hip_ctx_set_option
+    int opt_cd_count = 0, opt_lmf_lg = 0, opt_lmf_wps = 0, opt_cd_no_lmf = 0;
     // Grow-only scratch.  Growth frees the old block with hipFree, which synchronises the device,
     // so no in-flight kernel can still be using it.
     void* scratch(int slot, size_t bytes) {

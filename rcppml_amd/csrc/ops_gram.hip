@@ -37,6 +37,16 @@ extern "C" int rcppml_hip_ctx_sync(rcppml_hip_ctx* c) {
     try { HIPCHK(hipStreamSynchronize(c->stream)); return 0; }
     RCPPML_CATCH_RET
 }
+extern "C" int rcppml_hip_ctx_set_option(rcppml_hip_ctx* c, int option, int value) {
+    if (!c) return 1;
+    switch (option) {
+        case RCPPML_OPT_CD_COUNT_NOOP: c->opt_cd_count = value; return 0;
+        case RCPPML_OPT_CD_LMF_LANE_GROUPS: c->opt_lmf_lg = value; return 0;
+        case RCPPML_OPT_CD_LMF_WAVES_PER_SIMD: c->opt_lmf_wps = value; return 0;
+        case RCPPML_OPT_CD_NO_LMF: c->opt_cd_no_lmf = value; return 0;
+        default: rcppml_err() = "unknown option"; return 1;
+    }
+}
 extern "C" int rcppml_hip_ctx_stats(rcppml_hip_ctx* c, int reset, unsigned long long* out4) {
     try {
         HIPCHK(hipStreamSynchronize(c->stream));

@@ -99,6 +99,11 @@ static void cd_mfma_launch(rcppml_hip_ctx* c, const float* G, const float* /*unu
     HIPCHK(hipGetLastError());
 }
 
+
+// Lane = column MFMA variant (fp32, k <= 64, SIMPLE steps): ops_cd_lmf.hip (its own translation unit and flags)
+void rcppml_cd_lmf_dispatch(rcppml_hip_ctx* c, const float* G, const float* B, float* X, int k, int64_t ncols, float l1_pre,
+                            int warm, int zero_init, int maxit, float tol, float ub_post, int* sweeps, const int* order);
+
 // 16-column MFMA variant: v_mfma_f64_16x16x4_f64 (k <= 128) / v_mfma_f32_16x16x4_f32 (k <= 64), four coordinates per instruction.
 template <class T, int NT>
 static void cd_mfma64_launch(rcppml_hip_ctx* c, const T* G, const T* /*unused*/, const T* B, T* X, int k,
@@ -156,6 +161,20 @@ static void solve_cd_impl(rcppml_hip_ctx* c, const T* G, const T* B, T* X, int k
         return;
     }
     int KP = solve_kp(k);
+    // fp32 NMF half-updates (non-negativity only, k <= 64) can run on the lane = column MFMA kernel (kernels_cd_lmf.hip.h).
+    // Measured (tools/cd_bench.py, tools/cd_c2_bench.py): it wins by 25-35 % for k <= 32 once every SIMD gets a 64-column wave
+    // (100 000 x k=32: 0.108 vs 0.165 ms per 20 sweeps), and ties or loses at 32 < k <= 64 on C2-sized sides (the 64-row update
+    // is matrix-pipe bound either way and 100 000 columns do not fill 2 x 1024 waves of 64) -- so AUTO takes it for k <= 32 only.
+    const bool lmf_ok = std::is_same<T, float>::value && k <= 64 && nonneg && ub_cd <= T(0) && l1_cd == T(0) && l2_cd == T(0) && maxit >= 1;
+    if (variant == RCPPML_CD_LMF && !lmf_ok) variant = RCPPML_CD_AUTO;
+    if (variant == RCPPML_CD_AUTO && lmf_ok && k <= 32 && ncols >= (int64_t)256 * c->num_cu && !c->opt_cd_no_lmf &&
+        !exp_env("RCPPML_GPU_CD_VARIANT"))
+        variant = RCPPML_CD_LMF;
+    if (variant == RCPPML_CD_LMF) {
+        if constexpr (std::is_same<T, float>::value)
+            rcppml_cd_lmf_dispatch(c, G, B, X, k, ncols, l1_pre, warm, zero_init, maxit, tol, ub_post, sweeps, order);
+        return;
+    }
     if (variant == RCPPML_CD_AUTO) {
         const char* e = exp_env("RCPPML_GPU_CD_VARIANT");
         if (e && !strcmp(e, "lane")) variant = RCPPML_CD_LANE;

@@ -104,11 +104,11 @@ def _cd_problem(k, n, dtype, seed):
     return G, B, X0
 
 
-VARIANTS = ["lane", "wave", "group", "mfma", "mfma16"]     # mfma: fp32 k <= 64 (falls back to group otherwise)
+VARIANTS = ["lane", "wave", "group", "mfma", "mfma16", "lmf"]     # mfma: fp32 k <= 64 (falls back to group otherwise); lmf: fp32 k <= 64, plain non-negative steps (AUTO otherwise)
 
 
 def _var(_abi, name):
-    return dict(lane=_abi.CD_LANE, wave=_abi.CD_WAVE, group=_abi.CD_GROUP, mfma=_abi.CD_MFMA, mfma16=_abi.CD_MFMA16)[name]
+    return dict(lane=_abi.CD_LANE, wave=_abi.CD_WAVE, group=_abi.CD_GROUP, mfma=_abi.CD_MFMA, mfma16=_abi.CD_MFMA16, lmf=_abi.CD_LMF)[name]
 
 
 @pytest.mark.parametrize("variant", VARIANTS)
@@ -180,7 +180,7 @@ def test_cd_lane_equals_wave(env, dtype):
     k, n = 32, 200
     G, B, X0 = _cd_problem(k, n, dtype, 5)
     outs = []
-    for var in (_abi.CD_LANE, _abi.CD_WAVE, _abi.CD_GROUP, _abi.CD_MFMA, _abi.CD_MFMA16):
+    for var in (_abi.CD_LANE, _abi.CD_WAVE, _abi.CD_GROUP, _abi.CD_MFMA, _abi.CD_MFMA16, _abi.CD_LMF):
         dX = _dev(torch, X0.copy())
         ctx.solve_cd(_dt(_abi, dtype), _dev(torch, G), _dev(torch, B), dX, k, n, warm=1, maxit=30, tol=1e-8, variant=var)
         outs.append(dX.cpu().numpy())
@@ -373,7 +373,7 @@ def test_order_columns_permutation_and_order_invariance(env, n):
     Fm = rs.uniform(size=(4 * k, k))
     G = (Fm.T @ Fm).astype(np.float32)
     B = (rs.standard_normal((n, k)) * 2 + 1).astype(np.float32)
-    for variant in (_abi.CD_MFMA, _abi.CD_MFMA16):
+    for variant in (_abi.CD_MFMA, _abi.CD_MFMA16, _abi.CD_LMF):
         outs = []
         for use in (False, True):
             dX = torch.zeros((n, k), dtype=torch.float32, device="cuda")
@@ -381,3 +381,54 @@ def test_order_columns_permutation_and_order_invariance(env, n):
                            col_order=d_order if use else None)
             outs.append(dX.cpu().numpy())
         assert np.array_equal(outs[0], outs[1]), variant
+
+
+
+@pytest.mark.parametrize("lg", [1, 2, 4])
+@pytest.mark.parametrize("k", [7, 20, 32, 33, 48, 64])
+def test_cd_lmf_geometries_and_refill(env, lg, k):
+    """The persistent lane = column kernel (kernels_cd_lmf.hip.h) in every geometry: 1, 2, 4 lane groups per column, both
+    paddings (32 / 64), ONE resident wave per SIMD forced so that most columns arrive by refill through the ticket queue.
+    With a fixed sweep count its residual chains are the reference's sequential single-rounded fma chains, i.e. the lane-group
+    VALU kernel's: bit-identical results (the 32-column MFMA kernel's v_mfma_f32_32x32x2 differs from that chain in the last
+    bit); with the early exit on, sweep counts and iterates against the oracle's cd_nnls_col_fixed restatement
+    (nnls_batch.hpp:70-132)."""
+    torch, _abi, ctx = env
+    n = 70000 if lg == 1 else (36000 if lg == 2 else 20000)       # > 1024 waves x 64 / lg slots: refills happen
+    rs = np.random.default_rng(100 * lg + k)
+    Fm = rs.uniform(size=(4 * k + 5, k))
+    G = (Fm.T @ Fm).astype(np.float32)
+    G[np.diag_indices(k)] += np.float32(1e-15)
+    B = (rs.standard_normal((n, k)) * 3 + 1).astype(np.float32)
+    X0 = rs.uniform(size=(n, k)).astype(np.float32)
+    dG, dB = _dev(torch, G), _dev(torch, B)
+    ctx.set_option(_abi.OPT_CD_LMF_LANE_GROUPS, lg)
+    ctx.set_option(_abi.OPT_CD_LMF_WAVES_PER_SIMD, 1)
+    try:
+        for kw in (dict(warm=1), dict(warm=0), dict(zero_init=1), dict(warm=1, l1_pre=0.3, ub_post=0.4)):
+            outs = []
+            for var in (_abi.CD_GROUP, _abi.CD_LMF):
+                dX = _dev(torch, X0.copy())
+                ctx.solve_cd(_abi.F32, dG, dB, dX, k, n, maxit=6, tol=0.0, variant=var, **kw)
+                outs.append(dX.cpu().numpy())
+            assert np.array_equal(outs[0], outs[1]) and not np.signbit(outs[1]).any(), kw
+        # early exit: per-column sweep counts and iterates vs the oracle on a sample of columns; the work counters
+        ctx.stats(reset=True)
+        dX = _dev(torch, X0.copy())
+        d_sw = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+        ctx.solve_cd(_abi.F32, dG, dB, dX, k, n, warm=1, maxit=60, tol=1e-4, variant=_abi.CD_LMF, sweeps_out=d_sw)
+        X, sw = dX.cpu().numpy(), d_sw.cpu().numpy()
+        st = ctx.stats(reset=True)
+        assert sw.min() >= 1 and sw.max() <= 60
+        assert st["cd_columns"] == n and st["cd_column_sweeps"] == int(sw.sum())
+        assert st["cd_slot_sweeps"] >= st["cd_column_sweeps"] + n       # + one correction sweep per column
+        nbad = 0
+        for j in rs.choice(n, 48, replace=False):
+            b = B[j] - G @ X0[j]
+            xr, _, it = O.cd_col(G, b.astype(np.float32), X0[j].copy(), maxit=60, tol=1e-4)
+            assert np.abs(X[j] - xr).max() <= 3e-4 * max(1.0, np.abs(xr).max()), j
+            nbad += int(abs(int(sw[j]) - int(it)) > 1)       # v_rcp_f32 in the tolerance term: the exit sweep may differ by one
+        assert nbad <= 2
+    finally:
+        ctx.set_option(_abi.OPT_CD_LMF_LANE_GROUPS, 0)
+        ctx.set_option(_abi.OPT_CD_LMF_WAVES_PER_SIMD, 0)

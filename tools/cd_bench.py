@@ -16,7 +16,12 @@ G = ops.gram(F, 1e-15, 0.0)
 for n in (20000, 100000, 400000):
     X = torch.rand((n, k), device="cuda", dtype=td, generator=g)
     B = X @ G + 0.1 * torch.randn((n, k), device="cuda", dtype=td, generator=g)
-    for variant, name in ((_abi.CD_AUTO, "auto"), (_abi.CD_MFMA16, "mfma16"), (_abi.CD_GROUP, "group")):
+    for variant, name, lg, wps in ((_abi.CD_AUTO, "auto", 0, 0), (_abi.CD_MFMA, "mfma32", 0, 0), (_abi.CD_MFMA16, "mfma16", 0, 0), (_abi.CD_GROUP, "group", 0, 0),
+                                   (_abi.CD_LMF, "lmf lg1 wps1", 1, 1), (_abi.CD_LMF, "lmf lg1 wps2", 1, 2), (_abi.CD_LMF, "lmf lg1 wps3", 1, 3),
+                                   (_abi.CD_LMF, "lmf lg2 wps2", 2, 2), (_abi.CD_LMF, "lmf lg2 wps3", 2, 3), (_abi.CD_LMF, "lmf lg4 wps3", 4, 3)):
+        if dtype != "f32" and variant == _abi.CD_LMF:
+            continue
+        ops.ctx.set_option(_abi.OPT_CD_LMF_LANE_GROUPS, lg); ops.ctx.set_option(_abi.OPT_CD_LMF_WAVES_PER_SIMD, wps)
         Xw = torch.zeros_like(X)
         def run():
             ops.ctx.solve_cd(ops.dt, G, B, Xw, k, n, 0.0, 0, 1, 0.0, 0.0, 1, sweeps, 0.0, 0.0, 0.0, variant)
