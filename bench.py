@@ -8,8 +8,8 @@ computes in: src/RcppFunctions_nmf.cpp:4-5; gpu/bridge_nmf.hpp:187).  Metric: AL
 column solves per second = steps * (m + n_total) / wall.
 
 N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL): columns are sharded, every rank
-owns a fresh 100000-column shard (weak scaling), W_T is replicated; per iteration one k-vector
-all-reduce, one fused [H H^T | H A^T] all-reduce, and -- the m columns of W being solved in row blocks,
+owns a fresh 100000-column shard (weak scaling), W_T is replicated; per iteration ONE fused
+all-reduce [H H^T | H A^T | row sums of H] and -- the m columns of W being solved in row blocks,
 one per rank -- one all-gather of W_T (rcppml_amd/als.py).
 
 Launch: at N = 1 the K timed iterations are K replays of one captured hipGraph of the iteration (the plugin's loop does
@@ -54,6 +54,14 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline work (s)")
     ap.add_argument("--no-plugin-figure", action="store_true", help="skip the PCIe-inclusive 73-pointer plugin call")
     ap.add_argument("--no-graph", action="store_true", help="time an eager launch loop instead of replays of one captured hipGraph")
+    ap.add_argument("--no-cpu-ref", action="store_true", help="skip the CPU reference fit (fp64 oracle, same inputs, same iteration count) "
+                                                              "behind loss_rel_dev_vs_cpu_ref")
+    ap.add_argument("--no-fp64-leg", action="store_true", help="skip the fp64 (parity mode) run reported under `fp64`")
+    ap.add_argument("--data-shards", type=int, default=1, help="N = 1 only: build the matrix as the N = <data-shards> run does (that many "
+                                                              "column shards of cols / <data-shards>, each from its own generator "
+                                                              "stream) -- the single-rank twin of a multi-rank run")
+    ap.add_argument("--init-f32", action="store_true", help="fp64 run starting from the fp32-rounded factors (so that one CPU "
+                                                            "reference fit serves both precisions)")
     args = ap.parse_args()
     preset = {"c2": (20000, 100000, 0.01, 64), "c4": (30000, 162500, 0.03, 128)}[args.config]
     args.rows = args.rows or preset[0]
@@ -168,11 +176,22 @@ def main():
     m, n_loc, k = args.rows, args.cols, args.k
     n_total = n_loc * world
     dens = calibrated_density(m, k, args.density, seed=123)
-    A_loc, _, _ = data.simulate_nmf_sparse(m, n_loc, k, dens, seed=123, device=torch.device("cuda", local_rank),
-                                           col_offset=rank * n_loc, ncol_total=n_total)
+    if world == 1 and args.data_shards > 1:
+        if n_loc % args.data_shards:
+            raise SystemExit("--cols must be a multiple of --data-shards")
+        nsh = n_loc // args.data_shards
+        parts = [data.simulate_nmf_sparse(m, nsh, k, dens, seed=123, device=torch.device("cuda", local_rank), col_offset=r * nsh,
+                                          ncol_total=n_total)[0] for r in range(args.data_shards)]
+        off = np.cumsum([0] + [a.nnz for a in parts])
+        A_loc = data.CSC((m, n_loc), np.concatenate([parts[0].p[:1]] + [a.p[1:].astype(np.int64) + off[r] for r, a in enumerate(parts)]),
+                         np.concatenate([a.i for a in parts]), np.concatenate([a.x for a in parts]))
+    else:
+        A_loc, _, _ = data.simulate_nmf_sparse(m, n_loc, k, dens, seed=123, device=torch.device("cuda", local_rank),
+                                               col_offset=rank * n_loc, ncol_total=n_total)
     At_loc = A_loc.transpose()
     nd = np.float32 if args.dtype == "f32" else np.float64
-    W0, H0 = data.init_factors(args.seed, k, m, n_loc, nd, col_offset=rank * n_loc, n_total=n_total)
+    W0, H0 = data.init_factors(args.seed, k, m, n_loc, np.float32 if args.init_f32 else nd, col_offset=rank * n_loc, n_total=n_total)
+    W0, H0 = W0.astype(nd), H0.astype(nd)
     cfg = als.AlsConfig(k=k, max_iter=args.warmup + args.steps, tol=0.0, cd_maxit=args.cd_maxit,
                         solver_mode=0 if args.solver == "cd" else 1,
                         cd_variant={"auto": 0, "lane": 1, "wave": 2}[args.variant], order_columns=not args.no_order)
@@ -180,7 +199,9 @@ def main():
     # (rcppml_amd/csrc/plugin.hip) issues its steady-state iterations; an eager loop pays ~3 us of launch gap per kernel, ~35
     # kernels per iteration.  Everything then lives on a side stream (a capture cannot run on the default stream); the device
     # library is bound to it through the context's stream.  N > 1 (collectives in the loop) and --no-graph time the eager loop.
-    use_graph = world == 1 and not args.no_graph
+    # (a captured iteration bakes in the host-side branches of step(): warm start, Gram reuse, sweep-sorted order -- all in
+    # their steady state only from the third iteration on, so shorter warm-ups time the eager loop)
+    use_graph = world == 1 and not args.no_graph and args.warmup >= 2
     side = torch.cuda.Stream(device=local_rank) if use_graph else None
     stream_ctx = torch.cuda.stream(side) if use_graph else contextlib.nullcontext()
     with stream_ctx:
@@ -196,7 +217,7 @@ def main():
                         order={sd: {key: (v.clone() if hasattr(v, "clone") else v) for key, v in o.items()} for sd, o in ops._order.items()})
 
         def restore(snap):
-            st.W_T.copy_(snap["W"]); st.H.copy_(snap["H"]); st.d.copy_(snap["d"]); st.iter = snap["it"]
+            st.set_factors(W_T=snap["W"], H=snap["H"], d=snap["d"], iteration=snap["it"])
             st.G_wt.copy_(snap["Gwt"]); st._gwt_of_current_w = snap["gwt_ok"]     # (the loss Gram doubles as the next H-side Gram)
             for sd, o in snap["order"].items():
                 for key, v in o.items():
@@ -418,6 +439,34 @@ def main():
             except Exception as e:  # the baseline must never take the GPU number down with it
                 out["cpu_baseline"] = {"value": None, "unit": "cols/s", "cores": os.cpu_count(), "kind": "port",
                                        "sample": "failed: %r" % (e,)}
+        if world == 1 and args.solver == "cd" and args.dtype == "f32" and k <= 64:
+            try:
+                out["cd_noop_steps"] = cd_noop_fraction(st, ops, cfg, k)
+            except Exception as e:
+                out["cd_noop_steps"] = {"error": repr(e)}
+        # ---- the metric's second half: deviation of the fit's loss from a CPU reference fit (fp64 oracle restatement of
+        # nmf_fit<CPU>, same matrix, same starting factors, same number of iterations, tol = 0; outside the timed region)
+        ref_loss = None
+        if world == 1 and not args.no_cpu_ref:
+            try:
+                from oracle import oracle as O
+                t0 = time.perf_counter()
+                ref = O.nmf_fit(_to_oracle(A_loc), W0.astype(np.float64), H0.astype(np.float64), np.float64,
+                                max_iter=args.warmup + args.steps, tol=0.0, cd_maxit=args.cd_maxit, cd_tol=1e-8,
+                                solver_mode=0 if args.solver == "cd" else 1, threads=0, native=True)
+                ref_loss = ref.loss
+                out["cpu_ref"] = {"loss": ref.loss, "iterations": int(ref.iter), "dtype": "f64", "threads": O.num_threads(),
+                                  "seconds": time.perf_counter() - t0,
+                                  "what": "oracle/nmf_oracle.cpp nmf_fit (restatement of nmf/fit_cpu.hpp), fp64, same CSC and starting "
+                                          "factors as the GPU run, same iteration count, tol = 0"}
+                out["loss_rel_dev_vs_cpu_ref"] = abs(final_loss - ref.loss) / abs(ref.loss)
+            except Exception as e:
+                out["cpu_ref"] = {"error": repr(e)}
+        if world == 1 and not args.no_fp64_leg and args.dtype == "f32":
+            try:
+                out["fp64"] = fp64_leg(args, ref_loss)
+            except Exception as e:
+                out["fp64"] = {"error": repr(e)}
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
@@ -446,6 +495,54 @@ def plugin_figure(A, m, n, k, seed):
     return {"entry": "rcppml_gpu_nmf_unified_float", "ms_per_iteration": slope * 1e3, "ms_per_iteration_steady": steady * 1e3,
             "setup_ms": (t[1] - slope) * 1e3, "fit_11_iterations_ms": t[11] * 1e3, "fit_21_iterations_ms": t[21] * 1e3,
             "cols_per_s_11_iterations": 11 * (m + n) / t[11], "cols_per_s_21_iterations": 21 * (m + n) / t[21]}
+
+
+def cd_noop_fraction(st, ops, cfg, k):
+    """how many (wave, coordinate) steps of the CD solve move NO column of the wave (b - G * 0 is exact, such a
+    step could skip its matrix instructions).  One extra solve per side on copies of the live state with the counting build of
+    the lane = column kernel (kernels_cd_lmf.hip.h), 16 and 32 columns per wave, in the sweep-sorted work order."""
+    from rcppml_amd import _abi
+    ctx = ops.ctx
+    res = {}
+    for side, F, X, csc in (("H", st.W_T, st.H, st.A), ("W", st.H, st.W_T, st.At)):
+        G = ops.gram(F, 1e-15, 0.0)
+        B = ops.rhs(csc, F)
+        o = ops._order.get(side)
+        order = o["order"] if (o is not None and o["valid"] and X.shape[0] >= 16384) else None
+        for lg, cols in ((4, 16), (2, 32)):
+            Xc = X.clone()
+            ctx.set_option(_abi.OPT_CD_LMF_LANE_GROUPS, lg)
+            ctx.set_option(_abi.OPT_CD_LMF_WAVES_PER_SIMD, 2)
+            ctx.set_option(_abi.OPT_CD_COUNT_NOOP, 1)
+            ctx.stats(reset=True)
+            ctx.solve_cd(ops.dt, G, B, Xc, k, Xc.shape[0], warm=1, maxit=cfg.cd_maxit, tol=cfg.cd_tol, variant=_abi.CD_LMF, col_order=order)
+            stt = ctx.stats(reset=True)
+            steps = stt["cd_slot_sweeps"] / cols * 64        # wave-sweeps x 64 coordinates (k padded to 64)
+            res["%s_%d_columns_per_wave" % (side, cols)] = stt["cd_noop_steps"] / max(steps, 1)
+        for opt in (_abi.OPT_CD_LMF_LANE_GROUPS, _abi.OPT_CD_LMF_WAVES_PER_SIMD, _abi.OPT_CD_COUNT_NOOP):
+            ctx.set_option(opt, 0)
+    res["what"] = "fraction of (wave, coordinate) steps in which every column's step is exactly 0, steady state, sweep-sorted order"
+    return res
+
+
+def fp64_leg(args, ref_loss):
+    """The same workload in fp64 (parity mode) as a child process: ms per step, cols/s and the loss deviation from the CPU
+    reference fit.  Reported beside the fp32 headline; never `value`."""
+    cmd = [sys.executable, os.path.abspath(__file__), "--dtype", "f64", "--init-f32", "--no-cpu-baseline", "--no-plugin-figure",
+           "--no-cpu-ref", "--no-fp64-leg", "--steps", str(args.steps), "--warmup", str(args.warmup), "--config", args.config,
+           "--rows", str(args.rows), "--cols", str(args.cols), "--density", str(args.density), "--k", str(args.k),
+           "--solver", args.solver, "--cd-maxit", str(args.cd_maxit), "--seed", str(args.seed)]
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    line = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    if p.returncode != 0 or not line:
+        raise RuntimeError("fp64 leg failed: rc %d %s" % (p.returncode, p.stderr[-400:]))
+    r = json.loads(line[-1])
+    out = {"ms_per_step": r["ms_per_step"], "value": r["value"], "unit": r["unit"], "final_loss": r["final_loss"], "launch": r["launch"],
+           "phases_ms_per_step": r["phases_ms_per_step"],
+           "what": "same matrix, same (fp32-rounded) starting factors, fp64 arithmetic (rcppml_gpu_nmf_unified_double's kernels)"}
+    if ref_loss is not None:
+        out["loss_rel_dev_vs_cpu_ref"] = abs(r["final_loss"] - ref_loss) / abs(ref_loss)
+    return out
 
 
 def _to_oracle(A):

@@ -5,10 +5,12 @@ mask) restated over the device-level C-ABI ops, with the one exchange step the p
 columns of A (and of H) are sharded over ranks:
 
     H side  : every rank holds all of W_T; columns of A are independent -> no communication.
-    scaling : row L1 (or squared L2) sums of H are sums over ALL columns      -> all-reduce of k values.
-    W side  : H H^T and H A^T are sums over all columns -> each rank forms its partial k x k Gram and
-              k x m right-hand side from its shard and ONE all-reduce carries [G_p | B_p] (fused buffer);
-              every rank then solves all m columns of W_T redundantly and W_T stays replicated.
+    scaling : row L1 (or squared L2) sums of H are sums over ALL columns, and so are
+    W side  : H H^T and H A^T -> each rank forms, from its shard and the UNSCALED H, its partial k x k Gram, k x m right-hand
+              side and k row sums, and ONE all-reduce carries [G_raw | B_raw | rowsums] (fused buffer); the scaling
+              D = diag(d) is applied afterwards, locally: G = D^-1 G_raw D^-1 + eps I, B = B_raw D^-1, H_loc <- H_loc D^-1 --
+              algebraically the reference's "normalise, then multiply", different rounding (inside the N > 1 tolerance).
+              The m columns of W_T are then solved in row blocks, one per rank, and one all-gather replicates W_T again.
 
 For world_size == 1 the same code runs with the collectives skipped, so N = 1 and N > 1 share every
 kernel launch.  The compute backend is an `ops` object; the product backend is `HipOps` (HIP kernels
@@ -290,13 +292,15 @@ class ShardedALS:
         self.H = ops.to_device(H0, ops.tdtype)
         self.d = ops.zeros((k,)) + 1
         self.Bh = ops.empty((self.n_loc, k))
-        # fused exchange buffer [G_p (k*k) | B_p (m*k)]: one all-reduce per iteration
-        self.xbuf = ops.empty((k * k + m * k,))
+        # fused exchange buffer [G_p (k*k) | B_p (m*k) | row sums of H (k)]: ONE all-reduce per iteration
+        self.xbuf = ops.empty((k * k + m * k + k,))
         self.Gp = self.xbuf[:k * k].view(k, k)
-        self.Bw = self.xbuf[k * k:].view(m, k)
+        self.Bw = self.xbuf[k * k:k * k + m * k].view(m, k)
+        self.xsums = self.xbuf[k * k + m * k:]
+        self.d_tmp = ops.empty((k,))
         self.G = ops.empty((k, k))
         self.G_saved = ops.empty((k, k))
-        self._gwt_of_current_w = False    # G_wt holds the Gram of the current W_T (set by step(); cleared by set_factors)
+        self._gwt_of_current_w = False    # G_wt holds the Gram of the current W_T (set by step(); cleared by set_factors())
         self.G_wt = ops.empty((k, k))
         self.sums = ops.empty((k,))
         self.loss_out = ops.zeros((4,), ops.torch.float64)
@@ -319,16 +323,22 @@ class ShardedALS:
             G_h = self.G
         ops.rhs(self.A, self.W_T, out=self.Bh, tag="rhs_H")
         ops.solve(G_h, self.Bh, self.H, cfg, "H", warm, tag="solve_H")
-        ops.row_norms(self.H, cfg.norm_type, out=self.sums)
-        comm.all_reduce_sum(self.sums, tag="all_reduce_rowsums")
-        ops.apply_scaling(self.H, self.sums, cfg.norm_type, self.d)
-        # ---- W half-update (fit_cpu.hpp:711-893)
         if comm.world > 1:
+            # ---- W half-update, sharded (fit_cpu.hpp:711-893): partial sums from the UNSCALED H, one all-reduce, then D^-1
+            ops.row_norms(self.H, cfg.norm_type, out=self.xsums)
             ops.gram(self.H, 0.0, 0.0, out=self.Gp, tag="gram")             # partial H_loc H_loc^T, eps after the sum
             ops.rhs(self.At, self.H, out=self.Bw, tag="rhs_W")
-            comm.all_reduce_sum(self.xbuf, tag="all_reduce_gram_rhs")
+            comm.all_reduce_sum(self.xbuf, tag="all_reduce_gram_rhs_rowsums")
+            ops.apply_scaling(self.H, self.xsums, cfg.norm_type, self.d)     # H_loc <- H_loc D^-1, d = global row norms
+            ops.apply_scaling(self.Bw, self.xsums, cfg.norm_type, self.d_tmp)        # B = B_raw D^-1
+            ops.apply_scaling(self.Gp, self.xsums, cfg.norm_type, self.d_tmp)        # G[:, g] /= d_g ...
+            self.Gp.copy_(self.Gp.t().contiguous())                                   # ... (k x k, symmetric up to rounding order)
+            ops.apply_scaling(self.Gp, self.xsums, cfg.norm_type, self.d_tmp)        # ... and G[f, :] /= d_f
             ops.add_diag(self.Gp, self.eps)
         else:
+            ops.row_norms(self.H, cfg.norm_type, out=self.sums)
+            ops.apply_scaling(self.H, self.sums, cfg.norm_type, self.d)
+            # ---- W half-update (fit_cpu.hpp:711-893)
             ops.gram(self.H, self.eps, 0.0, out=self.Gp, tag="gram")
             ops.rhs(self.At, self.H, out=self.Bw, tag="rhs_W")
         # G_saved = Gram of H before L2 (:719-722), G = G_saved + L2_W I (:738).  Without an L2 penalty on W both are the
@@ -383,6 +393,19 @@ class ShardedALS:
                     patience_counter = 0
             iterations = it + 1
         return dict(iter=iterations, converged=converged, loss=prev, tol=final_tol, loss_history=history)
+
+    def set_factors(self, W_T=None, H=None, d=None, iteration=None):
+        """Overwrite factors from outside (device tensors or arrays of the same shapes).  Invalidates the loss Gram that step()
+        would otherwise reuse as the next H-side Gram."""
+        if W_T is not None:
+            self.W_T.copy_(W_T if hasattr(W_T, "is_cuda") else self.ops.to_device(W_T, self.ops.tdtype))
+            self._gwt_of_current_w = False
+        if H is not None:
+            self.H.copy_(H if hasattr(H, "is_cuda") else self.ops.to_device(H, self.ops.tdtype))
+        if d is not None:
+            self.d.copy_(d if hasattr(d, "is_cuda") else self.ops.to_device(d, self.ops.tdtype))
+        if iteration is not None:
+            self.iter = int(iteration)
 
     def factors(self):
         """(W_T (m,k), d (k), H_loc (n_loc,k)) as float64 numpy, unsorted."""

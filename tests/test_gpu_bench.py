@@ -37,3 +37,55 @@ def test_bench_line_graph_and_eager_modes_agree():
     # same iterations, same kernels: the modes differ in how launches are issued, not in what is computed
     assert g["final_loss"] == e["final_loss"]
     assert g["roofline"]["mean_sweeps_per_column"] == e["roofline"]["mean_sweeps_per_column"]
+
+
+def test_bench_line_carries_cpu_reference_deviation_and_fp64_leg():
+    """BASELINE.json's metric is "cols solved/s + MSE vs CPU ref": the line holds the relative deviation of the fit's loss
+    from the CPU reference fit (fp64 oracle, same inputs, same iteration count) for the fp32 headline AND for the fp64 leg, the
+    latter inside the north star's 1e-6; plus the all-zero coordinate-step rate of the CD solve."""
+    d = _run_full()
+    assert d["cpu_ref"]["iterations"] == 7 and d["cpu_ref"]["dtype"] == "f64"
+    assert 0 <= d["loss_rel_dev_vs_cpu_ref"] < 2e-4                     # fp32 arithmetic vs the fp64 CPU fit
+    f = d["fp64"]
+    assert f["ms_per_step"] > 0 and f["unit"] == "cols/s"
+    assert 0 <= f["loss_rel_dev_vs_cpu_ref"] < 1e-6                     # the north star's bar
+    nz = d["cd_noop_steps"]
+    for key in ("H_16_columns_per_wave", "H_32_columns_per_wave", "W_16_columns_per_wave", "W_32_columns_per_wave"):
+        assert 0.0 <= nz[key] < 1.0
+
+
+def _run_full():
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--rows", "3000", "--cols", "24000", "--density", "0.01", "--k", "64",
+           "--steps", "4", "--warmup", "3", "--no-cpu-baseline", "--no-plugin-figure"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    return json.loads(out.stdout.strip().splitlines()[-1])
+
+
+@pytest.mark.parametrize("config", ["c2", "c4"])
+def test_bench_self_launcher_two_ranks_sharing_the_gpu(config):
+    """`python bench.py --gpus 2` without a launcher re-executes itself under torch.distributed.run (what the driver's first
+    multi-GPU run will do).  On this one-GPU box both ranks share cuda:0 and the collectives run over gloo
+    (RCPPML_BENCH_BACKEND / RCPPML_BENCH_SHARE_GPU): the sharded loop must see world size 2, issue ONE all-reduce and one
+    all-gather per iteration, and land on the loss of the single-rank run over the same 2 x cols columns."""
+    shape = ["--rows", "3000", "--cols", "12000", "--density", "0.01"] + (["--k", "64"] if config == "c2" else ["--k", "128"])
+    common = ["--config", config, "--steps", "3", "--warmup", "2", "--no-cpu-baseline", "--no-plugin-figure", "--no-cpu-ref",
+              "--no-fp64-leg", "--no-graph", "--dtype", "f64"]
+    env = dict(os.environ, RCPPML_BENCH_BACKEND="gloo", RCPPML_BENCH_SHARE_GPU="1")
+    two = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", *shape, *common], capture_output=True,
+                         text=True, timeout=900, cwd=ROOT, env=env)
+    assert two.returncode == 0, two.stderr[-3000:]
+    d2 = json.loads([l for l in two.stdout.splitlines() if l.startswith("{")][-1])
+    assert d2["n_gpus"] == 2 and d2["world_size_seen"] == 2 and d2["backend"] == "gloo"
+    coll = d2["collectives_ms_per_step"]
+    assert set(coll) == {"all_reduce_gram_rhs_rowsums", "all_gather_W"}
+    assert coll["all_reduce_gram_rhs_rowsums"]["calls_per_step"] == 1 and coll["all_gather_W"]["calls_per_step"] == 1
+    k = 64 if config == "c2" else 128
+    assert coll["all_reduce_gram_rhs_rowsums"]["bytes"] == 8 * (k * k + 3000 * k + k)
+    one_shape = [a if a != "12000" else "24000" for a in shape]
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *one_shape, "--data-shards", "2", *common], capture_output=True, text=True,
+                         timeout=900, cwd=ROOT)
+    assert one.returncode == 0, one.stderr[-3000:]
+    d1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
+    # fp64: the two runs differ by the summation order of the reduced Gram / right-hand side and by "scale after the sum"
+    assert abs(d2["final_loss"] - d1["final_loss"]) / abs(d1["final_loss"]) < 1e-9
