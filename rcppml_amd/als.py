@@ -117,7 +117,10 @@ class HipOps:
         """Build the LDS row-tiled plan of csc for rank k (large inputs only; kept in csc["plans"], used by rhs())."""
         if os.environ.get("RCPPML_GPU_RHS_TILED", "1") == "0" or csc["nnz"] < min_nnz:
             return None
-        plan = self.ctx.rhs_plan(self.dt, csc["p"], csc["i"], csc["x"], csc["cols"], csc["rows"], k, partitions, slots)
+        try:
+            plan = self.ctx.rhs_plan(self.dt, csc["p"], csc["i"], csc["x"], csc["cols"], csc["rows"], k, partitions, slots)
+        except self._abi.BackendError:      # the plan is an optimisation: without it the products run on the gather kernel
+            plan = None
         if plan is not None:
             csc.setdefault("plans", {})[k] = plan
         return plan

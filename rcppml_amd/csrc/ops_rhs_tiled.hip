@@ -91,19 +91,20 @@ rcppml_rhs_plan* build_plan(rcppml_hip_ctx* c, int dtype, const int* colptr, con
     const double nseg = (double)ncols * (double)G.ntiles;
     const int cand[6] = {2, 3, 4, 5, 6, 8};
     int S = 0;
-    double best = 0;
+    double best = 0, ovf_est = 0;
+    auto spilled = [&](int s) { double o = 0; for (int b = s + 1; b < RT_MAX_HIST; ++b) o += (double)hh[b] * (b - s); return o; };
     for (int ci = 0; ci < 6; ++ci) {
         const int s = cand[ci];
-        double ovf = 0;
-        for (int b = s + 1; b < RT_MAX_HIST; ++b) ovf += (double)hh[b] * (b - s);
+        const double ovf = spilled(s);
         const double cost = nseg * s + 6.0 * ovf;          // a spilled nonzero costs about six slot steps in the gather kernel
-        if (S == 0 || cost < best) { S = s; best = cost; }
+        if (S == 0 || cost < best) { S = s; best = cost; ovf_est = ovf; }
     }
     if (force_S > 0) {
         bool okS = false;
         for (int ci = 0; ci < 6; ++ci) okS |= cand[ci] == force_S;
         if (!okS) throw std::runtime_error("rhs_plan: slot count must be one of 2,3,4,5,6,8");
         S = force_S;
+        ovf_est = spilled(S);
     }
     G.S = S;
     G.dbg = 0;
@@ -143,6 +144,24 @@ rcppml_rhs_plan* build_plan(rcppml_hip_ctx* c, int dtype, const int* colptr, con
             }
         }
     if (best_t < 0) return nullptr;
+    if (force_S <= 0) {
+        // Is the input dense enough for fixed slots at all?  The slot stream holds ncols x ntiles x S slots whatever nnz is: a
+        // hypersparse matrix (200 000 x 200 000 with 1.1 M nonzeros: 313 M slots, 1.9 GB, ~1 ms per product against ~14 us for
+        // the gather kernel) must not get a plan.  Decline -- the caller then uses the gather kernel -- when the predicted fill
+        // is below a quarter, when the slot stream would exceed four times the CSC itself or half of the free device memory,
+        // or when the cost model says the gather kernel (12.5 ps per nonzero on the whole chip) is faster.
+        const int64_t cap0 = 4ll * bestnr * bestNW;
+        const double nslots_est = (double)((best_tiled + cap0 - 1) / cap0) * G.ntiles * bestNW * (double)(bestnr * S) * 4.0;
+        const double fill_est = ((double)pl->nnz - ovf_est) * ((double)best_tiled / (double)ncols) / std::max(nslots_est, 1.0);
+        const double stream_bytes = nslots_est * (sizeof(T) + 2.0);
+        size_t free_b = 0, total_b = 0;
+        HIPCHK(hipMemGetInfo(&free_b, &total_b));
+        // (small plans -- the unit tests' matrices -- are harmless either way and are left alone)
+        const bool big = stream_bytes > (double)(32u << 20);
+        if (stream_bytes > 0.5 * (double)free_b ||
+            (big && (fill_est < 0.25 || stream_bytes > 4.0 * (double)pl->nnz * (sizeof(T) + 4.0) || best_t > (double)pl->nnz * 12.5e-6 + 5.0)))
+            return nullptr;
+    }
 #ifdef RCPPML_EXPERIMENTS
     { const char* e1 = getenv("RCPPML_RT_NW"); const char* e2 = getenv("RCPPML_RT_NR");
       if (e1 && e2 && rt_launch::shape_ok(NV, S, atoi(e1), atoi(e2), (int)sizeof(T))) { bestNW = atoi(e1); bestnr = atoi(e2); best_tiled = ncols; } }

@@ -175,8 +175,8 @@ void fit(FitParams& P) {
     // plans (small input, rank or layout the kernel is not compiled for) keep the gather kernel.
     struct PlanGuard { rcppml_rhs_plan* p = nullptr; ~PlanGuard() { rcppml_hip_rhs_plan_destroy(p); } } planA, planT;
     if (!dense && P.nnz >= (1 << 20)) {
-        OPCHK(rcppml_hip_rhs_plan_create(c, dt, dAp.as<int>(), dAi.as<int>(), dAx.p, n, m, k, 0, 0, &planA.p));
-        OPCHK(rcppml_hip_rhs_plan_create(c, dt, dTp.as<int>(), dTi.as<int>(), dTx.p, m, n, k, 0, 0, &planT.p));
+        plan_or_none(rcppml_hip_rhs_plan_create(c, dt, dAp.as<int>(), dAi.as<int>(), dAx.p, n, m, k, 0, 0, &planA.p), planA.p);
+        plan_or_none(rcppml_hip_rhs_plan_create(c, dt, dTp.as<int>(), dTi.as<int>(), dTx.p, m, n, k, 0, 0, &planT.p), planT.p);
     }
     // ---- target regularisation (variant_helpers.hpp:107-146): standard (unfused) path, as in the reference (fit_cpu.hpp:430-433)
     const bool tgtH = P.target_H && P.target_lambda_H != 0, tgtW = P.target_W && P.target_lambda_W != 0;

@@ -134,6 +134,16 @@ inline void upload_ints(const int* src, size_t n, DevBuf& dst, hipStream_t s) {
     HIPCHK(hipStreamSynchronize(s));
 }
 
+// The LDS row-tiled plan is an optimisation: a plan that cannot be built (out of device memory, unsupported shape) is "no
+// plan" -- the products then run on the gather kernel -- never a failed fit.
+inline void plan_or_none(int rc, rcppml_rhs_plan*& plan) {
+    if (rc != 0) {
+        plan = nullptr;
+        rcppml_err().clear();
+        (void)hipGetLastError();          // a failed hipMalloc leaves a sticky-until-read error behind
+    }
+}
+
 }  // namespace rcppml_plugin
 using namespace rcppml_plugin;
 

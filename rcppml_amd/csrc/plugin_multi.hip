@@ -32,6 +32,12 @@ __global__ void mg_diag_add_kernel(T* __restrict__ G, int k, T v) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < k) G[(size_t)i * k + i] += v;
 }
+// G(f, g) /= d_f d_g: the scaling D^-1 applied to a Gram that was formed (and all-reduced) from the unscaled factor
+template <class T>
+__global__ void mg_scale_gram_kernel(T* __restrict__ G, int k, const T* __restrict__ d) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < k * k) G[e] = G[e] / d[e % k] / d[e / k];
+}
 // out[r][i] = sum_r in[r][i] for every replica r (shared-device stand-in of the all-reduce; fixed order)
 template <class T>
 __global__ void mg_local_sum_kernel(T* const* __restrict__ bufs, int n, size_t count) {
@@ -174,14 +180,18 @@ void fit_multi(FitParams& P, const std::vector<int>& devices, bool shared) {
         std::vector<int> p((size_t)s.n_loc + 1);
         for (int j = 0; j <= s.n_loc; ++j) p[j] = P.col_ptr[s.c0 + j] - e0;
         upload_ints(p.data(), p.size(), s.Ap, s.g->s);
-        upload_ints(P.row_idx + e0, nz, s.Ai, s.g->s);
-        upload_cast<T>(c, P.values + e0, nz, s.Ax, s.g->s);
+        // (an empty shard -- e0 == nnz, or c0 == n when the last column alone holds more than nnz / nd entries -- uploads a dummy
+        // element instead of reading one past the caller's arrays)
+        const int zero_i = 0; const double zero_d = 0.0;
+        upload_ints(s.nnz_loc > 0 ? P.row_idx + e0 : &zero_i, nz, s.Ai, s.g->s);
+        upload_cast<T>(c, s.nnz_loc > 0 ? P.values + e0 : &zero_d, nz, s.Ax, s.g->s);
         s.Tp.alloc(((size_t)m + 1) * sizeof(int));
         s.Ti.alloc(nz * sizeof(int));
         s.Tx.alloc(nz * sizeof(T));
         OPCHK(rcppml_hip_transpose_csc(c, dt, m, s.n_loc, s.Ap.template as<int>(), s.Ai.template as<int>(), s.Ax.p, s.Tp.template as<int>(), s.Ti.template as<int>(), s.Tx.p));
         upload_cast<T>(c, P.W, (size_t)k * m, s.W, s.g->s);
-        upload_cast<T>(c, P.H + (size_t)k * s.c0, (size_t)k * std::max(s.n_loc, 1), s.H, s.g->s);
+        if (s.n_loc > 0) upload_cast<T>(c, P.H + (size_t)k * s.c0, (size_t)k * s.n_loc, s.H, s.g->s);
+        else { std::vector<double> hz(k, 0.0); upload_cast<T>(c, hz.data(), (size_t)k, s.H, s.g->s); }
         s.d.alloc((size_t)k * sizeof(T));
         {
             std::vector<T> ones(k, T(1));
@@ -189,15 +199,15 @@ void fit_multi(FitParams& P, const std::vector<int>& devices, bool shared) {
             HIPCHK(hipStreamSynchronize(s.g->s));
         }
         s.Bh.alloc((size_t)k * std::max(s.n_loc, 1) * sizeof(T));
-        s.xbuf.alloc(((size_t)k * k + (size_t)k * m) * sizeof(T));           // [G_p | B_p]: one all-reduce
+        s.xbuf.alloc(((size_t)k * k + (size_t)k * m + (size_t)k) * sizeof(T));           // [G_p | B_p | row sums of H]: ONE all-reduce
         s.G.alloc((size_t)k * k * sizeof(T)); s.Gs.alloc((size_t)k * k * sizeof(T)); s.Gwt.alloc((size_t)k * k * sizeof(T));
         s.sums.alloc((size_t)k * sizeof(T));
         s.tr.alloc(sizeof(double)); s.loss.alloc(4 * sizeof(double));
         s.swH.alloc((size_t)std::max(s.n_loc, 1) * sizeof(int)); s.ordH.alloc((size_t)std::max(s.n_loc, 1) * sizeof(int));
         s.swW.alloc((size_t)m * sizeof(int)); s.ordW.alloc((size_t)m * sizeof(int));
         if (s.nnz_loc >= (1 << 20)) {
-            OPCHK(rcppml_hip_rhs_plan_create(c, dt, s.Ap.template as<int>(), s.Ai.template as<int>(), s.Ax.p, s.n_loc, m, k, 0, 0, &s.planA));
-            OPCHK(rcppml_hip_rhs_plan_create(c, dt, s.Tp.template as<int>(), s.Ti.template as<int>(), s.Tx.p, m, s.n_loc, k, 0, 0, &s.planT));
+            plan_or_none(rcppml_hip_rhs_plan_create(c, dt, s.Ap.template as<int>(), s.Ai.template as<int>(), s.Ax.p, s.n_loc, m, k, 0, 0, &s.planA), s.planA);
+            plan_or_none(rcppml_hip_rhs_plan_create(c, dt, s.Tp.template as<int>(), s.Ti.template as<int>(), s.Tx.p, m, s.n_loc, k, 0, 0, &s.planT), s.planT);
         }
     }
     Exchange X;
@@ -237,7 +247,7 @@ void fit_multi(FitParams& P, const std::vector<int>& devices, bool shared) {
         for (int r = 0; r < nd; ++r) {
             Shard<T>& s = *S[r];
             rcppml_hip_ctx* c = s.g->c;
-            if (s.n_loc == 0) { HIPCHK(hipSetDevice(s.dev)); HIPCHK(hipMemsetAsync(s.sums.p, 0, (size_t)k * sizeof(T), s.g->s)); continue; }
+            if (s.n_loc == 0) { HIPCHK(hipSetDevice(s.dev)); HIPCHK(hipMemsetAsync(s.xbuf.p, 0, s.xbuf.bytes, s.g->s)); continue; }
             OPCHK(rcppml_hip_gram(c, dt, s.W.p, k, m, eps, P.L2_H, s.G.p));
             if (s.planA) OPCHK(rcppml_hip_rhs_planned(c, s.planA, s.W.p, s.Bh.p));
             else OPCHK(rcppml_hip_rhs(c, dt, s.Ap.template as<int>(), s.Ai.template as<int>(), s.Ax.p, s.n_loc, s.W.p, k, s.Bh.p));
@@ -250,33 +260,28 @@ void fit_multi(FitParams& P, const std::vector<int>& devices, bool shared) {
             } else {
                 OPCHK(rcppml_hip_solve_chol(c, dt, s.G.p, s.Bh.p, s.H.p, k, s.n_loc, P.L1_H > 0 ? P.L1_H : 0.0, P.nonneg_H, P.ub_H));
             }
-            OPCHK(rcppml_hip_row_norms(c, dt, s.H.p, k, s.n_loc, P.norm_type, s.sums.p));   // partial sums (L1: sum |h|; L2: sum h^2)
+            // ================= W half-update (fit_cpu.hpp:711-893).  H H^T, H A^T and the row norms of H are all sums over ALL
+            // columns: every shard forms its partials from the UNSCALED H into one buffer [G_p | B_p | row sums] ...
+            OPCHK(rcppml_hip_row_norms(c, dt, s.H.p, k, s.n_loc, P.norm_type, T_ptr(s.xbuf, (size_t)k * k + (size_t)k * m)));   // L1: sum |h|; L2: sum h^2
+            OPCHK(rcppml_hip_gram(c, dt, s.H.p, k, s.n_loc, 0.0, 0.0, s.xbuf.p));               // eps after the sum
+            if (s.planT) OPCHK(rcppml_hip_rhs_planned(c, s.planT, s.H.p, T_ptr(s.xbuf, (size_t)k * k)));
+            else OPCHK(rcppml_hip_rhs(c, dt, s.Tp.template as<int>(), s.Ti.template as<int>(), s.Tx.p, m, s.H.p, k, T_ptr(s.xbuf, (size_t)k * k)));
         }
-        // the scaling needs the sums over ALL columns (variant_helpers.hpp:286-305): k values
-        for (int r = 0; r < nd; ++r) bufs[r] = S[r]->sums.p;
-        X.template all_reduce<T>(bufs, (size_t)k);
-        // ================= W half-update (fit_cpu.hpp:711-893): partial Gram and right-hand side, one all-reduce
-        for (int r = 0; r < nd; ++r) {
-            Shard<T>& s = *S[r];
-            rcppml_hip_ctx* c = s.g->c;
-            HIPCHK(hipSetDevice(s.dev));
-            if (s.n_loc > 0) {
-                OPCHK(rcppml_hip_apply_scaling(c, dt, s.H.p, k, s.n_loc, P.norm_type, s.sums.p, s.d.p));
-                OPCHK(rcppml_hip_gram(c, dt, s.H.p, k, s.n_loc, 0.0, 0.0, s.xbuf.p));               // eps after the sum
-                if (s.planT) OPCHK(rcppml_hip_rhs_planned(c, s.planT, s.H.p, T_ptr(s.xbuf, (size_t)k * k)));
-                else OPCHK(rcppml_hip_rhs(c, dt, s.Tp.template as<int>(), s.Ti.template as<int>(), s.Tx.p, m, s.H.p, k, T_ptr(s.xbuf, (size_t)k * k)));
-            } else {
-                OPCHK(rcppml_hip_apply_scaling(c, dt, s.H.p, k, 0, P.norm_type, s.sums.p, s.d.p));   // d from the global sums
-                HIPCHK(hipMemsetAsync(s.xbuf.p, 0, s.xbuf.bytes, s.g->s));
-            }
-        }
+        // ... ONE all-reduce per iteration ...
         for (int r = 0; r < nd; ++r) bufs[r] = S[r]->xbuf.p;
-        X.template all_reduce<T>(bufs, (size_t)k * k + (size_t)k * m);
+        X.template all_reduce<T>(bufs, (size_t)k * k + (size_t)k * m + (size_t)k);
         for (int r = 0; r < nd; ++r) {
             Shard<T>& s = *S[r];
             rcppml_hip_ctx* c = s.g->c;
             HIPCHK(hipSetDevice(s.dev));
             hipStream_t st = s.g->s;
+            // ... and the scaling D = diag(d) (variant_helpers.hpp:286-305) is applied after the sum: H_loc <- D^-1 H_loc,
+            // B = D^-1 B_raw, G = D^-1 G_raw D^-1 -- the reference's "normalise, then multiply" up to rounding
+            void* gsums = T_ptr(s.xbuf, (size_t)k * k + (size_t)k * m);
+            OPCHK(rcppml_hip_apply_scaling(c, dt, s.H.p, k, s.n_loc, P.norm_type, gsums, s.d.p));      // also d from the global sums
+            OPCHK(rcppml_hip_apply_scaling(c, dt, T_ptr(s.xbuf, (size_t)k * k), k, m, P.norm_type, gsums, s.sums.p));
+            hipLaunchKernelGGL(mg_scale_gram_kernel<T>, dim3((k * k + 255) / 256), dim3(256), 0, st, (T*)s.xbuf.p, k, (const T*)s.d.p);
+            HIPCHK(hipGetLastError());
             hipLaunchKernelGGL(mg_diag_add_kernel<T>, dim3((k + 63) / 64), dim3(64), 0, st, (T*)s.xbuf.p, k, (T)eps);   // gram.hpp:50-52
             HIPCHK(hipGetLastError());
             HIPCHK(hipMemcpyAsync(s.Gs.p, s.xbuf.p, (size_t)k * k * sizeof(T), hipMemcpyDeviceToDevice, st));           // G_saved (:719-722)

@@ -105,3 +105,31 @@ def test_planned_rhs_ineligible_shapes(env):
     B = O.Csc((A.rows, A.cols), A.p, i, A.x)
     torch, _abi, ctx = env
     assert ctx.rhs_plan(_abi.F32, _dev(torch, B.p), _dev(torch, B.i), _dev(torch, B.values(np.float32)), B.cols, B.rows, 64) is None
+
+
+def test_hypersparse_input_gets_no_plan(env):
+    """The slot stream has ncols x ntiles x S slots whatever nnz is: a 200 000 x 200 000 matrix with ~1.1 M nonzeros would need
+    ~313 M slots (1.9 GB) and ~1 ms per product where the gather kernel takes ~14 us.  The planner declines (fill below a
+    quarter / stream far beyond the CSC itself) and the harness keeps the gather kernel."""
+    torch, _abi, ctx = env
+    n = 200000
+    rs = np.random.default_rng(3)
+    cols = np.sort(rs.integers(0, n, size=1100000))
+    rows = rs.integers(0, n, size=cols.shape[0])
+    key = np.unique(cols.astype(np.int64) * n + rows)            # sorted by column, then row; duplicates removed
+    cols, rows = (key // n).astype(np.int32), (key % n).astype(np.int32)
+    p = np.zeros(n + 1, np.int32)
+    np.cumsum(np.bincount(cols, minlength=n), out=p[1:])
+    x = rs.uniform(0.5, 1.5, size=rows.shape[0]).astype(np.float32)
+    free0 = torch.cuda.mem_get_info()[0]
+    plan = ctx.rhs_plan(_abi.F32, _dev(torch, p), _dev(torch, rows), _dev(torch, x), n, n, 64)
+    assert plan is None
+    assert free0 - torch.cuda.mem_get_info()[0] < (64 << 20)       # and it did not get there by allocating the stream first
+    # the products still run (gather kernel) and are right: checksum sum_j B(:, j) = F^T (A 1)
+    F = rs.uniform(size=(n, 64)).astype(np.float32)
+    dB = torch.empty((n, 64), dtype=torch.float32, device="cuda")
+    ctx.rhs(_abi.F32, _dev(torch, p), _dev(torch, rows), _dev(torch, x), n, _dev(torch, F), 64, dB)
+    rowsum = np.bincount(rows, weights=x.astype(np.float64), minlength=n)
+    want = F.astype(np.float64).T @ rowsum
+    got = dB.double().sum(dim=0).cpu().numpy()
+    assert np.abs(got - want).max() / np.abs(want).max() < 1e-5
