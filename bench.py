@@ -56,6 +56,7 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="time an eager launch loop instead of replays of one captured hipGraph")
     ap.add_argument("--no-cpu-ref", action="store_true", help="skip the CPU reference fit (fp64 oracle, same inputs, same iteration count) "
                                                               "behind loss_rel_dev_vs_cpu_ref")
+    ap.add_argument("--no-noop-count", action="store_true", help="skip the extra CD solves that count all-zero coordinate steps")
     ap.add_argument("--no-fp64-leg", action="store_true", help="skip the fp64 (parity mode) run reported under `fp64`")
     ap.add_argument("--data-shards", type=int, default=1, help="N = 1 only: build the matrix as the N = <data-shards> run does (that many "
                                                               "column shards of cols / <data-shards>, each from its own generator "
@@ -380,18 +381,21 @@ def main():
         # HBM/fabric bytes per launch from the committed rocprofv3 PMC passes of this same command (FETCH_SIZE x2 per the
         # gfx950 correction + WRITE_SIZE, profiles/summarize.py); only meaningful for the default workload
         default_wl = (m, n_loc, k, args.dtype, world) == (20000, 100000, 64, "f32", 1)
-        pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc.json")
+        import glob
+        pmcs = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r[0-9][0-9]_pmc.json")))
+        pmc_path = pmcs[-1] if pmcs else ""          # the latest round's counter passes
+        pmc_name = "profiles/" + os.path.basename(pmc_path)
         if default_wl and os.path.exists(pmc_path):
             try:
                 pmc = json.load(open(pmc_path))
                 if "rhs_per_launch" in pmc:
                     roof_rhs["traffic"] = pmc["rhs_per_launch"]["hbm_bytes_per_launch"]
                     roof_rhs["traffic_over_algorithmic"] = roof_rhs["traffic"] / avg_bytes
-                    roof_rhs["traffic_source"] = "profiles/r02_pmc.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes; all kernels of one rhs call, mean of both sides)"
+                    roof_rhs["traffic_source"] = pmc_name + " (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes; all kernels of one rhs call, mean of both sides)"
                 for name, v in pmc.get("kernels", {}).items():
                     if roof_cd is not None and "cd_mfma_kernel" in name:
                         roof_cd["traffic"] = v["hbm_bytes_per_launch"]
-                        roof_cd["traffic_source"] = "profiles/r02_pmc.json"
+                        roof_cd["traffic_source"] = pmc_name
             except Exception:
                 pass
         out = {
@@ -439,7 +443,7 @@ def main():
             except Exception as e:  # the baseline must never take the GPU number down with it
                 out["cpu_baseline"] = {"value": None, "unit": "cols/s", "cores": os.cpu_count(), "kind": "port",
                                        "sample": "failed: %r" % (e,)}
-        if world == 1 and args.solver == "cd" and args.dtype == "f32" and k <= 64:
+        if world == 1 and args.solver == "cd" and args.dtype == "f32" and k <= 64 and not args.no_noop_count:
             try:
                 out["cd_noop_steps"] = cd_noop_fraction(st, ops, cfg, k)
             except Exception as e:

@@ -87,4 +87,56 @@ if os.path.exists(trace):
             nt = 20 if "rhs_stage" in k else 10
             nt = min(nt, len(d))
             f.write("| `%s` | %d | %.1f | %.1f |\n" % (k[:70], len(d), sum(d) / len(d) / 1e3, sum(d[-nt:]) / nt / 1e3))
+# ---- roofline fractions from the trace alone: counted work of the traced run's own bench line / trace durations of the
+# same launches (the last `steps` iterations in the trace are the eager re-run of the timed iterations: same arithmetic)
+line_path = os.path.join(src, "bench_under_rocprof.json")
+if os.path.exists(trace) and os.path.exists(line_path) and os.path.getsize(line_path) > 2:
+    line = json.load(open(line_path))
+    with open(os.path.join(dst, tag + "_bench_under_rocprof.json"), "w") as f:
+        json.dump(line, f)
+    steps, warm = line["steps"], line["warmup"]
+    iters_in_trace = warm + 2 * steps
+    rows = list(csv.DictReader(open(trace)))
+    dur = collections.defaultdict(list)
+    for r in rows:
+        if "rk::" in r["Kernel_Name"]:
+            dur[r["Kernel_Name"]].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+    def timed_total_ns(pred):
+        tot = 0
+        for k, v in dur.items():
+            if not pred(k) or len(v) < iters_in_trace:          # (kernels of the one-time setup are not part of a launch)
+                continue
+            v.sort()
+            per_iter = len(v) / float(iters_in_trace)
+            nt = int(round(per_iter * steps))
+            tot += sum(x[1] for x in v[len(v) - nt:]) if nt else 0
+        return tot
+    cd = line["roofline"] if line["roofline"].get("bound") in ("mfma", "valu") else line.get("roofline_cd")
+    rhs = line["roofline_rhs"] if "roofline_rhs" in line else line["roofline"]
+    with open(os.path.join(dst, tag + "_summary.md"), "a") as f:
+        f.write("\n## Roofline fractions from this trace (counted work of the traced run's own bench line, `%s_bench_under_rocprof.json`, "
+                "over the trace durations of the same launches)\n\n| kernel group | counted work per launch | trace avg us per launch (timed launches) | achieved | peak | frac | bench line (HIP events) |\n|---|---|---|---|---|---|---|\n" % tag)
+        if cd:
+            # H side: the 32-column MFMA kernel (or whatever ran the H side: the longest CD kernel by total time)
+            names = [k for k in dur if "cd_" in k and "prep" not in k]
+            names.sort(key=lambda k: -sum(x[1] for x in dur[k]))
+            if names:
+                h_ns = timed_total_ns(lambda k: k == names[0]) / float(steps)
+                tf = cd["algorithmic_flops_per_launch"] / (h_ns * 1e-9) / 1e12
+                f.write("| CD solve, H side (`%s`) | %.3e flop | %.1f | %.1f TFLOP/s | %.1f | **%.3f** | %.3f (%.1f us) |\n"
+                        % (names[0][:60], cd["algorithmic_flops_per_launch"], h_ns / 1e3, tf, cd["peak"], tf / cd["peak"], cd["frac"], cd["avg_launch_ms"] * 1e3))
+                if len(names) > 1 and "w_side" in cd:
+                    w_ns = timed_total_ns(lambda k: k == names[1]) / float(steps)
+                    tfw = cd["w_side"]["algorithmic_flops_per_launch"] / (w_ns * 1e-9) / 1e12
+                    f.write("| CD solve, W side (`%s`) | %.3e flop | %.1f | %.1f TFLOP/s | %.1f | **%.3f** | %.3f (%.1f us) |\n"
+                            % (names[1][:60], cd["w_side"]["algorithmic_flops_per_launch"], w_ns / 1e3, tfw, cd["peak"], tfw / cd["peak"],
+                               cd["w_side"]["frac"], cd["w_side"]["avg_launch_ms"] * 1e3))
+        if rhs:
+            call_ns = timed_total_ns(lambda k: "rhs_" in k) / float(2 * steps)
+            gb = rhs["algorithmic_bytes_per_launch"] / (call_ns * 1e-9) / 1e9
+            f.write("| SpMM-like rhs call (all `rhs_*` kernels of a call, mean of both sides) | %.4e B | %.1f | %.0f GB/s | 8000 | **%.3f** | %.3f (%.1f us) |\n"
+                    % (rhs["algorithmic_bytes_per_launch"], call_ns / 1e3, gb, gb / 8000.0, rhs["frac"], rhs["avg_launch_ms"] * 1e3))
+            if doc.get("rhs_per_launch"):
+                f.write("\nHBM traffic of one rhs call from the counter passes: %.4e B = %.2f x the algorithmic bytes.\n"
+                        % (doc["rhs_per_launch"]["hbm_bytes_per_launch"], doc["rhs_per_launch"]["hbm_bytes_per_launch"] / rhs["algorithmic_bytes_per_launch"]))
 print(open(os.path.join(dst, tag + "_summary.md")).read())

@@ -14,7 +14,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def _run(*extra):
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--rows", "3000", "--cols", "24000", "--density", "0.01", "--k", "64",
-           "--steps", "4", "--warmup", "3", "--no-cpu-baseline", "--no-plugin-figure", *extra]
+           "--steps", "4", "--warmup", "3", "--no-cpu-baseline", "--no-plugin-figure", "--no-cpu-ref", "--no-fp64-leg",
+           "--no-noop-count", *extra]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
     return json.loads(out.stdout.strip().splitlines()[-1])
