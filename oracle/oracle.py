@@ -12,6 +12,9 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
+# RCPPML_ORACLE_DIR: load the shared objects from another directory (oracle/_san: the ASan + UBSan builds of
+# `make -C oracle sanitize`, run by tools/sanitize/run.sh)
+_LIBDIR = os.environ.get("RCPPML_ORACLE_DIR") or _HERE
 _LIBS = {}
 
 i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
@@ -27,8 +30,10 @@ def build(native=False, quiet=True):
 def lib(native=False):
     name = "liboracle_native.so" if native else "liboracle.so"
     if name not in _LIBS:
-        path = os.path.join(_HERE, name)
+        path = os.path.join(_LIBDIR, name)
         if not os.path.exists(path):
+            if _LIBDIR != _HERE:
+                raise FileNotFoundError(path)
             build(native)
         _LIBS[name] = C.CDLL(path)
     return _LIBS[name]
@@ -522,8 +527,10 @@ _spz = None
 def spz_lib():
     global _spz
     if _spz is None:
-        path = os.path.join(_HERE, "libspz_oracle.so")
+        path = os.path.join(_LIBDIR, "libspz_oracle.so")
         if not os.path.exists(path):
+            if _LIBDIR != _HERE:
+                raise FileNotFoundError(path)
             build()
         _spz = C.CDLL(path)
     return _spz
