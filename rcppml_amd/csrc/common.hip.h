@@ -48,6 +48,7 @@ inline bool exp_flag(const char*, const char*) { return false; }
 inline const char* exp_env(const char*) { return nullptr; }
 #endif
 
+struct rcppml_hip_ctx;
 enum { WS_GRAM = 0, WS_GPAD, WS_CHOL, WS_RED, WS_RED2, WS_ORDER, WS_IRLS, WS_MFMA, WS_FEAT, WS_GRAPH, WS_COUNT };
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-DEVICE property of a kernel: remember the largest size
@@ -77,6 +78,18 @@ struct rcppml_hip_ctx {
     unsigned long long* stats = nullptr;
     // rcppml_hip_ctx_set_option
     int opt_cd_count = 0, opt_lmf_lg = 0, opt_lmf_wps = 0, opt_cd_no_lmf = 0;
+    // Per-fit arena (plugin entries): ONE hipMalloc / hipFree for everything a fit allocates instead of ~60 pairs -- hipMalloc
+    // costs tens of microseconds and every hipFree synchronises the device; together they were 5-6 ms of a 20 ms one-iteration
+    // call.  Pure bump allocation, nothing is handed back before the fit ends.  arena_take() returns nullptr when there is no
+    // arena (the harness's contexts) or it is full: callers then fall back to hipMalloc.
+    char* arena = nullptr;
+    size_t arena_cap = 0, arena_off = 0;
+    void* arena_take(size_t bytes) {
+        const size_t a = (arena_off + 255) & ~(size_t)255;
+        if (!arena || a + bytes > arena_cap) return nullptr;
+        arena_off = a + bytes;
+        return arena + a;
+    }
     // Grow-only scratch.  Growth frees the old block with hipFree, which synchronises the device,
     // so no in-flight kernel can still be using it.
     void* scratch(int slot, size_t bytes) {
@@ -90,4 +103,18 @@ struct rcppml_hip_ctx {
         }
         return b.ptr;
     }
+};
+
+// Device temporary of a setup routine: from the context's arena when there is one, else hipMalloc / hipFree.
+struct DevTmp {
+    void* p = nullptr;
+    bool owned = false;
+    DevTmp(rcppml_hip_ctx* c, size_t bytes) {
+        if (bytes < 16) bytes = 16;
+        p = c ? c->arena_take(bytes) : nullptr;
+        if (!p) { HIPCHK(hipMalloc(&p, bytes)); owned = true; }
+    }
+    ~DevTmp() { if (p && owned) (void)hipFree(p); }
+    DevTmp(const DevTmp&) = delete;
+    DevTmp& operator=(const DevTmp&) = delete;
 };

@@ -11,11 +11,17 @@ using namespace rk;
 
 namespace {
 
-struct Tmp {
-    void* p = nullptr;
-    explicit Tmp(size_t bytes) { HIPCHK(hipMalloc(&p, bytes < 16 ? 16 : bytes)); }
-    ~Tmp() { if (p) (void)hipFree(p); }
-};
+// plan buffers: from the fit's arena when the context has one (then the plan does not own them), else hipMalloc
+template <class P>
+void plan_alloc(rcppml_hip_ctx* c, rcppml_rhs_plan* pl, P** out, size_t bytes) {
+    void* q = c->arena_take(bytes < 16 ? 16 : bytes);
+    if (q) pl->in_arena = true;
+    else {
+        if (pl->in_arena) throw std::runtime_error("rhs_plan: arena exhausted half-way through a plan");
+        HIPCHK(hipMalloc(&q, bytes < 16 ? 16 : bytes));
+    }
+    *out = static_cast<P*>(q);
+}
 
 template <class T>
 void run_plan(rcppml_hip_ctx* c, const rcppml_rhs_plan* pl, const T* F, T* B) {
@@ -77,7 +83,7 @@ rcppml_rhs_plan* build_plan(rcppml_hip_ctx* c, int dtype, const int* colptr, con
     if (P > G.ntiles) P = G.ntiles;
     G.P = P;
     // segment-length histogram -> S
-    Tmp dh((RT_MAX_HIST + 1) * sizeof(unsigned long long));
+    DevTmp dh(c, (RT_MAX_HIST + 1) * sizeof(unsigned long long));
     HIPCHK(hipMemsetAsync(dh.p, 0, (RT_MAX_HIST + 1) * sizeof(unsigned long long), c->stream));
     unsigned long long* dhist = (unsigned long long*)dh.p;
     int* dflag = (int*)(dhist + RT_MAX_HIST);
@@ -176,15 +182,15 @@ rcppml_rhs_plan* build_plan(rcppml_hip_ctx* c, int dtype, const int* colptr, con
     const unsigned gcol2 = (unsigned)((ncols + 3) / 4);
 
     // overflow column pointers
-    Tmp cnt(((size_t)ncols + 1) * sizeof(int));
+    DevTmp cnt(c, ((size_t)ncols + 1) * sizeof(int));
     HIPCHK(hipMemsetAsync(cnt.p, 0, ((size_t)ncols + 1) * sizeof(int), c->stream));
     hipLaunchKernelGGL(rhs_tiled_ovcount_kernel, dim3(gcol2), dim3(256), 0, c->stream, colptr, rowidx, ncols, G.rshift, S, (int*)cnt.p);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMalloc((void**)&pl->ovptr, ((size_t)ncols + 1) * sizeof(int)));
+    plan_alloc(c, pl.get(), &pl->ovptr, ((size_t)ncols + 1) * sizeof(int));
     {
         size_t sb = 0;
         HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, sb, (int*)cnt.p, pl->ovptr, (int)(ncols + 1), c->stream));
-        Tmp st(sb);
+        DevTmp st(c, sb);
         HIPCHK(hipcub::DeviceScan::ExclusiveSum(st.p, sb, (int*)cnt.p, pl->ovptr, (int)(ncols + 1), c->stream));
         int ovn = 0;
         HIPCHK(hipMemcpyAsync(&ovn, pl->ovptr + ncols, sizeof(int), hipMemcpyDeviceToHost, c->stream));
@@ -197,16 +203,16 @@ rcppml_rhs_plan* build_plan(rcppml_hip_ctx* c, int dtype, const int* colptr, con
     pl->nslots = (int64_t)G.ncb * G.ntiles * G.NW * (int64_t)(G.nr * S) * 4;
     pl->fill = (double)(pl->nnz - pl->ovnnz) / (double)pl->nslots;
     const size_t nalloc = (size_t)pl->nslots + 64;
-    HIPCHK(hipMalloc(&pl->svals, nalloc * sizeof(T)));
-    HIPCHK(hipMalloc((void**)&pl->soffs, nalloc * sizeof(uint16_t)));
+    plan_alloc(c, pl.get(), &pl->svals, nalloc * sizeof(T));
+    plan_alloc(c, pl.get(), &pl->soffs, nalloc * sizeof(uint16_t));
     HIPCHK(hipMemsetAsync(pl->svals, 0, nalloc * sizeof(T), c->stream));
     HIPCHK(hipMemsetAsync(pl->soffs, 0, nalloc * sizeof(uint16_t), c->stream));
-    HIPCHK(hipMalloc((void**)&pl->ovrow, (size_t)std::max<int64_t>(pl->ovnnz, 1) * sizeof(int)));
-    HIPCHK(hipMalloc(&pl->ovval, (size_t)std::max<int64_t>(pl->ovnnz, 1) * sizeof(T)));
+    plan_alloc(c, pl.get(), &pl->ovrow, (size_t)std::max<int64_t>(pl->ovnnz, 1) * sizeof(int));
+    plan_alloc(c, pl.get(), &pl->ovval, (size_t)std::max<int64_t>(pl->ovnnz, 1) * sizeof(T));
     hipLaunchKernelGGL(rhs_tiled_fill_kernel<T>, dim3(gcol2), dim3(256), 0, c->stream, colptr, rowidx, vals, G, (T*)pl->svals,
                        pl->soffs, (const int*)pl->ovptr, pl->ovrow, (T*)pl->ovval);
     HIPCHK(hipGetLastError());
-    if (G.P > 1) HIPCHK(hipMalloc(&pl->Bp, (size_t)G.P * (size_t)ncols * (size_t)k * sizeof(T)));     // ncols = tiled columns
+    if (G.P > 1) plan_alloc(c, pl.get(), &pl->Bp, (size_t)G.P * (size_t)ncols * (size_t)k * sizeof(T));     // ncols = tiled columns
     HIPCHK(hipStreamSynchronize(c->stream));          // temporaries die here
     return pl.release();
 }

@@ -6,6 +6,7 @@
 // the loop follows the CPU semantics of inst/include/FactorNet/nmf/fit_cpu.hpp:444-1855 because
 // CPU nmf() is the parity target.
 // ============================================================================
+#include <chrono>
 #include "plugin_common.hip.h"
 
 extern "C" const char* rcppml_gpu_last_error(void) { return rcppml_err().c_str(); }
@@ -65,6 +66,16 @@ void proj_adv_host(std::vector<double>& G, const std::vector<double>& TG, int k,
         }
 }
 
+// out(:, j) = in(idx, j): the factors (rows of the k x ncols arrays) in the order of descending d
+template <class T>
+__global__ void permute_rows_kernel(const T* __restrict__ in, int k, int64_t ncols, const int* __restrict__ idx, T* __restrict__ out) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (int64_t)k * ncols) return;
+    const int64_t j = e / k;
+    const int i = (int)(e - j * k);
+    out[e] = in[j * k + idx[i]];
+}
+
 // ----------------------------------------------------------------------------
 // The ALS loop (MSE; fused-path semantics of fit_cpu.hpp, or the explicit-mask path).
 // ----------------------------------------------------------------------------
@@ -72,13 +83,32 @@ template <class T>
 void fit(FitParams& P) {
     constexpr int dt = DT<T>::id;
     const int m = P.m, n = P.n, k = P.k;
+    // RCPPML_GPU_VERBOSE >= 2 (the ABI's verbose >= 2): wall time of the one-time phases around the iterations, to stderr
+    const auto tstart = std::chrono::steady_clock::now();
+    auto tlast = tstart;
+    auto phase = [&](const char* what, hipStream_t st) {
+        if (P.verbose < 2) return;
+        (void)hipStreamSynchronize(st);
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[rcppml_gpu setup] %-28s %8.3f ms (at %8.3f)\n", what, std::chrono::duration<double, std::milli>(now - tlast).count(),
+                std::chrono::duration<double, std::milli>(now - tstart).count());
+        tlast = now;
+    };
     CtxGuard g(P.device >= 0 ? P.device : env_device());
     rcppml_hip_ctx* c = g.c;
     hipStream_t s = g.s;
+    if (!P.dense && !P.csc_on_device) {
+        // everything this fit allocates, generously: the CSC twice (+ the double staging copy and the sort's temporaries),
+        // the factors, right-hand sides and their staging copies, the two row-tiled plans
+        const size_t est = (size_t)96 * (size_t)std::max<int64_t>(P.nnz, 1) + (size_t)96 * (size_t)k * ((size_t)m + n) + ((size_t)256 << 20);
+        g.reserve(est);
+    }
+    phase("context + stream + arena", s);
 
     // ---- upload A, build and upload A^T (one-time setup, fit_cpu.hpp:237-254)
     DevBuf dAp, dAi, dAx, dTp, dTi, dTx;
     const bool dense = P.dense != nullptr;
+    bool csc_transposed = false;
     if (dense) {                    // dense input: A itself (m x n, column-major) in the compute precision; no CSC, no transpose
         upload_cast<T>(c, P.dense, (size_t)m * n, dAx, s);
     } else if (P.csc_on_device) {          // zero-copy: the CSC already lives in device memory (values double)
@@ -89,18 +119,45 @@ void fit(FitParams& P) {
             dAx.alloc((size_t)std::max<int64_t>(P.nnz, 1) * sizeof(T));
             OPCHK(rcppml_hip_cast(c, RCPPML_F64, P.values, RCPPML_F32, dAx.p, P.nnz));
         }
+    } else if (c->arena) {
+        // Host CSC, overlapped setup: the row indices go first and the device starts sorting them (the transpose's expensive
+        // part needs nothing else) while the VALUES -- two thirds of the bytes -- are still crossing PCIe.  Pageable copies
+        // block the host, not the device, so the sort runs under the value upload; everything is ordered on the one stream.
+        upload_ints(P.col_ptr, (size_t)n + 1, dAp, s);
+        upload_ints(P.row_idx, (size_t)P.nnz, dAi, s);
+        dTp.alloc(((size_t)m + 1) * sizeof(int));
+        dTi.alloc((size_t)std::max<int64_t>(P.nnz, 1) * sizeof(int));
+        dTx.alloc((size_t)std::max<int64_t>(P.nnz, 1) * sizeof(T));
+        DevBuf dpos((size_t)std::max<int64_t>(P.nnz, 1) * sizeof(int));
+        OPCHK(rcppml_hip_transpose_csc_sort(c, m, n, P.nnz, dAi.as<int>(), dTp.as<int>(), dpos.as<int>()));      // asynchronous (arena)
+        OPCHK(rcppml_hip_transpose_csc_gather(c, dt, n, P.nnz, dAp.as<int>(), dpos.as<int>(), nullptr, dTi.as<int>(), nullptr));   // column indices of A^T
+        hipStream_t s2 = g.second_stream();
+        dAx.alloc((size_t)std::max<int64_t>(P.nnz, 1) * sizeof(T));
+        if constexpr (std::is_same<T, double>::value) {
+            HIPCHK(hipMemcpyAsync(dAx.p, P.values, (size_t)P.nnz * sizeof(double), hipMemcpyHostToDevice, s2));
+            HIPCHK(hipStreamSynchronize(s2));
+        } else {
+            DevBuf stage((size_t)std::max<int64_t>(P.nnz, 1) * sizeof(double));
+            HIPCHK(hipMemcpyAsync(stage.p, P.values, (size_t)P.nnz * sizeof(double), hipMemcpyHostToDevice, s2));
+            HIPCHK(hipStreamSynchronize(s2));
+            OPCHK(rcppml_hip_cast(c, RCPPML_F64, stage.p, RCPPML_F32, dAx.p, P.nnz));
+        }
+        OPCHK(rcppml_hip_transpose_csc_gather(c, dt, n, P.nnz, dAp.as<int>(), dpos.as<int>(), dAx.p, nullptr, dTx.p));             // its values
+        csc_transposed = true;
     } else {
         upload_ints(P.col_ptr, (size_t)n + 1, dAp, s);
         upload_ints(P.row_idx, (size_t)P.nnz, dAi, s);
         upload_cast<T>(c, P.values, (size_t)P.nnz, dAx, s);
     }
+    phase("upload CSC", s);
     // A^T on the device (stable sort by row index): rcppml_hip_transpose_csc
-    if (!dense) {
+    if (!dense && !csc_transposed) {
     dTp.alloc(((size_t)m + 1) * sizeof(int));
     dTi.alloc((size_t)P.nnz * sizeof(int));
     dTx.alloc((size_t)P.nnz * sizeof(T));
     OPCHK(rcppml_hip_transpose_csc(c, dt, m, n, dAp.as<int>(), dAi.as<int>(), dAx.p, dTp.as<int>(), dTi.as<int>(), dTx.p));
     }
+    phase("transpose", s);
     const bool has_mask = P.mask_p != nullptr;
     DevBuf dMp, dMi, dMTp, dMTi;
     if (has_mask) {
@@ -123,10 +180,12 @@ void fit(FitParams& P) {
         upload_ints(P.gW_p, (size_t)m + 1, dGWp, s); upload_ints(P.gW_i, (size_t)P.gW_nnz, dGWi, s);
         upload_cast<T>(c, P.gW_x, (size_t)P.gW_nnz, dGWx, s);
     }
-    // ---- factors
+    // ---- factors (their PCIe copies run on the second stream: under the transpose's gather when the setup is overlapped)
     DevBuf dW, dH, dd;
-    upload_cast<T>(c, P.W, (size_t)k * m, dW, s);
-    upload_cast<T>(c, P.H, (size_t)k * n, dH, s);
+    AsyncUpload<T> factors;               // joined just before the first iteration: the copies run under trAtA and the plans
+    factors.add(P.W, (size_t)k * m, dW);
+    factors.add(P.H, (size_t)k * n, dH);
+    factors.start(c->device, g.second_stream());
     dd.alloc((size_t)k * sizeof(T));
     {
         std::vector<T> ones(k, T(1));                       // fit_cpu.hpp:198 d = 1
@@ -178,6 +237,8 @@ void fit(FitParams& P) {
         plan_or_none(rcppml_hip_rhs_plan_create(c, dt, dAp.as<int>(), dAi.as<int>(), dAx.p, n, m, k, 0, 0, &planA.p), planA.p);
         plan_or_none(rcppml_hip_rhs_plan_create(c, dt, dTp.as<int>(), dTi.as<int>(), dTx.p, m, n, k, 0, 0, &planT.p), planT.p);
     }
+    factors.finish(c);
+    phase("buffers + trAtA + plans + factors", s);
     // ---- target regularisation (variant_helpers.hpp:107-146): standard (unfused) path, as in the reference (fit_cpu.hpp:430-433)
     const bool tgtH = P.target_H && P.target_lambda_H != 0, tgtW = P.target_W && P.target_lambda_W != 0;
     const bool unfused = dense || tgtH || tgtW;
@@ -414,20 +475,29 @@ void fit(FitParams& P) {
         download_cast<T>(c, th, (size_t)m, P.out_theta, s);
         P.out_theta_len = m;
     }
-    // ---- download, sort by descending d (core/result.hpp:169-188)
-    download_cast<T>(c, dW, (size_t)k * m, P.W, s);
-    download_cast<T>(c, dH, (size_t)k * n, P.H, s);
+    phase("iterations", s);
+    // ---- sort by descending d (core/result.hpp:169-188) on the device, download
     download_cast<T>(c, dd, (size_t)k, P.d, s);
     if (P.sort_model) {
         std::vector<int> idx(k);
         std::iota(idx.begin(), idx.end(), 0);
         std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return P.d[a] > P.d[b]; });
         std::vector<double> tmp(k);
-        for (int j = 0; j < m; ++j) { double* w = P.W + (size_t)j * k; for (int i = 0; i < k; ++i) tmp[i] = w[idx[i]]; std::copy(tmp.begin(), tmp.end(), w); }
-        for (int j = 0; j < n; ++j) { double* h = P.H + (size_t)j * k; for (int i = 0; i < k; ++i) tmp[i] = h[idx[i]]; std::copy(tmp.begin(), tmp.end(), h); }
         for (int i = 0; i < k; ++i) tmp[i] = P.d[idx[i]];
         std::copy(tmp.begin(), tmp.end(), P.d);
+        DevBuf didx((size_t)k * sizeof(int));
+        HIPCHK(hipMemcpyAsync(didx.p, idx.data(), (size_t)k * sizeof(int), hipMemcpyHostToDevice, s));
+        // the right-hand-side buffers are free now: W_T and H leave through them with their rows (factors) permuted
+        hipLaunchKernelGGL(permute_rows_kernel<T>, dim3((unsigned)(((size_t)k * m + 255) / 256)), dim3(256), 0, s, (const T*)dW.p, k, (int64_t)m, didx.as<int>(), (T*)dBw.p);
+        hipLaunchKernelGGL(permute_rows_kernel<T>, dim3((unsigned)(((size_t)k * n + 255) / 256)), dim3(256), 0, s, (const T*)dH.p, k, (int64_t)n, didx.as<int>(), (T*)dBh.p);
+        HIPCHK(hipGetLastError());
+        download_cast<T>(c, dBw, (size_t)k * m, P.W, s);
+        download_cast<T>(c, dBh, (size_t)k * n, P.H, s);
+    } else {
+        download_cast<T>(c, dW, (size_t)k * m, P.W, s);
+        download_cast<T>(c, dH, (size_t)k * n, P.H, s);
     }
+    phase("sort + download", s);
     P.out_iter = iterations; P.out_converged = converged ? 1 : 0; P.out_loss = train_loss; P.out_tol = final_tol;
 }
 

@@ -2,6 +2,8 @@
 // entry points; plugin_multi.hip: the multi-device loop): device buffers, context guard, the parameter carrier of a fit
 // and the host<->device conversions of the boundary's double buffers.
 #pragma once
+#include <memory>
+#include <thread>
 #include "common.hip.h"
 
 #include <algorithm>
@@ -15,6 +17,11 @@ namespace rcppml_plugin {
         if ((expr) != 0) throw std::runtime_error(std::string(#expr) + ": " + rcppml_err()); \
     } while (0)
 
+// the context whose per-fit arena (common.hip.h) serves this thread's DevBuf allocations; set by CtxGuard::reserve
+inline rcppml_hip_ctx*& devbuf_arena_ctx() {
+    static thread_local rcppml_hip_ctx* c = nullptr;
+    return c;
+}
 struct DevBuf {
     void* p = nullptr;
     size_t bytes = 0;
@@ -23,6 +30,9 @@ struct DevBuf {
     void alloc(size_t b) {
         release();
         bytes = b < 16 ? 16 : b;
+        rcppml_hip_ctx* ac = devbuf_arena_ctx();
+        p = ac ? ac->arena_take(bytes) : nullptr;
+        if (p) { owned = false; return; }
         HIPCHK(hipMalloc(&p, bytes));
     }
     bool owned = true;
@@ -45,8 +55,26 @@ struct CtxGuard {
             throw std::runtime_error("ctx_create: " + rcppml_err());
         }
     }
+    // a second stream for PCIe copies that should run beside device work of the fit's stream (created on first use)
+    hipStream_t s2 = nullptr;
+    hipStream_t second_stream() {
+        if (!s2) HIPCHK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+        return s2;
+    }
+    // One device allocation for the whole fit (see rcppml_hip_ctx::arena).  Best effort: if it cannot be had, every buffer
+    // falls back to its own hipMalloc.
+    void reserve(size_t bytes) {
+        void* q = nullptr;
+        if (hipMalloc(&q, bytes) != hipSuccess) { (void)hipGetLastError(); return; }
+        c->arena = static_cast<char*>(q); c->arena_cap = bytes; c->arena_off = 0;
+        devbuf_arena_ctx() = c;
+    }
     ~CtxGuard() {
-        if (c) rcppml_hip_ctx_destroy(c);
+        if (devbuf_arena_ctx() == c) devbuf_arena_ctx() = nullptr;
+        void* arena = c ? c->arena : nullptr;
+        if (c) { c->arena = nullptr; rcppml_hip_ctx_destroy(c); }
+        if (arena) (void)hipFree(arena);
+        if (s2) (void)hipStreamDestroy(s2);
         if (s) (void)hipStreamDestroy(s);
     }
 };
@@ -112,10 +140,59 @@ inline void upload_cast(rcppml_hip_ctx* c, const double* src, size_t n, DevBuf& 
     } else {
         DevBuf stage(n * sizeof(double));
         HIPCHK(hipMemcpyAsync(stage.p, src, n * sizeof(double), hipMemcpyHostToDevice, s));
+        if (s != c->stream) {
+            // copy on a side stream (it overlaps whatever the fit's stream is running), cast behind that work on the fit's stream;
+            // with an arena the staging copy outlives this call, so nothing waits for the cast here
+            HIPCHK(hipStreamSynchronize(s));
+            OPCHK(rcppml_hip_cast(c, RCPPML_F64, stage.p, RCPPML_F32, dst.p, (int64_t)n));
+            if (stage.owned) HIPCHK(hipStreamSynchronize(c->stream));
+            return;
+        }
         OPCHK(rcppml_hip_cast(c, RCPPML_F64, stage.p, RCPPML_F32, dst.p, (int64_t)n));
         HIPCHK(hipStreamSynchronize(s));
     }
 }
+// Host -> device copies of double buffers on a helper thread and a side stream, so that the calling thread can go on
+// building things on the fit's stream (pageable copies block the thread that issues them): add() allocates (calling
+// thread: the arena is per thread), start() launches the copies, finish() joins and enqueues the precision casts.
+template <class T>
+struct AsyncUpload {
+    struct Item { const double* src; size_t n; DevBuf* dst; DevBuf stage; };
+    std::vector<std::unique_ptr<Item>> items;
+    std::thread th;
+    std::string err;
+    void add(const double* src, size_t n, DevBuf& dst) {
+        std::unique_ptr<Item> it(new Item{src, n, &dst, DevBuf()});
+        dst.alloc(n * sizeof(T));
+        if (!std::is_same<T, double>::value) it->stage.alloc(n * sizeof(double));
+        items.push_back(std::move(it));
+    }
+    void start(int device, hipStream_t side) {
+        th = std::thread([this, device, side] {
+            try {
+                HIPCHK(hipSetDevice(device));
+                for (auto& it : items)
+                    HIPCHK(hipMemcpyAsync(std::is_same<T, double>::value ? it->dst->p : it->stage.p, it->src, it->n * sizeof(double),
+                                          hipMemcpyHostToDevice, side));
+                HIPCHK(hipStreamSynchronize(side));
+            } catch (const std::exception& e) { err = e.what(); }
+        });
+    }
+    void finish(rcppml_hip_ctx* c) {
+        if (th.joinable()) th.join();
+        if (!err.empty()) throw std::runtime_error(err);
+        if (!std::is_same<T, double>::value) {
+            bool owned = false;
+            for (auto& it : items) {
+                OPCHK(rcppml_hip_cast(c, RCPPML_F64, it->stage.p, RCPPML_F32, it->dst->p, (int64_t)it->n));
+                owned |= it->stage.owned;
+            }
+            if (owned) HIPCHK(hipStreamSynchronize(c->stream));      // hipMalloc'ed staging copies are freed with `items`
+        }
+        items.clear();
+    }
+    ~AsyncUpload() { if (th.joinable()) th.join(); }
+};
 template <class T>
 inline void download_cast(rcppml_hip_ctx* c, const DevBuf& src, size_t n, double* dst, hipStream_t s) {
     if constexpr (std::is_same<T, double>::value) {

@@ -19,7 +19,9 @@ struct rcppml_rhs_plan {
     const void* vals = nullptr;
     int64_t ovnnz = 0, nnz = 0, nslots = 0;
     double ov_fraction = 0.0, fill = 0.0;
+    bool in_arena = false;       // buffers live in the creating context's per-fit arena (freed with it): nothing to free here
     ~rcppml_rhs_plan() {
+        if (in_arena) return;
         for (void* p : {svals, (void*)soffs, (void*)ovptr, (void*)ovrow, ovval, Bp})
             if (p) (void)hipFree(p);
     }

@@ -22,3 +22,6 @@ for iters in (1, 1, 11, 21):
 slope = (res[21] - res[11]) / 10
 print("slope %.3f ms/iteration, intercept %.1f ms (nnz %d: %.0f MB of CSC in, %.0f MB of factors in+out)" % (
     slope * 1e3, (res[11] - 11 * slope) * 1e3, A.nnz, (A.nnz * 12 + n * 4) / 1e6, 2 * (m + n) * k * 8 / 1e6))
+# one-time phases of the call (RCPPML verbose = 2: wall time per setup phase, to stderr)
+W, H = W0.copy(), H0.copy()
+_abi.nmf_unified(p, i, x, m, n, k, W, H, entry="float", max_iter=1, tol=0.0, solver_mode=0, verbose=2)
