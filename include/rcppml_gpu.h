@@ -130,6 +130,15 @@ RCPPML_GPU_API void rcppml_gpu_nmf_cv_unified_double(RCPPML_NMF_CV_ARGS);
 /* Build-defined: + sort flag, precision (RCPPML_F32/F64), cv_patience, train / test loss histories (may be NULL). */
 RCPPML_GPU_API void rcppml_gpu_nmf_cv_ex(RCPPML_NMF_CV_ARGS, int* sort_model, int* precision, int* cv_patience,
                                          double* train_history, double* test_history);
+/* CV with the IRLS losses (loss_type 4 GP, 5 NB, 6 Gamma, 7 inverse Gaussian, 8 Tweedie; reference nmf/fit_cv.hpp:446-456, :670-689,
+ * :866-961, :1377-1443, nmf/cv_detail.hpp:101-292) runs through ALL the CV entries above.  The reference boundary carries loss_type,
+ * irls_max_iter and irls_tol only, so its entries take the reference's config defaults for the rest (per-row GP dispersion with
+ * theta_init 0.1 / theta_max 5, Tweedie power 1.5, no robust modifier: core/config.hpp:151-172, math/loss.hpp:109-115); this
+ * build-defined entry passes them, and returns GP's theta (out_theta: m doubles, may be NULL). */
+RCPPML_GPU_API void rcppml_gpu_nmf_cv_irls_ex(RCPPML_NMF_CV_ARGS, int* sort_model, int* precision, int* cv_patience,
+                                              double* train_history, double* test_history, int* dispersion_mode,
+                                              double* gp_theta_init, double* gp_theta_max, double* tweedie_power,
+                                              double* robust_delta, double* out_theta);
 
 /* Dense-input NMF.  Replaces reference `rcppml_gpu_nmf_dense_unified_float` (resolved by
  * inst/include/FactorNet/gpu/bridge_nmf.hpp:544-545; 52 pointers, typedef :101-126): A_data is the m x n column-major
@@ -463,6 +472,36 @@ RCPPML_GPU_API int rcppml_hip_nb_size_update(rcppml_hip_ctx* ctx, int dtype, con
 RCPPML_GPU_API int rcppml_hip_nb_loss(rcppml_hip_ctx* ctx, int dtype, const int* col_ptr, const int* row_idx,
                                       const void* values, int64_t ncols, const void* W_T, const void* d, const void* H,
                                       const void* theta_row, int k, double* out);
+
+/* Cross-validation with the IRLS losses -- reference nmf/cv_detail.hpp:101-292 (irls_solve_col_cv / irls_solve_row_cv), callers
+ * nmf/fit_cv.hpp:446-456, :670-689.  Per column of the CSC (H side: A, F = W_T; W side: A^T with transposed = 1, F = H; the speckled
+ * mask SplitMix64::hash(seed, i, j) < UINT64_MAX / floor(1 / fraction) is always asked in the coordinates of A), up to irls_max_iter
+ * passes of:  G_w = sum over the TRAINING entries of w f f^T + G_add + 1e-15 I,  b_w = sum (w a) f,  x <- CD(G_w, b_w, x; L1
+ * inside, cd_maxit sweeps, no tolerance) or Cholesky + clip, started from the current column WITHOUT a residual correction of
+ * b_w, until max |dx| / (|x_old| + 1e-12) < irls_tol.  Training entries: the nonzeros that are not held out (mask_zeros = 1) or
+ * every row that is not held out, zeros included (0).  The weight is the reference's compute_irls_weight(residual, predicted,
+ * loss) with its DEFAULT observed = 0 and theta = 0: NB / Gamma / inverse Gaussian / Tweedie distribution weights at theta 0,
+ * GP = irls_weight_gp(0, mu, 0, blend 1) (math/loss.hpp:197-229; not the KL weight of the non-CV fit), times the Huber
+ * modifier when robust_delta > 0.  G_add (k x k, may be NULL): the additive CV features (L2, graph, L21).  k <= 64. */
+RCPPML_GPU_API int rcppml_hip_solve_cv_irls(rcppml_hip_ctx* ctx, int dtype, int loss_type, const int* col_ptr, const int* row_idx,
+                                            const void* values, int64_t ncols, int nrows, const void* F, const void* G_add, void* X,
+                                            int k, double holdout_fraction, unsigned long long cv_seed, int mask_zeros,
+                                            int transposed, double l1, int nonneg, int cd_maxit, int solver_mode, int irls_max_iter,
+                                            double irls_tol, double loss_param, double robust_delta);
+/* out4 = {train sum, n_train, test sum, n_test} of compute_loss(value, prediction, loss, theta) (math/loss.hpp:511-535; loss_type 0
+ * = squared error) over the entries of A -- the nonzeros (mask_zeros = 1) or every entry -- split by the speckled mask; theta_row
+ * (per row, may be NULL) is read by GP only.  Reference nmf/fit_cv.hpp:1377-1443. */
+RCPPML_GPU_API int rcppml_hip_cv_irls_loss(rcppml_hip_ctx* ctx, int dtype, int loss_type, const int* col_ptr, const int* row_idx,
+                                           const void* values, int64_t ncols, int nrows, const void* W_T, const void* d,
+                                           const void* H, const void* theta_row, int k, double holdout_fraction,
+                                           unsigned long long cv_seed, int mask_zeros, double loss_param, double* out4);
+/* GP theta per row by the MM update (five inner passes) over the TRAINING entries only -- reference nmf/fit_cv.hpp:866-961: held-out
+ * nonzeros are skipped and the held-out pairs' predictions (zeros included) are taken out of sum_s.  Takes CSC(A^T) (nnz = its
+ * nonzero count).  mode 2 = PER_ROW, 1 = GLOBAL (mean).  holdout_fraction 0: the non-CV update. */
+RCPPML_GPU_API int rcppml_hip_cv_gp_theta_update(rcppml_hip_ctx* ctx, int dtype, int mode, const int* t_col_ptr, const int* t_row_idx,
+                                                 const void* t_values, int64_t m, int64_t nnz, const void* W_T, const void* d,
+                                                 const void* H, int64_t n, int k, double holdout_fraction,
+                                                 unsigned long long cv_seed, double theta_max, void* theta);
 
 #ifdef __cplusplus
 }

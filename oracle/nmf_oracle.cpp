@@ -42,6 +42,29 @@ template <class S> static inline S irls_weight_kl(S predicted) {
     return static_cast<S>(1) / std::max(predicted, static_cast<S>(1e-4));
 }
 // math/loss.hpp:382-398  loss_contribution_gp (fp64 inside)
+// math/loss.hpp:197-229  irls_weight_gp (observed Fisher information, geometric blend with the KL weight, fp64 inside).
+// The non-CV fit never calls it (fit_cpu.hpp:568-574 switches the GP updates to KL weights); the CV path does, through
+// compute_irls_weight's defaults: observed = 0, theta = 0, blend = LossConfig::gp_blend = 1 (cv_detail.hpp:154).
+template <class S> static inline S irls_weight_gp(S observed, S predicted, S theta, S blend = S(1)) {
+    const double s = std::max(static_cast<double>(predicted), static_cast<double>(static_cast<S>(1e-15)));
+    const double y = static_cast<double>(observed), th = static_cast<double>(theta), bl = static_cast<double>(blend);
+    const double eff_blend = bl * std::min(s, 1.0);
+    double w_gp = 1.0 / (s * s);
+    if (y >= 1.0) {
+        double denom = s + th * y;
+        denom = std::max(denom, static_cast<double>(static_cast<S>(1e-15)));
+        w_gp += (y - 1.0) / (denom * denom);
+    }
+    if (eff_blend < 0.999) {
+        const double log_w_kl = -std::log(s);
+        const double log_w_gp = std::log(std::max(w_gp, 1e-300));
+        double weight = std::exp((1.0 - eff_blend) * log_w_kl + eff_blend * log_w_gp);
+        weight = std::min(weight, 1e6);
+        return static_cast<S>(weight);
+    }
+    w_gp = std::min(w_gp, 1e6);
+    return static_cast<S>(w_gp);
+}
 template <class S> static inline S loss_contribution_gp(S observed, S predicted, S theta) {
     double s = std::max(static_cast<double>(predicted), 1e-10);
     double y = static_cast<double>(observed);
@@ -323,9 +346,141 @@ template <class S> struct CvResult {
     int iterations = 0, best_iter = 0; bool converged = false;
     S train_loss = 0, test_loss = 0, best_test_loss = 0, final_tol = 0;
     std::vector<S> train_hist, test_hist;
+    std::vector<S> theta;                 // GP: theta_vec at exit (result.theta, fit_cv.hpp:1647)
 };
 
-// nmf/fit_cv.hpp:123-1667  nmf_fit_cv, MSE / sparse / standard updates / no user mask / no IRLS.
+template <class S>
+static void gp_theta_update(const Csc<S>& A, const S* W_T, const S* H, const S* d, int k, const FitConfig<S>& cfg,
+                            std::vector<S>& theta, const SpeckledMask* cv_mask = nullptr);
+
+// The IRLS weight as the CV solves evaluate it: compute_irls_weight(residual, predicted, loss) with the DEFAULT observed = 0 and
+// theta = 0 (cv_detail.hpp:154, :255) -- the dispersion estimates never reach the CV weights, and GP takes irls_weight_gp
+// (not the KL weight of the non-CV fit).
+template <class S> static inline S cv_irls_weight(const FitConfig<S>& cfg, S residual, S predicted) {
+    const int lt = cfg.loss_type;
+    S w_dist;
+    if (lt == 0) w_dist = S(1);
+    else if (lt == 4) w_dist = irls_weight_gp(S(0), predicted, S(0), S(1));
+    else w_dist = irls_weight(lt, predicted, S(0), cfg.tweedie_power);
+    if (cfg.robust_delta > S(0)) {
+        const S sd_inv = std::sqrt(std::max(w_dist, static_cast<S>(1e-15)));
+        return w_dist * robust_huber_modifier(residual * sd_inv, cfg.robust_delta);
+    }
+    return w_dist;
+}
+
+// nmf/cv_detail.hpp:101-186 irls_solve_col_cv (H side: D = A, F = W_T) / :200-292 irls_solve_row_cv (W side: D = A^T, F = H,
+// transposed = the mask is asked in the coordinates of A).  Per column: the TRAIN entries (mask_zeros: the nonzeros that are not
+// held out; otherwise every row that is not held out, zeros included); up to irls_max_iter passes of
+//   G_w = sum_train w f f^T (+ the CV features: L2, graph, L21 -- all additive, passed in as G_add) + 1e-15 I,
+//   b_w = sum_train (w a) f,  x <- cholesky_clip_col / cd_nnls_col_fixed(G_w, b_w, x, L1 inside, cd_maxit sweeps, no tolerance)
+// started from the current column with b_w NOT residual-corrected for it (as in the MSE CV solve), until the largest relative
+// change of x drops below irls_tol.
+template <class S>
+static void cv_irls_half_update(const Csc<S>& D, const S* F, S* X, int k, const SpeckledMask& mask, bool transposed, S L1, bool nonneg,
+                                const FitConfig<S>& cfg, const S* G_add, int threads) {
+    const int nt = eff_threads(threads); (void)nt;
+    const int nrow = D.rows;
+#pragma omp parallel num_threads(nt)
+    {
+        std::vector<S> bw(k), x(k), xo(k), Gw((size_t)k * k), L((size_t)k * k);
+        std::vector<int> trow;
+        std::vector<S> tval;
+#pragma omp for schedule(dynamic, 16)
+        for (int j = 0; j < D.cols; ++j) {
+            trow.clear(); tval.clear();
+            auto held = [&](int r) { return transposed ? mask.is_holdout(j, r) : mask.is_holdout(r, j); };
+            if (mask.mask_zeros) {
+                for (int t = D.p[j]; t < D.p[j + 1]; ++t)
+                    if (!held(D.i[t])) { trow.push_back(D.i[t]); tval.push_back(D.x[t]); }
+            } else {
+                int t = D.p[j];
+                const int te = D.p[j + 1];
+                for (int r = 0; r < nrow; ++r) {
+                    S val = 0;
+                    if (t < te && D.i[t] == r) { val = D.x[t]; ++t; }
+                    if (!held(r)) { trow.push_back(r); tval.push_back(val); }
+                }
+            }
+            S* xj = X + (size_t)j * k;
+            for (int i = 0; i < k; ++i) x[i] = xj[i];
+            for (int it = 0; it < cfg.irls_max_iter; ++it) {
+                std::fill(Gw.begin(), Gw.end(), S(0));
+                std::fill(bw.begin(), bw.end(), S(0));
+                for (size_t e = 0; e < trow.size(); ++e) {
+                    const S* f = F + (size_t)trow[e] * k;
+                    S predicted = 0;
+                    for (int a = 0; a < k; ++a) predicted += f[a] * x[a];
+                    const S residual = tval[e] - predicted;
+                    const S w = cv_irls_weight(cfg, residual, predicted);
+                    const S wv = w * tval[e];
+                    for (int a = 0; a < k; ++a) {
+                        bw[a] += f[a] * wv;
+                        for (int bb = a; bb < k; ++bb) Gw[(size_t)bb * k + a] += w * f[a] * f[bb];      // G_w(a, bb), a <= bb
+                    }
+                }
+                for (int a = 0; a < k; ++a)
+                    for (int bb = a + 1; bb < k; ++bb) Gw[(size_t)a * k + bb] = Gw[(size_t)bb * k + a];   // G_w(bb, a) = G_w(a, bb)
+                if (G_add) for (size_t e = 0; e < (size_t)k * k; ++e) Gw[e] += G_add[e];
+                for (int a = 0; a < k; ++a) Gw[(size_t)a * k + a] += static_cast<S>(1e-15);
+                xo = x;
+                if (cfg.solver_mode == 1) {
+                    if (L1 > 0) for (int i = 0; i < k; ++i) bw[i] -= L1;
+                    llt_factor(Gw.data(), k, L.data());
+                    for (int i = 0; i < k; ++i) x[i] = bw[i];
+                    llt_solve(L.data(), k, x.data());
+                    if (nonneg) for (int i = 0; i < k; ++i) x[i] = std::max(x[i], S(0));
+                } else {
+                    cd_nnls_col_fixed(Gw.data(), bw.data(), x.data(), k, L1, S(0), nonneg, cfg.cd_maxit, S(0), S(0));
+                }
+                S max_change = 0;
+                for (int i = 0; i < k; ++i) {
+                    const S rel = std::abs(x[i] - xo[i]) / (std::abs(xo[i]) + static_cast<S>(1e-12));
+                    if (rel > max_change) max_change = rel;
+                }
+                if (max_change < cfg.irls_tol) break;
+            }
+            for (int i = 0; i < k; ++i) xj[i] = x[i];
+        }
+    }
+}
+
+// fit_cv.hpp:1377-1443  per-element loss of the non-MSE CV fit: compute_loss(value, prediction, loss, theta) summed separately over
+// the training and the held-out entries (mask_zeros: nonzeros only; otherwise every entry); theta = GP's theta_vec, 0 otherwise.
+template <class S>
+static void cv_explicit_loss(const Csc<S>& A, const S* W_Td, const S* H, int k, const SpeckledMask& mask, const FitConfig<S>& cfg,
+                             const S* theta, int threads, S* train_sum, int64_t* n_train, S* test_sum, int64_t* n_test) {
+    const int nt = eff_threads(threads); (void)nt;
+    S tr = 0, te = 0;
+    int64_t ntr = 0, nte = 0;
+#pragma omp parallel for reduction(+ : tr, te, ntr, nte) num_threads(nt) schedule(dynamic, 16)
+    for (int j = 0; j < A.cols; ++j) {
+        const S* h = H + (size_t)j * k;
+        auto term = [&](int i, S actual) {
+            const S* w = W_Td + (size_t)i * k;
+            S pred = 0;
+            for (int f = 0; f < k; ++f) pred += w[f] * h[f];
+            const S th = cfg.loss_type == 4 ? theta[i] : S(0);
+            const S lv = cfg.loss_type == 0 ? (actual - pred) * (actual - pred) : loss_contribution(cfg.loss_type, actual, pred, th, cfg.tweedie_power);
+            if (mask.is_holdout(i, j)) { te += lv; ++nte; } else { tr += lv; ++ntr; }
+        };
+        if (mask.mask_zeros) {
+            for (int t = A.p[j]; t < A.p[j + 1]; ++t) term(A.i[t], A.x[t]);
+        } else {
+            int t = A.p[j];
+            const int tend = A.p[j + 1];
+            for (int i = 0; i < A.rows; ++i) {
+                S actual = 0;
+                if (t < tend && A.i[t] == i) { actual = A.x[t]; ++t; }
+                term(i, actual);
+            }
+        }
+    }
+    *train_sum = tr; *n_train = ntr; *test_sum = te; *n_test = nte;
+}
+
+// nmf/fit_cv.hpp:123-1667  nmf_fit_cv, sparse / standard updates / no user mask / no zero inflation; MSE, or (cfg.loss_type in
+// 4..8, or robust_delta > 0) the IRLS path: per-column weighted Grams, GP theta over the training entries, per-element losses.
 // W_T (k x m) and H (k x n) hold the initial factors on entry; on exit W_T is normalised, H carries d ("absorb d
 // into H", :1636-1638) and d is ALSO returned, exactly as the reference packages it.
 template <class S>
@@ -343,7 +498,56 @@ static CvResult<S> nmf_fit_cv(const Csc<S>& A, const FitConfig<S>& cfg, double h
     CvResult<S> res;
     S best_test = std::numeric_limits<S>::max(), prev_conv = std::numeric_limits<S>::max();
     int best_iter = 0, patience_count = 0;
+    const bool irls = cfg.loss_type != 0 || cfg.robust_delta > S(0);                       // LossConfig::requires_irls()
+    const bool is_gp = cfg.loss_type == 4;
+    std::vector<S> theta_vec;                                                               // :195-202
+    if (is_gp) theta_vec.assign(m, (cfg.dispersion_mode == 2 || cfg.dispersion_mode == 1) ? cfg.gp_theta_init : S(0));
+    std::vector<S> G_add((size_t)k * k);
     for (int iter = 0; iter < cfg.max_iter; ++iter) {
+        if (irls) {
+            // ---- H update, IRLS (:446-456): the CV features enter every column's weighted Gram; they are additive, so they are
+            // formed once on a zero matrix
+            std::fill(G_add.begin(), G_add.end(), S(0));
+            if (cfg.L2_H > 0) for (int i = 0; i < k; ++i) G_add[(size_t)i * k + i] += cfg.L2_H;
+            if (cfg.has_graph_H) apply_graph_reg(G_add.data(), cfg.graph_H, H, k, cfg.graph_H_lambda);
+            apply_L21(G_add.data(), H, k, (int64_t)n, cfg.L21_H);
+            cv_irls_half_update(A, W_T, H, k, mask, false, cfg.L1_H, cfg.nonneg_H, cfg, G_add.data(), threads);
+            if (cfg.ub_H > 0) apply_upper_bound(H, (size_t)k * n, cfg.ub_H);
+            apply_angular_posthoc(H, k, (int64_t)n, cfg.angular_H);
+            extract_scaling(H, k, n, d, cfg.norm_type);
+            // ---- W update, IRLS (:670-689)
+            std::fill(G_add.begin(), G_add.end(), S(0));
+            if (cfg.L2_W > 0) for (int i = 0; i < k; ++i) G_add[(size_t)i * k + i] += cfg.L2_W;
+            if (cfg.has_graph_W) apply_graph_reg(G_add.data(), cfg.graph_W, W_T, k, cfg.graph_W_lambda);
+            apply_L21(G_add.data(), W_T, k, (int64_t)m, cfg.L21_W);
+            cv_irls_half_update(At, H, W_T, k, mask, true, cfg.L1_W, cfg.nonneg_W, cfg, G_add.data(), threads);
+            if (cfg.ub_W > 0) apply_upper_bound(W_T, (size_t)k * m, cfg.ub_W);
+            apply_angular_posthoc(W_T, k, (int64_t)m, cfg.angular_W);
+            extract_scaling(W_T, k, m, d, cfg.norm_type);
+            // ---- GP theta over the training entries (:866-961); the NB size and the Gamma-family phi are estimated by the reference
+            // too (:966-1155) but reach neither the CV weights nor the CV losses nor the plugin's outputs
+            if (is_gp && cfg.dispersion_mode != 0) gp_theta_update(A, W_T, H, d, k, cfg, theta_vec, &mask);
+            // ---- losses (:1377-1443, :1546-1549)
+            for (int i = 0; i < m; ++i) for (int f = 0; f < k; ++f) Wd[(size_t)i * k + f] = W_T[(size_t)i * k + f] * d[f];
+            S tr = 0, te = 0; int64_t ntr = 0, nte = 0;
+            cv_explicit_loss(A, Wd.data(), H, k, mask, cfg, theta_vec.data(), threads, &tr, &ntr, &te, &nte);
+            const S train_loss = ntr > 0 ? tr / static_cast<S>(ntr) : S(0);
+            const S test_loss = nte > 0 ? te / static_cast<S>(nte) : S(0);
+            res.train_hist.push_back(train_loss); res.test_hist.push_back(test_loss);
+            res.train_loss = train_loss; res.test_loss = test_loss;
+            S rel = 0;
+            if (iter > 0) rel = std::abs(prev_conv - test_loss) / (std::abs(prev_conv) + static_cast<S>(1e-15));
+            if (test_loss < best_test) { best_test = test_loss; best_iter = iter; patience_count = 0; }
+            else ++patience_count;
+            if (cv_patience > 0 && patience_count >= cv_patience) { res.iterations = iter + 1; res.converged = false; break; }
+            if (iter > 0) {
+                res.final_tol = rel;
+                if (rel < cfg.tol) { res.iterations = iter + 1; res.converged = true; break; }
+            }
+            prev_conv = test_loss;
+            res.iterations = iter + 1;
+            continue;
+        }
         // ---- H update (:408-535)
         gram(W_T, k, m, G.data());
         for (int i = 0; i < k; ++i) G[(size_t)i * k + i] += static_cast<S>(1e-15);        // :410 (on top of gram's own eps)
@@ -408,6 +612,7 @@ static CvResult<S> nmf_fit_cv(const Csc<S>& A, const FitConfig<S>& cfg, double h
         res.iterations = iter + 1;
     }
     res.best_test_loss = best_test; res.best_iter = best_iter;
+    res.theta = theta_vec;
     for (int j = 0; j < n; ++j) for (int f = 0; f < k; ++f) H[(size_t)j * k + f] *= d[f];   // :1636-1638
     return res;
 }
@@ -552,7 +757,9 @@ static void nb_size_update(const Csc<S>& A, const S* W_T, const S* H, const S* d
 // passes over the cached (row, y, s) of the nonzeros; everything in fp64 except s (a Scalar dot) and theta (stored Scalar).
 template <class S>
 static void gp_theta_update(const Csc<S>& A, const S* W_T, const S* H, const S* d, int k, const FitConfig<S>& cfg,
-                            std::vector<S>& theta) {
+                            std::vector<S>& theta, const SpeckledMask* cv_mask) {
+    // cv_mask: nmf/fit_cv.hpp:866-961 -- the same update over the TRAINING entries only: held-out nonzeros are skipped and the
+    // held-out pairs' predictions (zeros included) leave sum_s
     const int m = A.rows, n = A.cols;
     std::vector<S> Wd((size_t)k * m);
     for (int i = 0; i < m; ++i) for (int f = 0; f < k; ++f) Wd[(size_t)i * k + f] = W_T[(size_t)i * k + f] * d[f];
@@ -565,12 +772,21 @@ static void gp_theta_update(const Csc<S>& A, const S* W_T, const S* H, const S* 
         for (int f = 0; f < k; ++f) t += w[f] * h_rs[f];
         sum_s[i] = static_cast<double>(t);
     }
+    if (cv_mask)                                                                                     // fit_cv.hpp:886-893
+        for (int j = 0; j < n; ++j)
+            for (int i = 0; i < m; ++i)
+                if (cv_mask->is_holdout(i, j)) {
+                    S t = 0; const S* w = Wd.data() + (size_t)i * k; const S* h = H + (size_t)j * k;
+                    for (int f = 0; f < k; ++f) t += w[f] * h[f];
+                    sum_s[i] -= static_cast<double>(t);
+                }
     struct Nz { int row; double y, s; };
     std::vector<Nz> cache; cache.reserve((size_t)A.p[n]);
     for (int j = 0; j < n; ++j) {                                                                    // :941-952
         const S* h = H + (size_t)j * k;
         for (int t = A.p[j]; t < A.p[j + 1]; ++t) {
             const int i = A.i[t]; const S* w = Wd.data() + (size_t)i * k;
+            if (cv_mask && cv_mask->is_holdout(i, j)) continue;                                       // fit_cv.hpp:899
             S dot = 0; for (int f = 0; f < k; ++f) dot += w[f] * h[f];
             const double y = static_cast<double>(A.x[t]);
             const double sv = std::max(static_cast<double>(dot), 1e-10);
@@ -1133,6 +1349,54 @@ ORACLE_API int oracle_cv_is_holdout(double frac, uint64_t cv_seed, int i, int j)
         std::vector<S> Wd((size_t)k * m);                                                                          \
         for (int r = 0; r < m; ++r) for (int f = 0; f < k; ++f) Wd[(size_t)r * k + f] = W_T[(size_t)r * k + f] * d[f]; \
         cv_test_error(mk(m, n, p, i, x), Wd.data(), H, k, SpeckledMask(frac, cv_seed, mask_zeros != 0), 1, sq_err, n_test); \
+    }                                                                                                              \
+    ORACLE_API void oracle_cv_irls_half_update_##SUF(int rows, int cols, const int* p, const int* i, const S* x, const S* F, \
+                                                     const S* G_add, S* X, int k, double frac, uint64_t cv_seed, int mask_zeros, \
+                                                     int transposed, S L1, int nonneg, int cd_maxit, int solver_mode, int loss_type, \
+                                                     int irls_max_iter, S irls_tol, S power, S robust, int threads) { \
+        FitConfig<S> c;                                                                                            \
+        c.k = k; c.cd_maxit = cd_maxit; c.solver_mode = solver_mode; c.loss_type = loss_type; c.irls_max_iter = irls_max_iter; \
+        c.irls_tol = irls_tol; c.tweedie_power = power; c.robust_delta = robust;                                   \
+        cv_irls_half_update(mk(rows, cols, p, i, x), F, X, k, SpeckledMask(frac, cv_seed, mask_zeros != 0), transposed != 0, L1, \
+                            nonneg != 0, c, G_add, threads);                                                       \
+    }                                                                                                              \
+    ORACLE_API void oracle_cv_explicit_loss_##SUF(int m, int n, const int* p, const int* i, const S* x, const S* W_T, const S* d, \
+                                                  const S* H, int k, double frac, uint64_t cv_seed, int mask_zeros, int loss_type, \
+                                                  S power, const S* theta, S* out_train, int64_t* n_train, S* out_test, int64_t* n_test) { \
+        std::vector<S> Wd((size_t)k * m);                                                                          \
+        for (int r = 0; r < m; ++r) for (int f = 0; f < k; ++f) Wd[(size_t)r * k + f] = W_T[(size_t)r * k + f] * d[f]; \
+        FitConfig<S> c; c.k = k; c.loss_type = loss_type; c.tweedie_power = power;                                 \
+        cv_explicit_loss(mk(m, n, p, i, x), Wd.data(), H, k, SpeckledMask(frac, cv_seed, mask_zeros != 0), c, theta, 1, out_train, \
+                         n_train, out_test, n_test);                                                               \
+    }                                                                                                              \
+    ORACLE_API void oracle_cv_gp_theta_update_##SUF(int m, int n, const int* p, const int* i, const S* x, const S* W_T, const S* d, \
+                                                    const S* H, int k, double frac, uint64_t cv_seed, int mode, S theta_max, S* theta) { \
+        FitConfig<S> c; c.k = k; c.dispersion_mode = mode; c.gp_theta_max = theta_max;                             \
+        std::vector<S> th(theta, theta + m);                                                                       \
+        const SpeckledMask mk_(frac, cv_seed, false);                                                              \
+        gp_theta_update(mk(m, n, p, i, x), W_T, H, d, k, c, th, frac > 0 ? &mk_ : nullptr);                        \
+        std::copy(th.begin(), th.end(), theta);                                                                    \
+    }                                                                                                              \
+    ORACLE_API S oracle_irls_weight_gp_##SUF(S observed, S predicted, S theta, S blend) { return irls_weight_gp(observed, predicted, theta, blend); } \
+    ORACLE_API void oracle_nmf_fit_cv_irls_##SUF(int m, int n, const int* p, const int* i, const S* x, int k, S* W_T, S* H, \
+                                            S* d, int max_iter, S tol, S L1_H, S L1_W, S L2_H, S L2_W, int cd_maxit, \
+                                            int nonneg_W, int nonneg_H, int norm_type, int solver_mode, double frac, \
+                                            uint64_t cv_seed, int mask_zeros, int cv_patience, int threads,         \
+                                            int loss_type, int irls_max_iter, S irls_tol, int dispersion_mode, S gp_theta_init, \
+                                            S gp_theta_max, S power, S robust,                                      \
+                                            int* out_iter, int* out_converged, S* out_train, S* out_test,           \
+                                            S* out_best_test, int* out_best_iter, S* train_hist, S* test_hist, S* theta_out) { \
+        FitConfig<S> c;                                                                                            \
+        c.k = k; c.max_iter = max_iter; c.tol = tol; c.L1_H = L1_H; c.L1_W = L1_W; c.L2_H = L2_H; c.L2_W = L2_W;    \
+        c.cd_maxit = cd_maxit; c.nonneg_W = nonneg_W != 0; c.nonneg_H = nonneg_H != 0; c.norm_type = norm_type;     \
+        c.solver_mode = solver_mode; c.threads = threads; c.loss_type = loss_type; c.irls_max_iter = irls_max_iter; \
+        c.irls_tol = irls_tol; c.dispersion_mode = dispersion_mode; c.gp_theta_init = gp_theta_init; c.gp_theta_max = gp_theta_max; \
+        c.tweedie_power = power; c.robust_delta = robust;                                                          \
+        CvResult<S> r = nmf_fit_cv(mk(m, n, p, i, x), c, frac, cv_seed, mask_zeros != 0, cv_patience, W_T, H, d);   \
+        *out_iter = r.iterations; *out_converged = r.converged ? 1 : 0; *out_train = r.train_loss;                 \
+        *out_test = r.test_loss; *out_best_test = r.best_test_loss; *out_best_iter = r.best_iter;                   \
+        for (size_t t = 0; t < r.train_hist.size(); ++t) { if (train_hist) train_hist[t] = r.train_hist[t]; if (test_hist) test_hist[t] = r.test_hist[t]; } \
+        if (theta_out) for (size_t t = 0; t < r.theta.size(); ++t) theta_out[t] = r.theta[t];                       \
     }                                                                                                              \
     ORACLE_API void oracle_nmf_fit_cv_##SUF(int m, int n, const int* p, const int* i, const S* x, int k, S* W_T, S* H, \
                                             S* d, int max_iter, S tol, S L1_H, S L1_W, S L2_H, S L2_W, int cd_maxit, \

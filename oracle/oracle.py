@@ -486,16 +486,93 @@ def cv_test_error(A, W_T, d, H, frac, cv_seed, mask_zeros=False, dtype=np.float6
     return float(sq.value), int(cnt.value)
 
 
+def cv_irls_half_update(A, F, X, k, frac, cv_seed, loss_type, G_add=None, mask_zeros=False, transposed=False, L1=0.0, nonneg=True,
+                        cd_maxit=100, solver_mode=0, irls_max_iter=5, irls_tol=1e-4, power=1.5, robust=0.0, threads=1, dtype=np.float64):
+    """One CV half-update with an IRLS loss (reference nmf/cv_detail.hpp:101-292) over the columns of A (W side: A^T, transposed)."""
+    suf, ct = _suf(dtype)
+    F = _f(F, dtype)
+    X = _f(X, dtype).copy()
+    Ga = _f(G_add, dtype) if G_add is not None else None
+    x = A.values(dtype)
+    getattr(lib(), "oracle_cv_irls_half_update_" + suf)(
+        C.c_int(A.rows), C.c_int(A.cols), _p(A.p), _p(A.i), _p(x), _p(F), _p(Ga) if Ga is not None else None, _p(X), C.c_int(k),
+        C.c_double(frac), C.c_uint64(cv_seed), C.c_int(int(mask_zeros)), C.c_int(int(transposed)), ct(L1), C.c_int(int(nonneg)),
+        C.c_int(cd_maxit), C.c_int(solver_mode), C.c_int(loss_type), C.c_int(irls_max_iter), ct(irls_tol), ct(power), ct(robust),
+        C.c_int(threads))
+    return X
+
+
+def cv_explicit_loss(A, W_T, d, H, frac, cv_seed, loss_type, theta=None, mask_zeros=False, power=1.5, dtype=np.float64):
+    """(train sum, n_train, test sum, n_test) of the per-element losses (reference nmf/fit_cv.hpp:1377-1443)."""
+    suf, ct = _suf(dtype)
+    W_T, H, d = _f(W_T, dtype), _f(H, dtype), _f(d, dtype)
+    th = _f(theta if theta is not None else np.zeros(A.rows), dtype)
+    x = A.values(dtype)
+    tr, te, ntr, nte = ct(0), ct(0), C.c_int64(0), C.c_int64(0)
+    getattr(lib(), "oracle_cv_explicit_loss_" + suf)(
+        C.c_int(A.rows), C.c_int(A.cols), _p(A.p), _p(A.i), _p(x), _p(W_T), _p(d), _p(H), C.c_int(W_T.shape[1]), C.c_double(frac),
+        C.c_uint64(cv_seed), C.c_int(int(mask_zeros)), C.c_int(loss_type), ct(power), _p(th), C.byref(tr), C.byref(ntr), C.byref(te),
+        C.byref(nte))
+    return float(tr.value), int(ntr.value), float(te.value), int(nte.value)
+
+
+def cv_gp_theta_update(A, W_T, d, H, theta, frac, cv_seed, mode=2, theta_max=5.0, dtype=np.float64):
+    """GP theta (MM update, five inner passes) over the TRAINING entries (reference nmf/fit_cv.hpp:866-961); frac = 0: all entries."""
+    suf, ct = _suf(dtype)
+    W_T, H, d = _f(W_T, dtype), _f(H, dtype), _f(d, dtype)
+    th = _f(theta, dtype).copy()
+    x = A.values(dtype)
+    getattr(lib(), "oracle_cv_gp_theta_update_" + suf)(
+        C.c_int(A.rows), C.c_int(A.cols), _p(A.p), _p(A.i), _p(x), _p(W_T), _p(d), _p(H), C.c_int(W_T.shape[1]), C.c_double(frac),
+        C.c_uint64(cv_seed), C.c_int(mode), ct(theta_max), _p(th))
+    return th
+
+
+def irls_weight_gp(observed, predicted, theta, blend=1.0, dtype=np.float64):
+    suf, ct = _suf(dtype)
+    fn = getattr(lib(), "oracle_irls_weight_gp_" + suf)
+    fn.restype = ct
+    return fn(ct(observed), ct(predicted), ct(theta), ct(blend))
+
+
 class CvFitResult:
     pass
 
 
 def nmf_fit_cv(A, W_T, H, dtype=np.float64, max_iter=100, tol=1e-4, L1=(0.0, 0.0), L2=(0.0, 0.0), cd_maxit=100,
                nonneg=(True, True), norm_type=0, solver_mode=0, holdout_fraction=0.1, cv_seed=0, mask_zeros=False,
-               cv_patience=5, threads=1, native=False, graph_H=None, graph_W=None):
-    """CPU restatement of nmf_fit_cv (reference nmf/fit_cv.hpp), MSE / sparse.  Returns W_T (normalised), H WITH d
-    absorbed and d, as the reference packages them."""
+               cv_patience=5, threads=1, native=False, graph_H=None, graph_W=None, loss_type=0, irls_max_iter=5, irls_tol=1e-4,
+               dispersion_mode=2, gp_theta=(0.1, 5.0), tweedie_power=1.5, robust_delta=0.0):
+    """CPU restatement of nmf_fit_cv (reference nmf/fit_cv.hpp), sparse.  Returns W_T (normalised), H WITH d
+    absorbed and d, as the reference packages them.  loss_type != 0 (4 GP, 5 NB, 6 Gamma, 7 inverse Gaussian, 8 Tweedie) or
+    robust_delta > 0: the IRLS path (no graph arguments there); result.theta = GP theta at exit."""
     suf, ct = _suf(dtype)
+    if loss_type != 0 or robust_delta > 0:
+        assert graph_H is None and graph_W is None
+        W_T = _f(W_T, dtype).copy()
+        H = _f(H, dtype).copy()
+        m, k = W_T.shape
+        n = H.shape[0]
+        d = np.ones(k, dtype)
+        x = A.values(dtype)
+        th = np.full(max(max_iter, 1), np.nan, dtype)
+        eh = np.full(max(max_iter, 1), np.nan, dtype)
+        theta = np.zeros(m, dtype)
+        it, conv, bi = C.c_int(0), C.c_int(0), C.c_int(0)
+        tr, te, bt = ct(0), ct(0), ct(0)
+        getattr(lib(native), "oracle_nmf_fit_cv_irls_" + suf)(
+            C.c_int(m), C.c_int(n), _p(A.p), _p(A.i), _p(x), C.c_int(k), _p(W_T), _p(H), _p(d), C.c_int(max_iter), ct(tol),
+            ct(L1[1]), ct(L1[0]), ct(L2[1]), ct(L2[0]), C.c_int(cd_maxit), C.c_int(int(nonneg[0])), C.c_int(int(nonneg[1])),
+            C.c_int(norm_type), C.c_int(solver_mode), C.c_double(holdout_fraction), C.c_uint64(cv_seed), C.c_int(int(mask_zeros)),
+            C.c_int(cv_patience), C.c_int(threads), C.c_int(loss_type), C.c_int(irls_max_iter), ct(irls_tol), C.c_int(dispersion_mode),
+            ct(gp_theta[0]), ct(gp_theta[1]), ct(tweedie_power), ct(robust_delta),
+            C.byref(it), C.byref(conv), C.byref(tr), C.byref(te), C.byref(bt), C.byref(bi), _p(th), _p(eh), _p(theta))
+        r = CvFitResult()
+        r.W_T, r.H, r.d, r.theta = W_T, H, d, theta
+        r.iter, r.converged = it.value, bool(conv.value)
+        r.train_loss, r.test_loss, r.best_test_loss, r.best_iter = float(tr.value), float(te.value), float(bt.value), bi.value
+        r.train_history, r.test_history = th[:it.value].copy(), eh[:it.value].copy()
+        return r
     W_T = _f(W_T, dtype).copy()
     H = _f(H, dtype).copy()
     m, k = W_T.shape

@@ -19,6 +19,12 @@ __attribute__((visibility("default"))) float ref_loss_nb_f32(float observed, flo
 }
 __attribute__((visibility("default"))) double ref_irls_weight_kl_f64(double predicted) { return FactorNet::irls_weight_kl<double>(predicted); }
 __attribute__((visibility("default"))) float ref_irls_weight_kl_f32(float predicted) { return FactorNet::irls_weight_kl<float>(predicted); }
+__attribute__((visibility("default"))) double ref_irls_weight_gp_f64(double observed, double predicted, double theta, double blend) {
+    return FactorNet::irls_weight_gp<double>(observed, predicted, theta, blend);
+}
+__attribute__((visibility("default"))) float ref_irls_weight_gp_f32(float observed, float predicted, float theta, float blend) {
+    return FactorNet::irls_weight_gp<float>(observed, predicted, theta, blend);
+}
 __attribute__((visibility("default"))) double ref_loss_gp_f64(double observed, double predicted, double theta) {
     return FactorNet::loss_contribution_gp<double>(observed, predicted, theta);
 }

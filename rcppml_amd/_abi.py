@@ -20,12 +20,12 @@ OPT_CD_COUNT_NOOP, OPT_CD_LMF_LANE_GROUPS, OPT_CD_LMF_WAVES_PER_SIMD, OPT_CD_NO_
 # Every symbol include/rcppml_gpu.h declares (tests check the library exports all of them).
 EXPORTED_SYMBOLS = [
     "rcppml_gpu_detect", "rcppml_gpu_nmf_unified_float", "rcppml_gpu_nmf_unified_double", "rcppml_gpu_nmf_ex",
-    "rcppml_gpu_nmf_cv_unified_float", "rcppml_gpu_nmf_cv_unified_double", "rcppml_gpu_nmf_cv_ex", "rcppml_gpu_nmf_zerocopy_double",
+    "rcppml_gpu_nmf_cv_unified_float", "rcppml_gpu_nmf_cv_unified_double", "rcppml_gpu_nmf_cv_ex", "rcppml_gpu_nmf_cv_irls_ex", "rcppml_gpu_nmf_zerocopy_double",
     "rcppml_gpu_nnls_double", "rcppml_gpu_evaluate_mse_double", "rcppml_gpu_last_error",
     "rcppml_hip_ctx_create", "rcppml_hip_ctx_destroy", "rcppml_hip_ctx_sync", "rcppml_hip_ctx_stats", "rcppml_hip_ctx_set_option", "rcppml_hip_transpose_csc", "rcppml_hip_transpose_csc_sort", "rcppml_hip_transpose_csc_gather", "rcppml_hip_cast", "rcppml_hip_gram", "rcppml_hip_rhs",
     "rcppml_hip_solve_cd", "rcppml_hip_order_columns", "rcppml_hip_solve_chol", "rcppml_hip_row_norms", "rcppml_hip_apply_scaling",
     "rcppml_hip_sumsq", "rcppml_hip_loss_mse", "rcppml_hip_solve_masked", "rcppml_hip_loss_nonzeros",
-    "rcppml_hip_solve_irls_nb", "rcppml_hip_nb_size_update", "rcppml_hip_nb_loss", "rcppml_hip_solve_irls", "rcppml_hip_irls_loss", "rcppml_hip_apply_l21", "rcppml_hip_angular_posthoc", "rcppml_hip_solve_cv", "rcppml_hip_cv_test_error", "rcppml_hip_mul_rows", "rcppml_hip_apply_graph_reg", "rcppml_hip_dispersion_update", "rcppml_hip_vec_global", "rcppml_hip_spz_info", "rcppml_hip_spz_decode",
+    "rcppml_hip_solve_irls_nb", "rcppml_hip_nb_size_update", "rcppml_hip_nb_loss", "rcppml_hip_solve_irls", "rcppml_hip_irls_loss", "rcppml_hip_apply_l21", "rcppml_hip_angular_posthoc", "rcppml_hip_solve_cv", "rcppml_hip_cv_test_error", "rcppml_hip_solve_cv_irls", "rcppml_hip_cv_irls_loss", "rcppml_hip_cv_gp_theta_update", "rcppml_hip_mul_rows", "rcppml_hip_apply_graph_reg", "rcppml_hip_dispersion_update", "rcppml_hip_vec_global", "rcppml_hip_spz_info", "rcppml_hip_spz_decode",
     "rcppml_sp_read_gpu", "rcppml_sp_free_gpu", "rcppml_hip_rhs_dense", "rcppml_gpu_nmf_dense_unified_float",
     "rcppml_gpu_nmf_dense_unified_double",
     "rcppml_hip_rhs_plan_create", "rcppml_hip_rhs_plan_destroy", "rcppml_hip_rhs_plan_info", "rcppml_hip_rhs_planned",
@@ -249,10 +249,12 @@ def _dptr(t):
 def nmf_cv(p, i, x, m, n, k, W_T, H, *, entry="ex", max_iter=100, tol=1e-4, L1_H=0.0, L1_W=0.0, L2_H=0.0, L2_W=0.0, cd_maxit=100,
            verbose=0, seed=0, holdout_fraction=0.1, cv_seed=0, mask_zeros=0, nonneg_W=1, nonneg_H=1, norm_type=0, loss_type=0,
            solver_mode=0, projective=0, symmetric=0, graph_W_nnz=0, sort_model=1, precision=F64, cv_patience=5,
-           graph_W=None, graph_H=None):
+           graph_W=None, graph_H=None, irls_max_iter=5, irls_tol=1e-4, dispersion_mode=2, gp_theta=(0.1, 5.0), tweedie_power=1.5,
+           robust_delta=0.0):
     """Call the CV plugin entry as reference gpu/bridge_nmf.hpp:407-497 does (51 pointers; entry "float" | "double"), or
-    the build-defined "ex" form (+ sort flag, precision, patience, loss histories).  W_T (m, k) and H (n, k) float64
-    arrays are updated IN PLACE (H returns with d absorbed)."""
+    the build-defined "ex" form (+ sort flag, precision, patience, loss histories) or "irls_ex" (+ dispersion mode, GP theta
+    init / max, Tweedie power, robust_delta; returns theta).  W_T (m, k) and H (n, k) float64 arrays are updated IN PLACE (H
+    returns with d absorbed).  loss_type 4..8: the IRLS CV path."""
     L = lib()
     p = np.ascontiguousarray(p, np.int32)
     i = np.ascontiguousarray(i, np.int32)
@@ -269,7 +271,7 @@ def nmf_cv(p, i, x, m, n, k, W_T, H, *, entry="ex", max_iter=100, tol=1e-4, L1_H
         _np_ptr(W_T), _np_ptr(H), _np_ptr(d), _ci(max_iter), _cd(tol),
         _cd(L1_H), _cd(L1_W), _cd(L2_H), _cd(L2_W), _ci(cd_maxit), _ci(verbose), _ci(seed),
         _cd(holdout_fraction), _ci(cv_seed), _ci(mask_zeros), _ci(nonneg_W), _ci(nonneg_H), _ci(norm_type),
-        _ci(loss_type), _cd(1.0), _ci(5), _cd(1e-4),
+        _ci(loss_type), _cd(1.0), _ci(irls_max_iter), _cd(irls_tol),
         _np_ptr(dummy_i), _np_ptr(dummy_i), _np_ptr(dummy_d), _ci(0), _ci(graph_W_nnz), _cd(0.0),
         _np_ptr(dummy_i), _np_ptr(dummy_i), _np_ptr(dummy_d), _ci(0), _ci(0), _cd(0.0),
         _ci(projective), _ci(symmetric), _ci(solver_mode),
@@ -285,7 +287,16 @@ def nmf_cv(p, i, x, m, n, k, W_T, H, *, entry="ex", max_iter=100, tol=1e-4, L1_H
             keep.append((gp, gi, gx))
     assert len(args) == 51
     th = eh = None
-    if entry == "ex":
+    theta = None
+    if entry == "irls_ex":
+        th = np.full(max(max_iter, 1), np.nan)
+        eh = np.full(max(max_iter, 1), np.nan)
+        theta = np.zeros(max(m, 1), np.float64)
+        fn = L.rcppml_gpu_nmf_cv_irls_ex
+        fn.restype = None
+        fn(*args, _ci(sort_model), _ci(precision), _ci(cv_patience), _np_ptr(th), _np_ptr(eh), _ci(dispersion_mode), _cd(gp_theta[0]),
+           _cd(gp_theta[1]), _cd(tweedie_power), _cd(robust_delta), _np_ptr(theta))
+    elif entry == "ex":
         th = np.full(max(max_iter, 1), np.nan)
         eh = np.full(max(max_iter, 1), np.nan)
         fn = L.rcppml_gpu_nmf_cv_ex
@@ -301,6 +312,8 @@ def nmf_cv(p, i, x, m, n, k, W_T, H, *, entry="ex", max_iter=100, tol=1e-4, L1_H
         res["error"] = last_error()
     if th is not None:
         res["train_history"], res["test_history"] = th[:out_iter.value].copy(), eh[:out_iter.value].copy()
+    if theta is not None:
+        res["theta"] = theta
     return res
 
 
@@ -465,6 +478,28 @@ class Context:
         _chk(lib().rcppml_hip_cv_test_error(self._h, C.c_int(dt), _dptr(col_ptr), _dptr(row_idx), _dptr(values), C.c_int64(ncols),
                                             C.c_int(nrows), _dptr(W_T), _dptr(d), _dptr(H), C.c_int(k), C.c_double(frac),
                                             C.c_ulonglong(cv_seed), C.c_int(mask_zeros), _dptr(out2)), "cv_test_error")
+
+    def solve_cv_irls(self, dt, loss_type, col_ptr, row_idx, values, ncols, nrows, F, G_add, X, k, frac, cv_seed, mask_zeros=0, transposed=0,
+                      l1=0.0, nonneg=1, cd_maxit=100, solver_mode=0, irls_max_iter=5, irls_tol=1e-4, loss_param=1.5, robust_delta=0.0):
+        _chk(lib().rcppml_hip_solve_cv_irls(self._h, C.c_int(dt), C.c_int(loss_type), _dptr(col_ptr), _dptr(row_idx), _dptr(values),
+                                            C.c_int64(ncols), C.c_int(nrows), _dptr(F), _dptr(G_add) if G_add is not None else None,
+                                            _dptr(X), C.c_int(k), C.c_double(frac), C.c_ulonglong(cv_seed), C.c_int(mask_zeros),
+                                            C.c_int(transposed), C.c_double(l1), C.c_int(nonneg), C.c_int(cd_maxit), C.c_int(solver_mode),
+                                            C.c_int(irls_max_iter), C.c_double(irls_tol), C.c_double(loss_param), C.c_double(robust_delta)),
+             "solve_cv_irls")
+
+    def cv_irls_loss(self, dt, loss_type, col_ptr, row_idx, values, ncols, nrows, W_T, d, H, theta_row, k, frac, cv_seed, mask_zeros,
+                     loss_param, out4):
+        _chk(lib().rcppml_hip_cv_irls_loss(self._h, C.c_int(dt), C.c_int(loss_type), _dptr(col_ptr), _dptr(row_idx), _dptr(values),
+                                           C.c_int64(ncols), C.c_int(nrows), _dptr(W_T), _dptr(d), _dptr(H),
+                                           _dptr(theta_row) if theta_row is not None else None, C.c_int(k), C.c_double(frac),
+                                           C.c_ulonglong(cv_seed), C.c_int(mask_zeros), C.c_double(loss_param), _dptr(out4)), "cv_irls_loss")
+
+    def cv_gp_theta_update(self, dt, mode, t_col_ptr, t_row_idx, t_values, m, nnz, W_T, d, H, n, k, frac, cv_seed, theta_max, theta):
+        _chk(lib().rcppml_hip_cv_gp_theta_update(self._h, C.c_int(dt), C.c_int(mode), _dptr(t_col_ptr), _dptr(t_row_idx), _dptr(t_values),
+                                                 C.c_int64(m), C.c_int64(nnz), _dptr(W_T), _dptr(d), _dptr(H), C.c_int64(n), C.c_int(k),
+                                                 C.c_double(frac), C.c_ulonglong(cv_seed), C.c_double(theta_max), _dptr(theta)),
+             "cv_gp_theta_update")
 
     def apply_graph_reg(self, dt, G, lap_p, lap_i, lap_x, X, k, ncols, lam):
         _chk(lib().rcppml_hip_apply_graph_reg(self._h, C.c_int(dt), _dptr(G), _dptr(lap_p), _dptr(lap_i), _dptr(lap_x), _dptr(X),

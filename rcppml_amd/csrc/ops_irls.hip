@@ -216,3 +216,5 @@ extern "C" int rcppml_hip_nb_loss(rcppml_hip_ctx* c, int dtype, const int* col_p
                                   double* out) {
     return rcppml_hip_irls_loss(c, dtype, 5, col_ptr, row_idx, values, ncols, W_T, d, H, theta_row, k, 0.0, 0.0, out);
 }
+
+#include "ops_cv_irls.hip.h"

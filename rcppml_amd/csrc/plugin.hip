@@ -678,6 +678,12 @@ struct CvParams {
     double* train_history = nullptr; double* test_history = nullptr;     // optional, max_iter entries each
     const int* gH_p = nullptr; const int* gH_i = nullptr; const double* gH_x = nullptr; int gH_nnz = 0; double gH_lambda = 0;
     const int* gW_p = nullptr; const int* gW_i = nullptr; const double* gW_x = nullptr; int gW_nnz = 0; double gW_lambda = 0;
+    // IRLS losses (cv_detail.hpp:101-292).  The CV boundary carries loss_type, irls_max_iter and irls_tol only (bridge_nmf.hpp:77-99):
+    // dispersion mode, GP theta bounds, Tweedie power and robust_delta take the reference's config defaults (core/config.hpp:151-172,
+    // math/loss.hpp:109-115) unless the build-defined entry overrides them
+    int loss_type = 0, irls_max_iter = 5; double irls_tol = 1e-4;
+    int dispersion_mode = 2; double gp_theta_init = 0.1, gp_theta_max = 5.0, tweedie_power = 1.5, robust_delta = 0.0;
+    double* out_theta = nullptr;          // m doubles (GP theta at exit), may be NULL
     int out_iter = 0, out_converged = 0, out_best_iter = 0; double out_train = 0, out_test = 0, out_best_test = 0;
 };
 
@@ -730,7 +736,69 @@ void fit_cv(CvParams& P) {
         upload_ints(P.gW_p, (size_t)m + 1, dGWp, s); upload_ints(P.gW_i, (size_t)P.gW_nnz, dGWi, s);
         upload_cast<T>(c, P.gW_x, (size_t)P.gW_nnz, dGWx, s);
     }
+    const bool irls = P.loss_type != 0 || P.robust_delta > 0;        // LossConfig::requires_irls()
+    const bool is_gp = P.loss_type == 4;
+    DevBuf dtheta, dGadd;
+    if (irls) {
+        dGadd.alloc((size_t)k * k * sizeof(T));
+        if (is_gp) {                                                  // fit_cv.hpp:195-202
+            std::vector<T> th((size_t)m, static_cast<T>(P.dispersion_mode != 0 ? P.gp_theta_init : 0.0));
+            dtheta.alloc((size_t)m * sizeof(T));
+            HIPCHK(hipMemcpyAsync(dtheta.p, th.data(), (size_t)m * sizeof(T), hipMemcpyHostToDevice, s));
+            HIPCHK(hipStreamSynchronize(s));
+        }
+    }
+    // the additive CV features of one side (apply_cv_features on a zero matrix: L2 on the diagonal, graph term), added to every
+    // column's weighted Gram by the IRLS solve
+    auto features_only = [&](double l2, bool graph, DevBuf& gp, DevBuf& gi, DevBuf& gx, void* factor, int64_t len, double lambda) {
+        HIPCHK(hipMemsetAsync(dGadd.p, 0, (size_t)k * k * sizeof(T), s));
+        if (l2 > 0) OPCHK(rcppml_hip_add_diag(c, dt, dGadd.p, k, l2));
+        if (graph) OPCHK(rcppml_hip_apply_graph_reg(c, dt, dGadd.p, gp.as<int>(), gi.as<int>(), gx.p, factor, k, len, lambda));
+    };
     for (int iter = 0; iter < P.max_iter; ++iter) {
+        if (irls) {
+            // ---- IRLS path (fit_cv.hpp:446-456, :670-689): per-column weighted Grams over the training entries
+            features_only(P.L2_H, graph_H, dGHp, dGHi, dGHx, dH.p, n, P.gH_lambda);
+            OPCHK(rcppml_hip_solve_cv_irls(c, dt, P.loss_type, dAp.as<int>(), dAi.as<int>(), dAx.p, n, m, dW.p, dGadd.p, dH.p, k,
+                                           P.holdout_fraction, P.cv_seed, P.mask_zeros, 0, P.L1_H, P.nonneg_H, P.cd_maxit, P.solver_mode,
+                                           P.irls_max_iter, P.irls_tol, P.tweedie_power, P.robust_delta));
+            OPCHK(rcppml_hip_row_norms(c, dt, dH.p, k, n, P.norm_type, dsums.p));
+            OPCHK(rcppml_hip_apply_scaling(c, dt, dH.p, k, n, P.norm_type, dsums.p, dd.p));
+            features_only(P.L2_W, graph_W, dGWp, dGWi, dGWx, dW.p, m, P.gW_lambda);
+            OPCHK(rcppml_hip_solve_cv_irls(c, dt, P.loss_type, dTp.as<int>(), dTi.as<int>(), dTx.p, m, n, dH.p, dGadd.p, dW.p, k,
+                                           P.holdout_fraction, P.cv_seed, P.mask_zeros, 1, P.L1_W, P.nonneg_W, P.cd_maxit, P.solver_mode,
+                                           P.irls_max_iter, P.irls_tol, P.tweedie_power, P.robust_delta));
+            OPCHK(rcppml_hip_row_norms(c, dt, dW.p, k, m, P.norm_type, dsums.p));
+            OPCHK(rcppml_hip_apply_scaling(c, dt, dW.p, k, m, P.norm_type, dsums.p, dd.p));
+            // ---- GP theta over the training entries (:866-961).  (The NB size and the Gamma-family phi the reference also
+            // estimates here reach neither the CV weights, nor the CV losses, nor anything this boundary returns.)
+            if (is_gp && P.dispersion_mode != 0)
+                OPCHK(rcppml_hip_cv_gp_theta_update(c, dt, P.dispersion_mode, dTp.as<int>(), dTi.as<int>(), dTx.p, m, P.nnz, dW.p, dd.p, dH.p,
+                                                    n, k, P.holdout_fraction, P.cv_seed, P.gp_theta_max, dtheta.p));
+            // ---- per-element losses (:1377-1443, :1546-1549)
+            OPCHK(rcppml_hip_cv_irls_loss(c, dt, P.loss_type, dAp.as<int>(), dAi.as<int>(), dAx.p, n, m, dW.p, dd.p, dH.p,
+                                          is_gp ? dtheta.p : nullptr, k, P.holdout_fraction, P.cv_seed, P.mask_zeros, P.tweedie_power,
+                                          dloss.as<double>()));
+            HIPCHK(hipMemcpyAsync(hbuf, dloss.p, 4 * sizeof(double), hipMemcpyDeviceToHost, s));
+            HIPCHK(hipStreamSynchronize(s));
+            train_loss = hbuf[1] > 0 ? as_scalar(as_scalar(hbuf[0]) / hbuf[1]) : 0.0;
+            test_loss = hbuf[3] > 0 ? as_scalar(as_scalar(hbuf[2]) / hbuf[3]) : 0.0;
+            if (P.train_history) P.train_history[iter] = train_loss;
+            if (P.test_history) P.test_history[iter] = test_loss;
+            double rel = 0;
+            if (iter > 0) rel = std::fabs(prev_conv - test_loss) / (std::fabs(prev_conv) + 1e-15);
+            if (test_loss < best_test) { best_test = test_loss; best_iter = iter; patience_count = 0; }
+            else ++patience_count;
+            if (P.verbose) fprintf(stderr, "[rcppml_gpu cv] iter %d train %.9g test %.9g best %.9g\n", iter + 1, train_loss, test_loss, best_test);
+            iterations = iter + 1;
+            if (P.cv_patience > 0 && patience_count >= P.cv_patience) { converged = false; break; }
+            if (iter > 0) {
+                final_tol = rel;
+                if (rel < P.tol) { converged = true; break; }
+            }
+            prev_conv = test_loss;
+            continue;
+        }
         // ---- H half-update (:408-550): G = gram(W) (eps) + 1e-15 (:410) + L2
         OPCHK(rcppml_hip_gram(c, dt, dW.p, k, m, 2 * eps, P.L2_H, dG.p));
         if (graph_H) OPCHK(rcppml_hip_apply_graph_reg(c, dt, dG.p, dGHp.as<int>(), dGHi.as<int>(), dGHx.p, dH.p, k, n, P.gH_lambda));   // :416-417
@@ -779,6 +847,7 @@ void fit_cv(CvParams& P) {
         prev_conv = test_loss;
     }
     (void)final_tol;
+    if (is_gp && P.out_theta) download_cast<T>(c, dtheta, (size_t)m, P.out_theta, s);      // result.theta (:1647)
     download_cast<T>(c, dW, (size_t)k * m, P.W, s);
     download_cast<T>(c, dH, (size_t)k * n, P.H, s);
     download_cast<T>(c, dd, (size_t)k, P.d, s);
@@ -800,12 +869,17 @@ void fit_cv(CvParams& P) {
     P.out_best_test = best_test; P.out_best_iter = best_iter;
 }
 
-void nmf_cv_entry(RCPPML_NMF_CV_ARGS, int sort_model, int precision, int cv_patience, double* train_history, double* test_history) {
+// what the reference's CV boundary does not carry (build-defined entry rcppml_gpu_nmf_cv_irls_ex)
+struct CvExtra { int dispersion_mode; double gp_theta_init, gp_theta_max, tweedie_power, robust_delta; double* out_theta; };
+void nmf_cv_entry(RCPPML_NMF_CV_ARGS, int sort_model, int precision, int cv_patience, double* train_history, double* test_history,
+                  const CvExtra* cv_extra = nullptr) {
     try {
         rcppml_err().clear();
         *out_status = -1;
-        (void)seed_only_used_for_cv_seed_fallback; (void)huber_delta; (void)irls_max_iter; (void)irls_tol;
-        if (*loss_type != 0) throw std::runtime_error("CV: only the MSE loss is implemented");
+        (void)seed_only_used_for_cv_seed_fallback; (void)huber_delta;
+        // LossType (math/loss.hpp:36-47): 0 MSE; 4 GP, 5 NB, 6 Gamma, 7 inverse Gaussian, 8 Tweedie run the IRLS CV path; the legacy
+        // MAE / Huber / KL losses (1-3) are handed back, as in the non-CV entries
+        if (!(*loss_type == 0 || (*loss_type >= 4 && *loss_type <= 8))) throw std::runtime_error("CV: loss_type must be 0 (MSE) or 4..8 (GP, NB, Gamma, inverse Gaussian, Tweedie)");
         if ((*graph_H_nnz > 0 && *graph_H_dim != *n) || (*graph_W_nnz > 0 && *graph_W_dim != *m)) throw std::runtime_error("CV: graph Laplacian dimension mismatch");
         if (*projective != 0 || *symmetric != 0) throw std::runtime_error("CV: projective/symmetric NMF not supported");
         if (*solver_mode != 0 && *solver_mode != 1) throw std::runtime_error("CV: solver_mode must be 0 (CD) or 1 (Cholesky+clip)");
@@ -829,6 +903,12 @@ void nmf_cv_entry(RCPPML_NMF_CV_ARGS, int sort_model, int precision, int cv_pati
         P.mask_zeros = *mask_zeros != 0 ? 1 : 0;
         P.cv_patience = cv_patience; P.sort_model = sort_model;
         P.train_history = train_history; P.test_history = test_history;
+        P.loss_type = *loss_type; P.irls_max_iter = *irls_max_iter > 0 ? *irls_max_iter : 5; P.irls_tol = *irls_tol;
+        if (cv_extra) {
+            P.dispersion_mode = cv_extra->dispersion_mode; P.gp_theta_init = cv_extra->gp_theta_init; P.gp_theta_max = cv_extra->gp_theta_max;
+            P.tweedie_power = cv_extra->tweedie_power; P.robust_delta = cv_extra->robust_delta; P.out_theta = cv_extra->out_theta;
+            if (P.dispersion_mode < 0 || P.dispersion_mode > 2) throw std::runtime_error("CV: dispersion_mode must be 0 (none), 1 (global) or 2 (per row)");
+        }
         P.gH_p = graph_H_p; P.gH_i = graph_H_i; P.gH_x = graph_H_x; P.gH_nnz = *graph_H_nnz; P.gH_lambda = *graph_H_lambda;
         P.gW_p = graph_W_p; P.gW_i = graph_W_i; P.gW_x = graph_W_x; P.gW_nnz = *graph_W_nnz; P.gW_lambda = *graph_W_lambda;
         if (precision == RCPPML_F64) fit_cv<double>(P); else fit_cv<float>(P);
@@ -859,6 +939,15 @@ extern "C" void rcppml_gpu_nmf_cv_unified_double(RCPPML_NMF_CV_ARGS) {
 extern "C" void rcppml_gpu_nmf_cv_ex(RCPPML_NMF_CV_ARGS, int* sort_model, int* precision, int* cv_patience, double* train_history,
                                      double* test_history) {
     nmf_cv_entry(RCPPML_NMF_CV_PASS, *sort_model, *precision, *cv_patience, train_history, test_history);
+}
+
+// build-defined: the same + what the reference's CV boundary has no slot for: dispersion mode (0 none / 1 global / 2 per row), GP theta
+// init / max, Tweedie variance power, robust_delta, and the GP theta vector at exit (out_theta: m doubles, may be NULL)
+extern "C" void rcppml_gpu_nmf_cv_irls_ex(RCPPML_NMF_CV_ARGS, int* sort_model, int* precision, int* cv_patience, double* train_history,
+                                          double* test_history, int* dispersion_mode, double* gp_theta_init, double* gp_theta_max,
+                                          double* tweedie_power, double* robust_delta, double* out_theta) {
+    CvExtra ex{*dispersion_mode, *gp_theta_init, *gp_theta_max, *tweedie_power, *robust_delta, out_theta};
+    nmf_cv_entry(RCPPML_NMF_CV_PASS, *sort_model, *precision, *cv_patience, train_history, test_history, &ex);
 }
 
 // Zero-copy entry (reference src/gpu_bridge_nmf.cu:879-967, R/sp_gpu.R): the CSC arrays are DEVICE pointers whose

@@ -71,7 +71,8 @@ def nmf(data, k, tol=1e-4, maxit=100, L1=(0.0, 0.0), L2=(0.0, 0.0), seed=None, m
         robust=False, *, solver="auto", upper_bound=(0.0, 0.0), cd_maxit=100, cd_tol=1e-8, norm="L1", sort_model=True,
         patience=5, h_init=None, precision="fp32", resource="gpu", dispersion="per_row", irls_max_iter=5, irls_tol=1e-4,
         nb_size_init=10.0, nb_size_max=1e6, nb_size_min=0.01, tweedie_power=1.5, L21=(0.0, 0.0), angular=(0.0, 0.0),
-        graph_W=None, graph_H=None, graph_lambda=(0.0, 0.0), target_H=None, target_lambda=0.0):
+        graph_W=None, graph_H=None, graph_lambda=(0.0, 0.0), target_H=None, target_lambda=0.0, theta_init=0.1, theta_max=5.0,
+        theta_min=0.0):
     """Non-negative matrix factorisation A ~ w diag(d) h by alternating NNLS on the MI355X.
 
     `L1`, `L2`, `upper_bound`, `nonneg` are c(w, h) pairs (src/RcppFunctions_nmf.cpp:59-62).
@@ -80,6 +81,9 @@ def nmf(data, k, tol=1e-4, maxit=100, L1=(0.0, 0.0), L2=(0.0, 0.0), seed=None, m
     `precision`: "fp32" is what the reference computes in (F1); "fp64" is the parity mode.
     `robust`: False | True (Huber delta 1.345) | "mae" (1e-4) | positive delta (R/nmf_thin.R:343-352).
     `graph_W` (m x m) / `graph_H` (n x n): sparse graph Laplacians, `graph_lambda` = c(w, h) (R/nmf_thin.R:67-68, 500-506).
+    `theta_init`, `theta_max`, `theta_min`: the GP dispersion bounds R takes through `...` (R/nmf_thin.R:246-248).
+    `test_fraction` > 0 with loss in {gp, nb, gamma, inverse_gaussian, tweedie} or `robust`: the CV fit with per-column weighted
+    Grams over the training entries (nmf/fit_cv.hpp:446-456, :670-689).
     `target_H` (k x n) with `target_lambda` (a scalar is the H side, as R/nmf_thin.R:646-648; > 0 enrichment, < 0 PROJ_ADV).
     """
     if loss not in _LOSSES:
@@ -109,8 +113,8 @@ def nmf(data, k, tol=1e-4, maxit=100, L1=(0.0, 0.0), L2=(0.0, 0.0), seed=None, m
     if cv:
         if not (0 < test_fraction < 1):
             raise ValueError("test_fraction must be in [0, 1)")
-        if loss != "mse" or robust_delta > 0 or (mask is not None and not isinstance(mask, str)):
-            raise NotImplementedError("cross-validation is implemented for loss='mse' without an explicit mask")
+        if mask is not None and not isinstance(mask, str):
+            raise NotImplementedError("cross-validation with an explicit mask matrix is not implemented by the MI355X backend")
     if resource != "gpu":
         raise ValueError("rcppml_amd has no CPU path; resource must be 'gpu'")
     dense_in = isinstance(data, np.ndarray) and data.ndim == 2        # a base R matrix: the reference's dense path
@@ -184,7 +188,16 @@ def nmf(data, k, tol=1e-4, maxit=100, L1=(0.0, 0.0), L2=(0.0, 0.0), seed=None, m
         # test loss with `patience`; mask = "zeros" <=> mask_zeros (only nonzeros can be held out)
         if max(L21w, L21h, angw, angh, ubw, ubh) > 0:
             raise NotImplementedError("cross-validation with L21 / angular / upper bounds is not implemented by the MI355X backend")
-        res = _abi.nmf_cv(A.p, A.i, A.x, m, n, k, W_T, H, entry="ex", max_iter=int(maxit), tol=float(tol), L1_H=L1h, L1_W=L1w,
+        irls_cv = loss != "mse" or robust_delta > 0
+        if irls_cv and graph_args:
+            raise NotImplementedError("graph regularisation is implemented for the MSE cross-validation path")
+        cv_kw = {}
+        if irls_cv:          # nmf/fit_cv.hpp:446-456, :670-689: per-column weighted Grams over the training entries
+            cv_kw = dict(loss_type={"mse": 0, "gp": 4, "nb": 5, "gamma": 6, "inverse_gaussian": 7, "tweedie": 8}[loss],
+                         irls_max_iter=int(irls_max_iter), irls_tol=float(irls_tol),
+                         dispersion_mode={"none": 0, "global": 1, "per_row": 2}[dispersion], gp_theta=(float(theta_init), float(theta_max)),
+                         tweedie_power=float(tweedie_power), robust_delta=float(robust_delta))
+        res = _abi.nmf_cv(A.p, A.i, A.x, m, n, k, W_T, H, entry="irls_ex" if irls_cv else "ex", **cv_kw, max_iter=int(maxit), tol=float(tol), L1_H=L1h, L1_W=L1w,
                           L2_H=L2h, L2_W=L2w, cd_maxit=int(cd_maxit), verbose=int(verbose), seed=seed_int & 0x7FFFFFFF,
                           holdout_fraction=float(test_fraction), cv_seed=seed_int & 0x7FFFFFFF,
                           mask_zeros=int(isinstance(mask, str) and mask == "zeros"), nonneg_W=int(nnw), nonneg_H=int(nnh),
@@ -197,6 +210,8 @@ def nmf(data, k, tol=1e-4, maxit=100, L1=(0.0, 0.0), L2=(0.0, 0.0), seed=None, m
                     test_loss_history=res.get("test_history"), solver=solver, solver_mode=0 if solver == "cd" else 1,
                     L1=(L1w, L1h), L2=(L2w, L2h), seed=seed_int, precision=precision, resource="gpu", loss_type=loss,
                     test_fraction=float(test_fraction))
+        if irls_cv and loss == "gp":
+            misc["theta"] = res.get("theta")
         return NMFModel(w=W_T.copy(), d=res["d"], h=H.T.copy(), misc=misc)
     if dense_in and loss == "mse" and robust_delta == 0 and mask_arg is None and not graph_args and sort_model and target_H is None \
             and float(cd_tol) == 1e-8:
@@ -232,7 +247,7 @@ def nmf(data, k, tol=1e-4, maxit=100, L1=(0.0, 0.0), L2=(0.0, 0.0), seed=None, m
                            loss_type={"mse": 0, "gp": 4, "nb": 5, "gamma": 6, "inverse_gaussian": 7, "tweedie": 8}[loss], projective=int(bool(projective)), symmetric=int(bool(symmetric)),
                            tweedie_power=float(tweedie_power), robust_delta=robust_delta, irls_max_iter=int(irls_max_iter), irls_tol=float(irls_tol),
                            gp_dispersion_mode={"none": 0, "global": 1, "per_row": 2}[dispersion],
-                           nb_size=(nb_size_init, nb_size_max, nb_size_min),
+                           nb_size=(nb_size_init, nb_size_max, nb_size_min), gp_theta=(float(theta_init), float(theta_max), float(theta_min)),
                            sort_model=int(sort_model), precision=_abi.F32 if precision == "fp32" else _abi.F64,
                            want_history=True, **graph_args, **target_args)
     if res["status"] != 0:

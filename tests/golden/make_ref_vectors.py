@@ -76,6 +76,15 @@ Yg, Pg, Tg = np.meshgrid(obs, pred, theta, indexing="ij")
 out["gp_obs"], out["gp_pred"], out["gp_theta"] = Yg.ravel(), Pg.ravel(), Tg.ravel()
 out["gp_loss_f64"] = np.array([loss.ref_loss_gp_f64(C.c_double(y), C.c_double(a), C.c_double(b)) for y, a, b in zip(Yg.ravel(), Pg.ravel(), Tg.ravel())])
 out["gp_loss_f32"] = np.array([loss.ref_loss_gp_f32(C.c_float(y), C.c_float(a), C.c_float(b)) for y, a, b in zip(Yg.ravel(), Pg.ravel(), Tg.ravel())], dtype=np.float32)
+# GP weight as the CV half-updates call it (nmf/cv_detail.hpp:101-131 -> math/loss.hpp irls_weight_gp): grid over
+# (observed, predicted, theta, blend), including the CV call's observed = 0, theta = 0, blend = 1
+for nm, T in (("f64", C.c_double), ("f32", C.c_float)):
+    getattr(loss, "ref_irls_weight_gp_" + nm).restype = T
+    getattr(loss, "ref_irls_weight_gp_" + nm).argtypes = [T] * 4
+Yw, Pw_, Tw, Bw = np.meshgrid(obs, pred, theta, np.array([0.0, 0.5, 1.0]), indexing="ij")
+out["gpw_obs"], out["gpw_pred"], out["gpw_theta"], out["gpw_blend"] = Yw.ravel(), Pw_.ravel(), Tw.ravel(), Bw.ravel()
+out["gpw_f64"] = np.array([loss.ref_irls_weight_gp_f64(y, a, t, b) for y, a, t, b in zip(Yw.ravel(), Pw_.ravel(), Tw.ravel(), Bw.ravel())])
+out["gpw_f32"] = np.array([loss.ref_irls_weight_gp_f32(y, a, t, b) for y, a, t, b in zip(Yw.ravel(), Pw_.ravel(), Tw.ravel(), Bw.ravel())], dtype=np.float32)
 # power-variance family: weight 1/mu^p and the Gamma / inverse-Gaussian / Tweedie deviance terms
 powers = np.array([1.0, 1.5, 2.0, 2.5, 3.0])
 Pp, Pw = np.meshgrid(pred, powers, indexing="ij")

@@ -117,7 +117,7 @@ def test_cv_reference_entry_points_and_rejections():
     res32 = _abi.nmf_cv(A.p, A.i, A.x, A.rows, A.cols, k, W, H, entry="float", max_iter=8, tol=1e-6, solver_mode=1,
                         holdout_fraction=0.2, cv_seed=17)
     assert res32["status"] == 0 and abs(res32["test_loss"] - ref.test_loss) <= 5e-3 * abs(ref.test_loss)
-    for kw in (dict(loss_type=5), dict(projective=1), dict(symmetric=1), dict(graph_W_nnz=3), dict(solver_mode=2),
+    for kw in (dict(loss_type=1), dict(loss_type=3), dict(projective=1), dict(symmetric=1), dict(graph_W_nnz=3), dict(solver_mode=2),
                dict(holdout_fraction=0.0), dict(holdout_fraction=1.5)):
         W, H = W0.copy(), H0.copy()
         r = _abi.nmf_cv(A.p, A.i, A.x, A.rows, A.cols, k, W, H, entry="double", max_iter=2, **kw)
@@ -138,7 +138,31 @@ def test_cv_python_surface():
     mz = N.nmf(Ap, 4, test_fraction=0.1, seed=3, maxit=5, mask="zeros")
     assert np.isfinite(mz.misc["test_loss"])
     with pytest.raises(NotImplementedError):
-        N.nmf(Ap, 4, test_fraction=0.1, seed=3, loss="nb")
+        N.nmf(Ap, 4, test_fraction=0.1, seed=3, mask=np.ones((80, 110)))
+
+
+@pytest.mark.parametrize("loss", ["gp", "gamma", "tweedie"])
+def test_cv_python_surface_with_irls_losses(loss):
+    """nmf(test_fraction = ..., loss = "gp" / ...): the surface forwards the loss, IRLS and dispersion settings to the CV entry and
+    reproduces the oracle's fit from the same R-stream initialisation (fp64)."""
+    from rcppml_amd import nmf as N
+    from rcppml_amd.data import CSC
+    from rcppml_amd.data import r_runif, splitmix64_uniform
+    A = _counts_csc(40, 55, 0.35, seed=9)
+    Ap = CSC((A.rows, A.cols), A.p, A.i, A.x)
+    k, seed = 3, 11
+    mod = N.nmf(Ap, k, test_fraction=0.2, seed=seed, maxit=4, tol=1e-9, loss=loss, precision="fp64", irls_max_iter=3, sort_model=False,
+                theta_init=0.2)
+    lt = {"gp": 4, "gamma": 6, "tweedie": 8}[loss]
+    W0 = r_runif(seed, A.rows * k).reshape(k, A.rows).T.copy()
+    H0 = splitmix64_uniform(seed, 0, k * A.cols, np.float64).reshape(A.cols, k)
+    ref = O.nmf_fit_cv(A, W0, H0, np.float64, max_iter=4, tol=1e-9, holdout_fraction=0.2, cv_seed=seed, loss_type=lt, irls_max_iter=3,
+                       gp_theta=(0.2, 5.0), solver_mode=mod.misc["solver_mode"])
+    assert mod.misc["iter"] == ref.iter and mod.misc["loss_type"] == loss
+    assert np.allclose(mod.misc["test_loss_history"], ref.test_history, rtol=1e-7)
+    assert np.allclose(mod.misc["loss_history"], ref.train_history, rtol=1e-7)
+    if loss == "gp":
+        assert np.allclose(mod.misc["theta"], ref.theta, rtol=1e-6, atol=1e-12)
 
 
 @pytest.mark.parametrize("precision,tol_loss,tol_fac", [("f64", 1e-8, 1e-6), ("f32", 2e-3, 5e-3)])
@@ -170,3 +194,154 @@ def test_cv_fit_with_graph_regularisation(precision, tol_loss, tol_fac):
     assert res["iter"] == ref.iter and res["best_iter"] == ref.best_iter
     assert np.allclose(res["test_history"], ref.test_history, rtol=tol_loss, atol=0)
     assert np.abs(W - ref.W_T).max() < tol_fac and np.abs(H - ref.H).max() < tol_fac * max(1.0, np.abs(ref.H).max())
+
+
+def _counts_csc(rows, cols, dens, seed):
+    """Count-valued sparse matrix (what the IRLS losses are for)."""
+    A = lowrank_csc(rows, cols, 4, dens, seed=seed)
+    x = np.ceil(A.x / A.x.mean() * 2.0)
+    return O.Csc((A.rows, A.cols), A.p, A.i, x)
+
+
+@pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-7), (np.float32, 5e-3)])
+@pytest.mark.parametrize("loss_type", [4, 5, 6, 7, 8])
+@pytest.mark.parametrize("mask_zeros", [0, 1])
+@pytest.mark.parametrize("solver", [0, 1])
+def test_cv_irls_half_updates(env, dtype, tol, loss_type, mask_zeros, solver):
+    """The per-column weighted-Gram half-update of the IRLS CV path (reference nmf/cv_detail.hpp:101-292) on both sides, both
+    solvers, zeros held out or not, with an additive feature term, against the oracle's restatement."""
+    torch, _abi, ctx = env
+    k = 6 if loss_type in (4, 5) else 33
+    A = _counts_csc(70, 90, 0.25, seed=loss_type + 10 * mask_zeros)
+    At = A.transpose()
+    dt = _abi.F32 if dtype == np.float32 else _abi.F64
+    rng = np.random.default_rng(loss_type + solver)
+    frac, cv_seed = 0.15, 31
+    for (M, transposed) in ((A, 0), (At, 1)):
+        F = rng.uniform(0.05, 1.0, size=(M.rows, k)).astype(dtype)
+        X0 = rng.uniform(0.05, 0.4, size=(M.cols, k)).astype(dtype)
+        G_add = (np.eye(k) * 0.05 + 0.01 * np.ones((k, k))).astype(dtype)
+        kw = dict(mask_zeros=bool(mask_zeros), transposed=bool(transposed), L1=0.01, cd_maxit=15, solver_mode=solver, irls_max_iter=4,
+                  irls_tol=1e-4, power=1.6)
+        ref = O.cv_irls_half_update(M, F, X0, k, frac, cv_seed, loss_type, G_add=G_add, dtype=dtype, **kw)
+        dX = _dev(torch, X0.copy())
+        ctx.solve_cv_irls(dt, loss_type, _dev(torch, M.p), _dev(torch, M.i), _dev(torch, M.values(dtype)), M.cols, M.rows, _dev(torch, F),
+                          _dev(torch, G_add), dX, k, frac, cv_seed, mask_zeros=mask_zeros, transposed=transposed, l1=0.01, cd_maxit=15,
+                          solver_mode=solver, irls_max_iter=4, irls_tol=1e-4, loss_param=1.6)
+        X = dX.cpu().numpy()
+        assert np.all(np.isfinite(X)) and X.min() >= 0
+        assert not np.array_equal(X, X0)
+        # a column whose IRLS passes stop at a different pass (relative change right at irls_tol) may differ in fp32
+        err = np.abs(X - ref).max(axis=1) / max(np.abs(ref).max(), 1e-30)
+        assert np.median(err) < tol and (err < tol).mean() > (0.999 if dtype == np.float64 else 0.97), (loss_type, mask_zeros, solver, transposed, err.max())
+
+
+@pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-11), (np.float32, 2e-4)])
+@pytest.mark.parametrize("loss_type", [0, 4, 5, 6, 7, 8])
+@pytest.mark.parametrize("mask_zeros", [0, 1])
+def test_cv_irls_losses(env, dtype, tol, loss_type, mask_zeros):
+    """Per-element train / test losses (reference nmf/fit_cv.hpp:1377-1443): sums and counts vs the oracle."""
+    torch, _abi, ctx = env
+    k = 9
+    A = _counts_csc(80, 120, 0.2, seed=2)
+    dt = _abi.F32 if dtype == np.float32 else _abi.F64
+    rng = np.random.default_rng(loss_type)
+    W = rng.uniform(0.1, 1.0, size=(A.rows, k)).astype(dtype)
+    H = rng.uniform(0.1, 1.0, size=(A.cols, k)).astype(dtype)
+    d = rng.uniform(0.5, 2.0, size=k).astype(dtype)
+    theta = rng.uniform(0.0, 0.8, size=A.rows).astype(dtype)
+    ref = O.cv_explicit_loss(A, W, d, H, 0.2, 9, loss_type, theta=theta, mask_zeros=bool(mask_zeros), power=1.4, dtype=dtype)
+    out = torch.zeros((4,), dtype=torch.float64, device="cuda")
+    ctx.cv_irls_loss(dt, loss_type, _dev(torch, A.p), _dev(torch, A.i), _dev(torch, A.values(dtype)), A.cols, A.rows, _dev(torch, W),
+                     _dev(torch, d), _dev(torch, H), _dev(torch, theta), k, 0.2, 9, mask_zeros, 1.4, out)
+    tr, ntr, te, nte = out.cpu().numpy()
+    assert (int(ntr), int(nte)) == (ref[1], ref[3]) and ref[3] > 0
+    assert ntr + nte == (A.nnz if mask_zeros else A.rows * A.cols)
+    assert abs(tr - ref[0]) <= tol * abs(ref[0]) and abs(te - ref[2]) <= tol * abs(ref[2])
+
+
+@pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-9), (np.float32, 5e-4)])
+@pytest.mark.parametrize("mode", [2, 1])
+@pytest.mark.parametrize("frac", [0.2, 0.0])
+def test_cv_gp_theta_over_training_entries(env, dtype, tol, mode, frac):
+    """GP theta (MM update) over the training entries only (reference nmf/fit_cv.hpp:866-961); frac = 0 = the non-CV update."""
+    torch, _abi, ctx = env
+    k = 5
+    A = _counts_csc(60, 150, 0.3, seed=8)
+    At = A.transpose()
+    dt = _abi.F32 if dtype == np.float32 else _abi.F64
+    rng = np.random.default_rng(mode)
+    W = rng.uniform(0.1, 1.0, size=(A.rows, k)).astype(dtype)
+    H = rng.uniform(0.1, 1.0, size=(A.cols, k)).astype(dtype)
+    d = rng.uniform(0.5, 2.0, size=k).astype(dtype)
+    th0 = np.full(A.rows, 0.1, dtype)
+    ref = O.cv_gp_theta_update(A, W, d, H, th0, frac, 13, mode=mode, theta_max=5.0, dtype=dtype)
+    dth = _dev(torch, th0.copy())
+    ctx.cv_gp_theta_update(dt, mode, _dev(torch, At.p), _dev(torch, At.i), _dev(torch, At.values(dtype)), A.rows, A.nnz, _dev(torch, W),
+                           _dev(torch, d), _dev(torch, H), A.cols, k, frac, 13, 5.0, dth)
+    th = dth.cpu().numpy()
+    assert not np.allclose(th, th0)
+    assert np.abs(th - ref).max() <= tol * max(np.abs(ref).max(), 1e-30)
+
+
+
+@pytest.mark.parametrize("precision,tol_loss,tol_fac", [("f64", 1e-6, 1e-5), ("f32", 5e-3, 2e-2)])
+@pytest.mark.parametrize("loss_type", [4, 5, 6, 8])
+@pytest.mark.parametrize("mask_zeros", [0, 1])
+def test_cv_irls_fit_through_plugin(precision, tol_loss, tol_fac, loss_type, mask_zeros):
+    """CV fits with the IRLS losses through the plugin's CV boundary (the build-defined entry: histories, precision, sort off) vs
+    the oracle's nmf_fit_cv: iteration count, early-stopping decision, train / test losses per iteration, GP theta, factors."""
+    from rcppml_amd import _abi
+    A = _counts_csc(50, 70, 0.3, seed=20 + loss_type)
+    k = 3
+    dtype = np.float64 if precision == "f64" else np.float32
+    rng = np.random.default_rng(loss_type)
+    W0 = rng.uniform(0.2, 1.0, size=(A.rows, k)); H0 = rng.uniform(0.2, 1.0, size=(A.cols, k))
+    solver = 1 if loss_type in (5, 8) else 0
+    kw = dict(max_iter=6, tol=1e-9, solver_mode=solver, holdout_fraction=0.15, cv_seed=5, cv_patience=4)
+    ref = O.nmf_fit_cv(A, W0, H0, dtype, L1=(0.0, 0.01), L2=(0.02, 0.0), mask_zeros=bool(mask_zeros), loss_type=loss_type, irls_max_iter=3,
+                       irls_tol=1e-4, **kw)
+    W, H = W0.copy(), H0.copy()
+    res = _abi.nmf_cv(A.p, A.i, A.x, A.rows, A.cols, k, W, H, entry="irls_ex", L1_H=0.01, L2_W=0.02, mask_zeros=mask_zeros, sort_model=0,
+                      precision=_abi.F64 if precision == "f64" else _abi.F32, loss_type=loss_type, irls_max_iter=3, irls_tol=1e-4, **kw)
+    assert res["status"] == 0, res.get("error")
+    assert res["iter"] == ref.iter and res["converged"] == ref.converged
+    assert np.all(np.isfinite(res["test_history"]))
+    if not (precision == "f32" or loss_type == 5):
+        assert res["best_iter"] == ref.best_iter
+    if precision == "f32" or loss_type == 5:
+        # NB: the reference evaluates the CV weights at theta = 0 (r floored at 1e-10), so every per-column Gram is ~1e-10 f f^T plus the
+        # 1e-15 ridge -- conditioned so badly that rounding differences grow by orders of magnitude per iteration in EITHER precision
+        # (the fp32 oracle itself runs into NaN on some shapes; the GPU's Cholesky guards its pivots).  First iterations tightly, the
+        # rest loosely; the other losses in fp64 carry the trajectory parity.
+        ok = np.isfinite(ref.test_history)
+        n_tight = 2 if loss_type == 5 else 3
+        assert np.allclose(res["test_history"][:n_tight], ref.test_history[:n_tight], rtol=tol_loss, atol=0), (res["test_history"], ref.test_history)
+        assert np.allclose(res["test_history"][ok], ref.test_history[ok], rtol=0.05, atol=0)
+        assert np.allclose(res["train_history"][ok], ref.train_history[ok], rtol=0.05, atol=0)
+        return
+    assert np.allclose(res["test_history"], ref.test_history, rtol=tol_loss, atol=0), (res["test_history"], ref.test_history)
+    assert np.allclose(res["train_history"], ref.train_history, rtol=tol_loss, atol=0)
+    assert np.abs(res["d"] - ref.d).max() <= tol_fac * np.abs(ref.d).max()
+    assert np.abs(W - ref.W_T).max() < tol_fac and np.abs(H - ref.H).max() < tol_fac * max(1.0, np.abs(ref.H).max())
+    if loss_type == 4:
+        assert np.abs(res["theta"] - ref.theta).max() <= tol_fac * max(np.abs(ref.theta).max(), 1e-30)
+        assert res["theta"].max() > 0
+
+
+def test_cv_irls_reference_entry_takes_config_defaults():
+    """rcppml_gpu_nmf_cv_unified_double with loss_type = GP: the boundary carries no dispersion arguments, so the fit runs with the
+    reference's config defaults (per-row theta, init 0.1, max 5) -- equal to the oracle with those defaults."""
+    from rcppml_amd import _abi
+    A = _counts_csc(40, 60, 0.3, seed=3)
+    k = 3
+    rng = np.random.default_rng(1)
+    W0 = rng.uniform(0.2, 1.0, size=(A.rows, k)); H0 = rng.uniform(0.2, 1.0, size=(A.cols, k))
+    ref = O.nmf_fit_cv(A, W0, H0, np.float64, max_iter=4, tol=1e-9, holdout_fraction=0.2, cv_seed=11, cv_patience=5, loss_type=4, sort_model=False) \
+        if False else O.nmf_fit_cv(A, W0, H0, np.float64, max_iter=4, tol=1e-9, holdout_fraction=0.2, cv_seed=11, cv_patience=5, loss_type=4)
+    W, H = W0.copy(), H0.copy()
+    res = _abi.nmf_cv(A.p, A.i, A.x, A.rows, A.cols, k, W, H, entry="double", max_iter=4, tol=1e-9, holdout_fraction=0.2, cv_seed=11,
+                      loss_type=4)
+    assert res["status"] == 0 and res["iter"] == ref.iter
+    assert abs(res["test_loss"] - ref.test_loss) <= 1e-6 * abs(ref.test_loss)
+    assert abs(res["train_loss"] - ref.train_loss) <= 1e-6 * abs(ref.train_loss)
