@@ -37,7 +37,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--config", choices=["c2", "c4"], default="c2",
+    ap.add_argument("--config", choices=["c2", "c3", "c4", "c5"], default="c2",
                     help="BASELINE.json configs[1] (20000 x 100000 per GPU, 1 %%, k = 64: the headline) or configs[3] "
                          "(pbmc3k-shaped 30000 x 162500 per GPU = 1.3 M columns over 8 GPUs, 3 %%, k = 128)")
     ap.add_argument("--rows", type=int, default=None)
@@ -64,7 +64,10 @@ def parse():
     ap.add_argument("--init-f32", action="store_true", help="fp64 run starting from the fp32-rounded factors (so that one CPU "
                                                             "reference fit serves both precisions)")
     args = ap.parse_args()
-    preset = {"c2": (20000, 100000, 0.01, 64), "c4": (30000, 162500, 0.03, 128)}[args.config]
+    # c3: the movielens fixture (tests/golden/movielens.npz, extracted from the reference's data/movielens.rda), k = 32,
+    # L1 = c(0, 0.1), mask = "zeros" (a fit-time no-op in the reference); c5: NB counts, IRLS half-updates
+    preset = {"c2": (20000, 100000, 0.01, 64), "c4": (30000, 162500, 0.03, 128), "c3": (3867, 610, 0.0319, 32),
+              "c5": (10000, 200000, 0.02, 32)}[args.config]
     args.rows = args.rows or preset[0]
     args.cols = args.cols or preset[1]
     args.density = args.density or preset[2]
@@ -100,7 +103,7 @@ def algorithmic_bytes_rhs(nnz, ncols, rrows, k, sv):
     return nnz * (4 + sv) + (ncols + 1) * 4 + k * rrows * sv + k * ncols * sv
 
 
-def cpu_baseline(A_loc, At_loc, W_T, H, G_h, G_w, cfg_k, dtype, seconds, cd_maxit):
+def cpu_baseline(A_loc, At_loc, W_T, H, G_h, G_w, cfg_k, dtype, seconds, cd_maxit, L1_H=0.0):
     """Time the oracle's fused RHS+CD half-updates (reference fused_nnls.hpp:70-134 restated, OpenMP, fp32)
     on a column SAMPLE of the same workload, with the live factors (so CD sweep counts are representative)."""
     from oracle import oracle as O
@@ -122,7 +125,7 @@ def cpu_baseline(A_loc, At_loc, W_T, H, G_h, G_w, cfg_k, dtype, seconds, cd_maxi
         S = sample(A, ncols)
         t0 = time.perf_counter()
         O.fused_cd(S, F.astype(nd), G.astype(nd), X[:S.cols].astype(nd), maxit=cd_maxit, tol=1e-8, threads=0, warm=True,
-                   native=native)
+                   native=native, L1=L1_H if A is A_loc else 0.0)
         return S.cols, time.perf_counter() - t0
 
     # pilot to size the sample, then the timed sample (H side and W side share the time budget)
@@ -161,6 +164,10 @@ def main():
         raise SystemExit(self_launch(args))
     if world != args.gpus:
         raise SystemExit("bench.py --gpus %d launched with WORLD_SIZE=%d" % (args.gpus, world))
+    if args.config == "c5":
+        if world != 1:
+            raise SystemExit("--config c5 is benchmarked on one GPU (BASELINE configs[4])")
+        return bench_c5(args)
     # functional smoke of the N > 1 loop on a one-GPU box: RCPPML_BENCH_BACKEND=gloo RCPPML_BENCH_SHARE_GPU=1 maps every
     # rank onto cuda:0 (RCCL refuses two ranks per device); never used for reported numbers
     backend = os.environ.get("RCPPML_BENCH_BACKEND", "nccl")
@@ -176,8 +183,15 @@ def main():
 
     m, n_loc, k = args.rows, args.cols, args.k
     n_total = n_loc * world
-    dens = calibrated_density(m, k, args.density, seed=123)
-    if world == 1 and args.data_shards > 1:
+    if args.config == "c3":
+        if world != 1:
+            raise SystemExit("--config c3 (610 columns) is a one-GPU workload")
+        fx = np.load(os.path.join(ROOT, "tests", "golden", "movielens.npz"))
+        A_loc = data.CSC(tuple(int(v) for v in fx["shape"]), fx["p"], fx["i"], fx["x"])
+        m, n_loc = A_loc.shape
+        n_total = n_loc
+    elif world == 1 and args.data_shards > 1:
+        dens = calibrated_density(m, k, args.density, seed=123)
         if n_loc % args.data_shards:
             raise SystemExit("--cols must be a multiple of --data-shards")
         nsh = n_loc // args.data_shards
@@ -187,6 +201,7 @@ def main():
         A_loc = data.CSC((m, n_loc), np.concatenate([parts[0].p[:1]] + [a.p[1:].astype(np.int64) + off[r] for r, a in enumerate(parts)]),
                          np.concatenate([a.i for a in parts]), np.concatenate([a.x for a in parts]))
     else:
+        dens = calibrated_density(m, k, args.density, seed=123)
         A_loc, _, _ = data.simulate_nmf_sparse(m, n_loc, k, dens, seed=123, device=torch.device("cuda", local_rank),
                                                col_offset=rank * n_loc, ncol_total=n_total)
     At_loc = A_loc.transpose()
@@ -194,6 +209,7 @@ def main():
     W0, H0 = data.init_factors(args.seed, k, m, n_loc, np.float32 if args.init_f32 else nd, col_offset=rank * n_loc, n_total=n_total)
     W0, H0 = W0.astype(nd), H0.astype(nd)
     cfg = als.AlsConfig(k=k, max_iter=args.warmup + args.steps, tol=0.0, cd_maxit=args.cd_maxit,
+                        L1_H=0.1 if args.config == "c3" else 0.0,
                         solver_mode=0 if args.solver == "cd" else 1,
                         cd_variant={"auto": 0, "lane": 1, "wave": 2}[args.variant], order_columns=not args.no_order)
     # One GPU: the K timed iterations are replays of ONE captured hipGraph of the iteration -- how the plugin's loop
@@ -406,9 +422,11 @@ def main():
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": "%s: simulateNMF %dx%d (x%d GPUs, column shards) %.3g%%-dense CSC, k=%d, MSE, %s NNLS "
+            "config": {"workload": "%s %dx%d (x%d GPUs, column shards) %.3g%%-dense CSC, k=%d, MSE, %s NNLS "
                                    "(cd_maxit=%d, cd_tol=1e-8), L1 row normalisation, loss every iteration"
-                                   % ("configs[1]" if args.config == "c2" else "configs[3] (one GPU's share)", m, n_loc, world,
+                                   % ({"c2": "configs[1]: simulateNMF", "c4": "configs[3] (one GPU's share): simulateNMF",
+                                       "c3": "configs[2]: movielens (fixture of data/movielens.rda), L1 = c(0, 0.1), mask = 'zeros' (fit-time "
+                                             "no-op in the reference)"}[args.config], m, n_loc, world,
                                       100.0 * nnz / (m * float(n_loc)), k,
                                       "coordinate-descent" if args.solver == "cd" else "Cholesky+clip", args.cd_maxit),
                        "rows": m, "cols_per_gpu": n_loc, "nnz_per_gpu": nnz, "k": k, "solver": args.solver,
@@ -438,7 +456,7 @@ def main():
                 G_h = st.ops.gram(st.W_T, 1e-15, 0.0).cpu().numpy()
                 G_w = st.ops.gram(st.H, 1e-15, 0.0).cpu().numpy()
                 out["cpu_baseline"] = cpu_baseline(_to_oracle(A_loc), _to_oracle(At_loc), W_T, H, G_h, G_w, k, args.dtype,
-                                                   args.cpu_seconds, args.cd_maxit)
+                                                   args.cpu_seconds, args.cd_maxit, L1_H=cfg.L1_H)
                 out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
             except Exception as e:  # the baseline must never take the GPU number down with it
                 out["cpu_baseline"] = {"value": None, "unit": "cols/s", "cores": os.cpu_count(), "kind": "port",
@@ -455,7 +473,7 @@ def main():
             try:
                 from oracle import oracle as O
                 t0 = time.perf_counter()
-                ref = O.nmf_fit(_to_oracle(A_loc), W0.astype(np.float64), H0.astype(np.float64), np.float64,
+                ref = O.nmf_fit(_to_oracle(A_loc), W0.astype(np.float64), H0.astype(np.float64), np.float64, L1=(cfg.L1_W, cfg.L1_H),
                                 max_iter=args.warmup + args.steps, tol=0.0, cd_maxit=args.cd_maxit, cd_tol=1e-8,
                                 solver_mode=0 if args.solver == "cd" else 1, threads=0, native=True)
                 ref_loss = ref.loss
@@ -475,6 +493,134 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def bench_c5(args):
+    """BASELINE configs[4]: loss = "nb" on 10 000 x 200 000 Poisson-Gamma counts (2 % dense), k = 32, fp32, one GPU.  A step is
+    one outer NB iteration issued op by op in the order of the plugin's loop (rcppml_amd/csrc/plugin.hip, IRLS branch =
+    nmf/fit_cpu.hpp:565-606, :811-852, :1094-1265, :1684-1753): Gram of W, IRLS half-update of H (per-entry NB weights rebuilt
+    every pass: per-column weighted Gram + CD solve), scaling, the same for W, method-of-moments size update, NB likelihood."""
+    import torch
+    from rcppml_amd import als, data
+    m, n, k = args.rows, args.cols, args.k
+    A, _, _ = data.simulate_nb_counts(m, n, k, density=args.density, size=5.0, seed=123)
+    At = A.transpose()
+    nd = np.float32 if args.dtype == "f32" else np.float64
+    W0, H0 = data.init_factors(args.seed, k, m, n, nd)
+    ops = als.HipOps(0, args.dtype, record_events=False)
+    W, H = ops.to_device(W0), ops.to_device(H0)
+    Ad, Atd = ops.upload_csc(A), ops.upload_csc(At)
+    theta = torch.full((m,), 10.0, dtype=ops.tdtype, device="cuda")              # nb_size_init (core/config.hpp)
+    d = torch.ones((k,), dtype=ops.tdtype, device="cuda")
+    sums, G = ops.empty((k,)), ops.empty((k, k))
+    out4 = torch.zeros((4,), dtype=torch.float64, device="cuda")
+    irls_max_iter, irls_tol = 5, 1e-4                                            # R defaults of nmf(): irls_max_iter, irls_tol
+
+    def half(side):
+        F, X, csc = (W, H, Ad) if side == "H" else (H, W, Atd)
+        ops.gram(F, 1e-15, 0.0, out=G)
+        with ops._timed("solve_" + side):
+            ops.ctx.solve_irls(ops.dt, 5, csc["p"], csc["i"], csc["x"], csc["cols"], F, G, X, k, 0.0, 0.0, 1, args.cd_maxit,
+                               irls_max_iter, irls_tol, theta if side == "H" else None, None if side == "H" else theta)
+        with ops._timed("scale"):
+            ops.row_norms(X, 0, out=sums)
+            ops.apply_scaling(X, sums, 0, d)
+
+    def step():
+        half("H")
+        half("W")
+        with ops._timed("nb_size"):
+            ops.ctx.nb_size_update(ops.dt, Atd["p"], Atd["i"], Atd["x"], m, W, d, H, n, k, 0.01, 1e6, theta)
+        with ops._timed("loss"):
+            ops.ctx.irls_loss(ops.dt, 5, Ad["p"], Ad["i"], Ad["x"], n, W, d, H, theta, k, out4)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    ops.record = True
+    ops.reset_events()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ops.record = False
+    final_loss = float(out4[0].item())
+    ev = ops.event_ms()
+    phases = {name: round(ms / args.steps, 4) for name, (c, ms) in sorted(ev.items())}
+    # ---- work of one more iteration, counted by the kernels themselves (outside the timed region; two atomics per column)
+    ops.ctx.set_option(ops._abi.OPT_CD_COUNT_NOOP, 1)
+    counts = {}
+    for side in ("H", "W"):
+        ops.ctx.irls_stats(reset=True)
+        half(side)
+        counts[side] = ops.ctx.irls_stats(reset=True)
+    ops.ctx.set_option(ops._abi.OPT_CD_COUNT_NOOP, 0)
+    kp = 32 if k <= 32 else 64
+    sv = 4 if args.dtype == "f32" else 8
+    roof = {}
+    for side, ncols in (("H", n), ("W", m)):
+        cnt, ms = ev["solve_" + side]
+        sec = ms / cnt * 1e-3
+        nzp = counts[side]["irls_nonzero_passes"]
+        flops = 2.0 * kp * kp * nzp                       # one rank-1 update f f^T of the kp x kp accumulator tile per nonzero and pass
+        roof[side] = {"avg_launch_ms": sec * 1e3, "mean_passes_per_column": counts[side]["irls_column_passes"] / float(ncols),
+                      "nonzero_passes": nzp, "algorithmic_flops_per_launch": flops, "achieved": flops / sec / 1e12,
+                      "frac": flops / sec / 1e12 / (157.3 if args.dtype == "f32" else 78.6),
+                      # every pass re-reads the column's (row, value) pairs and gathers one k-row of F per nonzero
+                      "gathered_row_TBps": nzp * k * sv / sec / 1e12, "csc_stream_GBps": nzp * (4 + sv) / sec / 1e9}
+    big = "H" if roof["H"]["avg_launch_ms"] >= roof["W"]["avg_launch_ms"] else "W"
+    line = {
+        "metric": "ALS updates/sec (cols solved/s), k=%d sparse NMF, loss = nb" % k,
+        "value": args.steps * (m + n) / dt, "unit": "cols/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": "configs[4]: NB counts %dx%d (Poisson-Gamma, size 5, %.3g%%-dense CSC), k=%d, loss = 'nb' IRLS "
+                               "(irls_max_iter=%d, irls_tol=%g, cd_maxit=%d), per-row size by method of moments, NB likelihood every "
+                               "iteration" % (m, n, 100.0 * A.nnz / (m * float(n)), k, irls_max_iter, irls_tol, args.cd_maxit),
+                   "rows": m, "cols_per_gpu": n, "nnz_per_gpu": A.nnz, "k": k, "solver": "irls+cd", "parallelism": "one GPU"},
+        "roofline": dict({"bound": "mfma", "unit": "TFLOP/s", "peak": 157.3 if args.dtype == "f32" else 78.6, "traffic": None,
+                          "kernel": "irls_nb_mfma32_kernel (%s half-update: per-column weighted Gram G + F diag(w - 1) F^T on "
+                                    "v_mfma_f32_32x32x2_f32, one wave per column, then the CD solve)" % big,
+                          "counted": "2 k_pad^2 flops per nonzero and IRLS pass (passes counted by the kernel in one extra, untimed "
+                                     "iteration); CD sweeps of the per-pass solves not counted"}, **roof[big]),
+        "roofline_other_side": roof["W" if big == "H" else "H"],
+        "phases_ms_per_step": phases, "launch": "eager", "final_loss": final_loss, "world_size_seen": 1,
+    }
+    if not args.no_cpu_baseline:
+        try:
+            line["cpu_baseline"] = cpu_baseline_c5(A, At, W, H, theta, ops, k, nd, args)
+            line["speedup_vs_cpu_baseline"] = line["value"] / line["cpu_baseline"]["value"]
+        except Exception as e:
+            line["cpu_baseline"] = {"value": None, "unit": "cols/s", "cores": os.cpu_count(), "kind": "port", "sample": "failed: %r" % (e,)}
+    print(json.dumps(line))
+
+
+def cpu_baseline_c5(A, At, W, H, theta, ops, k, nd, args):
+    """The oracle's IRLS half-update (nnls_batch_irls.hpp restated, OpenMP over columns) on a column sample of both sides with the
+    device's live factors, extrapolated to one iteration (size update and likelihood not included: O(nnz k), minor)."""
+    from oracle import oracle as O
+    cores = O.num_threads()
+    Wh, Hh, th = W.cpu().numpy(), H.cpu().numpy(), theta.cpu().numpy()
+    out = {}
+    for side, (M, F) in dict(H=(A, Wh), W=(At, Hh)).items():
+        G = (F.astype(np.float64).T @ F.astype(np.float64) + 1e-15 * np.eye(k)).astype(nd)
+        rate, ncols = None, min(M.cols, 64 * cores)
+        for _ in range(2):                                     # pilot, then a sample sized to the time budget
+            e = int(M.p[ncols])
+            sub = O.Csc((M.rows, ncols), M.p[:ncols + 1], M.i[:e], M.x[:e])
+            t0 = time.perf_counter()
+            O.irls_nb(sub, F, G, k, threads=0, dtype=nd, cd_maxit=args.cd_maxit, theta_row=th if side == "H" else None,
+                      theta_col=None if side == "H" else th[:ncols])
+            sec = time.perf_counter() - t0
+            out[side] = (ncols, sec)
+            ncols = int(min(M.cols, max(ncols, ncols / max(sec, 1e-6) * args.cpu_seconds / 2)))
+    t_iter = A.cols * out["H"][1] / out["H"][0] + A.rows * out["W"][1] / out["W"][0]
+    return dict(value=(A.rows + A.cols) / t_iter, unit="cols/s", cores=cores, kind="port", dtype=args.dtype,
+                sample="NB-IRLS half-updates on the first %d of %d columns (H side, %.2fs) and the first %d of %d rows (W side, %.2fs), "
+                       "live factors after the timed iterations; extrapolated to one iteration" % (
+                           out["H"][0], A.cols, out["H"][1], out["W"][0], A.rows, out["W"][1]))
 
 
 def plugin_figure(A, m, n, k, seed):

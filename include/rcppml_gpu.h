@@ -235,8 +235,12 @@ RCPPML_GPU_API int rcppml_hip_ctx_sync(rcppml_hip_ctx* ctx);
  * moved (only with RCPPML_OPT_CD_COUNT_NOOP; a step is one coordinate of one wave-sweep).  Counted by the GROUP, MFMA and
  * LMF kernels (what RCPPML_CD_AUTO dispatches to). */
 RCPPML_GPU_API int rcppml_hip_ctx_stats(rcppml_hip_ctx* ctx, int reset, unsigned long long* out4);
+/* IRLS work counters (only while RCPPML_OPT_CD_COUNT_NOOP is set; two atomics per column): out2[0] = IRLS passes summed over
+ * the columns rcppml_hip_solve_irls solved (nnls_batch_irls.hpp:480-560: each pass rebuilds the weighted Gram and solves),
+ * out2[1] = the same weighted by the column's nonzeros = rank-1 updates f f^T of the weighted Grams (x 2 k_pad^2 = flops). */
+RCPPML_GPU_API int rcppml_hip_ctx_irls_stats(rcppml_hip_ctx* ctx, int reset, unsigned long long* out2);
 /* Tuning / diagnostic switches of a context (0 = default behaviour for all of them). */
-enum { RCPPML_OPT_CD_COUNT_NOOP = 1 /* LMF kernel counts all-zero coordinate steps into stats[3] (slower) */,
+enum { RCPPML_OPT_CD_COUNT_NOOP = 1 /* LMF kernel counts all-zero coordinate steps into stats[3], IRLS kernels count passes (slower) */,
        RCPPML_OPT_CD_LMF_LANE_GROUPS = 2 /* 1, 2 or 4 lane groups per column instead of the size heuristic */,
        RCPPML_OPT_CD_LMF_WAVES_PER_SIMD = 3 /* resident persistent waves per SIMD instead of the heuristic */,
        RCPPML_OPT_CD_NO_LMF = 4 /* RCPPML_CD_AUTO falls back to the 32- / 16-column MFMA kernels */ };

@@ -2009,14 +2009,18 @@ __global__ __launch_bounds__(256) void cv_test_error_kernel(
     unsigned long long cnt = 0;
     if (j < ncols) {
         const bool fok = lane < k;
-        // k <= 64: lane f holds d_f * H(f, j); a held-out entry costs one gather of W_T(row, :) and a wave reduction
+        // lane f holds d_f * H(f, j) for features f and f + 64 (k <= 128); a held-out entry costs one gather of W_T(row, :) and a
+        // wave reduction
+        const bool fok2 = lane + 64 < k;
         const T hd = fok ? H[j * (int64_t)k + lane] * d[lane] : T(0);
+        const T hd2 = fok2 ? H[j * (int64_t)k + lane + 64] * d[lane + 64] : T(0);
         const unsigned col = (unsigned)j;
         if (mask_zeros) {
             for (int t = colptr[j]; t < colptr[j + 1]; ++t) {
                 const int row = rowidx[t];
                 if (!(cv_hash_dev(seed, (unsigned)row, col) < threshold)) continue;
                 T p = fok ? W_T[(int64_t)row * k + lane] * hd : T(0);
+                if (fok2) p = tfma(W_T[(int64_t)row * k + lane + 64], hd2, p);
 #pragma unroll
                 for (int off = 32; off > 0; off >>= 1) p += shfl_xor_t(p, off);
                 const T diff = vals[t] - p;
@@ -2037,6 +2041,7 @@ __global__ __launch_bounds__(256) void cv_test_error_kernel(
                     while (t < te && rowidx[t] < row) ++t;
                     const T actual = (t < te && rowidx[t] == row) ? vals[t] : T(0);
                     T p = fok ? W_T[(int64_t)row * k + lane] * hd : T(0);
+                    if (fok2) p = tfma(W_T[(int64_t)row * k + lane + 64], hd2, p);
 #pragma unroll
                     for (int off = 32; off > 0; off >>= 1) p += shfl_xor_t(p, off);
                     const T diff = actual - p;

@@ -234,12 +234,13 @@ __global__ __launch_bounds__(256) void cv_irls_loss_kernel(
     double* __restrict__ psum /*2 per block*/, unsigned long long* __restrict__ pcnt /*2 per block*/) {
     __shared__ double sh[4][2];
     __shared__ unsigned long long shn[4][2];
-    __shared__ T hs[4][64];
-    __shared__ T dsh[64];
+    __shared__ T hs[4][128];
+    __shared__ T dsh[128];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t j = (int64_t)blockIdx.x * 4 + wave;
-    if (threadIdx.x < 64) dsh[threadIdx.x] = threadIdx.x < k ? d[threadIdx.x] : T(0);
+    if (threadIdx.x < 128) dsh[threadIdx.x] = (int)threadIdx.x < k ? d[threadIdx.x] : T(0);
     hs[wave][lane] = (j < ncols && lane < k) ? H[j * (int64_t)k + lane] : T(0);
+    hs[wave][lane + 64] = (j < ncols && lane + 64 < k) ? H[j * (int64_t)k + lane + 64] : T(0);
     __syncthreads();
     double tr = 0.0, te = 0.0;
     unsigned long long ntr = 0, nte = 0;
@@ -306,10 +307,12 @@ __global__ __launch_bounds__(256) void cv_gp_theta_rows_kernel(
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t i = (int64_t)blockIdx.x * 4 + wave;
     if (i >= m) return;
-    const bool fok = lane < k;
+    const bool fok = lane < k, fok2 = lane + 64 < k;                     // lane holds features lane and lane + 64 (k <= 128)
     const T wd = fok ? W_T[i * (int64_t)k + lane] * d[lane] : T(0);
-    __shared__ T wds[4][64];
+    const T wd2 = fok2 ? W_T[i * (int64_t)k + lane + 64] * d[lane + 64] : T(0);
+    __shared__ T wds[4][128];
     wds[wave][lane] = wd;
+    wds[wave][lane + 64] = wd2;
     __builtin_amdgcn_wave_barrier();
     const int ts = tp[i], te = tp[i + 1];
     double sum_y = 0.0, n_nz = 0.0;
@@ -327,7 +330,7 @@ __global__ __launch_bounds__(256) void cv_gp_theta_rows_kernel(
     }
     sum_y = wave_sum(sum_y);
     n_nz = wave_sum(n_nz);
-    double sum_s = static_cast<double>(wave_sum(fok ? wd * h_rs[lane] : T(0)));
+    double sum_s = static_cast<double>(wave_sum((fok ? wd * h_rs[lane] : T(0)) + (fok2 ? wd2 * h_rs[lane + 64] : T(0))));
     double held_s = 0.0;
     for (int64_t j0 = 0; j0 < n; j0 += 64) {
         const int64_t jj = j0 + lane;

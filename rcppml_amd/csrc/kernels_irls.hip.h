@@ -85,7 +85,8 @@ __global__ __launch_bounds__(256) void irls_nb_solve_kernel(
     const int* __restrict__ colptr, const int* __restrict__ rowidx, const T* __restrict__ vals, int64_t ncols,
     const T* __restrict__ F, const T* __restrict__ Gbase, T* __restrict__ X, int k, T l1, T l2, int nonneg,
     int cd_maxit, int irls_max_iter, T irls_tol, const T* __restrict__ theta_row, const T* __restrict__ theta_col,
-    int loss_type, T power, T robust) {
+    int loss_type, T power, T robust,
+    unsigned long long* __restrict__ stats) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     T* Gl = reinterpret_cast<T*>(smem_raw) + (size_t)wave * KP * KP;    // [c][r]
@@ -101,7 +102,9 @@ __global__ __launch_bounds__(256) void irls_nb_solve_kernel(
     const int as = colptr[j], ae = colptr[j + 1];
     const T th_col = theta_col ? theta_col[j] : T(0);
     T x = T(0);                                   // nnls_batch_irls.hpp:482-483  H.setZero(): no warm start
+    int passes = 0;
     for (int irls = 0; irls < irls_max_iter; ++irls) {
+        ++passes;
         T gw[KP];
 #pragma unroll
         for (int c = 0; c < KP; ++c) gw[c] = gb[c];
@@ -168,6 +171,8 @@ __global__ __launch_bounds__(256) void irls_nb_solve_kernel(
         if (rel < irls_tol) break;
     }
     if (fok) X[j * (int64_t)k + lane] = x;
+    // work counters (RCPPML_OPT_CD_COUNT_NOOP only): IRLS passes and nonzero-passes = weighted-Gram rank-1 updates
+    if (stats && lane == 0) { atomicAdd(stats, (unsigned long long)passes); atomicAdd(stats + 1, (unsigned long long)passes * (unsigned long long)(ae - as)); }
 }
 
 // ---------------------------------------------------------------------------
@@ -187,7 +192,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     const int* __restrict__ colptr, const int* __restrict__ rowidx, const float* __restrict__ vals, int64_t ncols,
     const float* __restrict__ F, const float* __restrict__ Gbase, float* __restrict__ X, int k, float l1, float l2,
     int nonneg, int cd_maxit, int irls_max_iter, float irls_tol, const float* __restrict__ theta_row,
-    const float* __restrict__ theta_col, int loss_type, float power, float robust) {
+    const float* __restrict__ theta_col, int loss_type, float power, float robust,
+    unsigned long long* __restrict__ stats) {
     constexpr int KP = 32, CH = 32, FS = 36;          // FS: padded row stride of the staged F rows (bank spread)
     constexpr int WAVE_FLOATS = CH * FS + 2 * CH + KP;  // staged rows | (w-1, w a) pairs | x
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -205,7 +211,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     const int as = colptr[j], ae = colptr[j + 1];
     const float th_col = theta_col ? theta_col[j] : 0.f;
     float x = 0.f;                                      // nnls_batch_irls.hpp:482-483  H.setZero(): no warm start
+    int passes = 0;
     for (int irls = 0; irls < irls_max_iter; ++irls) {
+        ++passes;
         // accumulator tile <- base Gram (identity padding), C/D map: col = lane&31, row = (v&3) + 8(v>>2) + 4(lane>>5)
         f32x16 acc;
 #pragma unroll
@@ -309,6 +317,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         if (rel < irls_tol) break;
     }
     if (fok) X[j * (int64_t)k + lane] = x;
+    // work counters (RCPPML_OPT_CD_COUNT_NOOP only): IRLS passes and nonzero-passes = weighted-Gram rank-1 updates
+    if (stats && lane == 0) { atomicAdd(stats, (unsigned long long)passes); atomicAdd(stats + 1, (unsigned long long)passes * (unsigned long long)(ae - as)); }
 }
 
 // ---------------------------------------------------------------------------
@@ -323,7 +333,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int* __restrict__ colptr, const int* __restrict__ rowidx, const float* __restrict__ vals, int64_t ncols,
     const float* __restrict__ F, const float* __restrict__ Gbase, float* __restrict__ X, int k, float l1, float l2,
     int nonneg, int cd_maxit, int irls_max_iter, float irls_tol, const float* __restrict__ theta_row,
-    const float* __restrict__ theta_col, int loss_type, float power, float robust) {
+    const float* __restrict__ theta_col, int loss_type, float power, float robust,
+    unsigned long long* __restrict__ stats) {
     constexpr int KP = 64, CH = 32, FS = 68;          // FS: padded stride of a staged F row (64 features + bank spread)
     constexpr int GW = KP * KP;                        // G_w slab; the staged rows (CH * FS = 2176 floats) alias its head
     constexpr int WAVE_FLOATS = GW + 2 * CH + KP;      // G_w | (w-1, w a) pairs | x
@@ -340,7 +351,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int as = colptr[j], ae = colptr[j + 1];
     const float th_col = theta_col ? theta_col[j] : 0.f;
     float x = 0.f;                                      // nnls_batch_irls.hpp:482-483  H.setZero(): no warm start
+    int passes = 0;
     for (int irls = 0; irls < irls_max_iter; ++irls) {
+        ++passes;
         // accumulator tiles <- base Gram (identity padding); C/D map of a tile: col = lane&31, row = (v&3) + 8(v>>2) + 4(lane>>5)
         f32x16 a00, a01, a11;                           // rows 0-31 x cols 0-31 | rows 0-31 x cols 32-63 | rows 32-63 x cols 32-63
 #pragma unroll
@@ -462,6 +475,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         if (rel < irls_tol) break;
     }
     if (fok) X[j * (int64_t)k + lane] = x;
+    // work counters (RCPPML_OPT_CD_COUNT_NOOP only): IRLS passes and nonzero-passes = weighted-Gram rank-1 updates
+    if (stats && lane == 0) { atomicAdd(stats, (unsigned long long)passes); atomicAdd(stats + 1, (unsigned long long)passes * (unsigned long long)(ae - as)); }
 }
 
 // ---------------------------------------------------------------------------
@@ -474,7 +489,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     const int* __restrict__ colptr, const int* __restrict__ rowidx, const double* __restrict__ vals, int64_t ncols,
     const double* __restrict__ F, const double* __restrict__ Gbase, double* __restrict__ X, int k, double l1, double l2,
     int nonneg, int cd_maxit, int irls_max_iter, double irls_tol, const double* __restrict__ theta_row,
-    const double* __restrict__ theta_col, int loss_type, double power, double robust) {
+    const double* __restrict__ theta_col, int loss_type, double power, double robust,
+    unsigned long long* __restrict__ stats) {
     constexpr int KP = 32, CH = 32, FS = 34;          // FS: padded row stride (doubles) of the staged F rows
     constexpr int WAVE_DOUBLES = CH * FS + 2 * CH + KP;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -493,7 +509,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     const int as = colptr[j], ae = colptr[j + 1];
     const double th_col = theta_col ? theta_col[j] : 0.0;
     double x = 0.0;
+    int passes = 0;
     for (int irls = 0; irls < irls_max_iter; ++irls) {
+        ++passes;
         f64x4 acc[2][2];
 #pragma unroll
         for (int ti = 0; ti < 2; ++ti)
@@ -604,6 +622,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
         if (rel < irls_tol) break;
     }
     if (fok) X[j * (int64_t)k + lane] = x;
+    // work counters (RCPPML_OPT_CD_COUNT_NOOP only): IRLS passes and nonzero-passes = weighted-Gram rank-1 updates
+    if (stats && lane == 0) { atomicAdd(stats, (unsigned long long)passes); atomicAdd(stats + 1, (unsigned long long)passes * (unsigned long long)(ae - as)); }
 }
 
 // NB size (r) method-of-moments update, one wavefront per ROW i of A (= column i of A^T):
@@ -616,11 +636,13 @@ __global__ __launch_bounds__(256) void nb_size_rows_kernel(
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t i = (int64_t)blockIdx.x * 4 + wave;
     if (i >= m) return;
-    const bool fok = lane < k;
+    const bool fok = lane < k, fok2 = lane + 64 < k;                     // lane holds features lane and lane + 64 (k <= 128)
     const T wd = fok ? W_T[i * (int64_t)k + lane] * d[lane] : T(0);     // apply_scaling(W_Td, d)
+    const T wd2 = fok2 ? W_T[i * (int64_t)k + lane + 64] * d[lane + 64] : T(0);
     // one lane per nonzero: the row of H is gathered with 16-byte loads and dotted in-lane against Wd_i (LDS broadcast)
-    __shared__ T wds[4][64];
+    __shared__ T wds[4][128];
     wds[wave][lane] = wd;
+    wds[wave][lane + 64] = wd2;
     __builtin_amdgcn_wave_barrier();
     constexpr int VEC = 16 / sizeof(T);
     typedef typename VecT<T, VEC>::type V;
@@ -648,13 +670,14 @@ __global__ __launch_bounds__(256) void nb_size_rows_kernel(
     }
     s_mu2 = wave_sum(s_mu2);
     s_res2 = wave_sum(s_res2);
-    const T tm = wave_sum(fok ? wd * h_rs[lane] : T(0));
+    const T tm = wave_sum((fok ? wd * h_rs[lane] : T(0)) + (fok2 ? wd2 * h_rs[lane + 64] : T(0)));
     const double total_mu = static_cast<double>(tm);
     // total_mu_sq = sum_ab Wd_a G_H(a,b) Wd_b  (fp64 accumulation as the reference)
     double acc = 0.0;
     for (int b2 = 0; b2 < k; ++b2) {
-        const double wb = static_cast<double>(__shfl(wd, b2, 64));
+        const double wb = static_cast<double>(wds[wave][b2]);
         if (fok) acc += static_cast<double>(wd) * static_cast<double>(G_H[(int64_t)b2 * k + lane]) * wb;
+        if (fok2) acc += static_cast<double>(wd2) * static_cast<double>(G_H[(int64_t)b2 * k + lane + 64]) * wb;
     }
     const double total_mu_sq = wave_sum(acc);
     if (lane == 0) {
@@ -685,10 +708,12 @@ __global__ __launch_bounds__(256) void dispersion_rows_kernel(
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t i = (int64_t)blockIdx.x * 4 + wave;
     if (i >= m) return;
-    const bool fok = lane < k;
+    const bool fok = lane < k, fok2 = lane + 64 < k;                     // lane holds features lane and lane + 64 (k <= 128)
     const T wd = fok ? W_T[i * (int64_t)k + lane] * d[lane] : T(0);     // apply_scaling(W_Td, d)
-    __shared__ T wds[4][64];
+    const T wd2 = fok2 ? W_T[i * (int64_t)k + lane + 64] * d[lane + 64] : T(0);
+    __shared__ T wds[4][128];
     wds[wave][lane] = wd;
+    wds[wave][lane + 64] = wd2;
     __builtin_amdgcn_wave_barrier();
     constexpr int VEC = 16 / sizeof(T);
     typedef typename VecT<T, VEC>::type V;
@@ -736,7 +761,7 @@ __global__ __launch_bounds__(256) void dispersion_rows_kernel(
         }
         return;
     }
-    const double sum_s = static_cast<double>(wave_sum(fok ? wd * h_rs[lane] : T(0)));       // Gram trick, :935-938
+    const double sum_s = static_cast<double>(wave_sum((fok ? wd * h_rs[lane] : T(0)) + (fok2 ? wd2 * h_rs[lane + 64] : T(0))));   // Gram trick, :935-938
     T th_s = theta[i];
     for (int mm = 0; mm < 5; ++mm) {                                                          // THETA_INNER_ITERS
         const double th = static_cast<double>(th_s);
@@ -800,12 +825,13 @@ __global__ __launch_bounds__(256) void nb_loss_lane_kernel(
     constexpr int VEC = 16 / sizeof(T);
     typedef typename VecT<T, VEC>::type V;
     __shared__ double sh[4];
-    __shared__ T hs[4][64];
-    __shared__ T dsh[64];
+    __shared__ T hs[4][128];
+    __shared__ T dsh[128];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t j = (int64_t)blockIdx.x * 4 + wave;
-    if (threadIdx.x < 64) dsh[threadIdx.x] = threadIdx.x < k ? d[threadIdx.x] : T(0);
+    if (threadIdx.x < 128) dsh[threadIdx.x] = (int)threadIdx.x < k ? d[threadIdx.x] : T(0);
     hs[wave][lane] = (j < ncols && lane < k) ? H[j * (int64_t)k + lane] : T(0);
+    hs[wave][lane + 64] = (j < ncols && lane + 64 < k) ? H[j * (int64_t)k + lane + 64] : T(0);
     __syncthreads();
     double acc = 0.0;
     if (j < ncols) {
@@ -893,11 +919,14 @@ __global__ __launch_bounds__(256) void nb_loss_kernel(
     double acc = 0.0;
     if (j < ncols) {
         const bool fok = lane < k;
+        const bool fok2 = lane + 64 < k;
         const T hv = fok ? H[j * (int64_t)k + lane] : T(0);
+        const T hv2 = fok2 ? H[j * (int64_t)k + lane + 64] : T(0);
         for (int t = colptr[j]; t < colptr[j + 1]; ++t) {
             const int row = rowidx[t];
             const T wd = fok ? W_T[(int64_t)row * k + lane] * d[lane] : T(0);
-            const T pred = wave_sum(wd * hv);
+            const T wd2 = fok2 ? W_T[(int64_t)row * k + lane + 64] * d[lane + 64] : T(0);
+            const T pred = wave_sum(wd * hv + wd2 * hv2);
             const double y = static_cast<double>(vals[t]);
             double mu = static_cast<double>(pred);
             mu = mu > 1e-10 ? mu : 1e-10;

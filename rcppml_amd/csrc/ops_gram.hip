@@ -19,8 +19,8 @@ extern "C" int rcppml_hip_ctx_create(rcppml_hip_ctx** out, int device, void* str
         hipDeviceProp_t prop;
         HIPCHK(hipGetDeviceProperties(&prop, device));
         c->num_cu = prop.multiProcessorCount;
-        HIPCHK(hipMalloc(&c->stats, 4 * sizeof(unsigned long long)));
-        HIPCHK(hipMemset(c->stats, 0, 4 * sizeof(unsigned long long)));
+        HIPCHK(hipMalloc(&c->stats, 8 * sizeof(unsigned long long)));
+        HIPCHK(hipMemset(c->stats, 0, 8 * sizeof(unsigned long long)));
         *out = c;
         return 0;
     }
@@ -52,6 +52,15 @@ extern "C" int rcppml_hip_ctx_stats(rcppml_hip_ctx* c, int reset, unsigned long 
         HIPCHK(hipStreamSynchronize(c->stream));
         if (out4) HIPCHK(hipMemcpy(out4, c->stats, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
         if (reset) HIPCHK(hipMemset(c->stats, 0, 4 * sizeof(unsigned long long)));
+        return 0;
+    }
+    RCPPML_CATCH_RET
+}
+extern "C" int rcppml_hip_ctx_irls_stats(rcppml_hip_ctx* c, int reset, unsigned long long* out2) {
+    try {
+        HIPCHK(hipStreamSynchronize(c->stream));
+        if (out2) HIPCHK(hipMemcpy(out2, c->stats + 4, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        if (reset) HIPCHK(hipMemset(c->stats + 4, 0, 2 * sizeof(unsigned long long)));
         return 0;
     }
     RCPPML_CATCH_RET

@@ -16,6 +16,7 @@ static void irls_impl(rcppml_hip_ctx* c, const int* cp, const int* ri, const T* 
         throw std::runtime_error("solve_irls: loss_type must be 4 (GP), 5 (NB), 6 (Gamma), 7 (inverse Gaussian), 8 (Tweedie), or 0 (MSE) with robust_delta > 0");
     if (k < 1 || k > 64) throw std::runtime_error("solve_irls_nb: k must be in [1,64]");
     const int64_t nblk = (ncols + 3) / 4;
+    unsigned long long* const st = c->opt_cd_count ? c->stats + 4 : nullptr;     // [4] IRLS passes, [5] nonzero-passes
     if constexpr (std::is_same<T, float>::value) {
         // fp32, k <= 32: weighted Gram on the matrix cores (RCPPML_GPU_IRLS_VARIANT=valu keeps the register form)
         static int use_mfma = -1;
@@ -23,7 +24,7 @@ static void irls_impl(rcppml_hip_ctx* c, const int* cp, const int* ri, const T* 
         if (use_mfma && k <= 32 && k % 4 == 0 && reinterpret_cast<uintptr_t>(F) % 16 == 0) {
             const size_t smem = (size_t)4 * (32 * 36 + 2 * 32 + 32) * sizeof(float);
             hipLaunchKernelGGL(irls_nb_mfma32_kernel, dim3((unsigned)nblk), dim3(256), smem, c->stream, cp, ri, vals, ncols, F,
-                               Gbase, X, k, l1, l2, nonneg, cd_maxit, irls_max_iter, irls_tol, theta_row, theta_col, loss_type, power, robust);
+                               Gbase, X, k, l1, l2, nonneg, cd_maxit, irls_max_iter, irls_tol, theta_row, theta_col, loss_type, power, robust, st);
             HIPCHK(hipGetLastError());
             return;
         }
@@ -32,7 +33,7 @@ static void irls_impl(rcppml_hip_ctx* c, const int* cp, const int* ri, const T* 
             static DynSmemOnce once;
             once.ensure(reinterpret_cast<const void*>(&irls_nb_mfma32x2_kernel), smem, c->device);
             hipLaunchKernelGGL(irls_nb_mfma32x2_kernel, dim3((unsigned)nblk), dim3(256), smem, c->stream, cp, ri, vals, ncols, F,
-                               Gbase, X, k, l1, l2, nonneg, cd_maxit, irls_max_iter, irls_tol, theta_row, theta_col, loss_type, power, robust);
+                               Gbase, X, k, l1, l2, nonneg, cd_maxit, irls_max_iter, irls_tol, theta_row, theta_col, loss_type, power, robust, st);
             HIPCHK(hipGetLastError());
             return;
         }
@@ -43,7 +44,7 @@ static void irls_impl(rcppml_hip_ctx* c, const int* cp, const int* ri, const T* 
         if (use_mfma64 && k <= 32 && k % 2 == 0 && reinterpret_cast<uintptr_t>(F) % 16 == 0) {
             const size_t smem = (size_t)4 * (32 * 34 + 2 * 32 + 32) * sizeof(double);
             hipLaunchKernelGGL(irls_nb_mfma64_kernel, dim3((unsigned)nblk), dim3(256), smem, c->stream, cp, ri, vals, ncols, F,
-                               Gbase, X, k, l1, l2, nonneg, cd_maxit, irls_max_iter, irls_tol, theta_row, theta_col, loss_type, power, robust);
+                               Gbase, X, k, l1, l2, nonneg, cd_maxit, irls_max_iter, irls_tol, theta_row, theta_col, loss_type, power, robust, st);
             HIPCHK(hipGetLastError());
             return;
         }
@@ -51,14 +52,14 @@ static void irls_impl(rcppml_hip_ctx* c, const int* cp, const int* ri, const T* 
     if (k <= 32) {      // 32-wide instantiation: half the rank-1 work per nonzero, 16 KB of LDS per block (8 waves per SIMD)
         const size_t smem = (size_t)4 * 32 * 32 * sizeof(T);
         hipLaunchKernelGGL((irls_nb_solve_kernel<T, 32>), dim3((unsigned)nblk), dim3(256), smem, c->stream, cp, ri, vals, ncols,
-                           F, Gbase, X, k, l1, l2, nonneg, cd_maxit, irls_max_iter, irls_tol, theta_row, theta_col, loss_type, power, robust);
+                           F, Gbase, X, k, l1, l2, nonneg, cd_maxit, irls_max_iter, irls_tol, theta_row, theta_col, loss_type, power, robust, st);
     } else {
         const size_t smem = (size_t)4 * 64 * 64 * sizeof(T);
         auto kern = irls_nb_solve_kernel<T, 64>;
         static DynSmemOnce once;
         once.ensure(reinterpret_cast<const void*>(kern), smem, c->device);
         hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), smem, c->stream, cp, ri, vals, ncols, F, Gbase, X, k, l1, l2,
-                           nonneg, cd_maxit, irls_max_iter, irls_tol, theta_row, theta_col, loss_type, power, robust);
+                           nonneg, cd_maxit, irls_max_iter, irls_tol, theta_row, theta_col, loss_type, power, robust, st);
     }
     HIPCHK(hipGetLastError());
 }

@@ -90,3 +90,35 @@ def test_bench_self_launcher_two_ranks_sharing_the_gpu(config):
     d1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
     # fp64: the two runs differ by the summation order of the reduced Gram / right-hand side and by "scale after the sum"
     assert abs(d2["final_loss"] - d1["final_loss"]) / abs(d1["final_loss"]) < 1e-9
+
+
+def test_bench_c3_line_on_the_movielens_fixture():
+    """--config c3: BASELINE configs[2] (movielens, k = 32, L1 = c(0, 0.1)) through the same loop; the fp64 leg stays inside the
+    north star's 1e-6 of the CPU reference fit."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--config", "c3", "--steps", "4", "--warmup", "3", "--no-plugin-figure",
+           "--cpu-seconds", "1", "--no-noop-count"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads(out.stdout.strip().splitlines()[-1])
+    assert d["config"]["rows"] == 3867 and d["config"]["cols_per_gpu"] == 610 and d["config"]["k"] == 32 and d["config"]["nnz_per_gpu"] == 75238
+    assert "movielens" in d["config"]["workload"] and d["value"] > 0 and d["cpu_baseline"]["value"] > 0
+    assert 0 <= d["loss_rel_dev_vs_cpu_ref"] < 2e-4 and 0 <= d["fp64"]["loss_rel_dev_vs_cpu_ref"] < 1e-6
+
+
+def test_bench_c5_line_reduced_shape():
+    """--config c5 (NB IRLS) on a reduced shape: the line carries the weighted-Gram roofline with the passes the kernel counted
+    (between 1 and irls_max_iter per column) and a CPU baseline of the same half-updates."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--config", "c5", "--rows", "2000", "--cols", "12000", "--steps", "3",
+           "--warmup", "2", "--cpu-seconds", "1"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads(out.stdout.strip().splitlines()[-1])
+    assert d["unit"] == "cols/s" and d["dtype"] == "f32" and "nb" in d["metric"] and d["value"] > 0
+    assert abs(d["value"] - 3 * (2000 + 12000) / (d["ms_per_step"] * 3e-3)) / d["value"] < 1e-6
+    for roof in (d["roofline"], d["roofline_other_side"]):
+        assert 1.0 <= roof["mean_passes_per_column"] <= 5.0 and roof["nonzero_passes"] >= d["config"]["nnz_per_gpu"]
+        assert 0 < roof["frac"] < 1
+    assert d["roofline"]["bound"] == "mfma" and abs(d["roofline"]["frac"] - d["roofline"]["achieved"] / d["roofline"]["peak"]) < 1e-9
+    assert set(d["phases_ms_per_step"]) >= {"gram", "solve_H", "solve_W", "scale", "nb_size", "loss"}
+    assert d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["cores"] >= 1
+    assert d["final_loss"] == d["final_loss"]          # finite, not NaN

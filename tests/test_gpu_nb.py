@@ -362,8 +362,10 @@ def _pick_cols(A, cols):
                  np.concatenate([A.x[A.p[c]:A.p[c + 1]] for c in cols]))
 
 
-def test_full_size_c5_nb_properties(env):
-    """BASELINE configs[4] at FULL size: loss = 'nb' on 10 000 x 200 000 Poisson-Gamma counts (2 % dense), k = 32, fp32.
+@pytest.mark.parametrize("precision", ["f32", "f64"])
+def test_full_size_c5_nb_properties(env, precision):
+    """BASELINE configs[4] at FULL size: loss = 'nb' on 10 000 x 200 000 Poisson-Gamma counts (2 % dense), k = 32, fp32 (what the
+    reference computes in) and fp64 (parity mode: the sampled columns must agree with the oracle to 1e-6).
     Two outer iterations driven op by op (IRLS half-update of H, scaling, IRLS half-update of W, scaling, method-of-moments
     size update, NB likelihood): everything finite and non-negative, the likelihood not increasing beyond the reference's
     slack, sizes inside their clamp, and 128 sampled columns of each IRLS half-update recomputed by the oracle's irls_nb from
@@ -374,12 +376,13 @@ def test_full_size_c5_nb_properties(env):
     A, _, _ = data.simulate_nb_counts(m, n, k, density=0.02, size=5.0, seed=123)
     assert 3.0e7 < A.nnz < 4.5e7
     At = A.transpose()
-    W0, H0 = data.init_factors(42, k, m, n, np.float32)
-    ops = als.HipOps(0, "f32")
+    nd = np.float32 if precision == "f32" else np.float64
+    W0, H0 = data.init_factors(42, k, m, n, nd)
+    ops = als.HipOps(0, precision)
     W, H = ops.to_device(W0), ops.to_device(H0)
     Ad, Atd = ops.upload_csc(A), ops.upload_csc(At)
-    theta = torch.full((m,), 10.0, dtype=torch.float32, device="cuda")           # nb_size_init (core/config.hpp)
-    d = torch.ones((k,), dtype=torch.float32, device="cuda")
+    theta = torch.full((m,), 10.0, dtype=ops.tdtype, device="cuda")              # nb_size_init (core/config.hpp)
+    d = torch.ones((k,), dtype=ops.tdtype, device="cuda")
     sums = ops.empty((k,))
     out = torch.zeros((2,), dtype=torch.float64, device="cuda")
     losses = []
@@ -395,15 +398,18 @@ def test_full_size_c5_nb_properties(env):
             cols = np.sort(np.random.default_rng(3 * it + (side == "W")).choice(host.cols, size=128, replace=False))
             sub = _pick_cols(host, cols)
             ref = O.irls_nb(sub, F_host, G_host, k, L1=0.0, L2=0.0, theta_row=th_host if side == "H" else None,
-                            theta_col=None if side == "H" else th_host[cols], dtype=np.float32)
+                            theta_col=None if side == "H" else th_host[cols], dtype=nd)
             # per-column deviation relative to the column's largest entry.  The W side solves rows of A with thousands of
             # nonzeros whose first-pass weights sit at the 1e6 cap (x = 0): a few such systems are ill-conditioned enough
             # that fp32 summation order moves single entries by several percent -- most columns agree to 1e-4
             errc = np.abs(X_new[cols] - ref).max(axis=1) / (np.abs(ref).max(axis=1) + 1e-30)
             worst = int(np.argmax(errc))
-            assert np.median(errc) < 2e-3 and np.mean(errc < 3e-2) >= 0.95 and np.sum(errc > 0.2) <= 2, (
-                it, side, np.percentile(errc, [50, 90, 99, 100]), "worst column nnz", int(sub.p[worst + 1] - sub.p[worst]),
-                "GPU", X_new[cols][worst][:6], "oracle", ref[worst][:6])
+            if precision == "f64":
+                assert errc.max() <= 1e-6, (it, side, np.percentile(errc, [50, 90, 99, 100]), "worst column nnz", int(sub.p[worst + 1] - sub.p[worst]))
+            else:
+                assert np.median(errc) < 2e-3 and np.mean(errc < 3e-2) >= 0.95 and np.sum(errc > 0.2) <= 2, (
+                    it, side, np.percentile(errc, [50, 90, 99, 100]), "worst column nnz", int(sub.p[worst + 1] - sub.p[worst]),
+                    "GPU", X_new[cols][worst][:6], "oracle", ref[worst][:6])
             ops.row_norms(X, 0, out=sums)
             ops.apply_scaling(X, sums, 0, d)
         ops.ctx.nb_size_update(ops.dt, Atd["p"], Atd["i"], Atd["x"], m, W, d, H, n, k, 0.01, 1e6, theta)
