@@ -188,7 +188,7 @@ __global__ __launch_bounds__(256) void irls_nb_solve_kernel(
 //   The CD solve is unchanged (exact sequential sweep with ballot skipping); G_w is written from the accumulator tile
 //   straight into its LDS slab, which aliases the staging buffer.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void irls_nb_mfma32_kernel(
+static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void irls_nb_mfma32_kernel(
     const int* __restrict__ colptr, const int* __restrict__ rowidx, const float* __restrict__ vals, int64_t ncols,
     const float* __restrict__ F, const float* __restrict__ Gbase, float* __restrict__ X, int k, float l1, float l2,
     int nonneg, int cd_maxit, int irls_max_iter, float irls_tol, const float* __restrict__ theta_row,
@@ -329,7 +329,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 // two blocks per CU -- an order of magnitude above the row-in-registers form this rank range used before (64 shuffles +
 // 64 fmas per nonzero and lane), not the occupancy of the k <= 32 kernel.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void irls_nb_mfma32x2_kernel(
+static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void irls_nb_mfma32x2_kernel(
     const int* __restrict__ colptr, const int* __restrict__ rowidx, const float* __restrict__ vals, int64_t ncols,
     const float* __restrict__ F, const float* __restrict__ Gbase, float* __restrict__ X, int k, float l1, float l2,
     int nonneg, int cd_maxit, int irls_max_iter, float irls_tol, const float* __restrict__ theta_row,
@@ -485,7 +485,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // f_t[16 tj + r], lane (r = lane&15, kk = lane>>4) serves nonzero 4s + kk), C/D map col = lane&15, row = (lane>>4) + 4v.
 // Phase A / CD solve as in irls_nb_mfma32_kernel (16-byte gathers = 2 doubles).
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void irls_nb_mfma64_kernel(
+static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void irls_nb_mfma64_kernel(
     const int* __restrict__ colptr, const int* __restrict__ rowidx, const double* __restrict__ vals, int64_t ncols,
     const double* __restrict__ F, const double* __restrict__ Gbase, double* __restrict__ X, int k, double l1, double l2,
     int nonneg, int cd_maxit, int irls_max_iter, double irls_tol, const double* __restrict__ theta_row,

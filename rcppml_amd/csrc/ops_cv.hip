@@ -3,6 +3,7 @@
 #include <cstring>
 #include "common.hip.h"
 #include "kernels.hip.h"
+#include "kernels_wide.hip.h"
 
 using namespace rk;
 
@@ -22,10 +23,19 @@ void cv_solve_impl(rcppml_hip_ctx* c, const int* cp, const int* ri, const T* val
                    const T* G, T* X, int k, double frac, unsigned long long cv_seed, int mask_zeros, int transposed, T l1,
                    int nonneg, int maxit, int solver_mode) {
     if (ncols <= 0) return;
-    if (k < 1 || k > 64) throw std::runtime_error("solve_cv: k must be in [1,64]");
+    if (k < 1 || k > 128) throw std::runtime_error("solve_cv: k must be in [1,128]");
     if (solver_mode != 0 && solver_mode != 1) throw std::runtime_error("solve_cv: solver_mode must be 0 (CD) or 1 (Cholesky+clip)");
     unsigned long long seed, thr;
     mask_params(frac, cv_seed, &seed, &thr);
+    if (k > 64) {          // one wave per column, two features per lane, Gram tile in LDS (kernels_wide.hip.h)
+        auto kern = wide_cv_solve_kernel<T>;
+        static DynSmemOnce once;
+        once.ensure(reinterpret_cast<const void*>(kern), wide_smem_bytes<T>(), c->device);
+        hipLaunchKernelGGL(kern, dim3((unsigned)ncols), dim3(64), wide_smem_bytes<T>(), c->stream, cp, ri, vals, ncols, nrows, F, G, X, k,
+                           seed, thr, mask_zeros, transposed, l1, nonneg, maxit, solver_mode);
+        HIPCHK(hipGetLastError());
+        return;
+    }
     const int64_t nblk = (ncols + 3) / 4;
     if constexpr (std::is_same<T, float>::value) {
         // fp32, k <= 32: Gram correction on the matrix cores (RCPPML_GPU_CV_VARIANT=valu keeps the LDS read-modify-write form)
@@ -92,7 +102,7 @@ __global__ void cv_sum_partials_kernel(const double* __restrict__ ps, const unsi
 template <class T>
 void cv_test_impl(rcppml_hip_ctx* c, const int* cp, const int* ri, const T* vals, int64_t ncols, int nrows, const T* W_T,
                   const T* d, const T* H, int k, double frac, unsigned long long cv_seed, int mask_zeros, double* out2) {
-    if (k < 1 || k > 64) throw std::runtime_error("cv_test_error: k must be in [1,64]");
+    if (k < 1 || k > 128) throw std::runtime_error("cv_test_error: k must be in [1,128]");
     unsigned long long seed, thr;
     mask_params(frac, cv_seed, &seed, &thr);
     const int64_t nblk = ncols > 0 ? (ncols + 3) / 4 : 1;

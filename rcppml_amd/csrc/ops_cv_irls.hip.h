@@ -26,6 +26,15 @@ void solve_impl(rcppml_hip_ctx* c, int loss_type, const int* cp, const int* ri, 
     unsigned long long seed, thr;
     cvi_mask_params(frac, cv_seed, &seed, &thr);
     const int64_t nblk = (ncols + 3) / 4;
+    if (k > 64) {          // one wave per column, two features per lane, Gram tile in LDS (kernels_wide.hip.h)
+        auto kern = wide_cv_irls_solve_kernel<T>;
+        static DynSmemOnce once;
+        once.ensure(reinterpret_cast<const void*>(kern), wide_smem_bytes<T>(), c->device);
+        hipLaunchKernelGGL(kern, dim3((unsigned)ncols), dim3(64), wide_smem_bytes<T>(), c->stream, cp, ri, vals, ncols, nrows, F, Gadd, X, k,
+                           seed, thr, mask_zeros, transposed, l1, nonneg, maxit, solver_mode, loss_type, irls_max_iter, irls_tol, power, robust);
+        HIPCHK(hipGetLastError());
+        return;
+    }
     if (k <= 32) {
         hipLaunchKernelGGL((cv_irls_solve_kernel<T, 32>), dim3((unsigned)nblk), dim3(256), (size_t)4 * 32 * 32 * sizeof(T), c->stream, cp, ri, vals,
                            ncols, nrows, F, Gadd, X, k, seed, thr, mask_zeros, transposed, l1, nonneg, maxit, solver_mode, loss_type,
@@ -83,7 +92,7 @@ extern "C" int rcppml_hip_solve_cv_irls(rcppml_hip_ctx* c, int dtype, int loss_t
                                         double loss_param, double robust_delta) {
     try {
         HIPCHK(hipSetDevice(c->device));
-        if (k < 1 || k > 64) throw std::runtime_error("solve_cv_irls: k must be in [1,64]");
+        if (k < 1 || k > 128) throw std::runtime_error("solve_cv_irls: k must be in [1,128]");
         if (!loss_ok(loss_type, robust_delta)) throw std::runtime_error("solve_cv_irls: loss_type must be in 4..8, or 0 with robust_delta > 0");
         if (solver_mode != 0 && solver_mode != 1) throw std::runtime_error("solve_cv_irls: solver_mode must be 0 (CD) or 1 (Cholesky+clip)");
         if (dtype == RCPPML_F32)
@@ -105,7 +114,7 @@ extern "C" int rcppml_hip_cv_irls_loss(rcppml_hip_ctx* c, int dtype, int loss_ty
                                        double loss_param, double* out4) {
     try {
         HIPCHK(hipSetDevice(c->device));
-        if (k < 1 || k > 64) throw std::runtime_error("cv_irls_loss: k must be in [1,64]");
+        if (k < 1 || k > 128) throw std::runtime_error("cv_irls_loss: k must be in [1,128]");
         if (!(loss_type == 0 || (loss_type >= 4 && loss_type <= 8))) throw std::runtime_error("cv_irls_loss: loss_type must be 0 or in 4..8");
         if (dtype == RCPPML_F32)
             loss_impl<float>(c, loss_type, col_ptr, row_idx, (const float*)values, ncols, nrows, (const float*)W_T, (const float*)d,
@@ -124,7 +133,7 @@ extern "C" int rcppml_hip_cv_gp_theta_update(rcppml_hip_ctx* c, int dtype, int m
                                              void* theta) {
     try {
         HIPCHK(hipSetDevice(c->device));
-        if (k < 1 || k > 64) throw std::runtime_error("cv_gp_theta_update: k must be in [1,64]");
+        if (k < 1 || k > 128) throw std::runtime_error("cv_gp_theta_update: k must be in [1,128]");
         if (mode != 1 && mode != 2) throw std::runtime_error("cv_gp_theta_update: mode must be 1 (global) or 2 (per row)");
         if (dtype == RCPPML_F32)
             theta_impl<float>(c, dtype, mode, t_col_ptr, t_row_idx, (const float*)t_values, m, nnz, (const float*)W_T, (const float*)d,

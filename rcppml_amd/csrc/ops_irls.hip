@@ -3,6 +3,7 @@
 #include <cstring>
 #include "common.hip.h"
 #include "kernels_irls.hip.h"
+#include "kernels_wide.hip.h"
 #include <hipcub/hipcub.hpp>
 
 using namespace rk;
@@ -14,9 +15,18 @@ static void irls_impl(rcppml_hip_ctx* c, const int* cp, const int* ri, const T* 
     if (ncols <= 0) return;
     if (!((loss_type >= 4 && loss_type <= 8) || (loss_type == 0 && robust > T(0))))
         throw std::runtime_error("solve_irls: loss_type must be 4 (GP), 5 (NB), 6 (Gamma), 7 (inverse Gaussian), 8 (Tweedie), or 0 (MSE) with robust_delta > 0");
-    if (k < 1 || k > 64) throw std::runtime_error("solve_irls_nb: k must be in [1,64]");
+    if (k < 1 || k > 128) throw std::runtime_error("solve_irls: k must be in [1,128]");
     const int64_t nblk = (ncols + 3) / 4;
     unsigned long long* const st = c->opt_cd_count ? c->stats + 4 : nullptr;     // [4] IRLS passes, [5] nonzero-passes
+    if (k > 64) {          // one wave per column, two features per lane, Gram tile in LDS (kernels_wide.hip.h)
+        auto kern = wide_irls_solve_kernel<T>;
+        static DynSmemOnce once;
+        once.ensure(reinterpret_cast<const void*>(kern), wide_smem_bytes<T>(), c->device);
+        hipLaunchKernelGGL(kern, dim3((unsigned)ncols), dim3(64), wide_smem_bytes<T>(), c->stream, cp, ri, vals, ncols, F, Gbase, X, k,
+                           l1, l2, nonneg, cd_maxit, irls_max_iter, irls_tol, theta_row, theta_col, loss_type, power, robust, st);
+        HIPCHK(hipGetLastError());
+        return;
+    }
     if constexpr (std::is_same<T, float>::value) {
         // fp32, k <= 32: weighted Gram on the matrix cores (RCPPML_GPU_IRLS_VARIANT=valu keeps the register form)
         static int use_mfma = -1;
@@ -93,7 +103,7 @@ extern "C" int rcppml_hip_solve_irls_nb(rcppml_hip_ctx* c, int dtype, const int*
 template <class T>
 static void nb_size_impl(rcppml_hip_ctx* c, int dtype, const int* tp, const int* ti, const T* tx, int64_t m, const T* W_T,
                          const T* d, const T* H, int64_t n, int k, double r_min, double r_max, T* nb_size) {
-    if (k < 1 || k > 64) throw std::runtime_error("nb_size_update: k must be in [1,64]");
+    if (k < 1 || k > 128) throw std::runtime_error("nb_size_update: k must be in [1,128]");
     T* tmp = static_cast<T*>(c->scratch(WS_IRLS, ((size_t)k * k + k) * sizeof(T)));
     T* G_H = tmp;
     T* h_rs = tmp + (size_t)k * k;
@@ -150,7 +160,7 @@ template <class T>
 static void dispersion_impl(rcppml_hip_ctx* c, int dtype, int loss_type, int mode, const int* tp, const int* ti, const T* tx,
                             int64_t m, int64_t nnz, const T* W_T, const T* d, const T* H, int64_t n, int k, double power,
                             double lo, double hi, T* theta) {
-    if (k < 1 || k > 64) throw std::runtime_error("dispersion_update: k must be in [1,64]");
+    if (k < 1 || k > 128) throw std::runtime_error("dispersion_update: k must be in [1,128]");
     if (!(loss_type == 4 || (loss_type >= 6 && loss_type <= 8))) throw std::runtime_error("dispersion_update: loss_type must be 4 (GP) or 6 / 7 / 8 (Gamma / inverse Gaussian / Tweedie)");
     if (mode != 1 && mode != 2) throw std::runtime_error("dispersion_update: mode must be 1 (global) or 2 (per row)");
     if (m <= 0) return;
@@ -199,7 +209,7 @@ extern "C" int rcppml_hip_irls_loss(rcppml_hip_ctx* c, int dtype, int loss_type,
                                     const void* theta_row, int k, double loss_param, double robust_delta, double* out) {
     try {
         HIPCHK(hipSetDevice(c->device));
-        if (k < 1 || k > 64) throw std::runtime_error("irls_loss: k must be in [1,64]");
+        if (k < 1 || k > 128) throw std::runtime_error("irls_loss: k must be in [1,128]");
         if (!((loss_type >= 4 && loss_type <= 8) || (loss_type == 0 && robust_delta > 0)))
             throw std::runtime_error("irls_loss: loss_type must be in 4..8, or 0 with robust_delta > 0");
         if (dtype == RCPPML_F32)

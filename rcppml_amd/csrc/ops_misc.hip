@@ -1,6 +1,7 @@
 // ops_misc.hip -- scaling, loss reductions, explicit-mask solve (device-level C ABI)
 #include "common.hip.h"
 #include "kernels.hip.h"
+#include "kernels_wide.hip.h"
 
 using namespace rk;
 // ----------------------------------------------------------------------------
@@ -223,8 +224,17 @@ static void solve_masked_impl(rcppml_hip_ctx* c, const int* cp, const int* ri, c
                               const int* mi, int64_t ncols, const T* F, const T* Gfull, T* X, int k, T l1, T l2,
                               int nonneg, int maxit, T tol, int solver_mode, int warm) {
     if (ncols <= 0) return;
-    if (k > 64) throw std::runtime_error("solve_masked: k > 64 not supported");
+    if (k < 1 || k > 128) throw std::runtime_error("solve_masked: k must be in [1,128]");
     const int64_t nblk = (ncols + 3) / 4;
+    if (k > 64) {          // one wave per column, two features per lane, Gram tile in LDS (kernels_wide.hip.h)
+        auto kern = wide_masked_solve_kernel<T>;
+        static DynSmemOnce once;
+        once.ensure(reinterpret_cast<const void*>(kern), wide_smem_bytes<T>(), c->device);
+        hipLaunchKernelGGL(kern, dim3((unsigned)ncols), dim3(64), wide_smem_bytes<T>(), c->stream, cp, ri, vals, mp, mi, ncols, F, Gfull, X, k,
+                           l1, l2, nonneg, maxit, tol, solver_mode, warm);
+        HIPCHK(hipGetLastError());
+        return;
+    }
     if (k <= 32) {     // 32-wide instantiation: 16 KB of LDS per block instead of 64 KB (8 waves per SIMD)
         const size_t smem = (size_t)4 * 32 * 32 * sizeof(T);
         hipLaunchKernelGGL((masked_solve_kernel<T, 32>), dim3((unsigned)nblk), dim3(256), smem, c->stream, cp, ri, vals, mp, mi,

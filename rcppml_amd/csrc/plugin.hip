@@ -520,18 +520,18 @@ void nmf_entry(RCPPML_NMF_UNIFIED_ARGS, const int* mask_p, const int* mask_i, do
             // parameter-free weights; theta / phi (dispersion global or per row) only enter the GP likelihood and the output
             if (*gp_dispersion_mode == 3) throw std::runtime_error("GP / Gamma / inverse-Gaussian / Tweedie loss: dispersion='per_col' not supported");
             if (*gp_dispersion_mode < 0 || *gp_dispersion_mode > 3) throw std::runtime_error("bad dispersion mode");
-            if (*k > 64) throw std::runtime_error("IRLS losses: k must be <= 64");
+            if (*k > 128) throw std::runtime_error("IRLS losses: k must be <= 128");
             if (*solver_mode != 0) throw std::runtime_error("IRLS losses require the CD solver");
             if (mask_p) throw std::runtime_error("IRLS losses with explicit mask: not supported");
         }
         if (*loss_type == 5) {
-            if (*k > 64) throw std::runtime_error("NB loss: k must be <= 64");
+            if (*k > 128) throw std::runtime_error("NB loss: k must be <= 128");
             if (*gp_dispersion_mode == 3) throw std::runtime_error("NB loss: dispersion='per_col' not supported");
             if (*solver_mode != 0) throw std::runtime_error("NB loss requires the CD solver");      // core/config.hpp:447-452
             if (mask_p) throw std::runtime_error("NB loss with explicit mask: not supported");
         }
         if (*robust_delta > 0) {   // Huber on Pearson residuals: every loss (MSE included) goes through the IRLS path
-            if (*k > 64) throw std::runtime_error("robust loss: k must be <= 64");
+            if (*k > 128) throw std::runtime_error("robust loss: k must be <= 128");
             if (*solver_mode != 0) throw std::runtime_error("robust loss requires the CD solver");
             if (mask_p) throw std::runtime_error("robust loss with explicit mask: not supported");
             if (*L21_H != 0 || *L21_W != 0 || *ortho_H != 0 || *ortho_W != 0) throw std::runtime_error("robust loss with L21 / angular: not supported");
@@ -883,7 +883,7 @@ void nmf_cv_entry(RCPPML_NMF_CV_ARGS, int sort_model, int precision, int cv_pati
         if ((*graph_H_nnz > 0 && *graph_H_dim != *n) || (*graph_W_nnz > 0 && *graph_W_dim != *m)) throw std::runtime_error("CV: graph Laplacian dimension mismatch");
         if (*projective != 0 || *symmetric != 0) throw std::runtime_error("CV: projective/symmetric NMF not supported");
         if (*solver_mode != 0 && *solver_mode != 1) throw std::runtime_error("CV: solver_mode must be 0 (CD) or 1 (Cholesky+clip)");
-        if (*k < 1 || *k > 64) throw std::runtime_error("CV: k must be in [1,64]");
+        if (*k < 1 || *k > 128) throw std::runtime_error("CV: k must be in [1,128]");
         if (*m < 1 || *n < 1) throw std::runtime_error("empty matrix");
         if (*norm_type < 0 || *norm_type > 2) throw std::runtime_error("bad norm_type");
         if (!(*holdout_frac > 0 && *holdout_frac < 1)) throw std::runtime_error("CV: holdout fraction must be in (0, 1)");

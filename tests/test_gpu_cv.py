@@ -22,7 +22,7 @@ def _dev(torch, a):
 
 
 @pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-8), (np.float32, 2e-3)])
-@pytest.mark.parametrize("k", [5, 32, 40])
+@pytest.mark.parametrize("k", [5, 32, 40, 72, 128])
 @pytest.mark.parametrize("mask_zeros", [0, 1])
 @pytest.mark.parametrize("solver", [0, 1])
 def test_cv_half_updates(env, dtype, tol, k, mask_zeros, solver):
@@ -51,9 +51,9 @@ def test_cv_half_updates(env, dtype, tol, k, mask_zeros, solver):
 
 @pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-11), (np.float32, 1e-4)])
 @pytest.mark.parametrize("mask_zeros", [0, 1])
-def test_cv_test_error(env, dtype, tol, mask_zeros):
+@pytest.mark.parametrize("k", [7, 100])
+def test_cv_test_error(env, dtype, tol, mask_zeros, k):
     torch, _abi, ctx = env
-    k = 7
     A = lowrank_csc(90, 140, 3, 0.25, seed=3)
     dt = _abi.F32 if dtype == np.float32 else _abi.F64
     rng = np.random.default_rng(5)
@@ -122,6 +122,25 @@ def test_cv_reference_entry_points_and_rejections():
         W, H = W0.copy(), H0.copy()
         r = _abi.nmf_cv(A.p, A.i, A.x, A.rows, A.cols, k, W, H, entry="double", max_iter=2, **kw)
         assert r["status"] == -1 and r["error"], kw
+
+@pytest.mark.parametrize("loss_type", [0, 6])
+def test_cv_fit_through_plugin_at_rank_above_64(loss_type):
+    """The CV entry at k = 80 (MSE: per-column Gram correction; Gamma: per-column weighted Grams) in fp64 vs the oracle."""
+    from rcppml_amd import _abi
+    A = _counts_csc(60, 85, 0.3, seed=6)
+    k = 80
+    rng = np.random.default_rng(2)
+    W0 = rng.uniform(0.2, 1.0, size=(A.rows, k)); H0 = rng.uniform(0.2, 1.0, size=(A.cols, k))
+    kw = dict(max_iter=3, tol=1e-12, solver_mode=0, holdout_fraction=0.15, cv_seed=5, cv_patience=5)
+    ref = O.nmf_fit_cv(A, W0, H0, np.float64, L2=(0.05, 0.05), loss_type=loss_type, irls_max_iter=3, **kw)
+    W, H = W0.copy(), H0.copy()
+    res = _abi.nmf_cv(A.p, A.i, A.x, A.rows, A.cols, k, W, H, entry="irls_ex" if loss_type else "ex", L2_H=0.05, L2_W=0.05, sort_model=0,
+                      precision=_abi.F64, **(dict(loss_type=loss_type, irls_max_iter=3) if loss_type else {}), **kw)
+    assert res["status"] == 0, res.get("error")
+    assert res["iter"] == ref.iter
+    assert np.allclose(res["test_history"], ref.test_history, rtol=1e-6) and np.allclose(res["train_history"], ref.train_history, rtol=1e-6)
+    assert np.abs(W - ref.W_T).max() < 1e-6 * max(1.0, np.abs(ref.W_T).max()) and np.abs(H - ref.H).max() < 1e-6 * max(1.0, np.abs(ref.H).max())
+
 
 
 def test_cv_python_surface():
@@ -211,7 +230,7 @@ def test_cv_irls_half_updates(env, dtype, tol, loss_type, mask_zeros, solver):
     """The per-column weighted-Gram half-update of the IRLS CV path (reference nmf/cv_detail.hpp:101-292) on both sides, both
     solvers, zeros held out or not, with an additive feature term, against the oracle's restatement."""
     torch, _abi, ctx = env
-    k = 6 if loss_type in (4, 5) else 33
+    k = {4: 6, 5: 6, 6: 33, 7: 70, 8: 128}[loss_type]          # 70, 128: the two-features-per-lane kernels (kernels_wide.hip.h)
     A = _counts_csc(70, 90, 0.25, seed=loss_type + 10 * mask_zeros)
     At = A.transpose()
     dt = _abi.F32 if dtype == np.float32 else _abi.F64
@@ -242,7 +261,7 @@ def test_cv_irls_half_updates(env, dtype, tol, loss_type, mask_zeros, solver):
 def test_cv_irls_losses(env, dtype, tol, loss_type, mask_zeros):
     """Per-element train / test losses (reference nmf/fit_cv.hpp:1377-1443): sums and counts vs the oracle."""
     torch, _abi, ctx = env
-    k = 9
+    k = 9 if loss_type != 6 else 90
     A = _counts_csc(80, 120, 0.2, seed=2)
     dt = _abi.F32 if dtype == np.float32 else _abi.F64
     rng = np.random.default_rng(loss_type)

@@ -31,7 +31,7 @@ def _dev(torch, a):
 
 
 @pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-7), (np.float32, 3e-2)])
-@pytest.mark.parametrize("k", [4, 16, 32, 64])
+@pytest.mark.parametrize("k", [4, 16, 32, 64, 80, 128])
 def test_irls_nb_half_updates(env, dtype, tol, k):
     torch, _abi, ctx = env
     A = _nb_problem(150, 220, 4, seed=k)
@@ -57,11 +57,11 @@ def test_irls_nb_half_updates(env, dtype, tol, k):
 
 
 @pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-9), (np.float32, 2e-3)])
-def test_nb_size_and_loss(env, dtype, tol):
+@pytest.mark.parametrize("k", [8, 96])
+def test_nb_size_and_loss(env, dtype, tol, k):
     torch, _abi, ctx = env
     A = _nb_problem(120, 180, 3, seed=5)
     At = A.transpose()
-    k = 8
     rng = np.random.default_rng(1)
     W_T = rng.uniform(size=(A.rows, k)).astype(dtype); W_T /= W_T.sum(axis=0, keepdims=True)
     H = rng.uniform(size=(A.cols, k)).astype(dtype); H /= H.sum(axis=0, keepdims=True)
@@ -107,8 +107,29 @@ def test_nb_fit_through_plugin(dispersion):
     assert np.all(res["theta"] >= 0.01) and np.all(res["theta"] <= 1e6)
 
 
+@pytest.mark.parametrize("loss_type,loss_kw", [(5, {}), (4, dict(gp_dispersion_mode=2)), (6, {})])
+def test_irls_fit_through_plugin_at_ranks_above_64(loss_type, loss_kw):
+    """The 73-pointer entry with an IRLS loss at k = 72 / 128 (BASELINE configs[3]'s rank): half-updates, dispersion updates and
+    likelihoods run on the two-features-per-lane kernels; fp64 against the oracle's fit."""
+    from rcppml_amd import _abi
+    A = _nb_problem(90, 140, 3, seed=4) if loss_type != 6 else _positive_problem(90, 140, seed=4)
+    k = 128 if loss_type == 5 else 72
+    W0, H0 = O.init_factors(3, k, A.rows, A.cols, np.float64)
+    ref = O.nmf_fit(A, W0, H0, np.float64, max_iter=3, tol=0.0, loss_type=loss_type, threads=0,
+                    **({"dispersion_mode": 2} if loss_type != 5 else {}))
+    W, H = W0.copy(), H0.copy()
+    res = _abi.nmf_unified(A.p, A.i, A.x, A.rows, A.cols, k, W, H, entry="double", max_iter=3, tol=0.0, loss_type=loss_type, **loss_kw)
+    assert res["status"] == 0, res.get("error")
+    assert res["iter"] == ref.iter
+    assert abs(res["loss"] - ref.loss) / abs(ref.loss) < 1e-6
+    # (72 factors on a 90 x 140 matrix: the Gamma weights 1 / mu^2 of near-zero predictions leave the factors loosely determined --
+    # the deviance agrees to 1e-6, single factor entries to 1e-3)
+    ftol = 1e-3 if loss_type == 6 else 1e-5
+    assert np.abs(W - ref.W_T).max() < ftol * max(1.0, np.abs(ref.W_T).max()) and np.abs(H - ref.H).max() < ftol * max(1.0, np.abs(ref.H).max())
+
+
 @pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-7), (np.float32, 3e-2)])
-@pytest.mark.parametrize("k", [4, 12, 32, 33])
+@pytest.mark.parametrize("k", [4, 12, 32, 33, 100])
 def test_irls_gp_half_update_and_loss(env, dtype, tol, k):
     """loss = "gp" (LossType 4): half-updates with the KL weight 1/max(mu, 1e-4) (fit_cpu.hpp:568-574) and the GP
     likelihood over the nonzeros (math/loss.hpp:382-398), vs the oracle (whose per-element pieces are pinned to the

@@ -190,10 +190,10 @@ def test_upper_bound_and_norms(abi):
         _compare(res, ref, 1e-6, 1e-6)
 
 
-@pytest.mark.parametrize("k", [8, 40])
+@pytest.mark.parametrize("k", [8, 40, 96])
 def test_explicit_mask(abi, k):
     """Explicit-mask path (reference nmf/masked_nnls.hpp) through the build-defined rcppml_gpu_nmf_ex entry
-    (k = 8: 32-wide kernel instantiation, k = 40: 64-wide)."""
+    (k = 8: 32-wide kernel instantiation, k = 40: 64-wide, k = 96: two features per lane, kernels_wide.hip.h)."""
     A = lowrank_csc(120, 160, 4, 0.15, seed=11)
     M = random_csc(120, 160, 0.05, seed=12)
     W0, H0 = O.init_factors(9, k, A.rows, A.cols, np.float64)
