@@ -1478,6 +1478,7 @@ __global__ __launch_bounds__(256) void cv_solve_kernel(
         for (int it = 0; it < maxit; ++it) {
             int cur = 0;
             bool any = false;
+            const auto x_sweep0 = x;
             while (true) {
                 T diff = sweep_quotient(b, gd, ginv);
                 if (l1 != T(0)) diff -= l1;
@@ -1495,7 +1496,7 @@ __global__ __launch_bounds__(256) void cv_solve_kernel(
                 cur = i + 1;
                 if (cur >= KP) break;
             }
-            if (!any) break;
+            if (!any || !__any(x != x_sweep0)) break;      // no effective step, or the iterate is at its floating-point fixed point
         }
     }
     if (fok) X[j * (int64_t)k + lane] = x;
@@ -1641,6 +1642,7 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8
         for (int it = 0; it < maxit; ++it) {
             int cur = 0;
             bool any = false;
+            const auto x_sweep0 = x;
             while (true) {
                 float diff = b * ginv;
                 if (l1 != 0.f) diff -= l1;
@@ -1658,7 +1660,7 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8
                 cur = i + 1;
                 if (cur >= KP) break;
             }
-            if (!any) break;
+            if (!any || !__any(x != x_sweep0)) break;      // no effective step, or the iterate is at its floating-point fixed point
         }
     }
     if (fok) X[j * (int64_t)k + lane] = x;
@@ -1807,6 +1809,7 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2
         for (int it = 0; it < maxit; ++it) {
             int cur = 0;
             bool any = false;
+            const auto x_sweep0 = x;
             while (true) {
                 float diff = b * ginv;
                 if (l1 != 0.f) diff -= l1;
@@ -1825,7 +1828,7 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2
                 cur = i + 1;
                 if (cur >= KP) break;
             }
-            if (!any) break;
+            if (!any || !__any(x != x_sweep0)) break;      // no effective step, or the iterate is at its floating-point fixed point
         }
     }
     if (fok) X[j * (int64_t)k + lane] = x;
@@ -1971,6 +1974,7 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8
         for (int it = 0; it < maxit; ++it) {
             int cur = 0;
             bool any = false;
+            const auto x_sweep0 = x;
             while (true) {
                 double diff = b / gd;
                 if (l1 != 0.0) diff -= l1;
@@ -1988,7 +1992,7 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8
                 cur = i + 1;
                 if (cur >= KP) break;
             }
-            if (!any) break;
+            if (!any || !__any(x != x_sweep0)) break;      // no effective step, or the iterate is at its floating-point fixed point
         }
     }
     if (fok) X[j * (int64_t)k + lane] = x;

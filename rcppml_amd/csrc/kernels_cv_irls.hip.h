@@ -197,6 +197,7 @@ __global__ __launch_bounds__(256) void cv_irls_solve_kernel(
             for (int sw = 0; sw < maxit; ++sw) {
                 int cur = 0;
                 bool any = false;
+                const auto x_sweep0 = x;
                 while (true) {
                     T diff = sweep_quotient(b, gd, ginv);
                     if (l1 != T(0)) diff -= l1;
@@ -214,7 +215,7 @@ __global__ __launch_bounds__(256) void cv_irls_solve_kernel(
                     cur = i + 1;
                     if (cur >= KP) break;
                 }
-                if (!any) break;
+                if (!any || !__any(x != x_sweep0)) break;      // no effective step, or the iterate is at its floating-point fixed point
             }
         }
         RK_WAVE_SYNC();

@@ -146,6 +146,7 @@ __global__ __launch_bounds__(256) void irls_nb_solve_kernel(
         for (int it = 0; it < cd_maxit; ++it) {
             int cur = 0;
             bool any = false;
+            const auto x_sweep0 = x;
             while (true) {
                 T diff = sweep_quotient(b, gd, ginv);
                 if (l1 != T(0)) diff -= l1;
@@ -163,7 +164,7 @@ __global__ __launch_bounds__(256) void irls_nb_solve_kernel(
                 cur = i + 1;
                 if (cur >= KP) break;
             }
-            if (!any) break;      // a sweep without any effective step: all remaining sweeps are no-ops too
+            if (!any || !__any(x != x_sweep0)) break;      // no effective step, or the iterate is at its floating-point fixed point
         }
         // IRLS convergence: max_i |x_i - x_old_i| / (|x_old_i| + 1e-12) < irls_tol
         T rel = fok ? tabs(x - x_old) / (tabs(x_old) + T(1e-12)) : T(0);
@@ -292,6 +293,7 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8
         for (int it = 0; it < cd_maxit; ++it) {
             int cur = 0;
             bool any = false;
+            const auto x_sweep0 = x;
             while (true) {
                 float diff = b * ginv;
                 if (l1 != 0.f) diff -= l1;
@@ -309,7 +311,7 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8
                 cur = i + 1;
                 if (cur >= KP) break;
             }
-            if (!any) break;      // a sweep without any effective step: all remaining sweeps are no-ops too
+            if (!any || !__any(x != x_sweep0)) break;      // no effective step, or the iterate is at its floating-point fixed point
         }
         float rel = fok ? tabs(x - x_old) / (tabs(x_old) + 1e-12f) : 0.f;
         rel = wave_max(rel);
@@ -449,6 +451,7 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2
         for (int it = 0; it < cd_maxit; ++it) {
             int cur = 0;
             bool any = false;
+            const auto x_sweep0 = x;
             while (true) {
                 float diff = b * ginv;
                 if (l1 != 0.f) diff -= l1;
@@ -467,7 +470,7 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2
                 cur = i + 1;
                 if (cur >= KP) break;
             }
-            if (!any) break;
+            if (!any || !__any(x != x_sweep0)) break;      // no effective step, or the iterate is at its floating-point fixed point
         }
         float rel = fok ? tabs(x - x_old) / (tabs(x_old) + 1e-12f) : 0.f;
         rel = wave_max(rel);
@@ -597,6 +600,7 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8
         for (int it = 0; it < cd_maxit; ++it) {
             int cur = 0;
             bool any = false;
+            const auto x_sweep0 = x;
             while (true) {
                 double diff = b / gd;
                 if (l1 != 0.0) diff -= l1;
@@ -614,7 +618,7 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8
                 cur = i + 1;
                 if (cur >= KP) break;
             }
-            if (!any) break;
+            if (!any || !__any(x != x_sweep0)) break;      // no effective step, or the iterate is at its floating-point fixed point
         }
         double rel = fok ? tabs(x - x_old) / (tabs(x_old) + 1e-12) : 0.0;
         rel = wave_max(rel);

@@ -108,6 +108,7 @@ template <class T> struct WideCol {
         for (int it = 0; it < maxit; ++it) {
             T tol_sum = T(0);
             bool any = false;
+            const T xs0 = x[0], xs1 = x[1];
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 if (64 * s >= k) break;
@@ -134,7 +135,7 @@ template <class T> struct WideCol {
                 }
             }
             if (check) { if (tol_sum * inv_k < tol) break; }
-            else if (!any) break;
+            else if (!any || !__any(x[0] != xs0 || x[1] != xs1)) break;   // no step, or the iterate is at its floating-point fixed point
         }
     }
     // in-LDS Cholesky (left-looking) of the leading k x k block, forward / back substitution, clip: x = max(G^-1 b, 0)

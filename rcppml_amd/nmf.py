@@ -145,8 +145,8 @@ def nmf(data, k, tol=1e-4, maxit=100, L1=(0.0, 0.0), L2=(0.0, 0.0), seed=None, m
         if Lg.shape != (dim, dim):
             raise ValueError("%s must be %d x %d" % (name, dim, dim))
         graph_args[name] = (Lg.p, Lg.i, Lg.x, float(lam))
-    if graph_args and (loss != "mse" or robust_delta > 0 or (mask is not None and not isinstance(mask, str)) or k > 64):
-        raise NotImplementedError("graph regularisation is implemented for the plain MSE path, k <= 64")
+    if graph_args and (loss != "mse" or robust_delta > 0 or (mask is not None and not isinstance(mask, str)) or k > 128):
+        raise NotImplementedError("graph regularisation is implemented for the plain MSE path, k <= 128")
     # ---- initialisation
     if seed is None:
         seed_int = int(np.random.SeedSequence().generate_state(1)[0] % (2 ** 31 - 1)) + 1
