@@ -58,8 +58,8 @@ RCPPML_GPU_API void rcppml_gpu_detect(int* num_gpus, double* total_mem_mb, doubl
  * Laplacians, upper bounds, nonneg, projective and symmetric NMF (MSE path); CD and Cholesky+clip;
  * env RCPPML_GPU_DEVICES=n shards plain MSE fits over n devices (plugin_multi.hip).  Not implemented
  * -- REJECTED with *out_status = -1 so the caller falls back to CPU rather than silently dropping
- * them: classifier guides, dispersion = per_col, zero-inflated losses, k > 256 (k > 64 for IRLS losses
- * and explicit masks, k > 128 for angular and graph penalties).  Target regularisation has no slot in these 73 arguments: see
+ * them: classifier guides, dispersion = per_col, zero-inflated losses, k > 256 (k > 128 for IRLS losses,
+ * explicit masks, angular and graph penalties).  Target regularisation has no slot in these 73 arguments: see
  * rcppml_gpu_nmf_target below. */
 #define RCPPML_NMF_UNIFIED_ARGS                                                                    \
     const int* col_ptr, const int* row_idx, const double* values, int* m, int* n, int* nnz, int* k, \
@@ -107,8 +107,10 @@ RCPPML_GPU_API void rcppml_gpu_nmf_zerocopy_double(double* d_col_ptr_addr, doubl
 
 /* Cross-validation NMF.  Replaces reference `rcppml_gpu_nmf_cv_unified_float` (type
  * inst/include/FactorNet/gpu/bridge_nmf.hpp:77-99, resolved and called at :407-497 by bridge_nmf_cv_sparse): 51 pointer
- * arguments, W (k x m) and H (k x n) are initialised by the caller, d = 1.  Implemented: MSE loss, CD and Cholesky+clip,
- * L1 / L2, both mask_zeros settings, k <= 64; anything else sets out_status = -1 (CPU fallback).  The held-out set is
+ * arguments, W (k x m) and H (k x n) are initialised by the caller, d = 1.  Implemented: MSE loss and loss_type 4..8 (GP, NB,
+ * Gamma, inverse Gaussian, Tweedie: per-column weighted Grams, nmf/fit_cv.hpp:446-456, 670-689; dispersion settings = the
+ * reference's config defaults, the boundary has no slot for them -- rcppml_gpu_nmf_cv_irls_ex below carries them), CD and
+ * Cholesky+clip, L1 / L2, both mask_zeros settings, k <= 128; anything else sets out_status = -1 (CPU fallback).  The held-out set is
  * the speckled mask of rcppml_hip_solve_cv with cv_seed, or seed when cv_seed = 0 (core/config.hpp:415-418).  Early
  * stopping: cv_patience = NMF_PATIENCE = 5 (not transmitted by the bridge; RCPPML_GPU_CV_PATIENCE overrides).  On
  * return H carries d and d is returned too (nmf/fit_cv.hpp:1636-1647). */
@@ -369,7 +371,7 @@ RCPPML_GPU_API int rcppml_hip_loss_nonzeros(rcppml_hip_ctx* ctx, int dtype, cons
  *   W; nrows = its row count): b = sum over the column's TRAIN nonzeros, G_local = G - sum over its TEST rows f f^T
  *   (mask_zeros = 1: held-out nonzeros only; 0: every held-out row, zeros included), then Cholesky+clip (solver_mode 1,
  *   L1 subtracted from b) or CD (solver_mode 0: L1 inside, cd_maxit sweeps, no tolerance) started from the current X
- *   without a warm-start correction -- fit_cv.hpp:420-478,591-830.  k <= 64.
+ *   without a warm-start correction -- fit_cv.hpp:420-478,591-830.  k <= 128 (above 64: kernels_wide.hip.h).
  * rcppml_hip_cv_test_error: out2[0] = sum of squared errors, out2[1] = count over the held-out entries of A
  *   (prediction W diag(d) H; fit_cv.hpp:1444-1494). */
 RCPPML_GPU_API int rcppml_hip_solve_cv(rcppml_hip_ctx* ctx, int dtype, const int* col_ptr, const int* row_idx,
@@ -384,7 +386,7 @@ RCPPML_GPU_API int rcppml_hip_cv_test_error(rcppml_hip_ctx* ctx, int dtype, cons
 /* Graph (Laplacian) regularisation -- reference features/graph_reg.hpp:38-50 at its fused-path place
  * (nmf/fit_cpu.hpp:508-509,741-742):  G += lambda * (X L) X^T  for the CURRENT factor X (k x ncols) and a sparse
  * ncols x ncols Laplacian L in CSC (device).  X L is formed by the SpMM kernel, the k x k product by a blocked reduction
- * with a fixed summation order.  k <= 64. */
+ * with a fixed summation order.  k <= 128. */
 RCPPML_GPU_API int rcppml_hip_apply_graph_reg(rcppml_hip_ctx* ctx, int dtype, void* G, const int* lap_p, const int* lap_i,
                                               const void* lap_x, const void* X, int k, int64_t ncols, double lambda);
 
@@ -403,7 +405,7 @@ RCPPML_GPU_API int rcppml_hip_clip_upper(rcppml_hip_ctx* ctx, int dtype, void* X
  * rcppml_hip_apply_l21: G(i,i) += lambda / ||X.row(i)||_2 for rows with norm > 1e-10 (features/L21.hpp:38-51); X is the
  *   CURRENT factor (k x ncols), applied to the Gram before the solve.
  * rcppml_hip_angular_posthoc: X <- max(0, X - lambda * diag(norms) * offdiag(Xh Xh^T) Xh), Xh = rows of X scaled to unit
- *   norm (features/angular.hpp:67-103); applied after the solve and the upper bound, before scaling.  k <= 64. */
+ *   norm (features/angular.hpp:67-103); applied after the solve and the upper bound, before scaling.  k <= 128. */
 RCPPML_GPU_API int rcppml_hip_apply_l21(rcppml_hip_ctx* ctx, int dtype, void* G, const void* X, int k, int64_t ncols,
                                         double lambda);
 RCPPML_GPU_API int rcppml_hip_angular_posthoc(rcppml_hip_ctx* ctx, int dtype, void* X, int k, int64_t ncols, double lambda);
@@ -414,7 +416,8 @@ RCPPML_GPU_API int rcppml_hip_angular_posthoc(rcppml_hip_ctx* ctx, int dtype, vo
  *   (+ l2 on the diagonal), b_w = F_nz (w o a), b = b_w - G_w x, CD(G_w, b, x, L1 inside, cd_maxit sweeps, no tolerance),
  *   stop when max |dx|/(|x_old|+1e-12) < irls_tol.
  * theta_row: NB size indexed by the nonzero's row (H side) or theta_col: indexed by the column (W side over A^T);
- * exactly one is non-NULL.  k <= 64. */
+ * exactly one is non-NULL.  k <= 128 (above 64: one wave per column with two features per lane, kernels_wide.hip.h).
+ * The tolerance-free sweeps end early at the iterate's floating-point fixed point (a whole sweep that changes no coordinate). */
 RCPPML_GPU_API int rcppml_hip_solve_irls_nb(rcppml_hip_ctx* ctx, int dtype, const int* col_ptr, const int* row_idx,
                                             const void* values, int64_t ncols, const void* F, const void* G_base,
                                             void* X, int k, double l1, double l2, int nonneg, int cd_maxit,
@@ -486,7 +489,7 @@ RCPPML_GPU_API int rcppml_hip_nb_loss(rcppml_hip_ctx* ctx, int dtype, const int*
  * every row that is not held out, zeros included (0).  The weight is the reference's compute_irls_weight(residual, predicted,
  * loss) with its DEFAULT observed = 0 and theta = 0: NB / Gamma / inverse Gaussian / Tweedie distribution weights at theta 0,
  * GP = irls_weight_gp(0, mu, 0, blend 1) (math/loss.hpp:197-229; not the KL weight of the non-CV fit), times the Huber
- * modifier when robust_delta > 0.  G_add (k x k, may be NULL): the additive CV features (L2, graph, L21).  k <= 64. */
+ * modifier when robust_delta > 0.  G_add (k x k, may be NULL): the additive CV features (L2, graph, L21).  k <= 128. */
 RCPPML_GPU_API int rcppml_hip_solve_cv_irls(rcppml_hip_ctx* ctx, int dtype, int loss_type, const int* col_ptr, const int* row_idx,
                                             const void* values, int64_t ncols, int nrows, const void* F, const void* G_add, void* X,
                                             int k, double holdout_fraction, unsigned long long cv_seed, int mask_zeros,
