@@ -565,6 +565,66 @@ __global__ __launch_bounds__(256) void rhs_tiled_spill_kernel(const int* __restr
     for (int v = 0; v < NV; ++v) *reinterpret_cast<V*>(dst + 64 * v * 4 / (int)sizeof(T)) = acc[v];
 }
 
+// ---------------------------------------------------------------------------
+// The tail columns (those beyond the last whole workgroup of the tiled kernel: 1 696 of C2's 100 000): a whole 256-thread
+// workgroup per column, sixteen 16-lane groups each gathering every sixteenth nonzero's row of F (a whole row per gather,
+// U in flight), partial rows summed through LDS in group order (fixed -> deterministic).  One wave per column, as the generic
+// gather kernel runs them, makes these few columns a 16 us latency chain of ~200 dependent gathers.
+// ---------------------------------------------------------------------------
+template <class T, int NV, int U>
+__global__ __launch_bounds__(256) void rhs_tail_kernel(const int* __restrict__ colptr, const int* __restrict__ rowidx,
+                                                       const T* __restrict__ vals, int64_t col0, int64_t ncols,
+                                                       const T* __restrict__ F, int k, T* __restrict__ B) {
+    typedef typename RtVec<T>::type V;
+    constexpr int VN = RtVec<T>::N;
+    __shared__ V part[16][16 * NV];
+    const int64_t j = col0 + blockIdx.x;
+    if (j >= ncols) return;
+    const int g = threadIdx.x >> 4, u = threadIdx.x & 15;
+    const int start = colptr[j], end = colptr[j + 1];
+    V acc[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+#pragma unroll
+        for (int e = 0; e < VN; ++e) acc[v][e] = T(0);
+    const T* Fl = F + (4 * u) * 4 / (int)sizeof(T);
+    for (int i = start + g; i < end; i += 16 * U) {
+        int r[U];
+        T a[U];
+#pragma unroll
+        for (int x = 0; x < U; ++x) {
+            const int ii = i + 16 * x;
+            const bool ok = ii < end;
+            r[x] = rowidx[ok ? ii : end - 1];
+            a[x] = ok ? vals[ii] : T(0);
+        }
+        V f[U][NV];
+#pragma unroll
+        for (int x = 0; x < U; ++x)
+#pragma unroll
+            for (int v = 0; v < NV; ++v) f[x][v] = *reinterpret_cast<const V*>(Fl + (int64_t)r[x] * k + 64 * v * 4 / (int)sizeof(T));
+#pragma unroll
+        for (int x = 0; x < U; ++x)
+#pragma unroll
+            for (int v = 0; v < NV; ++v)
+#pragma unroll
+                for (int e = 0; e < VN; ++e) acc[v][e] = rt_fma(a[x], f[x][v][e], acc[v][e]);
+    }
+#pragma unroll
+    for (int v = 0; v < NV; ++v) part[g][16 * v + u] = acc[v];
+    __syncthreads();
+    if (g == 0) {
+        T* dst = B + j * k + (4 * u) * 4 / (int)sizeof(T);
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            V s = part[0][16 * v + u];
+#pragma unroll
+            for (int q = 1; q < 16; ++q) s += part[q][16 * v + u];
+            *reinterpret_cast<V*>(dst + 64 * v * 4 / (int)sizeof(T)) = s;
+        }
+    }
+}
+
 // B (+)= sum_p Bp[p], partition order (deterministic)
 template <class T>
 __global__ __launch_bounds__(256) void rhs_tiled_reduce_kernel(const T* __restrict__ Bp, int P, int64_t n4, int accumulate,

@@ -28,9 +28,18 @@ void run_plan(rcppml_hip_ctx* c, const rcppml_rhs_plan* pl, const T* F, T* B) {
     const RhsTiledGeom& G = pl->G;
     const bool ov = pl->ovnnz > 0;
     const int64_t nt = G.ncols_tiled;
-    if (nt < G.ncols) {          // tail columns (those that do not fill a whole round of workgroups): gather kernel
-        if (rcppml_hip_rhs(c, pl->dtype, pl->colptr + nt, pl->rowidx, pl->vals, G.ncols - nt, F, pl->k, B + nt * pl->k) != 0)
-            throw std::runtime_error("rhs_planned: tail columns: " + rcppml_err());
+    if (nt < G.ncols) {          // tail columns (those that do not fill a whole round of workgroups): a workgroup per column
+        const unsigned grid = (unsigned)(G.ncols - nt);
+        if (G.rowb == 256)
+            hipLaunchKernelGGL((rhs_tail_kernel<T, 1, 4>), dim3(grid), dim3(256), 0, c->stream, pl->colptr, pl->rowidx, (const T*)pl->vals,
+                               nt, G.ncols, F, pl->k, B);
+        else if (G.rowb == 1024)
+            hipLaunchKernelGGL((rhs_tail_kernel<T, 4, 2>), dim3(grid), dim3(256), 0, c->stream, pl->colptr, pl->rowidx, (const T*)pl->vals,
+                               nt, G.ncols, F, pl->k, B);
+        else
+            hipLaunchKernelGGL((rhs_tail_kernel<T, 2, 2>), dim3(grid), dim3(256), 0, c->stream, pl->colptr, pl->rowidx, (const T*)pl->vals,
+                               nt, G.ncols, F, pl->k, B);
+        HIPCHK(hipGetLastError());
     }
     if (ov) {          // the spilled nonzeros first: their sums seed the accumulators
         const unsigned grid = (unsigned)((nt + 15) / 16);
