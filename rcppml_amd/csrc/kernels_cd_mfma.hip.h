@@ -33,30 +33,10 @@ namespace rk {
 // Gq[((i/2)*RT + rt)*64 + (i&1)*32 + r'] = -G(lrow, i), lrow = 32*rt + 2*v + h, h = (r'>>2)&1, v = (r'&3) + 4*(r'>>3).
 // tab[c] (c = coordinate; pair i = c & ~1 is served by lane half h = c & 1) = { 1/G(c,c) (0 if G(c,c) <= 0),
 //   coupling inside the pair: h ? G(i+1, i) : 0 }.
-// Reads the k x k Gram directly; the identity padding to KP and 1/G_ii (pad_gram's job for the other variants) are formed
-// on the fly -- one kernel boundary less per solve.
-static __global__ void cd_mfma_prep_kernel(const float* __restrict__ G, int k, int KP,
-                                           float* __restrict__ Gq, float2* __restrict__ tab) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= KP * KP) return;
-    auto gp = [&](int col, int row) { return (row < k && col < k) ? G[(int64_t)col * k + row] : (row == col ? 1.f : 0.f); };
-    const int i = e / KP, p = e % KP;
-    const int rt = p >> 5, r = p & 31;
-    const int h = (r >> 2) & 1, v = (r & 3) + 4 * (r >> 3);
-    const int lrow = 32 * rt + 2 * v + h;
-    // pair-major layout: 64 consecutive floats = one MFMA A operand (both halves of a wave) of pair i/2 and row
-    // tile rt, so every LDS read of the sweep is  <one base register> + <compile-time multiple of 256 bytes>
-    Gq[(((i >> 1) * (KP >> 5) + rt) << 6) + ((i & 1) << 5) + r] = -gp(i, lrow);
-    if (p == 0) {
-        // the high half (odd coordinate) reads its Gauss-Seidel coupling, the low half reads 0, so ONE evaluation
-        // of the second step serves both halves
-        float2 t;
-        const float gd = gp(i, i);
-        t.x = gd > 0.f ? 1.f / gd : 0.f;
-        t.y = (i & 1) ? gp(i - 1, i) : 0.f;
-        tab[i] = t;
-    }
-}
+// Formed by every workgroup of cd_mfma_kernel from the k x k Gram while it fills its LDS (identity padding to KP and 1/G_ii on the
+// fly): pair-major layout -- 64 consecutive floats = one MFMA A operand (both halves of a wave) of pair i/2 and row tile rt, so
+// every LDS read of the sweep is  <one base register> + <compile-time multiple of 256 bytes>; the high half (odd coordinate)
+// reads its Gauss-Seidel coupling from tab, the low half reads 0, so ONE evaluation of the second step serves both halves.
 
 struct CdStepOut { float a, nx; };
 
@@ -94,7 +74,7 @@ __device__ __forceinline__ CdStepOut cd_scalar_step(float b, float xo, float gin
 }
 
 template <int RT, int CT, bool SIMPLE>   // KP = 32*RT rows (k <= KP), 32*CT columns per wave, 4 waves per block share G
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((CT == 1 && RT <= 2) ? 4 : 2, 8))) void cd_mfma_kernel(const float* __restrict__ Gq, const float2* __restrict__ tab,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((CT == 1 && RT <= 2) ? 4 : 2, 8))) void cd_mfma_kernel(const float* __restrict__ G /* k x k, as rcppml_hip_gram wrote it */,
                                                        const float* __restrict__ B,
                                                        float* __restrict__ X, int k, int64_t ncols, float l1_pre,
                                                        int warm, int zero_init, float l1_cd, float l2_cd, int nonneg,
@@ -103,10 +83,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((CT == 1 &&
                                                        unsigned long long* __restrict__ stats) {
     constexpr int KP = 32 * RT;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    float* Gs = reinterpret_cast<float*>(smem_raw);      // KP*KP, pair-major (see cd_mfma_prep_kernel)
+    float* Gs = reinterpret_cast<float*>(smem_raw);      // KP*KP, pair-major (layout comment above)
     float2* tab_s = reinterpret_cast<float2*>(Gs + KP * KP);   // KP x {1/G_cc, pair coupling}
-    for (int e = threadIdx.x; e < KP * KP; e += blockDim.x) Gs[e] = Gq[e];
-    for (int e = threadIdx.x; e < KP; e += blockDim.x) tab_s[e] = tab[e];
+    // The permuted operand image and the per-coordinate table are formed HERE from the k x k Gram (until round 3 a launch of its own: every workgroup reads the same 4 k^2 bytes either way, and the solve is two launches shorter per
+    // iteration).  LDS element e <-> (pair, row tile, half, r): the layout comment above.
+    {
+        auto gp = [&](int col, int row) { return (row < k && col < k) ? G[(int64_t)col * k + row] : (row == col ? 1.f : 0.f); };
+        for (int e = threadIdx.x; e < KP * KP; e += blockDim.x) {
+            const int pr = e >> 6, w6 = e & 63;
+            const int i = 2 * (pr / RT) + (w6 >> 5), rt = pr % RT, r = w6 & 31;
+            const int h = (r >> 2) & 1, v = (r & 3) + 4 * (r >> 3);
+            Gs[e] = -gp(i, 32 * rt + 2 * v + h);
+        }
+        for (int i = threadIdx.x; i < KP; i += blockDim.x) {
+            float2 t;
+            const float gd = gp(i, i);
+            t.x = gd > 0.f ? 1.f / gd : 0.f;
+            t.y = (i & 1) ? gp(i - 1, i) : 0.f;
+            tab_s[i] = t;
+        }
+    }
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int half = lane >> 5, cl = lane & 31;

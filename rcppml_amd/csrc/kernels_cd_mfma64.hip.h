@@ -33,32 +33,6 @@ namespace rk {
 template <class T> struct Vec4T;
 template <> struct Vec4T<float> { typedef float4 type; };
 template <> struct Vec4T<double> { typedef double4 type; };
-template <class T>
-static __global__ void cd_mfma64_prep_kernel(const T* __restrict__ G, int k, int KP,
-                                             T* __restrict__ Gq, typename Vec4T<T>::type* __restrict__ tab) {
-    constexpr bool PERM = sizeof(T) == 4;
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= KP * KP) return;
-    // the k x k Gram is read directly: identity padding to KP and 1/G_cc formed here (no pad_gram launch in front)
-    auto gp = [&](int col, int row) { return (row < k && col < k) ? G[(int64_t)col * k + row] : (row == col ? T(1) : T(0)); };
-    const int i = e / KP, r = e % KP;
-    const int NT = KP >> 4;
-    const int q = i >> 2, kk = i & 3, t = r >> 4, rl = r & 15;
-    // physical row slot of logical row rl inside its tile
-    const int ps = PERM ? 4 * (rl & 3) + (rl >> 2) : rl;
-    Gq[((q * NT + t) << 6) + (kk << 4) + ps] = -gp(i, r);
-    if (r == 0) {
-        const int c = i, g = c & 3, qb = c & ~3;
-        typename Vec4T<T>::type v;
-        const T gd = gp(c, c);
-        v.x = gd > T(0) ? T(1) / gd : T(0);
-        v.y = g > 0 ? gp(qb + 0, c) : T(0);
-        v.z = g > 1 ? gp(qb + 1, c) : T(0);
-        v.w = g > 2 ? gp(qb + 2, c) : T(0);
-        tab[c] = v;
-    }
-}
-
 // Row-group broadcasts.  v_permlane16_swap_b32 vdst, src: vdst rows 1,3 <-> src rows 0,2 (16-lane rows);
 // v_permlane32_swap_b32 vdst, src: vdst rows 2,3 <-> src rows 0,1; with vdst == src the exchange is in place
 // (probed on gfx950: tools/probe/permlane_probe.hip).  Only the groups BEHIND row P need the value; the others may
@@ -130,7 +104,7 @@ __device__ __forceinline__ double fast_recip(double den) {
 
 template <class T, int NT, bool SIMPLE>   // KP = 16*NT rows (k <= KP), 16 columns per wave, 4 waves per block share G
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NT <= 2 ? 4 : (NT <= 4 ? 2 : 1), 8)))
-void cd_mfma64_kernel(const T* __restrict__ Gq, const typename Vec4T<T>::type* __restrict__ tab, const T* __restrict__ B,
+void cd_mfma64_kernel(const T* __restrict__ G /* k x k, as rcppml_hip_gram wrote it */, const T* __restrict__ B,
                       T* __restrict__ X, int k, int64_t ncols, T l1_pre, int warm, int zero_init, T l1_cd,
                       T l2_cd, int nonneg, int maxit, T tol, T ub_cd, T ub_post,
                       int* __restrict__ sweeps, const int* __restrict__ order, unsigned long long* __restrict__ stats) {
@@ -138,10 +112,29 @@ void cd_mfma64_kernel(const T* __restrict__ Gq, const typename Vec4T<T>::type* _
     typedef typename Acc4T<T>::type Acc4;
     constexpr int KP = 16 * NT;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    T* Gs = reinterpret_cast<T*>(smem_raw);               // KP*KP, quad-major (see cd_mfma64_prep_kernel)
+    T* Gs = reinterpret_cast<T*>(smem_raw);               // KP*KP, quad-major (layout comment above)
     Tab4* tab_s = reinterpret_cast<Tab4*>(Gs + KP * KP);     // KP x {1/G_cc, 3 in-quad couplings}
-    for (int e = threadIdx.x; e < KP * KP; e += blockDim.x) Gs[e] = Gq[e];
-    for (int e = threadIdx.x; e < KP; e += blockDim.x) tab_s[e] = tab[e];
+    // operand image and per-coordinate table formed here from the k x k Gram (layout comment above; until round 3 a launch of its own)
+    {
+        constexpr bool PERM = sizeof(T) == 4;
+        auto gp = [&](int col, int row) { return (row < k && col < k) ? G[(int64_t)col * k + row] : (row == col ? T(1) : T(0)); };
+        for (int e = threadIdx.x; e < KP * KP; e += blockDim.x) {
+            const int qt = e >> 6, kk = (e >> 4) & 3, ps = e & 15;
+            const int q = qt / NT, t = qt % NT;
+            const int rl = PERM ? (ps >> 2) + 4 * (ps & 3) : ps;          // inverse of ps = 4 (rl & 3) + (rl >> 2)
+            Gs[e] = -gp(4 * q + kk, 16 * t + rl);
+        }
+        for (int c = threadIdx.x; c < KP; c += blockDim.x) {
+            const int gg = c & 3, qb = c & ~3;
+            Tab4 v;
+            const T gd = gp(c, c);
+            v.x = gd > T(0) ? T(1) / gd : T(0);
+            v.y = gg > 0 ? gp(qb + 0, c) : T(0);
+            v.z = gg > 1 ? gp(qb + 1, c) : T(0);
+            v.w = gg > 2 ? gp(qb + 2, c) : T(0);
+            tab_s[c] = v;
+        }
+    }
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int g = lane >> 4, cl = lane & 15;

@@ -63,10 +63,6 @@ static void cd_mfma_launch(rcppml_hip_ctx* c, const float* G, const float* /*unu
                            int64_t ncols, float l1_pre, int warm, int zero_init, float l1_cd, float l2_cd, int nonneg,
                            int maxit, float tol, float ub_cd, float ub_post, int* sweeps, const int* order) {
     constexpr int KP = 32 * RT;
-    float* Gq = static_cast<float*>(c->scratch(WS_MFMA, ((size_t)KP * KP + 2 * KP) * sizeof(float)));
-    float2* tab = reinterpret_cast<float2*>(Gq + (size_t)KP * KP);
-    hipLaunchKernelGGL(cd_mfma_prep_kernel, dim3((KP * KP + 255) / 256), dim3(256), 0, c->stream, G, k, KP, Gq, tab);
-    HIPCHK(hipGetLastError());
     size_t smem = ((size_t)KP * KP + 2 * KP) * sizeof(float);
     const int64_t per_block = 4 * 32 * CT;          // 4 waves per block
     const int64_t nblk = (ncols + per_block - 1) / per_block;
@@ -91,10 +87,10 @@ static void cd_mfma_launch(rcppml_hip_ctx* c, const float* G, const float* /*unu
     if (simple) once_simple.ensure(reinterpret_cast<const void*>(&cd_mfma_kernel<RT, CT, true>), smem, c->device);
     else once_general.ensure(reinterpret_cast<const void*>(&cd_mfma_kernel<RT, CT, false>), smem, c->device);
     if (simple)
-        hipLaunchKernelGGL((cd_mfma_kernel<RT, CT, true>), dim3((unsigned)nblk), dim3(256), smem, c->stream, Gq, tab, B, X,
+        hipLaunchKernelGGL((cd_mfma_kernel<RT, CT, true>), dim3((unsigned)nblk), dim3(256), smem, c->stream, G, B, X,
                            k, ncols, l1_pre, warm, zero_init, l1_cd, l2_cd, nonneg, maxit, tol, ub_cd, ub_post, sweeps, order, c->stats);
     else
-        hipLaunchKernelGGL((cd_mfma_kernel<RT, CT, false>), dim3((unsigned)nblk), dim3(256), smem, c->stream, Gq, tab, B, X,
+        hipLaunchKernelGGL((cd_mfma_kernel<RT, CT, false>), dim3((unsigned)nblk), dim3(256), smem, c->stream, G, B, X,
                            k, ncols, l1_pre, warm, zero_init, l1_cd, l2_cd, nonneg, maxit, tol, ub_cd, ub_post, sweeps, order, c->stats);
     HIPCHK(hipGetLastError());
 }
@@ -110,11 +106,6 @@ static void cd_mfma64_launch(rcppml_hip_ctx* c, const T* G, const T* /*unused*/,
                              int64_t ncols, T l1_pre, int warm, int zero_init, T l1_cd, T l2_cd, int nonneg,
                              int maxit, T tol, T ub_cd, T ub_post, int* sweeps, const int* order) {
     constexpr int KP = 16 * NT;
-    typedef typename Vec4T<T>::type Tab4;
-    T* Gq = static_cast<T*>(c->scratch(WS_MFMA, ((size_t)KP * KP + 4 * KP) * sizeof(T)));
-    Tab4* tab = reinterpret_cast<Tab4*>(Gq + (size_t)KP * KP);
-    hipLaunchKernelGGL(cd_mfma64_prep_kernel<T>, dim3((KP * KP + 255) / 256), dim3(256), 0, c->stream, G, k, KP, Gq, tab);
-    HIPCHK(hipGetLastError());
     const size_t smem = ((size_t)KP * KP + 4 * KP) * sizeof(T);
     const int64_t nblk = (ncols + 63) / 64;          // 4 waves x 16 columns per block
     const bool simple = nonneg && ub_cd <= T(0) && l1_cd == T(0) && l2_cd == T(0);
@@ -122,10 +113,10 @@ static void cd_mfma64_launch(rcppml_hip_ctx* c, const T* G, const T* /*unused*/,
     if (simple) once_simple.ensure(reinterpret_cast<const void*>(&cd_mfma64_kernel<T, NT, true>), smem, c->device);
     else once_general.ensure(reinterpret_cast<const void*>(&cd_mfma64_kernel<T, NT, false>), smem, c->device);
     if (simple)
-        hipLaunchKernelGGL((cd_mfma64_kernel<T, NT, true>), dim3((unsigned)nblk), dim3(256), smem, c->stream, Gq, tab, B, X, k,
+        hipLaunchKernelGGL((cd_mfma64_kernel<T, NT, true>), dim3((unsigned)nblk), dim3(256), smem, c->stream, G, B, X, k,
                            ncols, l1_pre, warm, zero_init, l1_cd, l2_cd, nonneg, maxit, tol, ub_cd, ub_post, sweeps, order, c->stats);
     else
-        hipLaunchKernelGGL((cd_mfma64_kernel<T, NT, false>), dim3((unsigned)nblk), dim3(256), smem, c->stream, Gq, tab, B, X, k,
+        hipLaunchKernelGGL((cd_mfma64_kernel<T, NT, false>), dim3((unsigned)nblk), dim3(256), smem, c->stream, G, B, X, k,
                            ncols, l1_pre, warm, zero_init, l1_cd, l2_cd, nonneg, maxit, tol, ub_cd, ub_post, sweeps, order, c->stats);
     HIPCHK(hipGetLastError());
 }
