@@ -2293,14 +2293,26 @@ static __global__ __launch_bounds__(256) void order_scatter_kernel(const int* __
                                                                      const unsigned int* __restrict__ part /*gridDim.x x 128*/,
                                                                      int* __restrict__ order) {
     __shared__ unsigned int cnt[128], base[128], half_total;
-    // bin totals over all blocks, and the part of them that lies in blocks before this one
-    if (threadIdx.x < 128) {
+    __shared__ unsigned int tsum[2][128], bsum[2][128];
+    // bin totals over all blocks, and the part of them that lies in blocks before this one: thread (h, x) sums every
+    // second row of the table for bin x -- gridDim.x / 2 independent coalesced loads per thread instead of gridDim.x
+    // dependent-looking ones in half of the threads
+    {
+        const unsigned int x = threadIdx.x & 127u, h = threadIdx.x >> 7;
         unsigned int tot = 0, before = 0;
-        for (unsigned int b = 0; b < gridDim.x; ++b) {
-            const unsigned int c = part[(size_t)b * 128 + threadIdx.x];
-            if (b < blockIdx.x) before += c;
+#pragma unroll 8
+        for (unsigned int b = h; b < gridDim.x; b += 2) {
+            const unsigned int c = part[(size_t)b * 128 + x];
+            before += b < blockIdx.x ? c : 0u;
             tot += c;
         }
+        tsum[h][x] = tot;
+        bsum[h][x] = before;
+    }
+    __syncthreads();
+    if (threadIdx.x < 128) {
+        const unsigned int tot = tsum[0][threadIdx.x] + tsum[1][threadIdx.x];
+        const unsigned int before = bsum[0][threadIdx.x] + bsum[1][threadIdx.x];
         // exclusive scan of the totals over the 128 bins (two waves, shuffle scan)
         unsigned int incl = tot;
 #pragma unroll
