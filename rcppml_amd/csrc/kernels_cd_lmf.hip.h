@@ -98,8 +98,12 @@ __global__ __launch_bounds__(256) void cd_lmf_kernel(const float2* __restrict__ 
     const int64_t NW = (int64_t)gridDim.x * (blockDim.x >> 6);
     const int64_t wid = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave;
     // position of this wave's column of band b in the work order; -1 behind the end
+    // When the launch holds a slot for every column (no refill can happen) a wave takes CW CONSECUTIVE positions of the work
+    // order instead -- columns of similar sweep counts, as the tile kernels do: with the interleaved bands every wave would hold
+    // one of the longest columns and run to its end with most lanes idle.
+    const bool tile_mode = NW * CW >= ncols;
     auto column_of_band = [&](int64_t band) -> int64_t {
-        const int64_t t = band * NW + ((band & 1) ? NW - 1 - wid : wid);
+        const int64_t t = tile_mode ? (band < CW ? wid * CW + band : ncols) : band * NW + ((band & 1) ? NW - 1 - wid : wid);
         return t < ncols ? (order ? (int64_t)order[t] : t) : -1;
     };
     const bool vec_ok = LG == 1 && (k & 3) == 0 && ((reinterpret_cast<uintptr_t>(B) | reinterpret_cast<uintptr_t>(X)) & 15) == 0;

@@ -40,6 +40,12 @@ namespace rk {
 
 struct CdStepOut { float a, nx; };
 
+// max(a, b) as v_med3_f32(a, b, +inf): llvm.maxnum on a loop-carried operand costs a canonicalising v_max(b, b) in front of
+// the real one (IEEE mode: the instruction must not see a signalling NaN); the target intrinsic does not.  Same value for
+// every non-NaN input.  `inf` must be a RUN-TIME +infinity (the kernels' `hi` when there is no upper bound): with a literal
+// LLVM folds the median back into maxnum.
+__device__ __forceinline__ float cd_max_nc(float a, float b, float inf) { return __builtin_amdgcn_fmed3f(a, b, inf); }
+
 // The reference's scalar step.  SIMPLE = non-negativity only (no upper bound, no in-CD L1/L2): what every NMF
 // half-update uses; the general form serves nnls()/predict() (L1 inside CD, box constraints, nonneg = FALSE).
 template <bool SIMPLE>
@@ -73,6 +79,13 @@ __device__ __forceinline__ CdStepOut cd_scalar_step(float b, float xo, float gin
     return o;
 }
 
+// LDS bytes of the operand image (launch code: solve_cd_impl.hip.h).  RT <= 2 (k <= 64): PACKED -- one float4 per lane and
+// coordinate pair {A operand of row tile 0, of row tile 1, 1/G_cc, pair coupling}, i.e. ONE ds_read_b128 per pair instead of a
+// b64 (table) + a b32 pair (operands); RT > 2: the pair-major float image + the float2 table described above.
+__host__ __device__ constexpr size_t cd_mfma_lds_bytes(int RT) {
+    return RT <= 2 ? (size_t)(16 * RT) * 64 * sizeof(float4) : ((size_t)(32 * RT) * (32 * RT) + 2 * (32 * RT)) * sizeof(float);
+}
+
 template <int RT, int CT, bool SIMPLE>   // KP = 32*RT rows (k <= KP), 32*CT columns per wave, 4 waves per block share G
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((CT == 1 && RT <= 2) ? 4 : 2, 8))) void cd_mfma_kernel(const float* __restrict__ G /* k x k, as rcppml_hip_gram wrote it */,
                                                        const float* __restrict__ B,
@@ -82,25 +95,46 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((CT == 1 &&
                                                        int* __restrict__ sweeps, const int* __restrict__ order,
                                                        unsigned long long* __restrict__ stats) {
     constexpr int KP = 32 * RT;
+    constexpr bool PACK = RT <= 2;
+    // SIMPLE keeps the iterate NEGATED (xs = -x): the step is max(diff, -x) and v_max takes no free negation, the update is
+    // min(fma(-b, 1/G, -x), 0) with the negation folded into the fma's modifiers -- same magnitudes bit for bit, one VALU less
+    // per pair
+    constexpr float XSIGN = SIMPLE ? -1.f : 1.f;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    float* Gs = reinterpret_cast<float*>(smem_raw);      // KP*KP, pair-major (layout comment above)
-    float2* tab_s = reinterpret_cast<float2*>(Gs + KP * KP);   // KP x {1/G_cc, pair coupling}
+    float* Gs = reinterpret_cast<float*>(smem_raw);      // !PACK: KP*KP, pair-major (layout comment above)
+    float2* tab_s = reinterpret_cast<float2*>(Gs + KP * KP);   // !PACK: KP x {1/G_cc, pair coupling}
+    float4* img = reinterpret_cast<float4*>(smem_raw);   // PACK: (KP/2) x 64
     // The permuted operand image and the per-coordinate table are formed HERE from the k x k Gram (until round 3 a launch of its own: every workgroup reads the same 4 k^2 bytes either way, and the solve is two launches shorter per
     // iteration).  LDS element e <-> (pair, row tile, half, r): the layout comment above.
     {
         auto gp = [&](int col, int row) { return (row < k && col < k) ? G[(int64_t)col * k + row] : (row == col ? 1.f : 0.f); };
-        for (int e = threadIdx.x; e < KP * KP; e += blockDim.x) {
-            const int pr = e >> 6, w6 = e & 63;
-            const int i = 2 * (pr / RT) + (w6 >> 5), rt = pr % RT, r = w6 & 31;
-            const int h = (r >> 2) & 1, v = (r & 3) + 4 * (r >> 3);
-            Gs[e] = -gp(i, 32 * rt + 2 * v + h);
-        }
-        for (int i = threadIdx.x; i < KP; i += blockDim.x) {
-            float2 t;
-            const float gd = gp(i, i);
-            t.x = gd > 0.f ? 1.f / gd : 0.f;
-            t.y = (i & 1) ? gp(i - 1, i) : 0.f;
-            tab_s[i] = t;
+        if constexpr (PACK) {
+            for (int e = threadIdx.x; e < (KP / 2) * 64; e += blockDim.x) {
+                const int pr = e >> 6, w6 = e & 63;
+                const int i = 2 * pr + (w6 >> 5), r = w6 & 31;
+                const int h = (r >> 2) & 1, v = (r & 3) + 4 * (r >> 3);
+                const float gd = gp(i, i);
+                float4 t;
+                t.x = -gp(i, 2 * v + h);
+                t.y = RT == 2 ? -gp(i, 32 + 2 * v + h) : 0.f;
+                t.z = gd > 0.f ? 1.f / gd : 0.f;
+                t.w = (i & 1) ? gp(i - 1, i) : 0.f;
+                img[e] = t;
+            }
+        } else {
+            for (int e = threadIdx.x; e < KP * KP; e += blockDim.x) {
+                const int pr = e >> 6, w6 = e & 63;
+                const int i = 2 * (pr / RT) + (w6 >> 5), rt = pr % RT, r = w6 & 31;
+                const int h = (r >> 2) & 1, v = (r & 3) + 4 * (r >> 3);
+                Gs[e] = -gp(i, 32 * rt + 2 * v + h);
+            }
+            for (int i = threadIdx.x; i < KP; i += blockDim.x) {
+                float2 t;
+                const float gd = gp(i, i);
+                t.x = gd > 0.f ? 1.f / gd : 0.f;
+                t.y = (i & 1) ? gp(i - 1, i) : 0.f;
+                tab_s[i] = t;
+            }
         }
     }
     __syncthreads();
@@ -117,7 +151,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((CT == 1 &&
         j[ct] = (inb[ct] && order) ? order[slot] : slot;
     }
     f32x16 acc[RT][CT];
-    float xr[RT][CT][16];
+    float xr[RT][CT][16];          // XSIGN * x
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
@@ -131,21 +165,38 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((CT == 1 &&
                 float bv = ok ? bj[row] : 0.f;
                 if (ok && l1_pre != 0.f) bv -= l1_pre;
                 acc[rt][ct][v] = bv;
-                xr[rt][ct][v] = (ok && !zero_init) ? xj[row] : 0.f;
+                xr[rt][ct][v] = (ok && !zero_init) ? XSIGN * xj[row] : 0.f;
             }
         }
+    // operands of pair p for this lane: A values of the RT row tiles, {1/G_cc, coupling} of the lane half's coordinate
+    struct PairOps { float av[RT]; float ginv, coup; };
+    auto load_pair = [&](int p) {
+        PairOps o;
+        if constexpr (PACK) {
+            const float4 t = img[p * 64 + lane];
+            o.av[0] = t.x;
+            if constexpr (RT == 2) o.av[1] = t.y;
+            o.ginv = t.z; o.coup = t.w;
+        } else {
+#pragma unroll
+            for (int rt2 = 0; rt2 < RT; ++rt2) o.av[rt2] = Gs[(p * RT + rt2) * 64 + lane];
+            const float2 t = tab_s[2 * p + half];
+            o.ginv = t.x; o.coup = t.y;
+        }
+        return o;
+    };
     if (warm) {   // B -= G X (fused_nnls.hpp:121-123): the same MFMA stream with x in place of the steps
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
                 const int i = 32 * rt + 2 * q;
+                const PairOps po = load_pair(i >> 1);
 #pragma unroll
                 for (int rt2 = 0; rt2 < RT; ++rt2) {
-                    const float av = Gs[((i >> 1) * RT + rt2) * 64 + lane];
 #pragma unroll
                     for (int ct = 0; ct < CT; ++ct)
-                        acc[rt2][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, xr[rt][ct][q], acc[rt2][ct], 0, 0, 0);
+                        acc[rt2][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(po.av[rt2], XSIGN * xr[rt][ct][q], acc[rt2][ct], 0, 0, 0);
                 }
             }
     }
@@ -159,10 +210,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((CT == 1 &&
     for (int ct = 0; ct < CT; ++ct) { active[ct] = inb[ct]; nsweep[ct] = 0; }
     // LDS operands of the first pair; every pair then requests the NEXT pair's operands before it starts computing,
     // so their latency hides behind the current pair (the last pair of a sweep prefetches pair 0 again)
-    float2 tb_c = tab_s[half];
-    float av_c[RT];
-#pragma unroll
-    for (int rt2 = 0; rt2 < RT; ++rt2) av_c[rt2] = Gs[rt2 * 64 + lane];
+    PairOps cur = load_pair(0);
     for (int it = 0; it < maxit; ++it) {
         bool any_active = false;
 #pragma unroll
@@ -179,34 +227,47 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((CT == 1 &&
                 constexpr int KPc = KP;
                 const int inext = (32 * rt + 2 * q + 2) % KPc;
                 const int rtn = (q == 15 ? rt + 1 : rt) % RT;   // row tile of the next pair
-                const float2 tb_n = tab_s[inext + half];
-                float av_n[RT];
-#pragma unroll
-                for (int rt2 = 0; rt2 < RT; ++rt2) av_n[rt2] = Gs[((inext >> 1) * RT + rt2) * 64 + lane];
-                const float g_oe = tb_c.y;
+                const PairOps nxt = load_pair(inext >> 1);
+                const float g_oe = cur.coup;
                 float aval[CT];
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct) {
                     const float b = acc[rt][ct][q];
                     const float xo = xr[rt][ct][q];
-                    // SIMPLE: frozen columns / dead diagonals take ginv = 0 (step 0, iterate unchanged)
-                    const float ginv = SIMPLE ? (active[ct] ? tb_c.x : 0.f) : tb_c.x;
-                    // even coordinate (meaningful in the low half)
-                    const CdStepOut e = cd_scalar_step<SIMPLE>(b, xo, ginv, active[ct], l1_cd, l2_cd, lo, hi);
-                    // its step, seen from the high half (same column, lane - 32).  v_permlane32_swap with
-                    // vdst == src0 exchanges the two halves of one register in place (the builtin would copy the
-                    // operand first); the low half then holds a don't-care that meets g_oe = 0
-                    float ae_lo = e.a;
-                    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %0" : "+v"(ae_lo));
-                    // high half: odd coordinate after the lazy Gauss-Seidel correction b -= G(i+1,i) a_i.  Low half:
-                    // g_oe = 0, so this re-evaluates the even step on identical inputs -- the result register is
-                    // {a_i | a_i+1} = the MFMA B operand, and no half-select is needed.
-                    const float bo = __builtin_fmaf(-g_oe, ae_lo, b);
-                    const CdStepOut o = cd_scalar_step<SIMPLE>(bo, xo, ginv, active[ct], l1_cd, l2_cd, lo, hi);
-                    aval[ct] = o.a;
-                    xr[rt][ct][q] = o.nx;
-                    // |a| / (|x_new| + 1e-15): one evaluation per pair and half (v_rcp_f32), nnls_batch.hpp:117-120
-                    tsum[ct] = __builtin_fmaf(tabs(o.a), __builtin_amdgcn_rcpf(tabs(o.nx) + 1e-15f), tsum[ct]);
+                    if constexpr (SIMPLE) {
+                        // reference: nv = x + diff; if (nv < 0) { a = -x; x = 0 } else { a = diff; x = nv }.  nv < 0 <=> diff < -x
+                        // (the sum of two floats keeps its sign through rounding), so a = max(diff, -x), x = max(nv, 0): a
+                        // two-instruction dependent chain in front of the MFMA.  Frozen columns hold b = 0 (zeroed when they
+                        // converge, below): diff = 0, a = max(0, -x) = 0, x unchanged -- no per-pair select of 1/G_cc; a dead
+                        // diagonal arrives as 1/G_cc = 0.  xo = -x here.
+                        const float ginv = cur.ginv;
+                        float ae_lo = cd_max_nc(b * ginv, xo, hi);
+                        // its step, seen from the high half (same column, lane - 32).  v_permlane32_swap with vdst == src0
+                        // exchanges the two halves of one register in place; the low half then holds a don't-care that
+                        // meets g_oe = 0
+                        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %0" : "+v"(ae_lo));
+                        // high half: odd coordinate after the lazy Gauss-Seidel correction b -= G(i+1,i) a_i.  Low half:
+                        // g_oe = 0, so this re-evaluates the even step on identical inputs -- the result register is
+                        // {a_i | a_i+1} = the MFMA B operand, and no half-select is needed.
+                        const float bo = __builtin_fmaf(-g_oe, ae_lo, b);
+                        const float diff = bo * ginv;
+                        const float a = cd_max_nc(diff, xo, hi);
+                        const float nxn = __builtin_fminf(xo - diff, 0.f);      // -(max(x + diff, 0))
+                        aval[ct] = a;
+                        xr[rt][ct][q] = nxn;
+                        // |a| / (|x_new| + 1e-15): one evaluation per pair and half (v_rcp_f32), nnls_batch.hpp:117-120
+                        tsum[ct] = __builtin_fmaf(tabs(a), __builtin_amdgcn_rcpf(tabs(nxn) + 1e-15f), tsum[ct]);
+                    } else {
+                        const float ginv = cur.ginv;
+                        const CdStepOut e = cd_scalar_step<SIMPLE>(b, xo, ginv, active[ct], l1_cd, l2_cd, lo, hi);
+                        float ae_lo = e.a;
+                        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %0" : "+v"(ae_lo));
+                        const float bo = __builtin_fmaf(-g_oe, ae_lo, b);
+                        const CdStepOut o = cd_scalar_step<SIMPLE>(bo, xo, ginv, active[ct], l1_cd, l2_cd, lo, hi);
+                        aval[ct] = o.a;
+                        xr[rt][ct][q] = o.nx;
+                        tsum[ct] = __builtin_fmaf(tabs(o.a), __builtin_amdgcn_rcpf(tabs(o.nx) + 1e-15f), tsum[ct]);
+                    }
                 }
                 // the row tile that holds the NEXT pair's residuals goes first, so its results are back first
 #pragma unroll
@@ -214,21 +275,34 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((CT == 1 &&
                     const int rt2 = (rtn + s2) % RT;
 #pragma unroll
                     for (int ct = 0; ct < CT; ++ct)
-                        acc[rt2][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(av_c[rt2], aval[ct], acc[rt2][ct], 0, 0, 0);
+                        acc[rt2][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.av[rt2], aval[ct], acc[rt2][ct], 0, 0, 0);
                 }
-                tb_c = tb_n;
-#pragma unroll
-                for (int rt2 = 0; rt2 < RT; ++rt2) av_c[rt2] = av_n[rt2];
+                cur = nxt;
                 // one scheduling region per coordinate pair: without it hipcc hoists the LDS reads of many pairs and
                 // spends > 380 registers on this fully unrolled sweep
                 __builtin_amdgcn_sched_barrier(0);
             }
         // branch-free on purpose: behind an `if (check)` LLVM sinks all 64 tolerance terms of the sweep into the
         // branch and keeps every step and iterate of the sweep alive for it (+128 registers)
+        bool froze = false;
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
             const float tot = tsum[ct] + __shfl_xor(tsum[ct], 32, 64);       // even + odd coordinates
-            active[ct] = active[ct] && !(check && tot * inv_k < tol);
+            const bool now = active[ct] && !(check && tot * inv_k < tol);
+            froze |= active[ct] && !now;
+            active[ct] = now;
+        }
+        if constexpr (SIMPLE) {
+            // columns that converged in this sweep: their residuals are no longer needed -- zero them, and every later step of
+            // the column is exactly 0 (see the step above)
+            if (__any(froze)) {
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                        for (int v = 0; v < 16; ++v) acc[rt][ct][v] = active[ct] ? acc[rt][ct][v] : 0.f;
+            }
         }
     }
 #pragma unroll
@@ -241,7 +315,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((CT == 1 &&
             for (int v = 0; v < 16; ++v) {
                 const int row = 32 * rt + 2 * v + half;
                 if (row < k) {
-                    float val = xr[rt][ct][v];
+                    float val = SIMPLE ? 0.f - xr[rt][ct][v] : xr[rt][ct][v];      // 0 - (+-0) = +0: zeros leave as +0
                     if (ub_post > 0.f) val = val < ub_post ? val : ub_post;
                     xj[row] = val;
                 }

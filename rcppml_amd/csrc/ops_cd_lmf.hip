@@ -16,7 +16,7 @@ static void cd_lmf_launch(rcppml_hip_ctx* c, const float* G, const float* B, flo
     const int64_t waves = (ncols + Ge::CW - 1) / Ge::CW;
     int64_t nblk = (waves + 3) / 4;
     const int64_t cap = (int64_t)(c->num_cu > 0 ? c->num_cu : 256) * wps;
-    if (nblk > cap) {
+    if (wps < 8 && nblk > cap) {
         nblk = cap;
         // exactly wps blocks per CU: ask for so much LDS that one more block does not fit
         const size_t lds_cu = 160 * 1024;
@@ -47,7 +47,7 @@ void rcppml_cd_lmf_dispatch(rcppml_hip_ctx* c, const float* G, const float* B, f
     int wps = lg == 1 ? 2 : 3;
     if (c->opt_lmf_wps > 0) wps = c->opt_lmf_wps;
     if (const char* e = exp_env("RCPPML_GPU_LMF_WPS")) wps = atoi(e);
-    if (wps > 4) wps = 4;
+    if (wps > 4 && wps < 8) wps = 4;       // wps >= 8: no residency cap -- one wave per CW columns, all launched (tile mode)
 #define LMF_ARGS c, G, B, X, k, ncols, l1_pre, warm, zero_init, maxit, tol, ub_post, sweeps, order, wps
     if (k <= 32) {
         if (lg == 1) cd_lmf_launch<32, 1>(LMF_ARGS); else if (lg == 2) cd_lmf_launch<32, 2>(LMF_ARGS); else cd_lmf_launch<32, 4>(LMF_ARGS);

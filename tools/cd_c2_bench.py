@@ -80,7 +80,7 @@ for side in ("H", "W"):
     ref, sref = bench(side, "mfma32 (r02 default H)", _abi.CD_MFMA)
     x16, _ = bench(side, "mfma16 (r02 default W)", _abi.CD_MFMA16)
     for lg in (1, 2, 4):
-        for wps in (1, 2, 3, 4):
+        for wps in (1, 2, 3, 4, 5, 6, 8):
             if lg == 1 and wps > 2:
                 continue
             x, s = bench(side, "lmf lg=%d wps=%d" % (lg, wps), _abi.CD_LMF, lg, wps)
