@@ -127,9 +127,11 @@ rcppml_rhs_plan* build_plan(rcppml_hip_ctx* c, int dtype, const int* colptr, con
     { const char* e = getenv("RCPPML_RT_DBG"); G.dbg = e ? atoi(e) : 0; }
 #endif
     // Workgroup shape (NW waves x NR rounds, 4 NR NW columns per workgroup) and how many columns go through the tiles.
-    // Model (cycles per SIMD and tile, fitted to rocprofv3 on C2): waves per SIMD x (fixed 250 + 24 per step); workgroups
-    // run in rounds of num_cu / P.  Columns that would only fill part of a last round are cheaper in the gather kernel
-    // (12.5 ps per nonzero on the whole chip) than as a round of their own.
+    // Model (cycles per SIMD and tile, fitted to rocprofv3 on C2): waves per SIMD x (fixed 250 + 24 per step and 256-byte
+    // slice of the row); workgroups run in rounds of num_cu / P.  Columns that would only fill part of a last round are cheaper
+    // in the workgroup-per-column gather kernel (25 ps per nonzero and slice on the whole chip: 10 us for C2's 1 696 tail
+    // columns) than as a round of their own -- unless there are many of them: fp64 at k = 64 on C2's W side left 4 640 of
+    // 20 000 columns (0.23 ms of gathers) to that kernel while the slices were not in the model; it now takes two rounds.
     const int NV = rowb / 256;
     const int64_t conc = std::max<int64_t>(1, c->num_cu / P);                 // workgroups of one partition resident at once
     const double tiles_pp = (double)G.ntiles / P;
@@ -141,7 +143,7 @@ rcppml_rhs_plan* build_plan(rcppml_hip_ctx* c, int dtype, const int* colptr, con
         for (int nr = 2; nr <= 20; ++nr) {
             if (!rt_launch::shape_ok(NV, S, NW, nr, (int)sizeof(T))) continue;
             const int64_t cap = 4ll * nr * NW;
-            const double t_wg = tiles_pp * (NW / 4) * (250.0 + 24.0 * nr * S) / 2400.0 + 15.0;       // microseconds
+            const double t_wg = tiles_pp * (NW / 4) * (250.0 + 24.0 * NV * nr * S) / 2400.0 + 15.0;       // microseconds
             const int64_t full_rounds = ncols / (cap * conc);
             for (int opt = 0; opt < 2; ++opt) {
                 int64_t tiled;
@@ -153,7 +155,7 @@ rcppml_rhs_plan* build_plan(rcppml_hip_ctx* c, int dtype, const int* colptr, con
                 } else {                              // whole rounds only, the rest to the gather kernel
                     if (full_rounds < 1) continue;
                     tiled = full_rounds * cap * conc;
-                    t = (double)full_rounds * t_wg + 5.0 + (double)(ncols - tiled) * nnz_per_col * 12.5e-6;
+                    t = (double)full_rounds * t_wg + 5.0 + (double)(ncols - tiled) * nnz_per_col * 25e-6 * NV;
                 }
                 if (best_t < 0 || t < best_t) { best_t = t; bestNW = NW; bestnr = nr; best_tiled = tiled; }
             }
@@ -164,7 +166,7 @@ rcppml_rhs_plan* build_plan(rcppml_hip_ctx* c, int dtype, const int* colptr, con
         // hypersparse matrix (200 000 x 200 000 with 1.1 M nonzeros: 313 M slots, 1.9 GB, ~1 ms per product against ~14 us for
         // the gather kernel) must not get a plan.  Decline -- the caller then uses the gather kernel -- when the predicted fill
         // is below a quarter, when the slot stream would exceed four times the CSC itself or half of the free device memory,
-        // or when the cost model says the gather kernel (12.5 ps per nonzero on the whole chip) is faster.
+        // or when the cost model says the gather kernel (12.5 ps per nonzero and 256-byte slice on the whole chip) is faster.
         const int64_t cap0 = 4ll * bestnr * bestNW;
         const double nslots_est = (double)((best_tiled + cap0 - 1) / cap0) * G.ntiles * bestNW * (double)(bestnr * S) * 4.0;
         const double fill_est = ((double)pl->nnz - ovf_est) * ((double)best_tiled / (double)ncols) / std::max(nslots_est, 1.0);
@@ -174,7 +176,7 @@ rcppml_rhs_plan* build_plan(rcppml_hip_ctx* c, int dtype, const int* colptr, con
         // (small plans -- the unit tests' matrices -- are harmless either way and are left alone)
         const bool big = stream_bytes > (double)(32u << 20);
         if (stream_bytes > 0.5 * (double)free_b ||
-            (big && (fill_est < 0.25 || stream_bytes > 4.0 * (double)pl->nnz * (sizeof(T) + 4.0) || best_t > (double)pl->nnz * 12.5e-6 + 5.0)))
+            (big && (fill_est < 0.25 || stream_bytes > 4.0 * (double)pl->nnz * (sizeof(T) + 4.0) || best_t > (double)pl->nnz * 12.5e-6 * NV + 5.0)))
             return nullptr;
     }
 #ifdef RCPPML_EXPERIMENTS
