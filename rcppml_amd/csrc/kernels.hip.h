@@ -46,6 +46,45 @@ __device__ __forceinline__ double lane_value(double v, int i) {
     return __longlong_as_double(((unsigned long long)hi << 32) | lo);
 }
 
+// ---------------------------------------------------------------------------
+// Static coordinate sweeps for the wave-per-column CD solves with a PER-COLUMN Gram (IRLS, CV; fp32, lane = feature, the lane's
+// column of the Gram in registers): cd_nnls_col_fixed(G, b, x, L1 inside, nonneg, maxit, tol = 0) with the fixed-point exit.
+// Every coordinate is visited in turn with wave-uniform control flow: each lane evaluates the step of ITS coordinate from its own
+// residual and iterate (fma, med3), coordinate i's is read with one v_readlane at a compile-time lane and applied to all
+// residuals with one fma on a compile-time register; the iterate of lane i moves under a one-lane EXEC mask.  Dependent chain
+// per coordinate: fma -> med3 -> readlane -> fma.  The form this replaces found the next coordinate that moves with a ballot and
+// skipped the others: ~16 VALU + a dozen SALU operations and two branches per MOVING coordinate, all on one chain -- these
+// kernels are latency-bound even at eight waves per SIMD (four waves: 1.8x slower), so the chain length is what counts (C5:
+// NB iteration 32.4 -> 24.7 ms).  A dead diagonal / a lane beyond k holds 1/G_ii = 0 and no L1: its step is max(0, -x) = 0.
+// gcol(std::integral_constant<int, i>) = G(i, lane).  Must be called with all 64 lanes active.
+// ---------------------------------------------------------------------------
+template <int B, int E, class Fn> __device__ __forceinline__ void cd_static_for(Fn&& fn) {
+    if constexpr (B < E) { fn(std::integral_constant<int, B>{}); cd_static_for<B + 1, E>(fn); }
+}
+template <int KP, class GC>
+__device__ __forceinline__ void cd_static_sweeps_f32(float& b, float& x, float gd, bool fok, float l1, int nonneg, int maxit, GC&& gcol) {
+    const bool alive = fok && gd > 0.f;
+    const float ginv = alive ? 1.f / gd : 0.f;        // one division per solve; the sweep multiplies (as the MSE kernels do)
+    const float nl1 = alive ? -l1 : 0.f;
+    const float pinf = __builtin_inff();
+    float xe = nonneg ? x : pinf;                     // the clamp's operand: max(diff, -xe) is max(diff, -x) or diff
+    const float inf_rt = maxit >= 0 ? pinf : 0.f;     // +inf at run time: with a literal LLVM folds the median back into maxnum
+    for (int it = 0; it < maxit; ++it) {
+        const float x_sweep0 = x;
+        cd_static_for<0, KP>([&](auto IC) {
+            constexpr int i = decltype(IC)::value;
+            const float diff = __builtin_fmaf(b, ginv, nl1);
+            const float ad = __builtin_amdgcn_fmed3f(diff, -xe, inf_rt);       // max(diff, -xe) without a canonicalising pre-op
+            const float ad_i = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(ad), i));
+            // lane i only: x += ad, xe += ad (inf + ad = inf)
+            asm volatile("s_mov_b64 s[2:3], exec\n\ts_mov_b64 exec, %2\n\tv_add_f32 %0, %0, %3\n\tv_add_f32 %1, %1, %3\n\ts_mov_b64 exec, s[2:3]"
+                         : "+v"(x), "+v"(xe) : "s"(1ull << i), "v"(ad) : "s2", "s3");
+            b = __builtin_fmaf(-gcol(IC), ad_i, b);
+        });
+        if (!__any(x != x_sweep0)) break;      // no effective step, or the iterate is at its floating-point fixed point
+    }
+}
+
 __device__ __forceinline__ float shfl_xor_t(float v, int m) { return __shfl_xor(v, m, 64); }
 __device__ __forceinline__ double shfl_xor_t(double v, int m) { return __shfl_xor(v, m, 64); }
 
@@ -1638,30 +1677,7 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8
         f32x32 gcol;
 #pragma unroll
         for (int c = 0; c < KP; ++c) gcol[c] = Gl[c * KP + ll];
-        const float ginv = gd > 0.f ? 1.f / gd : 0.f;   // one division per column; the sweep multiplies (as the MSE and IRLS fp32 kernels do)
-        for (int it = 0; it < maxit; ++it) {
-            int cur = 0;
-            bool any = false;
-            const auto x_sweep0 = x;
-            while (true) {
-                float diff = b * ginv;
-                if (l1 != 0.f) diff -= l1;
-                const float nv = x + diff;
-                float ad = diff, nx = nv;
-                if (nonneg && nv < 0.f) { ad = -x; nx = 0.f; }
-                const bool moves = fok && (gd > 0.f) && (ad != 0.f) && (lane >= cur);
-                const unsigned long long mask = __ballot(moves);
-                if (mask == 0ull) break;
-                any = true;
-                const int i = __builtin_ctzll(mask);
-                const float ad_i = lane_value(ad, i);
-                if (lane == i) x = nx;
-                b = tfma(-gcol[i], ad_i, b);
-                cur = i + 1;
-                if (cur >= KP) break;
-            }
-            if (!any || !__any(x != x_sweep0)) break;      // no effective step, or the iterate is at its floating-point fixed point
-        }
+        cd_static_sweeps_f32<KP>(b, x, gd, fok, l1, nonneg, maxit, [&](auto IC) { return gcol[decltype(IC)::value]; });
     }
     if (fok) X[j * (int64_t)k + lane] = x;
 }
@@ -1805,31 +1821,10 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2
         f32x32 gcol0, gcol1;                                            //  s_set_gpr_idx, 64-element ones through scratch)
 #pragma unroll
         for (int c = 0; c < 32; ++c) { gcol0[c] = Gl[c * KP + ll]; gcol1[c] = Gl[(32 + c) * KP + ll]; }
-        const float ginv = gd > 0.f ? 1.f / gd : 0.f;   // one division per column; the sweep multiplies (as the MSE and IRLS fp32 kernels do)
-        for (int it = 0; it < maxit; ++it) {
-            int cur = 0;
-            bool any = false;
-            const auto x_sweep0 = x;
-            while (true) {
-                float diff = b * ginv;
-                if (l1 != 0.f) diff -= l1;
-                const float nv = x + diff;
-                float ad = diff, nx = nv;
-                if (nonneg && nv < 0.f) { ad = -x; nx = 0.f; }
-                const bool moves = fok && (gd > 0.f) && (ad != 0.f) && (lane >= cur);
-                const unsigned long long mask = __ballot(moves);
-                if (mask == 0ull) break;
-                any = true;
-                const int i = __builtin_ctzll(mask);
-                const float ad_i = lane_value(ad, i);
-                if (lane == i) x = nx;
-                const float g_lo = gcol0[i & 31], g_hi = gcol1[i & 31];
-                b = tfma(-(i < 32 ? g_lo : g_hi), ad_i, b);
-                cur = i + 1;
-                if (cur >= KP) break;
-            }
-            if (!any || !__any(x != x_sweep0)) break;      // no effective step, or the iterate is at its floating-point fixed point
-        }
+        cd_static_sweeps_f32<KP>(b, x, gd, fok, l1, nonneg, maxit, [&](auto IC) {
+            constexpr int i = decltype(IC)::value;
+            return i < 32 ? gcol0[i & 31] : gcol1[i & 31];
+        });
     }
     if (fok) X[j * (int64_t)k + lane] = x;
 }

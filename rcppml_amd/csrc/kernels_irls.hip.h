@@ -18,10 +18,6 @@
 
 namespace rk {
 
-template <int B, int E, class Fn> __device__ __forceinline__ void rt_irls_static_for(Fn&& fn) {
-    if constexpr (B < E) { fn(std::integral_constant<int, B>{}); rt_irls_static_for<B + 1, E>(fn); }
-}
-
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
@@ -295,35 +291,8 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(IRLS
             b = tfma(-gv, xc, b);
         }
         const float gd = Gl[ll * KP + ll];
-        // cd_nnls_col_fixed(G_w, b_c, x, L1 inside, L2 = 0, nonneg, cd_maxit, ub = 0, tol = 0): all sweeps.
-        // STATIC sweep (round 3): every coordinate is visited in turn with wave-uniform control flow -- each lane evaluates the
-        // step of ITS coordinate from its own residual and iterate (two dependent VALU operations), coordinate i's is read
-        // with one v_readlane at a compile-time lane and applied to all residuals with one fma on a compile-time register of
-        // the lane's Gram column; the iterate of lane i moves under a one-lane EXEC mask.  Dependent chain per coordinate:
-        // fma -> med3 -> readlane -> fma.  The form it replaces found the next coordinate that moves with a ballot and skipped
-        // the others: ~16 VALU + a dozen SALU operations and two branches per MOVING coordinate, all on one chain -- with the
-        // kernel latency-bound at eight waves per SIMD (four waves: 1.8x slower) the chain length is what counts.
-        // A dead diagonal / a lane beyond k holds 1/G_ii = 0 and no L1: its step is max(0, -x) = 0.
-        const bool alive = fok && gd > 0.f;
-        const float ginv = alive ? 1.f / gd : 0.f;        // one division per pass; the sweep multiplies (as the MSE kernels do)
-        const float nl1 = alive ? -l1 : 0.f;
-        const float pinf = __builtin_inff();
-        float xe = nonneg ? x : pinf;                     // the clamp's operand: max(diff, -xe) is max(diff, -x) or diff
-        const float inf_rt = cd_maxit >= 0 ? pinf : 0.f;  // +inf at run time: with a literal LLVM folds the median back into maxnum
-        for (int it = 0; it < cd_maxit; ++it) {
-            const float x_sweep0 = x;
-            rt_irls_static_for<0, KP>([&](auto IC) {
-                constexpr int i = decltype(IC)::value;
-                const float diff = __builtin_fmaf(b, ginv, nl1);
-                const float ad = __builtin_amdgcn_fmed3f(diff, -xe, inf_rt);       // max(diff, -xe) without a canonicalising pre-op
-                const float ad_i = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(ad), i));
-                // lane i only: x += ad, xe += ad (inf + ad = inf)
-                asm volatile("s_mov_b64 s[2:3], exec\n\ts_mov_b64 exec, %2\n\tv_add_f32 %0, %0, %3\n\tv_add_f32 %1, %1, %3\n\ts_mov_b64 exec, s[2:3]"
-                             : "+v"(x), "+v"(xe) : "s"(1ull << i), "v"(ad) : "s2", "s3");
-                b = __builtin_fmaf(-gcol[i], ad_i, b);
-            });
-            if (!__any(x != x_sweep0)) break;      // no effective step, or the iterate is at its floating-point fixed point
-        }
+        // cd_nnls_col_fixed(G_w, b_c, x, L1 inside, L2 = 0, nonneg, cd_maxit, ub = 0, tol = 0): all sweeps, static form (kernels.hip.h)
+        cd_static_sweeps_f32<KP>(b, x, gd, fok, l1, nonneg, cd_maxit, [&](auto IC) { return gcol[decltype(IC)::value]; });
         float rel = fok ? tabs(x - x_old) / (tabs(x_old) + 1e-12f) : 0.f;
         rel = wave_max(rel);
         __builtin_amdgcn_wave_barrier();
@@ -457,32 +426,11 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2
             b = tfma(-gv, xc, b);
         }
         const float gd = Gl[lane * KP + lane];
-        const float ginv = gd > 0.f ? 1.f / gd : 0.f;
-        // cd_nnls_col_fixed(G_w, b_c, x, L1 inside, L2 = 0, nonneg, cd_maxit, ub = 0, tol = 0): all sweeps
-        for (int it = 0; it < cd_maxit; ++it) {
-            int cur = 0;
-            bool any = false;
-            const auto x_sweep0 = x;
-            while (true) {
-                float diff = b * ginv;
-                if (l1 != 0.f) diff -= l1;
-                const float nv = x + diff;
-                float ad = diff, nx = nv;
-                if (nonneg && nv < 0.f) { ad = -x; nx = 0.f; }
-                const bool moves = fok && (gd > 0.f) && (ad != 0.f) && (lane >= cur);
-                const unsigned long long mask = __ballot(moves);
-                if (mask == 0ull) break;
-                any = true;
-                const int i = __builtin_ctzll(mask);
-                const float ad_i = lane_value(ad, i);
-                if (lane == i) x = nx;
-                const float g_lo = gcol0[i & 31], g_hi = gcol1[i & 31];
-                b = tfma(-(i < 32 ? g_lo : g_hi), ad_i, b);
-                cur = i + 1;
-                if (cur >= KP) break;
-            }
-            if (!any || !__any(x != x_sweep0)) break;      // no effective step, or the iterate is at its floating-point fixed point
-        }
+        // cd_nnls_col_fixed(G_w, b_c, x, L1 inside, L2 = 0, nonneg, cd_maxit, ub = 0, tol = 0): all sweeps, static form (kernels.hip.h)
+        cd_static_sweeps_f32<KP>(b, x, gd, fok, l1, nonneg, cd_maxit, [&](auto IC) {
+            constexpr int i = decltype(IC)::value;
+            return i < 32 ? gcol0[i & 31] : gcol1[i & 31];
+        });
         float rel = fok ? tabs(x - x_old) / (tabs(x_old) + 1e-12f) : 0.f;
         rel = wave_max(rel);
         __builtin_amdgcn_wave_barrier();
