@@ -62,8 +62,7 @@ template <int RT, int CT>
 static void cd_mfma_launch(rcppml_hip_ctx* c, const float* G, const float* /*unused*/, const float* B, float* X, int k,
                            int64_t ncols, float l1_pre, int warm, int zero_init, float l1_cd, float l2_cd, int nonneg,
                            int maxit, float tol, float ub_cd, float ub_post, int* sweeps, const int* order) {
-    constexpr int KP = 32 * RT;
-    size_t smem = cd_mfma_lds_bytes(RT);
+    size_t smem = cd_mfma_lds_bytes(RT);          // operand image of the k x k Gram, KP = 32 RT rows
     const int64_t per_block = 4 * 32 * CT;          // 4 waves per block
     const int64_t nblk = (ncols + per_block - 1) / per_block;
     const bool simple = nonneg && ub_cd <= 0.f && l1_cd == 0.f && l2_cd == 0.f;
