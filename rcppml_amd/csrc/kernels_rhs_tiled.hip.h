@@ -373,7 +373,7 @@ __global__ __launch_bounds__(64 * NW) void rhs_tiled_kernel(const T* __restrict_
 #ifdef RCPPML_EXPERIMENTS
     const bool nx_slab = !(G.dbg & 2), nx_slots = !(G.dbg & 4);
 #else
-    constexpr bool nx_slab = true, nx_slots = true;
+    [[maybe_unused]] constexpr bool nx_slab = true, nx_slots = true;
 #endif
     // piece CBASE exists for the first CEXTRA waves only; the others copy their own last piece once more (same bytes to the
     // same place) rather than branch
