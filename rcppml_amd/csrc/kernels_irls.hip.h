@@ -143,28 +143,34 @@ __global__ __launch_bounds__(256) void irls_nb_solve_kernel(
         const T gd = Gl[ll * KP + ll];
         const T ginv = gd > T(0) ? T(1) / gd : T(0);
         // cd_nnls_col_fixed(G_w, b_c, x, L1 inside, L2 = 0, nonneg, cd_maxit, ub = 0, tol = 0): all sweeps
-        for (int it = 0; it < cd_maxit; ++it) {
-            int cur = 0;
-            bool any = false;
-            const auto x_sweep0 = x;
-            while (true) {
-                T diff = sweep_quotient(b, gd, ginv);
-                if (l1 != T(0)) diff -= l1;
-                const T nv = x + diff;
-                T ad = diff, nx = nv;
-                if (nonneg && nv < T(0)) { ad = -x; nx = T(0); }
-                const bool moves = fok && (gd > T(0)) && (ad != T(0)) && (lane >= cur);
-                const unsigned long long mask = __ballot(moves);
-                if (mask == 0ull) break;
-                any = true;
-                const int i = __builtin_ctzll(mask);
-                const T ad_i = lane_value(ad, i);
-                if (lane == i) x = nx;
-                b = tfma(-Gl[i * KP + ll], ad_i, b);
-                cur = i + 1;
-                if (cur >= KP) break;
+        if constexpr (std::is_same<T, float>::value) {
+            // fp32: static coordinate sweeps (cd_static_sweeps_f32), the lane's Gram column read from the wave's LDS tile at
+            // compile-time offsets
+            cd_static_sweeps_f32<KP>(b, x, gd, fok, l1, nonneg, cd_maxit, [&](auto IC) { return Gl[decltype(IC)::value * KP + ll]; });
+        } else {
+            for (int it = 0; it < cd_maxit; ++it) {
+                int cur = 0;
+                bool any = false;
+                const auto x_sweep0 = x;
+                while (true) {
+                    T diff = sweep_quotient(b, gd, ginv);
+                    if (l1 != T(0)) diff -= l1;
+                    const T nv = x + diff;
+                    T ad = diff, nx = nv;
+                    if (nonneg && nv < T(0)) { ad = -x; nx = T(0); }
+                    const bool moves = fok && (gd > T(0)) && (ad != T(0)) && (lane >= cur);
+                    const unsigned long long mask = __ballot(moves);
+                    if (mask == 0ull) break;
+                    any = true;
+                    const int i = __builtin_ctzll(mask);
+                    const T ad_i = lane_value(ad, i);
+                    if (lane == i) x = nx;
+                    b = tfma(-Gl[i * KP + ll], ad_i, b);
+                    cur = i + 1;
+                    if (cur >= KP) break;
+                }
+                if (!any || !__any(x != x_sweep0)) break;      // no effective step, or the iterate is at its floating-point fixed point
             }
-            if (!any || !__any(x != x_sweep0)) break;      // no effective step, or the iterate is at its floating-point fixed point
         }
         // IRLS convergence: max_i |x_i - x_old_i| / (|x_old_i| + 1e-12) < irls_tol
         T rel = fok ? tabs(x - x_old) / (tabs(x_old) + T(1e-12)) : T(0);
