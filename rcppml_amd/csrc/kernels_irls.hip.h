@@ -195,10 +195,11 @@ __global__ __launch_bounds__(256) void irls_nb_solve_kernel(
 //   The CD solve is unchanged (exact sequential sweep with ballot skipping); G_w is written from the accumulator tile
 //   straight into its LDS slab, which aliases the staging buffer.
 // ---------------------------------------------------------------------------
-#ifndef IRLS32_WPE
-#define IRLS32_WPE 8
-#endif
-static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(IRLS32_WPE, 8))) void irls_nb_mfma32_kernel(
+// LT >= 0: the loss is known at compile time and there is no robust modifier (LT = 5: negative binomial, what C5 runs) -- the
+// weight function then holds neither the fp64 pow() of the power-variance losses nor the Huber branch, whose registers the
+// generic instantiation (LT = -1) pays for in every lane whatever loss it runs (64-VGPR budget at eight waves per SIMD).
+template <int LT>
+static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void irls_nb_mfma32_kernel(
     const int* __restrict__ colptr, const int* __restrict__ rowidx, const float* __restrict__ vals, int64_t ncols,
     const float* __restrict__ F, const float* __restrict__ Gbase, float* __restrict__ X, int k, float l1, float l2,
     int nonneg, int cd_maxit, int irls_max_iter, float irls_tol, const float* __restrict__ theta_row,
@@ -254,7 +255,7 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(IRLS
             }
             const float recon = part + __shfl_xor(part, 32, 64);                 // W_T.col(row).dot(x)
             const float th = theta_col ? th_col : (theta_row ? theta_row[row] : 0.f);
-            const float w = irls_weight_full_dev<float>(loss_type, a - recon, recon, th, power, robust);
+            const float w = irls_weight_full_dev<float>(LT >= 0 ? LT : loss_type, a - recon, recon, th, power, LT >= 0 ? 0.f : robust);
 #pragma unroll
             for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(Fst + r * FS + 16 * hh + 4 * q) = fv4[q];
             if (hh == 0) sc[r] = make_float2(ok ? w - 1.f : 0.f, ok ? w * a : 0.f);

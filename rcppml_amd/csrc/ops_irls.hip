@@ -33,8 +33,12 @@ static void irls_impl(rcppml_hip_ctx* c, const int* cp, const int* ri, const T* 
         if (use_mfma < 0) use_mfma = exp_flag("RCPPML_GPU_IRLS_VARIANT", "valu") ? 0 : 1;
         if (use_mfma && k <= 32 && k % 4 == 0 && reinterpret_cast<uintptr_t>(F) % 16 == 0) {
             const size_t smem = (size_t)4 * (32 * 36 + 2 * 32 + 32) * sizeof(float);
-            hipLaunchKernelGGL(irls_nb_mfma32_kernel, dim3((unsigned)nblk), dim3(256), smem, c->stream, cp, ri, vals, ncols, F,
-                               Gbase, X, k, l1, l2, nonneg, cd_maxit, irls_max_iter, irls_tol, theta_row, theta_col, loss_type, power, robust, st);
+            if (loss_type == 5 && !(robust > 0))          // negative binomial without the robust modifier: specialised weights
+                hipLaunchKernelGGL(irls_nb_mfma32_kernel<5>, dim3((unsigned)nblk), dim3(256), smem, c->stream, cp, ri, vals, ncols, F,
+                                   Gbase, X, k, l1, l2, nonneg, cd_maxit, irls_max_iter, irls_tol, theta_row, theta_col, loss_type, power, robust, st);
+            else
+                hipLaunchKernelGGL(irls_nb_mfma32_kernel<-1>, dim3((unsigned)nblk), dim3(256), smem, c->stream, cp, ri, vals, ncols, F,
+                                   Gbase, X, k, l1, l2, nonneg, cd_maxit, irls_max_iter, irls_tol, theta_row, theta_col, loss_type, power, robust, st);
             HIPCHK(hipGetLastError());
             return;
         }
