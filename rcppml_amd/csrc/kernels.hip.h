@@ -61,28 +61,44 @@ __device__ __forceinline__ double lane_value(double v, int i) {
 template <int B, int E, class Fn> __device__ __forceinline__ void cd_static_for(Fn&& fn) {
     if constexpr (B < E) { fn(std::integral_constant<int, B>{}); cd_static_for<B + 1, E>(fn); }
 }
-template <int KP, class GC>
-__device__ __forceinline__ void cd_static_sweeps_f32(float& b, float& x, float gd, bool fok, float l1, int nonneg, int maxit, GC&& gcol) {
-    const bool alive = fok && gd > 0.f;
-    const float ginv = alive ? 1.f / gd : 0.f;        // one division per solve; the sweep multiplies (as the MSE kernels do)
-    const float nl1 = alive ? -l1 : 0.f;
-    const float pinf = __builtin_inff();
-    float xe = nonneg ? x : pinf;                     // the clamp's operand: max(diff, -xe) is max(diff, -x) or diff
-    const float inf_rt = maxit >= 0 ? pinf : 0.f;     // +inf at run time: with a literal LLVM folds the median back into maxnum
+// x += ad, xe += ad in lane `mask`'s lanes only (one-lane EXEC mask; EXEC saved and restored)
+__device__ __forceinline__ void cd_masked_add2(float& x, float& xe, float ad, unsigned long long mask) {
+    asm volatile("s_mov_b64 s[2:3], exec\n\ts_mov_b64 exec, %2\n\tv_add_f32 %0, %0, %3\n\tv_add_f32 %1, %1, %3\n\ts_mov_b64 exec, s[2:3]"
+                 : "+v"(x), "+v"(xe) : "s"(mask), "v"(ad) : "s2", "s3");
+}
+__device__ __forceinline__ void cd_masked_add2(double& x, double& xe, double ad, unsigned long long mask) {
+    asm volatile("s_mov_b64 s[2:3], exec\n\ts_mov_b64 exec, %2\n\tv_add_f64 %0, %0, %3\n\tv_add_f64 %1, %1, %3\n\ts_mov_b64 exec, s[2:3]"
+                 : "+v"(x), "+v"(xe) : "s"(mask), "v"(ad) : "s2", "s3");
+}
+// max(a, b) on the step's chain: fp32 as v_med3_f32(a, b, +inf) (no canonicalising pre-op; `inf` must be a run-time +inf), fp64 plain
+__device__ __forceinline__ float cd_static_max(float a, float b, float inf) { return __builtin_amdgcn_fmed3f(a, b, inf); }
+__device__ __forceinline__ double cd_static_max(double a, double b, double) { return __builtin_fmax(a, b); }
+// fp64 note: the step multiplies by 1/G_ii formed once per solve (one rounding more than b / G_ii -- the same choice as the fp64 MSE
+// kernel, kernels_cd_mfma64.hip.h); an IEEE fp64 division is ~15 dependent instructions on the chain of every coordinate.
+template <class T, int KP, class GC>
+__device__ __forceinline__ void cd_static_sweeps(T& b, T& x, T gd, bool fok, T l1, int nonneg, int maxit, GC&& gcol) {
+    const bool alive = fok && gd > T(0);
+    const T ginv = alive ? T(1) / gd : T(0);          // one division per solve
+    const T nl1 = alive ? -l1 : T(0);
+    const T pinf = static_cast<T>(__builtin_inff());
+    T xe = nonneg ? x : pinf;                         // the clamp's operand: max(diff, -xe) is max(diff, -x) or diff
+    const T inf_rt = maxit >= 0 ? pinf : T(0);        // +inf at run time: with a literal LLVM folds the median back into maxnum
     for (int it = 0; it < maxit; ++it) {
-        const float x_sweep0 = x;
+        const T x_sweep0 = x;
         cd_static_for<0, KP>([&](auto IC) {
             constexpr int i = decltype(IC)::value;
-            const float diff = __builtin_fmaf(b, ginv, nl1);
-            const float ad = __builtin_amdgcn_fmed3f(diff, -xe, inf_rt);       // max(diff, -xe) without a canonicalising pre-op
-            const float ad_i = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(ad), i));
-            // lane i only: x += ad, xe += ad (inf + ad = inf)
-            asm volatile("s_mov_b64 s[2:3], exec\n\ts_mov_b64 exec, %2\n\tv_add_f32 %0, %0, %3\n\tv_add_f32 %1, %1, %3\n\ts_mov_b64 exec, s[2:3]"
-                         : "+v"(x), "+v"(xe) : "s"(1ull << i), "v"(ad) : "s2", "s3");
-            b = __builtin_fmaf(-gcol(IC), ad_i, b);
+            const T diff = tfma(b, ginv, nl1);
+            const T ad = cd_static_max(diff, -xe, inf_rt);
+            const T ad_i = lane_value(ad, i);
+            cd_masked_add2(x, xe, ad, 1ull << i);     // lane i only: x += ad, xe += ad (inf + ad = inf)
+            b = tfma(-gcol(IC), ad_i, b);
         });
         if (!__any(x != x_sweep0)) break;      // no effective step, or the iterate is at its floating-point fixed point
     }
+}
+template <int KP, class GC>
+__device__ __forceinline__ void cd_static_sweeps_f32(float& b, float& x, float gd, bool fok, float l1, int nonneg, int maxit, GC&& gcol) {
+    cd_static_sweeps<float, KP>(b, x, gd, fok, l1, nonneg, maxit, gcol);
 }
 
 __device__ __forceinline__ float shfl_xor_t(float v, int m) { return __shfl_xor(v, m, 64); }
@@ -1513,36 +1529,9 @@ __global__ __launch_bounds__(256) void cv_solve_kernel(
         if (nonneg) x = x > T(0) ? x : T(0);
     } else {
         const T gd = Gl[ll * KP + ll];
-        const T ginv = gd > T(0) ? T(1) / gd : T(0);
-        if constexpr (std::is_same<T, float>::value) {
-            // fp32: static coordinate sweeps (cd_static_sweeps_f32), the lane's Gram column read from the wave's LDS tile at
-            // compile-time offsets
-            cd_static_sweeps_f32<KP>(b, x, gd, fok, l1, nonneg, maxit, [&](auto IC) { return Gl[decltype(IC)::value * KP + ll]; });
-        } else {
-            for (int it = 0; it < maxit; ++it) {
-                int cur = 0;
-                bool any = false;
-                const auto x_sweep0 = x;
-                while (true) {
-                    T diff = sweep_quotient(b, gd, ginv);
-                    if (l1 != T(0)) diff -= l1;
-                    const T nv = x + diff;
-                    T ad = diff, nx = nv;
-                    if (nonneg && nv < T(0)) { ad = -x; nx = T(0); }
-                    const bool moves = fok && (gd > T(0)) && (ad != T(0)) && (lane >= cur);
-                    const unsigned long long mask = __ballot(moves);
-                    if (mask == 0ull) break;
-                    any = true;
-                    const int i = __builtin_ctzll(mask);
-                    const T ad_i = lane_value(ad, i), nx_i = lane_value(nx, i);
-                    if (lane == i) x = nx_i;
-                    b = tfma(-Gl[i * KP + ll], ad_i, b);
-                    cur = i + 1;
-                    if (cur >= KP) break;
-                }
-                if (!any || !__any(x != x_sweep0)) break;      // no effective step, or the iterate is at its floating-point fixed point
-            }
-        }
+        // static coordinate sweeps (cd_static_sweeps, kernels.hip.h): the lane's Gram column read from the wave's LDS tile at
+        // compile-time offsets
+        cd_static_sweeps<T, KP>(b, x, gd, fok, l1, nonneg, maxit, [&](auto IC) { return Gl[decltype(IC)::value * KP + ll]; });
     }
     if (fok) X[j * (int64_t)k + lane] = x;
 }
@@ -1972,29 +1961,7 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8
         if (nonneg) x = x > 0.0 ? x : 0.0;
     } else {
         const double gd = Gl[ll * KP + ll];
-        for (int it = 0; it < maxit; ++it) {
-            int cur = 0;
-            bool any = false;
-            const auto x_sweep0 = x;
-            while (true) {
-                double diff = b / gd;
-                if (l1 != 0.0) diff -= l1;
-                const double nv = x + diff;
-                double ad = diff, nx = nv;
-                if (nonneg && nv < 0.0) { ad = -x; nx = 0.0; }
-                const bool moves = fok && (gd > 0.0) && (ad != 0.0) && (lane >= cur);
-                const unsigned long long mask = __ballot(moves);
-                if (mask == 0ull) break;
-                any = true;
-                const int i = __builtin_ctzll(mask);
-                const double ad_i = lane_value(ad, i), nx_i = lane_value(nx, i);
-                if (lane == i) x = nx_i;
-                b = tfma(-Gl[i * KP + ll], ad_i, b);
-                cur = i + 1;
-                if (cur >= KP) break;
-            }
-            if (!any || !__any(x != x_sweep0)) break;      // no effective step, or the iterate is at its floating-point fixed point
-        }
+        cd_static_sweeps<double, KP>(b, x, gd, fok, l1, nonneg, maxit, [&](auto IC) { return Gl[decltype(IC)::value * KP + ll]; });
     }
     if (fok) X[j * (int64_t)k + lane] = x;
 }

@@ -193,36 +193,9 @@ __global__ __launch_bounds__(256) void cv_irls_solve_kernel(
             if (!fok) x = T(0);
         } else {
             const T gd = Gl[ll * KP + ll];
-            const T ginv = gd > T(0) ? T(1) / gd : T(0);
-            if constexpr (std::is_same<T, float>::value) {
-                // fp32: static coordinate sweeps (cd_static_sweeps_f32), the lane's Gram column read from the wave's LDS tile at
-                // compile-time offsets
-                cd_static_sweeps_f32<KP>(b, x, gd, fok, l1, nonneg, maxit, [&](auto IC) { return Gl[decltype(IC)::value * KP + ll]; });
-            } else {
-                for (int sw = 0; sw < maxit; ++sw) {
-                    int cur = 0;
-                    bool any = false;
-                    const auto x_sweep0 = x;
-                    while (true) {
-                        T diff = sweep_quotient(b, gd, ginv);
-                        if (l1 != T(0)) diff -= l1;
-                        const T nv = x + diff;
-                        T ad = diff, nx = nv;
-                        if (nonneg && nv < T(0)) { ad = -x; nx = T(0); }
-                        const bool moves = fok && (gd > T(0)) && (ad != T(0)) && (lane >= cur);
-                        const unsigned long long mask = __ballot(moves);
-                        if (mask == 0ull) break;
-                        any = true;
-                        const int i = __builtin_ctzll(mask);
-                        const T ad_i = lane_value(ad, i), nx_i = lane_value(nx, i);
-                        if (lane == i) x = nx_i;
-                        b = tfma(-Gl[i * KP + ll], ad_i, b);
-                        cur = i + 1;
-                        if (cur >= KP) break;
-                    }
-                    if (!any || !__any(x != x_sweep0)) break;      // no effective step, or the iterate is at its floating-point fixed point
-                }
-            }
+            // static coordinate sweeps (cd_static_sweeps, kernels.hip.h): the lane's Gram column read from the wave's LDS tile at
+            // compile-time offsets
+            cd_static_sweeps<T, KP>(b, x, gd, fok, l1, nonneg, maxit, [&](auto IC) { return Gl[decltype(IC)::value * KP + ll]; });
         }
         RK_WAVE_SYNC();
         const T rel = fok ? tabs(x - xo) / (tabs(xo) + T(1e-12)) : T(0);

@@ -141,37 +141,10 @@ __global__ __launch_bounds__(256) void irls_nb_solve_kernel(
             b = tfma(-gw[c], xc, b);
         }
         const T gd = Gl[ll * KP + ll];
-        const T ginv = gd > T(0) ? T(1) / gd : T(0);
         // cd_nnls_col_fixed(G_w, b_c, x, L1 inside, L2 = 0, nonneg, cd_maxit, ub = 0, tol = 0): all sweeps
-        if constexpr (std::is_same<T, float>::value) {
-            // fp32: static coordinate sweeps (cd_static_sweeps_f32), the lane's Gram column read from the wave's LDS tile at
-            // compile-time offsets
-            cd_static_sweeps_f32<KP>(b, x, gd, fok, l1, nonneg, cd_maxit, [&](auto IC) { return Gl[decltype(IC)::value * KP + ll]; });
-        } else {
-            for (int it = 0; it < cd_maxit; ++it) {
-                int cur = 0;
-                bool any = false;
-                const auto x_sweep0 = x;
-                while (true) {
-                    T diff = sweep_quotient(b, gd, ginv);
-                    if (l1 != T(0)) diff -= l1;
-                    const T nv = x + diff;
-                    T ad = diff, nx = nv;
-                    if (nonneg && nv < T(0)) { ad = -x; nx = T(0); }
-                    const bool moves = fok && (gd > T(0)) && (ad != T(0)) && (lane >= cur);
-                    const unsigned long long mask = __ballot(moves);
-                    if (mask == 0ull) break;
-                    any = true;
-                    const int i = __builtin_ctzll(mask);
-                    const T ad_i = lane_value(ad, i);
-                    if (lane == i) x = nx;
-                    b = tfma(-Gl[i * KP + ll], ad_i, b);
-                    cur = i + 1;
-                    if (cur >= KP) break;
-                }
-                if (!any || !__any(x != x_sweep0)) break;      // no effective step, or the iterate is at its floating-point fixed point
-            }
-        }
+        // static coordinate sweeps (cd_static_sweeps, kernels.hip.h): the lane's Gram column read from the wave's LDS tile at
+        // compile-time offsets
+        cd_static_sweeps<T, KP>(b, x, gd, fok, l1, nonneg, cd_maxit, [&](auto IC) { return Gl[decltype(IC)::value * KP + ll]; });
         // IRLS convergence: max_i |x_i - x_old_i| / (|x_old_i| + 1e-12) < irls_tol
         T rel = fok ? tabs(x - x_old) / (tabs(x_old) + T(1e-12)) : T(0);
         rel = wave_max(rel);
@@ -563,29 +536,7 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8
             b = tfma(-Gl[c * KP + ll], xc, b);
         }
         const double gd = Gl[ll * KP + ll];
-        for (int it = 0; it < cd_maxit; ++it) {
-            int cur = 0;
-            bool any = false;
-            const auto x_sweep0 = x;
-            while (true) {
-                double diff = b / gd;
-                if (l1 != 0.0) diff -= l1;
-                const double nv = x + diff;
-                double ad = diff, nx = nv;
-                if (nonneg && nv < 0.0) { ad = -x; nx = 0.0; }
-                const bool moves = fok && (gd > 0.0) && (ad != 0.0) && (lane >= cur);
-                const unsigned long long mask = __ballot(moves);
-                if (mask == 0ull) break;
-                any = true;
-                const int i = __builtin_ctzll(mask);
-                const double ad_i = lane_value(ad, i);
-                if (lane == i) x = nx;
-                b = tfma(-Gl[i * KP + ll], ad_i, b);
-                cur = i + 1;
-                if (cur >= KP) break;
-            }
-            if (!any || !__any(x != x_sweep0)) break;      // no effective step, or the iterate is at its floating-point fixed point
-        }
+        cd_static_sweeps<double, KP>(b, x, gd, fok, l1, nonneg, cd_maxit, [&](auto IC) { return Gl[decltype(IC)::value * KP + ll]; });
         double rel = fok ? tabs(x - x_old) / (tabs(x_old) + 1e-12) : 0.0;
         rel = wave_max(rel);
         __builtin_amdgcn_wave_barrier();
