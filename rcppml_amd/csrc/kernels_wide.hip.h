@@ -105,43 +105,40 @@ template <class T> struct WideCol {
         for (int s = 0; s < 2; ++s) { gd[s] = Gl[(lane + 64 * s) * WKP + lane + 64 * s]; ginv[s] = gd[s] > T(0) ? T(1) / gd[s] : T(0); }
         const bool check = tol > T(0);
         const T inv_k = T(1) / static_cast<T>(k);
-        if constexpr (std::is_same<T, float>::value) {
-            if (!check) {
-                // fp32 without the relative-change stop (the CV / IRLS callers): static coordinate sweeps, as cd_static_sweeps_f32
-                // (kernels.hip.h) -- wave-uniform control flow, fma -> med3 -> readlane -> two fmas per coordinate, the tile's
-                // column read at compile-time LDS offsets, the iterate of lane i under a one-lane EXEC mask
-                const float pinf = __builtin_inff();
-                const float inf_rt = maxit >= 0 ? pinf : 0.f;
-                float gi[2], nl1[2], xe[2];
+        if (!check) {
+            // no relative-change stop (the CV / IRLS callers): static coordinate sweeps, as cd_static_sweeps (kernels.hip.h) --
+            // wave-uniform control flow, fma -> max -> readlane -> two fmas per coordinate, the tile's column read at
+            // compile-time LDS offsets, the iterate of lane i under a one-lane EXEC mask; the step multiplies by 1/G_ii
+            const T pinf = static_cast<T>(__builtin_inff());
+            const T inf_rt = maxit >= 0 ? pinf : T(0);
+            T gi[2], nl1[2], xe[2];
 #pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    const bool alive = ok[s] && gd[s] > 0.f;
-                    gi[s] = alive ? ginv[s] : 0.f;
-                    nl1[s] = alive ? -l1_in : 0.f;
-                    xe[s] = nonneg ? x[s] : pinf;
-                }
-                for (int it = 0; it < maxit; ++it) {
-                    const float xs0 = x[0], xs1 = x[1];
-                    cd_static_for<0, 2>([&](auto SC) {
-                        constexpr int s = decltype(SC)::value;
-                        cd_static_for<0, 64>([&](auto IC) {
-                            constexpr int i = decltype(IC)::value;
-                            constexpr int ci = i + 64 * s;
-                            if (ci < k) {          // wave-uniform
-                                const float diff = __builtin_fmaf(b[s], gi[s], nl1[s]);
-                                const float ad = __builtin_amdgcn_fmed3f(diff, -xe[s], inf_rt);
-                                const float ad_i = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(ad), i));
-                                asm volatile("s_mov_b64 s[2:3], exec\n\ts_mov_b64 exec, %2\n\tv_add_f32 %0, %0, %3\n\tv_add_f32 %1, %1, %3\n\ts_mov_b64 exec, s[2:3]"
-                                             : "+v"(x[s]), "+v"(xe[s]) : "s"(1ull << i), "v"(ad) : "s2", "s3");
-                                b[0] = __builtin_fmaf(-Gl[ci * WKP + lane], ad_i, b[0]);
-                                b[1] = __builtin_fmaf(-Gl[ci * WKP + lane + 64], ad_i, b[1]);
-                            }
-                        });
-                    });
-                    if (!__any(x[0] != xs0 || x[1] != xs1)) break;   // no step, or the iterate is at its floating-point fixed point
-                }
-                return;
+            for (int s = 0; s < 2; ++s) {
+                const bool alive = ok[s] && gd[s] > T(0);
+                gi[s] = alive ? ginv[s] : T(0);
+                nl1[s] = alive ? -l1_in : T(0);
+                xe[s] = nonneg ? x[s] : pinf;
             }
+            for (int it = 0; it < maxit; ++it) {
+                const T xs0 = x[0], xs1 = x[1];
+                cd_static_for<0, 2>([&](auto SC) {
+                    constexpr int s = decltype(SC)::value;
+                    cd_static_for<0, 64>([&](auto IC) {
+                        constexpr int i = decltype(IC)::value;
+                        constexpr int ci = i + 64 * s;
+                        if (ci < k) {          // wave-uniform
+                            const T diff = tfma(b[s], gi[s], nl1[s]);
+                            const T ad = cd_static_max(diff, -xe[s], inf_rt);
+                            const T ad_i = lane_value(ad, i);
+                            cd_masked_add2(x[s], xe[s], ad, 1ull << i);
+                            b[0] = tfma(-Gl[ci * WKP + lane], ad_i, b[0]);
+                            b[1] = tfma(-Gl[ci * WKP + lane + 64], ad_i, b[1]);
+                        }
+                    });
+                });
+                if (!__any(x[0] != xs0 || x[1] != xs1)) break;   // no step, or the iterate is at its floating-point fixed point
+            }
+            return;
         }
         for (int it = 0; it < maxit; ++it) {
             T tol_sum = T(0);
