@@ -96,6 +96,45 @@ __device__ __forceinline__ void cd_static_sweeps(T& b, T& x, T gd, bool fok, T l
         if (!__any(x != x_sweep0)) break;      // no effective step, or the iterate is at its floating-point fixed point
     }
 }
+// The same sweeps with the reference's relative-change stop (explicit-mask solver: cd_nnls with cd_tol, no L1 inside the step):
+// every lane keeps the step of ITS coordinate (third write under the one-lane mask) and the sum of |a_i| / (|x_i| + 1e-15) is
+// one division per lane and a wave reduction per sweep (xor tree: the reference adds the terms in coordinate order).
+__device__ __forceinline__ void cd_masked_add3(float& x, float& xe, float& aown, float ad, unsigned long long mask) {
+    asm volatile("s_mov_b64 s[2:3], exec\n\ts_mov_b64 exec, %3\n\tv_add_f32 %0, %0, %4\n\tv_add_f32 %1, %1, %4\n\tv_mov_b32 %2, %4\n\ts_mov_b64 exec, s[2:3]"
+                 : "+v"(x), "+v"(xe), "+v"(aown) : "s"(mask), "v"(ad) : "s2", "s3");
+}
+__device__ __forceinline__ void cd_masked_add3(double& x, double& xe, double& aown, double ad, unsigned long long mask) {
+    asm volatile("s_mov_b64 s[2:3], exec\n\ts_mov_b64 exec, %3\n\tv_add_f64 %0, %0, %4\n\tv_add_f64 %1, %1, %4\n\tv_add_f64 %2, %4, 0\n\ts_mov_b64 exec, s[2:3]"
+                 : "+v"(x), "+v"(xe), "+v"(aown) : "s"(mask), "v"(ad) : "s2", "s3");
+}
+template <class T, int KP, class GC>
+__device__ __forceinline__ void cd_static_sweeps_tol(T& b, T& x, T gd, bool fok, int nonneg, int maxit, T tol, int k, GC&& gcol) {
+    const bool alive = fok && gd > T(0);
+    const T ginv = alive ? T(1) / gd : T(0);
+    const T pinf = static_cast<T>(__builtin_inff());
+    T xe = nonneg ? x : pinf;
+    const T inf_rt = maxit >= 0 ? pinf : T(0);
+    const bool check = tol > T(0);
+    const T inv_k = T(1) / static_cast<T>(k);
+    for (int it = 0; it < maxit; ++it) {
+        const T x_sweep0 = x;
+        T aown = T(0);
+        cd_static_for<0, KP>([&](auto IC) {
+            constexpr int i = decltype(IC)::value;
+            const T diff = b * ginv;
+            const T ad = cd_static_max(diff, -xe, inf_rt);
+            const T ad_i = lane_value(ad, i);
+            cd_masked_add3(x, xe, aown, ad, 1ull << i);
+            b = tfma(-gcol(IC), ad_i, b);
+        });
+        if (check) {
+            T term = fok ? (aown < T(0) ? -aown : aown) / ((x < T(0) ? -x : x) + T(1e-15)) : T(0);
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) term += __shfl_xor(term, off, 64);
+            if (term * inv_k < tol) break;
+        } else if (!__any(x != x_sweep0)) break;
+    }
+}
 template <int KP, class GC>
 __device__ __forceinline__ void cd_static_sweeps_f32(float& b, float& x, float gd, bool fok, float l1, int nonneg, int maxit, GC&& gcol) {
     cd_static_sweeps<float, KP>(b, x, gd, fok, l1, nonneg, maxit, gcol);
@@ -2150,31 +2189,9 @@ __global__ __launch_bounds__(256) void masked_solve_kernel(
         x = y;
         if (nonneg) x = x > T(0) ? x : T(0);
     } else {
-        const bool check = tol > T(0);
-        const T inv_k = T(1) / static_cast<T>(k);
+        // cd_nnls_col_fixed with the relative-change stop, static coordinate sweeps (cd_static_sweeps_tol above)
         const T gd = Gl[ll * KP + ll];
-        const T ginv = gd > T(0) ? T(1) / gd : T(0);
-        for (int it = 0; it < maxit; ++it) {
-            T tol_sum = T(0);
-            int cur = 0;
-            while (true) {
-                const T diff = sweep_quotient(b, gd, ginv);
-                const T nv = x + diff;
-                T ad = diff, nx = nv;
-                if (nonneg && nv < T(0)) { ad = -x; nx = T(0); }
-                const bool moves = fok && (gd > T(0)) && (ad != T(0)) && (lane >= cur);
-                const unsigned long long mask = __ballot(moves);
-                if (mask == 0ull) break;
-                const int i = __builtin_ctzll(mask);
-                const T ad_i = lane_value(ad, i), nx_i = lane_value(nx, i);
-                if (lane == i) x = nx_i;
-                if (check) tol_sum += tabs(ad_i) / (tabs(nx_i) + T(1e-15));
-                b = tfma(-Gl[i * KP + ll], ad_i, b);
-                cur = i + 1;
-                if (cur >= KP) break;
-            }
-            if (check && tol_sum * inv_k < tol) break;
-        }
+        cd_static_sweeps_tol<T, KP>(b, x, gd, fok, nonneg, maxit, tol, k, [&](auto IC) { return Gl[decltype(IC)::value * KP + ll]; });
     }
     if (fok) X[j * (int64_t)k + lane] = x;
 }
