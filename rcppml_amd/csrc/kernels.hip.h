@@ -61,79 +61,81 @@ __device__ __forceinline__ double lane_value(double v, int i) {
 template <int B, int E, class Fn> __device__ __forceinline__ void cd_static_for(Fn&& fn) {
     if constexpr (B < E) { fn(std::integral_constant<int, B>{}); cd_static_for<B + 1, E>(fn); }
 }
-// x += ad, xe += ad in lane `mask`'s lanes only (one-lane EXEC mask; EXEC saved and restored)
-__device__ __forceinline__ void cd_masked_add2(float& x, float& xe, float ad, unsigned long long mask) {
-    asm volatile("s_mov_b64 s[2:3], exec\n\ts_mov_b64 exec, %2\n\tv_add_f32 %0, %0, %3\n\tv_add_f32 %1, %1, %3\n\ts_mov_b64 exec, s[2:3]"
-                 : "+v"(x), "+v"(xe) : "s"(mask), "v"(ad) : "s2", "s3");
+// v_writelane: value (wave-uniform, an SGPR after v_readlane) into lane I of v.  Inline asm (this hipcc has no writelane builtin);
+// the s_nop covers the VALU-writes-SGPR -> VALU-reads-it wait states hipcc itself places after a v_readlane.
+template <int I> __device__ __forceinline__ float cd_write_lane(float v, float value) {
+    asm volatile("s_nop 1\n\tv_writelane_b32 %0, %1, %2" : "+v"(v) : "s"(value), "n"(I));
+    return v;
 }
-__device__ __forceinline__ void cd_masked_add2(double& x, double& xe, double ad, unsigned long long mask) {
-    asm volatile("s_mov_b64 s[2:3], exec\n\ts_mov_b64 exec, %2\n\tv_add_f64 %0, %0, %3\n\tv_add_f64 %1, %1, %3\n\ts_mov_b64 exec, s[2:3]"
-                 : "+v"(x), "+v"(xe) : "s"(mask), "v"(ad) : "s2", "s3");
+template <int I> __device__ __forceinline__ double cd_write_lane(double v, double value) {
+    unsigned long long u = __double_as_longlong(v);
+    const unsigned long long w = __double_as_longlong(value);
+    unsigned lo = (unsigned)u, hi = (unsigned)(u >> 32);
+    asm volatile("s_nop 1\n\tv_writelane_b32 %0, %2, %4\n\tv_writelane_b32 %1, %3, %4" : "+v"(lo), "+v"(hi) : "s"((unsigned)w), "s"((unsigned)(w >> 32)), "n"(I));
+    return __longlong_as_double(((unsigned long long)hi << 32) | lo);
 }
 // max(a, b) on the step's chain: fp32 as v_med3_f32(a, b, +inf) (no canonicalising pre-op; `inf` must be a run-time +inf), fp64 plain
 __device__ __forceinline__ float cd_static_max(float a, float b, float inf) { return __builtin_amdgcn_fmed3f(a, b, inf); }
 __device__ __forceinline__ double cd_static_max(double a, double b, double) { return __builtin_fmax(a, b); }
+// One static sweep.  A coordinate is visited once per sweep, so the iterate a step sees is the one the sweep started with: the
+// sweep only COLLECTS every lane's own step (v_writelane of the broadcast value into lane i) and the iterate moves once, after
+// the last coordinate.  Per coordinate: fma, med3, v_readlane, v_writelane, fma.
 // fp64 note: the step multiplies by 1/G_ii formed once per solve (one rounding more than b / G_ii -- the same choice as the fp64 MSE
 // kernel, kernels_cd_mfma64.hip.h); an IEEE fp64 division is ~15 dependent instructions on the chain of every coordinate.
+template <class T, int KP, class GC>
+__device__ __forceinline__ T cd_static_one_sweep(T& b, T xe, T ginv, T nl1, T inf_rt, GC&& gcol) {
+    T aown = T(0);
+    cd_static_for<0, KP>([&](auto IC) {
+        constexpr int i = decltype(IC)::value;
+        const T diff = tfma(b, ginv, nl1);
+        const T ad = cd_static_max(diff, -xe, inf_rt);
+        const T ad_i = lane_value(ad, i);
+        b = tfma(-gcol(IC), ad_i, b);           // the chain goes on from here; collecting the step is off it
+        aown = cd_write_lane<i>(aown, ad_i);
+    });
+    return aown;
+}
 template <class T, int KP, class GC>
 __device__ __forceinline__ void cd_static_sweeps(T& b, T& x, T gd, bool fok, T l1, int nonneg, int maxit, GC&& gcol) {
     const bool alive = fok && gd > T(0);
     const T ginv = alive ? T(1) / gd : T(0);          // one division per solve
     const T nl1 = alive ? -l1 : T(0);
     const T pinf = static_cast<T>(__builtin_inff());
-    T xe = nonneg ? x : pinf;                         // the clamp's operand: max(diff, -xe) is max(diff, -x) or diff
     const T inf_rt = maxit >= 0 ? pinf : T(0);        // +inf at run time: with a literal LLVM folds the median back into maxnum
     for (int it = 0; it < maxit; ++it) {
-        const T x_sweep0 = x;
-        cd_static_for<0, KP>([&](auto IC) {
-            constexpr int i = decltype(IC)::value;
-            const T diff = tfma(b, ginv, nl1);
-            const T ad = cd_static_max(diff, -xe, inf_rt);
-            const T ad_i = lane_value(ad, i);
-            cd_masked_add2(x, xe, ad, 1ull << i);     // lane i only: x += ad, xe += ad (inf + ad = inf)
-            b = tfma(-gcol(IC), ad_i, b);
-        });
-        if (!__any(x != x_sweep0)) break;      // no effective step, or the iterate is at its floating-point fixed point
+        const T xe = nonneg ? x : pinf;               // the clamp's operand: max(diff, -xe) is max(diff, -x) or diff
+        const T aown = cd_static_one_sweep<T, KP>(b, xe, ginv, nl1, inf_rt, gcol);
+        const T xn = x + aown;
+        const bool moved = xn != x;
+        x = xn;
+        if (!__any(moved)) break;              // no effective step, or the iterate is at its floating-point fixed point
     }
 }
-// The same sweeps with the reference's relative-change stop (explicit-mask solver: cd_nnls with cd_tol, no L1 inside the step):
-// every lane keeps the step of ITS coordinate (third write under the one-lane mask) and the sum of |a_i| / (|x_i| + 1e-15) is
-// one division per lane and a wave reduction per sweep (xor tree: the reference adds the terms in coordinate order).
-__device__ __forceinline__ void cd_masked_add3(float& x, float& xe, float& aown, float ad, unsigned long long mask) {
-    asm volatile("s_mov_b64 s[2:3], exec\n\ts_mov_b64 exec, %3\n\tv_add_f32 %0, %0, %4\n\tv_add_f32 %1, %1, %4\n\tv_mov_b32 %2, %4\n\ts_mov_b64 exec, s[2:3]"
-                 : "+v"(x), "+v"(xe), "+v"(aown) : "s"(mask), "v"(ad) : "s2", "s3");
-}
-__device__ __forceinline__ void cd_masked_add3(double& x, double& xe, double& aown, double ad, unsigned long long mask) {
-    asm volatile("s_mov_b64 s[2:3], exec\n\ts_mov_b64 exec, %3\n\tv_add_f64 %0, %0, %4\n\tv_add_f64 %1, %1, %4\n\tv_add_f64 %2, %4, 0\n\ts_mov_b64 exec, s[2:3]"
-                 : "+v"(x), "+v"(xe), "+v"(aown) : "s"(mask), "v"(ad) : "s2", "s3");
-}
+// The same sweeps with the reference's relative-change stop (explicit-mask solver, small-side MSE solver: cd_nnls with cd_tol, no
+// L1 inside the step): the sum of |a_i| / (|x_i| + 1e-15) is one division per lane and a wave reduction per sweep (xor tree: the
+// reference adds the terms in coordinate order).  Returns the number of sweeps.
 template <class T, int KP, class GC>
-__device__ __forceinline__ void cd_static_sweeps_tol(T& b, T& x, T gd, bool fok, int nonneg, int maxit, T tol, int k, GC&& gcol) {
+__device__ __forceinline__ int cd_static_sweeps_tol(T& b, T& x, T gd, bool fok, int nonneg, int maxit, T tol, int k, GC&& gcol) {
     const bool alive = fok && gd > T(0);
     const T ginv = alive ? T(1) / gd : T(0);
     const T pinf = static_cast<T>(__builtin_inff());
-    T xe = nonneg ? x : pinf;
     const T inf_rt = maxit >= 0 ? pinf : T(0);
     const bool check = tol > T(0);
     const T inv_k = T(1) / static_cast<T>(k);
     for (int it = 0; it < maxit; ++it) {
-        const T x_sweep0 = x;
-        T aown = T(0);
-        cd_static_for<0, KP>([&](auto IC) {
-            constexpr int i = decltype(IC)::value;
-            const T diff = b * ginv;
-            const T ad = cd_static_max(diff, -xe, inf_rt);
-            const T ad_i = lane_value(ad, i);
-            cd_masked_add3(x, xe, aown, ad, 1ull << i);
-            b = tfma(-gcol(IC), ad_i, b);
-        });
+        const T xe = nonneg ? x : pinf;
+        const T aown = cd_static_one_sweep<T, KP>(b, xe, ginv, T(0), inf_rt, gcol);
+        const T xn = x + aown;
+        const bool moved = xn != x;
+        x = xn;
         if (check) {
             T term = fok ? (aown < T(0) ? -aown : aown) / ((x < T(0) ? -x : x) + T(1e-15)) : T(0);
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) term += __shfl_xor(term, off, 64);
-            if (term * inv_k < tol) break;
-        } else if (!__any(x != x_sweep0)) break;
+            if (term * inv_k < tol) return it + 1;
+        } else if (!__any(moved)) return it + 1;
     }
+    return maxit;
 }
 template <int KP, class GC>
 __device__ __forceinline__ void cd_static_sweeps_f32(float& b, float& x, float gd, bool fok, float l1, int nonneg, int maxit, GC&& gcol) {
@@ -900,6 +902,47 @@ __device__ __forceinline__ void cd_stats_add(unsigned long long* stats, int nsw,
         atomicAdd(stats, (unsigned long long)v);
         atomicAdd(stats + 1, (unsigned long long)c);
     }
+}
+
+// ---------------------------------------------------------------------------
+// CD NNLS for SMALL sides (fewer columns than ~1.5 waves per SIMD: C3's 610 columns, hawaiibirds): one wavefront per column,
+// lane = coordinate, the lane's column of the SHARED Gram in registers, static coordinate sweeps with the relative-change stop
+// (cd_static_sweeps_tol).  With so few columns every wave runs alone on its SIMD and the solve lasts as long as one column's
+// dependent chain: four instructions per coordinate here against ~150 cycles per coordinate for a lone 32-column MFMA tile
+// (C3, k = 32, 610 columns).  Non-negativity only (what the NMF half-updates use); reference
+// nnls_batch.hpp:70-132, prologue fused_nnls.hpp:116-123.
+// ---------------------------------------------------------------------------
+template <class T, int KP>
+__global__ __launch_bounds__(256) void cd_wave_static_kernel(const T* __restrict__ G /* k x k */, const T* __restrict__ B,
+                                                              T* __restrict__ X, int k, int64_t ncols, T l1_pre, int warm,
+                                                              int zero_init, int maxit, T tol, T ub_post,
+                                                              int* __restrict__ sweeps, unsigned long long* __restrict__ stats) {
+    const int lane = threadIdx.x & 63;
+    const int64_t j = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (j >= ncols) return;                      // whole waves only
+    const bool fok = lane < k;
+    const int ll = fok ? lane : 0;
+    T gcol[KP];                                  // G(i, lane), identity padding
+#pragma unroll
+    for (int i = 0; i < KP; ++i) gcol[i] = (fok && i < k) ? G[(int64_t)i * k + ll] : (i == lane ? T(1) : T(0));
+    const T gd = fok ? G[(int64_t)ll * k + ll] : T(1);
+    T b = fok ? B[j * (int64_t)k + ll] - l1_pre : T(0);        // b - 0 is exact
+    T x = (fok && !zero_init) ? X[j * (int64_t)k + ll] : T(0);
+    if (warm) {                                  // b -= G x
+        const T xw = x;
+        cd_static_for<0, KP>([&](auto IC) {
+            constexpr int i = decltype(IC)::value;
+            b = tfma(-gcol[i], lane_value(xw, i), b);
+        });
+    }
+    const int nsweep = cd_static_sweeps_tol<T, KP>(b, x, gd, fok, 1, maxit, tol, k, [&](auto IC) { return gcol[decltype(IC)::value]; });
+    if (fok) {
+        T val = x;
+        if (ub_post > T(0)) val = val < ub_post ? val : ub_post;
+        X[j * (int64_t)k + lane] = val;
+    }
+    if (sweeps && lane == 0) sweeps[j] = nsweep;
+    cd_stats_add(stats, lane == 0 ? nsweep : 0, lane == 0 ? 1 : 0);
 }
 
 template <class T, int KP, int LPC, bool EXACT>

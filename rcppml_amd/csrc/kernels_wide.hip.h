@@ -111,16 +111,17 @@ template <class T> struct WideCol {
             // compile-time LDS offsets, the iterate of lane i under a one-lane EXEC mask; the step multiplies by 1/G_ii
             const T pinf = static_cast<T>(__builtin_inff());
             const T inf_rt = maxit >= 0 ? pinf : T(0);
-            T gi[2], nl1[2], xe[2];
+            T gi[2], nl1[2];
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 const bool alive = ok[s] && gd[s] > T(0);
                 gi[s] = alive ? ginv[s] : T(0);
                 nl1[s] = alive ? -l1_in : T(0);
-                xe[s] = nonneg ? x[s] : pinf;
             }
             for (int it = 0; it < maxit; ++it) {
-                const T xs0 = x[0], xs1 = x[1];
+                T xe[2], aown[2] = {T(0), T(0)};       // a coordinate is visited once per sweep: the steps are collected, x moves after the sweep
+#pragma unroll
+                for (int s = 0; s < 2; ++s) xe[s] = nonneg ? x[s] : pinf;
                 cd_static_for<0, 2>([&](auto SC) {
                     constexpr int s = decltype(SC)::value;
                     cd_static_for<0, 64>([&](auto IC) {
@@ -130,13 +131,16 @@ template <class T> struct WideCol {
                             const T diff = tfma(b[s], gi[s], nl1[s]);
                             const T ad = cd_static_max(diff, -xe[s], inf_rt);
                             const T ad_i = lane_value(ad, i);
-                            cd_masked_add2(x[s], xe[s], ad, 1ull << i);
+                            aown[s] = cd_write_lane<i>(aown[s], ad_i);
                             b[0] = tfma(-Gl[ci * WKP + lane], ad_i, b[0]);
                             b[1] = tfma(-Gl[ci * WKP + lane + 64], ad_i, b[1]);
                         }
                     });
                 });
-                if (!__any(x[0] != xs0 || x[1] != xs1)) break;   // no step, or the iterate is at its floating-point fixed point
+                const T x0n = x[0] + aown[0], x1n = x[1] + aown[1];
+                const bool moved = x0n != x[0] || x1n != x[1];
+                x[0] = x0n; x[1] = x1n;
+                if (!__any(moved)) break;   // no step, or the iterate is at its floating-point fixed point
             }
             return;
         }

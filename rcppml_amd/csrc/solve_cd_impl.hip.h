@@ -165,6 +165,23 @@ static void solve_cd_impl(rcppml_hip_ctx* c, const T* G, const T* B, T* X, int k
             rcppml_cd_lmf_dispatch(c, G, B, X, k, ncols, l1_pre, warm, zero_init, maxit, tol, ub_post, sweeps, order);
         return;
     }
+    // Small sides (at most ~1.5 columns per SIMD): one wavefront per column with static coordinate sweeps -- every wave runs alone
+    // there and the solve lasts as long as one column's dependent chain (cd_wave_static_kernel, kernels.hip.h)
+    if (variant == RCPPML_CD_AUTO && k <= 64 && nonneg && ub_cd <= T(0) && l1_cd == T(0) && l2_cd == T(0) && maxit >= 1 &&
+        ncols <= (int64_t)6 * (c->num_cu > 0 ? c->num_cu : 256) && !exp_env("RCPPML_GPU_CD_VARIANT")) {
+        const unsigned nblk = (unsigned)((ncols + 3) / 4);
+        if (k <= 16)
+            hipLaunchKernelGGL((cd_wave_static_kernel<T, 16>), dim3(nblk), dim3(256), 0, c->stream, G, B, X, k, ncols, l1_pre, warm, zero_init,
+                               maxit, tol, ub_post, sweeps, c->stats);
+        else if (k <= 32)
+            hipLaunchKernelGGL((cd_wave_static_kernel<T, 32>), dim3(nblk), dim3(256), 0, c->stream, G, B, X, k, ncols, l1_pre, warm, zero_init,
+                               maxit, tol, ub_post, sweeps, c->stats);
+        else
+            hipLaunchKernelGGL((cd_wave_static_kernel<T, 64>), dim3(nblk), dim3(256), 0, c->stream, G, B, X, k, ncols, l1_pre, warm, zero_init,
+                               maxit, tol, ub_post, sweeps, c->stats);
+        HIPCHK(hipGetLastError());
+        return;
+    }
     if (variant == RCPPML_CD_AUTO) {
         const char* e = exp_env("RCPPML_GPU_CD_VARIANT");
         if (e && !strcmp(e, "lane")) variant = RCPPML_CD_LANE;

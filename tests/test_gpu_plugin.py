@@ -284,7 +284,9 @@ def test_degenerate_inputs(abi, entry):
         tol = 1e-6 if entry == "double" else 5e-3
         # exact fits leave the Gram-trick loss at the cancellation floor of tr(A'A): compare on that scale too
         floor = (1e-12 if entry == "double" else 1e-5) * float(np.sum(A.x ** 2))
-        assert abs(res["loss"] - ref.loss) <= tol * abs(ref.loss) + floor + 1e-18, (name, res["loss"], ref.loss)
+        # (absolute floor: with an all-zero matrix the fp32 kernels, which multiply by 1/G_ii where the reference divides, may leave
+        #  factors of ~1e-9 instead of exact zeros -- a loss of 1e-18 where the oracle's is 0)
+        assert abs(res["loss"] - ref.loss) <= tol * abs(ref.loss) + floor + (1e-18 if entry == "double" else 1e-15), (name, res["loss"], ref.loss)
         if name == "identical_cols":
             R = (W * res["d"][None, :]) @ H.T
             assert np.linalg.norm(R - D) / np.linalg.norm(D) < 1e-2
