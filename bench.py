@@ -633,13 +633,17 @@ def plugin_figure(A, m, n, k, seed):
     W0, H0 = data.init_factors(seed, k, m, n, np.float64)
     p, i, x = A.p.astype(np.int32), A.i.astype(np.int32), A.x.astype(np.float64)
     t = {}
-    for iters in (1, 1, 11, 21):
-        W, H = W0.copy(), H0.copy()
+    for iters in (1, 1, 11, 21, 1, 11, 21):          # the first call warms the process up; then the best of two per length
+        W, H = W0.copy(), H0.copy()                  # (a single shot now and then catches a host hiccup of 100+ ms)
         t0 = time.perf_counter()
         r = _abi.nmf_unified(p, i, x, m, n, k, W, H, entry="float", max_iter=iters, tol=0.0, solver_mode=0)
-        t[iters] = time.perf_counter() - t0
+        dt = time.perf_counter() - t0
         if r["status"] != 0:
             raise RuntimeError(r.get("error"))
+        if iters == 1 and 1 not in t:
+            t[1] = float("inf")                      # warm-up call: not counted
+            continue
+        t[iters] = min(t.get(iters, float("inf")), dt)
     slope = (t[11] - t[1]) / 10
     steady = (t[21] - t[11]) / 10
     return {"entry": "rcppml_gpu_nmf_unified_float", "ms_per_iteration": slope * 1e3, "ms_per_iteration_steady": steady * 1e3,
