@@ -47,16 +47,17 @@ __device__ __forceinline__ double lane_value(double v, int i) {
 }
 
 // ---------------------------------------------------------------------------
-// Static coordinate sweeps for the wave-per-column CD solves with a PER-COLUMN Gram (IRLS, CV; fp32, lane = feature, the lane's
-// column of the Gram in registers): cd_nnls_col_fixed(G, b, x, L1 inside, nonneg, maxit, tol = 0) with the fixed-point exit.
+// Static coordinate sweeps for the wave-per-column CD solves (IRLS, CV, explicit masks with their PER-COLUMN Gram; the small-side
+// MSE solve with the shared one; lane = feature, the lane's column of the Gram in registers or an LDS tile):
+// cd_nnls_col_fixed(G, b, x, L1 inside, nonneg, maxit, tol = 0) with the fixed-point exit, or with the relative-change stop.
 // Every coordinate is visited in turn with wave-uniform control flow: each lane evaluates the step of ITS coordinate from its own
 // residual and iterate (fma, med3), coordinate i's is read with one v_readlane at a compile-time lane and applied to all
-// residuals with one fma on a compile-time register; the iterate of lane i moves under a one-lane EXEC mask.  Dependent chain
-// per coordinate: fma -> med3 -> readlane -> fma.  The form this replaces found the next coordinate that moves with a ballot and
+// residuals with one fma on a compile-time register; the steps are collected per lane (v_writelane) and the iterate moves once
+// per sweep (cd_static_one_sweep).  Dependent chain per coordinate: fma -> med3 -> readlane -> fma.  The form this replaces found the next coordinate that moves with a ballot and
 // skipped the others: ~16 VALU + a dozen SALU operations and two branches per MOVING coordinate, all on one chain -- these
 // kernels are latency-bound even at eight waves per SIMD (four waves: 1.8x slower), so the chain length is what counts (C5:
-// NB iteration 32.4 -> 24.7 ms).  A dead diagonal / a lane beyond k holds 1/G_ii = 0 and no L1: its step is max(0, -x) = 0.
-// gcol(std::integral_constant<int, i>) = G(i, lane).  Must be called with all 64 lanes active.
+// NB iteration 32.4 -> 22.5 ms).  A dead diagonal / a lane beyond k holds 1/G_ii = 0 and no L1: its step is max(0, -x) = 0.
+// gcol(std::integral_constant<int, i>) = G(i, lane).
 // ---------------------------------------------------------------------------
 template <int B, int E, class Fn> __device__ __forceinline__ void cd_static_for(Fn&& fn) {
     if constexpr (B < E) { fn(std::integral_constant<int, B>{}); cd_static_for<B + 1, E>(fn); }

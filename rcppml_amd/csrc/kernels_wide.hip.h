@@ -108,7 +108,7 @@ template <class T> struct WideCol {
         if (!check) {
             // no relative-change stop (the CV / IRLS callers): static coordinate sweeps, as cd_static_sweeps (kernels.hip.h) --
             // wave-uniform control flow, fma -> max -> readlane -> two fmas per coordinate, the tile's column read at
-            // compile-time LDS offsets, the iterate of lane i under a one-lane EXEC mask; the step multiplies by 1/G_ii
+            // compile-time LDS offsets, the steps collected per lane and the iterate moved once per sweep; the step multiplies by 1/G_ii
             const T pinf = static_cast<T>(__builtin_inff());
             const T inf_rt = maxit >= 0 ? pinf : T(0);
             T gi[2], nl1[2];
