@@ -138,6 +138,36 @@ __device__ __forceinline__ int cd_static_sweeps_tol(T& b, T& x, T gd, bool fok, 
     }
     return maxit;
 }
+// fp32, Gram column in REGISTERS: the sweep carries the SCALED residual d = b / G_ii - L1 (the quotient the step starts from) instead
+// of b, with the lane's Gram column scaled once per solve (gg_i = G(i, lane) / G(lane, lane)): d -= gg_i a_i is the same update in
+// exact arithmetic, and the quotient's fma leaves the chain -- med3 -> readlane -> fma per coordinate.  Rounding differs from
+// b * (1/G_ii) by an ulp here and there (fp32 fast path only; the fp64 kernels keep b).  gcol[] is overwritten.
+template <int KP>
+__device__ __forceinline__ void cd_static_sweeps_scaled_f32(float b, float& x, float gd, bool fok, float l1, int nonneg, int maxit,
+                                                            float (&gcol)[KP]) {
+    const bool alive = fok && gd > 0.f;
+    const float ginv = alive ? 1.f / gd : 0.f;
+    const float pinf = __builtin_inff();
+    const float inf_rt = maxit >= 0 ? pinf : 0.f;
+#pragma unroll
+    for (int i = 0; i < KP; ++i) gcol[i] *= ginv;
+    float d = __builtin_fmaf(b, ginv, alive ? -l1 : 0.f);
+    for (int it = 0; it < maxit; ++it) {
+        const float xe = nonneg ? x : pinf;
+        float aown = 0.f;
+        cd_static_for<0, KP>([&](auto IC) {
+            constexpr int i = decltype(IC)::value;
+            const float ad = cd_static_max(d, -xe, inf_rt);
+            const float ad_i = lane_value(ad, i);
+            d = __builtin_fmaf(-gcol[i], ad_i, d);
+            aown = cd_write_lane<i>(aown, ad_i);
+        });
+        const float xn = x + aown;
+        const bool moved = xn != x;
+        x = xn;
+        if (!__any(moved)) break;
+    }
+}
 template <int KP, class GC>
 __device__ __forceinline__ void cd_static_sweeps_f32(float& b, float& x, float gd, bool fok, float l1, int nonneg, int maxit, GC&& gcol) {
     cd_static_sweeps<float, KP>(b, x, gd, fok, l1, nonneg, maxit, gcol);
@@ -1755,7 +1785,12 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8
         f32x32 gcol;
 #pragma unroll
         for (int c = 0; c < KP; ++c) gcol[c] = Gl[c * KP + ll];
-        cd_static_sweeps_f32<KP>(b, x, gd, fok, l1, nonneg, maxit, [&](auto IC) { return gcol[decltype(IC)::value]; });
+        {
+            float gg[KP];
+#pragma unroll
+            for (int c = 0; c < KP; ++c) gg[c] = gcol[c];
+            cd_static_sweeps_scaled_f32<KP>(b, x, gd, fok, l1, nonneg, maxit, gg);
+        }
     }
     if (fok) X[j * (int64_t)k + lane] = x;
 }
@@ -1899,10 +1934,12 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2
         f32x32 gcol0, gcol1;                                            //  s_set_gpr_idx, 64-element ones through scratch)
 #pragma unroll
         for (int c = 0; c < 32; ++c) { gcol0[c] = Gl[c * KP + ll]; gcol1[c] = Gl[(32 + c) * KP + ll]; }
-        cd_static_sweeps_f32<KP>(b, x, gd, fok, l1, nonneg, maxit, [&](auto IC) {
-            constexpr int i = decltype(IC)::value;
-            return i < 32 ? gcol0[i & 31] : gcol1[i & 31];
-        });
+        {
+            float gg[KP];
+#pragma unroll
+            for (int c = 0; c < 32; ++c) { gg[c] = gcol0[c]; gg[32 + c] = gcol1[c]; }
+            cd_static_sweeps_scaled_f32<KP>(b, x, gd, fok, l1, nonneg, maxit, gg);
+        }
     }
     if (fok) X[j * (int64_t)k + lane] = x;
 }

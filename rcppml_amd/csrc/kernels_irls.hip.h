@@ -272,7 +272,12 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8
         }
         const float gd = Gl[ll * KP + ll];
         // cd_nnls_col_fixed(G_w, b_c, x, L1 inside, L2 = 0, nonneg, cd_maxit, ub = 0, tol = 0): all sweeps, static form (kernels.hip.h)
-        cd_static_sweeps_f32<KP>(b, x, gd, fok, l1, nonneg, cd_maxit, [&](auto IC) { return gcol[decltype(IC)::value]; });
+        {
+            float gg[KP];
+#pragma unroll
+            for (int c = 0; c < KP; ++c) gg[c] = gcol[c];
+            cd_static_sweeps_scaled_f32<KP>(b, x, gd, fok, l1, nonneg, cd_maxit, gg);
+        }
         float rel = fok ? tabs(x - x_old) / (tabs(x_old) + 1e-12f) : 0.f;
         rel = wave_max(rel);
         __builtin_amdgcn_wave_barrier();
@@ -407,10 +412,12 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2
         }
         const float gd = Gl[lane * KP + lane];
         // cd_nnls_col_fixed(G_w, b_c, x, L1 inside, L2 = 0, nonneg, cd_maxit, ub = 0, tol = 0): all sweeps, static form (kernels.hip.h)
-        cd_static_sweeps_f32<KP>(b, x, gd, fok, l1, nonneg, cd_maxit, [&](auto IC) {
-            constexpr int i = decltype(IC)::value;
-            return i < 32 ? gcol0[i & 31] : gcol1[i & 31];
-        });
+        {
+            float gg[KP];
+#pragma unroll
+            for (int c = 0; c < 32; ++c) { gg[c] = gcol0[c]; gg[32 + c] = gcol1[c]; }
+            cd_static_sweeps_scaled_f32<KP>(b, x, gd, fok, l1, nonneg, cd_maxit, gg);
+        }
         float rel = fok ? tabs(x - x_old) / (tabs(x_old) + 1e-12f) : 0.f;
         rel = wave_max(rel);
         __builtin_amdgcn_wave_barrier();
