@@ -223,7 +223,7 @@ __device__ __forceinline__ void rt_glds4_nc(const char* base_uniform, unsigned l
     } else {
         unsigned long long keep;
         asm volatile("s_mov_b32 m0, %3\n\tv_cmp_gt_u32 vcc, %4, %1\n\ts_and_saveexec_b64 %0, vcc\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b64 exec, %0"
-                     : "=&s"(keep) : "v"(lane_off), "s"(base_uniform), "s"(lds_addr_uniform), "n"(LIMIT) : "vcc");
+                     : "=&s"(keep) : "v"(lane_off), "s"(base_uniform), "s"(lds_addr_uniform), "n"(LIMIT) : "vcc", "scc");
     }
 }
 #ifdef RCPPML_EXPERIMENTS
@@ -232,12 +232,12 @@ __device__ __forceinline__ void rt_glds4_nc(const char* base_uniform, unsigned l
 __device__ __forceinline__ void rt_glds16_rt(const char* base_uniform, unsigned lane_off, unsigned lds_addr_uniform, unsigned limit) {
     unsigned long long keep;
     asm volatile("s_mov_b32 m0, %3\n\tv_cmp_gt_u32 vcc, %4, %1\n\ts_and_saveexec_b64 %0, vcc\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b64 exec, %0"
-                 : "=&s"(keep) : "v"(lane_off), "s"(base_uniform), "s"(lds_addr_uniform), "s"(limit) : "vcc");
+                 : "=&s"(keep) : "v"(lane_off), "s"(base_uniform), "s"(lds_addr_uniform), "s"(limit) : "vcc", "scc");
 }
 __device__ __forceinline__ void rt_glds4_rt(const char* base_uniform, unsigned lane_off, unsigned lds_addr_uniform, unsigned limit) {
     unsigned long long keep;
     asm volatile("s_mov_b32 m0, %3\n\tv_cmp_gt_u32 vcc, %4, %1\n\ts_and_saveexec_b64 %0, vcc\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b64 exec, %0"
-                 : "=&s"(keep) : "v"(lane_off), "s"(base_uniform), "s"(lds_addr_uniform), "s"(limit) : "vcc");
+                 : "=&s"(keep) : "v"(lane_off), "s"(base_uniform), "s"(lds_addr_uniform), "s"(limit) : "vcc", "scc");
 }
 #endif
 template <int N> __device__ __forceinline__ void rt_wait_vm() {

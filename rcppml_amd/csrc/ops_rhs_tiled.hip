@@ -242,8 +242,17 @@ extern "C" int rcppml_hip_rhs_plan_create(rcppml_hip_ctx* c, int dtype, const in
         *out = nullptr;
         HIPCHK(hipSetDevice(c->device));
         if (ncols > 0x7ffffff0ll || nrows > 0x7ffffff0ll) return 0;
-        if (dtype == RCPPML_F32) *out = build_plan<float>(c, dtype, col_ptr, row_idx, (const float*)values, ncols, nrows, k, partitions, slots);
-        else *out = build_plan<double>(c, dtype, col_ptr, row_idx, (const double*)values, ncols, nrows, k, partitions, slots);
+        // slots: 0 = choose (window plan first, slab plan if the window planner declines); 1 = slab plan, its own choice of S;
+        // 2..8 = slab plan with S slots per (column, tile); >= 100 = window plan with (slots - 100) / 4 slots per column and phase
+        if (slots == 0 || slots >= 100) {
+            const int rate_code = slots >= 100 ? slots - 100 : 0;
+            if (dtype == RCPPML_F32) *out = rcppml_rw_build_f32(c, col_ptr, row_idx, (const float*)values, ncols, nrows, k, partitions, rate_code);
+            else *out = rcppml_rw_build_f64(c, col_ptr, row_idx, (const double*)values, ncols, nrows, k, partitions, rate_code);
+            if (*out || slots >= 100) return 0;
+        }
+        const int S = slots == 1 ? 0 : slots;
+        if (dtype == RCPPML_F32) *out = build_plan<float>(c, dtype, col_ptr, row_idx, (const float*)values, ncols, nrows, k, partitions, S);
+        else *out = build_plan<double>(c, dtype, col_ptr, row_idx, (const double*)values, ncols, nrows, k, partitions, S);
         return 0;
     }
     RCPPML_CATCH_RET
@@ -253,6 +262,13 @@ extern "C" void rcppml_hip_rhs_plan_destroy(rcppml_rhs_plan* plan) { delete plan
 
 extern "C" int rcppml_hip_rhs_plan_info(const rcppml_rhs_plan* pl, double* out10 /* 11 doubles */) {
     if (!pl || !out10) return 1;
+    if (pl->kind == 1) {
+        const RhsWinGeom& W = pl->WG;
+        out10[0] = W.P; out10[1] = W.NW; out10[2] = W.nr; out10[3] = W.clo + W.nhi / 4.0; out10[4] = W.ncb; out10[5] = W.ntiles;
+        out10[6] = (double)pl->nslots; out10[7] = (double)pl->ovnnz; out10[8] = pl->fill; out10[9] = pl->stream_bytes;
+        out10[10] = (double)W.ncols;
+        return 0;
+    }
     const RhsTiledGeom& G = pl->G;
     out10[0] = G.P; out10[1] = G.NW; out10[2] = G.nr; out10[3] = G.S; out10[4] = G.ncb; out10[5] = G.ntiles;
     out10[6] = (double)pl->nslots; out10[7] = (double)pl->ovnnz; out10[8] = pl->fill;
@@ -268,9 +284,13 @@ extern "C" int rcppml_hip_rhs_planned(rcppml_hip_ctx* c, const rcppml_rhs_plan* 
         if (reinterpret_cast<uintptr_t>(F) % 16 || reinterpret_cast<uintptr_t>(B) % 16)
             throw std::runtime_error("rhs_planned: F and B must be 16-byte aligned");
         HIPCHK(hipSetDevice(c->device));
-        if (plan->dtype == RCPPML_F32) run_plan<float>(c, plan, (const float*)F, (float*)B);
+        if (plan->kind == 1) {
+            if (plan->dtype == RCPPML_F32) rcppml_rw_run_f32(c, plan, (const float*)F, (float*)B);
+            else rcppml_rw_run_f64(c, plan, (const double*)F, (double*)B);
+        } else if (plan->dtype == RCPPML_F32) run_plan<float>(c, plan, (const float*)F, (float*)B);
         else run_plan<double>(c, plan, (const double*)F, (double*)B);
         return 0;
     }
     RCPPML_CATCH_RET
 }
+

@@ -2,30 +2,7 @@
 // precision so the two sets of instantiations build in parallel).
 #pragma once
 #include <mutex>
-#include "common.hip.h"
-#include "kernels_rhs_tiled.hip.h"
-
-struct rcppml_rhs_plan {
-    int dtype = 0, k = 0, device = 0;
-    rk::RhsTiledGeom G{};
-    void* svals = nullptr;
-    uint16_t* soffs = nullptr;
-    int* ovptr = nullptr;
-    int* ovrow = nullptr;
-    void* ovval = nullptr;
-    void* Bp = nullptr;          // P > 1: per-partition partial outputs
-    const int* colptr = nullptr; // the caller's CSC (not owned): the tail columns go through the gather kernel
-    const int* rowidx = nullptr;
-    const void* vals = nullptr;
-    int64_t ovnnz = 0, nnz = 0, nslots = 0;
-    double ov_fraction = 0.0, fill = 0.0;
-    bool in_arena = false;       // buffers live in the creating context's per-fit arena (freed with it): nothing to free here
-    ~rcppml_rhs_plan() {
-        if (in_arena) return;
-        for (void* p : {svals, (void*)soffs, (void*)ovptr, (void*)ovrow, ovval, Bp})
-            if (p) (void)hipFree(p);
-    }
-};
+#include "rhs_plan.hip.h"
 
 namespace rt_launch {
 using namespace rk;

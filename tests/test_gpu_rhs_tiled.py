@@ -56,9 +56,48 @@ def _run(env, A, k, dtype, partitions=0, slots=0, expect_plan=True):
 def test_planned_rhs_slots(env, dtype, k, slots):
     # 700 rows: 2.7 tiles of 256 rows (k*s = 256 B) / 5.5 tiles of 128 rows; the last tile is short
     A = random_csc(700, 1500, 0.012, seed=slots + k)
-    info = _run(env, A, k, dtype, slots=slots)
+    info = _run(env, A, k, dtype, slots=slots)        # 0: the window plan (round 4); 2..8: the slab plan with that many slots
     if slots:
         assert info["slots"] == slots
+
+
+# window plans (kernels_rhs_win.hip.h): slots = 100 + 4 x (slots per column and 32 KiB phase); quarter steps up to 2, halves above
+WIN_RATES = [101, 102, 103, 104, 105, 106, 107, 108, 110, 112, 114, 116, 120, 124]
+
+
+@pytest.mark.parametrize("dtype,k", [(np.float32, 64), (np.float32, 128), (np.float64, 32), (np.float64, 64), (np.float64, 128)])
+@pytest.mark.parametrize("code", WIN_RATES)
+def test_window_rhs_rates(env, dtype, k, code):
+    # 700 rows: 5.5 phases of 128 rows (256-byte rows) ... 22 phases of 32 rows (1 KiB rows): a short last tile, a phase count
+    # that is not a multiple of four (the kernel pads with empty phases), overflow at the low rates
+    from rcppml_amd._abi import BackendError
+    A = random_csc(700, 1500, 0.012, seed=code + k)
+    try:
+        info = _run(env, A, k, dtype, slots=code)
+    except BackendError as e:           # a rate whose slot blocks do not fit the LDS behind the ring for every compiled shape
+        assert "not available" in str(e)
+        return
+    assert abs(info["slots"] - (code - 100) // 4) == 0          # plan_info reports the rate truncated to an integer
+
+
+@pytest.mark.parametrize("partitions", [1, 2, 3, 5, 8])
+@pytest.mark.parametrize("dtype,k", [(np.float32, 64), (np.float64, 64)])
+def test_window_rhs_partitions_and_overflow(env, partitions, dtype, k):
+    # 5 % dense: ~6 nonzeros per (column, 128-row tile) against one slot per phase -> most nonzeros overflow into the
+    # finishing kernel; partitions cut the 24 / 47 phases into uneven runs
+    A = random_csc(3000, 700, 0.05, seed=partitions)
+    info = _run(env, A, k, dtype, partitions=partitions, slots=104)
+    assert info["spilled_nnz"] > 0.3 * A.nnz
+    assert info["partitions"] == min(partitions, info["tiles"])
+
+
+def test_window_rhs_large_offsets_and_ring_wrap(env):
+    # 9 000 rows = 71 phases: every ring buffer is reused many times, offsets beyond 64 KiB (buffers 2 and 3) in use
+    A = random_csc(9000, 3000, 0.008, seed=4)
+    for code in (0, 106, 107):
+        _run(env, A, 64, np.float32, slots=code)
+    _run(env, A, 64, np.float64, slots=0)
+    _run(env, A.transpose(), 128, np.float32, slots=0)
 
 
 @pytest.mark.parametrize("partitions", [1, 2, 3, 8])
