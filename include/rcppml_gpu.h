@@ -259,11 +259,12 @@ RCPPML_GPU_API int rcppml_hip_transpose_csc(rcppml_hip_ctx* ctx, int dtype, int 
                                             const int* row_idx, const void* values, int* t_col_ptr, int* t_row_idx,
                                             void* t_values);
 /* The same transpose in two asynchronous steps (no stream synchronisation when the context serves temporaries from a per-fit
- * arena): _sort needs the row indices only -- row pointers of A^T and the nonzero positions sorted by row (sorted_pos: nnz
- * ints) -- so the plugin runs it while the VALUES are still crossing PCIe; _gather then fills t_row_idx / t_values (either
+ * arena): _sort needs the index arrays only -- it makes the row pointers of A^T and the nonzero positions sorted by row
+ * (sorted_pos: nnz ints; a stable counting sort over column chunks, own kernels) -- so the plugin runs it while the VALUES are
+ * still crossing PCIe; _gather then fills t_row_idx / t_values (either
  * may be NULL: indices before the values have arrived, values after). */
-RCPPML_GPU_API int rcppml_hip_transpose_csc_sort(rcppml_hip_ctx* ctx, int rows, int cols, int64_t nnz, const int* row_idx,
-                                                 int* t_col_ptr, int* sorted_pos);
+RCPPML_GPU_API int rcppml_hip_transpose_csc_sort(rcppml_hip_ctx* ctx, int rows, int cols, int64_t nnz, const int* col_ptr,
+                                                 const int* row_idx, int* t_col_ptr, int* sorted_pos);
 RCPPML_GPU_API int rcppml_hip_transpose_csc_gather(rcppml_hip_ctx* ctx, int dtype, int cols, int64_t nnz, const int* col_ptr,
                                                    const int* sorted_pos, const void* values, int* t_row_idx, void* t_values);
 RCPPML_GPU_API int rcppml_hip_cast(rcppml_hip_ctx* ctx, int dtype_src, const void* src, int dtype_dst, void* dst, int64_t n);

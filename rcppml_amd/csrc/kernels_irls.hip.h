@@ -723,12 +723,54 @@ __global__ __launch_bounds__(256) void dispersion_rows_kernel(
 
 // GLOBAL dispersion: every entry <- the mean (stat 0; GP, fit_cpu.hpp:1005-1008) or <- src[m/2] of the SORTED copy
 // (stat 1: nth_element at m/2; NB :1257-1262, phi :1664-1669).  Single block.
+// The median is found by an 8-bit radix SELECT on order-preserving integer keys (no sort: the reference only needs the element
+// nth_element would put at m / 2): per digit, a 256-bin histogram of the candidates that share the prefix found so far.
+template <class T> struct OrdKey;
+template <> struct OrdKey<float> {
+    typedef unsigned int U;
+    static __device__ __forceinline__ U enc(float v) { const U b = __float_as_uint(v); return b ^ ((b >> 31) ? 0xffffffffu : 0x80000000u); }
+    static __device__ __forceinline__ float dec(U k) { return __uint_as_float(k ^ ((k >> 31) ? 0x80000000u : 0xffffffffu)); }
+};
+template <> struct OrdKey<double> {
+    typedef unsigned long long U;
+    static __device__ __forceinline__ U enc(double v) { const U b = (U)__double_as_longlong(v); return b ^ ((b >> 63) ? ~0ull : 0x8000000000000000ull); }
+    static __device__ __forceinline__ double dec(U k) { return __longlong_as_double((long long)(k ^ ((k >> 63) ? 0x8000000000000000ull : ~0ull))); }
+};
 template <class T>
-__global__ __launch_bounds__(256) void vec_global_fill_kernel(T* __restrict__ x, const T* __restrict__ sorted, int64_t m, int stat) {
+__global__ __launch_bounds__(256) void vec_global_fill_kernel(T* __restrict__ x, int64_t m, int stat) {
     __shared__ double red[256];
+    __shared__ unsigned int hist[256];
+    __shared__ unsigned long long sel[2];              // [0] = digit chosen, [1] = rank left inside it
     T val;
     if (stat == 1) {
-        val = sorted[m / 2];
+        typedef typename OrdKey<T>::U U;
+        U prefix = 0, mask = 0;
+        unsigned long long kth = (unsigned long long)(m / 2);      // 0-based rank of the wanted element
+        for (int shift = (int)sizeof(U) * 8 - 8; shift >= 0; shift -= 8) {
+            hist[threadIdx.x] = 0;
+            __syncthreads();
+            for (int64_t i = threadIdx.x; i < m; i += 256) {
+                const U key = OrdKey<T>::enc(x[i]);
+                if ((key & mask) == prefix) atomicAdd(&hist[(unsigned)((key >> shift) & 0xff)], 1u);
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                unsigned long long run = 0;
+                int dgt = 0;
+                for (; dgt < 255; ++dgt) {
+                    if (run + hist[dgt] > kth) break;
+                    run += hist[dgt];
+                }
+                sel[0] = (unsigned long long)dgt;
+                sel[1] = kth - run;
+            }
+            __syncthreads();
+            prefix |= (U)sel[0] << shift;
+            mask |= (U)0xff << shift;
+            kth = sel[1];
+            __syncthreads();
+        }
+        val = OrdKey<T>::dec(prefix);
     } else {
         double acc = 0.0;
         for (int64_t i = threadIdx.x; i < m; i += 256) acc += static_cast<double>(x[i]);

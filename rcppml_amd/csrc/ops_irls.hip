@@ -4,7 +4,6 @@
 #include "common.hip.h"
 #include "kernels_irls.hip.h"
 #include "kernels_wide.hip.h"
-#include <hipcub/hipcub.hpp>
 
 using namespace rk;
 
@@ -137,16 +136,7 @@ extern "C" int rcppml_hip_nb_size_update(rcppml_hip_ctx* c, int dtype, const int
 template <class T>
 static void vec_global_impl(rcppml_hip_ctx* c, int stat, T* x, int64_t m) {
     if (m <= 0) return;
-    T* sorted = nullptr;
-    if (stat == 1) {
-        size_t tmp_bytes = 0;
-        HIPCHK(hipcub::DeviceRadixSort::SortKeys(nullptr, tmp_bytes, x, x, (int)m, 0, (int)sizeof(T) * 8, c->stream));
-        const size_t key_bytes = ((size_t)m * sizeof(T) + 255) / 256 * 256;
-        char* buf = static_cast<char*>(c->scratch(WS_RED2, key_bytes + tmp_bytes));
-        sorted = reinterpret_cast<T*>(buf);
-        HIPCHK(hipcub::DeviceRadixSort::SortKeys(buf + key_bytes, tmp_bytes, x, sorted, (int)m, 0, (int)sizeof(T) * 8, c->stream));
-    }
-    hipLaunchKernelGGL(vec_global_fill_kernel<T>, dim3(1), dim3(256), 0, c->stream, x, sorted, m, stat);
+    hipLaunchKernelGGL(vec_global_fill_kernel<T>, dim3(1), dim3(256), 0, c->stream, x, m, stat);
     HIPCHK(hipGetLastError());
 }
 extern "C" int rcppml_hip_vec_global(rcppml_hip_ctx* c, int dtype, int stat, void* x, int64_t m) {

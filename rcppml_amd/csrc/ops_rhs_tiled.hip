@@ -2,10 +2,10 @@
 // of one CSC matrix for one rank and precision, built once per fit on the device; rcppml_hip_rhs_planned runs it.
 // Reference semantics: primitives/cpu/rhs.hpp:52-70, fused_nnls.hpp:109-114 (same numbers as rcppml_hip_rhs up to
 // summation order).
-#include <hipcub/hipcub.hpp>
 #include <memory>
 #include <mutex>
 #include "rhs_tiled_launch.hip.h"
+#include "scan.hip.h"
 
 using namespace rk;
 
@@ -199,10 +199,7 @@ rcppml_rhs_plan* build_plan(rcppml_hip_ctx* c, int dtype, const int* colptr, con
     HIPCHK(hipGetLastError());
     plan_alloc(c, pl.get(), &pl->ovptr, ((size_t)ncols + 1) * sizeof(int));
     {
-        size_t sb = 0;
-        HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, sb, (int*)cnt.p, pl->ovptr, (int)(ncols + 1), c->stream));
-        DevTmp st(c, sb);
-        HIPCHK(hipcub::DeviceScan::ExclusiveSum(st.p, sb, (int*)cnt.p, pl->ovptr, (int)(ncols + 1), c->stream));
+        exclusive_scan_i32(c, (const int*)cnt.p, pl->ovptr, ncols + 1);
         int ovn = 0;
         HIPCHK(hipMemcpyAsync(&ovn, pl->ovptr + ncols, sizeof(int), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));

@@ -1,20 +1,71 @@
 // ops_setup.hip -- one-time setup of a fit on the device: CSC transpose (A^T for the W half-update, reference
 // nmf/fit_cpu.hpp:251-253 `At = A.transpose()`) and precision casts of the host's double buffers.
 //
-// The transpose is a STABLE radix sort of the nonzero positions by row index (rocPRIM through hipCUB: library sort, not
-// a hand-written one -- it runs once per fit): positions of one row stay in increasing order, i.e. column indices of
-// A^T come out sorted exactly as Eigen's transpose produces them.  Row pointers are a histogram + exclusive scan.
-#include <hipcub/hipcub.hpp>
+// The transpose is a STABLE counting sort of the nonzero positions by row index (own kernels, no library sort): the columns
+// are cut into B chunks; chunk b counts its nonzeros per row in LDS (transpose_count_kernel), a prefix over the chunks turns the
+// B x rows table into "where chunk b's first nonzero of row r goes" (transpose_prefix_kernel + the row-pointer scan), and
+// chunk b then walks its columns IN ORDER, handing out positions from LDS counters (transpose_scatter_kernel).  Positions of
+// one row stay in increasing order, i.e. column indices of A^T come out sorted exactly as Eigen's transpose produces them.
 #include "common.hip.h"
+#include "scan.hip.h"
 
 namespace {
 
-__global__ void iota_kernel(int* __restrict__ v, int64_t n) {
-    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) v[t] = (int)t;
+constexpr int TR_RCH = 32768;        // rows per pass: 128 KiB of LDS counters
+// chunk b = columns [b cpb, (b+1) cpb): nonzeros per row -> cnt[b][row]
+__global__ __launch_bounds__(256) void transpose_count_kernel(const int* __restrict__ p, const int* __restrict__ ri, int cols, int rows,
+                                                              int cpb, int* __restrict__ cnt) {
+    extern __shared__ int tr_lc[];
+    const int b = blockIdx.x;
+    const int c0 = b * cpb, c1 = c0 + cpb < cols ? c0 + cpb : cols;
+    const int e0 = p[c0], e1 = p[c1];
+    for (int r0 = 0; r0 < rows; r0 += TR_RCH) {
+        const int rc = rows - r0 < TR_RCH ? rows - r0 : TR_RCH;
+        for (int i = threadIdx.x; i < rc; i += 256) tr_lc[i] = 0;
+        __syncthreads();
+        for (int e = e0 + (int)threadIdx.x; e < e1; e += 256) {
+            const unsigned r = (unsigned)(ri[e] - r0);
+            if (r < (unsigned)rc) atomicAdd(&tr_lc[r], 1);
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < rc; i += 256) cnt[(size_t)b * rows + r0 + i] = tr_lc[i];
+        __syncthreads();
+    }
 }
-__global__ void row_hist_kernel(const int* __restrict__ ri, int64_t nnz, int* __restrict__ counts) {
-    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < nnz; t += (int64_t)gridDim.x * blockDim.x)
-        atomicAdd(&counts[ri[t]], 1);
+// cnt[b][r] <- sum of cnt[b'][r] over b' < b; rowcnt[r] <- the row's total (rowcnt[rows] = 0 feeds the pointer scan)
+__global__ void transpose_prefix_kernel(int* __restrict__ cnt, int rows, int B, int* __restrict__ rowcnt) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r > rows) return;
+    int run = 0;
+    if (r < rows)
+        for (int b = 0; b < B; ++b) {
+            const int t = cnt[(size_t)b * rows + r];
+            cnt[(size_t)b * rows + r] = run;
+            run += t;
+        }
+    rowcnt[r] = run;
+}
+// chunk b hands out the positions of its nonzeros: column by column (a barrier between columns keeps the positions of one row
+// in column order), inside a column the nonzeros of different rows in parallel
+__global__ __launch_bounds__(256) void transpose_scatter_kernel(const int* __restrict__ p, const int* __restrict__ ri, int cols, int rows,
+                                                                int cpb, const int* __restrict__ cnt, const int* __restrict__ tp,
+                                                                int* __restrict__ pos_out) {
+    extern __shared__ int tr_lc[];
+    const int b = blockIdx.x;
+    const int c0 = b * cpb, c1 = c0 + cpb < cols ? c0 + cpb : cols;
+    for (int r0 = 0; r0 < rows; r0 += TR_RCH) {
+        const int rc = rows - r0 < TR_RCH ? rows - r0 : TR_RCH;
+        for (int i = threadIdx.x; i < rc; i += 256) tr_lc[i] = tp[r0 + i] + cnt[(size_t)b * rows + r0 + i];
+        __syncthreads();
+        for (int j = c0; j < c1; ++j) {
+            const int e1 = p[j + 1];
+            for (int e = p[j] + (int)threadIdx.x; e < e1; e += 256) {
+                const unsigned r = (unsigned)(ri[e] - r0);
+                if (r < (unsigned)rc) pos_out[atomicAdd(&tr_lc[r], 1)] = e;
+            }
+            __syncthreads();
+        }
+    }
 }
 // column of the nonzero at position pos: largest j with p[j] <= pos
 __device__ __forceinline__ int col_of(const int* __restrict__ p, int cols, int pos) {
@@ -54,32 +105,30 @@ unsigned grid_for(int64_t n, int num_cu) {
 // The transpose in two steps, so that a caller can overlap the upload of the VALUES with the sort (which needs the row
 // indices only): begin = positions sorted by row + row pointers, finish = column indices and values gathered through the
 // sorted positions.  The sorted positions live in `pos_out` (nnz ints, caller-provided).
-void transpose_sort(rcppml_hip_ctx* c, int rows, int cols, int64_t nnz, const int* ri, int* tp, int* pos_out) {
+void transpose_sort(rcppml_hip_ctx* c, int rows, int cols, int64_t nnz, const int* p, const int* ri, int* tp, int* pos_out) {
     HIPCHK(hipMemsetAsync(tp, 0, ((size_t)rows + 1) * sizeof(int), c->stream));
-    if (nnz == 0) return;
-    DevTmp keys_out(c, (size_t)nnz * sizeof(int)), pos_in(c, (size_t)nnz * sizeof(int));
-    DevTmp counts(c, ((size_t)rows + 1) * sizeof(int));
-    int* kout = static_cast<int*>(keys_out.p);
-    int* pin = static_cast<int*>(pos_in.p);
-    int* cnt = static_cast<int*>(counts.p);
-    hipLaunchKernelGGL(iota_kernel, dim3(grid_for(nnz, c->num_cu)), dim3(256), 0, c->stream, pin, nnz);
+    if (nnz == 0 || rows <= 0 || cols <= 0) return;
+    // chunks: enough workgroups to fill the chip, the B x rows table at most 256 MB
+    int B = cols < 512 ? cols : 512;
+    const int64_t cap = (int64_t)(256u << 20) / ((int64_t)rows * 4);
+    if (B > cap) B = cap < 1 ? 1 : (int)cap;
+    const int cpb = (cols + B - 1) / B;
+    B = (cols + cpb - 1) / cpb;
+    DevTmp table(c, (size_t)B * rows * sizeof(int)), rowcnt(c, ((size_t)rows + 1) * sizeof(int));
+    const size_t lds = (size_t)(rows < TR_RCH ? rows : TR_RCH) * sizeof(int);
+    static DynSmemOnce once_count, once_scatter;
+    once_count.ensure(reinterpret_cast<const void*>(transpose_count_kernel), lds, c->device);
+    once_scatter.ensure(reinterpret_cast<const void*>(transpose_scatter_kernel), lds, c->device);
+    hipLaunchKernelGGL(transpose_count_kernel, dim3(B), dim3(256), lds, c->stream, p, ri, cols, rows, cpb, (int*)table.p);
+    hipLaunchKernelGGL(transpose_prefix_kernel, dim3((unsigned)((rows + 1 + 255) / 256)), dim3(256), 0, c->stream, (int*)table.p, rows, B,
+                       (int*)rowcnt.p);
     HIPCHK(hipGetLastError());
-    int end_bit = 1;
-    while ((1ll << end_bit) < rows) ++end_bit;
-    size_t tmp_bytes = 0;
-    HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, ri, kout, pin, pos_out, (int)nnz, 0, end_bit, c->stream));
-    DevTmp tmp(c, tmp_bytes);
-    HIPCHK(hipcub::DeviceRadixSort::SortPairs(tmp.p, tmp_bytes, ri, kout, pin, pos_out, (int)nnz, 0, end_bit, c->stream));
-    // row pointers: counts -> exclusive scan (rows + 1 entries, the last one = nnz)
-    HIPCHK(hipMemsetAsync(cnt, 0, ((size_t)rows + 1) * sizeof(int), c->stream));
-    hipLaunchKernelGGL(row_hist_kernel, dim3(grid_for(nnz, c->num_cu)), dim3(256), 0, c->stream, ri, nnz, cnt);
+    rk::exclusive_scan_i32(c, (const int*)rowcnt.p, tp, (int64_t)rows + 1);          // row pointers (the last one = nnz)
+    hipLaunchKernelGGL(transpose_scatter_kernel, dim3(B), dim3(256), lds, c->stream, p, ri, cols, rows, cpb, (const int*)table.p,
+                       (const int*)tp, pos_out);
     HIPCHK(hipGetLastError());
-    size_t scan_bytes = 0;
-    HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, cnt, tp, rows + 1, c->stream));
-    DevTmp stmp(c, scan_bytes);
-    HIPCHK(hipcub::DeviceScan::ExclusiveSum(stmp.p, scan_bytes, cnt, tp, rows + 1, c->stream));
     // temporaries from the context's per-fit arena outlive this call; hipMalloc'ed ones must not be freed under the kernels
-    if (keys_out.owned || pos_in.owned || counts.owned || tmp.owned || stmp.owned) HIPCHK(hipStreamSynchronize(c->stream));
+    if (table.owned || rowcnt.owned) HIPCHK(hipStreamSynchronize(c->stream));
 }
 template <class T>
 void transpose_gather(rcppml_hip_ctx* c, int cols, int64_t nnz, const int* p, const int* pos, const T* x, int* ti, T* tx) {
@@ -97,7 +146,7 @@ void transpose_impl(rcppml_hip_ctx* c, int rows, int cols, const int* p, const i
     HIPCHK(hipStreamSynchronize(c->stream));
     const int64_t nnz = nnz_i;
     DevTmp pos_out(c, (size_t)std::max<int64_t>(nnz, 1) * sizeof(int));
-    transpose_sort(c, rows, cols, nnz, ri, tp, static_cast<int*>(pos_out.p));
+    transpose_sort(c, rows, cols, nnz, p, ri, tp, static_cast<int*>(pos_out.p));
     transpose_gather<T>(c, cols, nnz, p, static_cast<const int*>(pos_out.p), x, ti, tx);
     HIPCHK(hipStreamSynchronize(c->stream));       // temporaries die here
 }
@@ -119,12 +168,12 @@ extern "C" int rcppml_hip_transpose_csc(rcppml_hip_ctx* c, int dtype, int rows, 
     RCPPML_CATCH_RET
 }
 
-extern "C" int rcppml_hip_transpose_csc_sort(rcppml_hip_ctx* c, int rows, int cols, int64_t nnz, const int* row_idx, int* t_col_ptr,
-                                             int* sorted_pos) {
+extern "C" int rcppml_hip_transpose_csc_sort(rcppml_hip_ctx* c, int rows, int cols, int64_t nnz, const int* col_ptr, const int* row_idx,
+                                             int* t_col_ptr, int* sorted_pos) {
     try {
         HIPCHK(hipSetDevice(c->device));
         if (rows < 0 || cols < 0 || nnz < 0) throw std::runtime_error("transpose_csc_sort: negative dimension");
-        transpose_sort(c, rows, cols, nnz, row_idx, t_col_ptr, sorted_pos);
+        transpose_sort(c, rows, cols, nnz, col_ptr, row_idx, t_col_ptr, sorted_pos);
         return 0;
     }
     RCPPML_CATCH_RET

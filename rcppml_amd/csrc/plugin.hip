@@ -129,7 +129,7 @@ void fit(FitParams& P) {
         dTi.alloc((size_t)std::max<int64_t>(P.nnz, 1) * sizeof(int));
         dTx.alloc((size_t)std::max<int64_t>(P.nnz, 1) * sizeof(T));
         DevBuf dpos((size_t)std::max<int64_t>(P.nnz, 1) * sizeof(int));
-        OPCHK(rcppml_hip_transpose_csc_sort(c, m, n, P.nnz, dAi.as<int>(), dTp.as<int>(), dpos.as<int>()));      // asynchronous (arena)
+        OPCHK(rcppml_hip_transpose_csc_sort(c, m, n, P.nnz, dAp.as<int>(), dAi.as<int>(), dTp.as<int>(), dpos.as<int>()));      // asynchronous (arena)
         OPCHK(rcppml_hip_transpose_csc_gather(c, dt, n, P.nnz, dAp.as<int>(), dpos.as<int>(), nullptr, dTi.as<int>(), nullptr));   // column indices of A^T
         hipStream_t s2 = g.second_stream();
         dAx.alloc((size_t)std::max<int64_t>(P.nnz, 1) * sizeof(T));
