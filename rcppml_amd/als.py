@@ -45,6 +45,11 @@ class AlsConfig:
     solver_mode: int = 0        # 0 = CD, 1 = Cholesky + clip
     cd_variant: int = 0         # 0 = auto (fp32: MFMA tiles, fp64 k <= 64: 16-column MFMA tiles, else lane-group), 1 = lane, 2 = wave, 5 = lane-group
     order_columns: bool = True  # schedule CD columns by the sweep counts of the previous iteration
+    # world > 1, W half-update: "block" = every rank solves its block of W's rows, one all-gather (the solve shrinks with the
+    # world size); "replicated" = every rank solves all of W from the all-reduced (G, B) and nothing is gathered (what the
+    # plugin's RCPPML_GPU_DEVICES path does by default).  Same numbers either way; which is faster over xGMI is a
+    # measurement the first 8-GPU run decides (unmeasured on hardware so far).
+    w_solve: str = "block"
 
 
 class HipOps:
@@ -276,6 +281,8 @@ class ShardedALS:
     """State of one rank: its column shard A_loc (m x n_loc), A_loc^T, H_loc (n_loc x k), replicated W_T (m x k)."""
 
     def __init__(self, ops, comm, A_loc, At_loc, W_T0, H0, cfg):
+        if cfg.w_solve not in ("block", "replicated"):
+            raise ValueError("AlsConfig.w_solve must be 'block' or 'replicated'")
         self.ops, self.comm, self.cfg = ops, comm, cfg
         self.m, self.n_loc, self.k = A_loc.rows, A_loc.cols, cfg.k
         self.A = ops.upload_csc(A_loc)
@@ -324,15 +331,23 @@ class ShardedALS:
         else:
             ops.gram(self.W_T, self.eps, cfg.L2_H, out=self.G, tag="gram")
             G_h = self.G
-        ops.rhs(self.A, self.W_T, out=self.Bh, tag="rhs_H")
-        ops.solve(G_h, self.Bh, self.H, cfg, "H", warm, tag="solve_H")
+        empty = self.n_loc == 0          # a rank whose shard holds no column (more ranks than columns): it only takes part in the exchange
+        if not empty:
+            ops.rhs(self.A, self.W_T, out=self.Bh, tag="rhs_H")
+            ops.solve(G_h, self.Bh, self.H, cfg, "H", warm, tag="solve_H")
         if comm.world > 1:
             # ---- W half-update, sharded (fit_cpu.hpp:711-893): partial sums from the UNSCALED H, one all-reduce, then D^-1
-            ops.row_norms(self.H, cfg.norm_type, out=self.xsums)
-            ops.gram(self.H, 0.0, 0.0, out=self.Gp, tag="gram")             # partial H_loc H_loc^T, eps after the sum
-            ops.rhs(self.At, self.H, out=self.Bw, tag="rhs_W")
+            if empty:
+                self.xbuf.zero_()
+            else:
+                ops.row_norms(self.H, cfg.norm_type, out=self.xsums)
+                ops.gram(self.H, 0.0, 0.0, out=self.Gp, tag="gram")             # partial H_loc H_loc^T, eps after the sum
+                ops.rhs(self.At, self.H, out=self.Bw, tag="rhs_W")
             comm.all_reduce_sum(self.xbuf, tag="all_reduce_gram_rhs_rowsums")
-            ops.apply_scaling(self.H, self.xsums, cfg.norm_type, self.d)     # H_loc <- H_loc D^-1, d = global row norms
+            if empty:
+                ops.apply_scaling(self.Gp[:1].clone(), self.xsums, cfg.norm_type, self.d)   # no column of H here: only d = the global row norms (on a scratch row)
+            else:
+                ops.apply_scaling(self.H, self.xsums, cfg.norm_type, self.d)     # H_loc <- H_loc D^-1, d = global row norms
             ops.apply_scaling(self.Bw, self.xsums, cfg.norm_type, self.d_tmp)        # B = B_raw D^-1
             ops.apply_scaling(self.Gp, self.xsums, cfg.norm_type, self.d_tmp)        # G[:, g] /= d_g ...
             self.Gp.copy_(self.Gp.t().contiguous())                                   # ... (k x k, symmetric up to rounding order)
@@ -353,7 +368,7 @@ class ShardedALS:
             G_w, G_saved = self.G, self.G_saved
         else:
             G_w, G_saved = self.Gp, self.Gp
-        if comm.world > 1:
+        if comm.world > 1 and cfg.w_solve == "block":
             if self.row_hi > self.row_lo:
                 ops.solve(G_w, self.Bw[self.row_lo:self.row_hi], self.W_T[self.row_lo:self.row_hi], cfg, "W", warm, tag="solve_W")
             comm.all_gather_rows(self.W_pad, self.rows_per)

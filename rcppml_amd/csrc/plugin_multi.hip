@@ -53,6 +53,7 @@ struct Rccl {
     decltype(&ncclCommInitAll) CommInitAll = nullptr;
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
     decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
     decltype(&ncclGroupStart) GroupStart = nullptr;
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
@@ -71,6 +72,7 @@ struct Rccl {
         CommInitAll = reinterpret_cast<decltype(CommInitAll)>(sym("ncclCommInitAll"));
         CommDestroy = reinterpret_cast<decltype(CommDestroy)>(sym("ncclCommDestroy"));
         AllReduce = reinterpret_cast<decltype(AllReduce)>(sym("ncclAllReduce"));
+        AllGather = reinterpret_cast<decltype(AllGather)>(sym("ncclAllGather"));
         GroupStart = reinterpret_cast<decltype(GroupStart)>(sym("ncclGroupStart"));
         GroupEnd = reinterpret_cast<decltype(GroupEnd)>(sym("ncclGroupEnd"));
         GetErrorString = reinterpret_cast<decltype(GetErrorString)>(sym("ncclGetErrorString"));
@@ -129,6 +131,30 @@ struct Exchange {
             rccl().chk(rccl().AllReduce(bufs[r], bufs[r], count, ty, ncclSum, comms[r], streams[r]), "ncclAllReduce");
         rccl().chk(rccl().GroupEnd(), "ncclGroupEnd");
     }
+    // In-place all-gather of equal blocks: block r (count elements at bufs[q] + r * count) of device r goes to every device q.
+    template <class T>
+    void all_gather(const std::vector<void*>& bufs, size_t count) {
+        if (n == 1) return;
+        if (shared) {
+            // every stream has written its own block -> each stream copies the other blocks once their owners are done
+            for (int r = 0; r < n; ++r) { HIPCHK(hipSetDevice(devs[r])); HIPCHK(hipEventRecord(ev[r], streams[r])); }
+            for (int q = 0; q < n; ++q) {
+                HIPCHK(hipSetDevice(devs[q]));
+                for (int r = 0; r < n; ++r) {
+                    if (r == q) continue;
+                    HIPCHK(hipStreamWaitEvent(streams[q], ev[r], 0));
+                    HIPCHK(hipMemcpyAsync((T*)bufs[q] + (size_t)r * count, (const T*)bufs[r] + (size_t)r * count, count * sizeof(T),
+                                          hipMemcpyDeviceToDevice, streams[q]));
+                }
+            }
+            return;
+        }
+        const ncclDataType_t ty = std::is_same<T, float>::value ? ncclFloat : ncclDouble;
+        rccl().chk(rccl().GroupStart(), "ncclGroupStart");
+        for (int r = 0; r < n; ++r)
+            rccl().chk(rccl().AllGather((const T*)bufs[r] + (size_t)r * count, bufs[r], count, ty, comms[r], streams[r]), "ncclAllGather");
+        rccl().chk(rccl().GroupEnd(), "ncclGroupEnd");
+    }
 };
 
 template <class T>
@@ -164,6 +190,14 @@ void fit_multi(FitParams& P, const std::vector<int>& devices, bool shared) {
             cut[r] = std::max(cut[r - 1], std::min(j, n));
         }
     }
+    // W half-update: "replicated" (default) = every device solves all m columns of W_T from the all-reduced (G, B);
+    // RCPPML_GPU_W_SOLVE=block = device r solves rows [r rows_per, (r+1) rows_per) and ONE all-gather replicates them (the harness's
+    // default, als.AlsConfig.w_solve).  Same numbers either way; which is faster over xGMI is for the first multi-GPU run to
+    // decide -- unmeasured on hardware so far.
+    const char* ws_env = getenv("RCPPML_GPU_W_SOLVE");
+    const bool w_block = nd > 1 && ws_env && !strcmp(ws_env, "block");
+    const int rows_per = w_block ? (((m + nd - 1) / nd + 3) / 4) * 4 : m;         // multiples of 4 rows: 16-byte aligned blocks for any k
+    const size_t w_elems = w_block ? (size_t)rows_per * nd * k : (size_t)k * m;
     std::vector<std::unique_ptr<Shard<T>>> S(nd);
     std::vector<hipStream_t> streams(nd);
     for (int r = 0; r < nd; ++r) {
@@ -189,7 +223,15 @@ void fit_multi(FitParams& P, const std::vector<int>& devices, bool shared) {
         s.Ti.alloc(nz * sizeof(int));
         s.Tx.alloc(nz * sizeof(T));
         OPCHK(rcppml_hip_transpose_csc(c, dt, m, s.n_loc, s.Ap.template as<int>(), s.Ai.template as<int>(), s.Ax.p, s.Tp.template as<int>(), s.Ti.template as<int>(), s.Tx.p));
-        upload_cast<T>(c, P.W, (size_t)k * m, s.W, s.g->s);
+        if (w_block) {           // padded so that every device owns a whole block; the pad rows stay zero
+            DevBuf w0;
+            upload_cast<T>(c, P.W, (size_t)k * m, w0, s.g->s);
+            s.W.alloc(w_elems * sizeof(T));
+            HIPCHK(hipMemsetAsync(s.W.p, 0, w_elems * sizeof(T), c->stream));
+            HIPCHK(hipMemcpyAsync(s.W.p, w0.p, (size_t)k * m * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
+            HIPCHK(hipStreamSynchronize(c->stream));
+        } else
+            upload_cast<T>(c, P.W, (size_t)k * m, s.W, s.g->s);
         if (s.n_loc > 0) upload_cast<T>(c, P.H + (size_t)k * s.c0, (size_t)k * s.n_loc, s.H, s.g->s);
         else { std::vector<double> hz(k, 0.0); upload_cast<T>(c, hz.data(), (size_t)k, s.H, s.g->s); }
         s.d.alloc((size_t)k * sizeof(T));
@@ -290,15 +332,31 @@ void fit_multi(FitParams& P, const std::vector<int>& devices, bool shared) {
                 hipLaunchKernelGGL(mg_diag_add_kernel<T>, dim3((k + 63) / 64), dim3(64), 0, st, (T*)s.G.p, k, (T)P.L2_W);   // :738
                 HIPCHK(hipGetLastError());
             }
+            const int lo = w_block ? std::min(m, r * rows_per) : 0, hi = w_block ? std::min(m, lo + rows_per) : m;
+            const int mb = hi - lo;                                      // the columns of W_T this device solves
+            if (mb > 0) {
+                void* Bb = T_ptr(s.xbuf, (size_t)k * k + (size_t)k * lo);
+                void* Wb = (T*)s.W.p + (size_t)k * lo;
+                if (P.solver_mode == 0) {
+                    const bool ord = use_order && iter > 0 && mb >= kOrderMinColumns;
+                    int* sw = use_order ? s.swW.template as<int>() + lo : nullptr;
+                    int* od = s.ordW.template as<int>() + lo;
+                    if (ord) OPCHK(rcppml_hip_order_columns(c, sw, mb, od));
+                    OPCHK(rcppml_hip_solve_cd(c, dt, s.G.p, Bb, Wb, k, mb, P.L1_W > 0 ? P.L1_W : 0.0, warm, 0, 0.0, 0.0, P.nonneg_W,
+                                              P.cd_maxit, P.cd_tol, 0.0, P.ub_W, RCPPML_CD_AUTO, sw, ord ? od : nullptr));
+                } else
+                    OPCHK(rcppml_hip_solve_chol(c, dt, s.G.p, Bb, Wb, k, mb, P.L1_W > 0 ? P.L1_W : 0.0, P.nonneg_W, P.ub_W));
+            }
+        }
+        if (w_block) {
+            for (int r = 0; r < nd; ++r) bufs[r] = S[r]->W.p;
+            X.template all_gather<T>(bufs, (size_t)rows_per * k);
+        }
+        for (int r = 0; r < nd; ++r) {
+            Shard<T>& s = *S[r];
+            rcppml_hip_ctx* c = s.g->c;
+            HIPCHK(hipSetDevice(s.dev));
             void* Bw = T_ptr(s.xbuf, (size_t)k * k);
-            if (P.solver_mode == 0) {
-                const bool ord = use_order && iter > 0 && m >= kOrderMinColumns;
-                if (ord) OPCHK(rcppml_hip_order_columns(c, s.swW.template as<int>(), m, s.ordW.template as<int>()));
-                OPCHK(rcppml_hip_solve_cd(c, dt, s.G.p, Bw, s.W.p, k, m, P.L1_W > 0 ? P.L1_W : 0.0, warm, 0, 0.0, 0.0, P.nonneg_W,
-                                          P.cd_maxit, P.cd_tol, 0.0, P.ub_W, RCPPML_CD_AUTO, use_order ? s.swW.template as<int>() : nullptr,
-                                          ord ? s.ordW.template as<int>() : nullptr));
-            } else
-                OPCHK(rcppml_hip_solve_chol(c, dt, s.G.p, Bw, s.W.p, k, m, P.L1_W > 0 ? P.L1_W : 0.0, P.nonneg_W, P.ub_W));
             OPCHK(rcppml_hip_row_norms(c, dt, s.W.p, k, m, P.norm_type, s.sums.p));
             OPCHK(rcppml_hip_apply_scaling(c, dt, s.W.p, k, m, P.norm_type, s.sums.p, s.d.p));
             // ---- loss (fit_cpu.hpp:1729-1753) from replicated quantities: identical on every device

@@ -24,12 +24,29 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, cfg_kw, q):
+def _matrix(kind):
+    """"even": 90 x 140, 20 % dense.  "skewed": the same rows, 61 columns of which a handful hold most of the nonzeros (dense blocks
+    next to nearly empty columns: nnz-balanced shards of very different widths).  "tiny": 5 columns for 8 ranks -- empty shards."""
+    if kind == "even":
+        return data.simulate_nmf_sparse(90, 140, 5, 0.2, seed=17)[0]
+    rs = np.random.default_rng(5)
+    cols = 61 if kind == "skewed" else 5
+    dens = np.where(rs.uniform(size=cols) < 0.15, 0.95, 0.02) if kind == "skewed" else np.full(cols, 0.5)
+    mask = rs.uniform(size=(90, cols)) < dens[None, :]
+    mask[0, :] = True                                     # no empty column
+    D = np.where(mask, rs.uniform(0.1, 1.0, size=(90, cols)), 0.0)
+    import scipy.sparse as sp
+    M = sp.csc_matrix(D)
+    M.sort_indices()
+    return data.CSC((90, cols), M.indptr.astype(np.int32), M.indices.astype(np.int32), M.data.astype(np.float64))
+
+
+def _worker(rank, world, port, cfg_kw, q, kind="even"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     torch.set_num_threads(1)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        A, _, _ = data.simulate_nmf_sparse(90, 140, 5, 0.2, seed=17)
+        A = _matrix(kind)
         k = 6
         bounds = als.partition_columns_by_nnz(A.p, world)
         c0, c1 = bounds[rank], bounds[rank + 1]
@@ -44,28 +61,40 @@ def _worker(rank, world, port, cfg_kw, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-@pytest.mark.parametrize("cfg_kw", [dict(max_iter=8, tol=0.0, L1_H=2e-6, L2_W=1e-3),
-                                    dict(max_iter=6, tol=0.0, solver_mode=1, norm_type=1)])
-def test_sharded_als_matches_single_process(world, cfg_kw):
+@pytest.mark.parametrize("world,kind,cfg_kw", [
+    (2, "even", dict(max_iter=8, tol=0.0, L1_H=2e-6, L2_W=1e-3)),
+    (3, "even", dict(max_iter=8, tol=0.0, L1_H=2e-6, L2_W=1e-3)),
+    (2, "even", dict(max_iter=6, tol=0.0, solver_mode=1, norm_type=1)),
+    (3, "even", dict(max_iter=6, tol=0.0, solver_mode=1, norm_type=1)),
+    (3, "even", dict(max_iter=6, tol=0.0, w_solve="replicated")),
+    # the 8-rank leg of BASELINE configs[3] in miniature: nnz-balanced shards of uneven width, and more ranks than columns
+    (8, "skewed", dict(max_iter=6, tol=0.0, L1_H=2e-6)),
+    (8, "skewed", dict(max_iter=5, tol=0.0, w_solve="replicated", solver_mode=1)),
+    (8, "tiny", dict(max_iter=5, tol=0.0)),
+])
+def test_sharded_als_matches_single_process(world, kind, cfg_kw):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, cfg_kw, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, cfg_kw, q, kind)) for r in range(world)]
     for p in procs:
         p.start()
-    outs = sorted([q.get(timeout=300) for _ in range(world)], key=lambda t: t[0])
+    outs = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
     # single-process reference on the full matrix (unsorted, to compare factor-by-factor)
-    A, _, _ = data.simulate_nmf_sparse(90, 140, 5, 0.2, seed=17)
+    A = _matrix(kind)
+    if kind != "even":          # the shards really are uneven / empty
+        widths = [o[2] - o[1] for o in outs]
+        assert (min(widths) == 0) if kind == "tiny" else (max(widths) >= 2 * max(1, min(widths)))
     Ao = O.Csc(A.shape, A.p, A.i, A.x)
     W0, H0 = data.init_factors(9, 6, A.rows, A.cols)
     ref = O.nmf_fit(Ao, W0, H0, max_iter=cfg_kw["max_iter"], tol=0.0, L1=(cfg_kw.get("L1_W", 0.0), cfg_kw.get("L1_H", 0.0)),
                     L2=(cfg_kw.get("L2_W", 0.0), cfg_kw.get("L2_H", 0.0)), solver_mode=cfg_kw.get("solver_mode", 0),
                     norm_type=cfg_kw.get("norm_type", 0), sort_model=False)
-    assert ref.d.min() > 1e-3 and (ref.H > 0).mean() > 0.2            # a live fit (penalties sized to data ~1e-4)
+    if kind == "even":
+        assert ref.d.min() > 1e-3 and (ref.H > 0).mean() > 0.2        # a live fit (penalties sized to data ~1e-4)
     H_full = np.concatenate([o[6] for o in outs], axis=0)
     assert outs[0][1] == 0 and outs[-1][2] == A.cols and all(outs[i][2] == outs[i + 1][1] for i in range(world - 1))
     for o in outs:   # W_T, d and the loss are replicated: identical on every rank

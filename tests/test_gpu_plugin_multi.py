@@ -44,9 +44,10 @@ class _Env:
                 os.environ[k] = v
 
 
-def _fit(abi, A, W0, H0, ndev, **kw):
+def _fit(abi, A, W0, H0, ndev, w_solve=None, **kw):
     W, H = W0.copy(), H0.copy()
-    with _Env(RCPPML_GPU_DEVICES=ndev if ndev > 1 else None, RCPPML_GPU_DEVICES_SHARE=1 if ndev > 1 else None):
+    with _Env(RCPPML_GPU_DEVICES=ndev if ndev > 1 else None, RCPPML_GPU_DEVICES_SHARE=1 if ndev > 1 else None,
+              RCPPML_GPU_W_SOLVE=w_solve):
         res = abi.nmf_unified(A.p, A.i, A.x, A.rows, A.cols, W.shape[1], W, H, entry="ex", **kw)
     assert res["status"] == 0, res.get("error")
     res["W_T"], res["H"] = W, H
@@ -74,6 +75,26 @@ def test_sharded_plugin_fit_matches_single_device_and_oracle(abi, ndev, solver):
     assert np.abs(many["W_T"] - ref.W_T).max() < 1e-6 and np.abs(many["H"] - ref.H).max() < 1e-6
     # deterministic run to run
     assert np.array_equal(many["W_T"], again["W_T"]) and np.array_equal(many["H"], again["H"]) and many["loss"] == again["loss"]
+
+
+@pytest.mark.parametrize("ndev", [2, 3, 8])
+@pytest.mark.parametrize("solver", [0, 1])
+def test_sharded_plugin_block_w_solve_equals_replicated(abi, ndev, solver):
+    """RCPPML_GPU_W_SOLVE=block: device r solves its block of W's rows and one all-gather replicates them -- the same numbers as
+    the default (every device solves all of W): the blocks are solved from identical (G, B) by the same kernels.  203 rows
+    over 8 devices: blocks of 28 rows, the last one short (7 rows), m not a multiple of the block."""
+    A = lowrank_csc(203, 900, 5, 0.08, seed=23 + ndev)
+    k = 8
+    W0, H0 = O.init_factors(3, k, A.rows, A.cols, np.float64)
+    kw = dict(max_iter=7, tol=0.0, solver_mode=solver, precision=1, L1_W=0.01, L2_H=0.02, want_history=True)
+    rep = _fit(abi, A, W0, H0, ndev, **kw)
+    blk = _fit(abi, A, W0, H0, ndev, w_solve="block", **kw)
+    assert blk["iter"] == rep["iter"]
+    # (small blocks may take another CD kernel form than the whole side: same iterates up to rounding and the cd_tol exit)
+    assert np.abs(blk["loss_history"] - rep["loss_history"]).max() / rep["loss_history"].max() < 1e-9
+    assert np.abs(blk["W_T"] - rep["W_T"]).max() < 1e-8 and np.abs(blk["H"] - rep["H"]).max() < 1e-8
+    one = _fit(abi, A, W0, H0, 1, **kw)
+    assert abs(blk["loss"] - one["loss"]) / abs(one["loss"]) < 1e-9
 
 
 def test_sharded_plugin_fit_fp32_convergence_and_norms(abi):
