@@ -53,6 +53,8 @@ def parse():
     ap.add_argument("--no-order", action="store_true", help="disable sweep-count column ordering")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline work (s)")
     ap.add_argument("--no-plugin-figure", action="store_true", help="skip the PCIe-inclusive 73-pointer plugin call")
+    ap.add_argument("--w-solve", choices=["block", "replicated"], default="block",
+                    help="N > 1: W half-update solved in row blocks + one all-gather (default) or replicated on every rank")
     ap.add_argument("--no-graph", action="store_true", help="time an eager launch loop instead of replays of one captured hipGraph")
     ap.add_argument("--no-cpu-ref", action="store_true", help="skip the CPU reference fit (fp64 oracle, same inputs, same iteration count) "
                                                               "behind loss_rel_dev_vs_cpu_ref")
@@ -151,6 +153,25 @@ def cpu_baseline(A_loc, At_loc, W_T, H, G_h, G_w, cfg_k, dtype, seconds, cd_maxi
                 dtype=dtype)
 
 
+def collectives_model(world, m, k, sv, w_solve):
+    """Expected payloads of one ALS iteration over `world` ranks and their xGMI time from the link figures of
+    MI355X_MICROARCH.md (7 links x ~153 GB/s per GPU, both directions together): a ring all-reduce moves 2 (N-1)/N of
+    the buffer over every rank's links, an all-gather (N-1)/N.  `per_link_ms`: one ring on one link direction (76.5 GB/s) --
+    the bound xGMI's point-to-point links set a single ring; `all_links_ms`: the buffer cut over N-1 rings, one per peer
+    link.  A MODEL to compare `collectives_ms_per_step` with -- no multi-GPU run has been made (unmeasured on hardware)."""
+    if world <= 1:
+        return None
+    ar = (k * k + k * m + k) * sv                      # [G_p | B_p | row sums of H]: the one all-reduce per iteration
+    ag = (k * m * sv) if w_solve == "block" else 0     # the solved blocks of W_T
+    f = (world - 1) / world
+    link = 76.5e9
+    t_ar, t_ag = 2 * f * ar / link, f * ag / link
+    return {"all_reduce_bytes": ar, "all_gather_bytes": ag, "w_solve": w_solve,
+            "per_link_ms": {"all_reduce": round(t_ar * 1e3, 4), "all_gather": round(t_ag * 1e3, 4)},
+            "all_links_ms": {"all_reduce": round(t_ar * 1e3 / max(1, world - 1), 4), "all_gather": round(t_ag * 1e3 / max(1, world - 1), 4)},
+            "note": "model from the xGMI link figures; unmeasured on hardware"}
+
+
 def main():
     args = parse()
     import torch
@@ -211,7 +232,7 @@ def main():
     cfg = als.AlsConfig(k=k, max_iter=args.warmup + args.steps, tol=0.0, cd_maxit=args.cd_maxit,
                         L1_H=0.1 if args.config == "c3" else 0.0,
                         solver_mode=0 if args.solver == "cd" else 1,
-                        cd_variant={"auto": 0, "lane": 1, "wave": 2}[args.variant], order_columns=not args.no_order)
+                        cd_variant={"auto": 0, "lane": 1, "wave": 2}[args.variant], order_columns=not args.no_order, w_solve=args.w_solve)
     # One GPU: the K timed iterations are replays of ONE captured hipGraph of the iteration -- how the plugin's loop
     # (rcppml_amd/csrc/plugin.hip) issues its steady-state iterations; an eager loop pays ~3 us of launch gap per kernel, ~35
     # kernels per iteration.  Everything then lives on a side stream (a capture cannot run on the default stream); the device
@@ -444,6 +465,7 @@ def main():
             "backend": (dist.get_backend() if world > 1 else None),
             "collectives_ms_per_step": {name: dict(ms=round(v["total_ms"] / args.steps, 4), calls_per_step=v["count"] / args.steps,
                                                    bytes=v["bytes"]) for name, v in sorted(coll.items())},
+            "collectives_model": collectives_model(world, m, k, 4 if args.dtype == "f32" else 8, args.w_solve),
         }
         if world == 1 and not args.no_plugin_figure and args.config == "c2":
             try:
