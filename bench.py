@@ -486,6 +486,15 @@ def main():
         if world == 1 and args.solver == "cd" and args.dtype == "f32" and k <= 64 and not args.no_noop_count:
             try:
                 out["cd_noop_steps"] = cd_noop_fraction(st, ops, cfg, k)
+                zs = out["cd_noop_steps"]
+                rf = out.get("roofline") or {}
+                if rf.get("bound") == "mfma" and "H_zero_step_share" in zs:
+                    # the roofline counts DENSE sweeps (every coordinate of every sweep: 2 k_pad^2 flops per column-sweep); the
+                    # reference executes only the steps whose update is non-zero -- useful_frac prices the kernel against those
+                    rf["zero_step_share"] = {"H": zs["H_zero_step_share"], "W": zs.get("W_zero_step_share")}
+                    rf["useful_frac"] = rf["frac"] * (1.0 - zs["H_zero_step_share"])
+                    rf["useful_frac_what"] = ("frac x (1 - share of (column, coordinate) steps of the H-side solve whose update is exactly 0): "
+                                              "the matrix-core rate on the work the reference's CD (which skips those steps) would count")
             except Exception as e:
                 out["cd_noop_steps"] = {"error": repr(e)}
         # ---- the metric's second half: deviation of the fit's loss from a CPU reference fit (fp64 oracle restatement of
@@ -691,13 +700,19 @@ def cd_noop_fraction(st, ops, cfg, k):
             ctx.set_option(_abi.OPT_CD_LMF_WAVES_PER_SIMD, 2)
             ctx.set_option(_abi.OPT_CD_COUNT_NOOP, 1)
             ctx.stats(reset=True)
+            ctx.cd_step_stats(reset=True)
             ctx.solve_cd(ops.dt, G, B, Xc, k, Xc.shape[0], warm=1, maxit=cfg.cd_maxit, tol=cfg.cd_tol, variant=_abi.CD_LMF, col_order=order)
             stt = ctx.stats(reset=True)
+            cst = ctx.cd_step_stats(reset=True)
             steps = stt["cd_slot_sweeps"] / cols * 64        # wave-sweeps x 64 coordinates (k padded to 64)
             res["%s_%d_columns_per_wave" % (side, cols)] = stt["cd_noop_steps"] / max(steps, 1)
+            if cols == 32:       # per (column, coordinate): steps whose update is exactly 0 -- what the reference's `continue` skips
+                res["%s_zero_step_share" % side] = cst["cd_zero_steps"] / max(cst["cd_steps"], 1)
         for opt in (_abi.OPT_CD_LMF_LANE_GROUPS, _abi.OPT_CD_LMF_WAVES_PER_SIMD, _abi.OPT_CD_COUNT_NOOP):
             ctx.set_option(opt, 0)
-    res["what"] = "fraction of (wave, coordinate) steps in which every column's step is exactly 0, steady state, sweep-sorted order"
+    res["what"] = ("*_columns_per_wave: fraction of (wave, coordinate) steps in which every column's step is exactly 0 (what a wave-uniform "
+                   "skip could save); *_zero_step_share: fraction of (column, coordinate) steps whose update is exactly 0 (the reference "
+                   "skips them: nnls_batch.hpp:102,106,109); steady state, sweep-sorted order")
     return res
 
 

@@ -241,6 +241,11 @@ RCPPML_GPU_API int rcppml_hip_ctx_stats(rcppml_hip_ctx* ctx, int reset, unsigned
  * the columns rcppml_hip_solve_irls solved (nnls_batch_irls.hpp:480-560: each pass rebuilds the weighted Gram and solves),
  * out2[1] = the same weighted by the column's nonzeros = rank-1 updates f f^T of the weighted Grams (x 2 k_pad^2 = flops). */
 RCPPML_GPU_API int rcppml_hip_ctx_irls_stats(rcppml_hip_ctx* ctx, int reset, unsigned long long* out2);
+/* Per-(column, coordinate) step counters of the lane = column CD kernel (only while RCPPML_OPT_CD_COUNT_NOOP is set): out2[0] =
+ * coordinate steps whose update is exactly 0 -- the steps the reference skips with `continue` (primitives/cpu/nnls_batch.hpp:
+ * 102,106,109) and a dense sweep still executes --, out2[1] = all coordinate steps of live columns (warm-start correction
+ * sweeps and padded coordinates excluded).  bench.py: roofline.useful_frac = frac x (1 - out2[0] / out2[1]). */
+RCPPML_GPU_API int rcppml_hip_ctx_cd_step_stats(rcppml_hip_ctx* ctx, int reset, unsigned long long* out2);
 /* Tuning / diagnostic switches of a context (0 = default behaviour for all of them). */
 enum { RCPPML_OPT_CD_COUNT_NOOP = 1 /* LMF kernel counts all-zero coordinate steps into stats[3], IRLS kernels count passes (slower) */,
        RCPPML_OPT_CD_LMF_LANE_GROUPS = 2 /* 1, 2 or 4 lane groups per column instead of the size heuristic */,

@@ -22,7 +22,7 @@ EXPORTED_SYMBOLS = [
     "rcppml_gpu_detect", "rcppml_gpu_nmf_unified_float", "rcppml_gpu_nmf_unified_double", "rcppml_gpu_nmf_ex",
     "rcppml_gpu_nmf_cv_unified_float", "rcppml_gpu_nmf_cv_unified_double", "rcppml_gpu_nmf_cv_ex", "rcppml_gpu_nmf_cv_irls_ex", "rcppml_gpu_nmf_zerocopy_double",
     "rcppml_gpu_nnls_double", "rcppml_gpu_evaluate_mse_double", "rcppml_gpu_last_error",
-    "rcppml_hip_ctx_create", "rcppml_hip_ctx_destroy", "rcppml_hip_ctx_sync", "rcppml_hip_ctx_stats", "rcppml_hip_ctx_irls_stats", "rcppml_hip_ctx_set_option", "rcppml_hip_transpose_csc", "rcppml_hip_transpose_csc_sort", "rcppml_hip_transpose_csc_gather", "rcppml_hip_cast", "rcppml_hip_gram", "rcppml_hip_rhs",
+    "rcppml_hip_ctx_create", "rcppml_hip_ctx_destroy", "rcppml_hip_ctx_sync", "rcppml_hip_ctx_stats", "rcppml_hip_ctx_irls_stats", "rcppml_hip_ctx_cd_step_stats", "rcppml_hip_ctx_set_option", "rcppml_hip_transpose_csc", "rcppml_hip_transpose_csc_sort", "rcppml_hip_transpose_csc_gather", "rcppml_hip_cast", "rcppml_hip_gram", "rcppml_hip_rhs",
     "rcppml_hip_solve_cd", "rcppml_hip_order_columns", "rcppml_hip_solve_chol", "rcppml_hip_row_norms", "rcppml_hip_apply_scaling",
     "rcppml_hip_sumsq", "rcppml_hip_loss_mse", "rcppml_hip_solve_masked", "rcppml_hip_loss_nonzeros",
     "rcppml_hip_solve_irls_nb", "rcppml_hip_nb_size_update", "rcppml_hip_nb_loss", "rcppml_hip_solve_irls", "rcppml_hip_irls_loss", "rcppml_hip_apply_l21", "rcppml_hip_angular_posthoc", "rcppml_hip_solve_cv", "rcppml_hip_cv_test_error", "rcppml_hip_solve_cv_irls", "rcppml_hip_cv_irls_loss", "rcppml_hip_cv_gp_theta_update", "rcppml_hip_mul_rows", "rcppml_hip_apply_graph_reg", "rcppml_hip_dispersion_update", "rcppml_hip_vec_global", "rcppml_hip_spz_info", "rcppml_hip_spz_decode",
@@ -377,6 +377,13 @@ class Context:
         out = (C.c_ulonglong * 4)()
         _chk(lib().rcppml_hip_ctx_stats(self._h, C.c_int(1 if reset else 0), out), "ctx_stats")
         return dict(cd_column_sweeps=int(out[0]), cd_columns=int(out[1]), cd_slot_sweeps=int(out[2]), cd_noop_steps=int(out[3]))
+
+    def cd_step_stats(self, reset=False):
+        """Per-(column, coordinate) steps of the lane = column CD kernel (only counted while OPT_CD_COUNT_NOOP is set): steps whose
+        update is exactly 0 (the reference skips them) and all steps of live columns."""
+        out = (C.c_ulonglong * 2)()
+        _chk(lib().rcppml_hip_ctx_cd_step_stats(self._h, C.c_int(1 if reset else 0), out), "ctx_cd_step_stats")
+        return dict(cd_zero_steps=int(out[0]), cd_steps=int(out[1]))
 
     def irls_stats(self, reset=False):
         """IRLS work counters (only counted while OPT_CD_COUNT_NOOP is set): passes over columns, nonzero-passes."""

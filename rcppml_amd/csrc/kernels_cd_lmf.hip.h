@@ -169,6 +169,7 @@ __global__ __launch_bounds__(256) void cd_lmf_kernel(const float2* __restrict__ 
     const bool check = tol > 0.f;
     const float inv_k = 1.f / static_cast<float>(k);
     unsigned long long my_colsweeps = 0, my_cols = 0, wave_sweeps = 0, noop_steps = 0;
+    [[maybe_unused]] unsigned long long col_noops = 0, col_steps = 0;
     bool ing[LG];
 #pragma unroll
     for (int q = 0; q < LG; ++q) ing[q] = g == q;
@@ -197,7 +198,14 @@ __global__ __launch_bounds__(256) void cd_lmf_kernel(const float2* __restrict__ 
             a = cm ? -xo : a;
             if constexpr (LG == 1) areg = a;
             else areg = ing[gi] ? a : areg;            // lanes of the other groups hold other coordinates' steps
-            if constexpr (COUNT) { if (!__any((LG == 1 || ing[gi]) && j >= 0 && a != 0.f)) noop_steps += 1; }
+            if constexpr (COUNT) {
+                const bool mine = (LG == 1 || ing[gi]) && j >= 0;
+                if (!__any(mine && a != 0.f)) noop_steps += 1;
+                if (!cm && i < k) {      // per (column, coordinate): the steps the reference skips (nnls_batch.hpp:102,106,109 `continue`)
+                    col_steps += __popcll(__ballot(mine));
+                    col_noops += __popcll(__ballot(mine && a == 0.f));
+                }
+            }
             lmf_static_for<0, NTL>([&](auto uc) {
                 constexpr int tt = (tn + decltype(uc)::value) % NTL;
                 acc[tt] = lmf_mfma<CBSZ, tt, Ge::blgp(gi)>(gq.x, areg, acc[tt]);
@@ -276,7 +284,7 @@ __global__ __launch_bounds__(256) void cd_lmf_kernel(const float2* __restrict__ 
         if (lane == 0) {
             if (c > 0) { atomicAdd(stats, v); atomicAdd(stats + 1, c); }
             atomicAdd(stats + 2, wave_sweeps * (unsigned long long)CW);     // slot-sweeps executed (idle + correction included)
-            if constexpr (COUNT) atomicAdd(stats + 3, noop_steps);
+            if constexpr (COUNT) { atomicAdd(stats + 3, noop_steps); atomicAdd(stats + 6, col_noops); atomicAdd(stats + 7, col_steps); }
         }
     }
 }

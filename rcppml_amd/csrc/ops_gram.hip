@@ -56,6 +56,16 @@ extern "C" int rcppml_hip_ctx_stats(rcppml_hip_ctx* c, int reset, unsigned long 
     }
     RCPPML_CATCH_RET
 }
+extern "C" int rcppml_hip_ctx_cd_step_stats(rcppml_hip_ctx* c, int reset, unsigned long long* out2) {
+    try {
+        HIPCHK(hipSetDevice(c->device));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        if (out2) HIPCHK(hipMemcpy(out2, c->stats + 6, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        if (reset) HIPCHK(hipMemset(c->stats + 6, 0, 2 * sizeof(unsigned long long)));
+        return 0;
+    }
+    RCPPML_CATCH_RET
+}
 extern "C" int rcppml_hip_ctx_irls_stats(rcppml_hip_ctx* c, int reset, unsigned long long* out2) {
     try {
         HIPCHK(hipStreamSynchronize(c->stream));
