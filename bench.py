@@ -619,6 +619,15 @@ def bench_c5(args):
         "roofline_other_side": roof["W" if big == "H" else "H"],
         "phases_ms_per_step": phases, "launch": "eager", "final_loss": final_loss, "world_size_seen": 1,
     }
+    if not args.no_cpu_ref:
+        # the metric's second half for this configuration: a WHOLE fit (3 outer NB iterations: IRLS half-updates, size updates,
+        # likelihood) through the 73-pointer fp64 entry against the CPU oracle's fp64 fit from the same starting factors
+        try:
+            line["cpu_ref"] = c5_parity_leg(A, m, n, k, args)
+            line["loss_rel_dev_vs_cpu_ref"] = line["cpu_ref"]["loss_rel_dev"]
+        except Exception as e:
+            line["cpu_ref"] = {"error": repr(e)}
+            line["loss_rel_dev_vs_cpu_ref"] = None
     if not args.no_cpu_baseline:
         try:
             line["cpu_baseline"] = cpu_baseline_c5(A, At, W, H, theta, ops, k, nd, args)
@@ -626,6 +635,56 @@ def bench_c5(args):
         except Exception as e:
             line["cpu_baseline"] = {"value": None, "unit": "cols/s", "cores": os.cpu_count(), "kind": "port", "sample": "failed: %r" % (e,)}
     print(json.dumps(line))
+
+
+def c5_parity_leg(A, m, n, k, args, iters=3):
+    """`iters` outer NB iterations through the plugin in fp64 (rcppml_gpu_nmf_ex: the 73-pointer argument list + loss history;
+    loss_type = 5, per-row dispersion, the reference's defaults) and the same fit by the CPU oracle in fp64 (nmf/fit_cpu.hpp
+    restated, OpenMP over the host's cores): relative deviation of the NB likelihood after EVERY iteration.  Outside the timed region.
+
+    How well-posed is the comparison?  NB-IRLS starts every column at x = 0 (weights at their 1e6 cap) and the method-of-moments
+    size divides by a difference of large sums, so rounding-level differences grow by 3-4 orders of magnitude per outer
+    iteration -- in the reference's own arithmetic.  `cpu_self_dev_by_iteration` is the deviation of the CPU fit from ITSELF with
+    the starting factors perturbed by 1e-14 relative (two draws, the larger one): the floor a second implementation (another
+    summation order) can be expected to reach; tools/probe/nb_parity_probe.py shows the two curves side by side at reduced size."""
+    from oracle import oracle as O
+    from rcppml_amd import _abi, data
+    W0, H0 = data.init_factors(args.seed, k, m, n, np.float64)
+    W, H = W0.copy(), H0.copy()
+    p, i, x = A.p.astype(np.int32), A.i.astype(np.int32), A.x.astype(np.float64)
+    t0 = time.perf_counter()
+    res = _abi.nmf_unified(p, i, x, m, n, k, W, H, entry="ex", precision=1, want_history=True, max_iter=iters, tol=0.0, solver_mode=0,
+                           loss_type=5, cd_maxit=args.cd_maxit)
+    t_gpu = time.perf_counter() - t0
+    if res["status"] != 0:
+        raise RuntimeError(res.get("error"))
+    try:
+        O.build(native=True)
+        native = True
+    except Exception:
+        native = False
+    C = O.Csc((m, n), A.p, A.i, A.x)
+    kw = dict(max_iter=iters, tol=0.0, solver_mode=0, loss_type=5, cd_maxit=args.cd_maxit, threads=0, native=native)
+    t0 = time.perf_counter()
+    ref = O.nmf_fit(C, W0, H0, np.float64, **kw)
+    t_cpu = time.perf_counter() - t0
+    rh = np.asarray(ref.loss_history, dtype=np.float64)
+    gh = np.asarray(res["loss_history"], dtype=np.float64)[:len(rh)]
+    self_dev = np.zeros(len(rh))
+    for draw in (1, 2):
+        rs = np.random.default_rng(draw)
+        r2 = O.nmf_fit(C, W0 * (1.0 + 1e-14 * rs.standard_normal(W0.shape)), H0 * (1.0 + 1e-14 * rs.standard_normal(H0.shape)),
+                       np.float64, **kw)
+        self_dev = np.maximum(self_dev, np.abs(np.asarray(r2.loss_history) - rh) / np.abs(rh))
+    dev = np.abs(gh - rh) / np.abs(rh)
+    out = {"iterations": iters, "gpu_entry": "rcppml_gpu_nmf_ex (fp64)", "gpu_loss": res["loss"], "cpu_loss": float(ref.loss),
+           "loss_rel_dev": float(dev[-1]), "loss_rel_dev_by_iteration": [float(v) for v in dev],
+           "cpu_self_dev_by_iteration": [float(v) for v in self_dev],
+           "cpu_self_dev_what": "the CPU fit against itself, starting factors perturbed by 1e-14 relative (larger of two draws)",
+           "gpu_fit_s": t_gpu, "cpu_fit_s": t_cpu, "cpu_threads": O.num_threads(),
+           "d_rel_dev": float(np.abs(res["d"] - ref.d).max() / np.abs(ref.d).max()),
+           "what": "same matrix, same starting factors, same iteration count, tol = 0, fp64 on both sides"}
+    return out
 
 
 def cpu_baseline_c5(A, At, W, H, theta, ops, k, nd, args):

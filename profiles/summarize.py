@@ -46,15 +46,16 @@ for k in sorted(set(fetch) | set(write)):
 # one rhs CALL = spill kernel + tiled kernel (+ partial reduce, + gather kernel on the tail columns): traffic of everything one
 # rcppml_hip_rhs_planned launches, averaged over the two sides (H and W) -- what bench.py's roofline_rhs.traffic quotes
 def is_rhs(k):
-    return "rhs_tiled_kernel" in k or "rhs_tiled_spill" in k or "rhs_tiled_reduce" in k or "rhs_stage_kernel" in k or "rhs_kernel" in k
+    return ("rhs_win_kernel" in k or "rhs_win_finish" in k or "rhs_tiled_kernel" in k or "rhs_tiled_spill" in k or "rhs_tiled_reduce" in k
+            or "rhs_stage_kernel" in k or "rhs_kernel" in k)
 rhs_total = sum(v["hbm_bytes_per_launch"] * v["launches"] for k, v in out.items() if is_rhs(k))
-tiled_launches = sum(v["launches"] for k, v in out.items() if "rhs_tiled_kernel" in k)
+tiled_launches = sum(v["launches"] for k, v in out.items() if "rhs_tiled_kernel" in k or "rhs_win_kernel" in k)
 gather_launches = sum(v["launches"] for k, v in out.items() if "rhs_stage_kernel" in k or "rhs_kernel<" in k)
 calls = tiled_launches if tiled_launches else gather_launches
 doc = dict(kernels=out)
 if calls:
     doc["rhs_per_launch"] = dict(calls=calls, hbm_bytes_per_launch=rhs_total / calls,
-                                 note="sum over every kernel of one rhs call (spill + tiled + reduce + tail gather), mean of both sides")
+                                 note="sum over every kernel of one rhs call (r4: window kernel + finishing kernel; r2/r3: spill + tiled + reduce + tail gather), mean of both sides")
 json.dump(doc, open(os.path.join(dst, tag + "_pmc.json"), "w"), indent=1)
 
 with open(os.path.join(dst, tag + "_summary.md"), "w") as f:
@@ -76,7 +77,7 @@ trace = os.path.join(src, "trace", "trace_kernel_trace.csv")
 if os.path.exists(trace):
     by = collections.defaultdict(list)
     for r in csv.DictReader(open(trace)):
-        if "rk::cd_mfma" in r["Kernel_Name"] and "prep" not in r["Kernel_Name"] or "rk::rhs_stage" in r["Kernel_Name"] or "rk::rhs_tiled" in r["Kernel_Name"]:
+        if "rk::cd_mfma" in r["Kernel_Name"] and "prep" not in r["Kernel_Name"] or "rk::rhs_stage" in r["Kernel_Name"] or "rk::rhs_tiled" in r["Kernel_Name"] or "rk::rhs_win" in r["Kernel_Name"]:
             by[r["Kernel_Name"]].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
     with open(os.path.join(dst, tag + "_summary.md"), "a") as f:
         f.write("\nLaunches of the timed iterations only (the run issues 3 warm-up iterations, the 10 timed ones as hipGraph replays, and the same 10 once more eagerly for the per-phase events: the column averages the last 10 launches of each kernel, i.e. that eager re-run; from the kernel trace):\n\n| kernel | launches | avg us (all) | avg us (timed) |\n|---|---|---|---|\n")
@@ -84,7 +85,7 @@ if os.path.exists(trace):
         for k, v in by.items():
             v.sort()
             d = [x[1] for x in v]
-            nt = 20 if "rhs_stage" in k else 10
+            nt = 20 if ("rhs_stage" in k or "rhs_win" in k) else 10          # kernels both sides share: 2 launches per iteration
             nt = min(nt, len(d))
             f.write("| `%s` | %d | %.1f | %.1f |\n" % (k[:70], len(d), sum(d) / len(d) / 1e3, sum(d[-nt:]) / nt / 1e3))
 # ---- roofline fractions from the trace alone: counted work of the traced run's own bench line / trace durations of the

@@ -60,7 +60,14 @@ struct DynSmemOnce {
         const int d = device & 31;
         std::lock_guard<std::mutex> lk(mu);
         if (smem > 48 * 1024 && smem > set_bytes[d]) {
-            HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+            if (e != hipSuccess) {
+                (void)hipGetLastError();
+                // e.g. the rank-65..128 IRLS / CV / mask kernels (68 KB fp32, 136 KB fp64 per workgroup) on a 64 KB-LDS device
+                throw std::runtime_error("this kernel needs " + std::to_string(smem) + " bytes of LDS per workgroup, more than device " +
+                                         std::to_string(device) + " grants (" + hipGetErrorString(e) +
+                                         "): the configuration (rank above 64?) needs gfx950's 160 KiB of LDS per CU");
+            }
             set_bytes[d] = smem;
         }
     }

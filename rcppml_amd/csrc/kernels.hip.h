@@ -104,7 +104,7 @@ __device__ __forceinline__ void cd_static_sweeps(T& b, T& x, T gd, bool fok, T l
     const T pinf = static_cast<T>(__builtin_inff());
     const T inf_rt = maxit >= 0 ? pinf : T(0);        // +inf at run time: with a literal LLVM folds the median back into maxnum
     for (int it = 0; it < maxit; ++it) {
-        const T xe = nonneg ? x : pinf;               // the clamp's operand: max(diff, -xe) is max(diff, -x) or diff
+        const T xe = !alive ? T(0) : (nonneg ? x : pinf);   // the clamp's operand: max(diff, -xe) is max(diff, -x) or diff; a dead diagonal (reference: `continue`) takes no step, whatever its warm x
         const T aown = cd_static_one_sweep<T, KP>(b, xe, ginv, nl1, inf_rt, gcol);
         const T xn = x + aown;
         const bool moved = xn != x;
@@ -124,7 +124,7 @@ __device__ __forceinline__ int cd_static_sweeps_tol(T& b, T& x, T gd, bool fok, 
     const bool check = tol > T(0);
     const T inv_k = T(1) / static_cast<T>(k);
     for (int it = 0; it < maxit; ++it) {
-        const T xe = nonneg ? x : pinf;
+        const T xe = !alive ? T(0) : (nonneg ? x : pinf);
         const T aown = cd_static_one_sweep<T, KP>(b, xe, ginv, T(0), inf_rt, gcol);
         const T xn = x + aown;
         const bool moved = xn != x;

@@ -11,15 +11,20 @@ using namespace rk;
 
 namespace {
 
-// plan buffers: from the fit's arena when the context has one (then the plan does not own them), else hipMalloc
+// plan buffers: ownership is decided by the FIRST buffer -- from the fit's arena (then the plan owns nothing) or hipMalloc (then
+// the destructor frees every one of them) -- and never mixed: a later buffer that does not fit the arena fails the plan (the
+// caller then runs without one) instead of leaving earlier hipMalloc'ed buffers behind
 template <class P>
 void plan_alloc(rcppml_hip_ctx* c, rcppml_rhs_plan* pl, P** out, size_t bytes) {
-    void* q = c->arena_take(bytes < 16 ? 16 : bytes);
-    if (q) pl->in_arena = true;
-    else {
-        if (pl->in_arena) throw std::runtime_error("rhs_plan: arena exhausted half-way through a plan");
-        HIPCHK(hipMalloc(&q, bytes < 16 ? 16 : bytes));
+    const size_t b = bytes < 16 ? 16 : bytes;
+    const bool first = !pl->svals && !pl->soffs && !pl->ovptr && !pl->ovrow && !pl->ovval && !pl->Bp;
+    void* q = nullptr;
+    if (first || pl->in_arena) {
+        q = c->arena_take(b);
+        if (q) pl->in_arena = true;
+        else if (pl->in_arena) throw std::runtime_error("rhs_plan: arena exhausted half-way through a plan");
     }
+    if (!q) HIPCHK(hipMalloc(&q, b));
     *out = static_cast<P*>(q);
 }
 

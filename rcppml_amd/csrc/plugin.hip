@@ -100,6 +100,7 @@ void fit(FitParams& P) {
     if (!P.dense && !P.csc_on_device) {
         // everything this fit allocates, generously: the CSC twice (+ the double staging copy and the sort's temporaries),
         // the factors, right-hand sides and their staging copies, the two row-tiled plans
+        // (the window plans take ~12 bytes per nonzero and side + the partial slabs of their row partitions: inside the 96 nnz)
         const size_t est = (size_t)96 * (size_t)std::max<int64_t>(P.nnz, 1) + (size_t)96 * (size_t)k * ((size_t)m + n) + ((size_t)256 << 20);
         g.reserve(est);
     }

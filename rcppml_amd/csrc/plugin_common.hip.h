@@ -64,6 +64,10 @@ struct CtxGuard {
     // One device allocation for the whole fit (see rcppml_hip_ctx::arena).  Best effort: if it cannot be had, every buffer
     // falls back to its own hipMalloc.
     void reserve(size_t bytes) {
+        // never more than 60 % of what is free: near device capacity the arena must not starve the allocations that do not go
+        // through it (context scratch, plans that fall back to hipMalloc); what does not fit falls back to hipMalloc per buffer
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && bytes > free_b / 10 * 6) bytes = free_b / 10 * 6;
         void* q = nullptr;
         if (hipMalloc(&q, bytes) != hipSuccess) { (void)hipGetLastError(); return; }
         c->arena = static_cast<char*>(q); c->arena_cap = bytes; c->arena_off = 0;
@@ -216,6 +220,8 @@ inline void upload_ints(const int* src, size_t n, DevBuf& dst, hipStream_t s) {
 inline void plan_or_none(int rc, rcppml_rhs_plan*& plan) {
     if (rc != 0) {
         plan = nullptr;
+        if (const char* v = getenv("RCPPML_GPU_VERBOSE"); v && atoi(v) >= 1)
+            fprintf(stderr, "[rcppml_gpu] row-tiled rhs plan dropped (%s): this side runs the gather kernel\n", rcppml_err().c_str());
         rcppml_err().clear();
         (void)hipGetLastError();          // a failed hipMalloc leaves a sticky-until-read error behind
     }

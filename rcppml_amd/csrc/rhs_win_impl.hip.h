@@ -195,7 +195,13 @@ rcppml_rhs_plan* build_plan(rcppml_hip_ctx* c, int dtype, const int* colptr, con
                 if (partitions <= 0 && P > 1 && G.ntiles / P < 8) break;
                 const double nph = (double)G.ntiles / P;
                 const double rounds = std::ceil((double)(ncb * P) / (double)c->num_cu);
-                const double t_wg = (nph * ((NW / 4) * nr * rate_est * c_step + c_phase * (NW / 12.0)) + 19000.0) / 2400.0;      // microseconds
+                double t_wg = (nph * ((NW / 4) * nr * rate_est * c_step + c_phase) + 19000.0) / 2400.0;      // microseconds
+                // XCD locality: workgroup b runs on XCD b % 8 and streams partition b % P, so an XCD sees P / gcd(8, P) partitions =
+                // |F| / gcd(8, P) bytes; beyond its 4 MiB L2 the tiles come from the Infinity Cache instead (C2's W side: P = 10 ran
+                // 4-8 % slower than P = 8 and doubled the fabric reads)
+                int g8 = 1;
+                for (int d = 8; d >= 1; d >>= 1) if (P % d == 0) { g8 = d; break; }
+                if ((double)nrows * rowb / g8 > 3.5 * 1048576.0 && (double)nrows * rowb > 3.5 * 1048576.0) t_wg *= 1.15;
                 const double t_fin = (P > 1 ? (double)(P + 1) * (double)ncols * rowb / 4.0e6 + 4.0 : 0.0);
                 const double t = rounds * t_wg + t_fin;
                 if (best_t < 0 || t < best_t) { best_t = t; bNW = NW; bNR = nr; bP = P; }

@@ -192,6 +192,8 @@ def nmf(data, k, tol=1e-4, maxit=100, L1=(0.0, 0.0), L2=(0.0, 0.0), seed=None, m
         if irls_cv and graph_args:
             raise NotImplementedError("graph regularisation is implemented for the MSE cross-validation path")
         cv_kw = {}
+        if irls_cv and dispersion not in ("none", "global", "per_row"):
+            raise NotImplementedError("dispersion = %r is not implemented for cross-validation by the MI355X backend (none / global / per_row)" % (dispersion,))
         if irls_cv:          # nmf/fit_cv.hpp:446-456, :670-689: per-column weighted Grams over the training entries
             cv_kw = dict(loss_type={"mse": 0, "gp": 4, "nb": 5, "gamma": 6, "inverse_gaussian": 7, "tweedie": 8}[loss],
                          irls_max_iter=int(irls_max_iter), irls_tol=float(irls_tol),

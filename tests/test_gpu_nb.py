@@ -459,9 +459,19 @@ def test_full_size_c5_nb_properties(env, precision):
             if precision == "f64":
                 assert errc.max() <= 1e-6, (it, side, np.percentile(errc, [50, 90, 99, 100]), "worst column nnz", int(sub.p[worst + 1] - sub.p[worst]))
             else:
-                assert np.median(errc) < 2e-3 and np.mean(errc < 3e-2) >= 0.95 and np.sum(errc > 0.2) <= 2, (
+                assert np.median(errc) < 2e-3 and np.mean(errc < 3e-2) >= 0.95, (
                     it, side, np.percentile(errc, [50, 90, 99, 100]), "worst column nnz", int(sub.p[worst + 1] - sub.p[worst]),
                     "GPU", X_new[cols][worst][:6], "oracle", ref[worst][:6])
+                # the outliers must be columns on which fp32 itself is not trustworthy: the ORACLE's fp32 solve of the same column
+                # deviates from its fp64 solve (same inputs widened) by a comparable amount -- not an unexplained 0.2
+                outl = np.nonzero(errc > 3e-2)[0]
+                if outl.size:
+                    sub_o = _pick_cols(sub, outl)
+                    ref64 = O.irls_nb(sub_o, F_host.astype(np.float64), G_host.astype(np.float64), k, L1=0.0, L2=0.0,
+                                      theta_row=th_host.astype(np.float64) if side == "H" else None,
+                                      theta_col=None if side == "H" else th_host[cols][outl].astype(np.float64), dtype=np.float64)
+                    dev_ref = np.abs(ref[outl] - ref64).max(axis=1) / (np.abs(ref64).max(axis=1) + 1e-30)
+                    assert np.all(errc[outl] <= np.maximum(3e-2, 20.0 * dev_ref)), (it, side, errc[outl], dev_ref)
             ops.row_norms(X, 0, out=sums)
             ops.apply_scaling(X, sums, 0, d)
         ops.ctx.nb_size_update(ops.dt, Atd["p"], Atd["i"], Atd["x"], m, W, d, H, n, k, 0.01, 1e6, theta)
