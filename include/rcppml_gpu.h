@@ -302,6 +302,13 @@ typedef struct rcppml_rhs_plan rcppml_rhs_plan;
 RCPPML_GPU_API int rcppml_hip_rhs_plan_create(rcppml_hip_ctx* ctx, int dtype, const int* col_ptr, const int* row_idx,
                                               const void* values, int64_t ncols, int64_t nrows, int k, int partitions,
                                               int slots, rcppml_rhs_plan** out_plan);
+/* The same plan in two steps: _create_indices does everything that needs only the index arrays (the schedule, the offsets, the
+ * overflow lists, and for every nonzero where its value will go), _set_values scatters the values with one coalesced pass and
+ * may be called again when the values of the same pattern change.  The plugin builds both plans while the values are still
+ * crossing PCIe.  *out_plan = NULL when the window planner declines the input (use rcppml_hip_rhs_plan_create then). */
+RCPPML_GPU_API int rcppml_hip_rhs_plan_create_indices(rcppml_hip_ctx* ctx, int dtype, const int* col_ptr, const int* row_idx, int64_t ncols,
+                                                      int64_t nrows, int k, int partitions, int slots, rcppml_rhs_plan** out_plan);
+RCPPML_GPU_API int rcppml_hip_rhs_plan_set_values(rcppml_hip_ctx* ctx, rcppml_rhs_plan* plan, const void* values);
 RCPPML_GPU_API void rcppml_hip_rhs_plan_destroy(rcppml_rhs_plan* plan);
 RCPPML_GPU_API int rcppml_hip_rhs_plan_info(const rcppml_rhs_plan* plan, double* out11);
 RCPPML_GPU_API int rcppml_hip_rhs_planned(rcppml_hip_ctx* ctx, const rcppml_rhs_plan* plan, const void* F, void* B);

@@ -28,7 +28,7 @@ EXPORTED_SYMBOLS = [
     "rcppml_hip_solve_irls_nb", "rcppml_hip_nb_size_update", "rcppml_hip_nb_loss", "rcppml_hip_solve_irls", "rcppml_hip_irls_loss", "rcppml_hip_apply_l21", "rcppml_hip_angular_posthoc", "rcppml_hip_solve_cv", "rcppml_hip_cv_test_error", "rcppml_hip_solve_cv_irls", "rcppml_hip_cv_irls_loss", "rcppml_hip_cv_gp_theta_update", "rcppml_hip_mul_rows", "rcppml_hip_apply_graph_reg", "rcppml_hip_dispersion_update", "rcppml_hip_vec_global", "rcppml_hip_spz_info", "rcppml_hip_spz_decode",
     "rcppml_sp_read_gpu", "rcppml_sp_free_gpu", "rcppml_hip_rhs_dense", "rcppml_gpu_nmf_dense_unified_float",
     "rcppml_gpu_nmf_dense_unified_double",
-    "rcppml_hip_rhs_plan_create", "rcppml_hip_rhs_plan_destroy", "rcppml_hip_rhs_plan_info", "rcppml_hip_rhs_planned",
+    "rcppml_hip_rhs_plan_create", "rcppml_hip_rhs_plan_create_indices", "rcppml_hip_rhs_plan_set_values", "rcppml_hip_rhs_plan_destroy", "rcppml_hip_rhs_plan_info", "rcppml_hip_rhs_planned",
     "rcppml_gpu_nmf_target", "rcppml_hip_axpy", "rcppml_hip_add_diag", "rcppml_hip_clip_upper",
 ]
 
@@ -84,7 +84,8 @@ def lib():
         _lib.rcppml_hip_ctx_destroy.restype = None
         _lib.rcppml_hip_rhs_plan_destroy.restype = None
         _lib.rcppml_hip_rhs_plan_destroy.argtypes = [C.c_void_p]
-        for name in ("rcppml_hip_rhs_plan_create", "rcppml_hip_rhs_plan_info", "rcppml_hip_rhs_planned"):
+        for name in ("rcppml_hip_rhs_plan_create", "rcppml_hip_rhs_plan_create_indices", "rcppml_hip_rhs_plan_set_values",
+                     "rcppml_hip_rhs_plan_info", "rcppml_hip_rhs_planned"):
             getattr(_lib, name).restype = C.c_int
         _lib.rcppml_hip_rhs_plan_info.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
     return _lib
@@ -414,6 +415,17 @@ class Context:
         _chk(lib().rcppml_hip_rhs_plan_create(self._h, C.c_int(dt), _dptr(col_ptr), _dptr(row_idx), _dptr(values), C.c_int64(ncols),
                                               C.c_int64(nrows), C.c_int(k), C.c_int(partitions), C.c_int(slots), C.byref(h)), "rhs_plan_create")
         return RhsPlan(h) if h.value else None
+
+    def rhs_plan_indices(self, dt, col_ptr, row_idx, ncols, nrows, k, partitions=0, slots=0):
+        """The index half of a window plan (no values yet); None when the window planner declines.  Then rhs_plan_set_values."""
+        h = C.c_void_p()
+        _chk(lib().rcppml_hip_rhs_plan_create_indices(self._h, C.c_int(dt), _dptr(col_ptr), _dptr(row_idx), C.c_int64(ncols),
+                                                      C.c_int64(nrows), C.c_int(k), C.c_int(partitions), C.c_int(slots), C.byref(h)),
+             "rhs_plan_create_indices")
+        return RhsPlan(h) if h.value else None
+
+    def rhs_plan_set_values(self, plan, values):
+        _chk(lib().rcppml_hip_rhs_plan_set_values(self._h, plan._h, _dptr(values)), "rhs_plan_set_values")
 
     def rhs_planned(self, plan, F, B):
         _chk(lib().rcppml_hip_rhs_planned(self._h, plan._h, _dptr(F), _dptr(B)), "rhs_planned")

@@ -159,11 +159,15 @@ static __global__ __launch_bounds__(256) void rw_ovcount_kernel(const int* __res
     ovcnt[idx] = cnt;
 }
 
-// scatter the nonzeros into the slot stream / the overflow lists (ovptr: one entry per (column, partition), column-major)
+// scatter the nonzeros into the slot stream / the overflow lists (ovptr: one entry per (column, partition), column-major).
+// vals == NULL: the index half of a DEFERRED plan -- offsets and overflow rows now, and for every nonzero where its value will
+// go (dest[e]: element index into the slot stream, or 0x80000000 | position in the overflow list), so that the values can be
+// scattered by a coalesced pass (rw_values_kernel) once they have arrived (the plugin builds plans while they cross PCIe).
 template <class T>
 __global__ __launch_bounds__(256) void rw_fill_kernel(const int* __restrict__ colptr, const int* __restrict__ rowidx,
                                                       const T* __restrict__ vals, RhsWinGeom G, char* __restrict__ slots,
-                                                      const int* __restrict__ ovptr, int* __restrict__ ovrow, T* __restrict__ ovval) {
+                                                      const int* __restrict__ ovptr, int* __restrict__ ovrow, T* __restrict__ ovval,
+                                                      unsigned* __restrict__ dest) {
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t j = idx / G.P;
     const int p = (int)(idx % G.P);
@@ -175,24 +179,37 @@ __global__ __launch_bounds__(256) void rw_fill_kernel(const int* __restrict__ co
     const int q = jw >> 2, g = jw & 3;
     int ob = ovptr[idx];
     const int t0 = rw_t0(G, p);
-    char* const reg = slots + (cb * G.P + p) * G.region;
+    const int64_t reg_off = (cb * G.P + p) * G.region;
     rw_walk_part(rowidx, colptr[j], colptr[j + 1], G.R, G.ntiles, G.P, p, G.clo, G.nhi, q, rw_ub(G.rowb), nullptr,
                  [&](int e, int t, int rank) {
                      const int cap = rw_cap(G, t);
                      const int nst = G.nr * cap;
-                     char* blk = reg + rw_block_off(G, t, w);
+                     const int64_t boff = reg_off + rw_block_off(G, t, w);
+                     char* blk = slots + boff;
                      const int sidx = (q * cap + rank) * 4 + g;
                      const int row = rowidx[e];
                      const int ta = row / G.R;
                      const unsigned off = (unsigned)((ta - t0) & (RW_NBUF - 1)) * (unsigned)RW_TB + (unsigned)(row - ta * G.R) * (unsigned)G.rowb;
-                     reinterpret_cast<T*>(blk)[sidx] = vals[e];
+                     if (vals) reinterpret_cast<T*>(blk)[sidx] = vals[e];
+                     else dest[e] = (unsigned)(boff / (int64_t)sizeof(T)) + (unsigned)sidx;
                      reinterpret_cast<uint16_t*>(blk + (size_t)nst * 4 * sizeof(T))[sidx] = (uint16_t)(off >> 4);
                  },
                  [&](int e) {
                      ovrow[ob] = rowidx[e];
-                     ovval[ob] = vals[e];
+                     if (vals) ovval[ob] = vals[e];
+                     else dest[e] = 0x80000000u | (unsigned)ob;
                      ++ob;
                  });
+}
+// the value half of a deferred plan: one thread per nonzero, coalesced reads
+template <class T>
+__global__ __launch_bounds__(256) void rw_values_kernel(const T* __restrict__ vals, const unsigned* __restrict__ dest, int64_t nnz,
+                                                        T* __restrict__ slots, T* __restrict__ ovval) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= nnz) return;
+    const unsigned d = dest[e];
+    if (d & 0x80000000u) ovval[d & 0x7fffffffu] = vals[e];
+    else slots[d] = vals[e];
 }
 
 __device__ __forceinline__ const char* rw_uniform_ptr(const char* p) {         // tell hipcc the pointer is wave-uniform (SGPR pair)

@@ -260,6 +260,36 @@ extern "C" int rcppml_hip_rhs_plan_create(rcppml_hip_ctx* c, int dtype, const in
     RCPPML_CATCH_RET
 }
 
+// The plan in two steps (window plans only): everything that needs only the INDEX arrays now, the values later -- the plugin
+// builds both plans while the values are still crossing PCIe.  *out = NULL when the window planner declines (the caller then
+// uses rcppml_hip_rhs_plan_create once the values are there).
+extern "C" int rcppml_hip_rhs_plan_create_indices(rcppml_hip_ctx* c, int dtype, const int* col_ptr, const int* row_idx, int64_t ncols,
+                                                  int64_t nrows, int k, int partitions, int slots, rcppml_rhs_plan** out) {
+    try {
+        if (!out) throw std::runtime_error("rhs_plan_create_indices: null output");
+        *out = nullptr;
+        HIPCHK(hipSetDevice(c->device));
+        if (ncols > 0x7ffffff0ll || nrows > 0x7ffffff0ll) return 0;
+        if (slots != 0 && slots < 100) return 0;                 // slab plans are built in one step
+        const int rate_code = slots >= 100 ? slots - 100 : 0;
+        if (dtype == RCPPML_F32) *out = rcppml_rw_build_f32(c, col_ptr, row_idx, nullptr, ncols, nrows, k, partitions, rate_code);
+        else *out = rcppml_rw_build_f64(c, col_ptr, row_idx, nullptr, ncols, nrows, k, partitions, rate_code);
+        return 0;
+    }
+    RCPPML_CATCH_RET
+}
+extern "C" int rcppml_hip_rhs_plan_set_values(rcppml_hip_ctx* c, rcppml_rhs_plan* plan, const void* values) {
+    try {
+        if (!plan || !values) throw std::runtime_error("rhs_plan_set_values: null argument");
+        if (plan->device != c->device) throw std::runtime_error("rhs_plan_set_values: plan belongs to another device");
+        HIPCHK(hipSetDevice(c->device));
+        if (plan->dtype == RCPPML_F32) rcppml_rw_set_values_f32(c, plan, (const float*)values);
+        else rcppml_rw_set_values_f64(c, plan, (const double*)values);
+        return 0;
+    }
+    RCPPML_CATCH_RET
+}
+
 extern "C" void rcppml_hip_rhs_plan_destroy(rcppml_rhs_plan* plan) { delete plan; }
 
 extern "C" int rcppml_hip_rhs_plan_info(const rcppml_rhs_plan* pl, double* out10 /* 11 doubles */) {
@@ -283,6 +313,7 @@ extern "C" int rcppml_hip_rhs_planned(rcppml_hip_ctx* c, const rcppml_rhs_plan* 
     try {
         if (!plan) throw std::runtime_error("rhs_planned: null plan");
         if (plan->device != c->device) throw std::runtime_error("rhs_planned: plan belongs to another device");
+        if (plan->dest && !plan->vals) throw std::runtime_error("rhs_planned: the plan has no values yet (rcppml_hip_rhs_plan_set_values)");
         if (reinterpret_cast<uintptr_t>(F) % 16 || reinterpret_cast<uintptr_t>(B) % 16)
             throw std::runtime_error("rhs_planned: F and B must be 16-byte aligned");
         HIPCHK(hipSetDevice(c->device));

@@ -12,3 +12,5 @@ rcppml_rhs_plan* rcppml_rw_build_f64(rcppml_hip_ctx* c, const int* colptr, const
     return rw_launch::build_plan<double>(c, RCPPML_F64, colptr, rowidx, vals, ncols, nrows, k, partitions, rate_code);
 }
 void rcppml_rw_run_f64(rcppml_hip_ctx* c, const rcppml_rhs_plan* pl, const double* F, double* B) { rw_launch::run_plan<double>(c, pl, F, B); }
+void rcppml_rw_set_values_f32(rcppml_hip_ctx* c, rcppml_rhs_plan* pl, const float* vals) { rw_launch::set_values<float>(c, pl, vals); }
+void rcppml_rw_set_values_f64(rcppml_hip_ctx* c, rcppml_rhs_plan* pl, const double* vals) { rw_launch::set_values<double>(c, pl, vals); }

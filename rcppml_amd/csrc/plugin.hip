@@ -108,6 +108,7 @@ void fit(FitParams& P) {
 
     // ---- upload A, build and upload A^T (one-time setup, fit_cpu.hpp:237-254)
     DevBuf dAp, dAi, dAx, dTp, dTi, dTx;
+    struct PlanGuard { rcppml_rhs_plan* p = nullptr; ~PlanGuard() { rcppml_hip_rhs_plan_destroy(p); } } planA, planT;   // row-tiled rhs plans (see below)
     const bool dense = P.dense != nullptr;
     bool csc_transposed = false;
     if (dense) {                    // dense input: A itself (m x n, column-major) in the compute precision; no CSC, no transpose
@@ -134,16 +135,31 @@ void fit(FitParams& P) {
         OPCHK(rcppml_hip_transpose_csc_gather(c, dt, n, P.nnz, dAp.as<int>(), dpos.as<int>(), nullptr, dTi.as<int>(), nullptr));   // column indices of A^T
         hipStream_t s2 = g.second_stream();
         dAx.alloc((size_t)std::max<int64_t>(P.nnz, 1) * sizeof(T));
-        if constexpr (std::is_same<T, double>::value) {
-            HIPCHK(hipMemcpyAsync(dAx.p, P.values, (size_t)P.nnz * sizeof(double), hipMemcpyHostToDevice, s2));
-            HIPCHK(hipStreamSynchronize(s2));
-        } else {
-            DevBuf stage((size_t)std::max<int64_t>(P.nnz, 1) * sizeof(double));
-            HIPCHK(hipMemcpyAsync(stage.p, P.values, (size_t)P.nnz * sizeof(double), hipMemcpyHostToDevice, s2));
-            HIPCHK(hipStreamSynchronize(s2));
-            OPCHK(rcppml_hip_cast(c, RCPPML_F64, stage.p, RCPPML_F32, dAx.p, P.nnz));
-        }
+        DevBuf stage;
+        if constexpr (!std::is_same<T, double>::value) stage.alloc((size_t)std::max<int64_t>(P.nnz, 1) * sizeof(double));
+        // the values cross PCIe on a helper thread (a pageable copy blocks its caller); this thread meanwhile builds the INDEX
+        // halves of the two row-tiled plans (schedule, offsets, overflow lists: everything but the values) behind the sort
+        std::exception_ptr up_err;
+        std::thread up([&] {
+            try {
+                HIPCHK(hipSetDevice(c->device));
+                HIPCHK(hipMemcpyAsync(std::is_same<T, double>::value ? dAx.p : stage.p, P.values, (size_t)P.nnz * sizeof(double),
+                                      hipMemcpyHostToDevice, s2));
+                HIPCHK(hipStreamSynchronize(s2));
+            } catch (...) { up_err = std::current_exception(); }
+        });
+        try {
+            if (P.nnz >= (1 << 20) && !P.mask_p) {
+                plan_or_none(rcppml_hip_rhs_plan_create_indices(c, dt, dAp.as<int>(), dAi.as<int>(), n, m, k, 0, 0, &planA.p), planA.p);
+                plan_or_none(rcppml_hip_rhs_plan_create_indices(c, dt, dTp.as<int>(), dTi.as<int>(), m, n, k, 0, 0, &planT.p), planT.p);
+            }
+        } catch (...) { up.join(); throw; }
+        up.join();
+        if (up_err) std::rethrow_exception(up_err);
+        if constexpr (!std::is_same<T, double>::value) OPCHK(rcppml_hip_cast(c, RCPPML_F64, stage.p, RCPPML_F32, dAx.p, P.nnz));
         OPCHK(rcppml_hip_transpose_csc_gather(c, dt, n, P.nnz, dAp.as<int>(), dpos.as<int>(), dAx.p, nullptr, dTx.p));             // its values
+        if (planA.p) OPCHK(rcppml_hip_rhs_plan_set_values(c, planA.p, dAx.p));
+        if (planT.p) OPCHK(rcppml_hip_rhs_plan_set_values(c, planT.p, dTx.p));
         csc_transposed = true;
     } else {
         upload_ints(P.col_ptr, (size_t)n + 1, dAp, s);
@@ -233,10 +249,9 @@ void fit(FitParams& P) {
     // B = F * A (columns of A) / B = F * A^T (rows of A): CSC gather kernels, or GEMMs for a dense A
     // Large sparse inputs: the LDS row-tiled form (kernels_rhs_tiled.hip.h), planned once per fit for each side; NULL
     // plans (small input, rank or layout the kernel is not compiled for) keep the gather kernel.
-    struct PlanGuard { rcppml_rhs_plan* p = nullptr; ~PlanGuard() { rcppml_hip_rhs_plan_destroy(p); } } planA, planT;
-    if (!dense && P.nnz >= (1 << 20)) {
-        plan_or_none(rcppml_hip_rhs_plan_create(c, dt, dAp.as<int>(), dAi.as<int>(), dAx.p, n, m, k, 0, 0, &planA.p), planA.p);
-        plan_or_none(rcppml_hip_rhs_plan_create(c, dt, dTp.as<int>(), dTi.as<int>(), dTx.p, m, n, k, 0, 0, &planT.p), planT.p);
+    if (!dense && P.nnz >= (1 << 20)) {             // (the overlapped set-up above has usually built them already)
+        if (!planA.p) plan_or_none(rcppml_hip_rhs_plan_create(c, dt, dAp.as<int>(), dAi.as<int>(), dAx.p, n, m, k, 0, 0, &planA.p), planA.p);
+        if (!planT.p) plan_or_none(rcppml_hip_rhs_plan_create(c, dt, dTp.as<int>(), dTi.as<int>(), dTx.p, m, n, k, 0, 0, &planT.p), planT.p);
     }
     factors.finish(c);
     phase("buffers + trAtA + plans + factors", s);

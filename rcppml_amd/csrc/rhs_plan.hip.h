@@ -16,6 +16,7 @@ struct rcppml_rhs_plan {
     int* ovrow = nullptr;
     void* ovval = nullptr;
     void* Bp = nullptr;          // P > 1: per-partition partial outputs
+    unsigned* dest = nullptr;    // kind 1, created without values: where the value of nonzero e goes (rcppml_hip_rhs_plan_set_values)
     const int* colptr = nullptr; // the caller's CSC (not owned): the tail columns go through the gather kernel
     const int* rowidx = nullptr;
     const void* vals = nullptr;
@@ -36,5 +37,7 @@ struct rcppml_rhs_plan {
 // ops_rhs_win.hip
 rcppml_rhs_plan* rcppml_rw_build_f32(rcppml_hip_ctx* c, const int* colptr, const int* rowidx, const float* vals, int64_t ncols, int64_t nrows, int k, int partitions, int rate_code);
 rcppml_rhs_plan* rcppml_rw_build_f64(rcppml_hip_ctx* c, const int* colptr, const int* rowidx, const double* vals, int64_t ncols, int64_t nrows, int k, int partitions, int rate_code);
+void rcppml_rw_set_values_f32(rcppml_hip_ctx* c, rcppml_rhs_plan* pl, const float* vals);
+void rcppml_rw_set_values_f64(rcppml_hip_ctx* c, rcppml_rhs_plan* pl, const double* vals);
 void rcppml_rw_run_f32(rcppml_hip_ctx* c, const rcppml_rhs_plan* pl, const float* F, float* B);
 void rcppml_rw_run_f64(rcppml_hip_ctx* c, const rcppml_rhs_plan* pl, const double* F, double* B);

@@ -109,6 +109,15 @@ void launch_clo(rcppml_hip_ctx* c, const rcppml_rhs_plan* pl, const T* F, T* Bou
     }
 }
 
+template <class T>
+void set_values(rcppml_hip_ctx* c, rcppml_rhs_plan* pl, const T* vals) {
+    if (!pl->dest) throw std::runtime_error("rhs_plan_set_values: the plan was not created without values");
+    hipLaunchKernelGGL(rw_values_kernel<T>, dim3((unsigned)((pl->nnz + 255) / 256)), dim3(256), 0, c->stream, vals, (const unsigned*)pl->dest,
+                       pl->nnz, (T*)pl->svals, (T*)pl->ovval);
+    HIPCHK(hipGetLastError());
+    pl->vals = vals;
+}
+
 }  // namespace rw_launch
 // one translation unit per (precision, row size): ops_rhs_win_f32_nv1.hip, ...
 void rcppml_rw_launch_f32_nv1(rcppml_hip_ctx* c, const rcppml_rhs_plan* pl, const float* F, float* Bout);
@@ -305,7 +314,10 @@ rcppml_rhs_plan* build_plan(rcppml_hip_ctx* c, int dtype, const int* colptr, con
     const size_t b_ovval = up((size_t)std::max<int64_t>(pl->ovnnz, 1) * sizeof(T));
     const size_t b_slots = up(stream_bytes);
     const size_t b_bp = G.P > 1 ? up((size_t)G.P * (size_t)G.ncb * cap * (size_t)k * sizeof(T)) : 0;
-    const size_t total = b_ovptr + b_ovrow + b_ovval + b_slots + b_bp + 256;
+    const bool deferred = vals == nullptr;
+    const size_t b_dest = deferred ? up((size_t)pl->nnz * sizeof(unsigned)) : 0;
+    if (deferred && (double)stream_bytes / sizeof(T) >= 2147483648.0) return nullptr;      // dest[] addresses 2^31 slot elements
+    const size_t total = b_ovptr + b_ovrow + b_ovval + b_slots + b_bp + b_dest + 256;
     char* blk = (char*)c->arena_take(total);
     if (blk) pl->in_arena = true;
     else HIPCHK(hipMalloc((void**)&blk, total));
@@ -315,12 +327,14 @@ rcppml_rhs_plan* build_plan(rcppml_hip_ctx* c, int dtype, const int* colptr, con
     pl->ovval = blk; blk += b_ovval;
     pl->svals = blk; blk += b_slots;
     pl->Bp = G.P > 1 ? blk : nullptr;
+    blk += b_bp;
+    pl->dest = deferred ? (unsigned*)blk : nullptr;
 
     // overflow pointers (already scanned), then the scatter
     HIPCHK(hipMemcpyAsync(pl->ovptr, ovp_tmp.p, ((size_t)nseg + 1) * sizeof(int), hipMemcpyDeviceToDevice, c->stream));
     HIPCHK(hipMemsetAsync(pl->svals, 0, stream_bytes, c->stream));
     hipLaunchKernelGGL(rw_fill_kernel<T>, dim3(gseg), dim3(256), 0, c->stream, colptr, rowidx, vals, G, (char*)pl->svals,
-                       (const int*)pl->ovptr, pl->ovrow, (T*)pl->ovval);
+                       (const int*)pl->ovptr, pl->ovrow, (T*)pl->ovval, pl->dest);
     HIPCHK(hipGetLastError());
     pl->colptr = colptr; pl->rowidx = rowidx; pl->vals = vals;
     HIPCHK(hipStreamSynchronize(c->stream));          // temporaries die here

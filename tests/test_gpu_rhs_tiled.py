@@ -172,3 +172,34 @@ def test_hypersparse_input_gets_no_plan(env):
     want = F.astype(np.float64).T @ rowsum
     got = dB.double().sum(dim=0).cpu().numpy()
     assert np.abs(got - want).max() / np.abs(want).max() < 1e-5
+
+
+@pytest.mark.parametrize("dtype,k", [(np.float32, 64), (np.float64, 64)])
+def test_window_plan_in_two_steps_equals_one_step(env, dtype, k):
+    """rcppml_hip_rhs_plan_create_indices + _set_values (the plugin builds the index half while the values cross PCIe) gives the
+    plan rcppml_hip_rhs_plan_create gives: bitwise the same product; set_values again with other values re-uses the schedule; a
+    plan without values refuses to run."""
+    torch, _abi, ctx = env
+    dt = _abi.F32 if dtype == np.float32 else _abi.F64
+    tt = torch.float32 if dtype == np.float32 else torch.float64
+    A = random_csc(3000, 2500, 0.02, seed=41)
+    F = np.random.default_rng(5).standard_normal((A.rows, k)).astype(dtype)
+    dp, di, dx, dF = _dev(torch, A.p), _dev(torch, A.i), _dev(torch, A.values(dtype)), _dev(torch, F)
+    one = ctx.rhs_plan(dt, dp, di, dx, A.cols, A.rows, k, 2, 106)
+    two = ctx.rhs_plan_indices(dt, dp, di, A.cols, A.rows, k, 2, 106)
+    assert one is not None and two is not None and two.info() == one.info()
+    B1 = torch.empty((A.cols, k), dtype=tt, device="cuda")
+    B2 = torch.full((A.cols, k), 5.0, dtype=tt, device="cuda")
+    with pytest.raises(_abi.BackendError):
+        ctx.rhs_planned(two, dF, B2)
+    ctx.rhs_plan_set_values(two, dx)
+    ctx.rhs_planned(one, dF, B1)
+    ctx.rhs_planned(two, dF, B2)
+    assert torch.equal(B1, B2)
+    assert rel_err(B2.cpu().numpy(), O.rhs(A, F, dtype)) < TOL[dtype]
+    x2 = A.values(dtype) * dtype(-0.5)
+    dx2 = _dev(torch, x2)
+    ctx.rhs_plan_set_values(two, dx2)
+    ctx.rhs_planned(two, dF, B2)
+    A2 = O.Csc((A.rows, A.cols), A.p, A.i, A.x * -0.5)
+    assert rel_err(B2.cpu().numpy(), O.rhs(A2, F, dtype)) < TOL[dtype]
