@@ -24,7 +24,7 @@ constexpr int rw_dyn_lds(int NW, int NR, int CLO, int tsize) { return RW_RING + 
 constexpr int RW_MAX_CLO = 1;
 #else
 #define RW_SHAPES_NV1(X) X(12, 8) X(12, 12) X(12, 14) X(12, 17) X(16, 4) X(16, 8) X(16, 10) X(16, 13)
-#define RW_SHAPES_NV2(X) X(12, 4) X(12, 6) X(12, 8) X(12, 10) X(12, 12) X(16, 2) X(16, 4) X(16, 6) X(8, 16) X(8, 20)
+#define RW_SHAPES_NV2(X) X(12, 4) X(12, 6) X(12, 8) X(12, 9) X(12, 10) X(12, 12) X(16, 2) X(16, 4) X(16, 6) X(8, 13) X(8, 16) X(8, 20)
 #define RW_SHAPES_NV4(X) X(12, 2) X(12, 4) X(12, 6) X(16, 1) X(16, 2) X(8, 8) X(8, 10)
 constexpr int RW_MAX_CLO = 5;
 #endif
