@@ -21,7 +21,7 @@
 //
 // Slot stream (built once per fit): [column block][partition][phase][wave] blocks of sb_lo / sb_hi bytes; a block holds the
 // values of its NR*C steps x 4 lane groups (step-major), then their u16 ring offsets (byte offset of the row inside the
-// 128 KiB ring >> 4).  One or two 16-byte-per-lane LDS-DMA instructions fetch a block two phases ahead.
+// 128 KiB ring + the 1 KiB zero row in front of it, >> 4; 0 = an empty slot).  One or two 16-byte-per-lane LDS-DMA instructions fetch a block two phases ahead.
 // Summation order per output element: partition by partition; inside a partition phase by phase in slot order (= row
 // order); overflow nonzeros last, in row order.  Fixed, so results are deterministic run to run.
 // ============================================================================
@@ -34,6 +34,8 @@ constexpr int RW_NBUF = 4;                   // ring buffers
 constexpr int RW_W = RW_NBUF - 1;            // complete tiles visible in a phase
 constexpr int RW_TB = 32768;                 // bytes per tile
 constexpr int RW_RING = RW_NBUF * RW_TB;     // 128 KiB
+constexpr int RW_ZROW = 1024;                // LDS bytes [0, 1024): a row of zeros -- what an empty slot (value 0, offset 0) reads, so
+                                             // that padding never multiplies 0 with a row of F (0 x Inf would reach every column)
 constexpr int RW_MAXCAND = 12;
 
 struct RhsWinGeom {
@@ -189,7 +191,7 @@ __global__ __launch_bounds__(256) void rw_fill_kernel(const int* __restrict__ co
                      const int sidx = (q * cap + rank) * 4 + g;
                      const int row = rowidx[e];
                      const int ta = row / G.R;
-                     const unsigned off = (unsigned)((ta - t0) & (RW_NBUF - 1)) * (unsigned)RW_TB + (unsigned)(row - ta * G.R) * (unsigned)G.rowb;
+                     const unsigned off = (unsigned)RW_ZROW + (unsigned)((ta - t0) & (RW_NBUF - 1)) * (unsigned)RW_TB + (unsigned)(row - ta * G.R) * (unsigned)G.rowb;
                      if (vals) reinterpret_cast<T*>(blk)[sidx] = vals[e];
                      else dest[e] = (unsigned)(boff / (int64_t)sizeof(T)) + (unsigned)sidx;
                      reinterpret_cast<uint16_t*>(blk + (size_t)nst * 4 * sizeof(T))[sidx] = (uint16_t)(off >> 4);
@@ -293,7 +295,7 @@ __global__ __launch_bounds__(64 * NW) void rhs_win_kernel(const char* __restrict
         nx_src = Fp + ((int64_t)te << 15);
         static_assert(RW_TB == 32768, "tile_set shifts by 15");
         nx_lim = te == last_tr ? short_lim : (unsigned)RW_TB - 16u;
-        nx_dst = lds0 + (unsigned)buf * RW_TB + cstart * 1024;
+        nx_dst = lds0 + RW_ZROW + (unsigned)buf * RW_TB + cstart * 1024;
     };
     auto tile_piece = [&](int pi) {
         const unsigned po = pi < CBASE ? (unsigned)pi * 1024u : xpiece;
@@ -305,8 +307,8 @@ __global__ __launch_bounds__(64 * NW) void rhs_win_kernel(const char* __restrict
         rt_glds16_nc(nx_src, o, nx_dst + po);
 #endif
     };
-    const unsigned sl0 = lds0 + RW_RING + w * SBH;                              // this wave's slot area of stage 0
-    char* const slp = rt_slab + RW_RING + w * SBH;
+    const unsigned sl0 = lds0 + RW_ZROW + RW_RING + w * SBH;                    // this wave's slot area of stage 0
+    char* const slp = rt_slab + RW_ZROW + RW_RING + w * SBH;
     constexpr int STAGE = NW * SBH;
     const int wlo = w * SBL, whi = w * SBH;
     // slot block of phase 4 grp + K for this wave: group base + compile-time offsets
@@ -448,6 +450,7 @@ __global__ __launch_bounds__(64 * NW) void rhs_win_kernel(const char* __restrict
     };
 
     if (nph > 0) {
+        if (threadIdx.x < RW_ZROW / 16) *reinterpret_cast<V*>(rt_slab + threadIdx.x * 16) = acc[0][0];      // the zero row (acc is still 0)
         // prologue: the first RW_W tiles and the first two slot blocks
         for (int tr = 0; tr < RW_W; ++tr) {
             tile_set(tr, tr);

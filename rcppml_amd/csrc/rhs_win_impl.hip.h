@@ -13,7 +13,7 @@ using namespace rk;
 
 constexpr int RW_MAX_LDS = 160 * 1024;
 constexpr int rw_sbh(int NR, int CLO, int tsize) { return (NR * (CLO + 1) * 4 * (tsize + 2) + 15) & ~15; }
-constexpr int rw_dyn_lds(int NW, int NR, int CLO, int tsize) { return RW_RING + 2 * NW * rw_sbh(NR, CLO, tsize); }
+constexpr int rw_dyn_lds(int NW, int NR, int CLO, int tsize) { return RW_ZROW + RW_RING + 2 * NW * rw_sbh(NR, CLO, tsize); }
 
 // Compiled shapes.  NW = 12 (three waves per SIMD, 168 VGPRs) or 16 (four, 128 VGPRs); columns per workgroup = 4 NR NW.
 // A shape must fit two stages of slot blocks into the 32 KiB of LDS behind the ring.

@@ -203,3 +203,34 @@ def test_window_plan_in_two_steps_equals_one_step(env, dtype, k):
     ctx.rhs_planned(two, dF, B2)
     A2 = O.Csc((A.rows, A.cols), A.p, A.i, A.x * -0.5)
     assert rel_err(B2.cpu().numpy(), O.rhs(A2, F, dtype)) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype,k", [(np.float32, 64), (np.float64, 64)])
+def test_window_rhs_non_finite_rows_stay_in_their_columns(env, dtype, k):
+    """Empty slots read a dedicated row of zeros in LDS, not a row of F: an Inf in F reaches exactly the columns that have a nonzero in
+    that row (the reference's behaviour: primitives/cpu/rhs.hpp adds a * F(:, i) for the stored entries only), however the padding
+    of the slot stream falls."""
+    torch, _abi, ctx = env
+    dt = _abi.F32 if dtype == np.float32 else _abi.F64
+    tt = torch.float32 if dtype == np.float32 else torch.float64
+    A = random_csc(2000, 1200, 0.01, seed=77)
+    R = 32768 // (k * np.dtype(dtype).itemsize)
+    F = np.random.default_rng(1).standard_normal((A.rows, k)).astype(dtype)
+    bad_rows = np.arange(0, A.rows, R)              # the first row of every tile: where r2/r3-style padding would have pointed
+    F[bad_rows] = np.inf
+    plan = ctx.rhs_plan(dt, _dev(torch, A.p), _dev(torch, A.i), _dev(torch, A.values(dtype)), A.cols, A.rows, k, 2, 105)
+    assert plan is not None and plan.info()["fill"] < 0.9          # there IS padding
+    dB = torch.empty((A.cols, k), dtype=tt, device="cuda")
+    ctx.rhs_planned(plan, _dev(torch, F), dB)
+    B = dB.cpu().numpy()
+    touched = np.zeros(A.cols, bool)
+    isbad = np.zeros(A.rows, bool)
+    isbad[bad_rows] = True
+    for j in range(A.cols):
+        touched[j] = isbad[A.i[A.p[j]:A.p[j + 1]]].any()
+    assert touched.any() and (~touched).sum() > A.cols // 2
+    assert np.all(np.isfinite(B[~touched])) and not np.any(np.isfinite(B[touched]).all(axis=1))
+    Fz = F.copy()
+    Fz[bad_rows] = 0
+    ref = O.rhs(A, Fz, dtype)
+    assert rel_err(B[~touched], ref[~touched]) < TOL[dtype]
