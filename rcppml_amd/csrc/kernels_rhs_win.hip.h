@@ -327,21 +327,19 @@ __global__ __launch_bounds__(64 * NW) void rhs_win_kernel(const char* __restrict
             rw_glds16_lim(grp + (pre + 1024 * i) + (K < NHI ? whi : wlo), 16u * lane, sl0 + stage * STAGE + 1024 * i, left);
         }
     };
-    // the wave's slots of one stage -> registers: the kernel wants step 16 b + u of lane group g in lane 16 g + u
+    // the wave's slots of one stage -> registers: the kernel wants step 16 b + u of lane group g in lane 16 g + u, i.e. slot
+    // (16 b + u) * 4 + g.  Two per-lane base addresses for the whole kernel; stage, block b and the start of the offsets are
+    // immediates of the reads.  Lanes past the last step of a block read whatever follows it (never consumed; the LDS
+    // allocation carries 1 KiB of slack behind the last stage).
+    char* const pv = slp + ((lane & 15) * 4 + (lane >> 4)) * (int)sizeof(T);
+    char* const po = slp + ((lane & 15) * 4 + (lane >> 4)) * 2;
     auto slots_read = [&](auto ST, auto CC, T (&cv)[NB], unsigned (&co)[NB]) {
         constexpr int stage = decltype(ST)::value;
         constexpr int nst = NR * decltype(CC)::value;
-        int u = lane & 15, g = lane >> 4;
-        asm volatile("" : "+v"(u), "+v"(g));            // recomputed per phase: hoisted out of the four-phase loop the per-lane
-                                                        // addresses of every (phase, stage) pair cost more registers than there are
-        const char* src = slp + stage * STAGE;
-        const char* so = src + nst * 4 * (int)sizeof(T);
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
-            const int step = 16 * b + u;
-            const int sidx = (step < nst ? step : 0) * 4 + g;                   // lanes past the last step re-read step 0 (never consumed)
-            cv[b] = *reinterpret_cast<const T*>(src + sidx * (int)sizeof(T));
-            co[b] = (unsigned)*reinterpret_cast<const uint16_t*>(so + sidx * 2) << 4;
+            cv[b] = *reinterpret_cast<const T*>(pv + stage * STAGE + b * 64 * (int)sizeof(T));
+            co[b] = (unsigned)*reinterpret_cast<const uint16_t*>(po + stage * STAGE + nst * 4 * (int)sizeof(T) + b * 128) << 4;
         }
     };
     // Two sets of slot registers: phase t consumes set t & 1 and fills the other one MID-phase with slots(t+1) (this wave's own
@@ -351,11 +349,12 @@ __global__ __launch_bounds__(64 * NW) void rhs_win_kernel(const char* __restrict
     V f[2][UB][NV];
     // batch 0 of a phase is PRE-ISSUED before the barrier that ends the previous phase (the planner keeps the newest tile out
     // of the first UB steps of every phase), so the LDS pipeline is full when the barrier opens
+    int lbase = (lane & 15) * 16;                   // re-materialised once per phase (see slots_read), NOT per batch: a fresh VALU
+                                                    // result in front of every batch's first DPP add costs two instructions and the
+                                                    // DPP hazard's wait states, nine times per phase
     auto reads = [&](auto QB, auto CC, const unsigned (&cox)[NB]) {
         constexpr int b = decltype(QB)::value;
         constexpr int NST = NR * decltype(CC)::value;
-        int lbase = (lane & 15) * 16;
-        asm volatile("" : "+v"(lbase));
         rt_static_for<0, UB>([&](auto I) {
             constexpr int i = decltype(I)::value;
             constexpr int step = b * UB + i;
@@ -374,6 +373,7 @@ __global__ __launch_bounds__(64 * NW) void rhs_win_kernel(const char* __restrict
         constexpr int NBATCH = (NST + UB - 1) / UB;
         constexpr int K1 = (K + 1) & 3, K2 = (K + 2) & 3;
         constexpr int C1 = CLO + (K1 < NHI ? 1 : 0);
+        asm volatile("" : "+v"(lbase));
         constexpr int S = K & 1;                            // slot register set of this phase
         constexpr int MID = NBATCH / 2;                     // the batch after which slots(t+1) go to registers
         constexpr int NSDK = ((K2 < NHI ? SBH : SBL) + 1023) / 1024;      // LDS-DMA pieces of the slot block fetched in this phase

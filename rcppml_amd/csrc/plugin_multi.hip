@@ -91,10 +91,11 @@ struct Exchange {
     std::vector<hipStream_t> streams;
     std::vector<int> devs;
     DevBuf ptrs;                       // shared mode: device array of the n buffer pointers
-    std::vector<hipEvent_t> ev;
+    std::vector<hipEvent_t> ev, ev2;
     ~Exchange() {
         for (auto c : comms) if (c) (void)rccl().CommDestroy(c);
         for (auto e : ev) if (e) (void)hipEventDestroy(e);
+        for (auto e : ev2) if (e) (void)hipEventDestroy(e);
     }
     void init(const std::vector<int>& devices, const std::vector<hipStream_t>& st, bool share) {
         n = (int)devices.size(); devs = devices; streams = st; shared = share;
@@ -103,6 +104,8 @@ struct Exchange {
             ptrs.alloc((size_t)n * sizeof(void*));
             ev.resize(n + 1, nullptr);
             for (auto& e : ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            ev2.resize(n, nullptr);
+            for (auto& e : ev2) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         } else {
             rccl().load();
             comms.assign(n, nullptr);
@@ -146,6 +149,13 @@ struct Exchange {
                     HIPCHK(hipMemcpyAsync((T*)bufs[q] + (size_t)r * count, (const T*)bufs[r] + (size_t)r * count, count * sizeof(T),
                                           hipMemcpyDeviceToDevice, streams[q]));
                 }
+            }
+            // a collective ends for everybody at once: no stream may go on (and scale its W in place) while another one is still
+            // copying its block out of it
+            for (int q = 0; q < n; ++q) { HIPCHK(hipSetDevice(devs[q])); HIPCHK(hipEventRecord(ev2[q], streams[q])); }
+            for (int r = 0; r < n; ++r) {
+                HIPCHK(hipSetDevice(devs[r]));
+                for (int q = 0; q < n; ++q) if (q != r) HIPCHK(hipStreamWaitEvent(streams[r], ev2[q], 0));
             }
             return;
         }

@@ -13,7 +13,7 @@ using namespace rk;
 
 constexpr int RW_MAX_LDS = 160 * 1024;
 constexpr int rw_sbh(int NR, int CLO, int tsize) { return (NR * (CLO + 1) * 4 * (tsize + 2) + 15) & ~15; }
-constexpr int rw_dyn_lds(int NW, int NR, int CLO, int tsize) { return RW_ZROW + RW_RING + 2 * NW * rw_sbh(NR, CLO, tsize); }
+constexpr int rw_dyn_lds(int NW, int NR, int CLO, int tsize) { return RW_ZROW + RW_RING + 2 * NW * rw_sbh(NR, CLO, tsize) + 1024; }   // + slack: slot reads past a block's last step
 
 // Compiled shapes.  NW = 12 (three waves per SIMD, 168 VGPRs) or 16 (four, 128 VGPRs); columns per workgroup = 4 NR NW.
 // A shape must fit two stages of slot blocks into the 32 KiB of LDS behind the ring.
@@ -31,8 +31,8 @@ constexpr int RW_MAX_CLO = 5;
 // slot rates compiled: CLO + NHI / 4 with quarter steps up to 2 slots per phase, half steps above
 // shapes hipcc cannot keep in registers (checked with tools/kres.sh: every compiled kernel must report ScratchSize 0)
 constexpr bool shape_spills(int NV, int CLO, int NHI, int NW, int NR) {       // NHI < 0: unknown yet
-    return NV == 2 && ((NW == 16 && NR == 6 && CLO >= 4) || (NW == 12 && NR == 10 && CLO >= 4) ||
-                       (NW == 12 && NR == 12 && CLO >= 2 && NHI == 4) || (NW == 8 && NR == 20 && CLO == 1 && NHI == 4));
+    return NV == 2 && ((NW == 16 && NR == 6 && CLO >= 4) || (NW == 12 && NR == 10 && CLO >= 4) || (NW == 12 && NR == 12 && CLO >= 2) ||
+                       (NW == 8 && NR == 20 && CLO <= 1 && NHI == 4));
 }
 constexpr bool rate_compiled(int CLO, int NHI) {
     return CLO >= 0 && CLO <= RW_MAX_CLO && NHI >= 1 && NHI <= 4 && (CLO <= 1 || NHI == 2 || NHI == 4);
