@@ -38,6 +38,19 @@ template <class T> __device__ __forceinline__ T wave_max(T v) {
 }
 
 
+// value of lane I of the caller's 16-lane DPP row, in every lane of that row (row_newbcast, gfx90a+; folds into a VOP2 consumer)
+template <int I> __device__ __forceinline__ float row_bcast(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x150 + I, 0xf, 0xf, true));
+}
+// d0 += g0 * s, d1 += g1 * s with s = lane I of the row's `src`: two v_fmac_f32 with the DPP broadcast folded into their first
+// operand.  (hipcc emits v_mov_b32_dpp + two fmacs for the builtin, and defers / spills the broadcasts of a half sweep.)  The
+// s_nop covers the two wait states a DPP read needs after the VALU write of `src`.
+template <int I> __device__ __forceinline__ void row_fmac2(float& d0, float& d1, float src, float g0, float g1) {
+    asm volatile("s_nop 1\n\tv_fmac_f32_dpp %0, %2, %3 row_newbcast:%5 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f32_dpp %1, %2, %4 row_newbcast:%5 row_mask:0xf bank_mask:0xf"
+                 : "+v"(d0), "+v"(d1) : "v"(src), "v"(g0), "v"(g1), "n"(I));
+}
+
 // math/loss.hpp:248-256  irls_weight_nb: computed in double, eps = tiny_num<Scalar>() = Scalar(1e-15)
 template <class T> __device__ __forceinline__ T irls_weight_nb_dev(T predicted, T nb_size) {
     double mu = static_cast<double>(predicted);
@@ -236,13 +249,22 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8
             // ---- phase B: nonzeros (2s, 2s+1) of the chunk per MFMA
             const int cnt = ae - t0 < CH ? ae - t0 : CH;
             const int nst = (cnt + 1) >> 1;
-#pragma unroll 4
-            for (int s2 = 0; s2 < nst; ++s2) {
-                const int t = 2 * s2 + hh;
-                const float fv = Fst[t * FS + r];
-                const float2 ws = sc[t];
-                bw = tfma(ws.y, fv, bw);                                          // b_w += f * (w a)
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ws.x * fv, fv, acc, 0, 0, 0);   // G_w += (f (w-1)) f^T
+            // (groups of four: the eight LDS reads of a group are issued ahead of its MFMAs; the nonzeros past cnt are staged as zero
+            //  rows with zero weights, so rounding the count up adds exact zeros)
+            for (int s2 = 0; s2 < nst; s2 += 4) {
+                float fv[4];
+                float2 ws[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int t = 2 * (s2 + u) + hh;
+                    fv[u] = Fst[t * FS + r];
+                    ws[u] = sc[t];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    bw = tfma(ws[u].y, fv[u], bw);                                    // b_w += f * (w a)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ws[u].x * fv[u], fv[u], acc, 0, 0, 0);   // G_w += (f (w-1)) f^T
+                }
             }
             __builtin_amdgcn_wave_barrier();
         }
@@ -286,6 +308,233 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8
     if (fok) X[j * (int64_t)k + lane] = x;
     // work counters (RCPPML_OPT_CD_COUNT_NOOP only): IRLS passes and nonzero-passes = weighted-Gram rank-1 updates
     if (stats && lane == 0) { atomicAdd(stats, (unsigned long long)passes); atomicAdd(stats + 1, (unsigned long long)passes * (unsigned long long)(ae - as)); }
+}
+
+// ---------------------------------------------------------------------------
+// fp32, k <= 32 (k % 4 == 0), MANY columns (H side of C5: 200 000 columns of ~190 nonzeros): FOUR columns per wavefront.
+// The CD solve of the kernel above spends 4 VALU operations per coordinate and sweep with half of the wave's lanes idle
+// (k = 32) and one column in flight; it is VALU-issue bound there (the solves are half of the H side's time).  Here the solve
+// puts one column on each 16-lane DPP row, a lane holding TWO coordinates (l and l + 16) and the two matching rows of its
+// column's scaled Gram (64 registers): coordinate i's step is broadcast inside every row at once by DPP row_newbcast folded
+// into the consuming v_fmac (no v_readlane / SGPR round trip), so one coordinate costs med3 + 2 fmac_dpp + 1 select for
+// FOUR columns instead of four operations for one.  The weighted Grams of the four columns are built one after the other by
+// the whole wave exactly as above (MFMA, chunks of 64 nonzeros = two phase-A halves so that every lane evaluates ONE NB
+// weight -- in the kernel above both halves of the wave evaluate the same 32), parked in the wave's LDS slab and picked up by
+// the column's row (columns l and l + 16 of the slab: 64 four-byte reads, conflict-free).
+// Steps, their order and the arithmetic of a column are those of irls_nb_mfma32_kernel: results are bit-identical to it
+// (tests/test_gpu_nb.py::test_quad_equals_single).  A column that converged keeps its iterate: its row holds a zero Gram and a
+// zero residual from then on, so the sweeps the other columns still need do not move it.
+// 128 VGPRs (four waves per SIMD = 16 columns per SIMD against 8), 9.75 KiB of LDS per wave.
+// ---------------------------------------------------------------------------
+template <int LT>
+static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void irls_nb_mfma32q_kernel(
+    const int* __restrict__ colptr, const int* __restrict__ rowidx, const float* __restrict__ vals, int64_t ncols,
+    const float* __restrict__ F, const float* __restrict__ Gbase, float* __restrict__ X, int k, float l1, float l2,
+    int nonneg, int cd_maxit, int irls_max_iter, float irls_tol, const float* __restrict__ theta_row,
+    const float* __restrict__ theta_col, int loss_type, float power, float robust,
+    unsigned long long* __restrict__ stats) {
+    constexpr int KP = 32, CH = 64, FS = 36;          // FS: padded row stride of the staged F rows and of the G_w slab
+    constexpr int WAVE_FLOATS = CH * FS + 2 * CH + 2 * KP;  // staged rows | (w-1, w a) pairs | x | b_w
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float* Fst = reinterpret_cast<float*>(smem_raw) + (size_t)wave * WAVE_FLOATS;
+    float2* sc = reinterpret_cast<float2*>(Fst + CH * FS);
+    float* xs = Fst + CH * FS + 2 * CH;
+    float* bws = xs + KP;
+    float* Gl = Fst;                                    // [i][c], stride FS: reused once a column's Gram is complete
+    const int64_t jw = ((int64_t)blockIdx.x * 4 + wave) * 4;      // first of this wave's four columns
+    if (jw >= ncols) return;
+    const int r = lane & 31, hh = lane >> 5;            // Gram phases: nonzero / feature r, half hh
+    const int qme = lane >> 4, l = lane & 15;           // solve: column jw + qme, coordinates l and l + 16
+    const int64_t jme = jw + qme;
+    const bool fok0 = l < k, fok1 = l + 16 < k;
+    bool active = jme < ncols;                          // uniform over a row
+    float x0 = 0.f, x1 = 0.f;                           // nnls_batch_irls.hpp:482-483  H.setZero(): no warm start
+    int passes = 0;
+    float ng0[KP], ng1[KP];                             // rows l and l + 16 of the column's Gram, then of -G_w / G_ii
+#pragma unroll
+    for (int c = 0; c < KP; ++c) { ng0[c] = 0.f; ng1[c] = 0.f; }
+    const float pinf = __builtin_inff();
+    const float inf_rt = cd_maxit >= 0 ? pinf : 0.f;
+    for (int irls = 0; irls < irls_max_iter; ++irls) {
+        const unsigned long long act = __ballot(active);
+        if (!act) break;
+        if (active) ++passes;
+        float b0 = 0.f, b1 = 0.f, gd0 = 0.f, gd1 = 0.f;
+        for (int q = 0; q < 4; ++q) {
+            if (!((act >> (16 * q)) & 1ull)) continue;                           // wave-uniform
+            const int64_t j = jw + q;
+            const int as = colptr[j], ae = colptr[j + 1];
+            const float th_col = theta_col ? theta_col[j] : 0.f;
+            if (qme == q) { xs[l] = x0; xs[l + 16] = x1; }
+            // accumulator tile <- base Gram (identity padding), C/D map: col = lane&31, row = (v&3) + 8(v>>2) + 4(lane>>5)
+            // (four 16-byte loads off one per-lane pointer: k % 4 == 0 keeps a group of four rows on one side of k)
+            f32x16 acc;
+            const float* gb = Gbase + (int64_t)r * k + 4 * hh;
+            asm volatile("" : "+v"(gb));                 // per pass, not 16 hoisted addresses
+#pragma unroll
+            for (int v4 = 0; v4 < 4; ++v4) {
+                const int gi0 = 8 * v4 + 4 * hh;
+                const float4 g = (gi0 < k && r < k) ? *reinterpret_cast<const float4*>(gb + 8 * v4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                const bool pad = r >= k;
+                acc[4 * v4 + 0] = pad && gi0 + 0 == r ? 1.f : g.x;
+                acc[4 * v4 + 1] = pad && gi0 + 1 == r ? 1.f : g.y;
+                acc[4 * v4 + 2] = pad && gi0 + 2 == r ? 1.f : g.z;
+                acc[4 * v4 + 3] = pad && gi0 + 3 == r ? 1.f : g.w;
+            }
+            float bw = 0.f;
+            __builtin_amdgcn_wave_barrier();
+            for (int t0 = as; t0 < ae; t0 += CH) {
+                // ---- phase A: two halves of 32 nonzeros (lane = nonzero r of the half, feature half hh), then ONE weight per lane
+                float recon_me = 0.f, a_me = 0.f;
+                int row_me = 0;
+                bool ok_me = false;
+#pragma unroll 1
+                for (int sub = 0; sub < 2; ++sub) {
+                    const int tt = t0 + 32 * sub + r;
+                    const bool ok = tt < ae;
+#ifdef IRLS_FAKE_ROWS
+                    const int row = ok ? (rowidx[tt] & 7) : 0;      // probe: every gather an L1 hit
+#else
+                    const int row = ok ? rowidx[tt] : 0;
+#endif
+                    const float a = ok ? vals[tt] : 0.f;
+                    const float* fsrc = F + (int64_t)row * k + 16 * hh;
+                    float4 fv4[4];
+                    float part = 0.f;
+#pragma unroll
+                    for (int qq = 0; qq < 4; ++qq) {
+                        const int c0 = 16 * hh + 4 * qq;
+                        fv4[qq] = (ok && c0 < k) ? *reinterpret_cast<const float4*>(fsrc + 4 * qq) : make_float4(0.f, 0.f, 0.f, 0.f);
+                        const float4 xv = *reinterpret_cast<const float4*>(xs + c0);
+                        part = tfma(fv4[qq].x, xv.x, part);
+                        part = tfma(fv4[qq].y, xv.y, part);
+                        part = tfma(fv4[qq].z, xv.z, part);
+                        part = tfma(fv4[qq].w, xv.w, part);
+                    }
+                    const float recon = part + __shfl_xor(part, 32, 64);             // W_T.col(row).dot(x)
+#pragma unroll
+                    for (int qq = 0; qq < 4; ++qq) *reinterpret_cast<float4*>(Fst + (32 * sub + r) * FS + 16 * hh + 4 * qq) = fv4[qq];
+                    if (hh == sub) { recon_me = recon; a_me = a; row_me = row; ok_me = ok; }
+                }
+                const float th = theta_col ? th_col : (theta_row ? theta_row[row_me] : 0.f);
+                const float w = irls_weight_full_dev<float>(LT >= 0 ? LT : loss_type, a_me - recon_me, recon_me, th, power, LT >= 0 ? 0.f : robust);
+                sc[lane] = make_float2(ok_me ? w - 1.f : 0.f, ok_me ? w * a_me : 0.f);   // lane = 32 hh + r = the nonzero's place in the chunk
+                __builtin_amdgcn_wave_barrier();
+                // ---- phase B: nonzeros (2s, 2s+1) of the chunk per MFMA
+                const int cnt = ae - t0 < CH ? ae - t0 : CH;
+                const int nst = (cnt + 1) >> 1;
+                // (groups of four: the eight LDS reads of a group are issued ahead of its MFMAs; the nonzeros past cnt are staged as
+                //  zero rows with zero weights, so rounding the count up adds exact zeros)
+                for (int s2 = 0; s2 < nst; s2 += 4) {
+                    float fv[4];
+                    float2 ws[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int t = 2 * (s2 + u) + hh;
+                        fv[u] = Fst[t * FS + r];
+                        ws[u] = sc[t];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        bw = tfma(ws[u].y, fv[u], bw);                                // b_w += f * (w a)
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ws[u].x * fv[u], fv[u], acc, 0, 0, 0);   // G_w += (f (w-1)) f^T
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+            bw += __shfl_xor(bw, 32, 64);
+            // park G_w in the slab (symmetric: accumulator row gi is slab row gi) and b_w next to it
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int gi = (v & 3) + 8 * (v >> 2) + 4 * hh;
+                float val = acc[v];
+                if (l2 > 0.f && gi == r && gi < k) val += l2;
+                Gl[gi * FS + r] = val;
+            }
+            if (lane < KP) bws[lane] = bw;
+            __builtin_amdgcn_wave_barrier();
+            if (qme == q) {                              // the column's row picks up rows l and l + 16 of G_w
+                // (COLUMNS l and l + 16 of the slab, as the one-column kernel reads them: the MFMA's G_w(i, j) = sum ((w-1) f_i) f_j is
+                //  not bitwise symmetric)
+#pragma unroll
+                for (int c = 0; c < KP; ++c) { ng0[c] = Gl[c * FS + l]; ng1[c] = Gl[c * FS + l + 16]; }
+                gd0 = Gl[l * FS + l];
+                gd1 = Gl[(l + 16) * FS + l + 16];
+                b0 = bws[l];
+                b1 = bws[l + 16];
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        // ---- all (still iterating) columns of the wave at once: residual b_c = b_w - G_w x_old, coordinates in order
+        const float xo0 = x0, xo1 = x1;
+        {
+            const float nx0 = -xo0, nx1 = -xo1;          // fma(-g, x, b) = fma(g, -x, b)
+            cd_static_for<0, 16>([&](auto IC) { constexpr int i = decltype(IC)::value; row_fmac2<i>(b0, b1, nx0, ng0[i], ng1[i]); });
+            cd_static_for<0, 16>([&](auto IC) { constexpr int i = decltype(IC)::value; row_fmac2<i>(b0, b1, nx1, ng0[16 + i], ng1[16 + i]); });
+        }
+        // cd_nnls_col_fixed(G_w, b_c, x, L1 inside, L2 = 0, nonneg, cd_maxit, ub = 0, tol = 0), static scaled form (kernels.hip.h):
+        // d = b / G_ii - L1, rows scaled by -1 / G_ii once; a row that is done (or dead) holds zeros and never moves
+        const bool alive0 = active && fok0 && gd0 > 0.f, alive1 = active && fok1 && gd1 > 0.f;
+        const float ginv0 = alive0 ? 1.f / gd0 : 0.f, ginv1 = alive1 ? 1.f / gd1 : 0.f;
+#pragma unroll
+        for (int c = 0; c < KP; ++c) { ng0[c] *= -ginv0; ng1[c] *= -ginv1; }
+        float d0 = __builtin_fmaf(active ? b0 : 0.f, ginv0, alive0 ? -l1 : 0.f);
+        float d1 = __builtin_fmaf(active ? b1 : 0.f, ginv1, alive1 ? -l1 : 0.f);
+        unsigned long long lane0_of_rows = 0x0001000100010001ull;
+        asm volatile("" : "+s"(lane0_of_rows));        // opaque: shifted at run time, not sixteen 64-bit literals
+        for (int it = 0; it < cd_maxit; ++it) {
+            const float xe0 = nonneg ? x0 : pinf, xe1 = nonneg ? x1 : pinf;
+            float aown0 = 0.f, aown1 = 0.f;
+            const float nxe0 = -xe0, nxe1 = -xe1;
+            // the lane whose turn it is keeps its step: lane mask of (l == i) as ONE scalar pair shifted by a SALU operation per
+            // coordinate (sixteen compare results held in SGPRs cost 32 of them and spill)
+            unsigned long long turn = lane0_of_rows;
+            cd_static_for<0, 16>([&](auto IC) {
+                constexpr int i = decltype(IC)::value;
+                const float ad = cd_static_max(d0, nxe0, inf_rt);
+                asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(aown0) : "v"(ad), "s"(turn));
+                turn <<= 1;
+                row_fmac2<i>(d0, d1, ad, ng0[i], ng1[i]);
+            });
+            turn = lane0_of_rows;
+            cd_static_for<0, 16>([&](auto IC) {
+                constexpr int i = decltype(IC)::value;
+                const float ad = cd_static_max(d1, nxe1, inf_rt);
+                asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(aown1) : "v"(ad), "s"(turn));
+                turn <<= 1;
+                row_fmac2<i>(d0, d1, ad, ng0[16 + i], ng1[16 + i]);
+            });
+            const float xn0 = x0 + aown0, xn1 = x1 + aown1;
+            const bool moved = xn0 != x0 || xn1 != x1;
+            x0 = xn0; x1 = xn1;
+            const unsigned long long mv = __ballot(moved);
+            if (!mv) break;
+            // a column none of whose coordinates moved is at the fixed point the one-column kernel stops at: zero residuals make
+            // every later step of its row exactly zero (the columns sharing the wave may need more sweeps)
+            if (!((mv >> (lane & 48)) & 0xffffull)) { d0 = 0.f; d1 = 0.f; }
+        }
+        float rel = fok0 ? tabs(x0 - xo0) / (tabs(xo0) + 1e-12f) : 0.f;
+        const float rel1 = fok1 ? tabs(x1 - xo1) / (tabs(xo1) + 1e-12f) : 0.f;
+        rel = rel1 > rel ? rel1 : rel;
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) {
+            const float o = __shfl_xor(rel, off, 64);
+            rel = o > rel ? o : rel;
+        }
+        if (rel < irls_tol) active = false;
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (jme < ncols) {
+        if (fok0) X[jme * (int64_t)k + l] = x0;
+        if (fok1) X[jme * (int64_t)k + l + 16] = x1;
+        // work counters (RCPPML_OPT_CD_COUNT_NOOP only): IRLS passes and nonzero-passes = weighted-Gram rank-1 updates
+        if (stats && l == 0) {
+            const int nzc = colptr[jme + 1] - colptr[jme];
+            atomicAdd(stats, (unsigned long long)passes);
+            atomicAdd(stats + 1, (unsigned long long)passes * (unsigned long long)nzc);
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------

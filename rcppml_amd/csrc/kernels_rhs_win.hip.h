@@ -355,6 +355,31 @@ __global__ __launch_bounds__(64 * NW) void rhs_win_kernel(const char* __restrict
     auto reads = [&](auto QB, auto CC, const unsigned (&cox)[NB]) {
         constexpr int b = decltype(QB)::value;
         constexpr int NST = NR * decltype(CC)::value;
+#ifdef RW_ASM_READS
+        // LDS reads hipcc does not see: no per-register lgkmcnt bookkeeping (it waits in front of every FMA pair), one counted
+        // wait per batch (rt_wait_lgkm in the phase) with a scheduling barrier behind it, because nothing else ties the FMAs
+        // to that wait.  The batch's addresses first, each in its own register: re-using one address register behind a read
+        // that still holds it costs hazard wait states.
+        int ad[UB];
+        rt_static_for<0, UB>([&](auto I) {
+            constexpr int i = decltype(I)::value;
+            constexpr int step = b * UB + i;
+            if constexpr (step < NST) ad[i] = lbase + rt_bc<(step & 15)>((int)cox[step >> 4]);
+        });
+        rt_static_for<0, UB>([&](auto I) {
+            constexpr int i = decltype(I)::value;
+            constexpr int step = b * UB + i;
+            if constexpr (step < NST) {
+                rt_static_for<0, NV>([&](auto VV) {
+                    constexpr int v = decltype(VV)::value;
+                    V got;
+                    const int aa = ad[i];
+                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(got) : "v"(aa), "n"(256 * v));
+                    f[b & 1][i][v] = got;
+                });
+            }
+        });
+#else
         rt_static_for<0, UB>([&](auto I) {
             constexpr int i = decltype(I)::value;
             constexpr int step = b * UB + i;
@@ -364,6 +389,7 @@ __global__ __launch_bounds__(64 * NW) void rhs_win_kernel(const char* __restrict
                 for (int v = 0; v < NV; ++v) f[b & 1][i][v] = *reinterpret_cast<const V*>(rt_slab + a + 256 * v);
             }
         });
+#endif
     };
     // one phase: K = t & 3 (compile time); sgrp = slot-stream base of the group of phase t
     auto phase = [&](auto KK, int t, const char* sgrp) {
@@ -405,6 +431,9 @@ __global__ __launch_bounds__(64 * NW) void rhs_win_kernel(const char* __restrict
                 if constexpr (b + 1 < NBATCH) reads(std::integral_constant<int, b + 1>{}, std::integral_constant<int, C>{}, co[S]);
                 __builtin_amdgcn_sched_barrier(0);
                 rt_wait_lgkm<nnext>();                  // LDS returns in order: everything but the reads just issued is back
+#ifdef RW_ASM_READS
+                __builtin_amdgcn_sched_barrier(0);
+#endif
                 rt_static_for<0, UB>([&](auto I) {
                     constexpr int i = decltype(I)::value;
                     constexpr int step = b * UB + i;

@@ -495,3 +495,69 @@ def test_nb_fit_with_upper_bounds():
     assert res["status"] == 0, res.get("error")
     assert abs(res["loss"] - ref.loss) / abs(ref.loss) < 1e-6
     assert np.abs(W - ref.W_T).max() < 1e-6 and np.abs(H - ref.H).max() < 1e-6
+
+
+@pytest.mark.parametrize("k", [8, 20, 32])
+@pytest.mark.parametrize("loss,opts", [(5, dict()), (5, dict(l1=0.05)), (5, dict(nonneg=0)), (4, dict()), (6, dict(robust_delta=1.5)),
+                                       (5, dict(cd_maxit=3, irls_max_iter=2))])
+def test_quad_equals_single(env, k, loss, opts):
+    """Four columns per wavefront (irls_nb_mfma32q_kernel, what many-column sides run) against one (irls_nb_mfma32_kernel), forced
+    through RCPPML_OPT_IRLS_COLUMNS_PER_WAVE: the arithmetic of a column is the same, so the results are bit-identical --
+    ragged and empty columns, a column count that is no multiple of 16, theta by row and by column, L1, no clamp, robust
+    weights, truncated sweeps."""
+    torch, _abi, ctx = env
+    rng = np.random.default_rng(100 * k + loss)
+    A = _nb_problem(180, 1003, 4, seed=k + loss)
+    # empty and near-empty columns, one dense column
+    x = A.x.copy()
+    p = A.p
+    for j in (0, 5, 17, 500, 1002):
+        x[p[j]:p[j + 1]] = 0
+    import scipy.sparse as sp
+    S = sp.csc_matrix((x, A.i, A.p), shape=(A.rows, A.cols)).tolil()
+    S[:, 33] = rng.integers(1, 9, size=(A.rows, 1))
+    S = S.tocsc()
+    S.eliminate_zeros()
+    S.sort_indices()
+    M = O.Csc(S.shape, S.indptr.astype(np.int32), S.indices.astype(np.int32), S.data.astype(np.float64))
+    for by_row in (True, False):
+        F = rng.uniform(0.05, 1.0, size=(M.rows, k)).astype(np.float32)
+        F /= F.sum(axis=0, keepdims=True)
+        F *= 30.0
+        G = O.gram(F)
+        theta = rng.uniform(2.0, 20.0, size=(M.rows if by_row else M.cols)).astype(np.float32)
+        out = {}
+        for cpw in (1, 4):
+            ctx.set_option(_abi.OPT_IRLS_COLUMNS_PER_WAVE, cpw)
+            dX = torch.full((M.cols, k), 3.0, dtype=torch.float32, device="cuda")
+            ctx.solve_irls(_abi.F32, loss, _dev(torch, M.p), _dev(torch, M.i), _dev(torch, M.values(np.float32)), M.cols,
+                           _dev(torch, F), _dev(torch, G), dX, k, l2=1e-3, theta_row=_dev(torch, theta) if by_row else None,
+                           theta_col=None if by_row else _dev(torch, theta), **opts)
+            out[cpw] = dX.cpu().numpy()
+        ctx.set_option(_abi.OPT_IRLS_COLUMNS_PER_WAVE, 0)
+        assert np.all(np.isfinite(out[4]))
+        assert np.array_equal(out[1], out[4]), float(np.abs(out[1] - out[4]).max())
+
+
+@pytest.mark.parametrize("k", [4, 16, 32])
+def test_irls_nb_half_update_four_columns_per_wave(env, k):
+    """The four-columns-per-wavefront kernel against the oracle (same check as test_irls_nb_half_updates, fp32 rows)."""
+    torch, _abi, ctx = env
+    A = _nb_problem(150, 220, 4, seed=k)
+    rng = np.random.default_rng(k)
+    F = rng.uniform(0.05, 1.0, size=(A.rows, k)).astype(np.float32)
+    F /= F.sum(axis=0, keepdims=True)
+    F *= 30.0
+    G = O.gram(F)
+    theta = rng.uniform(2.0, 20.0, size=A.rows).astype(np.float32)
+    ref = O.irls_nb(A, F, G, k, L1=0.0, L2=1e-3, theta_row=theta, theta_col=None, dtype=np.float32)
+    dX = torch.full((A.cols, k), 3.0, dtype=torch.float32, device="cuda")
+    ctx.set_option(_abi.OPT_IRLS_COLUMNS_PER_WAVE, 4)
+    try:
+        ctx.solve_irls_nb(_abi.F32, _dev(torch, A.p), _dev(torch, A.i), _dev(torch, A.values(np.float32)), A.cols, _dev(torch, F),
+                          _dev(torch, G), dX, k, l1=0.0, l2=1e-3, theta_row=_dev(torch, theta), theta_col=None)
+    finally:
+        ctx.set_option(_abi.OPT_IRLS_COLUMNS_PER_WAVE, 0)
+    X = dX.cpu().numpy()
+    assert X.min() >= 0 and np.all(np.isfinite(X))
+    assert np.abs(X - ref).max() / np.abs(ref).max() < 3e-2
