@@ -560,10 +560,8 @@ def bench_c5(args):
     def step():
         half("H")
         half("W")
-        with ops._timed("nb_size"):
-            ops.ctx.nb_size_update(ops.dt, Atd["p"], Atd["i"], Atd["x"], m, W, d, H, n, k, 0.01, 1e6, theta)
-        with ops._timed("loss"):
-            ops.ctx.irls_loss(ops.dt, 5, Ad["p"], Ad["i"], Ad["x"], n, W, d, H, theta, k, out4)
+        with ops._timed("nb_size_loss"):         # per-row sizes, then the likelihood with them: one pass over A^T, as the plugin's loop
+            ops.ctx.nb_size_update_loss(ops.dt, Atd["p"], Atd["i"], Atd["x"], m, At.nnz, W, d, H, n, k, 0.01, 1e6, theta, out4)
 
     for _ in range(args.warmup):
         step()

@@ -488,6 +488,15 @@ RCPPML_GPU_API int rcppml_hip_nb_size_update(rcppml_hip_ctx* ctx, int dtype, con
                                              const int* t_row_idx, const void* t_values, int64_t m, const void* W_T,
                                              const void* d, const void* H, int64_t n, int k, double r_min,
                                              double r_max, void* nb_size);
+/* The two calls above and below in one pass over CSC(A^T) (PER_ROW dispersion, no robust modifier): nb_size updated as by
+ * rcppml_hip_nb_size_update, then out[0] = the NB negative log-likelihood with the UPDATED sizes, as rcppml_hip_nb_loss returns it
+ * (the order of the reference's fit loop, nmf/fit_cpu.hpp:1094-1265 then :1684-1753 / explicit_loss.hpp:53-77).  The predictions of
+ * the first pass are parked (nnz Scalars of context scratch) and the likelihood terms are evaluated from them: one gather of
+ * factor rows per nonzero instead of two, lgamma(r_i) once per row.  nnz = t_col_ptr[m]. */
+RCPPML_GPU_API int rcppml_hip_nb_size_update_loss(rcppml_hip_ctx* ctx, int dtype, const int* t_col_ptr,
+                                                  const int* t_row_idx, const void* t_values, int64_t m, int64_t nnz,
+                                                  const void* W_T, const void* d, const void* H, int64_t n, int k,
+                                                  double r_min, double r_max, void* nb_size, double* out);
 /* out[0] = NB negative log-likelihood over the NONZEROS of A with per-row size -- reference nmf/explicit_loss.hpp:53-77,
  * math/loss.hpp:415-426. */
 RCPPML_GPU_API int rcppml_hip_nb_loss(rcppml_hip_ctx* ctx, int dtype, const int* col_ptr, const int* row_idx,

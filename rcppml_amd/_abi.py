@@ -25,7 +25,7 @@ EXPORTED_SYMBOLS = [
     "rcppml_hip_ctx_create", "rcppml_hip_ctx_destroy", "rcppml_hip_ctx_sync", "rcppml_hip_ctx_stats", "rcppml_hip_ctx_irls_stats", "rcppml_hip_ctx_cd_step_stats", "rcppml_hip_ctx_set_option", "rcppml_hip_transpose_csc", "rcppml_hip_transpose_csc_sort", "rcppml_hip_transpose_csc_gather", "rcppml_hip_cast", "rcppml_hip_gram", "rcppml_hip_rhs",
     "rcppml_hip_solve_cd", "rcppml_hip_order_columns", "rcppml_hip_solve_chol", "rcppml_hip_row_norms", "rcppml_hip_apply_scaling",
     "rcppml_hip_sumsq", "rcppml_hip_loss_mse", "rcppml_hip_solve_masked", "rcppml_hip_loss_nonzeros",
-    "rcppml_hip_solve_irls_nb", "rcppml_hip_nb_size_update", "rcppml_hip_nb_loss", "rcppml_hip_solve_irls", "rcppml_hip_irls_loss", "rcppml_hip_apply_l21", "rcppml_hip_angular_posthoc", "rcppml_hip_solve_cv", "rcppml_hip_cv_test_error", "rcppml_hip_solve_cv_irls", "rcppml_hip_cv_irls_loss", "rcppml_hip_cv_gp_theta_update", "rcppml_hip_mul_rows", "rcppml_hip_apply_graph_reg", "rcppml_hip_dispersion_update", "rcppml_hip_vec_global", "rcppml_hip_spz_info", "rcppml_hip_spz_decode",
+    "rcppml_hip_solve_irls_nb", "rcppml_hip_nb_size_update", "rcppml_hip_nb_size_update_loss", "rcppml_hip_nb_loss", "rcppml_hip_solve_irls", "rcppml_hip_irls_loss", "rcppml_hip_apply_l21", "rcppml_hip_angular_posthoc", "rcppml_hip_solve_cv", "rcppml_hip_cv_test_error", "rcppml_hip_solve_cv_irls", "rcppml_hip_cv_irls_loss", "rcppml_hip_cv_gp_theta_update", "rcppml_hip_mul_rows", "rcppml_hip_apply_graph_reg", "rcppml_hip_dispersion_update", "rcppml_hip_vec_global", "rcppml_hip_spz_info", "rcppml_hip_spz_decode",
     "rcppml_sp_read_gpu", "rcppml_sp_free_gpu", "rcppml_hip_rhs_dense", "rcppml_gpu_nmf_dense_unified_float",
     "rcppml_gpu_nmf_dense_unified_double",
     "rcppml_hip_rhs_plan_create", "rcppml_hip_rhs_plan_create_indices", "rcppml_hip_rhs_plan_set_values", "rcppml_hip_rhs_plan_destroy", "rcppml_hip_rhs_plan_info", "rcppml_hip_rhs_planned",
@@ -561,6 +561,13 @@ class Context:
         _chk(lib().rcppml_hip_nb_size_update(self._h, C.c_int(dt), _dptr(t_col_ptr), _dptr(t_row_idx), _dptr(t_values),
                                              C.c_int64(m), _dptr(W_T), _dptr(d), _dptr(H), C.c_int64(n), C.c_int(k),
                                              C.c_double(r_min), C.c_double(r_max), _dptr(nb_size)), "nb_size_update")
+
+    def nb_size_update_loss(self, dt, t_col_ptr, t_row_idx, t_values, m, nnz, W_T, d, H, n, k, r_min, r_max, nb_size, out):
+        """nb_size_update followed by nb_loss with the updated sizes, in one pass over CSC(A^T) (per-row dispersion)."""
+        _chk(lib().rcppml_hip_nb_size_update_loss(self._h, C.c_int(dt), _dptr(t_col_ptr), _dptr(t_row_idx), _dptr(t_values),
+                                                  C.c_int64(m), C.c_int64(nnz), _dptr(W_T), _dptr(d), _dptr(H), C.c_int64(n),
+                                                  C.c_int(k), C.c_double(r_min), C.c_double(r_max), _dptr(nb_size), _dptr(out)),
+             "nb_size_update_loss")
 
     def nb_loss(self, dt, col_ptr, row_idx, values, ncols, W_T, d, H, theta_row, k, out):
         _chk(lib().rcppml_hip_nb_loss(self._h, C.c_int(dt), _dptr(col_ptr), _dptr(row_idx), _dptr(values), C.c_int64(ncols),

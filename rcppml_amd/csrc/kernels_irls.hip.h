@@ -871,6 +871,102 @@ __global__ __launch_bounds__(256) void nb_size_rows_kernel(
     }
 }
 
+// NB size update AND the NB negative log-likelihood in one kernel (PER_ROW dispersion, no robust modifier): fit_cpu.hpp:1094-1265
+// followed by explicit_loss.hpp:53-77 + math/loss.hpp:415-426 with the UPDATED sizes, as the fit loop orders them.  One wavefront
+// per row i of A: the first pass over the row's nonzeros is nb_size_rows_kernel's (prediction = Wd_i . H_col, in-lane) and parks
+// every prediction in mu_cache (each lane re-reads only what it wrote); the row's new size r_i is then known to the whole wave,
+// and the second pass evaluates the likelihood terms from the parked predictions -- no second gather of factor rows (the
+// separate loss kernel re-gathers 128 B per nonzero), and lgamma(r_i) once per row instead of once per nonzero.  The terms are
+// those of nb_loss_lane_kernel (same prediction arithmetic: (W d) . H in feature order, same fp64 formula, each term cast to
+// Scalar); only the order of the fp64 sum differs (by row instead of by column).
+template <class T>
+__global__ __launch_bounds__(256) void nb_size_loss_rows_kernel(
+    const int* __restrict__ tp, const int* __restrict__ ti, const T* __restrict__ tx, int64_t m,
+    const T* __restrict__ W_T, const T* __restrict__ d, const T* __restrict__ H, const T* __restrict__ h_rs,
+    const T* __restrict__ G_H, int k, double r_min, double r_max, T* __restrict__ nb_size, T* __restrict__ mu_cache,
+    double* __restrict__ partial) {
+    __shared__ T wds[4][128];
+    __shared__ double sh[4];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * 4 + wave;
+    double nll_sum = 0.0;
+    if (i < m) {
+        const bool fok = lane < k, fok2 = lane + 64 < k;                     // lane holds features lane and lane + 64 (k <= 128)
+        const T wd = fok ? W_T[i * (int64_t)k + lane] * d[lane] : T(0);     // apply_scaling(W_Td, d)
+        const T wd2 = fok2 ? W_T[i * (int64_t)k + lane + 64] * d[lane + 64] : T(0);
+        wds[wave][lane] = wd;
+        wds[wave][lane + 64] = wd2;
+        __builtin_amdgcn_wave_barrier();
+        constexpr int VEC = 16 / sizeof(T);
+        typedef typename VecT<T, VEC>::type V;
+        const bool vec_ok = (k % VEC == 0) && (reinterpret_cast<uintptr_t>(H) % 16 == 0);
+        const int ts = tp[i], te = tp[i + 1];
+        double s_mu2 = 0.0, s_res2 = 0.0;
+        for (int t = ts + lane; t < te; t += 64) {
+            const int col = ti[t];
+            const T* hr = H + (int64_t)col * k;
+            T dot = T(0);
+            if (vec_ok) {
+                for (int c = 0; c < k; c += VEC) {
+                    const V v = *reinterpret_cast<const V*>(hr + c);
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) dot = tfma(wds[wave][c + e], v[e], dot);
+                }
+            } else {
+                for (int c = 0; c < k; ++c) dot = tfma(wds[wave][c], hr[c], dot);
+            }
+            mu_cache[t] = dot;
+            const double y = static_cast<double>(tx[t]);
+            double mu = static_cast<double>(dot);
+            mu = mu > 1e-10 ? mu : 1e-10;
+            const double resid = y - mu;
+            s_mu2 += mu * mu;
+            s_res2 += resid * resid;
+        }
+        s_mu2 = wave_sum(s_mu2);
+        s_res2 = wave_sum(s_res2);
+        const T tm = wave_sum((fok ? wd * h_rs[lane] : T(0)) + (fok2 ? wd2 * h_rs[lane + 64] : T(0)));
+        const double total_mu = static_cast<double>(tm);
+        double acc = 0.0;                                                    // total_mu_sq = Wd^T G_H Wd, fp64 as the reference
+        for (int b2 = 0; b2 < k; ++b2) {
+            const double wb = static_cast<double>(wds[wave][b2]);
+            if (fok) acc += static_cast<double>(wd) * static_cast<double>(G_H[(int64_t)b2 * k + lane]) * wb;
+            if (fok2) acc += static_cast<double>(wd2) * static_cast<double>(G_H[(int64_t)b2 * k + lane + 64]) * wb;
+        }
+        const double total_mu_sq = wave_sum(acc);
+        // every lane takes the decision lane 0 takes in nb_size_rows_kernel (wave_sum leaves the same value in all lanes)
+        T size_new = nb_size[i];
+        {
+            const double total_resid_sq = s_res2 + (total_mu_sq - s_mu2);
+            const double excess = total_resid_sq - total_mu;
+            if (excess > 1e-10 && total_mu_sq > 1e-10) {
+                double r_new = total_mu_sq / excess;
+                r_new = r_new < r_max ? r_new : r_max;
+                r_new = r_new > r_min ? r_new : r_min;
+                if (isfinite(r_new)) size_new = static_cast<T>(r_new);
+            } else {
+                size_new = static_cast<T>(r_max);
+            }
+        }
+        if (lane == 0) nb_size[i] = size_new;
+        // ---- likelihood terms of the row with the updated size (math/loss.hpp:415-426)
+        const double th = static_cast<double>(size_new);
+        const double r = th > 1e-10 ? th : 1e-10;
+        const double lg_r = lgamma(r);
+        for (int t = ts + lane; t < te; t += 64) {
+            const double y = static_cast<double>(tx[t]);
+            double mu = static_cast<double>(mu_cache[t]);
+            mu = mu > 1e-10 ? mu : 1e-10;
+            const double nll = -lgamma(y + r) + lg_r - r * log(r / (r + mu)) - y * log(mu / (r + mu));
+            nll_sum += static_cast<double>(static_cast<T>(nll));             // the reference casts each term to Scalar
+        }
+    }
+    nll_sum = wave_sum(nll_sum);
+    if (lane == 0) sh[wave] = nll_sum;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+
 // Dispersion estimators of the other IRLS losses, one wavefront per ROW i of A (= column i of A^T), one lane per nonzero
 // (the gather / in-lane dot of nb_size_rows_kernel):
 //   loss_type 4      GP theta, auxiliary-function (MM) update, nmf/fit_cpu.hpp:914-1001: the Scalar predictions s of the

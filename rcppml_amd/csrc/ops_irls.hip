@@ -153,6 +153,43 @@ extern "C" int rcppml_hip_nb_size_update(rcppml_hip_ctx* c, int dtype, const int
 }
 
 template <class T>
+static void nb_size_loss_impl(rcppml_hip_ctx* c, int dtype, const int* tp, const int* ti, const T* tx, int64_t m, int64_t nnz,
+                              const T* W_T, const T* d, const T* H, int64_t n, int k, double r_min, double r_max, T* nb_size,
+                              double* out) {
+    if (k < 1 || k > 128) throw std::runtime_error("nb_size_update_loss: k must be in [1,128]");
+    const size_t head = (((size_t)k * k + k) * sizeof(T) + 255) / 256 * 256;
+    char* buf = static_cast<char*>(c->scratch(WS_IRLS, head + (size_t)(nnz > 0 ? nnz : 1) * sizeof(T)));
+    T* G_H = reinterpret_cast<T*>(buf);
+    T* h_rs = G_H + (size_t)k * k;
+    T* mu_cache = reinterpret_cast<T*>(buf + head);
+    if (rcppml_hip_gram(c, dtype, H, k, n, 1e-15, 0.0, G_H) != 0) throw std::runtime_error(rcppml_err());
+    if (rcppml_hip_row_norms(c, dtype, H, k, n, 3, h_rs) != 0) throw std::runtime_error(rcppml_err());
+    const int64_t nblk = m > 0 ? (m + 3) / 4 : 1;
+    double* partial = static_cast<double*>(c->scratch(WS_RED2, (size_t)nblk * sizeof(double)));
+    hipLaunchKernelGGL(nb_size_loss_rows_kernel<T>, dim3((unsigned)nblk), dim3(256), 0, c->stream, tp, ti, tx, m, W_T, d, H, h_rs,
+                       G_H, k, r_min, r_max, nb_size, mu_cache, partial);
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(sum_partials, dim3(1), dim3(256), 0, c->stream, partial, (int)nblk, out);
+    HIPCHK(hipGetLastError());
+}
+extern "C" int rcppml_hip_nb_size_update_loss(rcppml_hip_ctx* c, int dtype, const int* t_col_ptr, const int* t_row_idx,
+                                              const void* t_values, int64_t m, int64_t nnz, const void* W_T, const void* d,
+                                              const void* H, int64_t n, int k, double r_min, double r_max, void* nb_size,
+                                              double* out) {
+    try {
+        HIPCHK(hipSetDevice(c->device));
+        if (dtype == RCPPML_F32)
+            nb_size_loss_impl<float>(c, dtype, t_col_ptr, t_row_idx, (const float*)t_values, m, nnz, (const float*)W_T,
+                                     (const float*)d, (const float*)H, n, k, r_min, r_max, (float*)nb_size, out);
+        else
+            nb_size_loss_impl<double>(c, dtype, t_col_ptr, t_row_idx, (const double*)t_values, m, nnz, (const double*)W_T,
+                                      (const double*)d, (const double*)H, n, k, r_min, r_max, (double*)nb_size, out);
+        return 0;
+    }
+    RCPPML_CATCH_RET
+}
+
+template <class T>
 static void vec_global_impl(rcppml_hip_ctx* c, int stat, T* x, int64_t m) {
     if (m <= 0) return;
     hipLaunchKernelGGL(vec_global_fill_kernel<T>, dim3(1), dim3(256), 0, c->stream, x, m, stat);

@@ -404,7 +404,12 @@ void fit(FitParams& P) {
         if (P.symmetric) HIPCHK(hipMemcpyAsync(dH.p, dW.p, (size_t)k * m * sizeof(T), hipMemcpyDeviceToDevice, s));   // :704 H = W_T
 
         // ================= NB size update (fit_cpu.hpp:1094-1265), then loss (fit_cpu.hpp:1684-1753)
-        if (is_nb && !is_gp && P.dispersion_mode != 0) {
+        // (PER_ROW sizes without the robust modifier: both in one pass over A^T, the predictions of the size update reused by the loss)
+        const bool nb_fused = P.loss_type == 5 && P.dispersion_mode == 2 && !(P.robust_delta > 0);
+        if (nb_fused) {
+            OPCHK(rcppml_hip_nb_size_update_loss(c, dt, dTp.as<int>(), dTi.as<int>(), dTx.p, m, P.nnz, dW.p, dd.p, dH.p, n, k,
+                                                 P.nb_size_min, P.nb_size_max, dtheta.p, dloss.as<double>()));
+        } else if (is_nb && !is_gp && P.dispersion_mode != 0) {
             OPCHK(rcppml_hip_nb_size_update(c, dt, dTp.as<int>(), dTi.as<int>(), dTx.p, m, dW.p, dd.p, dH.p, n, k,
                                             P.nb_size_min, P.nb_size_max, dtheta.p));
             if (P.dispersion_mode == 1) OPCHK(rcppml_hip_vec_global(c, dt, 1, dtheta.p, m));   // GLOBAL: median (nth_element at m/2), :1257-1262
@@ -414,7 +419,9 @@ void fit(FitParams& P) {
             OPCHK(rcppml_hip_dispersion_update(c, dt, P.loss_type, P.dispersion_mode, dTp.as<int>(), dTi.as<int>(), dTx.p, m, P.nnz,
                                                dW.p, dd.p, dH.p, n, k, P.tweedie_power, P.gamma_phi_min,
                                                P.loss_type == 4 ? P.gp_theta_max : P.gamma_phi_max, dtheta.p));
-        if (is_nb) {
+        if (nb_fused) {
+            // loss already in dloss
+        } else if (is_nb) {
             OPCHK(rcppml_hip_irls_loss(c, dt, P.loss_type, dAp.as<int>(), dAi.as<int>(), dAx.p, n, dW.p, dd.p, dH.p, dtheta.p, k, P.tweedie_power, P.robust_delta, dloss.as<double>()));
         } else if (has_mask) {
             OPCHK(rcppml_hip_loss_nonzeros(c, dt, dAp.as<int>(), dAi.as<int>(), dAx.p, dMp.as<int>(), dMi.as<int>(), n,

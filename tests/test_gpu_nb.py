@@ -112,6 +112,47 @@ def test_nb_size_and_loss(env, dtype, tol, k):
     assert abs(out[0].item() - ref_l) / abs(ref_l) < tol
 
 
+@pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-12), (np.float32, 1e-9)])
+@pytest.mark.parametrize("k", [8, 32, 96])
+def test_nb_size_update_loss_fused(env, dtype, tol, k):
+    """rcppml_hip_nb_size_update_loss (what the fit loop runs for per-row sizes) against the two separate calls: the sizes
+    bit for bit, the likelihood to the order of its fp64 sum (by row instead of by column; the terms themselves are identical),
+    and against the oracle at the tolerance of test_nb_size_and_loss.  Rows without nonzeros and a row with a huge count included."""
+    torch, _abi, ctx = env
+    A = _nb_problem(120, 180, 3, seed=5)
+    x = A.x.copy()
+    At0 = A.transpose()
+    import scipy.sparse as sp
+    S = sp.csc_matrix((x, A.i, A.p), shape=(A.rows, A.cols)).tolil()
+    S[7, :] = 0
+    S[50, :] = 0
+    S[3, 11] = 5000
+    S = S.tocsc(); S.eliminate_zeros(); S.sort_indices()
+    A = O.Csc(S.shape, S.indptr.astype(np.int32), S.indices.astype(np.int32), S.data.astype(np.float64))
+    At = A.transpose()
+    rng = np.random.default_rng(1)
+    W_T = rng.uniform(size=(A.rows, k)).astype(dtype); W_T /= W_T.sum(axis=0, keepdims=True)
+    H = rng.uniform(size=(A.cols, k)).astype(dtype); H /= H.sum(axis=0, keepdims=True)
+    d = rng.uniform(50, 500, size=k).astype(dtype)
+    th0 = np.full(A.rows, 10.0, dtype)
+    dt = _abi.F32 if dtype == np.float32 else _abi.F64
+    dev = lambda a: _dev(torch, a)
+    tp, ti, tx, W_d, d_d, H_d = dev(At.p), dev(At.i), dev(At.values(dtype)), dev(W_T), dev(d), dev(H)
+    th_sep = dev(th0)
+    ctx.nb_size_update(dt, tp, ti, tx, A.rows, W_d, d_d, H_d, A.cols, k, 0.01, 1e6, th_sep)
+    out_sep = torch.zeros(2, dtype=torch.float64, device="cuda")
+    ctx.nb_loss(dt, dev(A.p), dev(A.i), dev(A.values(dtype)), A.cols, W_d, d_d, H_d, th_sep, k, out_sep)
+    th_f = dev(th0)
+    out_f = torch.zeros(2, dtype=torch.float64, device="cuda")
+    ctx.nb_size_update_loss(dt, tp, ti, tx, A.rows, At.nnz, W_d, d_d, H_d, A.cols, k, 0.01, 1e6, th_f, out_f)
+    assert torch.equal(th_sep, th_f)
+    l_sep, l_f = out_sep[0].item(), out_f[0].item()
+    assert np.isfinite(l_f) and abs(l_f - l_sep) / abs(l_sep) < tol, (l_f, l_sep)
+    ref_r = O.nb_size_update(A, W_T, H, d, th0, dtype=dtype)
+    ref_l = O.nb_loss(A, W_T, d, H, ref_r, dtype=dtype)
+    assert abs(l_f - ref_l) / abs(ref_l) < (1e-9 if dtype == np.float64 else 2e-3)
+
+
 @pytest.mark.parametrize("dispersion", [2, 1, 0])
 def test_nb_fit_through_plugin(dispersion):
     """nmf(loss='nb') through rcppml_gpu_nmf_unified_double (loss_type = 5): theta returned through out_theta."""
