@@ -51,6 +51,15 @@ template <int I> __device__ __forceinline__ void row_fmac2(float& d0, float& d1,
                  : "+v"(d0), "+v"(d1) : "v"(src), "v"(g0), "v"(g1), "n"(I));
 }
 
+template <int I> __device__ __forceinline__ int row_bcast_i(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x150 + I, 0xf, 0xf, true); }
+// sum over the eight lanes 8g .. 8g+7 of v, left in all eight (quad_perm xor 1, xor 2, then row_half_mirror: the other quad's sum)
+__device__ __forceinline__ float sum8(float v) {
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, true));     // quad_perm:[1,0,3,2]
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, true));     // quad_perm:[2,3,0,1]
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xf, 0xf, true));    // row_half_mirror
+    return v;
+}
+
 // math/loss.hpp:248-256  irls_weight_nb: computed in double, eps = tiny_num<Scalar>() = Scalar(1e-15)
 template <class T> __device__ __forceinline__ T irls_weight_nb_dev(T predicted, T nb_size) {
     double mu = static_cast<double>(predicted);
@@ -202,6 +211,8 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8
     const int64_t j = (int64_t)blockIdx.x * 4 + wave;
     if (j >= ncols) return;
     const int r = lane & 31, hh = lane >> 5;            // phase A: nonzero r, feature half hh; phase B: feature r, K-slot hh
+    const int g8 = lane >> 3, p8 = lane & 7;            // gather: group of eight lanes = one row of F, lane = 16-byte piece
+    const bool pok = 4 * p8 < k;
     const bool fok = lane < k;
     const bool lin = lane < KP;
     const int ll = lin ? lane : 0;
@@ -220,30 +231,37 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8
         }
         if (lin) xs[lane] = x;
         float bw = 0.f;
+        __builtin_amdgcn_wave_barrier();
+        const float4 xq = *reinterpret_cast<const float4*>(xs + 4 * p8);    // the lane's piece of x
         for (int t0 = as; t0 < ae; t0 += CH) {
-            // ---- phase A
+            // ---- phase A.  Gather: the eight lanes 8g .. 8g+7 read the eight 16-byte pieces of ONE row of F (one 128-byte line per
+            // group and instruction, eight lines per instruction against 32 for a lane-per-row layout); instruction i of group g takes
+            // chunk row 4g + i.  The reconstruction f . x is four in-lane fmas against the lane's piece of x and a sum over the group.
             const int tt = t0 + r;
             const bool ok = tt < ae;
             const int row = ok ? rowidx[tt] : 0;
             const float a = ok ? vals[tt] : 0.f;
-            const float* fsrc = F + (int64_t)row * k + 16 * hh;
+            float mine = 0.f;
             float4 fv4[4];
-            float part = 0.f;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int c0 = 16 * hh + 4 * q;
-                fv4[q] = (ok && c0 < k) ? *reinterpret_cast<const float4*>(fsrc + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
-                const float4 xv = *reinterpret_cast<const float4*>(xs + c0);
-                part = tfma(fv4[q].x, xv.x, part);
-                part = tfma(fv4[q].y, xv.y, part);
-                part = tfma(fv4[q].z, xv.z, part);
-                part = tfma(fv4[q].w, xv.w, part);
+            for (int i = 0; i < 4; ++i) {
+                const int cr = 4 * g8 + i;                                       // row of the chunk
+                const int rowg = __shfl(row, cr, 64);
+                fv4[i] = (t0 + cr < ae && pok) ? *reinterpret_cast<const float4*>(F + (int64_t)rowg * k + 4 * p8) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
-            const float recon = part + __shfl_xor(part, 32, 64);                 // W_T.col(row).dot(x)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float part = fv4[i].x * xq.x;
+                part = tfma(fv4[i].y, xq.y, part);
+                part = tfma(fv4[i].z, xq.z, part);
+                part = tfma(fv4[i].w, xq.w, part);
+                part = sum8(part);                                               // W_T.col(row).dot(x), in the group's eight lanes
+                mine = (p8 & 3) == i ? part : mine;
+                *reinterpret_cast<float4*>(Fst + (4 * g8 + i) * FS + 4 * p8) = fv4[i];
+            }
+            const float recon = __shfl(mine, 8 * (r >> 2) + (r & 3), 64);        // row r of the chunk: group r / 4, instruction r % 4
             const float th = theta_col ? th_col : (theta_row ? theta_row[row] : 0.f);
             const float w = irls_weight_full_dev<float>(LT >= 0 ? LT : loss_type, a - recon, recon, th, power, LT >= 0 ? 0.f : robust);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(Fst + r * FS + 16 * hh + 4 * q) = fv4[q];
             if (hh == 0) sc[r] = make_float2(ok ? w - 1.f : 0.f, ok ? w * a : 0.f);
             __builtin_amdgcn_wave_barrier();
             // ---- phase B: nonzeros (2s, 2s+1) of the chunk per MFMA
@@ -346,6 +364,8 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4
     if (jw >= ncols) return;
     const int r = lane & 31, hh = lane >> 5;            // Gram phases: nonzero / feature r, half hh
     const int qme = lane >> 4, l = lane & 15;           // solve: column jw + qme, coordinates l and l + 16
+    const int g8 = lane >> 3, p8 = lane & 7;            // gather: group of eight lanes = one row of F, lane = 16-byte piece
+    const bool pok = 4 * p8 < k;
     const int64_t jme = jw + qme;
     const bool fok0 = l < k, fok1 = l + 16 < k;
     bool active = jme < ncols;                          // uniform over a row
@@ -384,42 +404,42 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4
             }
             float bw = 0.f;
             __builtin_amdgcn_wave_barrier();
+            const float4 xq = *reinterpret_cast<const float4*>(xs + 4 * p8);    // the lane's piece of x
             for (int t0 = as; t0 < ae; t0 += CH) {
-                // ---- phase A: two halves of 32 nonzeros (lane = nonzero r of the half, feature half hh), then ONE weight per lane
-                float recon_me = 0.f, a_me = 0.f;
-                int row_me = 0;
-                bool ok_me = false;
-#pragma unroll 1
-                for (int sub = 0; sub < 2; ++sub) {
-                    const int tt = t0 + 32 * sub + r;
-                    const bool ok = tt < ae;
-#ifdef IRLS_FAKE_ROWS
-                    const int row = ok ? (rowidx[tt] & 7) : 0;      // probe: every gather an L1 hit
-#else
-                    const int row = ok ? rowidx[tt] : 0;
-#endif
-                    const float a = ok ? vals[tt] : 0.f;
-                    const float* fsrc = F + (int64_t)row * k + 16 * hh;
+                // ---- phase A: lane t owns nonzero t of the chunk (its value, its weight); the gather is the group-of-eight form of
+                // the kernel above with eight instructions, instruction i of group g taking chunk row 8g + i -- so lane t finds the
+                // reconstruction of ITS nonzero in its own group at instruction t % 8, no shuffle
+                const int tt = t0 + lane;
+                const bool ok_me = tt < ae;
+                const int row_me = ok_me ? rowidx[tt] : 0;
+                const float a_me = ok_me ? vals[tt] : 0.f;
+                float recon_me = 0.f;
+                auto four_rows = [&](auto HC) {
+                    constexpr int h4 = decltype(HC)::value;
                     float4 fv4[4];
-                    float part = 0.f;
-#pragma unroll
-                    for (int qq = 0; qq < 4; ++qq) {
-                        const int c0 = 16 * hh + 4 * qq;
-                        fv4[qq] = (ok && c0 < k) ? *reinterpret_cast<const float4*>(fsrc + 4 * qq) : make_float4(0.f, 0.f, 0.f, 0.f);
-                        const float4 xv = *reinterpret_cast<const float4*>(xs + c0);
-                        part = tfma(fv4[qq].x, xv.x, part);
-                        part = tfma(fv4[qq].y, xv.y, part);
-                        part = tfma(fv4[qq].z, xv.z, part);
-                        part = tfma(fv4[qq].w, xv.w, part);
-                    }
-                    const float recon = part + __shfl_xor(part, 32, 64);             // W_T.col(row).dot(x)
-#pragma unroll
-                    for (int qq = 0; qq < 4; ++qq) *reinterpret_cast<float4*>(Fst + (32 * sub + r) * FS + 16 * hh + 4 * qq) = fv4[qq];
-                    if (hh == sub) { recon_me = recon; a_me = a; row_me = row; ok_me = ok; }
-                }
+                    cd_static_for<0, 4>([&](auto IC) {
+                        constexpr int i = 4 * h4 + decltype(IC)::value;
+                        const int rowg = (lane & 8) ? row_bcast_i<8 + i>(row_me) : row_bcast_i<i>(row_me);      // lane 8g + i of the wave
+                        fv4[i - 4 * h4] = (t0 + 8 * g8 + i < ae && pok) ? *reinterpret_cast<const float4*>(F + (int64_t)rowg * k + 4 * p8)
+                                                                       : make_float4(0.f, 0.f, 0.f, 0.f);
+                    });
+                    cd_static_for<0, 4>([&](auto IC) {
+                        constexpr int u = decltype(IC)::value, i = 4 * h4 + u;
+                        float part = fv4[u].x * xq.x;
+                        part = tfma(fv4[u].y, xq.y, part);
+                        part = tfma(fv4[u].z, xq.z, part);
+                        part = tfma(fv4[u].w, xq.w, part);
+                        part = sum8(part);                                           // W_T.col(row).dot(x), in the group's eight lanes
+                        recon_me = p8 == i ? part : recon_me;
+                        *reinterpret_cast<float4*>(Fst + (8 * g8 + i) * FS + 4 * p8) = fv4[u];
+                    });
+                };
+                four_rows(std::integral_constant<int, 0>{});
+                __builtin_amdgcn_sched_barrier(0);                                   // two batches of four loads: 16 registers, not 32
+                four_rows(std::integral_constant<int, 1>{});
                 const float th = theta_col ? th_col : (theta_row ? theta_row[row_me] : 0.f);
                 const float w = irls_weight_full_dev<float>(LT >= 0 ? LT : loss_type, a_me - recon_me, recon_me, th, power, LT >= 0 ? 0.f : robust);
-                sc[lane] = make_float2(ok_me ? w - 1.f : 0.f, ok_me ? w * a_me : 0.f);   // lane = 32 hh + r = the nonzero's place in the chunk
+                sc[lane] = make_float2(ok_me ? w - 1.f : 0.f, ok_me ? w * a_me : 0.f);
                 __builtin_amdgcn_wave_barrier();
                 // ---- phase B: nonzeros (2s, 2s+1) of the chunk per MFMA
                 const int cnt = ae - t0 < CH ? ae - t0 : CH;
