@@ -119,6 +119,6 @@ def test_bench_c5_line_reduced_shape():
         assert 1.0 <= roof["mean_passes_per_column"] <= 5.0 and roof["nonzero_passes"] >= d["config"]["nnz_per_gpu"]
         assert 0 < roof["frac"] < 1
     assert d["roofline"]["bound"] == "mfma" and abs(d["roofline"]["frac"] - d["roofline"]["achieved"] / d["roofline"]["peak"]) < 1e-9
-    assert set(d["phases_ms_per_step"]) >= {"gram", "solve_H", "solve_W", "scale", "nb_size", "loss"}
+    assert set(d["phases_ms_per_step"]) >= {"gram", "solve_H", "solve_W", "scale", "nb_size_loss"}
     assert d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["cores"] >= 1
     assert d["final_loss"] == d["final_loss"]          # finite, not NaN
