@@ -60,6 +60,36 @@ __device__ __forceinline__ float sum8(float v) {
     return v;
 }
 
+// One coordinate of a half sweep of the four-columns-per-wave CD solve, as ONE instruction group (see irls_nb_mfma32q_kernel):
+//   step = med3(dc, -x, inf);  do += go_prev * bcast(step_prev);  own = turn ? step : own;  dc += gc * bcast(step)
+// dc is the residual this half's steps are read from, `do` the other one (its update for the PREVIOUS coordinate, deferred by
+// one so that two independent operations separate the med3 from the DPP read of its result: no s_nop).
+template <int I> __device__ __forceinline__ float sweep_step(float& dc, float& dother, float& own, float step_prev, float nxe, float inf,
+                                                             unsigned long long turn, float gc, float go_prev) {
+    float step;
+    asm volatile("v_med3_f32 %0, %1, %4, %5\n\t"
+                 "v_fmac_f32_dpp %2, %6, %8 row_newbcast:%10 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_cndmask_b32_e64 %3, %3, %0, %9\n\t"
+                 "v_fmac_f32_dpp %1, %0, %7 row_newbcast:%11 row_mask:0xf bank_mask:0xf"
+                 : "=&v"(step), "+v"(dc), "+v"(dother), "+v"(own)
+                 : "v"(nxe), "v"(inf), "v"(step_prev), "v"(gc), "v"(go_prev), "s"(turn), "n"(I - 1), "n"(I));
+    return step;
+}
+// the first coordinate of a half: nothing deferred yet, one wait state filled by an s_nop
+template <int I> __device__ __forceinline__ float sweep_first(float& dc, float& own, float nxe, float inf, unsigned long long turn, float gc) {
+    float step;
+    asm volatile("v_med3_f32 %0, %1, %3, %4\n\t"
+                 "v_cndmask_b32_e64 %2, %2, %0, %6\n\t"
+                 "s_nop 0\n\t"
+                 "v_fmac_f32_dpp %1, %0, %5 row_newbcast:%7 row_mask:0xf bank_mask:0xf"
+                 : "=&v"(step), "+v"(dc), "+v"(own)
+                 : "v"(nxe), "v"(inf), "v"(gc), "s"(turn), "n"(I));
+    return step;
+}
+template <int I> __device__ __forceinline__ void row_fmac1(float& d, float src, float g) {
+    asm volatile("s_nop 1\n\tv_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(d) : "v"(src), "v"(g), "n"(I));
+}
+
 // math/loss.hpp:248-256  irls_weight_nb: computed in double, eps = tiny_num<Scalar>() = Scalar(1e-15)
 template <class T> __device__ __forceinline__ T irls_weight_nb_dev(T predicted, T nb_size) {
     double mu = static_cast<double>(predicted);
@@ -509,288 +539,24 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4
             const float nxe0 = -xe0, nxe1 = -xe1;
             // the lane whose turn it is keeps its step: lane mask of (l == i) as ONE scalar pair shifted by a SALU operation per
             // coordinate (sixteen compare results held in SGPRs cost 32 of them and spill)
+            // Four VALU operations per coordinate and no wait state: the fmac of the OTHER residual is the previous coordinate's
+            // (it is not on this half's chain) and sits, with the select, between the med3 that writes the step and the DPP read of it.
             unsigned long long turn = lane0_of_rows;
-            cd_static_for<0, 16>([&](auto IC) {
+            float adp = sweep_first<0>(d0, aown0, nxe0, inf_rt, turn, ng0[0]);
+            cd_static_for<1, 16>([&](auto IC) {
                 constexpr int i = decltype(IC)::value;
-                const float ad = cd_static_max(d0, nxe0, inf_rt);
-                asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(aown0) : "v"(ad), "s"(turn));
                 turn <<= 1;
-                row_fmac2<i>(d0, d1, ad, ng0[i], ng1[i]);
+                adp = sweep_step<i>(d0, d1, aown0, adp, nxe0, inf_rt, turn, ng0[i], ng1[i - 1]);
             });
+            row_fmac1<15>(d1, adp, ng1[15]);
             turn = lane0_of_rows;
-            cd_static_for<0, 16>([&](auto IC) {
+            adp = sweep_first<0>(d1, aown1, nxe1, inf_rt, turn, ng1[16]);
+            cd_static_for<1, 16>([&](auto IC) {
                 constexpr int i = decltype(IC)::value;
-                const float ad = cd_static_max(d1, nxe1, inf_rt);
-                asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(aown1) : "v"(ad), "s"(turn));
                 turn <<= 1;
-                row_fmac2<i>(d0, d1, ad, ng0[16 + i], ng1[16 + i]);
+                adp = sweep_step<i>(d1, d0, aown1, adp, nxe1, inf_rt, turn, ng1[16 + i], ng0[16 + i - 1]);
             });
-            const float xn0 = x0 + aown0, xn1 = x1 + aown1;
-            const bool moved = xn0 != x0 || xn1 != x1;
-            x0 = xn0; x1 = xn1;
-            const unsigned long long mv = __ballot(moved);
-            if (!mv) break;
-            // a column none of whose coordinates moved is at the fixed point the one-column kernel stops at: zero residuals make
-            // every later step of its row exactly zero (the columns sharing the wave may need more sweeps)
-            if (!((mv >> (lane & 48)) & 0xffffull)) { d0 = 0.f; d1 = 0.f; }
-        }
-        float rel = fok0 ? tabs(x0 - xo0) / (tabs(xo0) + 1e-12f) : 0.f;
-        const float rel1 = fok1 ? tabs(x1 - xo1) / (tabs(xo1) + 1e-12f) : 0.f;
-        rel = rel1 > rel ? rel1 : rel;
-#pragma unroll
-        for (int off = 8; off > 0; off >>= 1) {
-            const float o = __shfl_xor(rel, off, 64);
-            rel = o > rel ? o : rel;
-        }
-        if (rel < irls_tol) active = false;
-        __builtin_amdgcn_wave_barrier();
-    }
-    if (jme < ncols) {
-        if (fok0) X[jme * (int64_t)k + l] = x0;
-        if (fok1) X[jme * (int64_t)k + l + 16] = x1;
-        // work counters (RCPPML_OPT_CD_COUNT_NOOP only): IRLS passes and nonzero-passes = weighted-Gram rank-1 updates
-        if (stats && l == 0) {
-            const int nzc = colptr[jme + 1] - colptr[jme];
-            atomicAdd(stats, (unsigned long long)passes);
-            atomicAdd(stats + 1, (unsigned long long)passes * (unsigned long long)nzc);
-        }
-    }
-}
-
-__device__ __forceinline__ unsigned rt_m0_keep() {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0" : "=s"(keep));
-    return keep;
-}
-// ---------------------------------------------------------------------------
-// The same kernel for k = 32 exactly, with the weighted-Gram phase software-pipelined over stages of 32 nonzeros.  The phase
-// above is bound by the latency of the dependent pair (row index -> row of F) in front of every chunk's MFMAs;
-// at 128 VGPRs there is no room to keep the next chunk's rows in registers across the MFMA loop.  Here the rows of stage h + 1
-// travel global -> LDS directly (global_load_lds_dwordx4, one KiB = eight rows per instruction, no VGPR in flight) into the
-// second of two staging buffers while the MFMAs of stage h run from the first, and the (row, value) pairs are loaded two
-// stages ahead.  Arithmetic per column as above (same reconstruction tree, same weights, same MFMA order): bit-identical.
-// ---------------------------------------------------------------------------
-template <int LT>
-static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void irls_nb_mfma32qd_kernel(
-    const int* __restrict__ colptr, const int* __restrict__ rowidx, const float* __restrict__ vals, int64_t ncols,
-    const float* __restrict__ F, const float* __restrict__ Gbase, float* __restrict__ X, int k, float l1, float l2,
-    int nonneg, int cd_maxit, int irls_max_iter, float irls_tol, const float* __restrict__ theta_row,
-    const float* __restrict__ theta_col, int loss_type, float power, float robust,
-    unsigned long long* __restrict__ stats) {
-    constexpr int KP = 32, CH = 32, FS = 36;          // CH nonzeros per stage; FS: padded row stride of the G_w slab
-    constexpr int STAGE = CH * KP;                     // one staging buffer: 32 rows of 128 bytes, row 8i + g at 256 i + 32 g floats
-    constexpr int WAVE_FLOATS = 2 * STAGE + 2 * 2 * CH + 2 * KP;  // two staging buffers | two (w-1, w a) blocks | x | b_w
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    float* Fst = reinterpret_cast<float*>(smem_raw) + (size_t)wave * WAVE_FLOATS;
-    float2* sc = reinterpret_cast<float2*>(Fst + 2 * STAGE);
-    float* xs = Fst + 2 * STAGE + 2 * 2 * CH;
-    float* bws = xs + KP;
-    float* Gl = Fst;                                    // [i][c], stride FS: reused once a column's Gram is complete
-    const unsigned lds_stage0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)Fst);
-    const int64_t jw = ((int64_t)blockIdx.x * 4 + wave) * 4;      // first of this wave's four columns
-    if (jw >= ncols) return;
-    const int r = lane & 31, hh = lane >> 5;            // Gram phases: nonzero / feature r, half hh
-    const int qme = lane >> 4, l = lane & 15;           // solve: column jw + qme, coordinates l and l + 16
-    const int g8 = lane >> 3, p8 = lane & 7;            // gather: group of eight lanes = one row of F, lane = 16-byte piece
-    const bool pok = 4 * p8 < k;
-    const int64_t jme = jw + qme;
-    const bool fok0 = l < k, fok1 = l + 16 < k;
-    bool active = jme < ncols;                          // uniform over a row
-    float x0 = 0.f, x1 = 0.f;                           // nnls_batch_irls.hpp:482-483  H.setZero(): no warm start
-    int passes = 0;
-    float ng0[KP], ng1[KP];                             // rows l and l + 16 of the column's Gram, then of -G_w / G_ii
-#pragma unroll
-    for (int c = 0; c < KP; ++c) { ng0[c] = 0.f; ng1[c] = 0.f; }
-    const float pinf = __builtin_inff();
-    const float inf_rt = cd_maxit >= 0 ? pinf : 0.f;
-    for (int irls = 0; irls < irls_max_iter; ++irls) {
-        const unsigned long long act = __ballot(active);
-        if (!act) break;
-        if (active) ++passes;
-        float b0 = 0.f, b1 = 0.f, gd0 = 0.f, gd1 = 0.f;
-        for (int q = 0; q < 4; ++q) {
-            if (!((act >> (16 * q)) & 1ull)) continue;                           // wave-uniform
-            const int64_t j = jw + q;
-            const int as = colptr[j], ae = colptr[j + 1];
-            const float th_col = theta_col ? theta_col[j] : 0.f;
-            if (qme == q) { xs[l] = x0; xs[l + 16] = x1; }
-            // accumulator tile <- base Gram (identity padding), C/D map: col = lane&31, row = (v&3) + 8(v>>2) + 4(lane>>5)
-            // (four 16-byte loads off one per-lane pointer: k % 4 == 0 keeps a group of four rows on one side of k)
-            f32x16 acc;
-            const float* gb = Gbase + (int64_t)r * k + 4 * hh;
-            asm volatile("" : "+v"(gb));                 // per pass, not 16 hoisted addresses
-#pragma unroll
-            for (int v4 = 0; v4 < 4; ++v4) {
-                const int gi0 = 8 * v4 + 4 * hh;
-                const float4 g = (gi0 < k && r < k) ? *reinterpret_cast<const float4*>(gb + 8 * v4) : make_float4(0.f, 0.f, 0.f, 0.f);
-                const bool pad = r >= k;
-                acc[4 * v4 + 0] = pad && gi0 + 0 == r ? 1.f : g.x;
-                acc[4 * v4 + 1] = pad && gi0 + 1 == r ? 1.f : g.y;
-                acc[4 * v4 + 2] = pad && gi0 + 2 == r ? 1.f : g.z;
-                acc[4 * v4 + 3] = pad && gi0 + 3 == r ? 1.f : g.w;
-            }
-            float bw = 0.f;
-            __builtin_amdgcn_wave_barrier();
-            const float4 xq = *reinterpret_cast<const float4*>(xs + 4 * p8);    // the lane's piece of x
-            // ---- stages of 32 nonzeros, software-pipelined: while the MFMAs of stage h run, the rows of F of stage h + 1 are on
-            // their way INTO LDS (global_load_lds_dwordx4: no registers in flight) and the (row, value) pairs of stage h + 2 into
-            // registers; the reconstruction and the weights of stage h + 1 are formed after the MFMAs of stage h have been issued.
-            const int nh = (ae - as + CH - 1) / CH;
-            // (row, value) of a stage at a clamped position: a lane past the column's end stages the row of the column's LAST
-            // nonzero with the weight pair (0, 0) -- exact zeros in G_w and b_w, and nothing of a row the column does not hold
-            auto load_idx = [&](int h, int& row, float& a) {
-                const int tt = as + CH * h + r;
-                const int tc = tt < ae ? tt : ae - 1;
-                row = rowidx[tc];
-                a = tt < ae ? vals[tc] : 0.f;
-            };
-            // instruction i of group g takes row 8i + g of the stage: lane 8g + p supplies piece p, the eight lanes of a group
-            // land 128 contiguous bytes, the eight groups 1 KiB (M0 = LDS address of the instruction's KiB)
-            auto dma_stage = [&](int buf, int row) {
-                const unsigned m0keep = rt_m0_keep();
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int rowg = __shfl(row, 8 * i + g8, 64);
-                    const float* src = F + (int64_t)rowg * KP + 4 * p8;
-                    const unsigned dst = lds_stage0 + (unsigned)(buf * STAGE + 256 * i) * 4u;
-                    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(src), "s"(dst) : "memory");
-                }
-                asm volatile("s_mov_b32 m0, %0" :: "s"(m0keep));
-            };
-            // phase A of a stage whose rows have landed: reconstruction (four in-lane fmas on the lane's own 16 bytes + the sum
-            // over the group), weight, (w - 1, w a) pairs
-            auto weights_stage = [&](int buf, int h, int row, float a, float thr) {
-                const float* sb = Fst + buf * STAGE;
-                float mine = 0.f;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float4 f = *reinterpret_cast<const float4*>(sb + 256 * i + 4 * lane);
-                    float part = f.x * xq.x;
-                    part = tfma(f.y, xq.y, part);
-                    part = tfma(f.z, xq.z, part);
-                    part = tfma(f.w, xq.w, part);
-                    part = sum8(part);                                           // W_T.col(row).dot(x), in the group's eight lanes
-                    mine = (p8 & 3) == i ? part : mine;
-                }
-                const float recon = __shfl(mine, 8 * (r & 7) + (r >> 3), 64);    // row r of the stage: group r % 8, instruction r / 8
-                const bool ok = as + CH * h + r < ae;
-                const float th = theta_col ? th_col : thr;
-                const float w = irls_weight_full_dev<float>(LT >= 0 ? LT : loss_type, a - recon, recon, th, power, LT >= 0 ? 0.f : robust);
-                if (hh == 0) sc[buf * CH + r] = make_float2(ok ? w - 1.f : 0.f, ok ? w * a : 0.f);
-                (void)row;
-            };
-            int row_c = 0, row_n = 0;
-            float a_c = 0.f, a_n = 0.f, th_n = 0.f;
-            if (nh > 0) {
-                load_idx(0, row_c, a_c);
-                dma_stage(0, row_c);
-                const float th_c = theta_row ? theta_row[row_c] : 0.f;
-                load_idx(1, row_n, a_n);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                weights_stage(0, 0, row_c, a_c, th_c);
-                __builtin_amdgcn_wave_barrier();
-            }
-            for (int h = 0; h < nh; ++h) {
-                const int buf = h & 1;
-                const bool more = h + 1 < nh;
-                int row_nn = 0;
-                float a_nn = 0.f;
-                if (more) {
-                    dma_stage(buf ^ 1, row_n);
-                    th_n = theta_row ? theta_row[row_n] : 0.f;
-                    load_idx(h + 2, row_nn, a_nn);
-                }
-                // ---- phase B: nonzeros (2s, 2s+1) of the stage per MFMA, groups of four with their LDS reads issued ahead
-                const int cnt = ae - (as + CH * h) < CH ? ae - (as + CH * h) : CH;
-                const int nst = (cnt + 1) >> 1;
-                const float* sb = Fst + buf * STAGE;
-                const float2* scb = sc + buf * CH;
-                for (int s2 = 0; s2 < nst; s2 += 4) {
-                    float fv[4];
-                    float2 ws[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int t = 2 * (s2 + u) + hh;
-                        fv[u] = sb[256 * (t >> 3) + 32 * (t & 7) + r];
-                        ws[u] = scb[t];
-                    }
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        bw = tfma(ws[u].y, fv[u], bw);                                // b_w += f * (w a)
-                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ws[u].x * fv[u], fv[u], acc, 0, 0, 0);   // G_w += (f (w-1)) f^T
-                    }
-                }
-                if (more) {
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    weights_stage(buf ^ 1, h + 1, row_n, a_n, th_n);
-                    row_n = row_nn; a_n = a_nn;
-                }
-                __builtin_amdgcn_wave_barrier();
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            bw += __shfl_xor(bw, 32, 64);
-            // park G_w in the slab (symmetric: accumulator row gi is slab row gi) and b_w next to it
-#pragma unroll
-            for (int v = 0; v < 16; ++v) {
-                const int gi = (v & 3) + 8 * (v >> 2) + 4 * hh;
-                float val = acc[v];
-                if (l2 > 0.f && gi == r && gi < k) val += l2;
-                Gl[gi * FS + r] = val;
-            }
-            if (lane < KP) bws[lane] = bw;
-            __builtin_amdgcn_wave_barrier();
-            if (qme == q) {                              // the column's row picks up rows l and l + 16 of G_w
-                // (COLUMNS l and l + 16 of the slab, as the one-column kernel reads them: the MFMA's G_w(i, j) = sum ((w-1) f_i) f_j is
-                //  not bitwise symmetric)
-#pragma unroll
-                for (int c = 0; c < KP; ++c) { ng0[c] = Gl[c * FS + l]; ng1[c] = Gl[c * FS + l + 16]; }
-                gd0 = Gl[l * FS + l];
-                gd1 = Gl[(l + 16) * FS + l + 16];
-                b0 = bws[l];
-                b1 = bws[l + 16];
-            }
-            __builtin_amdgcn_wave_barrier();
-        }
-        // ---- all (still iterating) columns of the wave at once: residual b_c = b_w - G_w x_old, coordinates in order
-        const float xo0 = x0, xo1 = x1;
-        {
-            const float nx0 = -xo0, nx1 = -xo1;          // fma(-g, x, b) = fma(g, -x, b)
-            cd_static_for<0, 16>([&](auto IC) { constexpr int i = decltype(IC)::value; row_fmac2<i>(b0, b1, nx0, ng0[i], ng1[i]); });
-            cd_static_for<0, 16>([&](auto IC) { constexpr int i = decltype(IC)::value; row_fmac2<i>(b0, b1, nx1, ng0[16 + i], ng1[16 + i]); });
-        }
-        // cd_nnls_col_fixed(G_w, b_c, x, L1 inside, L2 = 0, nonneg, cd_maxit, ub = 0, tol = 0), static scaled form (kernels.hip.h):
-        // d = b / G_ii - L1, rows scaled by -1 / G_ii once; a row that is done (or dead) holds zeros and never moves
-        const bool alive0 = active && fok0 && gd0 > 0.f, alive1 = active && fok1 && gd1 > 0.f;
-        const float ginv0 = alive0 ? 1.f / gd0 : 0.f, ginv1 = alive1 ? 1.f / gd1 : 0.f;
-#pragma unroll
-        for (int c = 0; c < KP; ++c) { ng0[c] *= -ginv0; ng1[c] *= -ginv1; }
-        float d0 = __builtin_fmaf(active ? b0 : 0.f, ginv0, alive0 ? -l1 : 0.f);
-        float d1 = __builtin_fmaf(active ? b1 : 0.f, ginv1, alive1 ? -l1 : 0.f);
-        unsigned long long lane0_of_rows = 0x0001000100010001ull;
-        asm volatile("" : "+s"(lane0_of_rows));        // opaque: shifted at run time, not sixteen 64-bit literals
-        for (int it = 0; it < cd_maxit; ++it) {
-            const float xe0 = nonneg ? x0 : pinf, xe1 = nonneg ? x1 : pinf;
-            float aown0 = 0.f, aown1 = 0.f;
-            const float nxe0 = -xe0, nxe1 = -xe1;
-            // the lane whose turn it is keeps its step: lane mask of (l == i) as ONE scalar pair shifted by a SALU operation per
-            // coordinate (sixteen compare results held in SGPRs cost 32 of them and spill)
-            unsigned long long turn = lane0_of_rows;
-            cd_static_for<0, 16>([&](auto IC) {
-                constexpr int i = decltype(IC)::value;
-                const float ad = cd_static_max(d0, nxe0, inf_rt);
-                asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(aown0) : "v"(ad), "s"(turn));
-                turn <<= 1;
-                row_fmac2<i>(d0, d1, ad, ng0[i], ng1[i]);
-            });
-            turn = lane0_of_rows;
-            cd_static_for<0, 16>([&](auto IC) {
-                constexpr int i = decltype(IC)::value;
-                const float ad = cd_static_max(d1, nxe1, inf_rt);
-                asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(aown1) : "v"(ad), "s"(turn));
-                turn <<= 1;
-                row_fmac2<i>(d0, d1, ad, ng0[16 + i], ng1[16 + i]);
-            });
+            row_fmac1<15>(d0, adp, ng0[31]);
             const float xn0 = x0 + aown0, xn1 = x1 + aown1;
             const bool moved = xn0 != x0 || xn1 != x1;
             x0 = xn0; x1 = xn1;

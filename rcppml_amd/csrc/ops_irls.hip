@@ -32,24 +32,7 @@ static void irls_impl(rcppml_hip_ctx* c, const int* cp, const int* ri, const T* 
         if (use_mfma < 0) use_mfma = exp_flag("RCPPML_GPU_IRLS_VARIANT", "valu") ? 0 : 1;
         if (use_mfma && k <= 32 && k % 4 == 0 && reinterpret_cast<uintptr_t>(F) % 16 == 0) {
             // many short columns: four columns per wavefront in the CD solve (irls_nb_mfma32q_kernel); RCPPML_OPT_IRLS_COLUMNS_PER_WAVE forces
-            const bool quad = c->opt_irls_cpw > 0 ? (c->opt_irls_cpw == 4 || c->opt_irls_cpw == 14) : ncols >= (int64_t)64 * c->num_cu;
-            if (quad && k == 32 && c->opt_irls_cpw != 14) {      // k = 32: weighted-Gram phase pipelined through LDS-DMA (14 = without, for probes)
-                const size_t qsmem = (size_t)4 * (2 * 32 * 32 + 2 * 2 * 32 + 2 * 32) * sizeof(float);
-                const int64_t qblk = (ncols + 15) / 16;
-                if (loss_type == 5 && !(robust > 0)) {
-                    static DynSmemOnce once;
-                    once.ensure(reinterpret_cast<const void*>(&irls_nb_mfma32qd_kernel<5>), qsmem, c->device);
-                    hipLaunchKernelGGL(irls_nb_mfma32qd_kernel<5>, dim3((unsigned)qblk), dim3(256), qsmem, c->stream, cp, ri, vals, ncols, F,
-                                       Gbase, X, k, l1, l2, nonneg, cd_maxit, irls_max_iter, irls_tol, theta_row, theta_col, loss_type, power, robust, st);
-                } else {
-                    static DynSmemOnce once;
-                    once.ensure(reinterpret_cast<const void*>(&irls_nb_mfma32qd_kernel<-1>), qsmem, c->device);
-                    hipLaunchKernelGGL(irls_nb_mfma32qd_kernel<-1>, dim3((unsigned)qblk), dim3(256), qsmem, c->stream, cp, ri, vals, ncols, F,
-                                       Gbase, X, k, l1, l2, nonneg, cd_maxit, irls_max_iter, irls_tol, theta_row, theta_col, loss_type, power, robust, st);
-                }
-                HIPCHK(hipGetLastError());
-                return;
-            }
+            const bool quad = c->opt_irls_cpw > 0 ? c->opt_irls_cpw == 4 : ncols >= (int64_t)64 * c->num_cu;
             if (quad) {
                 const size_t qsmem = (size_t)4 * (64 * 36 + 2 * 64 + 2 * 32) * sizeof(float);
                 const int64_t qblk = (ncols + 15) / 16;

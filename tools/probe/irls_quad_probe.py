@@ -30,12 +30,12 @@ for side, csc, F, ncols, th in (("H", Ad, W, n, (theta, None)), ("W", Atd, H, m,
     G = ops.gram(F, 1e-15, 0.0)
     for cdm, irm in ((1, 1), (100, 1), (1, 5), (100, 5)):
         res = {}
-        for cpw in (1, 14, 4):
+        for cpw in (1, 4):
             ops.ctx.set_option(_abi.OPT_IRLS_COLUMNS_PER_WAVE, cpw)
             X = torch.zeros((ncols, k), dtype=W.dtype, device="cuda")
             t = timeit(lambda: ops.ctx.solve_irls_nb(ops.dt, csc["p"], csc["i"], csc["x"], ncols, F, G, X, k, 0.0, 0.0, 1, cdm, irm, 1e-4, th[0], th[1]))
             res[cpw] = (t, X)
-        same = bool(torch.equal(res[1][1], res[4][1])) and bool(torch.equal(res[1][1], res[14][1]))
+        same = bool(torch.equal(res[1][1], res[4][1]))
         dev = float((res[1][1] - res[4][1]).abs().max())
-        print("side %s cd_maxit %3d irls %d: 1/wave %.3f ms  4/wave %.3f ms  4/wave + LDS-DMA pipeline %.3f ms  identical %s (max abs diff %.3g)" % (side, cdm, irm, res[1][0], res[14][0], res[4][0], same, dev))
+        print("side %s cd_maxit %3d irls %d: 1/wave %.3f ms  4/wave %.3f ms  identical %s (max abs diff %.3g)" % (side, cdm, irm, res[1][0], res[4][0], same, dev))
 ops.ctx.set_option(_abi.OPT_IRLS_COLUMNS_PER_WAVE, 0)
