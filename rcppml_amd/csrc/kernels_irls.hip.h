@@ -243,6 +243,7 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8
     const int r = lane & 31, hh = lane >> 5;            // phase A: nonzero r, feature half hh; phase B: feature r, K-slot hh
     const int g8 = lane >> 3, p8 = lane & 7;            // gather: group of eight lanes = one row of F, lane = 16-byte piece
     const bool pok = 4 * p8 < k;
+    const char* Fp = reinterpret_cast<const char*>(F) + 16 * p8;    // the lane's piece of row 0
     const bool fok = lane < k;
     const bool lin = lane < KP;
     const int ll = lin ? lane : 0;
@@ -253,11 +254,21 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8
     for (int irls = 0; irls < irls_max_iter; ++irls) {
         ++passes;
         // accumulator tile <- base Gram (identity padding), C/D map: col = lane&31, row = (v&3) + 8(v>>2) + 4(lane>>5)
+        // (four 16-byte loads off one per-lane pointer: k % 4 == 0 keeps a group of four rows on one side of k)
         f32x16 acc;
+        {
+            const float* gb = Gbase + (int64_t)r * k + 4 * hh;
+            asm volatile("" : "+v"(gb));                 // per pass, not 16 hoisted addresses
 #pragma unroll
-        for (int v = 0; v < 16; ++v) {
-            const int gi = (v & 3) + 8 * (v >> 2) + 4 * hh, gj = r;
-            acc[v] = (gi < k && gj < k) ? Gbase[(int64_t)gj * k + gi] : (gi == gj ? 1.f : 0.f);
+            for (int v4 = 0; v4 < 4; ++v4) {
+                const int gi0 = 8 * v4 + 4 * hh;
+                const float4 g = (gi0 < k && r < k) ? *reinterpret_cast<const float4*>(gb + 8 * v4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                const bool pad = r >= k;
+                acc[4 * v4 + 0] = pad && gi0 + 0 == r ? 1.f : g.x;
+                acc[4 * v4 + 1] = pad && gi0 + 1 == r ? 1.f : g.y;
+                acc[4 * v4 + 2] = pad && gi0 + 2 == r ? 1.f : g.z;
+                acc[4 * v4 + 3] = pad && gi0 + 3 == r ? 1.f : g.w;
+            }
         }
         if (lin) xs[lane] = x;
         float bw = 0.f;
@@ -267,17 +278,27 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8
             // ---- phase A.  Gather: the eight lanes 8g .. 8g+7 read the eight 16-byte pieces of ONE row of F (one 128-byte line per
             // group and instruction, eight lines per instruction against 32 for a lane-per-row layout); instruction i of group g takes
             // chunk row 4g + i.  The reconstruction f . x is four in-lane fmas against the lane's piece of x and a sum over the group.
+            // (a lane past the column's end takes the position of the column's LAST nonzero: a valid row of F, no branch around
+            //  the loads; its weight pair is (0, 0), so it adds exact zeros to G_w and b_w all the same)
             const int tt = t0 + r;
             const bool ok = tt < ae;
-            const int row = ok ? rowidx[tt] : 0;
-            const float a = ok ? vals[tt] : 0.f;
+            const int tc = ok ? tt : ae - 1;
+            const int row = rowidx[tc];
+            const float a = ok ? vals[tc] : 0.f;
             float mine = 0.f;
             float4 fv4[4];
+            if (k == KP) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int cr = 4 * g8 + i;                                       // row of the chunk
-                const int rowg = __shfl(row, cr, 64);
-                fv4[i] = (t0 + cr < ae && pok) ? *reinterpret_cast<const float4*>(F + (int64_t)rowg * k + 4 * p8) : make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int i = 0; i < 4; ++i) {
+                    const unsigned rowg = (unsigned)__shfl(row, 4 * g8 + i, 64);  // row of the chunk: 4g + i
+                    fv4[i] = *reinterpret_cast<const float4*>(Fp + ((unsigned long long)rowg << 7));
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const unsigned rowg = (unsigned)__shfl(row, 4 * g8 + i, 64);
+                    fv4[i] = pok ? *reinterpret_cast<const float4*>(Fp + (unsigned long long)rowg * (unsigned)(4 * k)) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
