@@ -110,6 +110,9 @@ void fit(FitParams& P) {
     DevBuf dAp, dAi, dAx, dTp, dTi, dTx;
     struct PlanGuard { rcppml_rhs_plan* p = nullptr; ~PlanGuard() { rcppml_hip_rhs_plan_destroy(p); } } planA, planT;   // row-tiled rhs plans (see below)
     const bool dense = P.dense != nullptr;
+    // the IRLS half-updates (every loss but plain MSE) gather the factor rows per nonzero themselves and never call the rhs; only
+    // the projective H update does under such a loss.  No plans then: they were 6 ms of an NB fit's set-up (C5, fp64)
+    const bool plans_useful = !(P.loss_type != 0 || P.robust_delta > 0) || P.projective;
     bool csc_transposed = false;
     if (dense) {                    // dense input: A itself (m x n, column-major) in the compute precision; no CSC, no transpose
         upload_cast<T>(c, P.dense, (size_t)m * n, dAx, s);
@@ -149,7 +152,7 @@ void fit(FitParams& P) {
             } catch (...) { up_err = std::current_exception(); }
         });
         try {
-            if (P.nnz >= (1 << 20) && !P.mask_p) {
+            if (P.nnz >= (1 << 20) && !P.mask_p && plans_useful) {
                 plan_or_none(rcppml_hip_rhs_plan_create_indices(c, dt, dAp.as<int>(), dAi.as<int>(), n, m, k, 0, 0, &planA.p), planA.p);
                 plan_or_none(rcppml_hip_rhs_plan_create_indices(c, dt, dTp.as<int>(), dTi.as<int>(), m, n, k, 0, 0, &planT.p), planT.p);
             }
@@ -249,7 +252,7 @@ void fit(FitParams& P) {
     // B = F * A (columns of A) / B = F * A^T (rows of A): CSC gather kernels, or GEMMs for a dense A
     // Large sparse inputs: the LDS row-tiled form (kernels_rhs_tiled.hip.h), planned once per fit for each side; NULL
     // plans (small input, rank or layout the kernel is not compiled for) keep the gather kernel.
-    if (!dense && P.nnz >= (1 << 20)) {             // (the overlapped set-up above has usually built them already)
+    if (!dense && P.nnz >= (1 << 20) && plans_useful) {             // (the overlapped set-up above has usually built them already)
         if (!planA.p) plan_or_none(rcppml_hip_rhs_plan_create(c, dt, dAp.as<int>(), dAi.as<int>(), dAx.p, n, m, k, 0, 0, &planA.p), planA.p);
         if (!planT.p) plan_or_none(rcppml_hip_rhs_plan_create(c, dt, dTp.as<int>(), dTi.as<int>(), dTx.p, m, n, k, 0, 0, &planT.p), planT.p);
     }
