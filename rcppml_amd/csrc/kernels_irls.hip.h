@@ -410,7 +410,7 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4
     float2* sc = reinterpret_cast<float2*>(Fst + CH * FS);
     float* xs = Fst + CH * FS + 2 * CH;
     float* bws = xs + KP;
-    float* Gl = Fst;                                    // [i][c], stride FS: reused once a column's Gram is complete
+    float* Gl = Fst;                                    // [col][row], stride FS: reused once a column's Gram is complete
     const int64_t jw = ((int64_t)blockIdx.x * 4 + wave) * 4;      // first of this wave's four columns
     if (jw >= ncols) return;
     const int r = lane & 31, hh = lane >> 5;            // Gram phases: nonzero / feature r, half hh
@@ -515,21 +515,30 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4
                 __builtin_amdgcn_wave_barrier();
             }
             bw += __shfl_xor(bw, 32, 64);
-            // park G_w in the slab (symmetric: accumulator row gi is slab row gi) and b_w next to it
+            // park G_w in the slab column by column ([col r][row gi], as the kernel above) and b_w next to it
 #pragma unroll
-            for (int v = 0; v < 16; ++v) {
-                const int gi = (v & 3) + 8 * (v >> 2) + 4 * hh;
-                float val = acc[v];
-                if (l2 > 0.f && gi == r && gi < k) val += l2;
-                Gl[gi * FS + r] = val;
+            for (int v4 = 0; v4 < 4; ++v4) {
+                const int gi0 = 8 * v4 + 4 * hh;
+                float4 val = make_float4(acc[4 * v4], acc[4 * v4 + 1], acc[4 * v4 + 2], acc[4 * v4 + 3]);
+                if (l2 > 0.f && r < k) {
+                    if (gi0 + 0 == r) val.x += l2;
+                    if (gi0 + 1 == r) val.y += l2;
+                    if (gi0 + 2 == r) val.z += l2;
+                    if (gi0 + 3 == r) val.w += l2;
+                }
+                *reinterpret_cast<float4*>(Gl + r * FS + gi0) = val;
             }
             if (lane < KP) bws[lane] = bw;
             __builtin_amdgcn_wave_barrier();
-            if (qme == q) {                              // the column's row picks up rows l and l + 16 of G_w
-                // (COLUMNS l and l + 16 of the slab, as the one-column kernel reads them: the MFMA's G_w(i, j) = sum ((w-1) f_i) f_j is
-                //  not bitwise symmetric)
+            if (qme == q) {                              // the column's row picks up COLUMNS l and l + 16 of G_w
+                // (columns, as the one-column kernel reads them: the MFMA's G_w(i, j) = sum ((w-1) f_i) f_j is not bitwise symmetric)
 #pragma unroll
-                for (int c = 0; c < KP; ++c) { ng0[c] = Gl[c * FS + l]; ng1[c] = Gl[c * FS + l + 16]; }
+                for (int c4 = 0; c4 < KP / 4; ++c4) {
+                    const float4 u = *reinterpret_cast<const float4*>(Gl + l * FS + 4 * c4);
+                    const float4 v = *reinterpret_cast<const float4*>(Gl + (l + 16) * FS + 4 * c4);
+                    ng0[4 * c4] = u.x; ng0[4 * c4 + 1] = u.y; ng0[4 * c4 + 2] = u.z; ng0[4 * c4 + 3] = u.w;
+                    ng1[4 * c4] = v.x; ng1[4 * c4 + 1] = v.y; ng1[4 * c4 + 2] = v.z; ng1[4 * c4 + 3] = v.w;
+                }
                 gd0 = Gl[l * FS + l];
                 gd1 = Gl[(l + 16) * FS + l + 16];
                 b0 = bws[l];
