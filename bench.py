@@ -195,12 +195,21 @@ def main():
     if os.environ.get("RCPPML_BENCH_SHARE_GPU"):
         local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # RCPPML_BENCH_FORCE_DIST=1 with --gpus 1: a process group of ONE rank on the real backend (nccl = RCCL), and the loop takes
+    # its sharded branch -- every collective of the N > 1 path is issued (a one-rank sum is the identity), so the RCCL wiring
+    # executes on a one-GPU box and `collectives_ms_per_step` is the per-call launch floor of the library
+    force_dist = world == 1 and bool(os.environ.get("RCPPML_BENCH_FORCE_DIST"))
+    if force_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+    if world > 1 or force_dist:
         if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend=backend)
-    comm = als.Comm(dist if world > 1 else None, time_collectives=world > 1)
+    comm = als.Comm(dist if (world > 1 or force_dist) else None, time_collectives=world > 1 or force_dist, force=force_dist)
 
     m, n_loc, k = args.rows, args.cols, args.k
     n_total = n_loc * world
@@ -239,7 +248,7 @@ def main():
     # library is bound to it through the context's stream.  N > 1 (collectives in the loop) and --no-graph time the eager loop.
     # (a captured iteration bakes in the host-side branches of step(): warm start, Gram reuse, sweep-sorted order -- all in
     # their steady state only from the third iteration on, so shorter warm-ups time the eager loop)
-    use_graph = world == 1 and not args.no_graph and args.warmup >= 2
+    use_graph = world == 1 and not force_dist and not args.no_graph and args.warmup >= 2
     side = torch.cuda.Stream(device=local_rank) if use_graph else None
     stream_ctx = torch.cuda.stream(side) if use_graph else contextlib.nullcontext()
     with stream_ctx:
@@ -462,7 +471,8 @@ def main():
             "eager_ms_per_step": eager_ms_per_step,
             "final_loss": final_loss,
             "world_size_seen": world,
-            "backend": (dist.get_backend() if world > 1 else None),
+            "backend": (dist.get_backend() if (world > 1 or force_dist) else None),
+            "forced_one_rank_group": force_dist,
             "collectives_ms_per_step": {name: dict(ms=round(v["total_ms"] / args.steps, 4), calls_per_step=v["count"] / args.steps,
                                                    bytes=v["bytes"]) for name, v in sorted(coll.items())},
             "collectives_model": collectives_model(world, m, k, 4 if args.dtype == "f32" else 8, args.w_solve),
@@ -521,7 +531,7 @@ def main():
             except Exception as e:
                 out["fp64"] = {"error": repr(e)}
         print(json.dumps(out))
-    if world > 1:
+    if world > 1 or force_dist:
         dist.barrier()
         dist.destroy_process_group()
 

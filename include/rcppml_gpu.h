@@ -143,7 +143,7 @@ RCPPML_GPU_API void rcppml_gpu_nmf_cv_irls_ex(RCPPML_NMF_CV_ARGS, int* sort_mode
                                               double* robust_delta, double* out_theta);
 
 /* Dense-input NMF.  Replaces reference `rcppml_gpu_nmf_dense_unified_float` (resolved by
- * inst/include/FactorNet/gpu/bridge_nmf.hpp:544-545; 52 pointers, typedef :101-126): A_data is the m x n column-major
+ * inst/include/FactorNet/gpu/bridge_nmf.hpp:544-545; 50 pointers, typedef :101-126): A_data is the m x n column-major
  * matrix as doubles on the host; W (k x m), H (k x n), d in/out as in the sparse entry.  Semantics: the reference's
  * STANDARD path (separate RHS -> features -> nnls_batch / cholesky_clip_batch, nmf/fit_cpu.hpp:540-631, :774-881) --
  * zero start at iteration 0, residual-corrected warm start afterwards -- MSE loss; L1, L2, L21, angular, bounds,

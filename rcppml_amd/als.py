@@ -230,13 +230,16 @@ class _CommScope:
 
 
 class Comm:
-    """Collectives of the path.  world_size 1: no-ops."""
+    """Collectives of the path.  world_size 1: no-ops -- unless `force` (a process group of ONE rank): then the sharded branch
+    of step() runs and every collective is really issued (a one-rank sum is the identity), which executes the RCCL wiring
+    and measures its per-call floor on a one-GPU box (bench.py RCPPML_BENCH_FORCE_DIST=1)."""
 
-    def __init__(self, dist=None, time_collectives=False):
+    def __init__(self, dist=None, time_collectives=False, force=False):
         self.dist = dist
         self.world = dist.get_world_size() if dist is not None else 1
         self.rank = dist.get_rank() if dist is not None else 0
-        self.timed = bool(time_collectives) and self.world > 1
+        self.sharded = self.world > 1 or (bool(force) and dist is not None)
+        self.timed = bool(time_collectives) and self.sharded
         self.events = {}
 
     def _scope(self, name, t):
@@ -255,14 +258,14 @@ class Comm:
                 for k, v in self.events.items()}
 
     def all_reduce_sum(self, t, tag="all_reduce"):
-        if self.world > 1:
+        if self.sharded:
             with self._scope(tag, t):
                 self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
         return t
 
     def all_gather_rows(self, full, rows_per, tag="all_gather_W"):
         """In-place all-gather of equal row blocks: rank r's block full[r*rows_per:(r+1)*rows_per] goes to every rank."""
-        if self.world > 1:
+        if self.sharded:
             mine = full[self.rank * rows_per:(self.rank + 1) * rows_per]
             with self._scope(tag, full):
                 if self.dist.get_backend() == "gloo":          # CPU tests: gloo has no in-place tensor all-gather
@@ -273,7 +276,7 @@ class Comm:
         return full
 
     def barrier(self):
-        if self.world > 1:
+        if self.sharded:
             self.dist.barrier()
 
 
@@ -293,7 +296,7 @@ class ShardedALS:
         # W_T is replicated; for world > 1 its m columns (rows of the (m, k) array) are SOLVED in contiguous blocks of
         # rows_per per rank and all-gathered, so the W solve shrinks with the world size instead of being repeated.
         # rows_per is a multiple of 4 so every block starts 16-byte aligned for any k; the pad rows stay zero.
-        self.rows_per = ((m + comm.world - 1) // comm.world + 3) // 4 * 4 if comm.world > 1 else m
+        self.rows_per = ((m + comm.world - 1) // comm.world + 3) // 4 * 4 if comm.sharded else m
         self.W_pad = ops.zeros((self.rows_per * comm.world, k))
         self.W_T = self.W_pad[:m]
         self.W_T.copy_(ops.to_device(W_T0, ops.tdtype))
@@ -335,7 +338,7 @@ class ShardedALS:
         if not empty:
             ops.rhs(self.A, self.W_T, out=self.Bh, tag="rhs_H")
             ops.solve(G_h, self.Bh, self.H, cfg, "H", warm, tag="solve_H")
-        if comm.world > 1:
+        if comm.sharded:
             # ---- W half-update, sharded (fit_cpu.hpp:711-893): partial sums from the UNSCALED H, one all-reduce, then D^-1
             if empty:
                 self.xbuf.zero_()
@@ -368,7 +371,7 @@ class ShardedALS:
             G_w, G_saved = self.G, self.G_saved
         else:
             G_w, G_saved = self.Gp, self.Gp
-        if comm.world > 1 and cfg.w_solve == "block":
+        if comm.sharded and cfg.w_solve == "block":
             if self.row_hi > self.row_lo:
                 ops.solve(G_w, self.Bw[self.row_lo:self.row_hi], self.W_T[self.row_lo:self.row_hi], cfg, "W", warm, tag="solve_W")
             comm.all_gather_rows(self.W_pad, self.rows_per)

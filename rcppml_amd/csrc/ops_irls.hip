@@ -30,7 +30,7 @@ static void irls_impl(rcppml_hip_ctx* c, const int* cp, const int* ri, const T* 
         // fp32, k <= 32: weighted Gram on the matrix cores (RCPPML_GPU_IRLS_VARIANT=valu keeps the register form)
         static int use_mfma = -1;
         if (use_mfma < 0) use_mfma = exp_flag("RCPPML_GPU_IRLS_VARIANT", "valu") ? 0 : 1;
-        if (use_mfma && k <= 32 && k % 4 == 0 && reinterpret_cast<uintptr_t>(F) % 16 == 0) {
+        if (use_mfma && k <= 32 && k % 4 == 0 && reinterpret_cast<uintptr_t>(F) % 16 == 0 && reinterpret_cast<uintptr_t>(Gbase) % 16 == 0) {   // (16-byte loads of F rows and of the base Gram; unaligned views take the register kernel)
             // many short columns: four columns per wavefront in the CD solve (irls_nb_mfma32q_kernel); RCPPML_OPT_IRLS_COLUMNS_PER_WAVE forces
             const bool quad = c->opt_irls_cpw > 0 ? c->opt_irls_cpw == 4 : ncols >= (int64_t)64 * c->num_cu;
             if (quad) {

@@ -613,7 +613,9 @@ void nmf_entry(RCPPML_NMF_UNIFIED_ARGS, const int* mask_p, const int* mask_i, do
         // and n <= 1, runs the single-device loop
         int ndev = 1;
         if (const char* e = getenv("RCPPML_GPU_DEVICES")) ndev = atoi(e);
-        if (ndev > 1 && rcppml_fit_multi(P, precision, ndev)) {
+        const char* force_env = getenv("RCPPML_GPU_DEVICES_FORCE");      // test switch: RCPPML_GPU_DEVICES=1 through the sharded loop
+        const bool force_multi = ndev == 1 && getenv("RCPPML_GPU_DEVICES") && force_env && atoi(force_env) != 0;
+        if ((ndev > 1 || force_multi) && rcppml_fit_multi(P, precision, ndev)) {
             // done
         } else if (precision == RCPPML_F64) fit<double>(P);
         else fit<float>(P);

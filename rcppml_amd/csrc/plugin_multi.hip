@@ -17,6 +17,9 @@
 // RCCL is loaded at run time (dlopen) -- the single-device plugin has no dependency on it.
 // RCPPML_GPU_DEVICES_SHARE=1 maps every shard onto device 0 and replaces the collectives by a local sum kernel: the
 // sharded loop can then be exercised on a one-GPU box (RCCL refuses two ranks on one device).
+// RCPPML_GPU_DEVICES_FORCE=1 lets RCPPML_GPU_DEVICES=1 through this loop with a ONE-rank RCCL communicator whose collectives
+// are really issued (a one-rank sum is the identity): dlopen, the seven dlsym's, ncclCommInitAll and the grouped
+// ncclAllReduce / ncclAllGather then execute on a one-GPU box (tests/test_gpu_plugin_multi.py).
 // ============================================================================
 #include "plugin_common.hip.h"
 
@@ -87,6 +90,7 @@ Rccl& rccl() { static Rccl r; return r; }
 struct Exchange {
     int n = 0;
     bool shared = false;
+    bool always = false;               // issue the collectives for n == 1 as well (RCPPML_GPU_DEVICES_FORCE)
     std::vector<ncclComm_t> comms;
     std::vector<hipStream_t> streams;
     std::vector<int> devs;
@@ -97,8 +101,8 @@ struct Exchange {
         for (auto e : ev) if (e) (void)hipEventDestroy(e);
         for (auto e : ev2) if (e) (void)hipEventDestroy(e);
     }
-    void init(const std::vector<int>& devices, const std::vector<hipStream_t>& st, bool share) {
-        n = (int)devices.size(); devs = devices; streams = st; shared = share;
+    void init(const std::vector<int>& devices, const std::vector<hipStream_t>& st, bool share, bool force) {
+        n = (int)devices.size(); devs = devices; streams = st; shared = share; always = force;
         if (shared) {
             HIPCHK(hipSetDevice(devs[0]));
             ptrs.alloc((size_t)n * sizeof(void*));
@@ -114,7 +118,7 @@ struct Exchange {
     }
     template <class T>
     void all_reduce(const std::vector<void*>& bufs, size_t count) {
-        if (n == 1) return;
+        if (n == 1 && !always) return;
         if (shared) {
             // every stream's work on its buffer -> stream 0 sums -> every stream waits for the sum
             HIPCHK(hipSetDevice(devs[0]));
@@ -137,7 +141,7 @@ struct Exchange {
     // In-place all-gather of equal blocks: block r (count elements at bufs[q] + r * count) of device r goes to every device q.
     template <class T>
     void all_gather(const std::vector<void*>& bufs, size_t count) {
-        if (n == 1) return;
+        if (n == 1 && !always) return;
         if (shared) {
             // every stream has written its own block -> each stream copies the other blocks once their owners are done
             for (int r = 0; r < n; ++r) { HIPCHK(hipSetDevice(devs[r])); HIPCHK(hipEventRecord(ev[r], streams[r])); }
@@ -185,7 +189,7 @@ struct Shard {
 };
 
 template <class T>
-void fit_multi(FitParams& P, const std::vector<int>& devices, bool shared) {
+void fit_multi(FitParams& P, const std::vector<int>& devices, bool shared, bool force) {
     constexpr int dt = DT<T>::id;
     const int m = P.m, n = P.n, k = P.k, nd = (int)devices.size();
     const double eps = 1e-15;
@@ -205,7 +209,9 @@ void fit_multi(FitParams& P, const std::vector<int>& devices, bool shared) {
     // default, als.AlsConfig.w_solve).  Same numbers either way; which is faster over xGMI is for the first multi-GPU run to
     // decide -- unmeasured on hardware so far.
     const char* ws_env = getenv("RCPPML_GPU_W_SOLVE");
-    const bool w_block = nd > 1 && ws_env && !strcmp(ws_env, "block");
+    if (ws_env && strcmp(ws_env, "block") && strcmp(ws_env, "replicated") && getenv("RCPPML_GPU_VERBOSE"))
+        fprintf(stderr, "[rcppml_gpu] RCPPML_GPU_W_SOLVE=%s is neither 'block' nor 'replicated': using 'replicated'\n", ws_env);
+    const bool w_block = (nd > 1 || force) && ws_env && !strcmp(ws_env, "block");
     const int rows_per = w_block ? (((m + nd - 1) / nd + 3) / 4) * 4 : m;         // multiples of 4 rows: 16-byte aligned blocks for any k
     const size_t w_elems = w_block ? (size_t)rows_per * nd * k : (size_t)k * m;
     std::vector<std::unique_ptr<Shard<T>>> S(nd);
@@ -263,7 +269,7 @@ void fit_multi(FitParams& P, const std::vector<int>& devices, bool shared) {
         }
     }
     Exchange X;
-    X.init(devices, streams, shared);
+    X.init(devices, streams, shared, force);
 
     // ---- ||A||^2 over all shards
     double trAtA = 0;
@@ -350,10 +356,10 @@ void fit_multi(FitParams& P, const std::vector<int>& devices, bool shared) {
                 if (P.solver_mode == 0) {
                     const bool ord = use_order && iter > 0 && mb >= kOrderMinColumns;
                     int* sw = use_order ? s.swW.template as<int>() + lo : nullptr;
-                    int* od = s.ordW.template as<int>() + lo;
+                    int* od = ord ? s.ordW.template as<int>() + lo : nullptr;
                     if (ord) OPCHK(rcppml_hip_order_columns(c, sw, mb, od));
                     OPCHK(rcppml_hip_solve_cd(c, dt, s.G.p, Bb, Wb, k, mb, P.L1_W > 0 ? P.L1_W : 0.0, warm, 0, 0.0, 0.0, P.nonneg_W,
-                                              P.cd_maxit, P.cd_tol, 0.0, P.ub_W, RCPPML_CD_AUTO, sw, ord ? od : nullptr));
+                                              P.cd_maxit, P.cd_tol, 0.0, P.ub_W, RCPPML_CD_AUTO, sw, od));
                 } else
                     OPCHK(rcppml_hip_solve_chol(c, dt, s.G.p, Bb, Wb, k, mb, P.L1_W > 0 ? P.L1_W : 0.0, P.nonneg_W, P.ub_W));
             }
@@ -424,7 +430,9 @@ bool rcppml_fit_multi(FitParams& P, int precision, int ndev) {
     if (P.L21_H > 0 || P.L21_W > 0 || P.angular_H > 0 || P.angular_W > 0) return false;
     if ((P.target_H && P.target_lambda_H != 0) || (P.target_W && P.target_lambda_W != 0)) return false;
     if ((P.gH_p && P.gH_nnz > 0 && P.gH_lambda > 0) || (P.gW_p && P.gW_nnz > 0 && P.gW_lambda > 0)) return false;
-    if (ndev < 2 || P.n < ndev) return false;
+    const char* fo = getenv("RCPPML_GPU_DEVICES_FORCE");
+    const bool force = fo && atoi(fo) != 0;
+    if (ndev < (force ? 1 : 2) || P.n < ndev) return false;
     const char* sh = getenv("RCPPML_GPU_DEVICES_SHARE");
     const bool shared = sh && atoi(sh) != 0;
     int have = 0;
@@ -437,7 +445,7 @@ bool rcppml_fit_multi(FitParams& P, int precision, int ndev) {
                                                   " device(s) visible (RCPPML_GPU_DEVICES_SHARE=1 maps the shards onto one device for testing)");
         for (int r = 0; r < ndev; ++r) devices[r] = r;
     }
-    if (precision == RCPPML_F64) fit_multi<double>(P, devices, shared);
-    else fit_multi<float>(P, devices, shared);
+    if (precision == RCPPML_F64) fit_multi<double>(P, devices, shared, force);
+    else fit_multi<float>(P, devices, shared, force);
     return true;
 }

@@ -30,22 +30,24 @@ inline bool shape_ok(int NV, int S, int NW, int NR, int tsize) {
     return false;
 }
 
-template <class K>
-void set_lds_once(K kernel, int device) {
-    // per-device attribute, set to the one size this kernel ever asks for; serialised (concurrent fits from host threads)
+// One flag set PER KERNEL (the template parameter is the kernel itself, not its type: every instantiation of one precision has
+// the same function type, and a flag keyed on the type would give only the first shape launched on a device its opt-in to
+// more than 64 KiB of dynamic LDS); per-device attribute, serialised (concurrent fits from host threads)
+template <auto Kernel>
+void set_lds_once(int device) {
     static std::mutex mu;
     static bool done[64] = {};
     std::lock_guard<std::mutex> lk(mu);
     if (!done[device & 63]) {
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, RT_MAX_LDS));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(Kernel), hipFuncAttributeMaxDynamicSharedMemorySize, RT_MAX_LDS));
         done[device & 63] = true;
     }
 }
 
 template <class T, int NV, int S, int NW, int NR>
 void launch_tiled(rcppml_hip_ctx* c, const rcppml_rhs_plan* pl, const T* F, const T* Binit, T* Bout) {
-    auto kern = rhs_tiled_kernel<T, NV, S, NR, NW>;
-    set_lds_once(kern, c->device);
+    constexpr auto kern = rhs_tiled_kernel<T, NV, S, NR, NW>;
+    set_lds_once<kern>(c->device);
     const RhsTiledGeom& G = pl->G;
     if (!shape_ok(NV, S, NW, NR, (int)sizeof(T))) throw std::runtime_error("rhs_planned: shape exceeds the LDS");
     hipLaunchKernelGGL(kern, dim3((unsigned)(G.P * G.ncb)), dim3(64 * NW), rt_dyn_lds(NW, NR, S, (int)sizeof(T)), c->stream,

@@ -51,13 +51,16 @@ inline bool shape_ok(int NV, int CLO, int NW, int NR, int tsize, int NHI = -1) {
     return ok;
 }
 
-template <class K>
-void set_lds_once(K kernel, int device) {
+// One flag set PER KERNEL (the template parameter is the kernel itself, not its type: every instantiation of one precision has
+// the same function type, and a flag keyed on the type would give only the first shape launched on a device its opt-in to
+// more than 64 KiB of dynamic LDS); per-device attribute, serialised (concurrent fits from host threads)
+template <auto Kernel>
+void set_lds_once(int device) {
     static std::mutex mu;
     static bool done[64] = {};
     std::lock_guard<std::mutex> lk(mu);
     if (!done[device & 63]) {
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, RW_MAX_LDS));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(Kernel), hipFuncAttributeMaxDynamicSharedMemorySize, RW_MAX_LDS));
         done[device & 63] = true;
     }
 }
@@ -68,8 +71,8 @@ void launch_one(rcppml_hip_ctx* c, const rcppml_rhs_plan* pl, const T* F, T* Bou
     if constexpr (rw_dyn_lds(NW, NR, CLO, (int)sizeof(T)) > RW_MAX_LDS || regs > (NW == 8 ? 250 : (NW == 12 ? 164 : 124)) || !rate_compiled(CLO, NHI) || shape_spills(NV, CLO, NHI, NW, NR)) {
         throw std::runtime_error("rhs_planned: window shape not compiled");
     } else {
-        auto kern = rhs_win_kernel<T, NV, CLO, NHI, NR, NW>;
-        set_lds_once(kern, c->device);
+        constexpr auto kern = rhs_win_kernel<T, NV, CLO, NHI, NR, NW>;
+        set_lds_once<kern>(c->device);
         const RhsWinGeom& G = pl->WG;
         hipLaunchKernelGGL(kern, dim3((unsigned)(G.P * G.ncb)), dim3(64 * NW), rw_dyn_lds(NW, NR, CLO, (int)sizeof(T)), c->stream,
                            (const char*)pl->svals, F, G, Bout);

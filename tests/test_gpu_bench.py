@@ -92,6 +92,34 @@ def test_bench_self_launcher_two_ranks_sharing_the_gpu(config):
     assert abs(d2["final_loss"] - d1["final_loss"]) / abs(d1["final_loss"]) < 1e-9
 
 
+def test_bench_forced_one_rank_group_runs_rccl():
+    """RCPPML_BENCH_FORCE_DIST=1: `--gpus 1` with a process group of ONE rank on the nccl (= RCCL) backend and the loop in its
+    sharded branch -- the all-reduce of [G | B | row sums] and the all-gather of W's row blocks are really issued on the GPU,
+    so RCCL has executed before the first multi-GPU run.  A one-rank sum is the identity: the loss equals the unsharded
+    loop's (which scales BEFORE forming the Gram; the sharded branch scales after the sum) to fp64 rounding."""
+    shape = ["--rows", "3000", "--cols", "24000", "--density", "0.01", "--k", "64"]
+    common = ["--steps", "3", "--warmup", "2", "--no-cpu-baseline", "--no-plugin-figure", "--no-cpu-ref", "--no-fp64-leg",
+              "--no-noop-count", "--dtype", "f64"]
+    env = dict(os.environ, RCPPML_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None)
+    f = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *shape, *common], capture_output=True, text=True, timeout=900,
+                       cwd=ROOT, env=env)
+    assert f.returncode == 0, f.stderr[-3000:]
+    d = json.loads([l for l in f.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["backend"] == "nccl" and d["world_size_seen"] == 1 and d["forced_one_rank_group"] is True and d["launch"] == "eager"
+    coll = d["collectives_ms_per_step"]
+    assert set(coll) == {"all_reduce_gram_rhs_rowsums", "all_gather_W"}
+    for name in coll:
+        assert coll[name]["calls_per_step"] == 1 and coll[name]["ms"] > 0
+    assert coll["all_reduce_gram_rhs_rowsums"]["bytes"] == 8 * (64 * 64 + 3000 * 64 + 64)
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *shape, *common, "--no-graph"], capture_output=True, text=True,
+                         timeout=900, cwd=ROOT)
+    assert one.returncode == 0, one.stderr[-3000:]
+    d1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
+    assert d1["backend"] is None and not d1["collectives_ms_per_step"]
+    assert abs(d["final_loss"] - d1["final_loss"]) / abs(d1["final_loss"]) < 1e-9
+
+
 def test_bench_c3_line_on_the_movielens_fixture():
     """--config c3: BASELINE configs[2] (movielens, k = 32, L1 = c(0, 0.1)) through the same loop; the fp64 leg stays inside the
     north star's 1e-6 of the CPU reference fit."""

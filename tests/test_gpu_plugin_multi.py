@@ -97,6 +97,43 @@ def test_sharded_plugin_block_w_solve_equals_replicated(abi, ndev, solver):
     assert abs(blk["loss"] - one["loss"]) / abs(one["loss"]) < 1e-9
 
 
+def _rccl_mapped():
+    with open("/proc/self/maps") as f:
+        return any("librccl" in line for line in f)
+
+
+@pytest.mark.parametrize("w_solve", [None, "block"])
+@pytest.mark.parametrize("precision", [1, 0])
+def test_one_rank_rccl_communicator_executes(abi, w_solve, precision):
+    """RCPPML_GPU_DEVICES=1 + RCPPML_GPU_DEVICES_FORCE=1 WITHOUT the shared-device stand-in: the sharded loop with a real one-rank
+    RCCL communicator -- dlopen of librccl, the seven dlsym's, ncclCommInitAll(comms, 1, devs), the grouped ncclAllReduce on
+    [G | B | row sums] and (w_solve = block) ncclAllGather on W_T's row blocks all execute on this one-GPU box.  A one-rank sum
+    is the identity, so the fit must equal, BIT FOR BIT, the same loop with the local-sum stand-in, and agree with the
+    single-device loop (which scales H before forming its Gram, the sharded loop after the sum) to rounding."""
+    A = lowrank_csc(300, 1100, 6, 0.07, seed=23)
+    k = 12
+    W0, H0 = O.init_factors(5, k, A.rows, A.cols, np.float64)
+    kw = dict(max_iter=7, tol=0.0, solver_mode=0, precision=precision, L1_H=0.02, want_history=True)
+
+    def run(share):
+        W, H = W0.copy(), H0.copy()
+        with _Env(RCPPML_GPU_DEVICES=1, RCPPML_GPU_DEVICES_FORCE=1, RCPPML_GPU_DEVICES_SHARE=1 if share else None, RCPPML_GPU_W_SOLVE=w_solve):
+            res = abi.nmf_unified(A.p, A.i, A.x, A.rows, A.cols, k, W, H, entry="ex", **kw)
+        assert res["status"] == 0, res.get("error")
+        res["W_T"], res["H"] = W, H
+        return res
+
+    real = run(False)
+    assert _rccl_mapped(), "librccl was not loaded: the RCCL path did not run"
+    local = run(True)
+    assert real["loss"] == local["loss"] and np.array_equal(real["loss_history"], local["loss_history"])
+    assert np.array_equal(real["W_T"], local["W_T"]) and np.array_equal(real["H"], local["H"]) and np.array_equal(real["d"], local["d"])
+    one = _fit(abi, A, W0, H0, 1, **kw)
+    tol = 1e-9 if precision == 1 else 2e-4
+    assert real["iter"] == one["iter"]
+    assert abs(real["loss"] - one["loss"]) / abs(one["loss"]) < tol
+
+
 def test_sharded_plugin_fit_fp32_convergence_and_norms(abi):
     A = lowrank_csc(200, 900, 5, 0.1, seed=3)
     k = 8
