@@ -288,17 +288,26 @@ RCPPML_GPU_API int rcppml_hip_rhs(rcppml_hip_ctx* ctx, int dtype, const int* col
                                   const void* F, int k, void* B);
 
 /* Planned form of the same product for large inputs (build-defined; the reference has one CPU loop, rhs.hpp:52-70).
- * A plan is a tile-partitioned, slot-padded device copy of ONE CSC matrix for one rank k and precision: the rows of F
- * are staged through LDS in 64 KiB tiles, the output columns stay in registers (kernels_rhs_tiled.hip.h).
- *   plan_create: nrows = rows of the sparse matrix (= number of k-vectors in F).  partitions: 0 = automatic (one row
- *     partition per XCD when F is far larger than an XCD's L2, else one).  slots: 0 = chosen from the data.
- *     *out_plan stays NULL (return 0) when the shape is not eligible (k * sizeof(T) not 256 or 512 bytes -- or 1024 in fp64 --, rows not
- *     sorted inside a column, more than 35 % of the nonzeros would spill): call rcppml_hip_rhs then.
+ * A plan is a device copy of ONE CSC matrix for one rank k and precision, laid out for a kernel that stages the rows of F through
+ * LDS and keeps the output columns in registers.  Two plan kinds (plan_info field 0 says which the planner took):
+ *   window plan (kind 1, kernels_rhs_win.hip.h -- the default): a ring of four 32 KiB row tiles, nonzeros scheduled over a sliding
+ *     window of three tiles at a fractional slot rate; what the window cannot place (the "overflow", a few per cent) is added by
+ *     the finishing pass that also sums the row partitions; no tail launch.  Declined (-> slab plan) for slot rates above 6 per
+ *     phase, rows not sorted inside a column, hypersparse inputs, or more than 25 % overflow.
+ *   slab plan (kind 0, kernels_rhs_tiled.hip.h -- the r2/r3 form, the fallback): 64 KiB tiles, S slots per (column, tile), the
+ *     rest spilled to a gather kernel (refused above 35 % spill); columns that would only part-fill a last round of workgroups go
+ *     to the gather kernel.
+ *   plan_create: nrows = rows of the sparse matrix (= number of k-vectors in F).  partitions: 0 = automatic.
+ *     slots: 0 = window plan, then slab plan, then no plan; 1 = slab plan with S chosen from the data; 2..8 = slab plan with S
+ *     slots; >= 100 = window plan at (slots - 100) / 4 slots per column and phase (e.g. 107 = 1.75).
+ *     *out_plan stays NULL (return 0) when no plan kind is eligible (k * sizeof(T) not 256 or 512 bytes -- or 1024 in fp64 --,
+ *     unsorted rows, too irregular): call rcppml_hip_rhs then.
  *   rhs_planned: B = F * A(:, j) for all columns, same numbers as rcppml_hip_rhs up to summation order; deterministic.
- *     The plan keeps the col_ptr / row_idx / values POINTERS (columns that would only part-fill a last round of
- *     workgroups are left to the gather kernel): the CSC must outlive the plan.
- *   plan_info (11 doubles): {P, waves per workgroup, rounds per wave, slots, workgroups per partition, tiles, slot count,
- *     spilled nonzeros, slot fill fraction, slot stream bytes, columns handled by the tiled kernel}. */
+ *     The plan keeps the col_ptr / row_idx / values POINTERS: the CSC must outlive the plan.
+ *   plan_info (11 doubles): {P, waves per workgroup, rounds per wave, slots (slab: S; window: clo + nhi / 4 = the slot rate),
+ *     workgroups per partition, tiles, slot count, spilled / overflow nonzeros, slot fill fraction, slot stream bytes, columns
+ *     handled by the tiled kernel}.
+ *   plan_set_values works only on plans made by plan_create_indices (it needs their per-nonzero destination table). */
 typedef struct rcppml_rhs_plan rcppml_rhs_plan;
 RCPPML_GPU_API int rcppml_hip_rhs_plan_create(rcppml_hip_ctx* ctx, int dtype, const int* col_ptr, const int* row_idx,
                                               const void* values, int64_t ncols, int64_t nrows, int k, int partitions,
@@ -377,6 +386,14 @@ RCPPML_GPU_API int rcppml_hip_loss_nonzeros(rcppml_hip_ctx* ctx, int dtype, cons
                                             const int* mask_p, const int* mask_i, int64_t ncols,
                                             const void* W_T, const void* d, const void* H, int k,
                                             double* out);
+/* The same pass with the per-element term of the configured loss: out[0] = sum over the unmasked nonzeros of
+ * compute_loss(a, p, loss) (math/loss.hpp:512-536) -- the loss of a fit that has BOTH an explicit mask and a distribution loss
+ * (fit_cpu.hpp:1685-1690 -> nmf/masked_nnls.hpp:250-282, :277).  As in the reference the term is evaluated with theta = 0 (masked_loss
+ * passes no dispersion) and without the robust modifier.  loss_type 0 (MSE) or 4..8; out: 2 doubles, device (out[1] = sum p^2). */
+RCPPML_GPU_API int rcppml_hip_loss_masked(rcppml_hip_ctx* ctx, int dtype, int loss_type, double tweedie_power,
+                                          const int* col_ptr, const int* row_idx, const void* values,
+                                          const int* mask_p, const int* mask_i, int64_t ncols,
+                                          const void* W_T, const void* d, const void* H, int k, double* out);
 
 /* Cross-validation (reference nmf/fit_cv.hpp, nmf/cv_detail.hpp, nmf/speckled_cv.hpp).  The held-out
  * set is the lazy speckled mask  SplitMix64::hash(seed, i, j) < UINT64_MAX / floor(1 / holdout_fraction)  with

@@ -617,10 +617,12 @@ static CvResult<S> nmf_fit_cv(const Csc<S>& A, const FitConfig<S>& cfg, double h
     return res;
 }
 
-// nmf/masked_nnls.hpp:250-282   masked_loss (sparse A: unmasked NONZEROS only, MSE)
+// nmf/masked_nnls.hpp:250-282   masked_loss (sparse A: unmasked NONZEROS only).  Per element compute_loss(a, pred, loss_config)
+// (:277) -- math/loss.hpp:512-536 with its DEFAULT theta = 0: under a mask the reference evaluates a GP / NB term without the fitted
+// dispersion and never applies the robust modifier (compute_loss, not compute_robust_loss); restated as it is.
 template <class S>
 static S masked_loss(const Csc<S>& A, const S* W_Td, const S* H, const Csc<S>& mask, int k,
-                     int threads) {
+                     int threads, int loss_type = 0, S power = S(1.5)) {
     const int nt = eff_threads(threads); (void)nt;
     S total = 0;
 #pragma omp parallel num_threads(nt) reduction(+ : total)
@@ -637,8 +639,10 @@ static S masked_loss(const Csc<S>& A, const S* W_Td, const S* H, const Csc<S>& m
                 const S* w = W_Td + (size_t)i * k;
                 S pred = 0;
                 for (int f = 0; f < k; ++f) pred += w[f] * h[f];
-                const S diff = A.x[t] - pred;
-                total += diff * diff;
+                if (loss_type == 0) {
+                    const S diff = A.x[t] - pred;
+                    total += diff * diff;
+                } else total += loss_contribution(loss_type, A.x[t], pred, S(0), power);
             }
             for (int t = mask.p[j]; t < mask.p[j + 1]; ++t) is_masked[mask.i[t]] = 0;
         }
@@ -699,7 +703,7 @@ static void nnls_batch_irls_sparse_nb(const Csc<S>& A, const S* F, const S* G_ba
     }
 }
 
-// nmf/fit_cpu.hpp:1094-1265   NB size update (PER_ROW / GLOBAL), sparse branch
+// nmf/fit_cpu.hpp:1094-1265   NB size update (PER_ROW / GLOBAL / PER_COL), sparse branch
 template <class S>
 static void nb_size_update(const Csc<S>& A, const S* W_T, const S* H, const S* d, int k,
                            const FitConfig<S>& cfg, std::vector<S>& nb_size) {
@@ -707,6 +711,43 @@ static void nb_size_update(const Csc<S>& A, const S* W_T, const S* H, const S* d
     std::vector<S> Wd((size_t)k * m);
     for (int i = 0; i < m; ++i) for (int f = 0; f < k; ++f) Wd[(size_t)i * k + f] = W_T[(size_t)i * k + f] * d[f];
     const double r_min = static_cast<double>(cfg.nb_size_min), r_max = static_cast<double>(cfg.nb_size_max);
+    if (cfg.dispersion_mode == 3) {
+        // :1103-1162 PER_COL: per column j the nonzero sums, then the zeros' share from the totals over ALL rows, which the
+        // reference forms by a direct loop over the m rows (Scalar dot, summed in double, NOT clamped)
+        for (int j = 0; j < n; ++j) {
+            const S* h = H + (size_t)j * k;
+            double s_mu2 = 0.0, s_exc = 0.0, nz_mu = 0.0, nz_mu2 = 0.0;
+            for (int t = A.p[j]; t < A.p[j + 1]; ++t) {
+                const S* w = Wd.data() + (size_t)A.i[t] * k;
+                S dot = 0;
+                for (int f = 0; f < k; ++f) dot += w[f] * h[f];
+                const double y = static_cast<double>(A.x[t]);
+                const double mu = std::max(static_cast<double>(dot), 1e-10);
+                const double resid = y - mu;
+                s_mu2 += mu * mu;                                   // :1110
+                s_exc += resid * resid - mu;                        // :1111
+                nz_mu += mu; nz_mu2 += mu * mu;                     // :1127-1131 (second pass over the same nonzeros)
+            }
+            double tot_mu = 0.0, tot_mu2 = 0.0;                     // :1117-1122
+            for (int i = 0; i < m; ++i) {
+                const S* w = Wd.data() + (size_t)i * k;
+                S dot = 0;
+                for (int f = 0; f < k; ++f) dot += w[f] * h[f];
+                const double mu = static_cast<double>(dot);
+                tot_mu += mu; tot_mu2 += mu * mu;
+            }
+            s_mu2 += (tot_mu2 - nz_mu2);                            // :1134
+            s_exc += (tot_mu2 - nz_mu2) - (tot_mu - nz_mu);         // :1135
+            if (s_exc > 1e-10 && s_mu2 > 1e-10) {                   // :1151-1160
+                double r_new = s_mu2 / s_exc;
+                r_new = std::max(r_min, std::min(r_new, r_max));
+                if (std::isfinite(r_new)) nb_size[j] = static_cast<S>(r_new);
+            } else {
+                nb_size[j] = static_cast<S>(r_max);
+            }
+        }
+        return;
+    }
     std::vector<double> s_mu2(m, 0.0), s_res2(m, 0.0);
     for (int j = 0; j < n; ++j) {
         const S* h = H + (size_t)j * k;
@@ -763,6 +804,58 @@ static void gp_theta_update(const Csc<S>& A, const S* W_T, const S* H, const S* 
     const int m = A.rows, n = A.cols;
     std::vector<S> Wd((size_t)k * m);
     for (int i = 0; i < m; ++i) for (int f = 0; f < k; ++f) Wd[(size_t)i * k + f] = W_T[(size_t)i * k + f] * d[f];
+    if (cfg.dispersion_mode == 3 && !cv_mask) {
+        // :1009-1083 PER_COL: the same MM update with every accumulator indexed by the column; sum_s of column j is the direct
+        // sum over all m rows of the Scalar dot (:1021-1026)
+        std::vector<double> sy(n, 0.0), ss(n, 0.0);
+        std::vector<int> nn(n, 0);
+        struct NzC { int col; double y, s; };
+        std::vector<NzC> cc; cc.reserve((size_t)A.p[n]);
+        for (int j = 0; j < n; ++j) {
+            const S* h = H + (size_t)j * k;
+            double tot = 0;
+            for (int i = 0; i < m; ++i) {
+                const S* w = Wd.data() + (size_t)i * k;
+                S dot = 0; for (int f = 0; f < k; ++f) dot += w[f] * h[f];
+                tot += static_cast<double>(dot);
+            }
+            ss[j] = tot;
+            for (int t = A.p[j]; t < A.p[j + 1]; ++t) {
+                const S* w = Wd.data() + (size_t)A.i[t] * k;
+                S dot = 0; for (int f = 0; f < k; ++f) dot += w[f] * h[f];
+                const double y = static_cast<double>(A.x[t]);
+                const double sv = std::max(static_cast<double>(dot), 1e-10);
+                sy[j] += y;
+                if (y >= 1.0) nn[j]++;
+                cc.push_back({j, y, sv});
+            }
+        }
+        const double capc = static_cast<double>(cfg.gp_theta_max);
+        std::vector<double> al(n), ga(n);
+        for (int mm = 0; mm < 5; ++mm) {
+            std::fill(al.begin(), al.end(), 0.0); std::fill(ga.begin(), ga.end(), 0.0);
+            for (const NzC& z : cc)
+                if (z.y >= 1.0) {
+                    const double th = static_cast<double>(theta[z.col]);
+                    const double denom = std::max(z.s + th * z.y, 1e-10);
+                    const double eta1 = z.s / denom;
+                    al[z.col] += (z.y - 1.0) * eta1;
+                    ga[z.col] += (z.y - 1.0) * (1.0 - eta1);
+                }
+            for (int j = 0; j < n; ++j) {
+                const double a = al[j] + static_cast<double>(nn[j]);
+                const double b = (sy[j] - ss[j]) - ga[j] + a;
+                if (a > 1e-15) {
+                    const double disc = b * b + 4.0 * a * ga[j];
+                    if (disc > 0.0 && std::isfinite(disc)) {
+                        const double nt = (-b + std::sqrt(disc)) / (2.0 * a);
+                        if (std::isfinite(nt) && nt >= 0.0) theta[j] = static_cast<S>(std::min(nt, capc));
+                    }
+                }
+            }
+        }
+        return;
+    }
     std::vector<double> sum_y(m, 0.0), sum_s(m, 0.0);
     std::vector<int> n_nz(m, 0);
     std::vector<S> h_rs(k, S(0));                                                                    // :935
@@ -835,8 +928,10 @@ static void phi_update(const Csc<S>& A, const S* W_T, const S* H, const S* d, in
     for (int i = 0; i < m; ++i) for (int f = 0; f < k; ++f) Wd[(size_t)i * k + f] = W_T[(size_t)i * k + f] * d[f];
     const double var_power = cfg.loss_type == 8 ? static_cast<double>(cfg.tweedie_power) : (cfg.loss_type == 6 ? 2.0 : 3.0);
     const double phi_min = static_cast<double>(cfg.gamma_phi_min), phi_max = static_cast<double>(cfg.gamma_phi_max);
-    std::vector<double> sum_p(m, 0.0);
-    std::vector<int> cnt(m, 0);
+    const bool per_col = cfg.dispersion_mode == 3;                 // :1570-1611: the same sums indexed by the column
+    const int len = per_col ? n : m;
+    std::vector<double> sum_p(len, 0.0);
+    std::vector<int> cnt(len, 0);
     for (int j = 0; j < n; ++j) {
         const S* h = H + (size_t)j * k;
         for (int t = A.p[j]; t < A.p[j + 1]; ++t) {
@@ -848,11 +943,11 @@ static void phi_update(const Csc<S>& A, const S* W_T, const S* H, const S* d, in
             const double mu = std::max(static_cast<double>(dot), 1e-10);
             const double resid = y - mu;
             const double v_mu = std::pow(mu, var_power);
-            sum_p[i] += (resid * resid) / std::max(v_mu, 1e-20);
-            cnt[i]++;
+            sum_p[per_col ? j : i] += (resid * resid) / std::max(v_mu, 1e-20);
+            cnt[per_col ? j : i]++;
         }
     }
-    for (int i = 0; i < m; ++i)
+    for (int i = 0; i < len; ++i)
         if (cnt[i] > 0) {
             double pn = sum_p[i] / static_cast<double>(cnt[i]);
             pn = std::max(phi_min, std::min(pn, phi_max));
@@ -868,7 +963,8 @@ static void phi_update(const Csc<S>& A, const S* W_T, const S* H, const S* d, in
 // nmf/explicit_loss.hpp:53-77   NB NLL over NONZEROS only (per-row theta)
 template <class S>
 static S explicit_loss_sparse_nb(const Csc<S>& A, const S* W_Td, const S* H, int k,
-                                 const S* theta_row, int threads, int loss_type = 5, S power = S(1.5), S robust = S(0)) {
+                                 const S* theta_row, int threads, int loss_type = 5, S power = S(1.5), S robust = S(0),
+                                 bool theta_is_per_col = false) {                                      // explicit_loss.hpp:59, :70-71
     const int nt = eff_threads(threads); (void)nt;
     S total = 0;
 #pragma omp parallel for reduction(+ : total) num_threads(nt) schedule(dynamic, 64)
@@ -878,7 +974,7 @@ static S explicit_loss_sparse_nb(const Csc<S>& A, const S* W_Td, const S* H, int
             const S* w = W_Td + (size_t)A.i[t] * k;
             S pred = 0;
             for (int f = 0; f < k; ++f) pred += w[f] * h[f];
-            total += compute_robust_loss(loss_type, A.x[t], pred, theta_row ? theta_row[A.i[t]] : S(0), power, robust);
+            total += compute_robust_loss(loss_type, A.x[t], pred, theta_row ? theta_row[theta_is_per_col ? j : A.i[t]] : S(0), power, robust);
         }
     }
     return total;
@@ -974,10 +1070,12 @@ FitResult<S> nmf_fit(const Csc<S>& A, const FitConfig<S>& cfg, S* W_T, S* H, S* 
     const bool is_pow = cfg.loss_type == 6 || cfg.loss_type == 7 || cfg.loss_type == 8;   // phi: gamma_phi_init or 1 (:337-347)
     const bool irls = is_nb || is_gp || is_pow || cfg.robust_delta > 0;   // requires_irls() (math/loss.hpp:106-108)
     std::vector<S> nb_size;
-    if (is_nb)                                                // fit_cpu.hpp:316-328 (PER_ROW/GLOBAL/NONE)
-        nb_size.assign(m, cfg.dispersion_mode == 0 ? cfg.nb_size_max : cfg.nb_size_init);
-    if (is_gp) nb_size.assign(m, cfg.dispersion_mode == 0 ? S(0) : cfg.gp_theta_init);
-    if (is_pow) nb_size.assign(m, cfg.dispersion_mode == 0 ? S(1) : cfg.gamma_phi_init);
+    const bool per_col = cfg.dispersion_mode == 3;            // DispersionMode::PER_COL: one value per COLUMN of A (:300-301, :319-320, :341-342)
+    const size_t dlen = per_col ? (size_t)n : (size_t)m;
+    if (is_nb)                                                // fit_cpu.hpp:316-328 (PER_ROW/GLOBAL/NONE/PER_COL)
+        nb_size.assign(dlen, cfg.dispersion_mode == 0 ? cfg.nb_size_max : cfg.nb_size_init);
+    if (is_gp) nb_size.assign(dlen, cfg.dispersion_mode == 0 ? S(0) : cfg.gp_theta_init);
+    if (is_pow) nb_size.assign(dlen, cfg.dispersion_mode == 0 ? S(1) : cfg.gamma_phi_init);
     if (cfg.loss_type == 0) nb_size.assign(m, S(0));          // robust MSE: no dispersion; the IRLS of GP / power losses gets no theta
 
     std::vector<S> G((size_t)k * k), G_saved((size_t)k * k), G_wt((size_t)k * k);
@@ -1019,7 +1117,8 @@ FitResult<S> nmf_fit(const Csc<S>& A, const FitConfig<S>& cfg, S* W_T, S* H, S* 
             // :565-606 gram recomputed (eps only); L1 inside CD, L2 on G_w
             nnls_batch_irls_sparse_nb(A, W_T, G.data(), H, k, cfg.L1_H, cfg.L2_H, cfg.nonneg_H,
                                       cfg.cd_maxit, cfg.irls_max_iter, cfg.irls_tol, cfg.threads,
-                                      is_nb ? nb_size.data() : (const S*)nullptr, (const S*)nullptr, cfg.loss_type, cfg.tweedie_power, cfg.robust_delta);
+                                      is_nb && !per_col ? nb_size.data() : (const S*)nullptr,          // :577-583: PER_COL -> theta_per_col
+                                      is_nb && per_col ? nb_size.data() : (const S*)nullptr, cfg.loss_type, cfg.tweedie_power, cfg.robust_delta);
         } else {
             if (cfg.L2_H > 0) for (int i = 0; i < k; ++i) G[(size_t)i * k + i] += cfg.L2_H;   // :506
             if (cfg.has_graph_H) apply_graph_reg(G.data(), cfg.graph_H, H, k, cfg.graph_H_lambda);      // :508-509
@@ -1069,7 +1168,8 @@ FitResult<S> nmf_fit(const Csc<S>& A, const FitConfig<S>& cfg, S* W_T, S* H, S* 
             // :811-852: theta_per_col = nb_size (row of A == column of A^T)
             nnls_batch_irls_sparse_nb(At, H, G.data(), W_T, k, cfg.L1_W, cfg.L2_W, cfg.nonneg_W,
                                       cfg.cd_maxit, cfg.irls_max_iter, cfg.irls_tol, cfg.threads,
-                                      (const S*)nullptr, is_nb ? nb_size.data() : (const S*)nullptr, cfg.loss_type, cfg.tweedie_power, cfg.robust_delta);
+                                      is_nb && per_col ? nb_size.data() : (const S*)nullptr,           // :820-830: PER_COL -> row of A^T
+                                      is_nb && !per_col ? nb_size.data() : (const S*)nullptr, cfg.loss_type, cfg.tweedie_power, cfg.robust_delta);
         } else {
             if (cfg.L2_W > 0) for (int i = 0; i < k; ++i) G[(size_t)i * k + i] += cfg.L2_W;   // :738
             if (cfg.has_graph_W) apply_graph_reg(G.data(), cfg.graph_W, W_T, k, cfg.graph_W_lambda);    // :740-741
@@ -1106,8 +1206,8 @@ FitResult<S> nmf_fit(const Csc<S>& A, const FitConfig<S>& cfg, S* W_T, S* H, S* 
         if (cfg.has_mask || irls) {
             std::vector<S> Wd((size_t)k * m);
             for (int i = 0; i < m; ++i) for (int f = 0; f < k; ++f) Wd[(size_t)i * k + f] = W_T[(size_t)i * k + f] * d[f];
-            loss_val = cfg.has_mask ? masked_loss(A, Wd.data(), H, cfg.mask, k, threads)
-                                    : explicit_loss_sparse_nb(A, Wd.data(), H, k, nb_size.data(), cfg.threads > 0 ? cfg.threads : 1, cfg.loss_type, cfg.tweedie_power, cfg.robust_delta);
+            loss_val = cfg.has_mask ? masked_loss(A, Wd.data(), H, cfg.mask, k, threads, cfg.loss_type, cfg.tweedie_power)
+                                    : explicit_loss_sparse_nb(A, Wd.data(), H, k, nb_size.data(), cfg.threads > 0 ? cfg.threads : 1, cfg.loss_type, cfg.tweedie_power, cfg.robust_delta, per_col);
         } else {
             gram(W_T, k, m, G_wt.data());                                                   // :1734-1735
             S cross;
@@ -1294,9 +1394,10 @@ ORACLE_API float oracle_loss_gp_f32(float y, float p, float th) { return loss_co
                                                 const S* W_T, const S* H, const S* d, int k, int dispersion_mode, \
                                                 S r_min, S r_max, S* nb_size) {                                   \
         FitConfig<S> c; c.k = k; c.dispersion_mode = dispersion_mode; c.nb_size_min = r_min; c.nb_size_max = r_max; \
-        std::vector<S> v(nb_size, nb_size + m);                                                                   \
+        const size_t len = dispersion_mode == 3 ? (size_t)n : (size_t)m;   /* PER_COL: n values */                \
+        std::vector<S> v(nb_size, nb_size + len);                                                                 \
         nb_size_update(mk(m, n, p, i, x), W_T, H, d, k, c, v);                                                    \
-        std::memcpy(nb_size, v.data(), sizeof(S) * m);                                                            \
+        std::memcpy(nb_size, v.data(), sizeof(S) * len);                                                          \
     }                                                                                                             \
     /* loss_type 4: GP theta (hi = cap); 6 / 7 / 8: Pearson phi in [lo, hi]; mode 1 = GLOBAL, 2 = PER_ROW */       \
     ORACLE_API void oracle_dispersion_update_##SUF(int loss_type, int m, int n, const int* p, const int* i,       \
@@ -1304,10 +1405,11 @@ ORACLE_API float oracle_loss_gp_f32(float y, float p, float th) { return loss_co
                                                    int dispersion_mode, S power, S lo, S hi, S* theta) {          \
         FitConfig<S> c; c.k = k; c.dispersion_mode = dispersion_mode; c.loss_type = loss_type;                    \
         c.tweedie_power = power; c.gp_theta_max = hi; c.gamma_phi_min = lo; c.gamma_phi_max = hi;                 \
-        std::vector<S> v(theta, theta + m);                                                                       \
+        const size_t len = dispersion_mode == 3 ? (size_t)n : (size_t)m;   /* PER_COL: n values */                \
+        std::vector<S> v(theta, theta + len);                                                                     \
         if (loss_type == 4) gp_theta_update(mk(m, n, p, i, x), W_T, H, d, k, c, v);                               \
         else phi_update(mk(m, n, p, i, x), W_T, H, d, k, c, v);                                                   \
-        std::memcpy(theta, v.data(), sizeof(S) * m);                                                              \
+        std::memcpy(theta, v.data(), sizeof(S) * len);                                                            \
     }                                                                                                             \
     ORACLE_API S oracle_nb_loss_##SUF(int m, int n, const int* p, const int* i, const S* x, const S* W_T,         \
                                       const S* d, const S* H, int k, const S* theta_row) {                        \

@@ -320,7 +320,7 @@ def nmf_fit(A, W_T, H, dtype=np.float64, max_iter=100, tol=1e-4, L1=(0.0, 0.0), 
     d = np.ones(k, dtype)
     x = A.values(dtype)
     hist = np.full(max(max_iter, 1), np.nan, dtype)
-    theta = np.zeros(m, dtype)
+    theta = np.zeros(n if dispersion_mode == 3 else m, dtype)          # DispersionMode::PER_COL: one value per column
     it, conv = C.c_int(0), C.c_int(0)
     loss, ftol = ct(0), ct(0)
     if mask is not None:

@@ -24,7 +24,7 @@ EXPORTED_SYMBOLS = [
     "rcppml_gpu_nnls_double", "rcppml_gpu_evaluate_mse_double", "rcppml_gpu_last_error",
     "rcppml_hip_ctx_create", "rcppml_hip_ctx_destroy", "rcppml_hip_ctx_sync", "rcppml_hip_ctx_stats", "rcppml_hip_ctx_irls_stats", "rcppml_hip_ctx_cd_step_stats", "rcppml_hip_ctx_set_option", "rcppml_hip_transpose_csc", "rcppml_hip_transpose_csc_sort", "rcppml_hip_transpose_csc_gather", "rcppml_hip_cast", "rcppml_hip_gram", "rcppml_hip_rhs",
     "rcppml_hip_solve_cd", "rcppml_hip_order_columns", "rcppml_hip_solve_chol", "rcppml_hip_row_norms", "rcppml_hip_apply_scaling",
-    "rcppml_hip_sumsq", "rcppml_hip_loss_mse", "rcppml_hip_solve_masked", "rcppml_hip_loss_nonzeros",
+    "rcppml_hip_sumsq", "rcppml_hip_loss_mse", "rcppml_hip_solve_masked", "rcppml_hip_loss_nonzeros", "rcppml_hip_loss_masked",
     "rcppml_hip_solve_irls_nb", "rcppml_hip_nb_size_update", "rcppml_hip_nb_size_update_loss", "rcppml_hip_nb_loss", "rcppml_hip_solve_irls", "rcppml_hip_irls_loss", "rcppml_hip_apply_l21", "rcppml_hip_angular_posthoc", "rcppml_hip_solve_cv", "rcppml_hip_cv_test_error", "rcppml_hip_solve_cv_irls", "rcppml_hip_cv_irls_loss", "rcppml_hip_cv_gp_theta_update", "rcppml_hip_mul_rows", "rcppml_hip_apply_graph_reg", "rcppml_hip_dispersion_update", "rcppml_hip_vec_global", "rcppml_hip_spz_info", "rcppml_hip_spz_decode",
     "rcppml_sp_read_gpu", "rcppml_sp_free_gpu", "rcppml_hip_rhs_dense", "rcppml_gpu_nmf_dense_unified_float",
     "rcppml_gpu_nmf_dense_unified_double",
@@ -78,7 +78,7 @@ def lib():
         for name in ("rcppml_hip_ctx_create", "rcppml_hip_ctx_sync", "rcppml_hip_ctx_stats", "rcppml_hip_ctx_set_option", "rcppml_hip_transpose_csc", "rcppml_hip_cast", "rcppml_hip_gram", "rcppml_hip_rhs",
                      "rcppml_hip_solve_cd", "rcppml_hip_order_columns", "rcppml_hip_solve_chol", "rcppml_hip_row_norms",
                      "rcppml_hip_apply_scaling",
-                     "rcppml_hip_sumsq", "rcppml_hip_loss_mse", "rcppml_hip_solve_masked", "rcppml_hip_loss_nonzeros",
+                     "rcppml_hip_sumsq", "rcppml_hip_loss_mse", "rcppml_hip_solve_masked", "rcppml_hip_loss_nonzeros", "rcppml_hip_loss_masked",
                      "rcppml_hip_solve_irls_nb", "rcppml_hip_nb_size_update", "rcppml_hip_nb_loss"):
             getattr(_lib, name).restype = C.c_int
         _lib.rcppml_hip_ctx_destroy.restype = None
@@ -148,7 +148,9 @@ def nmf_unified(p, i, x, m, n, k, W_T, H, *, entry="float", max_iter=100, tol=1e
     d = np.ones(k, np.float64)
     dummy_i = np.zeros(2, np.int32)
     dummy_d = np.zeros(2, np.float64)
-    theta = np.zeros(max(m, 1), np.float64)
+    # out_theta: m doubles in the reference bridge (gpu/bridge_nmf.hpp:284); the build-defined "ex" entries take max(m, n) so that
+    # dispersion = "per_col" (gp_dispersion_mode 3) can return its n values
+    theta = np.zeros(max(m, n, 1) if entry == "ex" else max(m, 1), np.float64)
     out_iter, out_conv, out_status, out_theta_len = C.c_int(0), C.c_int(0), C.c_int(-99), C.c_int(0)
     out_loss, out_tol = C.c_double(0), C.c_double(0)
     args = [
@@ -466,6 +468,11 @@ class Context:
                                            _dptr(X), C.c_int(k), C.c_double(l1), C.c_double(l2), C.c_int(nonneg),
                                            C.c_int(cd_maxit), C.c_double(cd_tol), C.c_int(solver_mode), C.c_int(warm)),
              "solve_masked")
+
+    def loss_masked(self, dt, loss_type, col_ptr, row_idx, values, mask_p, mask_i, ncols, W_T, d, H, k, out, power=1.5):
+        _chk(lib().rcppml_hip_loss_masked(self._h, C.c_int(dt), C.c_int(loss_type), C.c_double(power), _dptr(col_ptr), _dptr(row_idx),
+                                          _dptr(values), _dptr(mask_p), _dptr(mask_i), C.c_int64(ncols), _dptr(W_T), _dptr(d),
+                                          _dptr(H), C.c_int(k), _dptr(out)), "loss_masked")
 
     def loss_nonzeros(self, dt, col_ptr, row_idx, values, mask_p, mask_i, ncols, W_T, d, H, k, out):
         _chk(lib().rcppml_hip_loss_nonzeros(self._h, C.c_int(dt), _dptr(col_ptr), _dptr(row_idx), _dptr(values),

@@ -2277,14 +2277,47 @@ __global__ __launch_bounds__(256) void masked_solve_kernel(
     if (fok) X[j * (int64_t)k + lane] = x;
 }
 
+// Per-element loss term of the distribution losses (math/loss.hpp:512-536 compute_loss): GP (4) :382-398, NB (5) :415-426,
+// Gamma (6) / inverse Gaussian (7) / Tweedie (8) deviance terms :439-505.  y, mu (>= 1e-10 already) and theta in double; the
+// caller casts the term to Scalar as the reference does.
+__device__ __forceinline__ double dist_loss_term(int loss_type, double y, double mu, double th, double power) {
+    if (loss_type == 4) {
+        const double opt = 1.0 + th;
+        double nll = -log(mu / opt);
+        if (y >= 1.0) {
+            double inner = (mu + th * y) / opt;
+            inner = inner > 1e-10 ? inner : 1e-10;
+            nll -= (y - 1.0) * log(inner);
+        }
+        return nll + (mu + th * y) / opt;
+    }
+    if (loss_type >= 6) {
+        const double yy = y > 1e-10 ? y : 1e-10;
+        const double pp = loss_type == 6 ? 2.0 : (loss_type == 7 ? 3.0 : power);
+        if (loss_type == 7) {
+            const double df = yy - mu;
+            return df * df / (mu * mu * yy);
+        }
+        if (fabs(pp - 1.0) < 1e-6) return 2.0 * (yy * log(yy / mu) - (yy - mu));
+        if (fabs(pp - 2.0) < 1e-6) return 2.0 * (-log(yy / mu) + (yy - mu) / mu);
+        const double omp = 1.0 - pp, tmp = 2.0 - pp;
+        return 2.0 * (pow(yy, tmp) / (omp * tmp) - yy * pow(mu, omp) / omp + pow(mu, tmp) / tmp);
+    }
+    const double r = th > 1e-10 ? th : 1e-10;
+    return -lgamma(y + r) + lgamma(r) - r * log(r / (r + mu)) - y * log(mu / (r + mu));
+}
+
 // Loss over (unmasked) nonzeros, fp64 accumulation, one wavefront per column
 // (reference nmf/masked_nnls.hpp:250-282; also the nonzero pass of evaluate()):
 //   partial[2b]   = sum (a - p)^2,  partial[2b+1] = sum p^2,   p = sum_f d_f W_T(f,i) H(f,j)
+// loss_type != 0 (a fit with an explicit mask AND a distribution loss): partial[2b] = sum compute_loss(a, p, loss) with the
+// reference's default theta = 0 (masked_nnls.hpp:277 passes no dispersion and applies no robust modifier), each term cast
+// to Scalar as there.
 template <class T>
 __global__ __launch_bounds__(256) void loss_nonzeros_kernel(
     const int* __restrict__ colptr, const int* __restrict__ rowidx, const T* __restrict__ vals,
     const int* __restrict__ mask_p, const int* __restrict__ mask_i, int64_t ncols,
-    const T* __restrict__ W_T, const T* __restrict__ d, const T* __restrict__ H, int k,
+    const T* __restrict__ W_T, const T* __restrict__ d, const T* __restrict__ H, int k, int loss_type, double power,
     double* __restrict__ partial) {
     __shared__ double sh[8];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -2303,8 +2336,13 @@ __global__ __launch_bounds__(256) void loss_nonzeros_kernel(
             double pd = static_cast<double>(p);
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) pd += __shfl_xor(pd, off, 64);
-            const double df = static_cast<double>(vals[t]) - pd;
-            acc += df * df;   // identical in all lanes
+            if (loss_type == 0) {
+                const double df = static_cast<double>(vals[t]) - pd;
+                acc += df * df;   // identical in all lanes
+            } else {
+                const double mu = static_cast<double>(static_cast<T>(pd));          // the prediction in Scalar, as the reference forms it
+                acc += static_cast<double>(static_cast<T>(dist_loss_term(loss_type, static_cast<double>(vals[t]), mu > 1e-10 ? mu : 1e-10, 0.0, power)));
+            }
             acc2 += pd * pd;
         }
     }

@@ -253,7 +253,6 @@ __global__ __launch_bounds__(64 * NW) void rhs_win_kernel(const char* __restrict
     constexpr int NPF = CBASE + (CEXTRA > 0 ? 1 : 0);
     constexpr int SBL = RwBlk<T, NR, CLO>::bytes, SBH = RwBlk<T, NR, CHI>::bytes;     // bytes of a "lo" / "hi" slot block
     constexpr int NSD = (SBH + 1023) / 1024;    // LDS-DMA instructions per slot block
-    constexpr int NPT = NPF + NSD;
     constexpr int GSTRIDE = NW * (4 * SBL + NHI * (SBH - SBL));      // slot bytes of a group of four phases (all waves)
     extern __shared__ char rt_slab[];           // ring of F tiles + the two-stage slot ring
     const int lane = threadIdx.x & 63;

@@ -269,11 +269,12 @@ extern "C" int rcppml_hip_solve_masked(rcppml_hip_ctx* c, int dtype, const int* 
 }
 template <class T>
 static void loss_nonzeros_impl(rcppml_hip_ctx* c, const int* cp, const int* ri, const T* vals, const int* mp,
-                               const int* mi, int64_t ncols, const T* W_T, const T* d, const T* H, int k, double* out) {
+                               const int* mi, int64_t ncols, const T* W_T, const T* d, const T* H, int k, double* out,
+                               int loss_type = 0, double power = 1.5) {
     const int64_t nblk = ncols > 0 ? (ncols + 3) / 4 : 1;
     double* partial = static_cast<double*>(c->scratch(WS_RED2, (size_t)nblk * 2 * sizeof(double)));
     hipLaunchKernelGGL(loss_nonzeros_kernel<T>, dim3((unsigned)nblk), dim3(256), 0, c->stream, cp, ri, vals, mp, mi,
-                       ncols, W_T, d, H, k, partial);
+                       ncols, W_T, d, H, k, loss_type, power, partial);
     HIPCHK(hipGetLastError());
     hipLaunchKernelGGL(sum_partials2, dim3(1), dim3(256), 0, c->stream, partial, (int)nblk, out);
     HIPCHK(hipGetLastError());
@@ -289,6 +290,25 @@ extern "C" int rcppml_hip_loss_nonzeros(rcppml_hip_ctx* c, int dtype, const int*
         else
             loss_nonzeros_impl<double>(c, col_ptr, row_idx, (const double*)values, mask_p, mask_i, ncols,
                                        (const double*)W_T, (const double*)d, (const double*)H, k, out);
+        return 0;
+    }
+    RCPPML_CATCH_RET
+}
+
+// The same pass with the per-element term of a distribution loss (math/loss.hpp:512-536, theta = 0): the loss of a fit with an
+// explicit mask under GP / NB / Gamma / inverse-Gaussian / Tweedie (nmf/masked_nnls.hpp:250-282, fit_cpu.hpp:1685-1690).
+extern "C" int rcppml_hip_loss_masked(rcppml_hip_ctx* c, int dtype, int loss_type, double tweedie_power, const int* col_ptr,
+                                      const int* row_idx, const void* values, const int* mask_p, const int* mask_i, int64_t ncols,
+                                      const void* W_T, const void* d, const void* H, int k, double* out) {
+    try {
+        HIPCHK(hipSetDevice(c->device));
+        if (loss_type != 0 && (loss_type < 4 || loss_type > 8)) throw std::runtime_error("loss_masked: loss_type must be 0 or 4..8");
+        if (dtype == RCPPML_F32)
+            loss_nonzeros_impl<float>(c, col_ptr, row_idx, (const float*)values, mask_p, mask_i, ncols, (const float*)W_T,
+                                      (const float*)d, (const float*)H, k, out, loss_type, tweedie_power);
+        else
+            loss_nonzeros_impl<double>(c, col_ptr, row_idx, (const double*)values, mask_p, mask_i, ncols,
+                                       (const double*)W_T, (const double*)d, (const double*)H, k, out, loss_type, tweedie_power);
         return 0;
     }
     RCPPML_CATCH_RET

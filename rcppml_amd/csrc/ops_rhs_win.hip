@@ -1,6 +1,7 @@
 // ops_rhs_win.hip -- planner and finishing kernels of the window form of the sparse right-hand side, both precisions
 // (rhs_win_impl.hip.h); the tile-loop kernels are instantiated in ops_rhs_win_{f32,f64}_nv*.hip.
 #include "rhs_win_impl.hip.h"
+#include "rhs_win_finish.hip.h"
 
 rcppml_rhs_plan* rcppml_rw_build_f32(rcppml_hip_ctx* c, const int* colptr, const int* rowidx, const float* vals, int64_t ncols,
                                      int64_t nrows, int k, int partitions, int rate_code) {

@@ -229,15 +229,20 @@ void fit(FitParams& P) {
     const bool is_pow = P.loss_type >= 6;                               // phi_vec = 1 for dispersion none (fit_cpu.hpp:336-347)
     const bool is_gp = P.loss_type == 4 || is_pow || P.loss_type == 0;  // theta_vec = Zero(m) (:297-304); "no theta in the solve"
     const bool is_nb = P.loss_type == 5 || (is_gp && (P.loss_type != 0 || P.robust_delta > 0));   // "is_irls": requires_irls()
+    // dispersion = "per_col" (DispersionMode::PER_COL, fit_cpu.hpp:300-301, :319-320, :341-342): one value per COLUMN of A.  Every
+    // device op below is written per row of the matrix whose CSC(transpose) it is handed; PER_COL hands it CSC(A) itself with the
+    // two factors swapped (mu_ij = (h_j * d) . w_i, the same product with d applied to the other factor)
+    const bool per_col = P.dispersion_mode == 3;
+    const size_t dlen = per_col ? (size_t)n : (size_t)m;
     DevBuf dtheta;
     if (is_nb) {                                                        // fit_cpu.hpp:316-328
         // GP theta: gp_theta_init or 0 (:297-307); phi: gamma_phi_init or 1 (:337-347); robust MSE: unused
         const double t0 = is_pow ? (P.dispersion_mode == 0 ? 1.0 : P.gamma_phi_init)
                         : P.loss_type == 4 ? (P.dispersion_mode == 0 ? 0.0 : P.gp_theta_init)
                         : is_gp ? 0.0 : (P.dispersion_mode == 0 ? P.nb_size_max : P.nb_size_init);
-        std::vector<T> th((size_t)m, static_cast<T>(t0));
-        dtheta.alloc((size_t)m * sizeof(T));
-        HIPCHK(hipMemcpyAsync(dtheta.p, th.data(), (size_t)m * sizeof(T), hipMemcpyHostToDevice, s));
+        std::vector<T> th(dlen, static_cast<T>(t0));
+        dtheta.alloc(dlen * sizeof(T));
+        HIPCHK(hipMemcpyAsync(dtheta.p, th.data(), dlen * sizeof(T), hipMemcpyHostToDevice, s));
         HIPCHK(hipStreamSynchronize(s));
     }
     const double eps = 1e-15;
@@ -315,17 +320,19 @@ void fit(FitParams& P) {
         } else if (P.projective) {                                                             // :462-472
             OPCHK(rcppml_hip_mul_rows(c, dt, dW.p, k, m, dd.p, dWd.p));
             rhs_fwd(dWd.p, dH.p);
-        } else if (is_nb) {                                                                    // :565-606 (G: eps only)
-            OPCHK(rcppml_hip_gram(c, dt, dW.p, k, m, eps, 0.0, dG.p));
-            OPCHK(rcppml_hip_solve_irls(c, dt, P.loss_type, dAp.as<int>(), dAi.as<int>(), dAx.p, n, dW.p, dG.p, dH.p, k, P.L1_H,
-                                        P.L2_H, P.nonneg_H, P.cd_maxit, P.irls_max_iter, P.irls_tol,
-                                        is_gp ? nullptr : dtheta.p, nullptr, P.tweedie_power, P.robust_delta));
-            if (P.ub_H > 0) OPCHK(rcppml_hip_clip_upper(c, dt, dH.p, (int64_t)k * n, P.ub_H));      // :636-637
-        } else if (has_mask) {
+        } else if (has_mask) {                                                                 // :560-564: the mask branch comes FIRST -- with a mask the
+            // half-updates are the masked MSE solves whatever the loss (requires_irls() is only asked in the else-branch)
             OPCHK(rcppml_hip_gram(c, dt, dW.p, k, m, eps, 0.0, dG.p));                 // :562 unmodified G
             OPCHK(rcppml_hip_solve_masked(c, dt, dAp.as<int>(), dAi.as<int>(), dAx.p, dMp.as<int>(), dMi.as<int>(),
                                           n, dW.p, dG.p, dH.p, k, P.L1_H, P.L2_H, P.nonneg_H, P.cd_maxit, P.cd_tol,
                                           P.solver_mode, warm));
+            if (P.ub_H > 0) OPCHK(rcppml_hip_clip_upper(c, dt, dH.p, (int64_t)k * n, P.ub_H));      // :636-637
+        } else if (is_nb) {                                                                    // :565-606 (G: eps only)
+            OPCHK(rcppml_hip_gram(c, dt, dW.p, k, m, eps, 0.0, dG.p));
+            OPCHK(rcppml_hip_solve_irls(c, dt, P.loss_type, dAp.as<int>(), dAi.as<int>(), dAx.p, n, dW.p, dG.p, dH.p, k, P.L1_H,
+                                        P.L2_H, P.nonneg_H, P.cd_maxit, P.irls_max_iter, P.irls_tol,
+                                        (is_gp || per_col) ? nullptr : dtheta.p, (!is_gp && per_col) ? dtheta.p : nullptr,   // :577-583
+                                        P.tweedie_power, P.robust_delta));
             if (P.ub_H > 0) OPCHK(rcppml_hip_clip_upper(c, dt, dH.p, (int64_t)k * n, P.ub_H));      // :636-637
         } else {
             // W_T^T W_T + eps I is what the previous iteration's loss formed from this very W_T (dGwt: same kernel, same
@@ -368,17 +375,18 @@ void fit(FitParams& P) {
                                           P.nonneg_W, P.cd_maxit, P.cd_tol, 0.0, P.ub_W, RCPPML_CD_AUTO, nullptr, nullptr));   // :684-692
             else
                 OPCHK(rcppml_hip_solve_chol(c, dt, dG.p, dBw.p, dW.p, k, m, P.L1_W > 0 ? P.L1_W : 0.0, P.nonneg_W, P.ub_W));   // :679-683
-        } else if (is_nb) {                                                             // :811-852 theta_per_col = r of the row
-            OPCHK(rcppml_hip_gram(c, dt, dH.p, k, n, eps, 0.0, dG.p));
-            OPCHK(rcppml_hip_solve_irls(c, dt, P.loss_type, dTp.as<int>(), dTi.as<int>(), dTx.p, m, dH.p, dG.p, dW.p, k, P.L1_W,
-                                        P.L2_W, P.nonneg_W, P.cd_maxit, P.irls_max_iter, P.irls_tol, nullptr,
-                                        is_gp ? nullptr : dtheta.p, P.tweedie_power, P.robust_delta));
-            if (P.ub_W > 0) OPCHK(rcppml_hip_clip_upper(c, dt, dW.p, (int64_t)k * m, P.ub_W));      // :884-885
-        } else if (has_mask) {
+        } else if (has_mask) {                                                          // :799-803 (mask before requires_irls())
             OPCHK(rcppml_hip_gram(c, dt, dH.p, k, n, eps, 0.0, dG.p));
             OPCHK(rcppml_hip_solve_masked(c, dt, dTp.as<int>(), dTi.as<int>(), dTx.p, dMTp.as<int>(), dMTi.as<int>(),
                                           m, dH.p, dG.p, dW.p, k, P.L1_W, P.L2_W, P.nonneg_W, P.cd_maxit, P.cd_tol,
                                           P.solver_mode, warm));
+            if (P.ub_W > 0) OPCHK(rcppml_hip_clip_upper(c, dt, dW.p, (int64_t)k * m, P.ub_W));      // :884-885
+        } else if (is_nb) {                                                             // :811-852 theta_per_col = r of the row
+            OPCHK(rcppml_hip_gram(c, dt, dH.p, k, n, eps, 0.0, dG.p));
+            OPCHK(rcppml_hip_solve_irls(c, dt, P.loss_type, dTp.as<int>(), dTi.as<int>(), dTx.p, m, dH.p, dG.p, dW.p, k, P.L1_W,
+                                        P.L2_W, P.nonneg_W, P.cd_maxit, P.irls_max_iter, P.irls_tol,
+                                        (!is_gp && per_col) ? dtheta.p : nullptr,            // :820-830 PER_COL: the ROW of A^T
+                                        (is_gp || per_col) ? nullptr : dtheta.p, P.tweedie_power, P.robust_delta));
             if (P.ub_W > 0) OPCHK(rcppml_hip_clip_upper(c, dt, dW.p, (int64_t)k * m, P.ub_W));      // :884-885
         } else {
             OPCHK(rcppml_hip_gram(c, dt, dH.p, k, n, eps, 0.0, dGs.p));                 // :715-722 G_w_saved
@@ -408,27 +416,39 @@ void fit(FitParams& P) {
 
         // ================= NB size update (fit_cpu.hpp:1094-1265), then loss (fit_cpu.hpp:1684-1753)
         // (PER_ROW sizes without the robust modifier: both in one pass over A^T, the predictions of the size update reused by the loss)
-        const bool nb_fused = P.loss_type == 5 && P.dispersion_mode == 2 && !(P.robust_delta > 0);
+        const bool nb_fused = P.loss_type == 5 && P.dispersion_mode == 2 && !(P.robust_delta > 0) && !has_mask;
         if (nb_fused) {
             OPCHK(rcppml_hip_nb_size_update_loss(c, dt, dTp.as<int>(), dTi.as<int>(), dTx.p, m, P.nnz, dW.p, dd.p, dH.p, n, k,
                                                  P.nb_size_min, P.nb_size_max, dtheta.p, dloss.as<double>()));
+        } else if (is_nb && !is_gp && per_col) {                                    // :1103-1162
+            OPCHK(rcppml_hip_nb_size_update(c, dt, dAp.as<int>(), dAi.as<int>(), dAx.p, n, dH.p, dd.p, dW.p, m, k,
+                                            P.nb_size_min, P.nb_size_max, dtheta.p));
         } else if (is_nb && !is_gp && P.dispersion_mode != 0) {
             OPCHK(rcppml_hip_nb_size_update(c, dt, dTp.as<int>(), dTi.as<int>(), dTx.p, m, dW.p, dd.p, dH.p, n, k,
                                             P.nb_size_min, P.nb_size_max, dtheta.p));
             if (P.dispersion_mode == 1) OPCHK(rcppml_hip_vec_global(c, dt, 1, dtheta.p, m));   // GLOBAL: median (nth_element at m/2), :1257-1262
         }
         // GP theta (fit_cpu.hpp:914-1008) / Gamma, inverse-Gaussian, Tweedie phi (:1561-1670), PER_ROW or GLOBAL
-        if ((P.loss_type == 4 || is_pow) && P.dispersion_mode != 0)
+        if ((P.loss_type == 4 || is_pow) && per_col)                                 // :1009-1083, :1570-1611
+            OPCHK(rcppml_hip_dispersion_update(c, dt, P.loss_type, 2, dAp.as<int>(), dAi.as<int>(), dAx.p, n, P.nnz,
+                                               dH.p, dd.p, dW.p, m, k, P.tweedie_power, P.gamma_phi_min,
+                                               P.loss_type == 4 ? P.gp_theta_max : P.gamma_phi_max, dtheta.p));
+        else if ((P.loss_type == 4 || is_pow) && P.dispersion_mode != 0)
             OPCHK(rcppml_hip_dispersion_update(c, dt, P.loss_type, P.dispersion_mode, dTp.as<int>(), dTi.as<int>(), dTx.p, m, P.nnz,
                                                dW.p, dd.p, dH.p, n, k, P.tweedie_power, P.gamma_phi_min,
                                                P.loss_type == 4 ? P.gp_theta_max : P.gamma_phi_max, dtheta.p));
         if (nb_fused) {
             // loss already in dloss
+        } else if (has_mask) {
+            // :1685-1690 masked_loss comes before the explicit loss of a distribution: compute_loss(a, pred, config.loss) per
+            // unmasked nonzero with its default theta = 0 and no robust modifier (masked_nnls.hpp:277) -- the fitted dispersion
+            // is updated above and returned, but does not enter this number
+            OPCHK(rcppml_hip_loss_masked(c, dt, P.loss_type, P.tweedie_power, dAp.as<int>(), dAi.as<int>(), dAx.p, dMp.as<int>(), dMi.as<int>(), n,
+                                         dW.p, dd.p, dH.p, k, dloss.as<double>()));
+        } else if (is_nb && per_col) {      // explicit_loss.hpp:59-71 theta_is_per_col: over CSC(A^T), whose nonzeros' "row" is the column j of A
+            OPCHK(rcppml_hip_irls_loss(c, dt, P.loss_type, dTp.as<int>(), dTi.as<int>(), dTx.p, m, dH.p, dd.p, dW.p, dtheta.p, k, P.tweedie_power, P.robust_delta, dloss.as<double>()));
         } else if (is_nb) {
             OPCHK(rcppml_hip_irls_loss(c, dt, P.loss_type, dAp.as<int>(), dAi.as<int>(), dAx.p, n, dW.p, dd.p, dH.p, dtheta.p, k, P.tweedie_power, P.robust_delta, dloss.as<double>()));
-        } else if (has_mask) {
-            OPCHK(rcppml_hip_loss_nonzeros(c, dt, dAp.as<int>(), dAi.as<int>(), dAx.p, dMp.as<int>(), dMi.as<int>(), n,
-                                           dW.p, dd.p, dH.p, k, dloss.as<double>()));
         } else {
             OPCHK(rcppml_hip_gram(c, dt, dW.p, k, m, eps, 0.0, dGwt.p));                // :1734-1735
             // B_w (raw RHS of the W update) is exactly the h_at of loss_cross_term_sparse_via_At
@@ -498,8 +518,8 @@ void fit(FitParams& P) {
 
     if (is_nb && P.out_theta) {
         DevBuf& th = dtheta;
-        download_cast<T>(c, th, (size_t)m, P.out_theta, s);
-        P.out_theta_len = m;
+        download_cast<T>(c, th, dlen, P.out_theta, s);
+        P.out_theta_len = (int)dlen;
     }
     phase("iterations", s);
     // ---- sort by descending d (core/result.hpp:169-188) on the device, download
@@ -530,7 +550,7 @@ void fit(FitParams& P) {
 // Shared body of the three NMF entry points
 void nmf_entry(RCPPML_NMF_UNIFIED_ARGS, const int* mask_p, const int* mask_i, double cd_tol, int sort_model,
                int precision, double* loss_history, const double* target_H = nullptr, double target_lambda_H = 0,
-               const double* target_W = nullptr, double target_lambda_W = 0) {
+               const double* target_W = nullptr, double target_lambda_W = 0, bool theta_holds_n = false) {
     try {
         rcppml_err().clear();
         *out_status = -1;
@@ -544,22 +564,19 @@ void nmf_entry(RCPPML_NMF_UNIFIED_ARGS, const int* mask_p, const int* mask_i, do
         if (*loss_type == 4 || *loss_type >= 6) {
             // GP with theta = 0 (Poisson / KL NMF) and the power-variance family with phi = 1: IRLS half-updates with
             // parameter-free weights; theta / phi (dispersion global or per row) only enter the GP likelihood and the output
-            if (*gp_dispersion_mode == 3) throw std::runtime_error("GP / Gamma / inverse-Gaussian / Tweedie loss: dispersion='per_col' not supported");
+            if (*gp_dispersion_mode == 3 && !theta_holds_n) throw std::runtime_error("dispersion='per_col' returns n values: the bridge's out_theta holds m (gpu/bridge_nmf.hpp:284); use rcppml_gpu_nmf_ex");
             if (*gp_dispersion_mode < 0 || *gp_dispersion_mode > 3) throw std::runtime_error("bad dispersion mode");
             if (*k > 128) throw std::runtime_error("IRLS losses: k must be <= 128");
             if (*solver_mode != 0) throw std::runtime_error("IRLS losses require the CD solver");
-            if (mask_p) throw std::runtime_error("IRLS losses with explicit mask: not supported");
         }
         if (*loss_type == 5) {
             if (*k > 128) throw std::runtime_error("NB loss: k must be <= 128");
-            if (*gp_dispersion_mode == 3) throw std::runtime_error("NB loss: dispersion='per_col' not supported");
+            if (*gp_dispersion_mode == 3 && !theta_holds_n) throw std::runtime_error("dispersion='per_col' returns n values: the bridge's out_theta holds m (gpu/bridge_nmf.hpp:284); use rcppml_gpu_nmf_ex");
             if (*solver_mode != 0) throw std::runtime_error("NB loss requires the CD solver");      // core/config.hpp:447-452
-            if (mask_p) throw std::runtime_error("NB loss with explicit mask: not supported");
         }
         if (*robust_delta > 0) {   // Huber on Pearson residuals: every loss (MSE included) goes through the IRLS path
             if (*k > 128) throw std::runtime_error("robust loss: k must be <= 128");
             if (*solver_mode != 0) throw std::runtime_error("robust loss requires the CD solver");
-            if (mask_p) throw std::runtime_error("robust loss with explicit mask: not supported");
             if (*L21_H != 0 || *L21_W != 0 || *ortho_H != 0 || *ortho_W != 0) throw std::runtime_error("robust loss with L21 / angular: not supported");
         }
         if ((*L21_H != 0 || *L21_W != 0 || *ortho_H != 0 || *ortho_W != 0) && (*loss_type != 0 || mask_p))
@@ -991,9 +1008,16 @@ extern "C" void rcppml_gpu_nmf_zerocopy_double(double* d_col_ptr_addr, double* d
     try {
         rcppml_err().clear();
         *out_status = -1;
-        (void)seed; (void)loss_every; (void)huber_delta; (void)irls_max_iter; (void)irls_tol;
+        (void)seed; (void)loss_every; (void)huber_delta;
         auto to_ptr = [](double addr) { return reinterpret_cast<void*>(static_cast<uintptr_t>(addr)); };
-        if (*loss_type != 0) throw std::runtime_error("zero-copy entry: only the MSE loss is implemented");
+        // the entry carries loss_type, irls_max_iter and irls_tol and nothing else of the IRLS configuration: the reference builds
+        // its NMFConfig from them and leaves the rest at the defaults (src/gpu_bridge_nmf.cu:908-934: dispersion PER_ROW,
+        // core/config.hpp:166-207) -- the same fit as the unified entry called with those defaults; theta is not returned
+        if (*loss_type != 0 && (*loss_type < 4 || *loss_type > 8))
+            throw std::runtime_error("loss_type must be MSE (0), GP (4), NB (5), Gamma (6), inverse Gaussian (7) or Tweedie (8) for this plugin build");
+        if (*loss_type != 0 && *k > 128) throw std::runtime_error("IRLS losses: k must be <= 128");
+        if (*loss_type != 0 && (*L21_H != 0 || *L21_W != 0 || *ortho_H != 0 || *ortho_W != 0))
+            throw std::runtime_error("L21 / angular penalties are implemented for the MSE path");
         if (*k < 1 || *k > 256) throw std::runtime_error("k must be in [1,256]");
         if ((*ortho_H != 0 || *ortho_W != 0) && *k > 128) throw std::runtime_error("angular penalty: k must be <= 128");
         if (*m < 1 || *n < 1) throw std::runtime_error("empty matrix");
@@ -1019,6 +1043,10 @@ extern "C" void rcppml_gpu_nmf_zerocopy_double(double* d_col_ptr_addr, double* d
         P.norm_type = *norm_type;
         P.solver_mode = 0;                                   // the entry has no solver argument: CD (config default)
         P.mask_p = nullptr; P.mask_i = nullptr; P.sort_model = env_sort(); P.loss_history = nullptr;
+        P.loss_type = *loss_type; P.irls_max_iter = *irls_max_iter; P.irls_tol = *irls_tol;
+        P.dispersion_mode = 2; P.nb_size_init = 10.0; P.nb_size_max = 1e6; P.nb_size_min = 0.01;      // core/config.hpp:166-207
+        P.gp_theta_init = 0.1; P.gp_theta_max = 5.0; P.gamma_phi_init = 1.0; P.gamma_phi_max = 1e4; P.gamma_phi_min = 1e-6;
+        P.tweedie_power = 1.5; P.robust_delta = 0.0; P.out_theta = nullptr;
         const char* e = getenv("RCPPML_GPU_PRECISION");
         if (e && !strcmp(e, "fp32")) fit<float>(P); else fit<double>(P);
         *out_iter = P.out_iter; *out_converged = P.out_converged; *out_loss = P.out_loss; *out_tol = P.out_tol;
@@ -1102,8 +1130,9 @@ extern "C" void rcppml_gpu_nmf_unified_double(RCPPML_NMF_UNIFIED_ARGS) {
 extern "C" void rcppml_gpu_nmf_ex(RCPPML_NMF_UNIFIED_ARGS, const int* mask_p, const int* mask_i, int* mask_nnz,
                                   double* cd_tol, int* sort_model, int* precision, double* loss_history) {
     const bool use_mask = mask_p && mask_nnz && *mask_nnz > 0;
+    // (build-defined contract of this entry: out_theta holds max(m, n) doubles -- dispersion = "per_col" returns n of them)
     nmf_entry(RCPPML_NMF_UNIFIED_PASS, use_mask ? mask_p : nullptr, use_mask ? mask_i : nullptr, *cd_tol, *sort_model,
-              *precision, loss_history);
+              *precision, loss_history, nullptr, 0.0, nullptr, 0.0, true);
 }
 
 extern "C" void rcppml_gpu_nmf_target(RCPPML_NMF_UNIFIED_ARGS, const int* mask_p, const int* mask_i, int* mask_nnz,
@@ -1113,7 +1142,7 @@ extern "C" void rcppml_gpu_nmf_target(RCPPML_NMF_UNIFIED_ARGS, const int* mask_p
     const bool use_mask = mask_p && mask_nnz && *mask_nnz > 0;
     nmf_entry(RCPPML_NMF_UNIFIED_PASS, use_mask ? mask_p : nullptr, use_mask ? mask_i : nullptr, *cd_tol, *sort_model,
               *precision, loss_history, target_H, target_lambda_H ? *target_lambda_H : 0.0, target_W,
-              target_lambda_W ? *target_lambda_W : 0.0);
+              target_lambda_W ? *target_lambda_W : 0.0, true);
 }
 
 // nnls()/predict() projection in fp64 (src/RcppFunctions_utils.cpp:313-366)

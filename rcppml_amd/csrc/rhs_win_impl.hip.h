@@ -130,38 +130,7 @@ void rcppml_rw_launch_f64_nv2(rcppml_hip_ctx* c, const rcppml_rhs_plan* pl, cons
 void rcppml_rw_launch_f64_nv4(rcppml_hip_ctx* c, const rcppml_rhs_plan* pl, const double* F, double* Bout);
 namespace rw_launch {
 
-template <class T>
-void run_plan(rcppml_hip_ctx* c, const rcppml_rhs_plan* pl, const T* F, T* B) {
-    const RhsWinGeom& G = pl->WG;
-    const int NV = G.rowb / 256;
-    T* Bout = G.P > 1 ? (T*)pl->Bp : B;
-    if constexpr (std::is_same<T, float>::value) {
-        if (NV == 1) rcppml_rw_launch_f32_nv1(c, pl, F, Bout);
-        else if (NV == 2) rcppml_rw_launch_f32_nv2(c, pl, F, Bout);
-        else throw std::runtime_error("rhs_planned: unsupported row size");
-    } else {
-        if (NV == 1) rcppml_rw_launch_f64_nv1(c, pl, F, Bout);
-        else if (NV == 2) rcppml_rw_launch_f64_nv2(c, pl, F, Bout);
-        else if (NV == 4) rcppml_rw_launch_f64_nv4(c, pl, F, Bout);
-        else throw std::runtime_error("rhs_planned: unsupported row size");
-    }
-    if (G.P > 1 || pl->ovnnz > 0) {
-        const unsigned grid = (unsigned)((G.ncols + 15) / 16);
-        const int64_t ncp = (int64_t)G.ncb * (4 * G.nr * G.NW);
-        const int* ovp = pl->ovnnz > 0 ? pl->ovptr : nullptr;
-        const int acc = G.P > 1 ? 0 : 1;
-        if (NV == 1)
-            hipLaunchKernelGGL((rhs_win_finish_kernel<T, 1, 4>), dim3(grid), dim3(256), 0, c->stream, (const T*)pl->Bp, G.P, ncp, acc, ovp,
-                               (const int*)pl->ovrow, (const T*)pl->ovval, G.ncols, F, pl->k, B);
-        else if (NV == 2)
-            hipLaunchKernelGGL((rhs_win_finish_kernel<T, 2, 4>), dim3(grid), dim3(256), 0, c->stream, (const T*)pl->Bp, G.P, ncp, acc, ovp,
-                               (const int*)pl->ovrow, (const T*)pl->ovval, G.ncols, F, pl->k, B);
-        else
-            hipLaunchKernelGGL((rhs_win_finish_kernel<T, 4, 2>), dim3(grid), dim3(256), 0, c->stream, (const T*)pl->Bp, G.P, ncp, acc, ovp,
-                               (const int*)pl->ovrow, (const T*)pl->ovval, G.ncols, F, pl->k, B);
-        HIPCHK(hipGetLastError());
-    }
-}
+// run_plan<T> (the launch of the tile kernel + the finishing pass): rhs_win_finish.hip.h, one translation unit
 
 // rate code: 4 * clo + nhi (slots per column and phase in quarters); 0 = choose
 template <class T>

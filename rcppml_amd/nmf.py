@@ -102,8 +102,10 @@ def nmf(data, k, tol=1e-4, maxit=100, L1=(0.0, 0.0), L2=(0.0, 0.0), seed=None, m
         raise ValueError("'robust' must be FALSE, TRUE, 'mae', or a positive numeric Huber delta.")
     if robust_delta > 0 and solver == "cholesky":
         raise ValueError("solver='cholesky' is not supported with robust IRLS (robust_delta > 0). Use solver='cd' for robust estimation.")
-    if dispersion not in ("none", "global", "per_row"):
-        raise NotImplementedError("dispersion must be 'none', 'global' or 'per_row' on the MI355X backend")
+    if dispersion not in ("none", "global", "per_row", "per_col"):
+        raise ValueError("dispersion must be 'none', 'global', 'per_row' or 'per_col'")
+    if dispersion == "per_col" and test_fraction and test_fraction > 0:
+        raise NotImplementedError("dispersion = 'per_col' under cross-validation is not implemented by the MI355X backend")
     if symmetric and (robust_delta > 0 or loss != "mse" or projective or (test_fraction and test_fraction > 0)
                       or (mask is not None and not isinstance(mask, str))):
         raise NotImplementedError("symmetric NMF is implemented for the plain MSE path")
@@ -248,7 +250,7 @@ def nmf(data, k, tol=1e-4, maxit=100, L1=(0.0, 0.0), L2=(0.0, 0.0), seed=None, m
                            norm_type=norm_type, solver_mode=0 if solver == "cd" else 1, mask=mask_arg, cd_tol=float(cd_tol),
                            loss_type={"mse": 0, "gp": 4, "nb": 5, "gamma": 6, "inverse_gaussian": 7, "tweedie": 8}[loss], projective=int(bool(projective)), symmetric=int(bool(symmetric)),
                            tweedie_power=float(tweedie_power), robust_delta=robust_delta, irls_max_iter=int(irls_max_iter), irls_tol=float(irls_tol),
-                           gp_dispersion_mode={"none": 0, "global": 1, "per_row": 2}[dispersion],
+                           gp_dispersion_mode={"none": 0, "global": 1, "per_row": 2, "per_col": 3}[dispersion],
                            nb_size=(nb_size_init, nb_size_max, nb_size_min), gp_theta=(float(theta_init), float(theta_max), float(theta_min)),
                            sort_model=int(sort_model), precision=_abi.F32 if precision == "fp32" else _abi.F64,
                            want_history=True, **graph_args, **target_args)

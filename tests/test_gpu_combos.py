@@ -1,0 +1,168 @@
+"""GPU tests of the combinations the plugin handed back until round 4 (VERDICT r4 "What's missing" 2-4), through the C ABI against
+the CPU oracle (whose restatements tests/test_oracle_combos.py checks against brute-force numpy):
+
+  * explicit mask + distribution loss (GP / NB / Gamma / inverse Gaussian / Tweedie / robust): masked MSE half-updates (the
+    reference takes the mask branch before it asks requires_irls(): nmf/fit_cpu.hpp:560-564, :799-803), dispersion updated as
+    without a mask, loss = masked_loss with compute_loss at theta = 0 (fit_cpu.hpp:1685-1690, nmf/masked_nnls.hpp:277);
+  * dispersion = "per_col" through the build-defined rcppml_gpu_nmf_ex (out_theta: n values; the bridge's buffer holds m);
+  * IRLS losses through the zero-copy entry (device-resident CSC), configuration defaults of src/gpu_bridge_nmf.cu:908-934."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests.util import random_csc
+
+pytestmark = pytest.mark.gpu
+
+
+def _counts(m, n, k, seed):
+    from rcppml_amd import data
+    A, _, _ = data.simulate_nb_counts(m, n, k, density=0.15, size=5.0, seed=seed)
+    return O.Csc(A.shape, A.p, A.i, A.x)
+
+
+def _positive(m, n, seed):
+    A = _counts(m, n, 3, seed)
+    rs = np.random.default_rng(seed)
+    A.x[:] = A.x * rs.uniform(0.5, 1.5, size=A.x.shape) + 0.1
+    return A
+
+
+@pytest.fixture(scope="module")
+def abi():
+    from rcppml_amd import _abi
+    assert _abi.detect()
+    return _abi
+
+
+@pytest.mark.parametrize("precision", [1, 0])
+@pytest.mark.parametrize("loss_type,kw", [(5, dict(gp_dispersion_mode=2)), (5, dict(gp_dispersion_mode=1)), (5, dict(gp_dispersion_mode=0)),
+                                          (4, dict(gp_dispersion_mode=2)), (6, dict(gp_dispersion_mode=2)), (7, dict(gp_dispersion_mode=0)),
+                                          (8, dict(gp_dispersion_mode=2, tweedie_power=1.3)), (0, dict(robust_delta=1.345))])
+def test_mask_with_distribution_loss_through_plugin(abi, loss_type, kw, precision):
+    A = _counts(110, 150, 3, seed=21) if loss_type in (0, 4, 5) else _positive(110, 150, seed=22)
+    M = random_csc(A.rows, A.cols, 0.08, seed=5)
+    k = 6
+    W0, H0 = O.init_factors(13, k, A.rows, A.cols, np.float64)
+    okw = dict(max_iter=6, tol=0.0, mask=M, loss_type=loss_type, L1=(0.01, 0.02), L2=(0.0, 0.01),
+               dispersion_mode=kw.get("gp_dispersion_mode", 2), tweedie_power=kw.get("tweedie_power", 1.5), robust_delta=kw.get("robust_delta", 0.0))
+    ref = O.nmf_fit(A, W0, H0, np.float64, **okw)
+    W, H = W0.copy(), H0.copy()
+    res = abi.nmf_unified(A.p, A.i, A.x, A.rows, A.cols, k, W, H, entry="ex", max_iter=6, tol=0.0, mask=(M.p, M.i), loss_type=loss_type,
+                          L1_W=0.01, L1_H=0.02, L2_H=0.01, precision=precision, want_history=True, **kw)
+    assert res["status"] == 0, res.get("error")
+    assert res["iter"] == ref.iter
+    # masked MSE solves: as tight as the MSE mask tests (fp64 1e-6 on loss and factors; fp32 at single-precision level)
+    ltol, ftol = (1e-6, 1e-6) if precision == 1 else (2e-3, 2e-2)
+    assert abs(res["loss"] - ref.loss) <= ltol * abs(ref.loss), (res["loss"], ref.loss)
+    assert np.abs(res["loss_history"] - ref.loss_history).max() <= ltol * np.abs(ref.loss_history).max()
+    assert np.abs(W - ref.W_T).max() < ftol * max(1.0, np.abs(ref.W_T).max()) and np.abs(H - ref.H).max() < ftol * max(1.0, np.abs(ref.H).max())
+    assert np.abs(res["d"] - ref.d).max() <= ftol * np.abs(ref.d).max()
+    if loss_type != 0:
+        assert len(res["theta"]) == A.rows
+        if precision == 1:
+            rel = np.abs(res["theta"] - ref.theta) / np.maximum(np.abs(ref.theta), 1e-12)
+            assert np.median(rel) < 1e-6 and rel.max() < 1e-3, (np.median(rel), rel.max())
+    # the loss is NOT the unmasked explicit loss, and the robust modifier changes nothing under a mask
+    if loss_type == 0:
+        W2, H2 = W0.copy(), H0.copy()
+        plain = abi.nmf_unified(A.p, A.i, A.x, A.rows, A.cols, k, W2, H2, entry="ex", max_iter=6, tol=0.0, mask=(M.p, M.i), L1_W=0.01, L1_H=0.02,
+                                L2_H=0.01, precision=precision)
+        assert plain["loss"] == res["loss"] and np.array_equal(W2, W) and np.array_equal(H2, H)
+
+
+def test_masked_loss_op_matches_oracle_terms(abi):
+    """rcppml_hip_loss_masked alone: sum over the unmasked nonzeros of the term at theta = 0, fp64 and fp32."""
+    import ctypes as C
+    import torch
+    L = O.lib()
+    L.oracle_loss_nb_f64.restype = C.c_double; L.oracle_loss_gp_f64.restype = C.c_double; L.oracle_loss_dev_f64.restype = C.c_double
+    A = _positive(60, 80, seed=3)
+    M = random_csc(A.rows, A.cols, 0.2, seed=9)
+    k = 10
+    rng = np.random.default_rng(0)
+    W_T, H, d = rng.uniform(0.1, 1.0, (A.rows, k)), rng.uniform(0.1, 1.0, (A.cols, k)), rng.uniform(0.5, 2.0, k)
+    Mk = np.zeros((A.rows, A.cols), bool)
+    for j in range(A.cols):
+        Mk[M.i[M.p[j]:M.p[j + 1]], j] = True
+    pred = (W_T * d) @ H.T
+    ctx = abi.Context(0)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    for loss_type, power in ((0, 1.5), (4, 1.5), (5, 1.5), (6, 1.5), (7, 1.5), (8, 1.3), (8, 2.6)):
+        def term(y, p):
+            if loss_type == 0:
+                return (y - p) ** 2
+            if loss_type == 5:
+                return L.oracle_loss_nb_f64(C.c_double(y), C.c_double(p), C.c_double(0.0))
+            if loss_type == 4:
+                return L.oracle_loss_gp_f64(C.c_double(y), C.c_double(p), C.c_double(0.0))
+            return L.oracle_loss_dev_f64(C.c_int(loss_type), C.c_double(y), C.c_double(p), C.c_double(power))
+        want = sum(term(A.x[t], pred[A.i[t], j]) for j in range(A.cols) for t in range(A.p[j], A.p[j + 1]) if not Mk[A.i[t], j])
+        for dt, nd, tol in ((abi.F64, np.float64, 1e-11), (abi.F32, np.float32, 2e-4)):
+            out = torch.zeros(2, dtype=torch.float64, device="cuda")
+            ctx.loss_masked(dt, loss_type, dev(A.p), dev(A.i), dev(A.x.astype(nd)), dev(M.p), dev(M.i), A.cols, dev(W_T.astype(nd)),
+                            dev(d.astype(nd)), dev(H.astype(nd)), k, out, power=power)
+            got = float(out[0].item())
+            assert abs(got - want) <= tol * abs(want), (loss_type, power, dt, got, want)
+
+
+@pytest.mark.parametrize("loss_type,kw", [(5, {}), (4, {}), (6, {}), (8, dict(tweedie_power=1.4))])
+def test_dispersion_per_col_through_plugin(abi, loss_type, kw):
+    """dispersion = "per_col": one value per column of A, returned through rcppml_gpu_nmf_ex (n values).  The device ops run per row
+    of CSC(A^T)^T = per column of A with the two factors swapped: mu_ij = (h_j * d) . w_i where the oracle forms (w_i * d) . h_j --
+    fp64 agrees to rounding (the totals over all rows come from the Gram of W instead of the reference's m-long loop)."""
+    A = _counts(90, 130, 3, seed=31) if loss_type in (4, 5) else _positive(90, 130, seed=32)
+    k = 5
+    W0, H0 = O.init_factors(17, k, A.rows, A.cols, np.float64)
+    ref = O.nmf_fit(A, W0, H0, np.float64, max_iter=4, tol=0.0, loss_type=loss_type, dispersion_mode=3, tweedie_power=kw.get("tweedie_power", 1.5), threads=1)
+    W, H = W0.copy(), H0.copy()
+    res = abi.nmf_unified(A.p, A.i, A.x, A.rows, A.cols, k, W, H, entry="ex", max_iter=4, tol=0.0, loss_type=loss_type, gp_dispersion_mode=3,
+                          precision=1, **kw)
+    assert res["status"] == 0, res.get("error")
+    assert res["iter"] == ref.iter and len(res["theta"]) == A.cols == len(ref.theta)
+    # the IRLS map amplifies rounding (see test_nb_fit_through_plugin); NB feeds theta back into the solves, the others do not
+    ltol, ftol = (1e-5, 1e-4) if loss_type == 5 else (1e-6, 1e-4)
+    if abs(ref.loss) < 1e8:
+        assert abs(res["loss"] - ref.loss) <= ltol * abs(ref.loss), (res["loss"], ref.loss)
+        assert np.abs(W - ref.W_T).max() < ftol * max(1.0, np.abs(ref.W_T).max()) and np.abs(H - ref.H).max() < ftol * max(1.0, np.abs(ref.H).max())
+        rel = np.abs(res["theta"] - ref.theta) / np.maximum(np.abs(ref.theta), 1e-12)
+        assert np.median(rel) < 1e-4 and rel.max() < 0.2, (np.median(rel), rel.max())
+    # the reference-typed entry cannot return n values: refused there with a message that says so
+    W2, H2 = W0.copy(), H0.copy()
+    bad = abi.nmf_unified(A.p, A.i, A.x, A.rows, A.cols, k, W2, H2, entry="double", max_iter=2, loss_type=loss_type, gp_dispersion_mode=3, **kw)
+    assert bad["status"] == -1 and "per_col" in bad["error"]
+
+
+def test_dispersion_per_col_through_the_r_surface():
+    from rcppml_amd import nmf as N
+    from rcppml_amd.data import CSC
+    A = _counts(80, 120, 3, seed=41)
+    model = N.nmf(CSC((A.rows, A.cols), A.p, A.i, A.x), 4, loss="nb", dispersion="per_col", seed=3, maxit=3, tol=0.0, precision="fp64")
+    assert len(model.misc["theta"]) == A.cols and np.isfinite(model.misc["loss"])
+    assert np.all(model.misc["theta"] >= 0.01) and np.all(model.misc["theta"] <= 1e6)
+
+
+@pytest.mark.parametrize("loss_type", [5, 4, 6])
+def test_irls_loss_through_zero_copy_entry(abi, loss_type):
+    """The zero-copy entry (device-resident CSC, reference src/gpu_bridge_nmf.cu:879-967) carries loss_type / irls_max_iter /
+    irls_tol only; the rest of the IRLS configuration is the NMFConfig default (PER_ROW dispersion, :908-934): same fit as the
+    host-CSC entry called with those defaults, bit for bit (same kernels on the same device data)."""
+    import torch
+    A = _counts(100, 140, 3, seed=51) if loss_type != 6 else _positive(100, 140, seed=52)
+    k = 5
+    W0, H0 = O.init_factors(23, k, A.rows, A.cols, np.float64)
+    W, H = W0.copy(), H0.copy()
+    host = abi.nmf_unified(A.p, A.i, A.x, A.rows, A.cols, k, W, H, entry="double", max_iter=4, tol=0.0, loss_type=loss_type, cd_maxit=10)
+    assert host["status"] == 0, host.get("error")
+    dp = torch.from_numpy(np.ascontiguousarray(A.p, np.int32)).cuda()
+    di = torch.from_numpy(np.ascontiguousarray(A.i, np.int32)).cuda()
+    dx = torch.from_numpy(np.ascontiguousarray(A.x, np.float64)).cuda()
+    Wz, Hz = W0.copy(), H0.copy()
+    zc = abi.nmf_zerocopy(dp.data_ptr(), di.data_ptr(), dx.data_ptr(), A.rows, A.cols, A.x.shape[0], k, Wz, Hz, max_iter=4, tol=0.0,
+                          loss_type=loss_type, cd_maxit=10)
+    assert zc["status"] == 0, zc.get("error")
+    assert zc["iter"] == host["iter"] and zc["loss"] == host["loss"]
+    assert np.array_equal(Wz, W) and np.array_equal(Hz, H) and np.array_equal(zc["d"], host["d"])
+    ref = O.nmf_fit(A, W0, H0, np.float64, max_iter=4, tol=0.0, loss_type=loss_type, cd_maxit=10, threads=1)
+    if abs(ref.loss) < 1e8:
+        assert abs(zc["loss"] - ref.loss) <= 1e-5 * abs(ref.loss)

@@ -259,8 +259,8 @@ def test_gp_fit_through_plugin_and_python_surface():
     Ap = CSC((A.rows, A.cols), A.p, A.i, A.x)
     model = N.nmf(Ap, k, loss="gp", dispersion="none", seed=3, maxit=5, tol=0.0)
     assert model.misc["loss_type"] == "gp" and np.isfinite(model.misc["loss"]) and model.w.min() >= 0 and model.h.min() >= 0
-    with pytest.raises(NotImplementedError):
-        N.nmf(Ap, k, loss="gp", dispersion="per_col", seed=3, maxit=2)
+    pc = N.nmf(Ap, k, loss="gp", dispersion="per_col", seed=3, maxit=2)            # round 5: one theta per column (tests/test_gpu_combos.py)
+    assert len(pc.misc["theta"]) == Ap.shape[1]
     disp = N.nmf(Ap, k, loss="gp", seed=3, maxit=5, tol=0.0)          # the R default: dispersion = "per_row"
     assert disp.misc["theta"].shape == (A.rows,) and disp.misc["theta"].max() > 0 and disp.misc["theta"].max() <= 5.0
 
@@ -327,8 +327,8 @@ def test_power_family_fit_through_plugin(loss, loss_type, power):
         assert np.abs(H - ref.H).max() < 2e-2 * np.abs(ref.H).max() + 1e-3
     model = N.nmf(CSC((A.rows, A.cols), A.p, A.i, A.x), k, loss=loss, dispersion="none", seed=3, maxit=4, tol=0.0, tweedie_power=power)
     assert model.misc["loss_type"] == loss and np.isfinite(model.misc["loss"])
-    with pytest.raises(NotImplementedError):
-        N.nmf(CSC((A.rows, A.cols), A.p, A.i, A.x), k, loss=loss, dispersion="per_col", seed=3, maxit=2)
+    pc = N.nmf(CSC((A.rows, A.cols), A.p, A.i, A.x), k, loss=loss, dispersion="per_col", seed=3, maxit=2)
+    assert len(pc.misc["theta"]) == A.cols
 
 
 @pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-6), (np.float32, 3e-2)])

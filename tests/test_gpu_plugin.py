@@ -487,5 +487,5 @@ def test_zerocopy_entry_matches_host_entry(abi):
     assert np.array_equal(W1, W2) and np.array_equal(H1, H2) and np.array_equal(r1["d"], r2["d"])
     # the caller's device arrays are untouched
     assert np.array_equal(dx.cpu().numpy(), A.x) and np.array_equal(di.cpu().numpy(), A.i.astype(np.int32))
-    bad = abi.nmf_zerocopy(dp, di, dx, A.rows, A.cols, A.nnz, k, W2, H2, max_iter=2, loss_type=5)
+    bad = abi.nmf_zerocopy(dp, di, dx, A.rows, A.cols, A.nnz, k, W2, H2, max_iter=2, loss_type=2)      # Huber: not a loss of this build
     assert bad["status"] == -1
