@@ -1264,6 +1264,25 @@ using namespace oracle;
 ORACLE_API uint64_t oracle_splitmix_next(uint64_t* state) {
     SplitMix64 r(1); r.state = *state; const uint64_t v = r.next(); *state = r.state; return v;
 }
+// Test infrastructure for the PRODUCT's fp64 coordinate sweeps (rcppml_amd/csrc/kernels.hip.h cd_quotient): they form b / g as
+// q0 = b ginv, q = q0 + (b - q0 g) ginv with ginv = 1 / g rounded once per column.  Counts the operand pairs (random sign, mantissa and
+// an exponent spread of 2^-40 .. 2^40) on which that differs from the division operator the reference writes (nnls_batch.hpp:100).
+// Compiled with -ffp-contract=off: the two fmas are the explicit ones.
+ORACLE_API long long oracle_corrected_quotient_mismatches(uint64_t seed, long long n, double* first_b, double* first_g) {
+    SplitMix64 r(seed);
+    long long bad = 0;
+    for (long long t = 0; t < n; ++t) {
+        const uint64_t u = r.next(), v = r.next();
+        const double g = std::ldexp(1.0 + (double)(u >> 12) * 0x1p-52, (int)(u & 63) - 32);                   // > 0
+        double b = std::ldexp(1.0 + (double)(v >> 12) * 0x1p-52, (int)(v & 63) - 32 + (int)((u >> 6) & 15) - 8);
+        if (v & 64) b = -b;
+        const double ginv = 1.0 / g;
+        const double q0 = b * ginv;
+        const double q = std::fma(std::fma(-q0, g, b), ginv, q0);
+        if (q != b / g) { if (!bad) { *first_b = b; *first_g = g; } ++bad; }
+    }
+    return bad;
+}
 ORACLE_API uint64_t oracle_splitmix_init_state(uint64_t seed) { return SplitMix64(seed).state; }
 ORACLE_API void oracle_fill_uniform_f64(uint64_t seed, double* out, int rows, int cols) { SplitMix64 r(seed); r.fill_uniform(out, rows, cols); }
 ORACLE_API void oracle_fill_uniform_f32(uint64_t seed, float* out, int rows, int cols) { SplitMix64 r(seed); r.fill_uniform(out, rows, cols); }

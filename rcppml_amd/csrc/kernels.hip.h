@@ -37,6 +37,21 @@ __device__ __forceinline__ double tfma(double a, double b, double c) { return __
 // division is ~10 dependent instructions on the chain of every step
 __device__ __forceinline__ float sweep_quotient(float b, float /*gd*/, float ginv) { return b * ginv; }
 __device__ __forceinline__ double sweep_quotient(double b, double gd, double /*ginv*/) { return b / gd; }
+// b / gd inside the fp64 ("parity mode") sweeps that keep 1 / G_cc per column: the quotient from that reciprocal plus ONE correction,
+//   q0 = b ginv,  r = b - q0 gd (a single fma: exact),  q = q0 + r ginv
+// -- with ginv = RN(1 / gd) this is RN(b / gd), the reference's `b[i] / g_diag` (nnls_batch.hpp:100), bar over/underflow of the
+// intermediates; two fmas on the chain of a coordinate instead of the ~15 dependent instructions of an IEEE fp64 division (until round 4
+// these sweeps took q0: one rounding more).  Checked against the division operator on 2e8 random operand pairs in
+// tests/test_oracle.py::test_corrected_reciprocal_quotient_equals_division (host fma = device fma: both IEEE).  gd <= 0 arrives as
+// ginv = 0: q = 0.  fp32 keeps b ginv (the reference's own fp32 arithmetic is what the fp32 mode is compared with at 1e-4..1e-6).
+__device__ __forceinline__ double cd_quotient(double b, double gd, double ginv) {
+    const double q0 = b * ginv;
+    return __builtin_fma(__builtin_fma(-q0, gd, b), ginv, q0);
+}
+__device__ __forceinline__ float cd_quotient(float b, float /*gd*/, float ginv) { return b * ginv; }
+// the step's quotient with the L1 term: fp32 one fma (b ginv - L1), fp64 the reference's two roundings (b / gd, then - L1)
+__device__ __forceinline__ float cd_static_diff(float b, float /*gd*/, float ginv, float nl1) { return __builtin_fmaf(b, ginv, nl1); }
+__device__ __forceinline__ double cd_static_diff(double b, double gd, double ginv, double nl1) { return cd_quotient(b, gd, ginv) + nl1; }
 __device__ __forceinline__ float lane_value(float v, int i) {
     return __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), i));
 }
@@ -81,14 +96,13 @@ __device__ __forceinline__ double cd_static_max(double a, double b, double) { re
 // One static sweep.  A coordinate is visited once per sweep, so the iterate a step sees is the one the sweep started with: the
 // sweep only COLLECTS every lane's own step (v_writelane of the broadcast value into lane i) and the iterate moves once, after
 // the last coordinate.  Per coordinate: fma, med3, v_readlane, v_writelane, fma.
-// fp64 note: the step multiplies by 1/G_ii formed once per solve (one rounding more than b / G_ii -- the same choice as the fp64 MSE
-// kernel, kernels_cd_mfma64.hip.h); an IEEE fp64 division is ~15 dependent instructions on the chain of every coordinate.
+// fp64: the quotient is the corrected one (cd_quotient above = b / G_ii); fp32 multiplies by 1/G_ii formed once per solve.
 template <class T, int KP, class GC>
-__device__ __forceinline__ T cd_static_one_sweep(T& b, T xe, T ginv, T nl1, T inf_rt, GC&& gcol) {
+__device__ __forceinline__ T cd_static_one_sweep(T& b, T xe, T gd, T ginv, T nl1, T inf_rt, GC&& gcol) {
     T aown = T(0);
     cd_static_for<0, KP>([&](auto IC) {
         constexpr int i = decltype(IC)::value;
-        const T diff = tfma(b, ginv, nl1);
+        const T diff = cd_static_diff(b, gd, ginv, nl1);
         const T ad = cd_static_max(diff, -xe, inf_rt);
         const T ad_i = lane_value(ad, i);
         b = tfma(-gcol(IC), ad_i, b);           // the chain goes on from here; collecting the step is off it
@@ -105,7 +119,7 @@ __device__ __forceinline__ void cd_static_sweeps(T& b, T& x, T gd, bool fok, T l
     const T inf_rt = maxit >= 0 ? pinf : T(0);        // +inf at run time: with a literal LLVM folds the median back into maxnum
     for (int it = 0; it < maxit; ++it) {
         const T xe = !alive ? T(0) : (nonneg ? x : pinf);   // the clamp's operand: max(diff, -xe) is max(diff, -x) or diff; a dead diagonal (reference: `continue`) takes no step, whatever its warm x
-        const T aown = cd_static_one_sweep<T, KP>(b, xe, ginv, nl1, inf_rt, gcol);
+        const T aown = cd_static_one_sweep<T, KP>(b, xe, gd, ginv, nl1, inf_rt, gcol);
         const T xn = x + aown;
         const bool moved = xn != x;
         x = xn;
@@ -125,7 +139,7 @@ __device__ __forceinline__ int cd_static_sweeps_tol(T& b, T& x, T gd, bool fok, 
     const T inv_k = T(1) / static_cast<T>(k);
     for (int it = 0; it < maxit; ++it) {
         const T xe = !alive ? T(0) : (nonneg ? x : pinf);
-        const T aown = cd_static_one_sweep<T, KP>(b, xe, ginv, T(0), inf_rt, gcol);
+        const T aown = cd_static_one_sweep<T, KP>(b, xe, gd, ginv, T(0), inf_rt, gcol);
         const T xn = x + aown;
         const bool moved = xn != x;
         x = xn;

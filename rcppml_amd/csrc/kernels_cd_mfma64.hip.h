@@ -64,18 +64,20 @@ template <class T> struct CdStepOut64 { T a, nx; };
 __device__ __forceinline__ float tmax(float a, float b) { return __builtin_fmaxf(a, b); }
 __device__ __forceinline__ double tmax(double a, double b) { return __builtin_fmax(a, b); }
 
+// fp64: diff = b / G_cc as the reference divides (cd_quotient, kernels.hip.h: the reciprocal's quotient + one exact-residual
+// correction); fp32: b * (1 / G_cc).  gd is only read in fp64.
 template <bool SIMPLE, class T>
-__device__ __forceinline__ CdStepOut64<T> cd_step64(T b, T xo, T ginv, bool active, T l1_cd, T l2_cd, T lo, T hi) {
+__device__ __forceinline__ CdStepOut64<T> cd_step64(T b, T xo, T gd, T ginv, bool active, T l1_cd, T l2_cd, T lo, T hi) {
     CdStepOut64<T> o;
     if constexpr (SIMPLE) {
         // a = max(diff, -xo), x = max(xo + diff, 0): the reference's clamped step with a two-instruction dependent chain
         // (see cd_scalar_step in kernels_cd_mfma.hip.h).  `active` and `if (g_diag <= 0) continue;` arrive folded into
         // ginv (= 0): diff = 0, a = 0, nx = xo
-        const T diff = b * ginv;
+        const T diff = cd_quotient(b, gd, ginv);
         o.a = tmax(diff, -xo);
         o.nx = tmax(xo + diff, T(0));
     } else {
-        T diff = b * ginv;
+        T diff = cd_quotient(b, gd, ginv);
         diff -= l1_cd;
         diff = tfma(l2_cd, xo, diff);
         const T nv = xo + diff;
@@ -114,6 +116,7 @@ void cd_mfma64_kernel(const T* __restrict__ G /* k x k, as rcppml_hip_gram wrote
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     T* Gs = reinterpret_cast<T*>(smem_raw);               // KP*KP, quad-major (layout comment above)
     Tab4* tab_s = reinterpret_cast<Tab4*>(Gs + KP * KP);     // KP x {1/G_cc, 3 in-quad couplings}
+    [[maybe_unused]] T* gd_s = Gs + KP * KP + 4 * KP;        // fp64 only: KP x G_cc (the corrected quotient's exact residual needs it)
     // operand image and per-coordinate table formed here from the k x k Gram (layout comment above; until round 3 a launch of its own)
     {
         constexpr bool PERM = sizeof(T) == 4;
@@ -133,6 +136,7 @@ void cd_mfma64_kernel(const T* __restrict__ G /* k x k, as rcppml_hip_gram wrote
             v.z = gg > 1 ? gp(qb + 1, c) : T(0);
             v.w = gg > 2 ? gp(qb + 2, c) : T(0);
             tab_s[c] = v;
+            if constexpr (sizeof(T) == 8) gd_s[c] = gd > T(0) ? gd : T(0);
         }
     }
     __syncthreads();
@@ -181,6 +185,8 @@ void cd_mfma64_kernel(const T* __restrict__ G /* k x k, as rcppml_hip_gram wrote
     int nsweep = 0;
     // operands of the first quad; every quad then requests the NEXT quad's operands before it starts computing
     Tab4 tb_c = tab_s[g];
+    [[maybe_unused]] T gd_c = T(0);
+    if constexpr (sizeof(T) == 8) gd_c = gd_s[g];
     T av_c[NT];
 #pragma unroll
     for (int t2 = 0; t2 < NT; ++t2) av_c[t2] = Gs[(t2 << 6) + lane];
@@ -196,6 +202,8 @@ void cd_mfma64_kernel(const T* __restrict__ G /* k x k, as rcppml_hip_gram wrote
                 const int qn = (4 * t + v + 1) % NQ;
                 const int tn = (v == 3 ? t + 1 : t) % NT;          // row tile of the next quad
                 const Tab4 tb_n = tab_s[4 * qn + g];
+                [[maybe_unused]] T gd_n = T(0);
+                if constexpr (sizeof(T) == 8) gd_n = gd_s[4 * qn + g];
                 T av_n[NT];
 #pragma unroll
                 for (int t2 = 0; t2 < NT; ++t2) av_n[t2] = Gs[((qn * NT + t2) << 6) + lane];
@@ -203,13 +211,13 @@ void cd_mfma64_kernel(const T* __restrict__ G /* k x k, as rcppml_hip_gram wrote
                 const T xo = xr[t][v];
                 const T ginv = SIMPLE ? (active ? tb_c.x : T(0)) : tb_c.x;
                 // phase p: group p's step is final; the groups behind it take the lazy correction, the others keep b
-                const CdStepOut64<T> s0 = cd_step64<SIMPLE, T>(b0, xo, ginv, active, l1_cd, l2_cd, lo, hi);
+                const CdStepOut64<T> s0 = cd_step64<SIMPLE, T>(b0, xo, gd_c, ginv, active, l1_cd, l2_cd, lo, hi);
                 const T b1 = tfma(-tb_c.y, bcast_row<0>(s0.a), b0);
-                const CdStepOut64<T> s1 = cd_step64<SIMPLE, T>(b1, xo, ginv, active, l1_cd, l2_cd, lo, hi);
+                const CdStepOut64<T> s1 = cd_step64<SIMPLE, T>(b1, xo, gd_c, ginv, active, l1_cd, l2_cd, lo, hi);
                 const T b2 = tfma(-tb_c.z, bcast_row<1>(s1.a), b1);
-                const CdStepOut64<T> s2 = cd_step64<SIMPLE, T>(b2, xo, ginv, active, l1_cd, l2_cd, lo, hi);
+                const CdStepOut64<T> s2 = cd_step64<SIMPLE, T>(b2, xo, gd_c, ginv, active, l1_cd, l2_cd, lo, hi);
                 const T b3 = tfma(-tb_c.w, bcast_row<2>(s2.a), b2);
-                const CdStepOut64<T> s3 = cd_step64<SIMPLE, T>(b3, xo, ginv, active, l1_cd, l2_cd, lo, hi);
+                const CdStepOut64<T> s3 = cd_step64<SIMPLE, T>(b3, xo, gd_c, ginv, active, l1_cd, l2_cd, lo, hi);
                 xr[t][v] = s3.nx;
                 // |a| / (|x_new| + 1e-15)  (nnls_batch.hpp:117-120): v_rcp_f64 + one Newton step
                 tsum = tfma(tabs(s3.a), fast_recip(tabs(s3.nx) + T(1e-15)), tsum);
@@ -220,6 +228,7 @@ void cd_mfma64_kernel(const T* __restrict__ G /* k x k, as rcppml_hip_gram wrote
                     acc[t2] = mfma16(av_c[t2], s3.a, acc[t2]);
                 }
                 tb_c = tb_n;
+                gd_c = gd_n;
 #pragma unroll
                 for (int t2 = 0; t2 < NT; ++t2) av_c[t2] = av_n[t2];
                 __builtin_amdgcn_sched_barrier(0);      // one scheduling region per quad (see kernels_cd_mfma.hip.h)

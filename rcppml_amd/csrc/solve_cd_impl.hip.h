@@ -105,7 +105,7 @@ static void cd_mfma64_launch(rcppml_hip_ctx* c, const T* G, const T* /*unused*/,
                              int64_t ncols, T l1_pre, int warm, int zero_init, T l1_cd, T l2_cd, int nonneg,
                              int maxit, T tol, T ub_cd, T ub_post, int* sweeps, const int* order) {
     constexpr int KP = 16 * NT;
-    const size_t smem = ((size_t)KP * KP + 4 * KP) * sizeof(T);
+    const size_t smem = ((size_t)KP * KP + 4 * KP + (sizeof(T) == 8 ? KP : 0)) * sizeof(T);      // fp64: + the diagonal itself
     const int64_t nblk = (ncols + 63) / 64;          // 4 waves x 16 columns per block
     const bool simple = nonneg && ub_cd <= T(0) && l1_cd == T(0) && l2_cd == T(0);
     static DynSmemOnce once_simple, once_general;    // fp64 above k = 64: the LDS copy of G passes 64 KiB (128 KiB at KP = 128)

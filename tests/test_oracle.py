@@ -281,3 +281,18 @@ def test_proj_adv_gram_matches_numpy_eigh():
             ref = G2 if w.min() >= 1e-8 else (V * np.maximum(w, 1e-8)) @ V.T
             assert np.abs(got - ref).max() <= 1e-11 * np.abs(ref).max()
             assert np.allclose(got, got.T, atol=1e-12 * np.abs(got).max())
+
+
+def test_corrected_reciprocal_quotient_equals_division():
+    """The product's fp64 coordinate sweeps keep 1 / G_cc per column and form the step's quotient as q0 = b ginv,
+    q = q0 + (b - q0 g) ginv (cd_quotient in rcppml_amd/csrc/kernels.hip.h): with a correctly rounded reciprocal and an exact
+    residual (one fma) that IS the reference's `b[i] / g_diag` (nnls_batch.hpp:100).  2e8 random operand pairs, host fma (IEEE,
+    as the device's): not one differs from the division operator."""
+    import ctypes as C
+    L = O.lib()
+    L.oracle_corrected_quotient_mismatches.restype = C.c_longlong
+    b, g = C.c_double(0), C.c_double(0)
+    bad = 0
+    for seed in (1, 2, 3, 4):
+        bad += L.oracle_corrected_quotient_mismatches(C.c_uint64(seed), C.c_longlong(50_000_000), C.byref(b), C.byref(g))
+    assert bad == 0, (bad, b.value, g.value)
