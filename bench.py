@@ -359,8 +359,11 @@ def main():
         gather_bytes = float(nnz) * k * sv
         deliv = gather_bytes / max(avg_s, 1e-12) / 1e12
         roof_rhs = {"bound": "hbm",
-                    "kernel": ("rhs_tiled_kernel + rhs_tiled_spill_kernel (+ reduce / tail): LDS row-tiled SpMM-like B = F * A(:,j), both half-updates"
-                               if planned else "rhs_stage_kernel (SpMM-like B = F * A(:,j), both half-updates)"),
+                    "kernel": ("rhs_win_kernel + rhs_win_finish_kernel: SpMM-like B = F * A(:,j), F through a ring of LDS row tiles, nonzeros scheduled "
+                               "over a sliding window, partition slabs + overflow summed by the finishing pass; both half-updates"
+                               if planned and all(p.get("kind", 1) == 1 for p in plan_info.values()) else
+                               "rhs_tiled_kernel + spill / reduce kernels (slab plan): SpMM-like B = F * A(:,j), both half-updates"
+                               if planned else "rhs_stage_kernel (gather form; SpMM-like B = F * A(:,j), both half-updates)"),
                     "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                     "traffic": None, "algorithmic_bytes_per_launch": avg_bytes, "avg_launch_ms": avg_s * 1e3,
                     "rhs_H_ms": ms_h / max(cnt_h, 1), "rhs_W_ms": ms_w / max(cnt_w, 1),
@@ -405,21 +408,27 @@ def main():
                     idle[side] = float(1.0 - tl.sum() / max(1, (tl.max(axis=1) * tile).sum()))
             except Exception:
                 pass
-            mfma = args.dtype == "f32" and k <= 64 and args.variant == "auto"
+            # what solve_cd_impl.hip.h launches for variant = auto: fp32 k <= 128 -> 32-column v_mfma_f32_32x32x2 tiles (16-column
+            # v_mfma_f32_16x16x4 tiles on sides with fewer than 4 tiles per CU, k <= 64; lane = column 4x4 blocks for k <= 32 on large
+            # sides); fp64 k <= 128 -> 16-column v_mfma_f64_16x16x4 tiles; above 128: the VALU lane-group kernel
+            mfma = k <= 128 and args.variant == "auto"
+            f32 = args.dtype == "f32"
+            w_small16 = f32 and k <= 64 and (m + 31) // 32 < 4 * 256
             flops_h = 2.0 * k * k * work["cd_column_sweeps"] * share_h / max(cnt_sh, 1)
             flops_w = 2.0 * k * k * work["cd_column_sweeps"] * (1.0 - share_h) / max(cnt_sw, 1)
             s_h, s_w = ms_sh / max(cnt_sh, 1) * 1e-3, ms_sw / max(cnt_sw, 1) * 1e-3
             tf_h, tf_w = flops_h / max(s_h, 1e-12) / 1e12, flops_w / max(s_w, 1e-12) / 1e12
             tf = cd_flops / max(cd_s, 1e-12) / 1e12
             roof_cd = {"bound": "mfma" if mfma else "valu",
-                       "kernel": ("cd_mfma_kernel (coordinate-descent NNLS on 32-column MFMA tiles, H half-update)" if mfma
-                                  else "coordinate-descent NNLS kernel, H half-update"),
+                       "kernel": (("cd_mfma_kernel (coordinate-descent NNLS on 32-column v_mfma_f32_32x32x2 tiles, H half-update)" if f32 else
+                                   "cd_mfma64_kernel<double> (coordinate-descent NNLS on 16-column v_mfma_f64_16x16x4 tiles, H half-update)") if mfma
+                                  else "cd_group_kernel (VALU lane groups; rank above 128 or a forced variant), H half-update"),
                        "achieved": tf_h, "peak": cd_peak, "unit": "TFLOP/s", "frac": tf_h / cd_peak, "traffic": None,
                        "algorithmic_flops_per_launch": flops_h, "avg_launch_ms": s_h * 1e3,
                        "mean_sweeps_per_column": work["cd_column_sweeps"] / work["cd_columns"],
                        "idle_slot_fraction": idle,
                        "solve_H_ms": s_h * 1e3, "solve_W_ms": s_w * 1e3,
-                       "w_side": {"kernel": "cd_mfma64_kernel<float> (16-column MFMA tiles)" if mfma else "same kernel",
+                       "w_side": {"kernel": ("cd_mfma64_kernel<float> (16-column v_mfma_f32_16x16x4 tiles)" if (mfma and w_small16) else "same kernel"),
                                   "achieved": tf_w, "frac": tf_w / cd_peak, "avg_launch_ms": s_w * 1e3,
                                   "algorithmic_flops_per_launch": flops_w},
                        "both_sides": {"achieved": tf, "frac": tf / cd_peak, "avg_launch_ms": cd_s * 1e3}}

@@ -289,7 +289,7 @@ RCPPML_GPU_API int rcppml_hip_rhs(rcppml_hip_ctx* ctx, int dtype, const int* col
 
 /* Planned form of the same product for large inputs (build-defined; the reference has one CPU loop, rhs.hpp:52-70).
  * A plan is a device copy of ONE CSC matrix for one rank k and precision, laid out for a kernel that stages the rows of F through
- * LDS and keeps the output columns in registers.  Two plan kinds (plan_info field 0 says which the planner took):
+ * LDS and keeps the output columns in registers.  Two plan kinds (rcppml_hip_rhs_plan_kind says which the planner took):
  *   window plan (kind 1, kernels_rhs_win.hip.h -- the default): a ring of four 32 KiB row tiles, nonzeros scheduled over a sliding
  *     window of three tiles at a fractional slot rate; what the window cannot place (the "overflow", a few per cent) is added by
  *     the finishing pass that also sums the row partitions; no tail launch.  Declined (-> slab plan) for slot rates above 6 per
@@ -316,6 +316,8 @@ RCPPML_GPU_API int rcppml_hip_rhs_plan_create(rcppml_hip_ctx* ctx, int dtype, co
  * overflow lists, and for every nonzero where its value will go), _set_values scatters the values with one coalesced pass and
  * may be called again when the values of the same pattern change.  The plugin builds both plans while the values are still
  * crossing PCIe.  *out_plan = NULL when the window planner declines the input (use rcppml_hip_rhs_plan_create then). */
+/* 1 = window plan, 0 = slab plan (see above), -1 = NULL. */
+RCPPML_GPU_API int rcppml_hip_rhs_plan_kind(const rcppml_rhs_plan* plan);
 RCPPML_GPU_API int rcppml_hip_rhs_plan_create_indices(rcppml_hip_ctx* ctx, int dtype, const int* col_ptr, const int* row_idx, int64_t ncols,
                                                       int64_t nrows, int k, int partitions, int slots, rcppml_rhs_plan** out_plan);
 RCPPML_GPU_API int rcppml_hip_rhs_plan_set_values(rcppml_hip_ctx* ctx, rcppml_rhs_plan* plan, const void* values);

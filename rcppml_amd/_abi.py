@@ -25,7 +25,7 @@ EXPORTED_SYMBOLS = [
     "rcppml_hip_ctx_create", "rcppml_hip_ctx_destroy", "rcppml_hip_ctx_sync", "rcppml_hip_ctx_stats", "rcppml_hip_ctx_irls_stats", "rcppml_hip_ctx_cd_step_stats", "rcppml_hip_ctx_set_option", "rcppml_hip_transpose_csc", "rcppml_hip_transpose_csc_sort", "rcppml_hip_transpose_csc_gather", "rcppml_hip_cast", "rcppml_hip_gram", "rcppml_hip_rhs",
     "rcppml_hip_solve_cd", "rcppml_hip_order_columns", "rcppml_hip_solve_chol", "rcppml_hip_row_norms", "rcppml_hip_apply_scaling",
     "rcppml_hip_sumsq", "rcppml_hip_loss_mse", "rcppml_hip_solve_masked", "rcppml_hip_loss_nonzeros", "rcppml_hip_loss_masked",
-    "rcppml_hip_solve_irls_nb", "rcppml_hip_nb_size_update", "rcppml_hip_nb_size_update_loss", "rcppml_hip_nb_loss", "rcppml_hip_solve_irls", "rcppml_hip_irls_loss", "rcppml_hip_apply_l21", "rcppml_hip_angular_posthoc", "rcppml_hip_solve_cv", "rcppml_hip_cv_test_error", "rcppml_hip_solve_cv_irls", "rcppml_hip_cv_irls_loss", "rcppml_hip_cv_gp_theta_update", "rcppml_hip_mul_rows", "rcppml_hip_apply_graph_reg", "rcppml_hip_dispersion_update", "rcppml_hip_vec_global", "rcppml_hip_spz_info", "rcppml_hip_spz_decode",
+    "rcppml_hip_solve_irls_nb", "rcppml_hip_nb_size_update", "rcppml_hip_nb_size_update_loss", "rcppml_hip_nb_loss", "rcppml_hip_solve_irls", "rcppml_hip_rhs_plan_kind", "rcppml_hip_irls_loss", "rcppml_hip_apply_l21", "rcppml_hip_angular_posthoc", "rcppml_hip_solve_cv", "rcppml_hip_cv_test_error", "rcppml_hip_solve_cv_irls", "rcppml_hip_cv_irls_loss", "rcppml_hip_cv_gp_theta_update", "rcppml_hip_mul_rows", "rcppml_hip_apply_graph_reg", "rcppml_hip_dispersion_update", "rcppml_hip_vec_global", "rcppml_hip_spz_info", "rcppml_hip_spz_decode",
     "rcppml_sp_read_gpu", "rcppml_sp_free_gpu", "rcppml_hip_rhs_dense", "rcppml_gpu_nmf_dense_unified_float",
     "rcppml_gpu_nmf_dense_unified_double",
     "rcppml_hip_rhs_plan_create", "rcppml_hip_rhs_plan_create_indices", "rcppml_hip_rhs_plan_set_values", "rcppml_hip_rhs_plan_destroy", "rcppml_hip_rhs_plan_info", "rcppml_hip_rhs_planned",
@@ -48,7 +48,10 @@ class RhsPlan:
         lib().rcppml_hip_rhs_plan_info(self._h, out)
         keys = ("partitions", "waves", "rounds", "slots", "workgroups_per_partition", "tiles", "slot_count", "spilled_nnz",
                 "fill", "stream_bytes", "tiled_columns")
-        return {k: (float(out[i]) if k == "fill" else int(out[i])) for i, k in enumerate(keys)}
+        d = {k: (float(out[i]) if k == "fill" else int(out[i])) for i, k in enumerate(keys)}
+        d["kind"] = {1: "window", 0: "slab"}.get(int(lib().rcppml_hip_rhs_plan_kind(self._h)), "?")
+        d["slot_rate"] = float(out[3])        # window plans: slots per column and phase (fractional); slab plans: S
+        return d
 
     def close(self):
         if self._h is not None and self._h.value:

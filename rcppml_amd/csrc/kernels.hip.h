@@ -42,7 +42,7 @@ __device__ __forceinline__ double sweep_quotient(double b, double gd, double /*g
 // -- with ginv = RN(1 / gd) this is RN(b / gd), the reference's `b[i] / g_diag` (nnls_batch.hpp:100), bar over/underflow of the
 // intermediates; two fmas on the chain of a coordinate instead of the ~15 dependent instructions of an IEEE fp64 division (until round 4
 // these sweeps took q0: one rounding more).  Checked against the division operator on 2e8 random operand pairs in
-// tests/test_oracle.py::test_corrected_reciprocal_quotient_equals_division (host fma = device fma: both IEEE).  gd <= 0 arrives as
+// the CPU test test_corrected_reciprocal_quotient_equals_division under tests/ (host fma = device fma: both IEEE).  gd <= 0 arrives as
 // ginv = 0: q = 0.  fp32 keeps b ginv (the reference's own fp32 arithmetic is what the fp32 mode is compared with at 1e-4..1e-6).
 __device__ __forceinline__ double cd_quotient(double b, double gd, double ginv) {
     const double q0 = b * ginv;

@@ -292,6 +292,7 @@ extern "C" int rcppml_hip_rhs_plan_set_values(rcppml_hip_ctx* c, rcppml_rhs_plan
 
 extern "C" void rcppml_hip_rhs_plan_destroy(rcppml_rhs_plan* plan) { delete plan; }
 
+extern "C" int rcppml_hip_rhs_plan_kind(const rcppml_rhs_plan* pl) { return pl ? pl->kind : -1; }
 extern "C" int rcppml_hip_rhs_plan_info(const rcppml_rhs_plan* pl, double* out10 /* 11 doubles */) {
     if (!pl || !out10) return 1;
     if (pl->kind == 1) {
