@@ -574,6 +574,8 @@ void nmf_entry(RCPPML_NMF_UNIFIED_ARGS, const int* mask_p, const int* mask_i, do
             if (*gp_dispersion_mode == 3 && !theta_holds_n) throw std::runtime_error("dispersion='per_col' returns n values: the bridge's out_theta holds m (gpu/bridge_nmf.hpp:284); use rcppml_gpu_nmf_ex");
             if (*solver_mode != 0) throw std::runtime_error("NB loss requires the CD solver");      // core/config.hpp:447-452
         }
+        if (*robust_delta > 0 && *gp_dispersion_mode == 3 && !theta_holds_n)       // (robust MSE returns a theta vector too: zeros, n of them under per_col)
+            throw std::runtime_error("dispersion='per_col' returns n values: the bridge's out_theta holds m (gpu/bridge_nmf.hpp:284); use rcppml_gpu_nmf_ex");
         if (*robust_delta > 0) {   // Huber on Pearson residuals: every loss (MSE included) goes through the IRLS path
             if (*k > 128) throw std::runtime_error("robust loss: k must be <= 128");
             if (*solver_mode != 0) throw std::runtime_error("robust loss requires the CD solver");

@@ -131,6 +131,11 @@ def test_dispersion_per_col_through_plugin(abi, loss_type, kw):
     W2, H2 = W0.copy(), H0.copy()
     bad = abi.nmf_unified(A.p, A.i, A.x, A.rows, A.cols, k, W2, H2, entry="double", max_iter=2, loss_type=loss_type, gp_dispersion_mode=3, **kw)
     assert bad["status"] == -1 and "per_col" in bad["error"]
+    # robust MSE returns a (zero) theta vector as well: n entries under per_col, so the bridge-typed entry refuses that too
+    bad = abi.nmf_unified(A.p, A.i, A.x, A.rows, A.cols, k, W2, H2, entry="double", max_iter=2, loss_type=0, robust_delta=1.0, gp_dispersion_mode=3)
+    assert bad["status"] == -1 and "per_col" in bad["error"]
+    ok = abi.nmf_unified(A.p, A.i, A.x, A.rows, A.cols, k, W2, H2, entry="ex", max_iter=2, loss_type=0, robust_delta=1.0, gp_dispersion_mode=3)
+    assert ok["status"] == 0 and len(ok["theta"]) == A.cols and np.all(ok["theta"] == 0)
 
 
 def test_dispersion_per_col_through_the_r_surface():
