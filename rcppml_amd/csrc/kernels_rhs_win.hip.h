@@ -225,6 +225,14 @@ __device__ __forceinline__ void rw_glds16_lim(const char* base_uniform, unsigned
     asm volatile("s_mov_b32 m0, %3\n\tv_cmp_gt_u32 vcc, %4, %1\n\ts_and_saveexec_b64 %0, vcc\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b64 exec, %0"
                  : "=&s"(keep) : "v"(lane_off), "s"(base_uniform), "s"(lds_addr_uniform), "s"(limit) : "vcc", "scc");
 }
+// the same with the non-temporal hint: the slot stream is read ONCE, by one workgroup -- it should not displace the rows of F that
+// every workgroup of the partition re-reads from the XCD's L2 (MI355X_MICROARCH.md "nt-weights": -18 % issue-to-landed for a stream
+// one CU reads once)
+__device__ __forceinline__ void rw_glds16_lim_nt(const char* base_uniform, unsigned lane_off, unsigned lds_addr_uniform, unsigned limit) {
+    unsigned long long keep;
+    asm volatile("s_mov_b32 m0, %3\n\tv_cmp_gt_u32 vcc, %4, %1\n\ts_and_saveexec_b64 %0, vcc\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b64 exec, %0"
+                 : "=&s"(keep) : "v"(lane_off), "s"(base_uniform), "s"(lds_addr_uniform), "s"(limit) : "vcc", "scc");
+}
 
 // ---------------------------------------------------------------------------
 // The kernel.  NV = 256-byte slices per row of F, CLO / NHI = slot rate (phase t carries CLO + ((t & 3) < NHI) slots per
@@ -323,7 +331,11 @@ __global__ __launch_bounds__(64 * NW) void rhs_win_kernel(const char* __restrict
 #else
             const unsigned left = live ? SB - 1024 * i : 0;
 #endif
+#ifdef RW_SLOTS_DEFAULT_POLICY
             rw_glds16_lim(grp + (pre + 1024 * i) + (K < NHI ? whi : wlo), 16u * lane, sl0 + stage * STAGE + 1024 * i, left);
+#else
+            rw_glds16_lim_nt(grp + (pre + 1024 * i) + (K < NHI ? whi : wlo), 16u * lane, sl0 + stage * STAGE + 1024 * i, left);
+#endif
         }
     };
     // the wave's slots of one stage -> registers: the kernel wants step 16 b + u of lane group g in lane 16 g + u, i.e. slot
