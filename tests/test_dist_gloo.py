@@ -117,3 +117,44 @@ def test_partition_by_nnz():
     # degenerate: more ranks than columns
     b = als.partition_columns_by_nnz(np.array([0, 3, 5]), 4)
     assert b[0] == 0 and b[-1] == 2 and all(b[i] <= b[i + 1] for i in range(4))
+
+
+def _one_rank_worker(port, cfg_kw, force, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        A = _matrix("even")
+        k = 6
+        W0, H0 = data.init_factors(9, k, A.rows, A.cols)
+        comm = als.Comm(dist, force=force)
+        st = als.ShardedALS(OracleOps("f64"), comm, A, A.transpose(), W0, H0, als.AlsConfig(k=k, **cfg_kw))
+        res = st.fit()
+        W_T, d, H = st.factors()
+        q.put((comm.sharded, st.rows_per, res, W_T, d, H))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("w_solve", ["block", "replicated"])
+def test_forced_one_rank_group_takes_the_sharded_branch(w_solve):
+    """Comm(force=True) with a process group of ONE rank (what bench.py RCPPML_BENCH_FORCE_DIST=1 builds on the GPU box with the nccl
+    backend): the loop runs its sharded branch -- partial Gram / right-hand side / row sums into the fused buffer, the all-reduce and
+    the all-gather really issued, D^-1 applied after the sum -- and lands on the unforced fit (scaling before the Gram) to rounding;
+    without `force` a one-rank group stays on the single-rank branch."""
+    ctx = mp.get_context("spawn")
+    out = {}
+    for force in (True, False):
+        q = ctx.Queue()
+        p = ctx.Process(target=_one_rank_worker, args=(_free_port(), dict(max_iter=6, tol=0.0, L1_H=2e-6, w_solve=w_solve), force, q))
+        p.start()
+        out[force] = q.get(timeout=240)
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    sharded, rows_per, res, W_T, d, H = out[True]
+    sharded0, rows_per0, res0, W_T0, d0, H0 = out[False]
+    assert sharded and not sharded0
+    assert rows_per % 4 == 0 and rows_per >= 90 and rows_per0 == 90            # forced: the padded block length of the all-gather
+    assert res["iter"] == res0["iter"]
+    assert abs(res["loss"] - res0["loss"]) <= 1e-9 * abs(res0["loss"])
+    assert np.abs(W_T - W_T0).max() < 1e-8 and np.abs(H - H0).max() < 1e-8 and np.abs(d - d0).max() <= 1e-8 * np.abs(d0).max()
