@@ -361,7 +361,7 @@ def main():
         roof_rhs = {"bound": "hbm",
                     "kernel": ("rhs_win_kernel + rhs_win_finish_kernel: SpMM-like B = F * A(:,j), F through a ring of LDS row tiles, nonzeros scheduled "
                                "over a sliding window, partition slabs + overflow summed by the finishing pass; both half-updates"
-                               if planned and all(p.get("kind", 1) == 1 for p in plan_info.values()) else
+                               if planned and all(p.get("kind", "window") == "window" for p in plan_info.values()) else
                                "rhs_tiled_kernel + spill / reduce kernels (slab plan): SpMM-like B = F * A(:,j), both half-updates"
                                if planned else "rhs_stage_kernel (gather form; SpMM-like B = F * A(:,j), both half-updates)"),
                     "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,

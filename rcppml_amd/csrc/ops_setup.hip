@@ -12,12 +12,30 @@
 namespace {
 
 constexpr int TR_RCH = 32768;        // rows per pass: 128 KiB of LDS counters
-// chunk b = columns [b cpb, (b+1) cpb): nonzeros per row -> cnt[b][row]
+// Chunks are cut by NONZEROS, on column boundaries (round 5; until then by column count, which left a matrix whose nonzeros sit in
+// a few columns to a few workgroups): chunk b = columns [bound(b), bound(b+1)), bound(b) = the first column j with
+// p[j] >= floor(b nnz / B) (bound(0) = 0, bound(B) = cols) -- non-decreasing in b, so the chunks tile the columns; both kernels
+// evaluate the same function.  A single column heavier than nnz / B is still one chunk's.
+__device__ __forceinline__ int tr_bound(const int* __restrict__ p, int cols, int b, int B) {
+    if (b <= 0) return 0;
+    if (b >= B) return cols;
+    const int target = (int)((int64_t)p[cols] * b / B);
+    int lo = 0, hi = cols;                     // first j in [0, cols] with p[j] >= target (p[cols] = nnz >= target)
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (p[mid] < target) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+// chunk b: nonzeros per row -> cnt[b][row]
 __global__ __launch_bounds__(256) void transpose_count_kernel(const int* __restrict__ p, const int* __restrict__ ri, int cols, int rows,
-                                                              int cpb, int* __restrict__ cnt) {
+                                                              int* __restrict__ cnt) {
     extern __shared__ int tr_lc[];
+    __shared__ int bnd[2];
     const int b = blockIdx.x;
-    const int c0 = b * cpb, c1 = c0 + cpb < cols ? c0 + cpb : cols;
+    if (threadIdx.x < 2) bnd[threadIdx.x] = tr_bound(p, cols, b + (int)threadIdx.x, (int)gridDim.x);
+    __syncthreads();
+    const int c0 = bnd[0], c1 = bnd[1];
     const int e0 = p[c0], e1 = p[c1];
     for (int r0 = 0; r0 < rows; r0 += TR_RCH) {
         const int rc = rows - r0 < TR_RCH ? rows - r0 : TR_RCH;
@@ -48,11 +66,14 @@ __global__ void transpose_prefix_kernel(int* __restrict__ cnt, int rows, int B, 
 // chunk b hands out the positions of its nonzeros: column by column (a barrier between columns keeps the positions of one row
 // in column order), inside a column the nonzeros of different rows in parallel
 __global__ __launch_bounds__(256) void transpose_scatter_kernel(const int* __restrict__ p, const int* __restrict__ ri, int cols, int rows,
-                                                                int cpb, const int* __restrict__ cnt, const int* __restrict__ tp,
+                                                                const int* __restrict__ cnt, const int* __restrict__ tp,
                                                                 int* __restrict__ pos_out) {
     extern __shared__ int tr_lc[];
+    __shared__ int bnd[2];
     const int b = blockIdx.x;
-    const int c0 = b * cpb, c1 = c0 + cpb < cols ? c0 + cpb : cols;
+    if (threadIdx.x < 2) bnd[threadIdx.x] = tr_bound(p, cols, b + (int)threadIdx.x, (int)gridDim.x);
+    __syncthreads();
+    const int c0 = bnd[0], c1 = bnd[1];
     for (int r0 = 0; r0 < rows; r0 += TR_RCH) {
         const int rc = rows - r0 < TR_RCH ? rows - r0 : TR_RCH;
         for (int i = threadIdx.x; i < rc; i += 256) tr_lc[i] = tp[r0 + i] + cnt[(size_t)b * rows + r0 + i];
@@ -112,19 +133,18 @@ void transpose_sort(rcppml_hip_ctx* c, int rows, int cols, int64_t nnz, const in
     int B = cols < 512 ? cols : 512;
     const int64_t cap = (int64_t)(256u << 20) / ((int64_t)rows * 4);
     if (B > cap) B = cap < 1 ? 1 : (int)cap;
-    const int cpb = (cols + B - 1) / B;
-    B = (cols + cpb - 1) / cpb;
+    if (B < 1) B = 1;
     DevTmp table(c, (size_t)B * rows * sizeof(int)), rowcnt(c, ((size_t)rows + 1) * sizeof(int));
     const size_t lds = (size_t)(rows < TR_RCH ? rows : TR_RCH) * sizeof(int);
     static DynSmemOnce once_count, once_scatter;
     once_count.ensure(reinterpret_cast<const void*>(transpose_count_kernel), lds, c->device);
     once_scatter.ensure(reinterpret_cast<const void*>(transpose_scatter_kernel), lds, c->device);
-    hipLaunchKernelGGL(transpose_count_kernel, dim3(B), dim3(256), lds, c->stream, p, ri, cols, rows, cpb, (int*)table.p);
+    hipLaunchKernelGGL(transpose_count_kernel, dim3(B), dim3(256), lds, c->stream, p, ri, cols, rows, (int*)table.p);
     hipLaunchKernelGGL(transpose_prefix_kernel, dim3((unsigned)((rows + 1 + 255) / 256)), dim3(256), 0, c->stream, (int*)table.p, rows, B,
                        (int*)rowcnt.p);
     HIPCHK(hipGetLastError());
     rk::exclusive_scan_i32(c, (const int*)rowcnt.p, tp, (int64_t)rows + 1);          // row pointers (the last one = nnz)
-    hipLaunchKernelGGL(transpose_scatter_kernel, dim3(B), dim3(256), lds, c->stream, p, ri, cols, rows, cpb, (const int*)table.p,
+    hipLaunchKernelGGL(transpose_scatter_kernel, dim3(B), dim3(256), lds, c->stream, p, ri, cols, rows, (const int*)table.p,
                        (const int*)tp, pos_out);
     HIPCHK(hipGetLastError());
     // temporaries from the context's per-fit arena outlive this call; hipMalloc'ed ones must not be freed under the kernels

@@ -321,6 +321,39 @@ def test_transpose_csc_and_cast(env):
     assert np.array_equal(back.cpu().numpy(), dst.cpu().numpy().astype(np.float64))
 
 
+def test_transpose_csc_skewed_and_tall(env):
+    """The transpose's chunks are cut by nonzeros on column boundaries (round 5): matrices whose nonzeros sit in a few columns, with
+    empty columns between them and at both ends, more columns than chunks (512), and more rows than one LDS pass holds (32 768)."""
+    import scipy.sparse as sp
+    torch, _abi, ctx = env
+    from oracle.oracle import Csc
+    rs = np.random.default_rng(12)
+    cases = []
+    # (a) 3 000 columns, 40 of them dense-ish, the rest empty or with one entry; (b) tall: 70 000 rows, 900 columns, skewed
+    for (m, n, heavy, hd, ld) in ((500, 3000, 40, 0.6, 0.0005), (70000, 900, 12, 0.05, 0.00005)):
+        dens = np.full(n, ld)
+        dens[rs.choice(n, size=heavy, replace=False)] = hd
+        dens[:5] = 0.0; dens[-7:] = 0.0                          # empty columns at both ends
+        cols = []
+        for j in range(n):
+            cnt = rs.binomial(m, dens[j])
+            rows = np.sort(rs.choice(m, size=cnt, replace=False))
+            cols.append(sp.csc_matrix((rs.uniform(0.1, 1.0, cnt), (rows, np.zeros(cnt, int))), shape=(m, 1)))
+        M = sp.hstack(cols, format="csc"); M.sort_indices()
+        cases.append(Csc((m, n), M.indptr.astype(np.int32), M.indices.astype(np.int32), M.data.astype(np.float64)))
+    for A in cases:
+        m, n = A.rows, A.cols
+        At = A.transpose()
+        dp, di, dx = _csc_dev(torch, A, np.float64)
+        tp = torch.full((m + 1,), -1, dtype=torch.int32, device="cuda")
+        ti = torch.full((max(A.nnz, 1),), -1, dtype=torch.int32, device="cuda")
+        tx = torch.zeros((max(A.nnz, 1),), dtype=torch.float64, device="cuda")
+        ctx.transpose_csc(_abi.F64, m, n, dp, di, dx, tp, ti, tx)
+        assert np.array_equal(tp.cpu().numpy(), At.p.astype(np.int32))
+        assert np.array_equal(ti.cpu().numpy()[:A.nnz], At.i.astype(np.int32))
+        assert np.array_equal(tx.cpu().numpy()[:A.nnz], At.values(np.float64))
+
+
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 @pytest.mark.parametrize("k,dim", [(3, 37), (10, 500), (16, 64), (33, 1200), (64, 3001)])
 def test_apply_graph_reg(env, dtype, k, dim):
