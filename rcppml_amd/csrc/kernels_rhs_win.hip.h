@@ -531,60 +531,4 @@ __global__ __launch_bounds__(64 * NW) void rhs_win_kernel(const char* __restrict
     }
 }
 
-// ---------------------------------------------------------------------------
-// B(:,j) = sum_p Bp[p](:,j) (partition order) + the overflow nonzeros of column j (row order).  One 16-lane group per
-// column: a whole row of F per gather, U gathers in flight.  With P == 1 the tiled kernel has written B itself and this
-// kernel only adds the overflow (accumulate = 1); it is not launched at all when P == 1 and nothing overflowed.
-// ---------------------------------------------------------------------------
-template <class T, int NV, int U>
-__global__ __launch_bounds__(256) void rhs_win_finish_kernel(const T* __restrict__ Bp, int P, int64_t ncp, int accumulate,
-                                                             const int* __restrict__ ovptr, const int* __restrict__ ovrow,
-                                                             const T* __restrict__ ovval, int64_t ncols,
-                                                             const T* __restrict__ F, int k, T* __restrict__ B) {
-    typedef typename RtVec<T>::type V;
-    constexpr int VN = RtVec<T>::N;
-    const int64_t j = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
-    if (j >= ncols) return;
-    const int u = threadIdx.x & 15;
-    const int lo = (4 * u) * 4 / (int)sizeof(T);
-    V acc[NV];
-    if (accumulate) {
-#pragma unroll
-        for (int v = 0; v < NV; ++v) acc[v] = *reinterpret_cast<const V*>(B + j * k + lo + 64 * v * 4 / (int)sizeof(T));
-    } else {
-#pragma unroll
-        for (int v = 0; v < NV; ++v) acc[v] = *reinterpret_cast<const V*>(Bp + j * k + lo + 64 * v * 4 / (int)sizeof(T));
-        for (int p = 1; p < P; ++p)
-#pragma unroll
-            for (int v = 0; v < NV; ++v) acc[v] += *reinterpret_cast<const V*>(Bp + (p * ncp + j) * k + lo + 64 * v * 4 / (int)sizeof(T));
-    }
-    const int start = ovptr ? ovptr[j * P] : 0, end = ovptr ? ovptr[(j + 1) * P] : 0;     // one pointer per (column, partition)
-    const T* Fl = F + lo;
-    for (int i = start; i < end; i += U) {
-        int r[U];
-        T a[U];
-#pragma unroll
-        for (int x = 0; x < U; ++x) {
-            const int ii = i + x < end ? i + x : end - 1;
-            r[x] = ovrow[ii];
-            const T av = ovval[ii];
-            a[x] = i + x < end ? av : T(0);
-        }
-        V f[U][NV];
-#pragma unroll
-        for (int x = 0; x < U; ++x)
-#pragma unroll
-            for (int v = 0; v < NV; ++v) f[x][v] = *reinterpret_cast<const V*>(Fl + (int64_t)r[x] * k + 64 * v * 4 / (int)sizeof(T));
-#pragma unroll
-        for (int x = 0; x < U; ++x)
-#pragma unroll
-            for (int v = 0; v < NV; ++v)
-#pragma unroll
-                for (int e = 0; e < VN; ++e) acc[v][e] = rt_fma(a[x], f[x][v][e], acc[v][e]);
-    }
-    T* dst = B + j * k + lo;
-#pragma unroll
-    for (int v = 0; v < NV; ++v) *reinterpret_cast<V*>(dst + 64 * v * 4 / (int)sizeof(T)) = acc[v];
-}
-
 }  // namespace rk

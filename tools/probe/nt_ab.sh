@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B of the non-temporal hints on the window rhs (slot-stream LDS-DMA loads + the finishing pass's slab loads): RcppML_gpu.so (nt) against
+# A/B of the non-temporal hints on the window rhs (slot-stream LDS-DMA loads): RcppML_gpu.so (nt) against
 # RcppML_gpu_np.so (make BUILD=build_np OUT=../lib/RcppML_gpu_np.so RWFLAGS=-DRW_SLOTS_DEFAULT_POLICY), alternating, on one box.
 B="--no-cpu-baseline --no-cpu-ref --no-fp64-leg --no-plugin-figure --no-noop-count"
 for rep in 1 2 3; do
