@@ -2383,13 +2383,16 @@ static __global__ __launch_bounds__(256) void sum_partials2(const double* __rest
 // Column work order for the CD kernels: sort columns by DESCENDING sweep count of the previous solve (counting
 // sort, 128 bins).  A wave runs until its slowest column converges (measured on the bench workload: mean 37 sweeps
 // per column but 54 per 64-column wave), so grouping columns that need similar sweep counts removes ~30 % of the
-// wasted lane-sweeps, and long-running waves start first.  Columns are independent, so any order gives identical results.
+// wasted lane-sweeps, and long-running waves start first.  Columns are independent, so any order gives identical solutions.
 // ---------------------------------------------------------------------------
 // Two launches, no global atomics, nothing to zero beforehand: block b counts ITS contiguous chunk of the columns per bin
 // (order_hist_kernel -> part[b][128]); order_scatter_kernel, launched with the same grid, turns the table into "where
 // does bin x of block b start" (exclusive scan over bins of the totals + the counts of the blocks before b) and ranks
-// its chunk inside LDS.  The position of a column depends on the block decomposition only (inside one bin and block the
-// LDS atomics decide), so the layout is reproducible run to run up to that.
+// its chunk.  The sort is STABLE -- inside one bin the columns keep their ascending index: each wavefront takes a
+// contiguous quarter of the chunk, its bins start after those of the wavefronts before it, and inside a 64-column round
+// the rank is the number of lower lanes with the same key (ballot).  So the order is a function of `sweeps` alone: the
+// same fit lays its columns out the same way every run, and anything that ever reduces ACROSS columns in work order stays
+// reproducible (the round-5 probe of row sums formed in the CD epilogues needed it: profiles/r05_fused_norms_ab.txt).
 constexpr int ORDER_BLOCKS_MAX = 128;
 static __global__ __launch_bounds__(256) void order_hist_kernel(const int* __restrict__ sweeps, int64_t n,
                                                                   unsigned int* __restrict__ part /*gridDim.x x 128*/) {
@@ -2410,8 +2413,17 @@ static __global__ __launch_bounds__(256) void order_hist_kernel(const int* __res
 static __global__ __launch_bounds__(256) void order_scatter_kernel(const int* __restrict__ sweeps, int64_t n,
                                                                      const unsigned int* __restrict__ part /*gridDim.x x 128*/,
                                                                      int* __restrict__ order) {
-    __shared__ unsigned int cnt[128], base[128], half_total;
+    __shared__ unsigned int base[128], half_total;
     __shared__ unsigned int tsum[2][128], bsum[2][128];
+    __shared__ unsigned int wcnt[4][128];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t per = (n + gridDim.x - 1) / gridDim.x;
+    const int64_t i0 = (int64_t)blockIdx.x * per;
+    const int64_t i1 = i0 + per < n ? i0 + per : n;
+    const int64_t wper = (per + 3) / 4;                       // this wavefront's contiguous quarter [j0, j1)
+    const int64_t j0 = i0 + w * wper < i1 ? i0 + w * wper : i1;
+    const int64_t j1 = j0 + wper < i1 ? j0 + wper : i1;
+    for (int t = threadIdx.x; t < 4 * 128; t += 256) (&wcnt[0][0])[t] = 0;
     // bin totals over all blocks, and the part of them that lies in blocks before this one: thread (h, x) sums every
     // second row of the table for bin x -- gridDim.x / 2 independent coalesced loads per thread instead of gridDim.x
     // dependent-looking ones in half of the threads
@@ -2428,6 +2440,11 @@ static __global__ __launch_bounds__(256) void order_scatter_kernel(const int* __
         bsum[h][x] = before;
     }
     __syncthreads();
+    for (int64_t i = j0 + lane; i < j1; i += 64) {            // per-wavefront bin counts of the quarter
+        int key = sweeps[i];
+        key = key < 0 ? 0 : (key > 127 ? 127 : key);
+        atomicAdd(&wcnt[w][127 - key], 1u);
+    }
     if (threadIdx.x < 128) {
         const unsigned int tot = tsum[0][threadIdx.x] + tsum[1][threadIdx.x];
         const unsigned int before = bsum[0][threadIdx.x] + bsum[1][threadIdx.x];
@@ -2437,28 +2454,42 @@ static __global__ __launch_bounds__(256) void order_scatter_kernel(const int* __
         for (int d = 1; d < 64; d <<= 1) { const unsigned int t = __shfl_up(incl, d, 64); if ((threadIdx.x & 63) >= d) incl += t; }
         if (threadIdx.x == 63) half_total = incl;        // total of bins 0..63
         base[threadIdx.x] = incl - tot + before;
-        cnt[threadIdx.x] = 0;
     }
     __syncthreads();
-    if (threadIdx.x >= 64 && threadIdx.x < 128) base[threadIdx.x] += half_total;
-    __syncthreads();
-    const int64_t per = (n + gridDim.x - 1) / gridDim.x;
-    const int64_t i0 = (int64_t)blockIdx.x * per;
-    const int64_t i1 = i0 + per < n ? i0 + per : n;
-    for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) {
-        int key = sweeps[i];
-        key = key < 0 ? 0 : (key > 127 ? 127 : key);
-        unsigned int pos = base[127 - key] + atomicAdd(&cnt[127 - key], 1u);
+    // lane l of a wavefront carries the running start of bins l and l + 64 of ITS quarter in registers
+    unsigned int b_lo = base[lane], b_hi = base[lane + 64] + half_total;
+    for (int v = 0; v < w; ++v) { b_lo += wcnt[v][lane]; b_hi += wcnt[v][lane + 64]; }
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    for (int64_t r = j0; r < j1; r += 64) {
+        const int64_t i = r + lane;
+        const bool valid = i < j1;
+        int bin = -1;
+        if (valid) {
+            int key = sweeps[i];
+            key = key < 0 ? 0 : (key > 127 ? 127 : key);
+            bin = 127 - key;
+        }
+        unsigned long long todo = __ballot(valid);
+        unsigned int pos = 0;
+        while (todo) {                                         // one turn per distinct key among the 64 columns
+            const int src = __ffsll((long long)todo) - 1;
+            const int kb = __shfl(bin, src, 64);
+            const unsigned long long grp = __ballot(bin == kb);
+            const unsigned int start = __shfl(kb < 64 ? b_lo : b_hi, kb & 63, 64);
+            if (bin == kb) pos = start + (unsigned int)__popcll(grp & lt);
+            if (lane == (kb & 63)) { if (kb < 64) b_lo += (unsigned int)__popcll(grp); else b_hi += (unsigned int)__popcll(grp); }
+            todo &= ~grp;
+        }
         // Serpentine: positions are handed out longest-first; every second group of 16 workgroups (128 slots each: four
         // 32-column or eight 16-column wavefronts) is laid out in reverse, so that neighbouring workgroups -- which the
         // dispatcher places on the same XCD / CU one after the other -- mix long and short tiles instead of stacking the
         // longest ones (measured on C2's H side: 494 -> 470 us, tools/probe/cd_order_probe.py; any period from 8 to 128
         // workgroups gives the same).  Only whole groups of full blocks are reversed: a bijection on the positions.
-        {
+        if (valid) {
             const unsigned int blk = pos >> 7, grp = blk >> 4;
             if ((grp & 1u) && (uint64_t)(grp + 1u) * 16u <= (uint64_t)(n >> 7)) pos = (((grp << 4) + 15u - (blk & 15u)) << 7) | (pos & 127u);
+            order[pos] = (int)i;
         }
-        order[pos] = (int)i;
     }
 }
 

@@ -387,7 +387,8 @@ def test_order_columns_permutation_and_order_invariance(env, n):
     """rcppml_hip_order_columns: the work order is a permutation of the columns, longest-first up to the serpentine
     layout (every group of 16 x 128 slots holds exactly the columns the descending sort puts there), and the CD kernels
     (32- and 16-column MFMA tiles) return bit-identical solutions with and without it -- columns are independent
-    (reference nnls_batch.hpp:70-132 solves them one by one)."""
+    (reference nnls_batch.hpp:70-132 solves them one by one).  Equal keys keep their column order (stable sort): the
+    layout is a function of the sweep counts alone."""
     torch, _abi, ctx = env
     rs = np.random.default_rng(n)
     sw = rs.integers(0, 140, size=n).astype(np.int32)            # counts above 127 share the last bin
@@ -402,6 +403,15 @@ def test_order_columns_permutation_and_order_invariance(env, n):
     for g0 in range(0, n, 2048):
         assert np.array_equal(np.sort(got[g0:g0 + 2048]), np.sort(want[g0:g0 + 2048])), g0
     assert np.all(np.diff(got[:128]) <= 0)                        # inside a block: still descending
+    # the sort is stable (equal keys keep their ascending column index), so the layout is a function of `sweeps` alone: the
+    # stable descending sort, then every second FULL group of 16 blocks x 128 slots with its blocks in reverse
+    pos = np.arange(n)
+    blk, grp = pos >> 7, pos >> 11
+    rev = ((grp & 1) == 1) & ((grp + 1) * 16 <= (n >> 7))
+    dest = np.where(rev, (((grp << 4) + 15 - (blk & 15)) << 7) | (pos & 127), pos)
+    expect = np.empty(n, np.int64)
+    expect[dest] = np.argsort(-key.astype(np.int64), kind="stable")
+    assert np.array_equal(order, expect)
     k = 24
     Fm = rs.uniform(size=(4 * k, k))
     G = (Fm.T @ Fm).astype(np.float32)
@@ -465,3 +475,4 @@ def test_cd_lmf_geometries_and_refill(env, lg, k):
     finally:
         ctx.set_option(_abi.OPT_CD_LMF_LANE_GROUPS, 0)
         ctx.set_option(_abi.OPT_CD_LMF_WAVES_PER_SIMD, 0)
+
