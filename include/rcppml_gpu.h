@@ -204,6 +204,20 @@ RCPPML_GPU_API void rcppml_gpu_evaluate_mse_double(const int* col_ptr, const int
                                                    const double* H, int* mask_zeros,
                                                    double* out_loss, int* out_status);
 
+/* Per-phase profile of the batch-CD ALS iteration -- the reference's `rcppml_gpu_nmf_profile_double`
+ * (src/gpu_bridge_utils.cu:48-57: the same fifteen pointers, in order; :14-36 the slots).  fp64; W_T and H from
+ * SplitMix64(*seed) (one stream, W_T first: initialize_factors), d = 1; one untimed warm-up iteration, then up to *max_iter
+ * iterations with a HIP-event pair around every phase and `|prev - loss| / (|prev| + 1e-15) < *tol` from the second timed
+ * iteration on; every solve runs *cd_maxit sweeps (no tolerance stop), cold solves start from max(B, 0).
+ * out_phase_ms_total[11] / out_phase_ms_per_iter[11] (total / *out_n_iters), slots:
+ *   0 gram_H   1 rhs_H   2 nnls_H   3 norm_H   4 gram_W   5 rhs_W by the plan-free gather kernel (the reference's slot holds
+ *   its atomicAdd baseline; it is not used by the solve here either)   6 rhs_W planned   7 nnls_W   8 norm_W   9 loss   10 iteration.
+ * *out_status 0 / -1 (rcppml_gpu_last_error). */
+RCPPML_GPU_API void rcppml_gpu_nmf_profile_double(const int* col_ptr, const int* row_idx, const double* values,
+                                                  int* m, int* n, int* nnz, int* k, int* max_iter, double* tol,
+                                                  int* cd_maxit, int* seed, double* out_phase_ms_total,
+                                                  double* out_phase_ms_per_iter, int* out_n_iters, int* out_status);
+
 /* Last error text of the calling thread ("" if none). */
 RCPPML_GPU_API const char* rcppml_gpu_last_error(void);
 

@@ -21,7 +21,7 @@ OPT_CD_COUNT_NOOP, OPT_CD_LMF_LANE_GROUPS, OPT_CD_LMF_WAVES_PER_SIMD, OPT_CD_NO_
 EXPORTED_SYMBOLS = [
     "rcppml_gpu_detect", "rcppml_gpu_nmf_unified_float", "rcppml_gpu_nmf_unified_double", "rcppml_gpu_nmf_ex",
     "rcppml_gpu_nmf_cv_unified_float", "rcppml_gpu_nmf_cv_unified_double", "rcppml_gpu_nmf_cv_ex", "rcppml_gpu_nmf_cv_irls_ex", "rcppml_gpu_nmf_zerocopy_double",
-    "rcppml_gpu_nnls_double", "rcppml_gpu_evaluate_mse_double", "rcppml_gpu_last_error",
+    "rcppml_gpu_nnls_double", "rcppml_gpu_evaluate_mse_double", "rcppml_gpu_nmf_profile_double", "rcppml_gpu_last_error",
     "rcppml_hip_ctx_create", "rcppml_hip_ctx_destroy", "rcppml_hip_ctx_sync", "rcppml_hip_ctx_stats", "rcppml_hip_ctx_irls_stats", "rcppml_hip_ctx_cd_step_stats", "rcppml_hip_ctx_set_option", "rcppml_hip_transpose_csc", "rcppml_hip_transpose_csc_sort", "rcppml_hip_transpose_csc_gather", "rcppml_hip_cast", "rcppml_hip_gram", "rcppml_hip_rhs",
     "rcppml_hip_solve_cd", "rcppml_hip_order_columns", "rcppml_hip_solve_chol", "rcppml_hip_row_norms", "rcppml_hip_apply_scaling",
     "rcppml_hip_sumsq", "rcppml_hip_loss_mse", "rcppml_hip_solve_masked", "rcppml_hip_loss_nonzeros", "rcppml_hip_loss_masked",
@@ -240,6 +240,22 @@ def evaluate_mse_double(p, i, x, m, n, k, W_T, d, H, mask_zeros=False):
     if st.value != 0:
         raise BackendError("rcppml_gpu_evaluate_mse_double: " + last_error())
     return out.value
+
+
+PROFILE_PHASES = ("gram_H", "rhs_H", "nnls_H", "norm_H", "gram_W", "rhs_W_gather", "rhs_W_planned", "nnls_W", "norm_W", "loss", "total")
+
+
+def nmf_profile_double(p, i, x, m, n, k, max_iter=10, tol=0.0, cd_maxit=10, seed=42):
+    """rcppml_gpu_nmf_profile_double (reference src/gpu_bridge_utils.cu:48): per-phase HIP-event times of the batch-CD ALS
+    iteration.  Returns dict(total_ms, per_iter_ms: {phase: ms}, iters)."""
+    p = np.ascontiguousarray(p, np.int32); i = np.ascontiguousarray(i, np.int32); x = np.ascontiguousarray(x, np.float64)
+    tot, per = np.zeros(11), np.zeros(11)
+    it, st = C.c_int(0), C.c_int(-99)
+    lib().rcppml_gpu_nmf_profile_double(_np_ptr(p), _np_ptr(i), _np_ptr(x), _ci(m), _ci(n), _ci(x.shape[0]), _ci(k), _ci(max_iter),
+                                        _cd(tol), _ci(cd_maxit), _ci(seed), _np_ptr(tot), _np_ptr(per), C.byref(it), C.byref(st))
+    if st.value != 0:
+        raise BackendError("rcppml_gpu_nmf_profile_double: " + last_error())
+    return dict(total_ms=dict(zip(PROFILE_PHASES, tot.tolist())), per_iter_ms=dict(zip(PROFILE_PHASES, per.tolist())), iters=it.value)
 
 
 # ----------------------------------------------------------------------------- device-level ops

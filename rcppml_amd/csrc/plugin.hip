@@ -1223,3 +1223,165 @@ extern "C" void rcppml_gpu_evaluate_mse_double(const int* col_ptr, const int* ro
         *out_status = -1;
     } catch (...) { rcppml_err() = "unknown error"; *out_status = -1; }
 }
+
+// ----------------------------------------------------------------------------
+// Per-phase profile of the batch-CD ALS iteration: the reference's `rcppml_gpu_nmf_profile_double`
+// (src/gpu_bridge_utils.cu:14-36 the eleven slots, :48-57 the fifteen pointers, :131-142 the untimed warm-up iteration,
+// :145-285 the loop: an event pair around every phase, one synchronisation per iteration, `rel < tol` on the loss from the
+// second timed iteration on).  Same protocol here -- SplitMix64(seed) fills W_T then H (one stream, :96-99 = initialize_factors),
+// d = 1, fixed `cd_maxit` sweeps per solve (no tolerance stop), cold solves start from max(B, 0) and later ones from the previous
+// factor (gpu/batch_nnls.cuh:66-75), L1 row scaling -- with this library's kernels in the slots:
+//   [0] gram_H  [1] rhs_H (planned, LDS row tiles)  [2] nnls_H  [3] norm_H  [4] gram_W
+//   [5] rhs_W by the plan-free gather kernel on CSC(A^T) (the reference's slot times its atomicAdd form as the baseline; there is
+//       no atomic form in this build -- the gather kernel is what runs when no plan exists)
+//   [6] rhs_W planned (the one the solve uses)  [7] nnls_W  [8] norm_W  [9] loss (Gram(W) + Gram-trick terms)  [10] iteration
+// The loss is the exact ||A - W diag(d) H||^2 of the factors the iteration ends with (fit_cpu.hpp:1710-1753); the reference's
+// profiler pairs the new W with the right-hand side of the old one (:248-262) -- its value only feeds the stopping rule.
+namespace {
+template <class T>
+__global__ void clip_copy_kernel(const T* __restrict__ in, int64_t n, T* __restrict__ out) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < n) out[e] = in[e] > T(0) ? in[e] : T(0);
+}
+// uniform<double>() of SplitMix64 (rng/rng.hpp:100-104): next() / 2^64, state advanced by the golden gamma
+struct SplitMixStream {
+    uint64_t s;
+    explicit SplitMixStream(uint64_t seed) : s(seed == 0 ? 12345ULL : seed) {}
+    double uniform() {
+        s += 0x9E3779B97F4A7C15ULL;
+        uint64_t z = s;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+        z ^= z >> 31;
+        return static_cast<double>(z) / 18446744073709551616.0;
+    }
+};
+}  // namespace
+
+extern "C" void rcppml_gpu_nmf_profile_double(const int* col_ptr, const int* row_idx, const double* values, int* m_ptr, int* n_ptr,
+                                              int* nnz_ptr, int* k_ptr, int* max_iter_ptr, double* tol_ptr, int* cd_maxit_ptr,
+                                              int* seed_ptr, double* out_phase_ms_total, double* out_phase_ms_per_iter,
+                                              int* out_n_iters, int* out_status) {
+    constexpr int NP = 11;
+    for (int p = 0; p < NP; ++p) out_phase_ms_total[p] = out_phase_ms_per_iter[p] = 0.0;
+    *out_n_iters = 0;
+    *out_status = -1;
+    hipEvent_t ev0[NP] = {}, ev1[NP] = {};
+    try {
+        rcppml_err().clear();
+        const int m = *m_ptr, n = *n_ptr, nnz = *nnz_ptr, k = *k_ptr, max_iter = *max_iter_ptr, cd_maxit = *cd_maxit_ptr;
+        const double tol = *tol_ptr;
+        if (k < 1 || k > 256) throw std::runtime_error("k must be in [1,256]");
+        if (m < 1 || n < 1 || nnz < 0 || col_ptr[n] != nnz) throw std::runtime_error("profile: inconsistent CSC");
+        constexpr int dt = RCPPML_F64;
+        CtxGuard g(env_device());
+        rcppml_hip_ctx* c = g.c;
+        hipStream_t s = g.s;
+        DevBuf dAp, dAi, dAx, dTp, dTi, dTx, dW, dH, dd;
+        upload_ints(col_ptr, (size_t)n + 1, dAp, s);
+        upload_ints(row_idx, (size_t)std::max(nnz, 1), dAi, s);
+        upload_cast<double>(c, values, (size_t)std::max(nnz, 1), dAx, s);
+        dTp.alloc(((size_t)m + 1) * sizeof(int));
+        dTi.alloc((size_t)std::max(nnz, 1) * sizeof(int));
+        dTx.alloc((size_t)std::max(nnz, 1) * sizeof(double));
+        OPCHK(rcppml_hip_transpose_csc(c, dt, m, n, dAp.as<int>(), dAi.as<int>(), dAx.p, dTp.as<int>(), dTi.as<int>(), dTx.p));
+        struct PlanGuard { rcppml_rhs_plan* p = nullptr; ~PlanGuard() { rcppml_hip_rhs_plan_destroy(p); } } planA, planT;
+        if (nnz >= (1 << 20)) {
+            plan_or_none(rcppml_hip_rhs_plan_create(c, dt, dAp.as<int>(), dAi.as<int>(), dAx.p, n, m, k, 0, 0, &planA.p), planA.p);
+            plan_or_none(rcppml_hip_rhs_plan_create(c, dt, dTp.as<int>(), dTi.as<int>(), dTx.p, m, n, k, 0, 0, &planT.p), planT.p);
+        }
+        {
+            SplitMixStream rng(static_cast<uint32_t>(*seed_ptr));
+            std::vector<double> w((size_t)k * m), h((size_t)k * n), ones(k, 1.0);
+            for (auto& v : w) v = rng.uniform();
+            for (auto& v : h) v = rng.uniform();
+            upload_cast<double>(c, w.data(), w.size(), dW, s);
+            upload_cast<double>(c, h.data(), h.size(), dH, s);
+            upload_cast<double>(c, ones.data(), ones.size(), dd, s);
+        }
+        DevBuf dBh((size_t)k * n * 8), dBw((size_t)k * m * 8), dBbase((size_t)k * m * 8);
+        DevBuf dG((size_t)k * k * 8), dGs((size_t)k * k * 8), dGwt((size_t)k * k * 8), dsums((size_t)k * 8);
+        DevBuf dtr(sizeof(double)), dloss(4 * sizeof(double));
+        OPCHK(rcppml_hip_sumsq(c, dt, dAx.p, nnz, dtr.as<double>()));
+        for (int p = 0; p < NP; ++p) { HIPCHK(hipEventCreate(&ev0[p])); HIPCHK(hipEventCreate(&ev1[p])); }
+        auto rhs_fwd = [&]() {
+            if (planA.p) OPCHK(rcppml_hip_rhs_planned(c, planA.p, dW.p, dBh.p));
+            else OPCHK(rcppml_hip_rhs(c, dt, dAp.as<int>(), dAi.as<int>(), dAx.p, n, dW.p, k, dBh.p));
+        };
+        auto rhs_bwd = [&]() {
+            if (planT.p) OPCHK(rcppml_hip_rhs_planned(c, planT.p, dH.p, dBw.p));
+            else OPCHK(rcppml_hip_rhs(c, dt, dTp.as<int>(), dTi.as<int>(), dTx.p, m, dH.p, k, dBw.p));
+        };
+        auto solve = [&](DevBuf& B, DevBuf& X, int64_t ncols, bool warm) {
+            if (!warm) {
+                const int64_t tot = (int64_t)k * ncols;
+                hipLaunchKernelGGL(clip_copy_kernel<double>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, B.as<double>(), tot, X.as<double>());
+                HIPCHK(hipGetLastError());
+            }
+            // the previous (or clipped) solution as the start: b -= G x, then cd_maxit sweeps, no tolerance stop
+            OPCHK(rcppml_hip_solve_cd(c, dt, dG.p, B.p, X.p, k, ncols, 0.0, 1, 0, 0.0, 0.0, 1, cd_maxit, 0.0, 0.0, 0.0, RCPPML_CD_AUTO, nullptr, nullptr));
+        };
+        auto scale = [&](DevBuf& X, int64_t ncols) {
+            OPCHK(rcppml_hip_row_norms(c, dt, X.p, k, ncols, 0, dsums.p));
+            OPCHK(rcppml_hip_apply_scaling(c, dt, X.p, k, ncols, 0, dsums.p, dd.p));
+        };
+        auto timed = [&](int p, auto&& body) {
+            HIPCHK(hipEventRecord(ev0[p], s));
+            body();
+            HIPCHK(hipEventRecord(ev1[p], s));
+        };
+        // warm-up iteration (:131-142): cold solves, no timing
+        OPCHK(rcppml_hip_gram(c, dt, dW.p, k, m, 1e-15, 0.0, dG.p));
+        rhs_fwd();
+        solve(dBh, dH, n, false);
+        scale(dH, n);
+        OPCHK(rcppml_hip_gram(c, dt, dH.p, k, n, 1e-15, 0.0, dG.p));
+        rhs_bwd();
+        solve(dBw, dW, m, false);
+        scale(dW, m);
+        HIPCHK(hipStreamSynchronize(s));
+        double prev_loss = std::numeric_limits<double>::max();
+        bool converged = false;
+        int iters = 0;
+        double hl[4];
+        for (int iter = 0; iter < max_iter && !converged; ++iter) {
+            HIPCHK(hipEventRecord(ev0[10], s));
+            timed(0, [&] { OPCHK(rcppml_hip_gram(c, dt, dW.p, k, m, 1e-15, 0.0, dG.p)); });
+            timed(1, [&] { rhs_fwd(); });
+            timed(2, [&] { solve(dBh, dH, n, iter > 0); });
+            timed(3, [&] { scale(dH, n); });
+            timed(4, [&] { OPCHK(rcppml_hip_gram(c, dt, dH.p, k, n, 1e-15, 0.0, dG.p)); });
+            timed(5, [&] { OPCHK(rcppml_hip_rhs(c, dt, dTp.as<int>(), dTi.as<int>(), dTx.p, m, dH.p, k, dBbase.p)); });
+            timed(6, [&] { rhs_bwd(); });
+            HIPCHK(hipMemcpyAsync(dGs.p, dG.p, (size_t)k * k * 8, hipMemcpyDeviceToDevice, s));           // Gram(H) for the loss
+            timed(7, [&] { solve(dBw, dW, m, iter > 0); });
+            timed(8, [&] { scale(dW, m); });
+            timed(9, [&] {
+                OPCHK(rcppml_hip_gram(c, dt, dW.p, k, m, 1e-15, 0.0, dGwt.p));
+                OPCHK(rcppml_hip_loss_mse(c, dt, dtr.as<double>(), dd.p, dW.p, dBw.p, k, m, dGwt.p, dGs.p, dloss.as<double>()));
+            });
+            HIPCHK(hipEventRecord(ev1[10], s));
+            HIPCHK(hipMemcpyAsync(hl, dloss.p, 4 * sizeof(double), hipMemcpyDeviceToHost, s));
+            HIPCHK(hipStreamSynchronize(s));
+            for (int p = 0; p < NP; ++p) {
+                float ms = 0.f;
+                HIPCHK(hipEventElapsedTime(&ms, ev0[p], ev1[p]));
+                out_phase_ms_total[p] += static_cast<double>(ms);
+            }
+            ++iters;
+            const double loss_val = hl[0];
+            if (iter > 0 && prev_loss > 0) {
+                const double rel = std::fabs(prev_loss - loss_val) / (std::fabs(prev_loss) + 1e-15);
+                if (rel < tol) converged = true;
+            }
+            prev_loss = loss_val;
+        }
+        *out_n_iters = iters;
+        if (iters > 0) for (int p = 0; p < NP; ++p) out_phase_ms_per_iter[p] = out_phase_ms_total[p] / iters;
+        *out_status = 0;
+    } catch (const std::exception& e) {
+        rcppml_err() = e.what();
+        *out_status = -1;
+    } catch (...) { rcppml_err() = "unknown error"; *out_status = -1; }
+    for (int p = 0; p < NP; ++p) { if (ev0[p]) (void)hipEventDestroy(ev0[p]); if (ev1[p]) (void)hipEventDestroy(ev1[p]); }
+}

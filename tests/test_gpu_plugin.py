@@ -489,3 +489,53 @@ def test_zerocopy_entry_matches_host_entry(abi):
     assert np.array_equal(dx.cpu().numpy(), A.x) and np.array_equal(di.cpu().numpy(), A.i.astype(np.int32))
     bad = abi.nmf_zerocopy(dp, di, dx, A.rows, A.cols, A.nnz, k, W2, H2, max_iter=2, loss_type=2)      # Huber: not a loss of this build
     assert bad["status"] == -1
+
+
+def test_profile_entry_phases_and_stopping_rule(abi):
+    """rcppml_gpu_nmf_profile_double (reference src/gpu_bridge_utils.cu:48-57, the aux entry SURVEY.md section 5 lists): eleven
+    HIP-event phase times per iteration, and the reference's stopping rule on the loss.  The protocol (:96-99 SplitMix64(seed)
+    factors, :131-142 untimed warm-up iteration, fixed cd_maxit sweeps from max(B, 0) / the previous factor, L1 scaling, rel < tol
+    from the second timed iteration) is restated here with the oracle's column CD, and the number of iterations the entry runs
+    under a tolerance chosen in the widest gap of the oracle's loss sequence has to match."""
+    A = lowrank_csc(70, 55, 4, 0.5, seed=9)
+    m, n, k, cd_maxit, seed = A.rows, A.cols, 5, 7, 11
+    D = np.zeros((m, n))
+    for j in range(n):
+        D[A.i[A.p[j]:A.p[j + 1]], j] = A.x[A.p[j]:A.p[j + 1]]
+    W, H = O.init_factors(seed, k, m, n, np.float64)
+    d = np.ones(k)
+
+    def half(F, Bm, X, cold):
+        G = F.T @ F + 1e-15 * np.eye(k)
+        B = Bm @ F
+        out = np.empty_like(X)
+        for j in range(B.shape[0]):
+            x0 = np.maximum(B[j], 0) if cold else X[j]
+            out[j], _, _ = O.cd_col(G, B[j] - G @ x0, x0, maxit=cd_maxit, tol=0.0)
+        s = np.abs(out).sum(axis=0)
+        return out / (s + 1e-15), s + 1e-15
+
+    H, d = half(W, D.T, H, True)
+    W, d = half(H, D, W, True)
+    rels, prev = [], None
+    for it in range(12):
+        H, d = half(W, D.T, H, it == 0)
+        W, d = half(H, D, W, it == 0)
+        loss = ((D - (W * d) @ H.T) ** 2).sum()
+        if it > 0:
+            rels.append(abs(prev - loss) / (abs(prev) + 1e-15))
+        prev = loss
+    # stop at the first rel < tol: pick tol in the widest relative gap between consecutive (decreasing) rels
+    best = max(range(len(rels) - 1), key=lambda t: rels[t] / max(rels[t + 1], 1e-300) if rels[t + 1] < rels[t] and all(r > rels[t + 1] for r in rels[:t + 1]) else 0)
+    assert rels[best] / rels[best + 1] > 1.3
+    tol = float(np.sqrt(rels[best] * rels[best + 1]))
+    res = abi.nmf_profile_double(A.p, A.i, A.x, m, n, k, max_iter=12, tol=tol, cd_maxit=cd_maxit, seed=seed)
+    assert res["iters"] == best + 3                      # timed iteration 0 has no check; rels[t] belongs to timed iteration t + 1
+    per, tot = res["per_iter_ms"], res["total_ms"]
+    assert set(per) == set(abi.PROFILE_PHASES) and all(v > 0 for v in per.values())
+    assert all(abs(tot[p] - per[p] * res["iters"]) <= 1e-9 * tot[p] for p in per)
+    assert sum(v for p, v in per.items() if p != "total") <= per["total"] * 1.05
+    full = abi.nmf_profile_double(A.p, A.i, A.x, m, n, k, max_iter=4, tol=0.0, cd_maxit=cd_maxit, seed=seed)
+    assert full["iters"] == 4
+    with pytest.raises(abi.BackendError):
+        abi.nmf_profile_double(A.p, A.i, A.x, m, n, 300, max_iter=1)
