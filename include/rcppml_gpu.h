@@ -147,7 +147,11 @@ RCPPML_GPU_API void rcppml_gpu_nmf_cv_irls_ex(RCPPML_NMF_CV_ARGS, int* sort_mode
  * matrix as doubles on the host; W (k x m), H (k x n), d in/out as in the sparse entry.  Semantics: the reference's
  * STANDARD path (separate RHS -> features -> nnls_batch / cholesky_clip_batch, nmf/fit_cpu.hpp:540-631, :774-881) --
  * zero start at iteration 0, residual-corrected warm start afterwards -- MSE loss; L1, L2, L21, angular, bounds,
- * projective, symmetric.  `_double` is build-defined (fp64 compute). */
+ * projective, symmetric.  loss_type 4..8 and robust_delta > 0 (round 5): the dense IRLS half-updates
+ * (nnls_batch_irls_dense, nmf/fit_cpu.hpp:607-614, :855-863 -- EVERY entry weighted, zeros included, each batch from zero),
+ * the dense branches of the dispersion updates and explicit_loss_dense; CD solver, k <= 128, m * n < 2^31, no L21 / angular /
+ * projective / symmetric; gamma_phi_* take the config defaults (no slot); out_theta holds max(m, n) doubles
+ * (gpu/bridge_nmf.hpp:622), *out_theta_len = m, or n under dispersion mode 3.  `_double` is build-defined (fp64 compute). */
 #define RCPPML_NMF_DENSE_ARGS                                                                       \
     const double* A_data, int* m, int* n, int* k, double* W, double* H, double* d, int* max_iter,   \
         double* tol, double* L1_H, double* L1_W, double* L2_H, double* L2_W, double* L21_H,         \

@@ -656,7 +656,9 @@ template <class S>
 static void nnls_batch_irls_sparse_nb(const Csc<S>& A, const S* F, const S* G_base, S* X, int k,
                                       S L1, S L2, bool nonneg, int cd_maxit, int irls_max_iter,
                                       S irls_tol, int threads, const S* theta_row,
-                                      const S* theta_col, int loss_type = 5, S power = S(1.5), S robust = S(0)) {
+                                      const S* theta_col, int loss_type = 5, S power = S(1.5), S robust = S(0), bool dense = false) {
+    // dense: irls_nnls_col_dense (nnls_batch_irls.hpp:376-450; batch :525-555, H.setZero() there too) -- every row of the column is
+    // stored and weighted, and G_w = sum_i w_i f_i f_i^T is formed from nothing (no G_base, hence no eps on its diagonal)
     const int nt = eff_threads(threads); (void)nt;
     std::fill(X, X + (size_t)k * A.cols, S(0));   // H.setZero(): no warm start across ALS iters
 #pragma omp parallel num_threads(nt)
@@ -666,7 +668,8 @@ static void nnls_batch_irls_sparse_nb(const Csc<S>& A, const S* F, const S* G_ba
         for (int j = 0; j < A.cols; ++j) {
             S* x = X + (size_t)j * k;
             for (int it = 0; it < irls_max_iter; ++it) {
-                std::memcpy(Gw.data(), G_base, sizeof(S) * k * k);
+                if (dense) std::fill(Gw.begin(), Gw.end(), S(0));
+                else std::memcpy(Gw.data(), G_base, sizeof(S) * k * k);
                 for (int f = 0; f < k; ++f) bw[f] = 0;
                 for (int t = A.p[j]; t < A.p[j + 1]; ++t) {
                     const int row = A.i[t];
@@ -675,7 +678,7 @@ static void nnls_batch_irls_sparse_nb(const Csc<S>& A, const S* F, const S* G_ba
                     for (int f = 0; f < k; ++f) recon += fr[f] * x[f];
                     const S th = theta_col ? theta_col[j] : (theta_row ? theta_row[row] : S(0));
                     const S w = compute_irls_weight(loss_type, A.x[t] - recon, recon, th, power, robust);
-                    const S dw = w - S(1);
+                    const S dw = dense ? w : w - S(1);
                     const S wv = w * A.x[t];
                     // G_w += dw * f f^T  (reference: W_nnz_scaled * W_block^T)
                     for (int c = 0; c < k; ++c) {
@@ -711,6 +714,43 @@ static void nb_size_update(const Csc<S>& A, const S* W_T, const S* H, const S* d
     std::vector<S> Wd((size_t)k * m);
     for (int i = 0; i < m; ++i) for (int f = 0; f < k; ++f) Wd[(size_t)i * k + f] = W_T[(size_t)i * k + f] * d[f];
     const double r_min = static_cast<double>(cfg.nb_size_min), r_max = static_cast<double>(cfg.nb_size_max);
+    if (cfg.dense_input) {
+        // dense branches (:1137-1148 PER_COL, :1226-1238 PER_ROW / GLOBAL): EVERY entry with its prediction floored at 1e-10, no
+        // Gram-trick totals; then the same moment estimator and clamps (:1151-1160, :1241-1262)
+        const bool pc = cfg.dispersion_mode == 3;
+        const int len = pc ? n : m;
+        std::vector<double> a_mu2(len, 0.0), a_exc(len, 0.0);
+        for (int j = 0; j < n; ++j) {
+            const S* h = H + (size_t)j * k;
+            for (int t = A.p[j]; t < A.p[j + 1]; ++t) {
+                const S* w = Wd.data() + (size_t)A.i[t] * k;
+                S dot = 0;
+                for (int f = 0; f < k; ++f) dot += w[f] * h[f];
+                const double y = static_cast<double>(A.x[t]);
+                const double mu = std::max(static_cast<double>(dot), 1e-10);
+                const double resid = y - mu;
+                const int o = pc ? j : A.i[t];
+                a_mu2[o] += mu * mu;
+                a_exc[o] += resid * resid - mu;
+            }
+        }
+        for (int o = 0; o < len; ++o) {
+            if (a_exc[o] > 1e-10 && a_mu2[o] > 1e-10) {
+                double r_new = a_mu2[o] / a_exc[o];
+                r_new = std::max(r_min, std::min(r_new, r_max));
+                if (std::isfinite(r_new)) nb_size[o] = static_cast<S>(r_new);
+            } else {
+                nb_size[o] = static_cast<S>(r_max);
+            }
+        }
+        if (cfg.dispersion_mode == 1) {
+            std::vector<S> r_vals(nb_size.begin(), nb_size.begin() + m);
+            std::nth_element(r_vals.begin(), r_vals.begin() + m / 2, r_vals.end());
+            const S med = r_vals[m / 2];
+            std::fill(nb_size.begin(), nb_size.end(), med);
+        }
+        return;
+    }
     if (cfg.dispersion_mode == 3) {
         // :1103-1162 PER_COL: per column j the nonzero sums, then the zeros' share from the totals over ALL rows, which the
         // reference forms by a direct loop over the m rows (Scalar dot, summed in double, NOT clamped)
@@ -819,13 +859,14 @@ static void gp_theta_update(const Csc<S>& A, const S* W_T, const S* H, const S* 
                 S dot = 0; for (int f = 0; f < k; ++f) dot += w[f] * h[f];
                 tot += static_cast<double>(dot);
             }
-            ss[j] = tot;
+            ss[j] = cfg.dense_input ? 0.0 : tot;                         // dense (:1041-1053): sum_s_col(j) += s, the floored prediction
             for (int t = A.p[j]; t < A.p[j + 1]; ++t) {
                 const S* w = Wd.data() + (size_t)A.i[t] * k;
                 S dot = 0; for (int f = 0; f < k; ++f) dot += w[f] * h[f];
                 const double y = static_cast<double>(A.x[t]);
                 const double sv = std::max(static_cast<double>(dot), 1e-10);
                 sy[j] += y;
+                if (cfg.dense_input) ss[j] += sv;
                 if (y >= 1.0) nn[j]++;
                 cc.push_back({j, y, sv});
             }
@@ -863,7 +904,7 @@ static void gp_theta_update(const Csc<S>& A, const S* W_T, const S* H, const S* 
     for (int i = 0; i < m; ++i) {                                                                    // :936-938
         S t = 0; const S* w = Wd.data() + (size_t)i * k;
         for (int f = 0; f < k; ++f) t += w[f] * h_rs[f];
-        sum_s[i] = static_cast<double>(t);
+        sum_s[i] = cfg.dense_input ? 0.0 : static_cast<double>(t);    // dense (:953-968): sum_s_d(i) += s per entry, floored
     }
     if (cv_mask)                                                                                     // fit_cv.hpp:886-893
         for (int j = 0; j < n; ++j)
@@ -884,6 +925,7 @@ static void gp_theta_update(const Csc<S>& A, const S* W_T, const S* H, const S* 
             const double y = static_cast<double>(A.x[t]);
             const double sv = std::max(static_cast<double>(dot), 1e-10);
             sum_y[i] += y;
+            if (cfg.dense_input) sum_s[i] += sv;
             if (y >= 1.0) n_nz[i]++;
             cache.push_back({i, y, sv});
         }
@@ -1118,7 +1160,7 @@ FitResult<S> nmf_fit(const Csc<S>& A, const FitConfig<S>& cfg, S* W_T, S* H, S* 
             nnls_batch_irls_sparse_nb(A, W_T, G.data(), H, k, cfg.L1_H, cfg.L2_H, cfg.nonneg_H,
                                       cfg.cd_maxit, cfg.irls_max_iter, cfg.irls_tol, cfg.threads,
                                       is_nb && !per_col ? nb_size.data() : (const S*)nullptr,          // :577-583: PER_COL -> theta_per_col
-                                      is_nb && per_col ? nb_size.data() : (const S*)nullptr, cfg.loss_type, cfg.tweedie_power, cfg.robust_delta);
+                                      is_nb && per_col ? nb_size.data() : (const S*)nullptr, cfg.loss_type, cfg.tweedie_power, cfg.robust_delta, cfg.dense_input);
         } else {
             if (cfg.L2_H > 0) for (int i = 0; i < k; ++i) G[(size_t)i * k + i] += cfg.L2_H;   // :506
             if (cfg.has_graph_H) apply_graph_reg(G.data(), cfg.graph_H, H, k, cfg.graph_H_lambda);      // :508-509
@@ -1169,7 +1211,7 @@ FitResult<S> nmf_fit(const Csc<S>& A, const FitConfig<S>& cfg, S* W_T, S* H, S* 
             nnls_batch_irls_sparse_nb(At, H, G.data(), W_T, k, cfg.L1_W, cfg.L2_W, cfg.nonneg_W,
                                       cfg.cd_maxit, cfg.irls_max_iter, cfg.irls_tol, cfg.threads,
                                       is_nb && per_col ? nb_size.data() : (const S*)nullptr,           // :820-830: PER_COL -> row of A^T
-                                      is_nb && !per_col ? nb_size.data() : (const S*)nullptr, cfg.loss_type, cfg.tweedie_power, cfg.robust_delta);
+                                      is_nb && !per_col ? nb_size.data() : (const S*)nullptr, cfg.loss_type, cfg.tweedie_power, cfg.robust_delta, cfg.dense_input);
         } else {
             if (cfg.L2_W > 0) for (int i = 0; i < k; ++i) G[(size_t)i * k + i] += cfg.L2_W;   // :738
             if (cfg.has_graph_W) apply_graph_reg(G.data(), cfg.graph_W, W_T, k, cfg.graph_W_lambda);    // :740-741
@@ -1364,6 +1406,7 @@ template <class S> static Csc<S> mk(int rows, int cols, const int* p, const int*
         c.gp_theta_init = gp_theta_init; c.gp_theta_max = gp_theta_max; c.gamma_phi_init = gamma_phi_init;  \
         c.gamma_phi_max = gamma_phi_max; c.gamma_phi_min = gamma_phi_min; c.symmetric = symmetric != 0;   \
         c.unfused = unfused != 0;                                                                         \
+        c.dense_input = unfused == 2;                                                                         \
         c.target_H = target_H; c.target_lambda_H = target_lambda_H; c.target_W = target_W; c.target_lambda_W = target_lambda_W; \
         if (gH_p) { c.has_graph_H = true; c.graph_H = mk(n, n, gH_p, gH_i, gH_x); c.graph_H_lambda = gH_lambda; } \
         if (gW_p) { c.has_graph_W = true; c.graph_W = mk(m, m, gW_p, gW_i, gW_x); c.graph_W_lambda = gW_lambda; } \
@@ -1412,7 +1455,8 @@ ORACLE_API float oracle_loss_gp_f32(float y, float p, float th) { return loss_co
     ORACLE_API void oracle_nb_size_update_##SUF(int m, int n, const int* p, const int* i, const S* x,             \
                                                 const S* W_T, const S* H, const S* d, int k, int dispersion_mode, \
                                                 S r_min, S r_max, S* nb_size) {                                   \
-        FitConfig<S> c; c.k = k; c.dispersion_mode = dispersion_mode; c.nb_size_min = r_min; c.nb_size_max = r_max; \
+        FitConfig<S> c; c.k = k; c.dense_input = dispersion_mode >= 16;   /* + 16: A stores every entry, dense branches */ \
+        dispersion_mode &= 15; c.dispersion_mode = dispersion_mode; c.nb_size_min = r_min; c.nb_size_max = r_max;   \
         const size_t len = dispersion_mode == 3 ? (size_t)n : (size_t)m;   /* PER_COL: n values */                \
         std::vector<S> v(nb_size, nb_size + len);                                                                 \
         nb_size_update(mk(m, n, p, i, x), W_T, H, d, k, c, v);                                                    \
@@ -1422,7 +1466,8 @@ ORACLE_API float oracle_loss_gp_f32(float y, float p, float th) { return loss_co
     ORACLE_API void oracle_dispersion_update_##SUF(int loss_type, int m, int n, const int* p, const int* i,       \
                                                    const S* x, const S* W_T, const S* H, const S* d, int k,       \
                                                    int dispersion_mode, S power, S lo, S hi, S* theta) {          \
-        FitConfig<S> c; c.k = k; c.dispersion_mode = dispersion_mode; c.loss_type = loss_type;                    \
+        FitConfig<S> c; c.k = k; c.dense_input = dispersion_mode >= 16; dispersion_mode &= 15;                    \
+        c.dispersion_mode = dispersion_mode; c.loss_type = loss_type;                                             \
         c.tweedie_power = power; c.gp_theta_max = hi; c.gamma_phi_min = lo; c.gamma_phi_max = hi;                 \
         const size_t len = dispersion_mode == 3 ? (size_t)n : (size_t)m;   /* PER_COL: n values */                \
         std::vector<S> v(theta, theta + len);                                                                     \
@@ -1441,8 +1486,9 @@ ORACLE_API float oracle_loss_gp_f32(float y, float p, float th) { return loss_co
                                       const S* F, const S* G, S* X, int k, S L1, S L2, int nonneg, int cd_maxit,  \
                                       int irls_max_iter, S irls_tol, int threads, const S* theta_row,             \
                                       const S* theta_col, S power, S robust) {                                    \
+        /* loss_type + 16: every row stored, the dense column solve (irls_nnls_col_dense) */                      \
         nnls_batch_irls_sparse_nb(mk(rows, cols, p, i, x), F, G, X, k, L1, L2, nonneg != 0, cd_maxit,             \
-                                  irls_max_iter, irls_tol, threads, theta_row, theta_col, loss_type, power, robust); \
+                                  irls_max_iter, irls_tol, threads, theta_row, theta_col, loss_type & 15, power, robust, loss_type >= 16); \
     }                                                                                                             \
     ORACLE_API S oracle_irls_loss_##SUF(int loss_type, int m, int n, const int* p, const int* i, const S* x,      \
                                         const S* W_T, const S* d, const S* H, int k, const S* theta_row, S power, S robust) { \

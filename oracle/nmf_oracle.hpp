@@ -457,6 +457,8 @@ template <class S> struct FitConfig {
     Csc<S> graph_H, graph_W; S graph_H_lambda = 0, graph_W_lambda = 0;
     bool projective = false;
     bool unfused = false;          // dense input: the STANDARD (separate RHS -> features -> nnls_batch) path of fit_cpu.hpp:540-640, :774-882
+    bool dense_input = false;      // A stores EVERY entry (oracle.py dense_as_csc) and the fit takes the reference's DENSE branches where they differ from the
+                                   // sparse ones: irls_nnls_col_dense (nnls_batch_irls.hpp:376-450), fit_cpu.hpp:953-968, :1041-1053, :1137-1148, :1226-1238
     bool symmetric = false;        // A ~ W diag(d) W^T, A square: only W is solved, H = W_T (fit_cpu.hpp:659-704)                  // NMFConfig::projective: H = diag(d) W_T A instead of an NNLS solve
     S robust_delta = 0;                       // LossConfig::robust_delta (math/loss.hpp:89-96): > 0 -> Huber on Pearson residuals
     S tweedie_power = S(1.5);                 // LossConfig::power_param (math/loss.hpp:99-104), loss_type 8 only

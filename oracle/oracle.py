@@ -306,7 +306,7 @@ def nmf_fit(A, W_T, H, dtype=np.float64, max_iter=100, tol=1e-4, L1=(0.0, 0.0), 
             cd_maxit=100, cd_tol=1e-8, patience=5, nonneg=(True, True), norm_type=0, solver_mode=0, loss_type=0,
             irls_max_iter=5, irls_tol=1e-4, dispersion_mode=2, nb_size=(10.0, 1e6, 0.01), sort_model=True, threads=1,
             mask=None, native=False, tweedie_power=1.5, L21=(0.0, 0.0), angular=(0.0, 0.0), robust_delta=0.0, projective=False, graph_H=None, graph_W=None,
-            gp_theta=(0.1, 5.0), gamma_phi=(1.0, 1e4, 1e-6), symmetric=False, unfused=False, target_H=None, target_W=None):
+            gp_theta=(0.1, 5.0), gamma_phi=(1.0, 1e4, 1e-6), symmetric=False, unfused=False, target_H=None, target_W=None, dense_input=False):
     """CPU restatement of nmf_fit<CPU> (reference nmf/fit_cpu.hpp).  L1/L2/ub/nonneg are (W, H) pairs as in R
     (src/RcppFunctions_nmf.cpp:59-62).  W_T: (m, k) array = column-major k x m; H: (n, k).
     graph_H / graph_W: (Csc Laplacian, lambda) over the columns of H / W_T (features/graph_reg.hpp).
@@ -336,7 +336,7 @@ def nmf_fit(A, W_T, H, dtype=np.float64, max_iter=100, tol=1e-4, L1=(0.0, 0.0), 
         C.c_int(int(sort_model)), C.c_int(threads), mp, mi, mxp, C.byref(it), C.byref(conv), C.byref(loss), C.byref(ftol),
         _p(hist), _p(theta), ct(tweedie_power), ct(L21[1]), ct(L21[0]), ct(angular[1]), ct(angular[0]), ct(robust_delta), C.c_int(int(projective)),
         *_graph_args(graph_H, dtype, ct), *_graph_args(graph_W, dtype, ct),
-        ct(gp_theta[0]), ct(gp_theta[1]), ct(gamma_phi[0]), ct(gamma_phi[1]), ct(gamma_phi[2]), C.c_int(int(symmetric)), C.c_int(int(unfused)),
+        ct(gp_theta[0]), ct(gp_theta[1]), ct(gamma_phi[0]), ct(gamma_phi[1]), ct(gamma_phi[2]), C.c_int(int(symmetric)), C.c_int(2 if dense_input else int(unfused)),
         *_target_args(target_H, dtype, ct), *_target_args(target_W, dtype, ct))
     r = FitResult()
     r.W_T, r.H, r.d = W_T, H, d
@@ -378,8 +378,8 @@ def num_threads():
 
 # ----------------------------------------------------------------------------- NB-IRLS primitives
 def irls(loss_type, A, F, G, k, L1=0.0, L2=0.0, nonneg=True, cd_maxit=100, irls_max_iter=5, irls_tol=1e-4, threads=1,
-         theta_row=None, theta_col=None, dtype=np.float64, power=1.5, robust=0.0):
-    """Generic IRLS half-update: loss_type 5 = NB, 4 = GP (KL weights, fit_cpu.hpp:568-574), 6 = Gamma, 7 = inverse
+         theta_row=None, theta_col=None, dtype=np.float64, power=1.5, robust=0.0, dense_input=False):
+    """Generic IRLS half-update (dense_input: A stores every entry and the column solve is the reference's dense one): loss_type 5 = NB, 4 = GP (KL weights, fit_cpu.hpp:568-574), 6 = Gamma, 7 = inverse
     Gaussian, 8 = Tweedie(power)."""
     suf, ct = _suf(dtype)
     F, G = _f(F, dtype), _f(G, dtype)
@@ -387,7 +387,7 @@ def irls(loss_type, A, F, G, k, L1=0.0, L2=0.0, nonneg=True, cd_maxit=100, irls_
     x = A.values(dtype)
     tr = _f(theta_row, dtype) if theta_row is not None else None
     tc = _f(theta_col, dtype) if theta_col is not None else None
-    getattr(lib(), "oracle_irls_" + suf)(C.c_int(loss_type), C.c_int(A.rows), C.c_int(A.cols), _p(A.p), _p(A.i), _p(x), _p(F),
+    getattr(lib(), "oracle_irls_" + suf)(C.c_int(loss_type + (16 if dense_input else 0)), C.c_int(A.rows), C.c_int(A.cols), _p(A.p), _p(A.i), _p(x), _p(F),
                                          _p(G), _p(X), C.c_int(k), ct(L1), ct(L2), C.c_int(int(nonneg)), C.c_int(cd_maxit),
                                          C.c_int(irls_max_iter), ct(irls_tol), C.c_int(threads),
                                          _p(tr) if tr is not None else None, _p(tc) if tc is not None else None, ct(power), ct(robust))
@@ -419,18 +419,18 @@ def irls_nb(A, F, G, k, L1=0.0, L2=0.0, nonneg=True, cd_maxit=100, irls_max_iter
     return X
 
 
-def nb_size_update(A, W_T, H, d, nb_size, dispersion_mode=2, r_min=0.01, r_max=1e6, dtype=np.float64):
+def nb_size_update(A, W_T, H, d, nb_size, dispersion_mode=2, r_min=0.01, r_max=1e6, dtype=np.float64, dense_input=False):
     suf, ct = _suf(dtype)
     W_T, H, d = _f(W_T, dtype), _f(H, dtype), _f(d, dtype)
     out = _f(nb_size, dtype).copy()
     x = A.values(dtype)
     getattr(lib(), "oracle_nb_size_update_" + suf)(C.c_int(A.rows), C.c_int(A.cols), _p(A.p), _p(A.i), _p(x), _p(W_T), _p(H),
-                                                  _p(d), C.c_int(W_T.shape[1]), C.c_int(dispersion_mode), ct(r_min),
+                                                  _p(d), C.c_int(W_T.shape[1]), C.c_int(dispersion_mode + (16 if dense_input else 0)), ct(r_min),
                                                   ct(r_max), _p(out))
     return out
 
 
-def dispersion_update(loss_type, A, W_T, H, d, theta, dispersion_mode=2, power=1.5, lo=1e-6, hi=1e4, dtype=np.float64):
+def dispersion_update(loss_type, A, W_T, H, d, theta, dispersion_mode=2, power=1.5, lo=1e-6, hi=1e4, dtype=np.float64, dense_input=False):
     """GP theta (loss_type 4, fit_cpu.hpp:914-1008, hi = cap) or Gamma / IG / Tweedie phi (6 / 7 / 8, :1561-1670)."""
     suf, ct = _suf(dtype)
     th = _f(theta, dtype).copy()
@@ -438,7 +438,7 @@ def dispersion_update(loss_type, A, W_T, H, d, theta, dispersion_mode=2, power=1
     k = W_T.shape[1]
     getattr(lib(), "oracle_dispersion_update_" + suf)(C.c_int(loss_type), C.c_int(A.rows), C.c_int(A.cols), _p(A.p), _p(A.i), _p(x),
                                                      _p(_f(W_T, dtype)), _p(_f(H, dtype)), _p(_f(d, dtype)), C.c_int(k),
-                                                     C.c_int(dispersion_mode), ct(power), ct(lo), ct(hi), _p(th))
+                                                     C.c_int(dispersion_mode + (16 if dense_input else 0)), ct(power), ct(lo), ct(hi), _p(th))
     return th
 
 

@@ -638,7 +638,9 @@ def sp_free_gpu(h):
 
 def nmf_dense(A, k, W_T, H, *, entry="float", max_iter=100, tol=1e-4, L1_H=0.0, L1_W=0.0, L2_H=0.0, L2_W=0.0, L21_H=0.0,
               L21_W=0.0, ortho_H=0.0, ortho_W=0.0, ub_H=0.0, ub_W=0.0, cd_maxit=100, verbose=0, seed=0, patience=5, nonneg_W=1,
-              nonneg_H=1, loss_type=0, norm_type=0, projective=0, symmetric=0, solver_mode=0, robust_delta=0.0):
+              nonneg_H=1, loss_type=0, norm_type=0, projective=0, symmetric=0, solver_mode=0, robust_delta=0.0, irls_max_iter=5,
+              irls_tol=1e-4, dispersion_mode=2, gp_theta_init=0.1, gp_theta_max=5.0, nb_size_init=10.0, nb_size_max=1e6,
+              nb_size_min=0.01, tweedie_power=1.5):
     """Call the dense plugin entry as reference gpu/bridge_nmf.hpp:537-690 does.  A: (m, n) float64 array (any layout: it
     is handed over column-major).  W_T (m, k), H (n, k) float64, updated IN PLACE.  entry: "float" | "double"."""
     L = lib()
@@ -647,18 +649,19 @@ def nmf_dense(A, k, W_T, H, *, entry="float", max_iter=100, tol=1e-4, L1_H=0.0, 
     assert W_T.dtype == np.float64 and H.dtype == np.float64 and W_T.flags.c_contiguous and H.flags.c_contiguous
     assert W_T.shape == (m, k) and H.shape == (n, k)
     d = np.ones(k, np.float64)
-    theta = np.zeros(max(m, 1), np.float64)
+    theta = np.zeros(max(m, n, 1), np.float64)          # gpu/bridge_nmf.hpp:622 theta_buf(max(m, n))
     out_iter, out_conv, out_status, out_theta_len = C.c_int(0), C.c_int(0), C.c_int(-99), C.c_int(0)
     out_loss, out_tol = C.c_double(0), C.c_double(0)
     args = [
         A.ctypes.data_as(C.POINTER(C.c_double)), _ci(m), _ci(n), _ci(k), _np_ptr(W_T), _np_ptr(H), _np_ptr(d), _ci(max_iter), _cd(tol),
         _cd(L1_H), _cd(L1_W), _cd(L2_H), _cd(L2_W), _cd(L21_H), _cd(L21_W), _cd(ortho_H), _cd(ortho_W), _cd(ub_H), _cd(ub_W),
         _ci(cd_maxit), _ci(verbose), _ci(seed), _ci(1), _ci(patience), _ci(nonneg_W), _ci(nonneg_H), _ci(loss_type), _cd(1.0),
-        _ci(5), _cd(1e-4), _ci(norm_type), _ci(2), _cd(0.1), _cd(5.0), _cd(0.0), _cd(10.0), _cd(1e6), _cd(0.01),
-        _cd(robust_delta), _cd(1.5), _ci(projective), _ci(symmetric), _ci(solver_mode), _np_ptr(theta), C.byref(out_theta_len),
+        _ci(irls_max_iter), _cd(irls_tol), _ci(norm_type), _ci(dispersion_mode), _cd(gp_theta_init), _cd(gp_theta_max), _cd(0.0),
+        _cd(nb_size_init), _cd(nb_size_max), _cd(nb_size_min),
+        _cd(robust_delta), _cd(tweedie_power), _ci(projective), _ci(symmetric), _ci(solver_mode), _np_ptr(theta), C.byref(out_theta_len),
         C.byref(out_iter), C.byref(out_conv), C.byref(out_loss), C.byref(out_status), C.byref(out_tol),
     ]
     assert len(args) == 50
     getattr(L, "rcppml_gpu_nmf_dense_unified_" + entry)(*args)
     return dict(d=d, iter=out_iter.value, converged=bool(out_conv.value), loss=out_loss.value, tol=out_tol.value,
-                status=out_status.value, error=last_error() if out_status.value != 0 else "")
+                theta=theta[:out_theta_len.value].copy(), status=out_status.value, error=last_error() if out_status.value != 0 else "")

@@ -76,6 +76,14 @@ __global__ void permute_rows_kernel(const T* __restrict__ in, int k, int64_t nco
     out[e] = in[j * k + idx[i]];
 }
 
+// index arrays of the CSC that stores every entry of a dense m x n matrix (column j = rows 0 .. m-1): the dense array itself is
+// its value array.  Used for dense input under a distribution loss, whose per-element passes are written over a CSC.
+__global__ void full_csc_index_kernel(int m, int64_t n, int* __restrict__ col_ptr, int* __restrict__ row_idx) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e <= n) col_ptr[e] = (int)(e * m);
+    if (e < (int64_t)m * n) row_idx[e] = (int)(e % m);
+}
+
 // ----------------------------------------------------------------------------
 // The ALS loop (MSE; fused-path semantics of fit_cpu.hpp, or the explicit-mask path).
 // ----------------------------------------------------------------------------
@@ -116,6 +124,23 @@ void fit(FitParams& P) {
     bool csc_transposed = false;
     if (dense) {                    // dense input: A itself (m x n, column-major) in the compute precision; no CSC, no transpose
         upload_cast<T>(c, P.dense, (size_t)m * n, dAx, s);
+        if (P.loss_type != 0 || P.robust_delta > 0) {
+            // ... except under a distribution loss (nnls_batch_irls_dense, fit_cpu.hpp:607-614, :855-863; explicit_loss_dense;
+            // the dense branches of the dispersion updates): every entry is weighted, zeros included -- which is what the
+            // per-nonzero IRLS / dispersion / likelihood passes compute on the CSC that stores every entry.  Its value array is the
+            // dense array; the transpose's comes from the stable device sort like any other.  (The reference's dense column solve
+            // forms G_w = sum_i w_i f_i f_i^T from nothing where the sparse one adds sum_i (w_i - 1) f_i f_i^T to G_base, and its
+            // dispersion sums floor every prediction at 1e-10: the same numbers up to rounding, oracle dense_input.)
+            const int64_t tot = (int64_t)m * n;
+            dAp.alloc(((size_t)n + 1) * sizeof(int));
+            dAi.alloc((size_t)tot * sizeof(int));
+            hipLaunchKernelGGL(full_csc_index_kernel, dim3((unsigned)((tot + 256) / 256)), dim3(256), 0, s, m, (int64_t)n, dAp.as<int>(), dAi.as<int>());
+            HIPCHK(hipGetLastError());
+            dTp.alloc(((size_t)m + 1) * sizeof(int));
+            dTi.alloc((size_t)tot * sizeof(int));
+            dTx.alloc((size_t)tot * sizeof(T));
+            OPCHK(rcppml_hip_transpose_csc(c, dt, m, n, dAp.as<int>(), dAi.as<int>(), dAx.p, dTp.as<int>(), dTi.as<int>(), dTx.p));
+        }
     } else if (P.csc_on_device) {          // zero-copy: the CSC already lives in device memory (values double)
         dAp.borrow(P.col_ptr);
         dAi.borrow(P.row_idx);
@@ -1070,10 +1095,19 @@ void nmf_dense_entry(RCPPML_NMF_DENSE_ARGS, int precision) {
     try {
         rcppml_err().clear();
         *out_status = -1;
-        (void)seed; (void)loss_every; (void)huber_delta; (void)irls_max_iter; (void)irls_tol; (void)gp_dispersion_mode;
-        (void)gp_theta_init; (void)gp_theta_max; (void)gp_theta_min; (void)nb_size_init; (void)nb_size_max; (void)nb_size_min;
-        (void)tweedie_power; (void)out_theta;
-        if (*loss_type != 0 || *robust_delta > 0) throw std::runtime_error("dense entry: only the MSE loss is implemented");
+        (void)seed; (void)loss_every; (void)huber_delta; (void)gp_theta_min;
+        if (out_theta_len) *out_theta_len = 0;
+        const bool irls = *loss_type != 0 || *robust_delta > 0;
+        if (*loss_type != 0 && (*loss_type < 4 || *loss_type > 8))
+            throw std::runtime_error("loss_type must be MSE (0), GP (4), NB (5), Gamma (6), inverse Gaussian (7) or Tweedie (8) for this plugin build");
+        if (irls) {          // the same conditions as on the sparse entries (nmf_entry above)
+            if (*gp_dispersion_mode < 0 || *gp_dispersion_mode > 3) throw std::runtime_error("bad dispersion mode");
+            if (*k > 128) throw std::runtime_error("IRLS losses: k must be <= 128");
+            if (*solver_mode != 0) throw std::runtime_error("IRLS losses require the CD solver");
+            if (*L21_H != 0 || *L21_W != 0 || *ortho_H != 0 || *ortho_W != 0) throw std::runtime_error("L21 / angular penalties are implemented for the MSE path");
+            if (*projective != 0 || *symmetric != 0) throw std::runtime_error("projective / symmetric NMF: plain MSE path only");
+            if ((int64_t)*m * *n > (int64_t)0x7fffffff) throw std::runtime_error("dense input with a distribution loss: m * n must fit 31 bits");
+        }
         if (*projective != 0 && *symmetric != 0) throw std::runtime_error("projective and symmetric cannot both be true");
         if (*symmetric != 0 && *m != *n) throw std::runtime_error("symmetric NMF needs a square matrix");
         if (*solver_mode != 0 && *solver_mode != 1) throw std::runtime_error("solver_mode must be 0 (CD) or 1 (Cholesky+clip)");
@@ -1096,8 +1130,14 @@ void nmf_dense_entry(RCPPML_NMF_DENSE_ARGS, int precision) {
         P.norm_type = *norm_type; P.solver_mode = *solver_mode;
         P.projective = *projective != 0 ? 1 : 0; P.symmetric = *symmetric != 0 ? 1 : 0;
         P.mask_p = nullptr; P.mask_i = nullptr; P.sort_model = env_sort(); P.loss_history = nullptr;
+        // the distribution losses (src/gpu_bridge_nmf.cu:685-700: the 50 pointers carry no gamma_phi_* -> NMFConfig defaults, core/config.hpp)
+        P.loss_type = *loss_type; P.irls_max_iter = *irls_max_iter; P.irls_tol = *irls_tol;
+        P.dispersion_mode = *gp_dispersion_mode; P.nb_size_init = *nb_size_init; P.nb_size_max = *nb_size_max; P.nb_size_min = *nb_size_min;
+        P.gp_theta_init = *gp_theta_init; P.gp_theta_max = *gp_theta_max;
+        P.gamma_phi_init = 1.0; P.gamma_phi_max = 1e4; P.gamma_phi_min = 1e-6;
+        P.tweedie_power = *tweedie_power; P.robust_delta = *robust_delta; P.out_theta = irls ? out_theta : nullptr;    // max(m, n) doubles (gpu/bridge_nmf.hpp:622)
         if (precision == RCPPML_F64) fit<double>(P); else fit<float>(P);
-        if (out_theta_len) *out_theta_len = 0;
+        if (out_theta_len) *out_theta_len = P.out_theta_len;
         *out_iter = P.out_iter; *out_converged = P.out_converged; *out_loss = P.out_loss; *out_tol = P.out_tol;
         *out_status = 0;
     } catch (const std::exception& e) {

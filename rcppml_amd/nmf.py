@@ -217,9 +217,9 @@ def nmf(data, k, tol=1e-4, maxit=100, L1=(0.0, 0.0), L2=(0.0, 0.0), seed=None, m
         if irls_cv and loss == "gp":
             misc["theta"] = res.get("theta")
         return NMFModel(w=W_T.copy(), d=res["d"], h=H.T.copy(), misc=misc)
-    if dense_in and loss == "mse" and robust_delta == 0 and mask_arg is None and not graph_args and sort_model and target_H is None \
-            and float(cd_tol) == 1e-8:
-        # dense input -> rcppml_gpu_nmf_dense_unified_* (GEMM right-hand sides, the reference's unfused update order).
+    if dense_in and mask_arg is None and not graph_args and sort_model and target_H is None and float(cd_tol) == 1e-8:
+        # dense input -> rcppml_gpu_nmf_dense_unified_* (GEMM right-hand sides, the reference's unfused update order; under a
+        # distribution loss the dense IRLS solves, which weight EVERY entry -- the sparse entry gives zeros weight 1).
         # The dense ABI (bridge_nmf.hpp:101-126) has no slot for cd_tol (the plugin uses the reference default 1e-8) and
         # returns no loss history: any other cd_tol keeps the sparse entry, which honours it; misc says which entry ran.
         res = _abi.nmf_dense(np.asarray(data, np.float64), k, W_T, H, entry="float" if precision == "fp32" else "double",
@@ -227,12 +227,19 @@ def nmf(data, k, tol=1e-4, maxit=100, L1=(0.0, 0.0), L2=(0.0, 0.0), seed=None, m
                              ortho_H=angh, ortho_W=angw, ub_H=ubh, ub_W=ubw, cd_maxit=int(cd_maxit), verbose=int(verbose),
                              seed=seed_int & 0x7FFFFFFF, patience=int(patience), nonneg_W=int(nnw), nonneg_H=int(nnh),
                              norm_type=norm_type, projective=int(bool(projective)), symmetric=int(bool(symmetric)),
-                             solver_mode=0 if solver == "cd" else 1)
+                             solver_mode=0 if solver == "cd" else 1,
+                             loss_type={"mse": 0, "gp": 4, "nb": 5, "gamma": 6, "inverse_gaussian": 7, "tweedie": 8}[loss],
+                             robust_delta=robust_delta, irls_max_iter=int(irls_max_iter), irls_tol=float(irls_tol),
+                             dispersion_mode={"none": 0, "global": 1, "per_row": 2, "per_col": 3}[dispersion],
+                             gp_theta_init=float(theta_init), gp_theta_max=float(theta_max), nb_size_init=nb_size_init,
+                             nb_size_max=nb_size_max, nb_size_min=nb_size_min, tweedie_power=float(tweedie_power))
         if res["status"] != 0:
             raise _abi.BackendError("GPU dense NMF failed: %s" % res.get("error"))
         misc = dict(tol=res["tol"], iter=res["iter"], loss=res["loss"], converged=res["converged"], solver=solver,
                     solver_mode=0 if solver == "cd" else 1, L1=(L1w, L1h), L2=(L2w, L2h), seed=seed_int, precision=precision,
                     resource="gpu", loss_type=loss, input="dense", loss_history=None)
+        if loss != "mse":
+            misc["theta"] = res["theta"]
         return NMFModel(w=W_T.copy(), d=res["d"], h=H.T.copy(), misc=misc)
     target_args = {}
     if target_H is not None:

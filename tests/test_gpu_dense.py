@@ -79,7 +79,8 @@ def test_dense_symmetric_and_rejections():
     assert res["status"] == 0 and abs(res["loss"] - ref.loss) / abs(ref.loss) < 1e-6
     assert np.abs(W - ref.W_T).max() < 1e-6 and np.array_equal(W, H)
     M = _dense_problem(30, 40, 3, seed=1)
-    for kw in (dict(loss_type=5), dict(robust_delta=1.0), dict(symmetric=1), dict(solver_mode=2), dict(ortho_H=-0.1)):
+    for kw in (dict(loss_type=3), dict(loss_type=5, solver_mode=1), dict(loss_type=5, projective=1), dict(robust_delta=1.0, ortho_H=0.1),
+               dict(loss_type=4, dispersion_mode=7), dict(symmetric=1), dict(solver_mode=2), dict(ortho_H=-0.1)):
         W1, H1 = O.init_factors(1, 3, 30, 40, np.float64)
         r = _abi.nmf_dense(M, 3, W1, H1, entry="double", max_iter=2, **kw)
         assert r["status"] == -1 and r["error"], kw
@@ -100,3 +101,80 @@ def test_nmf_surface_dense_input():
     ref = O.nmf_fit(O.dense_as_csc(M), W0, H0, np.float64, max_iter=10, tol=0.0, unfused=True)
     assert abs(md.misc["loss"] - ref.loss) / ref.loss < 1e-6 and np.abs(md.w - ref.W_T).max() < 1e-6
     assert abs(ms.misc["loss"] - md.misc["loss"]) / md.misc["loss"] < 0.2
+
+
+DENSE_LOSS_CASES = [
+    ("nb_per_row", dict(loss_type=5, dispersion_mode=2), "counts"),
+    ("nb_per_col", dict(loss_type=5, dispersion_mode=3), "counts"),
+    ("nb_global", dict(loss_type=5, dispersion_mode=1), "counts"),
+    ("nb_none_l1", dict(loss_type=5, dispersion_mode=0, L1_H=0.02, L1_W=0.01, L2_H=0.03), "counts"),
+    ("gp_per_row", dict(loss_type=4, dispersion_mode=2), "counts"),
+    ("gp_per_col", dict(loss_type=4, dispersion_mode=3), "counts"),
+    ("kl", dict(loss_type=4, dispersion_mode=0), "counts"),
+    ("gamma", dict(loss_type=6, dispersion_mode=2), "positive"),
+    ("inverse_gaussian_per_col", dict(loss_type=7, dispersion_mode=3), "positive"),
+    ("tweedie", dict(loss_type=8, dispersion_mode=2, tweedie_power=1.3), "counts"),
+    ("robust_mse", dict(loss_type=0, robust_delta=1.345), "counts"),
+    ("robust_nb", dict(loss_type=5, dispersion_mode=2, robust_delta=1.0), "counts"),
+]
+
+
+def _loss_problem(kind, m=46, n=37, r=3, seed=5):
+    rng = np.random.default_rng(seed)
+    mu = rng.gamma(2.0, 1.0, (m, r)) @ rng.gamma(2.0, 0.5, (r, n))
+    if kind == "counts":
+        M = rng.negative_binomial(4.0, 4.0 / (4.0 + mu)).astype(np.float64)     # overdispersed counts, ~ 10 % exact zeros: they carry weight in the dense solves
+    else:
+        M = mu * rng.gamma(8.0, 1.0 / 8.0, (m, n)) + 0.05       # strictly positive (the Gamma / inverse Gaussian deviances need y > 0)
+    return M
+
+
+@pytest.mark.parametrize("name,kw,kind", DENSE_LOSS_CASES, ids=[c[0] for c in DENSE_LOSS_CASES])
+def test_dense_fit_with_distribution_losses(name, kw, kind):
+    """Dense input under every distribution loss the sparse entries take -- the reference's nnls_batch_irls_dense half-updates
+    (nmf/fit_cpu.hpp:607-614, :855-863; primitives/cpu/nnls_batch_irls.hpp:376-450: EVERY entry weighted, zeros included, each batch
+    from H = 0), the dense branches of the dispersion updates (:953-968, :1041-1053, :1137-1148, :1226-1238, :1576-1650) and
+    explicit_loss_dense (explicit_loss.hpp:86-107) -- through the 50-pointer fp64 entry against the oracle's dense_input fit:
+    loss 1e-6 relative, factors 1e-6 (L1-normalised), dispersion vector 1e-5 relative; theta has m entries, n under per_col."""
+    from rcppml_amd import _abi
+    M = _loss_problem(kind)
+    m, n = M.shape
+    k = 4
+    A = O.dense_as_csc(M)
+    W0, H0 = O.init_factors(9, k, m, n, np.float64)
+    okw = dict(loss_type=kw.get("loss_type", 0), dispersion_mode=kw.get("dispersion_mode", 2), tweedie_power=kw.get("tweedie_power", 1.5),
+               robust_delta=kw.get("robust_delta", 0.0), L1=(kw.get("L1_W", 0.0), kw.get("L1_H", 0.0)), L2=(kw.get("L2_W", 0.0), kw.get("L2_H", 0.0)))
+    ref = O.nmf_fit(A, W0, H0, np.float64, max_iter=4, tol=0.0, cd_maxit=20, dense_input=True, **okw)
+    W, H = W0.copy(), H0.copy()
+    res = _abi.nmf_dense(M, k, W, H, entry="double", max_iter=4, tol=0.0, cd_maxit=20, **kw)
+    assert res["status"] == 0, res["error"]
+    assert res["iter"] == ref.iter
+    assert abs(res["loss"] - ref.loss) <= 1e-6 * abs(ref.loss), (res["loss"], ref.loss)
+    assert np.abs(res["d"] - ref.d).max() <= 1e-6 * np.abs(ref.d).max()
+    assert np.abs(W - ref.W_T).max() <= 1e-6 and np.abs(H - ref.H).max() <= 1e-6
+    want_len = n if kw.get("dispersion_mode", 2) == 3 else m
+    assert res["theta"].shape == (want_len,) and ref.theta.shape == (want_len,)
+    assert np.abs(res["theta"] - ref.theta).max() <= 1e-5 * max(np.abs(ref.theta).max(), 1e-300)
+    # not the sparse entry on the same numbers: there the zeros of A have weight 1 and drop out of the loss
+    if kind == "counts" and kw.get("loss_type", 0) != 0:
+        sp = O.nmf_fit(O.Csc.from_dense(M), W0, H0, np.float64, max_iter=4, tol=0.0, cd_maxit=20, **okw)
+        assert abs(sp.loss - ref.loss) > 1e-4 * abs(ref.loss)
+
+
+def test_dense_fit_with_nb_loss_fp32_entry_and_surface():
+    """The fp32 dense entry under NB (loss 2e-3 against the fp64 oracle; fp32 forms G_w as G_base + sum (w - 1) f f^T, the
+    cancellation costs ~1e-6 of the Gram), and nmf(<ndarray>, loss = "nb") reaching the dense entry with theta in misc."""
+    from rcppml_amd import _abi, nmf as N
+    M = _loss_problem("counts", seed=6)
+    m, n = M.shape
+    k = 3
+    W0, H0 = O.init_factors(2, k, m, n, np.float64)
+    W0, H0 = W0.astype(np.float32).astype(np.float64), H0.astype(np.float32).astype(np.float64)
+    ref = O.nmf_fit(O.dense_as_csc(M), W0, H0, np.float64, max_iter=4, tol=0.0, cd_maxit=20, loss_type=5, dense_input=True)
+    W, H = W0.copy(), H0.copy()
+    res = _abi.nmf_dense(M, k, W, H, entry="float", max_iter=4, tol=0.0, cd_maxit=20, loss_type=5)
+    assert res["status"] == 0, res["error"]
+    assert abs(res["loss"] - ref.loss) <= 2e-3 * abs(ref.loss)
+    assert np.abs(W - ref.W_T).max() <= 5e-3 and np.abs(H - ref.H).max() <= 5e-3
+    mod = N.nmf(M, k, loss="nb", seed=4, maxit=3, tol=0.0, precision="fp64")
+    assert mod.misc["input"] == "dense" and mod.misc["theta"].shape == (m,) and np.isfinite(mod.misc["loss"])

@@ -163,3 +163,112 @@ def test_per_col_fit_uses_the_column_dispersion_in_solves_and_loss(loss_type):
         b = O.nmf_fit(A, W0, H0, np.float64, max_iter=2, tol=0.0, loss_type=5, dispersion_mode=2, **const)
         assert np.allclose(a.W_T, b.W_T, rtol=0, atol=1e-12) and np.allclose(a.H, b.H, rtol=0, atol=1e-12)
         assert abs(a.loss - b.loss) <= 1e-12 * abs(b.loss)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# Dense input with a distribution loss: the reference's DENSE branches (nnls_batch_irls.hpp:376-450, :525-555; fit_cpu.hpp:953-968,
+# :1041-1053, :1137-1148, :1226-1238), which the oracle takes with dense_input=True on a CSC that stores every entry
+# ---------------------------------------------------------------------------------------------------------------------------
+def _dense_problem(m=19, n=13, k=3, seed=23):
+    rng = np.random.default_rng(seed)
+    D = rng.poisson(1.4, (m, n)).astype(np.float64)
+    D[rng.uniform(size=(m, n)) < 0.3] = 0.0
+    F = rng.uniform(0.1, 1.0, (m, k))
+    return D, O.dense_as_csc(D), F, rng
+
+
+def test_dense_irls_half_update_weights_every_row_and_builds_the_gram_from_nothing():
+    """irls_nnls_col_dense: x starts at 0; per pass recon = F x, w_i = weight(a_i - recon_i, recon_i) for ALL rows (zeros of A
+    included), G_w = F^T diag(w) F (+ L2), b_w = F^T (w * a), CD warm-started by b_w - G_w x; stop on the relative change."""
+    D, A, F, rng = _dense_problem()
+    m, n = D.shape
+    k = F.shape[1]
+    theta = rng.uniform(2.0, 30.0, m)
+    L = O.lib()
+    L.oracle_irls_weight_nb_f64.restype = C.c_double
+    L1, L2, cd_maxit, irls_it, irls_tol = 0.02, 0.05, 9, 4, 1e-4
+    got = O.irls(5, A, F, np.full((k, k), 7.0), k, L1=L1, L2=L2, cd_maxit=cd_maxit, irls_max_iter=irls_it, irls_tol=irls_tol,
+                 theta_row=theta, dense_input=True)                     # G_base is not read: any matrix gives the same result
+    want = np.zeros((n, k))
+    for j in range(n):
+        x = np.zeros(k)
+        for _ in range(irls_it):
+            recon = F @ x
+            w = np.array([L.oracle_irls_weight_nb_f64(C.c_double(recon[i]), C.c_double(theta[i])) for i in range(m)])
+            Gw = (F * w[:, None]).T @ F + L2 * np.eye(k)
+            bw = F.T @ (w * D[:, j])
+            xo = x.copy()
+            x, _, _ = O.cd_col(Gw, bw - Gw @ xo, xo, L1=L1, maxit=cd_maxit, tol=0.0)
+            if (np.abs(x - xo) / (np.abs(xo) + 1e-12)).max() < irls_tol:
+                break
+        want[j] = x
+    assert np.allclose(got, want, rtol=1e-10, atol=1e-13)
+    # the sparse form on the same all-entries CSC is the same solve up to the eps of G_base and rounding
+    sp = O.irls(5, A, F, F.T @ F + 1e-15 * np.eye(k), k, L1=L1, L2=L2, cd_maxit=cd_maxit, irls_max_iter=irls_it, irls_tol=irls_tol,
+                theta_row=theta)
+    assert np.allclose(got, sp, rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.parametrize("mode", [2, 3, 1])
+def test_dense_nb_size_update_floors_every_prediction(mode):
+    """:1137-1148 (PER_COL) / :1226-1238 (PER_ROW, GLOBAL = median): sums over ALL entries of mu^2 and (y - mu)^2 - mu with
+    mu = max(prediction, 1e-10) -- no Gram-trick totals as in the sparse branch."""
+    D, A, W_T, rng = _dense_problem(seed=29)
+    m, n = D.shape
+    k = W_T.shape[1]
+    H, d = rng.uniform(0.1, 1.0, (n, k)), rng.uniform(0.5, 2.0, k)
+    H[:, 0] = 0.0; W_T[3] = 0.0                                          # a row of exact-zero predictions: the floor is live
+    length = n if mode == 3 else m
+    got = O.nb_size_update(A, W_T, H, d, np.full(length, 10.0), dispersion_mode=mode, dense_input=True)
+    mu = np.maximum((W_T * d) @ H.T, 1e-10)
+    ax = 0 if mode == 3 else 1
+    s_mu2, s_exc = (mu ** 2).sum(axis=ax), ((D - mu) ** 2 - mu).sum(axis=ax)
+    want = np.where((s_exc > 1e-10) & (s_mu2 > 1e-10), np.clip(s_mu2 / np.where(s_exc > 1e-10, s_exc, 1.0), 0.01, 1e6), 1e6)
+    if mode == 1:
+        want = np.full(m, np.partition(want, m // 2)[m // 2])
+    assert np.allclose(got, want, rtol=1e-10, atol=0)
+
+
+@pytest.mark.parametrize("mode", [2, 3])
+def test_dense_gp_theta_update_sums_the_floored_predictions(mode):
+    """:953-968 / :1041-1053: sum_s is the per-entry sum of max(prediction, 1e-10) (the sparse branch takes it from the factors' sums,
+    unfloored); the MM passes read the entries with y >= 1 only.  Five passes of the closed-form quadratic, restated in numpy."""
+    D, A, W_T, rng = _dense_problem(seed=31)
+    m, n = D.shape
+    k = W_T.shape[1]
+    H, d = rng.uniform(0.1, 1.0, (n, k)), rng.uniform(0.5, 2.0, k)
+    W_T[5] = 0.0
+    length = n if mode == 3 else m
+    got = O.dispersion_update(4, A, W_T, H, d, np.full(length, 0.1), dispersion_mode=mode, hi=5.0, dense_input=True)
+    s = np.maximum((W_T * d) @ H.T, 1e-10)
+    ax = 0 if mode == 3 else 1
+    sum_y, sum_s, n_nz = D.sum(axis=ax), s.sum(axis=ax), (D >= 1).sum(axis=ax)
+    th = np.full(length, 0.1)
+    for _ in range(5):
+        thb = th[None, :] if mode == 3 else th[:, None]
+        eta1 = s / np.maximum(s + thb * D, 1e-10)
+        big = D >= 1
+        alpha = np.where(big, (D - 1) * eta1, 0.0).sum(axis=ax) + n_nz
+        gamma = np.where(big, (D - 1) * (1 - eta1), 0.0).sum(axis=ax)
+        beta = (sum_y - sum_s) - gamma + alpha
+        disc = beta ** 2 + 4 * alpha * gamma
+        ok = (alpha > 1e-15) & (disc > 0)
+        new = np.where(ok, (-beta + np.sqrt(np.where(ok, disc, 1.0))) / (2 * np.where(ok, alpha, 1.0)), th)
+        th = np.where(ok & (new >= 0), np.minimum(new, 5.0), th)
+    assert np.allclose(got, th, rtol=1e-9, atol=1e-12)
+
+
+def test_dense_input_fit_with_nb_loss_is_the_all_entries_fit():
+    """Whole fit, dense input + NB: theta has m entries, the loss is the explicit loss over ALL m n entries (explicit_loss.hpp:86-107)
+    and the fit agrees with the sparse-branch fit on the same all-entries CSC to rounding (the branches differ by floors that are not
+    live here and by the eps of G_base)."""
+    D, A, _, _ = _dense_problem(m=21, n=16, seed=37)
+    k = 3
+    W0, H0 = O.init_factors(6, k, A.rows, A.cols, np.float64)
+    fit = O.nmf_fit(A, W0, H0, np.float64, max_iter=3, tol=0.0, loss_type=5, dense_input=True, sort_model=False)
+    L = _olib()
+    pred = (fit.W_T * fit.d) @ fit.H.T
+    tot = sum(_term(L, 5, D[i, j], pred[i, j], fit.theta[i], 1.5) for i in range(A.rows) for j in range(A.cols))
+    assert fit.theta.shape == (A.rows,) and abs(fit.loss - tot) <= 1e-10 * abs(tot)
+    sp = O.nmf_fit(A, W0, H0, np.float64, max_iter=3, tol=0.0, loss_type=5, unfused=True, sort_model=False)
+    assert abs(sp.loss - fit.loss) <= 1e-9 * abs(fit.loss) and np.allclose(sp.H, fit.H, rtol=0, atol=1e-9)
