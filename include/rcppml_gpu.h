@@ -142,6 +142,17 @@ RCPPML_GPU_API void rcppml_gpu_nmf_cv_irls_ex(RCPPML_NMF_CV_ARGS, int* sort_mode
                                               double* gp_theta_init, double* gp_theta_max, double* tweedie_power,
                                               double* robust_delta, double* out_theta);
 
+/* Build-defined: rcppml_gpu_nmf_cv_irls_ex + a user mask -- pattern CSC of the m x n mask (mask_p: n + 1, mask_i: *mask_nnz rows, ascending
+ * inside a column; NULL / 0 = no mask).  The reference's nmf_fit_cv honours NMFConfig::mask (nmf/fit_cv.hpp:327-331, :491-501, :779-790;
+ * nmf/cv_detail.hpp:433-505): a masked entry is in no training sum, its row joins the rows taken out of the column's Gram, and both
+ * losses skip it -- computed explicitly per element for MSE too (:1377-1443).  Its CV boundary has no slot for the mask
+ * (gpu/bridge_nmf.hpp:77-99), hence this entry. */
+RCPPML_GPU_API void rcppml_gpu_nmf_cv_masked_ex(RCPPML_NMF_CV_ARGS, int* sort_model, int* precision, int* cv_patience,
+                                                double* train_history, double* test_history, int* dispersion_mode,
+                                                double* gp_theta_init, double* gp_theta_max, double* tweedie_power,
+                                                double* robust_delta, double* out_theta, const int* mask_p, const int* mask_i,
+                                                int* mask_nnz);
+
 /* Dense-input NMF.  Replaces reference `rcppml_gpu_nmf_dense_unified_float` (resolved by
  * inst/include/FactorNet/gpu/bridge_nmf.hpp:544-545; 50 pointers, typedef :101-126): A_data is the m x n column-major
  * matrix as doubles on the host; W (k x m), H (k x n), d in/out as in the sparse entry.  Semantics: the reference's
@@ -429,6 +440,12 @@ RCPPML_GPU_API int rcppml_hip_solve_cv(rcppml_hip_ctx* ctx, int dtype, const int
                                        const void* values, int64_t ncols, int nrows, const void* F, const void* G, void* X,
                                        int k, double holdout_fraction, unsigned long long cv_seed, int mask_zeros,
                                        int transposed, double l1, int nonneg, int cd_maxit, int solver_mode);
+/* The user mask of a CV fit (see rcppml_gpu_nmf_cv_masked_ex): device pointers to the pattern CSC of the mask (rows x cols of A) and of
+ * its transpose; they must stay valid until the mask is cleared (all four NULL).  While set, rcppml_hip_solve_cv,
+ * rcppml_hip_solve_cv_irls and rcppml_hip_cv_irls_loss exclude its entries as the reference does (rcppml_hip_cv_test_error does not: with
+ * a mask both losses come from rcppml_hip_cv_irls_loss, loss_type 0). */
+RCPPML_GPU_API int rcppml_hip_ctx_set_cv_mask(rcppml_hip_ctx* ctx, const int* mask_p, const int* mask_i, const int* maskT_p,
+                                              const int* maskT_i);
 RCPPML_GPU_API int rcppml_hip_cv_test_error(rcppml_hip_ctx* ctx, int dtype, const int* col_ptr, const int* row_idx,
                                             const void* values, int64_t ncols, int nrows, const void* W_T, const void* d,
                                             const void* H, int k, double holdout_fraction, unsigned long long cv_seed,

@@ -249,9 +249,11 @@ struct SpeckledMask {
 // Per column: b = train right-hand side (cv_detail.hpp:304-352 / :355-405), G_local = G - sum_test f f^T (:66-85),
 // then cholesky_clip_col(G_local, b, x, L1) or cd_nnls_col_fixed(G_local, b, x, L1 inside, cd_maxit sweeps, no
 // tolerance) started from the current column WITHOUT a warm-start correction of b -- as the reference does.
+// umask (optional): the user mask in the orientation of D (pattern; nmf/cv_detail.hpp:433-468 adjust_rhs_for_user_mask_h / _w): a
+// masked row that is not already a test row leaves b (if its entry is a nonzero) and joins the rows of the Gram correction
 template <class S>
 static void cv_half_update(const Csc<S>& D, const S* F, const S* G_full, S* X, int k, const SpeckledMask& mask,
-                           bool transposed, S L1, bool nonneg, int cd_maxit, int solver_mode, int threads) {
+                           bool transposed, S L1, bool nonneg, int cd_maxit, int solver_mode, int threads, const Csc<S>* umask = nullptr) {
     const int nt = eff_threads(threads); (void)nt;
     const int nrow = D.rows;
 #pragma omp parallel num_threads(nt)
@@ -278,6 +280,18 @@ static void cv_half_update(const Csc<S>& D, const S* F, const S* G_full, S* X, i
                     if (held(r)) test.push_back(r);
                     else if (val != S(0)) { const S* fc = F + (size_t)r * k; for (int f = 0; f < k; ++f) b[f] += val * fc[f]; }
                 }
+            }
+            if (umask) {
+                const size_t ntest = test.size();                 // `test` is ascending (both loops above visit rows in order)
+                for (int t = umask->p[j]; t < umask->p[j + 1]; ++t) {
+                    const int r = umask->i[t];
+                    if (std::binary_search(test.begin(), test.begin() + ntest, r)) continue;
+                    const int* lo = std::lower_bound(D.i + D.p[j], D.i + D.p[j + 1], r);
+                    const S a = (lo != D.i + D.p[j + 1] && *lo == r) ? D.x[lo - D.i] : S(0);
+                    if (a != S(0)) { const S* fc = F + (size_t)r * k; for (int f = 0; f < k; ++f) b[f] -= a * fc[f]; }
+                    test.push_back(r);
+                }
+                std::sort(test.begin(), test.end());
             }
             std::memcpy(Gl.data(), G_full, sizeof(S) * k * k);
             for (int r : test) {
@@ -378,7 +392,7 @@ template <class S> static inline S cv_irls_weight(const FitConfig<S>& cfg, S res
 // change of x drops below irls_tol.
 template <class S>
 static void cv_irls_half_update(const Csc<S>& D, const S* F, S* X, int k, const SpeckledMask& mask, bool transposed, S L1, bool nonneg,
-                                const FitConfig<S>& cfg, const S* G_add, int threads) {
+                                const FitConfig<S>& cfg, const S* G_add, int threads, const Csc<S>* umask = nullptr) {
     const int nt = eff_threads(threads); (void)nt;
     const int nrow = D.rows;
 #pragma omp parallel num_threads(nt)
@@ -389,7 +403,11 @@ static void cv_irls_half_update(const Csc<S>& D, const S* F, S* X, int k, const 
 #pragma omp for schedule(dynamic, 16)
         for (int j = 0; j < D.cols; ++j) {
             trow.clear(); tval.clear();
-            auto held = [&](int r) { return transposed ? mask.is_holdout(j, r) : mask.is_holdout(r, j); };
+            // user-masked rows are excluded rows like the test rows (fit_cv.hpp:491-501: gram_rows = test U masked -> is_test)
+            auto held = [&](int r) {
+                if (umask && std::binary_search(umask->i + umask->p[j], umask->i + umask->p[j + 1], r)) return true;
+                return transposed ? mask.is_holdout(j, r) : mask.is_holdout(r, j);
+            };
             if (mask.mask_zeros) {
                 for (int t = D.p[j]; t < D.p[j + 1]; ++t)
                     if (!held(D.i[t])) { trow.push_back(D.i[t]); tval.push_back(D.x[t]); }
@@ -449,7 +467,8 @@ static void cv_irls_half_update(const Csc<S>& D, const S* F, S* X, int k, const 
 // the training and the held-out entries (mask_zeros: nonzeros only; otherwise every entry); theta = GP's theta_vec, 0 otherwise.
 template <class S>
 static void cv_explicit_loss(const Csc<S>& A, const S* W_Td, const S* H, int k, const SpeckledMask& mask, const FitConfig<S>& cfg,
-                             const S* theta, int threads, S* train_sum, int64_t* n_train, S* test_sum, int64_t* n_test) {
+                             const S* theta, int threads, S* train_sum, int64_t* n_train, S* test_sum, int64_t* n_test,
+                             const Csc<S>* umask = nullptr) {
     const int nt = eff_threads(threads); (void)nt;
     S tr = 0, te = 0;
     int64_t ntr = 0, nte = 0;
@@ -457,6 +476,7 @@ static void cv_explicit_loss(const Csc<S>& A, const S* W_Td, const S* H, int k, 
     for (int j = 0; j < A.cols; ++j) {
         const S* h = H + (size_t)j * k;
         auto term = [&](int i, S actual) {
+            if (umask && std::binary_search(umask->i + umask->p[j], umask->i + umask->p[j + 1], i)) return;   // :1391, :1407, :1427
             const S* w = W_Td + (size_t)i * k;
             S pred = 0;
             for (int f = 0; f < k; ++f) pred += w[f] * h[f];
@@ -500,6 +520,13 @@ static CvResult<S> nmf_fit_cv(const Csc<S>& A, const FitConfig<S>& cfg, double h
     int best_iter = 0, patience_count = 0;
     const bool irls = cfg.loss_type != 0 || cfg.robust_delta > S(0);                       // LossConfig::requires_irls()
     const bool is_gp = cfg.loss_type == 4;
+    // user mask (:327-331): excluded rows of every half-update, skipped by the losses -- which are then the explicit per-element
+    // ones for MSE too (:1377-1379 "requires_irls() || use_mask")
+    const Csc<S>* um = cfg.has_mask ? &cfg.mask : nullptr;
+    CscOwned<S> umT_own;
+    Csc<S> umT_view{};
+    if (um) { umT_own = transpose_csc(cfg.mask); umT_view = umT_own.view(); }
+    const Csc<S>* umT = um ? &umT_view : nullptr;
     std::vector<S> theta_vec;                                                               // :195-202
     if (is_gp) theta_vec.assign(m, (cfg.dispersion_mode == 2 || cfg.dispersion_mode == 1) ? cfg.gp_theta_init : S(0));
     std::vector<S> G_add((size_t)k * k);
@@ -511,7 +538,7 @@ static CvResult<S> nmf_fit_cv(const Csc<S>& A, const FitConfig<S>& cfg, double h
             if (cfg.L2_H > 0) for (int i = 0; i < k; ++i) G_add[(size_t)i * k + i] += cfg.L2_H;
             if (cfg.has_graph_H) apply_graph_reg(G_add.data(), cfg.graph_H, H, k, cfg.graph_H_lambda);
             apply_L21(G_add.data(), H, k, (int64_t)n, cfg.L21_H);
-            cv_irls_half_update(A, W_T, H, k, mask, false, cfg.L1_H, cfg.nonneg_H, cfg, G_add.data(), threads);
+            cv_irls_half_update(A, W_T, H, k, mask, false, cfg.L1_H, cfg.nonneg_H, cfg, G_add.data(), threads, um);
             if (cfg.ub_H > 0) apply_upper_bound(H, (size_t)k * n, cfg.ub_H);
             apply_angular_posthoc(H, k, (int64_t)n, cfg.angular_H);
             extract_scaling(H, k, n, d, cfg.norm_type);
@@ -520,7 +547,7 @@ static CvResult<S> nmf_fit_cv(const Csc<S>& A, const FitConfig<S>& cfg, double h
             if (cfg.L2_W > 0) for (int i = 0; i < k; ++i) G_add[(size_t)i * k + i] += cfg.L2_W;
             if (cfg.has_graph_W) apply_graph_reg(G_add.data(), cfg.graph_W, W_T, k, cfg.graph_W_lambda);
             apply_L21(G_add.data(), W_T, k, (int64_t)m, cfg.L21_W);
-            cv_irls_half_update(At, H, W_T, k, mask, true, cfg.L1_W, cfg.nonneg_W, cfg, G_add.data(), threads);
+            cv_irls_half_update(At, H, W_T, k, mask, true, cfg.L1_W, cfg.nonneg_W, cfg, G_add.data(), threads, umT);
             if (cfg.ub_W > 0) apply_upper_bound(W_T, (size_t)k * m, cfg.ub_W);
             apply_angular_posthoc(W_T, k, (int64_t)m, cfg.angular_W);
             extract_scaling(W_T, k, m, d, cfg.norm_type);
@@ -530,7 +557,7 @@ static CvResult<S> nmf_fit_cv(const Csc<S>& A, const FitConfig<S>& cfg, double h
             // ---- losses (:1377-1443, :1546-1549)
             for (int i = 0; i < m; ++i) for (int f = 0; f < k; ++f) Wd[(size_t)i * k + f] = W_T[(size_t)i * k + f] * d[f];
             S tr = 0, te = 0; int64_t ntr = 0, nte = 0;
-            cv_explicit_loss(A, Wd.data(), H, k, mask, cfg, theta_vec.data(), threads, &tr, &ntr, &te, &nte);
+            cv_explicit_loss(A, Wd.data(), H, k, mask, cfg, theta_vec.data(), threads, &tr, &ntr, &te, &nte, um);
             const S train_loss = ntr > 0 ? tr / static_cast<S>(ntr) : S(0);
             const S test_loss = nte > 0 ? te / static_cast<S>(nte) : S(0);
             res.train_hist.push_back(train_loss); res.test_hist.push_back(test_loss);
@@ -554,7 +581,7 @@ static CvResult<S> nmf_fit_cv(const Csc<S>& A, const FitConfig<S>& cfg, double h
         if (cfg.L2_H > 0) for (int i = 0; i < k; ++i) G[(size_t)i * k + i] += cfg.L2_H;   // apply_cv_features (variant_helpers.hpp:174-189)
         if (cfg.has_graph_H) apply_graph_reg(G.data(), cfg.graph_H, H, k, cfg.graph_H_lambda);
         apply_L21(G.data(), H, k, (int64_t)n, cfg.L21_H);
-        cv_half_update(A, W_T, G.data(), H, k, mask, false, cfg.L1_H, cfg.nonneg_H, cfg.cd_maxit, cfg.solver_mode, threads);
+        cv_half_update(A, W_T, G.data(), H, k, mask, false, cfg.L1_H, cfg.nonneg_H, cfg.cd_maxit, cfg.solver_mode, threads, um);
         if (cfg.ub_H > 0) apply_upper_bound(H, (size_t)k * n, cfg.ub_H);
         apply_angular_posthoc(H, k, (int64_t)n, cfg.angular_H);
         extract_scaling(H, k, n, d, cfg.norm_type);                                        // :538-550
@@ -574,12 +601,32 @@ static CvResult<S> nmf_fit_cv(const Csc<S>& A, const FitConfig<S>& cfg, double h
                 for (int f = 0; f < k; ++f) bw[f] += a * hc[f];
             }
         }
-        cv_half_update(At, H, G.data(), W_T, k, mask, true, cfg.L1_W, cfg.nonneg_W, cfg.cd_maxit, cfg.solver_mode, threads);
+        cv_half_update(At, H, G.data(), W_T, k, mask, true, cfg.L1_W, cfg.nonneg_W, cfg.cd_maxit, cfg.solver_mode, threads, umT);
         if (cfg.ub_W > 0) apply_upper_bound(W_T, (size_t)k * m, cfg.ub_W);
         apply_angular_posthoc(W_T, k, (int64_t)m, cfg.angular_W);
         extract_scaling(W_T, k, m, d, cfg.norm_type);                                      // :848-859
         // ---- loss (:1345-1550): every iteration (cv_patience > 0 / history)
         for (int i = 0; i < m; ++i) for (int f = 0; f < k; ++f) Wd[(size_t)i * k + f] = W_T[(size_t)i * k + f] * d[f];
+        if (um) {          // :1377-1443 with loss MSE: explicit train and test sums over the entries that are not user-masked
+            S tr = 0, te = 0; int64_t ntr = 0, nte = 0;
+            cv_explicit_loss(A, Wd.data(), H, k, mask, cfg, theta_vec.data(), threads, &tr, &ntr, &te, &nte, um);
+            const S train_loss = ntr > 0 ? tr / static_cast<S>(ntr) : S(0);
+            const S test_loss = nte > 0 ? te / static_cast<S>(nte) : S(0);
+            res.train_hist.push_back(train_loss); res.test_hist.push_back(test_loss);
+            res.train_loss = train_loss; res.test_loss = test_loss;
+            S rel = 0;
+            if (iter > 0) rel = std::abs(prev_conv - test_loss) / (std::abs(prev_conv) + static_cast<S>(1e-15));
+            if (test_loss < best_test) { best_test = test_loss; best_iter = iter; patience_count = 0; }
+            else ++patience_count;
+            if (cv_patience > 0 && patience_count >= cv_patience) { res.iterations = iter + 1; res.converged = false; break; }
+            if (iter > 0) {
+                res.final_tol = rel;
+                if (rel < cfg.tol) { res.iterations = iter + 1; res.converged = true; break; }
+            }
+            prev_conv = test_loss;
+            res.iterations = iter + 1;
+            continue;
+        }
         S test_sq = 0; int64_t n_test = 0;
         cv_test_error(A, Wd.data(), H, k, mask, threads, &test_sq, &n_test);
         S cross = 0;
@@ -1559,6 +1606,28 @@ ORACLE_API int oracle_cv_is_holdout(double frac, uint64_t cv_seed, int i, int j)
         c.solver_mode = solver_mode; c.threads = threads; c.loss_type = loss_type; c.irls_max_iter = irls_max_iter; \
         c.irls_tol = irls_tol; c.dispersion_mode = dispersion_mode; c.gp_theta_init = gp_theta_init; c.gp_theta_max = gp_theta_max; \
         c.tweedie_power = power; c.robust_delta = robust;                                                          \
+        CvResult<S> r = nmf_fit_cv(mk(m, n, p, i, x), c, frac, cv_seed, mask_zeros != 0, cv_patience, W_T, H, d);   \
+        *out_iter = r.iterations; *out_converged = r.converged ? 1 : 0; *out_train = r.train_loss;                 \
+        *out_test = r.test_loss; *out_best_test = r.best_test_loss; *out_best_iter = r.best_iter;                   \
+        for (size_t t = 0; t < r.train_hist.size(); ++t) { if (train_hist) train_hist[t] = r.train_hist[t]; if (test_hist) test_hist[t] = r.test_hist[t]; } \
+        if (theta_out) for (size_t t = 0; t < r.theta.size(); ++t) theta_out[t] = r.theta[t];                       \
+    }                                                                                                              \
+    /* the same with a user mask (pattern CSC, m x n): MSE or IRLS by loss_type / robust */                         \
+    ORACLE_API void oracle_nmf_fit_cv_masked_##SUF(int m, int n, const int* p, const int* i, const S* x, int k, S* W_T, S* H, \
+                                            S* d, int max_iter, S tol, S L1_H, S L1_W, S L2_H, S L2_W, int cd_maxit, \
+                                            int nonneg_W, int nonneg_H, int norm_type, int solver_mode, double frac, \
+                                            uint64_t cv_seed, int mask_zeros, int cv_patience, int threads,         \
+                                            int loss_type, int irls_max_iter, S irls_tol, int dispersion_mode, S gp_theta_init, \
+                                            S gp_theta_max, S power, S robust, const int* mask_p, const int* mask_i, const S* mask_x, \
+                                            int* out_iter, int* out_converged, S* out_train, S* out_test,           \
+                                            S* out_best_test, int* out_best_iter, S* train_hist, S* test_hist, S* theta_out) { \
+        FitConfig<S> c;                                                                                            \
+        c.k = k; c.max_iter = max_iter; c.tol = tol; c.L1_H = L1_H; c.L1_W = L1_W; c.L2_H = L2_H; c.L2_W = L2_W;    \
+        c.cd_maxit = cd_maxit; c.nonneg_W = nonneg_W != 0; c.nonneg_H = nonneg_H != 0; c.norm_type = norm_type;     \
+        c.solver_mode = solver_mode; c.threads = threads; c.loss_type = loss_type; c.irls_max_iter = irls_max_iter; \
+        c.irls_tol = irls_tol; c.dispersion_mode = dispersion_mode; c.gp_theta_init = gp_theta_init; c.gp_theta_max = gp_theta_max; \
+        c.tweedie_power = power; c.robust_delta = robust;                                                          \
+        if (mask_p) { c.has_mask = true; c.mask = mk(m, n, mask_p, mask_i, mask_x); }                              \
         CvResult<S> r = nmf_fit_cv(mk(m, n, p, i, x), c, frac, cv_seed, mask_zeros != 0, cv_patience, W_T, H, d);   \
         *out_iter = r.iterations; *out_converged = r.converged ? 1 : 0; *out_train = r.train_loss;                 \
         *out_test = r.test_loss; *out_best_test = r.best_test_loss; *out_best_iter = r.best_iter;                   \

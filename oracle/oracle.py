@@ -542,11 +542,39 @@ class CvFitResult:
 def nmf_fit_cv(A, W_T, H, dtype=np.float64, max_iter=100, tol=1e-4, L1=(0.0, 0.0), L2=(0.0, 0.0), cd_maxit=100,
                nonneg=(True, True), norm_type=0, solver_mode=0, holdout_fraction=0.1, cv_seed=0, mask_zeros=False,
                cv_patience=5, threads=1, native=False, graph_H=None, graph_W=None, loss_type=0, irls_max_iter=5, irls_tol=1e-4,
-               dispersion_mode=2, gp_theta=(0.1, 5.0), tweedie_power=1.5, robust_delta=0.0):
-    """CPU restatement of nmf_fit_cv (reference nmf/fit_cv.hpp), sparse.  Returns W_T (normalised), H WITH d
+               dispersion_mode=2, gp_theta=(0.1, 5.0), tweedie_power=1.5, robust_delta=0.0, mask=None):
+    """CPU restatement of nmf_fit_cv (reference nmf/fit_cv.hpp), sparse.  mask (Csc pattern, m x n): the user mask of
+    fit_cv.hpp:327-331 -- its entries leave every half-update and both losses.  Returns W_T (normalised), H WITH d
     absorbed and d, as the reference packages them.  loss_type != 0 (4 GP, 5 NB, 6 Gamma, 7 inverse Gaussian, 8 Tweedie) or
     robust_delta > 0: the IRLS path (no graph arguments there); result.theta = GP theta at exit."""
     suf, ct = _suf(dtype)
+    if mask is not None:
+        assert graph_H is None and graph_W is None
+        W_T = _f(W_T, dtype).copy()
+        H = _f(H, dtype).copy()
+        m, k = W_T.shape
+        n = H.shape[0]
+        d = np.ones(k, dtype)
+        x = A.values(dtype)
+        mx = np.ones(mask.i.shape[0], dtype)
+        th = np.full(max(max_iter, 1), np.nan, dtype)
+        eh = np.full(max(max_iter, 1), np.nan, dtype)
+        theta = np.zeros(m, dtype)
+        it, conv, bi = C.c_int(0), C.c_int(0), C.c_int(0)
+        tr, te, bt = ct(0), ct(0), ct(0)
+        getattr(lib(native), "oracle_nmf_fit_cv_masked_" + suf)(
+            C.c_int(m), C.c_int(n), _p(A.p), _p(A.i), _p(x), C.c_int(k), _p(W_T), _p(H), _p(d), C.c_int(max_iter), ct(tol),
+            ct(L1[1]), ct(L1[0]), ct(L2[1]), ct(L2[0]), C.c_int(cd_maxit), C.c_int(int(nonneg[0])), C.c_int(int(nonneg[1])),
+            C.c_int(norm_type), C.c_int(solver_mode), C.c_double(holdout_fraction), C.c_uint64(cv_seed), C.c_int(int(mask_zeros)),
+            C.c_int(cv_patience), C.c_int(threads), C.c_int(loss_type), C.c_int(irls_max_iter), ct(irls_tol), C.c_int(dispersion_mode),
+            ct(gp_theta[0]), ct(gp_theta[1]), ct(tweedie_power), ct(robust_delta), _p(mask.p), _p(mask.i), _p(mx),
+            C.byref(it), C.byref(conv), C.byref(tr), C.byref(te), C.byref(bt), C.byref(bi), _p(th), _p(eh), _p(theta))
+        r = CvFitResult()
+        r.W_T, r.H, r.d, r.theta = W_T, H, d, theta
+        r.iter, r.converged = it.value, bool(conv.value)
+        r.train_loss, r.test_loss, r.best_test_loss, r.best_iter = float(tr.value), float(te.value), float(bt.value), bi.value
+        r.train_history, r.test_history = th[:it.value].copy(), eh[:it.value].copy()
+        return r
     if loss_type != 0 or robust_delta > 0:
         assert graph_H is None and graph_W is None
         W_T = _f(W_T, dtype).copy()

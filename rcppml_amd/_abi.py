@@ -20,7 +20,7 @@ OPT_CD_COUNT_NOOP, OPT_CD_LMF_LANE_GROUPS, OPT_CD_LMF_WAVES_PER_SIMD, OPT_CD_NO_
 # Every symbol include/rcppml_gpu.h declares (tests check the library exports all of them).
 EXPORTED_SYMBOLS = [
     "rcppml_gpu_detect", "rcppml_gpu_nmf_unified_float", "rcppml_gpu_nmf_unified_double", "rcppml_gpu_nmf_ex",
-    "rcppml_gpu_nmf_cv_unified_float", "rcppml_gpu_nmf_cv_unified_double", "rcppml_gpu_nmf_cv_ex", "rcppml_gpu_nmf_cv_irls_ex", "rcppml_gpu_nmf_zerocopy_double",
+    "rcppml_gpu_nmf_cv_unified_float", "rcppml_gpu_nmf_cv_unified_double", "rcppml_gpu_nmf_cv_ex", "rcppml_gpu_nmf_cv_irls_ex", "rcppml_gpu_nmf_cv_masked_ex", "rcppml_hip_ctx_set_cv_mask", "rcppml_gpu_nmf_zerocopy_double",
     "rcppml_gpu_nnls_double", "rcppml_gpu_evaluate_mse_double", "rcppml_gpu_nmf_profile_double", "rcppml_gpu_last_error",
     "rcppml_hip_ctx_create", "rcppml_hip_ctx_destroy", "rcppml_hip_ctx_sync", "rcppml_hip_ctx_stats", "rcppml_hip_ctx_irls_stats", "rcppml_hip_ctx_cd_step_stats", "rcppml_hip_ctx_set_option", "rcppml_hip_transpose_csc", "rcppml_hip_transpose_csc_sort", "rcppml_hip_transpose_csc_gather", "rcppml_hip_cast", "rcppml_hip_gram", "rcppml_hip_rhs",
     "rcppml_hip_solve_cd", "rcppml_hip_order_columns", "rcppml_hip_solve_chol", "rcppml_hip_row_norms", "rcppml_hip_apply_scaling",
@@ -272,10 +272,10 @@ def nmf_cv(p, i, x, m, n, k, W_T, H, *, entry="ex", max_iter=100, tol=1e-4, L1_H
            verbose=0, seed=0, holdout_fraction=0.1, cv_seed=0, mask_zeros=0, nonneg_W=1, nonneg_H=1, norm_type=0, loss_type=0,
            solver_mode=0, projective=0, symmetric=0, graph_W_nnz=0, sort_model=1, precision=F64, cv_patience=5,
            graph_W=None, graph_H=None, irls_max_iter=5, irls_tol=1e-4, dispersion_mode=2, gp_theta=(0.1, 5.0), tweedie_power=1.5,
-           robust_delta=0.0):
+           robust_delta=0.0, mask=None):
     """Call the CV plugin entry as reference gpu/bridge_nmf.hpp:407-497 does (51 pointers; entry "float" | "double"), or
     the build-defined "ex" form (+ sort flag, precision, patience, loss histories) or "irls_ex" (+ dispersion mode, GP theta
-    init / max, Tweedie power, robust_delta; returns theta).  W_T (m, k) and H (n, k) float64 arrays are updated IN PLACE (H
+    init / max, Tweedie power, robust_delta; returns theta), or -- mask = (mask_p, mask_i) given -- "masked_ex" (irls_ex + the user mask).  W_T (m, k) and H (n, k) float64 arrays are updated IN PLACE (H
     returns with d absorbed).  loss_type 4..8: the IRLS CV path."""
     L = lib()
     p = np.ascontiguousarray(p, np.int32)
@@ -310,7 +310,18 @@ def nmf_cv(p, i, x, m, n, k, W_T, H, *, entry="ex", max_iter=100, tol=1e-4, L1_H
     assert len(args) == 51
     th = eh = None
     theta = None
-    if entry == "irls_ex":
+    if mask is not None:
+        mp = np.ascontiguousarray(mask[0], np.int32); mi = np.ascontiguousarray(mask[1], np.int32)
+        if mi.shape[0] == 0:
+            mi = np.zeros(1, np.int32)
+        th = np.full(max(max_iter, 1), np.nan)
+        eh = np.full(max(max_iter, 1), np.nan)
+        theta = np.zeros(max(m, 1), np.float64)
+        fn = L.rcppml_gpu_nmf_cv_masked_ex
+        fn.restype = None
+        fn(*args, _ci(sort_model), _ci(precision), _ci(cv_patience), _np_ptr(th), _np_ptr(eh), _ci(dispersion_mode), _cd(gp_theta[0]),
+           _cd(gp_theta[1]), _cd(tweedie_power), _cd(robust_delta), _np_ptr(theta), _np_ptr(mp), _np_ptr(mi), _ci(int(mp[-1])))
+    elif entry == "irls_ex":
         th = np.full(max(max_iter, 1), np.nan)
         eh = np.full(max(max_iter, 1), np.nan)
         theta = np.zeros(max(m, 1), np.float64)

@@ -77,6 +77,10 @@ struct rcppml_hip_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     int num_cu = 256;
+    // user mask of a cross-validation fit (rcppml_hip_ctx_set_cv_mask): pattern CSC of the mask [0] and of its transpose [1], device
+    // pointers owned by the caller; the CV ops read the one that matches the CSC they are handed (their `transposed` flag)
+    const int* cv_mask_p[2] = {nullptr, nullptr};
+    const int* cv_mask_i[2] = {nullptr, nullptr};
     struct Buf { void* ptr = nullptr; size_t bytes = 0; };
     Buf bufs[WS_COUNT];
     // device counters read by rcppml_hip_ctx_stats: [0] column-sweeps executed by the CD kernels, [1] columns solved

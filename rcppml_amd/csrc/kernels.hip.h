@@ -1577,11 +1577,31 @@ __device__ __forceinline__ unsigned long long cv_hash_dev(unsigned long long see
     return h ^ (h >> 31);
 }
 
+// user mask of a CV fit (fit_cv.hpp:327-331; cv_detail.hpp:408-415 is_user_masked_h): pattern CSC in the orientation of the CSC the
+// kernel walks, rows ascending inside a column; NULL = none.  Bisection: masks are sparse and the question is asked per entry.
+__device__ __forceinline__ bool cv_user_masked(const int* __restrict__ mp, const int* __restrict__ mi, int64_t j, int row) {
+    if (!mp) return false;
+    int lo = mp[j];
+    const int end = mp[j + 1];
+    int hi = end;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (mi[mid] < row) lo = mid + 1; else hi = mid; }
+    return lo < end && mi[lo] == row;
+}
+// is `row` one of the stored rows of column [ts, te) of a CSC with ascending rows?
+__device__ __forceinline__ bool cv_row_stored(const int* __restrict__ rowidx, int ts, int te, int row) {
+    int lo = ts, hi = te;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (rowidx[mid] < row) lo = mid + 1; else hi = mid; }
+    return lo < te && rowidx[lo] == row;
+}
+
+// (mp, mi: optional user mask, cv_detail.hpp:433-505 -- a masked row that is not already a test row leaves b and joins the rows of
+// the Gram correction, whether its entry is a nonzero or not)
 template <class T, int KP>   // KP in {32, 64}
 __global__ __launch_bounds__(256) void cv_solve_kernel(
     const int* __restrict__ colptr, const int* __restrict__ rowidx, const T* __restrict__ vals, int64_t ncols, int nrows,
     const T* __restrict__ F, const T* __restrict__ Gfull, T* __restrict__ X, int k, unsigned long long seed,
-    unsigned long long threshold, int mask_zeros, int transposed, T l1, int nonneg, int maxit, int solver_mode) {
+    unsigned long long threshold, int mask_zeros, int transposed, T l1, int nonneg, int maxit, int solver_mode,
+    const int* __restrict__ mp = nullptr, const int* __restrict__ mi = nullptr) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     T* Gl = reinterpret_cast<T*>(smem_raw) + (size_t)wave * KP * KP;   // [c][r]
@@ -1602,7 +1622,7 @@ __global__ __launch_bounds__(256) void cv_solve_kernel(
         const bool held = (transposed ? cv_hash_dev(seed, col, (unsigned)row) : cv_hash_dev(seed, (unsigned)row, col)) < threshold;
         const T fr = fok ? F[(int64_t)row * k + lane] : T(0);
         if (!held) {
-            b = tfma(vals[t], fr, b);
+            if (!cv_user_masked(mp, mi, j, row)) b = tfma(vals[t], fr, b);
         } else if (mask_zeros) {
             for (int c = 0; c < k; ++c) {
                 const T fc = __shfl(fr, c, 64);
@@ -1625,6 +1645,19 @@ __global__ __launch_bounds__(256) void cv_solve_kernel(
                     const T fc = __shfl(fr, c, 64);
                     if (lin) Gl[c * KP + lane] -= fr * fc;
                 }
+            }
+        }
+    }
+    if (mp) {               // user-masked rows that are not test rows: out of the Gram as well
+        const int ts = colptr[j], te = colptr[j + 1];
+        for (int t = mp[j]; t < mp[j + 1]; ++t) {
+            const int row = mi[t];
+            const bool held = (transposed ? cv_hash_dev(seed, col, (unsigned)row) : cv_hash_dev(seed, (unsigned)row, col)) < threshold;
+            if (held && (!mask_zeros || cv_row_stored(rowidx, ts, te, row))) continue;      // already corrected above
+            const T fr = fok ? F[(int64_t)row * k + lane] : T(0);
+            for (int c = 0; c < k; ++c) {
+                const T fc = __shfl(fr, c, 64);
+                if (lin) Gl[c * KP + lane] -= fr * fc;
             }
         }
     }

@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void cv_irls_solve_kernel(
     const int* __restrict__ colptr, const int* __restrict__ rowidx, const T* __restrict__ vals, int64_t ncols, int nrows,
     const T* __restrict__ F, const T* __restrict__ Gadd, T* __restrict__ X, int k, unsigned long long seed,
     unsigned long long threshold, int mask_zeros, int transposed, T l1, int nonneg, int maxit, int solver_mode, int loss_type,
-    int irls_max_iter, T irls_tol, T power, T robust) {
+    int irls_max_iter, T irls_tol, T power, T robust, const int* __restrict__ mp = nullptr, const int* __restrict__ mi = nullptr) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     T* Gl = reinterpret_cast<T*>(smem_raw) + (size_t)wave * KP * KP;   // [c][r]
@@ -117,7 +117,8 @@ __global__ __launch_bounds__(256) void cv_irls_solve_kernel(
     const unsigned col = (unsigned)j;
     const int ts = colptr[j], te = colptr[j + 1];
     T x = fok ? X[j * (int64_t)k + lane] : T(0);
-    auto held_row = [&](int row) {
+    auto held_row = [&](int row) {          // excluded rows: held out, or user-masked (fit_cv.hpp:491-501 -> cv_detail.hpp:116-117)
+        if (cv_user_masked(mp, mi, j, row)) return true;
         return (transposed ? cv_hash_dev(seed, col, (unsigned)row) : cv_hash_dev(seed, (unsigned)row, col)) < threshold;
     };
     for (int it = 0; it < irls_max_iter; ++it) {
@@ -211,7 +212,8 @@ __global__ __launch_bounds__(256) void cv_irls_loss_kernel(
     const int* __restrict__ colptr, const int* __restrict__ rowidx, const T* __restrict__ vals, int64_t ncols, int nrows,
     const T* __restrict__ W_T, const T* __restrict__ d, const T* __restrict__ H, const T* __restrict__ theta_row, int k,
     unsigned long long seed, unsigned long long threshold, int mask_zeros, int loss_type, double power,
-    double* __restrict__ psum /*2 per block*/, unsigned long long* __restrict__ pcnt /*2 per block*/) {
+    double* __restrict__ psum /*2 per block*/, unsigned long long* __restrict__ pcnt /*2 per block*/,
+    const int* __restrict__ mp = nullptr, const int* __restrict__ mi = nullptr) {
     __shared__ double sh[4][2];
     __shared__ unsigned long long shn[4][2];
     __shared__ T hs[4][128];
@@ -227,6 +229,7 @@ __global__ __launch_bounds__(256) void cv_irls_loss_kernel(
     if (j < ncols) {
         const int as = colptr[j], ae = colptr[j + 1];
         auto term = [&](int row, T a) {
+            if (cv_user_masked(mp, mi, j, row)) return;              // fit_cv.hpp:1391, :1407: user-masked entries are in neither sum
             const T* wr = W_T + (int64_t)row * k;
             T pred = T(0);
             for (int c = 0; c < k; ++c) pred = tfma(wr[c] * dsh[c], hs[wave][c], pred);

@@ -308,7 +308,8 @@ template <class T>
 __global__ __launch_bounds__(64) void wide_cv_solve_kernel(
     const int* __restrict__ colptr, const int* __restrict__ rowidx, const T* __restrict__ vals, int64_t ncols, int nrows,
     const T* __restrict__ F, const T* __restrict__ Gfull, T* __restrict__ X, int k, unsigned long long seed,
-    unsigned long long threshold, int mask_zeros, int transposed, T l1, int nonneg, int maxit, int solver_mode) {
+    unsigned long long threshold, int mask_zeros, int transposed, T l1, int nonneg, int maxit, int solver_mode,
+    const int* __restrict__ mp = nullptr, const int* __restrict__ mi = nullptr) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int64_t j = blockIdx.x;
     if (j >= ncols) return;
@@ -330,6 +331,7 @@ __global__ __launch_bounds__(64) void wide_cv_solve_kernel(
     for (int t = colptr[j]; t < colptr[j + 1]; ++t) {
         const int row = rowidx[t];
         if (!held_row(row)) {
+            if (cv_user_masked(mp, mi, j, row)) continue;
             T fr[2];
             wc.load_row(F, row, fr);
             b[0] = tfma(vals[t], fr[0], b[0]);
@@ -347,6 +349,14 @@ __global__ __launch_bounds__(64) void wide_cv_solve_kernel(
                 m &= m - 1;
                 held_entry(r0 + bit);
             }
+        }
+    }
+    if (mp) {               // user-masked rows that are not test rows (cv_detail.hpp:433-468): out of the Gram as well
+        const int ts = colptr[j], te = colptr[j + 1];
+        for (int t = mp[j]; t < mp[j + 1]; ++t) {
+            const int row = mi[t];
+            if (held_row(row) && (!mask_zeros || cv_row_stored(rowidx, ts, te, row))) continue;
+            held_entry(row);
         }
     }
     if (ne) wc.template flush<false>(ne);
@@ -371,7 +381,7 @@ __global__ __launch_bounds__(64) void wide_cv_irls_solve_kernel(
     const int* __restrict__ colptr, const int* __restrict__ rowidx, const T* __restrict__ vals, int64_t ncols, int nrows,
     const T* __restrict__ F, const T* __restrict__ Gadd, T* __restrict__ X, int k, unsigned long long seed,
     unsigned long long threshold, int mask_zeros, int transposed, T l1, int nonneg, int maxit, int solver_mode, int loss_type,
-    int irls_max_iter, T irls_tol, T power, T robust) {
+    int irls_max_iter, T irls_tol, T power, T robust, const int* __restrict__ mp = nullptr, const int* __restrict__ mi = nullptr) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int64_t j = blockIdx.x;
     if (j >= ncols) return;
@@ -379,7 +389,8 @@ __global__ __launch_bounds__(64) void wide_cv_irls_solve_kernel(
     const int lane = wc.lane;
     const unsigned col = (unsigned)j;
     const int ts = colptr[j], te = colptr[j + 1];
-    auto held_row = [&](int row) {
+    auto held_row = [&](int row) {          // excluded rows: held out, or user-masked (fit_cv.hpp:491-501 -> cv_detail.hpp:116-117)
+        if (cv_user_masked(mp, mi, j, row)) return true;
         return (transposed ? cv_hash_dev(seed, col, (unsigned)row) : cv_hash_dev(seed, (unsigned)row, col)) < threshold;
     };
     T x[2];

@@ -27,17 +27,20 @@ void cv_solve_impl(rcppml_hip_ctx* c, const int* cp, const int* ri, const T* val
     if (solver_mode != 0 && solver_mode != 1) throw std::runtime_error("solve_cv: solver_mode must be 0 (CD) or 1 (Cholesky+clip)");
     unsigned long long seed, thr;
     mask_params(frac, cv_seed, &seed, &thr);
+    // user mask of the fit (rcppml_hip_ctx_set_cv_mask; cv_detail.hpp:433-505): the generic kernels take it, the MFMA forms below do not
+    const int* mp = c->cv_mask_p[transposed ? 1 : 0];
+    const int* mi = c->cv_mask_i[transposed ? 1 : 0];
     if (k > 64) {          // one wave per column, two features per lane, Gram tile in LDS (kernels_wide.hip.h)
         auto kern = wide_cv_solve_kernel<T>;
         static DynSmemOnce once;
         once.ensure(reinterpret_cast<const void*>(kern), wide_smem_bytes<T>(), c->device);
         hipLaunchKernelGGL(kern, dim3((unsigned)ncols), dim3(64), wide_smem_bytes<T>(), c->stream, cp, ri, vals, ncols, nrows, F, G, X, k,
-                           seed, thr, mask_zeros, transposed, l1, nonneg, maxit, solver_mode);
+                           seed, thr, mask_zeros, transposed, l1, nonneg, maxit, solver_mode, mp, mi);
         HIPCHK(hipGetLastError());
         return;
     }
     const int64_t nblk = (ncols + 3) / 4;
-    if constexpr (std::is_same<T, float>::value) {
+    if constexpr (std::is_same<T, float>::value) if (!mp) {
         // fp32, k <= 32: Gram correction on the matrix cores (RCPPML_GPU_CV_VARIANT=valu keeps the LDS read-modify-write form)
         static int use_mfma = -1;
         if (use_mfma < 0) use_mfma = exp_flag("RCPPML_GPU_CV_VARIANT", "valu") ? 0 : 1;
@@ -58,7 +61,7 @@ void cv_solve_impl(rcppml_hip_ctx* c, const int* cp, const int* ri, const T* val
             return;
         }
     }
-    if constexpr (std::is_same<T, double>::value) {
+    if constexpr (std::is_same<T, double>::value) if (!mp) {
         static int use_mfma64 = -1;
         if (use_mfma64 < 0) use_mfma64 = exp_flag("RCPPML_GPU_CV_VARIANT", "valu") ? 0 : 1;
         if (use_mfma64 && k <= 32 && k % 2 == 0 && reinterpret_cast<uintptr_t>(F) % 16 == 0) {
@@ -71,14 +74,14 @@ void cv_solve_impl(rcppml_hip_ctx* c, const int* cp, const int* ri, const T* val
     }
     if (k <= 32) {
         hipLaunchKernelGGL((cv_solve_kernel<T, 32>), dim3((unsigned)nblk), dim3(256), (size_t)4 * 32 * 32 * sizeof(T), c->stream, cp, ri,
-                           vals, ncols, nrows, F, G, X, k, seed, thr, mask_zeros, transposed, l1, nonneg, maxit, solver_mode);
+                           vals, ncols, nrows, F, G, X, k, seed, thr, mask_zeros, transposed, l1, nonneg, maxit, solver_mode, mp, mi);
     } else {
         const size_t smem = (size_t)4 * 64 * 64 * sizeof(T);
         auto kern = cv_solve_kernel<T, 64>;
         static DynSmemOnce once;
         once.ensure(reinterpret_cast<const void*>(kern), smem, c->device);
         hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), smem, c->stream, cp, ri, vals, ncols, nrows, F, G, X, k, seed, thr,
-                           mask_zeros, transposed, l1, nonneg, maxit, solver_mode);
+                           mask_zeros, transposed, l1, nonneg, maxit, solver_mode, mp, mi);
     }
     HIPCHK(hipGetLastError());
 }
@@ -148,4 +151,15 @@ extern "C" int rcppml_hip_cv_test_error(rcppml_hip_ctx* c, int dtype, const int*
         return 0;
     }
     RCPPML_CATCH_RET
+}
+
+// The user mask of a cross-validation fit (reference NMFConfig::mask under nmf_fit_cv, nmf/fit_cv.hpp:327-331): pattern CSC of the mask
+// (m x n) and of its transpose, device pointers that stay valid until the mask is cleared (all four NULL).  While set, rcppml_hip_solve_cv,
+// rcppml_hip_solve_cv_irls and rcppml_hip_cv_irls_loss treat its entries as the reference does (cv_detail.hpp:433-505, fit_cv.hpp:1391-1427).
+extern "C" int rcppml_hip_ctx_set_cv_mask(rcppml_hip_ctx* c, const int* mask_p, const int* mask_i, const int* maskT_p, const int* maskT_i) {
+    if (!c) return -1;
+    if ((mask_p == nullptr) != (maskT_p == nullptr) || (mask_p && (!mask_i || !maskT_i))) { rcppml_err() = "set_cv_mask: give the mask and its transpose, or neither"; return -1; }
+    c->cv_mask_p[0] = mask_p; c->cv_mask_i[0] = mask_i;
+    c->cv_mask_p[1] = maskT_p; c->cv_mask_i[1] = maskT_i;
+    return 0;
 }

@@ -26,26 +26,28 @@ void solve_impl(rcppml_hip_ctx* c, int loss_type, const int* cp, const int* ri, 
     unsigned long long seed, thr;
     cvi_mask_params(frac, cv_seed, &seed, &thr);
     const int64_t nblk = (ncols + 3) / 4;
+    const int* mp = c->cv_mask_p[transposed ? 1 : 0];          // user mask of the fit, if one is set (rcppml_hip_ctx_set_cv_mask)
+    const int* mi = c->cv_mask_i[transposed ? 1 : 0];
     if (k > 64) {          // one wave per column, two features per lane, Gram tile in LDS (kernels_wide.hip.h)
         auto kern = wide_cv_irls_solve_kernel<T>;
         static DynSmemOnce once;
         once.ensure(reinterpret_cast<const void*>(kern), wide_smem_bytes<T>(), c->device);
         hipLaunchKernelGGL(kern, dim3((unsigned)ncols), dim3(64), wide_smem_bytes<T>(), c->stream, cp, ri, vals, ncols, nrows, F, Gadd, X, k,
-                           seed, thr, mask_zeros, transposed, l1, nonneg, maxit, solver_mode, loss_type, irls_max_iter, irls_tol, power, robust);
+                           seed, thr, mask_zeros, transposed, l1, nonneg, maxit, solver_mode, loss_type, irls_max_iter, irls_tol, power, robust, mp, mi);
         HIPCHK(hipGetLastError());
         return;
     }
     if (k <= 32) {
         hipLaunchKernelGGL((cv_irls_solve_kernel<T, 32>), dim3((unsigned)nblk), dim3(256), (size_t)4 * 32 * 32 * sizeof(T), c->stream, cp, ri, vals,
                            ncols, nrows, F, Gadd, X, k, seed, thr, mask_zeros, transposed, l1, nonneg, maxit, solver_mode, loss_type,
-                           irls_max_iter, irls_tol, power, robust);
+                           irls_max_iter, irls_tol, power, robust, mp, mi);
     } else {
         const size_t smem = (size_t)4 * 64 * 64 * sizeof(T);
         auto kern = cv_irls_solve_kernel<T, 64>;
         static DynSmemOnce once;
         once.ensure(reinterpret_cast<const void*>(kern), smem, c->device);
         hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), smem, c->stream, cp, ri, vals, ncols, nrows, F, Gadd, X, k, seed, thr,
-                           mask_zeros, transposed, l1, nonneg, maxit, solver_mode, loss_type, irls_max_iter, irls_tol, power, robust);
+                           mask_zeros, transposed, l1, nonneg, maxit, solver_mode, loss_type, irls_max_iter, irls_tol, power, robust, mp, mi);
     }
     HIPCHK(hipGetLastError());
 }
@@ -61,7 +63,7 @@ void loss_impl(rcppml_hip_ctx* c, int loss_type, const int* cp, const int* ri, c
     double* ps = reinterpret_cast<double*>(buf);
     unsigned long long* pn = reinterpret_cast<unsigned long long*>(buf + (size_t)nblk * 16);
     hipLaunchKernelGGL(cv_irls_loss_kernel<T>, dim3((unsigned)nblk), dim3(256), 0, c->stream, cp, ri, vals, ncols, nrows, W_T, d, H, theta, k,
-                       seed, thr, mask_zeros, loss_type, power, ps, pn);
+                       seed, thr, mask_zeros, loss_type, power, ps, pn, c->cv_mask_p[0], c->cv_mask_i[0]);        // (the loss walks A itself)
     HIPCHK(hipGetLastError());
     hipLaunchKernelGGL(cv_irls_loss_final_kernel, dim3(1), dim3(256), 0, c->stream, ps, pn, (int)nblk, out4);
     HIPCHK(hipGetLastError());

@@ -756,6 +756,8 @@ struct CvParams {
     int loss_type = 0, irls_max_iter = 5; double irls_tol = 1e-4;
     int dispersion_mode = 2; double gp_theta_init = 0.1, gp_theta_max = 5.0, tweedie_power = 1.5, robust_delta = 0.0;
     double* out_theta = nullptr;          // m doubles (GP theta at exit), may be NULL
+    // user mask (NMFConfig::mask under nmf_fit_cv, fit_cv.hpp:327-331): pattern CSC, m x n; build-defined entry rcppml_gpu_nmf_cv_masked_ex
+    const int* mask_p = nullptr; const int* mask_i = nullptr;
     int out_iter = 0, out_converged = 0, out_best_iter = 0; double out_train = 0, out_test = 0, out_best_test = 0;
 };
 
@@ -774,6 +776,21 @@ void fit_cv(CvParams& P) {
     dTi.alloc((size_t)std::max<int64_t>(P.nnz, 1) * sizeof(int));
     dTx.alloc((size_t)std::max<int64_t>(P.nnz, 1) * sizeof(T));
     OPCHK(rcppml_hip_transpose_csc(c, dt, m, n, dAp.as<int>(), dAi.as<int>(), dAx.p, dTp.as<int>(), dTi.as<int>(), dTx.p));
+    // user mask: its pattern and the pattern of its transpose stay on the device for the fit; the CV ops find them through the
+    // context (rcppml_hip_ctx_set_cv_mask), cleared again on every way out
+    const bool has_mask = P.mask_p != nullptr;
+    DevBuf dMp, dMi, dMTp, dMTi;
+    struct CvMaskGuard { rcppml_hip_ctx* c; bool on = false; ~CvMaskGuard() { if (on) (void)rcppml_hip_ctx_set_cv_mask(c, nullptr, nullptr, nullptr, nullptr); } } mask_guard{c};
+    if (has_mask) {
+        const int mnnz = P.mask_p[n];
+        upload_ints(P.mask_p, (size_t)n + 1, dMp, s);
+        upload_ints(P.mask_i, (size_t)std::max(mnnz, 1), dMi, s);
+        dMTp.alloc(((size_t)m + 1) * sizeof(int));
+        dMTi.alloc((size_t)std::max(mnnz, 1) * sizeof(int));
+        OPCHK(rcppml_hip_transpose_csc(c, dt, m, n, dMp.as<int>(), dMi.as<int>(), nullptr, dMTp.as<int>(), dMTi.as<int>(), nullptr));
+        OPCHK(rcppml_hip_ctx_set_cv_mask(c, dMp.as<int>(), dMi.as<int>(), dMTp.as<int>(), dMTi.as<int>()));
+        mask_guard.on = true;
+    }
     DevBuf dW, dH, dd;
     upload_cast<T>(c, P.W, (size_t)k * m, dW, s);
     upload_cast<T>(c, P.H, (size_t)k * n, dH, s);
@@ -882,11 +899,21 @@ void fit_cv(CvParams& P) {
         OPCHK(rcppml_hip_gram(c, dt, dH.p, k, n, eps, 0.0, dGs.p));
         OPCHK(rcppml_hip_gram(c, dt, dH.p, k, n, 2 * eps, P.L2_W, dG.p));
         if (graph_W) OPCHK(rcppml_hip_apply_graph_reg(c, dt, dG.p, dGWp.as<int>(), dGWi.as<int>(), dGWx.p, dW.p, k, m, P.gW_lambda));   // :580-581
-        OPCHK(rcppml_hip_rhs(c, dt, dTp.as<int>(), dTi.as<int>(), dTx.p, m, dH.p, k, dBw.p));      // B_W_full: train + test
+        if (!has_mask) OPCHK(rcppml_hip_rhs(c, dt, dTp.as<int>(), dTi.as<int>(), dTx.p, m, dH.p, k, dBw.p));      // B_W_full: train + test
         OPCHK(rcppml_hip_solve_cv(c, dt, dTp.as<int>(), dTi.as<int>(), dTx.p, m, n, dH.p, dG.p, dW.p, k, P.holdout_fraction,
                                   P.cv_seed, P.mask_zeros, 1, P.L1_W, P.nonneg_W, P.cd_maxit, P.solver_mode));
         OPCHK(rcppml_hip_row_norms(c, dt, dW.p, k, m, P.norm_type, dsums.p));
         OPCHK(rcppml_hip_apply_scaling(c, dt, dW.p, k, m, P.norm_type, dsums.p, dd.p));
+        if (has_mask) {
+            // ---- losses under a user mask (:1377-1443, "requires_irls() || use_mask"): explicit squared errors, train and test, over the
+            // entries that are not user-masked -- the Gram trick would count the masked ones
+            OPCHK(rcppml_hip_cv_irls_loss(c, dt, 0, dAp.as<int>(), dAi.as<int>(), dAx.p, n, m, dW.p, dd.p, dH.p, nullptr, k, P.holdout_fraction,
+                                          P.cv_seed, P.mask_zeros, P.tweedie_power, dloss.as<double>()));
+            HIPCHK(hipMemcpyAsync(hbuf, dloss.p, 4 * sizeof(double), hipMemcpyDeviceToHost, s));
+            HIPCHK(hipStreamSynchronize(s));
+            train_loss = hbuf[1] > 0 ? as_scalar(as_scalar(hbuf[0]) / hbuf[1]) : 0.0;
+            test_loss = hbuf[3] > 0 ? as_scalar(as_scalar(hbuf[2]) / hbuf[3]) : 0.0;
+        } else {
         // ---- losses (:1345-1550): held-out squared error; total squared error by the Gram trick with B_W_full
         OPCHK(rcppml_hip_cv_test_error(c, dt, dAp.as<int>(), dAi.as<int>(), dAx.p, n, m, dW.p, dd.p, dH.p, k, P.holdout_fraction,
                                        P.cv_seed, P.mask_zeros, dtest.as<double>()));
@@ -903,6 +930,7 @@ void fit_cv(CvParams& P) {
         const int64_t n_train = total_entries - n_test;
         train_loss = n_train > 0 ? as_scalar(train_sq / (double)n_train) : 0.0;
         test_loss = n_test > 0 ? as_scalar(test_sq / (double)n_test) : 0.0;
+        }
         if (P.train_history) P.train_history[iter] = train_loss;
         if (P.test_history) P.test_history[iter] = test_loss;
         double rel = 0;
@@ -944,7 +972,7 @@ void fit_cv(CvParams& P) {
 // what the reference's CV boundary does not carry (build-defined entry rcppml_gpu_nmf_cv_irls_ex)
 struct CvExtra { int dispersion_mode; double gp_theta_init, gp_theta_max, tweedie_power, robust_delta; double* out_theta; };
 void nmf_cv_entry(RCPPML_NMF_CV_ARGS, int sort_model, int precision, int cv_patience, double* train_history, double* test_history,
-                  const CvExtra* cv_extra = nullptr) {
+                  const CvExtra* cv_extra = nullptr, const int* mask_p = nullptr, const int* mask_i = nullptr, int mask_nnz = 0) {
     try {
         rcppml_err().clear();
         *out_status = -1;
@@ -983,6 +1011,13 @@ void nmf_cv_entry(RCPPML_NMF_CV_ARGS, int sort_model, int precision, int cv_pati
         }
         P.gH_p = graph_H_p; P.gH_i = graph_H_i; P.gH_x = graph_H_x; P.gH_nnz = *graph_H_nnz; P.gH_lambda = *graph_H_lambda;
         P.gW_p = graph_W_p; P.gW_i = graph_W_i; P.gW_x = graph_W_x; P.gW_nnz = *graph_W_nnz; P.gW_lambda = *graph_W_lambda;
+        if (mask_p && mask_nnz > 0) {
+            if (mask_p[*n] != mask_nnz) throw std::runtime_error("CV: mask_p[n] != mask_nnz");
+            for (int j = 0; j < *n; ++j)
+                for (int t = mask_p[j]; t < mask_p[j + 1]; ++t)
+                    if (mask_i[t] < 0 || mask_i[t] >= *m || (t > mask_p[j] && mask_i[t] <= mask_i[t - 1])) throw std::runtime_error("CV: mask rows must be ascending inside a column and inside the matrix");
+            P.mask_p = mask_p; P.mask_i = mask_i;
+        }
         if (precision == RCPPML_F64) fit_cv<double>(P); else fit_cv<float>(P);
         *out_iter = P.out_iter; *out_converged = P.out_converged; *out_train_loss = P.out_train; *out_test_loss = P.out_test;
         *out_best_test = P.out_best_test; *out_best_iter = P.out_best_iter;
@@ -1020,6 +1055,16 @@ extern "C" void rcppml_gpu_nmf_cv_irls_ex(RCPPML_NMF_CV_ARGS, int* sort_model, i
                                           double* tweedie_power, double* robust_delta, double* out_theta) {
     CvExtra ex{*dispersion_mode, *gp_theta_init, *gp_theta_max, *tweedie_power, *robust_delta, out_theta};
     nmf_cv_entry(RCPPML_NMF_CV_PASS, *sort_model, *precision, *cv_patience, train_history, test_history, &ex);
+}
+
+// build-defined: the same + a user mask (pattern CSC of the m x n mask; NULL / 0 = none) -- the reference's nmf_fit_cv honours
+// NMFConfig::mask (nmf/fit_cv.hpp:327-331) but its CV boundary has no slot for it (gpu/bridge_nmf.hpp:77-99)
+extern "C" void rcppml_gpu_nmf_cv_masked_ex(RCPPML_NMF_CV_ARGS, int* sort_model, int* precision, int* cv_patience, double* train_history,
+                                            double* test_history, int* dispersion_mode, double* gp_theta_init, double* gp_theta_max,
+                                            double* tweedie_power, double* robust_delta, double* out_theta, const int* mask_p,
+                                            const int* mask_i, int* mask_nnz) {
+    CvExtra ex{*dispersion_mode, *gp_theta_init, *gp_theta_max, *tweedie_power, *robust_delta, out_theta};
+    nmf_cv_entry(RCPPML_NMF_CV_PASS, *sort_model, *precision, *cv_patience, train_history, test_history, &ex, mask_p, mask_i, mask_nnz ? *mask_nnz : 0);
 }
 
 // Zero-copy entry (reference src/gpu_bridge_nmf.cu:879-967, R/sp_gpu.R): the CSC arrays are DEVICE pointers whose

@@ -115,8 +115,6 @@ def nmf(data, k, tol=1e-4, maxit=100, L1=(0.0, 0.0), L2=(0.0, 0.0), seed=None, m
     if cv:
         if not (0 < test_fraction < 1):
             raise ValueError("test_fraction must be in [0, 1)")
-        if mask is not None and not isinstance(mask, str):
-            raise NotImplementedError("cross-validation with an explicit mask matrix is not implemented by the MI355X backend")
     if resource != "gpu":
         raise ValueError("rcppml_amd has no CPU path; resource must be 'gpu'")
     dense_in = isinstance(data, np.ndarray) and data.ndim == 2        # a base R matrix: the reference's dense path
@@ -201,6 +199,10 @@ def nmf(data, k, tol=1e-4, maxit=100, L1=(0.0, 0.0), L2=(0.0, 0.0), seed=None, m
                          irls_max_iter=int(irls_max_iter), irls_tol=float(irls_tol),
                          dispersion_mode={"none": 0, "global": 1, "per_row": 2}[dispersion], gp_theta=(float(theta_init), float(theta_max)),
                          tweedie_power=float(tweedie_power), robust_delta=float(robust_delta))
+        if mask_arg is not None:          # fit_cv.hpp:327-331: the user mask under CV (build-defined entry rcppml_gpu_nmf_cv_masked_ex)
+            if graph_args:
+                raise NotImplementedError("graph regularisation together with a mask matrix is not implemented for cross-validation")
+            cv_kw["mask"] = mask_arg
         res = _abi.nmf_cv(A.p, A.i, A.x, m, n, k, W_T, H, entry="irls_ex" if irls_cv else "ex", **cv_kw, max_iter=int(maxit), tol=float(tol), L1_H=L1h, L1_W=L1w,
                           L2_H=L2h, L2_W=L2w, cd_maxit=int(cd_maxit), verbose=int(verbose), seed=seed_int & 0x7FFFFFFF,
                           holdout_fraction=float(test_fraction), cv_seed=seed_int & 0x7FFFFFFF,

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 from oracle import oracle as O
-from tests.util import lowrank_csc
+from tests.util import lowrank_csc, random_csc
 
 pytestmark = pytest.mark.gpu
 
@@ -156,8 +156,8 @@ def test_cv_python_surface():
     assert mod.w.min() >= 0 and mod.h.min() >= 0
     mz = N.nmf(Ap, 4, test_fraction=0.1, seed=3, maxit=5, mask="zeros")
     assert np.isfinite(mz.misc["test_loss"])
-    with pytest.raises(NotImplementedError):
-        N.nmf(Ap, 4, test_fraction=0.1, seed=3, mask=np.ones((80, 110)))
+    mm = N.nmf(Ap, 4, test_fraction=0.1, seed=3, maxit=3, mask=(np.arange(80 * 110).reshape(80, 110) % 7 == 0).astype(float))   # round 5: runs
+    assert np.isfinite(mm.misc["test_loss"])
 
 
 @pytest.mark.parametrize("loss", ["gp", "gamma", "tweedie"])
@@ -364,3 +364,112 @@ def test_cv_irls_reference_entry_takes_config_defaults():
     assert res["status"] == 0 and res["iter"] == ref.iter
     assert abs(res["test_loss"] - ref.test_loss) <= 1e-6 * abs(ref.test_loss)
     assert abs(res["train_loss"] - ref.train_loss) <= 1e-6 * abs(ref.train_loss)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# Cross-validation together with a user mask (reference nmf/fit_cv.hpp:327-331, :491-501, :779-790, :1377-1443; cv_detail.hpp:433-505);
+# build-defined entry rcppml_gpu_nmf_cv_masked_ex, oracle pieces pinned to brute-force numpy in tests/test_oracle_cv.py
+# ---------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("precision,tol_loss,tol_fac", [("f64", 1e-7, 1e-6), ("f32", 2e-3, 5e-3)])
+@pytest.mark.parametrize("k", [4, 40, 72])
+@pytest.mark.parametrize("solver", [1, 0])
+@pytest.mark.parametrize("mask_zeros", [0, 1])
+def test_cv_fit_with_user_mask_through_plugin(precision, tol_loss, tol_fac, k, solver, mask_zeros):
+    """MSE CV fit with a user mask (masked nonzeros AND masked zeros) vs the oracle: iteration count, early-stopping decision, both
+    loss histories (explicit per-element means over the unmasked entries), factors; ranks on the 32-, 64- and wide-tile kernels."""
+    from rcppml_amd import _abi
+    if k > 4 and solver == 1:
+        pytest.skip("Cholesky on the near-singular Grams of a rank far above the data's: no stable trajectory to compare (CD carries these ranks)")
+    A = lowrank_csc(90, 120, 3, 0.3, seed=4)
+    M = random_csc(90, 120, 0.12, 77)
+    dtype = np.float64 if precision == "f64" else np.float32
+    W0, H0 = O.init_factors(6, k, A.rows, A.cols, np.float64)
+    kw = dict(max_iter=8, tol=1e-7, solver_mode=solver, holdout_fraction=0.12, cv_seed=9, cv_patience=5)
+    ref = O.nmf_fit_cv(A, W0, H0, dtype, L1=(0.0, 0.01), L2=(0.02, 0.0), mask_zeros=bool(mask_zeros), mask=M, **kw)
+    free = O.nmf_fit_cv(A, W0, H0, dtype, L1=(0.0, 0.01), L2=(0.02, 0.0), mask_zeros=bool(mask_zeros), **kw)
+    assert abs(free.test_history[0] - ref.test_history[0]) > 1e-4 * abs(ref.test_history[0])       # the mask matters
+    W, H = W0.copy(), H0.copy()
+    res = _abi.nmf_cv(A.p, A.i, A.x, A.rows, A.cols, k, W, H, entry="ex", L1_H=0.01, L2_W=0.02, mask_zeros=mask_zeros, sort_model=0,
+                      precision=_abi.F64 if precision == "f64" else _abi.F32, mask=(M.p, M.i), **kw)
+    assert res["status"] == 0, res.get("error")
+    assert res["iter"] == ref.iter and res["converged"] == ref.converged
+    if precision == "f64":
+        assert res["best_iter"] == ref.best_iter
+    tl = tol_loss * (10 if k > 4 else 1)         # (rank above the data's: the per-column Grams are close to singular, rounding grows)
+    assert np.allclose(res["test_history"], ref.test_history, rtol=tl, atol=0), (res["test_history"], ref.test_history)
+    assert np.allclose(res["train_history"], ref.train_history, rtol=tl, atol=0)
+    if k == 4:
+        assert np.abs(res["d"] - ref.d).max() <= tol_fac * np.abs(ref.d).max()
+        assert np.abs(W - ref.W_T).max() < tol_fac and np.abs(H - ref.H).max() < tol_fac * max(1.0, np.abs(ref.H).max())
+
+
+@pytest.mark.parametrize("loss_type", [4, 6, 8])
+@pytest.mark.parametrize("mask_zeros", [0, 1])
+def test_cv_irls_fit_with_user_mask_through_plugin(loss_type, mask_zeros):
+    """IRLS CV fit with a user mask, fp64: the masked entries leave the weighted Grams of both half-updates and both losses."""
+    from rcppml_amd import _abi
+    A = _counts_csc(50, 70, 0.3, seed=30 + loss_type)
+    M = random_csc(50, 70, 0.15, 5)
+    k = 3
+    rng = np.random.default_rng(loss_type)
+    W0 = rng.uniform(0.2, 1.0, size=(A.rows, k)); H0 = rng.uniform(0.2, 1.0, size=(A.cols, k))
+    kw = dict(max_iter=5, tol=1e-9, solver_mode=1 if loss_type == 8 else 0, holdout_fraction=0.15, cv_seed=5, cv_patience=4)
+    ref = O.nmf_fit_cv(A, W0, H0, np.float64, L1=(0.0, 0.01), L2=(0.02, 0.0), mask_zeros=bool(mask_zeros), loss_type=loss_type, irls_max_iter=3,
+                       irls_tol=1e-4, mask=M, **kw)
+    W, H = W0.copy(), H0.copy()
+    res = _abi.nmf_cv(A.p, A.i, A.x, A.rows, A.cols, k, W, H, entry="irls_ex", L1_H=0.01, L2_W=0.02, mask_zeros=mask_zeros, sort_model=0,
+                      precision=_abi.F64, loss_type=loss_type, irls_max_iter=3, irls_tol=1e-4, mask=(M.p, M.i), **kw)
+    assert res["status"] == 0, res.get("error")
+    assert res["iter"] == ref.iter and res["converged"] == ref.converged and res["best_iter"] == ref.best_iter
+    assert np.allclose(res["test_history"], ref.test_history, rtol=1e-6, atol=0), (res["test_history"], ref.test_history)
+    assert np.allclose(res["train_history"], ref.train_history, rtol=1e-6, atol=0)
+    assert np.abs(res["d"] - ref.d).max() <= 1e-5 * np.abs(ref.d).max()
+    assert np.abs(W - ref.W_T).max() < 1e-5 and np.abs(H - ref.H).max() < 1e-5 * max(1.0, np.abs(ref.H).max())
+    if loss_type == 4:
+        assert np.abs(res["theta"] - ref.theta).max() <= 1e-5 * max(np.abs(ref.theta).max(), 1e-30)
+
+
+def test_cv_user_mask_edge_cases_and_surface():
+    """An empty mask is the unmasked fit bit for bit (same kernels route aside: the generic solve kernel is what runs either way at
+    k = 5, fp64 uses the MFMA form without a mask -> compared to rounding); a mask that covers a whole column leaves that column at
+    alone with an empty right-hand side; malformed masks are refused; nmf(mask = <matrix>, test_fraction > 0) reaches
+    the entry; the context's mask is cleared after the fit (the next unmasked fit is the unmasked fit)."""
+    import scipy.sparse as sp
+    from rcppml_amd import _abi, nmf as N
+    A = lowrank_csc(60, 45, 3, 0.35, seed=12)
+    k = 5
+    W0, H0 = O.init_factors(3, k, A.rows, A.cols, np.float64)
+    kw = dict(max_iter=4, tol=0.0, holdout_fraction=0.2, cv_seed=2, cv_patience=0, sort_model=0, precision=_abi.F64)
+    W1, H1 = W0.copy(), H0.copy()
+    plain = _abi.nmf_cv(A.p, A.i, A.x, A.rows, A.cols, k, W1, H1, entry="ex", **kw)
+    W2, H2 = W0.copy(), H0.copy()
+    empty = _abi.nmf_cv(A.p, A.i, A.x, A.rows, A.cols, k, W2, H2, entry="ex", mask=(np.zeros(A.cols + 1, np.int32), np.zeros(0, np.int32)), **kw)
+    assert plain["status"] == 0 and empty["status"] == 0
+    assert np.allclose(W1, W2, rtol=0, atol=1e-10) and np.allclose(H1, H2, rtol=0, atol=1e-10)
+    assert np.allclose(plain["test_history"], empty["test_history"], rtol=1e-9, atol=0)
+    # every nonzero of column 7 masked: its right-hand side is empty, its Gram loses those rows
+    nz7 = A.i[A.p[7]:A.p[8]].astype(np.int32)
+    mp = np.zeros(A.cols + 1, np.int32); mp[8:] = nz7.shape[0]
+    Mcol = O.Csc((A.rows, A.cols), mp, nz7, np.ones(nz7.shape[0]))
+    ref = O.nmf_fit_cv(A, W0, H0, np.float64, max_iter=4, tol=0.0, holdout_fraction=0.2, cv_seed=2, cv_patience=0, mask=Mcol)
+    W3, H3 = W0.copy(), H0.copy()
+    full = _abi.nmf_cv(A.p, A.i, A.x, A.rows, A.cols, k, W3, H3, entry="ex", mask=(mp, nz7), **kw)
+    assert full["status"] == 0 and np.allclose(full["test_history"], ref.test_history, rtol=1e-7, atol=0)
+    assert np.abs(H3 - ref.H).max() < 1e-6 and np.abs(H3[7]).max() < 0.2 * np.abs(H1[7]).max()      # nothing pulls the column up
+    # malformed: descending rows, row out of range
+    bad = _abi.nmf_cv(A.p, A.i, A.x, A.rows, A.cols, k, W0.copy(), H0.copy(), entry="ex",
+                      mask=(np.r_[0, 2, np.full(A.cols - 1, 2)].astype(np.int32), np.array([5, 3], np.int32)), **kw)
+    assert bad["status"] == -1 and "mask" in bad["error"]
+    bad = _abi.nmf_cv(A.p, A.i, A.x, A.rows, A.cols, k, W0.copy(), H0.copy(), entry="ex",
+                      mask=(np.r_[0, 1, np.full(A.cols - 1, 1)].astype(np.int32), np.array([A.rows], np.int32)), **kw)
+    assert bad["status"] == -1
+    # the next fit without a mask is the plain one again
+    W4, H4 = W0.copy(), H0.copy()
+    again = _abi.nmf_cv(A.p, A.i, A.x, A.rows, A.cols, k, W4, H4, entry="ex", **kw)
+    assert np.array_equal(W4, W1) and np.array_equal(H4, H1) and np.array_equal(again["test_history"], plain["test_history"])
+    # R surface
+    Msp = sp.random(A.rows, A.cols, density=0.1, format="csc", random_state=3)
+    Asp = sp.csc_matrix((A.x, A.i, A.p), shape=(A.rows, A.cols))
+    mod = N.nmf(Asp, 3, test_fraction=0.2, mask=Msp, seed=5, maxit=4, tol=0.0, precision="fp64")
+    nomask = N.nmf(Asp, 3, test_fraction=0.2, seed=5, maxit=4, tol=0.0, precision="fp64")
+    assert np.isfinite(mod.misc["test_loss"]) and mod.misc["test_loss"] != nomask.misc["test_loss"]

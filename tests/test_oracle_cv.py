@@ -124,3 +124,79 @@ def test_cv_gp_theta_without_holdout_is_the_plain_update():
     held = holdout_matrix(m, n, 0.2, 3)
     untouched = ~held.any(axis=1)
     assert np.array_equal(all_entries[untouched], masked[untouched])
+
+
+@pytest.mark.parametrize("mask_zeros", [False, True])
+def test_cv_fit_with_user_mask_excludes_masked_entries_everywhere(mask_zeros):
+    """nmf_fit_cv with a user mask (fit_cv.hpp:327-331, :491-501, :779-790; cv_detail.hpp:433-505; losses :1377-1443), one MSE
+    iteration restated over dense arrays: per column the excluded rows are the test rows (held-out nonzeros with mask_zeros, every
+    held-out row without) UNION the user-masked rows; b sums the nonzeros that are neither held out nor masked; the Gram loses
+    f f^T of every excluded row (a masked ZERO entry too); CD starts from the current column with b used as it is; train and test
+    losses are explicit means over the entries that are not user-masked (nonzeros only with mask_zeros)."""
+    m, n, k, frac, seed, sweeps = 21, 16, 3, 0.25, 5, 6
+    A = random_csc(m, n, 0.45, 8, values="poisson")
+    M = random_csc(m, n, 0.2, 9)
+    D, Mk = dense_of(A), dense_of(M) != 0
+    assert (Mk & (D == 0)).any() and (Mk & (D != 0)).any()          # masked zeros and masked nonzeros both occur
+    held = holdout_matrix(m, n, frac, seed)
+    W0, H0 = O.init_factors(3, k, m, n, np.float64)
+    fit = O.nmf_fit_cv(A, W0, H0, np.float64, max_iter=1, tol=0.0, cd_maxit=sweeps, holdout_fraction=frac, cv_seed=seed,
+                       mask_zeros=mask_zeros, mask=M, L1=(0.01, 0.02))
+
+    def half(F, Dd, hd, mk, X, l1):
+        G = F.T @ F + 2e-15 * np.eye(k)
+        out = np.empty_like(X)
+        for j in range(Dd.shape[1]):
+            nz = Dd[:, j] != 0
+            test = hd[:, j] & nz if mask_zeros else hd[:, j]
+            excl = test | mk[:, j]
+            train_nz = nz & ~hd[:, j] & ~mk[:, j]
+            b = F[train_nz].T @ Dd[train_nz, j]
+            Gl = G - F[excl].T @ F[excl]
+            out[j], _, _ = O.cd_col(Gl, b, X[j].copy(), L1=l1, maxit=sweeps, tol=0.0)
+        s = np.abs(out).sum(axis=0) + 1e-15
+        return out / s, s
+
+    H, d = half(W0, D, held, Mk, H0, 0.02)
+    W, d = half(H, D.T, held.T, Mk.T, W0, 0.01)
+    pred = (W * d) @ H.T
+    use = ~Mk & ((D != 0) if mask_zeros else np.ones_like(Mk))
+    se = (D - pred) ** 2
+    want_test, want_train = se[use & held].mean(), se[use & ~held].mean()
+    assert np.allclose(fit.W_T, W, rtol=0, atol=1e-10) and np.allclose(fit.H, H * d, rtol=0, atol=1e-10)
+    assert abs(fit.test_loss - want_test) <= 1e-10 * want_test and abs(fit.train_loss - want_train) <= 1e-10 * want_train
+    # an empty mask is the unmasked fit's factors (its losses come from the Gram-trick branch: equal to rounding)
+    E = O.Csc((m, n), np.zeros(n + 1, np.int32), np.zeros(0, np.int32), np.zeros(0))
+    a = O.nmf_fit_cv(A, W0, H0, np.float64, max_iter=2, tol=0.0, cd_maxit=sweeps, holdout_fraction=frac, cv_seed=seed, mask_zeros=mask_zeros, mask=E)
+    b = O.nmf_fit_cv(A, W0, H0, np.float64, max_iter=2, tol=0.0, cd_maxit=sweeps, holdout_fraction=frac, cv_seed=seed, mask_zeros=mask_zeros)
+    assert np.array_equal(a.W_T, b.W_T) and np.array_equal(a.H, b.H) and abs(a.test_loss - b.test_loss) <= 1e-12 * b.test_loss
+    if not mask_zeros:      # (with mask_zeros the Gram-trick branch's total includes the zero entries' predictions, :1500-1530; the explicit one does not)
+        assert abs(a.train_loss - b.train_loss) <= 1e-9 * b.train_loss
+
+
+@pytest.mark.parametrize("loss_type", [4, 6])
+def test_cv_irls_fit_with_user_mask_drops_masked_entries_from_the_weighted_solves(loss_type):
+    """IRLS CV with a user mask: the masked rows join is_test (cv_detail.hpp:116-117 via gram_rows), i.e. the training entries of a
+    column are the not-held-out, not-masked ones; one half-update restated with the pinned weights."""
+    m, n, k, frac, seed = 19, 14, 3, 0.2, 11
+    A = random_csc(m, n, 0.5, 4, values="poisson")
+    M = random_csc(m, n, 0.2, 6)
+    D, Mk = dense_of(A), dense_of(M) != 0
+    held = holdout_matrix(m, n, frac, seed)
+    W0, H0 = O.init_factors(8, k, m, n, np.float64)
+    fit = O.nmf_fit_cv(A, W0, H0, np.float64, max_iter=1, tol=0.0, cd_maxit=5, holdout_fraction=frac, cv_seed=seed, mask_zeros=False,
+                       mask=M, loss_type=loss_type, irls_max_iter=1, dispersion_mode=0)
+    # H after the first half-update = fit.H / d restated: one IRLS pass from H0
+    Hb = np.empty_like(H0)
+    for j in range(n):
+        tr = ~held[:, j] & ~Mk[:, j]
+        x = H0[j].copy()
+        pred = W0[tr] @ x
+        w = np.array([weight(loss_type, p, 1.5) for p in pred])
+        Gw = (W0[tr] * w[:, None]).T @ W0[tr] + 1e-15 * np.eye(k)
+        bw = W0[tr].T @ (w * D[tr, j])
+        Hb[j], _, _ = O.cd_col(Gw, bw, x, maxit=5, tol=0.0)
+    s = np.abs(Hb).sum(axis=0) + 1e-15
+    # the returned H carries the FINAL d (after the W update); compare the normalised shape of the H half-update
+    Hn = fit.H / (np.abs(fit.H).sum(axis=0))
+    assert np.allclose(Hn, (Hb / s) / np.abs(Hb / s).sum(axis=0), rtol=0, atol=1e-9)
