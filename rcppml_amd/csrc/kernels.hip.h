@@ -2489,29 +2489,35 @@ static __global__ __launch_bounds__(256) void order_scatter_kernel(const int* __
         base[threadIdx.x] = incl - tot + before;
     }
     __syncthreads();
-    // lane l of a wavefront carries the running start of bins l and l + 64 of ITS quarter in registers
-    unsigned int b_lo = base[lane], b_hi = base[lane + 64] + half_total;
-    for (int v = 0; v < w; ++v) { b_lo += wcnt[v][lane]; b_hi += wcnt[v][lane + 64]; }
+    // wcnt[w][x] <- where wavefront w's first column of bin x goes (the bins of the wavefronts before it come first)
+    if (threadIdx.x < 128) {
+        unsigned int run = base[threadIdx.x] + (threadIdx.x >= 64 ? half_total : 0u);
+        for (int v = 0; v < 4; ++v) { const unsigned int t = wcnt[v][threadIdx.x]; wcnt[v][threadIdx.x] = run; run += t; }
+    }
+    __syncthreads();
+    volatile unsigned int* wb = wcnt[w];                       // this wavefront's running bin starts (LDS; one wavefront = program order)
     const unsigned long long lt = (1ull << lane) - 1ull;
     for (int64_t r = j0; r < j1; r += 64) {
         const int64_t i = r + lane;
         const bool valid = i < j1;
-        int bin = -1;
+        int bin = 0;
         if (valid) {
             int key = sweeps[i];
             key = key < 0 ? 0 : (key > 127 ? 127 : key);
             bin = 127 - key;
         }
-        unsigned long long todo = __ballot(valid);
+        // lanes with my bin: seven ballots, one per bit of the bin (no loop over the distinct keys of the round)
+        unsigned long long same = __ballot(valid);
+#pragma unroll
+        for (int bit = 0; bit < 7; ++bit) {
+            const unsigned long long bm = __ballot((bin >> bit) & 1);
+            same &= ((bin >> bit) & 1) ? bm : ~bm;
+        }
         unsigned int pos = 0;
-        while (todo) {                                         // one turn per distinct key among the 64 columns
-            const int src = __ffsll((long long)todo) - 1;
-            const int kb = __shfl(bin, src, 64);
-            const unsigned long long grp = __ballot(bin == kb);
-            const unsigned int start = __shfl(kb < 64 ? b_lo : b_hi, kb & 63, 64);
-            if (bin == kb) pos = start + (unsigned int)__popcll(grp & lt);
-            if (lane == (kb & 63)) { if (kb < 64) b_lo += (unsigned int)__popcll(grp); else b_hi += (unsigned int)__popcll(grp); }
-            todo &= ~grp;
+        if (valid) {
+            const unsigned int start = wb[bin];                 // every lane of the group reads the same word ...
+            pos = start + (unsigned int)__popcll(same & lt);
+            if ((same & lt) == 0ull) wb[bin] = start + (unsigned int)__popcll(same);      // ... its lowest lane moves it on
         }
         // Serpentine: positions are handed out longest-first; every second group of 16 workgroups (128 slots each: four
         // 32-column or eight 16-column wavefronts) is laid out in reverse, so that neighbouring workgroups -- which the
