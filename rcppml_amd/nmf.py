@@ -118,6 +118,23 @@ def nmf(data, k, tol=1e-4, maxit=100, L1=(0.0, 0.0), L2=(0.0, 0.0), seed=None, m
     if resource != "gpu":
         raise ValueError("rcppml_amd has no CPU path; resource must be 'gpu'")
     dense_in = isinstance(data, np.ndarray) and data.ndim == 2        # a base R matrix: the reference's dense path
+    # NA values (R/nmf_validation.R:44-51, :69-76 warn; R/nmf_thin.R:686-696 set them to 0 and mask <- "NA"; validate_mask :253-257
+    # then returns an EMPTY mask matrix with a `mask_na` flag nothing downstream reads): the fit sees zeros there, as in the reference
+    if dense_in and np.isnan(data).any():
+        import warnings
+        n_na = int(np.isnan(data).sum())
+        warnings.warn("Detected %d NA values (%.2f%% of data). Automatically creating mask for missing values." % (n_na, 100.0 * n_na / data.size))
+        data = np.where(np.isnan(data), 0.0, data)
+        if mask is None:
+            mask = "NA"
+    elif hasattr(data, "tocsc") and np.isnan(data.data).any():
+        import warnings
+        n_na = int(np.isnan(data.data).sum())
+        warnings.warn("Detected %d NA values (%.2f%% of data). Automatically creating mask for missing values." % (n_na, 100.0 * n_na / (data.shape[0] * data.shape[1])))
+        data = data.copy()
+        data.data[np.isnan(data.data)] = 0.0
+        if mask is None:
+            mask = "NA"
     A = _as_csc(data)
     m, n = A.shape
     if symmetric and m != n:
@@ -176,6 +193,8 @@ def nmf(data, k, tol=1e-4, maxit=100, L1=(0.0, 0.0), L2=(0.0, 0.0), seed=None, m
         if isinstance(mask, str):
             if mask == "zeros":
                 pass            # fit-time no-op in the reference; only evaluate() honours it
+            elif mask == "NA":
+                pass            # validate_mask: an empty mask matrix (R/nmf_validation.R:256-257); the NAs are zeros by now
             else:
                 raise NotImplementedError("mask='%s' is not implemented" % mask)
         else:

@@ -178,3 +178,58 @@ def test_dense_fit_with_nb_loss_fp32_entry_and_surface():
     assert np.abs(W - ref.W_T).max() <= 5e-3 and np.abs(H - ref.H).max() <= 5e-3
     mod = N.nmf(M, k, loss="nb", seed=4, maxit=3, tol=0.0, precision="fp64")
     assert mod.misc["input"] == "dense" and mod.misc["theta"].shape == (m,) and np.isfinite(mod.misc["loss"])
+
+
+def test_reference_dense_irls_properties():
+    """The properties the reference's own tests/testthat/test_dense_irls.R asserts for dense input under non-MSE losses, on the GPU
+    path: robust = TRUE / "mae" and GP fits end with a finite loss and non-negative factors (:7-45), dense and sparse robust fits of
+    the same data end within an order of magnitude (:47-62), robust with L1 + L2 (:84-95), dense GP under cross-validation (:97-107),
+    and the Gamma / inverse Gaussian / Tweedie fits improve on their second iteration's loss (:113-160; the dense boundary returns
+    no history, so the second iteration's loss comes from a two-iteration fit of the same seed -- the fits are deterministic)."""
+    from rcppml_amd import nmf as N
+    import scipy.sparse as sp
+    rng = np.random.default_rng(42)
+    A = np.abs(rng.standard_normal((50, 40))) + 0.1
+    for kw in (dict(robust=True), dict(robust="mae"), dict(loss="gp"), dict(robust=True, L1=(0.01, 0.01), L2=(0.01, 0.01))):
+        mod = N.nmf(A + (0.4 if kw.get("loss") == "gp" else 0.0), 3, maxit=50, tol=1e-5, seed=42, precision="fp64", **kw)
+        assert mod.misc["input"] == "dense" and np.isfinite(mod.misc["loss"]) and mod.w.min() >= 0 and mod.h.min() >= 0, kw
+    S = np.abs(rng.standard_normal((30, 3))) @ np.abs(rng.standard_normal((3, 25))) + 0.1 * np.abs(rng.standard_normal((30, 25)))
+    md = N.nmf(S, 3, robust=True, maxit=30, seed=42, precision="fp64")
+    ms = N.nmf(sp.csc_matrix(S), 3, robust=True, maxit=30, seed=42, precision="fp64")
+    assert abs(md.misc["loss"] - ms.misc["loss"]) / max(md.misc["loss"], ms.misc["loss"]) < 1.0
+    cv = N.nmf(A + 0.4, 3, test_fraction=0.1, loss="gp", maxit=20, seed=42, precision="fp64")
+    assert np.isfinite(cv.misc["loss"]) and np.isfinite(cv.misc["test_loss"])
+    G = np.maximum(np.abs(2.0 + 0.5 * rng.standard_normal((50, 40))), 1e-8)
+    for loss, extra in (("gamma", {}), ("inverse_gaussian", {}), ("tweedie", dict(tweedie_power=1.5))):
+        full = N.nmf(G, 3, loss=loss, dispersion="per_row", maxit=30, tol=1e-6, seed=42, precision="fp64", **extra)
+        two = N.nmf(G, 3, loss=loss, dispersion="per_row", maxit=2, tol=0.0, seed=42, precision="fp64", **extra)
+        assert np.isfinite(full.misc["loss"]) and full.w.min() >= 0, loss
+        assert full.misc["loss"] < two.misc["loss"], (loss, full.misc["loss"], two.misc["loss"])
+
+
+def test_reference_na_handling_properties():
+    """tests/testthat/test_masking.R:240-300 on the GPU path: NA values in a dense matrix are detected with the reference's warning,
+    the fit succeeds with finite loss and non-negative factors, explicit mask = "NA" works, and the region without NAs is fitted well
+    (R/nmf_thin.R:686-696: the NAs become zeros, mask <- "NA", whose mask matrix is empty, R/nmf_validation.R:253-257)."""
+    from rcppml_amd import nmf as N
+    rng = np.random.default_rng(42)
+    A = rng.uniform(size=(100, 50))
+    A[:5, :5] = np.nan
+    with pytest.warns(UserWarning, match="Detected 25 NA values"):
+        mod = N.nmf(A, 3, maxit=20, seed=1, precision="fp64")
+    assert np.isfinite(mod.misc["loss"]) and mod.w.min() >= 0 and mod.h.min() >= 0
+    B = rng.uniform(size=(80, 40)); B[:3, :3] = np.nan
+    with pytest.warns(UserWarning):
+        m2 = N.nmf(B, 2, mask="NA", maxit=15, seed=1, precision="fp64")
+    assert np.isfinite(m2.misc["loss"])
+    Cm = rng.uniform(size=(60, 40))
+    orig = Cm[9:15, 9:15].copy()
+    Cm[:5, :5] = np.nan
+    with pytest.warns(UserWarning):
+        m3 = N.nmf(Cm, 3, maxit=30, seed=1, precision="fp64")
+    recon = (m3.w * m3.d) @ m3.h
+    assert np.mean((orig - recon[9:15, 9:15]) ** 2) < 0.5
+    # the same zeros, passed as zeros, give the same fit: the "mask" of the reference is empty
+    Z = np.where(np.isnan(Cm), 0.0, Cm)
+    m4 = N.nmf(Z, 3, maxit=30, seed=1, precision="fp64")
+    assert np.array_equal(m3.w, m4.w) and m3.misc["loss"] == m4.misc["loss"]
