@@ -53,6 +53,8 @@ def parse():
     ap.add_argument("--no-order", action="store_true", help="disable sweep-count column ordering")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline work (s)")
     ap.add_argument("--no-plugin-figure", action="store_true", help="skip the PCIe-inclusive 73-pointer plugin call")
+    ap.add_argument("--no-fused-tail", action="store_true",
+                    help="scaling / work order / loss as their separate kernels (nine and seven launches between two solves instead of four): A/B of the fused tail")
     ap.add_argument("--w-solve", choices=["block", "replicated"], default="block",
                     help="N > 1: W half-update solved in row blocks + one all-gather (default) or replicated on every rank")
     ap.add_argument("--no-graph", action="store_true", help="time an eager launch loop instead of replays of one captured hipGraph")
@@ -253,6 +255,7 @@ def main():
     stream_ctx = torch.cuda.stream(side) if use_graph else contextlib.nullcontext()
     with stream_ctx:
         ops = als.HipOps(local_rank, args.dtype, record_events=False)
+        ops.fused_tail = not args.no_fused_tail
         st = als.ShardedALS(ops, comm, A_loc, At_loc, W0, H0, cfg)
         for _ in range(args.warmup):
             st.step()
@@ -300,8 +303,11 @@ def main():
                 graph.replay()
             loss = st.loss_out
         else:
-            for _ in range(args.steps):
+            for i in range(args.steps):
+                # (the last step's solves keep a copy of the work order they ran in -- two small device copies -- for the idle-slot figure)
+                ops.keep_order_used = i == args.steps - 1
                 loss = st.step()
+            ops.keep_order_used = False
         torch.cuda.synchronize()
         comm.barrier()
         dt = time.perf_counter() - t0
@@ -320,8 +326,10 @@ def main():
             ops.reset_events()
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            for _ in range(args.steps):
+            for i in range(args.steps):
+                ops.keep_order_used = i == args.steps - 1
                 st.step()
+            ops.keep_order_used = False
             torch.cuda.synchronize()
             eager_ms_per_step = (time.perf_counter() - t1) / args.steps * 1e3
             ops.record = False
@@ -373,7 +381,8 @@ def main():
         # NNLS solve: algorithmic flops = 2 k^2 per column and sweep (k coordinate steps, each a k-long residual
         # update; nnls_batch.hpp:96-121), sweeps counted by the kernels themselves.  fp32 k<=64 runs these updates
         # as v_mfma_f32_32x32x2_f32 (dense f32 MFMA peak 157.3 TFLOP/s = the f32 vector rate); the phase time
-        # also holds the Gram padding/permutation and column-ordering helper kernels (a few us).
+        # also holds the Gram padding/permutation helper kernel (a few us; the column-ordering kernels ride in the launches of
+        # the scaling pass since round 5: phase "scale").
         cnt_sh, ms_sh = ev.get("solve_H", (0, 0.0))
         cnt_sw, ms_sw = ev.get("solve_W", (0, 0.0))
         cd_launches = cnt_sh + cnt_sw
@@ -402,7 +411,8 @@ def main():
                     o = st.ops._order[side]
                     sw = o["sweeps"].cpu().numpy().astype(np.int64)
                     use_order = o["valid"] and cfg.cd_tol > 0 and sw.shape[0] >= als.ORDER_MIN_COLUMNS
-                    sq = sw[o["order"].cpu().numpy()] if use_order else sw
+                    # (with the fused tail o["order"] already ranks THESE counts for the next solve: the copy the last solve kept)
+                    sq = sw[o.get("order_used", o["order"]).cpu().numpy()] if use_order else sw
                     pad = (-len(sq)) % tile
                     tl = np.concatenate([sq, np.zeros(pad, np.int64)]).reshape(-1, tile)
                     idle[side] = float(1.0 - tl.sum() / max(1, (tl.max(axis=1) * tile).sum()))
@@ -477,6 +487,7 @@ def main():
             # how the timed iterations were issued; with graph replay the per-phase / per-kernel HIP-event durations above
             # come from an eager re-run of the same K iterations (checked bit-identical) right after the timed region
             "launch": launch_mode,
+            "fused_tail": bool(ops.fused_tail),
             "eager_ms_per_step": eager_ms_per_step,
             "final_loss": final_loss,
             "world_size_seen": world,

@@ -388,6 +388,13 @@ RCPPML_GPU_API int rcppml_hip_row_norms(rcppml_hip_ctx* ctx, int dtype, const vo
 RCPPML_GPU_API int rcppml_hip_apply_scaling(rcppml_hip_ctx* ctx, int dtype, void* X, int k,
                                             int64_t ncols, int norm_type, const void* sums, void* d);
 
+/* extract_scaling (rcppml_hip_row_norms + rcppml_hip_apply_scaling: the same row sums, d and X, bit for bit) and -- when `sweeps` /
+ * `order` are not NULL -- rcppml_hip_order_columns(sweeps, ncols, order) for the NEXT solve of this side inside the same three
+ * launches instead of five (independent kernels share a launch: the histogram beside the row sums, the scatter beside the scaling).  Reference:
+ * nmf/variant_helpers.hpp:286-305 (the work order has no reference counterpart).  `sums`: k values of scratch (the raw row sums). */
+RCPPML_GPU_API int rcppml_hip_scale_order(rcppml_hip_ctx* ctx, int dtype, void* X, int k, int64_t ncols, int norm_type,
+                                          void* sums, void* d, const int* sweeps, int* order);
+
 /* sum of squares of a length-len vector in fp64 -> out[0] (double, device) -- trace_AtA,
  * reference primitives/primitives.hpp:100-115. */
 RCPPML_GPU_API int rcppml_hip_sumsq(rcppml_hip_ctx* ctx, int dtype, const void* x, int64_t len,
@@ -400,6 +407,13 @@ RCPPML_GPU_API int rcppml_hip_loss_mse(rcppml_hip_ctx* ctx, int dtype, const dou
                                        const void* d, const void* W_T, const void* B_w, int k,
                                        int64_t m, const void* G_wt, const void* G_saved,
                                        double* out);
+
+/* G_wt = W_T W_T^T + eps I (rcppml_hip_gram with l2 = 0) and then rcppml_hip_loss_mse with it, in three launches instead of four (the
+ * cross-term partials share the launch of the Gram's final sum);
+ * the same G_wt and out[0..2] bit for bit -- reference nmf/fit_cpu.hpp:1729-1753. */
+RCPPML_GPU_API int rcppml_hip_gram_loss_mse(rcppml_hip_ctx* ctx, int dtype, const void* W_T, int k, int64_t m, double eps,
+                                            const double* trAtA, const void* d, const void* B_w, const void* G_saved,
+                                            void* G_wt, double* out);
 
 /* Explicit-mask per-column NNLS -- reference nmf/masked_nnls.hpp:96-154 / 177-242.
  * A and mask share shape (rows x ncols, CSC; mask nonzero = masked; mask values not needed). */

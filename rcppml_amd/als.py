@@ -71,6 +71,8 @@ class HipOps:
         self.record = record_events
         self.events = {}
         self._order = {}
+        self.fused_tail = True          # scale_order() / gram_loss_mse(): independent kernels share launches (False: the separate ops, for A/B runs and tests)
+        self.keep_order_used = False    # solve() keeps a copy of the work order it ran in (bench.py's idle-slot figure)
 
     # -- plumbing
     def to_device(self, a, dtype=None):
@@ -146,14 +148,17 @@ class HipOps:
                 # (worth its three small kernels from one 16-column wavefront per SIMD: C2's 20 000-column W side, whose
                 # slowest columns set the kernel's time, goes 0.350 -> 0.313 ms)
                 use = st is not None and st["valid"] and cfg.cd_tol > 0 and n >= ORDER_MIN_COLUMNS
-                if use:
+                if use and not st.get("fresh", False):     # (scale_order() already ranked these sweep counts: fused tail)
                     self.ctx.order_columns(st["sweeps"], n, st["order"])
+                if use and self.keep_order_used:            # bench.py's idle-slot figure wants the order THIS solve ran in
+                    st["order_used"] = st["order"].clone()
                 self.ctx.solve_cd(self.dt, G, B, X, k, n, l1_pre=l1 if l1 > 0 else 0.0, warm=int(warm), zero_init=0,
                                   nonneg=int(nonneg), maxit=cfg.cd_maxit, tol=cfg.cd_tol, ub_post=ub,
                                   variant=cfg.cd_variant, sweeps_out=st["sweeps"] if st is not None else None,
                                   col_order=st["order"] if use else None)
                 if st is not None:
                     st["valid"] = True
+                    st["fresh"] = False                     # new sweep counts: the order buffer is one solve behind again
             else:
                 self.ctx.solve_chol(self.dt, G, B, X, k, n, l1_pre=l1 if l1 > 0 else 0.0, nonneg=int(nonneg), ub_post=ub)
 
@@ -168,6 +173,32 @@ class HipOps:
         n, k = X.shape
         with self._timed("scale"):
             self.ctx.apply_scaling(self.dt, X, k, n, norm_type, sums, d)
+
+    def scale_order(self, X, sums, norm_type, d, cfg, side):
+        """extract_scaling of X (row_norms + apply_scaling) and, when the next solve of `side` will run in sweep-sorted work
+        order, that order from the sweep counts the solve just left -- three launches instead of five (rcppml_hip_scale_order;
+        the results of the separate calls bit for bit).  Falls back to the separate calls when fused_tail is off."""
+        n, k = X.shape
+        st = self._order.get(side) if (cfg.order_columns and cfg.solver_mode == 0) else None
+        rank = (st is not None and st["sweeps"].shape[0] == n and st["valid"] and cfg.cd_tol > 0 and n >= ORDER_MIN_COLUMNS)
+        if not self.fused_tail:
+            self.row_norms(X, norm_type, out=sums)
+            self.apply_scaling(X, sums, norm_type, d)
+            return
+        with self._timed("scale"):
+            self.ctx.scale_order(self.dt, X, k, n, norm_type, sums, d, st["sweeps"] if rank else None, st["order"] if rank else None)
+        if rank:
+            st["fresh"] = True
+
+    def gram_loss_mse(self, W_T, eps, trAtA, d, B_w, G_saved, G_wt, out):
+        """G_wt = gram(W_T) + eps I, then the Gram-trick loss with it: three launches instead of four (rcppml_hip_gram_loss_mse)."""
+        n, k = W_T.shape
+        if not self.fused_tail:
+            self.gram(W_T, eps, 0.0, out=G_wt, tag="gram")
+            self.loss_mse(trAtA, d, W_T, B_w, G_wt, G_saved, out)
+            return
+        with self._timed("loss"):
+            self.ctx.gram_loss_mse(self.dt, W_T, k, n, eps, trAtA, d, B_w, G_saved, G_wt, out)
 
     def sumsq(self, x):
         out = self.empty((1,), self.torch.float64)
@@ -357,8 +388,7 @@ class ShardedALS:
             ops.apply_scaling(self.Gp, self.xsums, cfg.norm_type, self.d_tmp)        # ... and G[f, :] /= d_f
             ops.add_diag(self.Gp, self.eps)
         else:
-            ops.row_norms(self.H, cfg.norm_type, out=self.sums)
-            ops.apply_scaling(self.H, self.sums, cfg.norm_type, self.d)
+            ops.scale_order(self.H, self.sums, cfg.norm_type, self.d, cfg, "H")
             # ---- W half-update (fit_cpu.hpp:711-893)
             ops.gram(self.H, self.eps, 0.0, out=self.Gp, tag="gram")
             ops.rhs(self.At, self.H, out=self.Bw, tag="rhs_W")
@@ -377,12 +407,15 @@ class ShardedALS:
             comm.all_gather_rows(self.W_pad, self.rows_per)
         else:
             ops.solve(G_w, self.Bw, self.W_T, cfg, "W", warm, tag="solve_W")
-        ops.row_norms(self.W_T, cfg.norm_type, out=self.sums)
-        ops.apply_scaling(self.W_T, self.sums, cfg.norm_type, self.d)
+        if comm.sharded and cfg.w_solve == "block":
+            # (a rank solved only its block of rows: their sweep counts do not describe the whole W_T this pass scales)
+            ops.row_norms(self.W_T, cfg.norm_type, out=self.sums)
+            ops.apply_scaling(self.W_T, self.sums, cfg.norm_type, self.d)
+        else:
+            ops.scale_order(self.W_T, self.sums, cfg.norm_type, self.d, cfg, "W")
         # ---- loss (fit_cpu.hpp:1729-1753): B_w is the h_at of the reference's third sparse pass
-        ops.gram(self.W_T, self.eps, 0.0, out=self.G_wt, tag="gram")
+        ops.gram_loss_mse(self.W_T, self.eps, self.trAtA, self.d, self.Bw, G_saved, self.G_wt, self.loss_out)
         self._gwt_of_current_w = True
-        ops.loss_mse(self.trAtA, self.d, self.W_T, self.Bw, self.G_wt, G_saved, self.loss_out)
         self.iter += 1
         return self.loss_out
 

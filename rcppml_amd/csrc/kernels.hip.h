@@ -428,9 +428,9 @@ __global__ __launch_bounds__(256) void gram_partial_f64(const double* __restrict
 // (gram.hpp:51 tiny_num, fit_cpu.hpp:506/738 L2), write the k x k result.  32 lanes per output element stride over
 // the blocks, then a fixed-shape xor-shuffle tree (a serial loop over up to 512 partials cost 25 us of pure latency).
 template <class T>
-__global__ __launch_bounds__(256) void gram_finalize(const T* __restrict__ partial, int nblk, int KP, int k, T eps, T l2,
-                                                      T* __restrict__ G) {
-    const int e = blockIdx.x * 8 + (threadIdx.x >> 5);
+__device__ __forceinline__ void gram_finalize_body(const T* __restrict__ partial, int nblk, int KP, int k, T eps, T l2,
+                                                   T* __restrict__ G, const unsigned bid) {
+    const int e = bid * 8 + (threadIdx.x >> 5);
     const int sl = threadIdx.x & 31;
     T s = 0;
     if (e < KP * KP)
@@ -442,6 +442,11 @@ __global__ __launch_bounds__(256) void gram_finalize(const T* __restrict__ parti
     if (i >= k || j >= k) return;
     if (i == j) { s += eps; s += l2; }
     G[(int64_t)j * k + i] = s;
+}
+template <class T>
+__global__ __launch_bounds__(256) void gram_finalize(const T* __restrict__ partial, int nblk, int KP, int k, T eps, T l2,
+                                                      T* __restrict__ G) {
+    gram_finalize_body<T>(partial, nblk, KP, k, eps, l2, G, blockIdx.x);
 }
 
 // ---------------------------------------------------------------------------
@@ -1277,8 +1282,8 @@ __global__ __launch_bounds__(64) void chol_solve_kernel(const T* __restrict__ L,
 // passes; then d = (sqrt) + 1e-15 and X(i,:) /= d_i.
 // ---------------------------------------------------------------------------
 template <class T>
-__global__ __launch_bounds__(256) void row_norm_partial(const T* __restrict__ X, int k, int64_t ncols,
-                                                         int norm_type, T* __restrict__ partial) {
+__device__ __forceinline__ void row_norm_partial_body(const T* __restrict__ X, int k, int64_t ncols, int norm_type,
+                                                      T* __restrict__ partial, const unsigned bid, const unsigned nb) {
     // thread t handles feature f = t % kp2 (kp2 = pow2 >= k, <= 256) and column slot t / kp2
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     T* sh = reinterpret_cast<T*>(smem_raw);
@@ -1287,8 +1292,8 @@ __global__ __launch_bounds__(256) void row_norm_partial(const T* __restrict__ X,
     if (kp2 > 256) kp2 = 256;  // k > 256 handled by the feature loop below
     const int slots = 256 / kp2;
     const int f0 = threadIdx.x % kp2, slot = threadIdx.x / kp2;
-    const int64_t per = (ncols + gridDim.x - 1) / gridDim.x;
-    const int64_t c0 = (int64_t)blockIdx.x * per;
+    const int64_t per = (ncols + nb - 1) / nb;
+    const int64_t c0 = (int64_t)bid * per;
     const int64_t c1 = c0 + per < ncols ? c0 + per : ncols;
     for (int f = f0; f < k; f += kp2) {
         T acc = 0;
@@ -1301,24 +1306,29 @@ __global__ __launch_bounds__(256) void row_norm_partial(const T* __restrict__ X,
         if (slot == 0) {
             T s = acc;
             for (int q = 1; q < slots; ++q) s += sh[q * kp2 + f0];
-            partial[(int64_t)blockIdx.x * k + f] = s;
+            partial[(int64_t)bid * k + f] = s;
         }
         __syncthreads();
     }
 }
+template <class T>
+__global__ __launch_bounds__(256) void row_norm_partial(const T* __restrict__ X, int k, int64_t ncols,
+                                                         int norm_type, T* __restrict__ partial) {
+    row_norm_partial_body<T>(X, k, ncols, norm_type, partial, blockIdx.x, gridDim.x);
+}
 // Vectorised form for k % VEC == 0 (16-byte loads, four independent accumulators per lane: the scalar kernel above is
 // one dependent 4-byte load chain per thread and runs at ~1.4 TB/s).  Same partial layout, fixed summation order.
 template <class T, int VEC>
-__global__ __launch_bounds__(256) void row_norm_partial_vec(const T* __restrict__ X, int k, int64_t ncols,
-                                                             int norm_type, T* __restrict__ partial) {
+__device__ __forceinline__ void row_norm_partial_vec_body(const T* __restrict__ X, int k, int64_t ncols, int norm_type,
+                                                          T* __restrict__ partial, const unsigned bid, const unsigned nb) {
     typedef typename VecT<T, VEC>::type V;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     T* sh = reinterpret_cast<T*>(smem_raw);          // slots x k
     const int lpc = k / VEC;                          // lanes per column (<= 256)
     const int slots = 256 / lpc;
     const int li = threadIdx.x % lpc, slot = threadIdx.x / lpc;
-    const int64_t per = (ncols + gridDim.x - 1) / gridDim.x;
-    const int64_t c0 = (int64_t)blockIdx.x * per;
+    const int64_t per = (ncols + nb - 1) / nb;
+    const int64_t c0 = (int64_t)bid * per;
     const int64_t c1 = c0 + per < ncols ? c0 + per : ncols;
     T acc[4][VEC];
 #pragma unroll
@@ -1347,18 +1357,27 @@ __global__ __launch_bounds__(256) void row_norm_partial_vec(const T* __restrict_
     for (int f = threadIdx.x; f < k; f += 256) {
         T s = T(0);
         for (int q = 0; q < slots; ++q) s += sh[q * k + f];
-        partial[(int64_t)blockIdx.x * k + f] = s;
+        partial[(int64_t)bid * k + f] = s;
     }
 }
+template <class T, int VEC>
+__global__ __launch_bounds__(256) void row_norm_partial_vec(const T* __restrict__ X, int k, int64_t ncols,
+                                                             int norm_type, T* __restrict__ partial) {
+    row_norm_partial_vec_body<T, VEC>(X, k, ncols, norm_type, partial, blockIdx.x, gridDim.x);
+}
+// one wavefront per feature: lane-strided sums over the blocks, then a fixed xor-shuffle tree
 template <class T>
-__global__ __launch_bounds__(64) void row_norm_final(const T* __restrict__ partial, int nblk, int k, T* __restrict__ out) {
-    const int f = blockIdx.x;            // one wavefront per feature
-    const int lane = threadIdx.x;
+__device__ __forceinline__ T row_norm_final_row(const T* partial, int nblk, int k, int f, int lane) {
     T s = 0;
     for (int b = lane; b < nblk; b += 64) s += partial[(int64_t)b * k + f];
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) s += shfl_xor_t(s, off);
-    if (lane == 0) out[f] = s;
+    return s;
+}
+template <class T>
+__global__ __launch_bounds__(64) void row_norm_final(const T* __restrict__ partial, int nblk, int k, T* __restrict__ out) {
+    const T s = row_norm_final_row<T>(partial, nblk, k, blockIdx.x, threadIdx.x);
+    if (threadIdx.x == 0) out[blockIdx.x] = s;
 }
 template <class T>
 __global__ void scaling_finalize(const T* __restrict__ sums, int k, int norm_type, T* __restrict__ d) {
@@ -1380,18 +1399,18 @@ __global__ __launch_bounds__(256) void scale_rows(T* __restrict__ X, int k, int6
 // scaling_finalize does, block 0 also stores d
 // 16-byte form of the same (k a multiple of the vector width, X 16-byte aligned): one vector load / store per VEC elements
 template <class T, int VEC>
-__global__ __launch_bounds__(256) void scale_rows_from_sums_vec(T* __restrict__ X, int k, int64_t total, const T* __restrict__ sums,
-                                                                int norm_type, T* __restrict__ d) {
+__device__ __forceinline__ void scale_rows_from_sums_vec_body(T* __restrict__ X, int k, int64_t total, const T* __restrict__ sums,
+                                                              int norm_type, T* __restrict__ d, const unsigned bid, const unsigned nb) {
     typedef typename VecT<T, VEC>::type V;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    if (blockIdx.x == 0)
+    const int64_t stride = (int64_t)nb * blockDim.x;
+    if (bid == 0)
         for (int f = threadIdx.x; f < k; f += blockDim.x) {
             T s = sums[f];
             if (norm_type == 1) s = sqrt(s);
             d[f] = s + T(1e-15);
         }
     const int64_t nvec = total / VEC;
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < nvec; e += stride) {
+    for (int64_t e = (int64_t)bid * blockDim.x + threadIdx.x; e < nvec; e += stride) {
         const int f0 = (int)((e * VEC) % k);
         V x = reinterpret_cast<V*>(X)[e];
 #pragma unroll
@@ -1403,21 +1422,31 @@ __global__ __launch_bounds__(256) void scale_rows_from_sums_vec(T* __restrict__ 
         reinterpret_cast<V*>(X)[e] = x;
     }
 }
+template <class T, int VEC>
+__global__ __launch_bounds__(256) void scale_rows_from_sums_vec(T* __restrict__ X, int k, int64_t total, const T* __restrict__ sums,
+                                                                int norm_type, T* __restrict__ d) {
+    scale_rows_from_sums_vec_body<T, VEC>(X, k, total, sums, norm_type, d, blockIdx.x, gridDim.x);
+}
 template <class T>
-__global__ __launch_bounds__(256) void scale_rows_from_sums(T* __restrict__ X, int k, int64_t total, const T* __restrict__ sums,
-                                                            int norm_type, T* __restrict__ d) {
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    if (blockIdx.x == 0)
+__device__ __forceinline__ void scale_rows_from_sums_body(T* __restrict__ X, int k, int64_t total, const T* __restrict__ sums,
+                                                          int norm_type, T* __restrict__ d, const unsigned bid, const unsigned nb) {
+    const int64_t stride = (int64_t)nb * blockDim.x;
+    if (bid == 0)
         for (int f = threadIdx.x; f < k; f += blockDim.x) {
             T s = sums[f];
             if (norm_type == 1) s = sqrt(s);
             d[f] = s + T(1e-15);
         }
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+    for (int64_t e = (int64_t)bid * blockDim.x + threadIdx.x; e < total; e += stride) {
         T s = sums[e % k];
         if (norm_type == 1) s = sqrt(s);
         X[e] = X[e] / (s + T(1e-15));
     }
+}
+template <class T>
+__global__ __launch_bounds__(256) void scale_rows_from_sums(T* __restrict__ X, int k, int64_t total, const T* __restrict__ sums,
+                                                            int norm_type, T* __restrict__ d) {
+    scale_rows_from_sums_body<T>(X, k, total, sums, norm_type, d, blockIdx.x, gridDim.x);
 }
 
 // Graph regularisation (features/graph_reg.hpp:38-50):  G += lambda * (F L) F^T  with FL = F L formed by the SpMM kernel.
@@ -1507,16 +1536,22 @@ __global__ __launch_bounds__(256) void sumsq_partial(const T* __restrict__ x, in
 }
 // cross partials: sum_e d[e%k] * W[e] * Bw[e]
 template <class T>
+__device__ __forceinline__ void cross_partial_body(const T* __restrict__ W, const T* __restrict__ Bw, const T* __restrict__ d, int k,
+                                                   int64_t total, double* __restrict__ partial, const unsigned bid, const unsigned nb,
+                                                   double* sh /* 4 doubles of LDS */) {
+    const int64_t stride = (int64_t)nb * blockDim.x;
+    double acc = 0;
+    for (int64_t e = (int64_t)bid * blockDim.x + threadIdx.x; e < total; e += stride)
+        acc += static_cast<double>(d[e % k]) * static_cast<double>(W[e]) * static_cast<double>(Bw[e]);
+    const double s = block_sum_256(acc, sh);
+    if (threadIdx.x == 0) partial[bid] = s;
+}
+template <class T>
 __global__ __launch_bounds__(256) void cross_partial(const T* __restrict__ W, const T* __restrict__ Bw,
                                                       const T* __restrict__ d, int k, int64_t total,
                                                       double* __restrict__ partial) {
     __shared__ double sh[4];
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    double acc = 0;
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride)
-        acc += static_cast<double>(d[e % k]) * static_cast<double>(W[e]) * static_cast<double>(Bw[e]);
-    const double s = block_sum_256(acc, sh);
-    if (threadIdx.x == 0) partial[blockIdx.x] = s;
+    cross_partial_body<T>(W, Bw, d, k, total, partial, blockIdx.x, gridDim.x, sh);
 }
 static __global__ __launch_bounds__(256) void sum_partials(const double* __restrict__ partial, int n,
                                                      double* __restrict__ out) {
@@ -1528,12 +1563,8 @@ static __global__ __launch_bounds__(256) void sum_partials(const double* __restr
 }
 // out[0] = trAtA - 2 cross + recon; out[1] = cross; out[2] = recon    (single block of 256)
 template <class T>
-__global__ __launch_bounds__(256) void loss_mse_final(const double* __restrict__ trAtA,
-                                                       const double* __restrict__ cross_part, int npart,
-                                                       const T* __restrict__ d, const T* __restrict__ Gwt,
-                                                       const T* __restrict__ Gsaved, int k,
-                                                       double* __restrict__ out) {
-    __shared__ double sh[4];
+__device__ __forceinline__ void loss_mse_final_body(const double* trAtA, const double* cross_part, int npart, const T* d, const T* Gwt,
+                                                    const T* Gsaved, int k, double* out, double* sh /* 4 doubles of LDS */) {
     double acc = 0;
     for (int e = threadIdx.x; e < k * k; e += 256) {
         const int i = e % k, j = e / k;
@@ -1549,6 +1580,15 @@ __global__ __launch_bounds__(256) void loss_mse_final(const double* __restrict__
         out[1] = cross;
         out[2] = recon;
     }
+}
+template <class T>
+__global__ __launch_bounds__(256) void loss_mse_final(const double* __restrict__ trAtA,
+                                                       const double* __restrict__ cross_part, int npart,
+                                                       const T* __restrict__ d, const T* __restrict__ Gwt,
+                                                       const T* __restrict__ Gsaved, int k,
+                                                       double* __restrict__ out) {
+    __shared__ double sh[4];
+    loss_mse_final_body<T>(trAtA, cross_part, npart, d, Gwt, Gsaved, k, out, sh);
 }
 
 // ---------------------------------------------------------------------------
@@ -2427,13 +2467,13 @@ static __global__ __launch_bounds__(256) void sum_partials2(const double* __rest
 // same fit lays its columns out the same way every run, and anything that ever reduces ACROSS columns in work order stays
 // reproducible (the round-5 probe of row sums formed in the CD epilogues needed it: profiles/r05_fused_norms_ab.txt).
 constexpr int ORDER_BLOCKS_MAX = 128;
-static __global__ __launch_bounds__(256) void order_hist_kernel(const int* __restrict__ sweeps, int64_t n,
-                                                                  unsigned int* __restrict__ part /*gridDim.x x 128*/) {
+static __device__ __forceinline__ void order_hist_body(const int* __restrict__ sweeps, int64_t n, unsigned int* __restrict__ part /*nb x 128*/,
+                                                       const unsigned bid, const unsigned nb) {
     __shared__ unsigned int sh[128];
     if (threadIdx.x < 128) sh[threadIdx.x] = 0;
     __syncthreads();
-    const int64_t per = (n + gridDim.x - 1) / gridDim.x;
-    const int64_t i0 = (int64_t)blockIdx.x * per;
+    const int64_t per = (n + nb - 1) / nb;
+    const int64_t i0 = (int64_t)bid * per;
     const int64_t i1 = i0 + per < n ? i0 + per : n;
     for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) {
         int key = sweeps[i];
@@ -2441,17 +2481,21 @@ static __global__ __launch_bounds__(256) void order_hist_kernel(const int* __res
         atomicAdd(&sh[127 - key], 1u);
     }
     __syncthreads();
-    if (threadIdx.x < 128) part[(size_t)blockIdx.x * 128 + threadIdx.x] = sh[threadIdx.x];
+    if (threadIdx.x < 128) part[(size_t)bid * 128 + threadIdx.x] = sh[threadIdx.x];
 }
-static __global__ __launch_bounds__(256) void order_scatter_kernel(const int* __restrict__ sweeps, int64_t n,
-                                                                     const unsigned int* __restrict__ part /*gridDim.x x 128*/,
-                                                                     int* __restrict__ order) {
+static __global__ __launch_bounds__(256) void order_hist_kernel(const int* __restrict__ sweeps, int64_t n,
+                                                                  unsigned int* __restrict__ part /*gridDim.x x 128*/) {
+    order_hist_body(sweeps, n, part, blockIdx.x, gridDim.x);
+}
+static __device__ __forceinline__ void order_scatter_body(const int* __restrict__ sweeps, int64_t n,
+                                                          const unsigned int* __restrict__ part /*nb x 128*/, int* __restrict__ order,
+                                                          const unsigned bid, const unsigned nb) {
     __shared__ unsigned int base[128], half_total;
     __shared__ unsigned int tsum[2][128], bsum[2][128];
     __shared__ unsigned int wcnt[4][128];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int64_t per = (n + gridDim.x - 1) / gridDim.x;
-    const int64_t i0 = (int64_t)blockIdx.x * per;
+    const int64_t per = (n + nb - 1) / nb;
+    const int64_t i0 = (int64_t)bid * per;
     const int64_t i1 = i0 + per < n ? i0 + per : n;
     const int64_t wper = (per + 3) / 4;                       // this wavefront's contiguous quarter [j0, j1)
     const int64_t j0 = i0 + w * wper < i1 ? i0 + w * wper : i1;
@@ -2464,9 +2508,9 @@ static __global__ __launch_bounds__(256) void order_scatter_kernel(const int* __
         const unsigned int x = threadIdx.x & 127u, h = threadIdx.x >> 7;
         unsigned int tot = 0, before = 0;
 #pragma unroll 8
-        for (unsigned int b = h; b < gridDim.x; b += 2) {
+        for (unsigned int b = h; b < nb; b += 2) {
             const unsigned int c = part[(size_t)b * 128 + x];
-            before += b < blockIdx.x ? c : 0u;
+            before += b < bid ? c : 0u;
             tot += c;
         }
         tsum[h][x] = tot;
@@ -2530,6 +2574,11 @@ static __global__ __launch_bounds__(256) void order_scatter_kernel(const int* __
             order[pos] = (int)i;
         }
     }
+}
+static __global__ __launch_bounds__(256) void order_scatter_kernel(const int* __restrict__ sweeps, int64_t n,
+                                                                     const unsigned int* __restrict__ part /*gridDim.x x 128*/,
+                                                                     int* __restrict__ order) {
+    order_scatter_body(sweeps, n, part, order, blockIdx.x, gridDim.x);
 }
 
 }  // namespace rk

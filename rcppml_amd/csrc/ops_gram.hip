@@ -1,6 +1,7 @@
 // ops_gram.hip -- context + Gram (device-level C ABI, include/rcppml_gpu.h layer 2)
 #include "common.hip.h"
 #include "kernels.hip.h"
+#include "kernels_tail.hip.h"
 
 using namespace rk;
 // ----------------------------------------------------------------------------
@@ -84,8 +85,9 @@ template <class T> static int gram_kp(int k);
 template <> int gram_kp<float>(int k) { return ((k + 31) / 32) * 32; }
 template <> int gram_kp<double>(int k) { return ((k + 15) / 16) * 16; }
 
+// per-block partial tiles of F F^T into the context's scratch; returns the table, *nblk_out tiles of KP x KP
 template <class T>
-static void gram_impl(rcppml_hip_ctx* c, const T* F, int k, int64_t r, T eps, T l2, T* G) {
+static T* gram_partials(rcppml_hip_ctx* c, const T* F, int k, int64_t r, int* nblk_out, int* KP_out) {
     const int KP = gram_kp<T>(k);
     if (KP > 256) throw std::runtime_error("gram: k > 256 not supported");
     // number of blocks: enough waves to fill the chip, each wave >= 64 K-steps
@@ -129,9 +131,47 @@ static void gram_impl(rcppml_hip_ctx* c, const T* F, int k, int64_t r, T eps, T 
 #undef GRAM64_CASE
     }
     HIPCHK(hipGetLastError());
-    hipLaunchKernelGGL(gram_finalize<T>, dim3((KP * KP + 7) / 8), dim3(256), 0, c->stream, partial,
-                       (int)nblk, KP, k, eps, l2, G);
+    *nblk_out = (int)nblk;
+    *KP_out = KP;
+    return partial;
+}
+template <class T>
+static void gram_impl(rcppml_hip_ctx* c, const T* F, int k, int64_t r, T eps, T l2, T* G) {
+    int nblk = 0, KP = 0;
+    const T* partial = gram_partials<T>(c, F, k, r, &nblk, &KP);
+    hipLaunchKernelGGL(gram_finalize<T>, dim3((KP * KP + 7) / 8), dim3(256), 0, c->stream, partial, nblk, KP, k, eps, l2, G);
     HIPCHK(hipGetLastError());
+}
+// Gram of W_T (+ eps) into G_wt and the MSE loss by the Gram trick, three launches instead of four: the cross-term partials share the
+// launch of the Gram's final sum (kernels_tail.hip.h) -- the results of rcppml_hip_gram + rcppml_hip_loss_mse bit for bit
+template <class T>
+static void gram_loss_mse_impl(rcppml_hip_ctx* c, const T* W_T, int k, int64_t m, T eps, const double* trAtA, const T* d, const T* B_w,
+                               const T* G_saved, T* G_wt, double* out) {
+    int nblk = 0, KP = 0;
+    const T* partial = gram_partials<T>(c, W_T, k, m, &nblk, &KP);
+    const int64_t total = (int64_t)k * m;
+    int64_t nbc = (total + 256 * 8 - 1) / (256 * 8);          // = loss_mse_impl's grid (ops_misc.hip): the same partial sums
+    if (nbc > 4 * (int64_t)c->num_cu) nbc = 4 * c->num_cu;
+    if (nbc < 1) nbc = 1;
+    double* cpart = static_cast<double*>(c->scratch(WS_RED, (size_t)nbc * sizeof(double)));
+    const unsigned nfin = (unsigned)((KP * KP + 7) / 8);
+    hipLaunchKernelGGL(tail_gramfin_cross_kernel<T>, dim3((unsigned)nbc + nfin), dim3(256), 0, c->stream, partial, nblk, KP, k, eps, T(0), G_wt,
+                       W_T, B_w, d, total, cpart, (unsigned)nbc);
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(loss_mse_final<T>, dim3(1), dim3(256), 0, c->stream, trAtA, cpart, (int)nbc, d, G_wt, G_saved, k, out);
+    HIPCHK(hipGetLastError());
+}
+extern "C" int rcppml_hip_gram_loss_mse(rcppml_hip_ctx* c, int dtype, const void* W_T, int k, int64_t m, double eps, const double* trAtA,
+                                        const void* d, const void* B_w, const void* G_saved, void* G_wt, double* out) {
+    try {
+        HIPCHK(hipSetDevice(c->device));
+        if (dtype == RCPPML_F32)
+            gram_loss_mse_impl<float>(c, (const float*)W_T, k, m, (float)eps, trAtA, (const float*)d, (const float*)B_w, (const float*)G_saved, (float*)G_wt, out);
+        else
+            gram_loss_mse_impl<double>(c, (const double*)W_T, k, m, eps, trAtA, (const double*)d, (const double*)B_w, (const double*)G_saved, (double*)G_wt, out);
+        return 0;
+    }
+    RCPPML_CATCH_RET
 }
 extern "C" int rcppml_hip_gram(rcppml_hip_ctx* c, int dtype, const void* F, int k, int64_t r, double eps,
                                double l2, void* G) {

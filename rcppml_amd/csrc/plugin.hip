@@ -250,6 +250,9 @@ void fit(FitParams& P) {
     // CD work order: columns sorted by the sweeps of the previous iteration (results are order-independent)
     DevBuf dswH((size_t)n * sizeof(int)), dswW((size_t)m * sizeof(int)), dordH((size_t)n * sizeof(int)), dordW((size_t)m * sizeof(int));
     const bool use_order = P.solver_mode == 0 && !has_mask && P.loss_type == 0 && P.cd_tol > 0 && !exp_env("RCPPML_GPU_NO_ORDER");
+    // the work order of a side's NEXT solve is ranked inside the launches of its scaling pass (rcppml_hip_scale_order); these say
+    // whether dordH / dordW already hold the ranking of the sweep counts in dswH / dswW
+    bool ordH_fresh = false, ordW_fresh = false;
 
     const bool is_pow = P.loss_type >= 6;                               // phi_vec = 1 for dispersion none (fit_cpu.hpp:336-347)
     const bool is_gp = P.loss_type == 4 || is_pow || P.loss_type == 0;  // theta_vec = Zero(m) (:297-304); "no theta in the solve"
@@ -371,18 +374,23 @@ void fit(FitParams& P) {
             void* Bh_use = tgtH ? apply_target(P.target_lambda_H, dTH, TG_H, dG.p, dBh.p, n) : dBh.p;
             if (P.solver_mode == 0) {                                                   // :516-524
                 const bool ord = use_order && iter > 0 && n >= kOrderMinColumns;
-                if (ord) OPCHK(rcppml_hip_order_columns(c, dswH.as<int>(), n, dordH.as<int>()));
+                if (ord && !ordH_fresh) OPCHK(rcppml_hip_order_columns(c, dswH.as<int>(), n, dordH.as<int>()));
                 OPCHK(rcppml_hip_solve_cd(c, dt, Gh, Bh_use, dH.p, k, n, P.L1_H > 0 ? P.L1_H : 0.0, warm, zinit, 0.0, 0.0,
                                           P.nonneg_H, P.cd_maxit, P.cd_tol, 0.0, P.ub_H, RCPPML_CD_AUTO,
                                           use_order ? dswH.as<int>() : nullptr, ord ? dordH.as<int>() : nullptr));
+                ordH_fresh = false;
             }
             else                                                                        // :527-534
                 OPCHK(rcppml_hip_solve_chol(c, dt, Gh, Bh_use, dH.p, k, n, P.L1_H > 0 ? P.L1_H : 0.0, P.nonneg_H, P.ub_H));
         }
         if (P.angular_H > 0 && !P.projective && !P.symmetric) OPCHK(rcppml_hip_angular_posthoc(c, dt, dH.p, k, n, P.angular_H));   // :638-639 (standard branch only)
+        // the branch whose CD solves leave sweep counts behind (dswH / dswW) and run in sweep-sorted work order
+        const bool std_cd = use_order && !P.symmetric && !P.projective && !has_mask && !is_nb;
         if (!P.symmetric) {
-            OPCHK(rcppml_hip_row_norms(c, dt, dH.p, k, n, P.norm_type, dsums.p));       // :645 extract_scaling
-            OPCHK(rcppml_hip_apply_scaling(c, dt, dH.p, k, n, P.norm_type, dsums.p, dd.p));
+            const bool rank = std_cd && n >= kOrderMinColumns;
+            OPCHK(rcppml_hip_scale_order(c, dt, dH.p, k, n, P.norm_type, dsums.p, dd.p,       // :645 extract_scaling (+ the next H solve's work order)
+                                         rank ? dswH.as<int>() : nullptr, rank ? dordH.as<int>() : nullptr));
+            if (rank) ordH_fresh = true;
         }
 
         // ================= W half-update (fit_cpu.hpp:711-893)
@@ -426,17 +434,22 @@ void fit(FitParams& P) {
             void* Bw_use = tgtW ? apply_target(P.target_lambda_W, dTW, TG_W, dG.p, dBw.p, m) : dBw.p;   // the loss keeps the raw B_w (:786-789)
             if (P.solver_mode == 0) {
                 const bool ord = use_order && iter > 0 && m >= kOrderMinColumns;
-                if (ord) OPCHK(rcppml_hip_order_columns(c, dswW.as<int>(), m, dordW.as<int>()));
+                if (ord && !ordW_fresh) OPCHK(rcppml_hip_order_columns(c, dswW.as<int>(), m, dordW.as<int>()));
                 OPCHK(rcppml_hip_solve_cd(c, dt, Gw, Bw_use, dW.p, k, m, P.L1_W > 0 ? P.L1_W : 0.0, warm, zinit, 0.0, 0.0,
                                           P.nonneg_W, P.cd_maxit, P.cd_tol, 0.0, P.ub_W, RCPPML_CD_AUTO,
                                           use_order ? dswW.as<int>() : nullptr, ord ? dordW.as<int>() : nullptr));
+                ordW_fresh = false;
             }
             else
                 OPCHK(rcppml_hip_solve_chol(c, dt, Gw, Bw_use, dW.p, k, m, P.L1_W > 0 ? P.L1_W : 0.0, P.nonneg_W, P.ub_W));
         }
         if (P.angular_W > 0) OPCHK(rcppml_hip_angular_posthoc(c, dt, dW.p, k, m, P.angular_W));   // :886-887
-        OPCHK(rcppml_hip_row_norms(c, dt, dW.p, k, m, P.norm_type, dsums.p));           // :893
-        OPCHK(rcppml_hip_apply_scaling(c, dt, dW.p, k, m, P.norm_type, dsums.p, dd.p));
+        {
+            const bool rank = std_cd && m >= kOrderMinColumns;
+            OPCHK(rcppml_hip_scale_order(c, dt, dW.p, k, m, P.norm_type, dsums.p, dd.p,       // :893 (+ the next W solve's work order)
+                                         rank ? dswW.as<int>() : nullptr, rank ? dordW.as<int>() : nullptr));
+            if (rank) ordW_fresh = true;
+        }
         if (P.symmetric) HIPCHK(hipMemcpyAsync(dH.p, dW.p, (size_t)k * m * sizeof(T), hipMemcpyDeviceToDevice, s));   // :704 H = W_T
 
         // ================= NB size update (fit_cpu.hpp:1094-1265), then loss (fit_cpu.hpp:1684-1753)
@@ -475,10 +488,9 @@ void fit(FitParams& P) {
         } else if (is_nb) {
             OPCHK(rcppml_hip_irls_loss(c, dt, P.loss_type, dAp.as<int>(), dAi.as<int>(), dAx.p, n, dW.p, dd.p, dH.p, dtheta.p, k, P.tweedie_power, P.robust_delta, dloss.as<double>()));
         } else {
-            OPCHK(rcppml_hip_gram(c, dt, dW.p, k, m, eps, 0.0, dGwt.p));                // :1734-1735
-            // B_w (raw RHS of the W update) is exactly the h_at of loss_cross_term_sparse_via_At
-            // (fused_nnls.hpp:305-362): the third O(nnz k) pass of the reference is not needed.
-            OPCHK(rcppml_hip_loss_mse(c, dt, dtr.as<double>(), dd.p, dW.p, dBw.p, k, m, dGwt.p, dGs.p, dloss.as<double>()));
+            // :1734-1735 Gram of the scaled W_T, then the Gram-trick loss.  B_w (raw RHS of the W update) is exactly the h_at of
+            // loss_cross_term_sparse_via_At (fused_nnls.hpp:305-362): the third O(nnz k) pass of the reference is not needed.
+            OPCHK(rcppml_hip_gram_loss_mse(c, dt, dW.p, k, m, eps, dtr.as<double>(), dd.p, dBw.p, dGs.p, dGwt.p, dloss.as<double>()));
         }
     };
 

@@ -476,3 +476,109 @@ def test_cd_lmf_geometries_and_refill(env, lg, k):
         ctx.set_option(_abi.OPT_CD_LMF_LANE_GROUPS, 0)
         ctx.set_option(_abi.OPT_CD_LMF_WAVES_PER_SIMD, 0)
 
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("norm_type", [0, 1, 2])
+@pytest.mark.parametrize("k,c,ranked", [(64, 100003, True), (64, 20000, True), (10, 1183, False), (7, 5, False), (100, 17000, True),
+                                        (128, 40000, True), (30, 16384, True)])
+def test_scale_order_equals_separate_ops(env, dtype, norm_type, k, c, ranked):
+    """rcppml_hip_scale_order (the iteration's tail in three launches: row sums beside the work-order histogram, their final sum,
+    scaling beside the scatter) returns the row sums, d, X and work order of rcppml_hip_row_norms + rcppml_hip_apply_scaling +
+    rcppml_hip_order_columns BIT FOR BIT -- same bodies, grids and summation orders.  Reference for the scaling:
+    nmf/variant_helpers.hpp:286-305."""
+    torch, _abi, ctx = env
+    rs = np.random.default_rng(k * 7 + c)
+    X = (rs.uniform(size=(c, k)) * (rs.uniform(size=(c, k)) < 0.6)).astype(dtype)
+    X[:, 0] = 0                                                    # dead factor -> d = 1e-15
+    sw = rs.integers(0, 110, size=c).astype(np.int32)
+    dt, tt = _dt(_abi, dtype), _tt(torch, dtype)
+    d_sw = _dev(torch, sw)
+    # separate ops
+    X1 = _dev(torch, X)
+    s1 = torch.empty(k, dtype=tt, device="cuda"); d1 = torch.empty(k, dtype=tt, device="cuda")
+    o1 = torch.full((c,), -1, dtype=torch.int32, device="cuda")
+    ctx.row_norms(dt, X1, k, c, norm_type, s1)
+    ctx.apply_scaling(dt, X1, k, c, norm_type, s1, d1)
+    if ranked:
+        ctx.order_columns(d_sw, c, o1)
+    for rep in range(2):
+        X2 = _dev(torch, X)
+        s2 = torch.full((k,), -7.0, dtype=tt, device="cuda"); d2 = torch.full((k,), -7.0, dtype=tt, device="cuda")
+        o2 = torch.full((c,), -1, dtype=torch.int32, device="cuda")
+        ctx.scale_order(dt, X2, k, c, norm_type, s2, d2, d_sw if ranked else None, o2 if ranked else None)
+        ctx.sync()
+        assert torch.equal(s1, s2), (rep, "row sums")
+        assert torch.equal(d1, d2), (rep, "d")
+        assert torch.equal(X1, X2), (rep, "X")
+        assert torch.equal(o1, o2), (rep, "order")
+    Xr, dr = O.extract_scaling(X, norm_type)
+    assert rel_err(d2.cpu().numpy(), dr) < TOL[dtype]
+    assert rel_err(X2.cpu().numpy(), Xr) < TOL[dtype] * 2
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("k,m", [(64, 20000), (10, 183), (32, 3867), (100, 5000), (128, 30000), (5, 3)])
+def test_gram_loss_mse_equals_separate_ops(env, dtype, k, m):
+    """rcppml_hip_gram_loss_mse (Gram partials; ONE launch in which the cross-term partials run beside the Gram's final sum; the
+    loss's final sum) = rcppml_hip_gram + rcppml_hip_loss_mse bit for bit: G_wt and out[0..2].  Reference: nmf/fit_cpu.hpp:1729-1753."""
+    torch, _abi, ctx = env
+    rs = np.random.default_rng(k + m)
+    dt, tt = _dt(_abi, dtype), _tt(torch, dtype)
+    W = _dev(torch, (rs.uniform(size=(m, k)) * (rs.uniform(size=(m, k)) < 0.7)).astype(dtype))
+    Bw = _dev(torch, rs.normal(size=(m, k)).astype(dtype))
+    d = _dev(torch, rs.uniform(0.5, 2.0, size=k).astype(dtype))
+    Gs = _dev(torch, rs.uniform(size=(k, k)).astype(dtype))
+    tr = torch.tensor([123.456], dtype=torch.float64, device="cuda")
+    G1 = torch.empty((k, k), dtype=tt, device="cuda"); out1 = torch.zeros(4, dtype=torch.float64, device="cuda")
+    ctx.gram(dt, W, k, m, 1e-15, 0.0, G1)
+    ctx.loss_mse(dt, tr, d, W, Bw, k, m, G1, Gs, out1)
+    for rep in range(2):
+        G2 = torch.full((k, k), -3.0, dtype=tt, device="cuda"); out2 = torch.full((4,), -3.0, dtype=torch.float64, device="cuda")
+        ctx.gram_loss_mse(dt, W, k, m, 1e-15, tr, d, Bw, Gs, G2, out2)
+        ctx.sync()
+        assert torch.equal(G1, G2), rep
+        assert torch.equal(out1[:3], out2[:3]), (rep, out1.tolist(), out2.tolist())
+    # oracle values of the three terms
+    Wd = W.cpu().numpy().astype(np.float64); dd = d.cpu().numpy().astype(np.float64)
+    cross = float(np.sum(Wd * dd[None, :] * Bw.cpu().numpy().astype(np.float64)))
+    recon = float(np.sum(np.outer(dd, dd) * (Wd.T @ Wd + 1e-15 * np.eye(k)) * Gs.cpu().numpy().astype(np.float64).T))
+    got = out2.cpu().numpy()
+    assert abs(got[1] - cross) <= 1e-5 * max(1.0, abs(cross)) and abs(got[2] - recon) <= (1e-4 if dtype == np.float32 else 1e-9) * max(1.0, abs(recon))
+
+
+def test_fused_tail_under_graph_replay(env):
+    """Both fused-tail ops inside one captured hipGraph, replayed: every replay reproduces the eager results bit for bit (the
+    plugin's steady-state iteration and bench.py's timed region run them this way)."""
+    torch, _abi, _ = env
+    k, c = 64, 50000
+    rs = np.random.default_rng(5)
+    X0 = _dev(torch, rs.uniform(size=(c, k)).astype(np.float32))
+    sw = _dev(torch, rs.integers(0, 100, size=c).astype(np.int32))
+    Bw = _dev(torch, rs.normal(size=(c, k)).astype(np.float32))
+    Gs = _dev(torch, rs.uniform(size=(k, k)).astype(np.float32))
+    tr = torch.tensor([9.0], dtype=torch.float64, device="cuda")
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        ctx = _abi.Context(torch.cuda.current_device())
+        X = X0.clone()
+        s = torch.empty(k, device="cuda"); d = torch.empty(k, device="cuda"); o = torch.empty(c, dtype=torch.int32, device="cuda")
+        G = torch.empty((k, k), device="cuda"); out = torch.zeros(4, dtype=torch.float64, device="cuda")
+
+        def body():
+            X.copy_(X0)
+            ctx.scale_order(_abi.F32, X, k, c, 0, s, d, sw, o)
+            ctx.gram_loss_mse(_abi.F32, X, k, c, 1e-15, tr, d, Bw, Gs, G, out)
+        body(); body()
+        torch.cuda.synchronize()
+        want = [t.clone() for t in (X, s, d, o, G, out[:3])]
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            body()
+        for rep in range(4):
+            for t in (s, d, G, out):
+                t.fill_(-1)
+            g.replay()
+            torch.cuda.synchronize()
+            for a, b in zip(want, (X, s, d, o, G, out[:3])):
+                assert torch.equal(a, b), rep
