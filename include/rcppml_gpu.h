@@ -415,6 +415,18 @@ RCPPML_GPU_API int rcppml_hip_gram_loss_mse(rcppml_hip_ctx* ctx, int dtype, cons
                                             const double* trAtA, const void* d, const void* B_w, const void* G_saved,
                                             void* G_wt, double* out);
 
+/* The tail of a half-update in one call.  rcppml_hip_tail_scale_gram = rcppml_hip_scale_order(X, ...) then rcppml_hip_gram(X, eps, l2)
+ * -> G (the H side: extract_scaling of H, then its Gram for the W update; nmf/fit_cpu.hpp:645, :715-722);
+ * rcppml_hip_tail_scale_gram_loss = rcppml_hip_scale_order(W_T, ...) then rcppml_hip_gram_loss_mse (the W side: extract_scaling of W_T,
+ * its Gram and the loss; :893, :1729-1753).  Same results as the separate calls bit for bit.  fp32 with k = 64 runs the scaling pass
+ * INSIDE the Gram's partial-tile kernel (the lane that loads an element divides, stores and multiplies it): four and five launches
+ * instead of seven and nine; every other shape takes the two calls above. */
+RCPPML_GPU_API int rcppml_hip_tail_scale_gram(rcppml_hip_ctx* ctx, int dtype, void* X, int k, int64_t ncols, int norm_type, void* sums,
+                                              void* d, const int* sweeps, int* order, double eps, double l2, void* G);
+RCPPML_GPU_API int rcppml_hip_tail_scale_gram_loss(rcppml_hip_ctx* ctx, int dtype, void* W_T, int k, int64_t m, int norm_type, void* sums,
+                                                   void* d, const int* sweeps, int* order, double eps, const double* trAtA,
+                                                   const void* B_w, const void* G_saved, void* G_wt, double* out);
+
 /* Explicit-mask per-column NNLS -- reference nmf/masked_nnls.hpp:96-154 / 177-242.
  * A and mask share shape (rows x ncols, CSC; mask nonzero = masked; mask values not needed). */
 RCPPML_GPU_API int rcppml_hip_solve_masked(rcppml_hip_ctx* ctx, int dtype, const int* col_ptr,

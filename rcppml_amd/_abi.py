@@ -30,7 +30,7 @@ EXPORTED_SYMBOLS = [
     "rcppml_gpu_nmf_dense_unified_double",
     "rcppml_hip_rhs_plan_create", "rcppml_hip_rhs_plan_create_indices", "rcppml_hip_rhs_plan_set_values", "rcppml_hip_rhs_plan_destroy", "rcppml_hip_rhs_plan_info", "rcppml_hip_rhs_planned",
     "rcppml_gpu_nmf_target", "rcppml_hip_axpy", "rcppml_hip_add_diag", "rcppml_hip_clip_upper",
-    "rcppml_hip_scale_order", "rcppml_hip_gram_loss_mse",
+    "rcppml_hip_scale_order", "rcppml_hip_gram_loss_mse", "rcppml_hip_tail_scale_gram", "rcppml_hip_tail_scale_gram_loss",
 ]
 
 
@@ -84,7 +84,7 @@ def lib():
                      "rcppml_hip_apply_scaling",
                      "rcppml_hip_sumsq", "rcppml_hip_loss_mse", "rcppml_hip_solve_masked", "rcppml_hip_loss_nonzeros", "rcppml_hip_loss_masked",
                      "rcppml_hip_solve_irls_nb", "rcppml_hip_nb_size_update", "rcppml_hip_nb_loss", "rcppml_hip_scale_order",
-                     "rcppml_hip_gram_loss_mse"):
+                     "rcppml_hip_gram_loss_mse", "rcppml_hip_tail_scale_gram", "rcppml_hip_tail_scale_gram_loss"):
             getattr(_lib, name).restype = C.c_int
         _lib.rcppml_hip_ctx_destroy.restype = None
         _lib.rcppml_hip_rhs_plan_destroy.restype = None
@@ -495,6 +495,17 @@ class Context:
         """gram(W_T, eps) -> G_wt, then loss_mse with it, in three launches instead of four; bit-identical to the separate calls."""
         _chk(lib().rcppml_hip_gram_loss_mse(self._h, C.c_int(dt), _dptr(W_T), C.c_int(k), C.c_int64(m), C.c_double(eps), _dptr(trAtA),
                                             _dptr(d), _dptr(B_w), _dptr(G_saved), _dptr(G_wt), _dptr(out)), "gram_loss_mse")
+
+    def tail_scale_gram(self, dt, X, k, ncols, norm_type, sums, d, sweeps, order, eps, l2, G):
+        """scale_order(X) then gram(X, eps, l2) -> G in one call (fp32 k = 64: the scaling inside the Gram's partial-tile kernel)."""
+        _chk(lib().rcppml_hip_tail_scale_gram(self._h, C.c_int(dt), _dptr(X), C.c_int(k), C.c_int64(ncols), C.c_int(norm_type), _dptr(sums),
+                                              _dptr(d), _dptr(sweeps), _dptr(order), C.c_double(eps), C.c_double(l2), _dptr(G)), "tail_scale_gram")
+
+    def tail_scale_gram_loss(self, dt, W_T, k, m, norm_type, sums, d, sweeps, order, eps, trAtA, B_w, G_saved, G_wt, out):
+        """scale_order(W_T) then gram_loss_mse in one call (fp32 k = 64: the scaling inside the Gram's partial-tile kernel)."""
+        _chk(lib().rcppml_hip_tail_scale_gram_loss(self._h, C.c_int(dt), _dptr(W_T), C.c_int(k), C.c_int64(m), C.c_int(norm_type), _dptr(sums),
+                                                   _dptr(d), _dptr(sweeps), _dptr(order), C.c_double(eps), _dptr(trAtA), _dptr(B_w),
+                                                   _dptr(G_saved), _dptr(G_wt), _dptr(out)), "tail_scale_gram_loss")
 
     def sumsq(self, dt, x, length, out):
         _chk(lib().rcppml_hip_sumsq(self._h, C.c_int(dt), _dptr(x), C.c_int64(length), _dptr(out)), "sumsq")

@@ -190,6 +190,39 @@ class HipOps:
         if rank:
             st["fresh"] = True
 
+    def _rank_state(self, X, cfg, side):
+        n = X.shape[0]
+        st = self._order.get(side) if (cfg.order_columns and cfg.solver_mode == 0) else None
+        rank = (st is not None and st["sweeps"].shape[0] == n and st["valid"] and cfg.cd_tol > 0 and n >= ORDER_MIN_COLUMNS)
+        return st, rank
+
+    def tail_scale_gram(self, X, sums, norm_type, d, cfg, side, eps, G):
+        """The H side's tail in one call: scale_order(X), then gram(X, eps, 0) -> G (rcppml_hip_tail_scale_gram)."""
+        if not self.fused_tail:
+            self.scale_order(X, sums, norm_type, d, cfg, side)
+            self.gram(X, eps, 0.0, out=G, tag="gram")
+            return
+        n, k = X.shape
+        st, rank = self._rank_state(X, cfg, side)
+        with self._timed("scale_gram"):
+            self.ctx.tail_scale_gram(self.dt, X, k, n, norm_type, sums, d, st["sweeps"] if rank else None, st["order"] if rank else None, eps, 0.0, G)
+        if rank:
+            st["fresh"] = True
+
+    def tail_scale_gram_loss(self, W_T, sums, norm_type, d, cfg, side, eps, trAtA, B_w, G_saved, G_wt, out):
+        """The W side's tail in one call: scale_order(W_T), then gram_loss_mse (rcppml_hip_tail_scale_gram_loss)."""
+        if not self.fused_tail:
+            self.scale_order(W_T, sums, norm_type, d, cfg, side)
+            self.gram_loss_mse(W_T, eps, trAtA, d, B_w, G_saved, G_wt, out)
+            return
+        n, k = W_T.shape
+        st, rank = self._rank_state(W_T, cfg, side)
+        with self._timed("scale_gram_loss"):
+            self.ctx.tail_scale_gram_loss(self.dt, W_T, k, n, norm_type, sums, d, st["sweeps"] if rank else None, st["order"] if rank else None,
+                                          eps, trAtA, B_w, G_saved, G_wt, out)
+        if rank:
+            st["fresh"] = True
+
     def gram_loss_mse(self, W_T, eps, trAtA, d, B_w, G_saved, G_wt, out):
         """G_wt = gram(W_T) + eps I, then the Gram-trick loss with it: three launches instead of four (rcppml_hip_gram_loss_mse)."""
         n, k = W_T.shape
@@ -388,9 +421,8 @@ class ShardedALS:
             ops.apply_scaling(self.Gp, self.xsums, cfg.norm_type, self.d_tmp)        # ... and G[f, :] /= d_f
             ops.add_diag(self.Gp, self.eps)
         else:
-            ops.scale_order(self.H, self.sums, cfg.norm_type, self.d, cfg, "H")
-            # ---- W half-update (fit_cpu.hpp:711-893)
-            ops.gram(self.H, self.eps, 0.0, out=self.Gp, tag="gram")
+            # extract_scaling of H (+ the next H solve's work order), then -- W half-update (fit_cpu.hpp:711-893) -- its Gram
+            ops.tail_scale_gram(self.H, self.sums, cfg.norm_type, self.d, cfg, "H", self.eps, self.Gp)
             ops.rhs(self.At, self.H, out=self.Bw, tag="rhs_W")
         # G_saved = Gram of H before L2 (:719-722), G = G_saved + L2_W I (:738).  Without an L2 penalty on W both are the
         # buffer the Gram kernel just wrote (it stays untouched until the next iteration's Gram of H): no copies
@@ -411,10 +443,11 @@ class ShardedALS:
             # (a rank solved only its block of rows: their sweep counts do not describe the whole W_T this pass scales)
             ops.row_norms(self.W_T, cfg.norm_type, out=self.sums)
             ops.apply_scaling(self.W_T, self.sums, cfg.norm_type, self.d)
+            # ---- loss (fit_cpu.hpp:1729-1753): B_w is the h_at of the reference's third sparse pass
+            ops.gram_loss_mse(self.W_T, self.eps, self.trAtA, self.d, self.Bw, G_saved, self.G_wt, self.loss_out)
         else:
-            ops.scale_order(self.W_T, self.sums, cfg.norm_type, self.d, cfg, "W")
-        # ---- loss (fit_cpu.hpp:1729-1753): B_w is the h_at of the reference's third sparse pass
-        ops.gram_loss_mse(self.W_T, self.eps, self.trAtA, self.d, self.Bw, G_saved, self.G_wt, self.loss_out)
+            ops.tail_scale_gram_loss(self.W_T, self.sums, cfg.norm_type, self.d, cfg, "W", self.eps, self.trAtA, self.Bw, G_saved, self.G_wt,
+                                     self.loss_out)
         self._gwt_of_current_w = True
         self.iter += 1
         return self.loss_out

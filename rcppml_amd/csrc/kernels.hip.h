@@ -297,13 +297,17 @@ __global__ __launch_bounds__(256) void gram_partial_f32(const float* __restrict_
 // k = 64 fp32 (two 32-row tiles, 8-byte vector loads: the headline shape): all four output tiles in ONE block, so every
 // slice of F is read once instead of once per tile row.  Same waves, same column pairs, same in-block and across-block
 // summation order as gram_partial_f32<2, true, STEPS> on a (nblk, 2) grid -- bitwise the same partial tiles.
-template <int STEPS>
-__global__ __launch_bounds__(256) void gram_partial_f32_k64(const float* __restrict__ F, int k, int64_t r,
-                                                             float* __restrict__ partial) {
+// SCALE (the iteration's tail, kernels_tail.hip.h): every element of F is loaded by exactly one lane of one block, so the lane can
+// divide it by its row's d (formed from the row sums exactly as scale_rows_from_sums does), store it back and feed the SCALED value to
+// the matrix cores: extract_scaling's second pass and the Gram partials in one pass over F, bit-identical to the two kernels.
+template <int STEPS, bool SCALE>
+__device__ __forceinline__ void gram_partial_f32_k64_body(float* __restrict__ F, int k, int64_t r, float* __restrict__ partial,
+                                                          const unsigned bid, const unsigned nb, const float* __restrict__ sums,
+                                                          int norm_type) {
     constexpr int KP = 64;
     __shared__ float red[3][4 * 1024];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int64_t nw = (int64_t)gridDim.x * 4, wid = (int64_t)blockIdx.x * 4 + wave;
+    const int64_t nw = (int64_t)nb * 4, wid = (int64_t)bid * 4 + wave;
     const int64_t npairs = (r + 1) / 2;
     const int64_t per = (npairs + nw - 1) / nw;
     const int64_t p0 = wid * per;
@@ -317,6 +321,14 @@ __global__ __launch_bounds__(256) void gram_partial_f32_k64(const float* __restr
 #pragma unroll
             for (int v = 0; v < 16; ++v) acc[a][b][v] = 0.f;
     typedef VecT<float, 2>::type V;
+    float dv0 = 1.f, dv1 = 1.f;              // SCALE: d of this lane's two rows (2 row, 2 row + 1)
+    if constexpr (SCALE) {
+        if (2 * row < k) {
+            float s0 = sums[2 * row], s1 = sums[2 * row + 1];
+            if (norm_type == 1) { s0 = sqrtf(s0); s1 = sqrtf(s1); }
+            dv0 = s0 + 1e-15f; dv1 = s1 + 1e-15f;
+        }
+    }
     for (int64_t pb = p0; pb < p1; pb += STEPS) {
         float a[STEPS][2];
 #pragma unroll
@@ -325,7 +337,11 @@ __global__ __launch_bounds__(256) void gram_partial_f32_k64(const float* __restr
             const bool cok = (pb + s) < p1 && c < r;
             const int r0 = 2 * row;
             if (cok && r0 < k) {
-                const V v = *reinterpret_cast<const V*>(F + c * (int64_t)k + r0);
+                V v = *reinterpret_cast<const V*>(F + c * (int64_t)k + r0);
+                if constexpr (SCALE) {
+                    v[0] = v[0] / dv0; v[1] = v[1] / dv1;
+                    *reinterpret_cast<V*>(F + c * (int64_t)k + r0) = v;
+                }
                 a[s][0] = v[0]; a[s][1] = v[1];
             } else { a[s][0] = 0.f; a[s][1] = 0.f; }
         }
@@ -347,7 +363,7 @@ __global__ __launch_bounds__(256) void gram_partial_f32_k64(const float* __restr
     }
     __syncthreads();
     if (wave == 0) {
-        float* out = partial + ((int64_t)blockIdx.x * KP * KP);
+        float* out = partial + ((int64_t)bid * KP * KP);
 #pragma unroll
         for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
@@ -362,6 +378,11 @@ __global__ __launch_bounds__(256) void gram_partial_f32_k64(const float* __restr
                     out[(int64_t)(2 * js + t) * KP + (2 * is + ti)] = s;
                 }
     }
+}
+template <int STEPS>
+__global__ __launch_bounds__(256) void gram_partial_f32_k64(const float* __restrict__ F, int k, int64_t r,
+                                                             float* __restrict__ partial) {
+    gram_partial_f32_k64_body<STEPS, false>(const_cast<float*>(F), k, r, partial, blockIdx.x, gridDim.x, nullptr, 0);
 }
 
 template <int T_TILES>  // KP = 16 * T_TILES  (v_mfma_f64_16x16x4_f64)

@@ -39,6 +39,25 @@ __global__ __launch_bounds__(256) void tail_scale_scatter_kernel(T* __restrict__
     if constexpr (VEC > 0) scale_rows_from_sums_vec_body<T, VEC>(X, k, total, sums, norm_type, d, bid, nb_scale);
     else scale_rows_from_sums_body<T>(X, k, total, sums, norm_type, d, bid, nb_scale);
 }
+// fp32, k = 64: extract_scaling's second pass INSIDE the Gram's partial-tile kernel (gram_partial_f32_k64_body<STEPS, true>: the one
+// lane that loads an element divides it by its row's d, stores it back and feeds the scaled value to the matrix cores) -- one pass
+// over the factor and one launch less; blocks [0, nb_order): order_scatter; block nb_order also stores d
+template <int STEPS>
+__global__ __launch_bounds__(256) void tail_scale_gram_k64_kernel(float* __restrict__ X, int k, int64_t ncols, const float* __restrict__ sums,
+                                                                   int norm_type, float* __restrict__ d, float* __restrict__ gpartial,
+                                                                   unsigned nb_gram, const int* __restrict__ sweeps,
+                                                                   const unsigned int* __restrict__ part, int* __restrict__ order,
+                                                                   unsigned nb_order) {
+    if (blockIdx.x < nb_order) { order_scatter_body(sweeps, ncols, part, order, blockIdx.x, nb_order); return; }
+    const unsigned bid = blockIdx.x - nb_order;
+    if (bid == 0)
+        for (int f = threadIdx.x; f < k; f += blockDim.x) {
+            float s = sums[f];
+            if (norm_type == 1) s = sqrtf(s);
+            d[f] = s + 1e-15f;
+        }
+    gram_partial_f32_k64_body<STEPS, true>(X, k, ncols, gpartial, bid, nb_gram, sums, norm_type);
+}
 // blocks [0, nb_cross): cross_partial; the rest: gram_finalize into G
 template <class T>
 __global__ __launch_bounds__(256) void tail_gramfin_cross_kernel(const T* __restrict__ gpartial, int nblk_g, int KP, int k, T eps, T l2,

@@ -1,7 +1,7 @@
 // ops_gram.hip -- context + Gram (device-level C ABI, include/rcppml_gpu.h layer 2)
 #include "common.hip.h"
 #include "kernels.hip.h"
-#include "kernels_tail.hip.h"
+#include "gram_launch.hip.h"
 
 using namespace rk;
 // ----------------------------------------------------------------------------
@@ -81,97 +81,12 @@ extern "C" int rcppml_hip_ctx_irls_stats(rcppml_hip_ctx* c, int reset, unsigned 
 // ----------------------------------------------------------------------------
 // Gram
 // ----------------------------------------------------------------------------
-template <class T> static int gram_kp(int k);
-template <> int gram_kp<float>(int k) { return ((k + 31) / 32) * 32; }
-template <> int gram_kp<double>(int k) { return ((k + 15) / 16) * 16; }
-
-// per-block partial tiles of F F^T into the context's scratch; returns the table, *nblk_out tiles of KP x KP
-template <class T>
-static T* gram_partials(rcppml_hip_ctx* c, const T* F, int k, int64_t r, int* nblk_out, int* KP_out) {
-    const int KP = gram_kp<T>(k);
-    if (KP > 256) throw std::runtime_error("gram: k > 256 not supported");
-    // number of blocks: enough waves to fill the chip, each wave >= 64 K-steps
-    const int64_t step = std::is_same<T, float>::value ? 2 : 4;
-    // enough waves to fill the chip; each wave >= 32 K-steps (more, smaller waves: the loop is latency-bound); the cap
-    // bounds the partial-tile traffic (nblk * KP^2 values written and re-read by gram_finalize)
-    int64_t nblk = (r / step + 4 * 32 - 1) / (4 * 32);
-    if (nblk < 1) nblk = 1;
-    if (nblk > 2 * (int64_t)c->num_cu) nblk = 2 * c->num_cu;
-    T* partial = static_cast<T*>(c->scratch(WS_GRAM, (size_t)nblk * KP * KP * sizeof(T)));
-    if constexpr (std::is_same<T, float>::value) {
-        const int tt = KP / 32;
-        dim3 grid((unsigned)nblk, tt), block(256);
-        const bool vl = (tt == 2 || tt == 4) && k % tt == 0 && reinterpret_cast<uintptr_t>(F) % (4 * tt) == 0;
-        switch (tt) {
-            case 1: hipLaunchKernelGGL((gram_partial_f32<1, false, 8>), grid, block, 0, c->stream, F, k, r, partial); break;
-            case 2:
-                if (vl) hipLaunchKernelGGL((gram_partial_f32_k64<8>), dim3((unsigned)nblk), block, 0, c->stream, F, k, r, partial);   // all four tiles per block: F read once
-                else hipLaunchKernelGGL((gram_partial_f32<2, false, 8>), grid, block, 0, c->stream, F, k, r, partial);
-                break;
-            case 3: hipLaunchKernelGGL((gram_partial_f32<3, false, 4>), grid, block, 0, c->stream, F, k, r, partial); break;
-            case 4:
-                if (vl) hipLaunchKernelGGL((gram_partial_f32<4, true, 4>), grid, block, 0, c->stream, F, k, r, partial);
-                else hipLaunchKernelGGL((gram_partial_f32<4, false, 4>), grid, block, 0, c->stream, F, k, r, partial);
-                break;
-            case 5: hipLaunchKernelGGL((gram_partial_f32<5, false, 4>), grid, block, 0, c->stream, F, k, r, partial); break;
-            case 6: hipLaunchKernelGGL((gram_partial_f32<6, false, 4>), grid, block, 0, c->stream, F, k, r, partial); break;
-            case 7: hipLaunchKernelGGL((gram_partial_f32<7, false, 2>), grid, block, 0, c->stream, F, k, r, partial); break;
-            default: hipLaunchKernelGGL((gram_partial_f32<8, false, 2>), grid, block, 0, c->stream, F, k, r, partial); break;
-        }
-    } else {
-        const int tt = KP / 16;
-        dim3 grid((unsigned)nblk, tt), block(256);
-#define GRAM64_CASE(N) case N: hipLaunchKernelGGL(gram_partial_f64<N>, grid, block, 0, c->stream, F, k, r, partial); break;
-        switch (tt) {
-            GRAM64_CASE(1) GRAM64_CASE(2) GRAM64_CASE(3) GRAM64_CASE(4) GRAM64_CASE(5) GRAM64_CASE(6)
-            GRAM64_CASE(7) GRAM64_CASE(8) GRAM64_CASE(9) GRAM64_CASE(10) GRAM64_CASE(11) GRAM64_CASE(12)
-            GRAM64_CASE(13) GRAM64_CASE(14) GRAM64_CASE(15)
-            default: hipLaunchKernelGGL(gram_partial_f64<16>, grid, block, 0, c->stream, F, k, r, partial); break;
-        }
-#undef GRAM64_CASE
-    }
-    HIPCHK(hipGetLastError());
-    *nblk_out = (int)nblk;
-    *KP_out = KP;
-    return partial;
-}
 template <class T>
 static void gram_impl(rcppml_hip_ctx* c, const T* F, int k, int64_t r, T eps, T l2, T* G) {
     int nblk = 0, KP = 0;
     const T* partial = gram_partials<T>(c, F, k, r, &nblk, &KP);
     hipLaunchKernelGGL(gram_finalize<T>, dim3((KP * KP + 7) / 8), dim3(256), 0, c->stream, partial, nblk, KP, k, eps, l2, G);
     HIPCHK(hipGetLastError());
-}
-// Gram of W_T (+ eps) into G_wt and the MSE loss by the Gram trick, three launches instead of four: the cross-term partials share the
-// launch of the Gram's final sum (kernels_tail.hip.h) -- the results of rcppml_hip_gram + rcppml_hip_loss_mse bit for bit
-template <class T>
-static void gram_loss_mse_impl(rcppml_hip_ctx* c, const T* W_T, int k, int64_t m, T eps, const double* trAtA, const T* d, const T* B_w,
-                               const T* G_saved, T* G_wt, double* out) {
-    int nblk = 0, KP = 0;
-    const T* partial = gram_partials<T>(c, W_T, k, m, &nblk, &KP);
-    const int64_t total = (int64_t)k * m;
-    int64_t nbc = (total + 256 * 8 - 1) / (256 * 8);          // = loss_mse_impl's grid (ops_misc.hip): the same partial sums
-    if (nbc > 4 * (int64_t)c->num_cu) nbc = 4 * c->num_cu;
-    if (nbc < 1) nbc = 1;
-    double* cpart = static_cast<double*>(c->scratch(WS_RED, (size_t)nbc * sizeof(double)));
-    const unsigned nfin = (unsigned)((KP * KP + 7) / 8);
-    hipLaunchKernelGGL(tail_gramfin_cross_kernel<T>, dim3((unsigned)nbc + nfin), dim3(256), 0, c->stream, partial, nblk, KP, k, eps, T(0), G_wt,
-                       W_T, B_w, d, total, cpart, (unsigned)nbc);
-    HIPCHK(hipGetLastError());
-    hipLaunchKernelGGL(loss_mse_final<T>, dim3(1), dim3(256), 0, c->stream, trAtA, cpart, (int)nbc, d, G_wt, G_saved, k, out);
-    HIPCHK(hipGetLastError());
-}
-extern "C" int rcppml_hip_gram_loss_mse(rcppml_hip_ctx* c, int dtype, const void* W_T, int k, int64_t m, double eps, const double* trAtA,
-                                        const void* d, const void* B_w, const void* G_saved, void* G_wt, double* out) {
-    try {
-        HIPCHK(hipSetDevice(c->device));
-        if (dtype == RCPPML_F32)
-            gram_loss_mse_impl<float>(c, (const float*)W_T, k, m, (float)eps, trAtA, (const float*)d, (const float*)B_w, (const float*)G_saved, (float*)G_wt, out);
-        else
-            gram_loss_mse_impl<double>(c, (const double*)W_T, k, m, eps, trAtA, (const double*)d, (const double*)B_w, (const double*)G_saved, (double*)G_wt, out);
-        return 0;
-    }
-    RCPPML_CATCH_RET
 }
 extern "C" int rcppml_hip_gram(rcppml_hip_ctx* c, int dtype, const void* F, int k, int64_t r, double eps,
                                double l2, void* G) {

@@ -1,7 +1,6 @@
 // ops_misc.hip -- scaling, loss reductions, explicit-mask solve (device-level C ABI)
 #include "common.hip.h"
 #include "kernels.hip.h"
-#include "kernels_tail.hip.h"
 #include "kernels_wide.hip.h"
 
 using namespace rk;
@@ -53,68 +52,6 @@ static void apply_scaling_impl(rcppml_hip_ctx* c, T* X, int k, int64_t ncols, in
     if (vec) hipLaunchKernelGGL((scale_rows_from_sums_vec<T, VEC>), dim3((unsigned)nblk), dim3(256), 0, c->stream, X, k, total, sums, norm_type, d);
     else hipLaunchKernelGGL(scale_rows_from_sums<T>, dim3((unsigned)nblk), dim3(256), 0, c->stream, X, k, total, sums, norm_type, d);
     HIPCHK(hipGetLastError());
-}
-// extract_scaling (row sums -> d -> X(i,:) /= d_i) and, with `sweeps`, the work order of the NEXT solve of this side from the
-// sweep counts the solve that just ran left behind: three launches instead of five (kernels_tail.hip.h).  Same
-// grids, bodies and summation orders as rcppml_hip_row_norms + rcppml_hip_apply_scaling (+ rcppml_hip_order_columns): bit-identical.
-template <class T>
-static void scale_order_impl(rcppml_hip_ctx* c, T* X, int k, int64_t ncols, int norm_type, T* sums, T* d, const int* sweeps, int* order) {
-    const int64_t total = (int64_t)k * ncols;
-    // --- grids of the unfused kernels (row_norms_impl, apply_scaling_impl, rcppml_hip_order_columns)
-    int64_t nbn = (ncols + 255) / 256;
-    if (nbn > 2 * (int64_t)c->num_cu) nbn = 2 * c->num_cu;
-    if (nbn < 1) nbn = 1;
-    constexpr int VEC = 16 / sizeof(T);
-    const bool vec_s = k % VEC == 0 && reinterpret_cast<uintptr_t>(X) % 16 == 0;       // apply_scaling_impl's choice
-    const bool vec = vec_s && k / VEC <= 256;                                             // row_norms_impl's choice
-    int64_t nbs = ((vec_s ? total / VEC : total) + 255) / 256;
-    if (nbs > 8 * (int64_t)c->num_cu) nbs = 8 * c->num_cu;
-    if (nbs < 1) nbs = 1;
-    int64_t nbo = 0;
-    unsigned int* part = nullptr;
-    if (sweeps && order) {
-        nbo = (ncols + 1023) / 1024;
-        if (nbo > ORDER_BLOCKS_MAX) nbo = ORDER_BLOCKS_MAX;
-        if (nbo < 1) nbo = 1;
-        part = static_cast<unsigned int*>(c->scratch(WS_ORDER, (size_t)ORDER_BLOCKS_MAX * 128 * sizeof(unsigned int)));
-    }
-    T* partial = static_cast<T*>(c->scratch(WS_RED, (size_t)nbn * k * sizeof(T)));
-    if (vec) {
-        const int slots = 256 / (k / VEC);
-        hipLaunchKernelGGL((tail_norm_hist_kernel<T, VEC>), dim3((unsigned)(nbo + nbn)), dim3(256), (size_t)slots * k * sizeof(T), c->stream,
-                           X, k, ncols, norm_type, partial, (unsigned)nbn, sweeps, part, (unsigned)nbo);
-    } else {
-        hipLaunchKernelGGL((tail_norm_hist_kernel<T, 0>), dim3((unsigned)(nbo + nbn)), dim3(256), 256 * sizeof(T), c->stream,
-                           X, k, ncols, norm_type, partial, (unsigned)nbn, sweeps, part, (unsigned)nbo);
-    }
-    HIPCHK(hipGetLastError());
-    hipLaunchKernelGGL(row_norm_final<T>, dim3(k), dim3(64), 0, c->stream, partial, (int)nbn, k, sums);
-    HIPCHK(hipGetLastError());
-    if (vec_s)
-        hipLaunchKernelGGL((tail_scale_scatter_kernel<T, VEC>), dim3((unsigned)(nbo + nbs)), dim3(256), 0, c->stream, X, k, total, sums, norm_type, d,
-                           (unsigned)nbs, sweeps, ncols, part, order, (unsigned)nbo);
-    else
-        hipLaunchKernelGGL((tail_scale_scatter_kernel<T, 0>), dim3((unsigned)(nbo + nbs)), dim3(256), 0, c->stream, X, k, total, sums, norm_type, d,
-                           (unsigned)nbs, sweeps, ncols, part, order, (unsigned)nbo);
-    HIPCHK(hipGetLastError());
-}
-extern "C" int rcppml_hip_order_columns(rcppml_hip_ctx* c, const int* sweeps, int64_t ncols, int* order);
-extern "C" int rcppml_hip_apply_scaling(rcppml_hip_ctx* c, int dtype, void* X, int k, int64_t ncols, int norm_type, const void* sums, void* d);
-extern "C" int rcppml_hip_scale_order(rcppml_hip_ctx* c, int dtype, void* X, int k, int64_t ncols, int norm_type, void* sums, void* d,
-                                      const int* sweeps, int* order) {
-    try {
-        HIPCHK(hipSetDevice(c->device));
-        if (norm_type == 2 || ncols <= 0 || k <= 0) {       // no scaling pass to share a launch with: the separate ops
-            if (rcppml_hip_row_norms(c, dtype, X, k, ncols, norm_type, sums) != 0) return 1;
-            if (rcppml_hip_apply_scaling(c, dtype, X, k, ncols, norm_type, sums, d) != 0) return 1;
-            if (sweeps && order && ncols > 0) return rcppml_hip_order_columns(c, sweeps, ncols, order);
-            return 0;
-        }
-        if (dtype == RCPPML_F32) scale_order_impl<float>(c, (float*)X, k, ncols, norm_type, (float*)sums, (float*)d, sweeps, order);
-        else scale_order_impl<double>(c, (double*)X, k, ncols, norm_type, (double*)sums, (double*)d, sweeps, order);
-        return 0;
-    }
-    RCPPML_CATCH_RET
 }
 // ----------------------------------------------------------------------------
 // k x k feature layer

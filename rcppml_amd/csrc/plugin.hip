@@ -386,10 +386,17 @@ void fit(FitParams& P) {
         if (P.angular_H > 0 && !P.projective && !P.symmetric) OPCHK(rcppml_hip_angular_posthoc(c, dt, dH.p, k, n, P.angular_H));   // :638-639 (standard branch only)
         // the branch whose CD solves leave sweep counts behind (dswH / dswW) and run in sweep-sorted work order
         const bool std_cd = use_order && !P.symmetric && !P.projective && !has_mask && !is_nb;
+        // the W half-update's standard branch forms gram(H) + eps -> dGs right after this scaling (:715-722): one call does both
+        // (rcppml_hip_tail_scale_gram; fp32 k = 64 scales inside the Gram's partial-tile kernel)
+        const bool w_std = !P.symmetric && !has_mask && !is_nb;
         if (!P.symmetric) {
             const bool rank = std_cd && n >= kOrderMinColumns;
-            OPCHK(rcppml_hip_scale_order(c, dt, dH.p, k, n, P.norm_type, dsums.p, dd.p,       // :645 extract_scaling (+ the next H solve's work order)
-                                         rank ? dswH.as<int>() : nullptr, rank ? dordH.as<int>() : nullptr));
+            if (w_std)
+                OPCHK(rcppml_hip_tail_scale_gram(c, dt, dH.p, k, n, P.norm_type, dsums.p, dd.p,   // :645 extract_scaling (+ the next H solve's work order), :715-722 G_w_saved
+                                                 rank ? dswH.as<int>() : nullptr, rank ? dordH.as<int>() : nullptr, eps, 0.0, dGs.p));
+            else
+                OPCHK(rcppml_hip_scale_order(c, dt, dH.p, k, n, P.norm_type, dsums.p, dd.p,       // :645 extract_scaling
+                                             rank ? dswH.as<int>() : nullptr, rank ? dordH.as<int>() : nullptr));
             if (rank) ordH_fresh = true;
         }
 
@@ -422,7 +429,7 @@ void fit(FitParams& P) {
                                         (is_gp || per_col) ? nullptr : dtheta.p, P.tweedie_power, P.robust_delta));
             if (P.ub_W > 0) OPCHK(rcppml_hip_clip_upper(c, dt, dW.p, (int64_t)k * m, P.ub_W));      // :884-885
         } else {
-            OPCHK(rcppml_hip_gram(c, dt, dH.p, k, n, eps, 0.0, dGs.p));                 // :715-722 G_w_saved
+            // :715-722 G_w_saved = gram(H) + eps: formed with the scaling of H above (w_std)
             // the solve's Gram: G_saved itself when nothing is added to it (no copy: one kernel boundary less per iteration)
             const bool gw_modified = P.L2_W > 0 || graph_W || P.L21_W > 0 || tgtW;
             void* const Gw = gw_modified ? dG.p : dGs.p;
@@ -444,17 +451,24 @@ void fit(FitParams& P) {
                 OPCHK(rcppml_hip_solve_chol(c, dt, Gw, Bw_use, dW.p, k, m, P.L1_W > 0 ? P.L1_W : 0.0, P.nonneg_W, P.ub_W));
         }
         if (P.angular_W > 0) OPCHK(rcppml_hip_angular_posthoc(c, dt, dW.p, k, m, P.angular_W));   // :886-887
+        // the Gram-trick loss (:1729-1753) needs gram(W_T) of the scaled W_T right after this scaling: one call does both
+        const bool nb_fused = P.loss_type == 5 && P.dispersion_mode == 2 && !(P.robust_delta > 0) && !has_mask;
+        const bool mse_loss = !nb_fused && !has_mask && !is_nb;
         {
             const bool rank = std_cd && m >= kOrderMinColumns;
-            OPCHK(rcppml_hip_scale_order(c, dt, dW.p, k, m, P.norm_type, dsums.p, dd.p,       // :893 (+ the next W solve's work order)
-                                         rank ? dswW.as<int>() : nullptr, rank ? dordW.as<int>() : nullptr));
+            if (mse_loss)
+                OPCHK(rcppml_hip_tail_scale_gram_loss(c, dt, dW.p, k, m, P.norm_type, dsums.p, dd.p,   // :893 (+ the next W solve's work order), :1734-1753
+                                                      rank ? dswW.as<int>() : nullptr, rank ? dordW.as<int>() : nullptr, eps, dtr.as<double>(),
+                                                      dBw.p, dGs.p, dGwt.p, dloss.as<double>()));
+            else
+                OPCHK(rcppml_hip_scale_order(c, dt, dW.p, k, m, P.norm_type, dsums.p, dd.p,       // :893
+                                             rank ? dswW.as<int>() : nullptr, rank ? dordW.as<int>() : nullptr));
             if (rank) ordW_fresh = true;
         }
         if (P.symmetric) HIPCHK(hipMemcpyAsync(dH.p, dW.p, (size_t)k * m * sizeof(T), hipMemcpyDeviceToDevice, s));   // :704 H = W_T
 
         // ================= NB size update (fit_cpu.hpp:1094-1265), then loss (fit_cpu.hpp:1684-1753)
         // (PER_ROW sizes without the robust modifier: both in one pass over A^T, the predictions of the size update reused by the loss)
-        const bool nb_fused = P.loss_type == 5 && P.dispersion_mode == 2 && !(P.robust_delta > 0) && !has_mask;
         if (nb_fused) {
             OPCHK(rcppml_hip_nb_size_update_loss(c, dt, dTp.as<int>(), dTi.as<int>(), dTx.p, m, P.nnz, dW.p, dd.p, dH.p, n, k,
                                                  P.nb_size_min, P.nb_size_max, dtheta.p, dloss.as<double>()));
@@ -488,9 +502,8 @@ void fit(FitParams& P) {
         } else if (is_nb) {
             OPCHK(rcppml_hip_irls_loss(c, dt, P.loss_type, dAp.as<int>(), dAi.as<int>(), dAx.p, n, dW.p, dd.p, dH.p, dtheta.p, k, P.tweedie_power, P.robust_delta, dloss.as<double>()));
         } else {
-            // :1734-1735 Gram of the scaled W_T, then the Gram-trick loss.  B_w (raw RHS of the W update) is exactly the h_at of
-            // loss_cross_term_sparse_via_At (fused_nnls.hpp:305-362): the third O(nnz k) pass of the reference is not needed.
-            OPCHK(rcppml_hip_gram_loss_mse(c, dt, dW.p, k, m, eps, dtr.as<double>(), dd.p, dBw.p, dGs.p, dGwt.p, dloss.as<double>()));
+            // :1734-1753 Gram of the scaled W_T and the Gram-trick loss: formed with the scaling of W_T above (mse_loss).  B_w (raw RHS of
+            // the W update) is exactly the h_at of loss_cross_term_sparse_via_At (fused_nnls.hpp:305-362): no third O(nnz k) pass.
         }
     };
 

@@ -77,6 +77,22 @@ class OracleOps:
         d.copy_(torch.from_numpy(dd.astype(self.ndtype)))
         X.div_(d)
 
+    def scale_order(self, X, sums, norm_type, d, cfg, side):      # HipOps: the scaling pass + the next solve's work order in shared launches
+        self.row_norms(X, norm_type, out=sums)
+        self.apply_scaling(X, sums, norm_type, d)
+
+    def tail_scale_gram(self, X, sums, norm_type, d, cfg, side, eps, G):
+        self.scale_order(X, sums, norm_type, d, cfg, side)
+        self.gram(X, eps, 0.0, out=G)
+
+    def tail_scale_gram_loss(self, W_T, sums, norm_type, d, cfg, side, eps, trAtA, B_w, G_saved, G_wt, out):
+        self.scale_order(W_T, sums, norm_type, d, cfg, side)
+        self.gram_loss_mse(W_T, eps, trAtA, d, B_w, G_saved, G_wt, out)
+
+    def gram_loss_mse(self, W_T, eps, trAtA, d, B_w, G_saved, G_wt, out):
+        self.gram(W_T, eps, 0.0, out=G_wt)
+        self.loss_mse(trAtA, d, W_T, B_w, G_wt, G_saved, out)
+
     def sumsq(self, x):
         return torch.tensor([float((x.double() ** 2).sum())], dtype=torch.float64)
 

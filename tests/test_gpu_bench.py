@@ -31,7 +31,9 @@ def test_bench_line_graph_and_eager_modes_agree():
         for roof in (d["roofline"], d["roofline_rhs"]):
             assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(roof)
             assert 0 < roof["frac"] < 1 and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9
-        assert set(d["phases_ms_per_step"]) >= {"gram", "rhs_H", "rhs_W", "solve_H", "solve_W", "scale", "loss"}
+        # (the tail between two solves is one call per side since round 5: "scale_gram" = scaling + next work order + Gram of H,
+        # "scale_gram_loss" = the same for W_T + the loss; bench.py --no-fused-tail keeps the separate "scale" / "gram" / "loss" phases)
+        assert d["fused_tail"] and set(d["phases_ms_per_step"]) >= {"rhs_H", "rhs_W", "solve_H", "solve_W", "scale_gram", "scale_gram_loss"}
         assert sum(d["phases_ms_per_step"].values()) < 1.25 * max(d["ms_per_step"], d["eager_ms_per_step"] or 0)
     assert "hipGraph" in g["launch"] and g["eager_ms_per_step"] > 0
     assert e["launch"] == "eager" and e["eager_ms_per_step"] is None

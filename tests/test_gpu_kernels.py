@@ -569,6 +569,10 @@ def test_fused_tail_under_graph_replay(env):
             X.copy_(X0)
             ctx.scale_order(_abi.F32, X, k, c, 0, s, d, sw, o)
             ctx.gram_loss_mse(_abi.F32, X, k, c, 1e-15, tr, d, Bw, Gs, G, out)
+            X.copy_(X0)
+            ctx.tail_scale_gram(_abi.F32, X, k, c, 0, s, d, sw, o, 1e-15, 0.0, G)        # (the k = 64 form: scaling inside the Gram kernel)
+            X.copy_(X0)
+            ctx.tail_scale_gram_loss(_abi.F32, X, k, c, 0, s, d, sw, o, 1e-15, tr, Bw, Gs, G, out)
         body(); body()
         torch.cuda.synchronize()
         want = [t.clone() for t in (X, s, d, o, G, out[:3])]
@@ -582,3 +586,51 @@ def test_fused_tail_under_graph_replay(env):
             torch.cuda.synchronize()
             for a, b in zip(want, (X, s, d, o, G, out[:3])):
                 assert torch.equal(a, b), rep
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("norm_type", [0, 1, 2])
+@pytest.mark.parametrize("k,c,ranked", [(64, 100003, True), (64, 20000, True), (64, 777, False), (64, 1, False), (32, 20000, True), (10, 1183, False)])
+def test_tail_ops_equal_separate_ops(env, dtype, norm_type, k, c, ranked):
+    """rcppml_hip_tail_scale_gram / rcppml_hip_tail_scale_gram_loss (a half-update's whole tail in one call; fp32 with k = 64 scales
+    the factor INSIDE the Gram's partial-tile kernel -- the lane that loads an element divides it, stores it back and feeds the scaled
+    value to the matrix cores) against the separate ops row_norms + apply_scaling + order_columns + gram (+ loss_mse): row sums, d, the
+    scaled factor, the work order, the Gram and the three loss terms BIT FOR BIT, every shape (the others take the unfused calls).
+    Reference: nmf/variant_helpers.hpp:286-305, primitives/cpu/gram.hpp:37-67, nmf/fit_cpu.hpp:1729-1753."""
+    torch, _abi, ctx = env
+    rs = np.random.default_rng(k * 11 + c)
+    X = (rs.uniform(size=(c, k)) * (rs.uniform(size=(c, k)) < 0.6)).astype(dtype)
+    X[:, 0] = 0
+    sw = _dev(torch, rs.integers(0, 110, size=c).astype(np.int32))
+    dt, tt = _dt(_abi, dtype), _tt(torch, dtype)
+    Bw = _dev(torch, rs.normal(size=(c, k)).astype(dtype))
+    Gs = _dev(torch, rs.uniform(size=(k, k)).astype(dtype))
+    tr = torch.tensor([77.0], dtype=torch.float64, device="cuda")
+    X1 = _dev(torch, X)
+    s1 = torch.empty(k, dtype=tt, device="cuda"); d1 = torch.empty(k, dtype=tt, device="cuda")
+    o1 = torch.full((c,), -1, dtype=torch.int32, device="cuda")
+    G1 = torch.empty((k, k), dtype=tt, device="cuda"); Gl1 = torch.empty((k, k), dtype=tt, device="cuda")
+    out1 = torch.zeros(4, dtype=torch.float64, device="cuda")
+    ctx.row_norms(dt, X1, k, c, norm_type, s1)
+    ctx.apply_scaling(dt, X1, k, c, norm_type, s1, d1)
+    if ranked:
+        ctx.order_columns(sw, c, o1)
+    ctx.gram(dt, X1, k, c, 1e-15, 0.25, G1)
+    ctx.gram(dt, X1, k, c, 1e-15, 0.0, Gl1)
+    ctx.loss_mse(dt, tr, d1, X1, Bw, k, c, Gl1, Gs, out1)
+    for which in ("gram", "loss"):
+        X2 = _dev(torch, X)
+        s2 = torch.full((k,), -7.0, dtype=tt, device="cuda"); d2 = torch.full((k,), -7.0, dtype=tt, device="cuda")
+        o2 = torch.full((c,), -1, dtype=torch.int32, device="cuda")
+        G2 = torch.full((k, k), -3.0, dtype=tt, device="cuda"); out2 = torch.full((4,), -3.0, dtype=torch.float64, device="cuda")
+        if which == "gram":
+            ctx.tail_scale_gram(dt, X2, k, c, norm_type, s2, d2, sw if ranked else None, o2 if ranked else None, 1e-15, 0.25, G2)
+        else:
+            ctx.tail_scale_gram_loss(dt, X2, k, c, norm_type, s2, d2, sw if ranked else None, o2 if ranked else None, 1e-15, tr, Bw, Gs, G2, out2)
+        ctx.sync()
+        assert torch.equal(s1, s2) and torch.equal(d1, d2), which
+        assert torch.equal(X1, X2), which
+        assert torch.equal(o1, o2), which
+        assert torch.equal(G1 if which == "gram" else Gl1, G2), which
+        if which == "loss":
+            assert torch.equal(out1[:3], out2[:3]), (out1.tolist(), out2.tolist())
