@@ -147,13 +147,26 @@ def nmf(data, k, tol=1e-4, maxit=100, L1=(0.0, 0.0), L2=(0.0, 0.0), seed=None, m
     L21w, L21h = _pair(L21, "L21")
     angw, angh = _pair(angular, "angular")
     ubw, ubh = _pair(upper_bound, "upper_bound")
-    if min(L1w, L1h, L2w, L2h) < 0:
-        raise ValueError("L1 and L2 penalties must be non-negative")
+    # R/nmf_validation.R:108-141 validate_all_penalties, message for message
+    if max(L1w, L1h) >= 1 or min(L1w, L1h) < 0:
+        raise ValueError("L1 penalties must be strictly in the range [0,1)")
+    if min(L2w, L2h) < 0:
+        raise ValueError("L2 penalties must be strictly >= 0")
+    if min(L21w, L21h) < 0:
+        raise ValueError("L21 penalties must be strictly >= 0")
+    if min(angw, angh) < 0:
+        raise ValueError("angular penalties must be strictly >= 0")
+    if min(ubw, ubh) < 0:
+        raise ValueError("'upper_bound' values must be non-negative")
+    if norm not in ("L1", "L2", "none", "None"):
+        raise ValueError("'arg' should be one of 'L1', 'L2', 'none'")          # match.arg(norm), R/nmf_thin.R
     nn = np.atleast_1d(nonneg)
     nnw, nnh = (bool(nn[0]), bool(nn[-1]))
     norm_type = {"L1": 0, "L2": 1, "none": 2, "None": 2}[norm]
     solver = select_solver(solver, k, (L1w, L1h), loss if robust_delta == 0 else "robust", use_gpu=True)
     glw, glh = _pair(graph_lambda, "graph_lambda")
+    if min(glw, glh) < 0:
+        raise ValueError("'graph_lambda' values must be non-negative")
     graph_args = {}
     for name, g, dim, lam in (("graph_W", graph_W, m, glw), ("graph_H", graph_H, n, glh)):
         if g is None or lam <= 0:
@@ -317,10 +330,23 @@ def nnls(w=None, h=None, A=None, L1=0.0, L2=0.0, cd_maxit=100, cd_tol=1e-8, uppe
     return out
 
 
-def predict(model, data, L1=0.0, L2=0.0, upper_bound=0.0):
+def predict(model, data, L1=None, L2=None, upper_bound=0.0):
     """R/predict_nmf.R:48-97 -> Rcpp_predict (src/RcppFunctions_utils.cpp:23-52): project new samples onto model.w
-    with cd_maxit = 100, cd_tol = 1e-8, nonneg = TRUE.  Returns h (k x n)."""
-    return nnls(w=model.w, A=data, L1=L1, L2=L2, cd_maxit=100, cd_tol=1e-8, upper_bound=upper_bound, nonneg=True)
+    with cd_maxit = 100, cd_tol = 1e-8, nonneg = TRUE.  Returns h (k x n).  L1 / L2 default to the h-side penalties the model was
+    fitted with (misc$L1[2], misc$L2[2]; R/predict_nmf.R:52-53) and are validated with the reference's messages (:56-59)."""
+    if L1 is None:
+        L1 = model.misc.get("L1", (0.0, 0.0))[1] if isinstance(model.misc, dict) else 0.0
+    if L2 is None:
+        L2 = model.misc.get("L2", (0.0, 0.0))[1] if isinstance(model.misc, dict) else 0.0
+    if np.ndim(L1) != 0:
+        raise ValueError("'L1' must be a single value giving the penalty on 'h'")
+    if L1 >= 1 or L1 < 0:
+        raise ValueError("L1 penalty must be strictly in the range [0,1)")
+    if np.ndim(L2) != 0:
+        raise ValueError("'L2' must be a single value giving the penalty on 'h'")
+    if L2 < 0:
+        raise ValueError("L2 penalty must be strictly >= 0")
+    return nnls(w=model.w, A=data, L1=float(L1), L2=float(L2), cd_maxit=100, cd_tol=1e-8, upper_bound=upper_bound, nonneg=True)
 
 
 def evaluate(model, data, mask=None):

