@@ -41,7 +41,7 @@ def _pair(v, name):
     if v.shape[0] == 1:
         v = np.repeat(v, 2)
     if v.shape[0] != 2:
-        raise ValueError("'%s' must be a vector of length 1 or 2: c(w, h)" % name)
+        raise ValueError("'%s' must be length 1 or 2 for c(w, h)" % name)          # R/nmf_validation.R:90-95 validate_penalty
     return float(v[0]), float(v[1])
 
 
@@ -102,6 +102,24 @@ def nmf(data, k, tol=1e-4, maxit=100, L1=(0.0, 0.0), L2=(0.0, 0.0), seed=None, m
         raise ValueError("'robust' must be FALSE, TRUE, 'mae', or a positive numeric Huber delta.")
     if robust_delta > 0 and solver == "cholesky":
         raise ValueError("solver='cholesky' is not supported with robust IRLS (robust_delta > 0). Use solver='cd' for robust estimation.")
+    if solver == "cholesky" and loss != "mse" and robust_delta == 0:                 # R/nmf_thin.R:378-382
+        raise ValueError("solver='cholesky' is not supported with non-MSE distributions (got '%s'). Use solver='cd' for IRLS-based distributions." % loss)
+    # R/nmf_validation.R:148-160 validate_cv_params, :280-296 validate_simple_params, :87-118 validate_mask -- message for message
+    if isinstance(test_fraction, (str, bytes)) or np.ndim(test_fraction) != 0:
+        raise ValueError("'test_fraction' must be a single numeric value")
+    if not (0 <= float(test_fraction) < 1):
+        raise ValueError("'test_fraction' must be in the range [0, 1)")
+    if isinstance(patience, (str, bytes)) or np.ndim(patience) != 0:
+        raise ValueError("'patience' must be a single numeric value")
+    if not isinstance(sort_model, (bool, np.bool_)):
+        raise ValueError("'sort_model' must be a single logical value")
+    _nn = np.atleast_1d(np.asarray(nonneg))
+    if _nn.dtype != np.bool_:
+        raise ValueError("'nonneg' must be logical")
+    if _nn.shape[0] not in (1, 2):
+        raise ValueError("'nonneg' must be length 1 or 2 with no NA values")
+    if isinstance(mask, str) and mask not in ("zeros", "NA"):
+        raise ValueError("'mask' must be NULL, 'zeros', 'NA', a matrix, or list(\"zeros\", <matrix>)")
     if dispersion not in ("none", "global", "per_row", "per_col"):
         raise ValueError("dispersion must be 'none', 'global', 'per_row' or 'per_col'")
     if dispersion == "per_col" and test_fraction and test_fraction > 0:
@@ -114,7 +132,7 @@ def nmf(data, k, tol=1e-4, maxit=100, L1=(0.0, 0.0), L2=(0.0, 0.0), seed=None, m
     cv = bool(test_fraction) and test_fraction > 0
     if cv:
         if not (0 < test_fraction < 1):
-            raise ValueError("test_fraction must be in [0, 1)")
+            raise ValueError("'test_fraction' must be in the range [0, 1)")
     if resource != "gpu":
         raise ValueError("rcppml_amd has no CPU path; resource must be 'gpu'")
     dense_in = isinstance(data, np.ndarray) and data.ndim == 2        # a base R matrix: the reference's dense path
@@ -172,8 +190,9 @@ def nmf(data, k, tol=1e-4, maxit=100, L1=(0.0, 0.0), L2=(0.0, 0.0), seed=None, m
         if g is None or lam <= 0:
             continue
         Lg = _as_csc(g)
-        if Lg.shape != (dim, dim):
-            raise ValueError("%s must be %d x %d" % (name, dim, dim))
+        if Lg.shape != (dim, dim):                                                   # R/nmf_validation.R:171-205 validate_graphs
+            raise ValueError("'%s' must be a %d x %d matrix (%s)" % (name, dim, dim, "p x p where p is number of features" if name == "graph_W"
+                                                                       else "n x n where n is number of samples"))
         graph_args[name] = (Lg.p, Lg.i, Lg.x, float(lam))
     if graph_args and (loss != "mse" or robust_delta > 0 or (mask is not None and not isinstance(mask, str)) or k > 128):
         raise NotImplementedError("graph regularisation is implemented for the plain MSE path, k <= 128")
