@@ -11,7 +11,7 @@
 
 namespace {
 
-constexpr int TR_RCH = 32768;        // rows per pass: 128 KiB of LDS counters
+constexpr int TR_RCH = 32768;        // rows the LDS-counter form handles (128 KiB of counters); taller inputs: radix passes below
 // Chunks are cut by NONZEROS, on column boundaries (round 5; until then by column count, which left a matrix whose nonzeros sit in
 // a few columns to a few workgroups): chunk b = columns [bound(b), bound(b+1)), bound(b) = the first column j with
 // p[j] >= floor(b nnz / B) (bound(0) = 0, bound(B) = cols) -- non-decreasing in b, so the chunks tile the columns; both kernels
@@ -88,6 +88,96 @@ __global__ __launch_bounds__(256) void transpose_scatter_kernel(const int* __res
         }
     }
 }
+// ---------------------------------------------------------------------------
+// Tall inputs (rows > TR_RCH): the passes above would re-read every chunk's nonzeros once per 32 768 rows (a 1M-row matrix: 31
+// times) and the B x rows table caps the number of chunks.  Instead: a STABLE least-significant-digit radix sort of the nonzero
+// positions by row index, 8 bits per pass (2 passes up to 65 536 rows, 3 up to 16.7 M), each pass = per-block digit counts
+// (radix_hist_kernel) + ranked scatter (radix_scatter_kernel: blocks take contiguous chunks of the current order, the four
+// wavefronts of a block contiguous quarters, inside a 64-element round the rank is the number of lower lanes with the same digit --
+// eight ballots), so equal digits keep their order and positions of one row end in increasing order, as the reference's
+// transpose leaves them.  O(passes * nnz) whatever the shape; no atomics on global memory except the row histogram (integer counts:
+// order-independent), nothing to zero but that histogram.
+// ---------------------------------------------------------------------------
+constexpr int RX_BINS = 256, RX_BLOCKS_MAX = 1024;
+__global__ __launch_bounds__(256) void radix_hist_kernel(const int* __restrict__ pos_in, const int* __restrict__ ri, int64_t n, int shift,
+                                                         unsigned int* __restrict__ part /* gridDim.x x 256 */) {
+    __shared__ unsigned int sh[RX_BINS];
+    sh[threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t per = (n + gridDim.x - 1) / gridDim.x;
+    const int64_t i0 = (int64_t)blockIdx.x * per;
+    const int64_t i1 = i0 + per < n ? i0 + per : n;
+    for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) {
+        const int e = pos_in ? pos_in[i] : (int)i;
+        atomicAdd(&sh[((unsigned)ri[e] >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    part[(size_t)blockIdx.x * RX_BINS + threadIdx.x] = sh[threadIdx.x];
+}
+__global__ __launch_bounds__(256) void radix_scatter_kernel(const int* __restrict__ pos_in, const int* __restrict__ ri, int64_t n, int shift,
+                                                            const unsigned int* __restrict__ part, int* __restrict__ pos_out) {
+    __shared__ unsigned int tot[RX_BINS], base[RX_BINS], wcnt[4][RX_BINS];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t per = (n + gridDim.x - 1) / gridDim.x;
+    const int64_t i0 = (int64_t)blockIdx.x * per;
+    const int64_t i1 = i0 + per < n ? i0 + per : n;
+    const int64_t wper = (per + 3) / 4;                       // this wavefront's contiguous quarter [j0, j1)
+    const int64_t j0 = i0 + w * wper < i1 ? i0 + w * wper : i1;
+    const int64_t j1 = j0 + wper < i1 ? j0 + wper : i1;
+    for (int v = 0; v < 4; ++v) wcnt[v][threadIdx.x] = 0;
+    {   // digit x = threadIdx.x: total over all blocks, and the part of it in the blocks before this one
+        unsigned int t = 0, before = 0;
+        for (unsigned int b = 0; b < gridDim.x; ++b) {
+            const unsigned int c = part[(size_t)b * RX_BINS + threadIdx.x];
+            before += b < blockIdx.x ? c : 0u;
+            t += c;
+        }
+        tot[threadIdx.x] = t;
+        base[threadIdx.x] = before;
+    }
+    __syncthreads();
+    for (int64_t i = j0 + lane; i < j1; i += 64) {            // per-wavefront digit counts of the quarter
+        const int e = pos_in ? pos_in[i] : (int)i;
+        atomicAdd(&wcnt[w][((unsigned)ri[e] >> shift) & 255u], 1u);
+    }
+    if (threadIdx.x == 0) {                                    // exclusive scan of the totals over the 256 digits
+        unsigned int run = 0;
+        for (int x = 0; x < RX_BINS; ++x) { const unsigned int t = tot[x]; tot[x] = run; run += t; }
+    }
+    __syncthreads();
+    {   // wcnt[v][x] <- where wavefront v's first element of digit x goes
+        unsigned int run = tot[threadIdx.x] + base[threadIdx.x];
+        for (int v = 0; v < 4; ++v) { const unsigned int t = wcnt[v][threadIdx.x]; wcnt[v][threadIdx.x] = run; run += t; }
+    }
+    __syncthreads();
+    volatile unsigned int* wb = wcnt[w];                       // this wavefront's running digit starts (one wavefront = program order)
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    for (int64_t r = j0; r < j1; r += 64) {
+        const int64_t i = r + lane;
+        const bool valid = i < j1;
+        int e = 0;
+        unsigned int dg = 0;
+        if (valid) {
+            e = pos_in ? pos_in[i] : (int)i;
+            dg = ((unsigned)ri[e] >> shift) & 255u;
+        }
+        unsigned long long same = __ballot(valid);
+#pragma unroll
+        for (int bit = 0; bit < 8; ++bit) {
+            const unsigned long long bm = __ballot((dg >> bit) & 1u);
+            same &= ((dg >> bit) & 1u) ? bm : ~bm;
+        }
+        if (valid) {
+            const unsigned int start = wb[dg];                  // every lane of the group reads the same word ...
+            pos_out[start + (unsigned int)__popcll(same & lt)] = e;
+            if ((same & lt) == 0ull) wb[dg] = start + (unsigned int)__popcll(same);      // ... its lowest lane moves it on
+        }
+    }
+}
+__global__ void row_count_kernel(const int* __restrict__ ri, int64_t nnz, int* __restrict__ rowcnt) {
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < nnz; t += (int64_t)gridDim.x * blockDim.x) atomicAdd(&rowcnt[ri[t]], 1);
+}
+
 // column of the nonzero at position pos: largest j with p[j] <= pos
 __device__ __forceinline__ int col_of(const int* __restrict__ p, int cols, int pos) {
     int lo = 0, hi = cols;      // invariant: p[lo] <= pos < p[hi]
@@ -129,6 +219,31 @@ unsigned grid_for(int64_t n, int num_cu) {
 void transpose_sort(rcppml_hip_ctx* c, int rows, int cols, int64_t nnz, const int* p, const int* ri, int* tp, int* pos_out) {
     HIPCHK(hipMemsetAsync(tp, 0, ((size_t)rows + 1) * sizeof(int), c->stream));
     if (nnz == 0 || rows <= 0 || cols <= 0) return;
+    if (rows > TR_RCH) {          // tall: stable LSD radix sort of the positions by row index (above)
+        int bits = 1;
+        while (((int64_t)1 << bits) < rows) ++bits;
+        const int passes = (bits + 7) / 8;
+        int64_t nblk = (nnz + 4095) / 4096;
+        if (nblk > RX_BLOCKS_MAX) nblk = RX_BLOCKS_MAX;
+        if (nblk < 1) nblk = 1;
+        DevTmp part(c, (size_t)nblk * RX_BINS * sizeof(unsigned int)), other(c, (size_t)nnz * sizeof(int)), rowcnt(c, ((size_t)rows + 1) * sizeof(int));
+        // ping-pong so that the LAST pass writes pos_out
+        int* bufs[2] = {passes % 2 ? pos_out : (int*)other.p, passes % 2 ? (int*)other.p : pos_out};
+        const int* in = nullptr;
+        for (int ps = 0; ps < passes; ++ps) {
+            int* out = bufs[ps % 2];
+            hipLaunchKernelGGL(radix_hist_kernel, dim3((unsigned)nblk), dim3(256), 0, c->stream, in, ri, nnz, 8 * ps, (unsigned int*)part.p);
+            hipLaunchKernelGGL(radix_scatter_kernel, dim3((unsigned)nblk), dim3(256), 0, c->stream, in, ri, nnz, 8 * ps, (const unsigned int*)part.p, out);
+            HIPCHK(hipGetLastError());
+            in = out;
+        }
+        HIPCHK(hipMemsetAsync(rowcnt.p, 0, ((size_t)rows + 1) * sizeof(int), c->stream));
+        hipLaunchKernelGGL(row_count_kernel, dim3(grid_for(nnz, c->num_cu)), dim3(256), 0, c->stream, ri, nnz, (int*)rowcnt.p);
+        HIPCHK(hipGetLastError());
+        rk::exclusive_scan_i32(c, (const int*)rowcnt.p, tp, (int64_t)rows + 1);
+        if (part.owned || other.owned || rowcnt.owned) HIPCHK(hipStreamSynchronize(c->stream));
+        return;
+    }
     // chunks: enough workgroups to fill the chip, the B x rows table at most 256 MB
     int B = cols < 512 ? cols : 512;
     const int64_t cap = (int64_t)(256u << 20) / ((int64_t)rows * 4);

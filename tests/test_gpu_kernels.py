@@ -354,6 +354,42 @@ def test_transpose_csc_skewed_and_tall(env):
         assert np.array_equal(tx.cpu().numpy()[:A.nnz], At.values(np.float64))
 
 
+@pytest.mark.parametrize("m,n,density", [(40000, 700, 0.002), (65536, 300, 0.004), (65537, 300, 0.004), (300000, 2000, 0.001),
+                                         (1 << 20, 64, 0.0005), (2500000, 40, 0.0004)])
+def test_transpose_csc_tall_radix_passes(env, m, n, density):
+    """Inputs with more than 32 768 rows take the stable LSD radix sort of the nonzero positions by row index (8 bits per pass: 2
+    passes up to 65 536 rows, 3 above; ADVICE r4: the LDS-counter form re-read every chunk once per 32 768 rows): row pointers, column
+    indices (ascending inside every row, as the reference's `A.transpose()` leaves them, nmf/fit_cpu.hpp:251-253) and values equal
+    scipy's transpose; also through the two-step entry the plugin uses (sort on the row indices, gather when the values arrive)."""
+    import scipy.sparse as sp
+    torch, _abi, ctx = env
+    rs = np.random.default_rng(m % 1000 + n)
+    M = sp.random(m, n, density=density, format="csc", random_state=rs, dtype=np.float64)
+    M.sort_indices()
+    T = sp.csc_matrix(M.T)
+    T.sort_indices()
+    nnz = M.nnz
+    dp = torch.from_numpy(M.indptr.astype(np.int32)).cuda(); di = torch.from_numpy(M.indices.astype(np.int32)).cuda()
+    dx = torch.from_numpy(M.data).cuda()
+    tp = torch.full((m + 1,), -1, dtype=torch.int32, device="cuda")
+    ti = torch.full((nnz,), -1, dtype=torch.int32, device="cuda")
+    tx = torch.zeros((nnz,), dtype=torch.float64, device="cuda")
+    ctx.transpose_csc(_abi.F64, m, n, dp, di, dx, tp, ti, tx)
+    assert np.array_equal(tp.cpu().numpy(), T.indptr.astype(np.int32))
+    assert np.array_equal(ti.cpu().numpy(), T.indices.astype(np.int32))
+    assert np.array_equal(tx.cpu().numpy(), T.data)
+    lib = _abi.lib()
+    import ctypes as C
+    tp2 = torch.full((m + 1,), -1, dtype=torch.int32, device="cuda"); pos = torch.full((nnz,), -1, dtype=torch.int32, device="cuda")
+    ti2 = torch.full((nnz,), -1, dtype=torch.int32, device="cuda"); tx2 = torch.zeros((nnz,), dtype=torch.float32, device="cuda")
+    x32 = dx.float()
+    vp = lambda t: C.c_void_p(t.data_ptr())
+    assert lib.rcppml_hip_transpose_csc_sort(ctx._h, C.c_int(m), C.c_int(n), C.c_int64(nnz), vp(dp), vp(di), vp(tp2), vp(pos)) == 0
+    assert lib.rcppml_hip_transpose_csc_gather(ctx._h, C.c_int(_abi.F32), C.c_int(n), C.c_int64(nnz), vp(dp), vp(pos), vp(x32), vp(ti2), vp(tx2)) == 0
+    ctx.sync()
+    assert torch.equal(tp2, tp) and torch.equal(ti2, ti) and np.array_equal(tx2.cpu().numpy(), T.data.astype(np.float32))
+
+
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 @pytest.mark.parametrize("k,dim", [(3, 37), (10, 500), (16, 64), (33, 1200), (64, 3001)])
 def test_apply_graph_reg(env, dtype, k, dim):
