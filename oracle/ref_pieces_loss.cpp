@@ -61,3 +61,15 @@ __attribute__((visibility("default"))) double ref_loss_mse_f64(double observed, 
     return FactorNet::loss_contribution_mse<double>(observed, predicted);
 }
 }
+
+// core/constants.hpp (self-contained: <limits>, <type_traits> only), the reference's numerical constants and algorithm defaults on the
+// NMF path, in the order tests/golden/make_ref_constants.py names them
+extern "C" __attribute__((visibility("default"))) int ref_constants(double* out, int cap) {
+    const double v[] = {FactorNet::tiny_num<double>(), (double)FactorNet::tiny_num<float>(), FactorNet::kl_epsilon<double>(),
+                        FactorNet::CD_TOL, (double)FactorNet::CD_MAXIT, FactorNet::CD_ABS_TOL, FactorNet::NMF_TOL,
+                        (double)FactorNet::NMF_MAXIT, (double)FactorNet::NMF_PATIENCE, FactorNet::DEFAULT_L1, FactorNet::DEFAULT_L2,
+                        FactorNet::DEFAULT_L21, FactorNet::DEFAULT_GRAPH_LAMBDA, FactorNet::DEFAULT_HUBER_DELTA};
+    const int n = (int)(sizeof(v) / sizeof(v[0]));
+    for (int i = 0; i < n && i < cap; ++i) out[i] = v[i];
+    return n;
+}
