@@ -626,7 +626,8 @@ def test_fused_tail_under_graph_replay(env):
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 @pytest.mark.parametrize("norm_type", [0, 1, 2])
-@pytest.mark.parametrize("k,c,ranked", [(64, 100003, True), (64, 20000, True), (64, 777, False), (64, 1, False), (32, 20000, True), (10, 1183, False)])
+@pytest.mark.parametrize("k,c,ranked", [(64, 100003, True), (64, 20000, True), (64, 777, False), (64, 1, False), (32, 20000, True), (10, 1183, False),
+                                        (60, 20000, True), (49, 777, False)])
 def test_tail_ops_equal_separate_ops(env, dtype, norm_type, k, c, ranked):
     """rcppml_hip_tail_scale_gram / rcppml_hip_tail_scale_gram_loss (a half-update's whole tail in one call; fp32 with k = 64 scales
     the factor INSIDE the Gram's partial-tile kernel -- the lane that loads an element divides it, stores it back and feeds the scaled
