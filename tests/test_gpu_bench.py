@@ -21,6 +21,21 @@ def _run(*extra):
     return json.loads(out.stdout.strip().splitlines()[-1])
 
 
+def test_bench_fused_tail_equals_separate_kernels():
+    """The fused iteration tail (15 launches per iteration: DESIGN 4.5) and the separate kernels (--no-fused-tail, 22 launches) are the
+    same arithmetic: identical final loss and work counters, in fp32 (scaling inside the Gram's partial-tile kernel at k = 64) and fp64;
+    the line says which form ran and names its phases accordingly."""
+    for dt in ("f32", "f64"):
+        f = _run("--dtype", dt)
+        s = _run("--dtype", dt, "--no-fused-tail")
+        assert f["fused_tail"] and not s["fused_tail"]
+        assert f["final_loss"] == s["final_loss"], (dt, f["final_loss"], s["final_loss"])
+        assert f["roofline"]["mean_sweeps_per_column"] == s["roofline"]["mean_sweeps_per_column"]
+        assert set(s["phases_ms_per_step"]) >= {"scale", "gram", "loss", "solve_H", "solve_W"} and "scale_gram" in f["phases_ms_per_step"]
+        for side in ("H", "W"):      # (the idle-slot figure comes from the work order the last solve RAN in, whichever form ranked it)
+            assert abs(f["roofline"]["idle_slot_fraction"][side] - s["roofline"]["idle_slot_fraction"][side]) < 1e-12
+
+
 def test_bench_line_graph_and_eager_modes_agree():
     g = _run()
     e = _run("--no-graph")
