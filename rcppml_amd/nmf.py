@@ -368,12 +368,38 @@ def predict(model, data, L1=None, L2=None, upper_bound=0.0):
     return nnls(w=model.w, A=data, L1=float(L1), L2=float(L2), cd_maxit=100, cd_tol=1e-8, upper_bound=upper_bound, nonneg=True)
 
 
-def evaluate(model, data, mask=None):
-    """R/nmf_methods.R:356-469 -> Rcpp_evaluate_loss: MEAN squared error of w diag(d) h over all entries, or over the
-    nonzeros of `data` if mask == 'zeros'.  (model.misc['loss'] is the SUM)"""
+def evaluate(model, data, mask=None, missing_only=False):
+    """R/nmf_methods.R:356-469 -> Rcpp_evaluate_loss / Rcpp_evaluate_loss_missing (src/RcppFunctions_utils.cpp:95-213): MEAN squared
+    error of w diag(d) h over all entries, over the nonzeros of `data` if mask == 'zeros', or -- mask = <matrix>, missing_only = TRUE --
+    over the entries the mask marks (values > 0), zeros of `data` included.  As in the reference, a mask MATRIX without missing_only
+    changes nothing: Rcpp_evaluate_loss receives it and never reads it (utils.cpp:152-163 -> compute_loss_general, :95-148).
+    (model.misc['loss'] is the SUM)"""
+    if missing_only and mask is None:
+        raise ValueError("a mask matrix must be specified to set 'missing_only = TRUE'")          # R/nmf_methods.R:366
     A = _as_csc(data)
-    if mask not in (None, "zeros"):
-        raise NotImplementedError("evaluate(): only mask=NULL or mask='zeros'")
     k = model.d.shape[0]
+    if mask is not None and not isinstance(mask, str):
+        M = _as_csc(mask)
+        if M.shape != A.shape:
+            raise ValueError("mask dimensions must match data")
+        if not missing_only:
+            mask = None                                                # the reference's quirk: the mask matrix is ignored here
+        else:
+            # the marked entries as a CSC that STORES them (zeros of `data` included): the device pass over stored entries is then
+            # exactly Rcpp_evaluate_loss_missing's loop (utils.cpp:185-206)
+            keep = M.x > 0
+            cols = np.repeat(np.arange(M.cols, dtype=np.int64), np.diff(M.p))[keep]
+            rows = M.i[keep].astype(np.int64)
+            if rows.shape[0] == 0:
+                return 0.0
+            vals = np.asarray(A.to_scipy().tocsr()[rows, cols]).ravel().astype(np.float64)
+            counts = np.bincount(cols, minlength=M.cols)
+            p = np.zeros(M.cols + 1, np.int64)
+            np.cumsum(counts, out=p[1:])
+            E = CSC(A.shape, p.astype(np.int32), rows.astype(np.int32), vals)
+            return _abi.evaluate_mse_double(E.p, E.i, E.x, E.rows, E.cols, k, np.ascontiguousarray(model.w), model.d,
+                                            np.ascontiguousarray(model.h.T), mask_zeros=True)
+    if mask not in (None, "zeros"):
+        raise ValueError("'mask' must be NULL, 'zeros', or a matrix")
     return _abi.evaluate_mse_double(A.p, A.i, A.x, A.rows, A.cols, k, np.ascontiguousarray(model.w),
                                     model.d, np.ascontiguousarray(model.h.T), mask_zeros=(mask == "zeros"))

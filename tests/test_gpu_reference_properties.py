@@ -117,6 +117,16 @@ def test_evaluate_suite():
     assert nz >= 0 and abs(nz - np.mean((D[D != 0] - R[D != 0]) ** 2)) <= 1e-9 * max(nz, 1e-12)
     bad = N.nmf(A, 3, seed=1, maxit=1, precision="fp64")
     assert N.evaluate(mod, A) <= N.evaluate(bad, A)
+    # :56-69 explicit mask + missing_only: the mean over the marked entries, zeros of the data included; :71-78 missing_only needs a mask;
+    # a mask matrix WITHOUT missing_only changes nothing in the reference (Rcpp_evaluate_loss never reads it) nor here
+    Mk = sp.random(50, 30, density=0.1, format="csc", random_state=rs)
+    Mk.data[:] = 1.0
+    got = N.evaluate(mod, A, mask=Mk, missing_only=True)
+    mr, mc = Mk.nonzero()
+    assert got >= 0 and abs(got - np.mean((D[mr, mc] - R[mr, mc]) ** 2)) <= 1e-9 * max(got, 1e-12)
+    assert N.evaluate(mod, A, mask=Mk) == full
+    with pytest.raises(ValueError, match="a mask matrix must be specified"):
+        N.evaluate(mod, A, missing_only=True)
     assert abs(full * D.size - mod.misc["loss"]) <= 1e-6 * mod.misc["loss"] or mod.misc["iter"] < 50      # misc$loss is the SUM at the last iteration
 
 
