@@ -403,3 +403,12 @@ def evaluate(model, data, mask=None, missing_only=False):
         raise ValueError("'mask' must be NULL, 'zeros', or a matrix")
     return _abi.evaluate_mse_double(A.p, A.i, A.x, A.rows, A.cols, k, np.ascontiguousarray(model.w),
                                     model.d, np.ascontiguousarray(model.h.T), mask_zeros=(mask == "zeros"))
+
+
+def mse(w, d=None, h=None, data=None, mask=None, missing_only=False):
+    """R/nmf_methods.R:488-492: evaluate() of the model (w, d, h) given as separate arrays; d defaults to ones."""
+    if h is None or data is None:
+        raise ValueError("'h' and 'data' are required")
+    h = np.asarray(h, np.float64)
+    d = np.ones(h.shape[0]) if d is None else np.asarray(d, np.float64)
+    return evaluate(NMFModel(w=np.asarray(w, np.float64), d=d, h=h, misc={}), data, mask=mask, missing_only=missing_only)

@@ -127,6 +127,9 @@ def test_evaluate_suite():
     assert N.evaluate(mod, A, mask=Mk) == full
     with pytest.raises(ValueError, match="a mask matrix must be specified"):
         N.evaluate(mod, A, missing_only=True)
+    # :80-105 the mse() wrapper: (w, d, h) given separately equals evaluate(); without d the scale travels in w
+    assert N.mse(mod.w, mod.d, mod.h, A) == full
+    assert abs(N.mse(mod.w * mod.d, h=mod.h, data=A) - full) <= 1e-12 * full
     assert abs(full * D.size - mod.misc["loss"]) <= 1e-6 * mod.misc["loss"] or mod.misc["iter"] < 50      # misc$loss is the SUM at the last iteration
 
 
