@@ -1,8 +1,8 @@
 // ops_setup.hip -- one-time setup of a fit on the device: CSC transpose (A^T for the W half-update, reference
 // nmf/fit_cpu.hpp:251-253 `At = A.transpose()`) and precision casts of the host's double buffers.
 //
-// The transpose is a STABLE counting sort of the nonzero positions by row index (own kernels, no library sort): the columns
-// are cut into B chunks; chunk b counts its nonzeros per row in LDS (transpose_count_kernel), a prefix over the chunks turns the
+// The transpose is a STABLE sort of the nonzero positions by row index (own kernels, no library sort).  Up to 32 768 rows a counting
+// sort with one LDS counter per row: the columns are cut into B chunks; chunk b counts its nonzeros per row in LDS (transpose_count_kernel), a prefix over the chunks turns the
 // B x rows table into "where chunk b's first nonzero of row r goes" (transpose_prefix_kernel + the row-pointer scan), and
 // chunk b then walks its columns IN ORDER, handing out positions from LDS counters (transpose_scatter_kernel).  Positions of
 // one row stay in increasing order, i.e. column indices of A^T come out sorted exactly as Eigen's transpose produces them.
@@ -37,18 +37,12 @@ __global__ __launch_bounds__(256) void transpose_count_kernel(const int* __restr
     __syncthreads();
     const int c0 = bnd[0], c1 = bnd[1];
     const int e0 = p[c0], e1 = p[c1];
-    for (int r0 = 0; r0 < rows; r0 += TR_RCH) {
-        const int rc = rows - r0 < TR_RCH ? rows - r0 : TR_RCH;
-        for (int i = threadIdx.x; i < rc; i += 256) tr_lc[i] = 0;
-        __syncthreads();
-        for (int e = e0 + (int)threadIdx.x; e < e1; e += 256) {
-            const unsigned r = (unsigned)(ri[e] - r0);
-            if (r < (unsigned)rc) atomicAdd(&tr_lc[r], 1);
-        }
-        __syncthreads();
-        for (int i = threadIdx.x; i < rc; i += 256) cnt[(size_t)b * rows + r0 + i] = tr_lc[i];
-        __syncthreads();
-    }
+    // rows <= TR_RCH here (taller inputs take the radix passes below): one LDS counter per row
+    for (int i = threadIdx.x; i < rows; i += 256) tr_lc[i] = 0;
+    __syncthreads();
+    for (int e = e0 + (int)threadIdx.x; e < e1; e += 256) atomicAdd(&tr_lc[ri[e]], 1);
+    __syncthreads();
+    for (int i = threadIdx.x; i < rows; i += 256) cnt[(size_t)b * rows + i] = tr_lc[i];
 }
 // cnt[b][r] <- sum of cnt[b'][r] over b' < b; rowcnt[r] <- the row's total (rowcnt[rows] = 0 feeds the pointer scan)
 __global__ void transpose_prefix_kernel(int* __restrict__ cnt, int rows, int B, int* __restrict__ rowcnt) {
@@ -74,18 +68,12 @@ __global__ __launch_bounds__(256) void transpose_scatter_kernel(const int* __res
     if (threadIdx.x < 2) bnd[threadIdx.x] = tr_bound(p, cols, b + (int)threadIdx.x, (int)gridDim.x);
     __syncthreads();
     const int c0 = bnd[0], c1 = bnd[1];
-    for (int r0 = 0; r0 < rows; r0 += TR_RCH) {
-        const int rc = rows - r0 < TR_RCH ? rows - r0 : TR_RCH;
-        for (int i = threadIdx.x; i < rc; i += 256) tr_lc[i] = tp[r0 + i] + cnt[(size_t)b * rows + r0 + i];
+    for (int i = threadIdx.x; i < rows; i += 256) tr_lc[i] = tp[i] + cnt[(size_t)b * rows + i];      // rows <= TR_RCH
+    __syncthreads();
+    for (int j = c0; j < c1; ++j) {
+        const int e1 = p[j + 1];
+        for (int e = p[j] + (int)threadIdx.x; e < e1; e += 256) pos_out[atomicAdd(&tr_lc[ri[e]], 1)] = e;
         __syncthreads();
-        for (int j = c0; j < c1; ++j) {
-            const int e1 = p[j + 1];
-            for (int e = p[j] + (int)threadIdx.x; e < e1; e += 256) {
-                const unsigned r = (unsigned)(ri[e] - r0);
-                if (r < (unsigned)rc) pos_out[atomicAdd(&tr_lc[r], 1)] = e;
-            }
-            __syncthreads();
-        }
     }
 }
 // ---------------------------------------------------------------------------
