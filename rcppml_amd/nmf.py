@@ -66,13 +66,47 @@ def select_solver(solver, k, L1, loss="mse", use_gpu=True):
     return "cholesky" if (k < 32 and all(v == 0 for v in L1)) else "cd"
 
 
+class CVTable(list):
+    """The reference's `nmfCrossValidate` data.frame (R/nmf_thin.R:1074-1090): a list of rows {rep, k, train_mse, test_mse, best_iter,
+    total_iter, mean_theta}; `col(name)` returns one column."""
+
+    def col(self, name):
+        return [r[name] for r in self]
+
+
+def _cv_across_ranks(data, ranks, seed, cv_seed, test_fraction, kw):
+    """R/nmf_thin.R:803-812, :1034-1090: test_fraction defaults to 0.1, the replicates' CV seeds default to the fit's seed, and every
+    (replicate, rank) fit starts from the reference's own initialize_factors stream SplitMix64((cv_seed + rank) mod INT_MAX) -- one
+    stream fills W_T and continues into H (nmf/nmf_init.hpp:166-182) -- with the replicate's holdout pattern."""
+    from .data import init_factors
+    if isinstance(seed, (list, tuple)) or (seed is not None and np.ndim(seed) == 2):
+        raise ValueError("Multiple initializations are not compatible with cross-validation. Use a single seed or matrix.")
+    if not test_fraction:
+        test_fraction = 0.1
+    A = _as_csc(data)
+    m, n = A.shape
+    seed_int = int(np.random.SeedSequence().generate_state(1)[0] % (2 ** 31 - 1)) + 1 if seed is None else int(np.atleast_1d(seed)[0])
+    cv_seeds = [seed_int] if cv_seed is None else [int(v) for v in np.atleast_1d(cv_seed)]
+    rows = CVTable()
+    for rep, cs in enumerate(cv_seeds, start=1):
+        for rank in ranks:
+            init_seed = int((cs + rank) % (2 ** 31 - 1))
+            W0, H0 = init_factors(init_seed, rank, m, n, np.float64)
+            mod = nmf(data, rank, seed=W0, h_init=H0.T, test_fraction=test_fraction, cv_seed=cs, **kw)
+            th = mod.misc.get("theta")
+            rows.append(dict(rep=rep, k=rank, train_mse=mod.misc["loss"], test_mse=mod.misc.get("best_test_loss", mod.misc["test_loss"]),
+                             best_iter=int(mod.misc.get("best_iter", 0)) + 1, total_iter=mod.misc["iter"],
+                             mean_theta=float(np.mean(th)) if th is not None else float("nan")))
+    return rows
+
+
 def nmf(data, k, tol=1e-4, maxit=100, L1=(0.0, 0.0), L2=(0.0, 0.0), seed=None, mask=None, loss="mse",
         nonneg=(True, True), test_fraction=0, verbose=False, projective=False, symmetric=False, zi="none",
         robust=False, *, solver="auto", upper_bound=(0.0, 0.0), cd_maxit=100, cd_tol=1e-8, norm="L1", sort_model=True,
         patience=5, h_init=None, precision="fp32", resource="gpu", dispersion="per_row", irls_max_iter=5, irls_tol=1e-4,
         nb_size_init=10.0, nb_size_max=1e6, nb_size_min=0.01, tweedie_power=1.5, L21=(0.0, 0.0), angular=(0.0, 0.0),
         graph_W=None, graph_H=None, graph_lambda=(0.0, 0.0), target_H=None, target_lambda=0.0, theta_init=0.1, theta_max=5.0,
-        theta_min=0.0):
+        theta_min=0.0, cv_seed=None):
     """Non-negative matrix factorisation A ~ w diag(d) h by alternating NNLS on the MI355X.
 
     `L1`, `L2`, `upper_bound`, `nonneg` are c(w, h) pairs (src/RcppFunctions_nmf.cpp:59-62).
@@ -85,7 +119,41 @@ def nmf(data, k, tol=1e-4, maxit=100, L1=(0.0, 0.0), L2=(0.0, 0.0), seed=None, m
     `test_fraction` > 0 with loss in {gp, nb, gamma, inverse_gaussian, tweedie} or `robust`: the CV fit with per-column weighted
     Grams over the training entries (nmf/fit_cv.hpp:446-456, :670-689).
     `target_H` (k x n) with `target_lambda` (a scalar is the H side, as R/nmf_thin.R:646-648; > 0 enrichment, < 0 PROJ_ADV).
+    `k` a vector: cross-validation across ranks (R/nmf_thin.R:803-812, :1034-1090) -- returns a CVTable (the reference's
+    nmfCrossValidate data.frame: one row per replicate and rank); `cv_seed`: the holdout pattern's seed(s), default the fit's seed.
+    `seed` a vector of integers or a list of W matrices: one fit per initialisation, the one with the lowest loss is returned
+    (R/nmf_thin.R:744-786, :828-917; misc$all_init_losses / best_init_idx).
     """
+    # ---- several ranks: cross-validation table (R/nmf_thin.R:803-812, 1034-1090)
+    if np.ndim(k) == 1 and len(k) > 1:
+        kw = dict(locals())
+        for drop in ("data", "k", "seed", "cv_seed", "test_fraction", "h_init"):
+            kw.pop(drop)
+        return _cv_across_ranks(data, [int(v) for v in k], seed, cv_seed, test_fraction, kw)
+    if np.ndim(k) == 1:
+        k = int(k[0])
+    # ---- several initialisations: best of (R/nmf_thin.R:744-786, 828-917)
+    multi = None
+    if isinstance(seed, (list, tuple)) and len(seed) > 0 and all(np.ndim(v) == 2 for v in seed):
+        multi = list(seed)
+    elif seed is not None and np.ndim(seed) == 1 and len(seed) > 1:
+        multi = [int(v) for v in seed]
+    elif seed is not None and np.ndim(seed) == 1:
+        seed = int(seed[0])
+    if multi is not None and len(multi) > 1:
+        if test_fraction and test_fraction > 0:
+            raise ValueError("Multiple initializations are not compatible with cross-validation. Use a single seed or matrix.")
+        kw = dict(locals())
+        for drop in ("data", "k", "seed", "multi"):
+            kw.pop(drop)
+        fits = [nmf(data, k, seed=sd, **kw) for sd in multi]
+        losses = [f.misc["loss"] for f in fits]
+        best = int(np.argmin(losses))
+        fits[best].misc["all_init_losses"] = np.asarray(losses)
+        fits[best].misc["best_init_idx"] = best
+        return fits[best]
+    if multi is not None:
+        seed = multi[0]
     if loss not in _LOSSES:
         raise ValueError("'arg' should be one of %s" % ", ".join(repr(x) for x in _LOSSES))
     if zi != "none":
@@ -207,6 +275,9 @@ def nmf(data, k, tol=1e-4, maxit=100, L1=(0.0, 0.0), L2=(0.0, 0.0), seed=None, m
         elif s.shape == (k, m):
             W0 = s.T.copy()
         else:
+            actual_k = s.shape[1] if s.shape[0] == m else (s.shape[0] if s.shape[1] == m else None)
+            if actual_k is not None and actual_k != k:                   # R/nmf_thin.R:760-763
+                raise ValueError("Rank mismatch: k=%d specified but custom initialization has rank %d." % (k, actual_k))
             raise ValueError("Custom init matrix dimensions incompatible with data")
         seed_int = int(abs(int(np.sum(s * 1e6) % (2 ** 31 - 1))))
     else:
@@ -256,7 +327,7 @@ def nmf(data, k, tol=1e-4, maxit=100, L1=(0.0, 0.0), L2=(0.0, 0.0), seed=None, m
             cv_kw["mask"] = mask_arg
         res = _abi.nmf_cv(A.p, A.i, A.x, m, n, k, W_T, H, entry="irls_ex" if irls_cv else "ex", **cv_kw, max_iter=int(maxit), tol=float(tol), L1_H=L1h, L1_W=L1w,
                           L2_H=L2h, L2_W=L2w, cd_maxit=int(cd_maxit), verbose=int(verbose), seed=seed_int & 0x7FFFFFFF,
-                          holdout_fraction=float(test_fraction), cv_seed=seed_int & 0x7FFFFFFF,
+                          holdout_fraction=float(test_fraction), cv_seed=(int(cv_seed) if cv_seed is not None else seed_int) & 0x7FFFFFFF,
                           mask_zeros=int(isinstance(mask, str) and mask == "zeros"), nonneg_W=int(nnw), nonneg_H=int(nnh),
                           norm_type=norm_type, solver_mode=0 if solver == "cd" else 1, sort_model=int(sort_model),
                           precision=_abi.F32 if precision == "fp32" else _abi.F64, cv_patience=int(patience), **graph_args)
@@ -265,8 +336,8 @@ def nmf(data, k, tol=1e-4, maxit=100, L1=(0.0, 0.0), L2=(0.0, 0.0), seed=None, m
         misc = dict(iter=res["iter"], converged=res["converged"], loss=res["train_loss"], test_loss=res["test_loss"],
                     best_test_loss=res["best_test_loss"], best_iter=res["best_iter"], loss_history=res.get("train_history"),
                     test_loss_history=res.get("test_history"), solver=solver, solver_mode=0 if solver == "cd" else 1,
-                    L1=(L1w, L1h), L2=(L2w, L2h), seed=seed_int, precision=precision, resource="gpu", loss_type=loss,
-                    test_fraction=float(test_fraction))
+                    L1=(L1w, L1h), L2=(L2w, L2h), seed=seed_int, cv_seed=(int(cv_seed) if cv_seed is not None else seed_int) & 0x7FFFFFFF,
+                    precision=precision, resource="gpu", loss_type=loss, test_fraction=float(test_fraction))
         if irls_cv and loss == "gp":
             misc["theta"] = res.get("theta")
         return NMFModel(w=W_T.copy(), d=res["d"], h=H.T.copy(), misc=misc)

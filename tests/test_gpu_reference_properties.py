@@ -498,3 +498,43 @@ def test_cv_distributions_suite():
             for mask in (None, "zeros"):
                 mod = N.nmf(data, 3, loss=loss, test_fraction=0.1, mask=mask, maxit=8, seed=42, precision="fp64")
                 assert np.isfinite(mod.misc["test_loss"]) and np.isfinite(mod.misc["loss"]) and mod.w.min() >= 0 and mod.h.min() >= 0, (loss, mask)
+
+
+def test_parameters_suite_ranks_and_initialisations():
+    """test_parameters.R:28-37 and test_gpu_cv.R:145-162 / test_gpu_features.R:17-42 (k a vector: a cross-validation table with one finite,
+    positive test loss per rank; test_fraction defaults to 0.1), :212-234 (cv_seed fixes the holdout pattern: the same seed reproduces
+    the table, another changes it; a vector of cv_seeds gives replicates), :138-156 (an integer seed reproduces, a matrix seed is used
+    as W_init), :554-602 (several seeds / several W matrices: one fit each, the best loss wins; rank mismatch and CV are rejected with the
+    reference's messages).  Every row of the table also equals the oracle's nmf_fit_cv from the reference's own start for that row --
+    SplitMix64((cv_seed + rank) mod INT_MAX) filling W_T then H (R/nmf_thin.R:1046, nmf/nmf_init.hpp:166-182)."""
+    from rcppml_amd import nmf as N, data
+    A, _, _ = simulate(100, 80, 4, noise=0.1, dropout=0.4, seed=17)
+    m, n = A.shape
+    tab = N.nmf(A, [2, 3, 4, 5], test_fraction=0.1, cv_seed=42, maxit=15, tol=1e-10, precision="fp64", solver="cd")
+    assert isinstance(tab, N.CVTable) and tab.col("k") == [2, 3, 4, 5] and all(np.isfinite(v) and v > 0 for v in tab.col("test_mse"))
+    assert N.nmf(A, [2, 3, 4, 5], test_fraction=0.1, cv_seed=42, maxit=15, tol=1e-10, precision="fp64", solver="cd").col("test_mse") == tab.col("test_mse")
+    other = N.nmf(A, [2, 3], cv_seed=43, maxit=15, tol=1e-10, precision="fp64", solver="cd")          # test_fraction -> 0.1
+    assert other.col("test_mse") != tab.col("test_mse")[:2]
+    reps = N.nmf(A, [2, 3], cv_seed=[456, 457], maxit=10, precision="fp64", solver="cd")
+    assert reps.col("rep") == [1, 1, 2, 2] and len(set(reps.col("test_mse"))) == 4
+    for row in tab:
+        W0, H0 = data.init_factors((42 + row["k"]) % (2 ** 31 - 1), row["k"], m, n, np.float64)
+        ref = O.nmf_fit_cv(csc_o(A), W0, H0, np.float64, max_iter=15, tol=1e-10, holdout_fraction=0.1, cv_seed=42, solver_mode=0)
+        assert row["total_iter"] == ref.iter and row["best_iter"] == ref.best_iter + 1, row
+        assert abs(row["test_mse"] - ref.best_test_loss) <= 1e-6 * abs(ref.best_test_loss) and abs(row["train_mse"] - ref.train_loss) <= 1e-6 * abs(ref.train_loss), row
+    # several initialisations
+    single = [N.nmf(A, 3, seed=s, maxit=20, precision="fp64") for s in (1, 2, 3)]
+    best = N.nmf(A, 3, seed=[1, 2, 3], maxit=20, precision="fp64")
+    losses = [f.misc["loss"] for f in single]
+    assert best.misc["loss"] == min(losses) and best.misc["best_init_idx"] == int(np.argmin(losses)) and np.array_equal(best.misc["all_init_losses"], losses)
+    assert np.array_equal(best.w, single[int(np.argmin(losses))].w)
+    rs = np.random.default_rng(3)
+    mats = [rs.uniform(size=(m, 3)) for _ in range(3)]
+    bm = N.nmf(A, 3, seed=mats, maxit=10, precision="fp64")
+    assert bm.misc["loss"] == min(N.nmf(A, 3, seed=w0, maxit=10, precision="fp64").misc["loss"] for w0 in mats)
+    with pytest.raises(ValueError, match="Rank mismatch: k=4 specified but custom initialization has rank 3"):
+        N.nmf(A, 4, seed=mats[0], maxit=2)
+    with pytest.raises(ValueError, match="Multiple initializations are not compatible with cross-validation"):
+        N.nmf(A, 3, seed=[1, 2], test_fraction=0.1, maxit=2)
+    with pytest.raises(ValueError, match="Multiple initializations are not compatible with cross-validation"):
+        N.nmf(A, [2, 3], seed=mats, maxit=2)

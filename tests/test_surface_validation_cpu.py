@@ -54,3 +54,15 @@ def test_solver_guards():
     for loss in ("mse", "gamma", "inverse_gaussian", "tweedie", "gp"):
         with pytest.raises(NotImplementedError, match="zero-inflated"):
             N.nmf(A_sparse, 2, loss=loss, zi="row")
+
+
+def test_initialisation_guards():
+    """test_parameters.R:581-620: a custom W_init of the wrong rank and several initialisations under cross-validation are rejected with the
+    reference's messages (R/nmf_thin.R:748-751, :829-832) -- before the backend is touched."""
+    W3 = np.abs(np.random.default_rng(2).standard_normal((50, 3)))
+    with pytest.raises(ValueError, match="Rank mismatch: k=4 specified but custom initialization has rank 3"):
+        N.nmf(A_dense, 4, seed=W3)
+    with pytest.raises(ValueError, match="Multiple initializations are not compatible with cross-validation"):
+        N.nmf(A_dense, 3, seed=[1, 2, 3], test_fraction=0.1)
+    with pytest.raises(ValueError, match="Multiple initializations are not compatible with cross-validation"):
+        N.nmf(A_dense, [2, 3], seed=[W3, W3])
