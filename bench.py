@@ -37,7 +37,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--config", choices=["c2", "c3", "c4", "c5"], default="c2",
+    ap.add_argument("--config", choices=["c1", "c2", "c3", "c4", "c5"], default="c2",
                     help="BASELINE.json configs[1] (20000 x 100000 per GPU, 1 %%, k = 64: the headline) or configs[3] "
                          "(pbmc3k-shaped 30000 x 162500 per GPU = 1.3 M columns over 8 GPUs, 3 %%, k = 128)")
     ap.add_argument("--rows", type=int, default=None)
@@ -70,7 +70,9 @@ def parse():
     args = ap.parse_args()
     # c3: the movielens fixture (tests/golden/movielens.npz, extracted from the reference's data/movielens.rda), k = 32,
     # L1 = c(0, 0.1), mask = "zeros" (a fit-time no-op in the reference); c5: NB counts, IRLS half-updates
-    preset = {"c2": (20000, 100000, 0.01, 64), "c4": (30000, 162500, 0.03, 128), "c3": (3867, 610, 0.0319, 32),
+    # c1: the hawaiibirds fixture (tests/golden/hawaiibirds.npz, extracted from the reference's data/hawaiibirds.rda), k = 10: the whole fit
+    # as ONE persistent kernel (rcppml_hip_als_small_fit)
+    preset = {"c1": (183, 1183, 0.142, 10), "c2": (20000, 100000, 0.01, 64), "c4": (30000, 162500, 0.03, 128), "c3": (3867, 610, 0.0319, 32),
               "c5": (10000, 200000, 0.02, 32)}[args.config]
     args.rows = args.rows or preset[0]
     args.cols = args.cols or preset[1]
@@ -191,6 +193,10 @@ def main():
         if world != 1:
             raise SystemExit("--config c5 is benchmarked on one GPU (BASELINE configs[4])")
         return bench_c5(args)
+    if args.config == "c1":
+        if world != 1:
+            raise SystemExit("--config c1 (hawaiibirds) is a one-GPU workload")
+        return bench_c1(args)
     # functional smoke of the N > 1 loop on a one-GPU box: RCPPML_BENCH_BACKEND=gloo RCPPML_BENCH_SHARE_GPU=1 maps every
     # rank onto cuda:0 (RCCL refuses two ranks per device); never used for reported numbers
     backend = os.environ.get("RCPPML_BENCH_BACKEND", "nccl")
@@ -339,6 +345,30 @@ def main():
             if not torch.equal(final_loss_t, st.loss_out):
                 raise RuntimeError("bench: graph replay and eager pass disagree on the loss")
         loss = final_loss_t
+        # ---- the reference's own protocol (tools/gpu_bench_final.R:15-33: nmf(..., maxit = 20, tol = 0), timed from iteration 0): the
+        # SAME number of iterations from the SplitMix64(seed) start, device-resident, loss formed every iteration.  Iterations 0 and 1
+        # differ from the steady state (no warm start / no work order yet; warm-started CD needs fewer sweeps late in a fit than
+        # early), so this is an eager loop -- the steady-state `ms_per_step` above is the contract's timed region, this figure is
+        # what a fit from scratch pays per iteration.
+        fit_from_start = None
+        if world == 1 and not force_dist:
+            snap_end = snapshot()                          # (everything below the timed region reads the state it left behind)
+            for o in ops._order.values():
+                o["valid"], o["fresh"] = False, False       # no sweep counts yet: iteration 0 and 1 run in natural column order
+            st.set_factors(W_T=W0, H=H0, d=np.ones(k, nd), iteration=0)
+            ops.sync()
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            for _ in range(args.steps):
+                st.step()
+            torch.cuda.synchronize()
+            dt2 = time.perf_counter() - t2
+            fit_from_start = {"iterations": args.steps, "ms_per_step": dt2 / args.steps * 1e3, "value": args.steps * (m + n_total) / dt2,
+                              "unit": "cols/s", "launch": "eager", "final_loss": float(st.loss_out[0].item()),
+                              "what": "iterations 0 .. %d from the SplitMix64(%d) start (tol = 0, loss every iteration, inputs resident in HBM, "
+                                      "no host read inside the loop): the reference's bench protocol, tools/gpu_bench_final.R:15-33" % (args.steps - 1, args.seed)}
+            restore(snap_end)
+            torch.cuda.synchronize()
     tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -490,6 +520,7 @@ def main():
             "fused_tail": bool(ops.fused_tail),
             "eager_ms_per_step": eager_ms_per_step,
             "final_loss": final_loss,
+            "fit_from_start": fit_from_start,
             "world_size_seen": world,
             "backend": (dist.get_backend() if (world > 1 or force_dist) else None),
             "forced_one_rank_group": force_dist,
@@ -554,6 +585,175 @@ def main():
     if world > 1 or force_dist:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def bench_c1(args):
+    """BASELINE configs[0]: data(hawaiibirds) (183 x 1183, 30 815 nonzeros), k = 10, MSE, fp32.  The whole fit is ONE persistent kernel on
+    one XCD (rcppml_amd/csrc/kernels_small.hip.h): a "step" is one ALS iteration inside it -- the warm-up launch runs W iterations from
+    the SplitMix64 start, the timed launch the next K (iter0 = W: warm starts, no iteration-0 quirk), each bracketed by a device
+    synchronise.  Beside it: the same K iterations from the start (`fit_from_start`, the reference's protocol), the multi-launch loop
+    on the same input (`multi_launch`), the plugin call end to end with the one-kernel path on and off, and the CPU oracle's whole
+    fit at several thread counts (`cpu_baseline` = the best of them; 256 OpenMP threads on 1 366 columns is not it)."""
+    import torch
+    from rcppml_amd import _abi, als, data
+    from oracle import oracle as O
+    fx = np.load(os.path.join(ROOT, "tests", "golden", "hawaiibirds.npz"))
+    A = data.CSC(tuple(int(v) for v in fx["shape"]), fx["p"], fx["i"], fx["x"])
+    At = A.transpose()
+    m, n = A.shape
+    k = args.k
+    nd = np.float32 if args.dtype == "f32" else np.float64
+    sv = 4 if args.dtype == "f32" else 8
+    solver = 0 if args.solver == "cd" else 1
+    W0, H0 = data.init_factors(args.seed, k, m, n, nd)
+    if not _abi.small_eligible(m, n, A.nnz, k):
+        raise SystemExit("--config c1: the one-kernel fit does not take this size")
+    ops = als.HipOps(0, args.dtype)
+    a, at = ops.upload_csc(A), ops.upload_csc(At)
+    tr = ops.sumsq(a["x"])
+    W, H, d = ops.to_device(W0), ops.to_device(H0), ops.zeros((k,)) + 1
+    res = torch.zeros(8, dtype=torch.float64, device="cuda")
+    hist = torch.zeros(max(args.warmup, args.steps, 1), dtype=torch.float64, device="cuda")
+
+    def launch(iters, iter0):
+        ops.ctx.als_small_fit(ops.dt, a, at, m, n, k, W, H, d, tr, solver_mode=solver, cd_maxit=args.cd_maxit, cd_tol=1e-8, max_iter=iters, tol=0.0,
+                              iter0=iter0, loss_history=hist, result8=res)
+
+    def reset():
+        W.copy_(ops.to_device(W0)); H.copy_(ops.to_device(H0)); d.fill_(1)
+
+    def timed(iters, iter0):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        launch(iters, iter0)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+
+    launch(max(args.warmup, 1), 0)                      # warm-up iterations (untimed)
+    torch.cuda.synchronize()
+    if float(res[4].item()) != 1.0:
+        raise SystemExit("--config c1: the one-kernel fit gave up at its barrier (result %s)" % res.cpu().numpy())
+    dt = timed(args.steps, max(args.warmup, 1))         # the timed region: exactly K iterations
+    final_loss = float(res[2].item())
+    state = (W.clone(), H.clone(), d.clone())
+    reps = []
+    for _ in range(15):                                 # the same region again (fresh start + warm-up each time): spread of a 0.5 ms measurement
+        reset(); launch(max(args.warmup, 1), 0)
+        reps.append(timed(args.steps, max(args.warmup, 1)) / args.steps * 1e3)
+    starts = []
+    for _ in range(15):
+        reset()
+        starts.append(timed(args.steps, 0) / args.steps * 1e3)
+    from_start_loss = float(res[2].item())
+    # ---- the multi-launch loop on the same input (graph replays of one captured iteration: how every larger fit runs)
+    multi = None
+    try:
+        side = torch.cuda.Stream(device=0)
+        with torch.cuda.stream(side):
+            ops2 = als.HipOps(0, args.dtype)
+            cfg = als.AlsConfig(k=k, max_iter=args.warmup + args.steps, tol=0.0, cd_maxit=args.cd_maxit, solver_mode=solver)
+            st = als.ShardedALS(ops2, als.Comm(None), A, At, W0, H0, cfg)
+            for _ in range(max(args.warmup, 2)):
+                st.step()
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            snapW, snapH, snapd, it0 = st.W_T.clone(), st.H.clone(), st.d.clone(), st.iter
+            with torch.cuda.graph(g, stream=side):
+                st.step()
+            st.set_factors(W_T=snapW, H=snapH, d=snapd, iteration=it0)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                g.replay()
+            torch.cuda.synchronize()
+            multi = {"ms_per_step": (time.perf_counter() - t0) / args.steps * 1e3, "launch": "hipGraph replay of the 15-launch iteration",
+                     "final_loss": float(st.loss_out[0].item())}
+    except Exception as e:
+        multi = {"error": repr(e)}
+    # ---- the plugin call end to end (upload, transpose, fit, download), one-kernel path on / off
+    plug = {}
+    for name, env in (("one_kernel", None), ("multi_launch", "1")):
+        old = os.environ.get("RCPPML_GPU_NO_SMALL")
+        if env is None:
+            os.environ.pop("RCPPML_GPU_NO_SMALL", None)
+        else:
+            os.environ["RCPPML_GPU_NO_SMALL"] = env
+        best = None
+        for _ in range(5):
+            Wp, Hp = W0.astype(np.float64).copy(), H0.astype(np.float64).copy()
+            t0 = time.perf_counter()
+            r = _abi.nmf_unified(A.p, A.i, A.x, m, n, k, Wp, Hp, entry="float" if args.dtype == "f32" else "double", max_iter=100, tol=0.0,
+                                 solver_mode=solver, cd_maxit=args.cd_maxit)
+            el = time.perf_counter() - t0
+            best = el if best is None else min(best, el)
+        plug[name] = {"fit_100_iterations_ms": best * 1e3, "status": r["status"], "loss": r["loss"]}
+        if old is None:
+            os.environ.pop("RCPPML_GPU_NO_SMALL", None)
+        else:
+            os.environ["RCPPML_GPU_NO_SMALL"] = old
+    total_iters = max(args.warmup, 1) + args.steps
+    alg_bytes = 2 * (A.nnz * (4 + sv) + (m + n + 2) * 4) + 4 * k * (m + n) * sv        # both sparse passes + factors read and written
+    line = {
+        "metric": "ALS updates/sec (cols solved/s), k=%d sparse NMF" % k,
+        "value": args.steps * (m + n) / dt, "unit": "cols/s", "n_gpus": 1, "steps": args.steps, "warmup": max(args.warmup, 1),
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": args.dtype, "data": "fixture (tests/golden/hawaiibirds.npz = the reference's data/hawaiibirds.rda)",
+        "config": {"workload": "configs[0]: data(hawaiibirds) %dx%d, nnz %d, k=%d, MSE, %s, L1 row normalisation, loss every iteration; the whole "
+                               "fit = one persistent kernel on one XCD" % (m, n, A.nnz, k, "coordinate-descent NNLS (cd_maxit=%d, cd_tol=1e-8)" % args.cd_maxit
+                                                                           if solver == 0 else "Cholesky + clip"),
+                   "rows": m, "cols_per_gpu": n, "nnz_per_gpu": A.nnz, "k": k, "solver": args.solver, "parallelism": "one GPU, one XCD (32 workgroups)"},
+        "roofline": {"bound": "hbm", "kernel": "als_small_kernel (the whole ALS loop; 4 grid barriers per iteration among 32 workgroups of XCD 0)",
+                     "achieved": alg_bytes / (dt / args.steps) / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": alg_bytes / (dt / args.steps) / 1e9 / 8000.0,
+                     "traffic": None, "algorithmic_bytes_per_launch": alg_bytes * args.steps, "avg_launch_ms": dt * 1e3,
+                     "note": "latency-bound by construction: %.0f KB of algorithmic traffic per iteration, all of it L2-resident; the iteration is four "
+                             "barriers (0.8 us each, profiles/r06_grid_barrier.txt) plus the dependent chains of one column's sparse product and "
+                             "solve per phase" % (alg_bytes / 1e3)},
+        "repeats_ms_per_step": {"median": float(np.median(reps)), "min": float(np.min(reps)), "max": float(np.max(reps)), "n": len(reps)},
+        "fit_from_start": {"iterations": args.steps, "ms_per_step": float(np.median(starts)), "value": (m + n) / (float(np.median(starts)) * 1e-3), "unit": "cols/s",
+                           "launch": "one kernel", "final_loss": from_start_loss, "what": "iterations 0 .. %d from the SplitMix64(%d) start, tol = 0, loss every "
+                           "iteration, one launch + one synchronise (median of %d)" % (args.steps - 1, args.seed, len(starts))},
+        "multi_launch": multi, "plugin_pcie_inclusive": plug,
+        "phases_ms_per_step": {}, "launch": "one persistent kernel for all %d iterations" % args.steps, "final_loss": final_loss, "world_size_seen": 1,
+    }
+    if multi and "ms_per_step" in multi:
+        line["speedup_vs_multi_launch"] = multi["ms_per_step"] / line["ms_per_step"]
+    W.copy_(state[0]); H.copy_(state[1]); d.copy_(state[2])
+    if not args.no_cpu_ref:
+        try:
+            ref = O.nmf_fit(_to_oracle(A), W0.astype(np.float64), H0.astype(np.float64), np.float64, max_iter=total_iters, tol=0.0, cd_maxit=args.cd_maxit,
+                            cd_tol=1e-8, solver_mode=solver, threads=1)
+            line["cpu_ref"] = {"loss": ref.loss, "iterations": int(ref.iter), "dtype": "f64", "threads": 1,
+                               "what": "oracle nmf_fit (restatement of nmf/fit_cpu.hpp), fp64, same CSC and starting factors, same iteration count"}
+            line["loss_rel_dev_vs_cpu_ref"] = abs(final_loss - ref.loss) / abs(ref.loss)
+        except Exception as e:
+            line["cpu_ref"] = {"error": repr(e)}
+    if not args.no_cpu_baseline:
+        try:
+            O.build(native=True)
+            native = True
+        except Exception:
+            native = False
+        try:
+            per = {}
+            for th in (1, 2, 4, 8, 16, 32, 0):
+                best = None
+                for _ in range(3 if th else 1):
+                    t0 = time.perf_counter()
+                    O.nmf_fit(_to_oracle(A), W0, H0, nd, max_iter=args.steps, tol=0.0, cd_maxit=args.cd_maxit, cd_tol=1e-8, solver_mode=solver,
+                              threads=th, native=native)
+                    el = time.perf_counter() - t0
+                    best = el if best is None else min(best, el)
+                per[str(th) if th else "all(%d)" % O.num_threads()] = best / args.steps * 1e3
+            bname = min(per, key=per.get)
+            line["cpu_baseline"] = {"value": (m + n) / (per[bname] * 1e-3), "unit": "cols/s", "cores": bname, "kind": "port",
+                                    "sample": "the oracle's whole nmf_fit (fused RHS + solve, scaling, loss) on the same input, %d iterations from the same "
+                                              "start, best of the thread counts tried; ms per iteration by thread count: %s" % (
+                                                  args.steps, {kk: round(v, 4) for kk, v in per.items()}), "dtype": args.dtype}
+            line["speedup_vs_cpu_baseline"] = line["fit_from_start"]["value"] / line["cpu_baseline"]["value"]
+            line["speedup_vs_cpu_baseline_what"] = "fit_from_start (the same K iterations from the same start as the CPU fit) over the best CPU thread count"
+        except Exception as e:
+            line["cpu_baseline"] = {"value": None, "unit": "cols/s", "cores": os.cpu_count(), "kind": "port", "sample": "failed: %r" % (e,)}
+    print(json.dumps(line))
 
 
 def bench_c5(args):

@@ -58,7 +58,8 @@ RCPPML_GPU_API void rcppml_gpu_detect(int* num_gpus, double* total_mem_mb, doubl
  * Laplacians, upper bounds, nonneg, projective and symmetric NMF (MSE path); CD and Cholesky+clip;
  * env RCPPML_GPU_DEVICES=n shards plain MSE fits over n devices (plugin_multi.hip).  Not implemented
  * -- REJECTED with *out_status = -1 so the caller falls back to CPU rather than silently dropping
- * them: classifier guides, dispersion = per_col, zero-inflated losses, k > 256 (k > 128 for IRLS losses,
+ * them: classifier guides, dispersion = per_col (n values: the bridge's out_theta holds m, gpu/bridge_nmf.hpp:284 --
+ * rcppml_gpu_nmf_ex takes a capacity), zero-inflated losses, k > 256 (k > 128 for IRLS losses,
  * explicit masks, angular and graph penalties).  Target regularisation has no slot in these 73 arguments: see
  * rcppml_gpu_nmf_target below. */
 #define RCPPML_NMF_UNIFIED_ARGS                                                                    \
@@ -184,7 +185,10 @@ RCPPML_GPU_API void rcppml_gpu_nmf_unified_double(RCPPML_NMF_UNIFIED_ARGS);
  * reference bridge does not transmit (gpu/bridge_nmf.hpp:180-346 drops config.mask, cd_tol,
  * sort_model): an explicit mask in CSC (nonzero = masked; nmf/masked_nnls.hpp), cd_tol, sort flag,
  * compute precision (0 = fp32, 1 = fp64) and an optional per-iteration loss history buffer
- * (length >= *max_iter, may be NULL). */
+ * (length >= *max_iter, may be NULL).
+ * out_theta CAPACITY: in this entry and in rcppml_gpu_nmf_target, *out_theta_len is read ON INPUT as the number of doubles
+ * out_theta can hold (<= 0: m, the reference bridge's buffer, gpu/bridge_nmf.hpp:284); on return it is the number written.
+ * dispersion mode 3 (per_col) writes n values and is refused with *out_status = -1 when the capacity is smaller than n. */
 RCPPML_GPU_API void rcppml_gpu_nmf_ex(RCPPML_NMF_UNIFIED_ARGS, const int* mask_p, const int* mask_i,
                                       int* mask_nnz, double* cd_tol, int* sort_model,
                                       int* precision, double* loss_history);
@@ -426,6 +430,26 @@ RCPPML_GPU_API int rcppml_hip_tail_scale_gram(rcppml_hip_ctx* ctx, int dtype, vo
 RCPPML_GPU_API int rcppml_hip_tail_scale_gram_loss(rcppml_hip_ctx* ctx, int dtype, void* W_T, int k, int64_t m, int norm_type, void* sums,
                                                    void* d, const int* sweeps, int* order, double eps, const double* trAtA,
                                                    const void* B_w, const void* G_saved, void* G_wt, double* out);
+
+/* The WHOLE plain sparse MSE fit of a SMALL matrix as one persistent kernel on one XCD (kernels_small.hip.h; round 6): nmf_fit<CPU>
+ * (nmf/fit_cpu.hpp:444-1855) with fused right-hand side + solve per column (primitives/cpu/fused_nnls.hpp:70-134 CD, :185-219
+ * Cholesky + clip), L1 / L2 / upper bounds / non-negativity, row scaling (nmf/variant_helpers.hpp:286-305), Gram-trick loss every
+ * iteration (fit_cpu.hpp:1729-1753) and the convergence rule (:1769-1809) evaluated on the device -- no launch per phase, no host
+ * round trip per iteration.  The iteration's grid-wide dependencies are barriers inside the kernel among 32 workgroups that all
+ * sit on XCD 0 (one L2: a relaxed L2 atomic + an L1 invalidate, 0.8 us; profiles/r06_grid_barrier.txt).
+ * rcppml_hip_als_small_eligible: k <= 32, (m + n) k^2 <= 4e5, nnz <= 2^18 (hawaiibirds; movielens at k = 32 is not).
+ * CSC(A) and CSC(A^T) with sorted rows; W (k x m), H (k x n) in / out, d (k) out; trAtA = sum a^2 (device, rcppml_hip_sumsq);
+ * iter0: iterations already run by earlier calls on these factors (0 = a fit from its start: iteration 0 then solves without the
+ * warm-start correction; > 0 continues a fit -- bench.py's warm-up / timed split); loss_history: max_iter doubles (device, may be NULL); result8 (device): [0] iterations [1] converged [2] train loss [3] last relative
+ * change [4] 1 = done, anything else = the kernel gave up at a barrier (its workgroups did not all land on one XCD): W / H are then
+ * partly overwritten and the caller must restart on the multi-launch ops. */
+RCPPML_GPU_API int rcppml_hip_als_small_eligible(int m, int n, int64_t nnz, int k);
+RCPPML_GPU_API int rcppml_hip_als_small_fit(rcppml_hip_ctx* ctx, int dtype, const int* col_ptr, const int* row_idx, const void* values,
+                                            const int* t_col_ptr, const int* t_row_idx, const void* t_values, int m, int n, int64_t nnz,
+                                            int k, void* W, void* H, void* d, const double* trAtA, double L1_H, double L1_W, double L2_H,
+                                            double L2_W, double ub_H, double ub_W, int nonneg_H, int nonneg_W, int norm_type,
+                                            int solver_mode, int cd_maxit, double cd_tol, int max_iter, double tol, int patience,
+                                            int iter0, double* loss_history, double* result8);
 
 /* Explicit-mask per-column NNLS -- reference nmf/masked_nnls.hpp:96-154 / 177-242.
  * A and mask share shape (rows x ncols, CSC; mask nonzero = masked; mask values not needed). */

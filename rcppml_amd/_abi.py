@@ -31,6 +31,7 @@ EXPORTED_SYMBOLS = [
     "rcppml_hip_rhs_plan_create", "rcppml_hip_rhs_plan_create_indices", "rcppml_hip_rhs_plan_set_values", "rcppml_hip_rhs_plan_destroy", "rcppml_hip_rhs_plan_info", "rcppml_hip_rhs_planned",
     "rcppml_gpu_nmf_target", "rcppml_hip_axpy", "rcppml_hip_add_diag", "rcppml_hip_clip_upper",
     "rcppml_hip_scale_order", "rcppml_hip_gram_loss_mse", "rcppml_hip_tail_scale_gram", "rcppml_hip_tail_scale_gram_loss",
+    "rcppml_hip_als_small_eligible", "rcppml_hip_als_small_fit",
 ]
 
 
@@ -96,6 +97,13 @@ def lib():
     return _lib
 
 
+def small_eligible(m, n, nnz, k):
+    """True when the one-kernel fit (rcppml_hip_als_small_fit) takes a plain sparse MSE fit of this size."""
+    f = lib().rcppml_hip_als_small_eligible
+    f.restype = C.c_int
+    return bool(f(C.c_int(m), C.c_int(n), C.c_int64(nnz), C.c_int(k)))
+
+
 def last_error():
     return lib().rcppml_gpu_last_error().decode("utf-8", "replace")
 
@@ -135,7 +143,7 @@ def nmf_unified(p, i, x, m, n, k, W_T, H, *, entry="float", max_iter=100, tol=1e
                 irls_tol=1e-4, norm_type=0, projective=0, symmetric=0, solver_mode=0, gp_dispersion_mode=2,
                 nb_size=(10.0, 1e6, 0.01), mask=None, cd_tol=1e-8, sort_model=1, precision=F64, want_history=False,
                 graph_W_nnz=0, guide_H_count=0, tweedie_power=1.5, robust_delta=0.0, graph_W=None, graph_H=None,
-                gp_theta=(0.1, 5.0, 0.0), gamma_phi=(1.0, 1e4, 1e-6), target_H=None, target_W=None):
+                gp_theta=(0.1, 5.0, 0.0), gamma_phi=(1.0, 1e4, 1e-6), target_H=None, target_W=None, theta_capacity=None):
     """Call the 73-pointer plugin entry exactly as reference gpu/bridge_nmf.hpp:310-342 does.
 
     p, i: int32 CSC arrays; x: float64 values.  W_T (m, k) and H (n, k) float64 arrays (memory = column-major
@@ -155,8 +163,12 @@ def nmf_unified(p, i, x, m, n, k, W_T, H, *, entry="float", max_iter=100, tol=1e
     dummy_d = np.zeros(2, np.float64)
     # out_theta: m doubles in the reference bridge (gpu/bridge_nmf.hpp:284); the build-defined "ex" entries take max(m, n) so that
     # dispersion = "per_col" (gp_dispersion_mode 3) can return its n values
+    # (theta_capacity: what the caller's buffer holds -- tests hand the "ex" entry the bridge's m doubles)
     theta = np.zeros(max(m, n, 1) if entry == "ex" else max(m, 1), np.float64)
-    out_iter, out_conv, out_status, out_theta_len = C.c_int(0), C.c_int(0), C.c_int(-99), C.c_int(0)
+    if theta_capacity is not None:
+        theta = np.zeros(max(int(theta_capacity), 1), np.float64)
+    # (the build-defined entries read *out_theta_len on input as the capacity of out_theta)
+    out_iter, out_conv, out_status, out_theta_len = C.c_int(0), C.c_int(0), C.c_int(-99), C.c_int((theta.shape[0] if theta_capacity is None else int(theta_capacity)) if entry == "ex" else 0)
     out_loss, out_tol = C.c_double(0), C.c_double(0)
     args = [
         _np_ptr(p), _np_ptr(i), _np_ptr(x), _ci(m), _ci(n), _ci(x.shape[0]), _ci(k),
@@ -507,6 +519,17 @@ class Context:
                                                    _dptr(d), _dptr(sweeps), _dptr(order), C.c_double(eps), _dptr(trAtA), _dptr(B_w),
                                                    _dptr(G_saved), _dptr(G_wt), _dptr(out)), "tail_scale_gram_loss")
 
+    def als_small_fit(self, dt, csc, csc_t, m, n, k, W, H, d, trAtA, *, L1_H=0.0, L1_W=0.0, L2_H=0.0, L2_W=0.0, ub_H=0.0, ub_W=0.0, nonneg_H=1,
+                      nonneg_W=1, norm_type=0, solver_mode=0, cd_maxit=100, cd_tol=1e-8, max_iter=100, tol=1e-4, patience=5, iter0=0, loss_history=None,
+                      result8=None):
+        """The whole plain sparse MSE fit as one persistent kernel (small problems only: small_eligible)."""
+        _chk(lib().rcppml_hip_als_small_fit(self._h, C.c_int(dt), _dptr(csc["p"]), _dptr(csc["i"]), _dptr(csc["x"]), _dptr(csc_t["p"]),
+                                            _dptr(csc_t["i"]), _dptr(csc_t["x"]), C.c_int(m), C.c_int(n), C.c_int64(csc["nnz"]), C.c_int(k),
+                                            _dptr(W), _dptr(H), _dptr(d), _dptr(trAtA), C.c_double(L1_H), C.c_double(L1_W), C.c_double(L2_H),
+                                            C.c_double(L2_W), C.c_double(ub_H), C.c_double(ub_W), C.c_int(nonneg_H), C.c_int(nonneg_W),
+                                            C.c_int(norm_type), C.c_int(solver_mode), C.c_int(cd_maxit), C.c_double(cd_tol), C.c_int(max_iter),
+                                            C.c_double(tol), C.c_int(patience), C.c_int(iter0), _dptr(loss_history), _dptr(result8)), "als_small_fit")
+
     def sumsq(self, dt, x, length, out):
         _chk(lib().rcppml_hip_sumsq(self._h, C.c_int(dt), _dptr(x), C.c_int64(length), _dptr(out)), "sumsq")
 
@@ -684,7 +707,8 @@ def nmf_dense(A, k, W_T, H, *, entry="float", max_iter=100, tol=1e-4, L1_H=0.0, 
     assert W_T.shape == (m, k) and H.shape == (n, k)
     d = np.ones(k, np.float64)
     theta = np.zeros(max(m, n, 1), np.float64)          # gpu/bridge_nmf.hpp:622 theta_buf(max(m, n))
-    out_iter, out_conv, out_status, out_theta_len = C.c_int(0), C.c_int(0), C.c_int(-99), C.c_int(0)
+    # (the build-defined entries read *out_theta_len on input as the capacity of out_theta)
+    out_iter, out_conv, out_status, out_theta_len = C.c_int(0), C.c_int(0), C.c_int(-99), C.c_int((theta.shape[0] if theta_capacity is None else int(theta_capacity)) if entry == "ex" else 0)
     out_loss, out_tol = C.c_double(0), C.c_double(0)
     args = [
         A.ctypes.data_as(C.POINTER(C.c_double)), _ci(m), _ci(n), _ci(k), _np_ptr(W_T), _np_ptr(H), _np_ptr(d), _ci(max_iter), _cd(tol),

@@ -91,6 +91,14 @@ class HipOps:
         return dict(rows=A.rows, cols=A.cols, nnz=A.nnz, p=self.to_device(A.p), i=self.to_device(A.i),
                     x=self.to_device(A.x, self.tdtype))
 
+    def transpose_csc(self, csc):
+        """CSC of the transpose, on the device (stable sort of the nonzeros by row: rows stay sorted inside every column)."""
+        t = self.torch
+        out = dict(rows=csc["cols"], cols=csc["rows"], nnz=csc["nnz"], p=self.empty((csc["rows"] + 1,), t.int32),
+                   i=self.empty((max(csc["nnz"], 1),), t.int32), x=self.empty((max(csc["nnz"], 1),)))
+        self.ctx.transpose_csc(self.dt, csc["rows"], csc["cols"], csc["p"], csc["i"], csc["x"], out["p"], out["i"], out["x"])
+        return out
+
     def _timed(self, name):
         return _EventScope(self, name) if self.record else _NULL
 
@@ -353,7 +361,9 @@ class ShardedALS:
         self.ops, self.comm, self.cfg = ops, comm, cfg
         self.m, self.n_loc, self.k = A_loc.rows, A_loc.cols, cfg.k
         self.A = ops.upload_csc(A_loc)
-        self.At = ops.upload_csc(At_loc)
+        # At_loc = None: A^T is built on the device from the uploaded CSC (rcppml_hip_transpose_csc, the plugin's own set-up
+        # path) -- a host-side transpose of 1e9 nonzeros takes minutes
+        self.At = ops.upload_csc(At_loc) if At_loc is not None else ops.transpose_csc(self.A)
         k, m = self.k, self.m
         ops.plan_rhs(self.A, k)
         ops.plan_rhs(self.At, k)

@@ -155,12 +155,14 @@ void fit(FitParams& P) {
         // block the host, not the device, so the sort runs under the value upload; everything is ordered on the one stream.
         upload_ints(P.col_ptr, (size_t)n + 1, dAp, s);
         upload_ints(P.row_idx, (size_t)P.nnz, dAi, s);
+        phase("  upload col_ptr + row_idx", s);
         dTp.alloc(((size_t)m + 1) * sizeof(int));
         dTi.alloc((size_t)std::max<int64_t>(P.nnz, 1) * sizeof(int));
         dTx.alloc((size_t)std::max<int64_t>(P.nnz, 1) * sizeof(T));
         DevBuf dpos((size_t)std::max<int64_t>(P.nnz, 1) * sizeof(int));
         OPCHK(rcppml_hip_transpose_csc_sort(c, m, n, P.nnz, dAp.as<int>(), dAi.as<int>(), dTp.as<int>(), dpos.as<int>()));      // asynchronous (arena)
         OPCHK(rcppml_hip_transpose_csc_gather(c, dt, n, P.nnz, dAp.as<int>(), dpos.as<int>(), nullptr, dTi.as<int>(), nullptr));   // column indices of A^T
+        if (P.verbose >= 2) phase("  transpose: sort + column indices (values in flight)", s);
         hipStream_t s2 = g.second_stream();
         dAx.alloc((size_t)std::max<int64_t>(P.nnz, 1) * sizeof(T));
         DevBuf stage;
@@ -182,8 +184,10 @@ void fit(FitParams& P) {
                 plan_or_none(rcppml_hip_rhs_plan_create_indices(c, dt, dTp.as<int>(), dTi.as<int>(), m, n, k, 0, 0, &planT.p), planT.p);
             }
         } catch (...) { up.join(); throw; }
+        if (P.verbose >= 2) phase("  plan index halves", s);
         up.join();
         if (up_err) std::rethrow_exception(up_err);
+        if (P.verbose >= 2) phase("  values across PCIe (joined)", s);
         if constexpr (!std::is_same<T, double>::value) OPCHK(rcppml_hip_cast(c, RCPPML_F64, stage.p, RCPPML_F32, dAx.p, P.nnz));
         OPCHK(rcppml_hip_transpose_csc_gather(c, dt, n, P.nnz, dAp.as<int>(), dpos.as<int>(), dAx.p, nullptr, dTx.p));             // its values
         if (planA.p) OPCHK(rcppml_hip_rhs_plan_set_values(c, planA.p, dAx.p));
@@ -517,7 +521,44 @@ void fit(FitParams& P) {
         ~GraphHolder() { if (e) (void)hipGraphExecDestroy(e); if (g) (void)hipGraphDestroy(g); }
     } gh;
 
-    for (int iter = 0; iter < P.max_iter; ++iter) {
+    // ---- small plain fits: the whole loop as ONE persistent kernel on one XCD (kernels_small.hip.h): no launch per phase, no loss
+    // round trip per iteration; the convergence rule runs on the device.  RCPPML_GPU_NO_SMALL=1 keeps the multi-launch loop.
+    bool small_done = false;
+    if (!dense && !has_mask && !is_nb && !unfused && !graph_H && !graph_W && P.L21_H == 0 && P.L21_W == 0 && P.angular_H == 0 &&
+        P.angular_W == 0 && !P.projective && !P.symmetric && P.max_iter >= 1 && !getenv("RCPPML_GPU_NO_SMALL") &&
+        rcppml_hip_als_small_eligible(m, n, P.nnz, k)) {
+        DevBuf dres(8 * sizeof(double)), dhist((size_t)P.max_iter * sizeof(double));
+        OPCHK(rcppml_hip_als_small_fit(c, dt, dAp.as<int>(), dAi.as<int>(), dAx.p, dTp.as<int>(), dTi.as<int>(), dTx.p, m, n, P.nnz, k, dW.p, dH.p, dd.p,
+                                       dtr.as<double>(), P.L1_H, P.L1_W, P.L2_H, P.L2_W, P.ub_H, P.ub_W, P.nonneg_H, P.nonneg_W, P.norm_type,
+                                       P.solver_mode, P.cd_maxit, P.cd_tol, P.max_iter, P.tol, P.patience, 0, dhist.as<double>(), dres.as<double>()));
+        double res[8] = {0};
+        HIPCHK(hipMemcpyAsync(res, dres.p, sizeof(res), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        if (res[4] == 1.0) {
+            iterations = (int)res[0]; converged = res[1] != 0.0; train_loss = res[2]; final_tol = res[3];
+            if (P.loss_history || P.verbose) {
+                std::vector<double> hist((size_t)iterations);
+                HIPCHK(hipMemcpyAsync(hist.data(), dhist.p, hist.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+                HIPCHK(hipStreamSynchronize(s));
+                if (P.loss_history) std::copy(hist.begin(), hist.end(), P.loss_history);
+                if (P.verbose) for (int i = 0; i < iterations; ++i) fprintf(stderr, "[rcppml_gpu] iter %d loss %.9g (one-kernel fit)\n", i + 1, hist[i]);
+            }
+            small_done = true;
+        } else {
+            // the kernel's workgroups did not all arrive on one XCD (its barrier gave up, nothing hung): start again on the multi-launch loop
+            if (P.verbose) fprintf(stderr, "[rcppml_gpu] one-kernel fit gave up at its barrier; running the multi-launch loop\n");
+            AsyncUpload<T> again;
+            again.add(P.W, (size_t)k * m, dW);
+            again.add(P.H, (size_t)k * n, dH);
+            again.start(c->device, g.second_stream());
+            again.finish(c);
+            std::vector<T> ones(k, T(1));
+            HIPCHK(hipMemcpyAsync(dd.p, ones.data(), k * sizeof(T), hipMemcpyHostToDevice, s));
+            HIPCHK(hipStreamSynchronize(s));
+        }
+    }
+
+    for (int iter = 0; iter < P.max_iter && !small_done; ++iter) {
         bool launched = false;
         if (graph_ok && !gh.failed && iter >= 2) {
             if (!gh.e) {
@@ -564,7 +605,7 @@ void fit(FitParams& P) {
         }
         iterations = iter + 1;
     }
-    if (!converged) train_loss = last_loss;
+    if (!converged && !small_done) train_loss = last_loss;
 
     if (is_nb && P.out_theta) {
         DevBuf& th = dtheta;
@@ -600,11 +641,15 @@ void fit(FitParams& P) {
 // Shared body of the three NMF entry points
 void nmf_entry(RCPPML_NMF_UNIFIED_ARGS, const int* mask_p, const int* mask_i, double cd_tol, int sort_model,
                int precision, double* loss_history, const double* target_H = nullptr, double target_lambda_H = 0,
-               const double* target_W = nullptr, double target_lambda_W = 0, bool theta_holds_n = false) {
+               const double* target_W = nullptr, double target_lambda_W = 0, int theta_capacity = 0) {
     try {
         rcppml_err().clear();
         *out_status = -1;
         *out_theta_len = 0;
+        // out_theta: the reference bridge hands over m doubles (gpu/bridge_nmf.hpp:284) and its entries carry no capacity; the
+        // build-defined entries read the capacity from *out_theta_len ON INPUT (theta_capacity; <= 0 = the bridge's m).
+        // dispersion = "per_col" writes n values: refused unless the caller's buffer is known to hold them
+        const bool theta_holds_n = theta_capacity >= *n;
         (void)seed; (void)loss_every; (void)huber_delta;
         (void)gp_theta_min; (void)guide_H_labels_flat; (void)guide_H_ns;
         (void)guide_H_lambdas; (void)guide_H_ncs;
@@ -614,18 +659,18 @@ void nmf_entry(RCPPML_NMF_UNIFIED_ARGS, const int* mask_p, const int* mask_i, do
         if (*loss_type == 4 || *loss_type >= 6) {
             // GP with theta = 0 (Poisson / KL NMF) and the power-variance family with phi = 1: IRLS half-updates with
             // parameter-free weights; theta / phi (dispersion global or per row) only enter the GP likelihood and the output
-            if (*gp_dispersion_mode == 3 && !theta_holds_n) throw std::runtime_error("dispersion='per_col' returns n values: the bridge's out_theta holds m (gpu/bridge_nmf.hpp:284); use rcppml_gpu_nmf_ex");
+            if (*gp_dispersion_mode == 3 && !theta_holds_n) throw std::runtime_error("dispersion='per_col' returns n values: the bridge's out_theta holds m (gpu/bridge_nmf.hpp:284); use rcppml_gpu_nmf_ex with *out_theta_len = capacity >= n on input");
             if (*gp_dispersion_mode < 0 || *gp_dispersion_mode > 3) throw std::runtime_error("bad dispersion mode");
             if (*k > 128) throw std::runtime_error("IRLS losses: k must be <= 128");
             if (*solver_mode != 0) throw std::runtime_error("IRLS losses require the CD solver");
         }
         if (*loss_type == 5) {
             if (*k > 128) throw std::runtime_error("NB loss: k must be <= 128");
-            if (*gp_dispersion_mode == 3 && !theta_holds_n) throw std::runtime_error("dispersion='per_col' returns n values: the bridge's out_theta holds m (gpu/bridge_nmf.hpp:284); use rcppml_gpu_nmf_ex");
+            if (*gp_dispersion_mode == 3 && !theta_holds_n) throw std::runtime_error("dispersion='per_col' returns n values: the bridge's out_theta holds m (gpu/bridge_nmf.hpp:284); use rcppml_gpu_nmf_ex with *out_theta_len = capacity >= n on input");
             if (*solver_mode != 0) throw std::runtime_error("NB loss requires the CD solver");      // core/config.hpp:447-452
         }
         if (*robust_delta > 0 && *gp_dispersion_mode == 3 && !theta_holds_n)       // (robust MSE returns a theta vector too: zeros, n of them under per_col)
-            throw std::runtime_error("dispersion='per_col' returns n values: the bridge's out_theta holds m (gpu/bridge_nmf.hpp:284); use rcppml_gpu_nmf_ex");
+            throw std::runtime_error("dispersion='per_col' returns n values: the bridge's out_theta holds m (gpu/bridge_nmf.hpp:284); use rcppml_gpu_nmf_ex with *out_theta_len = capacity >= n on input");
         if (*robust_delta > 0) {   // Huber on Pearson residuals: every loss (MSE included) goes through the IRLS path
             if (*k > 128) throw std::runtime_error("robust loss: k must be <= 128");
             if (*solver_mode != 0) throw std::runtime_error("robust loss requires the CD solver");
@@ -1242,9 +1287,11 @@ extern "C" void rcppml_gpu_nmf_unified_double(RCPPML_NMF_UNIFIED_ARGS) {
 extern "C" void rcppml_gpu_nmf_ex(RCPPML_NMF_UNIFIED_ARGS, const int* mask_p, const int* mask_i, int* mask_nnz,
                                   double* cd_tol, int* sort_model, int* precision, double* loss_history) {
     const bool use_mask = mask_p && mask_nnz && *mask_nnz > 0;
-    // (build-defined contract of this entry: out_theta holds max(m, n) doubles -- dispersion = "per_col" returns n of them)
+    // (build-defined contract of this entry: *out_theta_len is, ON INPUT, the capacity of out_theta in doubles -- dispersion = "per_col"
+    // returns n values and is refused with status -1 when fewer fit; <= 0 means the reference bridge's m doubles)
+    const int theta_cap = out_theta_len ? *out_theta_len : 0;
     nmf_entry(RCPPML_NMF_UNIFIED_PASS, use_mask ? mask_p : nullptr, use_mask ? mask_i : nullptr, *cd_tol, *sort_model,
-              *precision, loss_history, nullptr, 0.0, nullptr, 0.0, true);
+              *precision, loss_history, nullptr, 0.0, nullptr, 0.0, theta_cap);
 }
 
 extern "C" void rcppml_gpu_nmf_target(RCPPML_NMF_UNIFIED_ARGS, const int* mask_p, const int* mask_i, int* mask_nnz,
@@ -1252,9 +1299,10 @@ extern "C" void rcppml_gpu_nmf_target(RCPPML_NMF_UNIFIED_ARGS, const int* mask_p
                                       const double* target_H, double* target_lambda_H, const double* target_W,
                                       double* target_lambda_W) {
     const bool use_mask = mask_p && mask_nnz && *mask_nnz > 0;
+    const int theta_cap = out_theta_len ? *out_theta_len : 0;          // capacity of out_theta on input, as in rcppml_gpu_nmf_ex
     nmf_entry(RCPPML_NMF_UNIFIED_PASS, use_mask ? mask_p : nullptr, use_mask ? mask_i : nullptr, *cd_tol, *sort_model,
               *precision, loss_history, target_H, target_lambda_H ? *target_lambda_H : 0.0, target_W,
-              target_lambda_W ? *target_lambda_W : 0.0, true);
+              target_lambda_W ? *target_lambda_W : 0.0, theta_cap);
 }
 
 // nnls()/predict() projection in fp64 (src/RcppFunctions_utils.cpp:313-366)

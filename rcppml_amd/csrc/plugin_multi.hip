@@ -51,6 +51,21 @@ __global__ void mg_local_sum_kernel(T* const* __restrict__ bufs, int n, size_t c
     for (int r = 0; r < n; ++r) bufs[r][i] = s;
 }
 
+// 64-bit checksum of a buffer's bit patterns (position-weighted, integer sum: independent of the order the blocks finish in):
+// the replicas of W_T must agree BIT FOR BIT on every device -- the replicated W solve relies on it (no broadcast)
+template <class T>
+__global__ void mg_checksum_kernel(const T* __restrict__ x, size_t count, unsigned long long* __restrict__ out) {
+    unsigned long long h = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) {
+        unsigned long long b;
+        if constexpr (sizeof(T) == 4) b = (unsigned long long)__float_as_uint((float)x[i]);
+        else b = (unsigned long long)__double_as_longlong((double)x[i]);
+        h += b * (2ull * (unsigned long long)i + 1ull);
+    }
+    for (int o = 32; o > 0; o >>= 1) h += __shfl_down(h, o);
+    if ((threadIdx.x & 63) == 0) atomicAdd(out, h);
+}
+
 struct Rccl {
     void* h = nullptr;
     decltype(&ncclCommInitAll) CommInitAll = nullptr;
@@ -299,12 +314,31 @@ void fit_multi(FitParams& P, const std::vector<int>& devices, bool shared, bool 
     HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&hloss), 4 * sizeof(double)));
     struct HostFree { double* p; ~HostFree() { (void)hipHostFree(p); } } hf{hloss};
 
+    // RCPPML_GPU_VERBOSE >= 2 (the ABI's verbose >= 2): per-shard HIP-event times of the five phases of an iteration and the
+    // payloads of the collectives, to stderr after the fit -- the full-size input of bench.py's collectives_model.  (With
+    // RCPPML_GPU_DEVICES_SHARE the shards' streams share one device: their phases overlap and each is slower than on its own GPU.)
+    constexpr int NPH = 6;                                    // H solve | partials [G_p, B_p, row sums] | all-reduce (incl. waiting for the slowest shard) | scaling + W solve (+ all-gather) | W scaling + loss | (whole iteration)
+    const bool timing = P.verbose >= 2;
+    std::vector<std::vector<hipEvent_t>> tev(nd);
+    std::vector<std::vector<double>> tms(nd, std::vector<double>(NPH, 0.0));
+    struct EvFree { std::vector<std::vector<hipEvent_t>>& v; ~EvFree() { for (auto& a : v) for (auto e : a) if (e) (void)hipEventDestroy(e); } } evfree{tev};
+    if (timing)
+        for (int r = 0; r < nd; ++r) {
+            HIPCHK(hipSetDevice(S[r]->dev));
+            tev[r].assign(NPH + 2, nullptr);
+            for (auto& e : tev[r]) HIPCHK(hipEventCreate(&e));
+        }
+    auto mark = [&](int r, int slot) { if (timing) HIPCHK(hipEventRecord(tev[r][slot], S[r]->g->s)); };
+
     for (int iter = 0; iter < P.max_iter; ++iter) {
         const int warm = iter > 0 ? 1 : 0;
         // ================= H half-update on every shard (fit_cpu.hpp:486-645): no communication
         for (int r = 0; r < nd; ++r) {
             Shard<T>& s = *S[r];
             rcppml_hip_ctx* c = s.g->c;
+            HIPCHK(hipSetDevice(s.dev));
+            mark(r, 0);
+            if (s.n_loc == 0) { mark(r, 1); mark(r, 2); }
             if (s.n_loc == 0) { HIPCHK(hipSetDevice(s.dev)); HIPCHK(hipMemsetAsync(s.xbuf.p, 0, s.xbuf.bytes, s.g->s)); continue; }
             OPCHK(rcppml_hip_gram(c, dt, s.W.p, k, m, eps, P.L2_H, s.G.p));
             if (s.planA) OPCHK(rcppml_hip_rhs_planned(c, s.planA, s.W.p, s.Bh.p));
@@ -318,12 +352,14 @@ void fit_multi(FitParams& P, const std::vector<int>& devices, bool shared, bool 
             } else {
                 OPCHK(rcppml_hip_solve_chol(c, dt, s.G.p, s.Bh.p, s.H.p, k, s.n_loc, P.L1_H > 0 ? P.L1_H : 0.0, P.nonneg_H, P.ub_H));
             }
+            mark(r, 1);
             // ================= W half-update (fit_cpu.hpp:711-893).  H H^T, H A^T and the row norms of H are all sums over ALL
             // columns: every shard forms its partials from the UNSCALED H into one buffer [G_p | B_p | row sums] ...
             OPCHK(rcppml_hip_row_norms(c, dt, s.H.p, k, s.n_loc, P.norm_type, T_ptr(s.xbuf, (size_t)k * k + (size_t)k * m)));   // L1: sum |h|; L2: sum h^2
             OPCHK(rcppml_hip_gram(c, dt, s.H.p, k, s.n_loc, 0.0, 0.0, s.xbuf.p));               // eps after the sum
             if (s.planT) OPCHK(rcppml_hip_rhs_planned(c, s.planT, s.H.p, T_ptr(s.xbuf, (size_t)k * k)));
             else OPCHK(rcppml_hip_rhs(c, dt, s.Tp.template as<int>(), s.Ti.template as<int>(), s.Tx.p, m, s.H.p, k, T_ptr(s.xbuf, (size_t)k * k)));
+            mark(r, 2);
         }
         // ... ONE all-reduce per iteration ...
         for (int r = 0; r < nd; ++r) bufs[r] = S[r]->xbuf.p;
@@ -333,6 +369,7 @@ void fit_multi(FitParams& P, const std::vector<int>& devices, bool shared, bool 
             rcppml_hip_ctx* c = s.g->c;
             HIPCHK(hipSetDevice(s.dev));
             hipStream_t st = s.g->s;
+            mark(r, 3);
             // ... and the scaling D = diag(d) (variant_helpers.hpp:286-305) is applied after the sum: H_loc <- D^-1 H_loc,
             // B = D^-1 B_raw, G = D^-1 G_raw D^-1 -- the reference's "normalise, then multiply" up to rounding
             void* gsums = T_ptr(s.xbuf, (size_t)k * k + (size_t)k * m);
@@ -373,15 +410,26 @@ void fit_multi(FitParams& P, const std::vector<int>& devices, bool shared, bool 
             rcppml_hip_ctx* c = s.g->c;
             HIPCHK(hipSetDevice(s.dev));
             void* Bw = T_ptr(s.xbuf, (size_t)k * k);
+            mark(r, 4);
             OPCHK(rcppml_hip_row_norms(c, dt, s.W.p, k, m, P.norm_type, s.sums.p));
             OPCHK(rcppml_hip_apply_scaling(c, dt, s.W.p, k, m, P.norm_type, s.sums.p, s.d.p));
             // ---- loss (fit_cpu.hpp:1729-1753) from replicated quantities: identical on every device
             OPCHK(rcppml_hip_gram(c, dt, s.W.p, k, m, eps, 0.0, s.Gwt.p));
             OPCHK(rcppml_hip_loss_mse(c, dt, s.tr.template as<double>(), s.d.p, s.W.p, Bw, k, m, s.Gwt.p, s.Gs.p, s.loss.template as<double>()));
+            mark(r, 5);
         }
         HIPCHK(hipSetDevice(S[0]->dev));
         HIPCHK(hipMemcpyAsync(hloss, S[0]->loss.p, 4 * sizeof(double), hipMemcpyDeviceToHost, S[0]->g->s));
         for (int r = 0; r < nd; ++r) { HIPCHK(hipSetDevice(S[r]->dev)); HIPCHK(hipStreamSynchronize(S[r]->g->s)); }
+        if (timing)
+            for (int r = 0; r < nd; ++r) {
+                // slots: 0 start, 1 after the H solve, 2 after the partials, 3 after the all-reduce, 4 after the W solve (+ all-gather), 5 end
+                const int a[NPH] = {0, 1, 2, 3, 4, 0}, b[NPH] = {1, 2, 3, 4, 5, 5};
+                for (int ph = 0; ph < NPH; ++ph) {
+                    float ms = 0;
+                    if (hipEventElapsedTime(&ms, tev[r][a[ph]], tev[r][b[ph]]) == hipSuccess) tms[r][ph] += ms; else (void)hipGetLastError();
+                }
+            }
         double loss_val = hloss[0];
         if (std::is_same<T, float>::value) loss_val = static_cast<double>(static_cast<float>(loss_val));
         last_loss = loss_val;
@@ -403,6 +451,35 @@ void fit_multi(FitParams& P, const std::vector<int>& devices, bool shared, bool 
         iterations = iter + 1;
     }
     if (!converged) train_loss = last_loss;
+    if (timing && iterations > 0) {
+        const size_t sv = sizeof(T);
+        fprintf(stderr, "[rcppml_gpu x%d] %s per iteration: all-reduce [G_p | B_p | row sums] %zu bytes%s; W solve %s; %d iteration(s)\n", nd,
+                shared ? "shared-device stand-in" : "RCCL", ((size_t)k * k + (size_t)k * m + (size_t)k) * sv,
+                w_block ? (std::string(", all-gather of W_T ") + std::to_string((size_t)rows_per * nd * k * sv) + " bytes").c_str() : "",
+                w_block ? "block" : "replicated", iterations);
+        for (int r = 0; r < nd; ++r)
+            fprintf(stderr, "[rcppml_gpu x%d] shard %d: columns [%d, %d) nnz %lld  ms/iteration: H solve %.3f | partials %.3f | all-reduce %.3f | scaling + W solve %.3f | W scaling + loss %.3f | whole %.3f\n",
+                    nd, r, S[r]->c0, S[r]->c0 + S[r]->n_loc, (long long)S[r]->nnz_loc, tms[r][0] / iterations, tms[r][1] / iterations,
+                    tms[r][2] / iterations, tms[r][3] / iterations, tms[r][4] / iterations, tms[r][5] / iterations);
+    }
+    // ---- the replicas of W_T must be bitwise equal (replicated solve: identical inputs, deterministic kernels; block solve: the
+    // all-gather): checked on every fit -- a divergence would otherwise be silent, H of the other shards being solved against
+    // another W_T than the one that is returned
+    {
+        std::vector<unsigned long long> sums(nd, 0);
+        for (int r = 0; r < nd; ++r) {
+            HIPCHK(hipSetDevice(S[r]->dev));
+            DevBuf acc(sizeof(unsigned long long));
+            HIPCHK(hipMemsetAsync(acc.p, 0, sizeof(unsigned long long), S[r]->g->s));
+            hipLaunchKernelGGL(mg_checksum_kernel<T>, dim3(256), dim3(256), 0, S[r]->g->s, (const T*)S[r]->W.p, (size_t)k * m, (unsigned long long*)acc.p);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipMemcpyAsync(&sums[r], acc.p, sizeof(unsigned long long), hipMemcpyDeviceToHost, S[r]->g->s));
+            HIPCHK(hipStreamSynchronize(S[r]->g->s));
+        }
+        for (int r = 1; r < nd; ++r)
+            if (sums[r] != sums[0]) throw std::runtime_error("multi-device fit: the W_T replicas of devices 0 and " + std::to_string(r) + " differ");
+        if (timing) fprintf(stderr, "[rcppml_gpu x%d] W_T replicas bitwise equal (checksum %016llx)\n", nd, sums[0]);
+    }
 
     // ---- download (W, d from device 0; every shard's H) and sort by descending d (core/result.hpp:169-188)
     download_cast<T>(S[0]->g->c, S[0]->W, (size_t)k * m, P.W, S[0]->g->s);

@@ -176,6 +176,26 @@ def simulate_nmf_sparse(nrow, ncol, k, density, noise=0.5, seed=123, device=None
     return CSC((nrow, ncol), p, rows, vals), w, h
 
 
+def simulate_nmf_sparse_shards(nrow, ncol_total, k, density, shards, seed=123, device=None, round_f32=False):
+    """The ncol_total-wide simulateNMF sample built shard by shard (column shard r from its own generator stream, exactly the
+    matrix the `shards` ranks of a column-sharded run hold between them) and concatenated into ONE host CSC -- how a matrix too
+    large to sample in one piece (BASELINE configs[3]: 30 000 x 1 300 000, 1.17e9 nonzeros) is generated.  round_f32: values
+    rounded to fp32 (so that fp32 and fp64 consumers see the same numbers)."""
+    if ncol_total % shards:
+        raise ValueError("ncol_total must be a multiple of shards")
+    nsh = ncol_total // shards
+    ps, iis, xs, off = [np.zeros(1, np.int64)], [], [], 0
+    for r in range(shards):
+        a = simulate_nmf_sparse(nrow, nsh, k, density, seed=seed, device=device, col_offset=r * nsh, ncol_total=ncol_total)[0]
+        ps.append(a.p[1:].astype(np.int64) + off)
+        iis.append(a.i)
+        xs.append(a.x.astype(np.float32).astype(np.float64) if round_f32 else a.x)
+        off += a.nnz
+    if off >= 2 ** 31:
+        raise ValueError("more than 2^31 - 1 nonzeros: the CSC boundary's int col_ptr cannot hold them")
+    return CSC((nrow, ncol_total), np.concatenate(ps), np.concatenate(iis), np.concatenate(xs))
+
+
 def simulate_nb_counts(nrow, ncol, k, density=0.02, size=5.0, seed=123, scale=None):
     """NB counts for BASELINE config C5 (structure of tests/testthat/test_nb_nmf.R:11-27): mu = (w h) * scale,
     y ~ NegBin(size, mu) at Bernoulli(density)-sampled positions; zeros dropped."""

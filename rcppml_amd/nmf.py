@@ -91,7 +91,9 @@ def _cv_across_ranks(data, ranks, seed, cv_seed, test_fraction, kw):
     for rep, cs in enumerate(cv_seeds, start=1):
         for rank in ranks:
             init_seed = int((cs + rank) % (2 ** 31 - 1))
-            W0, H0 = init_factors(init_seed, rank, m, n, np.float64)
+            # (the stream is drawn in the compute Scalar: initialize_factors<float> when the fit runs in fp32, as the single fit does)
+            W0, H0 = init_factors(init_seed, rank, m, n, np.float32 if kw.get("precision", "fp32") == "fp32" else np.float64)
+            W0, H0 = W0.astype(np.float64), H0.astype(np.float64)
             mod = nmf(data, rank, seed=W0, h_init=H0.T, test_fraction=test_fraction, cv_seed=cs, **kw)
             th = mod.misc.get("theta")
             rows.append(dict(rep=rep, k=rank, train_mse=mod.misc["loss"], test_mse=mod.misc.get("best_test_loss", mod.misc["test_loss"]),
@@ -213,15 +215,15 @@ def nmf(data, k, tol=1e-4, maxit=100, L1=(0.0, 0.0), L2=(0.0, 0.0), seed=None, m
         data = np.where(np.isnan(data), 0.0, data)
         if mask is None:
             mask = "NA"
-    elif hasattr(data, "tocsc") and np.isnan(data.data).any():
+    A = _as_csc(data)
+    if not dense_in and np.isnan(A.x).any():          # any sparse container (scipy of every format, the repo's CSC): checked on the converted values
         import warnings
-        n_na = int(np.isnan(data.data).sum())
-        warnings.warn("Detected %d NA values (%.2f%% of data). Automatically creating mask for missing values." % (n_na, 100.0 * n_na / (data.shape[0] * data.shape[1])))
-        data = data.copy()
-        data.data[np.isnan(data.data)] = 0.0
+        n_na = int(np.isnan(A.x).sum())
+        warnings.warn("Detected %d NA values (%.2f%% of data). Automatically creating mask for missing values." % (n_na, 100.0 * n_na / (A.shape[0] * A.shape[1])))
+        from .data import CSC as _CSC
+        A = _CSC(A.shape, A.p, A.i, np.where(np.isnan(A.x), 0.0, A.x))
         if mask is None:
             mask = "NA"
-    A = _as_csc(data)
     m, n = A.shape
     if symmetric and m != n:
         raise ValueError('symmetric = TRUE requires a square matrix')
@@ -341,7 +343,15 @@ def nmf(data, k, tol=1e-4, maxit=100, L1=(0.0, 0.0), L2=(0.0, 0.0), seed=None, m
         if irls_cv and loss == "gp":
             misc["theta"] = res.get("theta")
         return NMFModel(w=W_T.copy(), d=res["d"], h=H.T.copy(), misc=misc)
-    if dense_in and mask_arg is None and not graph_args and sort_model and target_H is None and float(cd_tol) == 1e-8:
+    dense_entry_ok = mask_arg is None and not graph_args and sort_model and target_H is None and float(cd_tol) == 1e-8
+    if dense_in and (loss != "mse" or robust_delta > 0) and not dense_entry_ok:
+        # a dense matrix under a distribution loss / robust modifier is weighted ENTRY BY ENTRY, zeros included (nnls_batch_irls_dense,
+        # fit_cpu.hpp:607-614); the sparse entry gives zeros weight 1 -- another model.  Unrelated arguments must not switch between the
+        # two silently: what the dense entry has no slot for is refused here
+        raise NotImplementedError("dense input with loss = %r%s: the dense entry (rcppml_gpu_nmf_dense_unified_*) carries no mask, graph, target, "
+                                  "cd_tol or sort_model = FALSE; pass a sparse matrix for the sparse-input semantics (zeros unweighted)"
+                                  % (loss, " + robust" if robust_delta > 0 else ""))
+    if dense_in and dense_entry_ok:
         # dense input -> rcppml_gpu_nmf_dense_unified_* (GEMM right-hand sides, the reference's unfused update order; under a
         # distribution loss the dense IRLS solves, which weight EVERY entry -- the sparse entry gives zeros weight 1).
         # The dense ABI (bridge_nmf.hpp:101-126) has no slot for cd_tol (the plugin uses the reference default 1e-8) and
@@ -361,7 +371,8 @@ def nmf(data, k, tol=1e-4, maxit=100, L1=(0.0, 0.0), L2=(0.0, 0.0), seed=None, m
             raise _abi.BackendError("GPU dense NMF failed: %s" % res.get("error"))
         misc = dict(tol=res["tol"], iter=res["iter"], loss=res["loss"], converged=res["converged"], solver=solver,
                     solver_mode=0 if solver == "cd" else 1, L1=(L1w, L1h), L2=(L2w, L2h), seed=seed_int, precision=precision,
-                    resource="gpu", loss_type=loss, input="dense", loss_history=None)
+                    resource="gpu", loss_type=loss, input="dense", loss_history=None,
+                    entry="rcppml_gpu_nmf_dense_unified_" + ("float" if precision == "fp32" else "double"))
         if loss != "mse":
             misc["theta"] = res["theta"]
         return NMFModel(w=W_T.copy(), d=res["d"], h=H.T.copy(), misc=misc)
@@ -389,7 +400,8 @@ def nmf(data, k, tol=1e-4, maxit=100, L1=(0.0, 0.0), L2=(0.0, 0.0), seed=None, m
         raise _abi.BackendError("GPU NMF failed: %s" % res.get("error"))
     misc = dict(tol=res["tol"], iter=res["iter"], loss=res["loss"], loss_history=res.get("loss_history"),
                 converged=res["converged"], solver=solver, solver_mode=0 if solver == "cd" else 1, L1=(L1w, L1h),
-                L2=(L2w, L2h), seed=seed_int, precision=precision, resource="gpu", loss_type=loss)
+                L2=(L2w, L2h), seed=seed_int, precision=precision, resource="gpu", loss_type=loss,
+                entry="rcppml_gpu_nmf_target" if target_args else "rcppml_gpu_nmf_ex")
     if loss != "mse":
         misc["theta"] = res["theta"]                                   # R: misc$theta (RcppFunctions_nmf.cpp:156-158)
     return NMFModel(w=W_T.copy(), d=res["d"], h=H.T.copy(), misc=misc)

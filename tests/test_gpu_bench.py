@@ -50,6 +50,14 @@ def test_bench_line_graph_and_eager_modes_agree():
         # "scale_gram_loss" = the same for W_T + the loss; bench.py --no-fused-tail keeps the separate "scale" / "gram" / "loss" phases)
         assert d["fused_tail"] and set(d["phases_ms_per_step"]) >= {"rhs_H", "rhs_W", "solve_H", "solve_W", "scale_gram", "scale_gram_loss"}
         assert sum(d["phases_ms_per_step"].values()) < 1.25 * max(d["ms_per_step"], d["eager_ms_per_step"] or 0)
+    # the reference's protocol beside the steady state: the same number of iterations from the SplitMix64 start (no warm start and no
+    # work order in the first two, more CD sweeps early in a fit): never faster than the steady-state step, and its own cols/s
+    for d in (g, e):
+        ffs = d["fit_from_start"]
+        assert ffs["iterations"] == 4 and ffs["unit"] == "cols/s" and ffs["launch"] == "eager"
+        assert ffs["ms_per_step"] >= 0.98 * d["ms_per_step"]
+        assert abs(ffs["value"] - (3000 + 24000) / (ffs["ms_per_step"] * 1e-3)) / ffs["value"] < 1e-6
+    assert g["fit_from_start"]["final_loss"] == e["fit_from_start"]["final_loss"]
     assert "hipGraph" in g["launch"] and g["eager_ms_per_step"] > 0
     assert e["launch"] == "eager" and e["eager_ms_per_step"] is None
     # same iterations, same kernels: the modes differ in how launches are issued, not in what is computed

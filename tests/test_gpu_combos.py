@@ -136,6 +136,16 @@ def test_dispersion_per_col_through_plugin(abi, loss_type, kw):
     assert bad["status"] == -1 and "per_col" in bad["error"]
     ok = abi.nmf_unified(A.p, A.i, A.x, A.rows, A.cols, k, W2, H2, entry="ex", max_iter=2, loss_type=0, robust_delta=1.0, gp_dispersion_mode=3)
     assert ok["status"] == 0 and len(ok["theta"]) == A.cols and np.all(ok["theta"] == 0)
+    # the build-defined entry reads the CAPACITY of out_theta from *out_theta_len on input: a caller that sized the buffer
+    # as the reference bridge does (m doubles, n > m here) or that passes no capacity is refused instead of overrun
+    for cap in (A.rows, 0):
+        small = abi.nmf_unified(A.p, A.i, A.x, A.rows, A.cols, k, W0.copy(), H0.copy(), entry="ex", max_iter=2, loss_type=loss_type,
+                                gp_dispersion_mode=3, theta_capacity=cap, **kw)
+        assert small["status"] == -1 and "per_col" in small["error"], cap
+    # ... and per-row dispersion (m values) still fits the bridge-sized buffer
+    row = abi.nmf_unified(A.p, A.i, A.x, A.rows, A.cols, k, W0.copy(), H0.copy(), entry="ex", max_iter=2, loss_type=loss_type,
+                          gp_dispersion_mode=2, theta_capacity=A.rows, **kw)
+    assert row["status"] == 0 and len(row["theta"]) == A.rows
 
 
 def test_dispersion_per_col_through_the_r_surface():

@@ -178,6 +178,16 @@ def test_dense_fit_with_nb_loss_fp32_entry_and_surface():
     assert np.abs(W - ref.W_T).max() <= 5e-3 and np.abs(H - ref.H).max() <= 5e-3
     mod = N.nmf(M, k, loss="nb", seed=4, maxit=3, tol=0.0, precision="fp64")
     assert mod.misc["input"] == "dense" and mod.misc["theta"].shape == (m,) and np.isfinite(mod.misc["loss"])
+    assert mod.misc["entry"] == "rcppml_gpu_nmf_dense_unified_double"
+    # arguments the dense entry has no slot for must not switch a dense matrix to the sparse-input model (zeros unweighted) silently
+    for extra in (dict(sort_model=False), dict(cd_tol=1e-6)):
+        with pytest.raises(NotImplementedError, match="dense input"):
+            N.nmf(M, k, loss="nb", seed=4, maxit=2, precision="fp64", **extra)
+        with pytest.raises(NotImplementedError, match="dense input"):
+            N.nmf(M, k, robust=True, seed=4, maxit=2, precision="fp64", **extra)
+    # ... while plain MSE keeps both routes (same model either way; misc says which entry ran)
+    a = N.nmf(M, k, seed=4, maxit=2, precision="fp64", sort_model=False)
+    assert a.misc["entry"] == "rcppml_gpu_nmf_ex"
 
 
 def test_reference_dense_irls_properties():
