@@ -37,7 +37,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--config", choices=["c1", "c2", "c3", "c4", "c5"], default="c2",
+    ap.add_argument("--config", choices=["c1", "c2", "c3", "c4", "c4full", "c5"], default="c2",
                     help="BASELINE.json configs[1] (20000 x 100000 per GPU, 1 %%, k = 64: the headline) or configs[3] "
                          "(pbmc3k-shaped 30000 x 162500 per GPU = 1.3 M columns over 8 GPUs, 3 %%, k = 128)")
     ap.add_argument("--rows", type=int, default=None)
@@ -72,8 +72,15 @@ def parse():
     # L1 = c(0, 0.1), mask = "zeros" (a fit-time no-op in the reference); c5: NB counts, IRLS half-updates
     # c1: the hawaiibirds fixture (tests/golden/hawaiibirds.npz, extracted from the reference's data/hawaiibirds.rda), k = 10: the whole fit
     # as ONE persistent kernel (rcppml_hip_als_small_fit)
-    preset = {"c1": (183, 1183, 0.142, 10), "c2": (20000, 100000, 0.01, 64), "c4": (30000, 162500, 0.03, 128), "c3": (3867, 610, 0.0319, 32),
+    preset = {"c1": (183, 1183, 0.142, 10), "c2": (20000, 100000, 0.01, 64), "c4": (30000, 162500, 0.03, 128), "c4full": (30000, 1300000, 0.03, 128), "c3": (3867, 610, 0.0319, 32),
               "c5": (10000, 200000, 0.02, 32)}[args.config]
+    if args.config == "c4full":
+        # configs[3] at its FULL stated extent on ONE device (1.17e9 nonzeros, ~55 GB resident): generated as the eight shards of the
+        # 8-GPU run and concatenated; A^T is built on the device; the CPU reference fit and the fp64 leg are skipped (hours of host time)
+        if args.data_shards == 1:
+            args.data_shards = 8
+        args.no_cpu_ref = True
+        args.no_fp64_leg = True
     args.rows = args.rows or preset[0]
     args.cols = args.cols or preset[1]
     args.density = args.density or preset[2]
@@ -242,7 +249,7 @@ def main():
         dens = calibrated_density(m, k, args.density, seed=123)
         A_loc, _, _ = data.simulate_nmf_sparse(m, n_loc, k, dens, seed=123, device=torch.device("cuda", local_rank),
                                                col_offset=rank * n_loc, ncol_total=n_total)
-    At_loc = A_loc.transpose()
+    At_loc = A_loc.transpose() if args.config != "c4full" else None      # (full extent: transposed on the device, als.ShardedALS)
     nd = np.float32 if args.dtype == "f32" else np.float64
     W0, H0 = data.init_factors(args.seed, k, m, n_loc, np.float32 if args.init_f32 else nd, col_offset=rank * n_loc, n_total=n_total)
     W0, H0 = W0.astype(nd), H0.astype(nd)
@@ -503,7 +510,7 @@ def main():
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "%s %dx%d (x%d GPUs, column shards) %.3g%%-dense CSC, k=%d, MSE, %s NNLS "
                                    "(cd_maxit=%d, cd_tol=1e-8), L1 row normalisation, loss every iteration"
-                                   % ({"c2": "configs[1]: simulateNMF", "c4": "configs[3] (one GPU's share): simulateNMF",
+                                   % ({"c2": "configs[1]: simulateNMF", "c4": "configs[3] (one GPU's share): simulateNMF", "c4full": "configs[3] at FULL extent on one device: simulateNMF",
                                        "c3": "configs[2]: movielens (fixture of data/movielens.rda), L1 = c(0, 0.1), mask = 'zeros' (fit-time "
                                              "no-op in the reference)"}[args.config], m, n_loc, world,
                                       100.0 * nnz / (m * float(n_loc)), k,
@@ -538,7 +545,15 @@ def main():
                 W_T, dvec, H = st.factors()
                 G_h = st.ops.gram(st.W_T, 1e-15, 0.0).cpu().numpy()
                 G_w = st.ops.gram(st.H, 1e-15, 0.0).cpu().numpy()
-                out["cpu_baseline"] = cpu_baseline(_to_oracle(A_loc), _to_oracle(At_loc), W_T, H, G_h, G_w, k, args.dtype,
+                if At_loc is None:          # the W-side sample needs the first rows of A only: the leading columns of the device's A^T
+                    from oracle.oracle import Csc
+                    c1 = min(m, 2048)
+                    tp = st.At["p"][:c1 + 1].cpu().numpy()
+                    e1 = int(tp[-1])
+                    At_host = Csc((n_loc, c1), tp, st.At["i"][:e1].cpu().numpy(), st.At["x"][:e1].cpu().numpy().astype(np.float64))
+                else:
+                    At_host = _to_oracle(At_loc)
+                out["cpu_baseline"] = cpu_baseline(_to_oracle(A_loc), At_host, W_T, H, G_h, G_w, k, args.dtype,
                                                    args.cpu_seconds, args.cd_maxit, L1_H=cfg.L1_H)
                 out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
             except Exception as e:  # the baseline must never take the GPU number down with it

@@ -1645,13 +1645,13 @@ __device__ __forceinline__ bool cv_user_masked(const int* __restrict__ mp, const
     int lo = mp[j];
     const int end = mp[j + 1];
     int hi = end;
-    while (lo < hi) { const int mid = (lo + hi) >> 1; if (mi[mid] < row) lo = mid + 1; else hi = mid; }
+    while (lo < hi) { const int mid = lo + ((hi - lo) >> 1); if (mi[mid] < row) lo = mid + 1; else hi = mid; }
     return lo < end && mi[lo] == row;
 }
 // is `row` one of the stored rows of column [ts, te) of a CSC with ascending rows?
 __device__ __forceinline__ bool cv_row_stored(const int* __restrict__ rowidx, int ts, int te, int row) {
     int lo = ts, hi = te;
-    while (lo < hi) { const int mid = (lo + hi) >> 1; if (rowidx[mid] < row) lo = mid + 1; else hi = mid; }
+    while (lo < hi) { const int mid = lo + ((hi - lo) >> 1); if (rowidx[mid] < row) lo = mid + 1; else hi = mid; }
     return lo < te && rowidx[lo] == row;
 }
 

@@ -242,7 +242,7 @@ __global__ __launch_bounds__(256) void cv_irls_loss_kernel(
         } else {
             for (int row = lane; row < nrows; row += 64) {
                 int lo = as, hi = ae;               // first position with rowidx >= row
-                while (lo < hi) { const int mid = (lo + hi) >> 1; if (rowidx[mid] < row) lo = mid + 1; else hi = mid; }
+                while (lo < hi) { const int mid = lo + ((hi - lo) >> 1); if (rowidx[mid] < row) lo = mid + 1; else hi = mid; }
                 const T a = (lo < ae && rowidx[lo] == row) ? vals[lo] : T(0);
                 term(row, a);
             }

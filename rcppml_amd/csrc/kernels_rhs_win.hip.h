@@ -76,7 +76,7 @@ __host__ __device__ __forceinline__ int64_t rw_block_off(const RhsWinGeom& G, in
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ int rw_lower_bound(const int* __restrict__ rowidx, int lo, int hi, int row) {     // first e in [lo, hi) with rowidx[e] >= row
     while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
+        const int mid = lo + ((hi - lo) >> 1);          /* (lo + hi overflows an int above 2^30 nonzero positions: configs[3] at full extent) */
         if (rowidx[mid] < row) lo = mid + 1;
         else hi = mid;
     }

@@ -56,6 +56,8 @@ __device__ __forceinline__ unsigned sm_ld(const unsigned* p) { return __hip_atom
 // Load of data another CU may have rewritten since this CU last read it (factors, partial sums): relaxed, agent scope = the `sc1` form
 // of global_load, which does not hit in the CU's L1.  An L1 invalidate after the barrier (`buffer_inv sc0`) followed by ordinary loads
 // is NOT enough on gfx950 -- measured: 2.2e8 stale reads in tools/probe/grid_barrier_probe.hip, none with these loads.
+__device__ __forceinline__ float shfl_t(float v, int src) { return __shfl(v, src, 64); }
+__device__ __forceinline__ double shfl_t(double v, int src) { return __shfl(v, src, 64); }
 template <class T> __device__ __forceinline__ T sm_ldg(const T* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // Barrier among the SM_NB workgroups of one XCD.  Returns false when it gave up (a participant never arrived: the launch did not
@@ -99,29 +101,39 @@ __device__ __forceinline__ T sm_chol_solve(T b, const T (&Lrow)[KP], const T (&L
     return b;
 }
 
-// Sparse product of one column, lane = factor: NG = 64 / KP lane groups walk the column's nonzeros NG apart, four gathers in flight;
-// the group sums are added with an xor tree (every lane ends with the full sum of its factor).
+// Sparse product of one column, lane = factor.  The column's (row, value) pairs are fetched 64 at a time, one per lane (ONE round trip to
+// the L2 per batch instead of one per 64 / KP entries), handed to the NG = 64 / KP lane groups through ds_bpermute (group g takes
+// entries g, g + NG, ...), and all of a batch's row gathers are issued before the first is consumed; the group sums are added with an
+// xor tree (every lane ends with the full sum of its factor).  The walk is latency: with one or two waves per SIMD nothing hides a
+// round trip, so the number of dependent round trips per column is what counts (two per batch).
 template <class T, int KP>
 __device__ __forceinline__ T sm_rhs(const int* __restrict__ ci, const T* __restrict__ cx, int start, int end, const T* F /* rewritten by other CUs between phases: no restrict */, int k, int lane) {
-    constexpr int NG = 64 / KP, U = 4;
+    constexpr int NG = 64 / KP, PER = 64 / NG;          // PER = entries of a batch per lane group (= KP)
     const int g = lane / KP, f = lane % KP;
     const bool fok = f < k;
     const T* Ff = F + (fok ? f : 0);
     T acc = T(0);
-    for (int t = start + g; t < end; t += NG * U) {
-        int rr[U];
-        T vv[U], ff[U];
+    for (int base = start; base < end; base += 64) {
+        const int t = base + lane;
+        const bool ok = t < end;
+        const int rv = ok ? ci[t] : 0;
+        const T vv = ok ? cx[t] : T(0);
+        const int nb = end - base < 64 ? end - base : 64;
+        constexpr int UB = PER < 16 ? PER : 16;            // gathers in flight per lane (32 of them spill at KP = 32)
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int tt = t + u * NG;
-            const bool ok = tt < end;
-            rr[u] = ok ? ci[tt] : 0;
-            vv[u] = ok ? cx[tt] : T(0);
+        for (int u0 = 0; u0 < PER; u0 += UB) {
+            if (u0 * NG >= nb) break;
+            T ff[UB], va[UB];
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                const int src = (u0 + u) * NG + g;         // this group's (u0 + u)-th entry of the batch
+                const int row = __shfl(rv, src, 64);
+                va[u] = shfl_t(vv, src);
+                ff[u] = (fok && (u0 + u) * NG < nb) ? sm_ldg(Ff + (int64_t)row * k) : T(0);      // (entries past the column's end carry value 0)
+            }
+#pragma unroll
+            for (int u = 0; u < UB; ++u) acc = tfma(va[u], ff[u], acc);
         }
-#pragma unroll
-        for (int u = 0; u < U; ++u) ff[u] = fok ? sm_ldg(Ff + (int64_t)rr[u] * k) : T(0);
-#pragma unroll
-        for (int u = 0; u < U; ++u) acc = tfma(vv[u], ff[u], acc);
     }
 #pragma unroll
     for (int off = KP; off < 64; off <<= 1) acc += shfl_xor_t(acc, off);
@@ -208,7 +220,8 @@ __global__ __launch_bounds__(64 * SM_WPB) void als_small_kernel(SmallFit<T> P) {
     __shared__ int sh_flag;
     __shared__ T Gh[KP * KP], Gsaved[KP * KP], Gwt[KP * KP], Lf[CHOL ? KP * KP : 1];
     __shared__ T dsh[KP], nsh[KP];
-    __shared__ double red[SM_WPB];
+    __shared__ T red_t[64 * SM_WPB];
+    __shared__ double red[64];
     __shared__ double sh_loss[2];
     if (threadIdx.x == 0) sh_ticket = __hip_atomic_fetch_add(P.sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
@@ -264,15 +277,48 @@ __global__ __launch_bounds__(64 * SM_WPB) void als_small_kernel(SmallFit<T> P) {
             }
         }
     };
-    // after a barrier: G = sum over the workgroups' partial Grams (fixed order) + eps (+ l2) on the diagonal -> LDS dst
+    // after a barrier: the sum over the SM_NB workgroups' records of `count` consecutive values at offset `off` -> LDS dst[0 .. count).
+    // Every load is independent (a thread owns one value of a group of workgroups and issues its loads back to back: one round trip to
+    // the L2, not SM_NB dependent ones); the order of the additions is fixed -- inside a group ascending, then the groups ascending --
+    // so every workgroup forms bitwise the same sums.
+    auto part_sum = [&](int off, int count, T* dst) {
+        constexpr int NT = 64 * SM_WPB;
+        int groups = NT / count;                                    // count in {16, 32, 256, 1024}
+        if (groups > SM_NB) groups = SM_NB;
+        if (groups < 1) groups = 1;
+        const int per = SM_NB / groups;                              // workgroups per group (SM_NB and groups are powers of two)
+        const int epp = NT / groups;                                 // values per pass
+        for (int e0 = 0; e0 < count; e0 += epp) {
+            const int e = e0 + (int)threadIdx.x % epp, h = (int)threadIdx.x / epp;
+            if (e < count && h < groups) {
+                T sacc = T(0);
+                for (int b0 = 0; b0 < per; b0 += 8) {                 // eight loads in flight per thread
+                    T v[8];
+#pragma unroll
+                    for (int b = 0; b < 8; ++b) v[b] = b0 + b < per ? sm_ldg(P.part + (size_t)(h * per + b0 + b) * PS + off + e) : T(0);
+#pragma unroll
+                    for (int b = 0; b < 8; ++b) sacc += v[b];          // (+ 0 beyond the group's last workgroup: exact)
+                }
+                red_t[h * epp + (e - e0)] = sacc;
+            }
+            __syncthreads();
+            if (e < count && h == 0) {
+                T sacc = red_t[e - e0];
+                for (int hh = 1; hh < groups; ++hh) sacc += red_t[hh * epp + (e - e0)];
+                dst[e] = sacc;
+            }
+            __syncthreads();
+        }
+    };
+    // G = summed partial Grams + eps (+ l2) on the diagonal, identity padding -> LDS dst
     auto gram_sum = [&](T* dst, T l2) {
+        part_sum(KP, KP * KP, dst);
         for (int e = threadIdx.x; e < KP * KP; e += blockDim.x) {
-            T s = T(0);
-            for (int b = 0; b < SM_NB; ++b) s += sm_ldg(P.part + (size_t)b * PS + KP + e);
+            T sv = dst[e];
             const int r = e % KP, c = e / KP;
-            if (r == c) { if (r < k) { s += eps; s += l2; } else s = T(1); }
-            else if (r >= k || c >= k) s = T(0);
-            dst[e] = s;
+            if (r == c) { if (r < k) { sv += eps; sv += l2; } else sv = T(1); }
+            else if (r >= k || c >= k) sv = T(0);
+            dst[e] = sv;
         }
         __syncthreads();
     };
@@ -287,11 +333,11 @@ __global__ __launch_bounds__(64 * SM_WPB) void als_small_kernel(SmallFit<T> P) {
     };
     // after a barrier: d from the summed row norms (scaling_finalize above): dsh, and the caller's d
     auto norm_sum = [&]() {
+        part_sum(0, KP, nsh);
         if (threadIdx.x < KP) {
-            T s = T(0);
-            for (int b = 0; b < SM_NB; ++b) s += sm_ldg(P.part + (size_t)b * PS + threadIdx.x);
+            T sv = nsh[threadIdx.x];
             T dv = T(1);
-            if (P.norm_type != 2) { if (P.norm_type == 1) s = sqrt(s); dv = s + eps; }
+            if (P.norm_type != 2) { if (P.norm_type == 1) sv = sqrt(sv); dv = sv + eps; }
             dsh[threadIdx.x] = dv;
             if (me == 0 && (int)threadIdx.x < k) P.d[threadIdx.x] = dv;
         }
@@ -349,11 +395,15 @@ __global__ __launch_bounds__(64 * SM_WPB) void als_small_kernel(SmallFit<T> P) {
             for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
             if (lane == 0) red[wave] = acc;
             __syncthreads();
-            if (threadIdx.x == 0) {
-                double recon = 0.0, cross = 0.0;
-                for (int w = 0; w < SM_WPB; ++w) recon += red[w];
-                for (int b = 0; b < SM_NB; ++b) cross += sm_ldg(P.crossp + b);
-                sh_loss[0] = P.trAtA[0] - 2.0 * cross + recon;
+            if (wave == 0) {
+                double cross = lane < SM_NB ? sm_ldg(P.crossp + lane) : 0.0;          // one load per lane, then a fixed xor tree
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) cross += __shfl_xor(cross, off, 64);
+                if (lane == 0) {
+                    double recon = 0.0;
+                    for (int w = 0; w < SM_WPB; ++w) recon += red[w];
+                    sh_loss[0] = P.trAtA[0] - 2.0 * cross + recon;
+                }
             }
             __syncthreads();
         }
