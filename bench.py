@@ -650,6 +650,10 @@ def bench_c1(args):
         raise SystemExit("--config c1: the one-kernel fit gave up at its barrier (result %s)" % res.cpu().numpy())
     dt = timed(args.steps, max(args.warmup, 1))         # the timed region: exactly K iterations
     final_loss = float(res[2].item())
+    tk = res.cpu().numpy()[5:8] * 1e-2 / args.steps      # workgroup 0's 100 MHz ticks -> us per iteration
+    inside = {"half_updates_us": float(tk[0]), "barrier_wait_us": float(tk[1]), "other_us": float(tk[2] - tk[0] - tk[1]), "kernel_us": float(tk[2]),
+              "what": "workgroup 0's wall-clock ticks inside the timed launch, per iteration: fused rhs + solve of both sides | waiting at the four "
+                      "barriers for the slowest workgroup | scaling, Gram partials, fixed-order sums, loss"}
     state = (W.clone(), H.clone(), d.clone())
     reps = []
     for _ in range(15):                                 # the same region again (fresh start + warm-up each time): spread of a 0.5 ms measurement
@@ -727,7 +731,7 @@ def bench_c1(args):
         "fit_from_start": {"iterations": args.steps, "ms_per_step": float(np.median(starts)), "value": (m + n) / (float(np.median(starts)) * 1e-3), "unit": "cols/s",
                            "launch": "one kernel", "final_loss": from_start_loss, "what": "iterations 0 .. %d from the SplitMix64(%d) start, tol = 0, loss every "
                            "iteration, one launch + one synchronise (median of %d)" % (args.steps - 1, args.seed, len(starts))},
-        "multi_launch": multi, "plugin_pcie_inclusive": plug,
+        "inside_the_kernel": inside, "multi_launch": multi, "plugin_pcie_inclusive": plug,
         "phases_ms_per_step": {}, "launch": "one persistent kernel for all %d iterations" % args.steps, "final_loss": final_loss, "world_size_seen": 1,
     }
     if multi and "ms_per_step" in multi:

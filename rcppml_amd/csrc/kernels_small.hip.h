@@ -188,6 +188,134 @@ __device__ __forceinline__ T sm_half_update(const int* __restrict__ cp, const in
     return nacc;
 }
 
+// ---------------------------------------------------------------------------
+// k <= 16: FOUR columns per wavefront, one per 16-lane DPP row (lane = (row g, factor f)).  With one column per wave three quarters of
+// the lanes idle and a wave walks its columns one after the other -- hawaiibirds' H side is 1 183 columns on 256 waves, five dependent
+// solves deep; four abreast it is two.  Per column the arithmetic is the one-column form's statement for statement: the broadcast
+// of coordinate i is `row_newbcast:i` inside the row instead of v_readlane, the relative-change sum is the same xor tree (its upper
+// levels added zeros), and a row whose column has met the stop takes no further step (1 / G_ii := 0 makes every later step exactly 0).
+// ---------------------------------------------------------------------------
+template <int I> __device__ __forceinline__ float sm_row_bcast(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x150 + I, 0xf, 0xf, true));
+}
+template <int I> __device__ __forceinline__ int sm_row_bcast(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x150 + I, 0xf, 0xf, true); }
+template <int I> __device__ __forceinline__ double sm_row_bcast(double v) {
+    const unsigned long long u = __double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)u, 0x150 + I, 0xf, 0xf, true);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), 0x150 + I, 0xf, 0xf, true);
+    return __longlong_as_double(((unsigned long long)hi << 32) | lo);
+}
+
+template <class T, bool CHOL>
+__device__ __forceinline__ T sm_half_update4(const int* __restrict__ cp, const int* __restrict__ ci, const T* __restrict__ cx, int ncols,
+                                             const T* F, T* X, T* Braw, int k, const T* Gl, const T* Ll, T l1, T ub, int nonneg, int warm, int maxit,
+                                             T tol, int norm_type, int gw, int nw, int lane) {
+    constexpr int KP = 16;
+    const int g = lane >> 4, f = lane & 15;
+    const bool fok = f < k;
+    T gcol[KP], lrow[KP];
+    T gd = T(1);
+    if constexpr (CHOL) {
+#pragma unroll
+        for (int c = 0; c < KP; ++c) { gcol[c] = Ll[f * KP + c]; lrow[c] = Ll[c * KP + f]; }
+        gd = Ll[f * KP + f];
+    } else {
+#pragma unroll
+        for (int c = 0; c < KP; ++c) { gcol[c] = Gl[c * KP + f]; lrow[c] = T(0); }
+        gd = Gl[f * KP + f];
+    }
+    const bool alive = fok && gd > T(0);
+    const T ginv = alive ? T(1) / gd : T(0);
+    const T pinf = static_cast<T>(__builtin_inff());
+    const T inf_rt = maxit >= 0 ? pinf : T(0);                     // +inf at run time (cd_static_max)
+    const bool check = tol > T(0);
+    const T inv_k = T(1) / static_cast<T>(k);
+    const T* Ff = F + (fok ? f : 0);
+    T nacc = T(0);
+    for (int j0 = 4 * gw; j0 < ncols; j0 += 4 * nw) {
+        const int j = j0 + g;
+        const bool cok = j < ncols;
+        // ---- sparse product: every row walks ITS column, sixteen entries per round trip, sixteen gathers in flight
+        const int start = cok ? cp[j] : 0, end = cok ? cp[j + 1] : 0;
+        T b = T(0);
+        for (int base = start; __any(base < end); base += 16) {
+            const int t = base + f;
+            const bool ok = t < end;
+            const int rv = ok ? ci[t] : 0;
+            const T vv = ok ? cx[t] : T(0);
+            T ff[16], va[16];
+            cd_static_for<0, 16>([&](auto IC) {
+                constexpr int u = decltype(IC)::value;
+                const int row = sm_row_bcast<u>(rv);
+                va[u] = sm_row_bcast<u>(vv);
+                ff[u] = (fok && base + u < end) ? sm_ldg(Ff + (int64_t)row * k) : T(0);
+            });
+#pragma unroll
+            for (int u = 0; u < 16; ++u) b = tfma(va[u], ff[u], b);
+        }
+        if (Braw && fok && cok) Braw[(int64_t)j * k + f] = b;
+        b = fok ? b - l1 : T(0);
+        T x;
+        if constexpr (CHOL) {
+            cd_static_for<0, KP>([&](auto IC) {                    // forward, then backward substitution (sm_chol_solve, inside the row)
+                constexpr int i = decltype(IC)::value;
+                const T yi = sm_row_bcast<i>(b / gd);
+                b = f == i ? yi : (f > i ? tfma(-lrow[i], yi, b) : b);
+            });
+            cd_static_for<0, KP>([&](auto IC) {
+                constexpr int i = KP - 1 - decltype(IC)::value;
+                const T xi = sm_row_bcast<i>(b / gd);
+                b = f == i ? xi : (f < i ? tfma(-gcol[i], xi, b) : b);
+            });
+            x = b;
+            if (nonneg) x = x > T(0) ? x : T(0);
+            x = (fok && cok) ? x : T(0);
+        } else {
+            x = (fok && cok) ? sm_ldg(X + (int64_t)j * k + f) : T(0);
+            if (warm) {
+                const T xw = x;
+                cd_static_for<0, KP>([&](auto IC) {
+                    constexpr int i = decltype(IC)::value;
+                    b = tfma(-gcol[i], sm_row_bcast<i>(xw), b);
+                });
+            }
+            bool act = cok;                                         // row-uniform: this row's column still sweeps
+            for (int it = 0; it < maxit; ++it) {
+                if (!__any(act)) break;
+                const T xe = !alive ? T(0) : (nonneg ? x : pinf);
+                const T gi = act ? ginv : T(0);
+                T aown = T(0);
+                cd_static_for<0, KP>([&](auto IC) {
+                    constexpr int i = decltype(IC)::value;
+                    const T diff = cd_static_diff(b, gd, gi, T(0));
+                    const T ad = cd_static_max(diff, -xe, inf_rt);
+                    const T ad_i = sm_row_bcast<i>(ad);
+                    b = tfma(-gcol[i], ad_i, b);
+                    aown = f == i ? ad_i : aown;
+                });
+                const T xn = x + aown;
+                const bool moved = xn != x;
+                x = xn;
+                if (check) {
+                    T term = fok ? (aown < T(0) ? -aown : aown) / ((x < T(0) ? -x : x) + T(1e-15)) : T(0);
+#pragma unroll
+                    for (int off = 8; off > 0; off >>= 1) term += shfl_xor_t(term, off);
+                    if (term * inv_k < tol) act = false;
+                } else {
+                    const unsigned long long mv = __ballot(moved);
+                    if (!((mv >> (lane & 48)) & 0xffffull)) act = false;
+                }
+            }
+        }
+        if (ub > T(0)) x = x < ub ? x : ub;
+        if (fok && cok) X[(int64_t)j * k + f] = x;
+        nacc += norm_type == 1 ? x * x : (x < T(0) ? -x : x);
+    }
+    nacc += shfl_xor_t(nacc, 16);                                   // the four rows' partial norms of factor f
+    nacc += shfl_xor_t(nacc, 32);
+    return nacc;
+}
+
 // Unblocked lower Cholesky of the KP x KP matrix in LDS (A(r, c) at [c * KP + r]) by ONE wavefront, lane = row, left-looking as
 // chol_factor_kernel above (Eigen::LLT, fused_nnls.hpp:185): L overwrites the lower triangle, the upper one is zeroed.
 template <class T, int KP>
@@ -244,6 +372,26 @@ __global__ __launch_bounds__(64 * SM_WPB) void als_small_kernel(SmallFit<T> P) {
         for (int c = 0; c < KP; ++c) g[c] = T(0);
         const T dv = scale ? dsh[f] : T(1);
         double cacc = 0.0;
+        if constexpr (KP == 16) {                                   // four columns abreast, one per 16-lane row (sm_half_update4's mapping)
+            const int gr = lane >> 4;
+            const bool f16 = f < k;
+            for (int j0 = 4 * gw; j0 < ncols; j0 += 4 * nw) {
+                const int j = j0 + gr;
+                const bool cok = f16 && j < ncols;
+                T x = cok ? sm_ldg(X + (int64_t)j * k + f) : T(0);
+                if (scale) {
+                    x = cok ? x / dv : T(0);
+                    if (cok) X[(int64_t)j * k + f] = x;
+                }
+                if (Bw && cok) cacc += static_cast<double>(dv) * static_cast<double>(x) * static_cast<double>(sm_ldg(Bw + (int64_t)j * k + f));
+                cd_static_for<0, KP>([&](auto IC) {
+                    constexpr int c = decltype(IC)::value;
+                    g[c] = tfma(x, sm_row_bcast<c>(x), g[c]);
+                });
+            }
+#pragma unroll
+            for (int c = 0; c < KP; ++c) { g[c] += shfl_xor_t(g[c], 16); g[c] += shfl_xor_t(g[c], 32); }
+        } else
         for (int j = gw; j < ncols; j += nw) {
             T x = fok ? sm_ldg(X + (int64_t)j * k + lane) : T(0);
             if (scale) {
@@ -360,29 +508,54 @@ __global__ __launch_bounds__(64 * SM_WPB) void als_small_kernel(SmallFit<T> P) {
     double prev_loss = sizeof(T) == 4 ? (double)3.402823466e+38f : 1.7976931348623157e308;
     int patience_counter = 0, iterations = 0, converged = 0;
     double final_tol = 0, train_loss = 0, last_loss = 0;
+    // where workgroup 0's time goes, in ticks of the 100 MHz wall clock: the fused half-updates | waiting at the four barriers (= the
+    // slowest workgroup's lead) | everything else; reported in result[5 .. 7]
+    long long tk_half = 0, tk_bar = 0;
+    const long long tk_start = wall_clock64();
     for (int iter = 0; iter < P.max_iter; ++iter) {
         const int warm = iter + P.iter0 > 0 ? 1 : 0;
         // ================= H half-update (fit_cpu.hpp:486-645)
         factor(Gh);
-        T nacc = sm_half_update<T, KP, CHOL>(P.Ap, P.Ai, P.Ax, n, P.W, P.H, nullptr, k, Gh, Lf, P.L1_H, P.ub_H, P.nonneg_H, warm, P.cd_maxit, P.cd_tol,
-                                             P.norm_type, gw, nw, lane);
+        T nacc;
+        long long tk0 = wall_clock64();
+        if (KP == 16 && n > nw)
+            nacc = sm_half_update4<T, CHOL>(P.Ap, P.Ai, P.Ax, n, P.W, P.H, nullptr, k, Gh, Lf, P.L1_H, P.ub_H, P.nonneg_H, warm, P.cd_maxit, P.cd_tol,
+                                            P.norm_type, gw, nw, lane);
+        else
+            nacc = sm_half_update<T, KP, CHOL>(P.Ap, P.Ai, P.Ax, n, P.W, P.H, nullptr, k, Gh, Lf, P.L1_H, P.ub_H, P.nonneg_H, warm, P.cd_maxit, P.cd_tol,
+                                               P.norm_type, gw, nw, lane);
+        tk_half += wall_clock64() - tk0;
         norm_store(nacc);
+        tk0 = wall_clock64();
         if (!sm_barrier(P.sync, gen, &sh_flag)) return;
+        tk_bar += wall_clock64() - tk0;
         norm_sum();                                                // :645 extract_scaling
         gram_pass(P.H, n, P.norm_type != 2, nullptr, nullptr);     // scaled H, and its Gram's partials
+        tk0 = wall_clock64();
         if (!sm_barrier(P.sync, gen, &sh_flag)) return;
+        tk_bar += wall_clock64() - tk0;
         // ================= W half-update (:711-893)
         gram_sum(Gsaved, T(0));                                    // :715-722 G_saved = gram(H) + eps
         for (int e = threadIdx.x; e < KP * KP; e += blockDim.x) { const int r = e % KP, c = e / KP; Gh[e] = Gsaved[e] + ((r == c && r < k) ? P.L2_W : T(0)); }
         __syncthreads();
         factor(Gh);
-        nacc = sm_half_update<T, KP, CHOL>(P.Tp, P.Ti, P.Tx, m, P.H, P.W, P.Bw, k, Gh, Lf, P.L1_W, P.ub_W, P.nonneg_W, warm, P.cd_maxit, P.cd_tol,
-                                           P.norm_type, gw, nw, lane);
+        tk0 = wall_clock64();
+        if (KP == 16 && m > nw)
+            nacc = sm_half_update4<T, CHOL>(P.Tp, P.Ti, P.Tx, m, P.H, P.W, P.Bw, k, Gh, Lf, P.L1_W, P.ub_W, P.nonneg_W, warm, P.cd_maxit, P.cd_tol,
+                                            P.norm_type, gw, nw, lane);
+        else
+            nacc = sm_half_update<T, KP, CHOL>(P.Tp, P.Ti, P.Tx, m, P.H, P.W, P.Bw, k, Gh, Lf, P.L1_W, P.ub_W, P.nonneg_W, warm, P.cd_maxit, P.cd_tol,
+                                               P.norm_type, gw, nw, lane);
+        tk_half += wall_clock64() - tk0;
         norm_store(nacc);
+        tk0 = wall_clock64();
         if (!sm_barrier(P.sync, gen, &sh_flag)) return;
+        tk_bar += wall_clock64() - tk0;
         norm_sum();                                                // :893
         gram_pass(P.W, m, P.norm_type != 2, P.Bw, P.crossp);       // scaled W_T, its Gram's partials, the cross term's partials
+        tk0 = wall_clock64();
         if (!sm_barrier(P.sync, gen, &sh_flag)) return;
+        tk_bar += wall_clock64() - tk0;
         // ================= loss (:1729-1753), formed by every workgroup for itself: identical arithmetic, identical decision
         gram_sum(Gwt, T(0));
         {
@@ -430,6 +603,7 @@ __global__ __launch_bounds__(64 * SM_WPB) void als_small_kernel(SmallFit<T> P) {
     if (!converged) train_loss = last_loss;
     if (me == 0 && threadIdx.x == 0) {
         P.result[0] = iterations; P.result[1] = converged; P.result[2] = train_loss; P.result[3] = final_tol; P.result[4] = 1.0;
+        P.result[5] = (double)tk_half; P.result[6] = (double)tk_bar; P.result[7] = (double)(wall_clock64() - tk_start);
     }
 }
 
