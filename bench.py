@@ -479,6 +479,14 @@ def main():
                                   "achieved": tf_w, "frac": tf_w / cd_peak, "avg_launch_ms": s_w * 1e3,
                                   "algorithmic_flops_per_launch": flops_w},
                        "both_sides": {"achieved": tf, "frac": tf / cd_peak, "avg_launch_ms": cd_s * 1e3}}
+            if mfma and f32:
+                # the kernel's own ceiling: per coordinate pair a wave issues ceil(k / 32) f32 MFMAs of 64 cycles each and a
+                # dependent chain of ~100 VALU / LDS cycles that cannot overlap them on gfx950 (profiles/r03_issue_probe.txt); idle slots and
+                # the residency tail come on top
+                mf = 64.0 * ((k + 31) // 32)
+                roof_cd["ceiling_frac"] = mf / (mf + 100.0)
+                roof_cd["ceiling_what"] = ("MFMA-issue share of a coordinate pair's cycles (%d MFMA + ~100 dependent VALU / LDS, mutually exclusive on "
+                                           "the f32 pipes): what `frac` would be with no idle column slot and no residency tail" % int(mf))
         cd_dominant = roof_cd is not None and (ms_sh + ms_sw) > (ms_h + ms_w)
         # HBM/fabric bytes per launch from the committed rocprofv3 PMC passes of this same command (FETCH_SIZE x2 per the
         # gfx950 correction + WRITE_SIZE, profiles/summarize.py); only meaningful for the default workload
