@@ -274,6 +274,8 @@ RCPPML_GPU_API int rcppml_hip_ctx_stats(rcppml_hip_ctx* ctx, int reset, unsigned
  * the columns rcppml_hip_solve_irls solved (nnls_batch_irls.hpp:480-560: each pass rebuilds the weighted Gram and solves),
  * out2[1] = the same weighted by the column's nonzeros = rank-1 updates f f^T of the weighted Grams (x 2 k_pad^2 = flops). */
 RCPPML_GPU_API int rcppml_hip_ctx_irls_stats(rcppml_hip_ctx* ctx, int reset, unsigned long long* out2);
+/* out1[0] = CD sweeps executed inside the IRLS half-updates (per column and pass, until the column's own fixed point); counted with the above */
+RCPPML_GPU_API int rcppml_hip_ctx_irls_sweep_stats(rcppml_hip_ctx* ctx, int reset, unsigned long long* out1);
 /* Per-(column, coordinate) step counters of the lane = column CD kernel (only while RCPPML_OPT_CD_COUNT_NOOP is set): out2[0] =
  * coordinate steps whose update is exactly 0 -- the steps the reference skips with `continue` (primitives/cpu/nnls_batch.hpp:
  * 102,106,109) and a dense sweep still executes --, out2[1] = all coordinate steps of live columns (warm-start correction

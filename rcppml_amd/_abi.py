@@ -22,7 +22,7 @@ EXPORTED_SYMBOLS = [
     "rcppml_gpu_detect", "rcppml_gpu_nmf_unified_float", "rcppml_gpu_nmf_unified_double", "rcppml_gpu_nmf_ex",
     "rcppml_gpu_nmf_cv_unified_float", "rcppml_gpu_nmf_cv_unified_double", "rcppml_gpu_nmf_cv_ex", "rcppml_gpu_nmf_cv_irls_ex", "rcppml_gpu_nmf_cv_masked_ex", "rcppml_hip_ctx_set_cv_mask", "rcppml_gpu_nmf_zerocopy_double",
     "rcppml_gpu_nnls_double", "rcppml_gpu_evaluate_mse_double", "rcppml_gpu_nmf_profile_double", "rcppml_gpu_last_error",
-    "rcppml_hip_ctx_create", "rcppml_hip_ctx_destroy", "rcppml_hip_ctx_sync", "rcppml_hip_ctx_stats", "rcppml_hip_ctx_irls_stats", "rcppml_hip_ctx_cd_step_stats", "rcppml_hip_ctx_set_option", "rcppml_hip_transpose_csc", "rcppml_hip_transpose_csc_sort", "rcppml_hip_transpose_csc_gather", "rcppml_hip_cast", "rcppml_hip_gram", "rcppml_hip_rhs",
+    "rcppml_hip_ctx_create", "rcppml_hip_ctx_destroy", "rcppml_hip_ctx_sync", "rcppml_hip_ctx_stats", "rcppml_hip_ctx_irls_stats", "rcppml_hip_ctx_irls_sweep_stats", "rcppml_hip_ctx_cd_step_stats", "rcppml_hip_ctx_set_option", "rcppml_hip_transpose_csc", "rcppml_hip_transpose_csc_sort", "rcppml_hip_transpose_csc_gather", "rcppml_hip_cast", "rcppml_hip_gram", "rcppml_hip_rhs",
     "rcppml_hip_solve_cd", "rcppml_hip_order_columns", "rcppml_hip_solve_chol", "rcppml_hip_row_norms", "rcppml_hip_apply_scaling",
     "rcppml_hip_sumsq", "rcppml_hip_loss_mse", "rcppml_hip_solve_masked", "rcppml_hip_loss_nonzeros", "rcppml_hip_loss_masked",
     "rcppml_hip_solve_irls_nb", "rcppml_hip_nb_size_update", "rcppml_hip_nb_size_update_loss", "rcppml_hip_nb_loss", "rcppml_hip_solve_irls", "rcppml_hip_rhs_plan_kind", "rcppml_hip_irls_loss", "rcppml_hip_apply_l21", "rcppml_hip_angular_posthoc", "rcppml_hip_solve_cv", "rcppml_hip_cv_test_error", "rcppml_hip_solve_cv_irls", "rcppml_hip_cv_irls_loss", "rcppml_hip_cv_gp_theta_update", "rcppml_hip_mul_rows", "rcppml_hip_apply_graph_reg", "rcppml_hip_dispersion_update", "rcppml_hip_vec_global", "rcppml_hip_spz_info", "rcppml_hip_spz_decode",
@@ -436,7 +436,9 @@ class Context:
         """IRLS work counters (only counted while OPT_CD_COUNT_NOOP is set): passes over columns, nonzero-passes."""
         out = (C.c_ulonglong * 2)()
         _chk(lib().rcppml_hip_ctx_irls_stats(self._h, C.c_int(1 if reset else 0), out), "ctx_irls_stats")
-        return dict(irls_column_passes=int(out[0]), irls_nonzero_passes=int(out[1]))
+        sw = (C.c_ulonglong * 1)()
+        _chk(lib().rcppml_hip_ctx_irls_sweep_stats(self._h, C.c_int(1 if reset else 0), sw), "ctx_irls_sweep_stats")
+        return dict(irls_column_passes=int(out[0]), irls_nonzero_passes=int(out[1]), irls_cd_sweeps=int(sw[0]))
 
     def transpose_csc(self, dt, rows, cols, col_ptr, row_idx, values, t_col_ptr, t_row_idx, t_values):
         _chk(lib().rcppml_hip_transpose_csc(self._h, C.c_int(dt), C.c_int(rows), C.c_int(cols), _dptr(col_ptr), _dptr(row_idx),

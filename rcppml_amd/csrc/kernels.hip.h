@@ -111,7 +111,7 @@ __device__ __forceinline__ T cd_static_one_sweep(T& b, T xe, T gd, T ginv, T nl1
     return aown;
 }
 template <class T, int KP, class GC>
-__device__ __forceinline__ void cd_static_sweeps(T& b, T& x, T gd, bool fok, T l1, int nonneg, int maxit, GC&& gcol) {
+__device__ __forceinline__ int cd_static_sweeps(T& b, T& x, T gd, bool fok, T l1, int nonneg, int maxit, GC&& gcol) {      // returns the sweeps executed
     const bool alive = fok && gd > T(0);
     const T ginv = alive ? T(1) / gd : T(0);          // one division per solve
     const T nl1 = alive ? -l1 : T(0);
@@ -123,8 +123,9 @@ __device__ __forceinline__ void cd_static_sweeps(T& b, T& x, T gd, bool fok, T l
         const T xn = x + aown;
         const bool moved = xn != x;
         x = xn;
-        if (!__any(moved)) break;              // no effective step, or the iterate is at its floating-point fixed point
+        if (!__any(moved)) return it + 1;      // no effective step, or the iterate is at its floating-point fixed point
     }
+    return maxit > 0 ? maxit : 0;
 }
 // The same sweeps with the reference's relative-change stop (explicit-mask solver, small-side MSE solver: cd_nnls with cd_tol, no
 // L1 inside the step): the sum of |a_i| / (|x_i| + 1e-15) is one division per lane and a wave reduction per sweep (xor tree: the
@@ -157,8 +158,8 @@ __device__ __forceinline__ int cd_static_sweeps_tol(T& b, T& x, T gd, bool fok, 
 // exact arithmetic, and the quotient's fma leaves the chain -- med3 -> readlane -> fma per coordinate.  Rounding differs from
 // b * (1/G_ii) by an ulp here and there (fp32 fast path only; the fp64 kernels keep b).  gcol[] is overwritten.
 template <int KP>
-__device__ __forceinline__ void cd_static_sweeps_scaled_f32(float b, float& x, float gd, bool fok, float l1, int nonneg, int maxit,
-                                                            float (&gcol)[KP]) {
+__device__ __forceinline__ int cd_static_sweeps_scaled_f32(float b, float& x, float gd, bool fok, float l1, int nonneg, int maxit,
+                                                           float (&gcol)[KP]) {      // returns the sweeps executed
     const bool alive = fok && gd > 0.f;
     const float ginv = alive ? 1.f / gd : 0.f;
     const float pinf = __builtin_inff();
@@ -179,12 +180,13 @@ __device__ __forceinline__ void cd_static_sweeps_scaled_f32(float b, float& x, f
         const float xn = x + aown;
         const bool moved = xn != x;
         x = xn;
-        if (!__any(moved)) break;
+        if (!__any(moved)) return it + 1;
     }
+    return maxit > 0 ? maxit : 0;
 }
 template <int KP, class GC>
-__device__ __forceinline__ void cd_static_sweeps_f32(float& b, float& x, float gd, bool fok, float l1, int nonneg, int maxit, GC&& gcol) {
-    cd_static_sweeps<float, KP>(b, x, gd, fok, l1, nonneg, maxit, gcol);
+__device__ __forceinline__ int cd_static_sweeps_f32(float& b, float& x, float gd, bool fok, float l1, int nonneg, int maxit, GC&& gcol) {
+    return cd_static_sweeps<float, KP>(b, x, gd, fok, l1, nonneg, maxit, gcol);
 }
 
 __device__ __forceinline__ float shfl_xor_t(float v, int m) { return __shfl_xor(v, m, 64); }

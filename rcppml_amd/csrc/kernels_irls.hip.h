@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256) void irls_nb_solve_kernel(
     const int as = colptr[j], ae = colptr[j + 1];
     const T th_col = theta_col ? theta_col[j] : T(0);
     T x = T(0);                                   // nnls_batch_irls.hpp:482-483  H.setZero(): no warm start
-    int passes = 0;
+    int passes = 0, nsw = 0;      // IRLS passes; CD sweeps executed over all passes (work counters)
     for (int irls = 0; irls < irls_max_iter; ++irls) {
         ++passes;
         T gw[KP];
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(256) void irls_nb_solve_kernel(
         // cd_nnls_col_fixed(G_w, b_c, x, L1 inside, L2 = 0, nonneg, cd_maxit, ub = 0, tol = 0): all sweeps
         // static coordinate sweeps (cd_static_sweeps, kernels.hip.h): the lane's Gram column read from the wave's LDS tile at
         // compile-time offsets
-        cd_static_sweeps<T, KP>(b, x, gd, fok, l1, nonneg, cd_maxit, [&](auto IC) { return Gl[decltype(IC)::value * KP + ll]; });
+        nsw += cd_static_sweeps<T, KP>(b, x, gd, fok, l1, nonneg, cd_maxit, [&](auto IC) { return Gl[decltype(IC)::value * KP + ll]; });
         // IRLS convergence: max_i |x_i - x_old_i| / (|x_old_i| + 1e-12) < irls_tol
         T rel = fok ? tabs(x - x_old) / (tabs(x_old) + T(1e-12)) : T(0);
         rel = wave_max(rel);
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(256) void irls_nb_solve_kernel(
     }
     if (fok) X[j * (int64_t)k + lane] = x;
     // work counters (RCPPML_OPT_CD_COUNT_NOOP only): IRLS passes and nonzero-passes = weighted-Gram rank-1 updates
-    if (stats && lane == 0) { atomicAdd(stats, (unsigned long long)passes); atomicAdd(stats + 1, (unsigned long long)passes * (unsigned long long)(ae - as)); }
+    if (stats && lane == 0) { atomicAdd(stats, (unsigned long long)passes); atomicAdd(stats + 1, (unsigned long long)passes * (unsigned long long)(ae - as)); atomicAdd(stats + 4, (unsigned long long)nsw); }
 }
 
 // ---------------------------------------------------------------------------
@@ -250,7 +250,7 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8
     const int as = colptr[j], ae = colptr[j + 1];
     const float th_col = theta_col ? theta_col[j] : 0.f;
     float x = 0.f;                                      // nnls_batch_irls.hpp:482-483  H.setZero(): no warm start
-    int passes = 0;
+    int passes = 0, nsw = 0;      // IRLS passes; CD sweeps executed over all passes (work counters)
     for (int irls = 0; irls < irls_max_iter; ++irls) {
         ++passes;
         // accumulator tile <- base Gram (identity padding), C/D map: col = lane&31, row = (v&3) + 8(v>>2) + 4(lane>>5)
@@ -367,7 +367,7 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8
             float gg[KP];
 #pragma unroll
             for (int c = 0; c < KP; ++c) gg[c] = gcol[c];
-            cd_static_sweeps_scaled_f32<KP>(b, x, gd, fok, l1, nonneg, cd_maxit, gg);
+            nsw += cd_static_sweeps_scaled_f32<KP>(b, x, gd, fok, l1, nonneg, cd_maxit, gg);
         }
         float rel = fok ? tabs(x - x_old) / (tabs(x_old) + 1e-12f) : 0.f;
         rel = wave_max(rel);
@@ -376,7 +376,7 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8
     }
     if (fok) X[j * (int64_t)k + lane] = x;
     // work counters (RCPPML_OPT_CD_COUNT_NOOP only): IRLS passes and nonzero-passes = weighted-Gram rank-1 updates
-    if (stats && lane == 0) { atomicAdd(stats, (unsigned long long)passes); atomicAdd(stats + 1, (unsigned long long)passes * (unsigned long long)(ae - as)); }
+    if (stats && lane == 0) { atomicAdd(stats, (unsigned long long)passes); atomicAdd(stats + 1, (unsigned long long)passes * (unsigned long long)(ae - as)); atomicAdd(stats + 4, (unsigned long long)nsw); }
 }
 
 // ---------------------------------------------------------------------------
@@ -421,7 +421,7 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4
     const bool fok0 = l < k, fok1 = l + 16 < k;
     bool active = jme < ncols;                          // uniform over a row
     float x0 = 0.f, x1 = 0.f;                           // nnls_batch_irls.hpp:482-483  H.setZero(): no warm start
-    int passes = 0;
+    int passes = 0, nsw = 0;      // IRLS passes; CD sweeps executed over all passes (work counters)
     float ng0[KP], ng1[KP];                             // rows l and l + 16 of the column's Gram, then of -G_w / G_ii
 #pragma unroll
     for (int c = 0; c < KP; ++c) { ng0[c] = 0.f; ng1[c] = 0.f; }
@@ -563,7 +563,9 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4
         float d1 = __builtin_fmaf(active ? b1 : 0.f, ginv1, alive1 ? -l1 : 0.f);
         unsigned long long lane0_of_rows = 0x0001000100010001ull;
         asm volatile("" : "+s"(lane0_of_rows));        // opaque: shifted at run time, not sixteen 64-bit literals
+        bool rowdone = !active;                          // (work counter: a row's sweeps until its own fixed point)
         for (int it = 0; it < cd_maxit; ++it) {
+            nsw += rowdone ? 0 : 1;
             const float xe0 = nonneg ? x0 : pinf, xe1 = nonneg ? x1 : pinf;
             float aown0 = 0.f, aown1 = 0.f;
             const float nxe0 = -xe0, nxe1 = -xe1;
@@ -594,7 +596,7 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4
             if (!mv) break;
             // a column none of whose coordinates moved is at the fixed point the one-column kernel stops at: zero residuals make
             // every later step of its row exactly zero (the columns sharing the wave may need more sweeps)
-            if (!((mv >> (lane & 48)) & 0xffffull)) { d0 = 0.f; d1 = 0.f; }
+            if (!((mv >> (lane & 48)) & 0xffffull)) { d0 = 0.f; d1 = 0.f; rowdone = true; }
         }
         float rel = fok0 ? tabs(x0 - xo0) / (tabs(xo0) + 1e-12f) : 0.f;
         const float rel1 = fok1 ? tabs(x1 - xo1) / (tabs(xo1) + 1e-12f) : 0.f;
@@ -615,6 +617,7 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4
             const int nzc = colptr[jme + 1] - colptr[jme];
             atomicAdd(stats, (unsigned long long)passes);
             atomicAdd(stats + 1, (unsigned long long)passes * (unsigned long long)nzc);
+            atomicAdd(stats + 4, (unsigned long long)nsw);
         }
     }
 }
@@ -649,7 +652,7 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2
     const int as = colptr[j], ae = colptr[j + 1];
     const float th_col = theta_col ? theta_col[j] : 0.f;
     float x = 0.f;                                      // nnls_batch_irls.hpp:482-483  H.setZero(): no warm start
-    int passes = 0;
+    int passes = 0, nsw = 0;      // IRLS passes; CD sweeps executed over all passes (work counters)
     for (int irls = 0; irls < irls_max_iter; ++irls) {
         ++passes;
         // accumulator tiles <- base Gram (identity padding); C/D map of a tile: col = lane&31, row = (v&3) + 8(v>>2) + 4(lane>>5)
@@ -747,7 +750,7 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2
             float gg[KP];
 #pragma unroll
             for (int c = 0; c < 32; ++c) { gg[c] = gcol0[c]; gg[32 + c] = gcol1[c]; }
-            cd_static_sweeps_scaled_f32<KP>(b, x, gd, fok, l1, nonneg, cd_maxit, gg);
+            nsw += cd_static_sweeps_scaled_f32<KP>(b, x, gd, fok, l1, nonneg, cd_maxit, gg);
         }
         float rel = fok ? tabs(x - x_old) / (tabs(x_old) + 1e-12f) : 0.f;
         rel = wave_max(rel);
@@ -756,7 +759,7 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2
     }
     if (fok) X[j * (int64_t)k + lane] = x;
     // work counters (RCPPML_OPT_CD_COUNT_NOOP only): IRLS passes and nonzero-passes = weighted-Gram rank-1 updates
-    if (stats && lane == 0) { atomicAdd(stats, (unsigned long long)passes); atomicAdd(stats + 1, (unsigned long long)passes * (unsigned long long)(ae - as)); }
+    if (stats && lane == 0) { atomicAdd(stats, (unsigned long long)passes); atomicAdd(stats + 1, (unsigned long long)passes * (unsigned long long)(ae - as)); atomicAdd(stats + 4, (unsigned long long)nsw); }
 }
 
 // ---------------------------------------------------------------------------
@@ -789,7 +792,7 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8
     const int as = colptr[j], ae = colptr[j + 1];
     const double th_col = theta_col ? theta_col[j] : 0.0;
     double x = 0.0;
-    int passes = 0;
+    int passes = 0, nsw = 0;      // IRLS passes; CD sweeps executed over all passes (work counters)
     for (int irls = 0; irls < irls_max_iter; ++irls) {
         ++passes;
         f64x4 acc[2][2];
@@ -874,7 +877,7 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8
             b = tfma(-Gl[c * KP + ll], xc, b);
         }
         const double gd = Gl[ll * KP + ll];
-        cd_static_sweeps<double, KP>(b, x, gd, fok, l1, nonneg, cd_maxit, [&](auto IC) { return Gl[decltype(IC)::value * KP + ll]; });
+        nsw += cd_static_sweeps<double, KP>(b, x, gd, fok, l1, nonneg, cd_maxit, [&](auto IC) { return Gl[decltype(IC)::value * KP + ll]; });
         double rel = fok ? tabs(x - x_old) / (tabs(x_old) + 1e-12) : 0.0;
         rel = wave_max(rel);
         __builtin_amdgcn_wave_barrier();
@@ -882,7 +885,7 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8
     }
     if (fok) X[j * (int64_t)k + lane] = x;
     // work counters (RCPPML_OPT_CD_COUNT_NOOP only): IRLS passes and nonzero-passes = weighted-Gram rank-1 updates
-    if (stats && lane == 0) { atomicAdd(stats, (unsigned long long)passes); atomicAdd(stats + 1, (unsigned long long)passes * (unsigned long long)(ae - as)); }
+    if (stats && lane == 0) { atomicAdd(stats, (unsigned long long)passes); atomicAdd(stats + 1, (unsigned long long)passes * (unsigned long long)(ae - as)); atomicAdd(stats + 4, (unsigned long long)nsw); }
 }
 
 // NB size (r) method-of-moments update, one wavefront per ROW i of A (= column i of A^T):

@@ -20,8 +20,8 @@ extern "C" int rcppml_hip_ctx_create(rcppml_hip_ctx** out, int device, void* str
         hipDeviceProp_t prop;
         HIPCHK(hipGetDeviceProperties(&prop, device));
         c->num_cu = prop.multiProcessorCount;
-        HIPCHK(hipMalloc(&c->stats, 8 * sizeof(unsigned long long)));
-        HIPCHK(hipMemset(c->stats, 0, 8 * sizeof(unsigned long long)));
+        HIPCHK(hipMalloc(&c->stats, 12 * sizeof(unsigned long long)));
+        HIPCHK(hipMemset(c->stats, 0, 12 * sizeof(unsigned long long)));
         *out = c;
         return 0;
     }
@@ -73,6 +73,17 @@ extern "C" int rcppml_hip_ctx_irls_stats(rcppml_hip_ctx* c, int reset, unsigned 
         HIPCHK(hipStreamSynchronize(c->stream));
         if (out2) HIPCHK(hipMemcpy(out2, c->stats + 4, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
         if (reset) HIPCHK(hipMemset(c->stats + 4, 0, 2 * sizeof(unsigned long long)));
+        return 0;
+    }
+    RCPPML_CATCH_RET
+}
+
+// [8]: CD sweeps executed inside the IRLS half-updates (per column and pass, until the column's fixed point; counted with the passes)
+extern "C" int rcppml_hip_ctx_irls_sweep_stats(rcppml_hip_ctx* c, int reset, unsigned long long* out1) {
+    try {
+        HIPCHK(hipStreamSynchronize(c->stream));
+        if (out1) HIPCHK(hipMemcpy(out1, c->stats + 8, sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        if (reset) HIPCHK(hipMemset(c->stats + 8, 0, sizeof(unsigned long long)));
         return 0;
     }
     RCPPML_CATCH_RET
