@@ -932,6 +932,8 @@ void fit_cv(CvParams& P) {
             // ---- GP theta over the training entries (:866-961).  (The NB size and the Gamma-family phi the reference also
             // estimates here reach neither the CV weights, nor the CV losses, nor anything this boundary returns.)
             if (is_gp && P.dispersion_mode != 0)
+                // (the user mask is NOT handed to this update: the reference's MM update skips held-out entries only -- `mask.is_holdout`,
+                // nmf/fit_cv.hpp:866-961 -- and sums over user-masked ones like any other training entry; checked for ADVICE r5)
                 OPCHK(rcppml_hip_cv_gp_theta_update(c, dt, P.dispersion_mode, dTp.as<int>(), dTi.as<int>(), dTx.p, m, P.nnz, dW.p, dd.p, dH.p,
                                                     n, k, P.holdout_fraction, P.cv_seed, P.gp_theta_max, dtheta.p));
             // ---- per-element losses (:1377-1443, :1546-1549)

@@ -171,7 +171,32 @@ def test_bench_c5_line_reduced_shape():
     for roof in (d["roofline"], d["roofline_other_side"]):
         assert 1.0 <= roof["mean_passes_per_column"] <= 5.0 and roof["nonzero_passes"] >= d["config"]["nnz_per_gpu"]
         assert 0 < roof["frac"] < 1
+        # the CD sweeps of the per-pass solves are counted by the kernels and are part of `frac` since round 6: between 1 and cd_maxit
+        # per column and pass, and the weighted-Gram share alone is the smaller figure of rounds 3-5
+        assert 1.0 <= roof["mean_sweeps_per_column_pass"] <= 100.0 and 0 < roof["frac_weighted_gram_only"] < roof["frac"]
     assert d["roofline"]["bound"] == "mfma" and abs(d["roofline"]["frac"] - d["roofline"]["achieved"] / d["roofline"]["peak"]) < 1e-9
     assert set(d["phases_ms_per_step"]) >= {"gram", "solve_H", "solve_W", "scale", "nb_size_loss"}
     assert d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["cores"] >= 1
     assert d["final_loss"] == d["final_loss"]          # finite, not NaN
+
+
+def test_bench_c1_line_one_kernel_fit():
+    """--config c1: BASELINE configs[0] (hawaiibirds, k = 10) as one persistent kernel: the line's step is an iteration inside the
+    kernel, `inside_the_kernel` accounts for workgroup 0's clock, the same fit from the start and on the multi-launch loop are beside
+    it, and the loss stays within the fp32 bar of the CPU reference fit."""
+    for solver in ("cd", "chol"):
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--config", "c1", "--solver", solver, "--steps", "6", "--warmup", "3"]
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+        assert out.returncode == 0, out.stderr[-2000:]
+        d = json.loads(out.stdout.strip().splitlines()[-1])
+        assert d["config"]["rows"] == 183 and d["config"]["cols_per_gpu"] == 1183 and d["config"]["nnz_per_gpu"] == 30815 and d["config"]["k"] == 10
+        assert d["steps"] == 6 and d["warmup"] == 3 and d["n_gpus"] == 1 and d["unit"] == "cols/s" and d["vs_baseline"] is None
+        assert abs(d["value"] - (183 + 1183) / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
+        ins = d["inside_the_kernel"]
+        assert 0 < ins["half_updates_us"] < ins["kernel_us"] and 0 <= ins["barrier_wait_us"] < ins["kernel_us"]
+        assert ins["kernel_us"] <= d["ms_per_step"] * 1e3 * 1.05          # the kernel's own clock cannot exceed the host's bracket
+        assert d["fit_from_start"]["ms_per_step"] > 0 and d["multi_launch"]["ms_per_step"] > 0
+        assert d["plugin_pcie_inclusive"]["one_kernel"]["status"] == 0 and d["plugin_pcie_inclusive"]["multi_launch"]["status"] == 0
+        assert abs(d["plugin_pcie_inclusive"]["one_kernel"]["loss"] - d["plugin_pcie_inclusive"]["multi_launch"]["loss"]) <= 2e-4 * abs(d["plugin_pcie_inclusive"]["multi_launch"]["loss"])
+        assert 0 <= d["loss_rel_dev_vs_cpu_ref"] < 2e-4 and d["cpu_baseline"]["value"] > 0
+        assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(d["roofline"])
