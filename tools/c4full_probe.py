@@ -37,7 +37,7 @@ W0, H0 = W0.astype(np.float64), H0.astype(np.float64)
 say("factors drawn")
 
 
-def plugin(ndev, w_solve=None, iters=2):
+def plugin(ndev, w_solve=None, iters=2, precision=None):
     W, H = W0.copy(), H0.copy()
     env = dict(RCPPML_GPU_DEVICES=str(ndev) if ndev > 1 else None, RCPPML_GPU_DEVICES_SHARE="1" if ndev > 1 else None, RCPPML_GPU_W_SOLVE=w_solve)
     for k_, v in env.items():
@@ -46,7 +46,7 @@ def plugin(ndev, w_solve=None, iters=2):
         else:
             os.environ[k_] = v
     t = time.perf_counter()
-    res = _abi.nmf_unified(A.p, A.i, A.x, A.rows, A.cols, K, W, H, entry="ex", precision=_abi.F32, max_iter=iters, tol=0.0, solver_mode=0,
+    res = _abi.nmf_unified(A.p, A.i, A.x, A.rows, A.cols, K, W, H, entry="ex", precision=_abi.F32 if precision is None else precision, max_iter=iters, tol=0.0, solver_mode=0,
                            sort_model=0, want_history=True, verbose=2)
     say("plugin ndev=%d w_solve=%s: status %d %s, %.1f s, loss history %s" % (ndev, w_solve, res["status"], res.get("error", ""), time.perf_counter() - t,
                                                                              res.get("loss_history")))
@@ -55,6 +55,11 @@ def plugin(ndev, w_solve=None, iters=2):
 
 if "p1" in stages:
     plugin(1)
+if "p1f64" in stages:          # parity mode at full extent: 1024-byte rows in the window kernel, eight row tiles in the fp64 MFMA solve
+    r64, W64, H64 = plugin(1, precision=_abi.F64)
+    r32, W32, H32 = plugin(1)
+    say("fp64 vs fp32 at full extent: loss %s vs %s, max |dW| / max W %.2e, max |dH| / max H %.2e" % (
+        r64.get("loss_history"), r32.get("loss_history"), np.abs(W64 - W32).max() / W64.max(), np.abs(H64 - H32).max() / H64.max()))
 if "p8" in stages:
     plugin(8)
     plugin(8, "block")
