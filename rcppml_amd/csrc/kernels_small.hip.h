@@ -24,7 +24,7 @@
 
 namespace rk {
 
-constexpr int SM_WPB = 8;                       // wavefronts per workgroup
+constexpr int SM_WPB = 12;                      // wavefronts per workgroup (three per SIMD: the kernel's variants need <= 168 VGPRs)
 constexpr int SM_NB = 32;                       // participating workgroups (one XCD: 32 CUs)
 
 template <class T>
@@ -316,26 +316,31 @@ __device__ __forceinline__ T sm_half_update4(const int* __restrict__ cp, const i
     return nacc;
 }
 
-// Unblocked lower Cholesky of the KP x KP matrix in LDS (A(r, c) at [c * KP + r]) by ONE wavefront, lane = row, left-looking as
-// chol_factor_kernel above (Eigen::LLT, fused_nnls.hpp:185): L overwrites the lower triangle, the upper one is zeroed.
+// Unblocked lower Cholesky of the KP x KP matrix in LDS (A(r, c) at [c * KP + r]) by ONE wavefront, left-looking as chol_factor_kernel
+// above (Eigen::LLT, fused_nnls.hpp:185): lane = row holds its row in REGISTERS, L(j, p) reaches the other rows by v_readlane -- a
+// dependent chain of ~KP^2 / 2 fmas instead of as many LDS round trips (the LDS form cost ~5 us per factorisation at KP = 16, twice
+// per iteration while seven waves wait).  L overwrites the lower triangle, the upper one is zeroed.
 template <class T, int KP>
 __device__ __forceinline__ void sm_chol_factor(T* A, int lane) {
-    for (int j = 0; j < KP; ++j) {
-        T s = T(0);
-        if (lane >= j && lane < KP) {
-            s = A[j * KP + lane];
-            for (int p = 0; p < j; ++p) s -= A[p * KP + lane] * A[p * KP + j];
-        }
-        T djj = __shfl(s, j, 64);
+    const int r = lane % KP;
+    T a[KP];
+#pragma unroll
+    for (int c = 0; c < KP; ++c) a[c] = A[c * KP + r];
+    cd_static_for<0, KP>([&](auto JC) {
+        constexpr int j = decltype(JC)::value;
+        T sv = a[j];
+        cd_static_for<0, j>([&](auto PC) {
+            constexpr int pp = decltype(PC)::value;
+            sv -= a[pp] * lane_value(a[pp], j);                     // L(r, p) L(j, p): row j's entries p < j are final
+        });
+        T djj = lane_value(sv, j);
         if (!(djj > T(0))) djj = tabs(djj) + T(1e-30);
         const T ljj = sqrt(djj);
-        if (lane >= j && lane < KP) A[j * KP + lane] = lane == j ? ljj : s / ljj;
-        __builtin_amdgcn_wave_barrier();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    }
-    for (int e = lane; e < KP * KP; e += 64) {
-        const int r = e % KP, c = e / KP;
-        if (r < c) A[e] = T(0);
+        a[j] = r == j ? ljj : sv / ljj;                            // (rows above j hold garbage here: zeroed on the way out)
+    });
+    if (lane < KP) {
+#pragma unroll
+        for (int c = 0; c < KP; ++c) A[c * KP + r] = r >= c ? a[c] : T(0);
     }
     __builtin_amdgcn_wave_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -349,6 +354,8 @@ __global__ __launch_bounds__(64 * SM_WPB) void als_small_kernel(SmallFit<T> P) {
     __shared__ T Gh[KP * KP], Gsaved[KP * KP], Gwt[KP * KP], Lf[CHOL ? KP * KP : 1];
     __shared__ T dsh[KP], nsh[KP];
     __shared__ T red_t[64 * SM_WPB];
+    __shared__ T wnorm[SM_WPB * KP];
+    __shared__ T wtile[KP == 16 ? SM_WPB * KP * KP : 1];
     __shared__ double red[64];
     __shared__ double sh_loss[2];
     if (threadIdx.x == 0) sh_ticket = __hip_atomic_fetch_add(P.sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -404,15 +411,31 @@ __global__ __launch_bounds__(64 * SM_WPB) void als_small_kernel(SmallFit<T> P) {
                 g[c] = tfma(x, lane_value(x, c), g[c]);
             });
         }
-        T* dst = Gwt;                                               // workgroup accumulator (every caller re-reads the sum from `part`)
-        for (int w = 0; w < SM_WPB; ++w) {
-            if (wave == w && lane < KP) {
+        if constexpr (KP == 16) {
+            // every wave parks its partial tile in its own LDS slot, then one pass adds the slots in wave order (one barrier instead of
+            // one per wave)
+            if (lane < KP) {
 #pragma unroll
-                for (int c = 0; c < KP; ++c) dst[c * KP + lane] = w == 0 ? g[c] : dst[c * KP + lane] + g[c];
+                for (int c = 0; c < KP; ++c) wtile[wave * KP * KP + c * KP + lane] = g[c];
             }
             __syncthreads();
+            for (int e = threadIdx.x; e < KP * KP; e += blockDim.x) {
+                T sv = wtile[e];
+                for (int w = 1; w < SM_WPB; ++w) sv += wtile[w * KP * KP + e];
+                P.part[(size_t)me * PS + KP + e] = sv;
+            }
+            __syncthreads();
+        } else {
+            T* dst = Gwt;                                           // workgroup accumulator (every caller re-reads the sum from `part`)
+            for (int w = 0; w < SM_WPB; ++w) {
+                if (wave == w && lane < KP) {
+#pragma unroll
+                    for (int c = 0; c < KP; ++c) dst[c * KP + lane] = w == 0 ? g[c] : dst[c * KP + lane] + g[c];
+                }
+                __syncthreads();
+            }
+            for (int e = threadIdx.x; e < KP * KP; e += blockDim.x) P.part[(size_t)me * PS + KP + e] = dst[e];
         }
-        for (int e = threadIdx.x; e < KP * KP; e += blockDim.x) P.part[(size_t)me * PS + KP + e] = dst[e];
         if (cross_out) {
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) cacc += __shfl_xor(cacc, off, 64);
@@ -431,11 +454,10 @@ __global__ __launch_bounds__(64 * SM_WPB) void als_small_kernel(SmallFit<T> P) {
     // so every workgroup forms bitwise the same sums.
     auto part_sum = [&](int off, int count, T* dst) {
         constexpr int NT = 64 * SM_WPB;
-        int groups = NT / count;                                    // count in {16, 32, 256, 1024}
-        if (groups > SM_NB) groups = SM_NB;
-        if (groups < 1) groups = 1;
-        const int per = SM_NB / groups;                              // workgroups per group (SM_NB and groups are powers of two)
-        const int epp = NT / groups;                                 // values per pass
+        int groups = 1;                                             // a power of two <= min(NT / count, SM_NB); count in {16, 32, 256, 1024}
+        while (2 * groups * count <= NT && 2 * groups <= SM_NB) groups *= 2;
+        const int per = SM_NB / groups;                              // workgroups per group
+        const int epp = count < NT ? count : NT;                     // values per pass (threads beyond groups * epp idle)
         for (int e0 = 0; e0 < count; e0 += epp) {
             const int e = e0 + (int)threadIdx.x % epp, h = (int)threadIdx.x / epp;
             if (e < count && h < groups) {
@@ -473,11 +495,14 @@ __global__ __launch_bounds__(64 * SM_WPB) void als_small_kernel(SmallFit<T> P) {
     // workgroup sum of the waves' partial row norms -> part[me][0 .. KP)
     auto norm_store = [&](T nacc) {
         // (only the lanes below k hold a coordinate: the others carry zeros)
-        for (int w = 0; w < SM_WPB; ++w) {
-            if (wave == w && lane < KP) nsh[lane] = w == 0 ? nacc : nsh[lane] + nacc;
-            __syncthreads();
+        if (lane < KP) wnorm[wave * KP + lane] = nacc;
+        __syncthreads();
+        if (threadIdx.x < KP) {
+            T sv = wnorm[threadIdx.x];
+            for (int w = 1; w < SM_WPB; ++w) sv += wnorm[w * KP + threadIdx.x];          // wave order
+            P.part[(size_t)me * PS + threadIdx.x] = sv;
         }
-        if (threadIdx.x < KP) P.part[(size_t)me * PS + threadIdx.x] = nsh[threadIdx.x];
+        __syncthreads();
     };
     // after a barrier: d from the summed row norms (scaling_finalize above): dsh, and the caller's d
     auto norm_sum = [&]() {
