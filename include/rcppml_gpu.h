@@ -439,7 +439,8 @@ RCPPML_GPU_API int rcppml_hip_tail_scale_gram_loss(rcppml_hip_ctx* ctx, int dtyp
  * iteration (fit_cpu.hpp:1729-1753) and the convergence rule (:1769-1809) evaluated on the device -- no launch per phase, no host
  * round trip per iteration.  The iteration's grid-wide dependencies are barriers inside the kernel among 32 workgroups that all
  * sit on XCD 0 (one L2: a relaxed L2 atomic + an L1 invalidate, 0.8 us; profiles/r06_grid_barrier.txt).
- * rcppml_hip_als_small_eligible: k <= 32, (m + n) k^2 <= 4e5, nnz <= 2^18 (hawaiibirds; movielens at k = 32 is not).
+ * rcppml_hip_als_small_eligible: where the kernel PAYS and the plugin takes it -- k <= 16, m + n <= 3072, nnz <= 2^17 (measured:
+ * profiles/r06_small_threshold.txt; hawaiibirds is, movielens at k = 32 is not); rcppml_hip_als_small_fit itself accepts k <= 32, nnz <= 2^20, m + n <= 65536.
  * CSC(A) and CSC(A^T) with sorted rows; W (k x m), H (k x n) in / out, d (k) out; trAtA = sum a^2 (device, rcppml_hip_sumsq);
  * iter0: iterations already run by earlier calls on these factors (0 = a fit from its start: iteration 0 then solves without the
  * warm-start correction; > 0 continues a fit -- bench.py's warm-up / timed split); loss_history: max_iter doubles (device, may be NULL); result8 (device): [0] iterations [1] converged [2] train loss [3] last relative

@@ -6,13 +6,18 @@ namespace {
 
 using namespace rk;
 
-// What the persistent kernel takes: ranks up to 32, and little enough work for the 128 SIMDs of one XCD.  The solve is one wavefront
-// per column with ~6 k dependent instructions per sweep (CD) or ~4 k per substitution (Cholesky): beyond ~3e5 column-coordinates^2
-// the multi-launch path's whole-chip kernels win again (movielens, k = 32: 4 477 columns x 1 024 = 4.6e6 -- stays there).
+// What the persistent kernel CAN take (scratch and index ranges): ranks up to 32, 2^20 nonzeros, 65 536 columns on both sides together.
+bool small_can(int m, int n, int64_t nnz, int k) {
+    return k >= 1 && k <= 32 && m >= 1 && n >= 1 && nnz <= ((int64_t)1 << 20) && (int64_t)m + n <= 65536;
+}
+// ... and where it PAYS -- measured, tools/small_threshold.py -> profiles/r06_small_threshold.txt (us per iteration against graph replays of
+// the multi-launch iteration): with k <= 16 (four columns per wavefront) 2.0-2.3 x at 700 .. 1 400 columns, 1.2-1.5 x at 2 800 columns /
+// 76 000 nonzeros, break-even at 4 000 columns / 205 000 nonzeros (three rounds of 1 536 columns per half-update); with 16 < k <= 32 (one
+// column per wavefront, 32 coordinates per sweep) it loses at every size (0.75-0.9 x at 700 columns, 0.2-0.4 x at 7 500).  So: k <= 16,
+// at most 3 072 columns on both sides together and 2^17 nonzeros (hawaiibirds: 1 366 columns, 30 815 nonzeros; movielens has k = 32).
 bool small_ok(int m, int n, int64_t nnz, int k) {
-    if (k < 1 || k > 32 || m < 1 || n < 1) return false;
-    const double work = ((double)m + (double)n) * (double)k * (double)k;
-    return work <= 4.0e5 && nnz <= (int64_t)1 << 18 && (int64_t)m + n <= 16384;
+    if (!small_can(m, n, nnz, k)) return false;
+    return k <= 16 && (int64_t)m + n <= 3072 && nnz <= (int64_t)1 << 17;
 }
 
 template <class T, int KP, bool CHOL>
@@ -61,7 +66,7 @@ extern "C" int rcppml_hip_als_small_fit(rcppml_hip_ctx* c, int dtype, const int*
                                         double cd_tol, int max_iter, double tol, int patience, int iter0, double* loss_history, double* result8) {
     try {
         HIPCHK(hipSetDevice(c->device));
-        if (!small_ok(m, n, nnz, k)) throw std::runtime_error("als_small_fit: problem not eligible (k <= 32, (m + n) k^2 <= 4e5, nnz <= 2^18)");
+        if (!small_can(m, n, nnz, k)) throw std::runtime_error("als_small_fit: k <= 32, nnz <= 2^20, m + n <= 65536 (rcppml_hip_als_small_eligible says where the kernel pays)");
         if (solver_mode != 0 && solver_mode != 1) throw std::runtime_error("als_small_fit: solver_mode must be 0 or 1");
         if (norm_type < 0 || norm_type > 2) throw std::runtime_error("als_small_fit: bad norm_type");
         if (max_iter < 1 || iter0 < 0) throw std::runtime_error("als_small_fit: max_iter < 1 or iter0 < 0");

@@ -8,8 +8,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
-# The GPU suite's small matrices keep exercising the multi-launch kernels they were written for: plain sparse MSE fits with k <= 32 and
-# (m + n) k^2 <= 4e5 would otherwise all take the one-kernel path (rcppml_amd/csrc/kernels_small.hip.h), which has its own file of
+# The GPU suite's small matrices keep exercising the multi-launch kernels they were written for: plain sparse MSE fits with k <= 16,
+# m + n <= 3072 and nnz <= 2^17 would otherwise all take the one-kernel path (rcppml_amd/csrc/kernels_small.hip.h), which has its own file of
 # oracle comparisons (tests/test_gpu_small.py switches it on per call).  The library's default -- what __graft_entry__.smoke() and
 # bench.py --config c1 run -- is the one-kernel path.
 os.environ.setdefault("RCPPML_GPU_NO_SMALL", "1")

@@ -1,6 +1,8 @@
 """The one-kernel fit of small sparse matrices (rcppml_amd/csrc/kernels_small.hip.h, rcppml_hip_als_small_fit): the whole ALS loop --
 fused right-hand side + solve per column, scaling, Gram, loss, convergence rule -- as one persistent kernel on one XCD, the path the
-plugin takes for plain sparse MSE fits with k <= 32 and (m + n) k^2 <= 4e5 (hawaiibirds, BASELINE configs[0]).
+plugin takes for plain sparse MSE fits with k <= 16, m + n <= 3072 and nnz <= 2^17 (hawaiibirds, BASELINE configs[0]; the rule is
+measured: profiles/r06_small_threshold.txt).  Ranks 17 .. 32 run the kernel's one-column-per-wavefront form, which the plugin never takes
+(it loses to the multi-launch loop at every size) but the device-level op accepts: held to the oracle here all the same.
 
 Checked against the CPU oracle's nmf_fit (same bars as the multi-launch loop's plugin tests: fp64 loss 1e-6 / factors 1e-6 and in
 practice ~1e-12, fp32 2e-4 / 2e-3) AND against the multi-launch loop on the same inputs (RCPPML_GPU_NO_SMALL=1: the two paths differ
@@ -76,7 +78,8 @@ def test_eligibility(abi):
     assert abi.small_eligible(hb.rows, hb.cols, hb.nnz, 10)
     assert not abi.small_eligible(ml.rows, ml.cols, ml.nnz, 32)          # 4 477 columns x 32^2: the whole-chip kernels win there
     assert not abi.small_eligible(20000, 100000, 20000000, 64)
-    assert not abi.small_eligible(100, 100, 500, 33)
+    assert not abi.small_eligible(100, 100, 500, 17)                      # one column per wavefront: loses at every size (profiles/r06_small_threshold.txt)
+    assert not abi.small_eligible(800, 3200, 205276, 10) and abi.small_eligible(400, 2400, 76059, 10)
 
 
 @pytest.mark.parametrize("solver", [1, 0])
@@ -113,14 +116,32 @@ def test_hawaiibirds_one_kernel_fit_fp32(abi, solver):
 @pytest.mark.parametrize("k", [1, 2, 7, 16, 17, 24, 32])
 @pytest.mark.parametrize("solver", [0, 1])
 def test_ranks(abi, k, solver):
-    """Every padded size (KP = 16 up to k = 16, 32 above), ranks that are not multiples of anything."""
-    A = lowrank_csc(120, 190, 6, 0.12, seed=100 + k)
-    assert abi.small_eligible(A.rows, A.cols, A.nnz, k)
+    """Every padded size (KP = 16 up to k = 16: the form the plugin takes; KP = 32 above: device-level op only), ranks that are not
+    multiples of anything: the device-level op on caller-owned memory against the oracle's unsorted fit, and for k <= 16 the plugin."""
+    import torch
+    from rcppml_amd import als
+    from rcppml_amd.data import CSC
+    Ao = lowrank_csc(120, 190, 6, 0.12, seed=100 + k)
+    assert abi.small_eligible(Ao.rows, Ao.cols, Ao.nnz, k) == (k <= 16)
+    A = CSC((Ao.rows, Ao.cols), Ao.p, Ao.i, Ao.x)
     W0, H0 = O.init_factors(3 + k, k, A.rows, A.cols, np.float64)
-    ref = O.nmf_fit(A, W0, H0, np.float64, max_iter=8, tol=0.0, solver_mode=solver)
-    one = _fit(abi, A, W0, H0, True, max_iter=8, tol=0.0, solver_mode=solver)
-    _vs_oracle(one, ref, 1e-6, 1e-6)
-    assert np.all(np.diff(one["d"]) <= 0)                      # sorted on the way out, like every fit
+    ref = O.nmf_fit(Ao, W0, H0, np.float64, max_iter=8, tol=0.0, solver_mode=solver, sort_model=False)
+    ops = als.HipOps(0, "f64")
+    a, at = ops.upload_csc(A), ops.upload_csc(A.transpose())
+    W, H, d = ops.to_device(W0), ops.to_device(H0), ops.zeros((k,)) + 1
+    res, hist = torch.zeros(8, dtype=torch.float64, device="cuda"), torch.zeros(8, dtype=torch.float64, device="cuda")
+    ops.ctx.als_small_fit(ops.dt, a, at, A.rows, A.cols, k, W, H, d, ops.sumsq(a["x"]), solver_mode=solver, max_iter=8, tol=0.0,
+                          loss_history=hist, result8=res)
+    r = res.cpu().numpy()
+    assert r[4] == 1.0 and int(r[0]) == ref.iter
+    assert abs(r[2] - ref.loss) <= 1e-6 * abs(ref.loss) and np.abs(hist.cpu().numpy() - ref.loss_history).max() <= 1e-6 * ref.loss_history.max()
+    assert np.abs(W.cpu().numpy() - ref.W_T).max() < 1e-6 and np.abs(H.cpu().numpy() - ref.H).max() < 1e-6
+    assert np.abs(d.cpu().numpy() - ref.d).max() <= 1e-6 * ref.d.max()
+    if k <= 16:
+        refs = O.nmf_fit(Ao, W0, H0, np.float64, max_iter=8, tol=0.0, solver_mode=solver)
+        one = _fit(abi, Ao, W0, H0, True, max_iter=8, tol=0.0, solver_mode=solver)
+        _vs_oracle(one, refs, 1e-6, 1e-6)
+        assert np.all(np.diff(one["d"]) <= 0)                      # sorted on the way out, like every fit
 
 
 OPTIONS = [
@@ -161,10 +182,10 @@ def test_options(abi, opt, solver, shape):
 
 @pytest.mark.parametrize("seed", range(8))
 def test_random_shapes_and_degenerate_columns(abi, seed):
-    """Random small matrices with empty columns and rows, k drawn from 1 .. 32, both solvers alternating, fp32 and fp64."""
+    """Random small matrices with empty columns and rows, k drawn from 1 .. 16, both solvers alternating, fp32 and fp64."""
     rng = np.random.default_rng(500 + seed)
     m, n = int(rng.integers(3, 200)), int(rng.integers(3, 300))
-    k = int(rng.integers(1, min(32, m, n) + 1))
+    k = int(rng.integers(1, min(16, m, n) + 1))
     A = random_csc(m, n, float(rng.uniform(0.02, 0.3)), seed=seed)
     if A.nnz == 0 or not abi.small_eligible(m, n, A.nnz, k):
         pytest.skip("degenerate draw")

@@ -13,7 +13,7 @@ cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 bad, ran, skipped = [], 0, 0
 for c in range(cases):
-    k = int(rng.integers(1, 33))
+    k = int(rng.integers(1, 17))
     m, n = int(rng.integers(k + 1, 700)), int(rng.integers(k + 1, 900))
     if rng.random() < 0.5:
         A = lowrank_csc(m, n, int(rng.integers(1, 8)), float(rng.uniform(0.03, 0.25)), seed=int(rng.integers(1 << 30)))
