@@ -11,6 +11,9 @@
 // no stale read in 2 000 rounds; the same barrier with agent-scope fences across all 8 XCDs costs 2.5 us (64 workgroups) to 10 us (256),
 // and the relaxed form across XCDs reads stale data -- which is why the kernel keeps to one XCD: the launch has 8 x NB workgroups,
 // the dispatcher deals them round-robin over the XCDs (measured), and those that do not land on XCD 0 (HW_REG_XCC_ID) leave at once.
+// The 32 that stay must all be resident at once (12 waves of up to 168 VGPRs: one workgroup per CU).  If they are not -- another
+// persistent fit holds CUs of XCD 0, the device is partitioned differently -- a barrier gives up after 0.2 s and the caller restarts on
+// the multi-launch loop: slower, never hung.
 //
 // The loop is nmf_fit<CPU> (reference inst/include/FactorNet/nmf/fit_cpu.hpp:444-1855) for the plain sparse
 // MSE fit -- fused right-hand side + solve per column (primitives/cpu/fused_nnls.hpp:70-134 CD with the iteration-0 quirk, :185-219
