@@ -72,11 +72,11 @@ __device__ __forceinline__ bool sm_barrier(unsigned* sync, unsigned& gen, int* s
         ++gen;
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");          // this workgroup's stores are in the L2 (one thread's wait covers its own; the barrier above the others')
         __hip_atomic_fetch_add(sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const long long t0 = clock64();
+        const long long t0 = wall_clock64();                                 // the 100 MHz constant clock: 2e7 ticks = 0.2 s
         int ok = 1;
         while (sm_ld(sync) < gen * (unsigned)SM_NB) {
             __builtin_amdgcn_s_sleep(1);
-            if (sm_ld(sync + 2) || clock64() - t0 > 20000000ll) { __hip_atomic_store(sync + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ok = 0; break; }
+            if (sm_ld(sync + 2) || wall_clock64() - t0 > 20000000ll) { __hip_atomic_store(sync + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ok = 0; break; }
         }
         *sh_flag = ok;
     }
