@@ -286,7 +286,9 @@ enum { RCPPML_OPT_CD_COUNT_NOOP = 1 /* LMF kernel counts all-zero coordinate ste
        RCPPML_OPT_CD_LMF_LANE_GROUPS = 2 /* 1, 2 or 4 lane groups per column instead of the size heuristic */,
        RCPPML_OPT_CD_LMF_WAVES_PER_SIMD = 3 /* resident persistent waves per SIMD instead of the heuristic */,
        RCPPML_OPT_CD_NO_LMF = 4 /* RCPPML_CD_AUTO falls back to the 32- / 16-column MFMA kernels */,
-       RCPPML_OPT_IRLS_COLUMNS_PER_WAVE = 5 /* fp32 k <= 32 IRLS half-update: 0 = by the number of columns, 1 or 4 columns per wavefront */ };
+       RCPPML_OPT_IRLS_COLUMNS_PER_WAVE = 5, /* fp32 k <= 32 IRLS half-update: 0 = by the number of columns, 1 or 4 columns per wavefront */
+       RCPPML_OPT_SMALL_GIVE_UP = 6 /* test switch: the one-kernel fit's first barrier gives up at once (its abort flag is preset), as if
+                                       its workgroups had not all arrived on one XCD -- exercises the caller's restart on the multi-launch ops */ };
 RCPPML_GPU_API int rcppml_hip_ctx_set_option(rcppml_hip_ctx* ctx, int option, int value);
 
 /* One-time setup of a fit, on the device.

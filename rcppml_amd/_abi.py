@@ -15,7 +15,7 @@ _lib = None
 F32, F64 = 0, 1
 CD_AUTO, CD_LANE, CD_WAVE, CD_GROUP, CD_MFMA, CD_MFMA16, CD_LMF = 0, 1, 2, 5, 6, 7, 8
 # rcppml_hip_ctx_set_option
-OPT_CD_COUNT_NOOP, OPT_CD_LMF_LANE_GROUPS, OPT_CD_LMF_WAVES_PER_SIMD, OPT_CD_NO_LMF, OPT_IRLS_COLUMNS_PER_WAVE = 1, 2, 3, 4, 5
+OPT_CD_COUNT_NOOP, OPT_CD_LMF_LANE_GROUPS, OPT_CD_LMF_WAVES_PER_SIMD, OPT_CD_NO_LMF, OPT_IRLS_COLUMNS_PER_WAVE, OPT_SMALL_GIVE_UP = 1, 2, 3, 4, 5, 6
 
 # Every symbol include/rcppml_gpu.h declares (tests check the library exports all of them).
 EXPORTED_SYMBOLS = [

@@ -88,7 +88,7 @@ struct rcppml_hip_ctx {
     //   that kernel in which no column of the wave moved (only counted when opt_cd_count is set)
     unsigned long long* stats = nullptr;
     // rcppml_hip_ctx_set_option
-    int opt_cd_count = 0, opt_lmf_lg = 0, opt_lmf_wps = 0, opt_cd_no_lmf = 0, opt_irls_cpw = 0;
+    int opt_cd_count = 0, opt_lmf_lg = 0, opt_lmf_wps = 0, opt_cd_no_lmf = 0, opt_irls_cpw = 0, opt_small_give_up = 0;
     // Per-fit arena (plugin entries): ONE hipMalloc / hipFree for everything a fit allocates instead of ~60 pairs -- hipMalloc
     // costs tens of microseconds and every hipFree synchronises the device; together they were 5-6 ms of a 20 ms one-iteration
     // call.  Pure bump allocation, nothing is handed back before the fit ends.  arena_take() returns nullptr when there is no

@@ -46,6 +46,7 @@ extern "C" int rcppml_hip_ctx_set_option(rcppml_hip_ctx* c, int option, int valu
         case RCPPML_OPT_CD_LMF_WAVES_PER_SIMD: c->opt_lmf_wps = value; return 0;
         case RCPPML_OPT_CD_NO_LMF: c->opt_cd_no_lmf = value; return 0;
         case RCPPML_OPT_IRLS_COLUMNS_PER_WAVE: c->opt_irls_cpw = value; return 0;
+        case RCPPML_OPT_SMALL_GIVE_UP: c->opt_small_give_up = value; return 0;
         default: rcppml_err() = "unknown option"; return 1;
     }
 }

@@ -49,6 +49,7 @@ void run(rcppml_hip_ctx* c, const int* Ap, const int* Ai, const void* Ax, const 
     P.max_iter = max_iter; P.patience = patience; P.tol = tol; P.iter0 = iter0;
     P.loss_hist = loss_hist; P.result = result;
     HIPCHK(hipMemsetAsync(P.sync, 0, 256, c->stream));
+    if (c->opt_small_give_up) HIPCHK(hipMemsetAsync(P.sync + 2, 1, 1, c->stream));      // test switch: abort flag preset (low byte = 1)
     HIPCHK(hipMemsetAsync(result, 0, 8 * sizeof(double), c->stream));
     const bool chol = solver_mode == 1;
     if (KP == 16) { if (chol) launch<T, 16, true>(c, P); else launch<T, 16, false>(c, P); }

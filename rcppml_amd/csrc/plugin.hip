@@ -528,6 +528,8 @@ void fit(FitParams& P) {
         P.angular_W == 0 && !P.projective && !P.symmetric && P.max_iter >= 1 && !getenv("RCPPML_GPU_NO_SMALL") &&
         rcppml_hip_als_small_eligible(m, n, P.nnz, k)) {
         DevBuf dres(8 * sizeof(double)), dhist((size_t)P.max_iter * sizeof(double));
+        // (RCPPML_GPU_SMALL_GIVE_UP_TEST=1, test switch like RCPPML_GPU_DEVICES_FORCE: the kernel's first barrier gives up, so that the restart below runs)
+        if (getenv("RCPPML_GPU_SMALL_GIVE_UP_TEST")) OPCHK(rcppml_hip_ctx_set_option(c, RCPPML_OPT_SMALL_GIVE_UP, 1));
         OPCHK(rcppml_hip_als_small_fit(c, dt, dAp.as<int>(), dAi.as<int>(), dAx.p, dTp.as<int>(), dTi.as<int>(), dTx.p, m, n, P.nnz, k, dW.p, dH.p, dd.p,
                                        dtr.as<double>(), P.L1_H, P.L1_W, P.L2_H, P.L2_W, P.ub_H, P.ub_W, P.nonneg_H, P.nonneg_W, P.norm_type,
                                        P.solver_mode, P.cd_maxit, P.cd_tol, P.max_iter, P.tol, P.patience, 0, dhist.as<double>(), dres.as<double>()));

@@ -245,3 +245,38 @@ def test_r_surface_takes_the_one_kernel_path():
         b = nmf.nmf(A, 10, seed=42, tol=1e-5, maxit=40, precision="fp64")
     assert a.misc["iter"] == b.misc["iter"] and abs(a.misc["loss"] - b.misc["loss"]) <= 1e-9 * abs(b.misc["loss"])
     assert np.abs(a.w - b.w).max() < 1e-7 and np.abs(a.h - b.h).max() < 1e-7
+
+
+def test_give_up_path_restarts_on_the_multi_launch_loop(abi, capfd):
+    """The kernel's barrier gives up when its workgroups are not all resident on one XCD (another persistent fit, another partition mode).
+    Forced here by presetting the abort flag (RCPPML_OPT_SMALL_GIVE_UP / RCPPML_GPU_SMALL_GIVE_UP_TEST): the device op reports it in
+    result8[4] and leaves promptly, and the plugin restarts the fit from the caller's factors on the multi-launch loop -- same result as
+    with the path switched off, bit for bit."""
+    import torch
+    from rcppml_amd import als
+    from rcppml_amd.data import CSC
+    Ao = load_fixture("hawaiibirds")
+    k = 10
+    W0, H0 = O.init_factors(42, k, Ao.rows, Ao.cols, np.float64)
+    A = CSC((Ao.rows, Ao.cols), Ao.p, Ao.i, Ao.x)
+    ops = als.HipOps(0, "f64")
+    a, at = ops.upload_csc(A), ops.upload_csc(A.transpose())
+    W, H, d = ops.to_device(W0), ops.to_device(H0), ops.zeros((k,)) + 1
+    res = torch.zeros(8, dtype=torch.float64, device="cuda")
+    ops.ctx.set_option(abi.OPT_SMALL_GIVE_UP, 1)
+    ops.ctx.als_small_fit(ops.dt, a, at, A.rows, A.cols, k, W, H, d, ops.sumsq(a["x"]), max_iter=5, tol=0.0, result8=res)
+    assert float(res[4].item()) != 1.0                      # gave up: the caller must not use W / H
+    ops.ctx.set_option(abi.OPT_SMALL_GIVE_UP, 0)
+    ops.ctx.als_small_fit(ops.dt, a, at, A.rows, A.cols, k, ops.to_device(W0), ops.to_device(H0), d, ops.sumsq(a["x"]), max_iter=5, tol=0.0, result8=res)
+    assert float(res[4].item()) == 1.0
+    off = _fit(abi, Ao, W0, H0, False, max_iter=9, tol=0.0, solver_mode=0)
+    os.environ["RCPPML_GPU_SMALL_GIVE_UP_TEST"] = "1"
+    try:
+        capfd.readouterr()
+        gave_up = _fit(abi, Ao, W0, H0, True, max_iter=9, tol=0.0, solver_mode=0)
+        err = capfd.readouterr().err
+    finally:
+        os.environ.pop("RCPPML_GPU_SMALL_GIVE_UP_TEST", None)
+    assert "gave up at its barrier" in err and "one-kernel fit)" not in err
+    assert np.array_equal(gave_up["W_T"], off["W_T"]) and np.array_equal(gave_up["H"], off["H"]) and gave_up["loss"] == off["loss"]
+    assert np.array_equal(gave_up["loss_history"], off["loss_history"])
