@@ -87,6 +87,12 @@ __global__ void full_csc_index_kernel(int m, int64_t n, int* __restrict__ col_pt
 // ----------------------------------------------------------------------------
 // The ALS loop (MSE; fused-path semantics of fit_cpu.hpp, or the explicit-mask path).
 // ----------------------------------------------------------------------------
+// RCPPML_GPU_NO_SMALL set to anything but "" / "0": small plain fits stay on the multi-launch loop
+inline bool env_no_small() {
+    const char* e = getenv("RCPPML_GPU_NO_SMALL");
+    return e && *e && strcmp(e, "0") != 0;
+}
+
 template <class T>
 void fit(FitParams& P) {
     constexpr int dt = DT<T>::id;
@@ -525,7 +531,7 @@ void fit(FitParams& P) {
     // round trip per iteration; the convergence rule runs on the device.  RCPPML_GPU_NO_SMALL=1 keeps the multi-launch loop.
     bool small_done = false;
     if (!dense && !has_mask && !is_nb && !unfused && !graph_H && !graph_W && P.L21_H == 0 && P.L21_W == 0 && P.angular_H == 0 &&
-        P.angular_W == 0 && !P.projective && !P.symmetric && P.max_iter >= 1 && !getenv("RCPPML_GPU_NO_SMALL") &&
+        P.angular_W == 0 && !P.projective && !P.symmetric && P.max_iter >= 1 && !env_no_small() &&
         rcppml_hip_als_small_eligible(m, n, P.nnz, k)) {
         DevBuf dres(8 * sizeof(double)), dhist((size_t)P.max_iter * sizeof(double));
         // (RCPPML_GPU_SMALL_GIVE_UP_TEST=1, test switch like RCPPML_GPU_DEVICES_FORCE: the kernel's first barrier gives up, so that the restart below runs)

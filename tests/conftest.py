@@ -11,7 +11,8 @@ if ROOT not in sys.path:
 # The GPU suite's small matrices keep exercising the multi-launch kernels they were written for: plain sparse MSE fits with k <= 16,
 # m + n <= 3072 and nnz <= 2^17 would otherwise all take the one-kernel path (rcppml_amd/csrc/kernels_small.hip.h), which has its own file of
 # oracle comparisons (tests/test_gpu_small.py switches it on per call).  The library's default -- what __graft_entry__.smoke() and
-# bench.py --config c1 run -- is the one-kernel path.
+# bench.py --config c1 run -- is the one-kernel path.  (RCPPML_GPU_NO_SMALL=0 python -m pytest tests -m gpu runs the whole suite with
+# the path on: 1042 passed at the end of round 6, profiles/r06_gpu_suites.txt.)
 os.environ.setdefault("RCPPML_GPU_NO_SMALL", "1")
 
 
