@@ -447,7 +447,8 @@ RCPPML_GPU_API int rcppml_hip_tail_scale_gram_loss(rcppml_hip_ctx* ctx, int dtyp
  * iter0: iterations already run by earlier calls on these factors (0 = a fit from its start: iteration 0 then solves without the
  * warm-start correction; > 0 continues a fit -- bench.py's warm-up / timed split); loss_history: max_iter doubles (device, may be NULL); result8 (device): [0] iterations [1] converged [2] train loss [3] last relative
  * change [4] 1 = done, anything else = the kernel gave up at a barrier (its workgroups did not all land on one XCD): W / H are then
- * partly overwritten and the caller must restart on the multi-launch ops. */
+ * partly overwritten and the caller must restart on the multi-launch ops; [5..7] workgroup 0's 100 MHz clock ticks inside the launch:
+ * fused half-updates, waiting at barriers, whole kernel (bench.py --config c1 `inside_the_kernel`). */
 RCPPML_GPU_API int rcppml_hip_als_small_eligible(int m, int n, int64_t nnz, int k);
 RCPPML_GPU_API int rcppml_hip_als_small_fit(rcppml_hip_ctx* ctx, int dtype, const int* col_ptr, const int* row_idx, const void* values,
                                             const int* t_col_ptr, const int* t_row_idx, const void* t_values, int m, int n, int64_t nnz,

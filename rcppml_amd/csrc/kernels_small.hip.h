@@ -46,7 +46,7 @@ struct SmallFit {
     int iter0;                                      // iterations this fit has already run (a launch that continues one: warm start from its first iteration)
     double tol;
     double* loss_hist;                              // max_iter doubles (may be null)
-    double* result;                                 // [0] iterations [1] converged [2] train loss [3] final tol [4] status (1 = done, 2 = barrier timed out)
+    double* result;                                 // [0] iterations [1] converged [2] train loss [3] final tol [4] 1 = done (stays 0 when a barrier gave up) [5..7] workgroup 0's clock
     unsigned* sync;                                 // [0] barrier counter [1] live tickets [2] abort flag
 };
 
